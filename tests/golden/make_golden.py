@@ -1,0 +1,197 @@
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference, imported through _ref_shim).  The
+fixtures are data: seeded inputs and the reference's outputs.  Re-run with
+    python tests/golden/make_golden.py
+The GPU box never runs this file; tests read the committed .npz files.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shim as shim  # noqa: E402
+
+quiet = lambda: contextlib.redirect_stdout(io.StringIO())  # noqa: E731
+
+
+def coords_array(coords):
+    return np.array([[c.z_start, c.z_end, c.y_start, c.y_end, c.x_start, c.x_end] for c in coords], dtype=np.int64)
+
+
+def zero_stride_volume(shape, dtype=np.uint8):
+    return np.lib.stride_tricks.as_strided(np.zeros(1, dtype=dtype), shape=shape, strides=(0,) * len(shape))
+
+
+def synth_volume(seed, vshape):
+    """Seeded test volume + label mask; tests regenerate these instead of loading them."""
+    rs = np.random.RandomState(1000 + seed)
+    vol = rs.rand(*vshape).astype(np.float32)
+    mask = np.array([0, 1, 2, 3, 7, 255], dtype=np.uint8)[rs.randint(0, 6, size=tuple(vshape[:3]) + (1,))]
+    return vol, mask
+
+
+def synth_pred(seed, pshape):
+    """Seeded stand-in for the network output on every patch (not the identity, so the blend matters)."""
+    return np.random.RandomState(2000 + seed).rand(*pshape).astype(np.float32)
+
+
+def tiling_fixtures():
+    d3 = shim.load("biapy.data.data_3D_manipulation")
+    out = {}
+    # ---- (1) coordinate-only cases (load_data=False) -------------------------------------------
+    coord_cases = {
+        "c48": ((48, 48, 48, 1), (32, 32, 32, 1), (0.5, 0.5, 0.5), (0, 0, 0)),
+        "docstring": ((165, 768, 1024, 1), (80, 80, 80, 1), (0.5, 0.5, 0.5), (0, 0, 0)),
+        "docstring_noov": ((165, 768, 1024, 1), (80, 80, 80, 1), (0, 0, 0), (0, 0, 0)),
+        "cfg3_1024": ((1024, 1024, 1024, 1), (128, 128, 128, 1), (0.5, 0.5, 0.5), (0, 0, 0)),
+        "template_pad10": ((100, 200, 180, 1), (80, 80, 80, 1), (0, 0, 0), (10, 10, 10)),
+        "aniso": ((20, 128, 128, 1), (20, 64, 64, 1), (0, 0.25, 0.25), (4, 16, 16)),
+        "odd": ((100, 90, 70, 2), (32, 40, 24, 2), (0.3, 0.1, 0.6), (2, 4, 3)),
+        "exactfit": ((64, 64, 64, 1), (32, 32, 32, 1), (0, 0, 0), (0, 0, 0)),
+        "single": ((32, 40, 48, 1), (32, 40, 48, 1), (0.5, 0.5, 0.5), (0, 0, 0)),
+    }
+    for name, (vshape, pshape, ov, pad) in coord_cases.items():
+        with quiet():
+            cc = d3.crop_3D_data_with_overlap(zero_stride_volume(vshape), pshape, overlap=ov, padding=pad, load_data=False)
+        out[f"coords/{name}/args"] = np.array(list(vshape) + list(pshape) + list(pad), dtype=np.int64)
+        out[f"coords/{name}/overlap"] = np.array(ov, dtype=np.float64)
+        out[f"coords/{name}/coords"] = coords_array(cc)
+
+    # ---- (2) spline windows ---------------------------------------------------------------------
+    for name, (pshape, ovpx) in {
+        "w0": ((8, 8, 8), (0, 0, 0)),
+        "w4": ((16, 16, 16), (4, 4, 4)),
+        "w68": ((128, 128, 128), (68, 68, 68)),
+        "wmix": ((12, 20, 9), (3, 10, 7)),
+    }.items():
+        out[f"window/{name}/args"] = np.array(list(pshape) + list(ovpx), dtype=np.int64)
+        out[f"window/{name}/win"] = d3._get_spline_window_3D(pshape, ovpx)
+
+    # ---- (3) crop + merge data cases -------------------------------------------------------------
+    # inputs are regenerated from legacy-RandomState seeds (bit-stable across NumPy versions) so the
+    # fixture only has to carry the reference's OUTPUTS
+    data_cases = {
+        "m48": ((48, 48, 48, 1), (32, 32, 32, 1), (0.5, 0.5, 0.5), (0, 0, 0), "reflect", False),
+        "m_odd": ((50, 45, 37, 2), (16, 20, 12, 2), (0.3, 0.1, 0.6), (2, 4, 3), "reflect", False),
+        "m_pad": ((40, 60, 50, 1), (32, 32, 32, 1), (0, 0, 0), (6, 6, 6), "reflect", False),
+        "m_zeros": ((40, 33, 50, 3), (24, 16, 32, 3), (0.25, 0.5, 0.0), (4, 2, 8), "zeros", False),
+        "m_median": ((36, 36, 36, 1), (16, 16, 16, 1), (0.5, 0.5, 0.5), (2, 2, 2), "reflect", True),
+    }
+    for seed, (name, (vshape, pshape, ov, pad, pad_type, med)) in enumerate(data_cases.items()):
+        vol, mask = synth_volume(seed, vshape)
+        with quiet():
+            p, pm, cc = d3.crop_3D_data_with_overlap(
+                vol, pshape, data_mask=mask, overlap=ov, padding=pad, median_padding=med, pad_type=pad_type
+            )
+            # the merge consumes (a perturbed copy of) the patches so it is not just the identity
+            pred = synth_pred(seed, p.shape)
+            merged, merged_mask = d3.merge_3D_data_with_overlap(pred, vshape, data_mask=pm, overlap=ov, padding=pad)
+        out[f"data/{name}/args"] = np.array(list(vshape) + list(pshape) + list(pad) + [int(med)], dtype=np.int64)
+        out[f"data/{name}/overlap"] = np.array(ov, dtype=np.float64)
+        out[f"data/{name}/pad_type"] = np.array(pad_type)
+        out[f"data/{name}/seed"] = np.array(seed)
+        out[f"data/{name}/coords"] = coords_array(cc)
+        out[f"data/{name}/patches_crc"] = np.array([int(np.frombuffer(p.tobytes(), dtype=np.uint8).astype(np.uint64).sum())])
+        out[f"data/{name}/patch0"] = p[0]
+        out[f"data/{name}/patch_last"] = p[-1]
+        out[f"data/{name}/mask_patch_last"] = pm[-1]
+        out[f"data/{name}/merged"] = merged
+        out[f"data/{name}/merged_mask"] = merged_mask
+
+    # ---- (4) constant-label masks: pins the truncating uint8 cast ----------
+    for lab in (1, 2, 3, 5, 255):
+        pm = np.full((27, 32, 32, 32, 1), lab, dtype=np.uint8)
+        pd = np.ones((27, 32, 32, 32, 1), dtype=np.float32)
+        with quiet():
+            _, mm = d3.merge_3D_data_with_overlap(pd, (48, 48, 48, 1), data_mask=pm, overlap=(0.5, 0.5, 0.5))
+        out[f"label/{lab}/merged_mask"] = mm
+    np.savez_compressed(os.path.join(HERE, "tiling_golden.npz"), **out)
+    print("tiling_golden.npz:", len(out), "arrays")
+
+
+def resunet_fixtures():
+    rmod = shim.load("biapy.models.resunet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import net_oracle
+
+    def build(fm, patch, in_ch=1, seed=0):
+        torch.manual_seed(seed)
+        depth = len(fm) - 1
+        with quiet():
+            net = rmod.ResUNet(
+                image_shape=tuple(patch) + (in_ch,), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm),
+                normalization="in", k_size=3, upsample_layer="convtranspose", yx_down=[2] * depth, z_down=[2] * depth,
+                output_channels=[1], output_channel_info=["F"], head_activations=["ce_sigmoid"], isotropy=[True] * len(fm),
+                larger_io=False, conv_layers=[2] * len(fm),
+            )
+        # perturb norm affine + biases so the fixture exercises them (reference init is gamma=1, beta=0, bias=0)
+        g = torch.Generator().manual_seed(seed + 100)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if v.ndim == 1:
+                    v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+        return net
+
+    out = {}
+    # small architecture: full weights committed
+    fm, patch, B = [16, 32, 64], (32, 32, 32), 2
+    net = build(fm, patch)
+    g = torch.Generator().manual_seed(0)
+    x5 = torch.randn(B, *patch, 1, generator=g)                 # (B,Z,Y,X,C) as the data loader hands it over
+    x = x5.permute(0, 4, 1, 2, 3)                               # to_pytorch_format (biapy/utils/misc.py:689-713)
+    tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+    net.train()
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)            # metrics.py:543-544
+    loss.backward()
+    out["small/feature_maps"] = np.array(fm)
+    out["small/x"] = x5.numpy()
+    out["small/target"] = tgt.numpy().astype(np.uint8)
+    out["small/logits"] = logits.detach().numpy()
+    out["small/loss"] = np.array(loss.item(), dtype=np.float64)
+    for k, v in net.state_dict().items():
+        out[f"small/sd/{k}"] = v.numpy()
+    for k, p in net.named_parameters():
+        out[f"small/gradnorm/{k}"] = np.array(p.grad.norm().item(), dtype=np.float64)
+    # a few full gradients (first conv, a decoder conv, a norm affine, the up-conv, the head)
+    for k in [
+        "down_path.0.block.0.block.0.weight", "down_path.1.block.0.weight", "down_path.1.block.0.bias",
+        "up_paths.0.0.up.weight", "up_paths.0.1.conv_block.block.2.block.0.weight", "up_paths.0.1.conv_block.shortcut.0.weight",
+        "heads.0.weight", "heads.0.bias", "bottleneck.block.3.block.0.bias",
+    ]:
+        out[f"small/grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+    # oracle restatement must agree with the reference right here
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    lo = net_oracle.resunet_forward(sd, x, fm)
+    err = (lo - logits.detach()).abs().max().item()
+    print("oracle vs reference (small) max abs err:", err)
+    assert err < 2e-5
+
+    # full cfg-2 architecture at 32^3: weights NOT committed (26.8 MB); pinned here and by hash
+    fm2 = [16, 32, 64, 128, 256]
+    net2 = build(fm2, (32, 32, 32), seed=1)
+    net2.eval()
+    with torch.no_grad():
+        l2 = net2(x[:1])
+        sd2 = {k: v.detach() for k, v in net2.state_dict().items()}
+        lo2 = net_oracle.resunet_forward(sd2, x[:1], fm2)
+    err2 = (lo2 - l2).abs().max().item()
+    print("oracle vs reference (cfg2 arch) max abs err:", err2, "keys:", len(sd2), "params:", sum(v.numel() for v in sd2.values()))
+    assert err2 < 2e-5
+    out["cfg2/keys"] = np.array(list(sd2.keys()))
+    out["cfg2/shapes"] = np.array([str(tuple(v.shape)) for v in sd2.values()])
+    out["cfg2/n_params"] = np.array(sum(v.numel() for v in sd2.values()))
+    out["cfg2/oracle_vs_ref_err"] = np.array(err2)
+    np.savez_compressed(os.path.join(HERE, "resunet_golden.npz"), **out)
+    print("resunet_golden.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    tiling_fixtures()
+    resunet_fixtures()

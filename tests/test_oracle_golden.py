@@ -1,0 +1,122 @@
+"""The oracle (oracle/*.py) against the golden vectors captured from the reference (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from make_golden import synth_pred, synth_volume  # seeded input generators (pure numpy, no reference import)
+from oracle import net_oracle, tiling_oracle as T
+
+COORD_CASES = ["c48", "docstring", "docstring_noov", "cfg3_1024", "template_pad10", "aniso", "odd", "exactfit", "single"]
+DATA_CASES = ["m48", "m_odd", "m_pad", "m_zeros", "m_median"]
+
+
+@pytest.mark.parametrize("name", COORD_CASES)
+def test_crop_coords_match_reference(tiling_golden, name):
+    a = tiling_golden[f"coords/{name}/args"]
+    ov = tuple(tiling_golden[f"coords/{name}/overlap"])
+    got = T.crop_coords(a[0:3], a[4:7], ov, tuple(a[8:11]))
+    np.testing.assert_array_equal(got, tiling_golden[f"coords/{name}/coords"])
+
+
+def test_cfg3_grid_is_4096_patches(tiling_golden):
+    c = tiling_golden["coords/cfg3_1024/coords"]
+    assert c.shape == (4096, 6)
+    assert sorted(set(c[:, 0]))[-2:] == [840, 896]
+
+
+@pytest.mark.parametrize("name", ["w0", "w4", "w68", "wmix"])
+def test_window_bit_exact(tiling_golden, name):
+    a = tiling_golden[f"window/{name}/args"]
+    got = T.spline_window(tuple(a[:3]), tuple(a[3:]))
+    ref = tiling_golden[f"window/{name}/win"]
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", DATA_CASES)
+def test_crop_and_merge_bit_exact(tiling_golden, name):
+    g = tiling_golden
+    a = g[f"data/{name}/args"]
+    vshape, pshape, pad, med = tuple(a[0:4]), tuple(a[4:8]), tuple(a[8:11]), bool(a[11])
+    ov = tuple(g[f"data/{name}/overlap"])
+    seed = int(g[f"data/{name}/seed"])
+    pad_type = str(g[f"data/{name}/pad_type"])
+    vol, mask = synth_volume(seed, vshape)
+    p, coords = T.crop(vol, pshape, ov, pad, pad_type, med)
+    pm, _ = T.crop(mask, pshape[:3] + (1,), ov, pad, pad_type, False)
+    np.testing.assert_array_equal(coords, g[f"data/{name}/coords"])
+    np.testing.assert_array_equal(p[0], g[f"data/{name}/patch0"])
+    np.testing.assert_array_equal(p[-1], g[f"data/{name}/patch_last"])
+    np.testing.assert_array_equal(pm[-1], g[f"data/{name}/mask_patch_last"])
+    crc = int(np.frombuffer(p.tobytes(), dtype=np.uint8).astype(np.uint64).sum())
+    assert crc == int(g[f"data/{name}/patches_crc"][0])
+    pred = synth_pred(seed, p.shape)
+    merged, merged_mask = T.merge(pred, vshape, data_mask=pm, overlap=ov, padding=pad)
+    np.testing.assert_array_equal(merged.view(np.uint32), g[f"data/{name}/merged"].view(np.uint32))
+    np.testing.assert_array_equal(merged_mask, g[f"data/{name}/merged_mask"])
+
+
+@pytest.mark.parametrize("lab", [1, 2, 3, 5, 255])
+def test_label_truncation_quirk(tiling_golden, lab):
+    """Labels >=3 come back partly as label-1 through the float blend; the oracle must reproduce that."""
+    pm = np.full((27, 32, 32, 32, 1), lab, dtype=np.uint8)
+    pd = np.ones((27, 32, 32, 32, 1), dtype=np.float32)
+    _, mm = T.merge(pd, (48, 48, 48, 1), data_mask=pm, overlap=(0.5, 0.5, 0.5))
+    ref = tiling_golden[f"label/{lab}/merged_mask"]
+    np.testing.assert_array_equal(mm, ref)
+    if lab >= 3:
+        assert (ref != lab).any()
+
+
+def test_crop_errors():
+    v = np.zeros((16, 16, 16, 1), np.float32)
+    with pytest.raises(ValueError):
+        T.crop(v[..., 0], (8, 8, 8, 1))
+    with pytest.raises(ValueError):
+        T.crop_coords((16, 16, 16), (8, 8, 8), overlap=(1.0, 0, 0))
+
+
+def _small(resunet_golden):
+    g = resunet_golden
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    x = torch.from_numpy(g["small/x"]).permute(0, 4, 1, 2, 3)
+    tgt = torch.from_numpy(g["small/target"]).to(torch.float32)
+    return sd, x, tgt, list(g["small/feature_maps"])
+
+
+def test_net_oracle_forward_matches_reference(resunet_golden):
+    sd, x, tgt, fm = _small(resunet_golden)
+    logits = net_oracle.resunet_forward(sd, x, fm)
+    ref = torch.from_numpy(resunet_golden["small/logits"])
+    assert (logits - ref).abs().max().item() < 2e-5
+    loss = net_oracle.bce_with_logits(logits, tgt)
+    assert abs(loss.item() - float(resunet_golden["small/loss"])) < 1e-6
+
+
+def test_net_oracle_grads_match_reference(resunet_golden):
+    sd, x, tgt, fm = _small(resunet_golden)
+    loss, logits, grads = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm)
+    for k in resunet_golden.files:
+        if k.startswith("small/gradnorm/"):
+            name = k[len("small/gradnorm/"):]
+            ref = float(resunet_golden[k])
+            assert abs(grads[name].norm().item() - ref) <= 1e-4 * max(ref, 1e-6) + 1e-9, name
+        if k.startswith("small/grad/"):
+            name = k[len("small/grad/"):]
+            ref = torch.from_numpy(resunet_golden[k])
+            assert (grads[name] - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1e-6) + 1e-9, name
+
+
+def test_state_dict_schema_cfg2(resunet_golden):
+    """init_state_dict must produce exactly the reference's 98 keys / shapes for the cfg-2 architecture."""
+    sd = net_oracle.init_state_dict(1, [16, 32, 64, 128, 256])
+    keys = list(resunet_golden["cfg2/keys"])
+    shapes = dict(zip(keys, resunet_golden["cfg2/shapes"]))
+    assert set(sd.keys()) == set(keys)
+    for k, v in sd.items():
+        assert str(tuple(v.shape)) == shapes[k], k
+    assert sum(v.numel() for v in sd.values()) == int(resunet_golden["cfg2/n_params"]) == 6693777
+
+
+def test_flop_count_matches_baseline():
+    assert net_oracle.count_flops_forward(1, [16, 32, 64, 128, 256], (128, 128, 128)) == 303734718464
