@@ -1,0 +1,9 @@
+"""biapy_amd - MI355X (gfx950) native 3D patch U-Net hot path for BiaPy.
+
+Public surface mirrors the reference names for this path:
+  biapy_amd.resunet.ResUNet                       <- biapy.models.resunet.ResUNet
+  biapy_amd.tiling.crop_3D_data_with_overlap      <- biapy.data.data_3D_manipulation.crop_3D_data_with_overlap
+  biapy_amd.tiling.merge_3D_data_with_overlap     <- biapy.data.data_3D_manipulation.merge_3D_data_with_overlap
+  biapy_amd.workflow.SlidingWindowPredictor       <- Base_Workflow.process_test_sample (per-patch branch)
+"""
+__version__ = "0.1.0"

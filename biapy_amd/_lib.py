@@ -1,0 +1,119 @@
+"""ctypes binding of libbiapy_amd.so (include/biapy_amd.h).
+
+The HIP extension IS the product: there is no CPU or PyTorch fallback.  Importing this module
+without the built library raises immediately (``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C biapy_amd/csrc`` builds it in-tree).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbiapy_amd.so")
+
+F32, BF16, F16, U8 = 0, 1, 2, 3
+ACT = {"none": 0, "linear": 0, "elu": 1, "relu": 2, "silu": 3}
+PK_K3, PK_K3_T, PK_K1, PK_DENSE, PK_DENSE_T, PK_CT, PK_CT_T = range(7)
+
+
+class AxisGrid(C.Structure):
+    _fields_ = [("n", C.c_int32), ("step", C.c_int32), ("last", C.c_int32), ("patch", C.c_int32), ("limit", C.c_int32)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32)]
+
+
+NULL_T = Tensor(None, 0, 0)
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+_SIGS = {
+    "bpx_version": ([], C.c_int),
+    "bpx_last_error": ([], C.c_char_p),
+    "bpx_selftest_layouts": ([_vp, _vp], _i),
+    "bpx_debug_set_wgrad_tr": ([_i], _i),
+    "bpx_crop3d_gather": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _i64, _i64, _vp, _vp], _i),
+    "bpx_merge3d_blend": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
+                           _vp, _vp, _i, _vp, _i, _vp], _i),
+    "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
+    "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
+    "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
+    "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i], _i),
+    "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
+    "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp], _i),
+    "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
+    "bpx_convT3d_k2s2_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
+    "bpx_convT3d_stats_tiles": ([_i, _i, _i], _i),
+    "bpx_convT3d_k2s2_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp], _i),
+    "bpx_convT3d_k2s2_wgrad": ([_i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp, _vp], _i),
+    "bpx_norm_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _f, _i, _vp, _i, _i, _vp], _i),
+    "bpx_tensor_stats": ([_i, _i, _i64, Tensor, _vp, _vp], _i),
+    "bpx_tensor_stats_tiles": ([_i64], _i),
+    "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "bpx_norm_bwd_apply": ([_i, _i, _i64, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
+    "bpx_maxpool3d_fwd": ([_i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp], _i),
+    "bpx_maxpool3d_stats_tiles": ([_i, _i, _i, _i, _i], _i),
+    "bpx_maxpool3d_bwd": ([_i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp], _i),
+    "bpx_head_fwd": ([_i, _i64, _i, Tensor, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp], _i),
+    "bpx_head_bwd": ([_i, _i64, _i, Tensor, _vp, _i, _vp, _i64, _i64, Tensor, _vp, _vp, _vp], _i),
+    "bpx_conv3d_c1_fwd": ([_i, _i, _i, _i, _i, _vp, _vp, _vp, Tensor, _vp, _vp], _i),
+    "bpx_conv3d_c1_stats_tiles": ([_i, _i, _i], _i),
+    "bpx_conv3d_c1_wgrad": ([_i, _i, _i, _i, _i, _vp, Tensor, _vp, _vp, _vp], _i),
+    "bpx_cast": ([_i, _vp, _i, _vp, _i64, _vp], _i),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+
+class BpxError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the product and there is no fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C biapy_amd/csrc`."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError = the library does not export what the header declares
+        fn.argtypes = args
+        fn.restype = res
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise BpxError(lib.bpx_last_error().decode())
+
+
+def stream_ptr() -> Optional[int]:
+    """The current PyTorch HIP stream of the calling thread (kernels are launched on it)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t: torch.Tensor) -> int:
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16, torch.uint8: U8}[t.dtype]
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def tview(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Tensor:
+    """bpx_tensor for an NDHWC torch tensor (last dim = channels, contiguous), optionally a channel slice."""
+    if t is None:
+        return NULL_T
+    assert t.is_contiguous(), "NDHWC buffers must be contiguous"
+    ld = t.shape[-1]
+    cc = ld - c0 if c is None else c
+    return Tensor(t.data_ptr() + c0 * t.element_size(), ld, cc)

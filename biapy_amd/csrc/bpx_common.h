@@ -1,0 +1,124 @@
+// Shared device/host helpers for libbiapy_amd (gfx950 only - no portability layer by design).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/biapy_amd.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void bpx_set_error(const char* fmt, ...);
+#define BPX_FAIL(...)            \
+  do {                           \
+    bpx_set_error(__VA_ARGS__);  \
+    return 1;                    \
+  } while (0)
+#define BPX_CHECK(cond, ...) \
+  do {                       \
+    if (!(cond)) BPX_FAIL(__VA_ARGS__); \
+  } while (0)
+#define BPX_LAUNCH_CHECK(name)                                                         \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) BPX_FAIL("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- vector types ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;  // 8 bf16 = one 16x16x32 MFMA operand
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// storage-type traits: T = float (exact mode) or uint16_t (bf16 bits)
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int KPL = 4;   // elements per 16-byte lane operand
+  static constexpr int DT = BPX_F32;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemTraits<uint16_t> {
+  static constexpr int KPL = 8;
+  static constexpr int DT = BPX_BF16;
+  __device__ static __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16 bytes of T -> up to 8 floats and back
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& v, float* f) {
+  f[0] = __uint_as_float(v[0]); f[1] = __uint_as_float(v[1]); f[2] = __uint_as_float(v[2]); f[3] = __uint_as_float(v[3]);
+}
+template <> __device__ __forceinline__ void unpack16<uint16_t>(const u32x4_t& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(v[i]); f[2 * i + 1] = bf16hi(v[i]); }
+}
+template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
+template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
+  u32x4_t v; v[0] = __float_as_uint(f[0]); v[1] = __float_as_uint(f[1]); v[2] = __float_as_uint(f[2]); v[3] = __float_as_uint(f[3]);
+  return v;
+}
+template <> __device__ __forceinline__ u32x4_t pack16<uint16_t>(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+// ---- activations ----------------------------------------------------------------------------
+// act(u) and act'(u).  ELU(alpha=1): u>0 ? u : exp(u)-1 (PyTorch uses expm1; |diff| <= 1 ulp of 1.0
+// which is far below bf16 and within the stated fp32 tolerance).
+template <int ACT> __device__ __forceinline__ float act_fwd(float u) {
+  if (ACT == BPX_ACT_ELU) return u > 0.f ? u : (__expf(u) - 1.f);
+  if (ACT == BPX_ACT_RELU) return u > 0.f ? u : 0.f;
+  if (ACT == BPX_ACT_SILU) return u / (1.f + __expf(-u));
+  return u;
+}
+template <int ACT> __device__ __forceinline__ float act_bwd(float u) {
+  if (ACT == BPX_ACT_ELU) return u > 0.f ? 1.f : __expf(u);
+  if (ACT == BPX_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (ACT == BPX_ACT_SILU) { float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
+  return 1.f;
+}
+
+// ---- MFMA step: 16 bytes of A and B per lane -> one (bf16) or four (f32) MFMAs ----------------
+// D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[i=l&15][kgroup l>>4], B[kgroup l>>4][j=l&15];
+// result lane l holds D[i=(l>>4)*4+r][j=l&15], r=0..3 (cdna_hip_programming.md section 3).
+template <typename T> __device__ __forceinline__ f32x4_t mfma_step(const u32x4_t& a, const u32x4_t& b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mfma_step<uint16_t>(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+  return c;
+}
+
+__host__ __device__ __forceinline__ int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+static inline size_t dtype_size(int dt) {
+  switch (dt) {
+    case BPX_F32: return 4;
+    case BPX_BF16: case BPX_F16: return 2;
+    case BPX_U8: return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,408 @@
+// Conv3d 3x3x3 "same" as an implicit GEMM on the gfx950 matrix cores.
+//
+//   GEMM view : D[co][v] = sum_{tap,ci} Wp[co][(tap,ci)] * A[(tap,ci)][v]
+//               MFMA "A" operand = packed weights (16 output channels x K), "B" operand = activations
+//               (K x 16 voxels) so that a lane ends up holding 4 CONSECUTIVE CHANNELS of one voxel
+//               -> one 8-byte (bf16) / 16-byte (f32) store per lane, no LDS transpose in the epilogue.
+//   tile      : TZ x TY x TX output voxels per 256-thread workgroup (4 waves x MS m-subtiles of 16
+//               voxels), 16*NS output channels (blockIdx.y walks the rest of Cout).
+//   K loop    : input channels in chunks of 16.  For each chunk the (TZ+2)(TY+2)(TX+2) x 16 halo is
+//               staged ONCE in LDS ([voxel][16ch], 32 B (bf16) / 64 B (f32) per voxel - conflict-free
+//               for ds_read_b128 at 32 B) and read 27x by the taps; the normalisation
+//               + activation that precedes the convolution in the reference graph is applied while
+//               staging (fp32 math), so the normalised tensor never exists in HBM.
+//   weights   : pre-packed in fragment order [chunk][kgroup q][Cout][KPL]; a lane's 16-byte operand
+//               is one coalesced global load (L1/L2 resident - a whole chunk is <= 57 KB).
+//   epilogue  : FWD   : + bias (+ fused 1x1x1 shortcut conv of a second raw tensor, + its bias),
+//                       store, per-(n,c) sum / sum^2 partials for the NEXT InstanceNorm.
+//               DGRAD : g = acc * act'(scale*t+shift); store g; partials of sum(g), sum(g*xhat).
+#include <algorithm>
+#include <type_traits>
+
+#include "bpx_common.h"
+
+namespace {
+
+enum { EPI_FWD = 0, EPI_DGRAD = 1 };
+
+struct Conv3Params {
+  int N, D, H, W;
+  const void* x; int x_ld; int Cin;
+  const bpx_norm_rec* in_norm; int act;
+  const void* wp; const float* bias;
+  const void* sc; int sc_ld; int sc_C; const void* wsc; const float* bias_sc;
+  void* y; int y_ld; int Cout;
+  float* part;  // [N][tiles][2][Cout]
+  const void* t; int t_ld; const bpx_norm_rec* t_norm; int t_act;
+  int tilesY, tilesX, tilesPerSample;
+};
+
+template <typename T> __device__ __forceinline__ float apply_act_rt(float u, int act) {
+  constexpr bool PRECISE = std::is_same<T, float>::value;
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
+    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
+    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
+    default: return u;
+  }
+}
+template <typename T> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
+  constexpr bool PRECISE = std::is_same<T, float>::value;
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
+    case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case BPX_ACT_SILU: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
+    default: return 1.f;
+  }
+}
+
+// Stage an EZ x EY x EX block of voxels (16 channels of chunk `chunk`) into LDS as [voxel][16ch].
+// Voxel (0,0,0) of the block sits at volume coordinate (oz,oy,ox); out-of-volume voxels are ZERO
+// (Conv3d zero padding applies to the activated tensor, so the zero is written after the prologue).
+template <typename T, int EZ, int EY, int EX>
+__device__ __forceinline__ void stage_block(unsigned char* smem, const T* __restrict__ src, int ld, int chunk, int n, int D, int H,
+                                            int W, int oz, int oy, int ox, const bpx_norm_rec* __restrict__ norm, int C_norm,
+                                            int act, int tid) {
+  constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
+  constexpr int PIECES = EZ * EY * EX * GPT;
+  constexpr int UNR = 4;
+  const int sub = tid % GPT;
+  float sc[KPL], sh[KPL];
+  if (norm) {
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      bpx_norm_rec r = norm[(size_t)n * C_norm + chunk * 16 + sub * KPL + e];
+      sc[e] = r.scale; sh[e] = r.shift;
+    }
+  }
+  const T* sbase = src + chunk * 16 + sub * KPL;
+  for (int base = 0; base < PIECES; base += 256 * UNR) {
+    u32x4_t buf[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      int idx = base + u * 256 + tid;
+      ok[u] = false;
+      buf[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (idx < PIECES) {
+        int hv = idx / GPT;
+        int hx = hv % EX, hy = (hv / EX) % EY, hz = hv / (EX * EY);
+        int gz = oz + hz, gy = oy + hy, gx = ox + hx;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          ok[u] = true;
+          buf[u] = *reinterpret_cast<const u32x4_t*>(sbase + ((((size_t)n * D + gz) * H + gy) * W + gx) * (size_t)ld);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      int idx = base + u * 256 + tid;
+      if (idx < PIECES) {
+        u32x4_t v = buf[u];
+        if (norm && ok[u]) {
+          float f[KPL];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) f[e] = apply_act_rt<T>(fmaf(sc[e], f[e], sh[e]), act);
+          v = pack16<T>(f);
+        }
+        *reinterpret_cast<u32x4_t*>(smem + (size_t)(idx / GPT) * VB + sub * 16) = v;
+      }
+    }
+  }
+}
+
+template <int HY, int HX, int VB> __device__ __forceinline__ constexpr int tap_off(int tap) {
+  return (((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VB;
+}
+
+template <typename T, int TZ, int TY, int TX, int NS, int EPI>
+__global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
+  using Tr = ElemTraits<T>;
+  constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int QTOT = 27 * GPT, STEPS = (QTOT + 3) / 4, QPAD = STEPS * 4;
+  constexpr int MT = TZ * TY * TX / 16, MS = MT / 4;
+  static_assert(MT % 4 == 0 && MS >= 1, "tile must give every wave at least one m-subtile");
+  constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HV * VB + RED_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x % p.tilesPerSample, n = blockIdx.x / p.tilesPerSample;
+  const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
+  const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+  const int co_base = blockIdx.y * 16 * NS;
+  const int Cout = p.Cout;
+
+  f32x4_t acc[MS][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int hb[MS], tb[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    int t = (wave * MS + ms) * 16 + j;
+    int tz = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
+    hb[ms] = ((tz * HY + ty) * HX + tx) * VB;
+    tb[ms] = t * VB;
+  }
+  // per-lane (kgroup -> tap parity / channel-group) decomposition, see DESIGN.md "K order"
+  const int cg_off = (GPT == 2 ? (g & 1) : g) * 16;
+  const bool hi_tap = (GPT == 2) && (g >> 1);
+
+  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+  const int nchunks = p.Cin / 16;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();
+    stage_block<T, HZ, HY, HX>(smem, xin, p.x_ld, chunk, n, p.D, p.H, p.W, z0 - 1, y0 - 1, x0 - 1, p.in_norm, p.Cin, p.act, tid);
+    __syncthreads();
+    const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
+    u32x4_t wf[NS], wn[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)ns * 16 * KPL);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s + 1 < STEPS) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          wn[ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + 1) * 4 * Cout + ns * 16) * KPL);
+      }
+      int off;
+      if (GPT == 2) {
+        const int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;  // padded tap 27: zero weights, any valid address
+        off = hi_tap ? tap_off<HY, HX, VB>(t1) : tap_off<HY, HX, VB>(t0);
+      } else {
+        off = tap_off<HY, HX, VB>(s);
+      }
+      off += cg_off;
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) {
+        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + hb[ms] + off);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
+      }
+      if (s + 1 < STEPS) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) wf[ns] = wn[ns];
+      }
+    }
+  }
+
+  // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only) ------------------------------
+  if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16) {
+    const T* __restrict__ scin = reinterpret_cast<const T*>(p.sc);
+    const T* __restrict__ wsc = reinterpret_cast<const T*>(p.wsc);
+    const int nch = p.sc_C / 16;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+      __syncthreads();
+      stage_block<T, TZ, TY, TX>(smem, scin, p.sc_ld, chunk, n, p.D, p.H, p.W, z0, y0, x0, nullptr, 0, 0, tid);
+      __syncthreads();
+      const T* wl = wsc + ((size_t)chunk * 4 * Cout + (size_t)g * Cout + co_base + j) * KPL;
+      u32x4_t wf[NS];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)ns * 16 * KPL);
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) {
+        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + tb[ms] + cg_off);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
+      }
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  float s1[NS][4], s2[NS][4];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
+
+  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int co = co_base + ns * 16 + g * 4;
+    float add[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f};
+    bpx_norm_rec rec[4];
+    if (EPI == EPI_FWD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (p.bias) add[r] += p.bias[co + r];
+        if (p.sc && p.bias_sc) add[r] += p.bias_sc[co + r];
+        if (p.sc && p.sc_C == 1) w1[r] = reinterpret_cast<const float*>(p.wsc)[co + r];
+      }
+    } else if (p.t_norm) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rec[r] = p.t_norm[(size_t)n * Cout + co + r];
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      int t = (wave * MS + ms) * 16 + j;
+      int z = z0 + t / (TY * TX), y = y0 + (t / TX) % TY, x = x0 + t % TX;
+      if (z < p.D && y < p.H && x < p.W) {
+        size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
+        float v[4];
+        if (EPI == EPI_FWD) {
+          float img = (p.sc && p.sc_C == 1) ? reinterpret_cast<const float*>(p.sc)[vox] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[ms][ns][r] + add[r] + img * w1[r];
+            s1[ns][r] += v[r];
+            s2[ns][r] += v[r] * v[r];
+          }
+        } else {
+          if (p.t_norm) {
+            const T* tp = reinterpret_cast<const T*>(p.t) + vox * (size_t)p.t_ld + co;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float tv = Tr::ld(tp + r);
+              float u = fmaf(rec[r].scale, tv, rec[r].shift);
+              v[r] = acc[ms][ns][r] * apply_act_bwd_rt<T>(u, p.t_act);
+              float xh = (tv - rec[r].mean) * rec[r].rstd;
+              s1[ns][r] += v[r];
+              s2[ns][r] += v[r] * xh;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ms][ns][r];
+          }
+        }
+        T* yp = yout + vox * (size_t)p.y_ld + co;
+        if (std::is_same<T, float>::value) {
+          *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v[0], v[1], v[2], v[3]};
+        } else {
+          *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      }
+    }
+  }
+
+  if (p.part != nullptr) {
+    float* red = reinterpret_cast<float*>(smem + HV * VB);  // [wave][NS*16][2]
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[ns][r], b = s2[ns][r];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (j == 0) {
+          red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 0] = a;
+          red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < NS * 16 * 2) {
+      int c = tid >> 1, k = tid & 1;
+      float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
+                red[(3 * NS * 16 + c) * 2 + k];
+      p.part[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Cout + co_base + c] = a;
+    }
+  }
+}
+
+struct TileCfg { int tz, ty, tx, ns; };
+
+inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
+  TileCfg c;
+  c.ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
+  if (W > 8) {
+    c.tx = 16; c.tz = 4;
+    bool big = (dtype == BPX_BF16) && c.ns <= 2 && (int64_t)D * H * W >= 32768 && H >= 8;
+    c.ty = big ? 8 : 4;
+  } else {
+    c.tx = 8; c.tz = 4; c.ty = 4;
+  }
+  return c;
+}
+
+template <typename T, int EPI>
+int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
+  Conv3Params p = p0;
+  int tilesZ = cdiv(p.D, c.tz);
+  p.tilesY = cdiv(p.H, c.ty);
+  p.tilesX = cdiv(p.W, c.tx);
+  p.tilesPerSample = tilesZ * p.tilesY * p.tilesX;
+  dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
+#define L(TZ, TY, TX, NS)                                                        \
+  if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
+    conv3_kernel<T, TZ, TY, TX, NS, EPI><<<grid, 256, 0, s>>>(p);                \
+    return 0;                                                                    \
+  }
+  if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only
+    L(4, 8, 16, 1) L(4, 8, 16, 2)
+  }
+  L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 4) L(4, 4, 8, 1) L(4, 4, 8, 2) L(4, 4, 8, 4)
+#undef L
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int bpx_conv3d_stats_tiles(int dtype, int D, int H, int W, int Cout) {
+  TileCfg c = pick_cfg(dtype, D, H, W, Cout);
+  return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, c.tx);
+}
+
+static int check_tensor(const char* fn, const char* name, const bpx_tensor& t, int esize, bool need16) {
+  BPX_CHECK(t.ptr != nullptr, "%s: %s.ptr is null", fn, name);
+  BPX_CHECK(t.C >= 1 && t.ld >= t.C, "%s: %s has ld %d < C %d", fn, name, t.ld, t.C);
+  if (need16) {
+    BPX_CHECK(t.C % 16 == 0, "%s: %s.C = %d must be a multiple of 16", fn, name, t.C);
+    BPX_CHECK(((uintptr_t)t.ptr % 16) == 0 && ((size_t)t.ld * esize) % 16 == 0, "%s: %s must be 16-byte aligned (ptr and ld)", fn, name);
+  }
+  return 0;
+}
+
+extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                              const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
+                              const float* bias_sc_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_fwd";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  int es = (int)dtype_size(dtype);
+  BPX_CHECK(N > 0 && D > 0 && H > 0 && W > 0, "%s: empty volume", fn);
+  if (check_tensor(fn, "x", x, es, true) || check_tensor(fn, "y", y, es, true)) return 1;
+  BPX_CHECK(w_packed_d != nullptr, "%s: packed weights are null", fn);
+  if (sc.ptr) {
+    BPX_CHECK(w_sc_d != nullptr, "%s: shortcut weights are null", fn);
+    if (sc.C != 1 && check_tensor(fn, "sc", sc, es, true)) return 1;
+  }
+  Conv3Params p{};
+  p.N = N; p.D = D; p.H = H; p.W = W;
+  p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = in_norm_d; p.act = act;
+  p.wp = w_packed_d; p.bias = bias_d;
+  p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
+  p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
+  TileCfg c = pick_cfg(dtype, D, H, W, y.C);
+  int rc = (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream) : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
+  BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,
+                                const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_dgrad";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  int es = (int)dtype_size(dtype);
+  if (check_tensor(fn, "dy", dy, es, true) || check_tensor(fn, "g", g, es, true)) return 1;
+  BPX_CHECK(w_packed_T_d != nullptr, "%s: packed weights are null", fn);
+  if (t_norm_d) {
+    if (check_tensor(fn, "t", t, es, false)) return 1;
+    BPX_CHECK(t.C == g.C, "%s: t.C %d != g.C %d", fn, t.C, g.C);
+  }
+  Conv3Params p{};
+  p.N = N; p.D = D; p.H = H; p.W = W;
+  p.x = dy.ptr; p.x_ld = dy.ld; p.Cin = dy.C; p.in_norm = nullptr; p.act = 0;
+  p.wp = w_packed_T_d;
+  p.y = g.ptr; p.y_ld = g.ld; p.Cout = g.C; p.part = t_norm_d ? red_part_d : nullptr;
+  p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
+  TileCfg c = pick_cfg(dtype, D, H, W, g.C);
+  int rc = (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream) : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
+  BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}

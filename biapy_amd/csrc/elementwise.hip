@@ -1,0 +1,797 @@
+// HBM-bound kernels around the convolutions: normalisation statistics, InstanceNorm backward,
+// max-pooling, the 1x1x1 output head, the Cin=1 first layer, weight packing, casts and a lane-layout
+// self test.  All of them stream NDHWC tensors with 16-byte accesses along the channel axis.
+#include <type_traits>
+
+#include "bpx_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float elu_like(float u, int act) {
+  constexpr bool PRECISE = std::is_same<T, float>::value;
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
+    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
+    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
+    default: return u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics
+// ------------------------------------------------------------------------------------------------
+// part: [N][tiles][2][C].  One 256-thread block per (n, 16-channel group): thread = (tile lane, channel).
+__global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restrict__ part, int tiles, int C, double inv_count,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            int cpg /* channels per group */, bpx_norm_rec* __restrict__ out,
+                                                            int out_ld, int out_off) {
+  __shared__ double red[2][16][16];
+  const int n = blockIdx.y, c0 = blockIdx.x * 16;
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  double s1 = 0.0, s2 = 0.0;
+  if (c0 + c < C) {
+    const float* pp = part + (size_t)n * tiles * 2 * C + c0 + c;
+    for (int t = tl; t < tiles; t += 16) {
+      s1 += (double)pp[(size_t)t * 2 * C];
+      s2 += (double)pp[(size_t)t * 2 * C + C];
+    }
+  }
+  red[0][tl][c] = s1;
+  red[1][tl][c] = s2;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    double s = 0.0;
+    for (int t = 0; t < 16; ++t) s += red[k][t][cc];
+    red[k][0][cc] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && c0 + threadIdx.x < C) {
+    const int cc = threadIdx.x;
+    double m, v;
+    if (cpg == 1) {
+      m = red[0][0][cc] * inv_count;
+      v = red[1][0][cc] * inv_count - m * m;
+    } else {  // GroupNorm: cpg divides 16 or is a multiple of 16 handled by the host (cpg <= 16 here)
+      int gb = (cc / cpg) * cpg;
+      double a = 0.0, b = 0.0;
+      for (int q = 0; q < cpg; ++q) { a += red[0][0][gb + q]; b += red[1][0][gb + q]; }
+      m = a * inv_count / cpg;
+      v = b * inv_count / cpg - m * m;
+    }
+    if (v < 0.0) v = 0.0;
+    float rstd = (float)(1.0 / sqrt(v + (double)eps));
+    float ga = gamma ? gamma[c0 + cc] : 1.f, be = beta ? beta[c0 + cc] : 0.f;
+    bpx_norm_rec r;
+    r.mean = (float)m; r.rstd = rstd; r.scale = ga * rstd; r.shift = be - (float)m * ga * rstd;
+    out[(size_t)n * out_ld + out_off + c0 + cc] = r;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) tensor_stats_kernel(const T* __restrict__ x, int ld, int C, int64_t vps, int tiles,
+                                                          float* __restrict__ part) {
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int64_t v0 = (int64_t)tile * 256, v1 = min(v0 + 256, vps);
+  for (int c = threadIdx.x; c < C; c += 64) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t v = v0; v < v1; ++v) {
+      float f = ElemTraits<T>::ld(x + ((size_t)n * vps + v) * ld + c);
+      s1 += f; s2 += f * f;
+    }
+    part[(((size_t)n * tiles + tile) * 2 + 0) * C + c] = s1;
+    part[(((size_t)n * tiles + tile) * 2 + 1) * C + c] = s2;
+  }
+}
+
+// InstanceNorm backward finalize.  red: [N][tiles][2][C] partials of S1 = sum g, S2 = sum g*xhat.
+//   dx = (gamma*rstd) * (g - S1/M - xhat*S2/M),  xhat = (t-mean)*rstd
+//      = a*g + b*t + c0 with a = gamma*rstd, b = -a*rstd*S2/M, c0 = -a*S1/M + a*mean*rstd*S2/M
+//   dgamma[c] += sum_n S2, dbeta[c] += sum_n S1
+__global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int C,
+                                                                double inv_count, const bpx_norm_rec* __restrict__ rec,
+                                                                const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, bpx_nbwd_coef* __restrict__ coef) {
+  __shared__ double red[2][16][16];
+  const int n = blockIdx.y, c0 = blockIdx.x * 16;
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  double s1 = 0.0, s2 = 0.0;
+  if (c0 + c < C) {
+    const float* pp = red_part + (size_t)n * tiles * 2 * C + c0 + c;
+    for (int t = tl; t < tiles; t += 16) {
+      s1 += (double)pp[(size_t)t * 2 * C];
+      s2 += (double)pp[(size_t)t * 2 * C + C];
+    }
+  }
+  red[0][tl][c] = s1;
+  red[1][tl][c] = s2;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    double s = 0.0;
+    for (int t = 0; t < 16; ++t) s += red[k][t][cc];
+    red[k][0][cc] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && c0 + threadIdx.x < C) {
+    const int cc = c0 + threadIdx.x;
+    double S1 = red[0][0][threadIdx.x], S2 = red[1][0][threadIdx.x];
+    bpx_norm_rec r = rec[(size_t)n * C + cc];
+    double ga = gamma ? (double)gamma[cc] : 1.0;
+    double a = ga * r.rstd;
+    bpx_nbwd_coef k;
+    k.a = (float)a;
+    k.b = (float)(-a * r.rstd * S2 * inv_count);
+    k.c0 = (float)(-a * S1 * inv_count + a * r.mean * r.rstd * S2 * inv_count);
+    k.pad = 0.f;
+    coef[(size_t)n * C + cc] = k;
+    if (dgamma) atomicAdd(dgamma + cc, (float)S2);
+    if (dbeta) atomicAdd(dbeta + cc, (float)S1);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict__ g, int g_ld, const T* __restrict__ t, int t_ld,
+                                                             const bpx_nbwd_coef* __restrict__ coef, const T* __restrict__ addend,
+                                                             int a_ld, T* __restrict__ dx, int dx_ld, int C, int64_t vps, int N) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int G = C / KPL;
+  const int64_t total = (int64_t)N * vps * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cg = (int)(i % G);
+    int64_t vox = i / G;
+    int n = (int)(vox / vps);
+    u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + (size_t)vox * g_ld + cg * KPL);
+    u32x4_t tv = *reinterpret_cast<const u32x4_t*>(t + (size_t)vox * t_ld + cg * KPL);
+    float gf[KPL], tf[KPL], of[KPL];
+    unpack16<T>(gv, gf);
+    unpack16<T>(tv, tf);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      bpx_nbwd_coef k = coef[(size_t)n * C + cg * KPL + e];
+      of[e] = k.a * gf[e] + k.b * tf[e] + k.c0;
+    }
+    if (addend) {
+      u32x4_t av = *reinterpret_cast<const u32x4_t*>(addend + (size_t)vox * a_ld + cg * KPL);
+      float af[KPL];
+      unpack16<T>(av, af);
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) of[e] += af[e];
+    }
+    *reinterpret_cast<u32x4_t*>(dx + (size_t)vox * dx_ld + cg * KPL) = pack16<T>(of);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// max pooling 2x2x2
+// ------------------------------------------------------------------------------------------------
+constexpr int POOL_IPT = 4;  // items (output voxel x 16-byte channel group) per thread
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int C, int D, int H, int W,
+                                   int tiles, float* __restrict__ part) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  extern __shared__ float red[];  // [blockDim][2*KPL]
+  const int G = C / KPL;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t items = (int64_t)Do * Ho * Wo * G;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const int cg = threadIdx.x % G;
+  float s1[KPL], s2[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) s1[e] = s2[e] = 0.f;
+  for (int it = 0; it < POOL_IPT; ++it) {
+    int64_t i = ((int64_t)tile * POOL_IPT + it) * blockDim.x + threadIdx.x;
+    if (i >= items) break;
+    int64_t ov = i / G;
+    int xo = (int)(ov % Wo), yo = (int)((ov / Wo) % Ho), zo = (int)(ov / ((int64_t)Wo * Ho));
+    float m[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      size_t vox = (((size_t)n * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL);
+      float f[KPL];
+      unpack16<T>(v, f);
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) m[e] = f[e] > m[e] ? f[e] : m[e];
+    }
+    size_t ovox = (size_t)n * Do * Ho * Wo + ov;
+    *reinterpret_cast<u32x4_t*>(y + ovox * y_ld + cg * KPL) = pack16<T>(m);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) { s1[e] += m[e]; s2[e] += m[e] * m[e]; }
+  }
+  if (part) {
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) { red[threadIdx.x * 2 * KPL + e] = s1[e]; red[threadIdx.x * 2 * KPL + KPL + e] = s2[e]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * C; idx += blockDim.x) {
+      int k = idx / C, c = idx % C;
+      int g0 = c / KPL, e = c % KPL;
+      float s = 0.f;
+      for (int t = g0; t < (int)blockDim.x; t += G) s += red[t * 2 * KPL + k * KPL + e];
+      part[(((size_t)n * tiles + tile) * 2 + k) * C + c] = s;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
+                                                          const T* __restrict__ addend, int a_ld, T* __restrict__ dx, int dx_ld, int C,
+                                                          int D, int H, int W, int N) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int G = C / KPL;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Do * Ho * Wo * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cg = (int)(i % G);
+    int64_t ov = i / G;
+    int xo = (int)(ov % Wo), yo = (int)((ov / Wo) % Ho), zo = (int)((ov / ((int64_t)Wo * Ho)) % Do), n = (int)(ov / ((int64_t)Wo * Ho * Do));
+    float f[8][KPL];
+    float m[KPL];
+    int am[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) { m[e] = -INFINITY; am[e] = 0; }
+    size_t voxk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      voxk[k] = (((size_t)n * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + voxk[k] * x_ld + cg * KPL);
+      unpack16<T>(v, f[k]);
+#pragma unroll
+      for (int e = 0; e < KPL; ++e)
+        if (f[k][e] > m[e]) { m[e] = f[k][e]; am[e] = k; }  // strict >: first maximum wins, as in PyTorch
+    }
+    float d[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + (size_t)ov * dy_ld + cg * KPL), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float o[KPL];
+      if (addend) unpack16<T>(*reinterpret_cast<const u32x4_t*>(addend + voxk[k] * a_ld + cg * KPL), o);
+      else {
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) o[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) o[e] += (am[e] == k) ? d[e] : 0.f;
+      *reinterpret_cast<u32x4_t*>(dx + voxk[k] * dx_ld + cg * KPL) = pack16<T>(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// output head (1x1x1 conv to <= 4 fp32 channels, planar output) and its backward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CIN>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int Cout, int act, float* __restrict__ out,
+                                                       int64_t sn, int64_t sc, int64_t vps, int N) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  __shared__ float ws[4 * CIN + 4];
+  for (int i = threadIdx.x; i < Cout * CIN; i += blockDim.x) ws[i] = w[i];
+  if (threadIdx.x < Cout) ws[4 * CIN + threadIdx.x] = b ? b[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t total = (int64_t)N * vps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float f[CIN];
+#pragma unroll
+    for (int q = 0; q < CIN / KPL; ++q) unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (size_t)i * x_ld + q * KPL), f + q * KPL);
+    int n = (int)(i / vps);
+    int64_t v = i - (int64_t)n * vps;
+    for (int co = 0; co < Cout; ++co) {
+      float a = ws[4 * CIN + co];
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) a = fmaf(f[c], ws[co * CIN + c], a);
+      if (act == 1) a = 1.f / (1.f + expf(-a));
+      else if (act == 2) a = tanhf(a);
+      out[n * sn + co * sc + v] = a;
+    }
+  }
+}
+
+template <typename T, int CIN>
+__global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w, int Cout,
+                                                       const float* __restrict__ dout, int64_t sn, int64_t sc, T* __restrict__ dx,
+                                                       int dx_ld, float* __restrict__ dw, float* __restrict__ db, int64_t vps, int N) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  __shared__ float ws[4 * CIN];
+  for (int i = threadIdx.x; i < Cout * CIN; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  float dwl[4][CIN];
+  float dbl[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    dbl[co] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) dwl[co][c] = 0.f;
+  }
+  const int64_t total = (int64_t)N * vps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float f[CIN], o[CIN];
+#pragma unroll
+    for (int q = 0; q < CIN / KPL; ++q) unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (size_t)i * x_ld + q * KPL), f + q * KPL);
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) o[c] = 0.f;
+    int n = (int)(i / vps);
+    int64_t v = i - (int64_t)n * vps;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+      if (co < Cout) {
+        float d = dout[n * sn + co * sc + v];
+        dbl[co] += d;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) { o[c] = fmaf(d, ws[co * CIN + c], o[c]); dwl[co][c] = fmaf(d, f[c], dwl[co][c]); }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CIN / KPL; ++q) *reinterpret_cast<u32x4_t*>(dx + (size_t)i * dx_ld + q * KPL) = pack16<T>(o + q * KPL);
+  }
+#pragma unroll
+  for (int co = 0; co < 4; ++co) {
+    if (co < Cout) {
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        float a = dwl[co][c];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(dw + co * CIN + c, a);
+      }
+      float a = dbl[co];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+      if ((threadIdx.x & 63) == 0 && db) atomicAdd(db + co, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// first layer: Cin = 1, k = 3, fp32 image -> 16 output channels per blockIdx.y
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w /* (Cout,1,27) */,
+                                                          const float* __restrict__ bias, T* __restrict__ y, int y_ld, int Cout, int D,
+                                                          int H, int W, int tiles, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * 16 + 16];
+  __shared__ float red[4][32];
+  const int n = blockIdx.z, cb = blockIdx.y * 16, tile = blockIdx.x;
+  for (int i = threadIdx.x; i < 27 * 16; i += 256) { int tap = i / 16, c = i % 16; ws[i] = w[(size_t)(cb + c) * 27 + tap]; }
+  if (threadIdx.x < 16) ws[27 * 16 + threadIdx.x] = bias ? bias[cb + threadIdx.x] : 0.f;
+  __syncthreads();
+  const int64_t vps = (int64_t)D * H * W;
+  const int64_t v = (int64_t)tile * 256 + threadIdx.x;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = ws[27 * 16 + c];
+  const bool valid = v < vps;
+  if (valid) {
+    int x = (int)(v % W), yy = (int)((v / W) % H), z = (int)(v / ((int64_t)W * H));
+    const float* ip = img + (size_t)n * vps;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      int zz = z + tap / 9 - 1, yv = yy + (tap / 3) % 3 - 1, xv = x + tap % 3 - 1;
+      float iv = 0.f;
+      if (zz >= 0 && zz < D && yv >= 0 && yv < H && xv >= 0 && xv < W) iv = ip[((size_t)zz * H + yv) * W + xv];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = fmaf(iv, ws[tap * 16 + c], acc[c]);
+    }
+    T* yp = y + ((size_t)n * vps + v) * y_ld + cb;
+    if (std::is_same<T, float>::value) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(yp + q * 4) = pack16<T>(acc + q * 4);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t*>(yp + q * 8) = pack16<T>(acc + q * 8);
+    }
+  }
+  if (part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float a = valid ? acc[c] : 0.f, b = a * a;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+      if (lane == 0) { red[wave][c] = a; red[wave][16 + c] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+      float s = red[0][k * 16 + c] + red[1][k * 16 + c] + red[2][k * 16 + c] + red[3][k * 16 + c];
+      part[(((size_t)n * tiles + tile) * 2 + k) * Cout + cb + c] = s;
+    }
+  }
+}
+
+// dW[co][tap] += sum_v img[v+tap]*dy[v][co]; thread = (tap, voxel subset), 16 co in registers.
+template <typename T>
+__global__ void __launch_bounds__(256) conv_c1_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy, int dy_ld,
+                                                            int D, int H, int W, int N, int totalTiles, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+  constexpr int TZ = 4, TY = 8, TX = 8, HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
+  __shared__ float simg[HZ * HY * HX];
+  __shared__ __attribute__((aligned(16))) float sdy[TZ * TY * TX][16];
+  __shared__ float sred[9][27 + 1][16];
+  const int cb = blockIdx.y * 16;
+  const int tap = threadIdx.x % 27, sub = threadIdx.x / 27;  // sub 0..8 active (243 threads)
+  const bool worker = threadIdx.x < 243;
+  const int toff = ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3;
+  float acc[16], bs[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { acc[c] = 0.f; bs[c] = 0.f; }
+  const int tilesX = cdiv(W, TX), tilesY = cdiv(H, TY), tilesZ = cdiv(D, TZ);
+  const int tps = tilesX * tilesY * tilesZ;
+  for (int tt = blockIdx.x; tt < totalTiles; tt += gridDim.x) {
+    const int n = tt / tps, tile = tt % tps;
+    const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HZ * HY * HX; i += 256) {
+      int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+      int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+      simg[i] = (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
+    }
+    for (int i = threadIdx.x; i < TZ * TY * TX * 16; i += 256) {
+      int c = i % 16, t = i / 16;
+      int x = x0 + t % TX, y = y0 + (t / TX) % TY, z = z0 + t / (TX * TY);
+      sdy[t][c] = (z < D && y < H && x < W) ? ElemTraits<T>::ld(dy + ((((size_t)n * D + z) * H + y) * W + x) * dy_ld + cb + c) : 0.f;
+    }
+    __syncthreads();
+    if (worker) {
+      for (int t = sub; t < TZ * TY * TX; t += 9) {
+        int tx = t % TX, ty = (t / TX) % TY, tz = t / (TX * TY);
+        float iv = simg[(tz * HY + ty) * HX + tx + toff];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4_t d = *reinterpret_cast<const f32x4_t*>(&sdy[t][q * 4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[q * 4 + e] = fmaf(iv, d[e], acc[q * 4 + e]);
+            if (tap == 0) bs[q * 4 + e] += d[e];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (worker) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { sred[sub][tap][c] = acc[c]; if (tap == 0) sred[sub][27][c] = bs[c]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 28 * 16; i += 256) {
+    int t = i / 16, c = i % 16;
+    float s = 0.f;
+    for (int q = 0; q < 9; ++q) s += sred[q][t][c];
+    if (t < 27) atomicAdd(dw + (size_t)(cb + c) * 27 + t, s);
+    else if (db) atomicAdd(db + cb + c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (see DESIGN.md "packed weights")
+// ------------------------------------------------------------------------------------------------
+enum { PK_K3 = 0, PK_K3_T = 1, PK_K1 = 2, PK_DENSE = 3, PK_DENSE_T = 4, PK_CT = 5, PK_CT_T = 6 };
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout,
+                                                   int64_t total) {
+  constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int e = (int)(i % KPL);
+    int64_t r = i / KPL;
+    float v = 0.f;
+    if (mode == PK_K3 || mode == PK_K3_T) {
+      constexpr int QTOT = 27 * GPT, QPAD = ((QTOT + 3) / 4) * 4;
+      const int ncol = (mode == PK_K3) ? Cout : Cin;  // columns = output channels of the operator
+      int col = (int)(r % ncol); r /= ncol;
+      int q = (int)(r % QPAD);
+      int chunk = (int)(r / QPAD);
+      if (q < QTOT) {
+        int tap = q / GPT, cgp = q % GPT;
+        int kc = chunk * 16 + cgp * KPL + e;  // reduction channel
+        if (mode == PK_K3) v = w[((size_t)col * Cin + kc) * 27 + tap];                 // W[co][ci][tap]
+        else v = w[((size_t)kc * Cin + col) * 27 + (26 - tap)];                         // W[co=kc][ci=col][mirrored tap]
+      }
+    } else if (mode == PK_K1) {
+      int col = (int)(r % Cout); r /= Cout;
+      int q = (int)(r % 4);
+      int chunk = (int)(r / 4);
+      if (q < GPT) v = w[(size_t)col * Cin + chunk * 16 + q * KPL + e];
+    } else if (mode == PK_DENSE || mode == PK_DENSE_T) {
+      const int ncol = (mode == PK_DENSE) ? Cout : Cin, K = (mode == PK_DENSE) ? Cin : Cout;
+      int col = (int)(r % ncol);
+      int q = (int)(r / ncol);
+      int kc = q * KPL + e;
+      if (kc < K) v = (mode == PK_DENSE) ? w[(size_t)col * Cin + kc] : w[(size_t)kc * Cin + col];
+    } else if (mode == PK_CT) {  // ConvTranspose (Cin,Cout,8): columns = sub*Cout+co, K = Cin
+      const int ncol = 8 * Cout;
+      int col = (int)(r % ncol);
+      int q = (int)(r / ncol);
+      int kc = q * KPL + e;
+      int sub = col / Cout, co = col % Cout;
+      if (kc < Cin) v = w[((size_t)kc * Cout + co) * 8 + sub];
+    } else {  // PK_CT_T: columns = ci, K = sub*Cout+co
+      int col = (int)(r % Cin);
+      int q = (int)(r / Cin);
+      int kc = q * KPL + e;
+      if (kc < 8 * Cout) { int sub = kc / Cout, co = kc % Cout; v = w[((size_t)col * Cout + co) * 8 + sub]; }
+    }
+    ElemTraits<T>::st(out + i, v);
+  }
+}
+
+inline int64_t packed_elems(int mode, int Cin, int Cout, int dtype) {
+  const int KPL = dtype == BPX_BF16 ? 8 : 4, GPT = 16 / KPL;
+  const int QPAD3 = ((27 * GPT + 3) / 4) * 4;
+  auto r4 = [](int64_t q) { return (q + 3) / 4 * 4; };
+  switch (mode) {
+    case PK_K3: return (int64_t)(Cin / 16) * QPAD3 * Cout * KPL;
+    case PK_K3_T: return (int64_t)(Cout / 16) * QPAD3 * Cin * KPL;
+    case PK_K1: return (int64_t)(Cin / 16) * 4 * Cout * KPL;
+    case PK_DENSE: return r4(Cin / KPL) * Cout * KPL;
+    case PK_DENSE_T: return r4(Cout / KPL) * Cin * KPL;
+    case PK_CT: return r4(Cin / KPL) * 8 * Cout * KPL;
+    case PK_CT_T: return r4((int64_t)8 * Cout / KPL) * Cin * KPL;
+  }
+  return -1;
+}
+
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    ElemTraits<TD>::st(d + i, ElemTraits<TS>::ld(s + i));
+}
+
+// ------------------------------------------------------------------------------------------------
+// lane-layout self test (one wave)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) selftest_kernel(float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[32 * 16];
+  const int l = threadIdx.x, i = l & 15, g = l >> 4;
+  // (0) bf16 16x16x32: A[i][k] = ((3i+5k)%7)-3, B[k][j] = ((2k+7j)%5)-2
+  {
+    float a[8], b[8];
+    for (int e = 0; e < 8; ++e) { int k = 8 * g + e; a[e] = (float)((3 * i + 5 * k) % 7 - 3); b[e] = (float)((2 * k + 7 * i) % 5 - 2); }
+    u32x4_t av = pack16<uint16_t>(a), bv = pack16<uint16_t>(b);
+    f32x4_t c = mfma_step<uint16_t>(av, bv, f32x4_t{0.f, 0.f, 0.f, 0.f});
+    for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + i] = c[r];
+  }
+  // (1) f32 16x16x4 x4 (K = 16): lane supplies k = 4*g' .. as mfma_step<float> does: element jj <-> k = 4*g + jj?
+  //     mfma_step<float> issues 4 MFMAs; MFMA jj uses lane-group g as its k index, so the global reduction index
+  //     of element jj in group g is any bijection - here k = 4*g + jj.
+  {
+    float a[4], b[4];
+    for (int e = 0; e < 4; ++e) { int k = 4 * g + e; a[e] = (float)((3 * i + 5 * k) % 7 - 3); b[e] = (float)((2 * k + 7 * i) % 5 - 2); }
+    u32x4_t av = pack16<float>(a), bv = pack16<float>(b);
+    f32x4_t c = mfma_step<float>(av, bv, f32x4_t{0.f, 0.f, 0.f, 0.f});
+    for (int r = 0; r < 4; ++r) out[256 + (4 * g + r) * 16 + i] = c[r];
+  }
+  // (2) ds_read_b64_tr_b16: LDS [32 voxels][16 ch] of raw u16 = voxel*16 + ch; each lane reads as the wgrad does.
+  {
+    for (int q = l; q < 32 * 16; q += 64) lds[q] = (uint16_t)q;
+    __syncthreads();
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(lds) + g * 8 * 32 + (i >> 2) * 32 + (i & 3) * 8;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(base + 4 * 32));
+    for (int e = 0; e < 4; ++e) { out[512 + l * 8 + e] = (float)(uint16_t)lo[e]; out[512 + l * 8 + 4 + e] = (float)(uint16_t)hi[e]; }
+  }
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int bpx_selftest_layouts(float* out_d, bpx_stream_t stream) {
+  BPX_CHECK(out_d, "bpx_selftest_layouts: null");
+  selftest_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out_d);
+  BPX_LAUNCH_CHECK("bpx_selftest_layouts");
+  return 0;
+}
+
+extern "C" int bpx_norm_finalize(const float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel, const float* gamma_d,
+                                 const float* beta_d, float eps, int groups, bpx_norm_rec* out_d, int out_ld, int out_off,
+                                 bpx_stream_t stream) {
+  const char* fn = "bpx_norm_finalize";
+  BPX_CHECK(stats_part_d && out_d, "%s: null pointer", fn);
+  BPX_CHECK(groups >= 1 && C % groups == 0, "%s: groups %d must divide C %d", fn, groups, C);
+  int cpg = C / groups;
+  BPX_CHECK(cpg == 1 || (16 % cpg == 0), "%s: channels per group %d unsupported (must divide 16)", fn, cpg);
+  dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
+  norm_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(stats_part_d, tiles, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
+                                                              cpg, out_d, out_ld, out_off);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_tensor_stats_tiles(int64_t voxels) { return (int)cdiv64(voxels, 256); }
+
+extern "C" int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, float* stats_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_tensor_stats";
+  BPX_CHECK(x.ptr && stats_part_d, "%s: null pointer", fn);
+  int tiles = (int)cdiv64(voxels, 256);
+  dim3 grid((unsigned)tiles, (unsigned)N);
+  if (dtype == BPX_BF16) tensor_stats_kernel<uint16_t><<<grid, 64, 0, (hipStream_t)stream>>>((const uint16_t*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
+  else if (dtype == BPX_F32) tensor_stats_kernel<float><<<grid, 64, 0, (hipStream_t)stream>>>((const float*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
+                                     const float* gamma_d, float* dgamma_d, float* dbeta_d, bpx_nbwd_coef* coef_d, bpx_stream_t stream) {
+  const char* fn = "bpx_norm_bwd_finalize";
+  BPX_CHECK(red_part_d && rec_d && coef_d, "%s: null pointer", fn);
+  dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
+  norm_bwd_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, C, 1.0 / (double)count_per_channel, rec_d, gamma_d,
+                                                                  dgamma_d, dbeta_d, coef_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+static int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16); }
+
+extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
+                                  bpx_tensor addend, bpx_tensor dx, bpx_stream_t stream) {
+  const char* fn = "bpx_norm_bwd_apply";
+  BPX_CHECK(g.ptr && t.ptr && dx.ptr && coef_d, "%s: null pointer", fn);
+  BPX_CHECK(g.C == t.C && g.C == dx.C && g.C % 16 == 0, "%s: channel mismatch", fn);
+  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * voxels * (g.C / kpl);
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    norm_bwd_apply_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)g.ptr, g.ld, (const uint16_t*)t.ptr, t.ld, coef_d,
+                                                                    (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, g.C, voxels, N);
+  else if (dtype == BPX_F32)
+    norm_bwd_apply_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)g.ptr, g.ld, (const float*)t.ptr, t.ld, coef_d,
+                                                                 (const float*)addend.ptr, addend.ld, (float*)dx.ptr, dx.ld, g.C, voxels, N);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+static int pool_block(int C, int kpl) { int G = C / kpl; return (256 / G) * G; }
+
+extern "C" int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int C) {
+  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int bd = pool_block(C, kpl);
+  int64_t items = (int64_t)(D / 2) * (H / 2) * (W / 2) * (C / kpl);
+  return (int)cdiv64(items, (int64_t)bd * POOL_IPT);
+}
+
+extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor y, float* stats_part_d,
+                                 bpx_stream_t stream) {
+  const char* fn = "bpx_maxpool3d_fwd";
+  BPX_CHECK(x.ptr && y.ptr, "%s: null pointer", fn);
+  BPX_CHECK(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "%s: extents must be even (got %d,%d,%d)", fn, D, H, W);
+  BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
+  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int bd = pool_block(x.C, kpl);
+  int tiles = bpx_maxpool3d_stats_tiles(dtype, D, H, W, x.C);
+  dim3 grid((unsigned)tiles, (unsigned)N);
+  size_t shm = (size_t)bd * 2 * kpl * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    maxpool_fwd_kernel<uint16_t><<<grid, bd, shm, s>>>((const uint16_t*)x.ptr, x.ld, (uint16_t*)y.ptr, y.ld, x.C, D, H, W, tiles, stats_part_d);
+  else if (dtype == BPX_F32)
+    maxpool_fwd_kernel<float><<<grid, bd, shm, s>>>((const float*)x.ptr, x.ld, (float*)y.ptr, y.ld, x.C, D, H, W, tiles, stats_part_d);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy, bpx_tensor addend, bpx_tensor dx,
+                                 bpx_stream_t stream) {
+  const char* fn = "bpx_maxpool3d_bwd";
+  BPX_CHECK(x.ptr && dy.ptr && dx.ptr, "%s: null pointer", fn);
+  BPX_CHECK(x.C == dy.C && x.C == dx.C && x.C % 16 == 0, "%s: channel mismatch", fn);
+  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (x.C / kpl);
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    maxpool_bwd_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, (const uint16_t*)dy.ptr, dy.ld,
+                                                                 (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, N);
+  else if (dtype == BPX_F32)
+    maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)x.ptr, x.ld, (const float*)dy.ptr, dy.ld, (const float*)addend.ptr,
+                                                              addend.ld, (float*)dx.ptr, dx.ld, x.C, D, H, W, N);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_head_fwd(int dtype, int64_t vps, int N, bpx_tensor x, const float* w_d, const float* b_d, int Cout, int head_act,
+                            float* out_d, int64_t sn, int64_t sc, bpx_stream_t stream) {
+  const char* fn = "bpx_head_fwd";
+  BPX_CHECK(x.ptr && w_d && out_d, "%s: null pointer", fn);
+  BPX_CHECK(Cout >= 1 && Cout <= 4, "%s: Cout must be 1..4 (got %d)", fn, Cout);
+  BPX_CHECK(x.C == 16 || x.C == 32, "%s: Cin must be 16 or 32 (got %d)", fn, x.C);
+  int64_t total = (int64_t)N * vps;
+  hipStream_t s = (hipStream_t)stream;
+#define HL(T, CIN) head_fwd_kernel<T, CIN><<<grid_for(total), 256, 0, s>>>((const T*)x.ptr, x.ld, w_d, b_d, Cout, head_act, out_d, sn, sc, vps, N)
+  if (dtype == BPX_BF16) { if (x.C == 16) HL(uint16_t, 16); else HL(uint16_t, 32); }
+  else if (dtype == BPX_F32) { if (x.C == 16) HL(float, 16); else HL(float, 32); }
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+#undef HL
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_head_bwd(int dtype, int64_t vps, int N, bpx_tensor x, const float* w_d, int Cout, const float* dout_d, int64_t sn,
+                            int64_t sc, bpx_tensor dx, float* dw_d, float* db_d, bpx_stream_t stream) {
+  const char* fn = "bpx_head_bwd";
+  BPX_CHECK(x.ptr && w_d && dout_d && dx.ptr && dw_d, "%s: null pointer", fn);
+  BPX_CHECK(Cout >= 1 && Cout <= 4, "%s: Cout must be 1..4 (got %d)", fn, Cout);
+  BPX_CHECK(x.C == 16 || x.C == 32, "%s: Cin must be 16 or 32 (got %d)", fn, x.C);
+  int64_t total = (int64_t)N * vps;
+  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 1024);
+  hipStream_t s = (hipStream_t)stream;
+#define HL(T, CIN) head_bwd_kernel<T, CIN><<<blocks, 256, 0, s>>>((const T*)x.ptr, x.ld, w_d, Cout, dout_d, sn, sc, (T*)dx.ptr, dx.ld, dw_d, db_d, vps, N)
+  if (dtype == BPX_BF16) { if (x.C == 16) HL(uint16_t, 16); else HL(uint16_t, 32); }
+  else if (dtype == BPX_F32) { if (x.C == 16) HL(float, 16); else HL(float, 32); }
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+#undef HL
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_conv3d_c1_stats_tiles(int D, int H, int W) { return (int)cdiv64((int64_t)D * H * W, 256); }
+
+extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d, const float* bias_d,
+                                 bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_c1_fwd";
+  BPX_CHECK(img_d && w_d && y.ptr, "%s: null pointer", fn);
+  BPX_CHECK(y.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
+  int tiles = bpx_conv3d_c1_stats_tiles(D, H, W);
+  dim3 grid((unsigned)tiles, (unsigned)(y.C / 16), (unsigned)N);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tiles, stats_part_d);
+  else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tiles, stats_part_d);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy, float* dw_d, float* db_d,
+                                   bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_c1_wgrad";
+  BPX_CHECK(img_d && dy.ptr && dw_d, "%s: null pointer", fn);
+  BPX_CHECK(dy.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
+  int totalTiles = N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 8);
+  dim3 grid((unsigned)std::min(totalTiles, 1024), (unsigned)(dy.C / 16));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
+  else if (dtype == BPX_F32) conv_c1_wgrad_kernel<float><<<grid, 256, 0, s>>>(img_d, (const float*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int64_t bpx_packed_weight_elems(int mode, int Cin, int Cout, int dtype) { return packed_elems(mode, Cin, Cout, dtype); }
+
+extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, int dtype, void* packed_d, bpx_stream_t stream) {
+  const char* fn = "bpx_pack_weight";
+  BPX_CHECK(w_d && packed_d, "%s: null pointer", fn);
+  BPX_CHECK(mode >= PK_K3 && mode <= PK_CT_T, "%s: bad mode %d", fn, mode);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  if (mode <= PK_K1) BPX_CHECK(Cin % 16 == 0 && Cout % 16 == 0, "%s: Cin/Cout must be multiples of 16", fn);
+  if (mode == PK_K3_T) BPX_CHECK(Cout % 16 == 0, "%s: Cout must be a multiple of 16", fn);
+  int64_t total = packed_elems(mode, Cin, Cout, dtype);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16) pack_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>(w_d, (uint16_t*)packed_d, mode, Cin, Cout, total);
+  else pack_kernel<float><<<grid_for(total), 256, 0, s>>>(w_d, (float*)packed_d, mode, Cin, Cout, total);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64_t n, bpx_stream_t stream) {
+  const char* fn = "bpx_cast";
+  BPX_CHECK(src_d && dst_d, "%s: null pointer", fn);
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == BPX_F32 && dst_dtype == BPX_BF16) cast_kernel<float, uint16_t><<<grid_for(n), 256, 0, s>>>((const float*)src_d, (uint16_t*)dst_d, n);
+  else if (src_dtype == BPX_BF16 && dst_dtype == BPX_F32) cast_kernel<uint16_t, float><<<grid_for(n), 256, 0, s>>>((const uint16_t*)src_d, (float*)dst_d, n);
+  else BPX_FAIL("%s: unsupported conversion %d -> %d", fn, src_dtype, dst_dtype);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}

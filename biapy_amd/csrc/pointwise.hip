@@ -1,0 +1,257 @@
+// Voxel-wise GEMMs on the matrix cores: Conv3d k=1, ConvTranspose3d k=s=2 (forward and dgrad).
+//
+// All three are D[col][v] = sum_k Wp[col][k] * A[k][v] with no spatial reuse, so the activation
+// operand goes straight from global memory to the MFMA "B" registers (each element is read exactly
+// once from HBM; LDS would be a pure round trip) and the weights come from the dense packed layout
+// [kgroup q][cols][KPL] through L1/L2.  What differs is only how a voxel index maps to addresses:
+//   PW_CONV1  : A = x[v], store y[v]                       (+ bias, + IN-backward affine, + addend)
+//   PW_CONVT  : A = x[v], column block -> (sub-position, co), scatter to y[2v+sub]   (+ bias, stats)
+//   PW_CONVTD : A gathered from dy[2v+sub] over the 8 sub-positions (K = 8*Cout), store dx[v]
+#include <type_traits>
+
+#include "bpx_common.h"
+
+namespace {
+
+enum { PW_CONV1 = 0, PW_CONVT = 1, PW_CONVTD = 2 };
+
+struct PwParams {
+  int N, D, H, W;        // voxel grid of v (the low-res grid for the transposed conv)
+  int64_t vps;           // voxels per sample = D*H*W
+  const void* x; int x_ld; int K;          // K = reduction length in channels (8*Cout for CONVTD)
+  int Csub;              // CONVT: Cout (columns per sub-position); CONVTD: channels per sub-position of dy
+  const void* wp; const float* bias;
+  void* y; int y_ld; int Ncols;            // Ncols = total columns (8*Cout for CONVT)
+  // CONV1 extras
+  const void* g; int g_ld; const void* t; int t_ld; const bpx_nbwd_coef* coef;
+  const void* addend; int addend_ld;
+  float* part; int mblocks;                // CONVT stats: [N][mblocks*8][2][Csub]
+};
+
+template <typename T, int MS, int NS, int MODE>
+__global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
+  using Tr = ElemTraits<T>;
+  constexpr int KPL = Tr::KPL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int nbk = p.Ncols / (16 * NS);
+  const int nb = blockIdx.x % nbk;
+  const int mb = (blockIdx.x / nbk) % p.mblocks;
+  const int n = blockIdx.x / (nbk * p.mblocks);
+  const int col_base = nb * 16 * NS;
+
+  // voxel of lane (j) for each m-subtile
+  int64_t v[MS];
+  bool valid[MS];
+  size_t abase[MS];  // element offset of the voxel's channel 0 in x (CONV1/CONVT) or of sub-position 0 in dy (CONVTD)
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    v[ms] = ((int64_t)mb * 4 + wave) * (MS * 16) + ms * 16 + j;
+    valid[ms] = v[ms] < p.vps;
+    int64_t vv = valid[ms] ? v[ms] : 0;
+    if (MODE == PW_CONVTD) {
+      int xw = (int)(vv % p.W), yh = (int)((vv / p.W) % p.H), zd = (int)(vv / ((int64_t)p.W * p.H));
+      abase[ms] = ((((size_t)n * 2 * p.D + 2 * zd) * 2 * p.H + 2 * yh) * 2 * p.W + 2 * xw) * (size_t)p.x_ld;
+    } else {
+      abase[ms] = ((size_t)n * p.vps + vv) * (size_t)p.x_ld;
+    }
+  }
+
+  f32x4_t acc[MS][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+  const int ksteps = (p.K / KPL + 3) / 4;
+  for (int s = 0; s < ksteps; ++s) {
+    const int k = (4 * s + g) * KPL;  // first reduction channel of this lane's operand
+    const bool kin = k < p.K;
+    u32x4_t wf[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+      wf[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)(4 * s + g) * p.Ncols + col_base + ns * 16 + j) * KPL);
+    size_t koff;
+    if (MODE == PW_CONVTD) {
+      int sub = kin ? k / p.Csub : 0, c = kin ? k % p.Csub : 0;
+      int a = (sub >> 2) & 1, b = (sub >> 1) & 1, cc = sub & 1;
+      koff = (((size_t)a * 2 * p.H + b) * 2 * p.W + cc) * (size_t)p.x_ld + c;
+    } else {
+      koff = kin ? k : 0;
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      u32x4_t af = u32x4_t{0u, 0u, 0u, 0u};
+      if (kin && valid[ms]) af = *reinterpret_cast<const u32x4_t*>(xin + abase[ms] + koff);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
+    }
+  }
+
+  // ---- epilogue: lane holds columns col_base + ns*16 + 4g + r of voxel j ----------------------
+  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  float s1[NS][4], s2[NS][4];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
+
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int col = col_base + ns * 16 + g * 4;
+    int sub = 0, co = col;
+    if (MODE == PW_CONVT) { sub = col / p.Csub; co = col % p.Csub; }
+    float add[4] = {0.f, 0.f, 0.f, 0.f};
+    bpx_nbwd_coef cf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (p.bias) add[r] = p.bias[co + r];
+      if (MODE == PW_CONV1 && p.coef) cf[r] = p.coef[(size_t)n * p.Ncols + co + r];
+    }
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      if (!valid[ms]) continue;
+      size_t ovox;
+      if (MODE == PW_CONVT) {
+        int xw = (int)(v[ms] % p.W), yh = (int)((v[ms] / p.W) % p.H), zd = (int)(v[ms] / ((int64_t)p.W * p.H));
+        int a = (sub >> 2) & 1, b = (sub >> 1) & 1, cc = sub & 1;
+        ovox = (((size_t)n * 2 * p.D + 2 * zd + a) * 2 * p.H + 2 * yh + b) * 2 * p.W + 2 * xw + cc;
+      } else {
+        ovox = (size_t)n * p.vps + v[ms];
+      }
+      float val[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) val[r] = acc[ms][ns][r] + add[r];
+      if (MODE == PW_CONV1) {
+        if (p.coef) {
+          const T* gp = reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co;
+          const T* tp = reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[r] += cf[r].a * Tr::ld(gp + r) + cf[r].b * Tr::ld(tp + r) + cf[r].c0;
+        }
+        if (p.addend) {
+          const T* ap = reinterpret_cast<const T*>(p.addend) + ovox * (size_t)p.addend_ld + co;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[r] += Tr::ld(ap + r);
+        }
+      }
+      if (MODE == PW_CONVT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[ns][r] += val[r]; s2[ns][r] += val[r] * val[r]; }
+      }
+      T* yp = yout + ovox * (size_t)p.y_ld + co;
+      if (std::is_same<T, float>::value) *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{val[0], val[1], val[2], val[3]};
+      else *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+    }
+  }
+
+  if (MODE == PW_CONVT && p.part != nullptr) {
+    __shared__ float red[4 * NS * 16 * 2];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[ns][r], b = s2[ns][r];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (j == 0) {
+          red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 0] = a;
+          red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < NS * 16 * 2) {
+      int c = tid >> 1, k = tid & 1;
+      float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
+                red[(3 * NS * 16 + c) * 2 + k];
+      int col = col_base + c, sub = col / p.Csub, co = col % p.Csub;
+      p.part[((((size_t)n * p.mblocks + mb) * 8 + sub) * 2 + k) * p.Csub + co] = a;
+    }
+  }
+}
+
+constexpr int PW_MS = 2;  // 4 waves x 2 x 16 = 128 voxels per workgroup
+
+inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 : (ncols_per_group % 32 == 0) ? 2 : 1; }
+
+template <typename T, int MODE>
+int launch_pw(PwParams& p, int ns, hipStream_t s) {
+  p.mblocks = (int)cdiv64(p.vps, 64 * PW_MS);
+  int nbk = p.Ncols / (16 * ns);
+  dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
+  if (ns == 4) pw_kernel<T, PW_MS, 4, MODE><<<grid, 256, 0, s>>>(p);
+  else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE><<<grid, 256, 0, s>>>(p);
+  else pw_kernel<T, PW_MS, 1, MODE><<<grid, 256, 0, s>>>(p);
+  return 0;
+}
+
+int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
+  BPX_CHECK(t.ptr != nullptr, "%s: %s.ptr is null", fn, name);
+  BPX_CHECK(t.C % 16 == 0 && t.ld >= t.C, "%s: %s needs C %% 16 == 0 and ld >= C (C=%d ld=%d)", fn, name, t.C, t.ld);
+  BPX_CHECK(((uintptr_t)t.ptr % 16) == 0 && ((size_t)t.ld * es) % 16 == 0, "%s: %s must be 16-byte aligned", fn, name);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS) * 8; }
+
+extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                               bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
+                               bpx_stream_t stream) {
+  const char* fn = "bpx_conv1x1_fwd";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  int es = (int)dtype_size(dtype);
+  if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
+  BPX_CHECK(w_packed_d, "%s: weights null", fn);
+  if (coef_d) { if (chk(fn, "g", g, es) || chk(fn, "t", t, es)) return 1; }
+  PwParams p{};
+  p.N = N; p.D = 1; p.H = 1; p.W = 1; p.vps = vps;
+  p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
+  p.y = y.ptr; p.y_ld = y.ld; p.Ncols = y.C; p.Csub = y.C;
+  p.g = g.ptr; p.g_ld = g.ld; p.t = t.ptr; p.t_ld = t.ld; p.coef = coef_d;
+  p.addend = addend.ptr; p.addend_ld = addend.ld;
+  int ns = pw_ns(y.C);
+  if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream);
+  else launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                                    bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_convT3d_k2s2_fwd";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  int es = (int)dtype_size(dtype);
+  if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
+  BPX_CHECK(w_packed_d, "%s: weights null", fn);
+  PwParams p{};
+  p.N = N; p.D = D; p.H = H; p.W = W; p.vps = (int64_t)D * H * W;
+  p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
+  p.y = y.ptr; p.y_ld = y.ld; p.Ncols = 8 * y.C; p.Csub = y.C; p.part = stats_part_d;
+  int ns = pw_ns(y.C);
+  if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream);
+  else launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor dx,
+                                      bpx_stream_t stream) {
+  const char* fn = "bpx_convT3d_k2s2_dgrad";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  int es = (int)dtype_size(dtype);
+  if (chk(fn, "dy", dy, es) || chk(fn, "dx", dx, es)) return 1;
+  BPX_CHECK(w_packed_T_d, "%s: weights null", fn);
+  PwParams p{};
+  p.N = N; p.D = D; p.H = H; p.W = W; p.vps = (int64_t)D * H * W;
+  p.x = dy.ptr; p.x_ld = dy.ld; p.K = 8 * dy.C; p.Csub = dy.C; p.wp = w_packed_T_d;
+  p.y = dx.ptr; p.y_ld = dx.ld; p.Ncols = dx.C;
+  int ns = pw_ns(dx.C);
+  if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONVTD>(p, ns, (hipStream_t)stream);
+  else launch_pw<float, PW_CONVTD>(p, ns, (hipStream_t)stream);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}

@@ -1,0 +1,183 @@
+// Overlap tiling on device: patch gather (crop) and deterministic blend (merge).
+//
+// Both kernels are HBM-bound scans: every input element is read once, every output
+// element written once, x is the fastest thread index so a wave touches 64 consecutive voxels of one
+// (z,y) row.  The blend is a GATHER in the reference's patch order so that the fp32 sums are
+// bit-identical to NumPy's scatter `merged[sl] += data[c] * w` (data_3D_manipulation.py:838-844)
+// and independent of scheduling - no atomics.
+#include <hip/hip_fp16.h>
+
+#include "bpx_common.h"
+
+struct AxisG {
+  int n, step, last, patch, limit;
+  __device__ __forceinline__ int start(int i) const {
+    int s = i * step;
+    return s - ((s + patch < limit) ? 0 : last);
+  }
+};
+static inline AxisG to_axis(const bpx_axis_grid& g) { return AxisG{g.n, g.step, g.last, g.patch, g.limit}; }
+
+// ------------------------------------------------------------------------------------------------
+// crop
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pad_src(int q, int n, int mode, bool& inside) {
+  // q: coordinate in the un-padded volume, possibly outside [0,n)
+  if (q >= 0 && q < n) return q;
+  if (mode == BPX_PAD_ZEROS) { inside = false; return 0; }
+  return q < 0 ? -q : 2 * (n - 1) - q;  // np.pad(..., "reflect"): mirror without repeating the edge
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256) crop3d_kernel(const E* __restrict__ vol, E* __restrict__ out, int Z, int Y, int X, int C,
+                                                     int pz, int py, int px, int mode, AxisG gz, AxisG gy, AxisG gx,
+                                                     int64_t c_begin, int64_t total) {
+  const int Pz = gz.patch, Py = gy.patch, Px = gx.patch;
+  const int64_t row = (int64_t)Px * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / row;
+    int xc = (int)(i - r * row);
+    int lx = xc / C, ch = xc - lx * C;
+    int ly = (int)(r % Py); r /= Py;
+    int lz = (int)(r % Pz); r /= Pz;
+    int64_t c = c_begin + r;
+    int ix = (int)(c % gx.n); c /= gx.n;
+    int iy = (int)(c % gy.n);
+    int iz = (int)(c / gy.n);
+    bool inside = true;
+    int sz = pad_src(gz.start(iz) + lz - pz, Z, mode, inside);
+    int sy = pad_src(gy.start(iy) + ly - py, Y, mode, inside);
+    int sx = pad_src(gx.start(ix) + lx - px, X, mode, inside);
+    E v = 0;
+    if (inside) v = vol[(((int64_t)sz * Y + sy) * X + sx) * C + ch];
+    out[i] = v;
+  }
+}
+
+extern "C" int bpx_crop3d_gather(const void* vol_d, int elem_size, int Z, int Y, int X, int C, int pad_z, int pad_y, int pad_x,
+                                 int pad_mode, const bpx_axis_grid* g, int64_t c_begin, int64_t c_count, void* out_d,
+                                 bpx_stream_t stream) {
+  BPX_CHECK(vol_d && out_d && g, "bpx_crop3d_gather: null pointer");
+  BPX_CHECK(elem_size == 1 || elem_size == 2 || elem_size == 4, "bpx_crop3d_gather: elem_size %d unsupported", elem_size);
+  BPX_CHECK(pad_mode == BPX_PAD_REFLECT || pad_mode == BPX_PAD_ZEROS, "bpx_crop3d_gather: bad pad_mode %d", pad_mode);
+  BPX_CHECK(pad_z < Z && pad_y < Y && pad_x < X, "bpx_crop3d_gather: padding must be smaller than the volume");
+  int64_t n_all = (int64_t)g[0].n * g[1].n * g[2].n;
+  BPX_CHECK(c_begin >= 0 && c_count >= 0 && c_begin + c_count <= n_all, "bpx_crop3d_gather: patch range out of grid");
+  int64_t total = c_count * g[0].patch * g[1].patch * g[2].patch * C;
+  if (total == 0) return 0;
+  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  AxisG gz = to_axis(g[0]), gy = to_axis(g[1]), gx = to_axis(g[2]);
+  if (elem_size == 4)
+    crop3d_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)vol_d, (uint32_t*)out_d, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total);
+  else if (elem_size == 2)
+    crop3d_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)vol_d, (uint16_t*)out_d, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total);
+  else
+    crop3d_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)vol_d, (uint8_t*)out_d, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total);
+  BPX_LAUNCH_CHECK("bpx_crop3d_gather");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge
+// ------------------------------------------------------------------------------------------------
+template <typename E> __device__ __forceinline__ float load_as_f32(const E* p);
+template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_as_f32<uint8_t>(const uint8_t* p) { return (float)*p; }
+template <> __device__ __forceinline__ float load_as_f32<__half>(const __half* p) { return __half2float(*p); }
+
+template <typename E> __device__ __forceinline__ void store_from_f32(E* p, float v);
+template <> __device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_from_f32<uint8_t>(uint8_t* p, float v) { *p = (uint8_t)(int)v; }  // astype: truncate
+template <> __device__ __forceinline__ void store_from_f32<__half>(__half* p, float v) { *p = __float2half_rn(v); }
+
+__device__ __forceinline__ void cover_range(const AxisG& g, int q, int& lo, int& hi) {
+  // patches i with start(i) <= q < start(i)+patch lie in [lo,hi]; start(i) in [i*step-last, i*step]
+  int t = q - g.patch;
+  lo = t < 0 ? 0 : t / g.step + 1;
+  hi = (q + g.last) / g.step;
+  if (hi > g.n - 1) hi = g.n - 1;
+}
+
+template <typename EI, typename EO>
+__global__ void __launch_bounds__(256) merge3d_kernel(const EI* __restrict__ patches, int Pzf, int Pyf, int Pxf, int C, int pz, int py,
+                                                      int px, AxisG gz, AxisG gy, AxisG gx, const float* __restrict__ wz,
+                                                      const float* __restrict__ wy, const float* __restrict__ wx, int Y, int X,
+                                                      int z_lo, int z_hi, int zrow_lo, int zrow_hi, float* acc, float* wacc,
+                                                      int flags, EO* __restrict__ out) {
+  const int64_t row = (int64_t)X * C;
+  const int64_t total = (int64_t)(z_hi - z_lo) * Y * row;
+  const int64_t pstride_y = (int64_t)Pxf * C, pstride_z = pstride_y * Pyf, pstride_c = pstride_z * Pzf;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / row;
+    int xc = (int)(i - r * row);
+    int x = xc / C, ch = xc - x * C;
+    int y = (int)(r % Y);
+    int z = (int)(r / Y) + z_lo;
+    float num = 0.f, ws = 0.f;
+    if (flags & 2) { num = acc[i]; ws = wacc[i / C]; }
+    int zl, zh, yl, yh, xl, xh;
+    cover_range(gz, z, zl, zh);
+    cover_range(gy, y, yl, yh);
+    cover_range(gx, x, xl, xh);
+    if (zl < zrow_lo) zl = zrow_lo;
+    if (zh > zrow_hi - 1) zh = zrow_hi - 1;
+    for (int iz = zl; iz <= zh; ++iz) {
+      int lz = z - gz.start(iz);
+      if (lz < 0 || lz >= gz.patch) continue;
+      float wzv = wz[lz];
+      for (int iy = yl; iy <= yh; ++iy) {
+        int ly = y - gy.start(iy);
+        if (ly < 0 || ly >= gy.patch) continue;
+        float wzy = __fmul_rn(wzv, wy[ly]);
+        const EI* pbase = patches + ((int64_t)(iz - zrow_lo) * gy.n + iy) * gx.n * pstride_c + (int64_t)(lz + pz) * pstride_z +
+                          (int64_t)(ly + py) * pstride_y + ch;
+        for (int ix = xl; ix <= xh; ++ix) {
+          int lx = x - gx.start(ix);
+          if (lx < 0 || lx >= gx.patch) continue;
+          float w = __fmul_rn(wzy, wx[lx]);
+          float v = load_as_f32<EI>(pbase + (int64_t)ix * pstride_c + (int64_t)(lx + px) * C);
+          num = __fadd_rn(num, __fmul_rn(v, w));
+          ws = __fadd_rn(ws, w);
+        }
+      }
+    }
+    if (flags & 1) {
+      acc[i] = num;
+      if (ch == 0) wacc[i / C] = ws;
+    } else {
+      store_from_f32<EO>(out + i, __fdiv_rn(num, __fadd_rn(ws, 1e-18f)));
+    }
+  }
+}
+
+extern "C" int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int Py, int Px, int C, int pad_z, int pad_y, int pad_x,
+                                 const bpx_axis_grid* g, const float* wz_d, const float* wy_d, const float* wx_d, int Z, int Y, int X,
+                                 int z_lo, int z_hi, int zrow_lo, int zrow_hi, float* acc_d, float* wacc_d, int flags,
+                                 void* out_d, int out_dtype, bpx_stream_t stream) {
+  BPX_CHECK(patches_d && g && wz_d && wy_d && wx_d, "bpx_merge3d_blend: null pointer");
+  BPX_CHECK(0 <= z_lo && z_lo <= z_hi && z_hi <= Z, "bpx_merge3d_blend: bad z range [%d,%d) for Z=%d", z_lo, z_hi, Z);
+  BPX_CHECK(0 <= zrow_lo && zrow_lo <= zrow_hi && zrow_hi <= g[0].n, "bpx_merge3d_blend: bad patch-row range");
+  BPX_CHECK(g[0].patch == Pz - 2 * pad_z && g[1].patch == Py - 2 * pad_y && g[2].patch == Px - 2 * pad_x,
+            "bpx_merge3d_blend: grid patch extent must equal the padding-stripped patch");
+  BPX_CHECK(g[0].limit == Z && g[1].limit == Y && g[2].limit == X, "bpx_merge3d_blend: grid limit must equal the volume extent");
+  BPX_CHECK(!(flags & 3) || (acc_d && wacc_d), "bpx_merge3d_blend: acc/wacc required for partial/seeded blends");
+  BPX_CHECK((flags & 1) || out_d, "bpx_merge3d_blend: out_d is null");
+  int64_t total = (int64_t)(z_hi - z_lo) * Y * X * C;
+  if (total == 0) return 0;
+  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  AxisG gz = to_axis(g[0]), gy = to_axis(g[1]), gx = to_axis(g[2]);
+#define MERGE_LAUNCH(EI, EO)                                                                                                   \
+  merge3d_kernel<EI, EO><<<blocks, 256, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, \
+                                                wx_d, Y, X, z_lo, z_hi, zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d)
+  if (dtype == BPX_F32 && out_dtype == BPX_F32) MERGE_LAUNCH(float, float);
+  else if (dtype == BPX_U8 && out_dtype == BPX_U8) MERGE_LAUNCH(uint8_t, uint8_t);
+  else if (dtype == BPX_F16 && out_dtype == BPX_F16) MERGE_LAUNCH(__half, __half);
+  else if (dtype == BPX_F16 && out_dtype == BPX_F32) MERGE_LAUNCH(__half, float);
+  else if (dtype == BPX_U8 && out_dtype == BPX_F32) MERGE_LAUNCH(uint8_t, float);
+  else BPX_FAIL("bpx_merge3d_blend: unsupported dtype combination in=%d out=%d", dtype, out_dtype);
+#undef MERGE_LAUNCH
+  BPX_LAUNCH_CHECK("bpx_merge3d_blend");
+  return 0;
+}

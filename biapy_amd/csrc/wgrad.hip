@@ -1,0 +1,315 @@
+// Weight gradients as a reduction-over-voxels GEMM on the matrix cores.
+//
+//   dW[i = ci][j = co] (per tap) = sum_{v} A[v (+tap)][ci] * G[v][co]
+//
+// Both operands are stored channel-contiguous ([voxel][channel]) but the MFMA wants the REDUCTION
+// index (voxels) contiguous per lane, i.e. both operands transposed.  bf16: the gfx950 LDS
+// transpose read (ds_read_b64_tr_b16: a 16-lane group reads a [4 voxel][16 channel] block and lane
+// i receives channel i of the 4 voxels) delivers exactly that with no shuffles and, because its
+// alignment requirement is along the CHANNEL axis, works unchanged for the +-1 voxel tap shifts.
+// f32: v_mfma_f32_16x16x4_f32 takes one scalar per lane, a plain ds_read_b32 gather.
+//
+//   block   : 256 threads, one (tile-group, 16-channel ci chunk, 16*NS co block).  The activation
+//             halo (normalisation + activation applied while staging, exactly as in the forward
+//             kernel) and the matching dy tile are staged in LDS once per tile and reused by all 27 taps.
+//   waves   : TAPS=27 -> wave w owns taps {w, w+4, ...} (<= 7 accumulators x NS);
+//             TAPS=1  -> wave w owns K-chunks {w, w+4, ...} of the tile.
+//   output  : fp32 atomicAdd into the PyTorch-layout gradient after the block has walked all of its
+//             tiles (one flush per block, not per tile); bias gradient from the ci-chunk-0 blocks.
+#include <type_traits>
+
+#include "bpx_common.h"
+
+namespace {
+
+struct WgradParams {
+  int N, D, H, W;          // logical voxel grid of the reduction
+  const void* x; int x_ld; int Cin; const bpx_norm_rec* in_norm; int act;
+  const void* dy; int dy_ld; int Cout; int dy_vs; int dy_oz, dy_oy, dy_ox;  // dy voxel = vs*v + off (ConvTranspose)
+  float* dw; int64_t si, sj, st; int64_t off;   // dW index = i*si + j*sj + tap*st + off
+  float* db;
+  int tilesY, tilesX, tilesPerSample, totalTiles, groups;
+};
+
+template <typename T> __device__ __forceinline__ float act_rt(float u, int act) {
+  constexpr bool PRECISE = std::is_same<T, float>::value;
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
+    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
+    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
+    default: return u;
+  }
+}
+
+// Stage EZ*EY*EX voxels x NCH channels (NCH multiple of 16/GPT pieces) into LDS [voxel][NCH].
+// Source voxel = vs*(o+h)+a; voxels whose LOGICAL coordinate (o+h) is outside [0,D)x[0,H)x[0,W) are zero.
+template <typename T, int EZ, int EY, int EX, int NCH>
+__device__ __forceinline__ void stage_any(unsigned char* smem, const T* __restrict__ src, int ld, int c0, int n, int D, int H, int W,
+                                          int oz, int oy, int ox, int vs, int az, int ay, int ax,
+                                          const bpx_norm_rec* __restrict__ norm, int C_norm, int act, int tid) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  constexpr int PPV = NCH / KPL;  // 16-byte pieces per voxel
+  constexpr int PIECES = EZ * EY * EX * PPV;
+  constexpr int VB = NCH * (int)sizeof(T);
+  static_assert(256 % PPV == 0, "piece index must be thread-invariant");
+  const int sub = tid % PPV;
+  float sc[KPL], sh[KPL];
+  if (norm) {
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      bpx_norm_rec r = norm[(size_t)n * C_norm + c0 + sub * KPL + e];
+      sc[e] = r.scale; sh[e] = r.shift;
+    }
+  }
+  const T* sbase = src + c0 + sub * KPL;
+  const int Dp = D * vs, Hp = H * vs, Wp = W * vs;
+  constexpr int UNR = 4;
+  for (int base = 0; base < PIECES; base += 256 * UNR) {
+    u32x4_t buf[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      int idx = base + u * 256 + tid;
+      ok[u] = false;
+      buf[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (idx < PIECES) {
+        int hv = idx / PPV;
+        int hx = hv % EX, hy = (hv / EX) % EY, hz = hv / (EX * EY);
+        int gz = oz + hz, gy = oy + hy, gx = ox + hx;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          ok[u] = true;
+          size_t vox = (((size_t)n * Dp + (gz * vs + az)) * Hp + (gy * vs + ay)) * Wp + (gx * vs + ax);
+          buf[u] = *reinterpret_cast<const u32x4_t*>(sbase + vox * (size_t)ld);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      int idx = base + u * 256 + tid;
+      if (idx < PIECES) {
+        u32x4_t v = buf[u];
+        if (norm && ok[u]) {
+          float f[KPL];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) f[e] = act_rt<T>(fmaf(sc[e], f[e], sh[e]), act);
+          v = pack16<T>(f);
+        }
+        *reinterpret_cast<u32x4_t*>(smem + (size_t)(idx / PPV) * VB + sub * 16) = v;
+      }
+    }
+  }
+}
+
+// bf16 transposed fragment: 8 voxels (k) of channel (lane&15), voxels at `vox_byte` + {0..7}*VB.
+// Lane supplies the address of ITS 8-byte piece of the [4 voxel][16 ch] block: voxel (lane&15)/4,
+// channels ((lane&15)%4)*4..+3; the hardware hands lane i column i.
+template <int VB, bool USE_TR>
+__device__ __forceinline__ u32x4_t frag_T_bf16(const unsigned char* smem, int vox_byte, int ch_byte, int i) {
+  u32x4_t out;
+  if (USE_TR) {
+    const unsigned char* p = smem + vox_byte + (i >> 2) * VB + ch_byte + (i & 3) * 8;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * VB));
+    u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+    out[0] = l2[0]; out[1] = l2[1]; out[2] = h2[0]; out[3] = h2[1];
+  } else {
+    const unsigned char* p = smem + vox_byte + ch_byte + i * 2;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint16_t*>(p + k * VB);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = v[2 * k] | (v[2 * k + 1] << 16);
+  }
+  return out;
+}
+
+template <typename T, int TZ, int TY, int TX, int NS, int TAPS, bool USE_TR>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+  using Tr = ElemTraits<T>;
+  constexpr bool BF = std::is_same<T, uint16_t>::value;
+  constexpr int HALO = (TAPS == 27) ? 1 : 0;
+  constexpr int HZ = TZ + 2 * HALO, HY = TY + 2 * HALO, HX = TX + 2 * HALO, HV = HZ * HY * HX;
+  constexpr int VBA = 16 * (int)sizeof(T);        // activation tile: 16 channels per voxel
+  constexpr int CB = 16 * NS;                     // dy tile: CB channels per voxel
+  constexpr int VBG = CB * (int)sizeof(T);
+  constexpr int TV = TZ * TY * TX;
+  constexpr int KC = BF ? 32 : 4;                 // voxels per MFMA step
+  constexpr int NKC = TV / KC;
+  constexpr int NT = (TAPS == 27) ? 7 : 1;        // accumulator sets per wave
+  static_assert(TX % 8 == 0, "a lane's 8-voxel run must stay inside one x row");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HV * VBA + TV * VBG + 4 * CB * 4];
+  unsigned char* sA = smem;
+  unsigned char* sG = smem + HV * VBA;
+  float* sB = reinterpret_cast<float*>(smem + HV * VBA + TV * VBG);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x, chunk = blockIdx.y, co_base = blockIdx.z * CB;
+
+  f32x4_t acc[NT][NS];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[a][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gin = reinterpret_cast<const T*>(p.dy);
+
+  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
+    const int n = tt / p.tilesPerSample, tile = tt % p.tilesPerSample;
+    const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    __syncthreads();
+    stage_any<T, HZ, HY, HX, 16>(sA, xin, p.x_ld, chunk * 16, n, p.D, p.H, p.W, z0 - HALO, y0 - HALO, x0 - HALO, 1, 0, 0, 0,
+                                 p.in_norm, p.Cin, p.act, tid);
+    stage_any<T, TZ, TY, TX, CB>(sG, gin, p.dy_ld, co_base, n, p.D, p.H, p.W, z0, y0, x0, p.dy_vs, p.dy_oz, p.dy_oy, p.dy_ox,
+                                 nullptr, 0, 0, tid);
+    __syncthreads();
+
+    if (p.db != nullptr && chunk == 0) {  // bias gradient: column sums of the dy tile
+      const int c = tid % CB;
+      for (int v = tid / CB; v < TV; v += 256 / CB) bsum += Tr::ld(reinterpret_cast<const T*>(sG + (size_t)v * VBG) + c);
+    }
+
+    for (int kc = (TAPS == 27 ? 0 : wave); kc < NKC; kc += (TAPS == 27 ? 1 : 4)) {
+      // voxel run of this lane inside the tile
+      int t0 = kc * KC + (BF ? g * 8 : g);
+      int tz = t0 / (TY * TX), ty = (t0 / TX) % TY, tx = t0 % TX;
+      u32x4_t gf[NS];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        if (BF) gf[ns] = frag_T_bf16<VBG, USE_TR>(sG, t0 * VBG, ns * 32, i);
+        else gf[ns][0] = *reinterpret_cast<const uint32_t*>(sG + (size_t)t0 * VBG + (ns * 16 + i) * 4);
+      }
+      const int hbase = ((tz * HY + ty) * HX + tx) * VBA;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        int tap = (TAPS == 27) ? (wave + 4 * a) : 0;
+        if (TAPS == 27 && tap >= 27) continue;
+        int toff = (TAPS == 27) ? ((((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VBA) : 0;
+        u32x4_t af;
+        if (BF) af = frag_T_bf16<VBA, USE_TR>(sA, hbase + toff, 0, i);
+        else af[0] = *reinterpret_cast<const uint32_t*>(sA + hbase + toff + i * 4);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          if (BF) acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[ns]), acc[a][ns], 0, 0, 0);
+          else acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[0]), __uint_as_float(gf[ns][0]), acc[a][ns], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // flush: lane holds D[ci = 4g+r][co = i]
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    int tap = (TAPS == 27) ? (wave + 4 * a) : 0;
+    if (TAPS == 27 && tap >= 27) continue;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = chunk * 16 + 4 * g + r, co = co_base + ns * 16 + i;
+        atomicAdd(p.dw + ci * p.si + co * p.sj + tap * p.st + p.off, acc[a][ns][r]);
+      }
+  }
+  if (p.db != nullptr && chunk == 0) {
+    __syncthreads();
+    // reduce the 256/CB partial sums per channel through LDS
+    float* red = reinterpret_cast<float*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < CB) {
+      float s = 0.f;
+      for (int k = tid; k < 256; k += CB) s += red[k];
+      atomicAdd(p.db + co_base + tid, s);
+    }
+  }
+  (void)sB;
+}
+
+struct WCfg { int tz, ty, tx, ns; };
+inline WCfg pick_wcfg(int D, int H, int W, int Cout) {
+  WCfg c;
+  c.ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
+  c.tz = 4; c.ty = 4;
+  c.tx = (W > 8) ? 16 : 8;
+  return c;
+}
+
+template <typename T, int TAPS>
+int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t s) {
+  WgradParams p = p0;
+  int tilesZ = cdiv(p.D, c.tz);
+  p.tilesY = cdiv(p.H, c.ty);
+  p.tilesX = cdiv(p.W, c.tx);
+  p.tilesPerSample = tilesZ * p.tilesY * p.tilesX;
+  p.totalTiles = p.N * p.tilesPerSample;
+  int nchunks = p.Cin / 16, nb = p.Cout / (16 * c.ns);
+  int groups = std::max(1, std::min(p.totalTiles, 1024 / std::max(1, nchunks * nb)));
+  p.groups = groups;
+  dim3 grid((unsigned)groups, (unsigned)nchunks, (unsigned)nb);
+#define L(TX, NS)                                                                                   \
+  if (c.tx == TX && c.ns == NS) {                                                                   \
+    if (use_tr) wgrad_kernel<T, 4, 4, TX, NS, TAPS, true><<<grid, 256, 0, s>>>(p);                   \
+    else wgrad_kernel<T, 4, 4, TX, NS, TAPS, false><<<grid, 256, 0, s>>>(p);                         \
+    return 0;                                                                                       \
+  }
+  L(16, 1) L(16, 2) L(16, 4) L(8, 1) L(8, 2) L(8, 4)
+#undef L
+  return 1;
+}
+
+int g_use_tr = 1;
+
+int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, hipStream_t s) {
+  WCfg c = pick_wcfg(p.D, p.H, p.W, p.Cout);
+  int rc;
+  if (dtype == BPX_BF16) rc = (taps == 27) ? launch_wgrad<uint16_t, 27>(p, c, g_use_tr != 0, s) : launch_wgrad<uint16_t, 1>(p, c, g_use_tr != 0, s);
+  else rc = (taps == 27) ? launch_wgrad<float, 27>(p, c, false, s) : launch_wgrad<float, 1>(p, c, false, s);
+  BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+}  // namespace
+
+// test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 in the bf16 wgrad
+extern "C" int bpx_debug_set_wgrad_tr(int use_tr) { g_use_tr = use_tr; return 0; }
+
+extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                                bpx_tensor dy, int k, float* dw_d, float* db_d, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_wgrad";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(k == 1 || k == 3, "%s: k must be 1 or 3", fn);
+  BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
+  WgradParams p{};
+  p.N = N; p.D = D; p.H = H; p.W = W;
+  p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = in_norm_d; p.act = act;
+  p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 1;
+  int taps = k * k * k;
+  p.dw = dw_d; p.si = taps; p.sj = (int64_t)x.C * taps; p.st = 1; p.off = 0;  // (Cout,Cin,k,k,k)
+  p.db = db_d;
+  return run_wgrad(fn, dtype, p, taps, (hipStream_t)stream);
+}
+
+extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy, float* dw_d, float* db_d,
+                                      bpx_stream_t stream) {
+  const char* fn = "bpx_convT3d_k2s2_wgrad";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
+  for (int sub = 0; sub < 8; ++sub) {
+    WgradParams p{};
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = nullptr; p.act = 0;
+    p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 2;
+    p.dy_oz = (sub >> 2) & 1; p.dy_oy = (sub >> 1) & 1; p.dy_ox = sub & 1;
+    p.dw = dw_d; p.si = (int64_t)dy.C * 8; p.sj = 8; p.st = 0; p.off = sub;  // (Cin,Cout,2,2,2)
+    p.db = db_d;  // every sub contributes its voxels to the bias gradient
+    if (run_wgrad(fn, dtype, p, 1, (hipStream_t)stream)) return 1;
+  }
+  return 0;
+}

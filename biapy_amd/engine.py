@@ -1,0 +1,404 @@
+"""Executor of the 3D residual U-Net on the MI355X kernels (forward, and the hand-written backward).
+
+This is the host side of biapy/models/resunet.py:352-446 (forward graph) and of the autograd graph
+PyTorch would build for it (train_engine.py:173 ``loss.backward()``): it sequences the C-ABI kernels
+of include/biapy_amd.h on the current HIP stream.  No arithmetic happens here and no PyTorch operator
+touches an activation; PyTorch only owns the memory.
+
+Data layout in HBM (all NDHWC, storage dtype T = bf16 or f32):
+  * every raw (pre-normalisation) tensor is written once by its producer and read by its consumers;
+    InstanceNorm+ELU never materialise - the producer emits per-(n,c) partial statistics, a tiny
+    finalize kernel turns them into (mean, rstd, scale, shift) records and the consumer conv applies
+    them while staging its input halo in LDS;
+  * torch.cat([up, skip], 1) (blocks.py:1653) is a layout decision, not a kernel: each level owns one
+    buffer [B,S,S,S,Cup+Cskip]; the transposed conv writes channels [0,Cup), the encoder block writes
+    its output directly into [Cup, Cup+Cskip);
+  * the residual add and the 1x1x1 shortcut conv (blocks.py:1372,1458) are extra K-steps of the
+    block's second 3x3x3 conv kernel.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+lib = L.lib
+EPS = 1e-5
+
+
+@dataclass
+class NetConfig:
+    in_ch: int
+    feature_maps: Sequence[int]
+    out_channels: Sequence[int] = (1,)
+    activation: str = "elu"
+    normalization: str = "in"
+
+    def __post_init__(self):
+        fm = list(self.feature_maps)
+        if self.normalization != "in":
+            raise NotImplementedError(f"normalization={self.normalization!r}: the MI355X engine implements 'in' (the reference default)")
+        if self.activation not in L.ACT:
+            raise NotImplementedError(f"activation={self.activation!r} is not implemented on the MI355X engine")
+        if any(c % 16 for c in fm):
+            raise NotImplementedError(f"feature_maps {fm} must be multiples of 16 (MFMA tile)")
+        if self.in_ch != 1 and self.in_ch % 16:
+            raise NotImplementedError("input channels must be 1 or a multiple of 16")
+        if sum(self.out_channels) > 4 or fm[0] not in (16, 32):
+            raise NotImplementedError("output head supports <= 4 channels from 16 or 32 features")
+        self.depth = len(fm) - 1
+
+
+def block_keys(prefix: str, first: bool) -> Dict[str, str]:
+    """Reference state_dict keys of one ResConvBlock."""
+    i = 0 if first else 2
+    k = {
+        "w1": f"{prefix}.block.{i}.block.0.weight", "b1": f"{prefix}.block.{i}.block.0.bias",
+        "g1": f"{prefix}.block.{i}.block.1.weight", "be1": f"{prefix}.block.{i}.block.1.bias",
+        "w2": f"{prefix}.block.{i + 1}.block.0.weight", "b2": f"{prefix}.block.{i + 1}.block.0.bias",
+        "wsc": f"{prefix}.shortcut.0.weight", "bsc": f"{prefix}.shortcut.0.bias",
+    }
+    if not first:
+        k["g0"] = f"{prefix}.block.0.weight"
+        k["be0"] = f"{prefix}.block.0.bias"
+    return k
+
+
+class _Stats:
+    """Partial-statistics scratch + finalize into a norm-record array."""
+
+    @staticmethod
+    def alloc(B, tiles, C, dev):
+        return torch.empty((B, tiles, 2, C), dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def finalize(part, B, tiles, C, count, gamma, beta, rec, rec_ld, rec_off, st):
+        L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, C, count, gamma.data_ptr(), beta.data_ptr(), EPS, C,
+                                      rec.data_ptr(), rec_ld, rec_off, st))
+
+
+def _recs(B, C, dev):
+    return torch.empty((B, C, 4), dtype=torch.float32, device=dev)
+
+
+@dataclass
+class _Blk:
+    """Everything the backward needs about one residual block."""
+    keys: Dict[str, str]
+    first: bool
+    S: Tuple[int, int, int]
+    cin: int
+    cout: int
+    x: Optional[torch.Tensor] = None      # raw block input buffer (NDHWC) - None for the first block (image)
+    x_c0: int = 0                          # channel offset / count of the input view inside x
+    rec_x: Optional[torch.Tensor] = None
+    h: Optional[torch.Tensor] = None
+    rec_h: Optional[torch.Tensor] = None
+    out: Optional[torch.Tensor] = None     # buffer holding the block output
+    out_c0: int = 0
+
+
+class ResUNetEngine:
+    def __init__(self, cfg: NetConfig, dtype: torch.dtype = torch.bfloat16):
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.cfg = cfg
+        self.dtype = dtype
+        self.dt = L.BF16 if dtype == torch.bfloat16 else L.F32
+        self.act = L.ACT[cfg.activation]
+        self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._pack_versions: Dict[Tuple[int, int, int], int] = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, w: torch.Tensor, mode: int, cin: int, cout: int, cache: bool) -> torch.Tensor:
+        key = (w.data_ptr(), mode, self.dt)
+        if cache and key in self._pack_cache and self._pack_versions.get(key) == w._version:
+            return self._pack_cache[key]
+        n = lib.bpx_packed_weight_elems(mode, cin, cout, self.dt)
+        out = torch.empty(n, dtype=self.dtype, device=w.device)
+        wc = w.detach()
+        if wc.dtype != torch.float32 or not wc.is_contiguous():
+            wc = wc.float().contiguous()
+        L.check(lib.bpx_pack_weight(mode, wc.data_ptr(), cin, cout, self.dt, out.data_ptr(), L.stream_ptr()))
+        if cache:
+            self._pack_cache[key] = out
+            self._pack_versions[key] = w._version
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _res_block_fwd(self, P, blk: _Blk, B, img: Optional[torch.Tensor], st, cache: bool, want_out_stats: bool):
+        """Runs one residual block. Returns partial stats (part, tiles) of the block output if requested."""
+        D, H, W = blk.S
+        dev = blk.out.device
+        k = blk.keys
+        vox = D * H * W
+        C1 = blk.cout
+        # ---- conv1 -> h (+ stats) ----------------------------------------------------------------
+        if blk.first and self.cfg.in_ch == 1:
+            tiles = lib.bpx_conv3d_c1_stats_tiles(D, H, W)
+            part = _Stats.alloc(B, tiles, C1, dev)
+            L.check(lib.bpx_conv3d_c1_fwd(self.dt, B, D, H, W, img.data_ptr(), P[k["w1"]].data_ptr(), P[k["b1"]].data_ptr(),
+                                          L.tview(blk.h), part.data_ptr(), st))
+        else:
+            tiles = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, C1)
+            part = _Stats.alloc(B, tiles, C1, dev)
+            wp = self._pack(P[k["w1"]], L.PK_K3, blk.cin, C1, cache)
+            L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(blk.x, blk.x_c0, blk.cin),
+                                       L.ptr(blk.rec_x), self.act if blk.rec_x is not None else 0, wp.data_ptr(), P[k["b1"]].data_ptr(),
+                                       L.NULL_T, None, None, L.tview(blk.h), part.data_ptr(), st))
+        blk.rec_h = _recs(B, C1, dev)
+        _Stats.finalize(part, B, tiles, C1, vox, P[k["g1"]], P[k["be1"]], blk.rec_h, C1, 0, st)
+        # ---- conv2 (+ shortcut, + residual add) -> out (+ stats) ----------------------------------
+        wp2 = self._pack(P[k["w2"]], L.PK_K3, C1, C1, cache)
+        tiles2 = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, C1)
+        part2 = _Stats.alloc(B, tiles2, C1, dev) if want_out_stats else None
+        if blk.first and self.cfg.in_ch == 1:
+            sc = L.Tensor(img.data_ptr(), 1, 1)
+            wsc_ptr = P[k["wsc"]].data_ptr()  # (Cout,1,1,1,1) fp32 used as a vector
+        else:
+            sc = L.tview(blk.x, blk.x_c0, blk.cin)
+            wsc_ptr = self._pack(P[k["wsc"]], L.PK_K1, blk.cin, C1, cache).data_ptr()
+        L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, wp2.data_ptr(),
+                                   P[k["b2"]].data_ptr(), sc, wsc_ptr, P[k["bsc"]].data_ptr(),
+                                   L.tview(blk.out, blk.out_c0, C1), L.ptr(part2), st))
+        return part2, tiles2
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
+        """x: (B,C,Z,Y,X) fp32 with channels_last_3d strides (or any layout for C == 1).  Returns logits
+        (B,sum(out_ch),Z,Y,X) fp32 in channels-first planar layout, and the saved context (or None)."""
+        cfg = self.cfg
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
+        B, Cin, D0, H0, W0 = x.shape
+        assert Cin == cfg.in_ch, f"expected {cfg.in_ch} input channels, got {Cin}"
+        Lv = cfg.depth
+        div = 2 ** Lv
+        if D0 % div or H0 % div or W0 % div:
+            raise ValueError(f"patch {D0, H0, W0} must be divisible by {div} (DATA.PATCH_SIZE rule, check_configuration.py:3156-3202)")
+        dev = x.device
+        st = L.stream_ptr()
+        fm = list(cfg.feature_maps)
+        T = self.dtype
+        if Cin == 1:
+            img = x.reshape(B, D0, H0, W0).contiguous()
+            x_ndhwc = None
+        else:
+            img = None
+            xin = x.permute(0, 2, 3, 4, 1).contiguous()
+            x_ndhwc = torch.empty(xin.shape, dtype=T, device=dev)
+            if T == torch.float32:
+                x_ndhwc.copy_(xin)
+            else:
+                L.check(lib.bpx_cast(L.F32, xin.data_ptr(), L.BF16, x_ndhwc.data_ptr(), xin.numel(), st))
+
+        S = [(D0 >> i, H0 >> i, W0 >> i) for i in range(Lv + 1)]
+
+        def buf(i, C):
+            return torch.empty((B,) + S[i] + (C,), dtype=T, device=dev)
+
+        cat = [buf(i, fm[i + 1] + fm[i]) for i in range(Lv)]
+        blocks: List[_Blk] = []
+        pools = []
+        out_stats = []
+        cur, cur_rec = x_ndhwc, None
+        # ---------------- encoder ------------------------------------------------------------------
+        for i in range(Lv):
+            blk = _Blk(keys=block_keys(f"down_path.{i}", i == 0), first=(i == 0), S=S[i], cin=(cfg.in_ch if i == 0 else fm[i - 1]),
+                       cout=fm[i], x=cur, x_c0=0, rec_x=cur_rec, h=buf(i, fm[i]), out=cat[i], out_c0=fm[i + 1])
+            part, tiles = self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=True)
+            out_stats.append((part, tiles))
+            blocks.append(blk)
+            # pool -> P_i (+ stats) and the pre-norm record of the next block
+            pooled = buf(i + 1, fm[i])
+            D, H, W = S[i]
+            ptiles = lib.bpx_maxpool3d_stats_tiles(self.dt, D, H, W, fm[i])
+            ppart = _Stats.alloc(B, ptiles, fm[i], dev)
+            L.check(lib.bpx_maxpool3d_fwd(self.dt, B, D, H, W, L.tview(cat[i], fm[i + 1], fm[i]), L.tview(pooled), ppart.data_ptr(), st))
+            nxt = "bottleneck" if i == Lv - 1 else f"down_path.{i + 1}"
+            rec = _recs(B, fm[i], dev)
+            _Stats.finalize(ppart, B, ptiles, fm[i], S[i + 1][0] * S[i + 1][1] * S[i + 1][2], P[f"{nxt}.block.0.weight"],
+                            P[f"{nxt}.block.0.bias"], rec, fm[i], 0, st)
+            pools.append(pooled)
+            cur, cur_rec = pooled, rec
+        # ---------------- bottleneck ----------------------------------------------------------------
+        bot = _Blk(keys=block_keys("bottleneck", False), first=False, S=S[Lv], cin=fm[Lv - 1], cout=fm[Lv], x=cur, rec_x=cur_rec,
+                   h=buf(Lv, fm[Lv]), out=buf(Lv, fm[Lv]), out_c0=0)
+        self._res_block_fwd(P, bot, B, img, st, cache_weights, want_out_stats=False)
+        blocks.append(bot)
+        # ---------------- decoder -------------------------------------------------------------------
+        dec_in = bot.out
+        ups = []
+        for j, i in enumerate(range(Lv - 1, -1, -1)):
+            Cup = fm[i + 1]
+            Dl, Hl, Wl = S[i + 1]
+            wk, bk = f"up_paths.0.{j}.up.weight", f"up_paths.0.{j}.up.bias"
+            wp = self._pack(P[wk], L.PK_CT, Cup, Cup, cache_weights)
+            utiles = lib.bpx_convT3d_stats_tiles(Dl, Hl, Wl)
+            upart = _Stats.alloc(B, utiles, Cup, dev)
+            L.check(lib.bpx_convT3d_k2s2_fwd(self.dt, B, Dl, Hl, Wl, L.tview(dec_in), wp.data_ptr(), P[bk].data_ptr(),
+                                             L.tview(cat[i], 0, Cup), upart.data_ptr(), st))
+            Ccat = Cup + fm[i]
+            pre = f"up_paths.0.{j}.conv_block"
+            vox = S[i][0] * S[i][1] * S[i][2]
+            rec = _recs(B, Ccat, dev)
+            g0, be0 = P[f"{pre}.block.0.weight"], P[f"{pre}.block.0.bias"]
+            _Stats.finalize(upart, B, utiles, Cup, vox, g0[:Cup], be0[:Cup], rec, Ccat, 0, st)
+            spart, stiles = out_stats[i]
+            _Stats.finalize(spart, B, stiles, fm[i], vox, g0[Cup:], be0[Cup:], rec, Ccat, Cup, st)
+            blk = _Blk(keys=block_keys(pre, False), first=False, S=S[i], cin=Ccat, cout=fm[i], x=cat[i], x_c0=0, rec_x=rec,
+                       h=buf(i, fm[i]), out=buf(i, fm[i]), out_c0=0)
+            self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=False)
+            blocks.append(blk)
+            ups.append((wk, bk, dec_in, Cup, S[i + 1]))
+            dec_in = blk.out
+        # ---------------- heads ----------------------------------------------------------------------
+        n_out = sum(cfg.out_channels)
+        if len(cfg.out_channels) == 1:
+            hw, hb = P["heads.0.weight"], P["heads.0.bias"]
+        else:
+            hw = torch.cat([P[f"heads.{h}.weight"].reshape(-1, fm[0]) for h in range(len(cfg.out_channels))], 0)
+            hb = torch.cat([P[f"heads.{h}.bias"] for h in range(len(cfg.out_channels))], 0)
+        hw = hw.reshape(n_out, fm[0]).contiguous()
+        logits = torch.empty((B, n_out, D0, H0, W0), dtype=torch.float32, device=dev)
+        vox0 = D0 * H0 * W0
+        L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(dec_in), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(),
+                                 n_out * vox0, vox0, st))
+        ctx = None
+        if save:
+            ctx = dict(B=B, S=S, img=img, x_ndhwc=x_ndhwc, blocks=blocks, cat=cat, pools=pools, ups=ups, feat=dec_in, hw=hw)
+        return logits, ctx
+
+    # ------------------------------------------------------------------------------------------
+    def _block_bwd(self, P, G, blk: _Blk, B, dOut: L.Tensor, img, st, dx_extra: Optional[L.Tensor] = None, dx_out: Optional[L.Tensor] = None):
+        """Backward of one residual block.  dOut: gradient of the block output (T, NDHWC view).
+        Writes parameter grads into G; writes the input gradient into dx_out (a view with blk.cin channels)."""
+        D, H, W = blk.S
+        k = blk.keys
+        dev = blk.h.device
+        C1 = blk.cout
+        vox = D * H * W
+        T = self.dtype
+        # conv2 weight/bias grad, shortcut weight grad
+        L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, dOut, 3,
+                                     G[k["w2"]].data_ptr(), G[k["b2"]].data_ptr(), st))
+        if blk.first and self.cfg.in_ch == 1:
+            scratch = torch.zeros((C1, 27), dtype=torch.float32, device=dev)
+            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), dOut, scratch.data_ptr(), None, st))
+            G[k["wsc"]].view(C1).copy_(scratch[:, 13])
+        else:
+            L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1,
+                                         G[k["wsc"]].data_ptr(), None, st))
+        G[k["bsc"]].copy_(G[k["b2"]])  # both biases add to the same tensor: identical gradient
+        # conv2 dgrad fused with ELU' and the InstanceNorm reductions
+        g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
+        tiles = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, C1)
+        red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
+        w2t = self._pack(P[k["w2"]], L.PK_K3_T, C1, C1, False)
+        L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
+                                     L.tview(g1), red.data_ptr(), st))
+        coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
+        L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
+                                          G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), coef.data_ptr(), st))
+        L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g1), L.tview(blk.h), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
+        dH = L.tview(g1)
+        # conv1
+        if blk.first and self.cfg.in_ch == 1:
+            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), dH, G[k["w1"]].data_ptr(), G[k["b1"]].data_ptr(), st))
+            return
+        xv = L.tview(blk.x, blk.x_c0, blk.cin)
+        has_norm = blk.rec_x is not None
+        L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, xv, L.ptr(blk.rec_x), self.act if has_norm else 0, dH, 3,
+                                     G[k["w1"]].data_ptr(), G[k["b1"]].data_ptr(), st))
+        if dx_out is None:
+            return
+        Cx = blk.cin
+        g0 = torch.empty((B, D, H, W, Cx), dtype=T, device=dev)
+        tiles0 = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, Cx)
+        w1t = self._pack(P[k["w1"]], L.PK_K3_T, Cx, C1, False)
+        wsct = self._pack(P[k["wsc"]], L.PK_DENSE_T, Cx, C1, False)
+        if has_norm:
+            red0 = torch.empty((B, tiles0, 2, Cx), dtype=torch.float32, device=dev)
+            L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dH, w1t.data_ptr(), xv, blk.rec_x.data_ptr(), self.act, L.tview(g0),
+                                         red0.data_ptr(), st))
+            coef0 = torch.empty((B, Cx, 4), dtype=torch.float32, device=dev)
+            L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
+                                              G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), coef0.data_ptr(), st))
+            L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
+                                        dx_extra if dx_extra is not None else L.NULL_T, dx_out, st))
+        else:
+            L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dH, w1t.data_ptr(), L.NULL_T, None, 0, L.tview(g0), None, st))
+            L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.tview(g0), dx_out, st))
+
+    def backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        B, S, img = ctx["B"], ctx["S"], ctx["img"]
+        blocks: List[_Blk] = ctx["blocks"]
+        cat, pools, ups, feat = ctx["cat"], ctx["pools"], ctx["ups"], ctx["feat"]
+        fm = list(cfg.feature_maps)
+        Lv = cfg.depth
+        dev = dlogits.device
+        st = L.stream_ptr()
+        T = self.dtype
+        # one zero-filled slab for all parameter gradients (the wgrad kernels accumulate with atomics)
+        names = list(P.keys())
+        sizes = [P[n].numel() for n in names]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        G: Dict[str, torch.Tensor] = {}
+        o = 0
+        for n, s in zip(names, sizes):
+            G[n] = flat[o:o + s].view(P[n].shape)
+            o += s
+        # ---- head -------------------------------------------------------------------------------
+        n_out = sum(cfg.out_channels)
+        D0, H0, W0 = S[0]
+        vox0 = D0 * H0 * W0
+        dl = dlogits.contiguous().float()
+        dfeat = torch.empty((B, D0, H0, W0, fm[0]), dtype=T, device=dev)
+        hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
+        hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
+        L.check(lib.bpx_head_bwd(self.dt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
+                                 L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), st))
+        o = 0
+        for h, oc in enumerate(cfg.out_channels):
+            G[f"heads.{h}.weight"].copy_(hwg[o:o + oc].view(G[f"heads.{h}.weight"].shape))
+            G[f"heads.{h}.bias"].copy_(hbg[o:o + oc])
+            o += oc
+        # ---- decoder (blocks list: enc 0..Lv-1, bottleneck, dec j=0..Lv-1 for levels Lv-1..0) -------
+        dcat: List[Optional[torch.Tensor]] = [None] * Lv
+        dOut = L.tview(dfeat)
+        keep = [dfeat]
+        for j in range(Lv - 1, -1, -1):       # decoder block j handles level i = Lv-1-j; walk from level 0 up
+            i = Lv - 1 - j
+            blk = blocks[Lv + 1 + j]
+            Ccat = fm[i + 1] + fm[i]
+            dcat[i] = torch.empty((B,) + S[i] + (Ccat,), dtype=T, device=dev)
+            self._block_bwd(P, G, blk, B, dOut, img, st, None, L.tview(dcat[i]))
+            # transposed conv backward: dUp = dcat[i][..., :Cup]
+            wk, bk, x_in, Cup, Sl = ups[j]
+            dUp = L.tview(dcat[i], 0, Cup)
+            L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, Sl[0], Sl[1], Sl[2], L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), st))
+            dxin = torch.empty((B,) + Sl + (Cup,), dtype=T, device=dev)
+            wt = self._pack(P[wk], L.PK_CT_T, Cup, Cup, False)
+            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Sl[0], Sl[1], Sl[2], dUp, wt.data_ptr(), L.tview(dxin), st))
+            dOut = L.tview(dxin)
+            keep.append(dxin)
+        # ---- bottleneck -------------------------------------------------------------------------
+        dP = torch.empty((B,) + S[Lv] + (fm[Lv - 1],), dtype=T, device=dev)
+        self._block_bwd(P, G, blocks[Lv], B, dOut, img, st, None, L.tview(dP))
+        # ---- encoder ------------------------------------------------------------------------------
+        for i in range(Lv - 1, -1, -1):
+            D, H, W = S[i]
+            Cup = fm[i + 1]
+            # dOut_i = dSkip (dcat[i][..., Cup:]) + unpool(dP); written in place over the skip slice
+            skipv = L.tview(dcat[i], Cup, fm[i])
+            L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
+            if i > 0:
+                dPn = torch.empty((B,) + S[i] + (fm[i - 1],), dtype=T, device=dev)
+                self._block_bwd(P, G, blocks[i], B, skipv, img, st, None, L.tview(dPn))
+                keep.append(dP)
+                dP = dPn
+            else:
+                self._block_bwd(P, G, blocks[0], B, skipv, img, st, None, None)  # the image needs no gradient
+        return G

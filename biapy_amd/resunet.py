@@ -1,0 +1,218 @@
+"""Drop-in for ``biapy.models.resunet.ResUNet`` (3D) running on the MI355X engine.
+
+Contract kept from the reference (biapy/models/resunet.py:34-60, :352-446; registry call at
+biapy/models/__init__.py:120-147):
+  * same constructor keyword arguments;
+  * ``forward(x)`` takes ``(B,C,Z,Y,X)`` float32 (channels_last_3d strides, as ``to_pytorch_format``
+    produces them) and returns the prediction tensor (logits when ``explicit_activations`` is False);
+  * identical ``state_dict()`` keys and shapes so checkpoints load with
+    ``strict=True`` both ways (biapy/utils/misc.py:611-630), and parameters are ordinary
+    ``nn.Parameter``s so DistributedDataParallel / torchinfo / optimisers work unchanged.
+
+The module tree below exists only to own the parameters under the reference's names; no nn.Module
+forward of a leaf layer is ever called - ``forward`` hands the parameter tensors to
+:class:`biapy_amd.engine.ResUNetEngine`, and gradients come from its hand-written backward through one
+``torch.autograd.Function``.
+
+Configurations outside the accelerated hot path (2D, normalisation other than "in", larger_io,
+separated decoders, contrastive head, SR up-sampling, anisotropic kernels/strides, nconvs != 2,
+pre-activation order) raise ``NotImplementedError`` at construction: they stay on the reference's
+plain-PyTorch classes, selected by the same registry.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .engine import NetConfig, ResUNetEngine
+
+
+def _act_layer(name: str) -> nn.Module:
+    return {"elu": nn.ELU(alpha=1.0, inplace=True), "relu": nn.ReLU(inplace=True), "silu": nn.SiLU(inplace=True)}[name]
+
+
+class ConvBlock(nn.Module):
+    """Parameter holder named like blocks.py:25-192: ``block = Sequential(conv[, norm, act])``."""
+
+    def __init__(self, cin: int, cout: int, k: int, with_norm_act: bool, act: str):
+        super().__init__()
+        layers: List[nn.Module] = [nn.Conv3d(cin, cout, kernel_size=k, padding="same")]
+        if with_norm_act:
+            layers += [nn.InstanceNorm3d(cout, affine=True, momentum=0.1), _act_layer(act)]
+        self.block = nn.Sequential(*layers)
+
+
+class ResConvBlock(nn.Module):
+    """Parameter holder named like blocks.py:1194-1459 (post-activation order, two convolutions)."""
+
+    def __init__(self, cin: int, cout: int, k: int, act: str, first_block: bool):
+        super().__init__()
+        layers: List[nn.Module] = []
+        if not first_block:
+            layers += [nn.InstanceNorm3d(cin, affine=True, momentum=0.1), _act_layer(act)]
+        layers += [ConvBlock(cin, cout, k, True, act), ConvBlock(cout, cout, k, False, act)]
+        self.block = nn.Sequential(*layers)
+        self.shortcut = nn.Sequential(nn.Conv3d(cin, cout, kernel_size=1, padding="same"))
+
+
+class ResUpBlock(nn.Module):
+    """Parameter holder named like blocks.py:1462-1655."""
+
+    def __init__(self, cin: int, cbridge: int, cout: int, k: int, act: str):
+        super().__init__()
+        self.up = nn.ConvTranspose3d(cin, cin, kernel_size=(2, 2, 2), stride=(2, 2, 2))
+        self.conv_block = ResConvBlock(cin + cbridge, cout, k, act, False)
+
+
+class _ResUNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine: ResUNetEngine, names: List[str], *params):
+        P = dict(zip(names, (p.detach() for p in params)))
+        need = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        logits, saved = engine.forward(P, x.detach(), head_act=0, save=True)
+        ctx.engine, ctx.names, ctx.saved = engine, names, saved
+        ctx.params = P
+        del need
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        G = ctx.engine.backward(ctx.params, ctx.saved, dlogits)
+        ctx.saved = None
+        return (None, None, None) + tuple(G[n] for n in ctx.names)
+
+
+class ResUNet(nn.Module):
+    def __init__(
+        self,
+        image_shape=(256, 256, 1),
+        activation="ELU",
+        feature_maps=[32, 64, 128, 256],
+        drop_values=[0.1, 0.1, 0.1, 0.1],
+        normalization="none",
+        k_size=3,
+        upsample_layer="convtranspose",
+        yx_down=[2, 2, 2, 2],
+        z_down=[2, 2, 2, 2],
+        output_channels=[1],
+        separated_decoders=False,
+        divide_decoder_feature_maps=False,
+        output_channel_info=["F"],
+        explicit_activations: bool = False,
+        head_activations: List[str] = ["ce_sigmoid"],
+        upsampling_factor=(),
+        upsampling_position="pre",
+        isotropy=False,
+        larger_io=True,
+        conv_layers: List[int] = [2, 2, 2, 2, 2],
+        contrast: bool = False,
+        contrast_proj_dim: int = 256,
+        return_one_tensor: bool = False,
+        conv_block_order: str = "conv_norm_act",
+        compute_dtype: torch.dtype = torch.bfloat16,
+    ):
+        super().__init__()
+        if len(output_channels) == 0:
+            raise ValueError("'output_channels' needs to has at least one value")
+        act = activation.lower()
+        depth = len(feature_maps) - 1
+        iso = [isotropy] * len(feature_maps) if isinstance(isotropy, bool) else list(isotropy)
+
+        def unsupported(what):
+            raise NotImplementedError(f"biapy_amd.ResUNet: {what} is outside the MI355X hot path; use the reference PyTorch class for it")
+
+        if len(image_shape) != 4:
+            unsupported("2D input")
+        if k_size != 3 or not all(iso):
+            unsupported("kernel size != 3 or anisotropic (1,k,k) kernels")
+        if list(yx_down)[:depth] != [2] * depth or list(z_down)[:depth] != [2] * depth:
+            unsupported("down-sampling factors other than 2")
+        if upsample_layer != "convtranspose":
+            unsupported("upsample_layer != 'convtranspose'")
+        if separated_decoders or contrast or larger_io or len(upsampling_factor) > 0:
+            unsupported("separated decoders / contrastive head / larger_io / super-resolution up-sampling")
+        if conv_block_order != "conv_norm_act" or list(conv_layers)[: depth + 1] != [2] * (depth + 1):
+            unsupported("conv_block_order != 'conv_norm_act' or conv_layers != 2")
+        if any(float(d) > 0 for d in drop_values):
+            unsupported("dropout")
+        if explicit_activations or "class" in output_channel_info:
+            unsupported("explicit head activations / classification head")
+        self.depth = depth
+        self.ndim = 3
+        self.z_down, self.yx_down = z_down, yx_down
+        self.output_channels = output_channels
+        self.output_channel_info = output_channel_info
+        self.return_class = False
+        self.contrast = False
+        self.explicit_activations = False
+        self.return_one_tensor = return_one_tensor
+        in_ch = image_shape[-1]
+        self.cfg = NetConfig(in_ch=in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
+                             normalization=normalization)
+        self.compute_dtype = compute_dtype
+        self._engine: Optional[ResUNetEngine] = None
+
+        self.pre_upsampling = None
+        self.conv_in = None
+        self.down_path = nn.ModuleList()
+        self.mpooling_layers = nn.ModuleList()
+        c = in_ch
+        for i in range(depth):
+            self.down_path.append(ResConvBlock(c, feature_maps[i], k_size, act, first_block=(i == 0)))
+            self.mpooling_layers.append(nn.MaxPool3d((2, 2, 2)))
+            c = feature_maps[i]
+        self.bottleneck = ResConvBlock(c, feature_maps[-1], k_size, act, False)
+        self.num_decoders = 1
+        self.up_paths = nn.ModuleList([nn.ModuleList()])
+        c = feature_maps[-1]
+        for i in range(depth - 1, -1, -1):
+            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], k_size, act))
+            c = feature_maps[i]
+        self.conv_out = None
+        self.post_upsampling = None
+        self.heads = nn.Sequential()
+        for oc in output_channels:
+            self.heads.append(nn.Conv3d(feature_maps[0], oc, kernel_size=1, padding="same"))
+        self._init_weights()
+
+    def _init_weights(self):
+        # blocks.py:2301-2336: Xavier-uniform + zero bias on Conv3d only (ConvTranspose3d keeps PyTorch's default)
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------------------------------
+    def engine(self) -> ResUNetEngine:
+        if self._engine is None or self._engine.dtype != self.compute_dtype:
+            self._engine = ResUNetEngine(self.cfg, self.compute_dtype)
+        return self._engine
+
+    def _named(self):
+        names, params = [], []
+        for n, p in self.named_parameters():
+            names.append(n)
+            params.append(p)
+        return names, params
+
+    def forward(self, x) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("biapy_amd.ResUNet runs on the MI355X only (input is on %s); there is no CPU path" % x.device)
+        names, params = self._named()
+        x = x.to(torch.float32)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _ResUNetFn.apply(x, self.engine(), names, *params)
+        P = {n: p.detach() for n, p in zip(names, params)}
+        logits, _ = self.engine().forward(P, x, head_act=0, save=False, cache_weights=not self.training)
+        return logits
+
+    @torch.no_grad()
+    def predict_proba(self, x) -> torch.Tensor:
+        """Inference with the ``ce_sigmoid`` head activation (base_workflow.py:1403-1457) fused into the head kernel."""
+        names, params = self._named()
+        P = {n: p.detach() for n, p in zip(names, params)}
+        out, _ = self.engine().forward(P, x.to(torch.float32), head_act=1, save=False, cache_weights=True)
+        return out

@@ -1,0 +1,202 @@
+/*
+ * biapy_amd.h - C-ABI of libbiapy_amd.so: the MI355X (gfx950) kernels behind BiaPy's 3D patch
+ * U-Net hot path.  Plain pointers and sizes only; every pointer named *_d is a DEVICE pointer,
+ * the caller owns all memory, nothing is retained across calls, all launches go to `stream`
+ * (a hipStream_t; NULL = the default stream).  Every entry returns 0 on success, non-zero on
+ * error with bpx_last_error() (thread-local) describing it.
+ *
+ * The reference (BiaPyX/BiaPy v3.7.0) is 100 % Python on PyTorch/NumPy, so there is no native FFI
+ * to bind to; each entry cites the reference operator/function it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stubs a BiaPy maintainer would add.
+ *
+ * Tensor layout: activations are NDHWC ("(Z,Y,X,C) patch layout"), i.e. [N][D][H][W][ld] with the
+ * channel stride `ld` >= C so that a tensor can be a channel slice of a wider buffer (this is how
+ * torch.cat([up, skip], 1) - biapy/models/blocks.py:1653 - is eliminated).
+ */
+#ifndef BIAPY_AMD_H
+#define BIAPY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bpx_stream_t; /* hipStream_t */
+
+enum bpx_dtype { BPX_F32 = 0, BPX_BF16 = 1, BPX_F16 = 2, BPX_U8 = 3 };
+enum bpx_act { BPX_ACT_NONE = 0, BPX_ACT_ELU = 1, BPX_ACT_RELU = 2, BPX_ACT_SILU = 3 };
+enum bpx_pad_mode { BPX_PAD_REFLECT = 0, BPX_PAD_ZEROS = 1 };
+
+int bpx_version(void);
+const char* bpx_last_error(void);
+/* MFMA / LDS-transpose lane-layout self test (prints nothing; writes 64*16 floats). Used by tests. */
+int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
+int bpx_debug_set_wgrad_tr(int use_tr); /* test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Tiling.  Patch placement along one axis, exactly the reference's integer rule
+ * (biapy/data/data_3D_manipulation.py:541-547, :596-598 / :789-795, :826-835):
+ *   start(i) = i*step - ((i*step + patch < limit) ? 0 : last)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bpx_axis_grid {
+  int32_t n, step, last, patch, limit;
+} bpx_axis_grid;
+
+/* crop_3D_data_with_overlap's copy loop + np.pad (data_3D_manipulation.py:505-515, :591-623) as an
+ * on-device gather: out[c] = padded(vol)[z0:z0+Pz, y0:y0+Py, x0:x0+Px] for the patches
+ * c in [c_begin, c_begin+c_count) of the z-major patch order.  elem_size = bytes per element
+ * (1, 2 or 4); data is moved bit-exactly.  grid[] is the CROP grid (padded coordinates). */
+int bpx_crop3d_gather(const void* vol_d, int elem_size, int Z, int Y, int X, int C,
+                      int pad_z, int pad_y, int pad_x, int pad_mode,
+                      const bpx_axis_grid* grid_zyx /* host, 3 entries */,
+                      int64_t c_begin, int64_t c_count, void* out_d, bpx_stream_t stream);
+
+/* merge_3D_data_with_overlap (data_3D_manipulation.py:754-856) as a deterministic gather: every
+ * output voxel sums fl32(patch*w) over the patches covering it in the reference's patch order
+ * (z-major), w = fl32(fl32(wz*wy)*wx), then divides by fl32(sum(w)+1e-18f) and casts to out_dtype
+ * (truncating for u8, as NumPy's astype).  grid[] is the MERGE grid (original coordinates,
+ * padding-stripped patch).  Patches are [n][Pz][Py][Px][C] including the padding that is skipped.
+ *
+ * Sharding (one Z-slab of the volume per GPU): only output slices z in [z_lo, z_hi) are produced,
+ * from the patches whose z-row index is in [zrow_lo, zrow_hi) - `patches_d` holds just those rows.
+ * acc_d / wacc_d (float, [z_hi-z_lo][Y][X][C] / [..][1], may be NULL) seed the sums with a
+ * neighbour's partial sums; with write_partial != 0 the un-normalised sums are written back to
+ * acc_d / wacc_d instead of the normalised volume (used for the slab-boundary exchange). */
+int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int Py, int Px, int C,
+                      int pad_z, int pad_y, int pad_x,
+                      const bpx_axis_grid* grid_zyx /* host, 3 entries */,
+                      const float* wz_d, const float* wy_d, const float* wx_d,
+                      int Z, int Y, int X, int z_lo, int z_hi, int zrow_lo, int zrow_hi,
+                      float* acc_d, float* wacc_d, int write_partial,
+                      void* out_d, int out_dtype, bpx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Network kernels.  T = BPX_BF16 (bf16 storage, fp32 accumulate, v_mfma_f32_16x16x32_bf16) or
+ * BPX_F32 (fp32 storage, exact-fp32 v_mfma_f32_16x16x4_f32; the parity/debug mode).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per-(n,c) normalisation record produced by bpx_norm_finalize and consumed by conv prologues. */
+typedef struct bpx_norm_rec {
+  float mean, rstd, scale, shift; /* y = act(scale*x + shift), scale = gamma*rstd, shift = beta - mean*scale */
+} bpx_norm_rec;
+
+typedef struct bpx_tensor {
+  void* ptr;   /* device; element (n,z,y,x,c) at ((((n*D+z)*H+y)*W+x)*ld + c) */
+  int32_t ld;  /* channel stride in elements */
+  int32_t C;   /* channels used */
+} bpx_tensor;
+
+/* Weight packing: PyTorch fp32 weights -> MFMA operand order (DESIGN.md "packed weights").
+ *   mode 0 BPX_PK_K3     Conv3d (Cout,Cin,3,3,3)       -> [Cin/16][q<QPAD][Cout][KPL]      (bpx_conv3d_fwd)
+ *   mode 1 BPX_PK_K3_T   same weight, dgrad operator   -> [Cout/16][q<QPAD][Cin][KPL], taps mirrored (bpx_conv3d_dgrad)
+ *   mode 2 BPX_PK_K1     Conv3d (Cout,Cin,1,1,1)       -> [Cin/16][4][Cout][KPL]           (fused shortcut of bpx_conv3d_fwd)
+ *   mode 3 BPX_PK_DENSE  Conv3d k=1                    -> [ceil4(Cin/KPL)][Cout][KPL]      (bpx_conv1x1_fwd)
+ *   mode 4 BPX_PK_DENSE_T same weight, dgrad operator  -> [ceil4(Cout/KPL)][Cin][KPL]      (bpx_conv1x1_fwd as dgrad)
+ *   mode 5 BPX_PK_CT     ConvTranspose3d (Cin,Cout,2,2,2) -> [ceil4(Cin/KPL)][8*Cout][KPL] (bpx_convT3d_k2s2_fwd)
+ *   mode 6 BPX_PK_CT_T   same weight, dgrad operator   -> [8*Cout/KPL][Cin][KPL]           (bpx_convT3d_k2s2_dgrad)
+ * KPL = 8 (bf16) / 4 (f32) elements per 16-byte lane operand; QPAD = 56 (bf16) / 108 (f32). */
+enum bpx_pack_mode { BPX_PK_K3 = 0, BPX_PK_K3_T = 1, BPX_PK_K1 = 2, BPX_PK_DENSE = 3, BPX_PK_DENSE_T = 4, BPX_PK_CT = 5, BPX_PK_CT_T = 6 };
+int64_t bpx_packed_weight_elems(int mode, int Cin, int Cout, int dtype);
+int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, int dtype, void* packed_d, bpx_stream_t stream);
+
+/* Conv3d k=3 "same" + bias (biapy/models/blocks.py:154-157), implicit GEMM on MFMA with an
+ * LDS-staged input halo.  Fusions:
+ *   prologue : x <- act(scale*x+shift) with in_norm_d[n*Cin+c]  (the InstanceNorm+ELU that
+ *              precedes this conv, blocks.py:1308-1314 / :158-161); NULL = raw input.
+ *   shortcut : + Conv3d k=1 of a second raw tensor `sc` (blocks.py:1372, :1458) when sc.ptr != NULL;
+ *              sc.C == 1 is handled as a rank-1 update.  w_sc packed with k=1.
+ *   epilogue : per-(n,c) sum / sum-of-squares partials of the fp32 result into stats_part_d
+ *              ([n][tiles][2][Cout] floats) for the next InstanceNorm (NULL = skip).
+ * x.C must be 1 or a multiple of 16; Cout a multiple of 16. */
+int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                   const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_packed_d,
+                   const float* bias_sc_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
+int bpx_conv3d_stats_tiles(int dtype, int D, int H, int W, int Cout); /* tiles per sample the call above writes partials for */
+
+/* dgrad of the conv above w.r.t. its (normalised+activated) input, fused with the backward of that
+ * activation:  g = convT(dy, W) * act'(scale*t+shift),  t = the conv's raw input tensor.
+ * Writes g and the per-(n,c) partials of sum(g) and sum(g*xhat) (xhat = (t-mean)*rstd) that both
+ * InstanceNorm's input gradient and its dgamma/dbeta need.  t_norm_d == NULL: plain dgrad. */
+int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d,
+                     bpx_tensor t, const bpx_norm_rec* t_norm_d, int act, bpx_tensor g,
+                     float* red_part_d, bpx_stream_t stream);
+
+/* wgrad: dW[co][ci][tap] += sum_v act(norm(x))[v+tap][ci] * dy[v][co]  (fp32 atomics into the
+ * PyTorch-layout gradient), db[co] += sum_v dy[v][co].  k = 3 or 1. dw_d/db_d must be zeroed by the
+ * caller.  Used for Conv3d (k=3, k=1). */
+int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                     bpx_tensor dy, int k, float* dw_d, float* db_d, bpx_stream_t stream);
+
+/* Per-(n,c) coefficients of InstanceNorm's input gradient, dx = a*g + b*t + c0 (see bpx_norm_bwd_finalize). */
+typedef struct bpx_nbwd_coef { float a, b, c0, pad; } bpx_nbwd_coef;
+
+/* Conv3d k=1 as a GEMM over voxels: y = x*W + bias [+ a*g + b*t + c0] [+ addend].  Used for the dgrad of
+ * the residual shortcut (blocks.py:1372) fused with the InstanceNorm-backward affine of the main path, and
+ * for stand-alone 1x1x1 convolutions.  `voxels` = voxels per sample; g/t/coef_d and addend may be null. */
+int bpx_conv1x1_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                    bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
+                    bpx_stream_t stream);
+
+/* ConvTranspose3d k = s = 2 (blocks.py:1607): y[n,2z+a,2y+b,2x+c,:] = x[n,z,y,x,:]*W[:,:,a,b,c] + b.
+ * (D,H,W) are the INPUT extents; y has extents (2D,2H,2W) and may be a channel slice of the
+ * concat buffer.  stats_part_d: ([n][tiles][2][Cout]) partials for the following norm. */
+int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const void* w_packed_d,
+                         const float* bias_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
+int bpx_convT3d_stats_tiles(int D, int H, int W);
+int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d,
+                           bpx_tensor dx, bpx_stream_t stream);
+int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy,
+                           float* dw_d, float* db_d, bpx_stream_t stream);
+
+/* InstanceNorm3d(affine, eps) == GroupNorm with G = C (blocks.py:2122-2125).  Reduces the partials
+ * written by a producer kernel to bpx_norm_rec[n*out_ld + out_off + c]; groups < C gives GroupNorm(groups).
+ * out_ld/out_off let two producers (up-conv and skip) fill one record array for the concatenated tensor. */
+int bpx_norm_finalize(const float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel,
+                      const float* gamma_d, const float* beta_d, float eps, int groups,
+                      bpx_norm_rec* out_d, int out_ld, int out_off, bpx_stream_t stream);
+/* Stand-alone statistics of a tensor (used for tensors no conv kernel produced, and in tests). */
+int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, float* stats_part_d, bpx_stream_t stream);
+int bpx_tensor_stats_tiles(int64_t voxels);
+
+/* Backward of InstanceNorm given the partials from bpx_conv3d_dgrad:
+ *   coef[n*C+c] = {a, b, c0} with dx = a*g + b*t + c0 ;  dgamma[c] += sum_n S2 ; dbeta[c] += sum_n S1 */
+int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, int C, int64_t count_per_channel,
+                          const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d,
+                          bpx_nbwd_coef* coef_d, bpx_stream_t stream);
+/* dx = a*g + b*t + c0 (+ addend): applies the coefficients above elementwise. dx may alias g. */
+int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
+                       bpx_tensor addend, bpx_tensor dx, bpx_stream_t stream);
+
+/* MaxPool3d 2x2x2 (resunet.py:256-257) + statistics of the pooled tensor. (D,H,W) = input extents. */
+int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor y, float* stats_part_d,
+                      bpx_stream_t stream);
+int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int C);
+/* dx = addend + scatter(dy to the first maximal element of each window) */
+int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy, bpx_tensor addend,
+                      bpx_tensor dx, bpx_stream_t stream);
+
+/* Output head: Conv3d k=1 to `Cout` (<= 4) fp32 channels (resunet.py:346-348) with the head
+ * activation (base_workflow.py:1403-1457) fused: head_act 0 = logits, 1 = sigmoid, 2 = tanh.
+ * out is (N,Cout,D,H,W) fp32 contiguous per channel plane with arbitrary strides given in elements. */
+int bpx_head_fwd(int dtype, int64_t voxels_per_sample, int N, bpx_tensor x, const float* w_d /* [Cout][Cin] */,
+                 const float* b_d, int Cout, int head_act, float* out_d, int64_t out_stride_n, int64_t out_stride_c,
+                 bpx_stream_t stream);
+int bpx_head_bwd(int dtype, int64_t voxels_per_sample, int N, bpx_tensor x, const float* w_d, int Cout,
+                 const float* dout_d, int64_t stride_n, int64_t stride_c, bpx_tensor dx, float* dw_d, float* db_d,
+                 bpx_stream_t stream);
+
+/* First layer, Cin = 1 (fp32 image in, blocks.py:154 with in_size = 1): direct convolution. */
+int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d /* (Cout,1,3,3,3) */,
+                      const float* bias_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
+int bpx_conv3d_c1_stats_tiles(int D, int H, int W);
+int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy,
+                        float* dw_d, float* db_d, bpx_stream_t stream);
+
+/* dtype conversion helpers (NDHWC, strided channel slices) */
+int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64_t n, bpx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIAPY_AMD_H */

@@ -1,0 +1,80 @@
+"""Run every kernel/network parity check and print a table (does not stop at the first failure).
+
+    python tests/gpu_diag.py [--net] [--out gpurun_out/diag.txt]
+"""
+import argparse
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--net", action="store_true")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import kernel_checks as K
+
+    gt = np.load(os.path.join(ROOT, "tests", "golden", "tiling_golden.npz"))
+    gr = np.load(os.path.join(ROOT, "tests", "golden", "resunet_golden.npz"))
+    rows = []
+
+    def run(fn, *args, **kw):
+        try:
+            rows.extend(fn(*args, **kw))
+        except Exception as e:  # keep going: a GPU call is expensive
+            rows.append(dict(name=f"{fn.__name__}{args[:3]}", err=float("nan"), tol=0, ok=False, extra="EXC " + repr(e)[:300]))
+            traceback.print_exc()
+        torch.cuda.synchronize()
+
+    run(K.check_selftest)
+    run(K.check_tiling, gt)
+    run(K.check_merge_sharded)
+    L = K.L
+    for dt in (L.F32, L.BF16):
+        run(K.check_conv3d_fwd, dt, 2, (8, 8, 16), 16, 16, norm=True, sc_C=0)
+        run(K.check_conv3d_fwd, dt, 1, (8, 12, 20), 48, 16, norm=True, sc_C=48, slices=True)
+        run(K.check_conv3d_fwd, dt, 2, (6, 8, 8), 32, 64, norm=False, sc_C=1)
+        run(K.check_conv3d_fwd, dt, 1, (4, 4, 8), 64, 128, norm=True, sc_C=64)
+        run(K.check_conv3d_fwd, dt, 1, (32, 32, 32), 16, 32, norm=True, sc_C=16)
+        run(K.check_conv3d_dgrad, dt, 2, (8, 8, 16), 48, 16)
+        run(K.check_conv3d_dgrad, dt, 1, (4, 8, 8), 32, 64)
+        run(K.check_conv3d_wgrad, dt, 2, (8, 8, 16), 16, 16, k=3, norm=True)
+        run(K.check_conv3d_wgrad, dt, 1, (8, 12, 20), 48, 32, k=3, norm=True)
+        run(K.check_conv3d_wgrad, dt, 1, (4, 8, 8), 64, 64, k=3, norm=False)
+        run(K.check_conv3d_wgrad, dt, 2, (8, 8, 16), 48, 16, k=1, norm=False)
+        if dt == L.BF16:
+            run(K.check_conv3d_wgrad, dt, 2, (8, 8, 16), 16, 16, k=3, norm=True, use_tr=0)
+        run(K.check_conv1x1, dt, 2, 1000, 16, 48, with_coef=True)
+        run(K.check_conv1x1, dt, 1, 300, 128, 384, with_coef=False)
+        run(K.check_convT, dt, 2, (4, 6, 8), 32)
+        run(K.check_convT, dt, 1, (2, 2, 2), 256)
+        run(K.check_norm_pool_head, dt)
+    if a.net:
+        for dtype in (torch.float32, torch.bfloat16):
+            run(K.check_network, dtype, None, None, None, golden=gr)
+            run(K.check_network, dtype, [16, 32, 64, 128, 256], (32, 32, 32), 1, seed=3)
+    lines = []
+    nbad = 0
+    for r in rows:
+        nbad += 0 if r["ok"] else 1
+        lines.append("%-4s %-78s err=%.3e tol=%.1e %s" % ("ok" if r["ok"] else "FAIL", r["name"], r["err"], r["tol"], r.get("extra", "")))
+    lines.append(f"{len(rows) - nbad}/{len(rows)} checks passed")
+    text = "\n".join(lines)
+    print(text)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        open(a.out, "w").write(text + "\n")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,569 @@
+"""Parity checks of every C-ABI kernel against plain PyTorch CPU fp32 / the oracle.
+
+Each ``check_*`` returns a list of result dicts ``{name, err, tol, ok}`` so that the same code serves the
+pytest suite (asserts) and ``tests/gpu_diag.py`` (prints a full table without stopping at the first
+failure - useful on the GPU box where a call costs minutes).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from biapy_amd import _lib as L
+from biapy_amd import tiling
+from biapy_amd.engine import NetConfig, ResUNetEngine
+from oracle import net_oracle
+from oracle import tiling_oracle as TO
+
+lib = L.lib
+DEV = "cuda"
+
+
+def _res(name, err, tol, extra=""):
+    return dict(name=name, err=float(err), tol=float(tol), ok=bool(err <= tol), extra=extra)
+
+
+def tdtype(dt):
+    return torch.bfloat16 if dt == L.BF16 else torch.float32
+
+
+def rnd(t, dt):
+    """Round an fp32 CPU tensor to the storage dtype and back (what the device actually holds)."""
+    return t.to(tdtype(dt)).float()
+
+
+def to_dev(t, dt):
+    return t.to(tdtype(dt)).to(DEV).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def tol_for(dt):
+    return 1.5e-2 if dt == L.BF16 else 2e-5
+
+
+def ncdhw(t):  # (B,D,H,W,C) -> (B,C,D,H,W)
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def ndhwc(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def pack(w, mode, cin, cout, dt):
+    n = lib.bpx_packed_weight_elems(mode, cin, cout, dt)
+    out = torch.empty(n, dtype=tdtype(dt), device=DEV)
+    wd = w.float().contiguous().to(DEV)
+    L.check(lib.bpx_pack_weight(mode, wd.data_ptr(), cin, cout, dt, out.data_ptr(), L.stream_ptr()))
+    return out
+
+
+def make_recs(B, Cc, seed):
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.randn(B, Cc, generator=g) * 0.3
+    rstd = 0.5 + torch.rand(B, Cc, generator=g)
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.2 * torch.randn(Cc, generator=g)
+    scale = gamma[None] * rstd
+    shift = beta[None] - mean * scale
+    rec = torch.stack([mean, rstd, scale, shift], -1).contiguous()
+    return rec, gamma, beta
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_selftest():
+    out = torch.zeros(1024, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_selftest_layouts(out.data_ptr(), L.stream_ptr()))
+    o = out.cpu().numpy()
+    res = []
+    i = np.arange(16)[:, None]
+    for blk, K in ((0, 32), (1, 16)):
+        k = np.arange(K)
+        A = ((3 * i + 5 * k[None, :]) % 7 - 3).astype(np.float64)
+        Bm = ((2 * k[:, None] + 7 * np.arange(16)[None, :]) % 5 - 2).astype(np.float64)
+        ref = A @ Bm
+        got = o[blk * 256:(blk + 1) * 256].reshape(16, 16)
+        res.append(_res(f"mfma_layout_{'bf16_16x16x32' if blk == 0 else 'f32_16x16x4'}", np.abs(got - ref).max(), 0.0))
+    tr = o[512:].reshape(64, 8)
+    lane = np.arange(64)
+    exp = ((8 * (lane >> 4))[:, None] + np.arange(8)[None, :]) * 16 + (lane & 15)[:, None]
+    bad = int((tr != exp).sum())
+    extra = ""
+    if bad:
+        extra = "lane0=%s lane1=%s lane5=%s lane17=%s" % (tr[0].tolist(), tr[1].tolist(), tr[5].tolist(), tr[17].tolist())
+    res.append(_res("ds_read_tr16_b64_layout", bad, 0, extra))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_tiling(golden):
+    res = []
+    from make_golden import synth_pred, synth_volume
+
+    for name in ["m48", "m_odd", "m_pad", "m_zeros", "m_median"]:
+        a = golden[f"data/{name}/args"]
+        vshape, pshape, pad, med = tuple(int(v) for v in a[0:4]), tuple(int(v) for v in a[4:8]), tuple(int(v) for v in a[8:11]), bool(a[11])
+        ov = tuple(float(v) for v in golden[f"data/{name}/overlap"])
+        seed = int(golden[f"data/{name}/seed"])
+        pad_type = str(golden[f"data/{name}/pad_type"])
+        vol, mask = synth_volume(seed, vshape)
+        p, pm, coords = tiling.crop_3D_data_with_overlap(vol, pshape, data_mask=mask, overlap=ov, padding=pad, verbose=False,
+                                                         median_padding=med, pad_type=pad_type)
+        cref = golden[f"data/{name}/coords"]
+        cgot = np.array([[c.z_start, c.z_end, c.y_start, c.y_end, c.x_start, c.x_end] for c in coords])
+        e = int((cgot != cref).sum())
+        e += int((p[0] != golden[f"data/{name}/patch0"]).sum()) + int((p[-1] != golden[f"data/{name}/patch_last"]).sum())
+        e += int((pm[-1] != golden[f"data/{name}/mask_patch_last"]).sum())
+        crc = int(np.frombuffer(p.tobytes(), dtype=np.uint8).astype(np.uint64).sum())
+        e += int(crc != int(golden[f"data/{name}/patches_crc"][0]))
+        res.append(_res(f"crop_dropin[{name}]", e, 0))
+        pred = synth_pred(seed, p.shape)
+        merged, merged_mask = tiling.merge_3D_data_with_overlap(pred, vshape, data_mask=pm, overlap=ov, padding=pad, verbose=False)
+        e = int((merged.view(np.uint32) != golden[f"data/{name}/merged"].view(np.uint32)).sum())
+        res.append(_res(f"merge_dropin_f32_bits[{name}]", e, 0))
+        res.append(_res(f"merge_dropin_u8mask[{name}]", int((merged_mask != golden[f"data/{name}/merged_mask"]).sum()), 0))
+    for lab in (1, 2, 3, 5, 255):
+        pm = np.full((27, 32, 32, 32, 1), lab, dtype=np.uint8)
+        pd = np.ones((27, 32, 32, 32, 1), dtype=np.float32)
+        _, mm = tiling.merge_3D_data_with_overlap(pd, (48, 48, 48, 1), data_mask=pm, overlap=(0.5, 0.5, 0.5), verbose=False)
+        res.append(_res(f"merge_label_truncation[{lab}]", int((mm != golden[f"label/{lab}/merged_mask"]).sum()), 0))
+    # float16 patches (TEST.REDUCE_MEMORY) vs the oracle
+    rs = np.random.RandomState(5)
+    p16 = rs.rand(27, 32, 32, 32, 2).astype(np.float16)
+    m_ref = TO.merge(p16, (48, 48, 48, 2), overlap=(0.5, 0.5, 0.5))
+    m_got = tiling.merge_3D_data_with_overlap(p16, (48, 48, 48, 2), overlap=(0.5, 0.5, 0.5), verbose=False)
+    res.append(_res("merge_f16", int((m_got.view(np.uint16) != m_ref.view(np.uint16)).sum()), 0))
+    return res
+
+
+def check_merge_sharded():
+    """Two Z-slabs with the boundary partial sums handed over must equal the single-device merge bit for bit."""
+    rs = np.random.RandomState(11)
+    vshape, pshape, ov = (72, 40, 40, 1), (32, 32, 32, 1), (0.5, 0.5, 0.5)
+    vol = rs.rand(*vshape).astype(np.float32)
+    p, coords = TO.crop(vol, pshape, ov)
+    pred = rs.rand(*p.shape).astype(np.float32)
+    ref = TO.merge(pred, vshape, overlap=ov)
+    plan = tiling.MergePlan(vshape[:3], pshape[:3], ov, (0, 0, 0), torch.device(DEV))
+    nz, ny, nx = plan.grid[0].n, plan.grid[1].n, plan.grid[2].n
+    t = torch.from_numpy(pred).to(DEV)
+    full = tiling.merge_device(t, plan).cpu().numpy()
+    res = [_res("merge_device_vs_oracle", int((full.view(np.uint32) != ref.view(np.uint32)).sum()), 0)]
+    # rank 0 owns patch rows [0,h), rank 1 rows [h,nz)
+    h = nz // 2
+    z_split = plan.row_start(h)                      # first slice touched by rank 1's patches
+    z0_hi = plan.row_start(h - 1) + pshape[0]        # one past the last slice touched by rank 0
+    r0 = t[: h * ny * nx].contiguous()
+    r1 = t[h * ny * nx:].contiguous()
+    out = np.empty(vshape, np.float32)
+    out[:z_split] = tiling.merge_device(r0, plan, z_lo=0, z_hi=z_split, zrow_lo=0, zrow_hi=h).cpu().numpy()
+    nb = z0_hi - z_split
+    acc = torch.zeros((nb, vshape[1], vshape[2], 1), dtype=torch.float32, device=DEV)
+    wacc = torch.zeros((nb, vshape[1], vshape[2], 1), dtype=torch.float32, device=DEV)
+    tiling.merge_device(r0, plan, z_lo=z_split, z_hi=z0_hi, zrow_lo=0, zrow_hi=h, acc=acc, wacc=wacc, write_partial=True)
+    # (acc, wacc) is what travels over xGMI; rank 1 seeds its boundary with it
+    out[z_split:z0_hi] = tiling.merge_device(r1, plan, z_lo=z_split, z_hi=z0_hi, zrow_lo=h, zrow_hi=nz, acc=acc, wacc=wacc, seed=True).cpu().numpy()
+    out[z0_hi:] = tiling.merge_device(r1, plan, z_lo=z0_hi, z_hi=vshape[0], zrow_lo=h, zrow_hi=nz).cpu().numpy()
+    res.append(_res("merge_two_slabs_bit_exact", int((out.view(np.uint32) != ref.view(np.uint32)).sum()), 0))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+def _act_ref(u, act):
+    return {0: lambda v: v, 1: lambda v: F.elu(v), 2: F.relu, 3: F.silu}[act](u)
+
+
+def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=0, act=1):
+    D, H, W = S
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    rec = None
+    a = x
+    if norm:
+        rec, _, _ = make_recs(B, Cin, seed + 1)
+        a = rnd(_act_ref(x * rec[:, None, None, None, :, 2] + rec[:, None, None, None, :, 3], act), dt)
+    y_ref = F.conv3d(ncdhw(a), rnd(w, dt), b, padding=1)
+    sc = wsc = bsc = None
+    if sc_C:
+        if sc_C == 1:
+            sc = torch.randn(B, D, H, W, generator=g)
+            wsc = torch.randn(Cout, 1, 1, 1, 1, generator=g)
+            bsc = torch.randn(Cout, generator=g) * 0.1
+            y_ref = y_ref + sc[:, None] * wsc.view(1, Cout, 1, 1, 1) + bsc.view(1, Cout, 1, 1, 1)
+        else:
+            sc = rnd(torch.randn(B, D, H, W, sc_C, generator=g), dt)
+            wsc = torch.randn(Cout, sc_C, 1, 1, 1, generator=g) / sc_C ** 0.5
+            bsc = torch.randn(Cout, generator=g) * 0.1
+            y_ref = y_ref + F.conv3d(ncdhw(sc), rnd(wsc, dt), bsc)
+    # device buffers (optionally channel slices of wider buffers)
+    xo, yo = (16, 32) if slices else (0, 0)
+    xb = torch.zeros(B, D, H, W, Cin + 2 * xo, dtype=tdtype(dt), device=DEV)
+    xb[..., xo:xo + Cin] = to_dev(x, dt)
+    yb = torch.full((B, D, H, W, Cout + 2 * yo), 7.0, dtype=tdtype(dt), device=DEV)
+    wp = pack(w, L.PK_K3, Cin, Cout, dt)
+    tiles = lib.bpx_conv3d_stats_tiles(dt, D, H, W, Cout)
+    part = torch.zeros(B, tiles, 2, Cout, dtype=torch.float32, device=DEV)
+    recd = rec.to(DEV) if rec is not None else None
+    bd = b.to(DEV)
+    sct, wscp, bscd = L.NULL_T, None, None
+    keep = []
+    if sc_C == 1:
+        scd = sc.to(DEV).contiguous(); wscd = wsc.to(DEV).contiguous(); bscd = bsc.to(DEV)
+        sct, wscp = L.Tensor(scd.data_ptr(), 1, 1), wscd.data_ptr()
+        keep += [scd, wscd]
+    elif sc_C:
+        scd = to_dev(sc, dt); wpk = pack(wsc, L.PK_K1, sc_C, Cout, dt); bscd = bsc.to(DEV)
+        sct, wscp = L.tview(scd), wpk.data_ptr()
+        keep += [scd, wpk]
+    L.check(lib.bpx_conv3d_fwd(dt, B, D, H, W, L.tview(xb, xo, Cin), L.ptr(recd), act if norm else 0, wp.data_ptr(), bd.data_ptr(), sct, wscp,
+                               L.ptr(bscd), L.tview(yb, yo, Cout), part.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    y = ndhwc(y_ref)
+    got = yb[..., yo:yo + Cout].float().cpu()
+    tag = f"conv3d_fwd[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} {Cin}->{Cout} norm={int(norm)} sc={sc_C} sl={int(slices)}]"
+    res = [_res(tag, relerr(got, y), tol_for(dt))]
+    if slices:
+        untouched = (yb[..., :yo].float() == 7).all().item() and (yb[..., yo + Cout:].float() == 7).all().item()
+        res.append(_res(tag + ".neighbours_untouched", 0 if untouched else 1, 0))
+    s = part.sum(1).cpu()
+    s_ref = torch.stack([y.sum((1, 2, 3)), (y * y).sum((1, 2, 3))], 1)
+    res.append(_res(tag + ".stats", relerr(s, s_ref), 5e-3 if dt == L.BF16 else 1e-4))
+    return res
+
+
+def check_conv3d_dgrad(dt, B, S, Cin, Cout, seed=0, act=1):
+    """g = conv_transpose(dy, W) * act'(scale*t+shift) and its two reductions."""
+    D, H, W = S
+    g = torch.Generator().manual_seed(seed)
+    dy = rnd(torch.randn(B, D, H, W, Cout, generator=g), dt)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cout) ** 0.5
+    t = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    rec, _, _ = make_recs(B, Cin, seed + 1)
+    dA = F.conv_transpose3d(ncdhw(dy), rnd(w, dt), padding=1)
+    u = t * rec[:, None, None, None, :, 2] + rec[:, None, None, None, :, 3]
+    dact = {1: torch.where(u > 0, torch.ones_like(u), torch.exp(u)), 2: (u > 0).float()}[act]
+    g_ref = ndhwc(dA) * dact
+    xh = (t - rec[:, None, None, None, :, 0]) * rec[:, None, None, None, :, 1]
+    gd = torch.empty(B, D, H, W, Cin, dtype=tdtype(dt), device=DEV)
+    tiles = lib.bpx_conv3d_stats_tiles(dt, D, H, W, Cin)
+    red = torch.zeros(B, tiles, 2, Cin, dtype=torch.float32, device=DEV)
+    wp = pack(w, L.PK_K3_T, Cin, Cout, dt)
+    dyd, td, recd = to_dev(dy, dt), to_dev(t, dt), rec.to(DEV)
+    L.check(lib.bpx_conv3d_dgrad(dt, B, D, H, W, L.tview(dyd), wp.data_ptr(), L.tview(td), recd.data_ptr(), act, L.tview(gd), red.data_ptr(),
+                                 L.stream_ptr()))
+    torch.cuda.synchronize()
+    tag = f"conv3d_dgrad[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} dy{Cout}->g{Cin}]"
+    res = [_res(tag, relerr(gd, g_ref), tol_for(dt))]
+    s = red.sum(1).cpu()
+    s_ref = torch.stack([g_ref.sum((1, 2, 3)), (g_ref * xh).sum((1, 2, 3))], 1)
+    res.append(_res(tag + ".reductions", relerr(s, s_ref), 1e-2 if dt == L.BF16 else 1e-4))
+    # plain dgrad (no activation / statistics)
+    g2 = torch.empty_like(gd)
+    L.check(lib.bpx_conv3d_dgrad(dt, B, D, H, W, L.tview(dyd), wp.data_ptr(), L.NULL_T, None, 0, L.tview(g2), None, L.stream_ptr()))
+    res.append(_res(tag + ".plain", relerr(g2, ndhwc(dA)), tol_for(dt)))
+    return res
+
+
+def check_conv3d_wgrad(dt, B, S, Cin, Cout, k=3, norm=True, use_tr=1, seed=0, act=1):
+    D, H, W = S
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    dy = rnd(torch.randn(B, D, H, W, Cout, generator=g), dt)
+    rec = None
+    a = x
+    if norm:
+        rec, _, _ = make_recs(B, Cin, seed + 1)
+        a = rnd(_act_ref(x * rec[:, None, None, None, :, 2] + rec[:, None, None, None, :, 3], act), dt)
+    an = ncdhw(a).requires_grad_(False)
+    wz = torch.zeros(Cout, Cin, k, k, k, requires_grad=True)
+    bz = torch.zeros(Cout, requires_grad=True)
+    out = F.conv3d(an, wz, bz, padding=k // 2)
+    out.backward(ncdhw(dy))
+    dw = torch.zeros(Cout, Cin, k, k, k, dtype=torch.float32, device=DEV)
+    db = torch.zeros(Cout, dtype=torch.float32, device=DEV)
+    xd, dyd = to_dev(x, dt), to_dev(dy, dt)
+    recd = rec.to(DEV) if rec is not None else None
+    lib.bpx_debug_set_wgrad_tr(use_tr)
+    L.check(lib.bpx_conv3d_wgrad(dt, B, D, H, W, L.tview(xd), L.ptr(recd), act if norm else 0, L.tview(dyd), k, dw.data_ptr(), db.data_ptr(),
+                                 L.stream_ptr()))
+    torch.cuda.synchronize()
+    lib.bpx_debug_set_wgrad_tr(1)
+    tag = f"conv3d_wgrad[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} {Cin}->{Cout} k{k} norm={int(norm)} tr={use_tr}]"
+    return [_res(tag, relerr(dw, wz.grad), 2e-3 if dt == L.BF16 else 2e-5), _res(tag + ".bias", relerr(db, bz.grad), 2e-3 if dt == L.BF16 else 2e-5)]
+
+
+def check_conv1x1(dt, B, vox, Cin, Cout, with_coef=True, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, vox, Cin, generator=g), dt)
+    w = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5           # y = x @ w.T ; dense mode packs W[co][ci]
+    gg = rnd(torch.randn(B, vox, Cout, generator=g), dt)
+    tt = rnd(torch.randn(B, vox, Cout, generator=g), dt)
+    add = rnd(torch.randn(B, vox, Cout, generator=g), dt)
+    coef = torch.randn(B, Cout, 4, generator=g)
+    y_ref = x @ rnd(w, dt).t()
+    if with_coef:
+        y_ref = y_ref + coef[:, None, :, 0] * gg + coef[:, None, :, 1] * tt + coef[:, None, :, 2] + add
+    wp = pack(w.view(Cout, Cin, 1, 1, 1), L.PK_DENSE, Cin, Cout, dt)
+    y = torch.empty(B, vox, Cout, dtype=tdtype(dt), device=DEV)
+    xd, gd, td, ad, cd = to_dev(x, dt), to_dev(gg, dt), to_dev(tt, dt), to_dev(add, dt), coef.to(DEV)
+    if with_coef:
+        L.check(lib.bpx_conv1x1_fwd(dt, B, vox, L.tview(xd), wp.data_ptr(), None, L.tview(gd), L.tview(td), cd.data_ptr(), L.tview(ad), L.tview(y),
+                                    L.stream_ptr()))
+    else:
+        L.check(lib.bpx_conv1x1_fwd(dt, B, vox, L.tview(xd), wp.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(y), L.stream_ptr()))
+    torch.cuda.synchronize()
+    tag = f"conv1x1[{'bf16' if dt == L.BF16 else 'f32'} B{B} v{vox} {Cin}->{Cout} coef={int(with_coef)}]"
+    res = [_res(tag, relerr(y, y_ref), tol_for(dt))]
+    # the transposed (dgrad) packing: dx = dy @ W
+    wpt = pack(w.view(Cout, Cin, 1, 1, 1), L.PK_DENSE_T, Cin, Cout, dt)
+    dy = rnd(torch.randn(B, vox, Cout, generator=g), dt)
+    dx = torch.empty(B, vox, Cin, dtype=tdtype(dt), device=DEV)
+    dyd = to_dev(dy, dt)
+    L.check(lib.bpx_conv1x1_fwd(dt, B, vox, L.tview(dyd), wpt.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(dx), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".dgrad_pack", relerr(dx, dy @ rnd(w, dt)), tol_for(dt)))
+    return res
+
+
+def check_convT(dt, B, S, Cc, seed=0):
+    D, H, W = S
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
+    w = torch.randn(Cc, Cc, 2, 2, 2, generator=g) / Cc ** 0.5
+    b = torch.randn(Cc, generator=g) * 0.1
+    xr = ncdhw(x).requires_grad_(True)
+    wr = rnd(w, dt).requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = F.conv_transpose3d(xr, wr, br, stride=2)
+    dy = rnd(torch.randn(B, 2 * D, 2 * H, 2 * W, Cc, generator=g), dt)
+    y_ref.backward(ncdhw(dy))
+    tag = f"convT[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc}]"
+    # forward into a channel slice of a concat buffer
+    extra = 16
+    yb = torch.full((B, 2 * D, 2 * H, 2 * W, Cc + extra), 3.0, dtype=tdtype(dt), device=DEV)
+    wp = pack(w, L.PK_CT, Cc, Cc, dt)
+    tiles = lib.bpx_convT3d_stats_tiles(D, H, W)
+    part = torch.zeros(B, tiles, 2, Cc, dtype=torch.float32, device=DEV)
+    xd, bd = to_dev(x, dt), b.to(DEV)
+    L.check(lib.bpx_convT3d_k2s2_fwd(dt, B, D, H, W, L.tview(xd), wp.data_ptr(), bd.data_ptr(), L.tview(yb, 0, Cc), part.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    y = ndhwc(y_ref.detach())
+    res = [_res(tag + ".fwd", relerr(yb[..., :Cc], y), tol_for(dt))]
+    res.append(_res(tag + ".fwd.neighbours_untouched", 0 if (yb[..., Cc:].float() == 3).all().item() else 1, 0))
+    s_ref = torch.stack([y.sum((1, 2, 3)), (y * y).sum((1, 2, 3))], 1)
+    res.append(_res(tag + ".stats", relerr(part.sum(1), s_ref), 5e-3 if dt == L.BF16 else 1e-4))
+    # dgrad
+    wpt = pack(w, L.PK_CT_T, Cc, Cc, dt)
+    dyd = to_dev(dy, dt)
+    dx = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
+    L.check(lib.bpx_convT3d_k2s2_dgrad(dt, B, D, H, W, L.tview(dyd), wpt.data_ptr(), L.tview(dx), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".dgrad", relerr(dx, ndhwc(xr.grad)), tol_for(dt)))
+    # wgrad
+    dw = torch.zeros(Cc, Cc, 2, 2, 2, dtype=torch.float32, device=DEV)
+    db = torch.zeros(Cc, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".wgrad", relerr(dw, wr.grad), 2e-3 if dt == L.BF16 else 2e-5))
+    res.append(_res(tag + ".bgrad", relerr(db, br.grad), 2e-3 if dt == L.BF16 else 2e-5))
+    return res
+
+
+def check_norm_pool_head(dt, seed=0):
+    res = []
+    g = torch.Generator().manual_seed(seed)
+    B, D, H, W, Cc = 2, 8, 12, 16, 32
+    tagd = "bf16" if dt == L.BF16 else "f32"
+    x = rnd(torch.randn(B, D, H, W, Cc, generator=g) * 2 + 0.5, dt)
+    xd = to_dev(x, dt)
+    # tensor_stats + finalize == instance norm statistics
+    vox = D * H * W
+    tiles = lib.bpx_tensor_stats_tiles(vox)
+    part = torch.zeros(B, tiles, 2, Cc, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_tensor_stats(dt, B, vox, L.tview(xd), part.data_ptr(), L.stream_ptr()))
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g)); beta = 0.1 * torch.randn(Cc, generator=g)
+    rec = torch.zeros(B, Cc, 4, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, Cc, vox, gamma.to(DEV).data_ptr(), beta.to(DEV).data_ptr(), 1e-5, Cc, rec.data_ptr(), Cc, 0,
+                                  L.stream_ptr()))
+    torch.cuda.synchronize()
+    xf = x.reshape(B, vox, Cc)
+    mean = xf.mean(1); var = xf.var(1, unbiased=False); rstd = (var + 1e-5).rsqrt()
+    ref = torch.stack([mean, rstd, gamma[None] * rstd, beta[None] - mean * gamma[None] * rstd], -1)
+    res.append(_res(f"norm_finalize[{tagd}]", relerr(rec, ref), 1e-5))
+    # max pool fwd + stats
+    y = torch.empty(B, D // 2, H // 2, W // 2, Cc, dtype=tdtype(dt), device=DEV)
+    pt = lib.bpx_maxpool3d_stats_tiles(dt, D, H, W, Cc)
+    ppart = torch.zeros(B, pt, 2, Cc, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_maxpool3d_fwd(dt, B, D, H, W, L.tview(xd), L.tview(y), ppart.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    xr = ncdhw(x).requires_grad_(True)
+    y_ref = F.max_pool3d(xr, 2)
+    res.append(_res(f"maxpool_fwd[{tagd}]", relerr(y, ndhwc(y_ref.detach())), 0.0))
+    yr = ndhwc(y_ref.detach())
+    res.append(_res(f"maxpool_stats[{tagd}]", relerr(ppart.sum(1), torch.stack([yr.sum((1, 2, 3)), (yr * yr).sum((1, 2, 3))], 1)), 1e-4))
+    # max pool bwd with addend (ties are likely in bf16: first maximum must win as in PyTorch)
+    dy = rnd(torch.randn(B, D // 2, H // 2, W // 2, Cc, generator=g), dt)
+    add = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
+    y_ref.backward(ncdhw(dy))
+    dx = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
+    L.check(lib.bpx_maxpool3d_bwd(dt, B, D, H, W, L.tview(xd), L.tview(to_dev(dy, dt)), L.tview(to_dev(add, dt)), L.tview(dx), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"maxpool_bwd[{tagd}]", relerr(dx, rnd(ndhwc(xr.grad) + add, dt)), 1e-6))
+    # norm backward: finalize + apply == autograd of instance norm
+    t = x
+    tn = ncdhw(t).requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True); bt = beta.clone().requires_grad_(True)
+    out = F.instance_norm(tn, None, None, gm, bt, True, 0.1, 1e-5)
+    gsig = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)      # g = dL/d(norm output)
+    out.backward(ncdhw(gsig))
+    xh = (t - ref[:, None, None, None, :, 0]) * ref[:, None, None, None, :, 1]
+    red = torch.stack([gsig.sum((1, 2, 3)), (gsig * xh).sum((1, 2, 3))], 1).view(B, 1, 2, Cc).contiguous().to(DEV)
+    coef = torch.zeros(B, Cc, 4, dtype=torch.float32, device=DEV)
+    dgm = torch.zeros(Cc, dtype=torch.float32, device=DEV); dbt = torch.zeros(Cc, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, 1, Cc, vox, rec.data_ptr(), gamma.to(DEV).data_ptr(), dgm.data_ptr(), dbt.data_ptr(),
+                                      coef.data_ptr(), L.stream_ptr()))
+    dxn = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
+    L.check(lib.bpx_norm_bwd_apply(dt, B, vox, L.tview(to_dev(gsig, dt)), L.tview(xd), coef.data_ptr(), L.NULL_T, L.tview(dxn), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"norm_bwd_dx[{tagd}]", relerr(dxn, ndhwc(tn.grad)), 2e-2 if dt == L.BF16 else 1e-4))
+    res.append(_res(f"norm_bwd_dgamma[{tagd}]", relerr(dgm, gm.grad), 1e-4))
+    res.append(_res(f"norm_bwd_dbeta[{tagd}]", relerr(dbt, bt.grad), 1e-4))
+    # head fwd/bwd
+    Cf, Co = 16, 2
+    f = rnd(torch.randn(B, D, H, W, Cf, generator=g), dt)
+    hw = torch.randn(Co, Cf, generator=g) * 0.3; hb = torch.randn(Co, generator=g) * 0.1
+    fr = ncdhw(f).requires_grad_(True); hwr = hw.clone().requires_grad_(True); hbr = hb.clone().requires_grad_(True)
+    lo_ref = F.conv3d(fr, hwr.view(Co, Cf, 1, 1, 1), hbr)
+    fd = to_dev(f, dt)
+    lo = torch.empty(B, Co, D, H, W, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_head_fwd(dt, vox, B, L.tview(fd), hw.to(DEV).data_ptr(), hb.to(DEV).data_ptr(), Co, 0, lo.data_ptr(), Co * vox, vox, L.stream_ptr()))
+    pr = torch.empty_like(lo)
+    L.check(lib.bpx_head_fwd(dt, vox, B, L.tview(fd), hw.to(DEV).data_ptr(), hb.to(DEV).data_ptr(), Co, 1, pr.data_ptr(), Co * vox, vox, L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"head_fwd[{tagd}]", relerr(lo, lo_ref.detach()), 1e-5))
+    res.append(_res(f"head_fwd_sigmoid[{tagd}]", relerr(pr, torch.sigmoid(lo_ref.detach())), 1e-5))
+    dlo = torch.randn(B, Co, D, H, W, generator=g)
+    lo_ref.backward(dlo)
+    dfe = torch.empty(B, D, H, W, Cf, dtype=tdtype(dt), device=DEV)
+    dhw = torch.zeros(Co, Cf, dtype=torch.float32, device=DEV); dhb = torch.zeros(Co, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_head_bwd(dt, vox, B, L.tview(fd), hw.to(DEV).data_ptr(), Co, dlo.to(DEV).data_ptr(), Co * vox, vox, L.tview(dfe), dhw.data_ptr(),
+                             dhb.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"head_bwd_dx[{tagd}]", relerr(dfe, ndhwc(fr.grad)), tol_for(dt)))
+    res.append(_res(f"head_bwd_dw[{tagd}]", relerr(dhw, hwr.grad), 1e-4))
+    res.append(_res(f"head_bwd_db[{tagd}]", relerr(dhb, hbr.grad), 1e-4))
+    # Cin = 1 first layer
+    img = torch.randn(B, D, H, W, generator=g)
+    w1 = torch.randn(16, 1, 3, 3, 3, generator=g) * 0.2; b1 = torch.randn(16, generator=g) * 0.1
+    w1r = w1.clone().requires_grad_(True); b1r = b1.clone().requires_grad_(True)
+    y1_ref = F.conv3d(img[:, None], w1r, b1r, padding=1)
+    y1 = torch.empty(B, D, H, W, 16, dtype=tdtype(dt), device=DEV)
+    t1 = lib.bpx_conv3d_c1_stats_tiles(D, H, W)
+    p1 = torch.zeros(B, t1, 2, 16, dtype=torch.float32, device=DEV)
+    imgd = img.to(DEV).contiguous()
+    L.check(lib.bpx_conv3d_c1_fwd(dt, B, D, H, W, imgd.data_ptr(), w1.to(DEV).data_ptr(), b1.to(DEV).data_ptr(), L.tview(y1), p1.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    yr1 = ndhwc(y1_ref.detach())
+    res.append(_res(f"conv_c1_fwd[{tagd}]", relerr(y1, yr1), 4e-3 if dt == L.BF16 else 1e-5))
+    res.append(_res(f"conv_c1_stats[{tagd}]", relerr(p1.sum(1), torch.stack([yr1.sum((1, 2, 3)), (yr1 * yr1).sum((1, 2, 3))], 1)), 1e-4))
+    dy1 = rnd(torch.randn(B, D, H, W, 16, generator=g), dt)
+    y1_ref.backward(ncdhw(dy1))
+    dw1 = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float32, device=DEV); db1 = torch.zeros(16, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_conv3d_c1_wgrad(dt, B, D, H, W, imgd.data_ptr(), L.tview(to_dev(dy1, dt)), dw1.data_ptr(), db1.data_ptr(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"conv_c1_wgrad[{tagd}]", relerr(dw1, w1r.grad), 1e-4))
+    res.append(_res(f"conv_c1_bgrad[{tagd}]", relerr(db1, b1r.grad), 1e-4))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
+    """Whole network vs the oracle: logits, Dice, loss and every parameter gradient."""
+    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+    if golden is not None:
+        sd = {k[len("small/sd/"):]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("small/sd/")}
+        x = torch.from_numpy(golden["small/x"]).permute(0, 4, 1, 2, 3).contiguous()
+        tgt = torch.from_numpy(golden["small/target"]).float()
+        fm = [int(v) for v in golden["small/feature_maps"]]
+    else:
+        sd = net_oracle.init_state_dict(1, fm, seed=seed)
+        g = torch.Generator().manual_seed(seed + 7)
+        x = torch.randn(B, 1, *patch, generator=g)
+        tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).float()
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm), dtype)
+    P = {k: v.to(DEV) for k, v in sd.items()}
+    xd = x.to(DEV)
+    logits, ctx = eng.forward(P, xd, head_act=0, save=train)
+    torch.cuda.synchronize()
+    tag = f"resunet[{tagd} fm={fm} {tuple(x.shape)}{' golden' if golden is not None else ''}]"
+    res = []
+    if golden is not None:
+        lo_ref = torch.from_numpy(golden["small/logits"])
+    else:
+        lo_ref = net_oracle.resunet_forward(sd, x, fm)
+    scale = lo_ref.abs().max().item()
+    err = (logits.cpu() - lo_ref).abs().max().item() / scale
+    res.append(_res(tag + ".logits_rel", err, 6e-2 if dtype == torch.bfloat16 else 2e-4, extra=f"scale={scale:.3f}"))
+    # Dice parity: both predictions against the same target (north_star: |delta| < 1e-4 ... stated here per mode)
+    d_ref = net_oracle.dice(torch.sigmoid(lo_ref), tgt)
+    d_got = net_oracle.dice(torch.sigmoid(logits.cpu()), tgt)
+    agree = net_oracle.dice(torch.sigmoid(logits.cpu()), (torch.sigmoid(lo_ref) > 0.5).float())
+    res.append(_res(tag + ".dice_delta", abs(d_ref - d_got), 1e-4 if dtype == torch.float32 else 5e-3, extra=f"dice_ref={d_ref:.6f} dice_got={d_got:.6f}"))
+    res.append(_res(tag + ".label_disagreement", 1 - agree, 1e-4 if dtype == torch.float32 else 3e-2))
+    if not train:
+        return res
+    lg = logits.detach().clone().requires_grad_(True)
+    loss = F.binary_cross_entropy_with_logits(lg, tgt.to(DEV))
+    loss.backward()
+    G = eng.backward(P, ctx, lg.grad)
+    torch.cuda.synchronize()
+    loss_ref, _, grads_ref = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm)
+    res.append(_res(tag + ".loss", abs(loss.item() - loss_ref.item()), 2e-2 if dtype == torch.bfloat16 else 1e-5))
+    worst, worst_name = 0.0, ""
+    gtol = 0.12 if dtype == torch.bfloat16 else 2e-3
+    for k, gr in grads_ref.items():
+        gg = G[k].cpu()
+        denom = gr.norm().item()
+        e = (gg - gr).norm().item() / (denom + 1e-6 * max(1.0, gr.numel() ** 0.5))
+        if denom < 1e-7:      # biases in front of an InstanceNorm: the true gradient is exactly zero
+            e = (gg - gr).abs().max().item() / 1e-3
+        if e > worst:
+            worst, worst_name = e, k
+    res.append(_res(tag + ".grads_rel_l2_worst", worst, gtol, extra=worst_name))
+    return res
+
+
+def all_kernel_checks(golden_tiling=None, quick=False):
+    out = []
+    out += check_selftest()
+    if golden_tiling is not None:
+        out += check_tiling(golden_tiling)
+    out += check_merge_sharded()
+    for dt in (L.F32, L.BF16):
+        out += check_conv3d_fwd(dt, 2, (8, 8, 16), 16, 16, norm=True, sc_C=0)
+        out += check_conv3d_fwd(dt, 1, (8, 12, 20), 48, 16, norm=True, sc_C=48, slices=True)
+        out += check_conv3d_fwd(dt, 2, (6, 8, 8), 32, 64, norm=False, sc_C=1)
+        out += check_conv3d_fwd(dt, 1, (4, 4, 8), 64, 128, norm=True, sc_C=64)
+        out += check_conv3d_fwd(dt, 1, (32, 32, 32), 16, 32, norm=True, sc_C=16)
+        out += check_conv3d_dgrad(dt, 2, (8, 8, 16), 48, 16)
+        out += check_conv3d_dgrad(dt, 1, (4, 8, 8), 32, 64)
+        out += check_conv3d_wgrad(dt, 2, (8, 8, 16), 16, 16, k=3, norm=True)
+        out += check_conv3d_wgrad(dt, 1, (8, 12, 20), 48, 32, k=3, norm=True)
+        out += check_conv3d_wgrad(dt, 1, (4, 8, 8), 64, 64, k=3, norm=False)
+        out += check_conv3d_wgrad(dt, 2, (8, 8, 16), 48, 16, k=1, norm=False)
+        if dt == L.BF16:
+            out += check_conv3d_wgrad(dt, 2, (8, 8, 16), 16, 16, k=3, norm=True, use_tr=0)
+        out += check_conv1x1(dt, 2, 1000, 16, 48, with_coef=True)
+        out += check_conv1x1(dt, 1, 300, 128, 384, with_coef=False)
+        out += check_convT(dt, 2, (4, 6, 8), 32)
+        out += check_convT(dt, 1, (2, 2, 2), 256)
+        out += check_norm_pool_head(dt)
+    return out

@@ -1,0 +1,99 @@
+"""GPU parity tests: every C-ABI kernel and the whole network against the oracle (run with -m gpu)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_all(rows):
+    bad = [r for r in rows if not r["ok"]]
+    assert not bad, "\n".join("%s err=%.3e tol=%.1e %s" % (r["name"], r["err"], r["tol"], r.get("extra", "")) for r in bad)
+
+
+@pytest.fixture(scope="module")
+def K():
+    import kernel_checks
+
+    return kernel_checks
+
+
+def test_lane_layouts(K):
+    _assert_all(K.check_selftest())
+
+
+def test_tiling_dropins_bit_exact(K, tiling_golden):
+    _assert_all(K.check_tiling(tiling_golden))
+
+
+def test_merge_two_slabs_bit_exact(K):
+    _assert_all(K.check_merge_sharded())
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
+def test_conv3d_fwd(K, dt):
+    rows = []
+    rows += K.check_conv3d_fwd(dt, 2, (8, 8, 16), 16, 16, norm=True, sc_C=0)
+    rows += K.check_conv3d_fwd(dt, 1, (8, 12, 20), 48, 16, norm=True, sc_C=48, slices=True)
+    rows += K.check_conv3d_fwd(dt, 2, (6, 8, 8), 32, 64, norm=False, sc_C=1)
+    rows += K.check_conv3d_fwd(dt, 1, (4, 4, 8), 64, 128, norm=True, sc_C=64)
+    rows += K.check_conv3d_fwd(dt, 1, (32, 32, 32), 16, 32, norm=True, sc_C=16)
+    _assert_all(rows)
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
+def test_conv3d_backward_kernels(K, dt):
+    rows = []
+    rows += K.check_conv3d_dgrad(dt, 2, (8, 8, 16), 48, 16)
+    rows += K.check_conv3d_dgrad(dt, 1, (4, 8, 8), 32, 64)
+    rows += K.check_conv3d_wgrad(dt, 2, (8, 8, 16), 16, 16, k=3, norm=True)
+    rows += K.check_conv3d_wgrad(dt, 1, (8, 12, 20), 48, 32, k=3, norm=True)
+    rows += K.check_conv3d_wgrad(dt, 1, (4, 8, 8), 64, 64, k=3, norm=False)
+    rows += K.check_conv3d_wgrad(dt, 2, (8, 8, 16), 48, 16, k=1, norm=False)
+    _assert_all(rows)
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
+def test_pointwise_and_transposed_conv(K, dt):
+    rows = []
+    rows += K.check_conv1x1(dt, 2, 1000, 16, 48, with_coef=True)
+    rows += K.check_conv1x1(dt, 1, 300, 128, 384, with_coef=False)
+    rows += K.check_convT(dt, 2, (4, 6, 8), 32)
+    rows += K.check_convT(dt, 1, (2, 2, 2), 256)
+    _assert_all(rows)
+
+
+@pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
+def test_norm_pool_head_first_layer(K, dt):
+    _assert_all(K.check_norm_pool_head(dt))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_network_against_reference_golden(K, resunet_golden, dtype):
+    """Logits, loss, Dice and all parameter gradients vs the fixture captured from the reference ResUNet."""
+    _assert_all(K.check_network(dtype, None, None, None, golden=resunet_golden))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_network_cfg2_architecture(K, dtype):
+    _assert_all(K.check_network(dtype, [16, 32, 64, 128, 256], (32, 32, 32), 1, seed=3))
+
+
+def test_module_is_a_dropin(resunet_golden):
+    """state_dict round trip + autograd through the nn.Module wrapper."""
+    from biapy_amd.resunet import ResUNet
+
+    fm = [int(v) for v in resunet_golden["small/feature_maps"]]
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in",
+                yx_down=[2, 2], z_down=[2, 2], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3, compute_dtype=torch.float32)
+    sd = {k[len("small/sd/"):]: torch.from_numpy(resunet_golden[k]) for k in resunet_golden.files if k.startswith("small/sd/")}
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(resunet_golden["small/x"]).permute(0, 4, 1, 2, 3).cuda()
+    tgt = torch.from_numpy(resunet_golden["small/target"]).float().cuda()
+    out = m(x)
+    loss = torch.nn.BCEWithLogitsLoss()(out, tgt)
+    loss.backward()
+    assert abs(loss.item() - float(resunet_golden["small/loss"])) < 1e-5
+    for k, p in m.named_parameters():
+        ref = float(resunet_golden[f"small/gradnorm/{k}"])
+        assert abs(p.grad.norm().item() - ref) <= 2e-3 * max(ref, 1e-3), k
