@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py - voxels/s of the 3D ResUNet hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3                 # train step (fwd+bwd+AdamW), cfg 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                      # data parallel over RCCL, weak scaling
+    python bench.py --mode infer                                    # forward only (sigmoid head fused)
+    python bench.py --breakdown                                     # per-kernel event timing table (not timed run)
+
+Workload = BASELINE.json configs[1]: 3D ResUNet (feature maps 16-32-64-128-256, InstanceNorm, ELU), 128^3
+1-channel patches, batch 4 per GPU, bf16 storage / fp32 accumulate, synthetic data, random-init weights.
+One step = one pass over one batch.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+FM = [16, 32, 64, 128, 256]
+FLOP_PER_VOXEL_FWD = 144832       # BASELINE.md section 3 (2*MAC of all Conv3d/ConvTranspose3d), per input voxel
+MFMA_PEAK_BF16 = 2.5e15           # dense bf16 peak, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def synth_batch(B, P, device, seed):
+    """x ~ N(0,1) (zero-mean/unit-var normalised input), target = smoothed-noise blobs (~50 % fg)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(B, P, P, P, 1, generator=g, device=device)              # (B,Z,Y,X,C) as the data loader hands it over
+    x = x.permute(0, 4, 1, 2, 3)                                            # to_pytorch_format: channels_last_3d view
+    n = torch.randn(B, 1, P, P, P, generator=g, device=device)
+    t = (F.avg_pool3d(n, 9, stride=1, padding=4) > 0).to(torch.float32)
+    return x, t
+
+
+def conv_flops(name, key):
+    """Algorithmic FLOPs of one conv launch from its profile key (dtype,N,D,H,W,'Cx',...)."""
+    ints = [k for k in key if isinstance(k, int)]
+    cs = [int(k[1:]) for k in key if isinstance(k, str)]
+    N, D, H, W = ints[1:5]
+    vox = N * D * H * W
+    if name == "bpx_conv3d_fwd":      # x, sc, y
+        cin, csc, cout = cs[0], cs[1], cs[2]
+        return 2 * vox * (27 * cin + csc) * cout
+    if name == "bpx_conv3d_dgrad":    # dy, t, g
+        return 2 * vox * 27 * cs[0] * cs[2]
+    if name == "bpx_conv3d_wgrad":    # x, dy ; k is the last small int
+        k = ints[-1]
+        return 2 * vox * (k ** 3) * cs[0] * cs[1]
+    return 0
+
+
+def cpu_baseline(P, train):
+    """The oracle (plain PyTorch CPU fp32 restatement of the reference graph) on this host's cores, batch 1."""
+    from oracle import net_oracle
+
+    torch.manual_seed(0)
+    sd = net_oracle.init_state_dict(1, FM, seed=0)
+    x = torch.randn(1, 1, P, P, P)
+    tgt = (torch.rand(1, 1, P, P, P) > 0.5).float()
+    params = {k: v.clone().requires_grad_(train) for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3) if train else None
+
+    def step():
+        if train:
+            opt.zero_grad(set_to_none=True)
+            loss = net_oracle.bce_with_logits(net_oracle.resunet_forward(params, x, FM), tgt)
+            loss.backward()
+            opt.step()
+        else:
+            with torch.no_grad():
+                net_oracle.resunet_forward(params, x, FM)
+
+    t0 = time.time(); step(); warm = time.time() - t0
+    reps = 1 if warm > 12 else 2
+    t0 = time.time()
+    for _ in range(reps):
+        step()
+    dt = (time.time() - t0) / reps
+    return dict(value=P ** 3 / dt, unit="voxels/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{reps} {'train steps (fwd+BCE+bwd+AdamW)' if train else 'forwards'} of one {P}^3 patch, batch 1, fp32, after 1 warm-up "
+                       f"({dt:.2f} s each)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--patch", type=int, default=128)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel timing table of one step and exit")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://")
+
+    from biapy_amd import _lib as L
+    from biapy_amd.resunet import ResUNet
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = ResUNet(image_shape=(a.patch,) * 3 + (1,), activation="elu", feature_maps=FM, drop_values=[0.0] * 5, normalization="in",
+                    yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev)
+    train = a.mode == "train"
+    net = model
+    if train:
+        model.train()
+        if world > 1:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
+        try:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+        except Exception:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    else:
+        model.eval()
+    x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
+
+    def step():
+        if train:
+            opt.zero_grad(set_to_none=True)
+            loss = F.binary_cross_entropy_with_logits(net(x), tgt)     # LOSS.TYPE="CE" -> BCEWithLogits (metrics.py:543-544)
+            loss.backward()
+            opt.step()
+            return loss
+        return model.predict_proba(x)
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if train and not torch.isfinite(out.detach()).all():
+        raise SystemExit("non-finite loss in warm-up")
+
+    if a.breakdown:
+        prof = L.Profile()
+        L.lib.prof = prof
+        step()
+        torch.cuda.synchronize()
+        L.lib.prof = None
+        rows = sorted(prof.summary().items(), key=lambda kv: -kv[1][1])
+        tot = sum(v[1] for _, v in rows)
+        print(f"# per-call event timing of one {a.mode} step (B={a.batch}, {a.patch}^3, {a.dtype}); sum = {tot:.3f} ms")
+        for (name, key), (cnt, ms) in rows:
+            fl = conv_flops(name, key) * cnt
+            tf = f"{fl / (ms * 1e-3) / 1e12:8.1f} TF/s" if fl else " " * 13
+            print(f"{ms:9.3f} ms {100 * ms / tot:5.1f}% x{cnt:<3d} {tf} {name} {key}")
+        return
+
+    prof = L.Profile(names=("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad"))
+    L.lib.prof = prof
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.lib.prof = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    vox_step = world * a.batch * a.patch ** 3
+    value = vox_step * a.steps / elapsed
+    if rank == 0:
+        # dominant kernel = the conv entry point with the largest summed event time inside the timed region
+        summ = prof.summary()
+        per = {}
+        for (name, key), (cnt, ms) in summ.items():
+            d = per.setdefault(name, [0.0, 0.0, 0])
+            d[0] += conv_flops(name, key) * cnt
+            d[1] += ms
+            d[2] += cnt
+        dom = max(per.items(), key=lambda kv: kv[1][1]) if per else None
+        roofline = None
+        if dom:
+            name, (fl, ms, cnt) = dom
+            ach = fl / (ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_BF16 / 1e12 if a.dtype == "bf16" else 157.3
+            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                            traffic=None, launches=cnt, avg_launch_ms=round(ms / cnt, 4),
+                            all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), ms_per_step=round(v[1] / a.steps, 3)) for k, v in per.items()})
+        mult = 3 if train else 1
+        line = dict(
+            metric="voxels/sec 3D ResUNet 128^3 patch (%s)" % ("train: fwd+bwd+AdamW" if train else "inference forward"),
+            value=value, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+            config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, %s" % (a.patch, a.batch, a.mode),
+                        global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode=a.mode),
+            mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * mult / (world * MFMA_PEAK_BF16), 5),
+            roofline=roofline,
+        )
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.patch, train)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

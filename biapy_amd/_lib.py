@@ -88,7 +88,63 @@ def _load() -> C.CDLL:
     return lib
 
 
-lib = _load()
+class Profile:
+    """Per-launch HIP-event timing of selected C-ABI calls (events are recorded on the stream the kernels
+    run on - PyTorch's current stream).  Used by bench.py for the roofline figure and the breakdown."""
+
+    def __init__(self, names=None):
+        self.names = None if names is None else set(names)
+        self.records = []  # (name, int args, start event, end event)
+
+    def want(self, name: str) -> bool:
+        return self.names is None or name in self.names
+
+    def add(self, name, args, e0, e1):
+        key = []
+        for a in args[:-1]:  # the last argument of every entry point is the stream
+            if isinstance(a, Tensor):
+                key.append("C%d" % a.C)
+            elif isinstance(a, int) and not isinstance(a, bool) and abs(a) < (1 << 20):
+                key.append(a)
+        self.records.append((name, tuple(key), e0, e1))
+
+    def summary(self):
+        """{(name, small-int args): [count, total ms]} - call after torch.cuda.synchronize()."""
+        out = {}
+        for name, args, e0, e1 in self.records:
+            k = (name, args)
+            c = out.setdefault(k, [0, 0.0])
+            c[0] += 1
+            c[1] += e0.elapsed_time(e1)
+        return out
+
+
+class _LibProxy:
+    """Attribute-compatible wrapper of the CDLL that can time calls when ``prof`` is set."""
+
+    def __init__(self, raw):
+        object.__setattr__(self, "_raw", raw)
+        object.__setattr__(self, "prof", None)
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+
+        def call(*a):
+            p = self.prof
+            if p is None or not p.want(name):
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            p.add(name, a, e0, e1)
+            return rc
+
+        object.__setattr__(self, name, call)
+        return call
+
+
+lib = _LibProxy(_load())
 
 
 def check(rc: int) -> None:

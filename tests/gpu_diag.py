@@ -61,7 +61,7 @@ def main():
     if a.net:
         for dtype in (torch.float32, torch.bfloat16):
             run(K.check_network, dtype, None, None, None, golden=gr)
-            run(K.check_network, dtype, [16, 32, 64, 128, 256], (32, 32, 32), 1, seed=3)
+            run(K.check_network, dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3)
     lines = []
     nbad = 0
     for r in rows:

@@ -75,7 +75,7 @@ def test_network_against_reference_golden(K, resunet_golden, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_network_cfg2_architecture(K, dtype):
-    _assert_all(K.check_network(dtype, [16, 32, 64, 128, 256], (32, 32, 32), 1, seed=3))
+    _assert_all(K.check_network(dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3))
 
 
 def test_module_is_a_dropin(resunet_golden):
