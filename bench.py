@@ -42,6 +42,8 @@ def synth_batch(B, P, device, seed):
 
 def conv_flops(name, key):
     """Algorithmic FLOPs of one conv launch from its profile key (dtype,N,D,H,W,'Cx',...)."""
+    if name not in ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad"):
+        return 0
     ints = [k for k in key if isinstance(k, int)]
     cs = [int(k[1:]) for k in key if isinstance(k, str)]
     N, D, H, W = ints[1:5]

@@ -45,12 +45,14 @@ _SIGS = {
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i], _i),
     "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
-    "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp], _i),
+    "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _i64, _vp], _i),
+    "bpx_conv3d_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
+    "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
     "bpx_convT3d_k2s2_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_convT3d_stats_tiles": ([_i, _i, _i], _i),
     "bpx_convT3d_k2s2_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp], _i),
-    "bpx_convT3d_k2s2_wgrad": ([_i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp, _vp], _i),
+    "bpx_convT3d_k2s2_wgrad": ([_i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_norm_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _f, _i, _vp, _i, _i, _vp], _i),
     "bpx_tensor_stats": ([_i, _i, _i64, Tensor, _vp, _vp], _i),
     "bpx_tensor_stats_tiles": ([_i64], _i),

@@ -21,17 +21,28 @@ template <typename T> __device__ __forceinline__ float elu_like(float u, int act
 // statistics
 // ------------------------------------------------------------------------------------------------
 // part: [N][tiles][2][C].  One 256-thread block per (n, 16-channel group): thread = (tile lane, channel).
-__global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restrict__ part, int tiles, int C, double inv_count,
+__global__ void __launch_bounds__(1024) norm_finalize_kernel(const float* __restrict__ part, int tiles, int C, double inv_count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             int cpg /* channels per group */, bpx_norm_rec* __restrict__ out,
                                                             int out_ld, int out_off) {
-  __shared__ double red[2][16][16];
+  __shared__ double red[2][64][16];
   const int n = blockIdx.y, c0 = blockIdx.x * 16;
   const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
   double s1 = 0.0, s2 = 0.0;
   if (c0 + c < C) {
     const float* pp = part + (size_t)n * tiles * 2 * C + c0 + c;
-    for (int t = tl; t < tiles; t += 16) {
+    // 64 tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int t = tl;
+    for (; t + 192 < tiles; t += 256) {
+      a0 = pp[(size_t)t * 2 * C]; b0 = pp[(size_t)t * 2 * C + C];
+      a1 = pp[(size_t)(t + 64) * 2 * C]; b1 = pp[(size_t)(t + 64) * 2 * C + C];
+      a2 = pp[(size_t)(t + 128) * 2 * C]; b2 = pp[(size_t)(t + 128) * 2 * C + C];
+      a3 = pp[(size_t)(t + 192) * 2 * C]; b3 = pp[(size_t)(t + 192) * 2 * C + C];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; t < tiles; t += 64) {
       s1 += (double)pp[(size_t)t * 2 * C];
       s2 += (double)pp[(size_t)t * 2 * C + C];
     }
@@ -42,7 +53,7 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restr
   if (threadIdx.x < 32) {
     int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
     double s = 0.0;
-    for (int t = 0; t < 16; ++t) s += red[k][t][cc];
+    for (int t = 0; t < 64; ++t) s += red[k][t][cc];
     red[k][0][cc] = s;
   }
   __syncthreads();
@@ -88,17 +99,28 @@ __global__ void __launch_bounds__(64) tensor_stats_kernel(const T* __restrict__ 
 //   dx = (gamma*rstd) * (g - S1/M - xhat*S2/M),  xhat = (t-mean)*rstd
 //      = a*g + b*t + c0 with a = gamma*rstd, b = -a*rstd*S2/M, c0 = -a*S1/M + a*mean*rstd*S2/M
 //   dgamma[c] += sum_n S2, dbeta[c] += sum_n S1
-__global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int C,
+__global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int C,
                                                                 double inv_count, const bpx_norm_rec* __restrict__ rec,
                                                                 const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, bpx_nbwd_coef* __restrict__ coef) {
-  __shared__ double red[2][16][16];
+  __shared__ double red[2][64][16];
   const int n = blockIdx.y, c0 = blockIdx.x * 16;
   const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
   double s1 = 0.0, s2 = 0.0;
   if (c0 + c < C) {
     const float* pp = red_part + (size_t)n * tiles * 2 * C + c0 + c;
-    for (int t = tl; t < tiles; t += 16) {
+    // 64 tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int t = tl;
+    for (; t + 192 < tiles; t += 256) {
+      a0 = pp[(size_t)t * 2 * C]; b0 = pp[(size_t)t * 2 * C + C];
+      a1 = pp[(size_t)(t + 64) * 2 * C]; b1 = pp[(size_t)(t + 64) * 2 * C + C];
+      a2 = pp[(size_t)(t + 128) * 2 * C]; b2 = pp[(size_t)(t + 128) * 2 * C + C];
+      a3 = pp[(size_t)(t + 192) * 2 * C]; b3 = pp[(size_t)(t + 192) * 2 * C + C];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; t < tiles; t += 64) {
       s1 += (double)pp[(size_t)t * 2 * C];
       s2 += (double)pp[(size_t)t * 2 * C + C];
     }
@@ -109,7 +131,7 @@ __global__ void __launch_bounds__(256) norm_bwd_finalize_kernel(const float* __r
   if (threadIdx.x < 32) {
     int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
     double s = 0.0;
-    for (int t = 0; t < 16; ++t) s += red[k][t][cc];
+    for (int t = 0; t < 64; ++t) s += red[k][t][cc];
     red[k][0][cc] = s;
   }
   __syncthreads();
@@ -597,7 +619,7 @@ extern "C" int bpx_norm_finalize(const float* stats_part_d, int N, int tiles, in
   int cpg = C / groups;
   BPX_CHECK(cpg == 1 || (16 % cpg == 0), "%s: channels per group %d unsupported (must divide 16)", fn, cpg);
   dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
-  norm_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(stats_part_d, tiles, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
+  norm_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(stats_part_d, tiles, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
                                                               cpg, out_d, out_ld, out_off);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -622,7 +644,7 @@ extern "C" int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, 
   const char* fn = "bpx_norm_bwd_finalize";
   BPX_CHECK(red_part_d && rec_d && coef_d, "%s: null pointer", fn);
   dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
-  norm_bwd_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, C, 1.0 / (double)count_per_channel, rec_d, gamma_d,
+  norm_bwd_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, C, 1.0 / (double)count_per_channel, rec_d, gamma_d,
                                                                   dgamma_d, dbeta_d, coef_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;

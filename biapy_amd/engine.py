@@ -108,8 +108,21 @@ class ResUNetEngine:
         self.dtype = dtype
         self.dt = L.BF16 if dtype == torch.bfloat16 else L.F32
         self.act = L.ACT[cfg.activation]
+        self._ws: Optional[torch.Tensor] = None
         self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._pack_versions: Dict[Tuple[int, int, int], int] = {}
+
+    def _workspace(self, nbytes: int, dev) -> torch.Tensor:
+        """Grow-only scratch for the wgrad partial sums (launches are stream-ordered, so one slab is enough)."""
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def _wgrad(self, B, S, x: "L.Tensor", rec, act, dy: "L.Tensor", k, dw, db, st, dev):
+        D, H, W = S
+        nb = lib.bpx_conv3d_wgrad_workspace(B, D, H, W, x.C, dy.C, k)
+        ws = self._workspace(nb, dev)
+        L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db), ws.data_ptr(), ws.numel(), st))
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, w: torch.Tensor, mode: int, cin: int, cout: int, cache: bool) -> torch.Tensor:
@@ -281,15 +294,13 @@ class ResUNetEngine:
         vox = D * H * W
         T = self.dtype
         # conv2 weight/bias grad, shortcut weight grad
-        L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, dOut, 3,
-                                     G[k["w2"]].data_ptr(), G[k["b2"]].data_ptr(), st))
+        self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev)
         if blk.first and self.cfg.in_ch == 1:
             scratch = torch.zeros((C1, 27), dtype=torch.float32, device=dev)
             L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), dOut, scratch.data_ptr(), None, st))
             G[k["wsc"]].view(C1).copy_(scratch[:, 13])
         else:
-            L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1,
-                                         G[k["wsc"]].data_ptr(), None, st))
+            self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
         G[k["bsc"]].copy_(G[k["b2"]])  # both biases add to the same tensor: identical gradient
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
@@ -309,8 +320,7 @@ class ResUNetEngine:
             return
         xv = L.tview(blk.x, blk.x_c0, blk.cin)
         has_norm = blk.rec_x is not None
-        L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, xv, L.ptr(blk.rec_x), self.act if has_norm else 0, dH, 3,
-                                     G[k["w1"]].data_ptr(), G[k["b1"]].data_ptr(), st))
+        self._wgrad(B, blk.S, xv, blk.rec_x, self.act if has_norm else 0, dH, 3, G[k["w1"]], G[k["b1"]], st, dev)
         if dx_out is None:
             return
         Cx = blk.cin
@@ -378,7 +388,10 @@ class ResUNetEngine:
             # transposed conv backward: dUp = dcat[i][..., :Cup]
             wk, bk, x_in, Cup, Sl = ups[j]
             dUp = L.tview(dcat[i], 0, Cup)
-            L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, Sl[0], Sl[1], Sl[2], L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), st))
+            wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, Sl[0], Sl[1], Sl[2], Cup, Cup)
+            ws = self._workspace(wsn, dev)
+            L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, Sl[0], Sl[1], Sl[2], L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(),
+                                               ws.data_ptr(), ws.numel(), st))
             dxin = torch.empty((B,) + Sl + (Cup,), dtype=T, device=dev)
             wt = self._pack(P[wk], L.PK_CT_T, Cup, Cup, False)
             L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Sl[0], Sl[1], Sl[2], dUp, wt.data_ptr(), L.tview(dxin), st))

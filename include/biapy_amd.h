@@ -122,11 +122,13 @@ int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const
                      bpx_tensor t, const bpx_norm_rec* t_norm_d, int act, bpx_tensor g,
                      float* red_part_d, bpx_stream_t stream);
 
-/* wgrad: dW[co][ci][tap] += sum_v act(norm(x))[v+tap][ci] * dy[v][co]  (fp32 atomics into the
- * PyTorch-layout gradient), db[co] += sum_v dy[v][co].  k = 3 or 1. dw_d/db_d must be zeroed by the
- * caller.  Used for Conv3d (k=3, k=1). */
+/* wgrad: dW[co][ci][tap] = sum_v act(norm(x))[v+tap][ci] * dy[v][co] written (overwritten) in the PyTorch
+ * layout (Cout,Cin,k,k,k); db[co] += sum_v dy[v][co] (db_d must be zeroed by the caller, may be NULL).
+ * k = 3 or 1.  Deterministic: per-workgroup partial sums go to the caller-provided workspace and are
+ * summed in a fixed order.  ws_bytes >= bpx_conv3d_wgrad_workspace(...). */
+int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout, int k);
 int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
-                     bpx_tensor dy, int k, float* dw_d, float* db_d, bpx_stream_t stream);
+                     bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* Per-(n,c) coefficients of InstanceNorm's input gradient, dx = a*g + b*t + c0 (see bpx_norm_bwd_finalize). */
 typedef struct bpx_nbwd_coef { float a, b, c0, pad; } bpx_nbwd_coef;
@@ -146,8 +148,10 @@ int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, co
 int bpx_convT3d_stats_tiles(int D, int H, int W);
 int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d,
                            bpx_tensor dx, bpx_stream_t stream);
+int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout);
 int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy,
-                           float* dw_d, float* db_d, bpx_stream_t stream);
+                           float* dw_d /* (Cin,Cout,2,2,2), overwritten */, float* db_d /* accumulated */,
+                           void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* InstanceNorm3d(affine, eps) == GroupNorm with G = C (blocks.py:2122-2125).  Reduces the partials
  * written by a producer kernel to bpx_norm_rec[n*out_ld + out_off + c]; groups < C gives GroupNorm(groups).

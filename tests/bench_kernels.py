@@ -1,0 +1,134 @@
+"""Micro-benchmarks of single kernels at the cfg-2 layer shapes (events on the launch stream).
+
+    python tests/bench_kernels.py conv_fwd|conv_dgrad|wgrad|c1|merge|all [--reps 20] [--dtype bf16]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from biapy_amd import _lib as L  # noqa: E402
+
+lib = L.lib
+DEV = "cuda"
+# (spatial, Cin, Cout, shortcut C) of the 3x3x3 convolutions of cfg 2 (B = 4)
+FWD_LAYERS = [
+    (128, 48, 16, 0), (128, 16, 16, 48), (128, 16, 16, 1), (64, 96, 32, 0), (64, 32, 32, 96), (64, 16, 32, 0), (64, 32, 32, 16),
+    (32, 192, 64, 0), (32, 64, 64, 192), (32, 32, 64, 0), (32, 64, 64, 32), (16, 384, 128, 0), (16, 128, 128, 384), (16, 64, 128, 0),
+    (16, 128, 128, 64), (8, 128, 256, 0), (8, 256, 256, 128),
+]
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", type=int, default=-1, help="index into the layer table")
+    a = ap.parse_args()
+    dt = L.BF16 if a.dtype == "bf16" else L.F32
+    T = torch.bfloat16 if dt == L.BF16 else torch.float32
+    B = 4
+    st = L.stream_ptr()
+
+    def pack(w, mode, cin, cout):
+        n = lib.bpx_packed_weight_elems(mode, cin, cout, dt)
+        out = torch.empty(n, dtype=T, device=DEV)
+        L.check(lib.bpx_pack_weight(mode, w.data_ptr(), cin, cout, dt, out.data_ptr(), st))
+        return out
+
+    layers = FWD_LAYERS if a.only < 0 else [FWD_LAYERS[a.only]]
+    if a.what in ("conv_fwd", "all"):
+        for (S, cin, cout, csc) in layers:
+            x = torch.randn(B, S, S, S, cin, device=DEV).to(T)
+            y = torch.empty(B, S, S, S, cout, device=DEV, dtype=T)
+            w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
+            wp = pack(w, L.PK_K3, cin, cout)
+            bias = torch.zeros(cout, device=DEV)
+            rec = torch.rand(B, cin, 4, device=DEV)
+            tiles = lib.bpx_conv3d_stats_tiles(dt, S, S, S, cout)
+            part = torch.empty(B, tiles, 2, cout, device=DEV)
+            sct, wscp, keep = L.NULL_T, None, []
+            if csc == 1:
+                img = torch.randn(B, S, S, S, device=DEV); wsc = torch.randn(cout, device=DEV)
+                sct, wscp, keep = L.Tensor(img.data_ptr(), 1, 1), wsc.data_ptr(), [img, wsc]
+            elif csc:
+                sc = torch.randn(B, S, S, S, csc, device=DEV).to(T)
+                wk = pack(torch.randn(cout, csc, 1, 1, 1, device=DEV), L.PK_K1, csc, cout)
+                sct, wscp, keep = L.tview(sc), wk.data_ptr(), [sc, wk]
+            f = lambda: L.check(lib.bpx_conv3d_fwd(dt, B, S, S, S, L.tview(x), rec.data_ptr(), 1, wp.data_ptr(), bias.data_ptr(), sct, wscp,
+                                                   bias.data_ptr() if csc else None, L.tview(y), part.data_ptr(), st))
+            ms = timeit(f, a.reps)
+            fl = 2 * B * S ** 3 * (27 * cin + csc) * cout
+            by = B * S ** 3 * (cin + cout + csc) * x.element_size()
+            print(f"conv_fwd  {S:4d}^3 {cin:4d}->{cout:4d} sc={csc:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s  {by / ms / 1e6:8.1f} GB/s(alg)")
+    if a.what in ("conv_dgrad", "all"):
+        for (S, cin, cout, csc) in layers:
+            dy = torch.randn(B, S, S, S, cout, device=DEV).to(T)
+            t = torch.randn(B, S, S, S, cin, device=DEV).to(T)
+            g = torch.empty(B, S, S, S, cin, device=DEV, dtype=T)
+            wp = pack(torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05, L.PK_K3_T, cin, cout)
+            rec = torch.rand(B, cin, 4, device=DEV)
+            tiles = lib.bpx_conv3d_stats_tiles(dt, S, S, S, cin)
+            red = torch.empty(B, tiles, 2, cin, device=DEV)
+            f = lambda: L.check(lib.bpx_conv3d_dgrad(dt, B, S, S, S, L.tview(dy), wp.data_ptr(), L.tview(t), rec.data_ptr(), 1, L.tview(g),
+                                                     red.data_ptr(), st))
+            ms = timeit(f, a.reps)
+            fl = 2 * B * S ** 3 * 27 * cin * cout
+            print(f"conv_dgrad {S:4d}^3 dy{cout:4d}->g{cin:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s")
+    if a.what in ("wgrad", "all"):
+        for (S, cin, cout, csc) in layers:
+            x = torch.randn(B, S, S, S, cin, device=DEV).to(T)
+            dy = torch.randn(B, S, S, S, cout, device=DEV).to(T)
+            rec = torch.rand(B, cin, 4, device=DEV)
+            dw = torch.empty(cout, cin, 3, 3, 3, device=DEV)
+            db = torch.zeros(cout, device=DEV)
+            ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, S, S, S, cin, cout, 3)), dtype=torch.uint8, device=DEV)
+            f = lambda: L.check(lib.bpx_conv3d_wgrad(dt, B, S, S, S, L.tview(x), rec.data_ptr(), 1, L.tview(dy), 3, dw.data_ptr(), db.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), st))
+            ms = timeit(f, a.reps)
+            fl = 2 * B * S ** 3 * 27 * cin * cout
+            print(f"wgrad     {S:4d}^3 {cin:4d}->{cout:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s  ws={ws.numel() / 1e6:.1f} MB")
+    if a.what in ("c1", "all"):
+        S = 128
+        img = torch.randn(B, S, S, S, device=DEV)
+        y = torch.empty(B, S, S, S, 16, device=DEV, dtype=T)
+        w = torch.randn(16, 1, 3, 3, 3, device=DEV); b = torch.zeros(16, device=DEV)
+        tiles = lib.bpx_conv3d_c1_stats_tiles(S, S, S)
+        part = torch.empty(B, tiles, 2, 16, device=DEV)
+        ms = timeit(lambda: L.check(lib.bpx_conv3d_c1_fwd(dt, B, S, S, S, img.data_ptr(), w.data_ptr(), b.data_ptr(), L.tview(y), part.data_ptr(), st)), a.reps)
+        print(f"c1_fwd 128^3 1->16: {ms * 1e3:9.1f} us  {(B * S ** 3 * (4 + 16 * y.element_size())) / ms / 1e6:8.1f} GB/s(alg)")
+        dw = torch.zeros(16, 1, 3, 3, 3, device=DEV); db = torch.zeros(16, device=DEV)
+        ms = timeit(lambda: L.check(lib.bpx_conv3d_c1_wgrad(dt, B, S, S, S, img.data_ptr(), L.tview(y), dw.data_ptr(), db.data_ptr(), st)), a.reps)
+        print(f"c1_wgrad 128^3: {ms * 1e3:9.1f} us")
+    if a.what in ("merge", "all"):
+        from biapy_amd import tiling
+        vol = (512, 512, 512)
+        plan = tiling.MergePlan(vol, (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0), torch.device(DEV))
+        patches = torch.rand(plan.n_patches, 128, 128, 128, 1, device=DEV)
+        out = torch.empty(vol + (1,), device=DEV)
+        ms = timeit(lambda: tiling.merge_device(patches, plan, out=out), max(3, a.reps // 4))
+        by = patches.numel() * 4 + out.numel() * 4
+        print(f"merge 512^3 from {plan.n_patches} x 128^3: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)")
+        v = torch.rand(vol + (1,), device=DEV)
+        ms = timeit(lambda: tiling.crop_device(v, (128, 128, 128), (0.5, 0.5, 0.5), out=patches), max(3, a.reps // 4))
+        print(f"crop  512^3 -> {plan.n_patches} x 128^3: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)")
+
+
+if __name__ == "__main__":
+    main()

@@ -292,8 +292,10 @@ def check_conv3d_wgrad(dt, B, S, Cin, Cout, k=3, norm=True, use_tr=1, seed=0, ac
     xd, dyd = to_dev(x, dt), to_dev(dy, dt)
     recd = rec.to(DEV) if rec is not None else None
     lib.bpx_debug_set_wgrad_tr(use_tr)
+    ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, D, H, W, Cin, Cout, k)), dtype=torch.uint8, device=DEV)
+    dw.fill_(7.0)  # the kernel overwrites dW (no pre-zeroing contract)
     L.check(lib.bpx_conv3d_wgrad(dt, B, D, H, W, L.tview(xd), L.ptr(recd), act if norm else 0, L.tview(dyd), k, dw.data_ptr(), db.data_ptr(),
-                                 L.stream_ptr()))
+                                 ws.data_ptr(), ws.numel(), L.stream_ptr()))
     torch.cuda.synchronize()
     lib.bpx_debug_set_wgrad_tr(1)
     tag = f"conv3d_wgrad[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} {Cin}->{Cout} k{k} norm={int(norm)} tr={use_tr}]"
@@ -370,7 +372,9 @@ def check_convT(dt, B, S, Cc, seed=0):
     # wgrad
     dw = torch.zeros(Cc, Cc, 2, 2, 2, dtype=torch.float32, device=DEV)
     db = torch.zeros(Cc, dtype=torch.float32, device=DEV)
-    L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), L.stream_ptr()))
+    ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, Cc, Cc)), dtype=torch.uint8, device=DEV)
+    L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(tag + ".wgrad", relerr(dw, wr.grad), 2e-3 if dt == L.BF16 else 2e-5))
     res.append(_res(tag + ".bgrad", relerr(db, br.grad), 2e-3 if dt == L.BF16 else 2e-5))
