@@ -39,9 +39,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi);
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -74,11 +72,26 @@ template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
   u32x4_t v; v[0] = __float_as_uint(f[0]); v[1] = __float_as_uint(f[1]); v[2] = __float_as_uint(f[2]); v[3] = __float_as_uint(f[3]);
   return v;
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// hardware RNE conversion: v_cvt_pk_bf16_f32 (one instruction per two values)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, hw_bf16x2_t));
+}
 template <> __device__ __forceinline__ u32x4_t pack16<uint16_t>(const float* f) {
   u32x4_t v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  for (int i = 0; i < 4; ++i) v[i] = cvt_pk_bf16(f[2 * i], f[2 * i + 1]);
   return v;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
+
+// K order of the 27 taps for bf16 storage: one MFMA step = two taps x 16 channels.  Taps are paired so that
+// the LDS address difference between the two taps of a step is one of three constants (+1 voxel in x for the
+// (dx0,dx1) pairs, +1 row for the dx2 pairs, +1 plane for (8,17)); tap 26 is alone (-1 = zero weights).
+__host__ __device__ constexpr int bpx_tap_order_bf16(int i) {
+  constexpr int t[28] = {0, 1, 3, 4, 6, 7, 9, 10, 12, 13, 15, 16, 18, 19, 21, 22, 24, 25, 2, 5, 11, 14, 20, 23, 8, 17, 26, -1};
+  return t[i];
 }
 
 // ---- activations ----------------------------------------------------------------------------

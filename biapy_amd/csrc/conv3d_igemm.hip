@@ -37,8 +37,10 @@ struct Conv3Params {
   int tilesY, tilesX, tilesPerSample;
 };
 
-template <typename T> __device__ __forceinline__ float apply_act_rt(float u, int act) {
+// ACTK = 1: ELU known at compile time (the reference default) - no per-element control flow; ACTK = 0: runtime switch.
+template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
+  if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
   switch (act) {
     case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
     case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
@@ -46,8 +48,9 @@ template <typename T> __device__ __forceinline__ float apply_act_rt(float u, int
     default: return u;
   }
 }
-template <typename T> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
+template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
+  if (ACTK == 1) return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
   switch (act) {
     case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
     case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
@@ -116,7 +119,7 @@ template <int HY, int HX, int VB> __device__ __forceinline__ constexpr int tap_o
   return (((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VB;
 }
 
-template <typename T, int TZ, int TY, int TX, int NS, int EPI>
+template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK>
 __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
@@ -149,17 +152,87 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
     hb[ms] = ((tz * HY + ty) * HX + tx) * VB;
     tb[ms] = t * VB;
   }
-  // per-lane (kgroup -> tap parity / channel-group) decomposition, see DESIGN.md "K order"
+  // Per-lane K decomposition (DESIGN.md "K order").  bf16: a step covers two taps x 16 channels; lanes g<2 take tap A,
+  // lanes g>=2 tap B.  The taps are paired (bpx_tap_order_bf16) so that addr(B)-addr(A) is one of three constants;
+  // adding it to per-lane bases once makes every ds_read address = VGPR base + compile-time immediate.
   const int cg_off = (GPT == 2 ? (g & 1) : g) * 16;
   const bool hi_tap = (GPT == 2) && (g >> 1);
+  constexpr int NCLS = (GPT == 2) ? 4 : 1;
+  int lbase[NCLS][MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    if (GPT == 2) {
+      lbase[0][ms] = hb[ms] + cg_off + (hi_tap ? VB : 0);
+      lbase[1][ms] = hb[ms] + cg_off + (hi_tap ? HX * VB : 0);
+      lbase[2][ms] = hb[ms] + cg_off + (hi_tap ? HY * HX * VB : 0);
+      lbase[NCLS - 1][ms] = hb[ms] + cg_off;
+    } else {
+      lbase[0][ms] = hb[ms] + cg_off;
+    }
+  }
 
-  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
+  // ---- staging plan: which 16-byte pieces of the halo this thread moves (fixed for the tile) --------
+  constexpr int NPIECE = HV * GPT;                 // LDS image is piece-linear: piece idx lives at byte idx*16
+  constexpr int NP = (NPIECE + 255) / 256;
+  const int sub = tid % GPT;
+  uint32_t goff[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    int idx = u * 256 + tid;
+    goff[u] = 0xFFFFFFFFu;
+    if (idx < NPIECE) {
+      int hv = idx / GPT;
+      int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+      int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        goff[u] = (uint32_t)((((uint32_t)gz * p.H + gy) * p.W + gx) * (uint32_t)p.x_ld);
+    }
+  }
+  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.D * p.H * p.W * p.x_ld + sub * KPL;
   const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+  const bpx_norm_rec* __restrict__ nrec = p.in_norm ? p.in_norm + (size_t)n * p.Cin + sub * KPL : nullptr;
   const int nchunks = p.Cin / 16;
+
+  u32x4_t pbuf[NP];
+  float psc[KPL], psh[KPL];
+  // issue the global loads of chunk 0 (async-STAGE split: loads fly while the previous chunk's MFMAs run)
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
+    if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u]);
+  }
+  if (nrec) {
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) { bpx_norm_rec r = nrec[e]; psc[e] = r.scale; psh[e] = r.shift; }
+  }
+
   for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // transform (normalise + activate, fp32) and write the staged pieces
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      int idx = u * 256 + tid;
+      if (idx < NPIECE) {
+        u32x4_t v = pbuf[u];
+        if (nrec && goff[u] != 0xFFFFFFFFu) {
+          float f[KPL];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) f[e] = apply_act_rt<T, ACTK>(fmaf(psc[e], f[e], psh[e]), p.act);
+          v = pack16<T>(f);
+        }
+        *reinterpret_cast<u32x4_t*>(smem + (size_t)idx * 16) = v;
+      }
+    }
     __syncthreads();
-    stage_block<T, HZ, HY, HX>(smem, xin, p.x_ld, chunk, n, p.D, p.H, p.W, z0 - 1, y0 - 1, x0 - 1, p.in_norm, p.Cin, p.act, tid);
-    __syncthreads();
+    if (chunk + 1 < nchunks) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (chunk + 1) * 16);
+      if (nrec) {
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) { bpx_norm_rec r = nrec[(chunk + 1) * 16 + e]; psc[e] = r.scale; psh[e] = r.shift; }
+      }
+    }
     const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
     u32x4_t wf[NS], wn[NS];
 #pragma unroll
@@ -171,17 +244,12 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
         for (int ns = 0; ns < NS; ++ns)
           wn[ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + 1) * 4 * Cout + ns * 16) * KPL);
       }
-      int off;
-      if (GPT == 2) {
-        const int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;  // padded tap 27: zero weights, any valid address
-        off = hi_tap ? tap_off<HY, HX, VB>(t1) : tap_off<HY, HX, VB>(t0);
-      } else {
-        off = tap_off<HY, HX, VB>(s);
-      }
-      off += cg_off;
+      const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s) : s;
+      const int cls = (GPT == 2) ? (s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3) : 0;
+      const int imm = tap_off<HY, HX, VB>(tapA);
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) {
-        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + hb[ms] + off);
+        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls][ms] + imm);
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
       }
@@ -190,6 +258,7 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
         for (int ns = 0; ns < NS; ++ns) wf[ns] = wn[ns];
       }
     }
+    __syncthreads();  // every wave is done reading before the next chunk overwrites the tile
   }
 
   // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only) ------------------------------
@@ -260,7 +329,7 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
             for (int r = 0; r < 4; ++r) {
               float tv = Tr::ld(tp + r);
               float u = fmaf(rec[r].scale, tv, rec[r].shift);
-              v[r] = acc[ms][ns][r] * apply_act_bwd_rt<T>(u, p.t_act);
+              v[r] = acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act);
               float xh = (tv - rec[r].mean) * rec[r].rstd;
               s1[ns][r] += v[r];
               s2[ns][r] += v[r] * xh;
@@ -327,9 +396,11 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.tilesX = cdiv(p.W, c.tx);
   p.tilesPerSample = tilesZ * p.tilesY * p.tilesX;
   dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
+  const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
 #define L(TZ, TY, TX, NS)                                                        \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
-    conv3_kernel<T, TZ, TY, TX, NS, EPI><<<grid, 256, 0, s>>>(p);                \
+    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1><<<grid, 256, 0, s>>>(p);    \
+    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0><<<grid, 256, 0, s>>>(p);        \
     return 0;                                                                    \
   }
   if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only

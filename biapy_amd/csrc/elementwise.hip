@@ -507,8 +507,9 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, 
       int col = (int)(r % ncol); r /= ncol;
       int q = (int)(r % QPAD);
       int chunk = (int)(r / QPAD);
-      if (q < QTOT) {
-        int tap = q / GPT, cgp = q % GPT;
+      int tap = (q < QTOT) ? q / GPT : -1, cgp = q % GPT;
+      if (GPT == 2 && q < 56) tap = bpx_tap_order_bf16(q / GPT);  // paired tap order of the bf16 kernels
+      if (tap >= 0) {
         int kc = chunk * 16 + cgp * KPL + e;  // reduction channel
         if (mode == PK_K3) v = w[((size_t)col * Cin + kc) * 27 + tap];                 // W[co][ci][tap]
         else v = w[((size_t)kc * Cin + col) * 27 + (26 - tap)];                         // W[co=kc][ci=col][mirrored tap]

@@ -35,8 +35,9 @@ struct WgradParams {
   int tilesY, tilesX, tilesPerSample, totalTiles, groups;
 };
 
-template <typename T> __device__ __forceinline__ float act_rt(float u, int act) {
+template <typename T, int ACTK = 0> __device__ __forceinline__ float act_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
+  if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
   switch (act) {
     case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
     case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
@@ -47,7 +48,7 @@ template <typename T> __device__ __forceinline__ float act_rt(float u, int act) 
 
 // Stage EZ*EY*EX voxels x NCH channels (NCH multiple of 16/GPT pieces) into LDS [voxel][NCH].
 // Source voxel = vs*(o+h)+a; voxels whose LOGICAL coordinate (o+h) is outside [0,D)x[0,H)x[0,W) are zero.
-template <typename T, int EZ, int EY, int EX, int NCH>
+template <typename T, int EZ, int EY, int EX, int NCH, int ACTK = 0>
 __device__ __forceinline__ void stage_any(unsigned char* smem, const T* __restrict__ src, int ld, int c0, int n, int D, int H, int W,
                                           int oz, int oy, int ox, int vs, int az, int ay, int ax,
                                           const bpx_norm_rec* __restrict__ norm, int C_norm, int act, int tid) {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void stage_any(unsigned char* smem, const T* __restri
           float f[KPL];
           unpack16<T>(v, f);
 #pragma unroll
-          for (int e = 0; e < KPL; ++e) f[e] = act_rt<T>(fmaf(sc[e], f[e], sh[e]), act);
+          for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, ACTK>(fmaf(sc[e], f[e], sh[e]), act);
           v = pack16<T>(f);
         }
         *reinterpret_cast<u32x4_t*>(smem + (size_t)(idx / PPV) * VB + sub * 16) = v;
@@ -128,7 +129,7 @@ __device__ __forceinline__ u32x4_t frag_T_bf16(const unsigned char* smem, int vo
   return out;
 }
 
-template <typename T, int TZ, int TY, int TX, int NS, int TAPS, bool USE_TR>
+template <typename T, int TZ, int TY, int TX, int NS, int TAPS, bool USE_TR, int ACTK>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   using Tr = ElemTraits<T>;
   constexpr bool BF = std::is_same<T, uint16_t>::value;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
     const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
     __syncthreads();
-    stage_any<T, HZ, HY, HX, 16>(sA, xin, p.x_ld, chunk * 16, n, p.D, p.H, p.W, z0 - HALO, y0 - HALO, x0 - HALO, 1, 0, 0, 0,
+    stage_any<T, HZ, HY, HX, 16, ACTK>(sA, xin, p.x_ld, chunk * 16, n, p.D, p.H, p.W, z0 - HALO, y0 - HALO, x0 - HALO, 1, 0, 0, 0,
                                  p.in_norm, p.Cin, p.act, tid);
     stage_any<T, TZ, TY, TX, CB>(sG, gin, p.dy_ld, co_base, n, p.D, p.H, p.W, z0, y0, x0, p.dy_vs, p.dy_oz, p.dy_oy, p.dy_ox,
                                  nullptr, 0, 0, tid);
@@ -304,11 +305,14 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
   int nchunks = p.Cin / 16, nb = p.Cout / (16 * c.ns);
   int groups = c.groups;
   p.groups = groups;
+  const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
   dim3 grid((unsigned)groups, (unsigned)nchunks, (unsigned)nb);
 #define L(TX, NS)                                                                                   \
   if (c.tx == TX && c.ns == NS) {                                                                   \
-    if (use_tr) wgrad_kernel<T, 4, 4, TX, NS, TAPS, true><<<grid, 256, 0, s>>>(p);                   \
-    else wgrad_kernel<T, 4, 4, TX, NS, TAPS, false><<<grid, 256, 0, s>>>(p);                         \
+    if (use_tr && elu) wgrad_kernel<T, 4, 4, TX, NS, TAPS, true, 1><<<grid, 256, 0, s>>>(p);         \
+    else if (use_tr) wgrad_kernel<T, 4, 4, TX, NS, TAPS, true, 0><<<grid, 256, 0, s>>>(p);           \
+    else if (elu) wgrad_kernel<T, 4, 4, TX, NS, TAPS, false, 1><<<grid, 256, 0, s>>>(p);             \
+    else wgrad_kernel<T, 4, 4, TX, NS, TAPS, false, 0><<<grid, 256, 0, s>>>(p);                      \
     return 0;                                                                                       \
   }
   L(16, 1) L(16, 2) L(16, 4) L(8, 1) L(8, 2) L(8, 4)
