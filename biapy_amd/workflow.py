@@ -1,0 +1,201 @@
+"""Sliding-window inference on the device: crop -> forward -> blend, optionally sharded over the GPUs of a node.
+
+Host-side counterpart of ``Base_Workflow.process_test_sample`` (per-patch branch,
+biapy/engine/base_workflow.py:1944-1997) and ``predict_batches_in_test`` (:1696-1728):
+
+    crop_3D_data_with_overlap(X, PATCH_SIZE, overlap, padding)      -> bpx_crop3d_gather, batch by batch
+    model_call_func + apply_model_activations (sigmoid)              -> ResUNet engine, head activation fused
+    merge_3D_data_with_overlap(pred, shape, padding, overlap)        -> bpx_merge3d_blend (deterministic gather)
+
+Differences by design (MI355X-first, same results):
+  * nothing returns to the host between the three stages: patches are gathered from the HBM-resident volume
+    per batch (no 34 GB patch array), predictions stay in HBM (34 GB at cfg 3 - sized for 288 GB), and the
+    blend reads them once;
+  * multi-GPU: the reference runs this path on rank 0 only (base_workflow.py:1552-1559).  Here the patch grid
+    is cut along Z into contiguous row slabs, one per rank; forwards are independent; the blend of the slices
+    two slabs share is made bit-identical to the single-device result by handing the un-normalised partial sums
+    (numerator, weight sum) of the boundary slices to the next rank, which SEEDS its accumulation with them
+    (fp32 addition is not associative; the reference order is z-major, so lower ranks' terms come first).
+    One neighbour send/recv per boundary + one all-gather (or gather to rank 0) of the disjoint output slabs,
+    over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import tiling
+
+
+def split_rows(n_rows: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced [lo,hi) ranges of patch z-rows; ranks beyond n_rows get empty ranges."""
+    base, rem = divmod(n_rows, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+@dataclass
+class SlabPlan:
+    """Which output slices a rank finalises / hands over, derived only from the integer grid."""
+    rows: Tuple[int, int]          # patch z-rows [lo,hi) owned by the rank
+    own: Tuple[int, int]           # output slices [z0,z1) the rank normalises and owns
+    recv: Optional[Tuple[int, int]]  # slices whose partial sums arrive from the previous non-empty rank
+    send: Optional[Tuple[int, int]]  # slices whose partial sums go to the next non-empty rank
+    prev: Optional[int]
+    next: Optional[int]
+
+
+def plan_slabs(row_starts: Sequence[int], core_patch_z: int, Z: int, world: int) -> List[SlabPlan]:
+    n_rows = len(row_starts)
+    ranges = split_rows(n_rows, world)
+    active = [r for r in range(world) if ranges[r][1] > ranges[r][0]]
+    plans: List[SlabPlan] = []
+    for r in range(world):
+        lo, hi = ranges[r]
+        if hi <= lo:
+            plans.append(SlabPlan((lo, hi), (0, 0), None, None, None, None))
+            continue
+        k = active.index(r)
+        prev = active[k - 1] if k > 0 else None
+        nxt = active[k + 1] if k + 1 < len(active) else None
+        zs = 0 if prev is None else row_starts[lo]
+        ze = row_starts[hi - 1] + core_patch_z                     # one past the last slice this rank's patches touch
+        own_hi = Z if nxt is None else row_starts[ranges[nxt][0]]
+        recv = None
+        if prev is not None:
+            prev_ze = row_starts[ranges[prev][1] - 1] + core_patch_z
+            if prev_ze > zs:
+                recv = (zs, min(prev_ze, Z))
+        send = None
+        if nxt is not None and ze > own_hi:
+            send = (own_hi, min(ze, Z))
+        plans.append(SlabPlan((lo, hi), (zs, own_hi), recv, send, prev, nxt))
+    return plans
+
+
+class DeviceBlend:
+    """Blend backend on the MI355X kernels."""
+
+    def __init__(self, plan: tiling.MergePlan):
+        self.plan = plan
+
+    def blend(self, patches, z_lo, z_hi, rows, acc=None, wacc=None, seed=False, write_partial=False, out_dtype=None):
+        return tiling.merge_device(patches, self.plan, out_dtype=out_dtype, z_lo=z_lo, z_hi=z_hi, zrow_lo=rows[0], zrow_hi=rows[1],
+                                   acc=acc, wacc=wacc, seed=seed, write_partial=write_partial)
+
+
+def sharded_blend(backend, patches: torch.Tensor, plans: List[SlabPlan], rank: int, world: int, Y: int, X: int, C: int,
+                  gather: str = "all", group=None) -> Optional[torch.Tensor]:
+    """Blend this rank's predictions into its output slab, exchanging boundary partial sums with the neighbours.
+
+    ``patches`` holds the predictions of the rank's patch rows only.  Returns the full volume (Z,Y,X,C) on every
+    rank (gather="all"), on rank 0 only ("rank0"), or just the rank's own slab ("none").
+    """
+    me = plans[rank]
+    dev = patches.device
+    Z = max(p.own[1] for p in plans)
+    slab = None
+    if me.rows[1] > me.rows[0]:
+        z0, z1 = me.own
+        pieces = []
+        seed_hi = z0
+        if me.recv is not None:
+            r0, r1 = me.recv
+            acc = torch.empty((r1 - r0, Y, X, C), dtype=torch.float32, device=dev)
+            wacc = torch.empty((r1 - r0, Y, X, 1), dtype=torch.float32, device=dev)
+            if world > 1:
+                dist.recv(acc, src=me.prev, group=group)
+                dist.recv(wacc, src=me.prev, group=group)
+            seed_hi = r1
+        if me.send is not None:
+            s0, s1 = me.send
+            sacc = torch.zeros((s1 - s0, Y, X, C), dtype=torch.float32, device=dev)
+            swacc = torch.zeros((s1 - s0, Y, X, 1), dtype=torch.float32, device=dev)
+            if me.recv is not None and seed_hi > s0:       # a previous rank's terms reach into what we hand over
+                k = seed_hi - s0
+                sacc[:k] = acc[s0 - me.recv[0]:seed_hi - me.recv[0]]
+                swacc[:k] = wacc[s0 - me.recv[0]:seed_hi - me.recv[0]]
+                backend.blend(patches, s0, seed_hi, me.rows, acc=sacc[:k], wacc=swacc[:k], seed=True, write_partial=True)
+                if s1 > seed_hi:
+                    backend.blend(patches, seed_hi, s1, me.rows, acc=sacc[k:], wacc=swacc[k:], write_partial=True)
+            else:
+                backend.blend(patches, s0, s1, me.rows, acc=sacc, wacc=swacc, write_partial=True)
+            if world > 1:
+                dist.send(sacc, dst=me.next, group=group)
+                dist.send(swacc, dst=me.next, group=group)
+        # own slab: seeded part first, then the rest
+        if me.recv is not None:
+            e = min(seed_hi, z1)
+            if e > z0:
+                pieces.append(backend.blend(patches, z0, e, me.rows, acc=acc[: e - z0], wacc=wacc[: e - z0], seed=True))
+            if z1 > e:
+                pieces.append(backend.blend(patches, e, z1, me.rows))
+        else:
+            pieces.append(backend.blend(patches, z0, z1, me.rows))
+        slab = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0)
+    if gather == "none" or world == 1:
+        return slab
+    # the slabs are disjoint and ordered: exchange them padded to the largest one
+    sizes = [p.own[1] - p.own[0] for p in plans]
+    mx = max(sizes)
+    buf = torch.zeros((mx, Y, X, C), dtype=slab.dtype if slab is not None else torch.float32, device=dev)
+    if slab is not None:
+        buf[: slab.shape[0]] = slab
+    if gather == "all":
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf, group=group)
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, outs, dst=0, group=group)
+        if rank != 0:
+            return None
+    return torch.cat([o[:s] for o, s in zip(outs, sizes) if s > 0], 0)[:Z]
+
+
+class SlidingWindowPredictor:
+    """crop -> forward -> merge of one volume, entirely on the device(s)."""
+
+    def __init__(self, model, patch_zyx: Sequence[int], overlap=(0.5, 0.5, 0.5), padding=(0, 0, 0), batch_size: int = 4,
+                 pad_type: str = "reflect", forward: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+        self.model = model
+        self.patch = tuple(int(p) for p in patch_zyx)
+        self.overlap, self.padding, self.batch, self.pad_type = tuple(overlap), tuple(padding), int(batch_size), pad_type
+        # forward: (B,C,Z,Y,X) fp32 -> (B,Cout,Z,Y,X) fp32 probabilities (ce_sigmoid head)
+        self.forward = forward or (lambda x: model.predict_proba(x))
+
+    @torch.no_grad()
+    def predict(self, vol: torch.Tensor, rank: int = 0, world: int = 1, gather: str = "all", group=None) -> Optional[torch.Tensor]:
+        """vol: (Z,Y,X,C) float32 on this rank's device.  Returns the blended probability volume (Z,Y,X,Cout)."""
+        assert vol.is_cuda and vol.dim() == 4 and vol.dtype == torch.float32
+        Z, Y, X, Cin = vol.shape
+        plan = tiling.MergePlan((Z, Y, X), self.patch, self.overlap, self.padding, vol.device)
+        nz, ny, nx = plan.grid[0].n, plan.grid[1].n, plan.grid[2].n
+        row_starts = [plan.row_start(i) for i in range(nz)]
+        core_z = self.patch[0] - 2 * self.padding[0]
+        plans = plan_slabs(row_starts, core_z, Z, world)
+        lo, hi = plans[rank].rows
+        n_mine = (hi - lo) * ny * nx
+        pred = None
+        for b0 in range(0, n_mine, self.batch):
+            nb = min(self.batch, n_mine - b0)
+            xb = tiling.crop_device(vol, self.patch, self.overlap, self.padding, self.pad_type, c_begin=lo * ny * nx + b0, c_count=nb)
+            out = self.forward(xb.permute(0, 4, 1, 2, 3))                         # to_pytorch_format (misc.py:689-713)
+            if pred is None:
+                pred = torch.empty((n_mine,) + self.patch + (out.shape[1],), dtype=torch.float32, device=vol.device)
+            pred[b0:b0 + nb] = out.permute(0, 2, 3, 4, 1)                         # to_numpy_format, on the device
+        if pred is None:
+            pred = torch.empty((0,) + self.patch + (1,), dtype=torch.float32, device=vol.device)
+        cout = pred.shape[-1]
+        if world > 1:  # every rank must agree on the channel count even when it owns no rows
+            t = torch.tensor([cout], device=vol.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            cout = int(t.item())
+        return sharded_blend(DeviceBlend(plan), pred, plans, rank, world, Y, X, cout, gather=gather, group=group)

@@ -59,6 +59,9 @@ def main():
         run(K.check_convT, dt, 1, (2, 2, 2), 256)
         run(K.check_norm_pool_head, dt)
     if a.net:
+        run(K.check_sliding_window, torch.float32)
+        run(K.check_sliding_window, torch.bfloat16)
+        run(K.check_dice_parity_trained)
         for dtype in (torch.float32, torch.bfloat16):
             run(K.check_network, dtype, None, None, None, golden=gr)
             run(K.check_network, dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3)

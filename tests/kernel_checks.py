@@ -578,3 +578,78 @@ def all_kernel_checks(golden_tiling=None, quick=False):
         out += check_convT(dt, 1, (2, 2, 2), 256)
         out += check_norm_pool_head(dt)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_sliding_window(dtype=torch.float32):
+    """crop -> forward -> merge on the device vs the same pipeline built from the oracle pieces on the CPU."""
+    from biapy_amd.resunet import ResUNet
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    fm = [16, 32]
+    sd = net_oracle.init_state_dict(1, fm, seed=5)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0, 0.0], normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    rs = np.random.RandomState(2)
+    vol = rs.randn(48, 40, 56, 1).astype(np.float32)
+    ov, pad = (0.5, 0.25, 0.5), (0, 4, 0)
+    patch = (32, 32, 32)
+    p, _ = TO.crop(vol, patch + (1,), ov, pad)
+    with torch.no_grad():
+        pr = torch.sigmoid(net_oracle.resunet_forward(sd, torch.from_numpy(p).permute(0, 4, 1, 2, 3), fm)).permute(0, 2, 3, 4, 1).contiguous().numpy()
+    ref = TO.merge(pr, vol.shape, overlap=ov, padding=pad)
+    sw = SlidingWindowPredictor(m, patch, ov, pad, batch_size=5)
+    got = sw.predict(torch.from_numpy(vol).cuda()).cpu().numpy()
+    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+    res = [_res(f"sliding_window_prob[{tagd}]", np.abs(got - ref).max(), 2e-5 if dtype == torch.float32 else 3e-2)]
+    lab_ref, lab_got = (ref > 0.5), (got > 0.5)
+    near = np.abs(ref - 0.5) < (1e-5 if dtype == torch.float32 else 2e-2)        # voxels whose label is decided by the last bits
+    res.append(_res(f"sliding_window_labels_away_from_threshold[{tagd}]", int(((lab_ref != lab_got) & ~near).sum()), 0,
+                    extra=f"undecidable voxels: {int(near.sum())} of {near.size}"))
+    return res
+
+
+def check_dice_parity_trained(steps=120):
+    """Train a small ResUNet on synthetic blobs with the MI355X engine, then compare Dice of the bf16 / f32 device
+    forward with the fp32 CPU oracle using the SAME weights (north_star: |Dice delta| < 1e-4)."""
+    from biapy_amd.resunet import ResUNet
+
+    fm = [16, 32, 64]
+    torch.manual_seed(0)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in", yx_down=[2, 2],
+                z_down=[2, 2], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3, compute_dtype=torch.bfloat16).cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def batch(B):
+        n = torch.randn(B, 1, 32, 32, 32, generator=g, device="cuda")
+        t = (F.avg_pool3d(n, 5, stride=1, padding=2) > 0.05).float()
+        x = t * 1.5 + 0.8 * torch.randn(B, 1, 32, 32, 32, generator=g, device="cuda")       # noisy image of the blobs
+        return x, t
+
+    first = last = None
+    for it in range(steps):
+        x, t = batch(4)
+        opt.zero_grad(set_to_none=True)
+        loss = F.binary_cross_entropy_with_logits(m(x), t)
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    res = [_res("train_loss_decreases[bf16 engine]", last / first, 0.6, extra=f"loss {first:.4f} -> {last:.4f} in {steps} steps")]
+    m.eval()
+    x, t = batch(4)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        lo_ref = net_oracle.resunet_forward(sd, x.cpu(), fm)
+    d_ref = net_oracle.dice(torch.sigmoid(lo_ref), t.cpu())
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 1e-3)):
+        m.compute_dtype = dtype
+        with torch.no_grad():
+            lo = m(x).cpu()
+        d = net_oracle.dice(torch.sigmoid(lo), t.cpu())
+        tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+        res.append(_res(f"dice_delta_trained_model[{tagd}]", abs(d - d_ref), tol, extra=f"dice_ref={d_ref:.6f} dice={d:.6f}"))
+    return res

@@ -1,0 +1,163 @@
+"""World-size>1 logic on CPU with gloo: slab partition + boundary hand-over of the sharded blend, and DDP over a
+whole-network autograd.Function.  The compute inside is a NumPy stand-in built from the oracle (test infrastructure);
+what is under test is biapy_amd.workflow's partition / exchange protocol, which is device-agnostic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from biapy_amd import workflow
+from oracle import tiling_oracle as T
+
+
+class NumpyBlend:
+    """Same contract as workflow.DeviceBlend, evaluated with the oracle's arithmetic on CPU tensors."""
+
+    def __init__(self, vol_zyx, patch_zyx, overlap):
+        self.g = T.merge_grid(vol_zyx, patch_zyx, overlap, (0, 0, 0))
+        self.P = tuple(patch_zyx)
+        self.win = T.spline_window(self.P, tuple(g.ov_pixels for g in self.g))[..., 0]
+
+    def blend(self, patches, z_lo, z_hi, rows, acc=None, wacc=None, seed=False, write_partial=False, out_dtype=None):
+        gz, gy, gx = self.g
+        p = patches.numpy()
+        C = p.shape[-1]
+        Y, X = gy.limit, gx.limit
+        num = np.zeros((z_hi - z_lo, Y, X, C), np.float32)
+        ws = np.zeros((z_hi - z_lo, Y, X, 1), np.float32)
+        if seed:
+            num[:] = acc.numpy()
+            ws[:] = wacc.numpy()
+        c = 0
+        for iz in range(rows[0], rows[1]):
+            z0 = gz.start(iz)
+            for y0 in gy.starts():
+                for x0 in gx.starts():
+                    a, b = max(z0, z_lo), min(z0 + self.P[0], z_hi)
+                    if b > a:
+                        w = self.win[a - z0:b - z0, :, :, None]
+                        num[a - z_lo:b - z_lo, y0:y0 + self.P[1], x0:x0 + self.P[2]] += p[c, a - z0:b - z0] * w
+                        ws[a - z_lo:b - z_lo, y0:y0 + self.P[1], x0:x0 + self.P[2]] += w
+                    c += 1
+        if write_partial:
+            acc.copy_(torch.from_numpy(num))
+            wacc.copy_(torch.from_numpy(ws))
+            return None
+        return torch.from_numpy(np.true_divide(num, ws + 1e-18).astype(np.float32))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, vshape, pshape, ov, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(3)
+    g = T.merge_grid(vshape[:3], pshape[:3], ov, (0, 0, 0))
+    n = g[0].n * g[1].n * g[2].n
+    pred = rs.rand(n, *pshape).astype(np.float32)
+    ref = T.merge(pred, vshape, overlap=ov)
+    plans = workflow.plan_slabs(g[0].starts(), pshape[0], vshape[0], world)
+    lo, hi = plans[rank].rows
+    per_row = g[1].n * g[2].n
+    mine = torch.from_numpy(pred[lo * per_row:hi * per_row])
+    out = workflow.sharded_blend(NumpyBlend(vshape[:3], pshape[:3], ov), mine, plans, rank, world, vshape[1], vshape[2], vshape[3], gather="all")
+    ok = bool((out.numpy().view(np.uint32) == ref.view(np.uint32)).all())
+    out0 = workflow.sharded_blend(NumpyBlend(vshape[:3], pshape[:3], ov), mine, plans, rank, world, vshape[1], vshape[2], vshape[3], gather="rank0")
+    ok = ok and ((out0 is None) == (rank != 0))
+    if rank == 0:
+        ok = ok and bool((out0.numpy().view(np.uint32) == ref.view(np.uint32)).all())
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,vshape,pshape,ov", [
+    (2, (72, 40, 40, 1), (32, 32, 32, 1), (0.5, 0.5, 0.5)),
+    (3, (80, 24, 28, 2), (32, 16, 16, 2), (0.6, 0.25, 0.0)),     # overlap > 50 %: three patch rows cover one slice
+    (4, (40, 20, 20, 1), (32, 16, 16, 1), (0.5, 0.0, 0.5)),      # more ranks than patch rows: idle ranks must not dead-lock
+])
+def test_sharded_blend_bit_exact_gloo(world, vshape, pshape, ov):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, vshape, pshape, ov, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_plan_slabs_cfg3():
+    """cfg 3: 16 patch rows (starts 0,60,..,840,896), 8 GPUs -> two rows each, 68-slice hand-over, disjoint cover of [0,1024)."""
+    g = T.merge_grid((1024, 1024, 1024), (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0))
+    plans = workflow.plan_slabs(g[0].starts(), 128, 1024, 8)
+    assert [p.rows for p in plans] == [(2 * r, 2 * r + 2) for r in range(8)]
+    assert plans[0].own == (0, 120) and plans[0].recv is None and plans[0].send == (120, 188)
+    assert plans[3].own == (360, 480) and plans[3].recv == (360, 428) and plans[3].send == (480, 548)
+    assert plans[7].own == (840, 1024) and plans[7].send is None
+    cover = np.zeros(1024, int)
+    for p in plans:
+        cover[p.own[0]:p.own[1]] += 1
+    assert (cover == 1).all()
+
+
+class _WholeNetFn(torch.autograd.Function):
+    """Stand-in with the same autograd shape as biapy_amd.resunet._ResUNetFn: one Function, all parameter grads at once."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ctx.save_for_backward(x, *params)
+        return x * params[0].sum() + params[1].sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b = ctx.saved_tensors
+        return None, torch.full_like(w, (g * x).sum().item()), torch.full_like(b, g.sum().item())
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(5))
+        self.b = torch.nn.Parameter(torch.zeros(3))
+
+    def forward(self, x):
+        return _WholeNetFn.apply(x, self.w, self.b)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = torch.nn.parallel.DistributedDataParallel(_Net())
+    x = torch.full((4,), float(rank + 1))
+    net(x).sum().backward()
+    q.put((rank, net.module.w.grad[0].item(), net.module.b.grad[0].item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_averages_grads_of_a_whole_network_function():
+    """DistributedDataParallel (base_workflow.py:952-958) must average gradients that arrive from ONE autograd.Function."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    # rank0: sum(g*x)=4, rank1: 8 -> mean 6 ; bias grad 4 on both -> 4
+    assert all(abs(w - 6.0) < 1e-6 and abs(b - 4.0) < 1e-6 for _, w, b in res), res
