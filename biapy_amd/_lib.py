@@ -37,6 +37,7 @@ _SIGS = {
     "bpx_last_error": ([], C.c_char_p),
     "bpx_selftest_layouts": ([_vp, _vp], _i),
     "bpx_debug_set_wgrad_tr": ([_i], _i),
+    "bpx_debug_set_conv_ws": ([_i], _i),
     "bpx_crop3d_gather": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _i64, _i64, _vp, _vp], _i),
     "bpx_merge3d_blend": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                            _vp, _vp, _i, _vp, _i, _vp], _i),
@@ -66,6 +67,7 @@ _SIGS = {
     "bpx_conv3d_c1_fwd": ([_i, _i, _i, _i, _i, _vp, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_c1_stats_tiles": ([_i, _i, _i], _i),
     "bpx_conv3d_c1_wgrad": ([_i, _i, _i, _i, _i, _vp, Tensor, _vp, _vp, _vp], _i),
+    "bpx_conv1x1_c1_wgrad": ([_i, _i64, _vp, Tensor, _vp, _vp], _i),
     "bpx_cast": ([_i, _vp, _i, _vp, _i64, _vp], _i),
 }
 

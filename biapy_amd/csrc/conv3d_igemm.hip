@@ -16,48 +16,11 @@
 //   epilogue  : FWD   : + bias (+ fused 1x1x1 shortcut conv of a second raw tensor, + its bias),
 //                       store, per-(n,c) sum / sum^2 partials for the NEXT InstanceNorm.
 //               DGRAD : g = acc * act'(scale*t+shift); store g; partials of sum(g), sum(g*xhat).
-#include <algorithm>
-#include <type_traits>
+#include "conv3d_shared.h"
 
-#include "bpx_common.h"
+using namespace bpxconv;
 
 namespace {
-
-enum { EPI_FWD = 0, EPI_DGRAD = 1 };
-
-struct Conv3Params {
-  int N, D, H, W;
-  const void* x; int x_ld; int Cin;
-  const bpx_norm_rec* in_norm; int act;
-  const void* wp; const float* bias;
-  const void* sc; int sc_ld; int sc_C; const void* wsc; const float* bias_sc;
-  void* y; int y_ld; int Cout;
-  float* part;  // [N][tiles][2][Cout]
-  const void* t; int t_ld; const bpx_norm_rec* t_norm; int t_act;
-  int tilesY, tilesX, tilesPerSample;
-};
-
-// ACTK = 1: ELU known at compile time (the reference default) - no per-element control flow; ACTK = 0: runtime switch.
-template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_rt(float u, int act) {
-  constexpr bool PRECISE = std::is_same<T, float>::value;
-  if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
-    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
-    default: return u;
-  }
-}
-template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
-  constexpr bool PRECISE = std::is_same<T, float>::value;
-  if (ACTK == 1) return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
-    case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-    case BPX_ACT_SILU: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
-    default: return 1.f;
-  }
-}
 
 // Stage an EZ x EY x EX block of voxels (16 channels of chunk `chunk`) into LDS as [voxel][16ch].
 // Voxel (0,0,0) of the block sits at volume coordinate (oz,oy,ox); out-of-volume voxels are ZERO
@@ -115,20 +78,31 @@ __device__ __forceinline__ void stage_block(unsigned char* smem, const T* __rest
   }
 }
 
-template <int HY, int HX, int VB> __device__ __forceinline__ constexpr int tap_off(int tap) {
-  return (((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VB;
+// number of next-chunk weight fragments already re-loaded before step s (at most `per` per step from step np on, and
+// never fragment k before step k has consumed the current one)
+__host__ __device__ constexpr int wreg_next(int s, int np, int per) {
+  int k = 0;
+  for (int t = np; t < s; ++t) {
+    int c = t + 1 - k;
+    k += c < per ? (c > 0 ? c : 0) : per;
+  }
+  return k;
 }
 
 template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK>
-__global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
+__global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int QTOT = 27 * GPT, STEPS = (QTOT + 3) / 4, QPAD = STEPS * 4;
   constexpr int MT = TZ * TY * TX / 16, MS = MT / 4;
   static_assert(MT % 4 == 0 && MS >= 1, "tile must give every wave at least one m-subtile");
+  static_assert((HV * GPT + 255) / 256 <= STEPS, "one staged piece per MFMA step");
+  static_assert(sizeof(T) != 2 || wreg_next(STEPS, (HV * GPT + 255) / 256, (STEPS + (STEPS - (HV * GPT + 255) / 256) - 1) / (STEPS - (HV * GPT + 255) / 256)) == STEPS, "weight re-load schedule must cover every fragment");
   constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[HV * VB + RED_BYTES];
+  constexpr int BUFB = HV * VB;                 // one halo buffer; two of them (double buffering) + reduction scratch
+  static_assert(NS * 16 * 2 * 4 * 4 <= RED_BYTES, "reduction scratch");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + RED_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -195,51 +169,80 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
 
   u32x4_t pbuf[NP];
   float psc[KPL], psh[KPL];
-  // issue the global loads of chunk 0 (async-STAGE split: loads fly while the previous chunk's MFMAs run)
+
+  // One staged piece: normalise + activate (fp32) the raw 16 bytes held in pbuf[u] and store them into the LDS buffer
+  // at byte offset `wbuf`; then re-use the registers for the same piece of channel chunk `next_chunk` (if any).
+#define BPX_STAGE_PIECE(u, wbuf, next_chunk)                                                                  \
+  do {                                                                                                        \
+    const int idx_ = (u) * 256 + tid;                                                                         \
+    if (idx_ < NPIECE) {                                                                                      \
+      u32x4_t v_ = pbuf[u];                                                                                   \
+      if (nrec && goff[u] != 0xFFFFFFFFu) {                                                                   \
+        float f_[KPL];                                                                                        \
+        unpack16<T>(v_, f_);                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = apply_act_rt<T, ACTK>(fmaf(psc[e_], f_[e_], psh[e_]), p.act); \
+        v_ = pack16<T>(f_);                                                                                   \
+      }                                                                                                       \
+      *reinterpret_cast<u32x4_t*>(smem + (wbuf) + (size_t)idx_ * 16) = v_;                                    \
+      if ((next_chunk) < nchunks && goff[u] != 0xFFFFFFFFu)                                                   \
+        pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (next_chunk) * 16);                       \
+    }                                                                                                         \
+  } while (0)
+#define BPX_LOAD_NORM(chunk_)                                                                                 \
+  do {                                                                                                        \
+    if (nrec && (chunk_) < nchunks) {                                                                         \
+      _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) {                                                    \
+        bpx_norm_rec r_ = nrec[(chunk_) * 16 + e_];                                                           \
+        psc[e_] = r_.scale; psh[e_] = r_.shift;                                                               \
+      }                                                                                                       \
+    }                                                                                                         \
+  } while (0)
+
+  // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers ------------------------------------------------
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
     if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u]);
   }
-  if (nrec) {
+  BPX_LOAD_NORM(0);
 #pragma unroll
-    for (int e = 0; e < KPL; ++e) { bpx_norm_rec r = nrec[e]; psc[e] = r.scale; psh[e] = r.shift; }
-  }
+  for (int u = 0; u < NP; ++u) BPX_STAGE_PIECE(u, 0, 1);
+  BPX_LOAD_NORM(1);
+  __syncthreads();
 
+  // ---- main loop: the MFMAs of chunk c read LDS buffer c&1 while the SAME wave, between its MFMA steps, transforms
+  //      chunk c+1 (already in registers) into the other buffer and re-issues the global loads of chunk c+2.  VALU
+  //      (normalise/ELU/convert), the matrix pipe, LDS and HBM latency overlap inside every wave; one barrier per chunk.
+  // Weight operands.  VMEM results retire IN ORDER (one vmcnt queue), so a wait for an L1-resident weight fragment
+  // issued after a halo prefetch stalls for the full HBM latency of that prefetch.  WREG kernels therefore keep the
+  // whole chunk's fragments in registers: they are (re)loaded for chunk c+1 during the last steps of chunk c, AFTER the
+  // step loop has issued its halo re-loads, and are first needed a barrier later - no wait inside the step loop.
+  constexpr bool WREG = (sizeof(T) == 2) && (STEPS * NS * 4 <= 112);
+  constexpr int NWR = WREG ? STEPS : 1;
+  constexpr int WSTEPS = STEPS - NP;                                  // steps without a staging piece
+  constexpr int PER = WREG ? (STEPS + WSTEPS - 1) / WSTEPS : 1;       // fragments re-loaded per such step
+  u32x4_t wreg[NWR][NS];
+  if (WREG) {
+    const T* wl0 = wp + ((size_t)g * Cout + co_base + j) * KPL;
+#pragma unroll
+    for (int s = 0; s < NWR; ++s)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) wreg[s][ns] = *reinterpret_cast<const u32x4_t*>(wl0 + ((size_t)s * 4 * Cout + ns * 16) * KPL);
+  }
+  int cur = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    // transform (normalise + activate, fp32) and write the staged pieces
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      int idx = u * 256 + tid;
-      if (idx < NPIECE) {
-        u32x4_t v = pbuf[u];
-        if (nrec && goff[u] != 0xFFFFFFFFu) {
-          float f[KPL];
-          unpack16<T>(v, f);
-#pragma unroll
-          for (int e = 0; e < KPL; ++e) f[e] = apply_act_rt<T, ACTK>(fmaf(psc[e], f[e], psh[e]), p.act);
-          v = pack16<T>(f);
-        }
-        *reinterpret_cast<u32x4_t*>(smem + (size_t)idx * 16) = v;
-      }
-    }
-    __syncthreads();
-    if (chunk + 1 < nchunks) {
-#pragma unroll
-      for (int u = 0; u < NP; ++u)
-        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (chunk + 1) * 16);
-      if (nrec) {
-#pragma unroll
-        for (int e = 0; e < KPL; ++e) { bpx_norm_rec r = nrec[(chunk + 1) * 16 + e]; psc[e] = r.scale; psh[e] = r.shift; }
-      }
-    }
+    const int nxt = BUFB - cur;
+    const bool stage_next = chunk + 1 < nchunks;
     const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
+    const T* wl1 = wl + (size_t)QPAD * Cout * KPL;   // next chunk
     u32x4_t wf[NS], wn[NS];
+    if (!WREG) {
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)ns * 16 * KPL);
+      for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)ns * 16 * KPL);
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if (s + 1 < STEPS) {
+      if (!WREG && s + 1 < STEPS) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
           wn[ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + 1) * 4 * Cout + ns * 16) * KPL);
@@ -247,19 +250,45 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
       const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s) : s;
       const int cls = (GPT == 2) ? (s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3) : 0;
       const int imm = tap_off<HY, HX, VB>(tapA);
+      // issue ALL of the step's LDS reads before the first MFMA (one lgkmcnt wait per step instead of a serialised
+      // read->wait->mfma chain per fragment); sched_barrier keeps the compiler from re-serialising to save VGPRs
+      u32x4_t af[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls][ms] + imm);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) {
-        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls][ms] + imm);
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(WREG ? wreg[WREG ? s : 0][ns] : wf[ns], af[ms], acc[ms][ns]);
       }
-      if (s + 1 < STEPS) {
+      if (s < NP && stage_next) BPX_STAGE_PIECE(s < NP ? s : 0, nxt, chunk + 2);
+      if (WREG && s >= NP && stage_next) {
+        // re-load fragments [k0, k1) of the NEXT chunk; never a fragment this chunk has not consumed yet (k <= s)
+        const int k0 = wreg_next(s, NP, PER), k1 = wreg_next(s + 1, NP, PER);
+#pragma unroll
+        for (int k = k0; k < k1; ++k) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            wreg[WREG ? (k < STEPS ? k : 0) : 0][ns] = *reinterpret_cast<const u32x4_t*>(wl1 + ((size_t)k * 4 * Cout + ns * 16) * KPL);
+        }
+      }
+      if (!WREG && s + 1 < STEPS) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) wf[ns] = wn[ns];
       }
     }
-    __syncthreads();  // every wave is done reading before the next chunk overwrites the tile
+    BPX_LOAD_NORM(chunk + 2);
+    // flip the read buffer: every ds_read base register moves by +-BUFB (cheaper than an add per read)
+    const int flip = cur ? -BUFB : BUFB;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) lbase[c][ms] += flip;
+    cur = nxt;
+    __syncthreads();  // buffer `nxt` is complete and nobody reads the old one any more
   }
+#undef BPX_STAGE_PIECE
+#undef BPX_LOAD_NORM
 
   // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only) ------------------------------
   if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16) {
@@ -350,7 +379,7 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
   }
 
   if (p.part != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + HV * VB);  // [wave][NS*16][2]
+    float* red = reinterpret_cast<float*>(smem + 2 * BUFB);  // [wave][NS*16][2]
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -373,21 +402,6 @@ __global__ void __launch_bounds__(256) conv3_kernel(const Conv3Params p) {
   }
 }
 
-struct TileCfg { int tz, ty, tx, ns; };
-
-inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
-  TileCfg c;
-  c.ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
-  if (W > 8) {
-    c.tx = 16; c.tz = 4;
-    bool big = (dtype == BPX_BF16) && c.ns <= 2 && (int64_t)D * H * W >= 32768 && H >= 8;
-    c.ty = big ? 8 : 4;
-  } else {
-    c.tx = 8; c.tz = 4; c.ty = 4;
-  }
-  return c;
-}
-
 template <typename T, int EPI>
 int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   Conv3Params p = p0;
@@ -404,7 +418,7 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
     return 0;                                                                    \
   }
   if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only
-    L(4, 8, 16, 1) L(4, 8, 16, 2)
+    L(4, 8, 16, 1)
   }
   L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 4) L(4, 4, 8, 1) L(4, 4, 8, 2) L(4, 4, 8, 4)
 #undef L
@@ -413,9 +427,13 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 
 }  // namespace
 
+static int g_use_ws = 1;  // bf16: wave-specialised persistent kernel (0 = plain 4-wave kernel, for A/B tests)
+extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
+
 extern "C" int bpx_conv3d_stats_tiles(int dtype, int D, int H, int W, int Cout) {
   TileCfg c = pick_cfg(dtype, D, H, W, Cout);
-  return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, c.tx);
+  int t = cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, c.tx);
+  return (dtype == BPX_BF16 && g_use_ws) ? 4 * t : t;  // the wave-specialised kernel writes one partial per MFMA wave
 }
 
 static int check_tensor(const char* fn, const char* name, const bpx_tensor& t, int esize, bool need16) {
@@ -448,7 +466,8 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
   p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
-  int rc = (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream) : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
+  int rc = (dtype == BPX_BF16) ? (g_use_ws ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
+                               : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -472,7 +491,8 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.y = g.ptr; p.y_ld = g.ld; p.Cout = g.C; p.part = t_norm_d ? red_part_d : nullptr;
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
-  int rc = (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream) : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
+  int rc = (dtype == BPX_BF16) ? (g_use_ws ? launch_conv3_ws(EPI_DGRAD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream))
+                               : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

@@ -1,0 +1,72 @@
+// Declarations shared by the implicit-GEMM conv kernels (conv3d_igemm.hip: plain 4-wave kernel, used for the exact-fp32
+// mode; conv3d_ws.hip: the wave-specialised persistent kernel used for bf16).
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "bpx_common.h"
+
+namespace bpxconv {
+
+enum { EPI_FWD = 0, EPI_DGRAD = 1 };
+
+struct Conv3Params {
+  int N, D, H, W;
+  const void* x; int x_ld; int Cin;
+  const bpx_norm_rec* in_norm; int act;
+  const void* wp; const float* bias;
+  const void* sc; int sc_ld; int sc_C; const void* wsc; const float* bias_sc;
+  void* y; int y_ld; int Cout;
+  float* part;  // [N][tiles][2][Cout]
+  const void* t; int t_ld; const bpx_norm_rec* t_norm; int t_act;
+  int tilesY, tilesX, tilesPerSample, totalTiles;
+  int dbg;  // ablation switches for profiling (BPX_CONV_DBG): 1 = skip MFMA steps, 2 = skip staging transform+loads
+};
+
+// ACTK = 1: ELU known at compile time (the reference default) - no per-element control flow; ACTK = 0: runtime switch.
+template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_rt(float u, int act) {
+  constexpr bool PRECISE = std::is_same<T, float>::value;
+  if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
+    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
+    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
+    default: return u;
+  }
+}
+template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
+  constexpr bool PRECISE = std::is_same<T, float>::value;
+  if (ACTK == 1) return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
+    case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case BPX_ACT_SILU: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
+    default: return 1.f;
+  }
+}
+
+
+template <int HY, int HX, int VB> __device__ __forceinline__ constexpr int tap_off(int tap) {
+  return (((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VB;
+}
+
+struct TileCfg { int tz, ty, tx, ns; };
+
+inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
+  TileCfg c;
+  c.ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
+  if (W > 8) {
+    c.tx = 16; c.tz = 4;
+    bool big = (dtype == BPX_BF16) && c.ns == 1 && (int64_t)D * H * W >= 32768 && H >= 8 && getenv("BPX_SMALL_TILE") == nullptr;
+    c.ty = big ? 8 : 4;
+  } else {
+    c.tx = 8; c.tz = 4; c.ty = 4;
+  }
+  return c;
+}
+
+// wave-specialised bf16 kernel (conv3d_ws.hip)
+int launch_conv3_ws(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
+
+}  // namespace bpxconv

@@ -312,18 +312,18 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int CIN>
+template <typename T, int CIN, int COUT>
 __global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w, int Cout,
                                                        const float* __restrict__ dout, int64_t sn, int64_t sc, T* __restrict__ dx,
                                                        int dx_ld, float* __restrict__ dw, float* __restrict__ db, int64_t vps, int N) {
   constexpr int KPL = ElemTraits<T>::KPL;
-  __shared__ float ws[4 * CIN];
+  __shared__ float ws[COUT * CIN];
   for (int i = threadIdx.x; i < Cout * CIN; i += blockDim.x) ws[i] = w[i];
   __syncthreads();
-  float dwl[4][CIN];
-  float dbl[4];
+  float dwl[COUT][CIN];
+  float dbl[COUT];
 #pragma unroll
-  for (int co = 0; co < 4; ++co) {
+  for (int co = 0; co < COUT; ++co) {
     dbl[co] = 0.f;
 #pragma unroll
     for (int c = 0; c < CIN; ++c) dwl[co][c] = 0.f;
@@ -338,8 +338,8 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, 
     int n = (int)(i / vps);
     int64_t v = i - (int64_t)n * vps;
 #pragma unroll
-    for (int co = 0; co < 4; ++co) {
-      if (co < Cout) {
+    for (int co = 0; co < COUT; ++co) {
+      {
         float d = dout[n * sn + co * sc + v];
         dbl[co] += d;
 #pragma unroll
@@ -349,77 +349,127 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int q = 0; q < CIN / KPL; ++q) *reinterpret_cast<u32x4_t*>(dx + (size_t)i * dx_ld + q * KPL) = pack16<T>(o + q * KPL);
   }
+  // block reduction (wave shuffles, then LDS across the 4 waves) -> one atomic per value per block:
+  // a few hundred blocks x 17 values instead of 10^5 colliding atomics on the same 17 addresses
+  __shared__ float redh[4][COUT * CIN + COUT];
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
 #pragma unroll
-  for (int co = 0; co < 4; ++co) {
-    if (co < Cout) {
+  for (int co = 0; co < COUT; ++co) {
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) {
-        float a = dwl[co][c];
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(dw + co * CIN + c, a);
-      }
-      float a = dbl[co];
+    for (int c = 0; c < CIN; ++c) {
+      float a = dwl[co][c];
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
-      if ((threadIdx.x & 63) == 0 && db) atomicAdd(db + co, a);
+      if (ln == 0) redh[wv][co * CIN + c] = a;
     }
+    float a = dbl[co];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+    if (ln == 0) redh[wv][COUT * CIN + co] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < COUT * CIN + COUT; i += blockDim.x) {
+    float sum = redh[0][i] + redh[1][i] + redh[2][i] + redh[3][i];
+    if (i < COUT * CIN) atomicAdd(dw + i, sum);
+    else if (db) atomicAdd(db + (i - COUT * CIN), sum);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // first layer: Cin = 1, k = 3, fp32 image -> 16 output channels per blockIdx.y
 // ------------------------------------------------------------------------------------------------
+// Implicit GEMM with K = 27 taps (padded to 32 / 28): the image halo tile sits in LDS as fp32, a lane gathers the taps
+// of its voxel straight from it.  bf16 storage: the fp32 image value is split into hi + lo bf16 parts (two MFMAs) so the
+// raw input keeps ~16 mantissa bits; the weights are rounded to bf16 like every other layer in that mode.
 template <typename T>
 __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w /* (Cout,1,27) */,
                                                           const float* __restrict__ bias, T* __restrict__ y, int y_ld, int Cout, int D,
-                                                          int H, int W, int tiles, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float ws[27 * 16 + 16];
+                                                          int H, int W, int tilesY, int tilesX, int tilesPerSample, float* __restrict__ part) {
+  constexpr bool BF = std::is_same<T, uint16_t>::value;
+  constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX, MS = 8;
+  __shared__ float simg[HV];
   __shared__ float red[4][32];
-  const int n = blockIdx.z, cb = blockIdx.y * 16, tile = blockIdx.x;
-  for (int i = threadIdx.x; i < 27 * 16; i += 256) { int tap = i / 16, c = i % 16; ws[i] = w[(size_t)(cb + c) * 27 + tap]; }
-  if (threadIdx.x < 16) ws[27 * 16 + threadIdx.x] = bias ? bias[cb + threadIdx.x] : 0.f;
-  __syncthreads();
-  const int64_t vps = (int64_t)D * H * W;
-  const int64_t v = (int64_t)tile * 256 + threadIdx.x;
-  float acc[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x % tilesPerSample, n = blockIdx.x / tilesPerSample, cb = blockIdx.y * 16;
+  const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
+  for (int i = tid; i < HV; i += 256) {
+    int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+    int z = z0 + hz - 1, yy = y0 + hy - 1, x = x0 + hx - 1;
+    simg[i] = (z >= 0 && z < D && yy >= 0 && yy < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + yy) * W + x] : 0.f;
+  }
+  // weight operand of this lane: output channel cb + j, taps 8g..8g+7 (bf16) or 4s+g (f32)
+  u32x4_t wa = u32x4_t{0u, 0u, 0u, 0u};
+  float wf32[7];
+  int toff[BF ? 8 : 7];
+  if (BF) {
+    float wv[8];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = ws[27 * 16 + c];
-  const bool valid = v < vps;
-  if (valid) {
-    int x = (int)(v % W), yy = (int)((v / W) % H), z = (int)(v / ((int64_t)W * H));
-    const float* ip = img + (size_t)n * vps;
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      int zz = z + tap / 9 - 1, yv = yy + (tap / 3) % 3 - 1, xv = x + tap % 3 - 1;
-      float iv = 0.f;
-      if (zz >= 0 && zz < D && yv >= 0 && yv < H && xv >= 0 && xv < W) iv = ip[((size_t)zz * H + yv) * W + xv];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) acc[c] = fmaf(iv, ws[tap * 16 + c], acc[c]);
+    for (int e = 0; e < 8; ++e) {
+      int t = 8 * g + e;
+      wv[e] = t < 27 ? w[(size_t)(cb + j) * 27 + t] : 0.f;
+      int tc = t < 27 ? t : 26;
+      toff[e] = ((tc / 9) * HY + (tc / 3) % 3) * HX + tc % 3;
     }
-    T* yp = y + ((size_t)n * vps + v) * y_ld + cb;
-    if (std::is_same<T, float>::value) {
+    wa = pack16<uint16_t>(wv);
+  } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(yp + q * 4) = pack16<T>(acc + q * 4);
+    for (int s = 0; s < 7; ++s) {
+      int t = 4 * s + g;
+      wf32[s] = t < 27 ? w[(size_t)(cb + j) * 27 + t] : 0.f;
+      int tc = t < 27 ? t : 26;
+      toff[s] = ((tc / 9) * HY + (tc / 3) % 3) * HX + tc % 3;
+    }
+  }
+  __syncthreads();
+  float bsv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bsv[r] = bias ? bias[cb + 4 * g + r] : 0.f;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    int t = (wave * MS + ms) * 16 + j;
+    int tz = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
+    const float* base = simg + (tz * HY + ty) * HX + tx;
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (BF) {
+      float v[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = base[toff[e]];
+      u32x4_t hi = pack16<uint16_t>(v);
+      float hf[8];
+      unpack16<uint16_t>(hi, hf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lo[e] = v[e] - hf[e];
+      u32x4_t lov = pack16<uint16_t>(lo);
+      acc = mfma_step<uint16_t>(wa, hi, acc);
+      acc = mfma_step<uint16_t>(wa, lov, acc);
     } else {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t*>(yp + q * 8) = pack16<T>(acc + q * 8);
+      for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf32[s], base[toff[s]], acc, 0, 0, 0);
+    }
+    int z = z0 + tz, yy = y0 + ty, x = x0 + tx;
+    if (z < D && yy < H && x < W) {
+      float v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v4[r] = acc[r] + bsv[r]; s1[r] += v4[r]; s2[r] += v4[r] * v4[r]; }
+      T* yp = y + ((((size_t)n * D + z) * H + yy) * W + x) * (size_t)y_ld + cb + 4 * g;
+      if (BF) *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pack_bf16x2(v4[0], v4[1]), pack_bf16x2(v4[2], v4[3])};
+      else *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v4[0], v4[1], v4[2], v4[3]};
     }
   }
   if (part) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      float a = valid ? acc[c] : 0.f, b = a * a;
+    for (int r = 0; r < 4; ++r) {
+      float a = s1[r], b = s2[r];
 #pragma unroll
-      for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-      if (lane == 0) { red[wave][c] = a; red[wave][16 + c] = b; }
+      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+      if (j == 0) { red[wave][4 * g + r] = a; red[wave][16 + 4 * g + r] = b; }
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-      int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (tid < 32) {
+      int k = tid >> 4, c = tid & 15;
       float s = red[0][k * 16 + c] + red[1][k * 16 + c] + red[2][k * 16 + c] + red[3][k * 16 + c];
-      part[(((size_t)n * tiles + tile) * 2 + k) * Cout + cb + c] = s;
+      part[(((size_t)n * tilesPerSample + tile) * 2 + k) * Cout + cb + c] = s;
     }
   }
 }
@@ -486,6 +536,34 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_kernel(const float* __restr
     if (t < 27) atomicAdd(dw + (size_t)(cb + c) * 27 + t, s);
     else if (db) atomicAdd(db + cb + c, s);
   }
+}
+
+// shortcut of the first block (Conv3d 1 -> Cout, k = 1): dW[co] += sum_v img[v]*dy[v][co]; 16 channels per blockIdx.y
+template <typename T>
+__global__ void __launch_bounds__(256) rank1_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy, int dy_ld, int64_t total,
+                                                          float* __restrict__ dw) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int cb = blockIdx.y * 16;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    float iv = img[v], f[16];
+#pragma unroll
+    for (int q = 0; q < 16 / KPL; ++q) unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + (size_t)v * dy_ld + cb + q * KPL), f + q * KPL);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = fmaf(iv, f[c], acc[c]);
+  }
+  __shared__ float redr[4][16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    float a = acc[c];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+    if ((threadIdx.x & 63) == 0) redr[threadIdx.x >> 6][c] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(dw + cb + threadIdx.x, redr[0][threadIdx.x] + redr[1][threadIdx.x] + redr[2][threadIdx.x] + redr[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -749,16 +827,18 @@ extern "C" int bpx_head_bwd(int dtype, int64_t vps, int N, bpx_tensor x, const f
   int64_t total = (int64_t)N * vps;
   int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 1024);
   hipStream_t s = (hipStream_t)stream;
-#define HL(T, CIN) head_bwd_kernel<T, CIN><<<blocks, 256, 0, s>>>((const T*)x.ptr, x.ld, w_d, Cout, dout_d, sn, sc, (T*)dx.ptr, dx.ld, dw_d, db_d, vps, N)
+#define HL2(T, CIN, CO) head_bwd_kernel<T, CIN, CO><<<blocks, 256, 0, s>>>((const T*)x.ptr, x.ld, w_d, Cout, dout_d, sn, sc, (T*)dx.ptr, dx.ld, dw_d, db_d, vps, N)
+#define HL(T, CIN) do { if (Cout == 1) HL2(T, CIN, 1); else if (Cout == 2) HL2(T, CIN, 2); else if (Cout == 3) HL2(T, CIN, 3); else HL2(T, CIN, 4); } while (0)
   if (dtype == BPX_BF16) { if (x.C == 16) HL(uint16_t, 16); else HL(uint16_t, 32); }
   else if (dtype == BPX_F32) { if (x.C == 16) HL(float, 16); else HL(float, 32); }
+#undef HL2
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
 #undef HL
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
 
-extern "C" int bpx_conv3d_c1_stats_tiles(int D, int H, int W) { return (int)cdiv64((int64_t)D * H * W, 256); }
+extern "C" int bpx_conv3d_c1_stats_tiles(int D, int H, int W) { return cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16); }
 
 extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d, const float* bias_d,
                                  bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
@@ -766,10 +846,11 @@ extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const fl
   BPX_CHECK(img_d && w_d && y.ptr, "%s: null pointer", fn);
   BPX_CHECK(y.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
   int tiles = bpx_conv3d_c1_stats_tiles(D, H, W);
-  dim3 grid((unsigned)tiles, (unsigned)(y.C / 16), (unsigned)N);
+  int tY = cdiv(H, 8), tX = cdiv(W, 16);
+  dim3 grid((unsigned)(tiles * N), (unsigned)(y.C / 16));
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tiles, stats_part_d);
-  else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tiles, stats_part_d);
+  if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
+  else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -785,6 +866,19 @@ extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
   else if (dtype == BPX_F32) conv_c1_wgrad_kernel<float><<<grid, 256, 0, s>>>(img_d, (const float*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, bpx_stream_t stream) {
+  const char* fn = "bpx_conv1x1_c1_wgrad";
+  BPX_CHECK(img_d && dy.ptr && dw_d, "%s: null pointer", fn);
+  BPX_CHECK(dy.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
+  dim3 grid((unsigned)std::min<int64_t>(cdiv64(voxels_total, 256), 1024), (unsigned)(dy.C / 16));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16) rank1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, voxels_total, dw_d);
+  else if (dtype == BPX_F32) rank1_wgrad_kernel<float><<<grid, 256, 0, s>>>(img_d, (const float*)dy.ptr, dy.ld, voxels_total, dw_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

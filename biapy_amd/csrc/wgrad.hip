@@ -254,22 +254,30 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   (void)sB;
 }
 
-// sums the per-group partials in group order and writes dW in its final layout
+// sums the per-group partials in a fixed order and writes dW in its final layout.
+// 256 threads = 32 consecutive elements x 8 group lanes (the smallest dW has only 6912 elements; one thread per
+// element would leave the chip idle while it streams ~25 MB of partials).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int groups, int taps, int Cin, int Cout,
                                                            float* __restrict__ dw, int64_t si, int64_t sj, int64_t st, int64_t off) {
+  __shared__ float red[8][32];
   const int64_t total = (int64_t)taps * Cin * Cout;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int gq = 0;
-    for (; gq + 4 <= groups; gq += 4) {
-      s0 += part[(size_t)(gq + 0) * total + idx];
-      s1 += part[(size_t)(gq + 1) * total + idx];
-      s2 += part[(size_t)(gq + 2) * total + idx];
-      s3 += part[(size_t)(gq + 3) * total + idx];
+  const int e = threadIdx.x & 31, gl = threadIdx.x >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 32 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (idx < total) {
+    int gq = gl;
+    for (; gq + 8 < groups; gq += 16) {
+      s0 += part[(size_t)gq * total + idx];
+      s1 += part[(size_t)(gq + 8) * total + idx];
     }
-    for (; gq < groups; ++gq) s0 += part[(size_t)gq * total + idx];
+    if (gq < groups) s0 += part[(size_t)gq * total + idx];
+  }
+  red[gl][e] = s0 + s1;
+  __syncthreads();
+  if (gl == 0 && idx < total) {
+    float s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
     int co = (int)(idx % Cout), ci = (int)((idx / Cout) % Cin), tap = (int)(idx / ((int64_t)Cout * Cin));
-    dw[ci * si + co * sj + tap * st + off] = (s0 + s1) + (s2 + s3);
+    dw[ci * si + co * sj + tap * st + off] = s;
   }
 }
 
@@ -333,7 +341,7 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   int64_t total = (int64_t)taps * p.Cin * p.Cout;
-  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 2048);
+  int blocks = (int)cdiv64(total, 32);
   wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(p.part, c.groups, taps, p.Cin, p.Cout, p.dw, p.si, p.sj, p.st, p.off);
   BPX_LAUNCH_CHECK(fn);
   return 0;

@@ -296,9 +296,7 @@ class ResUNetEngine:
         # conv2 weight/bias grad, shortcut weight grad
         self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev)
         if blk.first and self.cfg.in_ch == 1:
-            scratch = torch.zeros((C1, 27), dtype=torch.float32, device=dev)
-            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), dOut, scratch.data_ptr(), None, st))
-            G[k["wsc"]].view(C1).copy_(scratch[:, 13])
+            L.check(lib.bpx_conv1x1_c1_wgrad(self.dt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(), st))
         else:
             self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
         G[k["bsc"]].copy_(G[k["b2"]])  # both biases add to the same tensor: identical gradient

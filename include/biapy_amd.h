@@ -33,6 +33,7 @@ const char* bpx_last_error(void);
 /* MFMA / LDS-transpose lane-layout self test (prints nothing; writes 64*16 floats). Used by tests. */
 int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
 int bpx_debug_set_wgrad_tr(int use_tr); /* test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 */
+int bpx_debug_set_conv_ws(int on);     /* test hook: 0 = plain 4-wave conv kernel instead of the wave-specialised one (bf16) */
 
 /* ------------------------------------------------------------------------------------------------
  * Tiling.  Patch placement along one axis, exactly the reference's integer rule
@@ -196,6 +197,10 @@ int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d,
 int bpx_conv3d_c1_stats_tiles(int D, int H, int W);
 int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy,
                         float* dw_d, float* db_d, bpx_stream_t stream);
+
+/* Shortcut of the first block (Conv3d 1 -> Cout, k = 1, blocks.py:1372 with in_size = 1): dW[co] += sum_v img[v]*dy[v][co].
+ * dw_d must be zeroed by the caller. */
+int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, bpx_stream_t stream);
 
 /* dtype conversion helpers (NDHWC, strided channel slices) */
 int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64_t n, bpx_stream_t stream);

@@ -472,7 +472,7 @@ def check_norm_pool_head(dt, seed=0):
     # Cin = 1 first layer
     img = torch.randn(B, D, H, W, generator=g)
     w1 = torch.randn(16, 1, 3, 3, 3, generator=g) * 0.2; b1 = torch.randn(16, generator=g) * 0.1
-    w1r = w1.clone().requires_grad_(True); b1r = b1.clone().requires_grad_(True)
+    w1r = rnd(w1, dt).requires_grad_(True); b1r = b1.clone().requires_grad_(True)   # bf16 mode rounds weights like every layer
     y1_ref = F.conv3d(img[:, None], w1r, b1r, padding=1)
     y1 = torch.empty(B, D, H, W, 16, dtype=tdtype(dt), device=DEV)
     t1 = lib.bpx_conv3d_c1_stats_tiles(D, H, W)
