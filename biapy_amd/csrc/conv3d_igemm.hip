@@ -420,14 +420,15 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only
     L(4, 8, 16, 1)
   }
-  L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 4) L(4, 4, 8, 1) L(4, 4, 8, 2) L(4, 4, 8, 4)
+  L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 3) L(4, 4, 16, 4) L(4, 4, 8, 1) L(4, 4, 8, 2) L(4, 4, 8, 3) L(4, 4, 8, 4)
 #undef L
   return 1;
 }
 
 }  // namespace
 
-static int g_use_ws = 1;  // bf16: wave-specialised persistent kernel (0 = plain 4-wave kernel, for A/B tests)
+static int g_use_ws = 0;  // 1 = wave-specialised persistent kernel (conv3d_ws.hip).  A/B on cfg 2 (gpurun_out/ab_ws.txt): the plain
+                          // 4-wave kernel is faster or equal on every layer (more co-resident workgroups), so it is the default.
 extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
 
 extern "C" int bpx_conv3d_stats_tiles(int dtype, int D, int H, int W, int Cout) {

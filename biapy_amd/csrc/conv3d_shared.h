@@ -55,7 +55,9 @@ struct TileCfg { int tz, ty, tx, ns; };
 
 inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   TileCfg c;
-  c.ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
+  // 16*NS output channels per workgroup; 48/96-channel outputs (dgrad into the concat buffers) take NS = 3 so that the
+  // halo is staged once instead of three times
+  c.ns = (Cout % 64 == 0) ? 4 : (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
   if (W > 8) {
     c.tx = 16; c.tz = 4;
     bool big = (dtype == BPX_BF16) && c.ns == 1 && (int64_t)D * H * W >= 32768 && H >= 8 && getenv("BPX_SMALL_TILE") == nullptr;

@@ -323,7 +323,7 @@ int launch_ws(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
     else conv3_ws_kernel<T, TZ, TY, TX, NS, EPI, 0><<<grid, 512, 0, s>>>(p);       \
     return 0;                                                                      \
   }
-  L(4, 8, 16, 1) L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 4) L(4, 4, 8, 1) L(4, 4, 8, 2) L(4, 4, 8, 4)
+  L(4, 8, 16, 1) L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 3) L(4, 4, 16, 4) L(4, 4, 8, 1) L(4, 4, 8, 2) L(4, 4, 8, 3) L(4, 4, 8, 4)
 #undef L
   return 1;
 }

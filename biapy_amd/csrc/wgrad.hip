@@ -162,47 +162,127 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ gin = reinterpret_cast<const T*>(p.dy);
 
-  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
+  // ---- staging plan.  16-byte pieces; the LDS images are piece-linear (piece idx at byte idx*16).  The global loads of
+  //      the NEXT tile are issued before the MFMA phase of the current one and land in registers (async-STAGE split);
+  //      they are normalised / activated / written to LDS after the barrier that ends the MFMA phase.
+  constexpr int KPL = Tr::KPL, GPT = 16 / KPL, PPVG = CB / KPL;
+  constexpr int NPA = (HV * GPT + 255) / 256, NPG = (TV * PPVG + 255) / 256;
+  static_assert(256 % GPT == 0 && 256 % PPVG == 0, "piece sub-index must be thread-invariant");
+  const int subA = tid % GPT, subG = tid % PPVG;
+  u32x4_t pa[NPA], pg[NPG];
+  uint32_t va = 0;  // bit u: piece u of the activation halo is inside the volume (gets the prologue)
+  float psc[KPL], psh[KPL];
+  const int Dp = p.D * p.dy_vs, Hp = p.H * p.dy_vs, Wp = p.W * p.dy_vs;
+  int n_cur = -1;
+
+  auto issue_loads = [&](int tt) {
     const int n = tt / p.tilesPerSample, tile = tt % p.tilesPerSample;
-    const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
-    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    const int z0 = (tile / (p.tilesX * p.tilesY)) * TZ, y0 = ((tile / p.tilesX) % p.tilesY) * TY, x0 = (tile % p.tilesX) * TX;
+    va = 0;
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int idx = u * 256 + tid, hv = idx / GPT;
+      const int gz = z0 - HALO + hv / (HX * HY), gy = y0 - HALO + (hv / HX) % HY, gx = x0 - HALO + hv % HX;
+      pa[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (idx < HV * GPT && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        pa[u] = *reinterpret_cast<const u32x4_t*>(xin + ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * (size_t)p.x_ld + chunk * 16 + subA * KPL);
+        va |= 1u << u;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NPG; ++u) {
+      const int idx = u * 256 + tid, t = idx / PPVG;
+      const int gz = z0 + t / (TY * TX), gy = y0 + (t / TX) % TY, gx = x0 + t % TX;
+      pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (idx < TV * PPVG && gz < p.D && gy < p.H && gx < p.W) {
+        const size_t vox = (((size_t)n * Dp + (gz * p.dy_vs + p.dy_oz)) * Hp + (gy * p.dy_vs + p.dy_oy)) * Wp + (gx * p.dy_vs + p.dy_ox);
+        pg[u] = *reinterpret_cast<const u32x4_t*>(gin + vox * (size_t)p.dy_ld + co_base + subG * KPL);
+      }
+    }
+    if (p.in_norm && n != n_cur) {
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) {
+        bpx_norm_rec r = p.in_norm[(size_t)n * p.Cin + chunk * 16 + subA * KPL + e];
+        psc[e] = r.scale; psh[e] = r.shift;
+      }
+    }
+    n_cur = n;
+  };
+  auto write_staged = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < HV * GPT) {
+        u32x4_t v = pa[u];
+        if (p.in_norm && ((va >> u) & 1u)) {
+          float f[KPL];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, ACTK>(fmaf(psc[e], f[e], psh[e]), p.act);
+          v = pack16<T>(f);
+        }
+        *reinterpret_cast<u32x4_t*>(sA + (size_t)idx * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NPG; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < TV * PPVG) *reinterpret_cast<u32x4_t*>(sG + (size_t)idx * 16) = pg[u];
+    }
+  };
+
+  // NB: the norm record of a tile must be the one its loads were issued with: psc/psh are refreshed in issue_loads, and
+  // write_staged of tile k runs BEFORE issue_loads(k+1), so they still belong to tile k.
+  if (grp < p.totalTiles) issue_loads(grp);
+  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
+    __syncthreads();          // previous MFMA phase has finished reading the LDS tiles
+    write_staged();
     __syncthreads();
-    stage_any<T, HZ, HY, HX, 16, ACTK>(sA, xin, p.x_ld, chunk * 16, n, p.D, p.H, p.W, z0 - HALO, y0 - HALO, x0 - HALO, 1, 0, 0, 0,
-                                 p.in_norm, p.Cin, p.act, tid);
-    stage_any<T, TZ, TY, TX, CB>(sG, gin, p.dy_ld, co_base, n, p.D, p.H, p.W, z0, y0, x0, p.dy_vs, p.dy_oz, p.dy_oy, p.dy_ox,
-                                 nullptr, 0, 0, tid);
-    __syncthreads();
+    if (tt + p.groups < p.totalTiles) issue_loads(tt + p.groups);
 
     if (p.db != nullptr && chunk == 0) {  // bias gradient: column sums of the dy tile
       const int c = tid % CB;
       for (int v = tid / CB; v < TV; v += 256 / CB) bsum += Tr::ld(reinterpret_cast<const T*>(sG + (size_t)v * VBG) + c);
     }
 
-    for (int kc = (TAPS == 27 ? 0 : wave); kc < NKC; kc += (TAPS == 27 ? 1 : 4)) {
-      // voxel run of this lane inside the tile
-      int t0 = kc * KC + (BF ? g * 8 : g);
-      int tz = t0 / (TY * TX), ty = (t0 / TX) % TY, tx = t0 % TX;
-      u32x4_t gf[NS];
+    // K loop over the tile's voxels: fetch every operand of a K-chunk (dy fragments + the activation fragments of all of
+    // the wave's taps) first, then issue the MFMAs back to back - one LDS wait per K-chunk instead of one per MFMA.
+    constexpr int KSTEP = (TAPS == 27) ? 1 : 4;
+    auto fetch = [&](int kc, u32x4_t* gfv, u32x4_t* afv) {
+      const int t0 = kc * KC + (BF ? g * 8 : g);
+      const int tz = t0 / (TY * TX), ty = (t0 / TX) % TY, tx = t0 % TX;
+      const int hbase = ((tz * HY + ty) * HX + tx) * VBA;
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
-        if (BF) gf[ns] = frag_T_bf16<VBG, USE_TR>(sG, t0 * VBG, ns * 32, i);
-        else gf[ns][0] = *reinterpret_cast<const uint32_t*>(sG + (size_t)t0 * VBG + (ns * 16 + i) * 4);
+        if (BF) gfv[ns] = frag_T_bf16<VBG, USE_TR>(sG, t0 * VBG, ns * 32, i);
+        else gfv[ns][0] = *reinterpret_cast<const uint32_t*>(sG + (size_t)t0 * VBG + (ns * 16 + i) * 4);
       }
-      const int hbase = ((tz * HY + ty) * HX + tx) * VBA;
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         int tap = (TAPS == 27) ? (wave + 4 * a) : 0;
-        if (TAPS == 27 && tap >= 27) continue;
-        int toff = (TAPS == 27) ? ((((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VBA) : 0;
-        u32x4_t af;
-        if (BF) af = frag_T_bf16<VBA, USE_TR>(sA, hbase + toff, 0, i);
-        else af[0] = *reinterpret_cast<const uint32_t*>(sA + hbase + toff + i * 4);
+        if (TAPS == 27 && tap > 26) tap = 26;   // wave 3 has one tap less: its 7th accumulator is computed but never flushed
+        const int toff = (TAPS == 27) ? ((((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VBA) : 0;
+        if (BF) afv[a] = frag_T_bf16<VBA, USE_TR>(sA, hbase + toff, 0, i);
+        else afv[a][0] = *reinterpret_cast<const uint32_t*>(sA + hbase + toff + i * 4);
+      }
+    };
+    auto mma = [&](const u32x4_t* gfv, const u32x4_t* afv) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
-          if (BF) acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[ns]), acc[a][ns], 0, 0, 0);
-          else acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[0]), __uint_as_float(gf[ns][0]), acc[a][ns], 0, 0, 0);
+          if (BF) acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afv[a]), __builtin_bit_cast(bf16x8_t, gfv[ns]), acc[a][ns], 0, 0, 0);
+          else acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(afv[a][0]), __uint_as_float(gfv[ns][0]), acc[a][ns], 0, 0, 0);
         }
       }
+    };
+    // (a second register set to prefetch K-chunk k+1 was measured: 230 VGPRs -> one wave per SIMD -> 1.4-1.6x SLOWER;
+    //  co-resident workgroups hide the LDS latency better than a deeper pipeline inside one wave.)
+    u32x4_t gfA[NS], afA[NT];
+    for (int kc = (TAPS == 27) ? 0 : wave; kc < NKC; kc += KSTEP) {
+      fetch(kc, gfA, afA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(gfA, afA);
     }
   }
 

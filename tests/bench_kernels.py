@@ -45,6 +45,8 @@ def main():
     T = torch.bfloat16 if dt == L.BF16 else torch.float32
     B = 4
     st = L.stream_ptr()
+    if os.environ.get('BPX_WS') is not None:
+        lib.bpx_debug_set_conv_ws(int(os.environ['BPX_WS']))
 
     def pack(w, mode, cin, cout):
         n = lib.bpx_packed_weight_elems(mode, cin, cout, dt)
