@@ -15,6 +15,17 @@ namespace {
 
 enum { PW_CONV1 = 0, PW_CONVT = 1, PW_CONVTD = 2 };
 
+// four consecutive channels of one voxel with a single 8-byte (bf16) / 16-byte (f32) load
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* f);
+template <> __device__ __forceinline__ void load4<uint16_t>(const uint16_t* p, float* f) {
+  u32x2_t v = *reinterpret_cast<const u32x2_t*>(p);
+  f[0] = bf16lo(v[0]); f[1] = bf16hi(v[0]); f[2] = bf16lo(v[1]); f[3] = bf16hi(v[1]);
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* f) {
+  f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
+  f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+}
+
 struct PwParams {
   int N, D, H, W;        // voxel grid of v (the low-res grid for the transposed conv)
   int64_t vps;           // voxels per sample = D*H*W
@@ -128,13 +139,18 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
         if (p.coef) {
           const T* gp = reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co;
           const T* tp = reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co;
+          float gq[4], tq[4];
+          load4<T>(gp, gq);
+          load4<T>(tp, tq);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) val[r] += cf[r].a * Tr::ld(gp + r) + cf[r].b * Tr::ld(tp + r) + cf[r].c0;
+          for (int r = 0; r < 4; ++r) val[r] += cf[r].a * gq[r] + cf[r].b * tq[r] + cf[r].c0;
         }
         if (p.addend) {
           const T* ap = reinterpret_cast<const T*>(p.addend) + ovox * (size_t)p.addend_ld + co;
+          float aq[4];
+          load4<T>(ap, aq);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) val[r] += Tr::ld(ap + r);
+          for (int r = 0; r < 4; ++r) val[r] += aq[r];
         }
       }
       if (MODE == PW_CONVT) {
@@ -174,7 +190,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 
 constexpr int PW_MS = 2;  // 4 waves x 2 x 16 = 128 voxels per workgroup
 
-inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 : (ncols_per_group % 32 == 0) ? 2 : 1; }
+inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 : (ncols_per_group % 48 == 0) ? 3 : (ncols_per_group % 32 == 0) ? 2 : 1; }
 
 template <typename T, int MODE>
 int launch_pw(PwParams& p, int ns, hipStream_t s) {
@@ -182,6 +198,7 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   int nbk = p.Ncols / (16 * ns);
   dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
   if (ns == 4) pw_kernel<T, PW_MS, 4, MODE><<<grid, 256, 0, s>>>(p);
+  else if (ns == 3) pw_kernel<T, PW_MS, 3, MODE><<<grid, 256, 0, s>>>(p);
   else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE><<<grid, 256, 0, s>>>(p);
   else pw_kernel<T, PW_MS, 1, MODE><<<grid, 256, 0, s>>>(p);
   return 0;

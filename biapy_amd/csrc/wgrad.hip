@@ -363,14 +363,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 
 struct WCfg { int tz, ty, tx, ns, groups; };
 // Deterministic in its arguments: the workspace query and the launch must agree.
-inline WCfg pick_wcfg(int N, int D, int H, int W, int Cin, int Cout, int taps) {
+inline WCfg pick_wcfg(int N, int D, int H, int W, int Cin, int Cout, int taps, bool big_ok) {
   WCfg c;
   c.tz = 4; c.ty = 4;
   c.tx = (W > 8) ? 16 : 8;
+  int ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
+  // k = 1 (shortcut, transposed conv): a 256-voxel tile is only 8 K-chunks - two per wave between barriers.  Large
+  // volumes take 8x8x16 tiles (8 K-chunks per wave); the dy tile then limits the block to 32 output channels.
+  if (big_ok && taps == 1 && W > 8 && D >= 8 && H >= 8) { c.tz = 8; c.ty = 8; if (ns > 2) ns = 2; }
   const int totalTiles = N * cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, c.tx);
   const int64_t dwElems = (int64_t)taps * Cin * Cout;
   const int nchunks = Cin / 16;
-  int ns = (Cout % 64 == 0) ? 4 : (Cout % 32 == 0) ? 2 : 1;
   for (;;) {
     int nb = Cout / (16 * ns);
     int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / dwElems);           // keep the partial slab <= ~50 MB round trip
@@ -395,15 +398,16 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
   p.groups = groups;
   const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
   dim3 grid((unsigned)groups, (unsigned)nchunks, (unsigned)nb);
-#define L(TX, NS)                                                                                   \
-  if (c.tx == TX && c.ns == NS) {                                                                   \
-    if (use_tr && elu) wgrad_kernel<T, 4, 4, TX, NS, TAPS, true, 1><<<grid, 256, 0, s>>>(p);         \
-    else if (use_tr) wgrad_kernel<T, 4, 4, TX, NS, TAPS, true, 0><<<grid, 256, 0, s>>>(p);           \
-    else if (elu) wgrad_kernel<T, 4, 4, TX, NS, TAPS, false, 1><<<grid, 256, 0, s>>>(p);             \
-    else wgrad_kernel<T, 4, 4, TX, NS, TAPS, false, 0><<<grid, 256, 0, s>>>(p);                      \
+#define L(TZY, TX, NS)                                                                              \
+  if (c.tz == TZY && c.tx == TX && c.ns == NS) {                                                    \
+    if (use_tr && elu) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, true, 1><<<grid, 256, 0, s>>>(p);     \
+    else if (use_tr) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, true, 0><<<grid, 256, 0, s>>>(p);       \
+    else if (elu) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, false, 1><<<grid, 256, 0, s>>>(p);         \
+    else wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, false, 0><<<grid, 256, 0, s>>>(p);                  \
     return 0;                                                                                       \
   }
-  L(16, 1) L(16, 2) L(16, 4) L(8, 1) L(8, 2) L(8, 4)
+  L(4, 16, 1) L(4, 16, 2) L(4, 16, 4) L(4, 8, 1) L(4, 8, 2) L(4, 8, 4)
+  if constexpr (TAPS == 1 && sizeof(T) == 2) { L(8, 16, 1) L(8, 16, 2) }
 #undef L
   return 1;
 }
@@ -411,7 +415,7 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
 int g_use_tr = 1;
 
 int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int64_t ws_bytes, hipStream_t s) {
-  WCfg c = pick_wcfg(p.N, p.D, p.H, p.W, p.Cin, p.Cout, taps);
+  WCfg c = pick_wcfg(p.N, p.D, p.H, p.W, p.Cin, p.Cout, taps, false);  // 8x8x16 tiles for k=1 measured slower (convT wgrad 0.76 -> 1.02 ms): off
   int64_t need = (int64_t)c.groups * taps * p.Cin * p.Cout * 4;
   BPX_CHECK(ws != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   p.part = reinterpret_cast<float*>(ws);
@@ -431,11 +435,11 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
 
 extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout, int k) {
   int taps = k * k * k;
-  WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, taps);
+  WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, taps, false);  // small tiles give the larger group count: an upper bound
   return (int64_t)c.groups * taps * Cin * Cout * 4;
 }
 extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
-  WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1);
+  WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);
   return (int64_t)c.groups * Cin * Cout * 4;
 }
 
