@@ -38,13 +38,14 @@ _SIGS = {
     "bpx_selftest_layouts": ([_vp, _vp], _i),
     "bpx_debug_set_wgrad_tr": ([_i], _i),
     "bpx_debug_set_conv_ws": ([_i], _i),
+    "bpx_debug_set_conv_stamps": ([_vp], _i),
     "bpx_crop3d_gather": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _i64, _i64, _vp, _vp], _i),
     "bpx_merge3d_blend": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                            _vp, _vp, _i, _vp, _i, _vp], _i),
     "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
     "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
-    "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i], _i),
+    "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
     "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_conv3d_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),

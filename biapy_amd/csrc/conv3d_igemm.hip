@@ -20,6 +20,10 @@
 
 using namespace bpxconv;
 
+namespace bpxconv { long long* g_conv_stamps = nullptr; }  // profiling hook: device buffer for per-workgroup cycle stamps
+#define g_stamps bpxconv::g_conv_stamps
+extern "C" int bpx_debug_set_conv_stamps(void* p) { g_stamps = (long long*)p; return 0; }
+
 namespace {
 
 // Stage an EZ x EY x EX block of voxels (16 channels of chunk `chunk`) into LDS as [voxel][16ch].
@@ -112,6 +116,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   const int co_base = blockIdx.y * 16 * NS;
   const int Cout = p.Cout;
 
+  int stamp_i = 0;
+#define BPX_STAMP() do { if (p.stamps && tid == 0 && blockIdx.y == 0 && stamp_i < 16) p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+  BPX_STAMP();  // 0: start
   f32x4_t acc[MS][NS];
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
@@ -177,14 +184,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     const int idx_ = (u) * 256 + tid;                                                                         \
     if (idx_ < NPIECE) {                                                                                      \
       u32x4_t v_ = pbuf[u];                                                                                   \
-      if (nrec && goff[u] != 0xFFFFFFFFu) {                                                                   \
+      if (nrec && goff[u] != 0xFFFFFFFFu && !(p.dbg & 2)) {                                                   \
         float f_[KPL];                                                                                        \
         unpack16<T>(v_, f_);                                                                                  \
         _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = apply_act_rt<T, ACTK>(fmaf(psc[e_], f_[e_], psh[e_]), p.act); \
         v_ = pack16<T>(f_);                                                                                   \
       }                                                                                                       \
       *reinterpret_cast<u32x4_t*>(smem + (wbuf) + (size_t)idx_ * 16) = v_;                                    \
-      if ((next_chunk) < nchunks && goff[u] != 0xFFFFFFFFu)                                                   \
+      if ((next_chunk) < nchunks && goff[u] != 0xFFFFFFFFu && !(p.dbg & 4))                                   \
         pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (next_chunk) * 16);                       \
     }                                                                                                         \
   } while (0)
@@ -198,6 +205,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     }                                                                                                         \
   } while (0)
 
+  BPX_STAMP();  // 1: index math done
   // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers ------------------------------------------------
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
@@ -208,7 +216,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
 #pragma unroll
   for (int u = 0; u < NP; ++u) BPX_STAGE_PIECE(u, 0, 1);
   BPX_LOAD_NORM(1);
+  BPX_STAMP();  // 2: chunk 0 transformed + written (includes the HBM latency of its loads)
   __syncthreads();
+  BPX_STAMP();  // 3: first barrier
 
   // ---- main loop: the MFMAs of chunk c read LDS buffer c&1 while the SAME wave, between its MFMA steps, transforms
   //      chunk c+1 (already in registers) into the other buffer and re-issues the global loads of chunk c+2.  VALU
@@ -277,6 +287,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
         for (int ns = 0; ns < NS; ++ns) wf[ns] = wn[ns];
       }
     }
+    BPX_STAMP();  // 4,6,8..: step loop of the chunk done
     BPX_LOAD_NORM(chunk + 2);
     // flip the read buffer: every ds_read base register moves by +-BUFB (cheaper than an add per read)
     const int flip = cur ? -BUFB : BUFB;
@@ -286,6 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
       for (int ms = 0; ms < MS; ++ms) lbase[c][ms] += flip;
     cur = nxt;
     __syncthreads();  // buffer `nxt` is complete and nobody reads the old one any more
+    BPX_STAMP();  // 5,7,9..: barrier passed
   }
 #undef BPX_STAGE_PIECE
 #undef BPX_LOAD_NORM
@@ -369,6 +381,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
           }
         }
         T* yp = yout + vox * (size_t)p.y_ld + co;
+        if (p.dbg & 8) continue;
         if (std::is_same<T, float>::value) {
           *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v[0], v[1], v[2], v[3]};
         } else {
@@ -378,6 +391,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     }
   }
 
+  BPX_STAMP();  // epilogue stores issued
   if (p.part != nullptr) {
     float* red = reinterpret_cast<float*>(smem + 2 * BUFB);  // [wave][NS*16][2]
 #pragma unroll
@@ -409,6 +423,8 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.tilesY = cdiv(p.H, c.ty);
   p.tilesX = cdiv(p.W, c.tx);
   p.tilesPerSample = tilesZ * p.tilesY * p.tilesX;
+  { const char* e = getenv("BPX_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.stamps = g_stamps;  // profiling ablations: 1 no MFMA, 2 no transform, 4 no re-loads, 8 no stores
   dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
 #define L(TZ, TY, TX, NS)                                                        \
@@ -427,14 +443,19 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 
 }  // namespace
 
-static int g_use_ws = 0;  // 1 = wave-specialised persistent kernel (conv3d_ws.hip).  A/B on cfg 2 (gpurun_out/ab_ws.txt): the plain
-                          // 4-wave kernel is faster or equal on every layer (more co-resident workgroups), so it is the default.
+// bf16 kernel selection: 0 = plain 4-wave kernel (this file), 1 = wave-specialised persistent (conv3d_ws.hip),
+// 2 = persistent 4-wave with a cross-tile stage pipeline (conv3d_persist.hip).  A/B on the cfg-2 layers, B=4 (us):
+//   fwd 48->16@128^3: 781 | 868 | 1006     fwd 16->16+img@128^3: 463 | 481 | 484     dgrad 16->48@128^3: 1077 | 2373 | 1205
+// The plain kernel wins everywhere: the alternatives hold a second stage in registers and either spill or drop to
+// fewer co-resident workgroups, which costs more than the latency they hide.
+static int g_use_ws = 0;
 extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
 
-extern "C" int bpx_conv3d_stats_tiles(int dtype, int D, int H, int W, int Cout) {
+extern "C" int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout) {
   TileCfg c = pick_cfg(dtype, D, H, W, Cout);
   int t = cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, c.tx);
-  return (dtype == BPX_BF16 && g_use_ws) ? 4 * t : t;  // the wave-specialised kernel writes one partial per MFMA wave
+  if (dtype == BPX_BF16 && g_use_ws == 2) return 4 * conv3_persist_groups(N * t, Cout / (16 * c.ns));  // one partial per (workgroup, wave)
+  return (dtype == BPX_BF16 && g_use_ws == 1) ? 4 * t : t;
 }
 
 static int check_tensor(const char* fn, const char* name, const bpx_tensor& t, int esize, bool need16) {
@@ -467,7 +488,8 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
   p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
-  int rc = (dtype == BPX_BF16) ? (g_use_ws ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
+  int rc = (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_FWD, p, c, (hipStream_t)stream)
+                                  : g_use_ws == 1 ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
                                : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
@@ -492,7 +514,8 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.y = g.ptr; p.y_ld = g.ld; p.Cout = g.C; p.part = t_norm_d ? red_part_d : nullptr;
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
-  int rc = (dtype == BPX_BF16) ? (g_use_ws ? launch_conv3_ws(EPI_DGRAD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream))
+  int rc = (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_DGRAD, p, c, (hipStream_t)stream)
+                                  : g_use_ws == 1 ? launch_conv3_ws(EPI_DGRAD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream))
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);

@@ -21,6 +21,7 @@ struct Conv3Params {
   float* part;  // [N][tiles][2][Cout]
   const void* t; int t_ld; const bpx_norm_rec* t_norm; int t_act;
   int tilesY, tilesX, tilesPerSample, totalTiles;
+  long long* stamps;  // profiling: per-workgroup s_memtime stamps [block][16] (BPX_CONV_STAMPS), else null
   int dbg;  // ablation switches for profiling (BPX_CONV_DBG): 1 = skip MFMA steps, 2 = skip staging transform+loads
 };
 
@@ -68,6 +69,13 @@ inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   return c;
 }
 
+extern long long* g_conv_stamps;  // profiling hook (bpx_debug_set_conv_stamps)
+
+// persistent workgroups per launch (~2 per CU); also fixes the layout of the statistics partials of conv3d_persist.hip
+inline int conv3_persist_groups(int totalTiles, int gy) { return std::max(1, std::min(totalTiles, (2 * 256 + gy - 1) / gy)); }
+
+// persistent 4-wave bf16 kernel (conv3d_persist.hip)
+int launch_conv3_persist(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 // wave-specialised bf16 kernel (conv3d_ws.hip)
 int launch_conv3_ws(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 

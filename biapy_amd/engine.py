@@ -184,7 +184,7 @@ class ResUNetEngine:
             L.check(lib.bpx_conv3d_c1_fwd(self.dt, B, D, H, W, img.data_ptr(), P[k["w1"]].data_ptr(), P[k["b1"]].data_ptr(),
                                           L.tview(blk.h), part.data_ptr(), st))
         else:
-            tiles = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, C1)
+            tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
             part = _Stats.alloc(B, tiles, C1, dev)
             wp = self._pack(P[k["w1"]], L.PK_K3, blk.cin, C1, cache)
             L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(blk.x, blk.x_c0, blk.cin),
@@ -194,7 +194,7 @@ class ResUNetEngine:
         _Stats.finalize(part, B, tiles, C1, vox, P[k["g1"]], P[k["be1"]], blk.rec_h, C1, 0, st)
         # ---- conv2 (+ shortcut, + residual add) -> out (+ stats) ----------------------------------
         wp2 = self._pack(P[k["w2"]], L.PK_K3, C1, C1, cache)
-        tiles2 = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, C1)
+        tiles2 = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
         part2 = _Stats.alloc(B, tiles2, C1, dev) if want_out_stats else None
         if blk.first and self.cfg.in_ch == 1:
             sc = L.Tensor(img.data_ptr(), 1, 1)
@@ -332,7 +332,7 @@ class ResUNetEngine:
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
         self._keep.append(g1)   # read by the side-stream wgrad of conv1
-        tiles = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, C1)
+        tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
         red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
         w2t = self._pack(P[k["w2"]], L.PK_K3_T, C1, C1, False)
         L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
@@ -355,7 +355,7 @@ class ResUNetEngine:
             return
         Cx = blk.cin
         g0 = torch.empty((B, D, H, W, Cx), dtype=T, device=dev)
-        tiles0 = lib.bpx_conv3d_stats_tiles(self.dt, D, H, W, Cx)
+        tiles0 = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, Cx)
         w1t = self._pack(P[k["w1"]], L.PK_K3_T, Cx, C1, False)
         wsct = self._pack(P[k["wsc"]], L.PK_DENSE_T, Cx, C1, False)
         if has_norm:

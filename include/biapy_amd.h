@@ -33,6 +33,7 @@ const char* bpx_last_error(void);
 /* MFMA / LDS-transpose lane-layout self test (prints nothing; writes 64*16 floats). Used by tests. */
 int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
 int bpx_debug_set_wgrad_tr(int use_tr); /* test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 */
+int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test hook: 0 = plain 4-wave conv kernel instead of the wave-specialised one (bf16) */
 
 /* ------------------------------------------------------------------------------------------------
@@ -113,7 +114,7 @@ int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, int dtype, vo
 int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                    const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_packed_d,
                    const float* bias_sc_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
-int bpx_conv3d_stats_tiles(int dtype, int D, int H, int W, int Cout); /* tiles per sample the call above writes partials for */
+int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout); /* partial-sum slots per sample the call above writes */
 
 /* dgrad of the conv above w.r.t. its (normalised+activated) input, fused with the backward of that
  * activation:  g = convT(dy, W) * act'(scale*t+shift),  t = the conv's raw input tensor.

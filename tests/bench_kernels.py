@@ -63,7 +63,7 @@ def main():
             wp = pack(w, L.PK_K3, cin, cout)
             bias = torch.zeros(cout, device=DEV)
             rec = torch.rand(B, cin, 4, device=DEV)
-            tiles = lib.bpx_conv3d_stats_tiles(dt, S, S, S, cout)
+            tiles = lib.bpx_conv3d_stats_tiles(dt, B, S, S, S, cout)
             part = torch.empty(B, tiles, 2, cout, device=DEV)
             sct, wscp, keep = L.NULL_T, None, []
             if csc == 1:
@@ -86,7 +86,7 @@ def main():
             g = torch.empty(B, S, S, S, cin, device=DEV, dtype=T)
             wp = pack(torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05, L.PK_K3_T, cin, cout)
             rec = torch.rand(B, cin, 4, device=DEV)
-            tiles = lib.bpx_conv3d_stats_tiles(dt, S, S, S, cin)
+            tiles = lib.bpx_conv3d_stats_tiles(dt, B, S, S, S, cin)
             red = torch.empty(B, tiles, 2, cin, device=DEV)
             f = lambda: L.check(lib.bpx_conv3d_dgrad(dt, B, S, S, S, L.tview(dy), wp.data_ptr(), L.tview(t), rec.data_ptr(), 1, L.tview(g),
                                                      red.data_ptr(), st))

@@ -209,7 +209,7 @@ def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=
     xb[..., xo:xo + Cin] = to_dev(x, dt)
     yb = torch.full((B, D, H, W, Cout + 2 * yo), 7.0, dtype=tdtype(dt), device=DEV)
     wp = pack(w, L.PK_K3, Cin, Cout, dt)
-    tiles = lib.bpx_conv3d_stats_tiles(dt, D, H, W, Cout)
+    tiles = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, Cout)
     part = torch.zeros(B, tiles, 2, Cout, dtype=torch.float32, device=DEV)
     recd = rec.to(DEV) if rec is not None else None
     bd = b.to(DEV)
@@ -253,7 +253,7 @@ def check_conv3d_dgrad(dt, B, S, Cin, Cout, seed=0, act=1):
     g_ref = ndhwc(dA) * dact
     xh = (t - rec[:, None, None, None, :, 0]) * rec[:, None, None, None, :, 1]
     gd = torch.empty(B, D, H, W, Cin, dtype=tdtype(dt), device=DEV)
-    tiles = lib.bpx_conv3d_stats_tiles(dt, D, H, W, Cin)
+    tiles = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, Cin)
     red = torch.zeros(B, tiles, 2, Cin, dtype=torch.float32, device=DEV)
     wp = pack(w, L.PK_K3_T, Cin, Cout, dt)
     dyd, td, recd = to_dev(dy, dt), to_dev(t, dt), rec.to(DEV)
