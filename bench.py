@@ -59,6 +59,21 @@ def conv_flops(name, key):
     return 0
 
 
+def conv_bytes(name, key, es):
+    """Algorithmic HBM bytes of one conv launch: every activation operand read once, the result written once."""
+    if name not in ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad"):
+        return 0
+    ints = [k for k in key if isinstance(k, int)]
+    cs = [int(k[1:]) for k in key if isinstance(k, str)]
+    N, D, H, W = ints[1:5]
+    vox = N * D * H * W
+    if name == "bpx_conv3d_fwd":      # read x, read shortcut input, write y
+        return vox * (cs[0] + cs[1] + cs[2]) * es
+    if name == "bpx_conv3d_dgrad":    # read dy, read the pre-activation t, write g
+        return vox * (cs[0] + 2 * cs[2]) * es
+    return vox * (cs[0] + cs[1]) * es  # wgrad: read x and dy
+
+
 def cpu_baseline(P, train):
     """The oracle (plain PyTorch CPU fp32 restatement of the reference graph) on this host's cores, batch 1."""
     from oracle import net_oracle
@@ -91,12 +106,62 @@ def cpu_baseline(P, train):
                        f"({dt:.2f} s each)")
 
 
+def synth_volume(V, dev, seed=3):
+    """SURVEY.md 8(d) cfg 3: closed-form sin/cos lattice + seeded noise, generated on the device (no 4.3 GB transfer)."""
+    ax = torch.arange(V, device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    vol = torch.sin(ax * 0.11)[:, None, None] * torch.cos(ax * 0.07)[None, :, None] + torch.sin(ax * 0.05)[None, None, :]
+    vol = vol + 0.3 * torch.randn(V, V, V, generator=g, device=dev)
+    return vol.unsqueeze(-1).contiguous()
+
+
+def bench_sliding(a, model, dev, rank, world):
+    """cfg 3: crop -> forward -> blend of one volume; patches sharded over the ranks (strong scaling)."""
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    model.eval()
+    V = a.vol
+    vol = synth_volume(V, dev)
+    sw = SlidingWindowPredictor(model, (a.patch,) * 3, (0.5, 0.5, 0.5), (0, 0, 0), batch_size=a.batch)
+    out = None
+    for _ in range(a.warmup):
+        out = sw.predict(vol, rank=rank, world=world, gather="rank0")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = sw.predict(vol, rank=rank, world=world, gather="rank0")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    if rank == 0:
+        from biapy_amd import tiling
+        plan = tiling.MergePlan((V, V, V), (a.patch,) * 3, (0.5, 0.5, 0.5), (0, 0, 0), dev)
+        pv = plan.n_patches * a.patch ** 3
+        print(json.dumps(dict(
+            metric="voxels/sec 3D ResUNet 128^3 patch (sliding-window inference: crop+forward+blend, patch voxels)",
+            value=pv * a.steps / elapsed, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
+            higher_is_better=True, scaling="strong", vs_baseline=None, dtype=a.dtype, data="synthetic",
+            config=dict(workload="cfg3: %d^3 volume, %d^3 patches, 50%% overlap, %d patches sharded over %d GPU(s)" % (V, a.patch, plan.n_patches, world),
+                        patches=plan.n_patches, volume=V, parallelism="z-slab x%d" % world),
+            output_voxels_per_s=V ** 3 * a.steps / elapsed, checksum=float(out.double().mean().item()) if out is not None else None)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--mode", choices=["train", "infer", "sliding"], default="train")
+    ap.add_argument("--vol", type=int, default=1024, help="sliding mode: edge of the synthetic volume (cfg 3 = 1024)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
@@ -121,6 +186,8 @@ def main():
     torch.manual_seed(0)
     model = ResUNet(image_shape=(a.patch,) * 3 + (1,), activation="elu", feature_maps=FM, drop_values=[0.0] * 5, normalization="in",
                     yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev)
+    if a.mode == "sliding":
+        return bench_sliding(a, model, dev, rank, world)
     train = a.mode == "train"
     net = model
     if train:
@@ -190,19 +257,34 @@ def main():
         summ = prof.summary()
         per = {}
         for (name, key), (cnt, ms) in summ.items():
-            d = per.setdefault(name, [0.0, 0.0, 0])
+            d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
             d[0] += conv_flops(name, key) * cnt
             d[1] += ms
             d[2] += cnt
+            d[3] += conv_bytes(name, key, 2 if a.dtype == "bf16" else 4) * cnt
         dom = max(per.items(), key=lambda kv: kv[1][1]) if per else None
         roofline = None
         if dom:
-            name, (fl, ms, cnt) = dom
-            ach = fl / (ms * 1e-3) / 1e12
+            name, (fl, ms, cnt, by) = dom
             peak = MFMA_PEAK_BF16 / 1e12 if a.dtype == "bf16" else 157.3
-            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                            traffic=None, launches=cnt, avg_launch_ms=round(ms / cnt, 4),
-                            all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), ms_per_step=round(v[1] / a.steps, 3)) for k, v in per.items()})
+            ach_f = fl / (ms * 1e-3) / 1e12                 # TFLOP/s
+            ach_b = by / (ms * 1e-3) / 1e9                  # GB/s of algorithmic bytes
+            # the binding roof is the one whose minimum time (work / peak) is larger for this kernel's launches
+            hbm_bound = by / HBM_PEAK > fl / (peak * 1e12)
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/pmc_traffic.py
+            try:
+                traffic = (json.load(open(tf)).get(name) or {}).get("total_bytes")
+            except (OSError, ValueError):
+                traffic = None
+            roofline = dict(bound="hbm" if hbm_bound else "mfma", kernel=name,
+                            achieved=round(ach_b if hbm_bound else ach_f, 2), peak=HBM_PEAK / 1e9 if hbm_bound else peak,
+                            unit="GB/s" if hbm_bound else "TFLOP/s",
+                            frac=round(ach_b / (HBM_PEAK / 1e9) if hbm_bound else ach_f / peak, 4),
+                            traffic=traffic, algorithmic_bytes_per_launch=round(by / cnt), flops_per_launch=round(fl / cnt),
+                            launches=cnt, avg_launch_ms=round(ms / cnt, 4), tflops=round(ach_f, 2), algorithmic_GBps=round(ach_b, 1),
+                            all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), GBps=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                         ms_per_step=round(v[1] / a.steps, 3)) for k, v in per.items()})
         mult = 3 if train else 1
         line = dict(
             metric="voxels/sec 3D ResUNet 128^3 patch (%s)" % ("train: fwd+bwd+AdamW" if train else "inference forward"),

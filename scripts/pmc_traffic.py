@@ -1,0 +1,55 @@
+"""HBM bytes per launch of the conv entry points from two rocprofv3 --pmc passes over `python bench.py ...`.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_f -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_w -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python scripts/pmc_traffic.py gpurun_out/pmc_f/*/p_results.db gpurun_out/pmc_w/*/p_results.db > profiles/pmc_traffic.json
+
+Units / corrections (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE tallies the
+128-byte requests of wide (16 B/lane) coalesced reads at 64 B, so it is doubled for the conv kernels, whose global reads are
+all 16 B/lane.  WRITE_SIZE is used as reported.  The same passes give the figures of the streaming `cast_kernel` (known byte
+count) as a calibration row.
+"""
+import json
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+GROUPS = [
+    ("bpx_conv3d_fwd", re.compile(r"conv3_kernel<[^>]*?, (\d+), 0, \d+>")),
+    ("bpx_conv3d_dgrad", re.compile(r"conv3_kernel<[^>]*?, (\d+), 1, \d+>")),
+    ("bpx_conv3d_wgrad", re.compile(r"::wgrad_kernel<")),
+    ("cast_kernel(calibration)", re.compile(r"cast_kernel")),
+]
+
+
+def collect(db, counter):
+    con = sqlite3.connect(db)
+    acc = defaultdict(list)
+    for name, val in con.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)):
+        for g, rx in GROUPS:
+            if rx.search(name):
+                acc[g].append(val)
+                break
+    return acc
+
+
+def main():
+    fdb, wdb = sys.argv[1], sys.argv[2]
+    f = collect(fdb, "FETCH_SIZE")
+    w = collect(wdb, "WRITE_SIZE")
+    out = {}
+    for g, _ in GROUPS:
+        if g not in f:
+            continue
+        nf, nw = len(f[g]), len(w.get(g, []))
+        fetch_raw = 1024.0 * sum(f[g]) / nf
+        write = 1024.0 * sum(w[g]) / nw if nw else None
+        out[g] = dict(launches=nf, fetch_raw_bytes=round(fetch_raw), fetch_bytes=round(2 * fetch_raw), write_bytes=round(write) if write else None,
+                      total_bytes=round(2 * fetch_raw + (write or 0)))
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
