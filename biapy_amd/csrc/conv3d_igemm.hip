@@ -23,6 +23,7 @@ using namespace bpxconv;
 namespace bpxconv { long long* g_conv_stamps = nullptr; }  // profiling hook: device buffer for per-workgroup cycle stamps
 #define g_stamps bpxconv::g_conv_stamps
 extern "C" int bpx_debug_set_conv_stamps(void* p) { g_stamps = (long long*)p; return 0; }
+static int g_use_ws = 0;  // bf16 kernel selection, see bpx_debug_set_conv_ws below
 
 namespace {
 
@@ -93,8 +94,11 @@ __host__ __device__ constexpr int wreg_next(int s, int np, int per) {
   return k;
 }
 
-template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK>
-__global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
+// LEAN = true trades the intra-workgroup pipeline (second halo buffer, register-prefetched next chunk, a chunk's weights
+// held in registers) for residency: one halo buffer and <= 128 VGPRs let 4 workgroups (16 waves) share a CU instead of 2,
+// and the other workgroups' MFMA/LDS/VALU work covers this one's global-load latency (measured: DESIGN.md section 6).
+template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool LEAN>
+__global__ void __launch_bounds__(256, LEAN ? ((NS == 1 && TY * TX * TZ <= 256) || TY * TX * TZ <= 128 ? 4 : 3) : 2) conv3_kernel(const Conv3Params p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
@@ -106,7 +110,8 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
   constexpr int BUFB = HV * VB;                 // one halo buffer; two of them (double buffering) + reduction scratch
   static_assert(NS * 16 * 2 * 4 * 4 <= RED_BYTES, "reduction scratch");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB + RED_BYTES];
+  constexpr int NBUF = LEAN ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUFB + RED_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -117,21 +122,29 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   const int Cout = p.Cout;
 
   int stamp_i = 0;
-#define BPX_STAMP() do { if (p.stamps && tid == 0 && blockIdx.y == 0 && stamp_i < 16) p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define BPX_STAMP() do { if (p.stamps && tid == 0 && blockIdx.y == 0 && stamp_i < 15) p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
   BPX_STAMP();  // 0: start
+  if (p.stamps && tid == 0 && blockIdx.y == 0)  // slot 15: where the workgroup ran (HW_ID | XCC_ID << 32)
+    p.stamps[(size_t)blockIdx.x * 16 + 15] =
+        (long long)(((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
   f32x4_t acc[MS][NS];
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  int hb[MS], tb[MS];
-#pragma unroll
-  for (int ms = 0; ms < MS; ++ms) {
-    int t = (wave * MS + ms) * 16 + j;
+  // A wave's MS m-subtiles are consecutive rows (TX = 16) or row pairs (TX = 8) of ONE z-slice of the tile, so the LDS
+  // address of subtile ms is the address of subtile 0 plus a compile-time stride: every ds_read below is
+  // VGPR base + immediate.
+  static_assert(TZ == 4 && MS * 16 == TY * TX && (TX == 16 || TX == 8), "wave = z-slice mapping");
+  constexpr int HSTR = (TX >= 16 ? 1 : 16 / TX) * HX * VB;      // halo-buffer stride between m-subtiles
+  constexpr int TSTR = 16 * VB;                                  // same for the un-haloed [voxel][16ch] block (shortcut)
+  int hb0, tb0;
+  {
+    int t = (wave * MS) * 16 + j;
     int tz = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
-    hb[ms] = ((tz * HY + ty) * HX + tx) * VB;
-    tb[ms] = t * VB;
+    hb0 = ((tz * HY + ty) * HX + tx) * VB;
+    tb0 = t * VB;
   }
   // Per-lane K decomposition (DESIGN.md "K order").  bf16: a step covers two taps x 16 channels; lanes g<2 take tap A,
   // lanes g>=2 tap B.  The taps are paired (bpx_tap_order_bf16) so that addr(B)-addr(A) is one of three constants;
@@ -139,17 +152,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   const int cg_off = (GPT == 2 ? (g & 1) : g) * 16;
   const bool hi_tap = (GPT == 2) && (g >> 1);
   constexpr int NCLS = (GPT == 2) ? 4 : 1;
-  int lbase[NCLS][MS];
-#pragma unroll
-  for (int ms = 0; ms < MS; ++ms) {
-    if (GPT == 2) {
-      lbase[0][ms] = hb[ms] + cg_off + (hi_tap ? VB : 0);
-      lbase[1][ms] = hb[ms] + cg_off + (hi_tap ? HX * VB : 0);
-      lbase[2][ms] = hb[ms] + cg_off + (hi_tap ? HY * HX * VB : 0);
-      lbase[NCLS - 1][ms] = hb[ms] + cg_off;
-    } else {
-      lbase[0][ms] = hb[ms] + cg_off;
-    }
+  int lbase[NCLS];
+  if (GPT == 2) {
+    lbase[0] = hb0 + cg_off + (hi_tap ? VB : 0);
+    lbase[1 % NCLS] = hb0 + cg_off + (hi_tap ? HX * VB : 0);
+    lbase[2 % NCLS] = hb0 + cg_off + (hi_tap ? HY * HX * VB : 0);
+    lbase[NCLS - 1] = hb0 + cg_off;
+  } else {
+    lbase[0] = hb0 + cg_off;
   }
 
   // ---- staging plan: which 16-byte pieces of the halo this thread moves (fixed for the tile) --------
@@ -206,6 +216,54 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   } while (0)
 
   BPX_STAMP();  // 1: index math done
+  if constexpr (LEAN) {
+    // ---- lean loop: stage chunk -> barrier -> MFMA steps -> barrier.  Nothing of the next chunk is held in registers;
+    //      latency is covered by the other workgroups resident on the CU.  Weight fragments (L1/L2-resident) are
+    //      fetched WD steps ahead through a small register ring.
+    constexpr int WD = (NS <= 2) ? 2 : 1;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      if (chunk) __syncthreads();  // every wave has finished reading the previous chunk
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
+        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + chunk * 16);
+      }
+      BPX_LOAD_NORM(chunk);
+      const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
+      u32x4_t wq[WD + 1][NS];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)d * 4 * Cout + ns * 16) * KPL);
+#pragma unroll
+      for (int u = 0; u < NP; ++u) BPX_STAGE_PIECE(u, 0, nchunks);
+      if (chunk == 0) BPX_STAMP();  // 2: chunk 0 transformed + written
+      __syncthreads();
+      if (chunk == 0) BPX_STAMP();  // 3: barrier
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        if (s + WD < STEPS) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + WD) * 4 * Cout + ns * 16) * KPL);
+        }
+        const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s) : s;
+        const int cls = (GPT == 2) ? (s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3) : 0;
+        const int imm = tap_off<HY, HX, VB>(tapA);
+        u32x4_t af[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[ms][ns]);
+        }
+      }
+      BPX_STAMP();  // step loop of the chunk done
+    }
+    __syncthreads();
+  } else {
   // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers ------------------------------------------------
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
@@ -264,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
       // read->wait->mfma chain per fragment); sched_barrier keeps the compiler from re-serialising to save VGPRs
       u32x4_t af[MS];
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls][ms] + imm);
+      for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) {
@@ -292,12 +350,11 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     // flip the read buffer: every ds_read base register moves by +-BUFB (cheaper than an add per read)
     const int flip = cur ? -BUFB : BUFB;
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c)
-#pragma unroll
-      for (int ms = 0; ms < MS; ++ms) lbase[c][ms] += flip;
+    for (int c = 0; c < NCLS; ++c) lbase[c] += flip;
     cur = nxt;
     __syncthreads();  // buffer `nxt` is complete and nobody reads the old one any more
     BPX_STAMP();  // 5,7,9..: barrier passed
+  }
   }
 #undef BPX_STAGE_PIECE
 #undef BPX_LOAD_NORM
@@ -317,7 +374,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
       for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)ns * 16 * KPL);
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) {
-        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + tb[ms] + cg_off);
+        u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + tb0 + ms * TSTR + cg_off);
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
       }
@@ -393,7 +450,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
 
   BPX_STAMP();  // epilogue stores issued
   if (p.part != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + 2 * BUFB);  // [wave][NS*16][2]
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUFB);  // [wave][NS*16][2]
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -427,10 +484,19 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.stamps = g_stamps;  // profiling ablations: 1 no MFMA, 2 no transform, 4 no re-loads, 8 no stores
   dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
+  // lean (high-residency) kernel where there are enough tiles for >= 4 rounds per CU; the double-buffered one below that
+  const bool lean = (sizeof(T) == 2) && (g_use_ws == 3 || (g_use_ws == 0 && (int64_t)p.D * p.H * p.W >= 262144));
 #define L(TZ, TY, TX, NS)                                                        \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
-    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1><<<grid, 256, 0, s>>>(p);    \
-    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0><<<grid, 256, 0, s>>>(p);        \
+    if constexpr (sizeof(T) == 2) {                                              \
+      if (lean) {                                                                \
+        if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, true><<<grid, 256, 0, s>>>(p);  \
+        else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0, true><<<grid, 256, 0, s>>>(p);      \
+        return 0;                                                                \
+      }                                                                          \
+    }                                                                            \
+    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, false><<<grid, 256, 0, s>>>(p);     \
+    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0, false><<<grid, 256, 0, s>>>(p);         \
     return 0;                                                                    \
   }
   if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only
@@ -443,12 +509,13 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 
 }  // namespace
 
-// bf16 kernel selection: 0 = plain 4-wave kernel (this file), 1 = wave-specialised persistent (conv3d_ws.hip),
-// 2 = persistent 4-wave with a cross-tile stage pipeline (conv3d_persist.hip).  A/B on the cfg-2 layers, B=4 (us):
+// bf16 kernel selection: 0 = automatic (this file: lean kernel for >= 64^3 volumes, double-buffered kernel below),
+// 1 = wave-specialised persistent (conv3d_ws.hip), 2 = persistent 4-wave with a cross-tile stage pipeline
+// (conv3d_persist.hip), 3 = always lean, 4 = always double-buffered.  A/B of 4 | 1 | 2 on the cfg-2 layers, B=4 (us):
 //   fwd 48->16@128^3: 781 | 868 | 1006     fwd 16->16+img@128^3: 463 | 481 | 484     dgrad 16->48@128^3: 1077 | 2373 | 1205
-// The plain kernel wins everywhere: the alternatives hold a second stage in registers and either spill or drop to
-// fewer co-resident workgroups, which costs more than the latency they hide.
-static int g_use_ws = 0;
+// Both lose to the double-buffered kernel: they hold a second stage in registers and either spill or drop to fewer
+// co-resident workgroups.  The lean kernel goes the other way (3-4 workgroups per CU, nothing pipelined inside a
+// workgroup) and wins wherever a CU gets >= 4 rounds of tiles: 725 / 342 / 944 us on the same three layers.
 extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
 
 extern "C" int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout) {

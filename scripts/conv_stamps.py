@@ -40,11 +40,15 @@ def run():
                                part.data_ptr(), st))
 
 
+if os.environ.get("BPX_WS") is not None:
+    lib.bpx_debug_set_conv_ws(int(os.environ["BPX_WS"]))
 run(); torch.cuda.synchronize()
 lib.bpx_debug_set_conv_stamps(stamps.data_ptr())
 run(); torch.cuda.synchronize()
 lib.bpx_debug_set_conv_stamps(None)
 s = stamps.cpu().numpy()
+hw = s[:, 15].copy()
+s = s[:, :15]
 nz = (s != 0).sum(1).max()
 d = np.diff(s[:, :nz], axis=1).astype(np.float64)
 if os.environ.get("BPX_STAMP_NAMES") == "persist":
@@ -65,5 +69,23 @@ for i in range(d.shape[1]):
     print(f"  {names[i] if i < len(names) else i:32s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 90):9.0f}")
 tot = (s[:, nz - 1] - s[:, 0]).astype(np.float64)
 print(f"  {'workgroup total':32s} {np.median(tot):9.0f} {tot.mean():9.0f} {np.percentile(tot, 90):9.0f}")
-span = s[:, :nz].max() - s[:, 0].min()
+# residency: workgroups of one CU (XCC, SE, SH, CU ids) share a clock, so their [start, end] intervals can be overlapped
+cu = ((hw >> 32) & 0xF) * 65536 + ((hw >> 8) & 0xFF)
+occ = []
+for c in np.unique(cu):
+    m = cu == c
+    st_, en_ = s[m, 0], s[m, nz - 1]
+    ev = np.concatenate([np.stack([st_, np.ones_like(st_)], 1), np.stack([en_, -np.ones_like(en_)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    live = np.cumsum(ev[:, 1])
+    dtv = np.diff(ev[:, 0])
+    occ.append((live[:-1] * dtv).sum() / max(dtv.sum(), 1))
+print(f"  {len(np.unique(cu))} distinct CUs; time-averaged resident workgroups per CU: mean {np.mean(occ):.2f}, min {np.min(occ):.2f}, max {np.max(occ):.2f}; "
+      f"tiles per CU {np.bincount(np.unique(cu, return_inverse=True)[1]).min()}..{np.bincount(np.unique(cu, return_inverse=True)[1]).max()}")
+ok = s[:, 0] > 0
+span = s[ok, :nz].max() - s[ok, 0].min()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+print(f"  event time {ms * 1e3:.0f} us -> stamp clock = {span / (ms * 1e-3) / 1e6:.0f} MHz")
 print(f"  kernel span {span} cycles; sum of workgroup totals / span = {tot.sum() / span:.1f} workgroups in flight (of {256 * 2} slots)")

@@ -40,6 +40,27 @@ def test_conv3d_fwd(K, dt):
     _assert_all(rows)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["wave-specialised", "persistent", "lean", "double-buffered"])
+def test_conv3d_bf16_kernel_variants(K, variant):
+    """Every schedule of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) computes the same convolution."""
+    from biapy_amd import _lib as L
+
+    L.lib.bpx_debug_set_conv_ws(variant)
+    try:
+        rows = []
+        rows += K.check_conv3d_fwd(1, 1, (8, 12, 20), 48, 16, norm=True, sc_C=48, slices=True)
+        rows += K.check_conv3d_fwd(1, 2, (6, 8, 8), 32, 64, norm=False, sc_C=1)
+        rows += K.check_conv3d_fwd(1, 1, (32, 32, 32), 16, 32, norm=True, sc_C=16)
+        rows += K.check_conv3d_fwd(1, 1, (32, 32, 32), 48, 16, norm=True, sc_C=0)
+        rows += K.check_conv3d_fwd(1, 1, (32, 32, 32), 16, 16, norm=True, sc_C=1)
+        rows += K.check_conv3d_dgrad(1, 2, (8, 8, 16), 48, 16)
+        rows += K.check_conv3d_dgrad(1, 1, (32, 32, 32), 16, 48)
+        rows += K.check_conv3d_dgrad(1, 1, (32, 32, 32), 32, 16)
+    finally:
+        L.lib.bpx_debug_set_conv_ws(0)
+    _assert_all(rows)
+
+
 @pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
 def test_conv3d_backward_kernels(K, dt):
     rows = []
