@@ -94,11 +94,8 @@ __host__ __device__ constexpr int wreg_next(int s, int np, int per) {
   return k;
 }
 
-// LEAN = true trades the intra-workgroup pipeline (second halo buffer, register-prefetched next chunk, a chunk's weights
-// held in registers) for residency: one halo buffer and <= 128 VGPRs let 4 workgroups (16 waves) share a CU instead of 2,
-// and the other workgroups' MFMA/LDS/VALU work covers this one's global-load latency (measured: DESIGN.md section 6).
-template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool LEAN>
-__global__ void __launch_bounds__(256, LEAN ? ((NS == 1 && TY * TX * TZ <= 256) || TY * TX * TZ <= 128 ? 4 : 3) : 2) conv3_kernel(const Conv3Params p) {
+template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK>
+__global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
@@ -110,7 +107,7 @@ __global__ void __launch_bounds__(256, LEAN ? ((NS == 1 && TY * TX * TZ <= 256) 
   constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
   constexpr int BUFB = HV * VB;                 // one halo buffer; two of them (double buffering) + reduction scratch
   static_assert(NS * 16 * 2 * 4 * 4 <= RED_BYTES, "reduction scratch");
-  constexpr int NBUF = LEAN ? 1 : 2;
+  constexpr int NBUF = 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUFB + RED_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -216,54 +213,7 @@ __global__ void __launch_bounds__(256, LEAN ? ((NS == 1 && TY * TX * TZ <= 256) 
   } while (0)
 
   BPX_STAMP();  // 1: index math done
-  if constexpr (LEAN) {
-    // ---- lean loop: stage chunk -> barrier -> MFMA steps -> barrier.  Nothing of the next chunk is held in registers;
-    //      latency is covered by the other workgroups resident on the CU.  Weight fragments (L1/L2-resident) are
-    //      fetched WD steps ahead through a small register ring.
-    constexpr int WD = (NS <= 2) ? 2 : 1;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      if (chunk) __syncthreads();  // every wave has finished reading the previous chunk
-#pragma unroll
-      for (int u = 0; u < NP; ++u) {
-        pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
-        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + chunk * 16);
-      }
-      BPX_LOAD_NORM(chunk);
-      const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
-      u32x4_t wq[WD + 1][NS];
-#pragma unroll
-      for (int d = 0; d < WD; ++d)
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)d * 4 * Cout + ns * 16) * KPL);
-#pragma unroll
-      for (int u = 0; u < NP; ++u) BPX_STAGE_PIECE(u, 0, nchunks);
-      if (chunk == 0) BPX_STAMP();  // 2: chunk 0 transformed + written
-      __syncthreads();
-      if (chunk == 0) BPX_STAMP();  // 3: barrier
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        if (s + WD < STEPS) {
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns)
-            wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + WD) * 4 * Cout + ns * 16) * KPL);
-        }
-        const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s) : s;
-        const int cls = (GPT == 2) ? (s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3) : 0;
-        const int imm = tap_off<HY, HX, VB>(tapA);
-        u32x4_t af[MS];
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[ms][ns]);
-        }
-      }
-      BPX_STAMP();  // step loop of the chunk done
-    }
-    __syncthreads();
-  } else {
+  {
   // ---- prologue: chunk 0 -> LDS buffer 0, chunk 1 -> registers ------------------------------------------------
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
@@ -484,19 +434,10 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.stamps = g_stamps;  // profiling ablations: 1 no MFMA, 2 no transform, 4 no re-loads, 8 no stores
   dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
-  // lean (high-residency) kernel where there are enough tiles for >= 4 rounds per CU; the double-buffered one below that
-  const bool lean = (sizeof(T) == 2) && (g_use_ws == 3 || (g_use_ws == 0 && (int64_t)p.D * p.H * p.W >= 262144));
 #define L(TZ, TY, TX, NS)                                                        \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
-    if constexpr (sizeof(T) == 2) {                                              \
-      if (lean) {                                                                \
-        if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, true><<<grid, 256, 0, s>>>(p);  \
-        else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0, true><<<grid, 256, 0, s>>>(p);      \
-        return 0;                                                                \
-      }                                                                          \
-    }                                                                            \
-    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, false><<<grid, 256, 0, s>>>(p);     \
-    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0, false><<<grid, 256, 0, s>>>(p);         \
+    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1><<<grid, 256, 0, s>>>(p);    \
+    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0><<<grid, 256, 0, s>>>(p);        \
     return 0;                                                                    \
   }
   if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only
@@ -509,14 +450,25 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 
 }  // namespace
 
-// bf16 kernel selection: 0 = automatic (this file: lean kernel for >= 64^3 volumes, double-buffered kernel below),
+// bf16 kernel selection: 0 = automatic (lean persistent kernel of conv3d_lean.hip for >= 64^3 volumes, the double-buffered
+// kernel of this file below that),
 // 1 = wave-specialised persistent (conv3d_ws.hip), 2 = persistent 4-wave with a cross-tile stage pipeline
-// (conv3d_persist.hip), 3 = always lean, 4 = always double-buffered.  A/B of 4 | 1 | 2 on the cfg-2 layers, B=4 (us):
+// (conv3d_persist.hip), 4 = always double-buffered, 5 = always lean persistent.  A/B of 4 | 1 | 2 on the cfg-2 layers, B=4 (us):
 //   fwd 48->16@128^3: 781 | 868 | 1006     fwd 16->16+img@128^3: 463 | 481 | 484     dgrad 16->48@128^3: 1077 | 2373 | 1205
 // Both lose to the double-buffered kernel: they hold a second stage in registers and either spill or drop to fewer
 // co-resident workgroups.  The lean kernel goes the other way (3-4 workgroups per CU, nothing pipelined inside a
 // workgroup) and wins wherever a CU gets >= 4 rounds of tiles: 725 / 342 / 944 us on the same three layers.
 extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
+
+// Lean persistent kernel (conv3d_lean.hip) where a CU gets >= 4 rounds of tiles; it uses 32-bit element offsets and
+// 16-byte vector loads of the per-channel parameter arrays.
+static bool use_lean(int dtype, const Conv3Params& p) {
+  if (dtype != BPX_BF16 || !(g_use_ws == 5 || (g_use_ws == 0 && (int64_t)p.D * p.H * p.W >= 262144))) return false;
+  const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
+  const int64_t ldmax = std::max<int64_t>(std::max(p.x_ld, p.y_ld), std::max(p.sc ? p.sc_ld : 0, p.t ? p.t_ld : 0));
+  auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  return p.W > 8 && vox * ldmax < (1ll << 31) && vox < (1ll << 30) && al(p.bias) && al(p.bias_sc) && al(p.wsc) && al(p.in_norm) && al(p.t_norm);
+}
 
 extern "C" int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout) {
   TileCfg c = pick_cfg(dtype, D, H, W, Cout);
@@ -555,7 +507,8 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
   p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
-  int rc = (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_FWD, p, c, (hipStream_t)stream)
+  int rc = use_lean(dtype, p) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
+           : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_FWD, p, c, (hipStream_t)stream)
                                   : g_use_ws == 1 ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
                                : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
@@ -581,7 +534,8 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.y = g.ptr; p.y_ld = g.ld; p.Cout = g.C; p.part = t_norm_d ? red_part_d : nullptr;
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
-  int rc = (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_DGRAD, p, c, (hipStream_t)stream)
+  int rc = use_lean(dtype, p) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
+           : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_DGRAD, p, c, (hipStream_t)stream)
                                   : g_use_ws == 1 ? launch_conv3_ws(EPI_DGRAD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream))
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);

@@ -1,0 +1,393 @@
+// Conv3d 3x3x3 implicit GEMM, bf16 storage: the "lean persistent" schedule used for the large layers (>= 64^3).
+//
+// Same GEMM mapping, LDS halo layout, packed-weight order and epilogue semantics as conv3_kernel (conv3d_igemm.hip - read
+// its header first).  What differs is the schedule, chosen from measurements:
+//   * residency instead of an intra-workgroup pipeline: ONE halo buffer, weights fetched per step through a small
+//     register ring, nothing of the next chunk held in registers -> <= 168 (big tile) / 128 VGPRs and <= 35 KB LDS, so 3-4
+//     workgroups (12-16 waves) share a CU and cover each other's global-load, LDS and barrier latency;
+//   * persistent workgroups: the grid is (CUs x residency) workgroups that walk the tile list, so the per-workgroup costs
+//     (launch, kernel-argument loads, the div/mod decomposition of the halo pieces, LDS base addresses) are paid once per
+//     workgroup instead of once per tile, and what remains per tile is strength-reduced (piece offset = tile base +
+//     per-lane constant; border handling only in tiles that touch the volume border);
+//   * XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x walks the contiguous tile range
+//     [x*T/8, (x+1)*T/8) with its workgroups on neighbouring tiles, so halo re-reads hit that XCD's L2;
+//   * the 16-lane statistics reductions use DPP row operations instead of ds_bpermute.
+#include "conv3d_shared.h"
+
+using namespace bpxconv;
+
+namespace {
+
+// workgroups per CU the register budget is set for; every configuration must compile WITHOUT scratch (a spilling kernel
+// runs up to 2x slower inside the network than alone: measured)
+constexpr int lp_occ(int vox, int ns, int epi, int actk) {
+  return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && actk == 0)) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (= the 16 voxels of an MFMA column group); every lane receives the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
+// normalised pair -> activated pair.  ELU(u) = med3(u, exp(u) - 1, 0): exp(u) - 1 >= u everywhere, so the median picks u
+// for u > 0 and exp(u) - 1 for u <= 0 - one VALU op instead of compare + select; the multiplies/adds pack (v_pk_*_f32).
+template <int ACTK> __device__ __forceinline__ void act_pair(float& a, float& b, int act) {
+  if (ACTK == 1) {
+    f32x2_t u{a, b};
+    f32x2_t w = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
+    f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + f32x2_t{-1.f, -1.f};
+    a = __builtin_amdgcn_fmed3f(u[0], e[0], 0.f);
+    b = __builtin_amdgcn_fmed3f(u[1], e[1], 0.f);
+  } else {
+    a = apply_act_rt<uint16_t, 0>(a, act);
+    b = apply_act_rt<uint16_t, 0>(b, act);
+  }
+}
+
+template <int TZ, int TY, int TX, int NS, int EPI, int ACTK>
+__global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv3_lp_kernel(const Conv3Params p) {
+  using T = uint16_t;
+  constexpr int KPL = 8, VB = 32;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int STEPS = 14, QPAD = 56;
+  constexpr int MT = TZ * TY * TX / 16, MS = MT / 4;
+  static_assert(TZ == 4 && MS * 16 == TY * TX && (TX == 16 || TX == 8), "wave = z-slice mapping");
+  static_assert(HZ < 256 && HY < 256 && HX < 256, "packed halo coordinates");
+  constexpr int NPIECE = HV * 2, NP = (NPIECE + 255) / 256;      // 16-byte pieces of the halo; piece idx lives at LDS byte idx*16
+  constexpr int NP2 = TZ * TY * TX * 2 / 256;                     // pieces of the un-haloed block (fused 1x1x1 shortcut)
+  constexpr int BUFB = HV * VB;
+  constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
+  constexpr int RS = (TX == 16) ? 1 : 2;                          // tile rows covered by one 16-voxel m-subtile
+  constexpr int HSTR = RS * HX * VB, TSTR = 16 * VB;              // LDS strides between m-subtiles (halo / plain block)
+  constexpr int WD = (NS == 1 || (NS == 2 && EPI == EPI_FWD)) ? 2 : 1;                           // weight prefetch distance (steps)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BUFB + RED_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int co_base = blockIdx.y * 16 * NS;
+  const int Cout = p.Cout, D = p.D, H = p.H, W = p.W;
+
+  // profiling: cycle stamps of this workgroup's 5th tile (steady state), scripts/conv_stamps.py
+  long long* stamps = (p.stamps && tid == 0 && blockIdx.y == 0) ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  int stamp_i = 0, it = 0;
+#define BPX_STAMP() do { if (stamps && it == 4 && stamp_i < 15) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+  if (stamps)
+    stamps[15] = (long long)(((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+
+  // ---- per-workgroup constants ------------------------------------------------------------------------------------
+  // this lane's output voxel inside the tile for m-subtile 0: (tz, ty, tx) = (wave, ey, ex); m-subtile ms adds RS*ms rows
+  const int ey = (TX == 16) ? 0 : (j >> 3), ex = j & (TX - 1);
+  const int cg_off = (g & 1) * 16;
+  const bool hi_tap = (g >> 1) != 0;
+  const int hb0 = ((wave * HY + ey) * HX + ex) * VB + cg_off;
+  // ds_read bases of the four tap-pair classes (bpx_tap_order_bf16): partner tap is +1 voxel / +1 row / +1 plane / absent
+  const int lbase[4] = {hb0 + (hi_tap ? VB : 0), hb0 + (hi_tap ? HX * VB : 0), hb0 + (hi_tap ? HY * HX * VB : 0), hb0};
+  const int tb0 = (wave * TY * TX + j) * VB + cg_off;
+  const int evox_rel = (wave * H + ey) * W + ex;
+
+  const int sub = tid & 1;
+  const bool last_ok = (NP - 1) * 256 + tid < NPIECE;
+  // All global accesses below are (uniform base pointer) + (32-bit per-lane BYTE offset): one VGPR per address and no
+  // 64-bit VALU address arithmetic (the launcher checks that every tensor is < 4 GB).
+  uint32_t rel[NP];  // byte offset of this thread's piece u relative to the halo origin of a tile
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int hv = (u * 256 + tid) >> 1;
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    rel[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.x_ld + sub * KPL) * 2u;
+    asm volatile("" : "+v"(rel[u]));  // keep it one 32-bit VGPR (not a hoisted, zero-extended 64-bit address)
+  }
+  const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ wp = reinterpret_cast<const char*>(p.wp);
+  const uint32_t wlane = (uint32_t)((g * Cout + co_base + j) * KPL) * 2u;  // this lane's 16-byte operand inside a [4][Cout][8] k-group block
+  const int nchunks = p.Cin / 16;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
+
+  for (int local = slot; local < p.tilesPerXcd; local += spx, ++it) {
+    const int tileId = xcd * p.tilesPerXcd + local;
+    if (tileId >= p.totalTiles) break;
+    BPX_STAMP();  // 0: tile start
+    const int n = tileId / p.tilesPerSample, tile = tileId - n * p.tilesPerSample;
+    const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+
+    // ---- global offsets (elements) of this thread's halo pieces: tile base + per-lane constant --------------------
+    const uint32_t base_b = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.x_ld * 2u;
+    const bool interior = z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+    uint32_t goff[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      bool ok = (u < NP - 1) || last_ok;
+      if (!interior) {  // border tiles only: re-derive the piece's halo coordinates (kept out of registers on purpose)
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int hv = (u * 256 + tid_o) >> 1;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+      }
+      goff[u] = ok ? base_b + rel[u] : 0xFFFFFFFFu;
+    }
+    // dgrad never normalises its input (dy): the prologue code is compiled out of those kernels
+    const bpx_norm_rec* __restrict__ nrec = (EPI == EPI_FWD && p.in_norm) ? p.in_norm + (size_t)n * p.Cin + sub * KPL : nullptr;
+
+    f32x4_t acc[MS][NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- K loop over 16-channel chunks: stage -> barrier -> 14 MFMA steps ------------------------------------------
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      __syncthreads();  // every wave is done reading the halo buffer (previous chunk / previous tile)
+      u32x4_t pbuf[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
+        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + (goff[u] + (uint32_t)chunk * 32u));
+      }
+      float psc[KPL], psh[KPL];
+      if (nrec) {
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) {
+          const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(&nrec[chunk * 16 + e].scale);
+          psc[e] = ss[0]; psh[e] = ss[1];
+        }
+      }
+      const char* wl = wp + (size_t)chunk * QPAD * Cout * 16;  // uniform; k-group block s is 4*Cout*16 bytes further
+      u32x4_t wq[WD + 1][NS];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)d * 4 * Cout * 16 + (wlane + ns * 256u));
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        if (u < NP - 1 || last_ok) {
+          u32x4_t v = pbuf[u];
+          if (nrec && goff[u] != 0xFFFFFFFFu) {  // zero padding applies to the ACTIVATED tensor: out-of-volume stays 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float a = fmaf(psc[2 * i], bf16lo(v[i]), psh[2 * i]), b = fmaf(psc[2 * i + 1], bf16hi(v[i]), psh[2 * i + 1]);
+              act_pair<ACTK>(a, b, p.act);
+              v[i] = cvt_pk_bf16(a, b);
+            }
+          }
+          *reinterpret_cast<u32x4_t*>(smem + (size_t)(u * 256 + tid) * 16) = v;
+        }
+      }
+      if (chunk == 0) BPX_STAMP();  // 1: first chunk staged
+      __syncthreads();
+      if (chunk == 0) BPX_STAMP();  // 2: barrier
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        if (s + WD < STEPS) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)(s + WD) * 4 * Cout * 16 + (wlane + ns * 256u));
+        }
+        const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
+        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
+        u32x4_t af[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[ms][ns]);
+      }
+      if (chunk == 0) BPX_STAMP();  // 3: first step loop
+    }
+
+    BPX_STAMP();  // 4: all chunks done
+    __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's operand loads out of the MFMA loop's register budget
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only): extra K steps over the un-haloed block -----------
+    if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16) {
+      const char* __restrict__ scin = reinterpret_cast<const char*>(p.sc);
+      const char* __restrict__ wsc = reinterpret_cast<const char*>(p.wsc);
+      const uint32_t base2 = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.sc_ld * 2u;
+      const int nch = p.sc_C / 16;
+      for (int chunk = 0; chunk < nch; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NP2; ++u) {
+          const int t = (u * 256 + tid) >> 1;
+          const int tz = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
+          const bool ok = full || (z0 + tz < D && y0 + ty < H && x0 + tx < W);
+          u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+          if (ok) v = *reinterpret_cast<const u32x4_t*>(scin + (base2 + (uint32_t)(((tz * H + ty) * W + tx) * p.sc_ld + sub * KPL + chunk * 16) * 2u));
+          *reinterpret_cast<u32x4_t*>(smem + (size_t)(u * 256 + tid) * 16) = v;
+        }
+        __syncthreads();
+        u32x4_t wf[NS];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wsc + (size_t)chunk * 4 * Cout * 16 + (wlane + ns * 256u));
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + tb0 + ms * TSTR);
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
+        }
+      }
+    }
+
+    // ---- epilogue: all loads first, then math + one 8-byte store per (m-subtile, 16-channel group) ------------------
+    const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;  // this lane's voxel for m-subtile 0
+    const bool okzx = full || (z0 + wave < D && x0 + ex < W);
+    const int yrem = full ? (1 << 20) : H - (y0 + ey);              // m-subtile ms is inside the volume iff RS*ms < yrem
+    char* __restrict__ yout = reinterpret_cast<char*>(p.y);
+    const uint32_t yrow = (uint32_t)(RS * W * p.y_ld) * 2u;                                  // bytes between m-subtiles
+    const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + co_base + g * 4) * 2u;
+    // statistics partials of one 16-channel group: 16 lanes (DPP) -> this wave's slot of the LDS scratch [wave][NS*16][2]
+    float* red = reinterpret_cast<float*>(smem + BUFB);
+    auto flush_stats = [&](int ns, const float* s1, const float* s2) {
+      if (p.part == nullptr) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
+        if (j == 0) *reinterpret_cast<f32x2_t*>(&red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+      }
+    };
+
+    if (EPI == EPI_FWD) {
+      const bool rank1 = p.sc != nullptr && p.sc_C == 1;
+      float img[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+        img[ms] = (rank1 && okzx && RS * ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * RS * W) * 4u) : 0.f;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int co = co_base + ns * 16 + g * 4;
+        f32x4_t add = f32x4_t{0.f, 0.f, 0.f, 0.f}, w1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) add += *reinterpret_cast<const f32x4_t*>(p.bias + co);
+        if (p.sc && p.bias_sc) add += *reinterpret_cast<const f32x4_t*>(p.bias_sc + co);
+        if (rank1) w1 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.wsc) + co);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          if (okzx && RS * ms < yrem) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[ms][ns][r] + add[r] + img[ms] * w1[r];
+              s1[r] += v[r];
+              s2[r] += v[r] * v[r];
+            }
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+          }
+        }
+        flush_stats(ns, s1, s2);
+      }
+    } else {
+      const bool has_t = p.t_norm != nullptr;
+      const char* __restrict__ tin = reinterpret_cast<const char*>(p.t);
+      const uint32_t trow = (uint32_t)(RS * W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + co_base + g * 4) * 2u;
+      // operands of channel group ns+1 are requested before group ns is computed (register double buffer over ns)
+      u32x2_t tv[NS > 1 ? 2 : 1][MS];
+      auto fetch = [&](int ns, int b) {
+        if (!has_t) return;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          tv[b][ms] = u32x2_t{0u, 0u};
+          if (okzx && RS * ms < yrem) tv[b][ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * 32u));
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int b = (NS > 1) ? (ns & 1) : 0;
+        if (ns + 1 < NS) fetch(ns + 1, (b ^ 1) & (NS > 1 ? 1 : 0));
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_t) {
+          // channel by channel (one {mean, rstd, scale, shift} record live at a time), gradients replace acc in place
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4_t rec = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + r]);
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+              const uint32_t w = tv[b][ms][r >> 1];
+              const float tf = (r & 1) ? bf16hi(w) : bf16lo(w);
+              const float u = fmaf(rec[2], tf, rec[3]);
+              const float gv = (okzx && RS * ms < yrem) ? acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act) : 0.f;
+              acc[ms][ns][r] = gv;
+              s1[r] += gv;
+              s2[r] += gv * ((tf - rec[0]) * rec[1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          if (okzx && RS * ms < yrem)
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) =
+                u32x2_t{cvt_pk_bf16(acc[ms][ns][0], acc[ms][ns][1]), cvt_pk_bf16(acc[ms][ns][2], acc[ms][ns][3])};
+        flush_stats(ns, s1, s2);
+      }
+    }
+    BPX_STAMP();  // 5: epilogue stores issued
+
+    // ---- statistics partials: 4 waves (LDS) -> global [n][tile][2][Cout] ------------------------------------------------
+    if (p.part != nullptr) {
+      __syncthreads();
+      if (tid < NS * 16 * 2) {
+        const int c = tid >> 1, k = tid & 1;
+        const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
+                        red[(3 * NS * 16 + c) * 2 + k];
+        p.part[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Cout + co_base + c] = a;
+      }
+    }
+    BPX_STAMP();  // 6: tile done
+  }
+#undef BPX_STAMP
+}
+
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+template <int EPI>
+int launch_lp(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
+  Conv3Params p = p0;
+  const int tilesZ = cdiv(p.D, c.tz);
+  p.tilesY = cdiv(p.H, c.ty);
+  p.tilesX = cdiv(p.W, c.tx);
+  p.tilesPerSample = tilesZ * p.tilesY * p.tilesX;
+  p.totalTiles = p.N * p.tilesPerSample;
+  p.tilesPerXcd = cdiv(p.totalTiles, 8);
+  p.stamps = g_conv_stamps;
+  const int gy = p.Cout / (16 * c.ns);
+  const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
+  const int occ = lp_occ(c.tz * c.ty * c.tx, c.ns, EPI, elu ? 1 : 0);
+  int gx = std::max(8, (cu_count() * occ / gy) & ~7);
+  gx = std::min(gx, 8 * p.tilesPerXcd);
+  dim3 grid((unsigned)gx, (unsigned)gy);
+#define L(TZ, TY, TX, NS)                                                          \
+  if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                      \
+    if (elu) conv3_lp_kernel<TZ, TY, TX, NS, EPI, 1><<<grid, 256, 0, s>>>(p);      \
+    else conv3_lp_kernel<TZ, TY, TX, NS, EPI, 0><<<grid, 256, 0, s>>>(p);          \
+    return 0;                                                                      \
+  }
+  L(4, 8, 16, 1) L(4, 4, 16, 1) L(4, 4, 16, 2) L(4, 4, 16, 3) L(4, 4, 16, 4)
+#undef L
+  return 1;  // W <= 8 tiles are never large enough for this kernel
+}
+
+}  // namespace
+
+namespace bpxconv {
+int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s) {
+  return epi == EPI_FWD ? launch_lp<EPI_FWD>(p, c, s) : launch_lp<EPI_DGRAD>(p, c, s);
+}
+}  // namespace bpxconv

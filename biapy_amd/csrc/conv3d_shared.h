@@ -1,5 +1,6 @@
-// Declarations shared by the implicit-GEMM conv kernels (conv3d_igemm.hip: plain 4-wave kernel, used for the exact-fp32
-// mode; conv3d_ws.hip: the wave-specialised persistent kernel used for bf16).
+// Declarations shared by the implicit-GEMM conv kernels (conv3d_igemm.hip: double-buffered 4-wave kernel, fp32 exact mode
+// and small bf16 layers; conv3d_lean.hip: lean persistent bf16 kernel for the large layers; conv3d_ws.hip /
+// conv3d_persist.hip: measured alternatives, off by default).
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -20,7 +21,7 @@ struct Conv3Params {
   void* y; int y_ld; int Cout;
   float* part;  // [N][tiles][2][Cout]
   const void* t; int t_ld; const bpx_norm_rec* t_norm; int t_act;
-  int tilesY, tilesX, tilesPerSample, totalTiles;
+  int tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd;
   long long* stamps;  // profiling: per-workgroup s_memtime stamps [block][16] (BPX_CONV_STAMPS), else null
   int dbg;  // ablation switches for profiling (BPX_CONV_DBG): 1 = skip MFMA steps, 2 = skip staging transform+loads
 };
@@ -76,6 +77,8 @@ inline int conv3_persist_groups(int totalTiles, int gy) { return std::max(1, std
 
 // persistent 4-wave bf16 kernel (conv3d_persist.hip)
 int launch_conv3_persist(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
+// lean persistent bf16 kernel (conv3d_lean.hip) - the production kernel of the >= 64^3 layers
+int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 // wave-specialised bf16 kernel (conv3d_ws.hip)
 int launch_conv3_ws(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 

@@ -32,7 +32,7 @@ part = torch.empty(B, tiles, 2, cout, device="cuda")
 nblk = B * tiles
 if os.environ.get('BPX_STAMP_NAMES') == 'persist':
     nblk = 512
-stamps = torch.zeros(nblk, 16, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(max(nblk, 4096), 16, dtype=torch.int64, device="cuda")
 
 
 def run():
@@ -47,6 +47,8 @@ lib.bpx_debug_set_conv_stamps(stamps.data_ptr())
 run(); torch.cuda.synchronize()
 lib.bpx_debug_set_conv_stamps(None)
 s = stamps.cpu().numpy()
+s = s[s[:, 0] != 0]
+nblk = len(s)
 hw = s[:, 15].copy()
 s = s[:, :15]
 nz = (s != 0).sum(1).max()
@@ -57,6 +59,12 @@ if os.environ.get("BPX_STAMP_NAMES") == "persist":
     while len(names) < nz:
         names += [f"stage{k} bookkeeping+index math", f"stage{k} step loop", f"stage{k} epilogue", f"stage{k} barrier"]
         k += 1
+elif os.environ.get("BPX_WS", "0") in ("0", "5") and S >= 64:
+    names = ["tile decode + chunk0 load+transform+write", "barrier", "chunk0 step loop", "chunks 1..", "shortcut + epilogue", "stats reduction + store"]
+    nblk = None
+elif os.environ.get("BPX_WS", "0") == "3" and S >= 64:
+    names = ["index math", "chunk0 load+transform+write", "barrier0", "chunk0 step loop"]
+    names += [f"chunk{k} barrier+stage+barrier+step loop" for k in range(1, nz - 5)] + ["final barrier + shortcut + epilogue"]
 else:
     names = ["index math", "chunk0 load+transform+write", "barrier0"]
     k = 0
@@ -66,7 +74,7 @@ else:
     names = names[: nz - 2] + ["epilogue"]
 print(f"layer {S}^3 {cin}->{cout}: {nblk} workgroups, {nz} stamps; cycles (median / mean / p90) per phase, wave 0 of each workgroup")
 for i in range(d.shape[1]):
-    print(f"  {names[i] if i < len(names) else i:32s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 90):9.0f}")
+    print(f"  {names[i] if i < len(names) else str(i):32s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 90):9.0f}")
 tot = (s[:, nz - 1] - s[:, 0]).astype(np.float64)
 print(f"  {'workgroup total':32s} {np.median(tot):9.0f} {tot.mean():9.0f} {np.percentile(tot, 90):9.0f}")
 # residency: workgroups of one CU (XCC, SE, SH, CU ids) share a clock, so their [start, end] intervals can be overlapped

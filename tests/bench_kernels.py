@@ -73,7 +73,8 @@ def main():
                 sc = torch.randn(B, S, S, S, csc, device=DEV).to(T)
                 wk = pack(torch.randn(cout, csc, 1, 1, 1, device=DEV), L.PK_K1, csc, cout)
                 sct, wscp, keep = L.tview(sc), wk.data_ptr(), [sc, wk]
-            f = lambda: L.check(lib.bpx_conv3d_fwd(dt, B, S, S, S, L.tview(x), rec.data_ptr(), 1, wp.data_ptr(), bias.data_ptr(), sct, wscp,
+            recp = None if os.environ.get('BPX_NO_NORM') else rec.data_ptr()   # ablation: skip the fused normalise+ELU prologue
+            f = lambda: L.check(lib.bpx_conv3d_fwd(dt, B, S, S, S, L.tview(x), recp, 1, wp.data_ptr(), bias.data_ptr(), sct, wscp,
                                                    bias.data_ptr() if csc else None, L.tview(y), part.data_ptr(), st))
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * (27 * cin + csc) * cout

@@ -40,7 +40,7 @@ def test_conv3d_fwd(K, dt):
     _assert_all(rows)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4], ids=["wave-specialised", "persistent", "lean", "double-buffered"])
+@pytest.mark.parametrize("variant", [1, 2, 4, 5], ids=["wave-specialised", "persistent", "double-buffered", "lean-persistent"])
 def test_conv3d_bf16_kernel_variants(K, variant):
     """Every schedule of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) computes the same convolution."""
     from biapy_amd import _lib as L
@@ -56,6 +56,8 @@ def test_conv3d_bf16_kernel_variants(K, variant):
         rows += K.check_conv3d_dgrad(1, 2, (8, 8, 16), 48, 16)
         rows += K.check_conv3d_dgrad(1, 1, (32, 32, 32), 16, 48)
         rows += K.check_conv3d_dgrad(1, 1, (32, 32, 32), 32, 16)
+        rows += K.check_conv3d_fwd(1, 2, (12, 20, 24), 32, 32, norm=True, sc_C=32)     # ragged: partial tiles on every axis
+        rows += K.check_conv3d_dgrad(1, 2, (12, 20, 24), 32, 32)
     finally:
         L.lib.bpx_debug_set_conv_ws(0)
     _assert_all(rows)
