@@ -110,6 +110,34 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float u) {
   return 1.f;
 }
 
+// ---- helpers shared by the bf16 "lean" kernels (conv3d_lean.hip, wgrad.hip) -------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (= the 16 voxels of an MFMA column group); every lane receives the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
+// normalised pair -> activated pair.  ELU(u) = med3(u, exp(u) - 1, 0): exp(u) - 1 >= u everywhere, so the median picks u
+// for u > 0 and exp(u) - 1 for u <= 0 - one VALU op instead of compare + select; the multiplies/adds pack (v_pk_*_f32).
+template <int ACTK> __device__ __forceinline__ void act_pair(float& a, float& b, int act) {
+  if (ACTK == 1) {
+    f32x2_t u{a, b};
+    f32x2_t w = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
+    f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + f32x2_t{-1.f, -1.f};
+    a = __builtin_amdgcn_fmed3f(u[0], e[0], 0.f);
+    b = __builtin_amdgcn_fmed3f(u[1], e[1], 0.f);
+  } else {
+    a = act == BPX_ACT_ELU ? (a > 0.f ? a : __expf(a) - 1.f) : act == BPX_ACT_RELU ? fmaxf(a, 0.f) : act == BPX_ACT_SILU ? a / (1.f + __expf(-a)) : a;
+    b = act == BPX_ACT_ELU ? (b > 0.f ? b : __expf(b) - 1.f) : act == BPX_ACT_RELU ? fmaxf(b, 0.f) : act == BPX_ACT_SILU ? b / (1.f + __expf(-b)) : b;
+  }
+}
+
 // ---- MFMA step: 16 bytes of A and B per lane -> one (bf16) or four (f32) MFMAs ----------------
 // D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[i=l&15][kgroup l>>4], B[kgroup l>>4][j=l&15];
 // result lane l holds D[i=(l>>4)*4+r][j=l&15], r=0..3 (cdna_hip_programming.md section 3).

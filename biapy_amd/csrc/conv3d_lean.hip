@@ -24,33 +24,6 @@ constexpr int lp_occ(int vox, int ns, int epi, int actk) {
   return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && actk == 0)) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
 }
 
-template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-// sum over the 16 lanes of a DPP row (= the 16 voxels of an MFMA column group); every lane receives the total
-__device__ __forceinline__ float row16_sum(float v) {
-  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);  // row_half_mirror
-  v = dpp_add<0x140>(v);  // row_mirror
-  return v;
-}
-
-// normalised pair -> activated pair.  ELU(u) = med3(u, exp(u) - 1, 0): exp(u) - 1 >= u everywhere, so the median picks u
-// for u > 0 and exp(u) - 1 for u <= 0 - one VALU op instead of compare + select; the multiplies/adds pack (v_pk_*_f32).
-template <int ACTK> __device__ __forceinline__ void act_pair(float& a, float& b, int act) {
-  if (ACTK == 1) {
-    f32x2_t u{a, b};
-    f32x2_t w = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
-    f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])} + f32x2_t{-1.f, -1.f};
-    a = __builtin_amdgcn_fmed3f(u[0], e[0], 0.f);
-    b = __builtin_amdgcn_fmed3f(u[1], e[1], 0.f);
-  } else {
-    a = apply_act_rt<uint16_t, 0>(a, act);
-    b = apply_act_rt<uint16_t, 0>(b, act);
-  }
-}
-
 template <int TZ, int TY, int TX, int NS, int EPI, int ACTK>
 __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv3_lp_kernel(const Conv3Params p) {
   using T = uint16_t;

@@ -343,6 +343,203 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   (void)sB;
 }
 
+
+// ---- 3x3x3 wgrad, bf16, large volumes: "shift dy" orientation ----------------------------------------------------------
+// dW[tap][ci][co] = sum_v A[v + tap - 1][ci] * G[v][co] = sum_u A[u][ci] * G[u - (tap - 1)][co]:
+// the tile of ACTIVATIONS is staged un-haloed (each voxel is normalised + activated exactly once - the prologue is the
+// VALU bottleneck of this kernel, and a haloed activation tile repeats it 2.5x), and the halo goes to dy, which is a raw
+// copy.  The activation fragment of a K-chunk is then shared by all taps; each tap reads its own shifted dy fragment.
+// Lean schedule as in conv3d_lean.hip: no register prefetch across the MFMA phase, <= 128 (NS=1) / 168 VGPRs, 29 / 50 KB
+// LDS -> 4 / 3 workgroups per CU; 32-bit byte offsets; per-tile index math reduced to base + per-lane constants.
+template <int NS, int ACTK>
+__global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const WgradParams p) {
+  using T = uint16_t;
+  constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int KPL = 8, VBA = 32, CB = 16 * NS, VBG = CB * 2, PPVG = 2 * NS;
+  constexpr int NKC = TV / 32, NT = 7;
+  constexpr int NPA = TV * 2 / 256, NPGT = HV * PPVG, NPG = (NPGT + 255) / 256;
+  static_assert(256 % PPVG == 0, "piece sub-index must be thread-invariant");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TV * VBA + HV * VBG];
+  unsigned char* sA = smem;
+  unsigned char* sG = smem + TV * VBA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W;
+  // workgroup -> (tile group, ci chunk, co block): same XCD-aware order as wgrad_kernel above
+  const int nchunks_ = p.Cin / 16, groups8 = (p.groups + 7) & ~7;
+  const int per_cb = groups8 * nchunks_;
+  const int cbi = (int)blockIdx.x / per_cb, rem = (int)blockIdx.x % per_cb;
+  const int chunk = (rem % (8 * nchunks_)) / 8;
+  const int grp = (rem / (8 * nchunks_)) * 8 + rem % 8;
+  const int co_base = cbi * CB;
+  if (grp >= p.groups) return;
+
+  f32x4_t acc[NT][NS];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[a][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ gin = reinterpret_cast<const char*>(p.dy);
+
+  // ---- per-workgroup constants: byte offsets of this thread's pieces relative to the tile / halo origin -----------------
+  uint32_t rel_a[NPA], rel_g[NPG];
+#pragma unroll
+  for (int u = 0; u < NPA; ++u) {
+    const int t = (u * 256 + tid) >> 1;
+    rel_a[u] = (uint32_t)((((t >> 6) * H + ((t >> 4) & 3)) * W + (t & 15)) * p.x_ld + chunk * 16 + (tid & 1) * KPL) * 2u;
+    asm volatile("" : "+v"(rel_a[u]));
+  }
+  const int subG = tid % PPVG;
+#pragma unroll
+  for (int u = 0; u < NPG; ++u) {
+    const int hv = (u * 256 + tid) / PPVG;
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    rel_g[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.dy_ld + co_base + subG * KPL) * 2u;
+    asm volatile("" : "+v"(rel_g[u]));
+  }
+  const bool last_ok = (NPG - 1) * 256 + tid < NPGT;
+  // fragment bases: lane (i, g) reads voxels 8g..8g+7 of a 32-voxel K-chunk (one x run), channel block via the tr-read
+  const int trl = (i >> 2), trc = (i & 3) * 8;
+  const int a_base = g * 8 * VBA + trl * VBA + trc;                                          // + kc*32*VBA
+  const int g_lane = (((g >> 1) * HX + (g & 1) * 8) + trl) * VBG + trc;                      // + kc part + tap shift + ns*32
+  int g_base[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    int tap = wave + 4 * a;
+    if (tap > 26) tap = 26;  // wave 3 has one tap less: its 7th accumulator is computed but never flushed
+    const int dz = tap / 9, dy_ = (tap / 3) % 3, dx = tap % 3;
+    g_base[a] = g_lane + (((2 - dz) * HY + (2 - dy_)) * HX + (2 - dx)) * VBG;
+  }
+  float psc[KPL], psh[KPL];
+  int n_cur = -1;
+
+  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
+    const int n = tt / p.tilesPerSample, tile = tt - n * p.tilesPerSample;
+    const int z0 = (tile / (p.tilesX * p.tilesY)) * TZ, y0 = ((tile / p.tilesX) % p.tilesY) * TY, x0 = (tile % p.tilesX) * TX;
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    const bool interior = full && z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+    const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
+    const uint32_t base_g = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.dy_ld * 2u;
+
+    u32x4_t pa[NPA], pg[NPG];
+    bool oka[NPA];
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int t = (u * 256 + tid) >> 1;
+      oka[u] = full || (z0 + (t >> 6) < D && y0 + ((t >> 4) & 3) < H && x0 + (t & 15) < W);
+      pa[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (oka[u]) pa[u] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a[u]));
+    }
+#pragma unroll
+    for (int u = 0; u < NPG; ++u) {
+      bool ok = (u < NPG - 1) || last_ok;
+      if (!interior) {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int hv = (u * 256 + tid_o) / PPVG;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+      }
+      pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (ok) pg[u] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + rel_g[u]));
+    }
+    if (p.in_norm && n != n_cur) {
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) {
+        const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(&p.in_norm[(size_t)n * p.Cin + chunk * 16 + (tid & 1) * KPL + e].scale);
+        psc[e] = ss[0]; psh[e] = ss[1];
+      }
+      n_cur = n;
+    }
+    __syncthreads();  // the previous tile's MFMA phase has finished reading LDS
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      u32x4_t v = pa[u];
+      if (p.in_norm && oka[u]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = fmaf(psc[2 * q], bf16lo(v[q]), psh[2 * q]), b = fmaf(psc[2 * q + 1], bf16hi(v[q]), psh[2 * q + 1]);
+          act_pair<ACTK>(a, b, p.act);
+          v[q] = cvt_pk_bf16(a, b);
+        }
+      }
+      *reinterpret_cast<u32x4_t*>(sA + (size_t)(u * 256 + tid) * 16) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NPG; ++u)
+      if (u < NPG - 1 || last_ok) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[u];
+    __syncthreads();
+
+    if (p.db != nullptr && chunk == 0) {  // bias gradient: column sums of dy over the tile's own voxels
+      const int c = tid % CB;
+      for (int v = tid / CB; v < TV; v += 256 / CB) {
+        const int hidx = (((v >> 6) + 1) * HY + ((v >> 4) & 3) + 1) * HX + (v & 15) + 1;
+        bsum += bf16_to_f32(*reinterpret_cast<const uint16_t*>(sG + (size_t)hidx * VBG + c * 2));
+      }
+    }
+
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      const int ka = kc * 32 * VBA;
+      const int kg = (((kc >> 1) * HY + (kc & 1) * 2) * HX) * VBG;
+      u32x4_t af, gf[NT][NS];
+      {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sA + a_base + ka));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(sA + a_base + ka + 4 * VBA));
+        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        af = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const unsigned char* q = sG + g_base[a] + kg + ns * 32;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
+          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+          gf[a][ns] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[a][ns], 0, 0, 0);
+    }
+  }
+
+  // flush: lane holds D[ci = 4g+r][co = i] of its taps
+  float* pp = p.part + (size_t)grp * 27 * p.Cin * p.Cout;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int tap = wave + 4 * a;
+    if (tap >= 27) continue;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = chunk * 16 + 4 * g + r, co = co_base + ns * 16 + i;
+        pp[((size_t)tap * p.Cin + ci) * p.Cout + co] = acc[a][ns][r];
+      }
+  }
+  if (p.db != nullptr && chunk == 0) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < CB) {
+      float s = 0.f;
+      for (int k = tid; k < 256; k += CB) s += red[k];
+      atomicAdd(p.db + co_base + tid, s);
+    }
+  }
+}
+
 // sums the per-group partials in a fixed order and writes dW in its final layout.
 // 256 threads = 32 consecutive elements x 8 group lanes (the smallest dW has only 6912 elements; one thread per
 // element would leave the chip idle while it streams ~25 MB of partials).
@@ -422,6 +619,24 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
 }
 
 int g_use_tr = 1;
+int g_wgrad_sd = -1;  // -1 automatic (wherever it applies), 0 never, 1 always (bpx_debug_set_wgrad_tr bits 1/2)
+
+// shift-dy kernel: bf16, 3x3x3, W > 8; 32-bit byte offsets -> every tensor < 4 GB
+int launch_wgrad_sd(const WgradParams& p0, const WCfg& c, hipStream_t s) {
+  WgradParams p = p0;
+  p.tilesY = cdiv(p.H, 4);
+  p.tilesX = cdiv(p.W, 16);
+  p.tilesPerSample = cdiv(p.D, 4) * p.tilesY * p.tilesX;
+  p.totalTiles = p.N * p.tilesPerSample;
+  p.groups = c.groups;
+  const int ns = std::min(c.ns, 2);
+  const int nchunks = p.Cin / 16, nb = p.Cout / (16 * ns);
+  const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
+  dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
+  if (ns == 1) { if (elu) wgrad_sd_kernel<1, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<1, 0><<<grid, 256, 0, s>>>(p); }
+  else { if (elu) wgrad_sd_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<2, 0><<<grid, 256, 0, s>>>(p); }
+  return 0;
+}
 
 int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int64_t ws_bytes, hipStream_t s) {
   WCfg c = pick_wcfg(p.N, p.D, p.H, p.W, p.Cin, p.Cout, taps, false);  // 8x8x16 tiles for k=1 measured slower (convT wgrad 0.76 -> 1.02 ms): off
@@ -429,7 +644,11 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   BPX_CHECK(ws != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   p.part = reinterpret_cast<float*>(ws);
   int rc;
-  if (dtype == BPX_BF16) rc = (taps == 27) ? launch_wgrad<uint16_t, 27>(p, c, g_use_tr != 0, s) : launch_wgrad<uint16_t, 1>(p, c, g_use_tr != 0, s);
+  const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
+  const bool sd_ok = dtype == BPX_BF16 && taps == 27 && p.dy_vs == 1 && c.tx == 16 && c.tz == 4 && g_use_tr != 0 &&
+                     vox * std::max(p.x_ld, p.dy_ld) < (1ll << 31) && (((uintptr_t)p.in_norm) & 7) == 0;
+  if (sd_ok && g_wgrad_sd != 0) rc = launch_wgrad_sd(p, c, s);   // measured faster at every cfg-2 layer with W > 8
+  else if (dtype == BPX_BF16) rc = (taps == 27) ? launch_wgrad<uint16_t, 27>(p, c, g_use_tr != 0, s) : launch_wgrad<uint16_t, 1>(p, c, g_use_tr != 0, s);
   else rc = (taps == 27) ? launch_wgrad<float, 27>(p, c, false, s) : launch_wgrad<float, 1>(p, c, false, s);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
@@ -453,7 +672,12 @@ extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, 
 }
 
 // test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 in the bf16 wgrad
-extern "C" int bpx_debug_set_wgrad_tr(int use_tr) { g_use_tr = use_tr; return 0; }
+// bits 1..2 select the 3x3x3 bf16 schedule: 0 automatic, 2 = never the shift-dy kernel, 4 = always
+extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
+  g_use_tr = use_tr & 1;
+  g_wgrad_sd = (use_tr & 4) ? 1 : (use_tr & 2) ? 0 : -1;
+  return 0;
+}
 
 extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                                 bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {

@@ -94,6 +94,8 @@ def main():
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * 27 * cin * cout
             print(f"conv_dgrad {S:4d}^3 dy{cout:4d}->g{cin:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s")
+    if os.environ.get('BPX_WGRAD') is not None:
+        lib.bpx_debug_set_wgrad_tr(int(os.environ['BPX_WGRAD']))   # 1 auto, 3 never shift-dy, 5 always
     if a.what in ("wgrad", "all"):
         for (S, cin, cout, csc) in layers:
             x = torch.randn(B, S, S, S, cin, device=DEV).to(T)

@@ -72,6 +72,11 @@ def test_conv3d_backward_kernels(K, dt):
     rows += K.check_conv3d_wgrad(dt, 1, (8, 12, 20), 48, 32, k=3, norm=True)
     rows += K.check_conv3d_wgrad(dt, 1, (4, 8, 8), 64, 64, k=3, norm=False)
     rows += K.check_conv3d_wgrad(dt, 2, (8, 8, 16), 48, 16, k=1, norm=False)
+    if dt == 1:  # the shift-dy schedule of the large bf16 layers (use_tr = 5: forced), incl. ragged volumes and bias
+        rows += K.check_conv3d_wgrad(dt, 2, (8, 8, 16), 16, 16, k=3, norm=True, use_tr=5)
+        rows += K.check_conv3d_wgrad(dt, 1, (8, 12, 20), 48, 32, k=3, norm=True, use_tr=5)
+        rows += K.check_conv3d_wgrad(dt, 2, (6, 9, 33), 32, 64, k=3, norm=False, use_tr=5)
+        rows += K.check_conv3d_wgrad(dt, 1, (32, 32, 32), 16, 48, k=3, norm=True, use_tr=5)
     _assert_all(rows)
 
 
