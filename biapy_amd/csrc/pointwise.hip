@@ -26,6 +26,42 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float* 
   f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
 }
 
+// 4*NQ consecutive channels of one voxel: 16-byte accesses for pairs of quads, one 8-byte access for an odd last quad
+// (fp32: one 16-byte access per quad).  The addresses are 8*NQ-byte (bf16) aligned, which global memory accepts.
+template <typename T, int NQ> __device__ __forceinline__ void loadq(const T* p, float (*f)[4]);
+template <typename T, int NQ> __device__ __forceinline__ void storeq(T* p, const float (*f)[4]);
+template <> __device__ __forceinline__ void loadq<float, 1>(const float* p, float (*f)[4]) { load4<float>(p, f[0]); }
+template <> __device__ __forceinline__ void loadq<float, 2>(const float* p, float (*f)[4]) { load4<float>(p, f[0]); load4<float>(p + 4, f[1]); }
+template <> __device__ __forceinline__ void loadq<float, 3>(const float* p, float (*f)[4]) { load4<float>(p, f[0]); load4<float>(p + 4, f[1]); load4<float>(p + 8, f[2]); }
+template <> __device__ __forceinline__ void loadq<float, 4>(const float* p, float (*f)[4]) { load4<float>(p, f[0]); load4<float>(p + 4, f[1]); load4<float>(p + 8, f[2]); load4<float>(p + 12, f[3]); }
+__device__ __forceinline__ void load8_bf16(const uint16_t* p, float* f0, float* f1) {
+  u32x4_t v = *reinterpret_cast<const u32x4_t*>(p);
+  f0[0] = bf16lo(v[0]); f0[1] = bf16hi(v[0]); f0[2] = bf16lo(v[1]); f0[3] = bf16hi(v[1]);
+  f1[0] = bf16lo(v[2]); f1[1] = bf16hi(v[2]); f1[2] = bf16lo(v[3]); f1[3] = bf16hi(v[3]);
+}
+template <> __device__ __forceinline__ void loadq<uint16_t, 1>(const uint16_t* p, float (*f)[4]) { load4<uint16_t>(p, f[0]); }
+template <> __device__ __forceinline__ void loadq<uint16_t, 2>(const uint16_t* p, float (*f)[4]) { load8_bf16(p, f[0], f[1]); }
+template <> __device__ __forceinline__ void loadq<uint16_t, 3>(const uint16_t* p, float (*f)[4]) { load8_bf16(p, f[0], f[1]); load4<uint16_t>(p + 8, f[2]); }
+template <> __device__ __forceinline__ void loadq<uint16_t, 4>(const uint16_t* p, float (*f)[4]) { load8_bf16(p, f[0], f[1]); load8_bf16(p + 8, f[2], f[3]); }
+template <int NQ> __device__ __forceinline__ void storeq_f32(float* p, const float (*f)[4]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4_t*>(p + 4 * q) = f32x4_t{f[q][0], f[q][1], f[q][2], f[q][3]};
+}
+template <> __device__ __forceinline__ void storeq<float, 1>(float* p, const float (*f)[4]) { storeq_f32<1>(p, f); }
+template <> __device__ __forceinline__ void storeq<float, 2>(float* p, const float (*f)[4]) { storeq_f32<2>(p, f); }
+template <> __device__ __forceinline__ void storeq<float, 3>(float* p, const float (*f)[4]) { storeq_f32<3>(p, f); }
+template <> __device__ __forceinline__ void storeq<float, 4>(float* p, const float (*f)[4]) { storeq_f32<4>(p, f); }
+__device__ __forceinline__ void store4_bf16(uint16_t* p, const float* f) {
+  *reinterpret_cast<u32x2_t*>(p) = u32x2_t{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])};
+}
+__device__ __forceinline__ void store8_bf16(uint16_t* p, const float* f0, const float* f1) {
+  *reinterpret_cast<u32x4_t*>(p) = u32x4_t{pack_bf16x2(f0[0], f0[1]), pack_bf16x2(f0[2], f0[3]), pack_bf16x2(f1[0], f1[1]), pack_bf16x2(f1[2], f1[3])};
+}
+template <> __device__ __forceinline__ void storeq<uint16_t, 1>(uint16_t* p, const float (*f)[4]) { store4_bf16(p, f[0]); }
+template <> __device__ __forceinline__ void storeq<uint16_t, 2>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); }
+template <> __device__ __forceinline__ void storeq<uint16_t, 3>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); store4_bf16(p + 8, f[2]); }
+template <> __device__ __forceinline__ void storeq<uint16_t, 4>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); store8_bf16(p + 8, f[2], f[3]); }
+
 struct PwParams {
   int N, D, H, W;        // voxel grid of v (the low-res grid for the transposed conv)
   int64_t vps;           // voxels per sample = D*H*W
@@ -83,7 +119,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     u32x4_t wf[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
-      wf[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)(4 * s + g) * p.Ncols + col_base + ns * 16 + j) * KPL);
+      wf[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)(4 * s + g) * p.Ncols + col_base + (j >> 2) * (4 * NS) + ns * 4 + (j & 3)) * KPL);
     size_t koff;
     if (MODE == PW_CONVTD) {
       int sub = kin ? k / p.Csub : 0, c = kin ? k % p.Csub : 0;
@@ -101,7 +137,11 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     }
   }
 
-  // ---- epilogue: lane holds columns col_base + ns*16 + 4g + r of voxel j ----------------------
+  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  // MFMA row i of column block ns is bound to column col_base + (i/4)*4NS + ns*4 + i%4 (see the weight load above), so
+  // lane (g, j) ends up with the 4*NS CONSECUTIVE columns col_base + g*4NS .. of voxel j: its g / t / addend operands and
+  // its results move as 16-byte (two column quads) + 8-byte accesses, and the 4 lanes of a voxel cover 16*NS contiguous
+  // channels.
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
   float s1[NS][4], s2[NS][4];
 #pragma unroll
@@ -109,58 +149,60 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
 
+  const int col0 = col_base + g * 4 * NS;        // first of this lane's columns
+  int sub = 0, co0 = col0;
+  if (MODE == PW_CONVT) { sub = col0 / p.Csub; co0 = col0 % p.Csub; }
+  float add[NS][4];
+  bpx_nbwd_coef cf[NS][4];
 #pragma unroll
-  for (int ns = 0; ns < NS; ++ns) {
-    const int col = col_base + ns * 16 + g * 4;
-    int sub = 0, co = col;
-    if (MODE == PW_CONVT) { sub = col / p.Csub; co = col % p.Csub; }
-    float add[4] = {0.f, 0.f, 0.f, 0.f};
-    bpx_nbwd_coef cf[4];
+  for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (p.bias) add[r] = p.bias[co + r];
-      if (MODE == PW_CONV1 && p.coef) cf[r] = p.coef[(size_t)n * p.Ncols + co + r];
+      add[ns][r] = p.bias ? p.bias[co0 + ns * 4 + r] : 0.f;
+      if (MODE == PW_CONV1 && p.coef) cf[ns][r] = p.coef[(size_t)n * p.Ncols + co0 + ns * 4 + r];
     }
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-      if (!valid[ms]) continue;
-      size_t ovox;
-      if (MODE == PW_CONVT) {
-        int xw = (int)(v[ms] % p.W), yh = (int)((v[ms] / p.W) % p.H), zd = (int)(v[ms] / ((int64_t)p.W * p.H));
-        int a = (sub >> 2) & 1, b = (sub >> 1) & 1, cc = sub & 1;
-        ovox = (((size_t)n * 2 * p.D + 2 * zd + a) * 2 * p.H + 2 * yh + b) * 2 * p.W + 2 * xw + cc;
-      } else {
-        ovox = (size_t)n * p.vps + v[ms];
-      }
-      float val[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) val[r] = acc[ms][ns][r] + add[r];
-      if (MODE == PW_CONV1) {
-        if (p.coef) {
-          const T* gp = reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co;
-          const T* tp = reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co;
-          float gq[4], tq[4];
-          load4<T>(gp, gq);
-          load4<T>(tp, tq);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) val[r] += cf[r].a * gq[r] + cf[r].b * tq[r] + cf[r].c0;
-        }
-        if (p.addend) {
-          const T* ap = reinterpret_cast<const T*>(p.addend) + ovox * (size_t)p.addend_ld + co;
-          float aq[4];
-          load4<T>(ap, aq);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) val[r] += aq[r];
-        }
-      }
-      if (MODE == PW_CONVT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[ns][r] += val[r]; s2[ns][r] += val[r] * val[r]; }
-      }
-      T* yp = yout + ovox * (size_t)p.y_ld + co;
-      if (std::is_same<T, float>::value) *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{val[0], val[1], val[2], val[3]};
-      else *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};
+  for (int ms = 0; ms < MS; ++ms) {
+    if (!valid[ms]) continue;
+    size_t ovox;
+    if (MODE == PW_CONVT) {
+      int xw = (int)(v[ms] % p.W), yh = (int)((v[ms] / p.W) % p.H), zd = (int)(v[ms] / ((int64_t)p.W * p.H));
+      int a = (sub >> 2) & 1, b = (sub >> 1) & 1, cc = sub & 1;
+      ovox = (((size_t)n * 2 * p.D + 2 * zd + a) * 2 * p.H + 2 * yh + b) * 2 * p.W + 2 * xw + cc;
+    } else {
+      ovox = (size_t)n * p.vps + v[ms];
     }
+    float val[NS][4];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) val[ns][r] = acc[ms][ns][r] + add[ns][r];
+    if (MODE == PW_CONV1) {
+      if (p.coef) {
+        float gq[NS][4], tq[NS][4];
+        loadq<T, NS>(reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co0, gq);
+        loadq<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[ns][r] += cf[ns][r].a * gq[ns][r] + cf[ns][r].b * tq[ns][r] + cf[ns][r].c0;
+      }
+      if (p.addend) {
+        float aq[NS][4];
+        loadq<T, NS>(reinterpret_cast<const T*>(p.addend) + ovox * (size_t)p.addend_ld + co0, aq);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[ns][r] += aq[ns][r];
+      }
+    }
+    if (MODE == PW_CONVT) {
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[ns][r] += val[ns][r]; s2[ns][r] += val[ns][r] * val[ns][r]; }
+    }
+    storeq<T, NS>(yout + ovox * (size_t)p.y_ld + co0, val);
   }
 
   if (MODE == PW_CONVT && p.part != nullptr) {
@@ -173,8 +215,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
         if (j == 0) {
-          red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 0] = a;
-          red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 1] = b;
+          red[((wave * NS * 16) + g * 4 * NS + ns * 4 + r) * 2 + 0] = a;   // slot = column offset inside the block
+          red[((wave * NS * 16) + g * 4 * NS + ns * 4 + r) * 2 + 1] = b;
         }
       }
     __syncthreads();
