@@ -540,6 +540,159 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const Wg
   }
 }
 
+
+// ---- ConvTranspose3d k=2 s=2 wgrad, bf16: all 8 sub-positions in ONE pass over x and dy ---------------------------------
+// dW[ci][co][sub] = sum_v x[v][ci] * dy[2v + sub][co].  The generic kernel above needs one launch per sub-position and
+// re-reads x eight times with a stride-2 gather of dy; here a workgroup stages a 2x4x16 tile of x and the matching
+// CONTIGUOUS 4x8x32 block of dy (de-interleaved into 8 per-sub planes while writing LDS), wave w owns subs 2w and 2w+1,
+// and the x fragment of a K-chunk is shared by all subs.  Partials [group][sub][Cin][Cout] -> wgrad_reduce_kernel.
+template <int NS>
+__global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const WgradParams p) {
+  using T = uint16_t;
+  constexpr int TZ = 2, TY = 4, TX = 16, TV = TZ * TY * TX;       // x tile
+  constexpr int GV = 8 * TV;                                      // dy voxels of the tile
+  constexpr int KPL = 8, VBA = 32, CB = 16 * NS, VBG = CB * 2, PPVG = 2 * NS;
+  constexpr int NKC = TV / 32;
+  constexpr int NPG = GV * PPVG / 256, BATCH = 8;
+  static_assert(NPG % BATCH == 0 && 256 % PPVG == 0, "staging plan");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TV * VBA + GV * VBG];
+  unsigned char* sA = smem;
+  unsigned char* sG = smem + TV * VBA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W;
+  const int nchunks_ = p.Cin / 16, groups8 = (p.groups + 7) & ~7;
+  const int per_cb = groups8 * nchunks_;
+  const int cbi = (int)blockIdx.x / per_cb, rem = (int)blockIdx.x % per_cb;
+  const int chunk = (rem % (8 * nchunks_)) / 8;
+  const int grp = (rem / (8 * nchunks_)) * 8 + rem % 8;
+  const int co_base = cbi * CB;
+  if (grp >= p.groups) return;
+
+  f32x4_t acc[2][NS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[a][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) bsum[e] = 0.f;
+  const bool want_bias = p.db != nullptr && chunk == 0;
+
+  const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ gin = reinterpret_cast<const char*>(p.dy);
+  // this thread's x piece: voxel t = tid>>1 of the tile, 8 channels
+  const int ta = tid >> 1, taz = ta >> 6, tay = (ta >> 4) & 3, tax = ta & 15;
+  const uint32_t rel_a = (uint32_t)(((taz * H + tay) * W + tax) * p.x_ld + chunk * 16 + (tid & 1) * KPL) * 2u;
+  const int subG = tid % PPVG, qlane = tid / PPVG;                 // dy piece u: block voxel q = u*(256/PPVG) + qlane
+  const int trl = (i >> 2), trc = (i & 3) * 8;
+  const int a_base = (g * 8 + trl) * VBA + trc;
+  const int g_base = ((2 * wave) * TV + g * 8 + trl) * VBG + trc;  // sub 2w; sub 2w+1 is TV*VBG further
+
+  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
+    const int n = tt / p.tilesPerSample, tile = tt - n * p.tilesPerSample;
+    const int z0 = (tile / (p.tilesX * p.tilesY)) * TZ, y0 = ((tile / p.tilesX) % p.tilesY) * TY, x0 = (tile % p.tilesX) * TX;
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
+    const uint32_t base_g = (uint32_t)(((n * 2 * D + 2 * z0) * 2 * H + 2 * y0) * 2 * W + 2 * x0) * (uint32_t)p.dy_ld * 2u;
+
+    u32x4_t pa = u32x4_t{0u, 0u, 0u, 0u};
+    if (full || (z0 + taz < D && y0 + tay < H && x0 + tax < W)) pa = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a));
+    __syncthreads();  // previous tile's MFMA phase is done with LDS
+    *reinterpret_cast<u32x4_t*>(sA + (size_t)tid * 16) = pa;
+#pragma unroll
+    for (int b0 = 0; b0 < NPG; b0 += BATCH) {
+      u32x4_t pg[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int q = (b0 + u) * (256 / PPVG) + qlane;             // voxel of the 4x8x32 dy block, x fastest
+        const int X = q & 31, Y = (q >> 5) & 7, Z = q >> 8;
+        pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+        if (full || (2 * z0 + Z < 2 * D && 2 * y0 + Y < 2 * H && 2 * x0 + X < 2 * W))
+          pg[u] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + (uint32_t)(((Z * 2 * H + Y) * 2 * W + X) * p.dy_ld + co_base + subG * KPL) * 2u));
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int q = (b0 + u) * (256 / PPVG) + qlane;
+        const int X = q & 31, Y = (q >> 5) & 7, Z = q >> 8;
+        const int sub = ((Z & 1) << 2) | ((Y & 1) << 1) | (X & 1), v = (((Z >> 1) * TY + (Y >> 1)) * TX) + (X >> 1);
+        *reinterpret_cast<u32x4_t*>(sG + (size_t)((sub * TV + v) * PPVG + subG) * 16) = pg[u];
+        if (want_bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bsum[2 * e] += bf16lo(pg[u][e]); bsum[2 * e + 1] += bf16hi(pg[u][e]); }
+        }
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      u32x4_t af, gf[2][NS];
+      {
+        const unsigned char* q = sA + a_base + kc * 32 * VBA;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBA));
+        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        af = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const unsigned char* q = sG + g_base + (a * TV + kc * 32) * VBG + ns * 32;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
+          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+          gf[a][ns] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[a][ns], 0, 0, 0);
+    }
+  }
+
+  float* pp = p.part + (size_t)grp * 8 * p.Cin * p.Cout;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = chunk * 16 + 4 * g + r, co = co_base + ns * 16 + i;
+        pp[((size_t)(2 * wave + a) * p.Cin + ci) * p.Cout + co] = acc[a][ns][r];
+      }
+  if (want_bias) {  // every thread summed the 8 channels of its pieces: combine the 256/PPVG threads of a channel group
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [256][8]
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) red[tid * KPL + e] = bsum[e];
+    __syncthreads();
+    if (tid < CB) {
+      const int sg = tid / KPL, e = tid % KPL;
+      float sum = 0.f;
+      for (int k = sg; k < 256; k += PPVG) sum += red[k * KPL + e];
+      atomicAdd(p.db + co_base + tid, sum);
+    }
+  }
+}
+
+struct CtCfg { int ns, groups, totalTiles, tilesY, tilesX, tilesPerSample; };
+inline CtCfg pick_ct(int N, int D, int H, int W, int Cin, int Cout) {
+  CtCfg c;
+  c.ns = (Cout % 32 == 0) ? 2 : 1;
+  c.tilesY = cdiv(H, 4); c.tilesX = cdiv(W, 16);
+  c.tilesPerSample = cdiv(D, 2) * c.tilesY * c.tilesX;
+  c.totalTiles = N * c.tilesPerSample;
+  const int nchunks = Cin / 16, nb = Cout / (16 * c.ns);
+  const int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / ((int64_t)8 * Cin * Cout));
+  c.groups = (int)std::min<int64_t>(std::min<int64_t>(c.totalTiles, cap), std::max(1, cdiv(2048, nchunks * nb)));
+  return c;
+}
+
 // sums the per-group partials in a fixed order and writes dW in its final layout.
 // 256 threads = 32 consecutive elements x 8 group lanes (the smallest dW has only 6912 elements; one thread per
 // element would leave the chip idle while it streams ~25 MB of partials).
@@ -667,8 +820,9 @@ extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Ci
   return (int64_t)c.groups * taps * Cin * Cout * 4;
 }
 extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
-  WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);
-  return (int64_t)c.groups * Cin * Cout * 4;
+  WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);           // fp32: one launch per sub-position
+  CtCfg t = pick_ct(N, D, H, W, Cin, Cout);                      // bf16: single pass, [groups][8][Cin][Cout]
+  return std::max((int64_t)c.groups * Cin * Cout * 4, (int64_t)t.groups * 8 * Cin * Cout * 4);
 }
 
 // test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 in the bf16 wgrad
@@ -702,6 +856,26 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
+  if (dtype == BPX_BF16 && g_use_tr != 0 && (int64_t)N * D * H * W * 8 * std::max(x.ld, dy.ld) < (1ll << 31)) {
+    CtCfg c = pick_ct(N, D, H, W, x.C, dy.C);
+    const int64_t need = (int64_t)c.groups * 8 * x.C * dy.C * 4;
+    BPX_CHECK(ws_d != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
+    WgradParams p{};
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C;
+    p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C;
+    p.part = reinterpret_cast<float*>(ws_d); p.db = db_d;
+    p.tilesY = c.tilesY; p.tilesX = c.tilesX; p.tilesPerSample = c.tilesPerSample; p.totalTiles = c.totalTiles; p.groups = c.groups;
+    const int nchunks = x.C / 16, nb = dy.C / (16 * c.ns);
+    dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
+    hipStream_t s = (hipStream_t)stream;
+    if (c.ns == 2) wgrad_ct_kernel<2><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1><<<grid, 256, 0, s>>>(p);
+    BPX_LAUNCH_CHECK(fn);
+    const int64_t total = (int64_t)8 * x.C * dy.C;   // (Cin, Cout, 2, 2, 2): index = ci*Cout*8 + co*8 + sub
+    wgrad_reduce_kernel<<<(int)cdiv64(total, 32), 256, 0, s>>>(p.part, c.groups, 8, x.C, dy.C, dw_d, (int64_t)dy.C * 8, 8, 1, 0);
+    BPX_LAUNCH_CHECK(fn);
+    return 0;
+  }
   for (int sub = 0; sub < 8; ++sub) {
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
