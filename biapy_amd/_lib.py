@@ -44,6 +44,7 @@ _SIGS = {
                            _vp, _vp, _i, _vp, _i, _vp], _i),
     "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
     "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
+    "bpx_pack_weights_batched": ([_i, _i, _vp, _vp], _i),
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
@@ -91,6 +92,12 @@ def _load() -> C.CDLL:
         fn.argtypes = args
         fn.restype = res
     return lib
+
+
+class PackJob(C.Structure):
+    """bpx_pack_job (include/biapy_amd.h)."""
+    _fields_ = [("w_d", C.c_void_p), ("packed_d", C.c_void_p), ("mode", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Profile:

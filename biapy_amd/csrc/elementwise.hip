@@ -572,10 +572,10 @@ __global__ void __launch_bounds__(256) rank1_wgrad_kernel(const float* __restric
 enum { PK_K3 = 0, PK_K3_T = 1, PK_K1 = 2, PK_DENSE = 3, PK_DENSE_T = 4, PK_CT = 5, PK_CT_T = 6 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout,
-                                                   int64_t total) {
+__device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int64_t total,
+                                           int64_t first, int64_t stride) {
   constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = first; i < total; i += stride) {
     int e = (int)(i % KPL);
     int64_t r = i / KPL;
     float v = 0.f;
@@ -618,6 +618,20 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, 
     }
     ElemTraits<T>::st(out + i, v);
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout,
+                                                   int64_t total) {
+  pack_elems<T>(w, out, mode, Cin, Cout, total, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+struct PackBatch { bpx_pack_job job[64]; int64_t total[64]; };
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch b) {   // blockIdx.y = job
+  const bpx_pack_job j = b.job[blockIdx.y];
+  pack_elems<T>(j.w_d, reinterpret_cast<T*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[blockIdx.y],
+                (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 inline int64_t packed_elems(int mode, int Cin, int Cout, int dtype) {
@@ -898,6 +912,32 @@ extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, in
   if (dtype == BPX_BF16) pack_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>(w_d, (uint16_t*)packed_d, mode, Cin, Cout, total);
   else pack_kernel<float><<<grid_for(total), 256, 0, s>>>(w_d, (float*)packed_d, mode, Cin, Cout, total);
   BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job* jobs, bpx_stream_t stream) {
+  const char* fn = "bpx_pack_weights_batched";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(count >= 0 && (count == 0 || jobs != nullptr), "%s: bad job list", fn);
+  hipStream_t s = (hipStream_t)stream;
+  for (int base = 0; base < count; base += 64) {
+    PackBatch b{};
+    const int n = std::min(64, count - base);
+    for (int k = 0; k < n; ++k) {
+      const bpx_pack_job& j = jobs[base + k];
+      BPX_CHECK(j.w_d && j.packed_d, "%s: job %d has a null pointer", fn, base + k);
+      BPX_CHECK(j.mode >= PK_K3 && j.mode <= PK_CT_T, "%s: job %d: unknown mode %d", fn, base + k, j.mode);
+      BPX_CHECK(j.Cin >= 1 && j.Cout >= 1, "%s: job %d: bad channel counts", fn, base + k);
+      if (j.mode == PK_K3 || j.mode == PK_K1) BPX_CHECK(j.Cin % 16 == 0, "%s: job %d: Cin must be a multiple of 16", fn, base + k);
+      if (j.mode == PK_K3_T) BPX_CHECK(j.Cout % 16 == 0, "%s: job %d: Cout must be a multiple of 16", fn, base + k);
+      b.job[k] = j;
+      b.total[k] = packed_elems(j.mode, j.Cin, j.Cout, dtype);
+    }
+    dim3 grid(32, (unsigned)n);
+    if (dtype == BPX_BF16) pack_batch_kernel<uint16_t><<<grid, 256, 0, s>>>(b);
+    else pack_batch_kernel<float><<<grid, 256, 0, s>>>(b);
+    BPX_LAUNCH_CHECK(fn);
+  }
   return 0;
 }
 

@@ -21,6 +21,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -154,7 +156,62 @@ class ResUNetEngine:
                                                                     ws.data_ptr(), ws.numel(), s_)))
 
     # ------------------------------------------------------------------------------------------
+    def _pack_plan(self, train: bool):
+        """(parameter name, pack mode, Cin, Cout) of every packed operand one step needs (forward; + backward if train)."""
+        cfg = self.cfg
+        fm, Lv = list(cfg.feature_maps), cfg.depth
+        plan = []
+
+        def block(prefix, first, cin, cout):
+            k = block_keys(prefix, first)
+            if not (first and cfg.in_ch == 1):
+                plan.append((k["w1"], L.PK_K3, cin, cout))
+                plan.append((k["wsc"], L.PK_K1, cin, cout))
+            plan.append((k["w2"], L.PK_K3, cout, cout))
+            if train:
+                plan.append((k["w2"], L.PK_K3_T, cout, cout))
+                if not first:
+                    plan.append((k["w1"], L.PK_K3_T, cin, cout))
+                    plan.append((k["wsc"], L.PK_DENSE_T, cin, cout))
+
+        for i in range(Lv):
+            block(f"down_path.{i}", i == 0, cfg.in_ch if i == 0 else fm[i - 1], fm[i])
+        block("bottleneck", False, fm[Lv - 1], fm[Lv])
+        for j, i in enumerate(range(Lv - 1, -1, -1)):
+            cup = fm[i + 1]
+            plan.append((f"up_paths.0.{j}.up.weight", L.PK_CT, cup, cup))
+            if train:
+                plan.append((f"up_paths.0.{j}.up.weight", L.PK_CT_T, cup, cup))
+            block(f"up_paths.0.{j}.conv_block", False, cup + fm[i], fm[i])
+        return plan
+
+    def _prepack(self, P: Dict[str, torch.Tensor], train: bool, dev) -> None:
+        """Pack every MFMA weight operand of the step with ONE launch into one buffer (the weights change after every
+        optimizer step, so training re-packs ~60 small tensors per step)."""
+        self._prepacked = {}
+        plan = self._pack_plan(train)
+        if any(P[name].dtype != torch.float32 or not P[name].is_contiguous() for name, _, _, _ in plan):
+            return  # _pack() falls back to per-tensor packing (with the conversion copy)
+        sizes = [int(lib.bpx_packed_weight_elems(mode, cin, cout, self.dt)) for _, mode, cin, cout in plan]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 127) // 128 * 128          # keep every operand 256-byte aligned
+        buf = torch.empty(tot, dtype=self.dtype, device=dev)
+        jobs = (L.PackJob * len(plan))()
+        es = buf.element_size()
+        for q, ((name, mode, cin, cout), off) in enumerate(zip(plan, offs)):
+            w = P[name]
+            jobs[q] = L.PackJob(w.data_ptr(), buf.data_ptr() + off * es, mode, cin, cout, 0)
+            self._prepacked[(w.data_ptr(), mode)] = buf[off:off + sizes[q]]
+        L.check(lib.bpx_pack_weights_batched(self.dt, len(plan), C.cast(jobs, C.c_void_p), L.stream_ptr()))
+
     def _pack(self, w: torch.Tensor, mode: int, cin: int, cout: int, cache: bool) -> torch.Tensor:
+        pre = getattr(self, "_prepacked", None)
+        if pre:
+            hit = pre.get((w.data_ptr(), mode))
+            if hit is not None:
+                return hit
         key = (w.data_ptr(), mode, self.dt)
         if cache and key in self._pack_cache and self._pack_versions.get(key) == w._version:
             return self._pack_cache[key]
@@ -223,6 +280,10 @@ class ResUNetEngine:
         st = L.stream_ptr()
         fm = list(cfg.feature_maps)
         T = self.dtype
+        if save and not cache_weights:
+            self._prepack(P, True, dev)
+        else:
+            self._prepacked = {}
         if Cin == 1:
             img = x.reshape(B, D0, H0, W0).contiguous()
             x_ndhwc = None

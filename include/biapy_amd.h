@@ -101,6 +101,14 @@ typedef struct bpx_tensor {
 enum bpx_pack_mode { BPX_PK_K3 = 0, BPX_PK_K3_T = 1, BPX_PK_K1 = 2, BPX_PK_DENSE = 3, BPX_PK_DENSE_T = 4, BPX_PK_CT = 5, BPX_PK_CT_T = 6 };
 int64_t bpx_packed_weight_elems(int mode, int Cin, int Cout, int dtype);
 int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, int dtype, void* packed_d, bpx_stream_t stream);
+/* The same for up to 64 weights in ONE launch (a training step re-packs ~60 small tensors after every optimizer step;
+ * one launch instead of 60).  `jobs` is a HOST array; it is copied into the kernel arguments, nothing is retained. */
+typedef struct bpx_pack_job {
+  const float* w_d;   /* fp32 weights, PyTorch layout, device */
+  void* packed_d;     /* destination, device, bpx_packed_weight_elems(mode, Cin, Cout, dtype) elements */
+  int32_t mode, Cin, Cout, reserved;
+} bpx_pack_job;
+int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job* jobs, bpx_stream_t stream);
 
 /* Conv3d k=3 "same" + bias (biapy/models/blocks.py:154-157), implicit GEMM on MFMA with an
  * LDS-staged input halo.  Fusions:
