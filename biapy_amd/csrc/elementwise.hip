@@ -501,10 +501,21 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_kernel(const float* __restr
       int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
       simg[i] = (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
     }
-    for (int i = threadIdx.x; i < TZ * TY * TX * 16; i += 256) {
-      int c = i % 16, t = i / 16;
-      int x = x0 + t % TX, y = y0 + (t / TX) % TY, z = z0 + t / (TX * TY);
-      sdy[t][c] = (z < D && y < H && x < W) ? ElemTraits<T>::ld(dy + ((((size_t)n * D + z) * H + y) * W + x) * dy_ld + cb + c) : 0.f;
+    {  // dy tile -> fp32 in LDS, moved as 16-byte pieces (KPL channels per piece)
+      constexpr int KPL = ElemTraits<T>::KPL, PPV = 16 / KPL;
+#pragma unroll
+      for (int u = 0; u < TZ * TY * TX * PPV / 256; ++u) {
+        const int i = u * 256 + threadIdx.x, t = i / PPV, sp = i % PPV;
+        const int x = x0 + t % TX, y = y0 + (t / TX) % TY, z = z0 + t / (TX * TY);
+        float f[KPL];
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) f[e] = 0.f;
+        if (z < D && y < H && x < W)
+          unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + ((((size_t)n * D + z) * H + y) * W + x) * dy_ld + cb + sp * KPL), f);
+#pragma unroll
+        for (int q = 0; q < KPL / 4; ++q)
+          *reinterpret_cast<f32x4_t*>(&sdy[t][sp * KPL + q * 4]) = f32x4_t{f[q * 4], f[q * 4 + 1], f[q * 4 + 2], f[q * 4 + 3]};
+      }
     }
     __syncthreads();
     if (worker) {

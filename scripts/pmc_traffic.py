@@ -6,8 +6,8 @@
 
 Units / corrections (MI355X_MICROARCH.md "HBM"): FETCH_SIZE and WRITE_SIZE are kilobytes; on gfx950 FETCH_SIZE tallies the
 128-byte requests of wide (16 B/lane) coalesced reads at 64 B, so it is doubled for the conv kernels, whose global reads are
-all 16 B/lane.  WRITE_SIZE is used as reported.  The same passes give the figures of the streaming `cast_kernel` (known byte
-count) as a calibration row.
+all 16 B/lane.  WRITE_SIZE is used as reported.  A wgrad call is its MFMA kernel plus the reduce kernel (and both k=3 and k=1 launches): pass the number of C-ABI calls of
+the profiled run as a JSON object in argv[3] to get bytes per CALL, the unit bench.py's roofline uses.
 """
 import json
 import re
@@ -15,11 +15,11 @@ import sqlite3
 import sys
 from collections import defaultdict
 
+# kernel name -> C-ABI entry point.  conv3_kernel<T,TZ,TY,TX,NS,EPI,ACTK> and conv3_lp_kernel<TZ,TY,TX,NS,EPI,ACTK>: EPI 0 = fwd, 1 = dgrad
 GROUPS = [
-    ("bpx_conv3d_fwd", re.compile(r"conv3_kernel<[^>]*?, (\d+), 0, \d+>")),
-    ("bpx_conv3d_dgrad", re.compile(r"conv3_kernel<[^>]*?, (\d+), 1, \d+>")),
-    ("bpx_conv3d_wgrad", re.compile(r"::wgrad_kernel<")),
-    ("cast_kernel(calibration)", re.compile(r"cast_kernel")),
+    ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+>")),
+    ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+>")),
+    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sd_)?kernel<|wgrad_reduce_kernel")),
 ]
 
 
@@ -39,10 +39,12 @@ def main():
     f = collect(fdb, "FETCH_SIZE")
     w = collect(wdb, "WRITE_SIZE")
     out = {}
+    launches = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}   # C-ABI launches in the profiled run (a call = >= 1 kernels)
     for g, _ in GROUPS:
         if g not in f:
             continue
-        nf, nw = len(f[g]), len(w.get(g, []))
+        nf = launches.get(g, len(f[g]))
+        nw = launches.get(g, len(w.get(g, [])))
         fetch_raw = 1024.0 * sum(f[g]) / nf
         write = 1024.0 * sum(w[g]) / nw if nw else None
         out[g] = dict(launches=nf, fetch_raw_bytes=round(fetch_raw), fetch_bytes=round(2 * fetch_raw), write_bytes=round(write) if write else None,
