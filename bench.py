@@ -218,26 +218,18 @@ def main():
     eager_step = step
     graphed = False
     if want_graph:
-        # HIP-graph capture of the whole step (forward, loss, backward, AdamW): one launch per step instead of ~230.
-        # Warm-up on a side stream first (allocator + lazy initialisation), as torch.cuda.graphs requires.
+        # HIP-graph capture of the whole step (forward, loss, backward, AdamW): one launch per step instead of ~170
+        # (biapy_amd/graphs.py).
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    out = step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            from biapy_amd.graphs import GraphedInference, GraphedTrainStep
+
             if train:
-                opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                gout = step()
-            torch.cuda.synchronize()
+                gstep = GraphedTrainStep(net, F.binary_cross_entropy_with_logits, opt, x, tgt)
+            else:
+                gstep = GraphedInference(model.predict_proba, x)
 
             def step():  # noqa: F811
-                graph.replay()
-                return gout
+                return gstep()
 
             graphed = True
         except Exception as e:  # capture is an optimisation, never a requirement

@@ -135,3 +135,45 @@ def test_sliding_window_pipeline(K, dtype):
 
 def test_dice_parity_on_a_trained_model(K):
     _assert_all(K.check_dice_parity_trained())
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_matches_eager(K):
+    """biapy_amd.graphs: replaying the captured step trains exactly like the eager step (same kernels, same order)."""
+    import copy
+
+    import torch.nn.functional as F
+
+    from biapy_amd.graphs import GraphedInference, GraphedTrainStep
+    from biapy_amd.resunet import ResUNet
+
+    torch.manual_seed(0)
+    kw = dict(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=[16, 32, 64], drop_values=[0.0] * 3, normalization="in",
+              yx_down=[2] * 2, z_down=[2] * 2, isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3)
+    m1 = ResUNet(**kw, compute_dtype=torch.float32).cuda()
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(2, 32, 32, 32, 1, device="cuda").permute(0, 4, 1, 2, 3)
+    t = (torch.rand(2, 1, 32, 32, 32, device="cuda") > 0.5).float()
+    o1 = torch.optim.AdamW(m1.parameters(), lr=1e-3, capturable=True)
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-3, capturable=True)
+    gs = GraphedTrainStep(m2, F.binary_cross_entropy_with_logits, o2, x, t, warmup=2)   # 2 warm-up steps run; capture only records
+    for _ in range(2):                                                                 # -> 2 eager steps on the twin
+        o1.zero_grad(set_to_none=True)
+        l1 = F.binary_cross_entropy_with_logits(m1(x), t)
+        l1.backward()
+        o1.step()
+    for _ in range(2):
+        o1.zero_grad(set_to_none=True)
+        l1 = F.binary_cross_entropy_with_logits(m1(x), t)
+        l1.backward()
+        o1.step()
+        l2 = gs()
+    torch.cuda.synchronize()
+    assert abs(l1.item() - l2.item()) < 1e-5, (l1.item(), l2.item())
+    # conv weights only: the biases in front of an InstanceNorm have an exactly-zero true gradient, Adam turns the sign of
+    # their rounding noise (atomic summation order) into +-lr, so they legitimately differ between any two runs
+    worst = max(float((p1 - p2).abs().max() / (p1.abs().max() + 1e-12)) for p1, p2 in zip(m1.parameters(), m2.parameters()) if p1.dim() == 5)
+    assert worst < 1e-3, worst
+    m1.eval()
+    gi = GraphedInference(m1.predict_proba, x)
+    assert torch.allclose(gi(), m1.predict_proba(x), atol=1e-6)
