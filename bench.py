@@ -205,11 +205,13 @@ def main():
         model.eval()
         want_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and not a.breakdown)
     x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
+    from biapy_amd.losses import BCEWithLogitsLoss
+    loss_fn = BCEWithLogitsLoss()                                      # LOSS.TYPE="CE" -> BCEWithLogits (metrics.py:543-544), fused HIP passes
 
     def step():
         if train:
             opt.zero_grad(set_to_none=True)
-            loss = F.binary_cross_entropy_with_logits(net(x), tgt)     # LOSS.TYPE="CE" -> BCEWithLogits (metrics.py:543-544)
+            loss = loss_fn(net(x), tgt)
             loss.backward()
             opt.step()
             return loss
@@ -224,7 +226,7 @@ def main():
             from biapy_amd.graphs import GraphedInference, GraphedTrainStep
 
             if train:
-                gstep = GraphedTrainStep(net, F.binary_cross_entropy_with_logits, opt, x, tgt)
+                gstep = GraphedTrainStep(net, loss_fn, opt, x, tgt)
             else:
                 gstep = GraphedInference(model.predict_proba, x)
 

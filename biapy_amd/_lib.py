@@ -45,6 +45,9 @@ _SIGS = {
     "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
     "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_pack_weights_batched": ([_i, _i, _vp, _vp], _i),
+    "bpx_seg_loss_blocks": ([_i64], _i),
+    "bpx_seg_loss_sums": ([_vp, _vp, _i64, _vp, _vp], _i),
+    "bpx_seg_loss_bwd": ([_vp, _vp, _i64, _vp, _vp, _vp], _i),
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),

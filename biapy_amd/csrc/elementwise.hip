@@ -301,14 +301,29 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, 
     for (int q = 0; q < CIN / KPL; ++q) unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (size_t)i * x_ld + q * KPL), f + q * KPL);
     int n = (int)(i / vps);
     int64_t v = i - (int64_t)n * vps;
+    float a[4];
     for (int co = 0; co < Cout; ++co) {
-      float a = ws[4 * CIN + co];
+      a[co] = ws[4 * CIN + co];
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) a = fmaf(f[c], ws[co * CIN + c], a);
-      if (act == 1) a = 1.f / (1.f + expf(-a));
-      else if (act == 2) a = tanhf(a);
-      out[n * sn + co * sc + v] = a;
+      for (int c = 0; c < CIN; ++c) a[co] = fmaf(f[c], ws[co * CIN + c], a[co]);
     }
+    // per-channel codes, 4 bits each (channel 0 in the low nibble): 0 linear, 1 sigmoid, 2 tanh, 3 softmax - consecutive
+    // softmax channels form ONE group (apply_model_activations, base_workflow.py:1403-1457)
+    for (int co = 0; co < Cout; ++co) {
+      const int code = (act >> (4 * co)) & 15;
+      if (code == 1) a[co] = 1.f / (1.f + expf(-a[co]));
+      else if (code == 2) a[co] = tanhf(a[co]);
+      else if (code == 3 && (co == 0 || ((act >> (4 * (co - 1))) & 15) != 3)) {
+        int e = co;
+        while (e + 1 < Cout && ((act >> (4 * (e + 1))) & 15) == 3) ++e;
+        float m = a[co];
+        for (int k = co + 1; k <= e; ++k) m = fmaxf(m, a[k]);
+        float ssum = 0.f;
+        for (int k = co; k <= e; ++k) { a[k] = expf(a[k] - m); ssum += a[k]; }
+        for (int k = co; k <= e; ++k) a[k] /= ssum;
+      }
+    }
+    for (int co = 0; co < Cout; ++co) out[n * sn + co * sc + v] = a[co];
   }
 }
 
@@ -754,6 +769,62 @@ extern "C" int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, 
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Binary segmentation loss on the 1-channel head (metrics.py:493-586 CrossEntropyLoss_wrapper -> BCEWithLogits,
+// :726-762 DiceLoss with batch_dice, :764-973 DiceCELoss) and the IoU@0.5 counts (:138-232), one streaming pass each way.
+//   sums[b] = { sum bce, sum p*t, sum p, sum t, |P&T|, |P|T| }  per block b, p = sigmoid(z), P = p > 0.5, T = t > 0.5
+//   backward: dz = a (p - t) - p (1 - p) (b t - c), (a, b, c) from the reduced sums (see losses.py)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) seg_loss_sums_kernel(const float* __restrict__ z, const float* __restrict__ t, int64_t n,
+                                                            float* __restrict__ part) {
+  float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4_t zv = reinterpret_cast<const f32x4_t*>(z)[i], tv = reinterpret_cast<const f32x4_t*>(t)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float zz = zv[e], tt = tv[e];
+      const float en = expf(-fabsf(zz));
+      const float p = zz >= 0.f ? 1.f / (1.f + en) : en / (1.f + en);
+      s[0] += fmaxf(zz, 0.f) - zz * tt + log1pf(en);
+      s[1] += p * tt; s[2] += p; s[3] += tt;
+      const bool P = p > 0.5f, T = tt > 0.5f;
+      s[4] += (P && T) ? 1.f : 0.f; s[5] += (P || T) ? 1.f : 0.f;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {  // tail
+    const float zz = z[n4 * 4 + threadIdx.x], tt = t[n4 * 4 + threadIdx.x];
+    const float en = expf(-fabsf(zz));
+    const float p = zz >= 0.f ? 1.f / (1.f + en) : en / (1.f + en);
+    s[0] += fmaxf(zz, 0.f) - zz * tt + log1pf(en);
+    s[1] += p * tt; s[2] += p; s[3] += tt;
+    const bool P = p > 0.5f, T = tt > 0.5f;
+    s[4] += (P && T) ? 1.f : 0.f; s[5] += (P || T) ? 1.f : 0.f;
+  }
+  __shared__ float red[4][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float v = s[k];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) part[(size_t)blockIdx.x * 6 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t, int64_t n,
+                                                           const float* __restrict__ coef, float* __restrict__ dz) {
+  const float a = coef[0], b = coef[1], c = coef[2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float zz = z[i], tt = t[i];
+    const float en = expf(-fabsf(zz));
+    const float p = zz >= 0.f ? 1.f / (1.f + en) : en / (1.f + en);
+    dz[i] = a * (p - tt) - p * (1.f - p) * (b * tt - c);
+  }
+}
+
 static int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16); }
 
 extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
@@ -949,6 +1020,29 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
     else pack_batch_kernel<float><<<grid, 256, 0, s>>>(b);
     BPX_LAUNCH_CHECK(fn);
   }
+  return 0;
+}
+
+
+extern "C" int bpx_seg_loss_blocks(int64_t n) { return (int)std::min<int64_t>(std::max<int64_t>(1, cdiv64(n / 4, 256)), 2048); }
+
+extern "C" int bpx_seg_loss_sums(const float* logits_d, const float* target_d, int64_t n, float* partials_d, bpx_stream_t stream) {
+  const char* fn = "bpx_seg_loss_sums";
+  BPX_CHECK(logits_d && target_d && partials_d, "%s: null pointer", fn);
+  BPX_CHECK(n > 0, "%s: empty input", fn);
+  BPX_CHECK((((uintptr_t)logits_d | (uintptr_t)target_d) & 15) == 0, "%s: logits and target must be 16-byte aligned", fn);
+  seg_loss_sums_kernel<<<bpx_seg_loss_blocks(n), 256, 0, (hipStream_t)stream>>>(logits_d, target_d, n, partials_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_seg_loss_bwd(const float* logits_d, const float* target_d, int64_t n, const float* coef_d, float* dlogits_d,
+                                bpx_stream_t stream) {
+  const char* fn = "bpx_seg_loss_bwd";
+  BPX_CHECK(logits_d && target_d && coef_d && dlogits_d, "%s: null pointer", fn);
+  BPX_CHECK(n > 0, "%s: empty input", fn);
+  seg_loss_bwd_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(logits_d, target_d, n, coef_d, dlogits_d);
+  BPX_LAUNCH_CHECK(fn);
   return 0;
 }
 

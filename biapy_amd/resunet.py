@@ -144,6 +144,7 @@ class ResUNet(nn.Module):
         self.z_down, self.yx_down = z_down, yx_down
         self.output_channels = output_channels
         self.output_channel_info = output_channel_info
+        self.head_activations = list(head_activations)
         self.return_class = False
         self.contrast = False
         self.explicit_activations = False
@@ -209,10 +210,27 @@ class ResUNet(nn.Module):
         logits, _ = self.engine().forward(P, x, head_act=0, save=False, cache_weights=not self.training)
         return logits
 
+    _HEAD_CODES = {"linear": 0, "ce_sigmoid": 1, "sigmoid": 1, "tanh": 2, "ce_softmax": 3, "softmax": 3}
+
+    def head_activation_code(self, head_activations=None) -> int:
+        """One 4-bit code per output channel for the head kernel (0 linear, 1 sigmoid, 2 tanh, 3 softmax; consecutive softmax
+        channels are one group) from the reference's per-channel activation names (``apply_model_activations``,
+        base_workflow.py:1403-1457).  A list shorter than the channel count repeats its last entry (one name per head)."""
+        acts = [a.lower() for a in (head_activations if head_activations is not None else self.head_activations)]
+        n_out = sum(self.output_channels)
+        acts = (acts + [acts[-1]] * n_out)[:n_out]
+        code = 0
+        for c, a in enumerate(acts):
+            if a not in self._HEAD_CODES:
+                raise NotImplementedError(f"head activation {a!r} is not implemented in the MI355X head kernel")
+            code |= self._HEAD_CODES[a] << (4 * c)
+        return code
+
     @torch.no_grad()
-    def predict_proba(self, x) -> torch.Tensor:
-        """Inference with the ``ce_sigmoid`` head activation (base_workflow.py:1403-1457) fused into the head kernel."""
+    def predict_proba(self, x, head_activations=None) -> torch.Tensor:
+        """Inference with the head activations (``ce_sigmoid`` by default; base_workflow.py:1403-1457) fused into the head kernel."""
         names, params = self._named()
         P = {n: p.detach() for n, p in zip(names, params)}
-        out, _ = self.engine().forward(P, x.to(torch.float32), head_act=1, save=False, cache_weights=True)
+        out, _ = self.engine().forward(P, x.to(torch.float32), head_act=self.head_activation_code(head_activations), save=False,
+                                       cache_weights=True)
         return out

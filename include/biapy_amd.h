@@ -191,7 +191,8 @@ int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_t
                       bpx_tensor dx, bpx_stream_t stream);
 
 /* Output head: Conv3d k=1 to `Cout` (<= 4) fp32 channels (resunet.py:346-348) with the head
- * activation (base_workflow.py:1403-1457) fused: head_act 0 = logits, 1 = sigmoid, 2 = tanh.
+ * activation (base_workflow.py:1403-1457) fused: head_act holds one 4-bit code per output channel (channel 0 in the low
+ * nibble): 0 = linear (logits), 1 = sigmoid, 2 = tanh, 3 = softmax, consecutive softmax channels forming one group.
  * out is (N,Cout,D,H,W) fp32 contiguous per channel plane with arbitrary strides given in elements. */
 int bpx_head_fwd(int dtype, int64_t voxels_per_sample, int N, bpx_tensor x, const float* w_d /* [Cout][Cin] */,
                  const float* b_d, int Cout, int head_act, float* out_d, int64_t out_stride_n, int64_t out_stride_c,
@@ -213,6 +214,17 @@ int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bp
 
 /* dtype conversion helpers (NDHWC, strided channel slices) */
 int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64_t n, bpx_stream_t stream);
+
+/* ---- binary segmentation loss (1-channel head) ---------------------------------------------------------------------------
+ * Replaces biapy/engine/metrics.py:493-586 (CrossEntropyLoss_wrapper -> BCEWithLogitsLoss), :726-762 (DiceLoss, batch_dice),
+ * :764-973 (DiceCELoss, binary case) and the counts of :138-232 (jaccard_index at threshold 0.5) with one streaming pass each
+ * way.  bpx_seg_loss_sums writes bpx_seg_loss_blocks(n) rows of {sum bce, sum p*t, sum p, sum t, |P&T|, |P|T|}
+ * (p = sigmoid(logit), P = p > 0.5, T = t > 0.5); the caller reduces the rows (deterministic) and forms the loss.
+ * bpx_seg_loss_bwd: dlogits = a (p - t) - p (1 - p) (b t - c) with coef_d = {a, b, c} on the device
+ * (a = w_ce*g/n, b = 2 w_dice*g/(U+s), c = w_dice*g*(2I+s)/(U+s)^2; biapy_amd/losses.py). fp32 planar logits and targets. */
+int bpx_seg_loss_blocks(int64_t n);
+int bpx_seg_loss_sums(const float* logits_d, const float* target_d, int64_t n, float* partials_d, bpx_stream_t stream);
+int bpx_seg_loss_bwd(const float* logits_d, const float* target_d, int64_t n, const float* coef_d, float* dlogits_d, bpx_stream_t stream);
 
 #ifdef __cplusplus
 }

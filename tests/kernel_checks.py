@@ -454,10 +454,20 @@ def check_norm_pool_head(dt, seed=0):
     lo = torch.empty(B, Co, D, H, W, dtype=torch.float32, device=DEV)
     L.check(lib.bpx_head_fwd(dt, vox, B, L.tview(fd), hw_d.data_ptr(), hb_d.data_ptr(), Co, 0, lo.data_ptr(), Co * vox, vox, L.stream_ptr()))
     pr = torch.empty_like(lo)
-    L.check(lib.bpx_head_fwd(dt, vox, B, L.tview(fd), hw_d.data_ptr(), hb_d.data_ptr(), Co, 1, pr.data_ptr(), Co * vox, vox, L.stream_ptr()))
+    L.check(lib.bpx_head_fwd(dt, vox, B, L.tview(fd), hw_d.data_ptr(), hb_d.data_ptr(), Co, 0x11, pr.data_ptr(), Co * vox, vox, L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(f"head_fwd[{tagd}]", relerr(lo, lo_ref.detach()), 1e-5))
     res.append(_res(f"head_fwd_sigmoid[{tagd}]", relerr(pr, torch.sigmoid(lo_ref.detach())), 1e-5))
+    # per-channel activation codes of apply_model_activations (base_workflow.py:1403-1457): 4 channels =
+    # [sigmoid, softmax, softmax, tanh] -> the two softmax channels form one group
+    hw4 = torch.randn(4, Cf, generator=g) * 0.3; hb4 = torch.randn(4, generator=g) * 0.1
+    lo4 = F.conv3d(ncdhw(f), hw4.view(4, Cf, 1, 1, 1), hb4)
+    ref4 = torch.cat([torch.sigmoid(lo4[:, 0:1]), torch.softmax(lo4[:, 1:3], dim=1), torch.tanh(lo4[:, 3:4])], 1)
+    hw4d, hb4d = hw4.to(DEV), hb4.to(DEV)
+    pr4 = torch.empty(B, 4, D, H, W, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_head_fwd(dt, vox, B, L.tview(fd), hw4d.data_ptr(), hb4d.data_ptr(), 4, 0x2331, pr4.data_ptr(), 4 * vox, vox, L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"head_fwd_mixed_acts[{tagd}]", relerr(pr4, ref4), 1e-5))
     dlo = torch.randn(B, Co, D, H, W, generator=g)
     lo_ref.backward(dlo)
     dfe = torch.empty(B, D, H, W, Cf, dtype=tdtype(dt), device=DEV)

@@ -177,3 +177,36 @@ def test_graphed_train_step_matches_eager(K):
     m1.eval()
     gi = GraphedInference(m1.predict_proba, x)
     assert torch.allclose(gi(), m1.predict_proba(x), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_segmentation_losses_match_reference_formulas():
+    """biapy_amd.losses (fused HIP passes) vs the formulas of metrics.py:493-586, 726-762, 764-973, 138-232 in plain torch."""
+    import torch.nn.functional as F
+
+    from biapy_amd import losses
+    from oracle import net_oracle
+
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randn(2, 1, 12, 20, 27, generator=g) * 3).cuda().requires_grad_(True)     # 12960 elements: not a multiple of 4*256
+    t = (torch.rand(2, 1, 12, 20, 27, generator=g) > 0.6).float().cuda()
+    zr = z.detach().cpu().double().requires_grad_(True)
+    tr = t.cpu().double()
+    p = torch.sigmoid(zr)
+    dice_ref = 1.0 - (2.0 * (p * tr).sum() + 1e-5) / (p.sum() + tr.sum() + 1e-5)
+    bce_ref = F.binary_cross_entropy_with_logits(zr, tr)
+    for mod, ref in ((losses.BCEWithLogitsLoss(), bce_ref), (losses.DiceLoss(), dice_ref), (losses.DiceCELoss(0.7, 1.3), 0.7 * bce_ref + 1.3 * dice_ref)):
+        z.grad = None
+        zr.grad = None
+        out = mod(z, t)
+        out.backward()
+        ref.backward(retain_graph=True)
+        assert abs(out.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item())), (type(mod).__name__, out.item(), ref.item())
+        err = (z.grad.cpu().double() - zr.grad).abs().max() / zr.grad.abs().max()
+        assert err < 1e-5, (type(mod).__name__, float(err))
+    pb, tb = (p > 0.5), (tr > 0.5)
+    iou_ref = (pb & tb).sum().double() / (pb | tb).sum().double()
+    assert abs(losses.jaccard_index(z.detach(), t).item() - iou_ref.item()) < 1e-6
+    assert abs(losses.hard_dice(z.detach(), t).item() - net_oracle.dice(p.detach().float(), tr.float())) < 1e-6
+    with pytest.raises(NotImplementedError):
+        losses.BCEWithLogitsLoss()(torch.zeros(1, 3, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))

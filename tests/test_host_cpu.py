@@ -72,3 +72,16 @@ def test_module_state_dict_schema(resunet_golden):
         m(torch.zeros(1, 1, 16, 16, 16))
     with pytest.raises(NotImplementedError):
         ResUNet(image_shape=(64, 64, 1), feature_maps=[16, 32], normalization="in", larger_io=False)
+
+
+def test_losses_fail_loudly_without_gpu():
+    """The device losses have no CPU fallback (product path rule): CPU tensors raise."""
+    import pytest
+    import torch
+
+    from biapy_amd import losses
+
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        losses.DiceCELoss()(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
+    with pytest.raises(NotImplementedError):
+        losses.DiceLoss(batch_dice=False)
