@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel timing table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="testing aid: take the multi-GPU code path (DDP over RCCL) even with one rank")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: single-GPU runs; the ~230 launches of a step are host-bound otherwise)")
     a = ap.parse_args()
@@ -177,8 +178,12 @@ def main():
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or a.force_ddp
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", init_method="env://")
 
     from biapy_amd import _lib as L
@@ -192,19 +197,29 @@ def main():
         return bench_sliding(a, model, dev, rank, world)
     train = a.mode == "train"
     net = model
+    x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
     if train:
         model.train()
-        if world > 1:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
-        want_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and not a.breakdown)
+        if multi:
+            if a.graph != "off":
+                # forward and backward as two HIP-graph replays below the autograd boundary; DDP's hooks, the RCCL all-reduce
+                # and the optimizer stay eager (ResUNet.capture_graphs)
+                try:
+                    model.capture_graphs(x)
+                except Exception as e:
+                    print(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                    model.release_graphs()
+            # one 27 MB bucket (a single ring all-reduce over xGMI) whose views ARE the .grad tensors: no copy-back kernels
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
+                                                            gradient_as_bucket_view=True, bucket_cap_mb=int(os.environ.get("BPX_DDP_BUCKET_MB", "64")))
+        want_graph = (a.graph == "on" or (a.graph == "auto" and not a.breakdown)) and not multi
         try:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=want_graph)
         except Exception:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=want_graph)
     else:
         model.eval()
-        want_graph = a.graph == "on" or (a.graph == "auto" and world == 1 and not a.breakdown)
-    x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
+        want_graph = a.graph == "on" or (a.graph == "auto" and not a.breakdown)   # no collective inside an inference step
     from biapy_amd.losses import BCEWithLogitsLoss
     loss_fn = BCEWithLogitsLoss()                                      # LOSS.TYPE="CE" -> BCEWithLogits (metrics.py:543-544), fused HIP passes
 
@@ -275,7 +290,10 @@ def main():
     elapsed = time.perf_counter() - t0
     L.lib.prof = None
     prof_steps = a.steps
-    if graphed:
+    fb_graphs = train and getattr(model, "_graphs", None) is not None
+    if fb_graphs:
+        model.release_graphs()
+    if graphed or fb_graphs:
         # a graph replay has no per-launch events: time the same launches on the same stream in eager steps right after
         # the timed region (same kernels, same shapes; `value` above is NOT taken from these steps)
         prof_steps = min(a.steps, 5)
@@ -324,7 +342,7 @@ def main():
                             launches=cnt, avg_launch_ms=round(ms / cnt, 4), tflops=round(ach_f, 2), algorithmic_GBps=round(ach_b, 1),
                             all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), GBps=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
                                          ms_per_step=round(v[1] / prof_steps, 3)) for k, v in per.items()},
-                            timed_on="eager steps right after the timed region (the timed region replays a HIP graph)" if graphed else "the timed region")
+                            timed_on="eager steps right after the timed region (the timed region replays HIP graphs)" if (graphed or fb_graphs) else "the timed region")
         mult = 3 if train else 1
         line = dict(
             metric="voxels/sec 3D ResUNet 128^3 patch (%s)" % ("train: fwd+bwd+AdamW" if train else "inference forward"),
@@ -332,14 +350,15 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
             config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, %s" % (a.patch, a.batch, a.mode),
                         global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode=a.mode),
-            launch="hip-graph replay" if graphed else "eager",
+            launch="hip-graph replay (whole step)" if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
+                                                                    if fb_graphs else "eager"),
             mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * mult / (world * MFMA_PEAK_BF16), 5),
             roofline=roofline,
         )
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.patch, train)
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

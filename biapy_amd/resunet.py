@@ -84,6 +84,25 @@ class _ResUNetFn(torch.autograd.Function):
         return (None, None, None) + tuple(G[n] for n in ctx.names)
 
 
+class _GraphedResUNetFn(torch.autograd.Function):
+    """Forward / backward of the whole network as two HIP-graph replays (ResUNet.capture_graphs).  Anything around it -
+    loss, DistributedDataParallel's gradient hooks and all-reduce, the optimizer - stays eager and unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, gr, *params):
+        gr["x"].copy_(x.detach(), non_blocking=True)
+        gr["fwd"].replay()
+        ctx.gr = gr
+        return gr["logits"].detach()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        gr = ctx.gr
+        gr["dlogits"].copy_(dlogits, non_blocking=True)
+        gr["bwd"].replay()
+        return (None, None) + tuple(gr["grads"][n] for n in gr["names"])
+
+
 class ResUNet(nn.Module):
     def __init__(
         self,
@@ -205,10 +224,51 @@ class ResUNet(nn.Module):
         names, params = self._named()
         x = x.to(torch.float32)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            gr = getattr(self, "_graphs", None)
+            if gr is not None and tuple(x.shape) == gr["shape"] and x.stride() == gr["stride"] and not torch.cuda.is_current_stream_capturing():
+                return _GraphedResUNetFn.apply(x, gr, *params)
             return _ResUNetFn.apply(x, self.engine(), names, *params)
         P = {n: p.detach() for n, p in zip(names, params)}
         logits, _ = self.engine().forward(P, x, head_act=0, save=False, cache_weights=not self.training)
         return logits
+
+    def capture_graphs(self, x_example: torch.Tensor, warmup: int = 3) -> None:
+        """Capture the training forward and backward for inputs shaped like ``x_example`` into two HIP graphs; later
+        training-mode calls with that shape replay them (two launches instead of ~170: an eager step is host-bound, 16.3 vs
+        13.8 ms measured).  Unlike ``graphs.GraphedTrainStep`` this leaves the autograd boundary intact, so it composes with
+        ``DistributedDataParallel`` (wrap AFTER capturing): gradient hooks, bucketed all-reduce and the optimizer run as
+        usual.  Parameters must keep their storage (in-place optimizer updates and ``load_state_dict`` do).  ``release_graphs()``
+        drops the graphs and their private memory pool."""
+        if not x_example.is_cuda:
+            raise RuntimeError("capture_graphs needs a CUDA/HIP example input")
+        names, params = self._named()
+        eng = self.engine()
+        P = {n: p.detach() for n, p in zip(names, params)}
+        xs = x_example.detach().to(torch.float32).clone()
+
+        def once():
+            logits, saved = eng.forward(P, xs, head_act=0, save=True)
+            eng.backward(P, saved, torch.ones_like(logits))
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                once()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf):
+            logits, saved = eng.forward(P, xs, head_act=0, save=True)
+        dl = torch.zeros_like(logits)
+        with torch.cuda.graph(gb, pool=gf.pool()):
+            grads = eng.backward(P, saved, dl)
+        torch.cuda.synchronize()
+        self._graphs = dict(shape=tuple(xs.shape), stride=xs.stride(), x=xs, logits=logits, saved=saved, dlogits=dl, grads=grads,
+                            names=names, fwd=gf, bwd=gb)
+
+    def release_graphs(self) -> None:
+        self._graphs = None
 
     _HEAD_CODES = {"linear": 0, "ce_sigmoid": 1, "sigmoid": 1, "tanh": 2, "ce_softmax": 3, "softmax": 3}
 
