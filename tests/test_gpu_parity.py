@@ -177,6 +177,17 @@ def test_graphed_train_step_matches_eager(K):
     m1.eval()
     gi = GraphedInference(m1.predict_proba, x)
     assert torch.allclose(gi(), m1.predict_proba(x), atol=1e-6)
+    # ResUNet.capture_graphs: forward and backward as two graph replays below the autograd boundary (the DDP-compatible form)
+    m1.train()
+    m3 = copy.deepcopy(m1)
+    m3.capture_graphs(x)
+    l1 = F.binary_cross_entropy_with_logits(m1(x), t)
+    l3 = F.binary_cross_entropy_with_logits(m3(x), t)
+    g1 = torch.autograd.grad(l1, [p for p in m1.parameters()])
+    g3 = torch.autograd.grad(l3, [p for p in m3.parameters()])
+    assert abs(l1.item() - l3.item()) < 1e-6
+    worst = max(float((a - b).abs().max() / (a.abs().max() + 1e-12)) for a, b in zip(g1, g3) if a.dim() == 5)
+    assert worst < 1e-4, worst
 
 
 @pytest.mark.gpu
