@@ -564,6 +564,110 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_kernel(const float* __restr
   }
 }
 
+
+// The same on the matrix cores (bf16 dy): D[tap][co] += sum_v A[tap][v] * G[v][co] with K = 32 voxels per MFMA step.
+// A = image patches (fp32 in LDS, split hi + lo into two bf16 operands exactly like conv_c1_fwd_kernel, so the image keeps
+// ~16 mantissa bits), two 16-row blocks for the 27 taps; row 27 is all ones -> D[27][co] = sum_v dy = the bias gradient.
+// G = dy^T fragments through ds_read_b64_tr_b16.  Wave w owns K-chunks {2w, 2w+1} of every 4x4x16 tile.
+__global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __restrict__ img, const uint16_t* __restrict__ dy, int dy_ld,
+                                                                 int D, int H, int W, int N, int totalTiles, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+  constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int VBG = 32;
+  __shared__ float simg[HV + 8];
+  __shared__ __attribute__((aligned(16))) unsigned char sG[TV * VBG];
+  __shared__ float sred[4][2][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y * 16;
+  f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  // this lane's two taps (rows i and 16 + i) as float offsets into the halo image; row 27 = ones, rows 28..31 unused
+  int toff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int tap = b * 16 + i;
+    toff[b] = tap < 27 ? ((tap / 9) * HY + (tap / 3) % 3) * HX + tap % 3 : -1;
+  }
+  const int tilesX = cdiv(W, TX), tilesY = cdiv(H, TY), tilesZ = cdiv(D, TZ);
+  const int tps = tilesX * tilesY * tilesZ;
+  // register-prefetched staging: the loads of tile k+1 are in flight while tile k is multiplied (the MFMA part is tiny, the
+  // kernel is otherwise pure load latency)
+  constexpr int NI = (HV + 255) / 256;
+  float pi[NI];
+  u32x4_t pg[2];
+  auto issue = [&](int tt) {
+    const int n = tt / tps, tile = tt % tps;
+    const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int q = u * 256 + tid;
+      const int hx = q % HX, hy = (q / HX) % HY, hz = q / (HX * HY);
+      const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+      pi[u] = (q < HV && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = u * 256 + tid, t = q >> 1;
+      const int x = x0 + (t & 15), y = y0 + ((t >> 4) & 3), z = z0 + (t >> 6);
+      pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (z < D && y < H && x < W) pg[u] = *reinterpret_cast<const u32x4_t*>(dy + ((((size_t)n * D + z) * H + y) * W + x) * dy_ld + cb + (q & 1) * 8);
+    }
+  };
+  if ((int)blockIdx.x < totalTiles) issue(blockIdx.x);
+  for (int tt = blockIdx.x; tt < totalTiles; tt += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NI; ++u)
+      if (u * 256 + tid < HV) simg[u * 256 + tid] = pi[u];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[u];
+    __syncthreads();
+    if (tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int kc = wave * 2 + kk;
+      const int t0 = kc * 32 + g * 8;                       // 8 consecutive x voxels of one row
+      const int hb = (((t0 >> 6) + 0) * HY + ((t0 >> 4) & 3)) * HX + (t0 & 15);
+      u32x4_t gf;
+      {
+        const unsigned char* q = sG + (t0 + (i >> 2)) * VBG + (i & 3) * 8;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
+        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        gf = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = toff[b] >= 0 ? simg[hb + toff[b] + k] : ((b == 1 && i == 11) ? 1.f : 0.f);
+        u32x4_t ah, al;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t h = cvt_pk_bf16(f[2 * k], f[2 * k + 1]);
+          ah[k] = h;
+          al[k] = cvt_pk_bf16(f[2 * k] - bf16lo(h), f[2 * k + 1] - bf16hi(h));
+        }
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, gf), acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, gf), acc[b], 0, 0, 0);
+      }
+    }
+  }
+  // lane holds D[row = 4g + r][co = i] of each block: sum the four waves, then one atomic per (tap, co) and workgroup
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sred[wave][b][lane][r] = acc[b][r];
+  __syncthreads();
+  for (int q = tid; q < 2 * 64 * 4; q += 256) {
+    const int r = q & 3, ln = (q >> 2) & 63, b = q >> 8;
+    const float sum = sred[0][b][ln][r] + sred[1][b][ln][r] + sred[2][b][ln][r] + sred[3][b][ln][r];
+    const int row = b * 16 + 4 * (ln >> 4) + r, co = ln & 15;
+    if (row < 27) atomicAdd(dw + (size_t)(cb + co) * 27 + row, sum);
+    else if (row == 27 && db) atomicAdd(db + cb + co, sum);
+  }
+}
+
 // shortcut of the first block (Conv3d 1 -> Cout, k = 1): dW[co] += sum_v img[v]*dy[v][co]; 16 channels per blockIdx.y
 template <typename T>
 __global__ void __launch_bounds__(256) rank1_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy, int dy_ld, int64_t total,
@@ -960,7 +1064,11 @@ extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const 
   int totalTiles = N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 8);
   dim3 grid((unsigned)std::min(totalTiles, 1024), (unsigned)(dy.C / 16));
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
+  if (dtype == BPX_BF16 && W > 8 && ((uintptr_t)dy.ptr & 15) == 0 && (dy.ld & 7) == 0) {
+    const int tiles = N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
+    dim3 gm((unsigned)std::min(tiles, 2048), (unsigned)(dy.C / 16));
+    conv_c1_wgrad_mfma_kernel<<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, dw_d, db_d);
+  } else if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
   else if (dtype == BPX_F32) conv_c1_wgrad_kernel<float><<<grid, 256, 0, s>>>(img_d, (const float*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
