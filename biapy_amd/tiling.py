@@ -309,3 +309,104 @@ def merge_3D_data_with_overlap(data, orig_vol_shape, data_mask=None, overlap=(0,
     if data_mask is not None:
         return merged, run(data_mask)
     return merged
+
+
+# ---------------------------------------------------------------------------------------------------
+# 2D drop-ins (biapy/data/data_2D_manipulation.py:54-316 crop_data_with_overlap, :366-533 merge_data_with_overlap)
+# ---------------------------------------------------------------------------------------------------
+# An image stack (N,Y,X,C) is a volume whose z axis has patch size 1, no overlap and no padding: the reference's 2D code
+# uses the same per-axis grid arithmetic, taper and fp32 blend as its 3D code, so the 3D gather / blend kernels serve both
+# (bit-exact against the reference's 2D outputs: tests/golden/tiling2d_golden.npz).
+def crop_data_with_overlap(data, crop_shape, data_mask=None, overlap=(0, 0), padding=(0, 0), verbose=True, load_data=True,
+                           pad_type="reflect"):
+    """Drop-in for biapy.data.data_2D_manipulation.crop_data_with_overlap (same checks, messages, returns)."""
+    if data.ndim != 4:
+        raise ValueError("data expected to be 4 dimensional, given {}".format(data.shape))
+    if data_mask is not None:
+        if data.ndim != 4:
+            raise ValueError("data mask expected to be 4 dimensional, given {}".format(data_mask.shape))
+        if data.shape[:-1] != data_mask.shape[:-1]:
+            raise ValueError("data and data_mask shapes mismatch: {} vs {}".format(data.shape[:-1], data_mask.shape[:-1]))
+    for i, p in enumerate(padding):
+        if p >= crop_shape[i] // 2:
+            raise ValueError("'Padding' can not be greater than the half of 'crop_shape'. Max value for this {} input shape is {}".format(
+                crop_shape, ((crop_shape[0] // 2) - 1, (crop_shape[1] // 2) - 1)))
+    if len(crop_shape) != 3:
+        raise ValueError("crop_shape expected to be of length 3, given {}".format(crop_shape))
+    for a in range(2):
+        if crop_shape[a] > data.shape[a + 1]:
+            raise ValueError("'crop_shape[{}]' {} greater than {} (you can reduce 'DATA.PATCH_SIZE' or use 'DATA.REFLECT_TO_COMPLETE_SHAPE')".format(
+                a, crop_shape[a], data.shape[a + 1]))
+    if (overlap[0] >= 1 or overlap[0] < 0) or (overlap[1] >= 1 or overlap[1] < 0):
+        raise ValueError("'overlap' values must be floats between range [0, 1)")
+    if verbose:
+        print("### OV-CROP ###")
+        print("Cropping {} images into {} with overlapping. . .".format(data.shape, crop_shape))
+        print("Minimum overlap selected: {}".format(overlap))
+        print("Padding: {}".format(padding))
+    patch3, ov3, pad3 = (1, crop_shape[0], crop_shape[1]), (0.0, overlap[0], overlap[1]), (0, padding[0], padding[1])
+    g = crop_grid(data.shape[:3], patch3, ov3, pad3)
+    if verbose:
+        print("{} patches per (y,x) axis".format((g[1].n, g[2].n)))
+    coords: List[PatchCoords] = []
+    for _ in range(g[0].n):
+        for iy in range(g[1].n):
+            y0 = _start(g[1], iy)
+            for ix in range(g[2].n):
+                x0 = _start(g[2], ix)
+                coords.append(PatchCoords(y_start=y0, y_end=y0 + crop_shape[0], x_start=x0, x_end=x0 + crop_shape[1]))
+    if not load_data:
+        return coords
+    dev = _device()
+
+    def run(arr: np.ndarray) -> np.ndarray:
+        if arr.dtype.itemsize not in (1, 2, 4):
+            raise ValueError(f"dtype {arr.dtype} is not supported by the device crop (1/2/4-byte element types only)")
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(_uint_view(arr.dtype))).to(dev)
+        out = crop_device(t, patch3, ov3, pad3, pad_type)
+        return out.cpu().numpy().view(arr.dtype)[:, 0]
+
+    cropped = run(data)
+    cropped_mask = run(data_mask) if data_mask is not None else None
+    if verbose:
+        print("**** New data shape is: {}".format(cropped.shape))
+        print("### END OV-CROP ###")
+    if data_mask is not None:
+        return cropped, cropped_mask, coords
+    return cropped, coords
+
+
+def merge_data_with_overlap(data, original_shape, data_mask=None, overlap=(0, 0), padding=(0, 0), verbose=True):
+    """Drop-in for biapy.data.data_2D_manipulation.merge_data_with_overlap (bit-exact, deterministic)."""
+    if data_mask is not None:
+        if data.shape[:-1] != data_mask.shape[:-1]:
+            raise ValueError("data and data_mask shapes mismatch: {} vs {}".format(data.shape[:-1], data_mask.shape[:-1]))
+    for i, p in enumerate(padding):
+        if p >= data.shape[i + 1] // 2:
+            raise ValueError(f"'Padding' cannot be greater than half of 'data' shape. Max value for this {data.shape} input shape is "
+                             f"{(data.shape[1] // 2) - 1, (data.shape[2] // 2) - 1}")
+    if (overlap[0] >= 1 or overlap[0] < 0) or (overlap[1] >= 1 or overlap[1] < 0):
+        raise ValueError("'overlap' values must be floats between range [0, 1)")
+    if verbose:
+        print("### MERGE-OV-CROP ###")
+        print(f"Merging {data.shape} images into {original_shape} with smooth blending . . .")
+        print(f"Overlap selected: {overlap}")
+        print(f"Padding: {padding}")
+    dev = _device()
+    plan = MergePlan(original_shape[:3], (1, data.shape[1], data.shape[2]), (0.0, overlap[0], overlap[1]), (0, padding[0], padding[1]), dev)
+    if plan.n_patches != data.shape[0]:
+        raise ValueError(f"expected {plan.n_patches} patches for images {tuple(original_shape)}, got {data.shape[0]}")
+
+    def run(arr: np.ndarray) -> np.ndarray:
+        if arr.dtype not in _MERGE_DT:
+            raise ValueError(f"dtype {arr.dtype} is not supported by the device merge (float32, float16, uint8)")
+        t = torch.from_numpy(np.ascontiguousarray(arr[:, None])).to(dev)
+        return merge_device(t, plan).cpu().numpy()
+
+    merged = run(data)
+    if verbose:
+        print(f"**** New data shape is: {merged.shape}")
+        print("### END MERGE-OV-CROP ###")
+    if data_mask is not None:
+        return merged, run(data_mask)
+    return merged

@@ -174,3 +174,24 @@ def merge(data: np.ndarray, orig_vol_shape, data_mask: Optional[np.ndarray] = No
     if acc_mask is not None:
         return merged, np.true_divide(acc_mask, wsum + 1e-18).astype(data_mask.dtype)
     return merged
+
+
+# ---------------------------------------------------------------------------------------------------
+# 2D tiling (biapy/data/data_2D_manipulation.py:54-533)
+# ---------------------------------------------------------------------------------------------------
+# The 2D functions walk (image, y, x) with the SAME per-axis grid arithmetic (:194-211 crop, :466-483 merge), the same taper
+# (:342-351) and the same fp32 blend (:497-516) as the 3D ones; an image stack (N,Y,X,C) is therefore a volume whose z axis
+# has patch size 1, no overlap and no padding.  That embedding is pinned against the reference's own 2D outputs in
+# tests/golden/tiling2d_golden.npz (tests/test_oracle_golden.py::test_tiling2d_*).
+def crop2d(data: np.ndarray, crop_shape, overlap=(0, 0), padding=(0, 0), pad_type="reflect"):
+    """Returns (patches (n,Py,Px,C), coords (n,4) = y0,y1,x0,x1) in the reference's (image, y, x) order."""
+    if data.ndim != 4:
+        raise ValueError("data expected to be 4 dimensional, given {}".format(data.shape))
+    p, c = crop(data, (1, crop_shape[0], crop_shape[1], data.shape[-1]), (0.0, overlap[0], overlap[1]), (0, padding[0], padding[1]), pad_type)
+    return p[:, 0], c[:, 2:]
+
+
+def merge2d(data: np.ndarray, original_shape, data_mask: Optional[np.ndarray] = None, overlap=(0, 0), padding=(0, 0)):
+    """(n,Py,Px,C) patches -> (N,Y,X,C) images (+ mask)."""
+    dm = None if data_mask is None else data_mask[:, None]
+    return merge(data[:, None], tuple(original_shape), dm, (0.0, overlap[0], overlap[1]), (0, padding[0], padding[1]))

@@ -115,6 +115,38 @@ def tiling_fixtures():
     print("tiling_golden.npz:", len(out), "arrays")
 
 
+def tiling2d_fixtures():
+    """2D crop / merge (data_2D_manipulation.py:54-533): the reference's outputs on seeded inputs."""
+    d2 = shim.load("biapy.data.data_2D_manipulation")
+    out = {}
+    cases = {
+        "t256": ((2, 300, 280, 1), (256, 256, 1), (0.0, 0.0), (0, 0), "reflect"),
+        "ov": ((3, 70, 90, 2), (32, 32, 2), (0.5, 0.25), (4, 2), "reflect"),
+        "zeros": ((2, 64, 50, 1), (24, 40, 1), (0.3, 0.0), (3, 6), "zeros"),
+        "fit": ((1, 48, 48, 1), (48, 48, 1), (0.5, 0.5), (0, 0), "reflect"),
+    }
+    for seed, (name, (dshape, cshape, ov, pad, pad_type)) in enumerate(cases.items()):
+        rs = np.random.RandomState(3000 + seed)
+        data = rs.rand(*dshape).astype(np.float32)
+        mask = np.array([0, 1, 2, 3, 7, 255], dtype=np.uint8)[rs.randint(0, 6, size=tuple(dshape[:3]) + (1,))]
+        with quiet():
+            p, pm, cc = d2.crop_data_with_overlap(data, cshape, data_mask=mask, overlap=ov, padding=pad, pad_type=pad_type)
+            pred = np.random.RandomState(4000 + seed).rand(*p.shape).astype(np.float32)
+            merged, merged_mask = d2.merge_data_with_overlap(pred, dshape, data_mask=pm, overlap=ov, padding=pad)
+        out[f"{name}/args"] = np.array(list(dshape) + list(cshape) + list(pad), dtype=np.int64)
+        out[f"{name}/overlap"] = np.array(ov, dtype=np.float64)
+        out[f"{name}/pad_type"] = np.array(pad_type)
+        out[f"{name}/seed"] = np.array(seed)
+        out[f"{name}/coords"] = np.array([[c.y_start, c.y_end, c.x_start, c.x_end] for c in cc], dtype=np.int64)
+        out[f"{name}/patches_crc"] = np.array([int(np.frombuffer(p.tobytes(), dtype=np.uint8).astype(np.uint64).sum())])
+        out[f"{name}/patch_last"] = p[-1]
+        out[f"{name}/mask_patch_last"] = pm[-1]
+        out[f"{name}/merged"] = merged
+        out[f"{name}/merged_mask"] = merged_mask
+    np.savez_compressed(os.path.join(HERE, "tiling2d_golden.npz"), **out)
+    print("tiling2d_golden.npz:", len(out), "arrays")
+
+
 def resunet_fixtures():
     rmod = shim.load("biapy.models.resunet")
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
@@ -193,5 +225,10 @@ def resunet_fixtures():
 
 
 if __name__ == "__main__":
-    tiling_fixtures()
-    resunet_fixtures()
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet"]
+    if "tiling" in which:
+        tiling_fixtures()
+    if "tiling2d" in which:
+        tiling2d_fixtures()
+    if "resunet" in which:
+        resunet_fixtures()

@@ -221,3 +221,26 @@ def test_segmentation_losses_match_reference_formulas():
     assert abs(losses.hard_dice(z.detach(), t).item() - net_oracle.dice(p.detach().float(), tr.float())) < 1e-6
     with pytest.raises(NotImplementedError):
         losses.BCEWithLogitsLoss()(torch.zeros(1, 3, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["t256", "ov", "zeros", "fit"])
+def test_tiling2d_dropins_bit_exact(tiling2d_golden, name):
+    """biapy_amd.tiling.crop_data_with_overlap / merge_data_with_overlap vs the reference's 2D outputs (row U of SURVEY 8a)."""
+    import numpy as np
+
+    from biapy_amd import tiling
+    from test_oracle_golden import _case2d
+
+    g = tiling2d_golden
+    data, mask, dshape, cshape, ov, pad, pad_type, seed = _case2d(g, name)
+    p, pm, cc = tiling.crop_data_with_overlap(data, cshape, data_mask=mask, overlap=ov, padding=pad, verbose=False, pad_type=pad_type)
+    got = np.array([[c.y_start, c.y_end, c.x_start, c.x_end] for c in cc], dtype=np.int64)
+    np.testing.assert_array_equal(got, g[f"{name}/coords"])
+    assert int(np.frombuffer(p.tobytes(), dtype=np.uint8).astype(np.uint64).sum()) == int(g[f"{name}/patches_crc"][0])
+    np.testing.assert_array_equal(p[-1], g[f"{name}/patch_last"])
+    np.testing.assert_array_equal(pm[-1], g[f"{name}/mask_patch_last"])
+    pred = np.random.RandomState(4000 + seed).rand(*p.shape).astype(np.float32)
+    merged, merged_mask = tiling.merge_data_with_overlap(pred, dshape, data_mask=pm, overlap=ov, padding=pad, verbose=False)
+    np.testing.assert_array_equal(merged.view(np.uint32), g[f"{name}/merged"].view(np.uint32))
+    np.testing.assert_array_equal(merged_mask, g[f"{name}/merged_mask"])

@@ -120,3 +120,32 @@ def test_state_dict_schema_cfg2(resunet_golden):
 
 def test_flop_count_matches_baseline():
     assert net_oracle.count_flops_forward(1, [16, 32, 64, 128, 256], (128, 128, 128)) == 303734718464
+
+
+def _case2d(g, name):
+    a = g[f"{name}/args"]
+    dshape, cshape, pad = tuple(int(v) for v in a[:4]), tuple(int(v) for v in a[4:7]), tuple(int(v) for v in a[7:9])
+    seed = int(g[f"{name}/seed"])
+    rs = np.random.RandomState(3000 + seed)
+    data = rs.rand(*dshape).astype(np.float32)
+    mask = np.array([0, 1, 2, 3, 7, 255], dtype=np.uint8)[rs.randint(0, 6, size=tuple(dshape[:3]) + (1,))]
+    return data, mask, dshape, cshape, tuple(g[f"{name}/overlap"]), pad, str(g[f"{name}/pad_type"]), seed
+
+
+@pytest.mark.parametrize("name", ["t256", "ov", "zeros", "fit"])
+def test_tiling2d_oracle_matches_reference(tiling2d_golden, name):
+    """2D crop / merge (data_2D_manipulation.py:54-533) restated through the z = image-index embedding: bit-exact."""
+    from oracle import tiling_oracle as T
+
+    g = tiling2d_golden
+    data, mask, dshape, cshape, ov, pad, pad_type, seed = _case2d(g, name)
+    p, cc = T.crop2d(data, cshape, ov, pad, pad_type)
+    pm, _ = T.crop2d(mask, cshape[:2] + (1,), ov, pad, pad_type)
+    np.testing.assert_array_equal(cc, g[f"{name}/coords"])
+    assert int(np.frombuffer(p.tobytes(), dtype=np.uint8).astype(np.uint64).sum()) == int(g[f"{name}/patches_crc"][0])
+    np.testing.assert_array_equal(p[-1], g[f"{name}/patch_last"])
+    np.testing.assert_array_equal(pm[-1], g[f"{name}/mask_patch_last"])
+    pred = np.random.RandomState(4000 + seed).rand(*p.shape).astype(np.float32)
+    merged, merged_mask = T.merge2d(pred, dshape, pm, ov, pad)
+    np.testing.assert_array_equal(merged.view(np.uint32), g[f"{name}/merged"].view(np.uint32))
+    np.testing.assert_array_equal(merged_mask, g[f"{name}/merged_mask"])
