@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libbiapy_amd.so")
 
 F32, BF16, F16, U8 = 0, 1, 2, 3
 ACT = {"none": 0, "linear": 0, "elu": 1, "relu": 2, "silu": 3}
-PK_K3, PK_K3_T, PK_K1, PK_DENSE, PK_DENSE_T, PK_CT, PK_CT_T = range(7)
+PK_K3, PK_K3_T, PK_K1, PK_DENSE, PK_DENSE_T, PK_CT, PK_CT_T, PK_CT4, PK_CT4_T = range(9)
 
 
 class AxisGrid(C.Structure):
@@ -53,20 +53,20 @@ _SIGS = {
     "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
     "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_conv3d_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
-    "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i], _i64),
+    "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
-    "bpx_convT3d_k2s2_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
-    "bpx_convT3d_stats_tiles": ([_i, _i, _i], _i),
-    "bpx_convT3d_k2s2_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp], _i),
-    "bpx_convT3d_k2s2_wgrad": ([_i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
+    "bpx_convT3d_k2s2_fwd": ([_i, _i, _i, _i, _i, _i, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
+    "bpx_convT3d_stats_tiles": ([_i, _i, _i, _i], _i),
+    "bpx_convT3d_k2s2_dgrad": ([_i, _i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp], _i),
+    "bpx_convT3d_k2s2_wgrad": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_norm_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _f, _i, _vp, _i, _i, _vp], _i),
     "bpx_tensor_stats": ([_i, _i, _i64, Tensor, _vp, _vp], _i),
     "bpx_tensor_stats_tiles": ([_i64], _i),
     "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_norm_bwd_apply": ([_i, _i, _i64, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
-    "bpx_maxpool3d_fwd": ([_i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp], _i),
-    "bpx_maxpool3d_stats_tiles": ([_i, _i, _i, _i, _i], _i),
-    "bpx_maxpool3d_bwd": ([_i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp], _i),
+    "bpx_maxpool3d_fwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp], _i),
+    "bpx_maxpool3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
+    "bpx_maxpool3d_bwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp], _i),
     "bpx_head_fwd": ([_i, _i64, _i, Tensor, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp], _i),
     "bpx_head_bwd": ([_i, _i64, _i, Tensor, _vp, _i, _vp, _i64, _i64, Tensor, _vp, _vp, _vp], _i),
     "bpx_conv3d_c1_fwd": ([_i, _i, _i, _i, _i, _vp, _vp, _vp, Tensor, _vp, _vp], _i),

@@ -507,7 +507,7 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
   p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
-  int rc = use_lean(dtype, p) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
+  int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_FWD, p, c, (hipStream_t)stream)
                                   : g_use_ws == 1 ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
                                : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
@@ -534,7 +534,7 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.y = g.ptr; p.y_ld = g.ld; p.Cout = g.C; p.part = t_norm_d ? red_part_d : nullptr;
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
-  int rc = use_lean(dtype, p) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
+  int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_DGRAD, p, c, (hipStream_t)stream)
                                   : g_use_ws == 1 ? launch_conv3_ws(EPI_DGRAD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream))
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);

@@ -190,12 +190,12 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict
 constexpr int POOL_IPT = 4;  // items (output voxel x 16-byte channel group) per thread
 
 template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int C, int D, int H, int W,
-                                   int tiles, float* __restrict__ part) {
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int C, int D, int H, int W, int sz,
+                                   int tiles, float* __restrict__ part) {  // window (sz,2,2): sz = z_down of the level (1 or 2)
   constexpr int KPL = ElemTraits<T>::KPL;
   extern __shared__ float red[];  // [blockDim][2*KPL]
   const int G = C / KPL;
-  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int Do = D / sz, Ho = H / 2, Wo = W / 2;
   const int64_t items = (int64_t)Do * Ho * Wo * G;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int cg = threadIdx.x % G;
@@ -212,7 +212,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restr
     for (int e = 0; e < KPL; ++e) m[e] = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      size_t vox = (((size_t)n * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
+      if (k >= 4 * sz) break;
+      size_t vox = (((size_t)n * D + sz * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
       u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL);
       float f[KPL];
       unpack16<T>(v, f);
@@ -241,10 +242,10 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restr
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
                                                           const T* __restrict__ addend, int a_ld, T* __restrict__ dx, int dx_ld, int C,
-                                                          int D, int H, int W, int N) {
+                                                          int D, int H, int W, int sz, int N) {
   constexpr int KPL = ElemTraits<T>::KPL;
   const int G = C / KPL;
-  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int Do = D / sz, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int cg = (int)(i % G);
@@ -258,7 +259,8 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
     size_t voxk[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      voxk[k] = (((size_t)n * D + 2 * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
+      if (k >= 4 * sz) break;
+      voxk[k] = (((size_t)n * D + sz * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
       u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + voxk[k] * x_ld + cg * KPL);
       unpack16<T>(v, f[k]);
 #pragma unroll
@@ -269,6 +271,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + (size_t)ov * dy_ld + cg * KPL), d);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      if (k >= 4 * sz) break;
       float o[KPL];
       if (addend) unpack16<T>(*reinterpret_cast<const u32x4_t*>(addend + voxk[k] * a_ld + cg * KPL), o);
       else {
@@ -699,7 +702,7 @@ __global__ void __launch_bounds__(256) rank1_wgrad_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // weight packing (see DESIGN.md "packed weights")
 // ------------------------------------------------------------------------------------------------
-enum { PK_K3 = 0, PK_K3_T = 1, PK_K1 = 2, PK_DENSE = 3, PK_DENSE_T = 4, PK_CT = 5, PK_CT_T = 6 };
+enum { PK_K3 = 0, PK_K3_T = 1, PK_K1 = 2, PK_DENSE = 3, PK_DENSE_T = 4, PK_CT = 5, PK_CT_T = 6, PK_CT4 = 7, PK_CT4_T = 8 };
 
 template <typename T>
 __device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int64_t total,
@@ -733,18 +736,20 @@ __device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __res
       int q = (int)(r / ncol);
       int kc = q * KPL + e;
       if (kc < K) v = (mode == PK_DENSE) ? w[(size_t)col * Cin + kc] : w[(size_t)kc * Cin + col];
-    } else if (mode == PK_CT) {  // ConvTranspose (Cin,Cout,8): columns = sub*Cout+co, K = Cin
-      const int ncol = 8 * Cout;
+    } else if (mode == PK_CT || mode == PK_CT4) {  // ConvTranspose (Cin,Cout,nsub): columns = sub*Cout+co, K = Cin
+      const int nsub = (mode == PK_CT) ? 8 : 4;           // kernel (2,2,2) or (1,2,2)
+      const int ncol = nsub * Cout;
       int col = (int)(r % ncol);
       int q = (int)(r / ncol);
       int kc = q * KPL + e;
       int sub = col / Cout, co = col % Cout;
-      if (kc < Cin) v = w[((size_t)kc * Cout + co) * 8 + sub];
-    } else {  // PK_CT_T: columns = ci, K = sub*Cout+co
+      if (kc < Cin) v = w[((size_t)kc * Cout + co) * nsub + sub];
+    } else {  // PK_CT_T / PK_CT4_T: columns = ci, K = sub*Cout+co
+      const int nsub = (mode == PK_CT_T) ? 8 : 4;
       int col = (int)(r % Cin);
       int q = (int)(r / Cin);
       int kc = q * KPL + e;
-      if (kc < 8 * Cout) { int sub = kc / Cout, co = kc % Cout; v = w[((size_t)col * Cout + co) * 8 + sub]; }
+      if (kc < nsub * Cout) { int sub = kc / Cout, co = kc % Cout; v = w[((size_t)col * Cout + co) * nsub + sub]; }
     }
     ElemTraits<T>::st(out + i, v);
   }
@@ -776,6 +781,8 @@ inline int64_t packed_elems(int mode, int Cin, int Cout, int dtype) {
     case PK_DENSE_T: return r4(Cout / KPL) * Cin * KPL;
     case PK_CT: return r4(Cin / KPL) * 8 * Cout * KPL;
     case PK_CT_T: return r4((int64_t)8 * Cout / KPL) * Cin * KPL;
+    case PK_CT4: return r4(Cin / KPL) * 4 * Cout * KPL;
+    case PK_CT4_T: return r4((int64_t)4 * Cout / KPL) * Cin * KPL;
   }
   return -1;
 }
@@ -953,49 +960,51 @@ extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g
 
 static int pool_block(int C, int kpl) { int G = C / kpl; return (256 / G) * G; }
 
-extern "C" int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int C) {
+extern "C" int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int sz, int C) {
   int kpl = dtype == BPX_BF16 ? 8 : 4;
   int bd = pool_block(C, kpl);
-  int64_t items = (int64_t)(D / 2) * (H / 2) * (W / 2) * (C / kpl);
+  int64_t items = (int64_t)(D / (sz == 1 ? 1 : 2)) * (H / 2) * (W / 2) * (C / kpl);
   return (int)cdiv64(items, (int64_t)bd * POOL_IPT);
 }
 
-extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor y, float* stats_part_d,
+extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor y, float* stats_part_d,
                                  bpx_stream_t stream) {
   const char* fn = "bpx_maxpool3d_fwd";
   BPX_CHECK(x.ptr && y.ptr, "%s: null pointer", fn);
-  BPX_CHECK(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "%s: extents must be even (got %d,%d,%d)", fn, D, H, W);
+  BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
+  BPX_CHECK(D % sz == 0 && H % 2 == 0 && W % 2 == 0, "%s: extents must be divisible by the window (%d,2,2) (got %d,%d,%d)", fn, sz, D, H, W);
   BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
   int kpl = dtype == BPX_BF16 ? 8 : 4;
   int bd = pool_block(x.C, kpl);
-  int tiles = bpx_maxpool3d_stats_tiles(dtype, D, H, W, x.C);
+  int tiles = bpx_maxpool3d_stats_tiles(dtype, D, H, W, sz, x.C);
   dim3 grid((unsigned)tiles, (unsigned)N);
   size_t shm = (size_t)bd * 2 * kpl * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
-    maxpool_fwd_kernel<uint16_t><<<grid, bd, shm, s>>>((const uint16_t*)x.ptr, x.ld, (uint16_t*)y.ptr, y.ld, x.C, D, H, W, tiles, stats_part_d);
+    maxpool_fwd_kernel<uint16_t><<<grid, bd, shm, s>>>((const uint16_t*)x.ptr, x.ld, (uint16_t*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
   else if (dtype == BPX_F32)
-    maxpool_fwd_kernel<float><<<grid, bd, shm, s>>>((const float*)x.ptr, x.ld, (float*)y.ptr, y.ld, x.C, D, H, W, tiles, stats_part_d);
+    maxpool_fwd_kernel<float><<<grid, bd, shm, s>>>((const float*)x.ptr, x.ld, (float*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
 
-extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy, bpx_tensor addend, bpx_tensor dx,
+extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, bpx_tensor addend, bpx_tensor dx,
                                  bpx_stream_t stream) {
   const char* fn = "bpx_maxpool3d_bwd";
   BPX_CHECK(x.ptr && dy.ptr && dx.ptr, "%s: null pointer", fn);
+  BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   BPX_CHECK(x.C == dy.C && x.C == dx.C && x.C % 16 == 0, "%s: channel mismatch", fn);
   int kpl = dtype == BPX_BF16 ? 8 : 4;
-  int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (x.C / kpl);
+  int64_t total = (int64_t)N * (D / sz) * (H / 2) * (W / 2) * (x.C / kpl);
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
     maxpool_bwd_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, (const uint16_t*)dy.ptr, dy.ld,
-                                                                 (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, N);
+                                                                 (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
   else if (dtype == BPX_F32)
     maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)x.ptr, x.ld, (const float*)dy.ptr, dy.ld, (const float*)addend.ptr,
-                                                              addend.ld, (float*)dx.ptr, dx.ld, x.C, D, H, W, N);
+                                                              addend.ld, (float*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -1093,7 +1102,7 @@ extern "C" int64_t bpx_packed_weight_elems(int mode, int Cin, int Cout, int dtyp
 extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, int dtype, void* packed_d, bpx_stream_t stream) {
   const char* fn = "bpx_pack_weight";
   BPX_CHECK(w_d && packed_d, "%s: null pointer", fn);
-  BPX_CHECK(mode >= PK_K3 && mode <= PK_CT_T, "%s: bad mode %d", fn, mode);
+  BPX_CHECK(mode >= PK_K3 && mode <= PK_CT4_T, "%s: bad mode %d", fn, mode);
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   if (mode <= PK_K1) BPX_CHECK(Cin % 16 == 0 && Cout % 16 == 0, "%s: Cin/Cout must be multiples of 16", fn);
   if (mode == PK_K3_T) BPX_CHECK(Cout % 16 == 0, "%s: Cout must be a multiple of 16", fn);
@@ -1116,7 +1125,7 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
     for (int k = 0; k < n; ++k) {
       const bpx_pack_job& j = jobs[base + k];
       BPX_CHECK(j.w_d && j.packed_d, "%s: job %d has a null pointer", fn, base + k);
-      BPX_CHECK(j.mode >= PK_K3 && j.mode <= PK_CT_T, "%s: job %d: unknown mode %d", fn, base + k, j.mode);
+      BPX_CHECK(j.mode >= PK_K3 && j.mode <= PK_CT4_T, "%s: job %d: unknown mode %d", fn, base + k, j.mode);
       BPX_CHECK(j.Cin >= 1 && j.Cout >= 1, "%s: job %d: bad channel counts", fn, base + k);
       if (j.mode == PK_K3 || j.mode == PK_K1) BPX_CHECK(j.Cin % 16 == 0, "%s: job %d: Cin must be a multiple of 16", fn, base + k);
       if (j.mode == PK_K3_T) BPX_CHECK(j.Cout % 16 == 0, "%s: job %d: Cout must be a multiple of 16", fn, base + k);

@@ -64,6 +64,7 @@ template <> __device__ __forceinline__ void storeq<uint16_t, 4>(uint16_t* p, con
 
 struct PwParams {
   int N, D, H, W;        // voxel grid of v (the low-res grid for the transposed conv)
+  int sz;                // transposed conv: kernel = stride = (sz,2,2), sz = 1 or 2 -> 4*sz sub-positions, sub = (a*2+b)*2+c
   int64_t vps;           // voxels per sample = D*H*W
   const void* x; int x_ld; int K;          // K = reduction length in channels (8*Cout for CONVTD)
   int Csub;              // CONVT: Cout (columns per sub-position); CONVTD: channels per sub-position of dy
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     int64_t vv = valid[ms] ? v[ms] : 0;
     if (MODE == PW_CONVTD) {
       int xw = (int)(vv % p.W), yh = (int)((vv / p.W) % p.H), zd = (int)(vv / ((int64_t)p.W * p.H));
-      abase[ms] = ((((size_t)n * 2 * p.D + 2 * zd) * 2 * p.H + 2 * yh) * 2 * p.W + 2 * xw) * (size_t)p.x_ld;
+      abase[ms] = ((((size_t)n * p.sz * p.D + p.sz * zd) * 2 * p.H + 2 * yh) * 2 * p.W + 2 * xw) * (size_t)p.x_ld;
     } else {
       abase[ms] = ((size_t)n * p.vps + vv) * (size_t)p.x_ld;
     }
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     if (MODE == PW_CONVT) {
       int xw = (int)(v[ms] % p.W), yh = (int)((v[ms] / p.W) % p.H), zd = (int)(v[ms] / ((int64_t)p.W * p.H));
       int a = (sub >> 2) & 1, b = (sub >> 1) & 1, cc = sub & 1;
-      ovox = (((size_t)n * 2 * p.D + 2 * zd + a) * 2 * p.H + 2 * yh + b) * 2 * p.W + 2 * xw + cc;
+      ovox = (((size_t)n * p.sz * p.D + p.sz * zd + a) * 2 * p.H + 2 * yh + b) * 2 * p.W + 2 * xw + cc;
     } else {
       ovox = (size_t)n * p.vps + v[ms];
     }
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
                 red[(3 * NS * 16 + c) * 2 + k];
       int col = col_base + c, sub = col / p.Csub, co = col % p.Csub;
-      p.part[((((size_t)n * p.mblocks + mb) * 8 + sub) * 2 + k) * p.Csub + co] = a;
+      p.part[((((size_t)n * p.mblocks + mb) * (4 * p.sz) + sub) * 2 + k) * p.Csub + co] = a;
     }
   }
 }
@@ -255,7 +256,7 @@ int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
 
 }  // namespace
 
-extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS) * 8; }
+extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS) * 4 * (sz == 1 ? 1 : 2); }
 
 extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                                bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
@@ -279,17 +280,18 @@ extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, cons
   return 0;
 }
 
-extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                                     bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
   const char* fn = "bpx_convT3d_k2s2_fwd";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   int es = (int)dtype_size(dtype);
   if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
   BPX_CHECK(w_packed_d, "%s: weights null", fn);
   PwParams p{};
-  p.N = N; p.D = D; p.H = H; p.W = W; p.vps = (int64_t)D * H * W;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.sz = sz; p.vps = (int64_t)D * H * W;
   p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
-  p.y = y.ptr; p.y_ld = y.ld; p.Ncols = 8 * y.C; p.Csub = y.C; p.part = stats_part_d;
+  p.y = y.ptr; p.y_ld = y.ld; p.Ncols = 4 * sz * y.C; p.Csub = y.C; p.part = stats_part_d;
   int ns = pw_ns(y.C);
   if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream);
   else launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream);
@@ -297,16 +299,17 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, bpx_t
   return 0;
 }
 
-extern "C" int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor dx,
+extern "C" int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, int sz, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor dx,
                                       bpx_stream_t stream) {
   const char* fn = "bpx_convT3d_k2s2_dgrad";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   int es = (int)dtype_size(dtype);
   if (chk(fn, "dy", dy, es) || chk(fn, "dx", dx, es)) return 1;
   BPX_CHECK(w_packed_T_d, "%s: weights null", fn);
   PwParams p{};
-  p.N = N; p.D = D; p.H = H; p.W = W; p.vps = (int64_t)D * H * W;
-  p.x = dy.ptr; p.x_ld = dy.ld; p.K = 8 * dy.C; p.Csub = dy.C; p.wp = w_packed_T_d;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.sz = sz; p.vps = (int64_t)D * H * W;
+  p.x = dy.ptr; p.x_ld = dy.ld; p.K = 4 * sz * dy.C; p.Csub = dy.C; p.wp = w_packed_T_d;
   p.y = dx.ptr; p.y_ld = dx.ld; p.Ncols = dx.C;
   int ns = pw_ns(dx.C);
   if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONVTD>(p, ns, (hipStream_t)stream);

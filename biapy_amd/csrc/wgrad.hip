@@ -29,6 +29,7 @@ struct WgradParams {
   int N, D, H, W;          // logical voxel grid of the reduction
   const void* x; int x_ld; int Cin; const bpx_norm_rec* in_norm; int act;
   const void* dy; int dy_ld; int Cout; int dy_vs; int dy_oz, dy_oy, dy_ox;  // dy voxel = vs*v + off (ConvTranspose)
+  int dy_vz;               // z stride of that mapping (0 = same as dy_vs): kernel (1,2,2) has vz = 1
   float* part;                                   // [groups][taps][Cin][Cout] per-block partial sums (workspace)
   float* dw; int64_t si, sj, st; int64_t off;   // final dW index = ci*si + co*sj + tap*st + off (reduce kernel)
   float* db;
@@ -181,7 +182,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   u32x4_t pa[NPA], pg[NPG];
   uint32_t va = 0;  // bit u: piece u of the activation halo is inside the volume (gets the prologue)
   float psc[KPL], psh[KPL];
-  const int Dp = p.D * p.dy_vs, Hp = p.H * p.dy_vs, Wp = p.W * p.dy_vs;
+  const int vz = p.dy_vz ? p.dy_vz : p.dy_vs;
+  const int Dp = p.D * vz, Hp = p.H * p.dy_vs, Wp = p.W * p.dy_vs;
   int n_cur = -1;
 
   auto issue_loads = [&](int tt) {
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       const int gz = z0 + t / (TY * TX), gy = y0 + (t / TX) % TY, gx = x0 + t % TX;
       pg[u] = u32x4_t{0u, 0u, 0u, 0u};
       if (idx < TV * PPVG && gz < p.D && gy < p.H && gx < p.W) {
-        const size_t vox = (((size_t)n * Dp + (gz * p.dy_vs + p.dy_oz)) * Hp + (gy * p.dy_vs + p.dy_oy)) * Wp + (gx * p.dy_vs + p.dy_ox);
+        const size_t vox = (((size_t)n * Dp + (gz * vz + p.dy_oz)) * Hp + (gy * p.dy_vs + p.dy_oy)) * Wp + (gx * p.dy_vs + p.dy_ox);
         pg[u] = *reinterpret_cast<const u32x4_t*>(gin + vox * (size_t)p.dy_ld + co_base + subG * KPL);
       }
     }
@@ -546,14 +548,15 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const Wg
 // re-reads x eight times with a stride-2 gather of dy; here a workgroup stages a 2x4x16 tile of x and the matching
 // CONTIGUOUS 4x8x32 block of dy (de-interleaved into 8 per-sub planes while writing LDS), wave w owns subs 2w and 2w+1,
 // and the x fragment of a K-chunk is shared by all subs.  Partials [group][sub][Cin][Cout] -> wgrad_reduce_kernel.
-template <int NS>
+template <int NS, int SZ>   // SZ = z extent of the kernel = z stride (1 or 2): 4*SZ sub-positions, sub = (a*2 + b)*2 + c
 __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const WgradParams p) {
   using T = uint16_t;
   constexpr int TZ = 2, TY = 4, TX = 16, TV = TZ * TY * TX;       // x tile
-  constexpr int GV = 8 * TV;                                      // dy voxels of the tile
+  constexpr int NSUB = 4 * SZ, SPW = NSUB / 4;                    // sub-positions; per wave
+  constexpr int GV = NSUB * TV;                                   // dy voxels of the tile
   constexpr int KPL = 8, VBA = 32, CB = 16 * NS, VBG = CB * 2, PPVG = 2 * NS;
   constexpr int NKC = TV / 32;
-  constexpr int NPG = GV * PPVG / 256, BATCH = 8;
+  constexpr int NPG = GV * PPVG / 256, BATCH = NPG < 8 ? NPG : 8;
   static_assert(NPG % BATCH == 0 && 256 % PPVG == 0, "staging plan");
   __shared__ __attribute__((aligned(16))) unsigned char smem[TV * VBA + GV * VBG];
   unsigned char* sA = smem;
@@ -570,9 +573,9 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   const int co_base = cbi * CB;
   if (grp >= p.groups) return;
 
-  f32x4_t acc[2][NS];
+  f32x4_t acc[SPW][NS];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < SPW; ++a)
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) acc[a][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum[KPL];
@@ -588,14 +591,14 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   const int subG = tid % PPVG, qlane = tid / PPVG;                 // dy piece u: block voxel q = u*(256/PPVG) + qlane
   const int trl = (i >> 2), trc = (i & 3) * 8;
   const int a_base = (g * 8 + trl) * VBA + trc;
-  const int g_base = ((2 * wave) * TV + g * 8 + trl) * VBG + trc;  // sub 2w; sub 2w+1 is TV*VBG further
+  const int g_base = ((SPW * wave) * TV + g * 8 + trl) * VBG + trc;  // first sub of this wave; the next one is TV*VBG further
 
   for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
     const int n = tt / p.tilesPerSample, tile = tt - n * p.tilesPerSample;
     const int z0 = (tile / (p.tilesX * p.tilesY)) * TZ, y0 = ((tile / p.tilesX) % p.tilesY) * TY, x0 = (tile % p.tilesX) * TX;
     const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
     const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
-    const uint32_t base_g = (uint32_t)(((n * 2 * D + 2 * z0) * 2 * H + 2 * y0) * 2 * W + 2 * x0) * (uint32_t)p.dy_ld * 2u;
+    const uint32_t base_g = (uint32_t)(((n * SZ * D + SZ * z0) * 2 * H + 2 * y0) * 2 * W + 2 * x0) * (uint32_t)p.dy_ld * 2u;
 
     u32x4_t pa = u32x4_t{0u, 0u, 0u, 0u};
     if (full || (z0 + taz < D && y0 + tay < H && x0 + tax < W)) pa = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a));
@@ -606,17 +609,17 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
       u32x4_t pg[BATCH];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int q = (b0 + u) * (256 / PPVG) + qlane;             // voxel of the 4x8x32 dy block, x fastest
+        const int q = (b0 + u) * (256 / PPVG) + qlane;             // voxel of the (SZ*TZ)x8x32 dy block, x fastest
         const int X = q & 31, Y = (q >> 5) & 7, Z = q >> 8;
         pg[u] = u32x4_t{0u, 0u, 0u, 0u};
-        if (full || (2 * z0 + Z < 2 * D && 2 * y0 + Y < 2 * H && 2 * x0 + X < 2 * W))
+        if (full || (SZ * z0 + Z < SZ * D && 2 * y0 + Y < 2 * H && 2 * x0 + X < 2 * W))
           pg[u] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + (uint32_t)(((Z * 2 * H + Y) * 2 * W + X) * p.dy_ld + co_base + subG * KPL) * 2u));
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         const int q = (b0 + u) * (256 / PPVG) + qlane;
         const int X = q & 31, Y = (q >> 5) & 7, Z = q >> 8;
-        const int sub = ((Z & 1) << 2) | ((Y & 1) << 1) | (X & 1), v = (((Z >> 1) * TY + (Y >> 1)) * TX) + (X >> 1);
+        const int sub = ((SZ == 2 ? (Z & 1) : 0) << 2) | ((Y & 1) << 1) | (X & 1), v = (((SZ == 2 ? (Z >> 1) : Z) * TY + (Y >> 1)) * TX) + (X >> 1);
         *reinterpret_cast<u32x4_t*>(sG + (size_t)((sub * TV + v) * PPVG + subG) * 16) = pg[u];
         if (want_bias) {
 #pragma unroll
@@ -628,7 +631,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
 
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-      u32x4_t af, gf[2][NS];
+      u32x4_t af, gf[SPW][NS];
       {
         const unsigned char* q = sA + a_base + kc * 32 * VBA;
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
@@ -637,7 +640,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
         af = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < SPW; ++a)
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
           const unsigned char* q = sG + g_base + (a * TV + kc * 32) * VBG + ns * 32;
@@ -648,22 +651,22 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < SPW; ++a)
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
           acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[a][ns], 0, 0, 0);
     }
   }
 
-  float* pp = p.part + (size_t)grp * 8 * p.Cin * p.Cout;
+  float* pp = p.part + (size_t)grp * NSUB * p.Cin * p.Cout;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < SPW; ++a)
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = chunk * 16 + 4 * g + r, co = co_base + ns * 16 + i;
-        pp[((size_t)(2 * wave + a) * p.Cin + ci) * p.Cout + co] = acc[a][ns][r];
+        pp[((size_t)(SPW * wave + a) * p.Cin + ci) * p.Cout + co] = acc[a][ns][r];
       }
   if (want_bias) {  // every thread summed the 8 channels of its pieces: combine the 256/PPVG threads of a channel group
     __syncthreads();
@@ -681,14 +684,14 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
 }
 
 struct CtCfg { int ns, groups, totalTiles, tilesY, tilesX, tilesPerSample; };
-inline CtCfg pick_ct(int N, int D, int H, int W, int Cin, int Cout) {
+inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   CtCfg c;
   c.ns = (Cout % 32 == 0) ? 2 : 1;
   c.tilesY = cdiv(H, 4); c.tilesX = cdiv(W, 16);
   c.tilesPerSample = cdiv(D, 2) * c.tilesY * c.tilesX;
   c.totalTiles = N * c.tilesPerSample;
   const int nchunks = Cin / 16, nb = Cout / (16 * c.ns);
-  const int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / ((int64_t)8 * Cin * Cout));
+  const int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / ((int64_t)4 * sz * Cin * Cout));
   c.groups = (int)std::min<int64_t>(std::min<int64_t>(c.totalTiles, cap), std::max(1, cdiv(2048, nchunks * nb)));
   return c;
 }
@@ -819,10 +822,10 @@ extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Ci
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, taps, false);  // small tiles give the larger group count: an upper bound
   return (int64_t)c.groups * taps * Cin * Cout * 4;
 }
-extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);           // fp32: one launch per sub-position
-  CtCfg t = pick_ct(N, D, H, W, Cin, Cout);                      // bf16: single pass, [groups][8][Cin][Cout]
-  return std::max((int64_t)c.groups * Cin * Cout * 4, (int64_t)t.groups * 8 * Cin * Cout * 4);
+  CtCfg t = pick_ct(N, D, H, W, sz, Cin, Cout);                  // bf16: single pass, [groups][4*sz][Cin][Cout]
+  return std::max((int64_t)c.groups * Cin * Cout * 4, (int64_t)t.groups * 4 * sz * Cin * Cout * 4);
 }
 
 // test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 in the bf16 wgrad
@@ -850,15 +853,17 @@ extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   return run_wgrad(fn, dtype, p, taps, ws_d, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy, float* dw_d, float* db_d,
+extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, float* dw_d, float* db_d,
                                       void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
   const char* fn = "bpx_convT3d_k2s2_wgrad";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
+  const int nsub = 4 * sz;
   BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
-  if (dtype == BPX_BF16 && g_use_tr != 0 && (int64_t)N * D * H * W * 8 * std::max(x.ld, dy.ld) < (1ll << 31)) {
-    CtCfg c = pick_ct(N, D, H, W, x.C, dy.C);
-    const int64_t need = (int64_t)c.groups * 8 * x.C * dy.C * 4;
+  if (dtype == BPX_BF16 && g_use_tr != 0 && (int64_t)N * D * H * W * nsub * std::max(x.ld, dy.ld) < (1ll << 31)) {
+    CtCfg c = pick_ct(N, D, H, W, sz, x.C, dy.C);
+    const int64_t need = (int64_t)c.groups * nsub * x.C * dy.C * 4;
     BPX_CHECK(ws_d != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
@@ -869,20 +874,21 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx
     const int nchunks = x.C / 16, nb = dy.C / (16 * c.ns);
     dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
     hipStream_t s = (hipStream_t)stream;
-    if (c.ns == 2) wgrad_ct_kernel<2><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1><<<grid, 256, 0, s>>>(p);
+    if (sz == 2) { if (c.ns == 2) wgrad_ct_kernel<2, 2><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 2><<<grid, 256, 0, s>>>(p); }
+    else { if (c.ns == 2) wgrad_ct_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 1><<<grid, 256, 0, s>>>(p); }
     BPX_LAUNCH_CHECK(fn);
-    const int64_t total = (int64_t)8 * x.C * dy.C;   // (Cin, Cout, 2, 2, 2): index = ci*Cout*8 + co*8 + sub
-    wgrad_reduce_kernel<<<(int)cdiv64(total, 32), 256, 0, s>>>(p.part, c.groups, 8, x.C, dy.C, dw_d, (int64_t)dy.C * 8, 8, 1, 0);
+    const int64_t total = (int64_t)nsub * x.C * dy.C;   // (Cin, Cout, sz, 2, 2): index = ci*Cout*nsub + co*nsub + sub
+    wgrad_reduce_kernel<<<(int)cdiv64(total, 32), 256, 0, s>>>(p.part, c.groups, nsub, x.C, dy.C, dw_d, (int64_t)dy.C * nsub, nsub, 1, 0);
     BPX_LAUNCH_CHECK(fn);
     return 0;
   }
-  for (int sub = 0; sub < 8; ++sub) {
+  for (int sub = 0; sub < nsub; ++sub) {
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = nullptr; p.act = 0;
-    p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 2;
+    p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 2; p.dy_vz = sz;
     p.dy_oz = (sub >> 2) & 1; p.dy_oy = (sub >> 1) & 1; p.dy_ox = sub & 1;
-    p.dw = dw_d; p.si = (int64_t)dy.C * 8; p.sj = 8; p.st = 0; p.off = sub;  // (Cin,Cout,2,2,2)
+    p.dw = dw_d; p.si = (int64_t)dy.C * nsub; p.sj = nsub; p.st = 0; p.off = sub;  // (Cin,Cout,sz,2,2)
     p.db = db_d;  // every sub contributes its voxels to the bias gradient
     if (run_wgrad(fn, dtype, p, 1, ws_d, ws_bytes, (hipStream_t)stream)) return 1;
   }

@@ -38,9 +38,14 @@ class NetConfig:
     out_channels: Sequence[int] = (1,)
     activation: str = "elu"
     normalization: str = "in"
+    z_down: Optional[Sequence[int]] = None    # MODEL.Z_DOWN per level (1 or 2; None = 2 everywhere); YX_DOWN is always 2
 
     def __post_init__(self):
         fm = list(self.feature_maps)
+        zd = [2] * (len(fm) - 1) if self.z_down is None else [int(v) for v in list(self.z_down)[: len(fm) - 1]]
+        if len(zd) != len(fm) - 1 or any(v not in (1, 2) for v in zd):
+            raise NotImplementedError(f"z_down={self.z_down!r}: one value per level, each 1 or 2")
+        self.z_down = tuple(zd)
         if self.normalization != "in":
             raise NotImplementedError(f"normalization={self.normalization!r}: the MI355X engine implements 'in' (the reference default)")
         if self.activation not in L.ACT:
@@ -179,9 +184,9 @@ class ResUNetEngine:
         block("bottleneck", False, fm[Lv - 1], fm[Lv])
         for j, i in enumerate(range(Lv - 1, -1, -1)):
             cup = fm[i + 1]
-            plan.append((f"up_paths.0.{j}.up.weight", L.PK_CT, cup, cup))
+            plan.append((f"up_paths.0.{j}.up.weight", L.PK_CT if cfg.z_down[i] == 2 else L.PK_CT4, cup, cup))
             if train:
-                plan.append((f"up_paths.0.{j}.up.weight", L.PK_CT_T, cup, cup))
+                plan.append((f"up_paths.0.{j}.up.weight", L.PK_CT_T if cfg.z_down[i] == 2 else L.PK_CT4_T, cup, cup))
             block(f"up_paths.0.{j}.conv_block", False, cup + fm[i], fm[i])
         return plan
 
@@ -274,8 +279,11 @@ class ResUNetEngine:
         assert Cin == cfg.in_ch, f"expected {cfg.in_ch} input channels, got {Cin}"
         Lv = cfg.depth
         div = 2 ** Lv
-        if D0 % div or H0 % div or W0 % div:
-            raise ValueError(f"patch {D0, H0, W0} must be divisible by {div} (DATA.PATCH_SIZE rule, check_configuration.py:3156-3202)")
+        zdiv = 1
+        for v in cfg.z_down:
+            zdiv *= v
+        if D0 % zdiv or H0 % div or W0 % div:
+            raise ValueError(f"patch {D0, H0, W0} must be divisible by {(zdiv, div, div)} (DATA.PATCH_SIZE rule, check_configuration.py:3156-3202)")
         dev = x.device
         st = L.stream_ptr()
         fm = list(cfg.feature_maps)
@@ -296,7 +304,9 @@ class ResUNetEngine:
             else:
                 L.check(lib.bpx_cast(L.F32, xin.data_ptr(), L.BF16, x_ndhwc.data_ptr(), xin.numel(), st))
 
-        S = [(D0 >> i, H0 >> i, W0 >> i) for i in range(Lv + 1)]
+        S = [(D0, H0, W0)]
+        for i in range(Lv):
+            S.append((S[i][0] // cfg.z_down[i], S[i][1] // 2, S[i][2] // 2))
 
         def buf(i, C):
             return torch.empty((B,) + S[i] + (C,), dtype=T, device=dev)
@@ -316,9 +326,9 @@ class ResUNetEngine:
             # pool -> P_i (+ stats) and the pre-norm record of the next block
             pooled = buf(i + 1, fm[i])
             D, H, W = S[i]
-            ptiles = lib.bpx_maxpool3d_stats_tiles(self.dt, D, H, W, fm[i])
+            ptiles = lib.bpx_maxpool3d_stats_tiles(self.dt, D, H, W, cfg.z_down[i], fm[i])
             ppart = _Stats.alloc(B, ptiles, fm[i], dev)
-            L.check(lib.bpx_maxpool3d_fwd(self.dt, B, D, H, W, L.tview(cat[i], fm[i + 1], fm[i]), L.tview(pooled), ppart.data_ptr(), st))
+            L.check(lib.bpx_maxpool3d_fwd(self.dt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], fm[i + 1], fm[i]), L.tview(pooled), ppart.data_ptr(), st))
             nxt = "bottleneck" if i == Lv - 1 else f"down_path.{i + 1}"
             rec = _recs(B, fm[i], dev)
             _Stats.finalize(ppart, B, ptiles, fm[i], S[i + 1][0] * S[i + 1][1] * S[i + 1][2], P[f"{nxt}.block.0.weight"],
@@ -337,10 +347,11 @@ class ResUNetEngine:
             Cup = fm[i + 1]
             Dl, Hl, Wl = S[i + 1]
             wk, bk = f"up_paths.0.{j}.up.weight", f"up_paths.0.{j}.up.bias"
-            wp = self._pack(P[wk], L.PK_CT, Cup, Cup, cache_weights)
-            utiles = lib.bpx_convT3d_stats_tiles(Dl, Hl, Wl)
+            szl = cfg.z_down[i]
+            wp = self._pack(P[wk], L.PK_CT if szl == 2 else L.PK_CT4, Cup, Cup, cache_weights)
+            utiles = lib.bpx_convT3d_stats_tiles(Dl, Hl, Wl, szl)
             upart = _Stats.alloc(B, utiles, Cup, dev)
-            L.check(lib.bpx_convT3d_k2s2_fwd(self.dt, B, Dl, Hl, Wl, L.tview(dec_in), wp.data_ptr(), P[bk].data_ptr(),
+            L.check(lib.bpx_convT3d_k2s2_fwd(self.dt, B, Dl, Hl, Wl, szl, L.tview(dec_in), wp.data_ptr(), P[bk].data_ptr(),
                                              L.tview(cat[i], 0, Cup), upart.data_ptr(), st))
             Ccat = Cup + fm[i]
             pre = f"up_paths.0.{j}.conv_block"
@@ -354,7 +365,7 @@ class ResUNetEngine:
                        h=buf(i, fm[i]), out=buf(i, fm[i]), out_c0=0)
             self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=False)
             blocks.append(blk)
-            ups.append((wk, bk, dec_in, Cup, S[i + 1]))
+            ups.append((wk, bk, dec_in, Cup, S[i + 1], szl))
             dec_in = blk.out
         # ---------------- heads ----------------------------------------------------------------------
         n_out = sum(cfg.out_channels)
@@ -478,15 +489,15 @@ class ResUNetEngine:
             dcat[i] = torch.empty((B,) + S[i] + (Ccat,), dtype=T, device=dev)
             self._block_bwd(P, G, blk, B, dOut, img, st, None, L.tview(dcat[i]))
             # transposed conv backward: dUp = dcat[i][..., :Cup]
-            wk, bk, x_in, Cup, Sl = ups[j]
+            wk, bk, x_in, Cup, Sl, szl = ups[j]
             dUp = L.tview(dcat[i], 0, Cup)
-            wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, Sl[0], Sl[1], Sl[2], Cup, Cup)
+            wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, Sl[0], Sl[1], Sl[2], szl, Cup, Cup)
             ws = self._workspace(wsn, dev)
-            self._run_side(dev, lambda s_, x_in=x_in, dUp=dUp, wk=wk, bk=bk, Sl=Sl, ws=ws: L.check(lib.bpx_convT3d_k2s2_wgrad(
-                self.dt, B, Sl[0], Sl[1], Sl[2], L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), ws.data_ptr(), ws.numel(), s_)))
+            self._run_side(dev, lambda s_, x_in=x_in, dUp=dUp, wk=wk, bk=bk, Sl=Sl, ws=ws, szl=szl: L.check(lib.bpx_convT3d_k2s2_wgrad(
+                self.dt, B, Sl[0], Sl[1], Sl[2], szl, L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), ws.data_ptr(), ws.numel(), s_)))
             dxin = torch.empty((B,) + Sl + (Cup,), dtype=T, device=dev)
-            wt = self._pack(P[wk], L.PK_CT_T, Cup, Cup, False)
-            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Sl[0], Sl[1], Sl[2], dUp, wt.data_ptr(), L.tview(dxin), st))
+            wt = self._pack(P[wk], L.PK_CT_T if szl == 2 else L.PK_CT4_T, Cup, Cup, False)
+            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Sl[0], Sl[1], Sl[2], szl, dUp, wt.data_ptr(), L.tview(dxin), st))
             dOut = L.tview(dxin)
             keep.append(dxin)
         # ---- bottleneck -------------------------------------------------------------------------
@@ -498,7 +509,7 @@ class ResUNetEngine:
             Cup = fm[i + 1]
             # dOut_i = dSkip (dcat[i][..., Cup:]) + unpool(dP); written in place over the skip slice
             skipv = L.tview(dcat[i], Cup, fm[i])
-            L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
+            L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
             if i > 0:
                 dPn = torch.empty((B,) + S[i] + (fm[i - 1],), dtype=T, device=dev)
                 self._block_bwd(P, G, blocks[i], B, skipv, img, st, None, L.tview(dPn))

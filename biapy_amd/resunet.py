@@ -15,7 +15,7 @@ forward of a leaf layer is ever called - ``forward`` hands the parameter tensors
 ``torch.autograd.Function``.
 
 Configurations outside the accelerated hot path (2D, normalisation other than "in", larger_io,
-separated decoders, contrastive head, SR up-sampling, anisotropic kernels/strides, nconvs != 2,
+separated decoders, contrastive head, SR up-sampling, anisotropic (1,k,k) kernels, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2,
 pre-activation order) raise ``NotImplementedError`` at construction: they stay on the reference's
 plain-PyTorch classes, selected by the same registry.
 """
@@ -60,9 +60,9 @@ class ResConvBlock(nn.Module):
 class ResUpBlock(nn.Module):
     """Parameter holder named like blocks.py:1462-1655."""
 
-    def __init__(self, cin: int, cbridge: int, cout: int, k: int, act: str):
+    def __init__(self, cin: int, cbridge: int, cout: int, k: int, act: str, z_down: int = 2):
         super().__init__()
-        self.up = nn.ConvTranspose3d(cin, cin, kernel_size=(2, 2, 2), stride=(2, 2, 2))
+        self.up = nn.ConvTranspose3d(cin, cin, kernel_size=(z_down, 2, 2), stride=(z_down, 2, 2))   # k = s = (z_down, yx, yx), blocks.py:1607
         self.conv_block = ResConvBlock(cin + cbridge, cout, k, act, False)
 
 
@@ -146,8 +146,8 @@ class ResUNet(nn.Module):
             unsupported("2D input")
         if k_size != 3 or not all(iso):
             unsupported("kernel size != 3 or anisotropic (1,k,k) kernels")
-        if list(yx_down)[:depth] != [2] * depth or list(z_down)[:depth] != [2] * depth:
-            unsupported("down-sampling factors other than 2")
+        if list(yx_down)[:depth] != [2] * depth or any(int(v) not in (1, 2) for v in list(z_down)[:depth]) or len(list(z_down)) < depth:
+            unsupported("YX_DOWN other than 2 / Z_DOWN other than 1 or 2")
         if upsample_layer != "convtranspose":
             unsupported("upsample_layer != 'convtranspose'")
         if separated_decoders or contrast or larger_io or len(upsampling_factor) > 0:
@@ -169,8 +169,9 @@ class ResUNet(nn.Module):
         self.explicit_activations = False
         self.return_one_tensor = return_one_tensor
         in_ch = image_shape[-1]
+        zd = [int(v) for v in list(z_down)[:depth]]
         self.cfg = NetConfig(in_ch=in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
-                             normalization=normalization)
+                             normalization=normalization, z_down=zd)
         self.compute_dtype = compute_dtype
         self._engine: Optional[ResUNetEngine] = None
 
@@ -181,14 +182,14 @@ class ResUNet(nn.Module):
         c = in_ch
         for i in range(depth):
             self.down_path.append(ResConvBlock(c, feature_maps[i], k_size, act, first_block=(i == 0)))
-            self.mpooling_layers.append(nn.MaxPool3d((2, 2, 2)))
+            self.mpooling_layers.append(nn.MaxPool3d((zd[i], 2, 2)))
             c = feature_maps[i]
         self.bottleneck = ResConvBlock(c, feature_maps[-1], k_size, act, False)
         self.num_decoders = 1
         self.up_paths = nn.ModuleList([nn.ModuleList()])
         c = feature_maps[-1]
         for i in range(depth - 1, -1, -1):
-            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], k_size, act))
+            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], k_size, act, zd[i]))
             c = feature_maps[i]
         self.conv_out = None
         self.post_upsampling = None

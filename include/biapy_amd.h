@@ -97,8 +97,10 @@ typedef struct bpx_tensor {
  *   mode 4 BPX_PK_DENSE_T same weight, dgrad operator  -> [ceil4(Cout/KPL)][Cin][KPL]      (bpx_conv1x1_fwd as dgrad)
  *   mode 5 BPX_PK_CT     ConvTranspose3d (Cin,Cout,2,2,2) -> [ceil4(Cin/KPL)][8*Cout][KPL] (bpx_convT3d_k2s2_fwd)
  *   mode 6 BPX_PK_CT_T   same weight, dgrad operator   -> [8*Cout/KPL][Cin][KPL]           (bpx_convT3d_k2s2_dgrad)
+ *   mode 7 / 8 BPX_PK_CT4 / _T   the same for the anisotropic kernel (1,2,2) (Z_DOWN = 1): 4 sub-positions instead of 8
  * KPL = 8 (bf16) / 4 (f32) elements per 16-byte lane operand; QPAD = 56 (bf16) / 108 (f32). */
-enum bpx_pack_mode { BPX_PK_K3 = 0, BPX_PK_K3_T = 1, BPX_PK_K1 = 2, BPX_PK_DENSE = 3, BPX_PK_DENSE_T = 4, BPX_PK_CT = 5, BPX_PK_CT_T = 6 };
+enum bpx_pack_mode { BPX_PK_K3 = 0, BPX_PK_K3_T = 1, BPX_PK_K1 = 2, BPX_PK_DENSE = 3, BPX_PK_DENSE_T = 4, BPX_PK_CT = 5, BPX_PK_CT_T = 6,
+                     BPX_PK_CT4 = 7, BPX_PK_CT4_T = 8 };
 int64_t bpx_packed_weight_elems(int mode, int Cin, int Cout, int dtype);
 int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, int dtype, void* packed_d, bpx_stream_t stream);
 /* The same for up to 64 weights in ONE launch (a training step re-packs ~60 small tensors after every optimizer step;
@@ -150,17 +152,19 @@ int bpx_conv1x1_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const void* 
                     bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
                     bpx_stream_t stream);
 
-/* ConvTranspose3d k = s = 2 (blocks.py:1607): y[n,2z+a,2y+b,2x+c,:] = x[n,z,y,x,:]*W[:,:,a,b,c] + b.
- * (D,H,W) are the INPUT extents; y has extents (2D,2H,2W) and may be a channel slice of the
- * concat buffer.  stats_part_d: ([n][tiles][2][Cout]) partials for the following norm. */
-int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const void* w_packed_d,
+/* ConvTranspose3d k = s = (sz,2,2), sz = z_down of the level = 1 or 2 (blocks.py:1607):
+ * y[n,sz*z+a,2y+b,2x+c,:] = x[n,z,y,x,:]*W[:,:,a,b,c] + b.
+ * (D,H,W) are the INPUT extents; y has extents (sz*D,2H,2W) and may be a channel slice of the
+ * concat buffer.  stats_part_d: ([n][tiles][2][Cout]) partials for the following norm.
+ * Weights packed with BPX_PK_CT / _T (sz = 2) or BPX_PK_CT4 / _T (sz = 1). */
+int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, const void* w_packed_d,
                          const float* bias_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
-int bpx_convT3d_stats_tiles(int D, int H, int W);
-int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d,
+int bpx_convT3d_stats_tiles(int D, int H, int W, int sz);
+int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, int sz, bpx_tensor dy, const void* w_packed_T_d,
                            bpx_tensor dx, bpx_stream_t stream);
-int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout);
-int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy,
-                           float* dw_d /* (Cin,Cout,2,2,2), overwritten */, float* db_d /* accumulated */,
+int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int sz, int Cin, int Cout);
+int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy,
+                           float* dw_d /* (Cin,Cout,sz,2,2), overwritten */, float* db_d /* accumulated */,
                            void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* InstanceNorm3d(affine, eps) == GroupNorm with G = C (blocks.py:2122-2125).  Reduces the partials
@@ -182,12 +186,13 @@ int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, int C, int6
 int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
                        bpx_tensor addend, bpx_tensor dx, bpx_stream_t stream);
 
-/* MaxPool3d 2x2x2 (resunet.py:256-257) + statistics of the pooled tensor. (D,H,W) = input extents. */
-int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor y, float* stats_part_d,
+/* MaxPool3d (sz,2,2), sz = z_down of the level = 1 or 2 (resunet.py:256-257) + statistics of the pooled tensor.
+ * (D,H,W) = input extents. */
+int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor y, float* stats_part_d,
                       bpx_stream_t stream);
-int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int C);
+int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int sz, int C);
 /* dx = addend + scatter(dy to the first maximal element of each window) */
-int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, bpx_tensor x, bpx_tensor dy, bpx_tensor addend,
+int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, bpx_tensor addend,
                       bpx_tensor dx, bpx_stream_t stream);
 
 /* Output head: Conv3d k=1 to `Cout` (<= 4) fp32 channels (resunet.py:346-348) with the head

@@ -39,6 +39,13 @@ def tiling_golden():
 
 
 @pytest.fixture(scope="session")
+def resunet_aniso_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunet_aniso_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def tiling2d_golden():
     import numpy as np
 

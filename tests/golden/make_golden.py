@@ -224,11 +224,70 @@ def resunet_fixtures():
     print("resunet_golden.npz:", len(out), "arrays")
 
 
+def resunet_aniso_fixtures():
+    """Anisotropic ResUNet (MODEL.Z_DOWN = [1, 2]: pooling / transposed conv (1,2,2) at the first level): reference logits,
+    loss and every gradient of a small net (fm 16-32-64, 8x32x32 patches)."""
+    rmod = shim.load("biapy.models.resunet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import net_oracle
+
+    fm, patch, B, zd = [16, 32, 64], (8, 32, 32), 2, [1, 2]
+    torch.manual_seed(5)
+    with quiet():
+        net = rmod.ResUNet(
+            image_shape=tuple(patch) + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in", k_size=3,
+            upsample_layer="convtranspose", yx_down=[2, 2], z_down=zd, output_channels=[1], output_channel_info=["F"],
+            head_activations=["ce_sigmoid"], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3,
+        )
+    g = torch.Generator().manual_seed(105)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if v.ndim == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    g = torch.Generator().manual_seed(6)
+    x5 = torch.randn(B, *patch, 1, generator=g)
+    x = x5.permute(0, 4, 1, 2, 3)
+    tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+    net.train()
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)
+    loss.backward()
+    out = {"feature_maps": np.array(fm), "z_down": np.array(zd), "x": x5.numpy(), "target": tgt.numpy().astype(np.uint8),
+           "logits": logits.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64)}
+    for k, v in net.state_dict().items():
+        out[f"sd/{k}"] = v.numpy().astype(np.float16) if v.ndim == 5 and v.numel() > 20000 else v.numpy()
+    # the big conv weights are stored as fp16 to keep the fixture small: re-run the reference ON THE ROUNDED weights so that
+    # the stored outputs belong to exactly the stored parameters
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            v.copy_(torch.from_numpy(out[f"sd/{k}"].astype(np.float32)))
+    net.zero_grad()
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)
+    loss.backward()
+    out["logits"] = logits.detach().numpy()
+    out["loss"] = np.array(loss.item(), dtype=np.float64)
+    for k, p in net.named_parameters():
+        out[f"gradnorm/{k}"] = np.array(p.grad.norm().item(), dtype=np.float64)
+    for k in ["down_path.0.block.0.block.0.weight", "up_paths.0.0.up.weight", "up_paths.0.1.up.weight", "up_paths.0.1.up.bias",
+              "down_path.1.block.0.weight", "heads.0.weight"]:
+        out[f"grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    lo = net_oracle.resunet_forward(sd, x, fm, z_down=zd)
+    err = (lo - logits.detach()).abs().max().item()
+    print("oracle vs reference (anisotropic) max abs err:", err)
+    assert err < 2e-5
+    np.savez_compressed(os.path.join(HERE, "resunet_aniso_golden.npz"), **out)
+    print("resunet_aniso_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso"]
     if "tiling" in which:
         tiling_fixtures()
     if "tiling2d" in which:
         tiling2d_fixtures()
     if "resunet" in which:
         resunet_fixtures()
+    if "resunet_aniso" in which:
+        resunet_aniso_fixtures()

@@ -335,27 +335,28 @@ def check_conv1x1(dt, B, vox, Cin, Cout, with_coef=True, seed=0):
     return res
 
 
-def check_convT(dt, B, S, Cc, seed=0):
+def check_convT(dt, B, S, Cc, seed=0, sz=2):
+    """ConvTranspose3d k = s = (sz,2,2) forward / dgrad / wgrad (sz = 1: the anisotropic Z_DOWN = 1 level)."""
     D, H, W = S
     g = torch.Generator().manual_seed(seed)
     x = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
-    w = torch.randn(Cc, Cc, 2, 2, 2, generator=g) / Cc ** 0.5
+    w = torch.randn(Cc, Cc, sz, 2, 2, generator=g) / Cc ** 0.5
     b = torch.randn(Cc, generator=g) * 0.1
     xr = ncdhw(x).requires_grad_(True)
     wr = rnd(w, dt).requires_grad_(True)
     br = b.clone().requires_grad_(True)
-    y_ref = F.conv_transpose3d(xr, wr, br, stride=2)
-    dy = rnd(torch.randn(B, 2 * D, 2 * H, 2 * W, Cc, generator=g), dt)
+    y_ref = F.conv_transpose3d(xr, wr, br, stride=(sz, 2, 2))
+    dy = rnd(torch.randn(B, sz * D, 2 * H, 2 * W, Cc, generator=g), dt)
     y_ref.backward(ncdhw(dy))
-    tag = f"convT[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc}]"
+    tag = f"convT[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc} sz{sz}]"
     # forward into a channel slice of a concat buffer
     extra = 16
-    yb = torch.full((B, 2 * D, 2 * H, 2 * W, Cc + extra), 3.0, dtype=tdtype(dt), device=DEV)
-    wp = pack(w, L.PK_CT, Cc, Cc, dt)
-    tiles = lib.bpx_convT3d_stats_tiles(D, H, W)
+    yb = torch.full((B, sz * D, 2 * H, 2 * W, Cc + extra), 3.0, dtype=tdtype(dt), device=DEV)
+    wp = pack(w, L.PK_CT if sz == 2 else L.PK_CT4, Cc, Cc, dt)
+    tiles = lib.bpx_convT3d_stats_tiles(D, H, W, sz)
     part = torch.zeros(B, tiles, 2, Cc, dtype=torch.float32, device=DEV)
     xd, bd = to_dev(x, dt), b.to(DEV)
-    L.check(lib.bpx_convT3d_k2s2_fwd(dt, B, D, H, W, L.tview(xd), wp.data_ptr(), bd.data_ptr(), L.tview(yb, 0, Cc), part.data_ptr(), L.stream_ptr()))
+    L.check(lib.bpx_convT3d_k2s2_fwd(dt, B, D, H, W, sz, L.tview(xd), wp.data_ptr(), bd.data_ptr(), L.tview(yb, 0, Cc), part.data_ptr(), L.stream_ptr()))
     torch.cuda.synchronize()
     y = ndhwc(y_ref.detach())
     res = [_res(tag + ".fwd", relerr(yb[..., :Cc], y), tol_for(dt))]
@@ -363,17 +364,17 @@ def check_convT(dt, B, S, Cc, seed=0):
     s_ref = torch.stack([y.sum((1, 2, 3)), (y * y).sum((1, 2, 3))], 1)
     res.append(_res(tag + ".stats", relerr(part.sum(1), s_ref), 5e-3 if dt == L.BF16 else 1e-4))
     # dgrad
-    wpt = pack(w, L.PK_CT_T, Cc, Cc, dt)
+    wpt = pack(w, L.PK_CT_T if sz == 2 else L.PK_CT4_T, Cc, Cc, dt)
     dyd = to_dev(dy, dt)
     dx = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
-    L.check(lib.bpx_convT3d_k2s2_dgrad(dt, B, D, H, W, L.tview(dyd), wpt.data_ptr(), L.tview(dx), L.stream_ptr()))
+    L.check(lib.bpx_convT3d_k2s2_dgrad(dt, B, D, H, W, sz, L.tview(dyd), wpt.data_ptr(), L.tview(dx), L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(tag + ".dgrad", relerr(dx, ndhwc(xr.grad)), tol_for(dt)))
     # wgrad
-    dw = torch.zeros(Cc, Cc, 2, 2, 2, dtype=torch.float32, device=DEV)
+    dw = torch.zeros(Cc, Cc, sz, 2, 2, dtype=torch.float32, device=DEV)
     db = torch.zeros(Cc, dtype=torch.float32, device=DEV)
-    ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, Cc, Cc)), dtype=torch.uint8, device=DEV)
-    L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
+    ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, sz, Cc, Cc)), dtype=torch.uint8, device=DEV)
+    L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, sz, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
                                        L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(tag + ".wgrad", relerr(dw, wr.grad), 2e-3 if dt == L.BF16 else 2e-5))
@@ -403,26 +404,26 @@ def check_norm_pool_head(dt, seed=0):
     mean = xf.mean(1); var = xf.var(1, unbiased=False); rstd = (var + 1e-5).rsqrt()
     ref = torch.stack([mean, rstd, gamma[None] * rstd, beta[None] - mean * gamma[None] * rstd], -1)
     res.append(_res(f"norm_finalize[{tagd}]", relerr(rec, ref), 1e-5))
-    # max pool fwd + stats
-    y = torch.empty(B, D // 2, H // 2, W // 2, Cc, dtype=tdtype(dt), device=DEV)
-    pt = lib.bpx_maxpool3d_stats_tiles(dt, D, H, W, Cc)
-    ppart = torch.zeros(B, pt, 2, Cc, dtype=torch.float32, device=DEV)
-    L.check(lib.bpx_maxpool3d_fwd(dt, B, D, H, W, L.tview(xd), L.tview(y), ppart.data_ptr(), L.stream_ptr()))
-    torch.cuda.synchronize()
-    xr = ncdhw(x).requires_grad_(True)
-    y_ref = F.max_pool3d(xr, 2)
-    res.append(_res(f"maxpool_fwd[{tagd}]", relerr(y, ndhwc(y_ref.detach())), 0.0))
-    yr = ndhwc(y_ref.detach())
-    res.append(_res(f"maxpool_stats[{tagd}]", relerr(ppart.sum(1), torch.stack([yr.sum((1, 2, 3)), (yr * yr).sum((1, 2, 3))], 1)), 1e-4))
-    # max pool bwd with addend (ties are likely in bf16: first maximum must win as in PyTorch)
-    dy = rnd(torch.randn(B, D // 2, H // 2, W // 2, Cc, generator=g), dt)
-    add = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
-    y_ref.backward(ncdhw(dy))
-    dx = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
-    dy_d, add_d = to_dev(dy, dt), to_dev(add, dt)
-    L.check(lib.bpx_maxpool3d_bwd(dt, B, D, H, W, L.tview(xd), L.tview(dy_d), L.tview(add_d), L.tview(dx), L.stream_ptr()))
-    torch.cuda.synchronize()
-    res.append(_res(f"maxpool_bwd[{tagd}]", relerr(dx, rnd(ndhwc(xr.grad) + add, dt)), 1e-6))
+    # max pool (sz,2,2) fwd + stats, bwd with addend (ties are likely in bf16: the first maximum must win as in PyTorch)
+    for sz in (2, 1):
+        y = torch.empty(B, D // sz, H // 2, W // 2, Cc, dtype=tdtype(dt), device=DEV)
+        pt = lib.bpx_maxpool3d_stats_tiles(dt, D, H, W, sz, Cc)
+        ppart = torch.zeros(B, pt, 2, Cc, dtype=torch.float32, device=DEV)
+        L.check(lib.bpx_maxpool3d_fwd(dt, B, D, H, W, sz, L.tview(xd), L.tview(y), ppart.data_ptr(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        xr = ncdhw(x).requires_grad_(True)
+        y_ref = F.max_pool3d(xr, (sz, 2, 2))
+        res.append(_res(f"maxpool_fwd[{tagd} sz{sz}]", relerr(y, ndhwc(y_ref.detach())), 0.0))
+        yr = ndhwc(y_ref.detach())
+        res.append(_res(f"maxpool_stats[{tagd} sz{sz}]", relerr(ppart.sum(1), torch.stack([yr.sum((1, 2, 3)), (yr * yr).sum((1, 2, 3))], 1)), 1e-4))
+        dy = rnd(torch.randn(B, D // sz, H // 2, W // 2, Cc, generator=g), dt)
+        add = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
+        y_ref.backward(ncdhw(dy))
+        dx = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
+        dy_d, add_d = to_dev(dy, dt), to_dev(add, dt)
+        L.check(lib.bpx_maxpool3d_bwd(dt, B, D, H, W, sz, L.tview(xd), L.tview(dy_d), L.tview(add_d), L.tview(dx), L.stream_ptr()))
+        torch.cuda.synchronize()
+        res.append(_res(f"maxpool_bwd[{tagd} sz{sz}]", relerr(dx, rnd(ndhwc(xr.grad) + add, dt)), 1e-6))
     # norm backward: finalize + apply == autograd of instance norm
     t = x
     tn = ncdhw(t).requires_grad_(True)
@@ -559,6 +560,48 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
         if e > worst:
             worst, worst_name = e, k
     res.append(_res(tag + ".grads_rel_l2_worst", worst, gtol, extra=worst_name))
+    return res
+
+
+def check_network_aniso(dtype, golden):
+    """Anisotropic ResUNet (Z_DOWN = [1, 2]) against the reference fixture tests/golden/resunet_aniso_golden.npz: logits, loss
+    and every gradient norm + the stored full gradients."""
+    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+    fm = [int(v) for v in golden["feature_maps"]]
+    zd = [int(v) for v in golden["z_down"]]
+    sd = {k[3:]: torch.from_numpy(golden[k].astype(np.float32)) for k in golden.files if k.startswith("sd/")}
+    x = torch.from_numpy(golden["x"]).permute(0, 4, 1, 2, 3).contiguous()
+    tgt = torch.from_numpy(golden["target"]).float()
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, z_down=zd), dtype)
+    P = {k: v.to(DEV) for k, v in sd.items()}
+    logits, ctx = eng.forward(P, x.to(DEV), head_act=0, save=True)
+    lg = logits.detach().clone().requires_grad_(True)
+    loss = F.binary_cross_entropy_with_logits(lg, tgt.to(DEV))
+    loss.backward()
+    G = eng.backward(P, ctx, lg.grad)
+    torch.cuda.synchronize()
+    tag = f"resunet_aniso[{tagd} fm={fm} z_down={zd}]"
+    lo_ref = torch.from_numpy(golden["logits"])
+    res = [_res(tag + ".logits_rel", (logits.cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 6e-2 if dtype == torch.bfloat16 else 2e-4)]
+    res.append(_res(tag + ".loss", abs(loss.item() - float(golden["loss"])), 2e-2 if dtype == torch.bfloat16 else 1e-5))
+    gtol = 0.15 if dtype == torch.bfloat16 else 2e-3
+    worst, wname = 0.0, ""
+    for k in golden.files:
+        if k.startswith("grad/"):
+            gr = torch.from_numpy(golden[k])
+            e = (G[k[5:]].cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
+            if e > worst:
+                worst, wname = e, k[5:]
+    res.append(_res(tag + ".grads_rel_l2_worst", worst, gtol, extra=wname))
+    worst, wname = 0.0, ""
+    for k in golden.files:
+        if k.startswith("gradnorm/"):
+            ref = float(golden[k])
+            if ref > 1e-6:
+                e = abs(G[k[9:]].norm().item() - ref) / ref
+                if e > worst:
+                    worst, wname = e, k[9:]
+    res.append(_res(tag + ".gradnorm_rel_worst", worst, gtol, extra=wname))
     return res
 
 

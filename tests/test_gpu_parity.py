@@ -87,6 +87,8 @@ def test_pointwise_and_transposed_conv(K, dt):
     rows += K.check_conv1x1(dt, 1, 300, 128, 384, with_coef=False)
     rows += K.check_convT(dt, 2, (4, 6, 8), 32)
     rows += K.check_convT(dt, 1, (2, 2, 2), 256)
+    rows += K.check_convT(dt, 2, (5, 6, 8), 32, sz=1)      # anisotropic level (Z_DOWN = 1): kernel (1,2,2)
+    rows += K.check_convT(dt, 1, (3, 4, 20), 64, sz=1)
     _assert_all(rows)
 
 
@@ -99,6 +101,12 @@ def test_norm_pool_head_first_layer(K, dt):
 def test_network_against_reference_golden(K, resunet_golden, dtype):
     """Logits, loss, Dice and all parameter gradients vs the fixture captured from the reference ResUNet."""
     _assert_all(K.check_network(dtype, None, None, None, golden=resunet_golden))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_anisotropic_network_against_reference_golden(K, resunet_aniso_golden, dtype):
+    """MODEL.Z_DOWN = [1, 2]: pooling and transposed conv (1,2,2) at the first level (blocks.py:1607, resunet.py:256-257)."""
+    _assert_all(K.check_network_aniso(dtype, resunet_aniso_golden))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -172,7 +180,8 @@ def test_graphed_train_step_matches_eager(K):
     assert abs(l1.item() - l2.item()) < 1e-5, (l1.item(), l2.item())
     # conv weights only: the biases in front of an InstanceNorm have an exactly-zero true gradient, Adam turns the sign of
     # their rounding noise (atomic summation order) into +-lr, so they legitimately differ between any two runs
-    worst = max(float((p1 - p2).abs().max() / (p1.abs().max() + 1e-12)) for p1, p2 in zip(m1.parameters(), m2.parameters()) if p1.dim() == 5)
+    worst = max(float((p1.detach() - p2.detach()).abs().max() / (p1.detach().abs().max() + 1e-12))
+                for p1, p2 in zip(m1.parameters(), m2.parameters()) if p1.dim() == 5)
     assert worst < 1e-3, worst
     m1.eval()
     gi = GraphedInference(m1.predict_proba, x)

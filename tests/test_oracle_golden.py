@@ -149,3 +149,23 @@ def test_tiling2d_oracle_matches_reference(tiling2d_golden, name):
     merged, merged_mask = T.merge2d(pred, dshape, pm, ov, pad)
     np.testing.assert_array_equal(merged.view(np.uint32), g[f"{name}/merged"].view(np.uint32))
     np.testing.assert_array_equal(merged_mask, g[f"{name}/merged_mask"])
+
+
+def test_net_oracle_anisotropic_matches_reference(resunet_aniso_golden):
+    """Z_DOWN = [1, 2] (anisotropic pooling / transposed conv): oracle logits, loss and gradients vs the reference fixture."""
+    import torch
+
+    from oracle import net_oracle
+
+    g = resunet_aniso_golden
+    fm, zd = [int(v) for v in g["feature_maps"]], [int(v) for v in g["z_down"]]
+    sd = {k[3:]: torch.from_numpy(g[k].astype(np.float32)) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3)
+    tgt = torch.from_numpy(g["target"]).float()
+    loss, logits, grads = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm, z_down=zd)
+    assert (logits - torch.from_numpy(g["logits"])).abs().max().item() < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(g[k])
+            assert (grads[k[5:]] - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
