@@ -60,6 +60,7 @@ inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   // 16*NS output channels per workgroup; 48/96-channel outputs (dgrad into the concat buffers) take NS = 3 so that the
   // halo is staged once instead of three times
   c.ns = (Cout % 64 == 0) ? 4 : (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
+  if (c.ns == 4 && (int64_t)D * H * W <= 512) c.ns = 2;   // 8^3 bottleneck: twice the workgroups (29 -> 23, 62 -> 48 us)
   // <= 16^3 volumes: 4x4x8 tiles double the workgroup count of these latency-bound launches (measured 114 -> 92, 61 -> 48 us)
   if (W > 8 && (int64_t)D * H * W > 4096) {
     c.tx = 16; c.tz = 4;

@@ -1132,7 +1132,7 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
       b.job[k] = j;
       b.total[k] = packed_elems(j.mode, j.Cin, j.Cout, dtype);
     }
-    dim3 grid(32, (unsigned)n);
+    dim3 grid(256, (unsigned)n);   // the largest operands (256x256x27) are ~1.8 M elements: 27 per thread
     if (dtype == BPX_BF16) pack_batch_kernel<uint16_t><<<grid, 256, 0, s>>>(b);
     else pack_batch_kernel<float><<<grid, 256, 0, s>>>(b);
     BPX_LAUNCH_CHECK(fn);
