@@ -34,11 +34,10 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
   static_assert(TZ == 4 && MS * 16 == TY * TX && (TX == 16 || TX == 8), "wave = z-slice mapping");
   static_assert(HZ < 256 && HY < 256 && HX < 256, "packed halo coordinates");
   constexpr int NPIECE = HV * 2, NP = (NPIECE + 255) / 256;      // 16-byte pieces of the halo; piece idx lives at LDS byte idx*16
-  constexpr int NP2 = TZ * TY * TX * 2 / 256;                     // pieces of the un-haloed block (fused 1x1x1 shortcut)
   constexpr int BUFB = HV * VB;
   constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
   constexpr int RS = (TX == 16) ? 1 : 2;                          // tile rows covered by one 16-voxel m-subtile
-  constexpr int HSTR = RS * HX * VB, TSTR = 16 * VB;              // LDS strides between m-subtiles (halo / plain block)
+  constexpr int HSTR = RS * HX * VB;                              // LDS stride between m-subtiles of the halo image
   constexpr int WD = (NS == 1 || (NS == 2 && EPI == EPI_FWD)) ? 2 : 1;                           // weight prefetch distance (steps)
   __shared__ __attribute__((aligned(16))) unsigned char smem[BUFB + RED_BYTES];
 
@@ -62,7 +61,6 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
   const int hb0 = ((wave * HY + ey) * HX + ex) * VB + cg_off;
   // ds_read bases of the four tap-pair classes (bpx_tap_order_bf16): partner tap is +1 voxel / +1 row / +1 plane / absent
   const int lbase[4] = {hb0 + (hi_tap ? VB : 0), hb0 + (hi_tap ? HX * VB : 0), hb0 + (hi_tap ? HY * HX * VB : 0), hb0};
-  const int tb0 = (wave * TY * TX + j) * VB + cg_off;
   const int evox_rel = (wave * H + ey) * W + ex;
 
   const int sub = tid & 1;
@@ -181,40 +179,35 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     BPX_STAMP();  // 4: all chunks done
     __builtin_amdgcn_sched_barrier(0);  // keep the epilogue's operand loads out of the MFMA loop's register budget
     const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
-    // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only): extra K steps over the un-haloed block -----------
+    // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only): extra K steps ------------------------------------
+    // A 1x1x1 conv has no spatial reuse, so its activation operand goes straight from global memory to the MFMA B
+    // registers (lane (j, g) needs 16 bytes of voxel j: channels chunk*16 + (g&1)*8 ..; the k-groups g >= 2 meet zero
+    // weights in the packed [chunk][4][Cout][8] layout) - no LDS round trip, no barriers.
+    const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;  // this lane's voxel for m-subtile 0
+    const bool okzx = full || (z0 + wave < D && x0 + ex < W);
+    const int yrem = full ? (1 << 20) : H - (y0 + ey);              // m-subtile ms is inside the volume iff RS*ms < yrem
     if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16) {
       const char* __restrict__ scin = reinterpret_cast<const char*>(p.sc);
       const char* __restrict__ wsc = reinterpret_cast<const char*>(p.wsc);
-      const uint32_t base2 = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.sc_ld * 2u;
+      const uint32_t sb0 = (uint32_t)(vox0 * p.sc_ld) * 2u + (uint32_t)cg_off, srow = (uint32_t)(RS * W * p.sc_ld) * 2u;
       const int nch = p.sc_C / 16;
       for (int chunk = 0; chunk < nch; ++chunk) {
-        __syncthreads();
+        u32x4_t bq[MS], wf[NS];
 #pragma unroll
-        for (int u = 0; u < NP2; ++u) {
-          const int t = (u * 256 + tid) >> 1;
-          const int tz = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
-          const bool ok = full || (z0 + tz < D && y0 + ty < H && x0 + tx < W);
-          u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-          if (ok) v = *reinterpret_cast<const u32x4_t*>(scin + (base2 + (uint32_t)(((tz * H + ty) * W + tx) * p.sc_ld + sub * KPL + chunk * 16) * 2u));
-          *reinterpret_cast<u32x4_t*>(smem + (size_t)(u * 256 + tid) * 16) = v;
+        for (int ms = 0; ms < MS; ++ms) {
+          bq[ms] = u32x4_t{0u, 0u, 0u, 0u};
+          if (okzx && RS * ms < yrem) bq[ms] = *reinterpret_cast<const u32x4_t*>(scin + (sb0 + ms * srow + (uint32_t)chunk * 32u));
         }
-        __syncthreads();
-        u32x4_t wf[NS];
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wsc + (size_t)chunk * 4 * Cout * 16 + (wlane + ns * 256u));
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-          const u32x4_t af = *reinterpret_cast<const u32x4_t*>(smem + tb0 + ms * TSTR);
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
-        }
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], bq[ms], acc[ms][ns]);
       }
     }
 
     // ---- epilogue: all loads first, then math + one 8-byte store per (m-subtile, 16-channel group) ------------------
-    const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;  // this lane's voxel for m-subtile 0
-    const bool okzx = full || (z0 + wave < D && x0 + ex < W);
-    const int yrem = full ? (1 << 20) : H - (y0 + ey);              // m-subtile ms is inside the volume iff RS*ms < yrem
     char* __restrict__ yout = reinterpret_cast<char*>(p.y);
     const uint32_t yrow = (uint32_t)(RS * W * p.y_ld) * 2u;                                  // bytes between m-subtiles
     const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + co_base + g * 4) * 2u;
