@@ -56,7 +56,7 @@ class GraphedTrainStep:
         _warm(eager, warmup)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = eager()
         torch.cuda.synchronize()
 
@@ -80,7 +80,7 @@ class GraphedInference:
         with torch.no_grad():
             _warm(lambda: fn(self.x), warmup)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.y = fn(self.x)
         torch.cuda.synchronize()
 

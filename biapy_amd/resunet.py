@@ -259,10 +259,12 @@ class ResUNet(nn.Module):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gf):
+        # thread_local: a HIP call from another thread (e.g. the RCCL watchdog of an initialised process group) must not
+        # invalidate the capture
+        with torch.cuda.graph(gf, capture_error_mode="thread_local"):
             logits, saved = eng.forward(P, xs, head_act=0, save=True)
         dl = torch.zeros_like(logits)
-        with torch.cuda.graph(gb, pool=gf.pool()):
+        with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
             grads = eng.backward(P, saved, dl)
         torch.cuda.synchronize()
         self._graphs = dict(shape=tuple(xs.shape), stride=xs.stride(), x=xs, logits=logits, saved=saved, dlogits=dl, grads=grads,
