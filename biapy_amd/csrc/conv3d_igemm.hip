@@ -487,10 +487,10 @@ static int check_tensor(const char* fn, const char* name, const bpx_tensor& t, i
   return 0;
 }
 
-extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
-                              const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
-                              const float* bias_sc_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
-  const char* fn = "bpx_conv3d_fwd";
+static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                           const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
+                           const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
+                           float* pool_stats_part_d, bpx_stream_t stream) {
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   int es = (int)dtype_size(dtype);
   BPX_CHECK(N > 0 && D > 0 && H > 0 && W > 0, "%s: empty volume", fn);
@@ -507,6 +507,14 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
   p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
+  if (pool_sz) {
+    BPX_CHECK(use_lean(dtype, p) && c.tx == 16, "%s: the fused pooling needs the lean bf16 kernel (bpx_conv3d_fwd_pool_supported)", fn);
+    BPX_CHECK(pool_sz == 1 || pool_sz == 2, "%s: pool z stride must be 1 or 2 (got %d)", fn, pool_sz);
+    BPX_CHECK(D % pool_sz == 0 && H % 2 == 0 && W % 2 == 0, "%s: extents must be divisible by the pooling window", fn);
+    if (check_tensor(fn, "pooled", pooled, es, true)) return 1;
+    BPX_CHECK(pooled.C == y.C, "%s: pooled.C %d != y.C %d", fn, pooled.C, y.C);
+    p.pool = pooled.ptr; p.pool_ld = pooled.ld; p.pool_sz = pool_sz; p.pool_part = pool_stats_part_d;
+  }
   int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_FWD, p, c, (hipStream_t)stream)
                                   : g_use_ws == 1 ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
@@ -514,6 +522,27 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
+}
+
+extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                              const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
+                              const float* bias_sc_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
+  return conv3d_fwd_impl("bpx_conv3d_fwd", dtype, N, D, H, W, x, in_norm_d, act, w_packed_d, bias_d, sc, w_sc_d, bias_sc_d, y, stats_part_d, 0,
+                         bpx_tensor{nullptr, 0, 0}, nullptr, stream);
+}
+
+extern "C" int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                                   const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
+                                   const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
+                                   float* pool_stats_part_d, bpx_stream_t stream) {
+  return conv3d_fwd_impl("bpx_conv3d_fwd_pool", dtype, N, D, H, W, x, in_norm_d, act, w_packed_d, bias_d, sc, w_sc_d, bias_sc_d, y, stats_part_d,
+                         pool_sz, pooled, pool_stats_part_d, stream);
+}
+
+extern "C" int bpx_conv3d_fwd_pool_supported(int dtype, int N, int D, int H, int W, int x_ld, int y_ld, int Cout) {
+  if (dtype != BPX_BF16 || g_use_ws != 0 || (int64_t)D * H * W < 262144 || W <= 8) return 0;
+  TileCfg c = pick_cfg(dtype, D, H, W, Cout);
+  return c.tx == 16 && (int64_t)N * D * H * W * std::max(x_ld, y_ld) < (1ll << 31) ? 1 : 0;
 }
 
 extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,

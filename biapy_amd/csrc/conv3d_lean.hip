@@ -21,7 +21,7 @@ namespace {
 // workgroups per CU the register budget is set for; every configuration must compile WITHOUT scratch (a spilling kernel
 // runs up to 2x slower inside the network than alone: measured)
 constexpr int lp_occ(int vox, int ns, int epi, int actk) {
-  return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && actk == 0)) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
+  return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
 }
 
 template <int TZ, int TY, int TX, int NS, int EPI, int ACTK>
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
   static_assert(HZ < 256 && HY < 256 && HX < 256, "packed halo coordinates");
   constexpr int NPIECE = HV * 2, NP = (NPIECE + 255) / 256;      // 16-byte pieces of the halo; piece idx lives at LDS byte idx*16
   constexpr int BUFB = HV * VB;
-  constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
+  constexpr int RED_BYTES = 2 * 4 * NS * 16 * 2 * 4;                // statistics scratch: the output's and the fused pool's
   constexpr int RS = (TX == 16) ? 1 : 2;                          // tile rows covered by one 16-voxel m-subtile
   constexpr int HSTR = RS * HX * VB;                              // LDS stride between m-subtiles of the halo image
   constexpr int WD = (NS == 1 || (NS == 2 && EPI == EPI_FWD)) ? 2 : 1;                           // weight prefetch distance (steps)
@@ -213,12 +213,12 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + co_base + g * 4) * 2u;
     // statistics partials of one 16-channel group: 16 lanes (DPP) -> this wave's slot of the LDS scratch [wave][NS*16][2]
     float* red = reinterpret_cast<float*>(smem + BUFB);
-    auto flush_stats = [&](int ns, const float* s1, const float* s2) {
-      if (p.part == nullptr) return;
+    auto flush_stats = [&](int ns, const float* s1, const float* s2, int which = 0) {
+      if ((which ? (float*)p.pool_part : p.part) == nullptr) return;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
-        if (j == 0) *reinterpret_cast<f32x2_t*>(&red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+        if (j == 0) *reinterpret_cast<f32x2_t*>(&red[which * 4 * NS * 16 * 2 + ((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
       }
     };
 
@@ -236,8 +236,10 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         if (p.sc && p.bias_sc) add += *reinterpret_cast<const f32x4_t*>(p.bias_sc + co);
         if (rank1) w1 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.wsc) + co);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        u32x2_t pk[MS];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
+          pk[ms] = u32x2_t{0u, 0u};
           if (okzx && RS * ms < yrem) {
             float v[4];
 #pragma unroll
@@ -246,8 +248,58 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               s1[r] += v[r];
               s2[r] += v[r] * v[r];
             }
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+            pk[ms] = u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = pk[ms];
           }
+        }
+        if (TX == 16 && p.pool != nullptr) {
+          // ---- fused MaxPool3d (pool_sz,2,2) of the bf16 values just written (max commutes with the rounding, so this
+          //      equals pooling the stored tensor): y pairs are two m-subtiles of this lane, x pairs are lanes j / j^1
+          //      (DPP quad_perm), z pairs are waves w / w+1 (through LDS).  Saves the re-read of the output slice.
+          float m[MS / 2][4];
+#pragma unroll
+          for (int k = 0; k < MS / 2; ++k) {
+            const u32x2_t a = pk[2 * k], b = pk[2 * k + 1];
+            m[k][0] = fmaxf(bf16lo(a[0]), bf16lo(b[0])); m[k][1] = fmaxf(bf16hi(a[0]), bf16hi(b[0]));
+            m[k][2] = fmaxf(bf16lo(a[1]), bf16lo(b[1])); m[k][3] = fmaxf(bf16hi(a[1]), bf16hi(b[1]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              m[k][r] = fmaxf(m[k][r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[k][r]), 0xB1, 0xF, 0xF, true)));
+          }
+          if (p.pool_sz == 2) {
+            f32x4_t* ex = reinterpret_cast<f32x4_t*>(smem);  // [wave pair][k][lane]
+            __syncthreads();                                 // the halo image (or the previous group's exchange) is no longer read
+            if (wave & 1) {
+#pragma unroll
+              for (int k = 0; k < MS / 2; ++k) ex[((wave >> 1) * (MS / 2) + k) * 64 + lane] = f32x4_t{m[k][0], m[k][1], m[k][2], m[k][3]};
+            }
+            __syncthreads();
+            if (!(wave & 1)) {
+#pragma unroll
+              for (int k = 0; k < MS / 2; ++k) {
+                const f32x4_t o = ex[((wave >> 1) * (MS / 2) + k) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m[k][r] = fmaxf(m[k][r], o[r]);
+              }
+            }
+          }
+          float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+          if ((p.pool_sz == 1 || !(wave & 1)) && !(j & 1) && z0 + wave < D && x0 + j < W) {
+            const int Dp = D / p.pool_sz, Hp = H >> 1, Wp = W >> 1;
+            const int pz = (z0 + wave) / p.pool_sz, px = (x0 + j) >> 1;
+            char* __restrict__ pout = reinterpret_cast<char*>(p.pool);
+#pragma unroll
+            for (int k = 0; k < MS / 2; ++k) {
+              if (y0 + 2 * k < H) {
+                const int py = (y0 >> 1) + k;
+                *reinterpret_cast<u32x2_t*>(pout + (uint32_t)((((n * Dp + pz) * Hp + py) * Wp + px) * p.pool_ld + co) * 2u) =
+                    u32x2_t{cvt_pk_bf16(m[k][0], m[k][1]), cvt_pk_bf16(m[k][2], m[k][3])};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q1[r] += m[k][r]; q2[r] += m[k][r] * m[k][r]; }
+              }
+            }
+          }
+          flush_stats(ns, q1, q2, 1);
         }
         flush_stats(ns, s1, s2);
       }
@@ -299,13 +351,17 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     BPX_STAMP();  // 5: epilogue stores issued
 
     // ---- statistics partials: 4 waves (LDS) -> global [n][tile][2][Cout] ------------------------------------------------
-    if (p.part != nullptr) {
+    if (p.part != nullptr || (EPI == EPI_FWD && p.pool_part != nullptr)) {
       __syncthreads();
-      if (tid < NS * 16 * 2) {
-        const int c = tid >> 1, k = tid & 1;
-        const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
-                        red[(3 * NS * 16 + c) * 2 + k];
-        p.part[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Cout + co_base + c] = a;
+      if (tid < 2 * NS * 16 * 2) {
+        const int which = tid / (NS * 16 * 2), q = tid % (NS * 16 * 2);
+        const int c = q >> 1, k = q & 1;
+        float* dst = which ? (EPI == EPI_FWD ? p.pool_part : nullptr) : p.part;
+        if (dst != nullptr) {
+          const float* rd = red + which * 4 * NS * 16 * 2;
+          const float a = rd[(0 * NS * 16 + c) * 2 + k] + rd[(1 * NS * 16 + c) * 2 + k] + rd[(2 * NS * 16 + c) * 2 + k] + rd[(3 * NS * 16 + c) * 2 + k];
+          dst[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Cout + co_base + c] = a;
+        }
       }
     }
     BPX_STAMP();  // 6: tile done

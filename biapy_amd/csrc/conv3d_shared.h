@@ -21,6 +21,8 @@ struct Conv3Params {
   void* y; int y_ld; int Cout;
   float* part;  // [N][tiles][2][Cout]
   const void* t; int t_ld; const bpx_norm_rec* t_norm; int t_act;
+  // fused MaxPool3d (pool_sz,2,2) of the output (forward, lean kernel only): pooled tensor + its statistics partials
+  void* pool; int pool_ld; int pool_sz; float* pool_part;
   int tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd;
   long long* stamps;  // profiling: per-workgroup s_memtime stamps [block][16] (BPX_CONV_STAMPS), else null
   int dbg;  // ablation switches for profiling (BPX_CONV_DBG): 1 = skip MFMA steps, 2 = skip staging transform+loads

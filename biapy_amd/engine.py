@@ -232,8 +232,10 @@ class ResUNetEngine:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def _res_block_fwd(self, P, blk: _Blk, B, img: Optional[torch.Tensor], st, cache: bool, want_out_stats: bool):
-        """Runs one residual block. Returns partial stats (part, tiles) of the block output if requested."""
+    def _res_block_fwd(self, P, blk: _Blk, B, img: Optional[torch.Tensor], st, cache: bool, want_out_stats: bool, pool=None):
+        """Runs one residual block. Returns partial stats (part, tiles) of the block output if requested.
+        pool = (z stride, pooled tensor, its partial-statistics tensor): fuse the MaxPool3d that follows an encoder block into
+        the epilogue of the block's last convolution (bpx_conv3d_fwd_pool; the caller checked that it is supported)."""
         D, H, W = blk.S
         dev = blk.out.device
         k = blk.keys
@@ -264,9 +266,14 @@ class ResUNetEngine:
         else:
             sc = L.tview(blk.x, blk.x_c0, blk.cin)
             wsc_ptr = self._pack(P[k["wsc"]], L.PK_K1, blk.cin, C1, cache).data_ptr()
-        L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, wp2.data_ptr(),
-                                   P[k["b2"]].data_ptr(), sc, wsc_ptr, P[k["bsc"]].data_ptr(),
-                                   L.tview(blk.out, blk.out_c0, C1), L.ptr(part2), st))
+        if pool is not None:
+            L.check(lib.bpx_conv3d_fwd_pool(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, wp2.data_ptr(),
+                                            P[k["b2"]].data_ptr(), sc, wsc_ptr, P[k["bsc"]].data_ptr(),
+                                            L.tview(blk.out, blk.out_c0, C1), L.ptr(part2), pool[0], L.tview(pool[1]), pool[2].data_ptr(), st))
+        else:
+            L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, wp2.data_ptr(),
+                                       P[k["b2"]].data_ptr(), sc, wsc_ptr, P[k["bsc"]].data_ptr(),
+                                       L.tview(blk.out, blk.out_c0, C1), L.ptr(part2), st))
         return part2, tiles2
 
     # ------------------------------------------------------------------------------------------
@@ -320,15 +327,24 @@ class ResUNetEngine:
         for i in range(Lv):
             blk = _Blk(keys=block_keys(f"down_path.{i}", i == 0), first=(i == 0), S=S[i], cin=(cfg.in_ch if i == 0 else fm[i - 1]),
                        cout=fm[i], x=cur, x_c0=0, rec_x=cur_rec, h=buf(i, fm[i]), out=cat[i], out_c0=fm[i + 1])
-            part, tiles = self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=True)
-            out_stats.append((part, tiles))
-            blocks.append(blk)
-            # pool -> P_i (+ stats) and the pre-norm record of the next block
+            # pool -> P_i (+ stats) and the pre-norm record of the next block; fused into the block's last conv where the
+            # lean kernel runs (>= 64^3 levels, bf16): the output slice is then not read again
             pooled = buf(i + 1, fm[i])
             D, H, W = S[i]
-            ptiles = lib.bpx_maxpool3d_stats_tiles(self.dt, D, H, W, cfg.z_down[i], fm[i])
-            ppart = _Stats.alloc(B, ptiles, fm[i], dev)
-            L.check(lib.bpx_maxpool3d_fwd(self.dt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], fm[i + 1], fm[i]), L.tview(pooled), ppart.data_ptr(), st))
+            k_ = blk.keys
+            fused = bool(lib.bpx_conv3d_fwd_pool_supported(self.dt, B, D, H, W, fm[i], cat[i].shape[-1], fm[i])) and all(
+                P[k_[q]].data_ptr() % 16 == 0 for q in ("b2", "bsc", "wsc"))
+            if fused:
+                ptiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, fm[i])
+                ppart = _Stats.alloc(B, ptiles, fm[i], dev)
+                part, tiles = self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=True, pool=(cfg.z_down[i], pooled, ppart))
+            else:
+                part, tiles = self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=True)
+                ptiles = lib.bpx_maxpool3d_stats_tiles(self.dt, D, H, W, cfg.z_down[i], fm[i])
+                ppart = _Stats.alloc(B, ptiles, fm[i], dev)
+                L.check(lib.bpx_maxpool3d_fwd(self.dt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], fm[i + 1], fm[i]), L.tview(pooled), ppart.data_ptr(), st))
+            out_stats.append((part, tiles))
+            blocks.append(blk)
             nxt = "bottleneck" if i == Lv - 1 else f"down_path.{i + 1}"
             rec = _recs(B, fm[i], dev)
             _Stats.finalize(ppart, B, ptiles, fm[i], S[i + 1][0] * S[i + 1][1] * S[i + 1][2], P[f"{nxt}.block.0.weight"],

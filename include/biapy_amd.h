@@ -125,6 +125,15 @@ int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor x, const bp
                    const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_packed_d,
                    const float* bias_sc_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
 int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout); /* partial-sum slots per sample the call above writes */
+/* The same convolution with the MaxPool3d (pool_sz,2,2) that follows an encoder block (resunet.py:256-257) fused into the
+ * epilogue: `pooled` (extents D/pool_sz, H/2, W/2) and its statistics partials ([n][tiles][2][Cout], same tile count) are
+ * written from registers, so the output slice is not read again.  Only where bpx_conv3d_fwd_pool_supported() returns 1
+ * (the lean bf16 kernel of the >= 64^3 levels); elsewhere use bpx_conv3d_fwd + bpx_maxpool3d_fwd. */
+int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                        const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_packed_d,
+                        const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
+                        float* pool_stats_part_d, bpx_stream_t stream);
+int bpx_conv3d_fwd_pool_supported(int dtype, int N, int D, int H, int W, int x_ld, int y_ld, int Cout);
 
 /* dgrad of the conv above w.r.t. its (normalised+activated) input, fused with the backward of that
  * activation:  g = convT(dy, W) * act'(scale*t+shift),  t = the conv's raw input tensor.

@@ -239,6 +239,45 @@ def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=
     return res
 
 
+def check_conv3d_fwd_pool(B, S, Cin, Cout, sz, seed=0):
+    """bpx_conv3d_fwd_pool (MaxPool3d fused into the lean kernel's epilogue) == bpx_conv3d_fwd followed by bpx_maxpool3d_fwd:
+    the same bf16 output bits, the same pooled bits, the same statistics partial sums."""
+    dt = L.BF16
+    D, H, W = S
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    rec, _, _ = make_recs(B, Cin, seed + 1)
+    xd, recd, bd = to_dev(x, dt), rec.to(DEV), bias.to(DEV)
+    wp = pack(w, L.PK_K3, Cin, Cout, dt)
+    tiles = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, Cout)
+    tag = f"conv3d_fwd_pool[B{B} {S} {Cin}->{Cout} sz{sz}]"
+    if not lib.bpx_conv3d_fwd_pool_supported(dt, B, D, H, W, Cin, Cout, Cout):
+        return [_res(tag + ".supported", 1, 0)]
+    outs = []
+    for fused in (False, True):
+        y = torch.zeros(B, D, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        part = torch.zeros(B, tiles, 2, Cout, dtype=torch.float32, device=DEV)
+        pooled = torch.zeros(B, D // sz, H // 2, W // 2, Cout, dtype=torch.bfloat16, device=DEV)
+        if fused:
+            ppart = torch.zeros(B, tiles, 2, Cout, dtype=torch.float32, device=DEV)
+            L.check(lib.bpx_conv3d_fwd_pool(dt, B, D, H, W, L.tview(xd), recd.data_ptr(), 1, wp.data_ptr(), bd.data_ptr(), L.NULL_T, None, None,
+                                            L.tview(y), part.data_ptr(), sz, L.tview(pooled), ppart.data_ptr(), L.stream_ptr()))
+        else:
+            L.check(lib.bpx_conv3d_fwd(dt, B, D, H, W, L.tview(xd), recd.data_ptr(), 1, wp.data_ptr(), bd.data_ptr(), L.NULL_T, None, None, L.tview(y),
+                                       part.data_ptr(), L.stream_ptr()))
+            pt = lib.bpx_maxpool3d_stats_tiles(dt, D, H, W, sz, Cout)
+            ppart = torch.zeros(B, pt, 2, Cout, dtype=torch.float32, device=DEV)
+            L.check(lib.bpx_maxpool3d_fwd(dt, B, D, H, W, sz, L.tview(y), L.tview(pooled), ppart.data_ptr(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((y, pooled, part.sum(1), ppart.sum(1)))
+    (y0, p0, s0, q0), (y1, p1, s1, q1) = outs
+    return [_res(tag + ".y_bits", int((y0.view(torch.int16) != y1.view(torch.int16)).sum().item()), 0),
+            _res(tag + ".pooled_bits", int((p0.view(torch.int16) != p1.view(torch.int16)).sum().item()), 0),
+            _res(tag + ".stats", relerr(s1, s0), 1e-5), _res(tag + ".pool_stats", relerr(q1, q0), 1e-5)]
+
+
 def check_conv3d_dgrad(dt, B, S, Cin, Cout, seed=0, act=1):
     """g = conv_transpose(dy, W) * act'(scale*t+shift) and its two reductions."""
     D, H, W = S

@@ -63,6 +63,15 @@ def test_conv3d_bf16_kernel_variants(K, variant):
     _assert_all(rows)
 
 
+def test_conv3d_fused_maxpool_is_bit_identical(K):
+    rows = []
+    rows += K.check_conv3d_fwd_pool(1, (64, 64, 64), 16, 16, 2)          # big tile, z pairs through LDS
+    rows += K.check_conv3d_fwd_pool(1, (64, 64, 64), 32, 32, 2)          # 4x4x16 tile, NS = 2
+    rows += K.check_conv3d_fwd_pool(2, (32, 72, 120), 16, 16, 1)         # anisotropic level (no z pooling), partial tiles
+    rows += K.check_conv3d_fwd_pool(1, (68, 66, 70), 16, 32, 2)          # ragged in every axis
+    _assert_all(rows)
+
+
 @pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
 def test_conv3d_backward_kernels(K, dt):
     rows = []
