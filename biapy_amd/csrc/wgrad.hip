@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // Lean schedule as in conv3d_lean.hip: no register prefetch across the MFMA phase, <= 128 (NS=1) / 168 VGPRs, 29 / 50 KB
 // LDS -> 4 / 3 workgroups per CU; 32-bit byte offsets; per-tile index math reduced to base + per-lane constants.
 template <int NS, int ACTK>
-__global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const WgradParams p) {
   using T = uint16_t;
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
@@ -428,8 +428,36 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const Wg
     const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
     const uint32_t base_g = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.dy_ld * 2u;
 
-    u32x4_t pa[NPA], pg[NPG];
+    // dy pieces move in batches of GB registers: everything in flight at once for NS = 1; two batches for NS = 2 so that
+    // the kernel stays below 168 VGPRs (3 workgroups per CU) without scratch
+    constexpr int GB = (NS == 1) ? NPG : 6;
+    u32x4_t pa[NPA], pg[GB];
     bool oka[NPA];
+    auto load_g = [&](int b0) {
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int u = b0 + q;
+        pg[q] = u32x4_t{0u, 0u, 0u, 0u};
+        if (u < NPG) {
+          bool ok = (u < NPG - 1) || last_ok;
+          if (!interior) {
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            const int hv = (u * 256 + tid_o) / PPVG;
+            const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+            ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+          }
+          if (ok) pg[q] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + rel_g[u]));
+        }
+      }
+    };
+    auto store_g = [&](int b0) {
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const int u = b0 + q;
+        if (u < NPG && (u < NPG - 1 || last_ok)) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[q];
+      }
+    };
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
       const int t = (u * 256 + tid) >> 1;
@@ -437,19 +465,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const Wg
       pa[u] = u32x4_t{0u, 0u, 0u, 0u};
       if (oka[u]) pa[u] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a[u]));
     }
-#pragma unroll
-    for (int u = 0; u < NPG; ++u) {
-      bool ok = (u < NPG - 1) || last_ok;
-      if (!interior) {
-        int tid_o = tid;
-        asm volatile("" : "+v"(tid_o));
-        const int hv = (u * 256 + tid_o) / PPVG;
-        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-        ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
-      }
-      pg[u] = u32x4_t{0u, 0u, 0u, 0u};
-      if (ok) pg[u] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + rel_g[u]));
-    }
+    load_g(0);
     if (p.in_norm && n != n_cur) {
 #pragma unroll
       for (int e = 0; e < KPL; ++e) {
@@ -472,9 +488,9 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const Wg
       }
       *reinterpret_cast<u32x4_t*>(sA + (size_t)(u * 256 + tid) * 16) = v;
     }
+    store_g(0);
 #pragma unroll
-    for (int u = 0; u < NPG; ++u)
-      if (u < NPG - 1 || last_ok) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[u];
+    for (int b0 = GB; b0 < NPG; b0 += GB) { load_g(b0); store_g(b0); }
     __syncthreads();
 
     if (p.db != nullptr && chunk == 0) {  // bias gradient: column sums of dy over the tile's own voxels
@@ -496,22 +512,29 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_sd_kernel(const Wg
         u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
         af = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
       }
+      // taps in groups of TG: all dy fragments of a group are fetched before its MFMAs (one LDS wait per group); NS = 2
+      // uses two groups to halve the fragment registers
+      constexpr int TG = (NS == 1) ? NT : 4;
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+      for (int a0 = 0; a0 < NT; a0 += TG) {
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) {
-          const unsigned char* q = sG + g_base[a] + kg + ns * 32;
-          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
-          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
-          u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-          gf[a][ns] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
-        }
-      __builtin_amdgcn_sched_barrier(0);
+        for (int a = a0; a < a0 + TG && a < NT; ++a)
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+          for (int ns = 0; ns < NS; ++ns) {
+            const unsigned char* q = sG + g_base[a] + kg + ns * 32;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
+            u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+            gf[a][ns] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+          }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
-          acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[a][ns], 0, 0, 0);
+        for (int a = a0; a < a0 + TG && a < NT; ++a)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[a][ns], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -741,7 +764,8 @@ inline WCfg pick_wcfg(int N, int D, int H, int W, int Cin, int Cout, int taps, b
     int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / dwElems);           // keep the partial slab <= ~50 MB round trip
     int groups = (int)std::min<int64_t>(std::min<int64_t>(totalTiles, cap), std::max(1, cdiv(2048, nchunks * nb)));
     c.ns = ns; c.groups = groups;
-    if (ns == 1 || (int64_t)groups * nchunks * nb >= 512) break;
+    const int minblk = ((int64_t)D * H * W <= 512) ? 128 : 512;   // 8^3 bottleneck: wider co blocks win (82 -> 61 us); elsewhere NS = 1
+    if (ns == 1 || (int64_t)groups * nchunks * nb >= minblk) break;
     ns >>= 1;                                                                  // not enough workgroups: split the co blocks finer
   }
   return c;
