@@ -1075,7 +1075,9 @@ extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16 && W > 8 && ((uintptr_t)dy.ptr & 15) == 0 && (dy.ld & 7) == 0) {
     const int tiles = N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
-    dim3 gm((unsigned)std::min(tiles, 2048), (unsigned)(dy.C / 16));
+    // 768 workgroups (3 per CU): every workgroup ends with 448 fp32 atomics on the same addresses - 2048 workgroups spent more
+    // time in that contention than in the kernel proper (277 vs 173 us)
+    dim3 gm((unsigned)std::min(tiles, 768), (unsigned)(dy.C / 16));
     conv_c1_wgrad_mfma_kernel<<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, dw_d, db_d);
   } else if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
   else if (dtype == BPX_F32) conv_c1_wgrad_kernel<float><<<grid, 256, 0, s>>>(img_d, (const float*)dy.ptr, dy.ld, D, H, W, N, totalTiles, dw_d, db_d);
