@@ -45,6 +45,14 @@ _SIGS = {
     "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
     "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_pack_weights_batched": ([_i, _i, _vp, _vp], _i),
+    "bpx_scan_blocks": ([_i64], _i),
+    "bpx_select_workspace": ([], _i64),
+    "bpx_select_kth_f32": ([_vp, _i64, _i64, _vp, _vp, _vp], _i),
+    "bpx_minmax_f32": ([_vp, _i64, _vp, _vp], _i),
+    "bpx_moment_f32": ([_vp, _i64, C.c_double, _i, _vp, _vp], _i),
+    "bpx_histogram_f32": ([_vp, _i64, _f, _f, _i, _vp, _vp, _vp], _i),
+    "bpx_threshold_u8": ([_vp, _i64, _f, _vp, _vp], _i),
+    "bpx_clip_affine_f32": ([_vp, _i64, _f, _f, _f, _f, _vp, _vp], _i),
     "bpx_seg_loss_blocks": ([_i64], _i),
     "bpx_seg_loss_sums": ([_vp, _vp, _i64, _vp, _vp], _i),
     "bpx_seg_loss_bwd": ([_vp, _vp, _i64, _vp, _vp, _vp], _i),

@@ -240,6 +240,27 @@ int bpx_seg_loss_blocks(int64_t n);
 int bpx_seg_loss_sums(const float* logits_d, const float* target_d, int64_t n, float* partials_d, bpx_stream_t stream);
 int bpx_seg_loss_bwd(const float* logits_d, const float* target_d, int64_t n, const float* coef_d, float* dlogits_d, bpx_stream_t stream);
 
+/* ---- scans either side of the network ---------------------------------------------------------------
+ * Input normalisation (biapy/data/norm.py: percentile_clip :395-473 -> np.percentile, zero_mean_unit_variance_normalization
+ * :586-645) and the Otsu binarisation after the merge (biapy/engine/semantic_seg.py:418-431) on volumes that live on the device.
+ *   bpx_select_kth_f32 : exact k-th smallest element (0-based), 4-pass radix select, result written to out_d (device float)
+ *   bpx_minmax_f32     : per-block {min, max} partials, bpx_scan_blocks(n) rows
+ *   bpx_moment_f32     : per-block partial sums of (x - center)^power in double (power 1 or 2), bpx_scan_blocks(n) rows
+ *   bpx_histogram_f32  : np.histogram(a, bins=nbins, range=(first, last)) of a float32 array, bit-identical counts;
+ *                        edges_d = the float32 edge table NumPy builds (np.linspace(first, last, nbins + 1, dtype=float32));
+ *                        counts_d (uint64[nbins]) is ACCUMULATED into (zero it first)
+ *   bpx_threshold_u8   : out = x > thr
+ *   bpx_clip_affine_f32: out = (clip(x, lo, hi) - sub) / div in float32 operations */
+int bpx_scan_blocks(int64_t n);
+int64_t bpx_select_workspace(void);
+int bpx_select_kth_f32(const float* x_d, int64_t n, int64_t k, float* out_d, void* ws_d, bpx_stream_t stream);
+int bpx_minmax_f32(const float* x_d, int64_t n, float* partials_d, bpx_stream_t stream);
+int bpx_moment_f32(const float* x_d, int64_t n, double center, int power, double* partials_d, bpx_stream_t stream);
+int bpx_histogram_f32(const float* x_d, int64_t n, float first_edge, float last_edge, int nbins, const float* edges_d,
+                      unsigned long long* counts_d, bpx_stream_t stream);
+int bpx_threshold_u8(const float* x_d, int64_t n, float thr, uint8_t* out_d, bpx_stream_t stream);
+int bpx_clip_affine_f32(const float* x_d, int64_t n, float lo, float hi, float sub, float div, float* out_d, bpx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,5 +135,35 @@ def main():
         print(f"crop  512^3 -> {plan.n_patches} x 128^3: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)")
 
 
+def bench_prepost(reps=5):
+    """HBM-bound scans of biapy_amd.prepost on a 512^3 float32 volume (537 MB)."""
+    from biapy_amd import prepost
+
+    n = 512 ** 3
+    x = torch.rand(n, device=DEV) * 100
+    st = L.stream_ptr()
+    ws = torch.empty(int(lib.bpx_select_workspace()), dtype=torch.uint8, device=DEV)
+    out = torch.empty(1, device=DEV)
+    ms = timeit(lambda: L.check(lib.bpx_select_kth_f32(x.data_ptr(), n, n // 100, out.data_ptr(), ws.data_ptr(), st)), reps)
+    print(f"select_kth (4 passes) 512^3: {ms * 1e3:9.1f} us  {4 * n * 4 / ms / 1e6:8.1f} GB/s")
+    edges = torch.linspace(0, 100, 257, device=DEV)
+    counts = torch.zeros(256, dtype=torch.int64, device=DEV)
+    ms = timeit(lambda: L.check(lib.bpx_histogram_f32(x.data_ptr(), n, 0.0, 100.0, 256, edges.data_ptr(), counts.data_ptr(), st)), reps)
+    print(f"histogram256          512^3: {ms * 1e3:9.1f} us  {n * 4 / ms / 1e6:8.1f} GB/s")
+    o8 = torch.empty(n, dtype=torch.uint8, device=DEV)
+    ms = timeit(lambda: L.check(lib.bpx_threshold_u8(x.data_ptr(), n, 50.0, o8.data_ptr(), st)), reps)
+    print(f"threshold -> u8       512^3: {ms * 1e3:9.1f} us  {n * 5 / ms / 1e6:8.1f} GB/s")
+    o = torch.empty_like(x)
+    ms = timeit(lambda: L.check(lib.bpx_clip_affine_f32(x.data_ptr(), n, 1.0, 99.0, 50.0, 20.0, o.data_ptr(), st)), reps)
+    print(f"clip + normalise      512^3: {ms * 1e3:9.1f} us  {n * 8 / ms / 1e6:8.1f} GB/s")
+    part = torch.empty(lib.bpx_scan_blocks(n), dtype=torch.float64, device=DEV)
+    ms = timeit(lambda: L.check(lib.bpx_moment_f32(x.data_ptr(), n, 50.0, 2, part.data_ptr(), st)), reps)
+    print(f"moment (double acc.)  512^3: {ms * 1e3:9.1f} us  {n * 4 / ms / 1e6:8.1f} GB/s")
+    del prepost
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "prepost":
+        bench_prepost()
+        sys.exit(0)
     main()

@@ -224,6 +224,33 @@ def resunet_fixtures():
     print("resunet_golden.npz:", len(out), "arrays")
 
 
+def synth_prepost(seed, shape):
+    """Seeded intensity volume with a heavy tail (so that percentile clipping matters) - tests regenerate it."""
+    rs = np.random.RandomState(5000 + seed)
+    v = rs.gamma(2.0, 30.0, size=shape).astype(np.float32) + rs.rand(*shape).astype(np.float32)
+    v[rs.rand(*shape) < 0.001] = 4000.0
+    return v
+
+
+def prepost_fixtures():
+    """biapy/data/norm.py outputs (percentile_clip, zero_mean_unit_variance_normalization) on seeded volumes."""
+    nm = shim.load("biapy.data.norm")
+    out = {}
+    for seed, (name, shape, lo, hi) in enumerate([("a", (20, 33, 47), 0.2, 99.8), ("b", (64, 64, 64), 1.0, 99.0), ("c", (7, 130, 131), 5.0, 50.0)]):
+        v = synth_prepost(seed, shape)
+        clipped, x_lwr, x_upr = nm.percentile_clip(v.copy(), lo, hi)
+        normed, mean, std = nm.zero_mean_unit_variance_normalization(clipped.copy())
+        out[f"{name}/args"] = np.array(list(shape), dtype=np.int64)
+        out[f"{name}/pct"] = np.array([lo, hi], dtype=np.float64)
+        out[f"{name}/seed"] = np.array(seed)
+        out[f"{name}/bounds"] = np.array([x_lwr, x_upr], dtype=np.float64)
+        out[f"{name}/mean_std"] = np.array([mean, std], dtype=np.float64)
+        out[f"{name}/clipped_crc"] = np.array([int(np.frombuffer(clipped.tobytes(), dtype=np.uint8).astype(np.uint64).sum())])
+        out[f"{name}/normed_slice"] = normed[shape[0] // 2, ::3, ::5].copy()
+    np.savez_compressed(os.path.join(HERE, "prepost_golden.npz"), **out)
+    print("prepost_golden.npz:", len(out), "arrays")
+
+
 def resunet_aniso_fixtures():
     """Anisotropic ResUNet (MODEL.Z_DOWN = [1, 2]: pooling / transposed conv (1,2,2) at the first level): reference logits,
     loss and every gradient of a small net (fm 16-32-64, 8x32x32 patches)."""
@@ -282,7 +309,9 @@ def resunet_aniso_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost"]
+    if "prepost" in which:
+        prepost_fixtures()
     if "tiling" in which:
         tiling_fixtures()
     if "tiling2d" in which:

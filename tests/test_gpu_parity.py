@@ -262,3 +262,43 @@ def test_tiling2d_dropins_bit_exact(tiling2d_golden, name):
     merged, merged_mask = tiling.merge_data_with_overlap(pred, dshape, data_mask=pm, overlap=ov, padding=pad, verbose=False)
     np.testing.assert_array_equal(merged.view(np.uint32), g[f"{name}/merged"].view(np.uint32))
     np.testing.assert_array_equal(merged_mask, g[f"{name}/merged_mask"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_prepost_scans(prepost_golden, name):
+    """biapy_amd.prepost on the device: percentile bounds bit-identical to the reference (np.percentile), clipped volume
+    bit-identical, mean/std to 1e-6 relative, histogram counts identical to np.histogram, Otsu mask identical to the oracle."""
+    import numpy as np
+
+    from biapy_amd import prepost
+    from oracle import prepost_oracle as PO
+    from test_oracle_golden import _prepost_volume
+
+    g = prepost_golden
+    shape = tuple(int(v) for v in g[f"{name}/args"])
+    lo, hi = (float(v) for v in g[f"{name}/pct"])
+    v = _prepost_volume(int(g[f"{name}/seed"]), shape)
+    vd = torch.from_numpy(v).cuda()
+    srt = np.sort(v.reshape(-1))
+    ranks = [0, 1, v.size // 3, v.size - 2, v.size - 1]
+    assert prepost.kth_values(vd, ranks) == [float(srt[k]) for k in ranks]
+    clipped, x_lwr, x_upr = prepost.percentile_clip(vd, lo, hi)
+    assert (x_lwr, x_upr) == tuple(float(b) for b in g[f"{name}/bounds"]), (x_lwr, x_upr, g[f"{name}/bounds"])
+    cn = clipped.cpu().numpy()
+    assert int(np.frombuffer(cn.tobytes(), dtype=np.uint8).astype(np.uint64).sum()) == int(g[f"{name}/clipped_crc"][0])
+    normed, mean, std = prepost.zero_mean_unit_variance_normalization(clipped)
+    mref, sref = (float(b) for b in g[f"{name}/mean_std"])
+    assert abs(mean - mref) <= 1e-6 * abs(mref) and abs(std - sref) <= 1e-6 * sref, (mean, mref, std, sref)   # stated tolerance
+    ref_slice = g[f"{name}/normed_slice"]
+    got_slice = normed.cpu().numpy()[shape[0] // 2, ::3, ::5]
+    assert np.abs(got_slice - ref_slice).max() <= 2e-6 * max(1.0, np.abs(ref_slice).max())
+    # histogram: identical counts; Otsu threshold and mask identical to the oracle's (which uses np.histogram)
+    pred = torch.sigmoid((vd - 60.0) / 25.0)
+    pn = pred.cpu().numpy()
+    counts, edges = prepost.histogram(pred, 256)
+    rc, re_ = np.histogram(pn.reshape(-1), bins=256, range=(pn.min(), pn.max()))
+    np.testing.assert_array_equal(counts, rc)
+    np.testing.assert_array_equal(edges, re_)
+    assert prepost.threshold_otsu(pred) == PO.threshold_otsu(pn)
+    np.testing.assert_array_equal(prepost.binarize(pred).cpu().numpy(), PO.binarize(pn))

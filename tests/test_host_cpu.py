@@ -85,3 +85,13 @@ def test_losses_fail_loudly_without_gpu():
         losses.DiceCELoss()(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
     with pytest.raises(NotImplementedError):
         losses.DiceLoss(batch_dice=False)
+
+
+def test_prepost_fails_loudly_without_gpu():
+    import pytest
+    import torch
+
+    from biapy_amd import prepost
+
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        prepost.threshold_otsu(torch.zeros(4, 4, 4))

@@ -169,3 +169,27 @@ def test_net_oracle_anisotropic_matches_reference(resunet_aniso_golden):
         if k.startswith("grad/"):
             ref = torch.from_numpy(g[k])
             assert (grads[k[5:]] - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
+
+
+def _prepost_volume(seed, shape):
+    rs = np.random.RandomState(5000 + seed)
+    v = rs.gamma(2.0, 30.0, size=shape).astype(np.float32) + rs.rand(*shape).astype(np.float32)
+    v[rs.rand(*shape) < 0.001] = 4000.0
+    return v
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_prepost_oracle_matches_reference(prepost_golden, name):
+    """percentile_clip / zero_mean_unit_variance_normalization (biapy/data/norm.py) restated: same bounds, bits, moments."""
+    from oracle import prepost_oracle as PO
+
+    g = prepost_golden
+    shape = tuple(int(v) for v in g[f"{name}/args"])
+    lo, hi = (float(v) for v in g[f"{name}/pct"])
+    v = _prepost_volume(int(g[f"{name}/seed"]), shape)
+    clipped, x_lwr, x_upr = PO.percentile_clip(v.copy(), lo, hi)
+    assert (x_lwr, x_upr) == tuple(float(b) for b in g[f"{name}/bounds"])
+    assert int(np.frombuffer(clipped.tobytes(), dtype=np.uint8).astype(np.uint64).sum()) == int(g[f"{name}/clipped_crc"][0])
+    normed, mean, std = PO.zero_mean_unit_variance_normalization(clipped.copy())
+    assert (mean, std) == tuple(float(b) for b in g[f"{name}/mean_std"])
+    np.testing.assert_array_equal(normed[shape[0] // 2, ::3, ::5], g[f"{name}/normed_slice"])
