@@ -53,6 +53,8 @@ _SIGS = {
     "bpx_histogram_f32": ([_vp, _i64, _f, _f, _i, _vp, _vp, _vp], _i),
     "bpx_threshold_u8": ([_vp, _i64, _f, _vp, _vp], _i),
     "bpx_clip_affine_f32": ([_vp, _i64, _f, _f, _f, _f, _vp, _vp], _i),
+    "bpx_tta_orient": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "bpx_tta_accumulate": ([_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_seg_loss_blocks": ([_i64], _i),
     "bpx_seg_loss_sums": ([_vp, _vp, _i64, _vp, _vp], _i),
     "bpx_seg_loss_bwd": ([_vp, _vp, _i64, _vp, _vp, _vp], _i),

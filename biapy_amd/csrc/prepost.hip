@@ -232,3 +232,85 @@ extern "C" int bpx_clip_affine_f32(const float* x_d, int64_t n, float lo, float 
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
+
+// ---- test-time augmentation: signed axis permutations of (Z,Y,X,C) volumes ---------------------------
+// biapy/data/post_processing/tta.py:64-196 (AxisTransform: output axis a comes from input axis perm[a], reversed when
+// sign[a] == -1) and post_processing.py:1386-1540 (ensemble_predictions: predict every orientation, undo it, reduce).
+// orient    : out = t.apply(in)                                   (gather, out has the permuted extents)
+// accumulate: acc (op)= t.inverse.apply(pred_t), op = first ? assign : add / min / max - called once per orientation in the
+//             reference's order, so the float32 sum is the same sequential sum np.mean(stack, axis=0) forms.
+namespace {
+struct Orient { int n_in[3]; int perm[3]; int sign[3]; int C; };
+
+__global__ void __launch_bounds__(256) tta_orient_kernel(const float* __restrict__ in, float* __restrict__ out, Orient t, int64_t total) {
+  const int no[3] = {t.n_in[t.perm[0]], t.n_in[t.perm[1]], t.n_in[t.perm[2]]};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(q % t.C);
+    int64_t v = q / t.C;
+    int o[3];
+    o[2] = (int)(v % no[2]); v /= no[2];
+    o[1] = (int)(v % no[1]); o[0] = (int)(v / no[1]);
+    int i[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) i[t.perm[a]] = t.sign[a] > 0 ? o[a] : no[a] - 1 - o[a];
+    out[q] = in[(((int64_t)i[0] * t.n_in[1] + i[1]) * t.n_in[2] + i[2]) * t.C + c];
+  }
+}
+
+// acc is in the un-oriented frame (extents n_in), pred in the oriented frame; mode 0 mean-sum, 1 min, 2 max
+__global__ void __launch_bounds__(256) tta_accumulate_kernel(const float* __restrict__ pred, float* __restrict__ acc, Orient t, int mode,
+                                                             int first, float scale, int64_t total) {
+  const int no[3] = {t.n_in[t.perm[0]], t.n_in[t.perm[1]], t.n_in[t.perm[2]]};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(q % t.C);
+    int64_t v = q / t.C;
+    int i[3];
+    i[2] = (int)(v % t.n_in[2]); v /= t.n_in[2];
+    i[1] = (int)(v % t.n_in[1]); i[0] = (int)(v / t.n_in[1]);
+    int o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[a] = t.sign[a] > 0 ? i[t.perm[a]] : no[a] - 1 - i[t.perm[a]];
+    const float p = pred[(((int64_t)o[0] * no[1] + o[1]) * no[2] + o[2]) * t.C + c];
+    float r = first ? p : (mode == 0 ? acc[q] + p : mode == 1 ? fminf(acc[q], p) : fmaxf(acc[q], p));
+    if (scale != 1.f) r = r / scale;     // last orientation of "mean": the sum divided by the count, as np.mean does
+    acc[q] = r;
+  }
+}
+
+int fill_orient(const char* fn, Orient& t, int Z, int Y, int X, int C, const int* perm, const int* sign) {
+  BPX_CHECK(Z > 0 && Y > 0 && X > 0 && C > 0, "%s: empty volume", fn);
+  bool seen[3] = {false, false, false};
+  for (int a = 0; a < 3; ++a) {
+    BPX_CHECK(perm[a] >= 0 && perm[a] < 3 && !seen[perm[a]], "%s: perm must be a permutation of (0,1,2)", fn);
+    BPX_CHECK(sign[a] == 1 || sign[a] == -1, "%s: sign entries must be +1 or -1", fn);
+    seen[perm[a]] = true;
+    t.perm[a] = perm[a]; t.sign[a] = sign[a];
+  }
+  t.n_in[0] = Z; t.n_in[1] = Y; t.n_in[2] = X; t.C = C;
+  return 0;
+}
+}  // namespace
+
+extern "C" int bpx_tta_orient(const float* in_d, int Z, int Y, int X, int C, const int* perm, const int* sign, float* out_d, bpx_stream_t stream) {
+  const char* fn = "bpx_tta_orient";
+  BPX_CHECK(in_d && out_d && perm && sign, "%s: null pointer", fn);
+  Orient t;
+  if (fill_orient(fn, t, Z, Y, X, C, perm, sign)) return 1;
+  const int64_t total = (int64_t)Z * Y * X * C;
+  tta_orient_kernel<<<blocks_for(total), 256, 0, (hipStream_t)stream>>>(in_d, out_d, t, total);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_tta_accumulate(const float* pred_d, int Z, int Y, int X, int C, const int* perm, const int* sign, int mode, int first,
+                                  int count_if_last, float* acc_d, bpx_stream_t stream) {
+  const char* fn = "bpx_tta_accumulate";
+  BPX_CHECK(pred_d && acc_d && perm && sign, "%s: null pointer", fn);
+  BPX_CHECK(mode >= 0 && mode <= 2, "%s: mode must be 0 (mean), 1 (min) or 2 (max)", fn);
+  Orient t;
+  if (fill_orient(fn, t, Z, Y, X, C, perm, sign)) return 1;
+  const int64_t total = (int64_t)Z * Y * X * C;
+  tta_accumulate_kernel<<<blocks_for(total), 256, 0, (hipStream_t)stream>>>(pred_d, acc_d, t, mode, first, (mode == 0 && count_if_last > 0) ? (float)count_if_last : 1.f, total);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}

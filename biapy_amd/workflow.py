@@ -164,8 +164,12 @@ class SlidingWindowPredictor:
     """crop -> forward -> merge of one volume, entirely on the device(s)."""
 
     def __init__(self, model, patch_zyx: Sequence[int], overlap=(0.5, 0.5, 0.5), padding=(0, 0, 0), batch_size: int = 4,
-                 pad_type: str = "reflect", forward: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 pad_type: str = "reflect", forward: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 tta: Optional[str] = None, tta_mode: str = "mean"):
+        """tta: None, or the orientation group of TEST.AUGMENTATION ("full" = 16 orientations in 3D, "flips" = 8): every patch
+        is then predicted through ``biapy_amd.tta.ensemble_predictions`` (predict_batches_in_test, base_workflow.py:1659-1673)."""
         self.model = model
+        self.tta, self.tta_mode = tta, tta_mode
         self.patch = tuple(int(p) for p in patch_zyx)
         self.overlap, self.padding, self.batch, self.pad_type = tuple(overlap), tuple(padding), int(batch_size), pad_type
         # forward: (B,C,Z,Y,X) fp32 -> (B,Cout,Z,Y,X) fp32 probabilities (ce_sigmoid head)
@@ -187,10 +191,17 @@ class SlidingWindowPredictor:
         for b0 in range(0, n_mine, self.batch):
             nb = min(self.batch, n_mine - b0)
             xb = tiling.crop_device(vol, self.patch, self.overlap, self.padding, self.pad_type, c_begin=lo * ny * nx + b0, c_count=nb)
-            out = self.forward(xb.permute(0, 4, 1, 2, 3))                         # to_pytorch_format (misc.py:689-713)
+            if self.tta:
+                from . import tta as _tta
+
+                outs = [_tta.ensemble_predictions(xb[q], lambda b: self.forward(b.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1), 3,
+                                                  batch_size_value=self.batch, mode=self.tta_mode, group=self.tta) for q in range(nb)]
+                out5 = torch.stack(outs, 0)                                       # (nb, Z, Y, X, Cout)
+            else:
+                out5 = self.forward(xb.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)   # to_pytorch_format / to_numpy_format (misc.py:689-733)
             if pred is None:
-                pred = torch.empty((n_mine,) + self.patch + (out.shape[1],), dtype=torch.float32, device=vol.device)
-            pred[b0:b0 + nb] = out.permute(0, 2, 3, 4, 1)                         # to_numpy_format, on the device
+                pred = torch.empty((n_mine,) + self.patch + (out5.shape[-1],), dtype=torch.float32, device=vol.device)
+            pred[b0:b0 + nb] = out5
         if pred is None:
             pred = torch.empty((0,) + self.patch + (1,), dtype=torch.float32, device=vol.device)
         cout = pred.shape[-1]

@@ -261,6 +261,17 @@ int bpx_histogram_f32(const float* x_d, int64_t n, float first_edge, float last_
 int bpx_threshold_u8(const float* x_d, int64_t n, float thr, uint8_t* out_d, bpx_stream_t stream);
 int bpx_clip_affine_f32(const float* x_d, int64_t n, float lo, float hi, float sub, float div, float* out_d, bpx_stream_t stream);
 
+/* ---- test-time augmentation -------------------------------------------------------------------------
+ * Signed axis permutations of a (Z,Y,X,C) float32 volume (biapy/data/post_processing/tta.py:64-196, AxisTransform: output
+ * axis a comes from input axis perm[a], reversed when sign[a] == -1; 2D images use Z = 1) and the reduction of
+ * post_processing.py:1349-1383.  (Z,Y,X) are always the extents of the UN-oriented volume.
+ *   bpx_tta_orient     : out = t.apply(in); out has extents (n[perm[0]], n[perm[1]], n[perm[2]])
+ *   bpx_tta_accumulate : acc (op)= t.inverse.apply(pred), op: first != 0 -> assign, else mode 0 add / 1 min / 2 max;
+ *                        count_if_last > 0 with mode 0 divides the finished sum by that count (np.mean's sum / n). */
+int bpx_tta_orient(const float* in_d, int Z, int Y, int X, int C, const int* perm, const int* sign, float* out_d, bpx_stream_t stream);
+int bpx_tta_accumulate(const float* pred_d, int Z, int Y, int X, int C, const int* perm, const int* sign, int mode, int first,
+                       int count_if_last, float* acc_d, bpx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,13 @@ def resunet_aniso_golden():
 
 
 @pytest.fixture(scope="session")
+def tta_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "tta_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def prepost_golden():
     import numpy as np
 

@@ -224,6 +224,34 @@ def resunet_fixtures():
     print("resunet_golden.npz:", len(out), "arrays")
 
 
+def tta_fixtures():
+    """Orientation groups and transforms of biapy/data/post_processing/tta.py (the part of TTA that imports here)."""
+    # the package __init__ pulls in post_processing.py (cv2, h5py, zarr, scikit-image: not installed); tta.py itself only needs
+    # NumPy, so it is loaded from its file
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_ref_tta", os.path.join(shim.REF, "biapy", "data", "post_processing", "tta.py"))
+    tt = importlib.util.module_from_spec(spec)
+    sys.modules["_ref_tta"] = tt
+    spec.loader.exec_module(tt)
+    out = {}
+    for ndim in (2, 3):
+        for level in ("full", "flips", "none"):
+            grp = tt.build_axis_transform_group(ndim, level=level)
+            out[f"group/{ndim}/{level}"] = np.array([list(t.perm) + list(t.sign) for t in grp], dtype=np.int64)
+    rs = np.random.RandomState(6000)
+    a3 = rs.rand(3, 4, 5, 2).astype(np.float32)
+    a2 = rs.rand(4, 6, 3).astype(np.float32)
+    out["a3"], out["a2"] = a3, a2
+    for name, arr, ndim in (("a3", a3, 3), ("a2", a2, 2)):
+        for n, t in enumerate(tt.build_axis_transform_group(ndim, level="full")):
+            out[f"apply/{name}/{n}"] = t.apply(arr)
+            out[f"roundtrip/{name}/{n}"] = t.inverse.apply(t.apply(arr))
+            out[f"inverse/{name}/{n}"] = np.array(list(t.inverse.perm) + list(t.inverse.sign), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "tta_golden.npz"), **out)
+    print("tta_golden.npz:", len(out), "arrays")
+
+
 def synth_prepost(seed, shape):
     """Seeded intensity volume with a heavy tail (so that percentile clipping matters) - tests regenerate it."""
     rs = np.random.RandomState(5000 + seed)
@@ -309,9 +337,11 @@ def resunet_aniso_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta"]
     if "prepost" in which:
         prepost_fixtures()
+    if "tta" in which:
+        tta_fixtures()
     if "tiling" in which:
         tiling_fixtures()
     if "tiling2d" in which:

@@ -193,3 +193,24 @@ def test_prepost_oracle_matches_reference(prepost_golden, name):
     normed, mean, std = PO.zero_mean_unit_variance_normalization(clipped.copy())
     assert (mean, std) == tuple(float(b) for b in g[f"{name}/mean_std"])
     np.testing.assert_array_equal(normed[shape[0] // 2, ::3, ::5], g[f"{name}/normed_slice"])
+
+
+def test_tta_group_and_transforms_match_reference(tta_golden):
+    """Orientation group (order included), apply and inverse of biapy/data/post_processing/tta.py: oracle and product."""
+    from biapy_amd import tta as T
+    from oracle import tta_oracle as TO
+
+    g = tta_golden
+    for ndim in (2, 3):
+        for level in ("full", "flips", "none"):
+            ref = g[f"group/{ndim}/{level}"]
+            for impl in (TO.group(ndim, level), T.build_axis_transform_group(ndim, level)):
+                got = np.array([list(p) + list(s) for p, s in impl], dtype=np.int64)
+                np.testing.assert_array_equal(got, ref)
+    for name, ndim in (("a3", 3), ("a2", 2)):
+        arr = g[name]
+        for n, (p, s) in enumerate(TO.group(ndim, "full")):
+            np.testing.assert_array_equal(TO.apply(arr, p, s), g[f"apply/{name}/{n}"])
+            ip, is_ = TO.inverse(p, s)
+            np.testing.assert_array_equal(np.array(list(ip) + list(is_)), g[f"inverse/{name}/{n}"])
+            np.testing.assert_array_equal(TO.apply(TO.apply(arr, p, s), ip, is_), g[f"roundtrip/{name}/{n}"])
