@@ -703,6 +703,33 @@ def check_sliding_window(dtype=torch.float32):
     return res
 
 
+def check_sliding_window_tta():
+    """SlidingWindowPredictor(tta="full"): every patch through the 16-orientation ensemble, vs the oracle pipeline on the CPU."""
+    from biapy_amd.resunet import ResUNet
+    from biapy_amd.workflow import SlidingWindowPredictor
+    from oracle import tta_oracle
+
+    fm = [16, 32]
+    sd = net_oracle.init_state_dict(1, fm, seed=6)
+    m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=fm, drop_values=[0.0, 0.0], normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    vol = np.random.RandomState(3).randn(24, 16, 28, 1).astype(np.float32)
+    ov, pad, patch = (0.25, 0.0, 0.5), (0, 0, 0), (16, 16, 16)
+    p, _ = TO.crop(vol, patch + (1,), ov, pad)
+
+    def f(b):                                                                      # (n, Z, Y, X, C) numpy -> probabilities
+        with torch.no_grad():
+            return torch.sigmoid(net_oracle.resunet_forward(sd, torch.from_numpy(np.ascontiguousarray(b)).permute(0, 4, 1, 2, 3), fm)).permute(0, 2, 3, 4, 1).contiguous().numpy()
+
+    pr = np.stack([tta_oracle.ensemble(p[i], f, 3, mode="mean", level="full", batch_size_value=4) for i in range(p.shape[0])])
+    ref = TO.merge(pr, vol.shape, overlap=ov, padding=pad)
+    sw = SlidingWindowPredictor(m, patch, ov, pad, batch_size=3, tta="full", tta_mode="mean")
+    got = sw.predict(torch.from_numpy(vol).cuda()).cpu().numpy()
+    return [_res("sliding_window_tta_prob[f32]", np.abs(got - ref).max(), 2e-5)]
+
+
 def check_dice_parity_trained(steps=120):
     """Train a small ResUNet on synthetic blobs with the MI355X engine, then compare Dice of the bf16 / f32 device
     forward with the fp32 CPU oracle using the SAME weights (north_star: |Dice delta| < 1e-4)."""

@@ -305,6 +305,11 @@ def test_prepost_scans(prepost_golden, name):
 
 
 @pytest.mark.gpu
+def test_sliding_window_tta(K):
+    _assert_all(K.check_sliding_window_tta())
+
+
+@pytest.mark.gpu
 def test_tta_on_device(tta_golden):
     """biapy_amd.tta: orient kernel vs the reference's AxisTransform.apply outputs (bit-exact), and the ensembled prediction
     vs the oracle pipeline with a position-dependent stand-in predictor (mean / min / max, 2D with padding, 3D)."""
