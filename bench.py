@@ -167,7 +167,10 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel timing table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-ddp", action="store_true", help="testing aid: take the multi-GPU code path (DDP over RCCL) even with one rank")
+    ap.add_argument("--force-ddp", action="store_true", help="testing aid: take the multi-GPU code path (RCCL process group) even with one rank")
+    ap.add_argument("--dp", choices=["flat", "ddp"], default="flat",
+                    help="multi-GPU gradient exchange: flat = two HIP-graph replays around ONE flat-gradient all-reduce "
+                         "(biapy_amd.graphs.DataParallelTrainStep); ddp = torch DistributedDataParallel with eager hooks")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: single-GPU runs; the ~230 launches of a step are host-bound otherwise)")
     a = ap.parse_args()
@@ -200,7 +203,8 @@ def main():
     x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
     if train:
         model.train()
-        if multi:
+        use_ddp = multi and (a.dp == "ddp" or a.graph == "off" or a.breakdown)
+        if use_ddp:
             if a.graph != "off":
                 # forward and backward as two HIP-graph replays below the autograd boundary; DDP's hooks, the RCCL all-reduce
                 # and the optimizer stay eager (ResUNet.capture_graphs)
@@ -212,7 +216,7 @@ def main():
             # one 27 MB bucket (a single ring all-reduce over xGMI) whose views ARE the .grad tensors: no copy-back kernels
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False,
                                                             gradient_as_bucket_view=True, bucket_cap_mb=int(os.environ.get("BPX_DDP_BUCKET_MB", "64")))
-        want_graph = (a.graph == "on" or (a.graph == "auto" and not a.breakdown)) and not multi
+        want_graph = (a.graph == "on" or (a.graph == "auto" and not a.breakdown)) and not use_ddp
         try:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=want_graph)
         except Exception:
@@ -240,7 +244,11 @@ def main():
         try:
             from biapy_amd.graphs import GraphedInference, GraphedTrainStep
 
-            if train:
+            if train and multi:
+                from biapy_amd.graphs import DataParallelTrainStep
+
+                gstep = DataParallelTrainStep(net, loss_fn, opt, x, tgt)
+            elif train:
                 gstep = GraphedTrainStep(net, loss_fn, opt, x, tgt)
             else:
                 gstep = GraphedInference(model.predict_proba, x)
@@ -253,6 +261,11 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             step = eager_step
             torch.cuda.synchronize()
+            if train and multi:                                        # still exchange gradients: same three phases, eager
+                from biapy_amd.graphs import DataParallelTrainStep
+
+                estep = DataParallelTrainStep(net, loss_fn, opt, x, tgt, graph=False, broadcast_parameters=False)
+                step = lambda: estep()  # noqa: E731
 
     for _ in range(a.warmup):
         out = step()
@@ -350,7 +363,8 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
             config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, %s" % (a.patch, a.batch, a.mode),
                         global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode=a.mode),
-            launch="hip-graph replay (whole step)" if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
+            launch=("hip-graph replays (forward+loss+backward | optimizer) around one flat-gradient RCCL all-reduce" if multi else
+                    "hip-graph replay (whole step)") if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
                                                                     if fb_graphs else "eager"),
             mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * mult / (world * MFMA_PEAK_BF16), 5),
             roofline=roofline,

@@ -161,3 +161,56 @@ def test_ddp_averages_grads_of_a_whole_network_function():
         p.join(timeout=60)
     # rank0: sum(g*x)=4, rank1: 8 -> mean 6 ; bias grad 4 on both -> 4
     assert all(abs(w - 6.0) < 1e-6 and abs(b - 4.0) < 1e-6 for _, w, b in res), res
+
+
+def _small_net(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.ELU(), torch.nn.Conv3d(4, 1, 1))
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from biapy_amd.graphs import DataParallelTrainStep
+
+    g = torch.Generator().manual_seed(10 + rank)                       # every rank its own shard of the data
+    xs = [torch.randn(2, 1, 6, 6, 6, generator=g) for _ in range(3)]
+    ts = [(torch.rand(2, 1, 6, 6, 6, generator=g) > 0.5).float() for _ in range(3)]
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    # reference behaviour: DDP wrap (base_workflow.py:952-958), both start from rank 0's weights
+    ref = torch.nn.parallel.DistributedDataParallel(_small_net(0))
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    for x, t in zip(xs, ts):
+        ropt.zero_grad(set_to_none=True)
+        loss_fn(ref(x), t).backward()
+        ropt.step()
+    # flat-gradient step; rank 1 deliberately starts from different weights: the constructor must broadcast rank 0's
+    net = _small_net(0 if rank == 0 else 7)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    step = DataParallelTrainStep(net, loss_fn, opt, xs[0], ts[0], graph=False)
+    for x, t in zip(xs, ts):
+        step(x, t)
+    err = max((a - b).abs().max().item() for a, b in zip(net.parameters(), ref.module.parameters()))
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], o) for o in gathered)
+    step._check_views()
+    q.put((rank, err, same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_data_parallel_step_matches_ddp():
+    """biapy_amd.graphs.DataParallelTrainStep (eager form): same weights as DistributedDataParallel after 3 AdamW steps on
+    disjoint shards, identical on every rank, parameters broadcast from rank 0 at construction."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(err < 1e-6 and same for _, err, same in res), res
