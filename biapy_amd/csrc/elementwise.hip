@@ -156,31 +156,38 @@ template <typename T>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict__ g, int g_ld, const T* __restrict__ t, int t_ld,
                                                              const bpx_nbwd_coef* __restrict__ coef, const T* __restrict__ addend,
                                                              int a_ld, T* __restrict__ dx, int dx_ld, int C, int64_t vps, int N) {
+  // one sample per blockIdx.y; blockDim.x * gridDim.x is a multiple of G, so a thread keeps its channel group and holds its
+  // 3 x KPL coefficients in registers (loading them per element made the kernel load-instruction bound: 2.2 TB/s)
   constexpr int KPL = ElemTraits<T>::KPL;
   const int G = C / KPL;
-  const int64_t total = (int64_t)N * vps * G;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int cg = (int)(i % G);
-    int64_t vox = i / G;
-    int n = (int)(vox / vps);
-    u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + (size_t)vox * g_ld + cg * KPL);
-    u32x4_t tv = *reinterpret_cast<const u32x4_t*>(t + (size_t)vox * t_ld + cg * KPL);
+  const int n = blockIdx.y;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float ka[KPL], kb[KPL], kc[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    bpx_nbwd_coef k = coef[(size_t)n * C + cg * KPL + e];
+    ka[e] = k.a; kb[e] = k.b; kc[e] = k.c0;
+  }
+  const size_t base = (size_t)n * vps;
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    size_t vox = base + (size_t)(i / G);
+    u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + vox * g_ld + cg * KPL);
+    u32x4_t tv = *reinterpret_cast<const u32x4_t*>(t + vox * t_ld + cg * KPL);
     float gf[KPL], tf[KPL], of[KPL];
     unpack16<T>(gv, gf);
     unpack16<T>(tv, tf);
 #pragma unroll
-    for (int e = 0; e < KPL; ++e) {
-      bpx_nbwd_coef k = coef[(size_t)n * C + cg * KPL + e];
-      of[e] = k.a * gf[e] + k.b * tf[e] + k.c0;
-    }
+    for (int e = 0; e < KPL; ++e) of[e] = ka[e] * gf[e] + kb[e] * tf[e] + kc[e];
     if (addend) {
-      u32x4_t av = *reinterpret_cast<const u32x4_t*>(addend + (size_t)vox * a_ld + cg * KPL);
+      u32x4_t av = *reinterpret_cast<const u32x4_t*>(addend + vox * a_ld + cg * KPL);
       float af[KPL];
       unpack16<T>(av, af);
 #pragma unroll
       for (int e = 0; e < KPL; ++e) of[e] += af[e];
     }
-    *reinterpret_cast<u32x4_t*>(dx + (size_t)vox * dx_ld + cg * KPL) = pack16<T>(of);
+    *reinterpret_cast<u32x4_t*>(dx + vox * dx_ld + cg * KPL) = pack16<T>(of);
   }
 }
 
@@ -947,11 +954,18 @@ extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g
   int64_t total = (int64_t)N * voxels * (g.C / kpl);
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  const int G = g.C / kpl;                                   // 256 * blocks must be a multiple of G (a thread keeps its channel group)
+  int odd = G;
+  while ((odd & 1) == 0 && odd > 1) odd >>= 1;
+  BPX_CHECK(G / odd <= 256, "%s: unsupported channel count %d", fn, g.C);
+  int bx = (int)std::min<int64_t>(cdiv64(voxels * G, 256), std::max(1, 256 * 16 / N));
+  bx = (bx + odd - 1) / odd * odd;
+  dim3 grid((unsigned)bx, (unsigned)N);
   if (dtype == BPX_BF16)
-    norm_bwd_apply_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)g.ptr, g.ld, (const uint16_t*)t.ptr, t.ld, coef_d,
+    norm_bwd_apply_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)g.ptr, g.ld, (const uint16_t*)t.ptr, t.ld, coef_d,
                                                                     (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, g.C, voxels, N);
   else if (dtype == BPX_F32)
-    norm_bwd_apply_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)g.ptr, g.ld, (const float*)t.ptr, t.ld, coef_d,
+    norm_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)g.ptr, g.ld, (const float*)t.ptr, t.ld, coef_d,
                                                                  (const float*)addend.ptr, addend.ld, (float*)dx.ptr, dx.ld, g.C, voxels, N);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
