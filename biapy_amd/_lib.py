@@ -76,6 +76,9 @@ _SIGS = {
     "bpx_tensor_stats_tiles": ([_i64], _i),
     "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_norm_bwd_apply": ([_i, _i, _i64, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
+    "bpx_norm_act_tiles": ([_i, _i64, _i], _i),
+    "bpx_norm_act_fwd": ([_i, _i, _i64, Tensor, _vp, _i, Tensor, _vp], _i),
+    "bpx_norm_act_bwd": ([_i, _i, _i64, Tensor, Tensor, _vp, _i, Tensor, Tensor, _vp, _vp], _i),
     "bpx_maxpool3d_fwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp], _i),
     "bpx_maxpool3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_maxpool3d_bwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp], _i),

@@ -192,6 +192,105 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Materialised InstanceNorm + activation (plain U-Net, biapy/models/blocks.py:154-166 Conv -> Norm -> Act, where the consumer
+// is a pooling / transposed-conv / head kernel without a fused prologue) and its backward.
+//   fwd: y = act(scale*x + shift)
+//   bwd: g = dy * act'(scale*x + shift) (+ addend);  partial sums per (sample, block, channel) of S1 = sum g, S2 = sum g*xhat
+//        over THIS kernel's product only (an addend brings its own partial sums), in the [N][tiles][2][C] layout
+//        bpx_norm_bwd_finalize reads.  One sample per blockIdx.y; a thread keeps its channel group (see norm_bwd_apply).
+// ------------------------------------------------------------------------------------------------
+constexpr int NA_BLOCKS = 512;   // blocks (= partial-sum slots) per sample, upper bound
+
+template <typename T>
+__global__ void __launch_bounds__(256) norm_act_fwd_kernel(const T* __restrict__ x, int x_ld, const bpx_norm_rec* __restrict__ rec, int act,
+                                                           T* __restrict__ y, int y_ld, int C, int64_t vps) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int G = C / KPL;
+  const int n = blockIdx.y;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float sc[KPL], sh[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    bpx_norm_rec r = rec[(size_t)n * C + cg * KPL + e];
+    sc[e] = r.scale; sh[e] = r.shift;
+  }
+  const size_t base = (size_t)n * vps;
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    size_t vox = base + (size_t)(i / G);
+    float f[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      float u = sc[e] * f[e] + sh[e];
+      f[e] = act == BPX_ACT_ELU ? act_fwd<BPX_ACT_ELU>(u) : act == BPX_ACT_RELU ? act_fwd<BPX_ACT_RELU>(u)
+           : act == BPX_ACT_SILU ? act_fwd<BPX_ACT_SILU>(u) : u;
+    }
+    *reinterpret_cast<u32x4_t*>(y + vox * y_ld + cg * KPL) = pack16<T>(f);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ x, int x_ld,
+                                                           const bpx_norm_rec* __restrict__ rec, int act, const T* __restrict__ addend,
+                                                           int a_ld, T* __restrict__ g, int g_ld, int C, int64_t vps,
+                                                           float* __restrict__ red_part) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  extern __shared__ float nred[];   // [256][2*KPL]
+  const int G = C / KPL;
+  const int n = blockIdx.y, tiles = gridDim.x;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float sc[KPL], sh[KPL], mu[KPL], rs[KPL], s1[KPL], s2[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    bpx_norm_rec r = rec[(size_t)n * C + cg * KPL + e];
+    sc[e] = r.scale; sh[e] = r.shift; mu[e] = r.mean; rs[e] = r.rstd;
+    s1[e] = s2[e] = 0.f;
+  }
+  const size_t base = (size_t)n * vps;
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    size_t vox = base + (size_t)(i / G);
+    float d[KPL], f[KPL], o[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + vox * dy_ld + cg * KPL), d);
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      float u = sc[e] * f[e] + sh[e];
+      float da = act == BPX_ACT_ELU ? act_bwd<BPX_ACT_ELU>(u) : act == BPX_ACT_RELU ? act_bwd<BPX_ACT_RELU>(u)
+               : act == BPX_ACT_SILU ? act_bwd<BPX_ACT_SILU>(u) : 1.f;
+      float gv = d[e] * da;
+      s1[e] += gv;
+      s2[e] += gv * ((f[e] - mu[e]) * rs[e]);
+      o[e] = gv;
+    }
+    if (addend) {
+      float af[KPL];
+      unpack16<T>(*reinterpret_cast<const u32x4_t*>(addend + vox * a_ld + cg * KPL), af);
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) o[e] += af[e];
+    }
+    *reinterpret_cast<u32x4_t*>(g + vox * g_ld + cg * KPL) = pack16<T>(o);
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    nred[threadIdx.x * 2 * KPL + e] = s1[e];
+    nred[threadIdx.x * 2 * KPL + KPL + e] = s2[e];
+  }
+  __syncthreads();
+  // threads with equal (threadIdx.x % G) share a channel group (256 * blockIdx.x is a multiple of G by construction)
+  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
+    const int which = o / C, c = o % C, grp = c / KPL, e = c % KPL;
+    const int lane0 = (int)(((int64_t)grp - (int64_t)blockIdx.x * blockDim.x % G + G) % G);
+    float acc = 0.f;
+    for (int t = lane0; t < (int)blockDim.x; t += G) acc += nred[t * 2 * KPL + which * KPL + e];
+    red_part[(((size_t)n * tiles + blockIdx.x) * 2 + which) * C + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // max pooling 2x2x2
 // ------------------------------------------------------------------------------------------------
 constexpr int POOL_IPT = 4;  // items (output voxel x 16-byte channel group) per thread
@@ -967,6 +1066,57 @@ extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g
   else if (dtype == BPX_F32)
     norm_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)g.ptr, g.ld, (const float*)t.ptr, t.ld, coef_d,
                                                                  (const float*)addend.ptr, addend.ld, (float*)dx.ptr, dx.ld, g.C, voxels, N);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+static int na_blocks(int64_t voxels, int C, int kpl) {
+  const int G = C / kpl;
+  int odd = G;
+  while ((odd & 1) == 0 && odd > 1) odd >>= 1;
+  int bx = (int)std::min<int64_t>(cdiv64(voxels * G, 256), NA_BLOCKS);
+  return (bx + odd - 1) / odd * odd;   // 256 * bx is a multiple of G: a thread keeps its channel group
+}
+
+extern "C" int bpx_norm_act_tiles(int dtype, int64_t voxels, int C) { return na_blocks(voxels, C, dtype == BPX_BF16 ? 8 : 4); }
+
+extern "C" int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, bpx_tensor y,
+                                bpx_stream_t stream) {
+  const char* fn = "bpx_norm_act_fwd";
+  BPX_CHECK(x.ptr && y.ptr && rec_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  if ((int64_t)N * voxels == 0) return 0;
+  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    norm_act_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, rec_d, act, (uint16_t*)y.ptr, y.ld, x.C, voxels);
+  else if (dtype == BPX_F32)
+    norm_act_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x.ptr, x.ld, rec_d, act, (float*)y.ptr, y.ld, x.C, voxels);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act,
+                                bpx_tensor addend, bpx_tensor g, float* red_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_norm_act_bwd";
+  BPX_CHECK(dy.ptr && x.ptr && g.ptr && rec_d && red_part_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C == dy.C && x.C == g.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  if ((int64_t)N * voxels == 0) return 0;
+  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
+  const size_t shm = (size_t)256 * 2 * kpl * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    norm_act_bwd_kernel<uint16_t><<<grid, 256, shm, s>>>((const uint16_t*)dy.ptr, dy.ld, (const uint16_t*)x.ptr, x.ld, rec_d, act,
+                                                         (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)g.ptr, g.ld, x.C, voxels, red_part_d);
+  else if (dtype == BPX_F32)
+    norm_act_bwd_kernel<float><<<grid, 256, shm, s>>>((const float*)dy.ptr, dy.ld, (const float*)x.ptr, x.ld, rec_d, act,
+                                                      (const float*)addend.ptr, addend.ld, (float*)g.ptr, g.ld, x.C, voxels, red_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

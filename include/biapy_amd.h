@@ -195,6 +195,17 @@ int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, int C, int6
 int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
                        bpx_tensor addend, bpx_tensor dx, bpx_stream_t stream);
 
+/* Materialised InstanceNorm + activation and its backward, for consumers without a fused prologue (plain U-Net:
+ * biapy/models/blocks.py:154-166 Conv -> Norm -> Act feeding MaxPool / ConvTranspose / the head, unet.py:382-394).
+ *   fwd: y = act(scale*x + shift), rec_d = [N][C] records of bpx_norm_finalize.
+ *   bwd: g = dy * act'(scale*x + shift) (+ addend); red_part_d = [N][bpx_norm_act_tiles()][2][C] partial sums of
+ *        S1 = sum g, S2 = sum g*xhat of the product term only, the layout bpx_norm_bwd_finalize reads.  g may alias dy. */
+int bpx_norm_act_tiles(int dtype, int64_t voxels, int C);
+int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, bpx_tensor y,
+                     bpx_stream_t stream);
+int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act,
+                     bpx_tensor addend, bpx_tensor g, float* red_part_d, bpx_stream_t stream);
+
 /* MaxPool3d (sz,2,2), sz = z_down of the level = 1 or 2 (resunet.py:256-257) + statistics of the pooled tensor.
  * (D,H,W) = input extents. */
 int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor y, float* stats_part_d,

@@ -71,3 +71,10 @@ def resunet_golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "resunet_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def unet_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "unet_golden.npz"))

@@ -336,8 +336,61 @@ def resunet_aniso_fixtures():
     print("resunet_aniso_golden.npz:", len(out), "arrays")
 
 
+def unet_fixtures():
+    """Plain U-Net (row U / cfg 1 family): reference ``U_Net`` logits, BCE loss and every gradient norm of a 2D net
+    (fm 16-32-64, 64x64 patches, B=2) and a 3D net (fm 16-32, 16x32x32, z_down [1])."""
+    umod = shim.load("biapy.models.unet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import unet_oracle
+
+    out = {}
+    for tag, fm, patch, zd, seed in (("2d", [16, 32, 64], (64, 64), [2, 2], 11), ("3d", [16, 32], (16, 32, 32), [1], 12)):
+        depth = len(fm) - 1
+        torch.manual_seed(seed)
+        with quiet():
+            net = umod.U_Net(
+                image_shape=tuple(patch) + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", k_size=3,
+                upsample_layer="convtranspose", yx_down=[2] * depth, z_down=zd, output_channels=[1], output_channel_info=["F"],
+                head_activations=["ce_sigmoid"], isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm),
+            )
+        g = torch.Generator().manual_seed(100 + seed)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if v.ndim == 1:                       # move the IN affine / biases off their init so their gradients are exercised
+                    v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+        B = 2
+        xl = torch.randn(B, *patch, 1, generator=g)                              # channels-last, as the data pipeline holds it
+        x = xl.permute(0, len(patch) + 1, *range(1, len(patch) + 1))
+        tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+        net.train()
+        logits = net(x)
+        loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)
+        loss.backward()
+        out[f"{tag}/feature_maps"] = np.array(fm)
+        out[f"{tag}/z_down"] = np.array(zd)
+        out[f"{tag}/x"] = xl.numpy()
+        out[f"{tag}/target"] = tgt.numpy().astype(np.uint8)
+        out[f"{tag}/logits"] = logits.detach().numpy()
+        out[f"{tag}/loss"] = np.array(loss.item(), dtype=np.float64)
+        for k, v in net.state_dict().items():
+            out[f"{tag}/sd/{k}"] = v.numpy()
+        for k, p_ in net.named_parameters():
+            out[f"{tag}/gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+        names = dict(net.named_parameters())
+        for k in ["down_path.0.block.0.block.0.weight", "down_path.0.block.1.block.1.weight", "up_paths.0.0.up.0.weight",
+                  "up_paths.0.0.up.1.bias", "heads.0.weight"]:
+            out[f"{tag}/grad/{k}"] = names[k].grad.numpy()
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        lo = unet_oracle.unet_forward(sd, x, fm, z_down=zd)
+        err = (lo - logits.detach()).abs().max().item()
+        print(f"unet {tag}: params {sum(p_.numel() for p_ in net.parameters())}, oracle vs reference max abs err {err:.3e}")
+        assert err < 2e-5
+    np.savez_compressed(os.path.join(HERE, "unet_golden.npz"), **out)
+    print("unet_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "unet_golden.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -350,3 +403,5 @@ if __name__ == "__main__":
         resunet_fixtures()
     if "resunet_aniso" in which:
         resunet_aniso_fixtures()
+    if "unet" in which:
+        unet_fixtures()

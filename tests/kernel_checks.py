@@ -374,12 +374,14 @@ def check_conv1x1(dt, B, vox, Cin, Cout, with_coef=True, seed=0):
     return res
 
 
-def check_convT(dt, B, S, Cc, seed=0, sz=2):
-    """ConvTranspose3d k = s = (sz,2,2) forward / dgrad / wgrad (sz = 1: the anisotropic Z_DOWN = 1 level)."""
+def check_convT(dt, B, S, Cc, seed=0, sz=2, Cout=None):
+    """ConvTranspose3d k = s = (sz,2,2) forward / dgrad / wgrad (sz = 1: the anisotropic Z_DOWN = 1 level); Cout != Cin is the
+    plain U-Net's UpBlock (blocks.py:603)."""
     D, H, W = S
     g = torch.Generator().manual_seed(seed)
-    x = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
-    w = torch.randn(Cc, Cc, sz, 2, 2, generator=g) / Cc ** 0.5
+    Cin, Cc = Cc, (Cout or Cc)
+    x = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    w = torch.randn(Cin, Cc, sz, 2, 2, generator=g) / Cin ** 0.5
     b = torch.randn(Cc, generator=g) * 0.1
     xr = ncdhw(x).requires_grad_(True)
     wr = rnd(w, dt).requires_grad_(True)
@@ -387,11 +389,11 @@ def check_convT(dt, B, S, Cc, seed=0, sz=2):
     y_ref = F.conv_transpose3d(xr, wr, br, stride=(sz, 2, 2))
     dy = rnd(torch.randn(B, sz * D, 2 * H, 2 * W, Cc, generator=g), dt)
     y_ref.backward(ncdhw(dy))
-    tag = f"convT[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc} sz{sz}]"
+    tag = f"convT[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cin}->{Cc} sz{sz}]"
     # forward into a channel slice of a concat buffer
     extra = 16
     yb = torch.full((B, sz * D, 2 * H, 2 * W, Cc + extra), 3.0, dtype=tdtype(dt), device=DEV)
-    wp = pack(w, L.PK_CT if sz == 2 else L.PK_CT4, Cc, Cc, dt)
+    wp = pack(w, L.PK_CT if sz == 2 else L.PK_CT4, Cin, Cc, dt)
     tiles = lib.bpx_convT3d_stats_tiles(D, H, W, sz)
     part = torch.zeros(B, tiles, 2, Cc, dtype=torch.float32, device=DEV)
     xd, bd = to_dev(x, dt), b.to(DEV)
@@ -403,16 +405,16 @@ def check_convT(dt, B, S, Cc, seed=0, sz=2):
     s_ref = torch.stack([y.sum((1, 2, 3)), (y * y).sum((1, 2, 3))], 1)
     res.append(_res(tag + ".stats", relerr(part.sum(1), s_ref), 5e-3 if dt == L.BF16 else 1e-4))
     # dgrad
-    wpt = pack(w, L.PK_CT_T if sz == 2 else L.PK_CT4_T, Cc, Cc, dt)
+    wpt = pack(w, L.PK_CT_T if sz == 2 else L.PK_CT4_T, Cin, Cc, dt)
     dyd = to_dev(dy, dt)
-    dx = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
+    dx = torch.empty(B, D, H, W, Cin, dtype=tdtype(dt), device=DEV)
     L.check(lib.bpx_convT3d_k2s2_dgrad(dt, B, D, H, W, sz, L.tview(dyd), wpt.data_ptr(), L.tview(dx), L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(tag + ".dgrad", relerr(dx, ndhwc(xr.grad)), tol_for(dt)))
     # wgrad
-    dw = torch.zeros(Cc, Cc, sz, 2, 2, dtype=torch.float32, device=DEV)
+    dw = torch.zeros(Cin, Cc, sz, 2, 2, dtype=torch.float32, device=DEV)
     db = torch.zeros(Cc, dtype=torch.float32, device=DEV)
-    ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, sz, Cc, Cc)), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, sz, Cin, Cc)), dtype=torch.uint8, device=DEV)
     L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, sz, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(),
                                        L.stream_ptr()))
     torch.cuda.synchronize()
@@ -641,6 +643,146 @@ def check_network_aniso(dtype, golden):
                 if e > worst:
                     worst, wname = e, k[9:]
     res.append(_res(tag + ".gradnorm_rel_worst", worst, gtol, extra=wname))
+    return res
+
+
+def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0):
+    """bpx_norm_act_fwd / bpx_norm_act_bwd (+ finalize + apply) against autograd through act(instance_norm(x))."""
+    D, H, W = S
+    vox = D * H * W
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cc, generator=g) * 1.5 + 0.3, dt)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.2
+    dy = rnd(torch.randn(B, D, H, W, Cc, generator=g), dt)
+    xr = ncdhw(x).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    fn = {"elu": F.elu, "relu": F.relu, "silu": F.silu}[act]
+    y_ref = fn(F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    y_ref.backward(ncdhw(dy))
+    tag = f"norm_act[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc} {act}]"
+    st = L.stream_ptr()
+    xd, dyd = to_dev(x, dt), to_dev(dy, dt)
+    tiles = lib.bpx_tensor_stats_tiles(vox)
+    part = torch.zeros(B, tiles, 2, Cc, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_tensor_stats(dt, B, vox, L.tview(xd), part.data_ptr(), st))
+    rec = torch.empty(B, Cc, 4, dtype=torch.float32, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, Cc, vox, gd.data_ptr(), bd.data_ptr(), 1e-5, Cc, rec.data_ptr(), Cc, 0, st))
+    extra = 16
+    yb = torch.full((B, D, H, W, Cc + extra), 3.0, dtype=tdtype(dt), device=DEV)
+    code = L.ACT[act]
+    L.check(lib.bpx_norm_act_fwd(dt, B, vox, L.tview(xd), rec.data_ptr(), code, L.tview(yb, extra, Cc), st))
+    torch.cuda.synchronize()
+    res = [_res(tag + ".fwd", relerr(yb[..., extra:], ndhwc(y_ref.detach())), tol_for(dt))]
+    res.append(_res(tag + ".fwd.neighbours_untouched", 0 if (yb[..., :extra].float() == 3).all().item() else 1, 0))
+    nt = lib.bpx_norm_act_tiles(dt, vox, Cc)
+    red = torch.zeros(B, nt, 2, Cc, dtype=torch.float32, device=DEV)
+    gbuf = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
+    L.check(lib.bpx_norm_act_bwd(dt, B, vox, L.tview(dyd), L.tview(xd), rec.data_ptr(), code, L.NULL_T, L.tview(gbuf), red.data_ptr(), st))
+    coef = torch.empty(B, Cc, 4, dtype=torch.float32, device=DEV)
+    dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, nt, Cc, vox, rec.data_ptr(), gd.data_ptr(), dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st))
+    L.check(lib.bpx_norm_bwd_apply(dt, B, vox, L.tview(gbuf), L.tview(xd), coef.data_ptr(), L.NULL_T, L.tview(gbuf), st))
+    torch.cuda.synchronize()
+    tol = 3e-2 if dt == L.BF16 else 2e-4
+    res.append(_res(tag + ".dx", relerr(gbuf, ndhwc(xr.grad)), tol))
+    res.append(_res(tag + ".dgamma", relerr(dg, gr.grad), tol))
+    res.append(_res(tag + ".dbeta", relerr(db, br.grad), tol))
+    return res
+
+
+def check_unet(dtype, tag, golden):
+    """Plain U-Net (2D / 3D) against the reference fixture tests/golden/unet_golden.npz: logits, loss, every gradient norm and
+    the stored full gradients, through the module (load_state_dict strict -> forward -> autograd backward)."""
+    from biapy_amd.unet import U_Net
+
+    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+    fm = [int(v) for v in golden[f"{tag}/feature_maps"]]
+    zd = [int(v) for v in golden[f"{tag}/z_down"]]
+    pre = f"{tag}/sd/"
+    sd = {k[len(pre):]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith(pre)}
+    xl = torch.from_numpy(golden[f"{tag}/x"])
+    nd = xl.dim() - 2
+    x = xl.permute(0, nd + 1, *range(1, nd + 1)).contiguous()
+    tgt = torch.from_numpy(golden[f"{tag}/target"]).float()
+    m = U_Net(image_shape=tuple(xl.shape[1:]), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in",
+              yx_down=[2] * (len(fm) - 1), z_down=zd, isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm), compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    name = f"unet{tag}[{tagd} fm={fm}]"
+    lo_ref = torch.from_numpy(golden[f"{tag}/logits"])
+    bf = dtype == torch.bfloat16
+    res = [_res(name + ".logits_rel", (logits.detach().cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 6e-2 if bf else 2e-4)]
+    res.append(_res(name + ".loss", abs(loss.item() - float(golden[f"{tag}/loss"])), 2e-2 if bf else 1e-5))
+    gtol = 0.15 if bf else 2e-3
+    G = {k: p.grad for k, p in m.named_parameters()}
+    worst, wname = 0.0, ""
+    pre = f"{tag}/grad/"
+    for k in golden.files:
+        if k.startswith(pre):
+            gr = torch.from_numpy(golden[k])
+            e = (G[k[len(pre):]].cpu() - gr).norm().item() / (gr.norm().item() + 1e-12)
+            if e > worst:
+                worst, wname = e, k[len(pre):]
+    res.append(_res(name + ".grads_rel_l2_worst", worst, gtol, extra=wname))
+    worst, wname = 0.0, ""
+    pre = f"{tag}/gradnorm/"
+    gmax = max(float(golden[k]) for k in golden.files if k.startswith(pre))
+    for k in golden.files:
+        if k.startswith(pre):
+            ref = float(golden[k])
+            if ref > 1e-5 * gmax:
+                e = abs(G[k[len(pre):]].norm().item() - ref) / ref
+                if e > worst:
+                    worst, wname = e, k[len(pre):]
+    res.append(_res(name + ".gradnorm_rel_worst", worst, gtol, extra=wname))
+    with torch.no_grad():
+        pr = m.eval().predict_proba(x.to(DEV))
+    res.append(_res(name + ".predict_proba", (pr.cpu() - torch.sigmoid(lo_ref)).abs().max().item(), 3e-2 if bf else 2e-5))
+    return res
+
+
+def check_unet_cfg1(dtype=torch.float32):
+    """BASELINE.json configs[0]: 2D U-Net, 256x256x1 patches, batch 2, fm 16-32-64-128-256 (1,944,241 parameters) - one train
+    step's logits, BCE loss and gradients on the device against the CPU oracle on the same seeded inputs and weights."""
+    from biapy_amd.unet import U_Net
+    from oracle import unet_oracle
+
+    fm = [16, 32, 64, 128, 256]
+    torch.manual_seed(21)
+    m = U_Net(image_shape=(256, 256, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4,
+              z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype)
+    nparams = sum(p.numel() for p in m.parameters())
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 1, 256, 256, generator=g)
+    tgt = (torch.rand(2, 1, 256, 256, generator=g) > 0.5).float()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    lo_ref = unet_oracle.unet_forward(sd, x, fm)
+    loss_ref = F.binary_cross_entropy_with_logits(lo_ref, tgt)
+    loss_ref.backward()
+    m = m.to(DEV).train()
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    name = f"unet2d_cfg1[{'bf16' if bf else 'f32'}]"
+    res = [_res(name + ".params", abs(nparams - 1944241), 0)]
+    res.append(_res(name + ".logits_rel", (logits.detach().cpu() - lo_ref.detach()).abs().max().item() / lo_ref.abs().max().item(), 6e-2 if bf else 3e-4))
+    res.append(_res(name + ".loss", abs(loss.item() - loss_ref.item()), 2e-2 if bf else 1e-5))
+    gmax = max(v.grad.norm().item() for v in sd.values())
+    worst, wname = 0.0, ""
+    for k, p_ in m.named_parameters():
+        ref = sd[k].grad
+        if ref.norm().item() > 1e-5 * gmax:
+            e = (p_.grad.cpu() - ref).norm().item() / ref.norm().item()
+            if e > worst:
+                worst, wname = e, k
+    res.append(_res(name + ".grads_rel_l2_worst", worst, 0.2 if bf else 3e-3, extra=wname))
     return res
 
 

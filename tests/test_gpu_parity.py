@@ -349,3 +349,36 @@ def test_tta_on_device(tta_golden):
                 ref = TO.ensemble(vol, pred_np, ndim, mode, level, bs)
                 got = T.ensemble_predictions(torch.from_numpy(vol).cuda(), pred_t, ndim, batch_size_value=bs, mode=mode, group=level)
                 np.testing.assert_array_equal(got.cpu().numpy(), ref, err_msg=f"{shape} {mode} {level}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_norm_act_kernels(K, dt):
+    """Materialised InstanceNorm+activation forward / backward (plain U-Net block outputs) vs autograd."""
+    from biapy_amd import _lib as L
+
+    d = L.F32 if dt == "f32" else L.BF16
+    rows = K.check_norm_act(d, 2, (6, 10, 12), 48, "elu") + K.check_norm_act(d, 1, (1, 40, 24), 16, "relu", seed=1)
+    rows += K.check_norm_act(d, 3, (5, 7, 9), 96, "silu", seed=2)
+    _assert_all(rows)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_convT_channel_changing(K, dt):
+    """ConvTranspose(in -> out != in): the plain U-Net's UpBlock (blocks.py:603), 3D (2,2,2) and the 2D-as-one-slice (1,2,2)."""
+    from biapy_amd import _lib as L
+
+    d = L.F32 if dt == "f32" else L.BF16
+    _assert_all(K.check_convT(d, 2, (4, 6, 8), 64, seed=3, sz=2, Cout=32) + K.check_convT(d, 2, (1, 16, 16), 32, seed=4, sz=1, Cout=16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_unet_matches_reference_fixture(K, unet_golden, tag, dtype):
+    """biapy_amd.unet.U_Net (row U; 2D = cfg 1 family) vs the reference's own outputs: logits, loss, all gradients."""
+    _assert_all(K.check_unet(dtype, tag, unet_golden))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_unet2d_cfg1_train_step(K, dtype):
+    """BASELINE.json configs[0] (2D U-Net 256x256x1, batch 2): a device train step against the CPU oracle."""
+    _assert_all(K.check_unet_cfg1(dtype))

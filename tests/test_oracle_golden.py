@@ -214,3 +214,52 @@ def test_tta_group_and_transforms_match_reference(tta_golden):
             ip, is_ = TO.inverse(p, s)
             np.testing.assert_array_equal(np.array(list(ip) + list(is_)), g[f"inverse/{name}/{n}"])
             np.testing.assert_array_equal(TO.apply(TO.apply(arr, p, s), ip, is_), g[f"roundtrip/{name}/{n}"])
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_unet_oracle_matches_reference(unet_golden, tag):
+    """oracle/unet_oracle.py (plain U-Net, row U) vs the reference's U_Net outputs: logits, BCE loss and gradients."""
+    import torch
+    import torch.nn.functional as F
+
+    from oracle import unet_oracle
+
+    g = unet_golden
+    fm, zd = [int(v) for v in g[f"{tag}/feature_maps"]], [int(v) for v in g[f"{tag}/z_down"]]
+    pre = f"{tag}/sd/"
+    sd = {k[len(pre):]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(pre)}
+    xl = torch.from_numpy(g[f"{tag}/x"])
+    nd = xl.dim() - 2
+    x = xl.permute(0, nd + 1, *range(1, nd + 1))
+    logits = unet_oracle.unet_forward(sd, x, fm, z_down=zd)
+    loss = F.binary_cross_entropy_with_logits(logits, torch.from_numpy(g[f"{tag}/target"]).float())
+    loss.backward()
+    assert (logits.detach() - torch.from_numpy(g[f"{tag}/logits"])).abs().max().item() < 2e-5
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-6
+    pre = f"{tag}/grad/"
+    for k in g.files:
+        if k.startswith(pre):
+            ref = torch.from_numpy(g[k])
+            assert (sd[k[len(pre):]].grad - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
+
+
+@pytest.mark.parametrize("tag,shape", [("2d", (64, 64, 1)), ("3d", (16, 32, 32, 1))])
+def test_unet_module_keeps_the_reference_state_dict(unet_golden, tag, shape):
+    """biapy_amd.unet.U_Net owns its parameters under the reference's names and shapes (strict load of the reference's
+    state_dict) and refuses to run without the GPU (no CPU fallback)."""
+    import torch
+
+    from biapy_amd.unet import U_Net
+
+    g = unet_golden
+    fm, zd = [int(v) for v in g[f"{tag}/feature_maps"]], [int(v) for v in g[f"{tag}/z_down"]]
+    m = U_Net(image_shape=shape, activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", yx_down=[2] * (len(fm) - 1),
+              z_down=zd, isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm))
+    pre = f"{tag}/sd/"
+    sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros((1, 1) + tuple(shape[:-1])))
+    with pytest.raises(NotImplementedError):
+        U_Net(image_shape=shape, feature_maps=fm, drop_values=[0.0] * len(fm), normalization="bn", larger_io=False)
