@@ -566,6 +566,210 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 }
 
 
+// ---- shift-dy wgrad, MC input-channel chunks per workgroup (Cout block = 16) -----------------------------------------------
+// wgrad_sd_kernel issues 2 + 14 transposing LDS reads per 7 MFMAs and K-chunk; measured, those reads bound it (the kernel
+// runs at the same speed with or without software pipelining of the fragments).  The shifted dy fragments do not depend on
+// the input-channel chunk, so a workgroup that owns MC chunks of the same tiles re-uses every dy fragment MC times:
+// 2*MC + 14 reads per 7*MC MFMAs (MC = 2: 1.29 reads per MFMA instead of 2.29).  The InstanceNorm scale/shift of the MC*16
+// channels live in LDS (they would cost 32*MC registers), everything else follows wgrad_sd_kernel.
+template <int MC, int ACTK>
+__global__ void __launch_bounds__(256, MC == 2 ? 3 : 2) wgrad_sdm_kernel(const WgradParams p) {
+  constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int KPL = 8, VBA = 32, CB = 16, VBG = CB * 2, PPVG = 2;
+  constexpr int NKC = TV / 32, NT = 7;
+  constexpr int NPA = TV * 2 / 256, NPGT = HV * PPVG, NPG = (NPGT + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MC * TV * VBA + HV * VBG + MC * 16 * 8];
+  unsigned char* sA = smem;                                   // [MC][TV][32 B]
+  unsigned char* sG = smem + MC * TV * VBA;
+  float* sN = reinterpret_cast<float*>(smem + MC * TV * VBA + HV * VBG);   // [MC*16][scale, shift]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W;
+  const int ncg = p.Cin / (16 * MC), groups8 = (p.groups + 7) & ~7;   // chunk groups
+  const int per_cb = groups8 * ncg;
+  const int cbi = (int)blockIdx.x / per_cb, rem = (int)blockIdx.x % per_cb;
+  const int cgi = (rem % (8 * ncg)) / 8;
+  const int grp = (rem / (8 * ncg)) * 8 + rem % 8;
+  const int co_base = cbi * CB, ci_base = cgi * 16 * MC;
+  if (grp >= p.groups) return;
+
+  f32x4_t acc[NT][MC];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int c = 0; c < MC; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ gin = reinterpret_cast<const char*>(p.dy);
+  uint32_t rel_a[NPA], rel_g[NPG];
+#pragma unroll
+  for (int u = 0; u < NPA; ++u) {
+    const int t = (u * 256 + tid) >> 1;
+    rel_a[u] = (uint32_t)((((t >> 6) * H + ((t >> 4) & 3)) * W + (t & 15)) * p.x_ld + ci_base + (tid & 1) * KPL) * 2u;
+    asm volatile("" : "+v"(rel_a[u]));
+  }
+  const int subG = tid % PPVG;
+#pragma unroll
+  for (int u = 0; u < NPG; ++u) {
+    const int hv = (u * 256 + tid) / PPVG;
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    rel_g[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.dy_ld + co_base + subG * KPL) * 2u;
+    asm volatile("" : "+v"(rel_g[u]));
+  }
+  const bool last_ok = (NPG - 1) * 256 + tid < NPGT;
+  const int trl = (i >> 2), trc = (i & 3) * 8;
+  const int a_base = g * 8 * VBA + trl * VBA + trc;
+  const int g_lane = (((g >> 1) * HX + (g & 1) * 8) + trl) * VBG + trc;
+  int g_base[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    int tap = wave + 4 * a;
+    if (tap > 26) tap = 26;
+    const int dz = tap / 9, dy_ = (tap / 3) % 3, dx = tap % 3;
+    g_base[a] = g_lane + (((2 - dz) * HY + (2 - dy_)) * HX + (2 - dx)) * VBG;
+  }
+  int n_cur = -1;
+
+  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
+    const int n = tt / p.tilesPerSample, tile = tt - n * p.tilesPerSample;
+    const int z0 = (tile / (p.tilesX * p.tilesY)) * TZ, y0 = ((tile / p.tilesX) % p.tilesY) * TY, x0 = (tile % p.tilesX) * TX;
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    const bool interior = full && z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+    const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
+    const uint32_t base_g = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.dy_ld * 2u;
+
+    u32x4_t pa[MC][NPA], pg[NPG];
+    bool oka[NPA];
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int t = (u * 256 + tid) >> 1;
+      oka[u] = full || (z0 + (t >> 6) < D && y0 + ((t >> 4) & 3) < H && x0 + (t & 15) < W);
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        pa[c][u] = u32x4_t{0u, 0u, 0u, 0u};
+        if (oka[u]) pa[c][u] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a[u]) + c * 32);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NPG; ++u) {
+      pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+      bool ok = (u < NPG - 1) || last_ok;
+      if (!interior) {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        const int hv = (u * 256 + tid_o) / PPVG;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+      }
+      if (ok) pg[u] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + rel_g[u]));
+    }
+    const bool new_n = p.in_norm && n != n_cur;   // uniform
+    if (new_n && tid < MC * 16) {
+      const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(&p.in_norm[(size_t)n * p.Cin + ci_base + tid].scale);
+      // every wave is past the previous tile's staging phase (it passed that tile's second barrier), nobody reads sN now
+      sN[2 * tid] = ss[0]; sN[2 * tid + 1] = ss[1];
+    }
+    n_cur = n;
+    __syncthreads();  // the previous tile's MFMA phase has finished reading LDS; sN is visible
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      float psc[KPL], psh[KPL];
+      if (p.in_norm) {
+        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(sN + 2 * (c * 16 + (tid & 1) * KPL));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x4_t v = q[e];
+          psc[2 * e] = v[0]; psh[2 * e] = v[1]; psc[2 * e + 1] = v[2]; psh[2 * e + 1] = v[3];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NPA; ++u) {
+        u32x4_t v = pa[c][u];
+        if (p.in_norm && oka[u]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a = fmaf(psc[2 * q], bf16lo(v[q]), psh[2 * q]), b = fmaf(psc[2 * q + 1], bf16hi(v[q]), psh[2 * q + 1]);
+            act_pair<ACTK>(a, b, p.act);
+            v[q] = cvt_pk_bf16(a, b);
+          }
+        }
+        *reinterpret_cast<u32x4_t*>(sA + (size_t)c * TV * VBA + (size_t)(u * 256 + tid) * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NPG; ++u)
+      if (u < NPG - 1 || last_ok) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[u];
+    __syncthreads();
+
+    if (p.db != nullptr && cgi == 0) {  // bias gradient: column sums of dy over the tile's own voxels
+      const int c = tid % CB;
+      for (int v = tid / CB; v < TV; v += 256 / CB) {
+        const int hidx = (((v >> 6) + 1) * HY + ((v >> 4) & 3) + 1) * HX + (v & 15) + 1;
+        bsum += bf16_to_f32(*reinterpret_cast<const uint16_t*>(sG + (size_t)hidx * VBG + c * 2));
+      }
+    }
+
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      const int ka = kc * 32 * VBA;
+      const int kg = (((kc >> 1) * HY + (kc & 1) * 2) * HX) * VBG;
+      u32x4_t af[MC], gf[NT];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const unsigned char* q = sA + c * TV * VBA + a_base + ka;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBA));
+        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        af[c] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const unsigned char* q = sG + g_base[a] + kg;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
+        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
+        gf[a] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf[a]), acc[a][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float* pp = p.part + (size_t)grp * 27 * p.Cin * p.Cout;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int tap = wave + 4 * a;
+    if (tap >= 27) continue;
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci_base + c * 16 + 4 * g + r, co = co_base + i;
+        pp[((size_t)tap * p.Cin + ci) * p.Cout + co] = acc[a][c][r];
+      }
+  }
+  if (p.db != nullptr && cgi == 0) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < CB) {
+      float s = 0.f;
+      for (int k = tid; k < 256; k += CB) s += red[k];
+      atomicAdd(p.db + co_base + tid, s);
+    }
+  }
+}
+
+
 // ---- ConvTranspose3d k=2 s=2 wgrad, bf16: all 8 sub-positions in ONE pass over x and dy ---------------------------------
 // dW[ci][co][sub] = sum_v x[v][ci] * dy[2v + sub][co].  The generic kernel above needs one launch per sub-position and
 // re-reads x eight times with a stride-2 gather of dy; here a workgroup stages a 2x4x16 tile of x and the matching
@@ -799,6 +1003,7 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
 }
 
 int g_use_tr = 1;
+int g_sd_mc = -1;     // input-channel chunks per workgroup of the shift-dy kernel: -1 automatic, 1 / 2 / 3 forced (hook bits 3/4)
 int g_wgrad_sd = -1;  // -1 automatic (wherever it applies), 0 never, 1 always (bpx_debug_set_wgrad_tr bits 1/2)
 
 // shift-dy kernel: bf16, 3x3x3, W > 8; 32-bit byte offsets -> every tensor < 4 GB
@@ -812,6 +1017,14 @@ int launch_wgrad_sd(const WgradParams& p0, const WCfg& c, hipStream_t s) {
   const int ns = std::min(c.ns, 2);
   const int nchunks = p.Cin / 16, nb = p.Cout / (16 * ns);
   const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
+  const int mc = g_sd_mc >= 0 ? g_sd_mc : (nchunks % 2 == 0 ? 2 : nchunks % 3 == 0 ? 3 : 1);
+  if (ns == 1 && mc > 1 && nchunks % mc == 0 && (((uintptr_t)p.in_norm) & 7) == 0) {
+    dim3 gridm((unsigned)(((c.groups + 7) & ~7) * (nchunks / mc) * nb));
+    if (mc == 2) { if (elu) wgrad_sdm_kernel<2, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<2, 0><<<gridm, 256, 0, s>>>(p); }
+    else if (mc == 3) { if (elu) wgrad_sdm_kernel<3, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<3, 0><<<gridm, 256, 0, s>>>(p); }
+    else return 1;
+    return 0;
+  }
   dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
   if (ns == 1) { if (elu) wgrad_sd_kernel<1, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<1, 0><<<grid, 256, 0, s>>>(p); }
   else { if (elu) wgrad_sd_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<2, 0><<<grid, 256, 0, s>>>(p); }
@@ -857,6 +1070,7 @@ extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, 
 extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
   g_use_tr = use_tr & 1;
   g_wgrad_sd = (use_tr & 4) ? 1 : (use_tr & 2) ? 0 : -1;
+  g_sd_mc = ((use_tr >> 3) & 3) ? ((use_tr >> 3) & 3) : -1;
   return 0;
 }
 
