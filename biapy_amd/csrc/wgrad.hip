@@ -572,17 +572,72 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 // the input-channel chunk, so a workgroup that owns MC chunks of the same tiles re-uses every dy fragment MC times:
 // 2*MC + 14 reads per 7*MC MFMAs (MC = 2: 1.29 reads per MFMA instead of 2.29).  The InstanceNorm scale/shift of the MC*16
 // channels live in LDS (they would cost 32*MC registers), everything else follows wgrad_sd_kernel.
+//
+// Second saving: the three taps of one (dz, dy) row use dy fragments that are the same 8-voxel x-window slid by one voxel.
+// A lane reads the row's 10..12-voxel window once (3 transposing reads) and derives the three fragments in registers
+// (v_alignbit_b32 for the odd shift) instead of 6 reads.  Wave w owns the taps [7w, 7w+7) in (dz, dy, dx) order, i.e. 2-3 row
+// segments; the four waves run four compile-time specialisations of the MFMA phase.  LDS reads per K-chunk and workgroup:
+// 64 -> 39 (MC = 1), 72 -> 47 (MC = 2), 80 -> 55 (MC = 3).
+template <int W, int MC, int HY, int HX, int VBA, int VBG, int TV, int NKC>
+__device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC]) {
+  constexpr int T0 = 7 * W, T1 = (T0 + 7 < 27) ? T0 + 7 : 27;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    const int ka = kc * 32 * VBA;
+    const int kg = (((kc >> 1) * HY + (kc & 1) * 2) * HX) * VBG;
+    u32x4_t af[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      const unsigned char* q = sA + c * TV * VBA + a_base + ka;
+      u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+      u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBA)));
+      af[c] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+    }
+#pragma unroll
+    for (int row = T0 / 3; row <= (T1 - 1) / 3; ++row) {
+      const int d0 = (T0 > 3 * row ? T0 : 3 * row) - 3 * row, d1 = (T1 < 3 * row + 3 ? T1 : 3 * row + 3) - 1 - 3 * row;   // dx range of this segment
+      const int smin = 2 - d1, nt = d1 - d0 + 1;
+      const int dz = row / 3, dyy = row % 3;
+      const unsigned char* q = sG + g_lane + kg + ((((2 - dz) * HY + (2 - dyy)) * HX + smin) * VBG);
+      uint32_t w[6];
+      {
+        u32x2_t r0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+        u32x2_t r1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBG)));
+        w[0] = r0[0]; w[1] = r0[1]; w[2] = r1[0]; w[3] = r1[1]; w[4] = 0u; w[5] = 0u;
+        if (nt > 1) {
+          u32x2_t r2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 8 * VBG)));
+          w[4] = r2[0]; w[5] = r2[1];
+        }
+      }
+#pragma unroll
+      for (int dx = d1; dx >= d0; --dx) {
+        const int rs = (2 - dx) - smin;   // window shift of this tap in voxels: 0, 1 or 2
+        u32x4_t gf;
+        if (rs == 0) gf = u32x4_t{w[0], w[1], w[2], w[3]};
+        else if (rs == 2) gf = u32x4_t{w[1], w[2], w[3], w[4]};
+        else gf = u32x4_t{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                          __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w[4], w[3], 16)};
+        const int a = 3 * row + dx - T0;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf), acc[a][c], 0, 0, 0);
+      }
+    }
+  }
+}
+
 template <int MC, int ACTK>
-__global__ void __launch_bounds__(256, MC == 2 ? 3 : 2) wgrad_sdm_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_kernel(const WgradParams p) {
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int KPL = 8, VBA = 32, CB = 16, VBG = CB * 2, PPVG = 2;
   constexpr int NKC = TV / 32, NT = 7;
   constexpr int NPA = TV * 2 / 256, NPGT = HV * PPVG, NPG = (NPGT + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[MC * TV * VBA + HV * VBG + MC * 16 * 8];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MC * TV * VBA + HV * VBG + 64 + MC * 16 * 8];   // 64: window over-read of the last halo row
   unsigned char* sA = smem;                                   // [MC][TV][32 B]
   unsigned char* sG = smem + MC * TV * VBA;
-  float* sN = reinterpret_cast<float*>(smem + MC * TV * VBA + HV * VBG);   // [MC*16][scale, shift]
+  float* sN = reinterpret_cast<float*>(smem + MC * TV * VBA + HV * VBG + 64);   // [MC*16][scale, shift]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -623,14 +678,6 @@ __global__ void __launch_bounds__(256, MC == 2 ? 3 : 2) wgrad_sdm_kernel(const W
   const int trl = (i >> 2), trc = (i & 3) * 8;
   const int a_base = g * 8 * VBA + trl * VBA + trc;
   const int g_lane = (((g >> 1) * HX + (g & 1) * 8) + trl) * VBG + trc;
-  int g_base[NT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a) {
-    int tap = wave + 4 * a;
-    if (tap > 26) tap = 26;
-    const int dz = tap / 9, dy_ = (tap / 3) % 3, dx = tap % 3;
-    g_base[a] = g_lane + (((2 - dz) * HY + (2 - dy_)) * HX + (2 - dx)) * VBG;
-  }
   int n_cur = -1;
 
   for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
@@ -712,41 +759,18 @@ __global__ void __launch_bounds__(256, MC == 2 ? 3 : 2) wgrad_sdm_kernel(const W
       }
     }
 
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {
-      const int ka = kc * 32 * VBA;
-      const int kg = (((kc >> 1) * HY + (kc & 1) * 2) * HX) * VBG;
-      u32x4_t af[MC], gf[NT];
-#pragma unroll
-      for (int c = 0; c < MC; ++c) {
-        const unsigned char* q = sA + c * TV * VBA + a_base + ka;
-        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
-        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBA));
-        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-        af[c] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
-      }
-#pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        const unsigned char* q = sG + g_base[a] + kg;
-        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
-        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBG));
-        u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-        gf[a] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int c = 0; c < MC; ++c)
-          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf[a]), acc[a][c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    switch (wave) {   // wave-uniform
+      case 0: sd_mfma_phase<0, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
+      case 1: sd_mfma_phase<1, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
+      case 2: sd_mfma_phase<2, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
+      default: sd_mfma_phase<3, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
     }
   }
 
   float* pp = p.part + (size_t)grp * 27 * p.Cin * p.Cout;
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
-    const int tap = wave + 4 * a;
+    const int tap = 7 * wave + a;
     if (tap >= 27) continue;
 #pragma unroll
     for (int c = 0; c < MC; ++c)
@@ -1003,28 +1027,53 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
 }
 
 int g_use_tr = 1;
-int g_sd_mc = -1;     // input-channel chunks per workgroup of the shift-dy kernel: -1 automatic, 1 / 2 / 3 forced (hook bits 3/4)
+int g_sd_mc = -1;     // input-channel chunks per workgroup of the windowed shift-dy kernel: -1 automatic, 1 / 2 / 3 forced, 0 = the plain
+                      // shift-dy kernel (hook bits 3..5)
 int g_wgrad_sd = -1;  // -1 automatic (wherever it applies), 0 never, 1 always (bpx_debug_set_wgrad_tr bits 1/2)
 
+int g_sd_fill = 100;  // windowed kernel: workgroups launched, in percent of the co-resident capacity (256 CUs x occupancy)
+
+// Plan of the windowed shift-dy kernel: chunks per workgroup and tile groups.  Every workgroup is resident at once (one
+// "wave" of workgroups, each looping over its share of the tiles), so the partial slab is groups x 27 x Cin x Cout floats.
+struct SdmPlan { int mc, groups; };
+inline SdmPlan sdm_plan(int N, int D, int H, int W, int Cin, int Cout) {
+  const int nchunks = Cin / 16, nb = Cout / 16;
+  SdmPlan q;
+  q.mc = g_sd_mc > 0 ? g_sd_mc : (nchunks % 2 == 0 ? 2 : nchunks % 3 == 0 ? 3 : 1);   // 4 chunks (254 VGPRs) measured no better than 2
+  if (g_sd_mc == 0 || nchunks % q.mc != 0) { q.mc = 0; q.groups = 0; return q; }
+  const int occ = q.mc == 1 ? 4 : q.mc == 2 ? 3 : 2;
+  const int units = (nchunks / q.mc) * nb;
+  const int64_t totalTiles = (int64_t)N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
+  int64_t g = cdiv64((int64_t)256 * occ * g_sd_fill / 100, units);
+  g = (g + 7) & ~7ll;                                                      // the grid rounds groups up to a multiple of 8 anyway
+  const int64_t cap = std::max<int64_t>(8, ((int64_t)16000000 / ((int64_t)27 * Cin * Cout)) & ~7ll);   // partial slab <= 64 MB
+  q.groups = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, cap), totalTiles));
+  return q;
+}
+
 // shift-dy kernel: bf16, 3x3x3, W > 8; 32-bit byte offsets -> every tensor < 4 GB
-int launch_wgrad_sd(const WgradParams& p0, const WCfg& c, hipStream_t s) {
+int launch_wgrad_sd(const WgradParams& p0, WCfg& c, hipStream_t s) {
   WgradParams p = p0;
   p.tilesY = cdiv(p.H, 4);
   p.tilesX = cdiv(p.W, 16);
   p.tilesPerSample = cdiv(p.D, 4) * p.tilesY * p.tilesX;
   p.totalTiles = p.N * p.tilesPerSample;
-  p.groups = c.groups;
   const int ns = std::min(c.ns, 2);
   const int nchunks = p.Cin / 16, nb = p.Cout / (16 * ns);
   const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
-  const int mc = g_sd_mc >= 0 ? g_sd_mc : (nchunks % 2 == 0 ? 2 : nchunks % 3 == 0 ? 3 : 1);
-  if (ns == 1 && mc > 1 && nchunks % mc == 0 && (((uintptr_t)p.in_norm) & 7) == 0) {
+  const SdmPlan q = sdm_plan(p.N, p.D, p.H, p.W, p.Cin, p.Cout);
+  const int mc = q.mc;
+  if (ns == 1 && mc > 0) {
+    c.groups = q.groups;                                   // the reduce that follows reads this many partial slabs
+    p.groups = q.groups;
     dim3 gridm((unsigned)(((c.groups + 7) & ~7) * (nchunks / mc) * nb));
-    if (mc == 2) { if (elu) wgrad_sdm_kernel<2, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<2, 0><<<gridm, 256, 0, s>>>(p); }
+    if (mc == 1) { if (elu) wgrad_sdm_kernel<1, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<1, 0><<<gridm, 256, 0, s>>>(p); }
+    else if (mc == 2) { if (elu) wgrad_sdm_kernel<2, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<2, 0><<<gridm, 256, 0, s>>>(p); }
     else if (mc == 3) { if (elu) wgrad_sdm_kernel<3, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<3, 0><<<gridm, 256, 0, s>>>(p); }
     else return 1;
     return 0;
   }
+  p.groups = c.groups;
   dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
   if (ns == 1) { if (elu) wgrad_sd_kernel<1, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<1, 0><<<grid, 256, 0, s>>>(p); }
   else { if (elu) wgrad_sd_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<2, 0><<<grid, 256, 0, s>>>(p); }
@@ -1034,6 +1083,7 @@ int launch_wgrad_sd(const WgradParams& p0, const WCfg& c, hipStream_t s) {
 int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int64_t ws_bytes, hipStream_t s) {
   WCfg c = pick_wcfg(p.N, p.D, p.H, p.W, p.Cin, p.Cout, taps, false);  // 8x8x16 tiles for k=1 measured slower (convT wgrad 0.76 -> 1.02 ms): off
   int64_t need = (int64_t)c.groups * taps * p.Cin * p.Cout * 4;
+  if (taps == 27) need = std::max(need, (int64_t)sdm_plan(p.N, p.D, p.H, p.W, p.Cin, p.Cout).groups * taps * p.Cin * p.Cout * 4);
   BPX_CHECK(ws != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   p.part = reinterpret_cast<float*>(ws);
   int rc;
@@ -1057,7 +1107,9 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
 extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout, int k) {
   int taps = k * k * k;
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, taps, false);  // small tiles give the larger group count: an upper bound
-  return (int64_t)c.groups * taps * Cin * Cout * 4;
+  int64_t groups = c.groups;
+  if (taps == 27) groups = std::max<int64_t>(groups, sdm_plan(N, D, H, W, Cin, Cout).groups);
+  return groups * taps * Cin * Cout * 4;
 }
 extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);           // fp32: one launch per sub-position
@@ -1070,7 +1122,8 @@ extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, 
 extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
   g_use_tr = use_tr & 1;
   g_wgrad_sd = (use_tr & 4) ? 1 : (use_tr & 2) ? 0 : -1;
-  g_sd_mc = ((use_tr >> 3) & 3) ? ((use_tr >> 3) & 3) : -1;
+  g_sd_mc = ((use_tr >> 3) & 7) == 4 ? 0 : ((use_tr >> 3) & 3) ? ((use_tr >> 3) & 3) : -1;
+  g_sd_fill = (use_tr >> 8) ? (use_tr >> 8) : 100;   // bits 8..: workgroups in percent of the co-resident capacity
   return 0;
 }
 
