@@ -934,6 +934,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   }
 }
 
+int g_ct_resident = 1;   // test hook bit 6 clears it: the former 2048-workgroup target
 struct CtCfg { int ns, groups, totalTiles, tilesY, tilesX, tilesPerSample; };
 inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   CtCfg c;
@@ -943,7 +944,11 @@ inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   c.totalTiles = N * c.tilesPerSample;
   const int nchunks = Cin / 16, nb = Cout / (16 * c.ns);
   const int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / ((int64_t)4 * sz * Cin * Cout));
-  c.groups = (int)std::min<int64_t>(std::min<int64_t>(c.totalTiles, cap), std::max(1, cdiv(2048, nchunks * nb)));
+  // one resident wave of workgroups (256 CUs x occupancy of wgrad_ct_kernel), each looping over its share of the tiles:
+  // measured best for the shift-dy kernels, same structure here
+  const int occ = c.ns == 1 ? 4 : 2;
+  const int64_t want = g_ct_resident ? (cdiv64((int64_t)256 * occ, nchunks * nb) + 7) & ~7ll : std::max(1, cdiv(2048, nchunks * nb));
+  c.groups = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(c.totalTiles, cap), want));
   return c;
 }
 
@@ -1123,6 +1128,7 @@ extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
   g_use_tr = use_tr & 1;
   g_wgrad_sd = (use_tr & 4) ? 1 : (use_tr & 2) ? 0 : -1;
   g_sd_mc = ((use_tr >> 3) & 7) == 4 ? 0 : ((use_tr >> 3) & 3) ? ((use_tr >> 3) & 3) : -1;
+  g_ct_resident = ((use_tr >> 6) & 1) ? 0 : 1;
   g_sd_fill = (use_tr >> 8) ? (use_tr >> 8) : 100;   // bits 8..: workgroups in percent of the co-resident capacity
   return 0;
 }
