@@ -382,3 +382,31 @@ def test_unet_matches_reference_fixture(K, unet_golden, tag, dtype):
 def test_unet2d_cfg1_train_step(K, dtype):
     """BASELINE.json configs[0] (2D U-Net 256x256x1, batch 2): a device train step against the CPU oracle."""
     _assert_all(K.check_unet_cfg1(dtype))
+
+
+def test_train_one_epoch_graph_replay_equals_eager():
+    """biapy_amd.train_engine.train_one_epoch: the HIP-graph replay path (incl. the undo of the capture warm-up and the eager
+    fallback for a ragged last batch) trains exactly like the eager loop of the reference (train_engine.py:127-180)."""
+    from biapy_amd import train_engine as TE
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from biapy_amd.resunet import ResUNet
+
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.randn(2, 16, 16, 16, 1, generator=g), (torch.rand(2, 16, 16, 16, 1, generator=g) > 0.5).float()) for _ in range(5)]
+    data.append((torch.randn(1, 16, 16, 16, 1, generator=g), (torch.rand(1, 16, 16, 16, 1, generator=g) > 0.5).float()))   # ragged last batch
+    nets, stats = [], []
+    for mode in ("off", "on"):
+        torch.manual_seed(0)
+        m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
+                    z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+        s, last = TE.train_one_epoch(m, BCEWithLogitsLoss(), data, opt, torch.device("cuda"), epoch=0, patch_size=(16, 16, 16, 1), graph=mode, sync_every=4)
+        assert last == 5
+        nets.append(m)
+        stats.append(s)
+    assert abs(stats[0]["loss"] - stats[1]["loss"]) < 1e-5, stats
+    for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if p.dim() == 5:
+            assert (p - q).abs().max().item() <= 2e-5 * max(1.0, p.abs().max().item()), k
+    ev = TE.evaluate(nets[1], BCEWithLogitsLoss(), data[:2], torch.device("cuda"), epoch=0)
+    assert 0.0 < ev["loss"] < 2.0

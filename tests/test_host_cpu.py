@@ -95,3 +95,58 @@ def test_prepost_fails_loudly_without_gpu():
 
     with pytest.raises(RuntimeError, match="MI355X only"):
         prepost.threshold_otsu(torch.zeros(4, 4, 4))
+
+
+# ---- train_engine: step drivers (row T) -------------------------------------------------------------------------------
+def _toy_loader(n, B=2, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(B, 4, 6, 6, 1, generator=g), (torch.rand(B, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(n)]
+
+
+def _toy_net(seed=0):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.ELU(), torch.nn.Conv3d(4, 1, 1))
+
+
+def test_train_one_epoch_matches_a_plain_loop():
+    """biapy_amd.train_engine.train_one_epoch (eager form, the one that runs without a GPU) == the reference loop's arithmetic
+    (train_engine.py:127-180): zero_grad, forward on (B,C,Z,Y,X), loss, backward, step; returns ({loss, lr}, last step)."""
+    from biapy_amd import train_engine as TE
+
+    data = _toy_loader(7)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    a, b = _toy_net(), _toy_net()
+    oa, ob = torch.optim.AdamW(a.parameters(), lr=1e-2), torch.optim.AdamW(b.parameters(), lr=1e-2)
+    stats, last = TE.train_one_epoch(a, loss_fn, data, oa, torch.device("cpu"), epoch=0, patch_size=(4, 6, 6, 1), graph="off", sync_every=3)
+    tot = 0.0
+    for x, t in data:
+        ob.zero_grad()
+        loss = loss_fn(b(x.permute(0, 4, 1, 2, 3)), t.permute(0, 4, 1, 2, 3))
+        loss.backward()
+        ob.step()
+        tot += loss.item()
+    assert last == 6 and abs(stats["loss"] - tot / 7) < 1e-6 and stats["lr"] == 1e-2
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, atol=1e-7)
+    ev = TE.evaluate(a, loss_fn, data[:3], torch.device("cpu"), epoch=0)
+    with torch.no_grad():
+        ref = sum(loss_fn(b(x.permute(0, 4, 1, 2, 3)), t.permute(0, 4, 1, 2, 3)).item() for x, t in data[:3]) / 3
+    assert abs(ev["loss"] - ref) < 1e-6
+
+
+def test_train_one_epoch_error_behaviour():
+    """Same failures as the reference: wrong patch shape -> ValueError with its message (train_engine.py:139-143); a non-finite
+    loss -> sys.exit(1) (:166-169)."""
+    from biapy_amd import train_engine as TE
+
+    net, loss_fn = _toy_net(), torch.nn.BCEWithLogitsLoss()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    with pytest.raises(ValueError, match="different shape than 'DATA.PATCH_SIZE'"):
+        TE.train_one_epoch(net, loss_fn, _toy_loader(2), opt, "cpu", 0, patch_size=(8, 6, 6, 1), graph="off")
+    bad = _toy_loader(4)
+    bad[1] = (bad[1][0] * float("nan"), bad[1][1])
+    with pytest.raises(SystemExit) as e:
+        TE.train_one_epoch(net, loss_fn, bad, opt, "cpu", 0, patch_size=(4, 6, 6, 1), graph="off", sync_every=2)
+    assert e.value.code == 1
+    with pytest.raises(ValueError, match="graph='on'"):
+        TE.train_one_epoch(net, loss_fn, _toy_loader(1), opt, "cpu", 0, graph="on")
