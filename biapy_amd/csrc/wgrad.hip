@@ -953,27 +953,37 @@ inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
 }
 
 // sums the per-group partials in a fixed order and writes dW in its final layout.
-// 256 threads = 32 consecutive elements x 8 group lanes (the smallest dW has only 6912 elements; one thread per
-// element would leave the chip idle while it streams ~25 MB of partials).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int groups, int taps, int Cin, int Cout,
-                                                           float* __restrict__ dw, int64_t si, int64_t sj, int64_t st, int64_t off) {
-  __shared__ float red[8][32];
+// 1024 threads = 32 consecutive elements x 32 group lanes, four loads in flight per thread: the smallest dW has only 6912
+// elements (216 blocks) against up to 1024 partial slabs, so the kernel is a latency chain per block - with 8 group lanes
+// and two loads in flight it took ~70 us for the 16->16 layers, more than a quarter of their MFMA kernel.
+__global__ void __launch_bounds__(1024) wgrad_reduce_kernel(const float* __restrict__ part, int groups, int taps, int Cin, int Cout,
+                                                            float* __restrict__ dw, int64_t si, int64_t sj, int64_t st, int64_t off) {
+  __shared__ float red[32][33];
   const int64_t total = (int64_t)taps * Cin * Cout;
   const int e = threadIdx.x & 31, gl = threadIdx.x >> 5;
   const int64_t idx = (int64_t)blockIdx.x * 32 + e;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (idx < total) {
     int gq = gl;
-    for (; gq + 8 < groups; gq += 16) {
+    for (; gq + 96 < groups; gq += 128) {
       s0 += part[(size_t)gq * total + idx];
-      s1 += part[(size_t)(gq + 8) * total + idx];
+      s1 += part[(size_t)(gq + 32) * total + idx];
+      s2 += part[(size_t)(gq + 64) * total + idx];
+      s3 += part[(size_t)(gq + 96) * total + idx];
     }
-    if (gq < groups) s0 += part[(size_t)gq * total + idx];
+    for (; gq < groups; gq += 32) s0 += part[(size_t)gq * total + idx];
   }
-  red[gl][e] = s0 + s1;
+  red[gl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (gl < 4) {           // fixed-order tree: 4 lanes x 8 rows, then 4 values
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[gl * 8 + r][e];
+    red[gl * 8][e] = s;
+  }
   __syncthreads();
   if (gl == 0 && idx < total) {
-    float s = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+    float s = (red[0][e] + red[8][e]) + (red[16][e] + red[24][e]);
     int co = (int)(idx % Cout), ci = (int)((idx / Cout) % Cin), tap = (int)(idx / ((int64_t)Cout * Cin));
     dw[ci * si + co * sj + tap * st + off] = s;
   }
@@ -1102,7 +1112,7 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   BPX_LAUNCH_CHECK(fn);
   int64_t total = (int64_t)taps * p.Cin * p.Cout;
   int blocks = (int)cdiv64(total, 32);
-  wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(p.part, c.groups, taps, p.Cin, p.Cout, p.dw, p.si, p.sj, p.st, p.off);
+  wgrad_reduce_kernel<<<blocks, 1024, 0, s>>>(p.part, c.groups, taps, p.Cin, p.Cout, p.dw, p.si, p.sj, p.st, p.off);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -1175,7 +1185,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     else { if (c.ns == 2) wgrad_ct_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 1><<<grid, 256, 0, s>>>(p); }
     BPX_LAUNCH_CHECK(fn);
     const int64_t total = (int64_t)nsub * x.C * dy.C;   // (Cin, Cout, sz, 2, 2): index = ci*Cout*nsub + co*nsub + sub
-    wgrad_reduce_kernel<<<(int)cdiv64(total, 32), 256, 0, s>>>(p.part, c.groups, nsub, x.C, dy.C, dw_d, (int64_t)dy.C * nsub, nsub, 1, 0);
+    wgrad_reduce_kernel<<<(int)cdiv64(total, 32), 1024, 0, s>>>(p.part, c.groups, nsub, x.C, dy.C, dw_d, (int64_t)dy.C * nsub, nsub, 1, 0);
     BPX_LAUNCH_CHECK(fn);
     return 0;
   }
