@@ -20,8 +20,46 @@ template <typename T> __device__ __forceinline__ float elu_like(float u, int act
 // ------------------------------------------------------------------------------------------------
 // statistics
 // ------------------------------------------------------------------------------------------------
+// Partial arrays of the 128^3 levels have 4-16 K tiles per sample; one block per (sample, 16 channels) walking them is a
+// latency chain (70 us for the transposed-conv statistics).  Above 1024 tiles a first pass with `nseg` blocks per
+// (sample, channel group) sums `seg` consecutive tiles each, in double, and writes the result over the FIRST tile of its
+// own segment (only that block reads the segment, so this is race-free and needs no scratch); the finalize kernels then
+// read every seg-th tile.
+__global__ void __launch_bounds__(1024) stats_compact_kernel(float* __restrict__ part, int tiles, int C, int seg) {
+  __shared__ double red[2][64][16];
+  const int n = blockIdx.y, c0 = blockIdx.x * 16, sg = blockIdx.z;
+  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int t0 = sg * seg, t1 = min(tiles, t0 + seg);
+  double s1 = 0.0, s2 = 0.0;
+  if (c0 + c < C) {
+    const float* pp = part + (size_t)n * tiles * 2 * C + c0 + c;
+    for (int t = t0 + tl; t < t1; t += 64) {
+      s1 += (double)pp[(size_t)t * 2 * C];
+      s2 += (double)pp[(size_t)t * 2 * C + C];
+    }
+  }
+  red[0][tl][c] = s1;
+  red[1][tl][c] = s2;
+  __syncthreads();   // every read of the segment is done
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    double s = 0.0;
+    for (int t = 0; t < 64; ++t) s += red[k][t][cc];
+    if (c0 + cc < C && t0 < tiles) part[((size_t)n * tiles + t0) * 2 * C + (size_t)k * C + c0 + cc] = (float)s;
+  }
+}
+
+// returns the tile stride the finalize kernel has to use (1 = untouched)
+static int compact_stats(float* part, int N, int tiles, int C, hipStream_t s) {
+  if (tiles < 1024) return 1;
+  const int seg = cdiv(tiles, 32);
+  dim3 grid((unsigned)cdiv(C, 16), (unsigned)N, (unsigned)cdiv(tiles, seg));
+  stats_compact_kernel<<<grid, 1024, 0, s>>>(part, tiles, C, seg);
+  return seg;
+}
+
 // part: [N][tiles][2][C].  One 256-thread block per (n, 16-channel group): thread = (tile lane, channel).
-__global__ void __launch_bounds__(1024) norm_finalize_kernel(const float* __restrict__ part, int tiles, int C, double inv_count,
+__global__ void __launch_bounds__(1024) norm_finalize_kernel(const float* __restrict__ part, int tiles, int tstride, int C, double inv_count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             int cpg /* channels per group */, bpx_norm_rec* __restrict__ out,
                                                             int out_ld, int out_off) {
@@ -31,20 +69,22 @@ __global__ void __launch_bounds__(1024) norm_finalize_kernel(const float* __rest
   double s1 = 0.0, s2 = 0.0;
   if (c0 + c < C) {
     const float* pp = part + (size_t)n * tiles * 2 * C + c0 + c;
+    const size_t ts = (size_t)tstride * 2 * C;   // distance between the tiles that hold sums
     // 64 tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    const int nt = (tiles + tstride - 1) / tstride;
     int t = tl;
-    for (; t + 192 < tiles; t += 256) {
-      a0 = pp[(size_t)t * 2 * C]; b0 = pp[(size_t)t * 2 * C + C];
-      a1 = pp[(size_t)(t + 64) * 2 * C]; b1 = pp[(size_t)(t + 64) * 2 * C + C];
-      a2 = pp[(size_t)(t + 128) * 2 * C]; b2 = pp[(size_t)(t + 128) * 2 * C + C];
-      a3 = pp[(size_t)(t + 192) * 2 * C]; b3 = pp[(size_t)(t + 192) * 2 * C + C];
+    for (; t + 192 < nt; t += 256) {
+      a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
+      a1 = pp[(size_t)(t + 64) * ts]; b1 = pp[(size_t)(t + 64) * ts + C];
+      a2 = pp[(size_t)(t + 128) * ts]; b2 = pp[(size_t)(t + 128) * ts + C];
+      a3 = pp[(size_t)(t + 192) * ts]; b3 = pp[(size_t)(t + 192) * ts + C];
       s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
       s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    for (; t < tiles; t += 64) {
-      s1 += (double)pp[(size_t)t * 2 * C];
-      s2 += (double)pp[(size_t)t * 2 * C + C];
+    for (; t < nt; t += 64) {
+      s1 += (double)pp[(size_t)t * ts];
+      s2 += (double)pp[(size_t)t * ts + C];
     }
   }
   red[0][tl][c] = s1;
@@ -99,7 +139,7 @@ __global__ void __launch_bounds__(64) tensor_stats_kernel(const T* __restrict__ 
 //   dx = (gamma*rstd) * (g - S1/M - xhat*S2/M),  xhat = (t-mean)*rstd
 //      = a*g + b*t + c0 with a = gamma*rstd, b = -a*rstd*S2/M, c0 = -a*S1/M + a*mean*rstd*S2/M
 //   dgamma[c] += sum_n S2, dbeta[c] += sum_n S1
-__global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int C,
+__global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int tstride, int C,
                                                                 double inv_count, const bpx_norm_rec* __restrict__ rec,
                                                                 const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, bpx_nbwd_coef* __restrict__ coef) {
@@ -109,20 +149,22 @@ __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __
   double s1 = 0.0, s2 = 0.0;
   if (c0 + c < C) {
     const float* pp = red_part + (size_t)n * tiles * 2 * C + c0 + c;
+    const size_t ts = (size_t)tstride * 2 * C;
     // 64 tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    const int nt = (tiles + tstride - 1) / tstride;
     int t = tl;
-    for (; t + 192 < tiles; t += 256) {
-      a0 = pp[(size_t)t * 2 * C]; b0 = pp[(size_t)t * 2 * C + C];
-      a1 = pp[(size_t)(t + 64) * 2 * C]; b1 = pp[(size_t)(t + 64) * 2 * C + C];
-      a2 = pp[(size_t)(t + 128) * 2 * C]; b2 = pp[(size_t)(t + 128) * 2 * C + C];
-      a3 = pp[(size_t)(t + 192) * 2 * C]; b3 = pp[(size_t)(t + 192) * 2 * C + C];
+    for (; t + 192 < nt; t += 256) {
+      a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
+      a1 = pp[(size_t)(t + 64) * ts]; b1 = pp[(size_t)(t + 64) * ts + C];
+      a2 = pp[(size_t)(t + 128) * ts]; b2 = pp[(size_t)(t + 128) * ts + C];
+      a3 = pp[(size_t)(t + 192) * ts]; b3 = pp[(size_t)(t + 192) * ts + C];
       s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
       s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    for (; t < tiles; t += 64) {
-      s1 += (double)pp[(size_t)t * 2 * C];
-      s2 += (double)pp[(size_t)t * 2 * C + C];
+    for (; t < nt; t += 64) {
+      s1 += (double)pp[(size_t)t * ts];
+      s2 += (double)pp[(size_t)t * ts + C];
     }
   }
   red[0][tl][c] = s1;
@@ -946,7 +988,7 @@ extern "C" int bpx_selftest_layouts(float* out_d, bpx_stream_t stream) {
   return 0;
 }
 
-extern "C" int bpx_norm_finalize(const float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel, const float* gamma_d,
+extern "C" int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel, const float* gamma_d,
                                  const float* beta_d, float eps, int groups, bpx_norm_rec* out_d, int out_ld, int out_off,
                                  bpx_stream_t stream) {
   const char* fn = "bpx_norm_finalize";
@@ -955,7 +997,8 @@ extern "C" int bpx_norm_finalize(const float* stats_part_d, int N, int tiles, in
   int cpg = C / groups;
   BPX_CHECK(cpg == 1 || (16 % cpg == 0), "%s: channels per group %d unsupported (must divide 16)", fn, cpg);
   dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
-  norm_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(stats_part_d, tiles, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
+  const int tstride = compact_stats(stats_part_d, N, tiles, C, (hipStream_t)stream);   // consumes the partials
+  norm_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(stats_part_d, tiles, tstride, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
                                                               cpg, out_d, out_ld, out_off);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -975,12 +1018,13 @@ extern "C" int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, 
   return 0;
 }
 
-extern "C" int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
+extern "C" int bpx_norm_bwd_finalize(float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
                                      const float* gamma_d, float* dgamma_d, float* dbeta_d, bpx_nbwd_coef* coef_d, bpx_stream_t stream) {
   const char* fn = "bpx_norm_bwd_finalize";
   BPX_CHECK(red_part_d && rec_d && coef_d, "%s: null pointer", fn);
   dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
-  norm_bwd_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, C, 1.0 / (double)count_per_channel, rec_d, gamma_d,
+  const int tstride = compact_stats(red_part_d, N, tiles, C, (hipStream_t)stream);     // consumes the partials
+  norm_bwd_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, tstride, C, 1.0 / (double)count_per_channel, rec_d, gamma_d,
                                                                   dgamma_d, dbeta_d, coef_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;

@@ -178,8 +178,9 @@ int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int sz, bpx_te
 
 /* InstanceNorm3d(affine, eps) == GroupNorm with G = C (blocks.py:2122-2125).  Reduces the partials
  * written by a producer kernel to bpx_norm_rec[n*out_ld + out_off + c]; groups < C gives GroupNorm(groups).
- * out_ld/out_off let two producers (up-conv and skip) fill one record array for the concatenated tensor. */
-int bpx_norm_finalize(const float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel,
+ * out_ld/out_off let two producers (up-conv and skip) fill one record array for the concatenated tensor.
+ * The partial array is CONSUMED: with >= 1024 tiles a first pass compacts it in place (no scratch buffer). */
+int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel,
                       const float* gamma_d, const float* beta_d, float eps, int groups,
                       bpx_norm_rec* out_d, int out_ld, int out_off, bpx_stream_t stream);
 /* Stand-alone statistics of a tensor (used for tensors no conv kernel produced, and in tests). */
@@ -188,7 +189,7 @@ int bpx_tensor_stats_tiles(int64_t voxels);
 
 /* Backward of InstanceNorm given the partials from bpx_conv3d_dgrad:
  *   coef[n*C+c] = {a, b, c0} with dx = a*g + b*t + c0 ;  dgamma[c] += sum_n S2 ; dbeta[c] += sum_n S1 */
-int bpx_norm_bwd_finalize(const float* red_part_d, int N, int tiles, int C, int64_t count_per_channel,
+int bpx_norm_bwd_finalize(float* red_part_d /* consumed, see bpx_norm_finalize */, int N, int tiles, int C, int64_t count_per_channel,
                           const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d,
                           bpx_nbwd_coef* coef_d, bpx_stream_t stream);
 /* dx = a*g + b*t + c0 (+ addend): applies the coefficients above elementwise. dx may alias g. */
