@@ -989,6 +989,7 @@ __global__ void __launch_bounds__(1024) wgrad_reduce_kernel(const float* __restr
   }
 }
 
+int g_k1_wgs = 768;    // workgroups targeted by the k = 1 launches: 768 (three per CU) measured best of 256..2048 (test hook: bit 7 + percent of 1024 in bits 8..)
 struct WCfg { int tz, ty, tx, ns, groups; };
 // Deterministic in its arguments: the workspace query and the launch must agree.
 inline WCfg pick_wcfg(int N, int D, int H, int W, int Cin, int Cout, int taps, bool big_ok) {
@@ -1005,7 +1006,7 @@ inline WCfg pick_wcfg(int N, int D, int H, int W, int Cin, int Cout, int taps, b
   for (;;) {
     int nb = Cout / (16 * ns);
     int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / dwElems);           // keep the partial slab <= ~50 MB round trip
-    int groups = (int)std::min<int64_t>(std::min<int64_t>(totalTiles, cap), std::max(1, cdiv(2048, nchunks * nb)));
+    int groups = (int)std::min<int64_t>(std::min<int64_t>(totalTiles, cap), std::max(1, cdiv(taps == 1 ? g_k1_wgs : 2048, nchunks * nb)));
     c.ns = ns; c.groups = groups;
     const int minblk = ((int64_t)D * H * W <= 512) ? 128 : 512;   // 8^3 bottleneck: wider co blocks win (82 -> 61 us); elsewhere NS = 1
     if (ns == 1 || (int64_t)groups * nchunks * nb >= minblk) break;
@@ -1139,7 +1140,8 @@ extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
   g_wgrad_sd = (use_tr & 4) ? 1 : (use_tr & 2) ? 0 : -1;
   g_sd_mc = ((use_tr >> 3) & 7) == 4 ? 0 : ((use_tr >> 3) & 3) ? ((use_tr >> 3) & 3) : -1;
   g_ct_resident = ((use_tr >> 6) & 1) ? 0 : 1;
-  g_sd_fill = (use_tr >> 8) ? (use_tr >> 8) : 100;   // bits 8..: workgroups in percent of the co-resident capacity
+  if ((use_tr >> 7) & 1) { g_k1_wgs = 1024 * (use_tr >> 8) / 100; g_sd_fill = 100; }
+  else g_sd_fill = (use_tr >> 8) ? (use_tr >> 8) : 100;   // bits 8..: workgroups in percent of the co-resident capacity
   return 0;
 }
 
