@@ -70,6 +70,7 @@ struct PwParams {
   int Csub;              // CONVT: Cout (columns per sub-position); CONVTD: channels per sub-position of dy
   const void* wp; const float* bias;
   void* y; int y_ld; int Ncols;            // Ncols = total columns (8*Cout for CONVT)
+  void* y2; int y2_ld; int ysplit;         // CONV1, optional: columns >= ysplit go to y2 (column - ysplit); ysplit % 4 == 0
   // CONV1 extras
   const void* g; int g_ld; const void* t; int t_ld; const bpx_nbwd_coef* coef;
   const void* addend; int addend_ld;
@@ -203,7 +204,16 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[ns][r] += val[ns][r]; s2[ns][r] += val[ns][r] * val[ns][r]; }
     }
-    storeq<T, NS>(yout + ovox * (size_t)p.y_ld + co0, val);
+    if (MODE == PW_CONV1 && p.y2 != nullptr) {   // two dense destinations instead of channel slices of one buffer
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int col = co0 + ns * 4;
+        T* dst = col < p.ysplit ? yout + ovox * (size_t)p.y_ld + col : reinterpret_cast<T*>(p.y2) + ovox * (size_t)p.y2_ld + (col - p.ysplit);
+        storeq<T, 1>(dst, val + ns);
+      }
+    } else {
+      storeq<T, NS>(yout + ovox * (size_t)p.y_ld + co0, val);
+    }
   }
 
   if (MODE == PW_CONVT && p.part != nullptr) {
@@ -258,26 +268,45 @@ int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
 
 extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS) * 4 * (sz == 1 ? 1 : 2); }
 
-extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
-                               bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
-                               bpx_stream_t stream) {
-  const char* fn = "bpx_conv1x1_fwd";
+static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                        bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y, bpx_tensor y2,
+                        bpx_stream_t stream) {
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   int es = (int)dtype_size(dtype);
   if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
   BPX_CHECK(w_packed_d, "%s: weights null", fn);
   if (coef_d) { if (chk(fn, "g", g, es) || chk(fn, "t", t, es)) return 1; }
+  const int ncols = y.C + (y2.ptr ? y2.C : 0);
+  if (y2.ptr) {
+    if (chk(fn, "y_hi", y2, es)) return 1;
+    BPX_CHECK(y.C % 4 == 0 && y2.C % 4 == 0, "%s: split outputs need channel counts that are multiples of 4 (got %d, %d)", fn, y.C, y2.C);
+  }
   PwParams p{};
   p.N = N; p.D = 1; p.H = 1; p.W = 1; p.vps = vps;
   p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
-  p.y = y.ptr; p.y_ld = y.ld; p.Ncols = y.C; p.Csub = y.C;
+  p.y = y.ptr; p.y_ld = y.ld; p.Ncols = ncols; p.Csub = ncols;
+  p.y2 = y2.ptr; p.y2_ld = y2.ld; p.ysplit = y.C;
   p.g = g.ptr; p.g_ld = g.ld; p.t = t.ptr; p.t_ld = t.ld; p.coef = coef_d;
   p.addend = addend.ptr; p.addend_ld = addend.ld;
-  int ns = pw_ns(y.C);
+  int ns = pw_ns(ncols);
   if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream);
   else launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream);
   BPX_LAUNCH_CHECK(fn);
   return 0;
+}
+
+extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                               bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
+                               bpx_stream_t stream) {
+  return conv1x1_impl("bpx_conv1x1_fwd", dtype, N, vps, x, w_packed_d, bias_d, g, t, coef_d, addend, y, bpx_tensor{nullptr, 0, 0}, stream);
+}
+
+extern "C" int bpx_conv1x1_fwd_split(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                                     bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y_lo,
+                                     bpx_tensor y_hi, bpx_stream_t stream) {
+  const char* fn = "bpx_conv1x1_fwd_split";
+  BPX_CHECK(y_hi.ptr != nullptr, "%s: y_hi null", fn);
+  return conv1x1_impl(fn, dtype, N, vps, x, w_packed_d, bias_d, g, t, coef_d, addend, y_lo, y_hi, stream);
 }
 
 extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, const void* w_packed_d, const float* bias_d,

@@ -453,8 +453,13 @@ class ResUNetEngine:
             coef0 = torch.empty((B, Cx, 4), dtype=torch.float32, device=dev)
             L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
                                               G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), coef0.data_ptr(), st))
-            L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
-                                        dx_extra if dx_extra is not None else L.NULL_T, dx_out, st))
+            if isinstance(dx_out, tuple):   # decoder block: the gradient of the concatenated input leaves as its (up, skip) parts
+                assert dx_extra is None
+                L.check(lib.bpx_conv1x1_fwd_split(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
+                                                  L.NULL_T, dx_out[0], dx_out[1], st))
+            else:
+                L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
+                                            dx_extra if dx_extra is not None else L.NULL_T, dx_out, st))
         else:
             L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dH, w1t.data_ptr(), L.NULL_T, None, 0, L.tview(g0), None, st))
             L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.tview(g0), dx_out, st))
@@ -495,18 +500,19 @@ class ResUNetEngine:
             G[f"heads.{h}.bias"].copy_(hbg[o:o + oc])
             o += oc
         # ---- decoder (blocks list: enc 0..Lv-1, bottleneck, dec j=0..Lv-1 for levels Lv-1..0) -------
-        dcat: List[Optional[torch.Tensor]] = [None] * Lv
+        dskip: List[Optional[torch.Tensor]] = [None] * Lv      # d(concat) leaves the decoder block as two dense tensors
         dOut = L.tview(dfeat)
         keep = [dfeat]
         for j in range(Lv - 1, -1, -1):       # decoder block j handles level i = Lv-1-j; walk from level 0 up
             i = Lv - 1 - j
             blk = blocks[Lv + 1 + j]
-            Ccat = fm[i + 1] + fm[i]
-            dcat[i] = torch.empty((B,) + S[i] + (Ccat,), dtype=T, device=dev)
-            self._block_bwd(P, G, blk, B, dOut, img, st, None, L.tview(dcat[i]))
-            # transposed conv backward: dUp = dcat[i][..., :Cup]
             wk, bk, x_in, Cup, Sl, szl = ups[j]
-            dUp = L.tview(dcat[i], 0, Cup)
+            dup = torch.empty((B,) + S[i] + (Cup,), dtype=T, device=dev)
+            dskip[i] = torch.empty((B,) + S[i] + (fm[i],), dtype=T, device=dev)
+            self._block_bwd(P, G, blk, B, dOut, img, st, None, (L.tview(dup), L.tview(dskip[i])))
+            # transposed conv backward
+            keep.append(dup)
+            dUp = L.tview(dup)
             wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, Sl[0], Sl[1], Sl[2], szl, Cup, Cup)
             ws = self._workspace(wsn, dev)
             self._run_side(dev, lambda s_, x_in=x_in, dUp=dUp, wk=wk, bk=bk, Sl=Sl, ws=ws, szl=szl: L.check(lib.bpx_convT3d_k2s2_wgrad(
@@ -523,8 +529,8 @@ class ResUNetEngine:
         for i in range(Lv - 1, -1, -1):
             D, H, W = S[i]
             Cup = fm[i + 1]
-            # dOut_i = dSkip (dcat[i][..., Cup:]) + unpool(dP); written in place over the skip slice
-            skipv = L.tview(dcat[i], Cup, fm[i])
+            # dOut_i = dSkip + unpool(dP); written in place over dSkip
+            skipv = L.tview(dskip[i])
             L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
             if i > 0:
                 dPn = torch.empty((B,) + S[i] + (fm[i - 1],), dtype=T, device=dev)

@@ -160,6 +160,12 @@ typedef struct bpx_nbwd_coef { float a, b, c0, pad; } bpx_nbwd_coef;
 int bpx_conv1x1_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                     bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
                     bpx_stream_t stream);
+/* Same, with the output columns split over two dense tensors: [0, y_lo.C) -> y_lo, the rest -> y_hi (both counts multiples
+ * of 4).  The gradient of torch.cat([up, bridge], 1) (blocks.py:1653) leaves as its two parts, each consumed by a kernel
+ * that would otherwise read a channel slice with a 3/2x or 3x line over-fetch. */
+int bpx_conv1x1_fwd_split(int dtype, int N, int64_t voxels, bpx_tensor x, const void* w_packed_d, const float* bias_d,
+                          bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y_lo,
+                          bpx_tensor y_hi, bpx_stream_t stream);
 
 /* ConvTranspose3d k = s = (sz,2,2), sz = z_down of the level = 1 or 2 (blocks.py:1607):
  * y[n,sz*z+a,2y+b,2x+c,:] = x[n,z,y,x,:]*W[:,:,a,b,c] + b.

@@ -371,6 +371,16 @@ def check_conv1x1(dt, B, vox, Cin, Cout, with_coef=True, seed=0):
     L.check(lib.bpx_conv1x1_fwd(dt, B, vox, L.tview(dyd), wpt.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(dx), L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(tag + ".dgrad_pack", relerr(dx, dy @ rnd(w, dt)), tol_for(dt)))
+    # split output: columns [0, 2/3 Cout) and the rest into two dense tensors must equal the one-tensor result bit for bit
+    if with_coef and Cout % 48 == 0:
+        lo = Cout * 2 // 3
+        y_lo = torch.empty(B, vox, lo, dtype=tdtype(dt), device=DEV)
+        y_hi = torch.empty(B, vox, Cout - lo, dtype=tdtype(dt), device=DEV)
+        L.check(lib.bpx_conv1x1_fwd_split(dt, B, vox, L.tview(xd), wp.data_ptr(), None, L.tview(gd), L.tview(td), cd.data_ptr(), L.tview(ad),
+                                          L.tview(y_lo), L.tview(y_hi), L.stream_ptr()))
+        torch.cuda.synchronize()
+        same = torch.equal(torch.cat([y_lo, y_hi], -1).view(torch.int16 if dt == L.BF16 else torch.int32), y.view(torch.int16 if dt == L.BF16 else torch.int32))
+        res.append(_res(tag + ".split_identical", 0 if same else 1, 0))
     return res
 
 

@@ -94,6 +94,7 @@ def test_pointwise_and_transposed_conv(K, dt):
     rows = []
     rows += K.check_conv1x1(dt, 2, 1000, 16, 48, with_coef=True)
     rows += K.check_conv1x1(dt, 1, 300, 128, 384, with_coef=False)
+    rows += K.check_conv1x1(dt, 2, 777, 32, 96, with_coef=True, seed=2)
     rows += K.check_convT(dt, 2, (4, 6, 8), 32)
     rows += K.check_convT(dt, 1, (2, 2, 2), 256)
     rows += K.check_convT(dt, 2, (5, 6, 8), 32, sz=1)      # anisotropic level (Z_DOWN = 1): kernel (1,2,2)
