@@ -19,8 +19,11 @@ from collections import defaultdict
 GROUPS = [
     ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+>")),
     ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+>")),
-    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sd_)?kernel<|wgrad_reduce_kernel")),
+    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel<|wgrad_reduce_kernel")),
 ]
+
+
+CALLS = defaultdict(int)
 
 
 def collect(db, counter):
@@ -30,6 +33,8 @@ def collect(db, counter):
         for g, rx in GROUPS:
             if rx.search(name):
                 acc[g].append(val)
+                if "reduce" not in name:
+                    CALLS[(db, g)] += 1          # a C-ABI call = one MFMA kernel (+ its reduce kernel for wgrad)
                 break
     return acc
 
@@ -43,8 +48,8 @@ def main():
     for g, _ in GROUPS:
         if g not in f:
             continue
-        nf = launches.get(g, len(f[g]))
-        nw = launches.get(g, len(w.get(g, [])))
+        nf = launches.get(g, CALLS[(fdb, g)] or len(f[g]))
+        nw = launches.get(g, CALLS[(wdb, g)] or len(w.get(g, [])))
         fetch_raw = 1024.0 * sum(f[g]) / nf
         write = 1024.0 * sum(w[g]) / nw if nw else None
         out[g] = dict(launches=nf, fetch_raw_bytes=round(fetch_raw), fetch_bytes=round(2 * fetch_raw), write_bytes=round(write) if write else None,
