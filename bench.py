@@ -40,6 +40,12 @@ def synth_batch(B, P, device, seed):
     return x, t
 
 
+def wgrad_k(key):
+    """Kernel size of a bpx_conv3d_wgrad profile key: the int that follows the second tensor argument."""
+    pos = [i for i, k in enumerate(key) if isinstance(k, str)]
+    return key[pos[1] + 1]
+
+
 def conv_flops(name, key):
     """Algorithmic FLOPs of one conv launch from its profile key (dtype,N,D,H,W,'Cx',...)."""
     if name not in ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad"):
@@ -53,8 +59,8 @@ def conv_flops(name, key):
         return 2 * vox * (27 * cin + csc) * cout
     if name == "bpx_conv3d_dgrad":    # dy, t, g
         return 2 * vox * 27 * cs[0] * cs[2]
-    if name == "bpx_conv3d_wgrad":    # x, dy ; k is the last small int
-        k = ints[-1]
+    if name == "bpx_conv3d_wgrad":    # x, act, dy, k[, small workspace size]
+        k = wgrad_k(key)
         return 2 * vox * (k ** 3) * cs[0] * cs[1]
     return 0
 
@@ -288,7 +294,7 @@ def main():
             print(f"{ms:9.3f} ms {100 * ms / tot:5.1f}% x{cnt:<3d} {tf} {name} {key}")
         return
 
-    prof = L.Profile(names=("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad"))
+    prof = L.Profile(names=("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad", "bpx_wgrad_defer_flush"))
     if not graphed:
         L.lib.prof = prof
     if world > 1:
@@ -327,6 +333,9 @@ def main():
         summ = prof.summary()
         per = {}
         for (name, key), (cnt, ms) in summ.items():
+            if name == "bpx_wgrad_defer_flush":      # the batched reduction of the step's partial slabs is part of the wgrad calls' time
+                per.setdefault("bpx_conv3d_wgrad", [0.0, 0.0, 0, 0.0])[1] += ms
+                continue
             d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
             d[0] += conv_flops(name, key) * cnt
             d[1] += ms

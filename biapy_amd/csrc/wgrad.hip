@@ -19,7 +19,9 @@
 //             slower than the same bytes streamed); a second tiny kernel sums the groups in a fixed
 //             order and writes the PyTorch-layout gradient, so the result is deterministic.
 //             Bias gradient: column sums from the ci-chunk-0 blocks (few atomics).
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "bpx_common.h"
 
@@ -956,37 +958,70 @@ inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
 // 1024 threads = 32 consecutive elements x 32 group lanes, four loads in flight per thread: the smallest dW has only 6912
 // elements (216 blocks) against up to 1024 partial slabs, so the kernel is a latency chain per block - with 8 group lanes
 // and two loads in flight it took ~70 us for the 16->16 layers, more than a quarter of their MFMA kernel.
-__global__ void __launch_bounds__(1024) wgrad_reduce_kernel(const float* __restrict__ part, int groups, int taps, int Cin, int Cout,
-                                                            float* __restrict__ dw, int64_t si, int64_t sj, int64_t st, int64_t off) {
-  __shared__ float red[32][33];
-  const int64_t total = (int64_t)taps * Cin * Cout;
-  const int e = threadIdx.x & 31, gl = threadIdx.x >> 5;
-  const int64_t idx = (int64_t)blockIdx.x * 32 + e;
+struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; };
+
+// 1024 threads = EL consecutive elements x GL group lanes (GL = reduce_glanes(groups), EL = 1024 / GL), up to four loads in
+// flight per thread; lane sums are combined in a fixed order, so the result does not depend on scheduling.
+__host__ __device__ inline int reduce_glanes(int groups) {
+  int gl = 1;
+  while (gl < 32 && gl * 4 < groups) gl <<= 1;   // ~4 slabs per thread and more for the many-group layers
+  return gl;
+}
+inline int reduce_blocks(const ReduceJob& j) { return (int)cdiv64((int64_t)j.taps * j.Cin * j.Cout, 1024 / reduce_glanes(j.groups)); }
+
+__device__ __forceinline__ void wgrad_reduce_block(const ReduceJob& j, int block) {
+  __shared__ float red[1024];
+  const float* __restrict__ part = j.part;
+  const int groups = j.groups;
+  const int GL = reduce_glanes(groups), EL = 1024 / GL;
+  const int64_t total = (int64_t)j.taps * j.Cin * j.Cout;
+  const int e = threadIdx.x % EL, gl = threadIdx.x / EL;
+  const int64_t idx = (int64_t)block * EL + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (idx < total) {
     int gq = gl;
-    for (; gq + 96 < groups; gq += 128) {
+    for (; gq + 3 * GL < groups; gq += 4 * GL) {
       s0 += part[(size_t)gq * total + idx];
-      s1 += part[(size_t)(gq + 32) * total + idx];
-      s2 += part[(size_t)(gq + 64) * total + idx];
-      s3 += part[(size_t)(gq + 96) * total + idx];
+      s1 += part[(size_t)(gq + GL) * total + idx];
+      s2 += part[(size_t)(gq + 2 * GL) * total + idx];
+      s3 += part[(size_t)(gq + 3 * GL) * total + idx];
     }
-    for (; gq < groups; gq += 32) s0 += part[(size_t)gq * total + idx];
+    for (; gq < groups; gq += GL) s0 += part[(size_t)gq * total + idx];
   }
-  red[gl][e] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (gl < 4) {           // fixed-order tree: 4 lanes x 8 rows, then 4 values
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) s += red[gl * 8 + r][e];
-    red[gl * 8][e] = s;
-  }
+  red[gl * EL + e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (gl == 0 && idx < total) {
-    float s = (red[0][e] + red[8][e]) + (red[16][e] + red[24][e]);
-    int co = (int)(idx % Cout), ci = (int)((idx / Cout) % Cin), tap = (int)(idx / ((int64_t)Cout * Cin));
-    dw[ci * si + co * sj + tap * st + off] = s;
+    float s = red[e];
+    for (int q = 1; q < GL; ++q) s += red[q * EL + e];
+    int co = (int)(idx % j.Cout), ci = (int)((idx / j.Cout) % j.Cin), tap = (int)(idx / ((int64_t)j.Cout * j.Cin));
+    j.dw[ci * j.si + co * j.sj + tap * j.st + j.off] = s;
   }
+}
+
+__global__ void __launch_bounds__(1024) wgrad_reduce_kernel(const ReduceJob j) { wgrad_reduce_block(j, (int)blockIdx.x); }
+
+// deferred form: up to 32 pending reductions in ONE launch (bpx_wgrad_defer_begin / _flush).  A layer's reduction is a
+// latency chain of a few hundred blocks; 29 of them back to back cost 0.6 ms per step, together they overlap.
+constexpr int RB_MAX = 32;
+struct ReduceBatch { ReduceJob job[RB_MAX]; int first_block[RB_MAX + 1]; int count; };
+__global__ void __launch_bounds__(1024) wgrad_reduce_batch_kernel(const ReduceBatch b) {
+  int lo = 0, hi = b.count;                          // job k owns blocks [first_block[k], first_block[k+1]); block-uniform search
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= b.first_block[mid]) lo = mid; else hi = mid;
+  }
+  wgrad_reduce_block(b.job[lo], (int)blockIdx.x - b.first_block[lo]);
+}
+
+struct DeferState { bool active = false; std::vector<ReduceJob> jobs; };
+thread_local DeferState t_defer;
+
+// reduce now, or queue the reduction while the deferred mode is on
+int finish_wgrad(const char* fn, const ReduceJob& j, hipStream_t s) {
+  if (t_defer.active) { t_defer.jobs.push_back(j); return 0; }
+  wgrad_reduce_kernel<<<reduce_blocks(j), 1024, 0, s>>>(j);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
 }
 
 int g_k1_wgs = 768;    // workgroups targeted by the k = 1 launches: 768 (three per CU) measured best of 256..2048 (test hook: bit 7 + percent of 1024 in bits 8..)
@@ -1111,11 +1146,7 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   else rc = (taps == 27) ? launch_wgrad<float, 27>(p, c, false, s) : launch_wgrad<float, 1>(p, c, false, s);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
-  int64_t total = (int64_t)taps * p.Cin * p.Cout;
-  int blocks = (int)cdiv64(total, 32);
-  wgrad_reduce_kernel<<<blocks, 1024, 0, s>>>(p.part, c.groups, taps, p.Cin, p.Cout, p.dw, p.si, p.sj, p.st, p.off);
-  BPX_LAUNCH_CHECK(fn);
-  return 0;
+  return finish_wgrad(fn, ReduceJob{p.part, p.dw, c.groups, taps, p.Cin, p.Cout, p.si, p.sj, p.st, p.off}, s);
 }
 
 }  // namespace
@@ -1186,11 +1217,11 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     if (sz == 2) { if (c.ns == 2) wgrad_ct_kernel<2, 2><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 2><<<grid, 256, 0, s>>>(p); }
     else { if (c.ns == 2) wgrad_ct_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 1><<<grid, 256, 0, s>>>(p); }
     BPX_LAUNCH_CHECK(fn);
-    const int64_t total = (int64_t)nsub * x.C * dy.C;   // (Cin, Cout, sz, 2, 2): index = ci*Cout*nsub + co*nsub + sub
-    wgrad_reduce_kernel<<<(int)cdiv64(total, 32), 1024, 0, s>>>(p.part, c.groups, nsub, x.C, dy.C, dw_d, (int64_t)dy.C * nsub, nsub, 1, 0);
-    BPX_LAUNCH_CHECK(fn);
-    return 0;
+    // (Cin, Cout, sz, 2, 2): index = ci*Cout*nsub + co*nsub + sub
+    return finish_wgrad(fn, ReduceJob{p.part, dw_d, c.groups, nsub, x.C, dy.C, (int64_t)dy.C * nsub, nsub, 1, 0}, s);
   }
+  // one launch per sub-position, all through the same workspace: these reductions cannot wait
+  struct NoDefer { bool was; NoDefer() : was(t_defer.active) { t_defer.active = false; } ~NoDefer() { t_defer.active = was; } } no_defer;
   for (int sub = 0; sub < nsub; ++sub) {
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
@@ -1200,6 +1231,36 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     p.dw = dw_d; p.si = (int64_t)dy.C * nsub; p.sj = nsub; p.st = 0; p.off = sub;  // (Cin,Cout,sz,2,2)
     p.db = db_d;  // every sub contributes its voxels to the bias gradient
     if (run_wgrad(fn, dtype, p, 1, ws_d, ws_bytes, (hipStream_t)stream)) return 1;
+  }
+  return 0;
+}
+
+// ---- deferred reductions -------------------------------------------------------------------------------------------------
+extern "C" int bpx_wgrad_defer_begin(void) {
+  t_defer.active = true;
+  t_defer.jobs.clear();
+  return 0;
+}
+
+extern "C" int bpx_wgrad_defer_flush(bpx_stream_t stream) {
+  const char* fn = "bpx_wgrad_defer_flush";
+  std::vector<ReduceJob> jobs;
+  jobs.swap(t_defer.jobs);
+  t_defer.active = false;
+  hipStream_t s = (hipStream_t)stream;
+  for (size_t base = 0; base < jobs.size(); base += RB_MAX) {
+    ReduceBatch b{};
+    b.count = (int)std::min<size_t>(RB_MAX, jobs.size() - base);
+    int blocks = 0;
+    for (int k = 0; k < b.count; ++k) {
+      b.job[k] = jobs[base + k];
+      b.first_block[k] = blocks;
+      blocks += reduce_blocks(b.job[k]);
+    }
+    b.first_block[b.count] = blocks;
+    if (blocks == 0) continue;
+    wgrad_reduce_batch_kernel<<<blocks, 1024, 0, s>>>(b);
+    BPX_LAUNCH_CHECK(fn);
   }
   return 0;
 }

@@ -146,7 +146,12 @@ class ResUNetEngine:
             fn(side.cuda_stream)
 
     def _workspace(self, nbytes: int, dev) -> torch.Tensor:
-        """Grow-only scratch for the wgrad partial sums (launches are stream-ordered, so one slab is enough)."""
+        """Scratch for the wgrad partial sums.  Deferred reductions (backward): one slab per call, kept until the flush.
+        Otherwise grow-only (launches are stream-ordered, so one slab is enough)."""
+        if getattr(self, "_deferred", False):
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            self._keep.append(ws)
+            return ws
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             if self._ws is not None and hasattr(self, "_keep"):
                 self._keep.append(self._ws)   # a side-stream kernel may still be using the old slab
@@ -476,6 +481,29 @@ class ResUNetEngine:
         T = self.dtype
         # one zero-filled slab for all parameter gradients (the wgrad kernels accumulate with atomics)
         self._keep = []   # buffers the side stream may still be reading; released after the final stream join
+        # the ~29 weight-gradient reductions of a step run as one batched launch at the end (they are latency chains of a
+        # few hundred blocks each; back to back they cost 0.6 ms).  Not with the side stream: the flush is stream-ordered.
+        self._deferred = self._side(dlogits.device) is None
+        if self._deferred:
+            L.check(lib.bpx_wgrad_defer_begin())
+        try:
+            return self._backward(P, ctx, dlogits)
+        finally:
+            if self._deferred:
+                self._deferred = False
+                L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
+            self._keep = []
+
+    def _backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        B, S, img = ctx["B"], ctx["S"], ctx["img"]
+        blocks: List[_Blk] = ctx["blocks"]
+        cat, pools, ups, feat = ctx["cat"], ctx["pools"], ctx["ups"], ctx["feat"]
+        fm = list(cfg.feature_maps)
+        Lv = cfg.depth
+        dev = dlogits.device
+        st = L.stream_ptr()
+        T = self.dtype
         names = list(P.keys())
         sizes = [P[n].numel() for n in names]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -542,5 +570,4 @@ class ResUNetEngine:
         side = self._side(dev)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-        self._keep = []
         return G

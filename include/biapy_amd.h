@@ -151,6 +151,13 @@ int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout
 int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                      bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
+/* Deferred reduction of the weight-gradient partials.  Between bpx_wgrad_defer_begin() and bpx_wgrad_defer_flush() (same
+ * host thread) bpx_conv3d_wgrad and the bf16 bpx_convT3d_k2s2_wgrad write only their partial slabs and queue the reduction;
+ * the flush finishes up to 32 of them per launch (dw_d is written then).  Every deferred call needs its OWN workspace, alive
+ * and untouched until the flush has run on the stream.  db_d is not affected (accumulated by the MFMA kernels). */
+int bpx_wgrad_defer_begin(void);
+int bpx_wgrad_defer_flush(bpx_stream_t stream);
+
 /* Per-(n,c) coefficients of InstanceNorm's input gradient, dx = a*g + b*t + c0 (see bpx_norm_bwd_finalize). */
 typedef struct bpx_nbwd_coef { float a, b, c0, pad; } bpx_nbwd_coef;
 
