@@ -19,7 +19,7 @@ from collections import defaultdict
 GROUPS = [
     ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+>")),
     ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+>")),
-    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel<|wgrad_reduce_kernel")),
+    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel<|wgrad_reduce(_batch)?_kernel")),
 ]
 
 
