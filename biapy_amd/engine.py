@@ -39,6 +39,7 @@ class NetConfig:
     activation: str = "elu"
     normalization: str = "in"
     z_down: Optional[Sequence[int]] = None    # MODEL.Z_DOWN per level (1 or 2; None = 2 everywhere); YX_DOWN is always 2
+    ndim: int = 3                             # 2: (B,C,Y,X) tensors, run as one-z-slice volumes (z_down is then 1 everywhere)
 
     def __post_init__(self):
         fm = list(self.feature_maps)
@@ -57,6 +58,42 @@ class NetConfig:
         if sum(self.out_channels) > 4 or fm[0] not in (16, 32):
             raise NotImplementedError("output head supports <= 4 channels from 16 or 32 features")
         self.depth = len(fm) - 1
+
+
+def needs_lift(w: torch.Tensor) -> bool:
+    return w.dim() == 4 or (w.dim() == 5 and w.shape[2] == 1 and w.shape[-1] == 3)
+
+
+def lift_params(P: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Parameters in the shapes the 3-D kernels take.  Conv2d (Cout,Cin,3,3) and anisotropic Conv3d (Cout,Cin,1,3,3) weights
+    become (Cout,Cin,3,3,3) with only the centre z-tap non-zero; other 4-D weights (1x1 convs, ConvTranspose2d (Cin,Cout,2,2))
+    get a unit z extent (a view).  Everything else passes through."""
+    Q = {}
+    for k, w in P.items():
+        if w.dim() == 4 and w.shape[-1] == 3:
+            w5 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=torch.float32, device=w.device)
+            w5[:, :, 1] = w
+            Q[k] = w5
+        elif w.dim() == 5 and w.shape[2] == 1 and w.shape[-1] == 3:
+            w5 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=torch.float32, device=w.device)
+            w5[:, :, 1] = w[:, :, 0]
+            Q[k] = w5
+        elif w.dim() == 4:
+            Q[k] = w.reshape(w.shape[:2] + (1,) + w.shape[2:])
+        else:
+            Q[k] = w
+    return Q
+
+
+def unlift_grads(G: Dict[str, torch.Tensor], P: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Gradients of lifted parameters back in the shapes of the module's parameters (centre z-tap / dropped unit extent)."""
+    out = {}
+    for n, p in P.items():
+        g = G[n]
+        if g.shape != p.shape:
+            g = g[:, :, 1].reshape(p.shape) if p.shape[-1] == 3 else g.reshape(p.shape)
+        out[n] = g if g.is_contiguous() else g.contiguous()
+    return out
 
 
 def block_keys(prefix: str, first: bool) -> Dict[str, str]:
@@ -286,7 +323,20 @@ class ResUNetEngine:
         """x: (B,C,Z,Y,X) fp32 with channels_last_3d strides (or any layout for C == 1).  Returns logits
         (B,sum(out_ch),Z,Y,X) fp32 in channels-first planar layout, and the saved context (or None)."""
         cfg = self.cfg
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == cfg.ndim + 2
+        if cfg.ndim == 2:
+            x = x.unsqueeze(2)
+        P_orig = P
+        if any(needs_lift(w) for w in P.values()):
+            # 2D / anisotropic levels: zero-padded 3x3x3 weights.  Inference keeps the lifted copies while the parameters
+            # are unchanged, so that the packed-operand cache (keyed by storage) keeps hitting.
+            vers = tuple((w.data_ptr(), w._version) for w in P.values())
+            hit = getattr(self, "_lift_cache", None)
+            if cache_weights and hit is not None and hit[0] == vers:
+                P = hit[1]
+            else:
+                P = lift_params(P)
+                self._lift_cache = (vers, P) if cache_weights else None
         B, Cin, D0, H0, W0 = x.shape
         assert Cin == cfg.in_ch, f"expected {cfg.in_ch} input channels, got {Cin}"
         Lv = cfg.depth
@@ -400,9 +450,12 @@ class ResUNetEngine:
         vox0 = D0 * H0 * W0
         L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(dec_in), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(),
                                  n_out * vox0, vox0, st))
+        if cfg.ndim == 2:
+            logits = logits.reshape(B, n_out, H0, W0)
         ctx = None
         if save:
-            ctx = dict(B=B, S=S, img=img, x_ndhwc=x_ndhwc, blocks=blocks, cat=cat, pools=pools, ups=ups, feat=dec_in, hw=hw)
+            ctx = dict(B=B, S=S, img=img, x_ndhwc=x_ndhwc, blocks=blocks, cat=cat, pools=pools, ups=ups, feat=dec_in, hw=hw,
+                       Pw=(P if P is not P_orig else None))
         return logits, ctx
 
     # ------------------------------------------------------------------------------------------
@@ -470,29 +523,21 @@ class ResUNetEngine:
             L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.tview(g0), dx_out, st))
 
     def backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
-        cfg = self.cfg
-        B, S, img = ctx["B"], ctx["S"], ctx["img"]
-        blocks: List[_Blk] = ctx["blocks"]
-        cat, pools, ups, feat = ctx["cat"], ctx["pools"], ctx["ups"], ctx["feat"]
-        fm = list(cfg.feature_maps)
-        Lv = cfg.depth
-        dev = dlogits.device
-        st = L.stream_ptr()
-        T = self.dtype
-        # one zero-filled slab for all parameter gradients (the wgrad kernels accumulate with atomics)
         self._keep = []   # buffers the side stream may still be reading; released after the final stream join
         # the ~29 weight-gradient reductions of a step run as one batched launch at the end (they are latency chains of a
         # few hundred blocks each; back to back they cost 0.6 ms).  Not with the side stream: the flush is stream-ordered.
         self._deferred = self._side(dlogits.device) is None
         if self._deferred:
             L.check(lib.bpx_wgrad_defer_begin())
+        Pw = ctx.get("Pw")
         try:
-            return self._backward(P, ctx, dlogits)
+            G = self._backward(P if Pw is None else Pw, ctx, dlogits)
         finally:
             if self._deferred:
                 self._deferred = False
                 L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
             self._keep = []
+        return G if Pw is None else unlift_grads(G, P)      # after the flush: it is the flush that writes the conv gradients
 
     def _backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
         cfg = self.cfg

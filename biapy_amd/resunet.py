@@ -14,9 +14,13 @@ forward of a leaf layer is ever called - ``forward`` hands the parameter tensors
 :class:`biapy_amd.engine.ResUNetEngine`, and gradients come from its hand-written backward through one
 ``torch.autograd.Function``.
 
-Configurations outside the accelerated hot path (2D, normalisation other than "in", larger_io,
-separated decoders, contrastive head, SR up-sampling, anisotropic (1,k,k) kernels, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2,
-pre-activation order) raise ``NotImplementedError`` at construction: they stay on the reference's
+2D networks and anisotropic levels (``MODEL.ISOTROPY[i] = False``: (1,3,3) kernels) run through the same 3x3x3 kernels with
+zero-padded taps (``engine.lift_params``): correct, but 2/3 of those layers' MFMA work is spent on zeros - they are accepted
+so that the drop-in covers the reference's templates, the tuned path is the isotropic 3D one.
+
+Configurations outside the accelerated hot path (normalisation other than "in", larger_io,
+separated decoders, contrastive head, SR up-sampling, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2,
+pre-activation order, dropout) raise ``NotImplementedError`` at construction: they stay on the reference's
 plain-PyTorch classes, selected by the same registry.
 """
 from __future__ import annotations
@@ -33,37 +37,49 @@ def _act_layer(name: str) -> nn.Module:
     return {"elu": nn.ELU(alpha=1.0, inplace=True), "relu": nn.ReLU(inplace=True), "silu": nn.SiLU(inplace=True)}[name]
 
 
-class ConvBlock(nn.Module):
-    """Parameter holder named like blocks.py:25-192: ``block = Sequential(conv[, norm, act])``."""
+def _conv(ndim: int):
+    return nn.Conv2d if ndim == 2 else nn.Conv3d
 
-    def __init__(self, cin: int, cout: int, k: int, with_norm_act: bool, act: str):
+
+def _inorm(ndim: int, c: int) -> nn.Module:
+    return (nn.InstanceNorm2d if ndim == 2 else nn.InstanceNorm3d)(c, affine=True, momentum=0.1)
+
+
+class ConvBlock(nn.Module):
+    """Parameter holder named like blocks.py:25-192: ``block = Sequential(conv[, norm, act])``.  ``k`` is an int or the
+    reference's kernel tuple ((3,3) in 2D, (1,3,3) for an anisotropic level)."""
+
+    def __init__(self, cin: int, cout: int, k, with_norm_act: bool, act: str, ndim: int = 3):
         super().__init__()
-        layers: List[nn.Module] = [nn.Conv3d(cin, cout, kernel_size=k, padding="same")]
+        layers: List[nn.Module] = [_conv(ndim)(cin, cout, kernel_size=k, padding="same")]
         if with_norm_act:
-            layers += [nn.InstanceNorm3d(cout, affine=True, momentum=0.1), _act_layer(act)]
+            layers += [_inorm(ndim, cout), _act_layer(act)]
         self.block = nn.Sequential(*layers)
 
 
 class ResConvBlock(nn.Module):
     """Parameter holder named like blocks.py:1194-1459 (post-activation order, two convolutions)."""
 
-    def __init__(self, cin: int, cout: int, k: int, act: str, first_block: bool):
+    def __init__(self, cin: int, cout: int, k, act: str, first_block: bool, ndim: int = 3):
         super().__init__()
         layers: List[nn.Module] = []
         if not first_block:
-            layers += [nn.InstanceNorm3d(cin, affine=True, momentum=0.1), _act_layer(act)]
-        layers += [ConvBlock(cin, cout, k, True, act), ConvBlock(cout, cout, k, False, act)]
+            layers += [_inorm(ndim, cin), _act_layer(act)]
+        layers += [ConvBlock(cin, cout, k, True, act, ndim), ConvBlock(cout, cout, k, False, act, ndim)]
         self.block = nn.Sequential(*layers)
-        self.shortcut = nn.Sequential(nn.Conv3d(cin, cout, kernel_size=1, padding="same"))
+        self.shortcut = nn.Sequential(_conv(ndim)(cin, cout, kernel_size=1, padding="same"))
 
 
 class ResUpBlock(nn.Module):
     """Parameter holder named like blocks.py:1462-1655."""
 
-    def __init__(self, cin: int, cbridge: int, cout: int, k: int, act: str, z_down: int = 2):
+    def __init__(self, cin: int, cbridge: int, cout: int, k, act: str, z_down: int = 2, ndim: int = 3):
         super().__init__()
-        self.up = nn.ConvTranspose3d(cin, cin, kernel_size=(z_down, 2, 2), stride=(z_down, 2, 2))   # k = s = (z_down, yx, yx), blocks.py:1607
-        self.conv_block = ResConvBlock(cin + cbridge, cout, k, act, False)
+        if ndim == 2:
+            self.up = nn.ConvTranspose2d(cin, cin, kernel_size=(2, 2), stride=(2, 2))
+        else:
+            self.up = nn.ConvTranspose3d(cin, cin, kernel_size=(z_down, 2, 2), stride=(z_down, 2, 2))   # k = s = (z_down, yx, yx), blocks.py:1607
+        self.conv_block = ResConvBlock(cin + cbridge, cout, k, act, False, ndim)
 
 
 class _ResUNetFn(torch.autograd.Function):
@@ -142,12 +158,13 @@ class ResUNet(nn.Module):
         def unsupported(what):
             raise NotImplementedError(f"biapy_amd.ResUNet: {what} is outside the MI355X hot path; use the reference PyTorch class for it")
 
-        if len(image_shape) != 4:
-            unsupported("2D input")
-        if k_size != 3 or not all(iso):
-            unsupported("kernel size != 3 or anisotropic (1,k,k) kernels")
-        if list(yx_down)[:depth] != [2] * depth or any(int(v) not in (1, 2) for v in list(z_down)[:depth]) or len(list(z_down)) < depth:
-            unsupported("YX_DOWN other than 2 / Z_DOWN other than 1 or 2")
+        ndim = 3 if len(image_shape) == 4 else 2
+        if k_size != 3:
+            unsupported("kernel size != 3")
+        if list(yx_down)[:depth] != [2] * depth:
+            unsupported("YX_DOWN other than 2")
+        if ndim == 3 and (len(list(z_down)) < depth or any(int(v) not in (1, 2) for v in list(z_down)[:depth])):
+            unsupported("Z_DOWN other than 1 or 2")
         if upsample_layer != "convtranspose":
             unsupported("upsample_layer != 'convtranspose'")
         if separated_decoders or contrast or larger_io or len(upsampling_factor) > 0:
@@ -159,7 +176,7 @@ class ResUNet(nn.Module):
         if explicit_activations or "class" in output_channel_info:
             unsupported("explicit head activations / classification head")
         self.depth = depth
-        self.ndim = 3
+        self.ndim = ndim
         self.z_down, self.yx_down = z_down, yx_down
         self.output_channels = output_channels
         self.output_channel_info = output_channel_info
@@ -169,9 +186,11 @@ class ResUNet(nn.Module):
         self.explicit_activations = False
         self.return_one_tensor = return_one_tensor
         in_ch = image_shape[-1]
-        zd = [int(v) for v in list(z_down)[:depth]]
+        zd = [int(v) for v in list(z_down)[:depth]] if ndim == 3 else [1] * depth
         self.cfg = NetConfig(in_ch=in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
-                             normalization=normalization, z_down=zd)
+                             normalization=normalization, z_down=zd, ndim=ndim)
+        # kernel of level i (resunet.py:239-241, :260-262, :282-284): (3,3) in 2D, (1,3,3) where MODEL.ISOTROPY[i] is False
+        ks = [(3, 3) if ndim == 2 else ((3, 3, 3) if iso[i] else (1, 3, 3)) for i in range(depth + 1)]
         self.compute_dtype = compute_dtype
         self._engine: Optional[ResUNetEngine] = None
 
@@ -181,27 +200,27 @@ class ResUNet(nn.Module):
         self.mpooling_layers = nn.ModuleList()
         c = in_ch
         for i in range(depth):
-            self.down_path.append(ResConvBlock(c, feature_maps[i], k_size, act, first_block=(i == 0)))
-            self.mpooling_layers.append(nn.MaxPool3d((zd[i], 2, 2)))
+            self.down_path.append(ResConvBlock(c, feature_maps[i], ks[i], act, first_block=(i == 0), ndim=ndim))
+            self.mpooling_layers.append(nn.MaxPool2d((2, 2)) if ndim == 2 else nn.MaxPool3d((zd[i], 2, 2)))
             c = feature_maps[i]
-        self.bottleneck = ResConvBlock(c, feature_maps[-1], k_size, act, False)
+        self.bottleneck = ResConvBlock(c, feature_maps[-1], ks[-1], act, False, ndim)
         self.num_decoders = 1
         self.up_paths = nn.ModuleList([nn.ModuleList()])
         c = feature_maps[-1]
         for i in range(depth - 1, -1, -1):
-            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], k_size, act, zd[i]))
+            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], ks[i], act, zd[i], ndim))
             c = feature_maps[i]
         self.conv_out = None
         self.post_upsampling = None
         self.heads = nn.Sequential()
         for oc in output_channels:
-            self.heads.append(nn.Conv3d(feature_maps[0], oc, kernel_size=1, padding="same"))
+            self.heads.append(_conv(ndim)(feature_maps[0], oc, kernel_size=1, padding="same"))
         self._init_weights()
 
     def _init_weights(self):
         # blocks.py:2301-2336: Xavier-uniform + zero bias on Conv3d only (ConvTranspose3d keeps PyTorch's default)
         for m in self.modules():
-            if isinstance(m, nn.Conv3d):
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
                 nn.init.xavier_uniform_(m.weight)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)

@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib as L
-from .engine import EPS, NetConfig, ResUNetEngine, _recs, _Stats
+from .engine import EPS, NetConfig, ResUNetEngine, _recs, _Stats, lift_params, unlift_grads
 
 lib = L.lib
 
@@ -50,21 +50,9 @@ class UNetEngine(ResUNetEngine):
         self.ndim = ndim
         self.nconvs = nconvs
 
-    # ---- parameters: 2D weights are lifted to one-z-slice 3D weights ------------------------------------------------------
+    # ---- parameters: 2D weights are lifted to one-z-slice 3D weights (engine.lift_params) -----------------------------------
     def _lift(self, P: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        if self.ndim == 3:
-            return P
-        Q = {}
-        for k, w in P.items():
-            if w.dim() == 4 and w.shape[-1] == 3:                    # Conv2d (Cout,Cin,3,3) -> (Cout,Cin,3,3,3), centre z-tap
-                w5 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=torch.float32, device=w.device)
-                w5[:, :, 1] = w
-                Q[k] = w5
-            elif w.dim() == 4:                                       # ConvTranspose2d (Cin,Cout,2,2) / 1x1 head: add a unit z extent
-                Q[k] = w.reshape(w.shape[:2] + (1,) + w.shape[2:])
-            else:
-                Q[k] = w
-        return Q
+        return lift_params(P) if self.ndim == 2 else P
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     def _conv_block_fwd(self, P, prefix, B, S, cin, cout, x, img, out_view, st, dev) -> _CB:
@@ -294,11 +282,4 @@ class UNetEngine(ResUNetEngine):
             else:
                 self._conv_block_bwd(Pw, G, blocks[0], B, skipv, img, None, st, dev)   # the image needs no gradient
         self._keep = []
-        # ---- un-lift: gradients in the shapes of the module's parameters ------------------------------------------------
-        out = {}
-        for n, p in P.items():
-            g = G[n]
-            if g.shape != p.shape:
-                g = g[:, :, 1] if (p.dim() == 4 and p.shape[-1] == 3) else g.reshape(p.shape)
-            out[n] = g.contiguous() if not g.is_contiguous() else g
-        return out
+        return unlift_grads(G, P)   # gradients in the shapes of the module's parameters

@@ -57,8 +57,8 @@ def _norm(x: torch.Tensor, sd, key: str, kind: str, groups: int = 8) -> torch.Te
 
 def _conv(x, sd, key):
     w = sd[key + ".weight"]
-    pad = tuple(k // 2 for k in w.shape[2:])
-    return F.conv3d(x, w, sd.get(key + ".bias"), padding=pad)
+    pad = tuple(k // 2 for k in w.shape[2:])      # "same" for the odd kernels of the path: 3, 1, (1,3,3), (3,3)
+    return (F.conv2d if w.dim() == 4 else F.conv3d)(x, w, sd.get(key + ".bias"), padding=pad)
 
 
 def res_conv_block(x, sd, prefix: str, first_block: bool, act: str, norm: str):
@@ -93,14 +93,18 @@ def resunet_forward(
     z_down = list(z_down) if z_down is not None else [2] * depth
     yx_down = list(yx_down) if yx_down is not None else [2] * depth
     skips: List[torch.Tensor] = []
+    two_d = x.dim() == 4                               # 2D network (resunet.py:195-207 picks the 2D layer classes)
     for i in range(depth):
         x = res_conv_block(x, sd, f"down_path.{i}", i == 0, activation, normalization)
         skips.append(x)
-        x = F.max_pool3d(x, (z_down[i], yx_down[i], yx_down[i]))
+        x = F.max_pool2d(x, yx_down[i]) if two_d else F.max_pool3d(x, (z_down[i], yx_down[i], yx_down[i]))
     x = res_conv_block(x, sd, "bottleneck", False, activation, normalization)
     for j, i in enumerate(range(depth - 1, -1, -1)):
         s = (z_down[i], yx_down[i], yx_down[i])
-        up = F.conv_transpose3d(x, sd[f"up_paths.0.{j}.up.weight"], sd[f"up_paths.0.{j}.up.bias"], stride=s)
+        if two_d:
+            up = F.conv_transpose2d(x, sd[f"up_paths.0.{j}.up.weight"], sd[f"up_paths.0.{j}.up.bias"], stride=yx_down[i])
+        else:
+            up = F.conv_transpose3d(x, sd[f"up_paths.0.{j}.up.weight"], sd[f"up_paths.0.{j}.up.bias"], stride=s)
         x = torch.cat([up, skips[i]], 1)
         x = res_conv_block(x, sd, f"up_paths.0.{j}.conv_block", False, activation, normalization)
     outs = [_conv(x, sd, f"heads.{h}") for h in range(n_heads)]

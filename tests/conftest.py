@@ -78,3 +78,10 @@ def unet_golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "unet_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def resunet_variants_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunet_variants_golden.npz"))

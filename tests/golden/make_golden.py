@@ -389,8 +389,60 @@ def unet_fixtures():
     print("unet_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "unet_golden.npz")) // 1024, "KiB")
 
 
+def resunet_variants_fixtures():
+    """ResUNet configurations that run through zero-padded 3x3x3 kernels: a 2D network (fm 16-32-64, 64x64) and a 3D one with
+    anisotropic levels (MODEL.ISOTROPY = [False, False, True] -> (1,3,3) kernels, Z_DOWN = [1, 2]).  Reference logits, loss,
+    gradient norms and a few full gradients."""
+    rmod = shim.load("biapy.models.resunet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import net_oracle
+
+    out = {}
+    for tag, fm, patch, zd, iso, seed in (("2d", [16, 32, 64], (64, 64), [2, 2], [True] * 3, 31),
+                                          ("anisok", [16, 32, 64], (8, 32, 32), [1, 2], [False, False, True], 32)):
+        depth = len(fm) - 1
+        torch.manual_seed(seed)
+        with quiet():
+            net = rmod.ResUNet(
+                image_shape=tuple(patch) + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", k_size=3,
+                upsample_layer="convtranspose", yx_down=[2] * depth, z_down=zd, output_channels=[1], output_channel_info=["F"],
+                head_activations=["ce_sigmoid"], isotropy=iso, larger_io=False, conv_layers=[2] * len(fm),
+            )
+        g = torch.Generator().manual_seed(100 + seed)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if v.ndim == 1:
+                    v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+        B = 2
+        xl = torch.randn(B, *patch, 1, generator=g)
+        x = xl.permute(0, len(patch) + 1, *range(1, len(patch) + 1))
+        tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+        net.train()
+        logits = net(x)
+        loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)
+        loss.backward()
+        out[f"{tag}/feature_maps"], out[f"{tag}/z_down"], out[f"{tag}/isotropy"] = np.array(fm), np.array(zd), np.array(iso)
+        out[f"{tag}/x"], out[f"{tag}/target"] = xl.numpy(), tgt.numpy().astype(np.uint8)
+        out[f"{tag}/logits"], out[f"{tag}/loss"] = logits.detach().numpy(), np.array(loss.item(), dtype=np.float64)
+        for k, v in net.state_dict().items():
+            out[f"{tag}/sd/{k}"] = v.numpy()
+        names = dict(net.named_parameters())
+        for k, p_ in names.items():
+            out[f"{tag}/gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+        for k in ["down_path.0.block.0.block.0.weight", "down_path.1.block.2.block.0.weight", "up_paths.0.0.up.weight",
+                  "up_paths.0.1.conv_block.shortcut.0.weight", "heads.0.weight"]:
+            out[f"{tag}/grad/{k}"] = names[k].grad.numpy()
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        lo = net_oracle.resunet_forward(sd, x, fm, z_down=zd)
+        err = (lo - logits.detach()).abs().max().item()
+        print(f"resunet {tag}: kernel shapes {sorted(set(tuple(v.shape[2:]) for v in sd.values() if v.ndim >= 4))}, oracle vs reference {err:.3e}")
+        assert err < 2e-5
+    np.savez_compressed(os.path.join(HERE, "resunet_variants_golden.npz"), **out)
+    print("resunet_variants_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_variants_golden.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -405,3 +457,5 @@ if __name__ == "__main__":
         resunet_aniso_fixtures()
     if "unet" in which:
         unet_fixtures()
+    if "resunet_variants" in which:
+        resunet_variants_fixtures()

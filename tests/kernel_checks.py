@@ -701,11 +701,20 @@ def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0):
     return res
 
 
-def check_unet(dtype, tag, golden):
+def check_resunet_variant(dtype, tag, golden):
+    """ResUNet configurations that run on zero-padded 3x3x3 kernels - 2D, and 3D with MODEL.ISOTROPY False levels ((1,3,3)
+    kernels) - against the reference fixture tests/golden/resunet_variants_golden.npz, through the module."""
+    from biapy_amd.resunet import ResUNet
+
+    return check_unet(dtype, tag, golden, cls=ResUNet, name="resunet_" + tag)
+
+
+def check_unet(dtype, tag, golden, cls=None, name=None):
     """Plain U-Net (2D / 3D) against the reference fixture tests/golden/unet_golden.npz: logits, loss, every gradient norm and
     the stored full gradients, through the module (load_state_dict strict -> forward -> autograd backward)."""
     from biapy_amd.unet import U_Net
 
+    cls = cls or U_Net
     tagd = "bf16" if dtype == torch.bfloat16 else "f32"
     fm = [int(v) for v in golden[f"{tag}/feature_maps"]]
     zd = [int(v) for v in golden[f"{tag}/z_down"]]
@@ -715,15 +724,16 @@ def check_unet(dtype, tag, golden):
     nd = xl.dim() - 2
     x = xl.permute(0, nd + 1, *range(1, nd + 1)).contiguous()
     tgt = torch.from_numpy(golden[f"{tag}/target"]).float()
-    m = U_Net(image_shape=tuple(xl.shape[1:]), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in",
-              yx_down=[2] * (len(fm) - 1), z_down=zd, isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm), compute_dtype=dtype)
+    iso = [bool(v) for v in golden[f"{tag}/isotropy"]] if f"{tag}/isotropy" in golden.files else [True] * len(fm)
+    m = cls(image_shape=tuple(xl.shape[1:]), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in",
+            yx_down=[2] * (len(fm) - 1), z_down=zd, isotropy=iso, larger_io=False, conv_layers=[2] * len(fm), compute_dtype=dtype)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).train()
     logits = m(x.to(DEV))
     loss = F.binary_cross_entropy_with_logits(logits, tgt.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
-    name = f"unet{tag}[{tagd} fm={fm}]"
+    name = f"{name or 'unet' + tag}[{tagd} fm={fm}]"
     lo_ref = torch.from_numpy(golden[f"{tag}/logits"])
     bf = dtype == torch.bfloat16
     res = [_res(name + ".logits_rel", (logits.detach().cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 6e-2 if bf else 2e-4)]

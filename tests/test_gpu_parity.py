@@ -411,3 +411,10 @@ def test_train_one_epoch_graph_replay_equals_eager():
             assert (p - q).abs().max().item() <= 2e-5 * max(1.0, p.abs().max().item()), k
     ev = TE.evaluate(nets[1], BCEWithLogitsLoss(), data[:2], torch.device("cuda"), epoch=0)
     assert 0.0 < ev["loss"] < 2.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["2d", "anisok"])
+def test_resunet_2d_and_anisotropic_kernels(K, resunet_variants_golden, tag, dtype):
+    """biapy_amd.resunet.ResUNet in 2D and with MODEL.ISOTROPY False levels ((1,3,3) kernels) vs the reference's own outputs."""
+    _assert_all(K.check_resunet_variant(dtype, tag, resunet_variants_golden))
