@@ -6,6 +6,7 @@ Public surface mirrors the reference names for this path:
   biapy_amd.tiling.crop_3D_data_with_overlap      <- biapy.data.data_3D_manipulation.crop_3D_data_with_overlap
   biapy_amd.tiling.merge_3D_data_with_overlap     <- biapy.data.data_3D_manipulation.merge_3D_data_with_overlap
   biapy_amd.workflow.SlidingWindowPredictor       <- Base_Workflow.process_test_sample (per-patch branch)
+  biapy_amd.chunked.ChunkedPredictor / ChunkGrid  <- chunked_test_pair_data_generator + process_test_sample_by_chunks (in-HBM volumes)
   biapy_amd.train_engine.train_one_epoch/evaluate <- biapy.engine.train_engine.train_one_epoch / evaluate
   biapy_amd.losses / prepost / tta                <- biapy.engine.metrics, biapy.data.norm + semantic_seg Otsu, biapy.data.post_processing TTA
 """

@@ -79,6 +79,75 @@ extern "C" int bpx_crop3d_gather(const void* vol_d, int elem_size, int Z, int Y,
 }
 
 // ------------------------------------------------------------------------------------------------
+// by-chunks tiler (biapy/data/generators/chunked_test_pair_data_generator.py:440-565, base_workflow.py:2603-2610):
+// a patch is the padded read region of one chunk, clipped to the volume and completed by np.pad(..., "reflect"); its
+// prediction is written back without the padding.  The reflection is about the edges of the CLIPPED region, so the host
+// expresses it as three source-index tables per patch (chunked.ChunkGrid.index_tables) and the gather is table driven.
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) gather3d_tables_kernel(const E* __restrict__ vol, int Y, int X, int C, const int* __restrict__ tables,
+                                                              int Pz, int Py, int Px, E* __restrict__ out, int64_t total) {
+  const int64_t per = (int64_t)Pz * Py * Px * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per;
+    int64_t r = i - b * per;
+    const int c = (int)(r % C); r /= C;
+    const int x = (int)(r % Px); r /= Px;
+    const int y = (int)(r % Py);
+    const int z = (int)(r / Py);
+    const int* t = tables + b * (int64_t)(Pz + Py + Px);
+    out[i] = vol[(((size_t)t[z] * Y + t[Pz + y]) * X + t[Pz + Py + x]) * C + c];
+  }
+}
+
+// regions: per patch {src z0,y0,x0 (first voxel kept, i.e. the padding stripped), dst z0,y0,x0, length z,y,x}
+__global__ void __launch_bounds__(256) scatter3d_regions_kernel(const float* __restrict__ pred, int Py, int Px, int C, int64_t patch_elems,
+                                                                const int* __restrict__ regions, float* __restrict__ out, int Y, int X) {
+  const int b = blockIdx.y;
+  const int* r = regions + b * 9;
+  const int lz = r[6], ly = r[7], lx = r[8];
+  const int64_t n = (int64_t)lz * ly * lx * C;
+  const float* src = pred + (size_t)b * patch_elems;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t q = i;
+    const int c = (int)(q % C); q /= C;
+    const int x = (int)(q % lx); q /= lx;
+    const int y = (int)(q % ly);
+    const int z = (int)(q / ly);
+    out[(((size_t)(r[3] + z) * Y + r[4] + y) * X + r[5] + x) * C + c] = src[(((size_t)(r[0] + z) * Py + r[1] + y) * Px + r[2] + x) * C + c];
+  }
+}
+
+extern "C" int bpx_gather3d_tables(const void* vol_d, int elem_size, int Z, int Y, int X, int C, const int* tables_d, int n, int Pz, int Py, int Px,
+                                   void* out_d, bpx_stream_t stream) {
+  const char* fn = "bpx_gather3d_tables";
+  BPX_CHECK(vol_d && out_d && tables_d, "%s: null pointer", fn);
+  BPX_CHECK(elem_size == 1 || elem_size == 2 || elem_size == 4, "%s: elem_size %d unsupported", fn, elem_size);
+  BPX_CHECK(Z > 0 && Y > 0 && X > 0 && C > 0 && n >= 0 && Pz > 0 && Py > 0 && Px > 0, "%s: bad extents", fn);
+  const int64_t total = (int64_t)n * Pz * Py * Px * C;
+  if (total == 0) return 0;
+  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (elem_size == 4) gather3d_tables_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint32_t*)out_d, total);
+  else if (elem_size == 2) gather3d_tables_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint16_t*)out_d, total);
+  else gather3d_tables_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint8_t*)out_d, total);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_scatter3d_regions(const float* pred_d, int n, int Pz, int Py, int Px, int C, const int* regions_d, float* out_d, int Z, int Y,
+                                     int X, bpx_stream_t stream) {
+  const char* fn = "bpx_scatter3d_regions";
+  BPX_CHECK(pred_d && out_d && regions_d, "%s: null pointer", fn);
+  BPX_CHECK(n >= 0 && Pz > 0 && Py > 0 && Px > 0 && C > 0 && Z > 0 && Y > 0 && X > 0, "%s: bad extents", fn);
+  if (n == 0) return 0;
+  dim3 grid((unsigned)std::min<int64_t>(cdiv64((int64_t)Pz * Py * Px * C, 256), 1024), (unsigned)n);
+  scatter3d_regions_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(pred_d, Py, Px, C, (int64_t)Pz * Py * Px * C, regions_d, out_d, Y, X);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge
 // ------------------------------------------------------------------------------------------------
 template <typename E> __device__ __forceinline__ float load_as_f32(const E* p);

@@ -73,6 +73,16 @@ int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int Py, int Px, 
                       float* acc_d, float* wacc_d, int write_partial,
                       void* out_d, int out_dtype, bpx_stream_t stream);
 
+/* By-chunks tiler (chunked_test_pair_data_generator.py:440-565; base_workflow.py:2603-2610).
+ * gather: out[b,z,y,x,c] = vol[tz[z], ty[y], tx[x], c] with the three int32 source-index tables of patch b stored back to
+ * back in tables_d[b*(Pz+Py+Px) ...] (they encode the clipped read region + np.pad "reflect"); data moves bit-exactly.
+ * scatter: the prediction of patch b without its padding goes to its place in the output volume; regions_d[b*9 ...] =
+ * {first kept voxel of the patch z,y,x ; destination z,y,x ; extent z,y,x}.  Regions of different patches are disjoint. */
+int bpx_gather3d_tables(const void* vol_d, int elem_size, int Z, int Y, int X, int C, const int* tables_d, int n, int Pz, int Py, int Px,
+                        void* out_d, bpx_stream_t stream);
+int bpx_scatter3d_regions(const float* pred_d, int n, int Pz, int Py, int Px, int C, const int* regions_d, float* out_d, int Z, int Y,
+                          int X, bpx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Network kernels.  T = BPX_BF16 (bf16 storage, fp32 accumulate, v_mfma_f32_16x16x32_bf16) or
  * BPX_F32 (fp32 storage, exact-fp32 v_mfma_f32_16x16x4_f32; the parity/debug mode).

@@ -85,3 +85,10 @@ def resunet_variants_golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "resunet_variants_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def chunked_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "chunked_golden.npz"))

@@ -441,8 +441,82 @@ def resunet_variants_fixtures():
     print("resunet_variants_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_variants_golden.npz")) // 1024, "KiB")
 
 
+def chunked_fixtures():
+    """By-chunks tiler: the reference generator's own ``_patch_coords`` / ``extract_and_prepare_sample`` on seeded uint8
+    volumes (the class is loaded with the third-party modules it never calls on this path stubbed; a bare object carrying the
+    attributes its ``__init__`` derives (:272-289) stands in for a Zarr-backed instance)."""
+    import importlib
+    import math
+    import types
+
+    shim.install()
+
+    class _Any(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            sub = _Any(self.__name__ + "." + k)
+            sys.modules[sub.__name__] = sub
+            return sub
+
+        def __call__(self, *a, **k):
+            return self
+
+    g = types.ModuleType("biapy.data.generators")
+    g.__path__ = [os.path.join(shim.REF, "biapy/data/generators")]
+    sys.modules["biapy.data.generators"] = g
+    mod = None
+    for _ in range(40):
+        try:
+            mod = importlib.import_module("biapy.data.generators.chunked_test_pair_data_generator")
+            break
+        except ModuleNotFoundError as e:
+            if e.name.startswith("biapy"):
+                raise
+            sys.modules[e.name] = _Any(e.name)
+    cls = mod.chunked_test_pair_data_generator
+    out = {}
+    # d: padding wider than the last, clipped chunk -> np.pad reflects more than once about the edges of the clipped region
+    cases = [("a", (70, 90, 100), (32, 32, 32), (4, 8, 2), False, 11), ("b", (40, 64, 64), (32, 32, 32), (0, 0, 0), False, 12),
+             ("c", (33, 47, 129), (16, 32, 64), (3, 5, 10), True, 13), ("d", (18, 33, 65), (16, 32, 64), (6, 12, 24), False, 14)]
+    for tag, dim, crop, pad, keep, seed in cases:
+        rs = np.random.RandomState(seed)
+        vol = rs.randint(0, 256, size=dim + (1,)).astype(np.uint8)
+        me = types.SimpleNamespace()
+        me.X_parallel_data, me.Y_parallel_data = vol, None
+        me.input_axes = me.mask_input_axes = "ZYXC"
+        me.crop_shape, me.padding = crop + (1,), pad
+        me.z_dim, me.y_dim, me.x_dim = dim
+        me.step_z, me.step_y, me.step_x = (c - 2 * p for c, p in zip(crop, pad))
+        me.vols_per_z, me.vols_per_y, me.vols_per_x = (math.ceil(d / s) for d, s in zip(dim, (me.step_z, me.step_y, me.step_x)))
+        me.z_vol_start, me.vols_per_z_effective = 0, me.vols_per_z
+        me.convert_to_rgb, me.norm_module = False, {}
+        total = me.vols_per_z * me.vols_per_y * me.vols_per_x
+        ext, real, pads, patches = [], [], [], []
+        for vid in range(total):
+            z, y, x, pe, pr = cls._patch_coords(me, vid)
+            data, added = cls.extract_and_prepare_sample(me, z, y, x, pe)
+            ext.append([pe.z_start, pe.z_end, pe.y_start, pe.y_end, pe.x_start, pe.x_end])
+            real.append([pr.z_start, pr.z_end, pr.y_start, pr.y_end, pr.x_start, pr.x_end])
+            pads.append(added)
+            patches.append(data)
+        out[f"{tag}/dim"], out[f"{tag}/crop"], out[f"{tag}/padding"] = np.array(dim), np.array(crop), np.array(pad)
+        out[f"{tag}/extract"], out[f"{tag}/real"], out[f"{tag}/added_pad"] = np.array(ext), np.array(real), np.array(pads)
+        out[f"{tag}/patch_sums"] = np.array([int(p_.astype(np.int64).sum()) for p_ in patches])
+        out[f"{tag}/patch_wsums"] = np.array([int((p_.astype(np.int64).ravel() * (np.arange(p_.size) % 977 + 1)).sum()) for p_ in patches])
+        if keep:
+            out[f"{tag}/vol"] = vol
+            out[f"{tag}/patches"] = np.stack(patches)
+        out[f"{tag}/seed"] = np.array(seed)       # vol = RandomState(seed).randint(0, 256, dim + (1,)).astype(uint8)
+        print(f"chunked {tag}: dim {dim} crop {crop} pad {pad}: {total} chunks")
+    np.savez_compressed(os.path.join(HERE, "chunked_golden.npz"), **out)
+    print("chunked_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "chunked_golden.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -459,3 +533,5 @@ if __name__ == "__main__":
         unet_fixtures()
     if "resunet_variants" in which:
         resunet_variants_fixtures()
+    if "chunked" in which:
+        chunked_fixtures()

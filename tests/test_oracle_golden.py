@@ -297,3 +297,74 @@ def test_resunet_variants_oracle_and_module(resunet_variants_golden, tag, shape)
                 z_down=zd, isotropy=iso, larger_io=False, conv_layers=[2] * len(fm))
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+
+
+def _chunked_case(g, tag):
+    dim, crop, pad = tuple(int(v) for v in g[f"{tag}/dim"]), tuple(int(v) for v in g[f"{tag}/crop"]), tuple(int(v) for v in g[f"{tag}/padding"])
+    vol = np.random.RandomState(int(g[f"{tag}/seed"])).randint(0, 256, size=dim + (1,)).astype(np.uint8)
+    return dim, crop, pad, vol
+
+
+def _wsum(p):
+    return int((p.astype(np.int64).ravel() * (np.arange(p.size) % 977 + 1)).sum())
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_chunked_oracle_and_host_grid_match_reference(chunked_golden, tag):
+    """By-chunks tiler: oracle/chunked_oracle.py AND the product's host arithmetic (biapy_amd.chunked.ChunkGrid: regions, reflect
+    index tables, strip offsets) against the reference generator's own per-chunk outputs - read region, write-back region,
+    padding added, and the padded patches (position-weighted checksums for all chunks, full arrays for case c)."""
+    from biapy_amd.chunked import ChunkGrid
+    from oracle import chunked_oracle as CO
+
+    g = chunked_golden
+    dim, crop, pad, vol = _chunked_case(g, tag)
+    if f"{tag}/vol" in g.files:
+        np.testing.assert_array_equal(vol, g[f"{tag}/vol"])
+    grid = ChunkGrid(dim, crop, pad)
+    assert grid.total == g[f"{tag}/extract"].shape[0]
+    Pz, Py, Px = crop
+    for vid in range(grid.total):
+        q, ext, real = CO.patch_coords(vid, dim, crop, pad)
+        assert [v for ab in ext for v in ab] == list(g[f"{tag}/extract"][vid]) and [v for ab in real for v in ab] == list(g[f"{tag}/real"][vid])
+        patch, _, strip = CO.extract(vol, vid, crop, pad)
+        assert strip == g[f"{tag}/added_pad"][vid].tolist()[:3]      # the reference appends [0, 0] for the channel axis
+        assert int(patch.astype(np.int64).sum()) == int(g[f"{tag}/patch_sums"][vid]) and _wsum(patch) == int(g[f"{tag}/patch_wsums"][vid])
+        # product host logic
+        _, _, _, pe, pr = grid.patch_coords(vid)
+        assert list(pe) == list(g[f"{tag}/extract"][vid]) and list(pr) == list(g[f"{tag}/real"][vid])
+        t = grid.index_tables(vid)
+        mine = vol[t[:Pz]][:, t[Pz:Pz + Py]][:, :, t[Pz + Py:]]
+        np.testing.assert_array_equal(mine, patch)
+        r = grid.region(vid)
+        assert list(r[:3]) == [s[0] for s in strip] and list(r[3:6]) == [pr.z_start, pr.y_start, pr.x_start]
+        if f"{tag}/patches" in g.files:
+            np.testing.assert_array_equal(patch, g[f"{tag}/patches"][vid])
+
+
+def test_chunked_rank_order_is_the_distributed_sampler():
+    """ChunkGrid.rank_order == torch's DistributedSampler(shuffle=False) over the chunk ids (generator __iter__, :603-612)."""
+    from torch.utils.data import DistributedSampler
+
+    from biapy_amd.chunked import ChunkGrid
+
+    grid = ChunkGrid((33, 47, 129), (16, 32, 64), (3, 5, 10))
+    ids = list(range(grid.total))
+    for world in (1, 2, 3, 5, 8, 40):
+        for rank in range(world):
+            ref = list(DistributedSampler(ids, num_replicas=world, rank=rank, shuffle=False))
+            assert grid.rank_order(world, rank) == ref
+    with pytest.raises(ValueError, match="Axis problem"):
+        ChunkGrid((10, 47, 129), (16, 32, 64), (3, 5, 10))
+    with pytest.raises(ValueError, match="can not be greater than half"):
+        ChunkGrid((33, 47, 129), (16, 32, 64), (8, 5, 10))
+
+
+def test_chunked_oracle_identity_round_trip(chunked_golden):
+    """read -> identity prediction -> strip -> insert reproduces the volume (the chunks tile it exactly)."""
+    from oracle import chunked_oracle as CO
+
+    for tag in ("c", "d"):
+        dim, crop, pad, vol = _chunked_case(chunked_golden, tag)
+        out = CO.predict_by_chunks(vol, lambda p: p.astype(np.float32), crop, pad)
+        np.testing.assert_array_equal(out, vol.astype(np.float32))
