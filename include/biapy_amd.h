@@ -32,7 +32,12 @@ int bpx_version(void);
 const char* bpx_last_error(void);
 /* MFMA / LDS-transpose lane-layout self test (prints nothing; writes 64*16 floats). Used by tests. */
 int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
-int bpx_debug_set_wgrad_tr(int use_tr); /* test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 */
+/* Test / A-B hook of the weight-gradient kernels (default 1).  bit 0: ds_read_b64_tr_b16 operands (0 = scalar LDS gathers);
+ * bits 1-2 choose the bf16 3x3x3 schedule: 2 = never a shift-dy kernel, 4 = always; bits 3-5: input-channel chunks per
+ * workgroup of the windowed shift-dy kernel (1, 2, 3 forced; 4 = the plain shift-dy kernel); bit 6: transposed-conv wgrad
+ * with the former 2048-workgroup target; bit 7 + bits 8..: k = 1 launches target (value)% of 1024 workgroups; without bit 7,
+ * bits 8..: windowed kernel workgroups in percent of the co-resident capacity. */
+int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test hook: 0 = plain 4-wave conv kernel instead of the wave-specialised one (bf16) */
 
