@@ -154,7 +154,8 @@ class ResUNetEngine:
         self.act = L.ACT[cfg.activation]
         self._ws: Optional[torch.Tensor] = None
         self._side_stream = None
-        self.use_side_stream = False  # measured on cfg 2: 19.5 ms/step with the side stream vs 18.1 ms without (kernels already fill the chip)
+        self.use_side_stream = False  # measured on cfg 2: 19.5 vs 18.1 ms/step (early kernels, eager); 11.13 vs 11.18 with the final kernels
+        # under graph replay, 21 vs 15 ms eager - every kernel already launches one resident wave of workgroups
         self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._pack_versions: Dict[Tuple[int, int, int], int] = {}
 
