@@ -135,6 +135,25 @@ def main():
         print(f"crop  512^3 -> {plan.n_patches} x 128^3: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)")
 
 
+def bench_convt(reps=20):
+    """Transposed conv forward 32->32 @64^3 -> 128^3 (B=4): output into a channel slice of the 48-channel concat buffer vs a dense tensor."""
+    B, S, Cc = 4, 64, 32
+    st = L.stream_ptr()
+    x = torch.randn(B, S, S, S, Cc, device=DEV).to(torch.bfloat16)
+    w = torch.randn(Cc, Cc, 2, 2, 2, device=DEV) / Cc ** 0.5
+    b = torch.zeros(Cc, device=DEV)
+    n = lib.bpx_packed_weight_elems(L.PK_CT, Cc, Cc, L.BF16)
+    wp = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.bpx_pack_weight(L.PK_CT, w.data_ptr(), Cc, Cc, L.BF16, wp.data_ptr(), st))
+    tiles = lib.bpx_convT3d_stats_tiles(S, S, S, 2)
+    part = torch.empty(B, tiles, 2, Cc, device=DEV)
+    for ld, name in ((48, "slice of a 48-channel buffer"), (32, "dense"), (64, "slice of a 64-channel buffer")):
+        y = torch.empty(B, 2 * S, 2 * S, 2 * S, ld, dtype=torch.bfloat16, device=DEV)
+        f = lambda: L.check(lib.bpx_convT3d_k2s2_fwd(L.BF16, B, S, S, S, 2, L.tview(x), wp.data_ptr(), b.data_ptr(), L.tview(y, 0, Cc), part.data_ptr(), st))
+        ms = timeit(f, reps)
+        print(f"convT fwd 32->32 64^3->128^3 into {name}: {ms * 1e3:8.1f} us  {(x.numel() + B * (2 * S) ** 3 * Cc) * 2 / ms / 1e6:8.1f} GB/s")
+
+
 def bench_chunked():
     """By-chunks inference of a 512^3 float32 volume: 128^3 patches, padding 16 -> 96^3 chunks (216 of them), cfg-2 ResUNet bf16."""
     import time
@@ -193,6 +212,9 @@ def bench_prepost(reps=5):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "convt":
+        bench_convt()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "chunked":
         bench_chunked()
         sys.exit(0)
