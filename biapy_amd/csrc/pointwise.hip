@@ -90,17 +90,25 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const int col_base = nb * 16 * NS;
 
   // voxel of lane (j) for each m-subtile
-  int64_t v[MS];
+  // voxels per sample < 2^31 (checked on the host): 32-bit index math - the 64-bit div/mod sequences of the transposed-conv
+  // coordinates were ~300 of the kernel's ~490 VALU instructions per wave, which bound it
+  uint32_t v[MS];
   bool valid[MS];
   size_t abase[MS];  // element offset of the voxel's channel 0 in x (CONV1/CONVT) or of sub-position 0 in dy (CONVTD)
+  uint32_t cx[MS], cy[MS], cz[MS];   // (x, y, z) of the voxel on the p.W x p.H x p.D grid (CONVT / CONVTD)
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
-    v[ms] = ((int64_t)mb * 4 + wave) * (MS * 16) + ms * 16 + j;
-    valid[ms] = v[ms] < p.vps;
-    int64_t vv = valid[ms] ? v[ms] : 0;
+    v[ms] = ((uint32_t)mb * 4u + (uint32_t)wave) * (uint32_t)(MS * 16) + (uint32_t)(ms * 16 + j);
+    valid[ms] = v[ms] < (uint32_t)p.vps;
+    const uint32_t vv = valid[ms] ? v[ms] : 0u;
+    if (MODE != PW_CONV1) {
+      const uint32_t row = vv / (uint32_t)p.W;
+      cx[ms] = vv - row * (uint32_t)p.W;
+      cz[ms] = row / (uint32_t)p.H;
+      cy[ms] = row - cz[ms] * (uint32_t)p.H;
+    }
     if (MODE == PW_CONVTD) {
-      int xw = (int)(vv % p.W), yh = (int)((vv / p.W) % p.H), zd = (int)(vv / ((int64_t)p.W * p.H));
-      abase[ms] = ((((size_t)n * p.sz * p.D + p.sz * zd) * 2 * p.H + 2 * yh) * 2 * p.W + 2 * xw) * (size_t)p.x_ld;
+      abase[ms] = ((((size_t)n * p.sz * p.D + p.sz * cz[ms]) * 2 * p.H + 2 * cy[ms]) * 2 * p.W + 2 * cx[ms]) * (size_t)p.x_ld;
     } else {
       abase[ms] = ((size_t)n * p.vps + vv) * (size_t)p.x_ld;
     }
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     if (!valid[ms]) continue;
     size_t ovox;
     if (MODE == PW_CONVT) {
-      int xw = (int)(v[ms] % p.W), yh = (int)((v[ms] / p.W) % p.H), zd = (int)(v[ms] / ((int64_t)p.W * p.H));
+      const int xw = (int)cx[ms], yh = (int)cy[ms], zd = (int)cz[ms];
       int a = (sub >> 2) & 1, b = (sub >> 1) & 1, cc = sub & 1;
       ovox = (((size_t)n * p.sz * p.D + p.sz * zd + a) * 2 * p.H + 2 * yh + b) * 2 * p.W + 2 * xw + cc;
     } else {
@@ -222,9 +230,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a = s1[ns][r], b = s2[ns][r];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        const float a = row16_sum(s1[ns][r]), b = row16_sum(s2[ns][r]);   // over the 16 voxels of the lane row: DPP, no LDS
         if (j == 0) {
           red[((wave * NS * 16) + g * 4 * NS + ns * 4 + r) * 2 + 0] = a;   // slot = column offset inside the block
           red[((wave * NS * 16) + g * 4 * NS + ns * 4 + r) * 2 + 1] = b;
@@ -247,6 +253,7 @@ inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 :
 
 template <typename T, int MODE>
 int launch_pw(PwParams& p, int ns, hipStream_t s) {
+  if (p.vps >= (1ll << 31) - 64 * PW_MS) { bpx_set_error("pointwise kernels: more than 2^31 voxels per sample"); return 1; }
   p.mblocks = (int)cdiv64(p.vps, 64 * PW_MS);
   int nbk = p.Ncols / (16 * ns);
   dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
@@ -289,8 +296,7 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
   p.g = g.ptr; p.g_ld = g.ld; p.t = t.ptr; p.t_ld = t.ld; p.coef = coef_d;
   p.addend = addend.ptr; p.addend_ld = addend.ld;
   int ns = pw_ns(ncols);
-  if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream);
-  else launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream);
+  if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -322,8 +328,7 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
   p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Ncols = 4 * sz * y.C; p.Csub = y.C; p.part = stats_part_d;
   int ns = pw_ns(y.C);
-  if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream);
-  else launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream);
+  if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -341,8 +346,7 @@ extern "C" int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, int
   p.x = dy.ptr; p.x_ld = dy.ld; p.K = 4 * sz * dy.C; p.Csub = dy.C; p.wp = w_packed_T_d;
   p.y = dx.ptr; p.y_ld = dx.ld; p.Ncols = dx.C;
   int ns = pw_ns(dx.C);
-  if (dtype == BPX_BF16) launch_pw<uint16_t, PW_CONVTD>(p, ns, (hipStream_t)stream);
-  else launch_pw<float, PW_CONVTD>(p, ns, (hipStream_t)stream);
+  if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVTD>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONVTD>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
