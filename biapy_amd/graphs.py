@@ -130,22 +130,68 @@ class DataParallelTrainStep:
 
         self._fwd_bwd, self._update = fwd_bwd, update
         self.graphs = None
+        self.adopted = False
         if graph:
-            def eager():
-                fwd_bwd()
-                self._all_reduce()
-                update()
-
             side = torch.cuda.Stream()                                   # warm-up and capture on ONE stream: the parameters'
-            _warm(eager, warmup, side)                                   # AccumulateGrad nodes remember the stream they were made on
+            #                                                              AccumulateGrad nodes remember the stream they were made on
+            # Zero-copy form: when autograd leaves the gradients as consecutive views of ONE allocation in parameter order
+            # (the MI355X engine writes every parameter gradient into one slab), that slab IS the flat buffer - no zero-fill
+            # and no per-parameter accumulate kernels (98 small launches, ~0.3 ms per step for cfg 2).
+            def fwd_bwd_adopt():
+                optimizer.zero_grad(set_to_none=True)
+                loss = loss_fn(model(self.x), self.target)
+                loss.backward()
+                return loss
+
+            def probe():
+                fwd_bwd_adopt()
+
+            _warm(probe, 1, side)
+            self.adopted = self._adopted_flat() is not None
+            if self.adopted:
+                def eager():
+                    fwd_bwd_adopt()
+                    self.flat_grad = self._adopted_flat()
+                    self._all_reduce()
+                    update()
+            else:
+                off = 0
+                for p in self.params:                                    # the probe replaced the views
+                    p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+
+                def eager():
+                    fwd_bwd()
+                    self._all_reduce()
+                    update()
+
+            _warm(eager, warmup, side)
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
-                self.loss = fwd_bwd()
+                self.loss = fwd_bwd_adopt() if self.adopted else fwd_bwd()
+            if self.adopted:
+                self.flat_grad = self._adopted_flat()                    # the slab of the captured run: static across replays
+                if self.flat_grad is None:
+                    raise RuntimeError("gradient layout changed between warm-up and capture")
             with torch.cuda.graph(g2, pool=g1.pool(), stream=side, capture_error_mode="thread_local"):
                 update()
             torch.cuda.synchronize()
             self._check_views()
             self.graphs = (g1, g2)
+
+    def _adopted_flat(self) -> Optional[torch.Tensor]:
+        """The gradients as one flat tensor if they are consecutive contiguous fp32 views of one allocation, in parameter order."""
+        g0 = self.params[0].grad
+        if g0 is None:
+            return None
+        store, base, off = g0.untyped_storage(), g0.data_ptr(), 0
+        for p in self.params:
+            g = p.grad
+            if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != store.data_ptr()
+                    or g.data_ptr() != base + 4 * off):
+                return None
+            off += p.numel()
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(store, g0.storage_offset(), (off,), (1,))
 
     def _check_views(self):
         base = self.flat_grad.data_ptr()

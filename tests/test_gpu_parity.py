@@ -477,3 +477,40 @@ def test_chunked_predictor_matches_oracle_pipeline():
     ref = CO.predict_by_chunks(vol, f, crop, pad)
     got = ChunkedPredictor(m.predict_proba, crop, pad, batch_size=5).predict(torch.from_numpy(vol).cuda()).cpu().numpy()
     assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5
+
+
+def test_data_parallel_step_adopts_the_engine_gradient_slab():
+    """graphs.DataParallelTrainStep in graph mode: the engine's one-slab gradients are adopted as the flat all-reduce buffer
+    (no accumulate kernels) and three replayed steps equal three eager steps."""
+    from biapy_amd.graphs import DataParallelTrainStep
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from biapy_amd.resunet import ResUNet
+
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(2, 1, 16, 16, 16, generator=g).cuda(), (torch.rand(2, 1, 16, 16, 16, generator=g) > 0.5).float().cuda()) for _ in range(3)]
+    nets = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
+                    z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda().train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+        if graph:
+            snap = ([p.detach().clone() for p in m.parameters()])
+            step = DataParallelTrainStep(m, BCEWithLogitsLoss(), opt, data[0][0], data[0][1], graph=True, warmup=1)
+            assert step.adopted
+            with torch.no_grad():                                   # undo the warm-up steps (train_engine does the same)
+                for p, s in zip(m.parameters(), snap):
+                    p.copy_(s)
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+        else:
+            step = DataParallelTrainStep(m, BCEWithLogitsLoss(), opt, data[0][0], data[0][1], graph=False)
+        for x, t in data:
+            step(x, t)
+        torch.cuda.synchronize()
+        nets.append(m)
+    for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if p.dim() == 5:
+            assert (p - q).abs().max().item() <= 2e-5 * max(1.0, p.abs().max().item()), k
