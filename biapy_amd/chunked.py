@@ -108,8 +108,12 @@ class ChunkGrid:
 class ChunkedPredictor:
     """``predict(vol)``: by-chunks prediction of a device-resident ``(Z, Y, X, C)`` volume; returns ``(Z, Y, X, Cout)`` float32."""
 
-    def __init__(self, forward: Callable[[torch.Tensor], torch.Tensor], crop_zyx: Sequence[int], padding: Sequence[int], batch_size: int = 4):
+    def __init__(self, forward: Callable[[torch.Tensor], torch.Tensor], crop_zyx: Sequence[int], padding: Sequence[int], batch_size: int = 4,
+                 out_channels: Optional[int] = None):
+        """out_channels: channels of the prediction; only needed when a rank can end up without chunks (world > chunks), so
+        that it can still take part in the reduction with an all-zero partial result."""
         self.forward, self.crop, self.padding, self.batch = forward, tuple(int(v) for v in crop_zyx[:3]), tuple(int(v) for v in padding), int(batch_size)
+        self.out_channels = out_channels
 
     @torch.no_grad()
     def predict(self, vol: torch.Tensor, rank: int = 0, world: int = 1, gather: str = "all", group=None) -> Optional[torch.Tensor]:
@@ -145,7 +149,9 @@ class ChunkedPredictor:
         if world > 1 and gather != "none":   # "none": this rank's chunks only (zeros elsewhere), no collective
             # every chunk belongs to exactly one rank and the others hold zeros there: the sum is the union, bit for bit
             if out is None:
-                raise RuntimeError("a rank without chunks cannot size the result; use world <= number of chunks")
+                if self.out_channels is None:
+                    raise RuntimeError("a rank without chunks cannot size the result: pass out_channels, or use world <= number of chunks")
+                out = torch.zeros((Z, Y, X, self.out_channels), dtype=torch.float32, device=vol.device)
             if gather == "all":
                 dist.all_reduce(out, group=group)
             else:
