@@ -71,6 +71,19 @@ class GraphedTrainStep:
         return self.loss
 
 
+@torch.no_grad()
+def broadcast_parameters_from_rank0(params, group=None) -> None:
+    """What ``DistributedDataParallel`` does when it wraps a module (base_workflow.py:952-958): every rank starts from rank 0's
+    parameters.  One packed broadcast."""
+    params = list(params)
+    pack = torch.cat([p.reshape(-1) for p in params])
+    dist.broadcast(pack, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    off = 0
+    for p in params:
+        p.copy_(pack[off:off + p.numel()].view_as(p))
+        off += p.numel()
+
+
 class DataParallelTrainStep:
     """Data-parallel step, one process per GPU: ``[zero grads, forward, loss, backward]`` -> all-reduce -> ``[mean, optimizer]``.
 
@@ -102,13 +115,7 @@ class DataParallelTrainStep:
                 if not g.get("capturable", False):
                     raise ValueError("build the optimizer with capturable=True to capture its step")
         if self.world > 1 and broadcast_parameters:                      # DDP's construction-time broadcast from rank 0
-            with torch.no_grad():
-                pack = torch.cat([p.reshape(-1) for p in self.params])
-                dist.broadcast(pack, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                off = 0
-                for p in self.params:
-                    p.copy_(pack[off:off + p.numel()].view_as(p))
-                    off += p.numel()
+            broadcast_parameters_from_rank0(self.params, group)
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:

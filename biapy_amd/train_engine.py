@@ -124,9 +124,15 @@ def train_one_epoch(
             if gstep is None:
                 from . import graphs
 
-                cls = graphs.DataParallelTrainStep if _world() > 1 else graphs.GraphedTrainStep
+                multi = _world() > 1
+                if multi and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+                    graphs.broadcast_parameters_from_rank0(inner.parameters())    # a DDP wrap has done this already
                 snap = _snapshot(inner, optimizer)                      # capture warms up with real optimizer steps: undo them
-                gstep, gshape = cls(inner, loss_function, optimizer, x, t), (tuple(x.shape), tuple(t.shape))
+                if multi:
+                    gstep = graphs.DataParallelTrainStep(inner, loss_function, optimizer, x, t, broadcast_parameters=False)
+                else:
+                    gstep = graphs.GraphedTrainStep(inner, loss_function, optimizer, x, t)
+                gshape = (tuple(x.shape), tuple(t.shape))
                 _restore(inner, optimizer, snap)
             if (tuple(x.shape), tuple(t.shape)) == gshape:
                 loss = gstep(x, t)

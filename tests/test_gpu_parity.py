@@ -514,3 +514,74 @@ def test_data_parallel_step_adopts_the_engine_gradient_slab():
     for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
         if p.dim() == 5:
             assert (p - q).abs().max().item() <= 2e-5 * max(1.0, p.abs().max().item()), k
+
+
+def _dp2_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors too: two ranks can share one GPU
+    torch.cuda.set_device(0)
+    from biapy_amd import train_engine as TE
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from biapy_amd.resunet import ResUNet
+
+    g = torch.Generator().manual_seed(20 + rank)
+    data = [(torch.randn(2, 16, 16, 16, 1, generator=g), (torch.rand(2, 16, 16, 16, 1, generator=g) > 0.5).float()) for _ in range(3)]
+    torch.manual_seed(0 if rank == 0 else 7)                            # rank 1 starts elsewhere: the step must broadcast rank 0's weights
+    m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
+                z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+    stats, _ = TE.train_one_epoch(m, BCEWithLogitsLoss(), data, opt, torch.device("cuda"), epoch=0, patch_size=(16, 16, 16, 1), graph="on")
+    q.put((rank, stats["loss"], {k: p.detach().cpu().numpy() for k, p in m.named_parameters() if p.dim() == 5}))   # arrays pickle by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_data_parallel_training_on_one_gpu():
+    """Two ranks (gloo, both on cuda:0) through train_one_epoch's graph path = DataParallelTrainStep: parameters broadcast from
+    rank 0, one flat all-reduce between the two graph replays, gradients averaged.  Both ranks must end with the weights a
+    single process gets from the concatenated batches (mean loss over 4 samples = mean of the two ranks' mean losses)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from biapy_amd.resunet import ResUNet
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    # single-process reference on the concatenated batches
+    gens = [torch.Generator().manual_seed(20 + r) for r in range(2)]
+    per_rank = [[(torch.randn(2, 16, 16, 16, 1, generator=g), (torch.rand(2, 16, 16, 16, 1, generator=g) > 0.5).float()) for _ in range(3)] for g in gens]
+    torch.manual_seed(0)
+    m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
+                z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+    loss_fn, tot = BCEWithLogitsLoss(), 0.0
+    for k in range(3):
+        x = torch.cat([per_rank[0][k][0], per_rank[1][k][0]]).permute(0, 4, 1, 2, 3).cuda()
+        t = torch.cat([per_rank[0][k][1], per_rank[1][k][1]]).permute(0, 4, 1, 2, 3).cuda()
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(m(x), t)
+        loss.backward()
+        opt.step()
+        tot += loss.item()
+    ref = {k: p.detach().cpu() for k, p in m.named_parameters() if p.dim() == 5}
+    assert abs(res[0][1] - res[1][1]) < 1e-7 and abs(res[0][1] - tot / 3) < 1e-5, (res[0][1], res[1][1], tot / 3)
+    for k, w in ref.items():
+        a, b = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
+        assert torch.equal(a, b), k                                            # the ranks stay bit-identical
+        assert (a - w).abs().max().item() <= 2e-5 * max(1.0, w.abs().max().item()), k
