@@ -185,6 +185,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("BPX_BENCH_ONE_DEVICE") == "1":   # testing aid: all ranks on cuda:0 (a 1-GPU box can then run the N > 1 launch line)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or a.force_ddp
@@ -193,7 +195,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", init_method="env://")
+        # "nccl" IS RCCL on ROCm; BPX_BENCH_BACKEND=gloo is a testing aid (gloo moves device tensors too, so two ranks can share a GPU)
+        dist.init_process_group(os.environ.get("BPX_BENCH_BACKEND", "nccl"), init_method="env://")
 
     from biapy_amd import _lib as L
     from biapy_amd.resunet import ResUNet
