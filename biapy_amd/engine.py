@@ -18,7 +18,7 @@ Data layout in HBM (all NDHWC, storage dtype T = bf16 or f32):
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import ctypes as C

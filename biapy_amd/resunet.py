@@ -25,7 +25,7 @@ plain-PyTorch classes, selected by the same registry.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.nn as nn

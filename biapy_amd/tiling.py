@@ -12,7 +12,7 @@ scalars); everything that touches voxel data is on the device.
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch

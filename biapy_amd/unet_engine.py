@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib as L
-from .engine import EPS, NetConfig, ResUNetEngine, _recs, _Stats, lift_params, unlift_grads
+from .engine import NetConfig, ResUNetEngine, _recs, _Stats, lift_params, unlift_grads
 
 lib = L.lib
 
