@@ -333,6 +333,79 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Channel attention of the RCAN trunk (biapy/models/rcan.py ChannelAttention / RCAB_rcan: x + h * sigmoid(MLP(avgpool(h)))):
+//   channel_affine: y = [x +] s[n,c] * h [+ off[n,c]]     (forward: x + s*h ; backward: dh = s*dy + dmean/voxels)
+//   dot_stats:      part[n][block][c] = sum over the block's voxels of a*b   (ds[n,c] = sum_v dy*h)
+// Same thread mapping as norm_act_*: one sample per blockIdx.y, a thread keeps its channel group.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) channel_affine_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ h, int h_ld,
+                                                             const float* __restrict__ sc, const float* __restrict__ off, T* __restrict__ y,
+                                                             int y_ld, int C, int64_t vps) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int G = C / KPL;
+  const int n = blockIdx.y;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float ks[KPL], ko[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    ks[e] = sc[(size_t)n * C + cg * KPL + e];
+    ko[e] = off ? off[(size_t)n * C + cg * KPL + e] : 0.f;
+  }
+  const size_t base = (size_t)n * vps;
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const size_t vox = base + (size_t)(i / G);
+    float hf[KPL], o[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(h + vox * h_ld + cg * KPL), hf);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) o[e] = ks[e] * hf[e] + ko[e];
+    if (x) {
+      float xf[KPL];
+      unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), xf);
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) o[e] += xf[e];
+    }
+    *reinterpret_cast<u32x4_t*>(y + vox * y_ld + cg * KPL) = pack16<T>(o);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dot_stats_kernel(const T* __restrict__ a, int a_ld, const T* __restrict__ b, int b_ld, int C,
+                                                        int64_t vps, float* __restrict__ part) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  extern __shared__ float dred[];   // [256][KPL]
+  const int G = C / KPL;
+  const int n = blockIdx.y, tiles = gridDim.x;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float s[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) s[e] = 0.f;
+  const size_t base = (size_t)n * vps;
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const size_t vox = base + (size_t)(i / G);
+    float af[KPL], bf[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(a + vox * a_ld + cg * KPL), af);
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(b + vox * b_ld + cg * KPL), bf);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) s[e] += af[e] * bf[e];
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) dred[threadIdx.x * KPL + e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int grp = c / KPL, e = c % KPL;
+    const int lane0 = (int)(((int64_t)grp - (int64_t)blockIdx.x * blockDim.x % G + G) % G);
+    float acc = 0.f;
+    for (int t = lane0; t < (int)blockDim.x; t += G) acc += dred[t * KPL + e];
+    part[((size_t)n * tiles + blockIdx.x) * C + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // max pooling 2x2x2
 // ------------------------------------------------------------------------------------------------
 constexpr int POOL_IPT = 4;  // items (output voxel x 16-byte channel group) per thread
@@ -1183,6 +1256,42 @@ extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy,
   else if (dtype == BPX_F32)
     norm_act_bwd_kernel<float><<<grid, 256, shm, s>>>((const float*)dy.ptr, dy.ld, (const float*)x.ptr, x.ld, rec_d, act,
                                                       (const float*)addend.ptr, addend.ld, (float*)g.ptr, g.ld, x.C, voxels, red_part_d);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x, bpx_tensor h, const float* scale_d, const float* offset_d,
+                                  bpx_tensor y, bpx_stream_t stream) {
+  const char* fn = "bpx_channel_affine";
+  BPX_CHECK(h.ptr && y.ptr && scale_d, "%s: null pointer", fn);
+  BPX_CHECK(h.C == y.C && h.C % 16 == 0 && h.C <= 2048 && (x.ptr == nullptr || x.C == h.C), "%s: channels must match and be a multiple of 16", fn);
+  if ((int64_t)N * voxels == 0) return 0;
+  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  dim3 grid((unsigned)na_blocks(voxels, h.C, kpl) * 4, (unsigned)N);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    channel_affine_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, (const uint16_t*)h.ptr, h.ld, scale_d, offset_d, (uint16_t*)y.ptr,
+                                                         y.ld, h.C, voxels);
+  else if (dtype == BPX_F32)
+    channel_affine_kernel<float><<<grid, 256, 0, s>>>((const float*)x.ptr, x.ld, (const float*)h.ptr, h.ld, scale_d, offset_d, (float*)y.ptr, y.ld, h.C,
+                                                      voxels);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx_tensor b, float* part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_dot_stats";
+  BPX_CHECK(a.ptr && b.ptr && part_d, "%s: null pointer", fn);
+  BPX_CHECK(a.C == b.C && a.C % 16 == 0 && a.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
+  if ((int64_t)N * voxels == 0) return 0;
+  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  dim3 grid((unsigned)na_blocks(voxels, a.C, kpl), (unsigned)N);
+  const size_t shm = (size_t)256 * kpl * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16) dot_stats_kernel<uint16_t><<<grid, 256, shm, s>>>((const uint16_t*)a.ptr, a.ld, (const uint16_t*)b.ptr, b.ld, a.C, voxels, part_d);
+  else if (dtype == BPX_F32) dot_stats_kernel<float><<<grid, 256, shm, s>>>((const float*)a.ptr, a.ld, (const float*)b.ptr, b.ld, a.C, voxels, part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

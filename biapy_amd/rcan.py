@@ -1,0 +1,88 @@
+"""Drop-in for ``biapy.models.rcan.rcan`` - the 3-D trunk without the up-scaling layer (cfg 5 family).
+
+Same constructor keywords as the reference (biapy/models/rcan.py:241-300), same ``state_dict`` keys and shapes (``sf``,
+``rgs.g.module.r.module.{0,2}`` convolutions, ``rgs.g.module.r.module.3.module.{1,3}`` channel attention, ``rgs.g.module.n``
+group tail, ``conv1``, ``conv2``), ordinary ``nn.Parameter``s; ``forward`` hands them to :class:`biapy_amd.rcan_engine.RCANEngine`.
+
+Not covered (``NotImplementedError`` at construction): 2D, ``upscaling_layer=True`` (the reference's own 3-D branch raises:
+``nn.PixelShuffle`` on 5-D tensors), more than one input channel, filters other than 16 / 32, more than 4 output channels.
+Training goes through the linear output (``head_activations=["linear"]``, what the SR workflows use); other head activations
+are inference-only (``predict``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .rcan_engine import RCANEngine
+from .resunet import _ResUNetFn
+
+
+class ChannelAttention(nn.Module):
+    def __init__(self, num_features: int, reduction: int):
+        super().__init__()
+        self.module = nn.Sequential(nn.AdaptiveAvgPool3d(1), nn.Conv3d(num_features, num_features // reduction, kernel_size=1), nn.SiLU(inplace=True),
+                                    nn.Conv3d(num_features // reduction, num_features, kernel_size=1), nn.Sigmoid())
+
+
+class RCAB_rcan(nn.Module):
+    def __init__(self, num_features: int, reduction: int):
+        super().__init__()
+        self.module = nn.Sequential(nn.Conv3d(num_features, num_features, kernel_size=3, padding="same"), nn.SiLU(inplace=True),
+                                    nn.Conv3d(num_features, num_features, kernel_size=3, padding="same"), ChannelAttention(num_features, reduction))
+
+
+class RG(nn.Module):
+    def __init__(self, num_features: int, num_rcab: int, reduction: int):
+        super().__init__()
+        self.module = nn.Sequential(*([RCAB_rcan(num_features, reduction) for _ in range(num_rcab)] +
+                                      [nn.Conv3d(num_features, num_features, kernel_size=3, padding="same")]))
+
+
+class rcan(nn.Module):
+    _HEAD = {"linear": 0, "sigmoid": 1, "tanh": 2}
+
+    def __init__(self, ndim, num_channels=3, filters=64, scale=2, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=True,
+                 out_channels: Optional[int] = None, head_activations: Optional[List[str]] = None, compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        if type(scale) is not int and isinstance(scale, Sequence):
+            scale = scale[0]
+        if ndim != 3 or upscaling_layer:
+            raise NotImplementedError("biapy_amd.rcan: the 3-D trunk without the up-scaling layer is what runs on the MI355X path "
+                                      "(the reference's own 3-D up-scaling branch raises)")
+        if out_channels is None:
+            out_channels = num_channels
+        self.ndim, self.upscaling_layer = ndim, upscaling_layer
+        act_name = (head_activations[0] if head_activations else "linear").lower().removeprefix("ce_")
+        if act_name not in self._HEAD:
+            raise NotImplementedError(f"biapy_amd.rcan: output activation {act_name!r}")
+        self.head_code = self._HEAD[act_name]
+        self.cfg = dict(num_channels=num_channels, filters=filters, num_rg=num_rg, num_rcab=num_rcab, reduction=reduction, out_channels=out_channels)
+        self.compute_dtype = compute_dtype
+        self._engine: Optional[RCANEngine] = None
+        RCANEngine(dtype=compute_dtype, **self.cfg)                      # validates the configuration (raises NotImplementedError)
+        self.sf = nn.Conv3d(num_channels, filters, kernel_size=3, padding="same")
+        self.rgs = nn.Sequential(*[RG(filters, num_rcab, reduction) for _ in range(num_rg)])
+        self.conv1 = nn.Conv3d(filters, filters, kernel_size=3, padding="same")
+        self.conv2 = nn.Conv3d(filters, out_channels, kernel_size=3, padding="same")
+
+    def engine(self) -> RCANEngine:
+        if self._engine is None or self._engine.dtype != self.compute_dtype:
+            self._engine = RCANEngine(dtype=self.compute_dtype, **self.cfg)
+        return self._engine
+
+    def forward(self, x) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("biapy_amd.rcan runs on the MI355X only (input is on %s); there is no CPU path" % x.device)
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        x = x.to(torch.float32)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if self.head_code != 0:
+                raise NotImplementedError("biapy_amd.rcan trains through the linear output; use head_activations=['linear']")
+            return _ResUNetFn.apply(x, self.engine(), names, *params)
+        P = {n: p.detach() for n, p in zip(names, params)}
+        y, _ = self.engine().forward(P, x, head_act=self.head_code, save=False)
+        return y

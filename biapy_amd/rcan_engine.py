@@ -1,0 +1,212 @@
+"""Executor of the RCAN trunk (3D, no up-scaling layer) on the MI355X kernels (cfg 5 family).
+
+Host side of ``biapy/models/rcan.py`` (``rcan.forward`` :335-347, ``RG``, ``RCAB_rcan``, ``ChannelAttention``) and of its autograd
+graph, from the same C-ABI kernels as the U-Nets:
+
+  * every 3x3x3 convolution is ``bpx_conv3d_fwd`` / ``_dgrad`` / ``_wgrad``; the SiLU between the two convolutions of an RCAB is the
+    consumer's prologue (an identity normalisation record + activation), so the activated tensor never materialises;
+  * the residual additions of ``RG`` (``x + module(x)``) and of the trunk (``x += residual``) are extra K-steps of the producing
+    convolution: its fused 1x1x1 shortcut operand with an identity matrix;
+  * channel attention: the global average pool comes out of the second convolution's statistics epilogue, the two 1x1 "convs"
+    on the pooled (B, C) vector are a few hundred FLOPs and stay in PyTorch (with its autograd), the recalibration and the RCAB
+    residual are one streaming pass (``bpx_channel_affine``: y = x + s[n,c] * h); the backward needs one reduction
+    (``bpx_dot_stats``: ds[n,c] = sum dy*h) and the same affine pass (dh = s*dy + dmean/voxels);
+  * the last convolution (filters -> out_channels <= 4) runs with its output channels zero-padded to 16 and the head kernel picks
+    the real ones and applies the output activation.
+
+The reference's 3-D up-scaling branch (``nn.PixelShuffle`` on 5-D tensors) raises, so only ``upscaling_layer=False`` exists here.
+This is a correctness-first path (parity with the reference trunk); it is not tuned.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .engine import NetConfig, ResUNetEngine, _recs, _Stats
+
+lib = L.lib
+
+
+class RCANEngine(ResUNetEngine):
+    def __init__(self, num_channels: int, filters: int, num_rg: int, num_rcab: int, reduction: int, out_channels: int,
+                 dtype: torch.dtype = torch.bfloat16):
+        if num_channels != 1:
+            raise NotImplementedError("RCANEngine: one input channel (the first layer kernel is the Cin = 1 one)")
+        if filters not in (16, 32) or not 1 <= out_channels <= 4:
+            raise NotImplementedError("RCANEngine: filters must be 16 or 32 and out_channels <= 4 (head kernel)")
+        super().__init__(NetConfig(in_ch=1, feature_maps=[filters, filters], out_channels=(out_channels,), activation="silu"), dtype)
+        self.Fc, self.num_rg, self.num_rcab, self.red, self.n_out = filters, num_rg, num_rcab, max(1, filters // reduction), out_channels
+        self.silu = L.ACT["silu"]
+
+    # ---- small helpers -----------------------------------------------------------------------------------------------------
+    def _consts(self, B, dev):
+        key = (B, str(dev))
+        if getattr(self, "_ckey", None) != key:
+            Fc = self.Fc
+            rec = torch.zeros((B, Fc, 4), dtype=torch.float32, device=dev)
+            rec[..., 1] = 1.0
+            rec[..., 2] = 1.0                                              # identity record: scale 1, shift 0 -> prologue = activation only
+            eye = torch.eye(Fc, dtype=torch.float32, device=dev).reshape(Fc, Fc, 1, 1, 1).contiguous()
+            self._c = dict(rec=rec, eye_packed=self._pack(eye, L.PK_K1, Fc, Fc, False), zeros=torch.zeros(Fc, dtype=torch.float32, device=dev),
+                           ones_bc=torch.ones((B, Fc), dtype=torch.float32, device=dev), ones=torch.ones(Fc, dtype=torch.float32, device=dev))
+            self._ckey = key
+        return self._c
+
+    def _conv(self, B, S, x, rec, act, w, b, y, part=None, sc=None):
+        D, H, W = S
+        c = self._c
+        wp = self._pack(w, L.PK_K3, self.Fc, w.shape[0], False)
+        if sc is None:
+            L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(x), L.ptr(rec), act, wp.data_ptr(), b.data_ptr(), L.NULL_T, None, None,
+                                       L.tview(y), L.ptr(part), L.stream_ptr()))
+        else:                                                                # + identity shortcut: y = conv(x) + sc
+            L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(x), L.ptr(rec), act, wp.data_ptr(), b.data_ptr(), L.tview(sc),
+                                       c["eye_packed"].data_ptr(), c["zeros"].data_ptr(), L.tview(y), L.ptr(part), L.stream_ptr()))
+
+    def _attention(self, P, p, mean, track: bool):
+        """s = sigmoid(W2 SiLU(W1 mean + b1) + b2) on the pooled (B, C) vector - PyTorch, with its autograd when training."""
+        Fc, r = self.Fc, self.red
+        names = [f"{p}.module.3.module.1.weight", f"{p}.module.3.module.1.bias", f"{p}.module.3.module.3.weight", f"{p}.module.3.module.3.bias"]
+        leaves = [mean.detach()] + [P[n].detach() for n in names]
+        if track:
+            leaves = [t.clone().requires_grad_(True) for t in leaves]
+        with torch.enable_grad() if track else torch.no_grad():
+            m, w1, b1, w2, b2 = leaves
+            s = torch.sigmoid(F.silu(m @ w1.reshape(r, Fc).t() + b1) @ w2.reshape(Fc, r).t() + b2)
+        return s, leaves, names
+
+    # ---- forward -----------------------------------------------------------------------------------------------------------
+    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 1
+        B, _, D, H, W = x.shape
+        S, vox, Fc, T, dev, st = (D, H, W), D * H * W, self.Fc, self.dtype, x.device, L.stream_ptr()
+        self._prepacked = {}
+        c = self._consts(B, dev)
+        img = x.reshape(B, D, H, W).contiguous()
+
+        def buf(C=Fc):
+            return torch.empty((B, D, H, W, C), dtype=T, device=dev)
+
+        f0 = buf()
+        part = _Stats.alloc(B, lib.bpx_conv3d_c1_stats_tiles(D, H, W), Fc, dev)
+        L.check(lib.bpx_conv3d_c1_fwd(self.dt, B, D, H, W, img.data_ptr(), P["sf.weight"].data_ptr(), P["sf.bias"].data_ptr(), L.tview(f0), part.data_ptr(), st))
+        tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, Fc)
+        cur, groups = f0, []
+        for g in range(self.num_rg):
+            xg, z, blocks = cur, cur, []
+            for r in range(self.num_rcab):
+                p = f"rgs.{g}.module.{r}"
+                h1, h2 = buf(), buf()
+                self._conv(B, S, z, None, 0, P[f"{p}.module.0.weight"], P[f"{p}.module.0.bias"], h1)
+                part2 = _Stats.alloc(B, tiles, Fc, dev)
+                self._conv(B, S, h1, c["rec"], self.silu, P[f"{p}.module.2.weight"], P[f"{p}.module.2.bias"], h2, part=part2)
+                recm = _recs(B, Fc, dev)
+                _Stats.finalize(part2, B, tiles, Fc, vox, c["ones"], c["zeros"], recm, Fc, 0, st)
+                s, leaves, names = self._attention(P, p, recm[:, :, 0].contiguous(), save)
+                sd = s.detach().contiguous()
+                zn = buf()
+                L.check(lib.bpx_channel_affine(self.dt, B, vox, L.tview(z), L.tview(h2), sd.data_ptr(), None, L.tview(zn), st))
+                blocks.append(dict(p=p, z=z, h1=h1, h2=h2, s=s, sd=sd, leaves=leaves, names=names))
+                z = zn
+            out = buf()
+            pt = f"rgs.{g}.module.{self.num_rcab}"
+            self._conv(B, S, z, None, 0, P[f"{pt}.weight"], P[f"{pt}.bias"], out, sc=xg)
+            groups.append(dict(pt=pt, z=z, blocks=blocks))
+            cur = out
+        t = buf()
+        self._conv(B, S, cur, None, 0, P["conv1.weight"], P["conv1.bias"], t, sc=f0)
+        # last conv: out_channels (<= 4) zero-padded to 16 output channels; the head kernel picks them and applies the activation
+        w2p = torch.zeros((16, Fc, 3, 3, 3), dtype=torch.float32, device=dev)
+        b2p = torch.zeros(16, dtype=torch.float32, device=dev)
+        w2p[: self.n_out] = P["conv2.weight"]
+        b2p[: self.n_out] = P["conv2.bias"]
+        o16 = buf(16)
+        self._conv(B, S, t, None, 0, w2p, b2p, o16)
+        hw = torch.eye(self.n_out, 16, dtype=torch.float32, device=dev).contiguous()
+        hb = torch.zeros(self.n_out, dtype=torch.float32, device=dev)
+        y = torch.empty((B, self.n_out, D, H, W), dtype=torch.float32, device=dev)
+        L.check(lib.bpx_head_fwd(self.dt, vox, B, L.tview(o16), hw.data_ptr(), hb.data_ptr(), self.n_out, head_act, y.data_ptr(), self.n_out * vox, vox, st))
+        ctx = dict(B=B, S=S, img=img, f0=f0, groups=groups, last=cur, t=t, o16=o16, w2p=w2p, hw=hw, head_act=head_act) if save else None
+        return y, ctx
+
+    # ---- backward ------------------------------------------------------------------------------------------------------------
+    def backward(self, P: Dict[str, torch.Tensor], ctx, dy_out: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """dy_out: gradient of the (linear) output; the head activation must be linear when training through this engine."""
+        assert ctx["head_act"] == 0, "train on the linear output (the reference applies its output activation inside the model; pass head_activations=['linear'])"
+        B, S = ctx["B"], ctx["S"]
+        D, H, W = S
+        vox, Fc, T, dev, st, c = D * H * W, self.Fc, self.dtype, dy_out.device, L.stream_ptr(), self._c
+        self._keep = []
+        G = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in P.items()}
+        self._deferred = True
+        L.check(lib.bpx_wgrad_defer_begin())
+        try:
+            def buf(C=Fc):
+                t_ = torch.empty((B, D, H, W, C), dtype=T, device=dev)
+                self._keep.append(t_)
+                return t_
+
+            def wgrad(x, rec, act, dy, dw, db):
+                self._wgrad(B, S, L.tview(x), rec, act, L.tview(dy), 3, dw, db, st, dev)
+
+            def dgrad(dy, w, t_pre=None, rec=None, act=0):
+                g = buf(w.shape[1])
+                wt = self._pack(w, L.PK_K3_T, w.shape[1], w.shape[0], False)
+                L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, L.tview(dy), wt.data_ptr(), L.tview(t_pre) if t_pre is not None else L.NULL_T,
+                                             L.ptr(rec), act, L.tview(g), None, st))
+                return g
+
+            def add(a, b):                                                     # a + b, elementwise
+                o = buf()
+                L.check(lib.bpx_channel_affine(self.dt, B, vox, L.tview(a), L.tview(b), c["ones_bc"].data_ptr(), None, L.tview(o), st))
+                return o
+
+            # head (linear): gradient of the padded 16-channel tensor
+            do16 = buf(16)
+            hwg = torch.zeros((self.n_out, 16), dtype=torch.float32, device=dev)
+            hbg = torch.zeros((self.n_out,), dtype=torch.float32, device=dev)
+            dl = dy_out.contiguous().float()
+            L.check(lib.bpx_head_bwd(self.dt, vox, B, L.tview(ctx["o16"]), ctx["hw"].data_ptr(), self.n_out, dl.data_ptr(), self.n_out * vox, vox,
+                                     L.tview(do16), hwg.data_ptr(), hbg.data_ptr(), st))
+            dw16 = torch.zeros((16, Fc, 3, 3, 3), dtype=torch.float32, device=dev)
+            db16 = torch.zeros(16, dtype=torch.float32, device=dev)
+            wgrad(ctx["t"], None, 0, do16, dw16, db16)
+            dt = dgrad(do16, ctx["w2p"])
+            # conv1 (+ identity from f0)
+            wgrad(ctx["last"], None, 0, dt, G["conv1.weight"], G["conv1.bias"])
+            dcur = dgrad(dt, P["conv1.weight"])
+            for g in range(self.num_rg - 1, -1, -1):
+                grp = ctx["groups"][g]
+                pt = grp["pt"]
+                wgrad(grp["z"], None, 0, dcur, G[f"{pt}.weight"], G[f"{pt}.bias"])
+                dz = dgrad(dcur, P[f"{pt}.weight"])
+                for blk in reversed(grp["blocks"]):
+                    p = blk["p"]
+                    nt = lib.bpx_norm_act_tiles(self.dt, vox, Fc)
+                    dpart = torch.empty((B, nt, Fc), dtype=torch.float32, device=dev)
+                    L.check(lib.bpx_dot_stats(self.dt, B, vox, L.tview(dz), L.tview(blk["h2"]), dpart.data_ptr(), st))
+                    ds = dpart.sum(1)
+                    grads = torch.autograd.grad([blk["s"]], blk["leaves"], grad_outputs=[ds])
+                    for n, gv in zip(blk["names"], grads[1:]):
+                        G[n] += gv.reshape(G[n].shape)
+                    off = (grads[0] / float(vox)).contiguous()                  # d mean -> every voxel of the channel
+                    dh2 = buf()
+                    L.check(lib.bpx_channel_affine(self.dt, B, vox, L.NULL_T, L.tview(dz), blk["sd"].data_ptr(), off.data_ptr(), L.tview(dh2), st))
+                    self._keep += [off, ds]
+                    wgrad(blk["h1"], c["rec"], self.silu, dh2, G[f"{p}.module.2.weight"], G[f"{p}.module.2.bias"])
+                    dh1 = dgrad(dh2, P[f"{p}.module.2.weight"], blk["h1"], c["rec"], self.silu)
+                    wgrad(blk["z"], None, 0, dh1, G[f"{p}.module.0.weight"], G[f"{p}.module.0.bias"])
+                    dz = add(dz, dgrad(dh1, P[f"{p}.module.0.weight"]))
+                dcur = add(dz, dcur)                                           # through the RCABs + the group's identity path
+            df0 = add(dcur, dt)                                                # + the trunk's `x += residual`
+            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, ctx["img"].data_ptr(), L.tview(df0), G["sf.weight"].data_ptr(), G["sf.bias"].data_ptr(), st))
+        finally:
+            self._deferred = False
+            L.check(lib.bpx_wgrad_defer_flush(st))
+        G["conv2.weight"].copy_(dw16[: self.n_out])
+        G["conv2.bias"].copy_(db16[: self.n_out])
+        self._keep = []
+        return G

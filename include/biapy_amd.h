@@ -235,6 +235,14 @@ int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_n
 int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act,
                      bpx_tensor addend, bpx_tensor g, float* red_part_d, bpx_stream_t stream);
 
+/* Channel attention of the RCAN trunk (biapy/models/rcan.py: ChannelAttention.forward `x * module(x)`, RCAB_rcan.forward
+ * `x + module(x)`): y = [x +] scale[n,c] * h [+ offset[n,c]] with per-(sample, channel) fp32 factors (x.ptr / offset_d may be
+ * null; y may alias h), and the reduction its backward needs: part_d[n][bpx_norm_act_tiles()][C] partial sums of a*b over
+ * voxels (d scale[n,c] = sum_v dy*h). */
+int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x, bpx_tensor h, const float* scale_d, const float* offset_d,
+                       bpx_tensor y, bpx_stream_t stream);
+int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx_tensor b, float* part_d, bpx_stream_t stream);
+
 /* MaxPool3d (sz,2,2), sz = z_down of the level = 1 or 2 (resunet.py:256-257) + statistics of the pooled tensor.
  * (D,H,W) = input extents. */
 int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor y, float* stats_part_d,

@@ -92,3 +92,10 @@ def chunked_golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "chunked_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def rcan_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "rcan_golden.npz"))

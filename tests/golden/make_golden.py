@@ -515,8 +515,46 @@ def chunked_fixtures():
     print("chunked_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "chunked_golden.npz")) // 1024, "KiB")
 
 
+def rcan_fixtures():
+    """RCAN trunk (row S; the 3-D up-scaling branch of the reference raises): reference ``rcan(ndim=3, upscaling_layer=False)``
+    with 16 filters, 2 groups x 2 RCABs on a 16x24x32 patch, B = 2: output, L1 loss and all gradients."""
+    rmod = shim.load("biapy.models.rcan")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import rcan_oracle
+
+    torch.manual_seed(41)
+    net = rmod.rcan(ndim=3, num_channels=1, filters=16, scale=2, num_rg=2, num_rcab=2, reduction=16, upscaling_layer=False, out_channels=1,
+                    head_activations=["linear"])
+    g = torch.Generator().manual_seed(141)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if v.ndim == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    xl = torch.randn(2, 16, 24, 32, 1, generator=g)
+    x = xl.permute(0, 4, 1, 2, 3)
+    tgt = torch.randn(2, 1, 16, 24, 32, generator=g)
+    net.train()
+    y = net(x)
+    loss = torch.nn.L1Loss()(y, tgt)          # SR workflows train with MAE (LOSS.TYPE = "MAE")
+    loss.backward()
+    out = {"x": xl.numpy(), "target": tgt.numpy(), "y": y.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64),
+           "num_rg": np.array(2), "num_rcab": np.array(2)}
+    for k, v in net.state_dict().items():
+        out[f"sd/{k}"] = v.numpy()
+    for k, p_ in net.named_parameters():
+        out[f"gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+        if p_.numel() <= 7000:
+            out[f"grad/{k}"] = p_.grad.numpy()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    err = (rcan_oracle.rcan_forward(sd, x, 2, 2) - y.detach()).abs().max().item()
+    print("rcan: params", sum(p_.numel() for p_ in net.parameters()), "oracle vs reference", err)
+    assert err < 2e-5
+    np.savez_compressed(os.path.join(HERE, "rcan_golden.npz"), **out)
+    print("rcan_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "rcan_golden.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -535,3 +573,5 @@ if __name__ == "__main__":
         resunet_variants_fixtures()
     if "chunked" in which:
         chunked_fixtures()
+    if "rcan" in which:
+        rcan_fixtures()

@@ -585,3 +585,40 @@ def test_two_process_data_parallel_training_on_one_gpu():
         a, b = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
         assert torch.equal(a, b), k                                            # the ranks stay bit-identical
         assert (a - w).abs().max().item() <= 2e-5 * max(1.0, w.abs().max().item()), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rcan_trunk_matches_reference_fixture(rcan_golden, dtype):
+    """biapy_amd.rcan.rcan (3-D trunk, row S) vs the reference's own output, L1 loss and every gradient."""
+    import torch.nn.functional as F
+
+    from biapy_amd.rcan import rcan
+
+    g = rcan_golden
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    m = rcan(ndim=3, num_channels=1, filters=16, scale=2, num_rg=int(g["num_rg"]), num_rcab=int(g["num_rcab"]), reduction=16, upscaling_layer=False,
+             out_channels=1, head_activations=["linear"], compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3).contiguous().cuda()
+    y = m(x)
+    loss = F.l1_loss(y, torch.from_numpy(g["target"]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    bf = dtype == torch.bfloat16
+    yr = torch.from_numpy(g["y"])
+    assert (y.detach().cpu() - yr).abs().max().item() / yr.abs().max().item() < (6e-2 if bf else 2e-4)
+    assert abs(loss.item() - float(g["loss"])) < (2e-2 if bf else 1e-5)
+    gmax = max(float(g[k]) for k in g.files if k.startswith("gradnorm/"))
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = float(g[f"gradnorm/{k}"])
+        if ref > 1e-4 * gmax:
+            worst = max(worst, abs(p.grad.norm().item() - ref) / ref)
+        if f"grad/{k}" in g.files and ref > 1e-4 * gmax:
+            gr = torch.from_numpy(g[f"grad/{k}"])
+            e = (p.grad.cpu() - gr).norm().item() / gr.norm().item()
+            assert e < (0.25 if bf else 3e-3), (k, e)
+    assert worst < (0.2 if bf else 3e-3), worst
+    with torch.no_grad():
+        assert (m.eval()(x).cpu() - yr).abs().max().item() / yr.abs().max().item() < (6e-2 if bf else 2e-4)

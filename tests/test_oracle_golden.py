@@ -368,3 +368,34 @@ def test_chunked_oracle_identity_round_trip(chunked_golden):
         dim, crop, pad, vol = _chunked_case(chunked_golden, tag)
         out = CO.predict_by_chunks(vol, lambda p: p.astype(np.float32), crop, pad)
         np.testing.assert_array_equal(out, vol.astype(np.float32))
+
+
+def test_rcan_oracle_and_module_match_reference(rcan_golden):
+    """RCAN trunk (row S): oracle output / L1 loss / gradients vs the reference's ``rcan(ndim=3, upscaling_layer=False)``; the
+    drop-in module owns the reference's parameter names and refuses what the path does not cover."""
+    import torch
+
+    from biapy_amd.rcan import rcan
+    from oracle import rcan_oracle
+
+    g = rcan_golden
+    sd = {k[3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3)
+    y = rcan_oracle.rcan_forward(sd, x, int(g["num_rg"]), int(g["num_rcab"]))
+    loss = torch.nn.L1Loss()(y, torch.from_numpy(g["target"]))
+    loss.backward()
+    assert (y.detach() - torch.from_numpy(g["y"])).abs().max().item() < 2e-5 and abs(loss.item() - float(g["loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(g[k])
+            assert (sd[k[5:]].grad - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
+    m = rcan(ndim=3, num_channels=1, filters=16, scale=2, num_rg=2, num_rcab=2, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"])
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 1, 8, 8, 8))
+    for bad in (dict(ndim=2), dict(upscaling_layer=True), dict(filters=64), dict(num_channels=3)):
+        kw = dict(ndim=3, num_channels=1, filters=16, num_rg=1, num_rcab=1, upscaling_layer=False)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            rcan(**kw)
