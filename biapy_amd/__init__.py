@@ -3,6 +3,7 @@
 Public surface mirrors the reference names for this path:
   biapy_amd.resunet.ResUNet                       <- biapy.models.resunet.ResUNet
   biapy_amd.unet.U_Net                            <- biapy.models.unet.U_Net (2D and 3D)
+  biapy_amd.rcan.rcan                             <- biapy.models.rcan.rcan (3D trunk, upscaling_layer=False)
   biapy_amd.tiling.crop_3D_data_with_overlap      <- biapy.data.data_3D_manipulation.crop_3D_data_with_overlap
   biapy_amd.tiling.merge_3D_data_with_overlap     <- biapy.data.data_3D_manipulation.merge_3D_data_with_overlap
   biapy_amd.workflow.SlidingWindowPredictor       <- Base_Workflow.process_test_sample (per-patch branch)

@@ -154,6 +154,44 @@ def bench_convt(reps=20):
         print(f"convT fwd 32->32 64^3->128^3 into {name}: {ms * 1e3:8.1f} us  {(x.numel() + B * (2 * S) ** 3 * Cc) * 2 / ms / 1e6:8.1f} GB/s")
 
 
+def bench_rcan():
+    """RCAN trunk of cfg 5 (16 filters, 10 groups x 20 RCABs, no up-scaling) on one 64^3 patch: forward and train step (untuned path)."""
+    import time
+
+    from biapy_amd.rcan import rcan
+
+    torch.manual_seed(0)
+    m = rcan(ndim=3, num_channels=1, filters=16, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"]).cuda()
+    x = torch.randn(1, 1, 64, 64, 64, device=DEV)
+    t = torch.randn(1, 1, 64, 64, 64, device=DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    with torch.no_grad():
+        m.eval()(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m(x)
+        torch.cuda.synchronize()
+        fwd = (time.perf_counter() - t0) / 3
+    m.train()
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(m(x), t)
+        loss.backward()
+        opt.step()
+        return loss
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        loss = step()
+    torch.cuda.synchronize()
+    tr = (time.perf_counter() - t0) / 3
+    fl = 2 * 64 ** 3 * 27 * 16 * 16 * (10 * 20 * 2 + 10 + 1) + 2 * 64 ** 3 * 27 * 16 * 2
+    print(f"rcan trunk 64^3 (10x20 RCABs, 16 filters): forward {fwd * 1e3:.1f} ms ({fl / fwd / 1e12:.1f} TFLOP/s), train step {tr * 1e3:.1f} ms "
+          f"({64 ** 3 / tr / 1e6:.2f} Mvox/s), loss {loss.item():.4f}")
+
+
 def bench_chunked():
     """By-chunks inference of a 512^3 float32 volume: 128^3 patches, padding 16 -> 96^3 chunks (216 of them), cfg-2 ResUNet bf16."""
     import time
@@ -212,6 +250,9 @@ def bench_prepost(reps=5):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rcan":
+        bench_rcan()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "convt":
         bench_convt()
         sys.exit(0)
