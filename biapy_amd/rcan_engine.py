@@ -8,7 +8,7 @@ graph, from the same C-ABI kernels as the U-Nets:
   * the residual additions of ``RG`` (``x + module(x)``) and of the trunk (``x += residual``) are extra K-steps of the producing
     convolution: its fused 1x1x1 shortcut operand with an identity matrix;
   * channel attention: the global average pool comes out of the second convolution's statistics epilogue, the two 1x1 "convs"
-    on the pooled (B, C) vector are a few hundred FLOPs and stay in PyTorch (with its autograd), the recalibration and the RCAB
+    on the pooled (B, C) vector are a few hundred FLOPs and stay PyTorch device ops (backward written out by hand), the recalibration and the RCAB
     residual are one streaming pass (``bpx_channel_affine``: y = x + s[n,c] * h); the backward needs one reduction
     (``bpx_dot_stats``: ds[n,c] = sum dy*h) and the same affine pass (dh = s*dy + dmean/voxels);
   * the last convolution (filters -> out_channels <= 4) runs with its output channels zero-padded to 16 and the head kernel picks
@@ -66,17 +66,26 @@ class RCANEngine(ResUNetEngine):
             L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(x), L.ptr(rec), act, wp.data_ptr(), b.data_ptr(), L.tview(sc),
                                        c["eye_packed"].data_ptr(), c["zeros"].data_ptr(), L.tview(y), L.ptr(part), L.stream_ptr()))
 
-    def _attention(self, P, p, mean, track: bool):
-        """s = sigmoid(W2 SiLU(W1 mean + b1) + b2) on the pooled (B, C) vector - PyTorch, with its autograd when training."""
+    def _attention(self, P, p, mean):
+        """s = sigmoid(W2 SiLU(W1 mean + b1) + b2) on the pooled (B, C) vector: a few hundred FLOPs, done with PyTorch device ops.
+        Returns s and what the hand-written backward below needs (no nested autograd: it would re-enter the autograd engine from
+        inside ``Function.backward``, which HIP-graph capture does not survive)."""
         Fc, r = self.Fc, self.red
         names = [f"{p}.module.3.module.1.weight", f"{p}.module.3.module.1.bias", f"{p}.module.3.module.3.weight", f"{p}.module.3.module.3.bias"]
-        leaves = [mean.detach()] + [P[n].detach() for n in names]
-        if track:
-            leaves = [t.clone().requires_grad_(True) for t in leaves]
-        with torch.enable_grad() if track else torch.no_grad():
-            m, w1, b1, w2, b2 = leaves
-            s = torch.sigmoid(F.silu(m @ w1.reshape(r, Fc).t() + b1) @ w2.reshape(Fc, r).t() + b2)
-        return s, leaves, names
+        w1, b1, w2, b2 = P[names[0]].reshape(r, Fc), P[names[1]], P[names[2]].reshape(Fc, r), P[names[3]]
+        u1 = mean @ w1.t() + b1
+        a1 = F.silu(u1)
+        s = torch.sigmoid(a1 @ w2.t() + b2).contiguous()
+        return s, dict(m=mean, u1=u1, a1=a1, w1=w1, w2=w2), names
+
+    @staticmethod
+    def _attention_bwd(s, sv, ds):
+        """Gradients of the pooled-vector MLP: (d mean, dW1, db1, dW2, db2)."""
+        du2 = ds * s * (1.0 - s)
+        dw2, db2 = du2.t() @ sv["a1"], du2.sum(0)
+        sg = torch.sigmoid(sv["u1"])
+        du1 = (du2 @ sv["w2"]) * (sg * (1.0 + sv["u1"] * (1.0 - sg)))
+        return du1 @ sv["w1"], du1.t() @ sv["m"], du1.sum(0), dw2, db2
 
     # ---- forward -----------------------------------------------------------------------------------------------------------
     def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
@@ -105,11 +114,10 @@ class RCANEngine(ResUNetEngine):
                 self._conv(B, S, h1, c["rec"], self.silu, P[f"{p}.module.2.weight"], P[f"{p}.module.2.bias"], h2, part=part2)
                 recm = _recs(B, Fc, dev)
                 _Stats.finalize(part2, B, tiles, Fc, vox, c["ones"], c["zeros"], recm, Fc, 0, st)
-                s, leaves, names = self._attention(P, p, recm[:, :, 0].contiguous(), save)
-                sd = s.detach().contiguous()
+                sd, sv, names = self._attention(P, p, recm[:, :, 0].contiguous())
                 zn = buf()
                 L.check(lib.bpx_channel_affine(self.dt, B, vox, L.tview(z), L.tview(h2), sd.data_ptr(), None, L.tview(zn), st))
-                blocks.append(dict(p=p, z=z, h1=h1, h2=h2, s=s, sd=sd, leaves=leaves, names=names))
+                blocks.append(dict(p=p, z=z, h1=h1, h2=h2, sd=sd, sv=sv, names=names))
                 z = zn
             out = buf()
             pt = f"rgs.{g}.module.{self.num_rcab}"
@@ -189,7 +197,7 @@ class RCANEngine(ResUNetEngine):
                     dpart = torch.empty((B, nt, Fc), dtype=torch.float32, device=dev)
                     L.check(lib.bpx_dot_stats(self.dt, B, vox, L.tview(dz), L.tview(blk["h2"]), dpart.data_ptr(), st))
                     ds = dpart.sum(1)
-                    grads = torch.autograd.grad([blk["s"]], blk["leaves"], grad_outputs=[ds])
+                    grads = self._attention_bwd(blk["sd"], blk["sv"], ds)
                     for n, gv in zip(blk["names"], grads[1:]):
                         G[n] += gv.reshape(G[n].shape)
                     off = (grads[0] / float(vox)).contiguous()                  # d mean -> every voxel of the channel

@@ -189,7 +189,20 @@ def bench_rcan():
     tr = (time.perf_counter() - t0) / 3
     fl = 2 * 64 ** 3 * 27 * 16 * 16 * (10 * 20 * 2 + 10 + 1) + 2 * 64 ** 3 * 27 * 16 * 2
     print(f"rcan trunk 64^3 (10x20 RCABs, 16 filters): forward {fwd * 1e3:.1f} ms ({fl / fwd / 1e12:.1f} TFLOP/s), train step {tr * 1e3:.1f} ms "
-          f"({64 ** 3 / tr / 1e6:.2f} Mvox/s), loss {loss.item():.4f}")
+          f"({64 ** 3 / tr / 1e6:.2f} Mvox/s), loss {loss.item():.4f}", flush=True)
+    # the same through HIP-graph replay (the eager numbers are launch-bound: ~1300 / ~5000 launches from Python)
+    from biapy_amd.graphs import GraphedInference, GraphedTrainStep
+
+    gi = GraphedInference(m.eval(), x)
+    gi()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gi()
+    torch.cuda.synchronize()
+    gf = (time.perf_counter() - t0) / 5
+    print(f"  graph replay: forward {gf * 1e3:.1f} ms ({fl / gf / 1e12:.1f} TFLOP/s)", flush=True)
+    # (a GraphedTrainStep of this ~5000-launch step dumped core in hipGraph instantiate / launch on ROCm 7.2: training stays eager)
 
 
 def bench_chunked():
