@@ -150,3 +150,25 @@ def test_train_one_epoch_error_behaviour():
     assert e.value.code == 1
     with pytest.raises(ValueError, match="graph='on'"):
         TE.train_one_epoch(net, loss_fn, _toy_loader(1), opt, "cpu", 0, graph="on")
+
+
+def test_chunk_grid_rank_partition_covers_every_chunk_once():
+    """ChunkedPredictor's ownership rule (a sampler pad-repeat is left to the rank holding the chunk's first occurrence): over all
+    ranks every chunk is written exactly once and the written regions tile the volume, for ragged grids and world sizes that do
+    not divide the chunk count."""
+    from biapy_amd.chunked import ChunkGrid
+
+    for dim, crop, pad in (((33, 47, 129), (16, 32, 64), (3, 5, 10)), ((18, 33, 65), (16, 32, 64), (6, 12, 24)), ((40, 64, 64), (32, 32, 32), (0, 0, 0))):
+        grid = ChunkGrid(dim, crop, pad)
+        for world in (1, 2, 3, 7, 8, 16):
+            owned = []
+            for rank in range(world):
+                owned += [v for k, v in enumerate(grid.rank_order(world, rank)) if rank + k * world < grid.total]
+            assert sorted(owned) == list(range(grid.total)), (dim, world)
+        cover = np.zeros(dim, np.int32)
+        for v in range(grid.total):
+            r = grid.region(v)
+            cover[r[3]:r[3] + r[6], r[4]:r[4] + r[7], r[5]:r[5] + r[8]] += 1
+            t = grid.index_tables(v)
+            assert len(t) == sum(crop) and t.min() >= 0 and (t[:crop[0]] < dim[0]).all() and (t[crop[0]:crop[0] + crop[1]] < dim[1]).all()
+        assert (cover == 1).all()
