@@ -214,3 +214,37 @@ def test_flat_gradient_data_parallel_step_matches_ddp():
     for p in procs:
         p.join(timeout=60)
     assert all(err < 1e-6 and same for _, err, same in res), res
+
+
+def _epoch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from biapy_amd import train_engine as TE
+
+    g = torch.Generator().manual_seed(30 + rank)
+    n = 3 if rank == 0 else 5                                           # unequal shard lengths: the epoch average weights by count
+    data = [(torch.randn(2, 4, 6, 6, 1, generator=g), (torch.rand(2, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(n)]
+    net = _small_net(0)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    with torch.no_grad():
+        local = [loss_fn(net(x.permute(0, 4, 1, 2, 3)), t.permute(0, 4, 1, 2, 3)).item() for x, t in data]
+    ev = TE.evaluate(net, loss_fn, data, torch.device("cpu"), epoch=0)
+    q.put((rank, ev["loss"], sum(local), len(local)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_averages_over_ranks_by_count():
+    """train_engine.evaluate: the validation loss is the average over ALL batches of ALL ranks (MetricLogger
+    .synchronize_between_processes, train_engine.py:318), also when the ranks hold different numbers of batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    want = (res[0][2] + res[1][2]) / (res[0][3] + res[1][3])
+    assert abs(res[0][1] - want) < 1e-6 and abs(res[1][1] - want) < 1e-6, (res, want)
