@@ -124,6 +124,11 @@ def train_one_epoch(
             if gstep is None:
                 from . import graphs
 
+                key = (id(optimizer), id(loss_function), tuple(x.shape), tuple(t.shape), _world())
+                cached = getattr(inner, "_bpx_graph_step", None)
+                if cached is not None and cached[0] == key:              # later epochs replay the graphs captured in the first one
+                    gstep, gshape = cached[1], (tuple(x.shape), tuple(t.shape))
+            if gstep is None:
                 multi = _world() > 1
                 if multi and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
                     graphs.broadcast_parameters_from_rank0(inner.parameters())    # a DDP wrap has done this already
@@ -134,10 +139,11 @@ def train_one_epoch(
                     gstep = graphs.GraphedTrainStep(inner, loss_function, optimizer, x, t)
                 gshape = (tuple(x.shape), tuple(t.shape))
                 _restore(inner, optimizer, snap)
+                inner._bpx_graph_step = (key, gstep)
             if (tuple(x.shape), tuple(t.shape)) == gshape:
                 loss = gstep(x, t)
             else:                                                      # ragged last batch: same three phases, eagerly
-                loss = _eager_step(inner if _world() > 1 else model, loss_function, optimizer, x, t, 0.0, None, flat=getattr(gstep, "flat_grad", None))
+                loss = _eager_step(inner, loss_function, optimizer, x, t)
         else:
             t = prep(targets, batch)
             outputs = call(batch, is_train=True)
@@ -196,19 +202,22 @@ def _restore(model, optimizer, snap) -> None:
     torch.cuda.synchronize()
 
 
-def _eager_step(model, loss_function, optimizer, x, t, clip, sched, flat=None):
-    if flat is not None:
-        flat.zero_()
-    else:
-        optimizer.zero_grad(set_to_none=True)                          # p.grad may still alias a graph's private gradient buffers
+def _eager_step(model, loss_function, optimizer, x, t):
+    """One eager step for a batch the captured graphs do not fit (ragged last batch); gradients averaged over the ranks."""
+    optimizer.zero_grad(set_to_none=True)                              # p.grad may still alias a graph's private gradient buffers
     loss = loss_function(model(x), t)
     loss.backward()
-    if flat is not None and _world() > 1:
-        dist.all_reduce(flat)
-        flat.mul_(1.0 / _world())
+    if _world() > 1:
+        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        pack = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(pack)
+        pack.mul_(1.0 / _world())
+        off = 0
+        for g in grads:
+            g.copy_(pack[off:off + g.numel()].view_as(g))
+            off += g.numel()
     optimizer.step()
-    if flat is None:
-        optimizer.zero_grad()
+    optimizer.zero_grad()
     return loss
 
 

@@ -401,8 +401,11 @@ def test_train_one_epoch_graph_replay_equals_eager():
         m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
                     z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda()
         opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
-        s, last = TE.train_one_epoch(m, BCEWithLogitsLoss(), data, opt, torch.device("cuda"), epoch=0, patch_size=(16, 16, 16, 1), graph=mode, sync_every=4)
-        assert last == 5
+        loss_fn = BCEWithLogitsLoss()
+        for epoch in range(2):                                          # the second epoch replays the graphs captured in the first
+            s, last = TE.train_one_epoch(m, loss_fn, data, opt, torch.device("cuda"), epoch=epoch, patch_size=(16, 16, 16, 1), graph=mode, sync_every=4)
+            assert last == 5
+        assert (mode == "on") == hasattr(m, "_bpx_graph_step")
         nets.append(m)
         stats.append(s)
     assert abs(stats[0]["loss"] - stats[1]["loss"]) < 1e-5, stats
