@@ -202,7 +202,22 @@ def bench_rcan():
     torch.cuda.synchronize()
     gf = (time.perf_counter() - t0) / 5
     print(f"  graph replay: forward {gf * 1e3:.1f} ms ({fl / gf / 1e12:.1f} TFLOP/s)", flush=True)
-    # (a GraphedTrainStep of this ~5000-launch step dumped core in hipGraph instantiate / launch on ROCm 7.2: training stays eager)
+    # train step replayed from a graph: a FRESH model and a capturable optimizer (capturing it on the model above, after the
+    # eager AdamW and the inference graph, dumped core once; in isolation it is fine)
+    del gi, opt, m
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    m2 = rcan(ndim=3, num_channels=1, filters=16, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"]).cuda().train()
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-4, capturable=True)
+    gs = GraphedTrainStep(m2, torch.nn.functional.l1_loss, opt2, x, t, warmup=1)
+    gs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gs()
+    torch.cuda.synchronize()
+    gt = (time.perf_counter() - t0) / 5
+    print(f"  graph replay: train step {gt * 1e3:.1f} ms ({64 ** 3 / gt / 1e6:.2f} Mvox/s)", flush=True)
 
 
 def bench_chunked():
