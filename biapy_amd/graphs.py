@@ -9,7 +9,8 @@ an addition of the MI355X path, used by ``bench.py`` and offered to callers who 
 BiaPy does (``DATA.PATCH_SIZE`` is fixed per run, ``TRAIN.BATCH_SIZE`` with ``drop_last``).
 
 Constraints (those of ``torch.cuda.graphs``): static shapes; the optimizer must be built with ``capturable=True``; no host
-synchronisation inside the step.  ``GraphedTrainStep`` is single-process; ``DataParallelTrainStep`` is the multi-GPU form
+synchronisation inside the step; no autograd graph of an earlier eager backward may still be referenced when a graphed step is
+built (``del loss`` first - the constructors raise a ``RuntimeError`` otherwise, see ``_warm``).  ``GraphedTrainStep`` is single-process; ``DataParallelTrainStep`` is the multi-GPU form
 (one process per GPU): the same two replays with ONE flat-gradient RCCL all-reduce between them.
 """
 from __future__ import annotations
@@ -20,12 +21,34 @@ import torch
 import torch.distributed as dist
 
 
+_STALE_GRAPH = (
+    "an autograd graph from an earlier backward is still alive (typically the last `loss` tensor of an eager loop): its "
+    "AccumulateGrad nodes are bound to the stream they ran on, and capturing a backward that has to synchronise with that stream "
+    "kills the process on ROCm.  Delete those references (`del loss`) before building a graphed step."
+)
+
+
 def _warm(fn, iters: int = 3, side=None) -> None:
+    """Eager warm-up on the stream the capture will use.  PyTorch warns when a parameter's AccumulateGrad node belongs to
+    another stream; followed by a capture that situation dumped core (measured), so it is turned into an error here."""
+    import warnings
+
     side = side if side is not None else torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(iters):
-            fn()
+    always = torch.is_warn_always_enabled()
+    torch.set_warn_always(True)                       # the warning is a warn-once one: without this only the first hazard of a process is seen
+    try:
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
+            try:
+                with torch.cuda.stream(side):
+                    for _ in range(iters):
+                        fn()
+            except UserWarning:
+                torch.cuda.synchronize()
+                raise RuntimeError(_STALE_GRAPH) from None
+    finally:
+        torch.set_warn_always(always)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
 

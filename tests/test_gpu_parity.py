@@ -625,3 +625,23 @@ def test_rcan_trunk_matches_reference_fixture(rcan_golden, dtype):
     assert worst < (0.2 if bf else 3e-3), worst
     with torch.no_grad():
         assert (m.eval()(x).cpu() - yr).abs().max().item() / yr.abs().max().item() < (6e-2 if bf else 2e-4)
+
+
+def test_graphed_step_refuses_a_stale_autograd_graph():
+    """Building a graphed step while a loss of an earlier eager backward is still referenced used to kill the process during
+    capture (its AccumulateGrad nodes belong to another stream); graphs._warm turns PyTorch's warning into a RuntimeError."""
+    from biapy_amd.graphs import GraphedTrainStep
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from biapy_amd.resunet import ResUNet
+
+    torch.manual_seed(0)
+    m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
+                z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2]).cuda().train()
+    x = torch.randn(2, 1, 16, 16, 16, device="cuda")
+    t = (torch.rand(2, 1, 16, 16, 16, device="cuda") > 0.5).float()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+    loss = BCEWithLogitsLoss()(m(x), t)
+    loss.backward()
+    opt.step()
+    with pytest.raises(RuntimeError, match="earlier backward is still alive"):
+        GraphedTrainStep(m, BCEWithLogitsLoss(), opt, x, t, warmup=1)
