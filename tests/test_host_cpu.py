@@ -172,3 +172,27 @@ def test_chunk_grid_rank_partition_covers_every_chunk_once():
             t = grid.index_tables(v)
             assert len(t) == sum(crop) and t.min() >= 0 and (t[:crop[0]] < dim[0]).all() and (t[crop[0]:crop[0] + crop[1]] < dim[1]).all()
         assert (cover == 1).all()
+
+
+def test_lift_params_is_the_same_convolution():
+    """engine.lift_params / unlift_grads (2D and (1,3,3) weights -> zero-padded 3x3x3): the lifted weights compute the same
+    convolution on a one-slice / any volume, and gradients map back to the centre z-tap - checked with PyTorch's CPU convs."""
+    import torch.nn.functional as F
+
+    from biapy_amd.engine import lift_params, needs_lift, unlift_grads
+
+    g = torch.Generator().manual_seed(0)
+    P = {"c2d": torch.randn(5, 3, 3, 3, generator=g), "aniso": torch.randn(4, 3, 1, 3, 3, generator=g), "iso": torch.randn(4, 3, 3, 3, 3, generator=g),
+         "ct2d": torch.randn(3, 5, 2, 2, generator=g), "k1": torch.randn(6, 3, 1, 1, generator=g), "bias": torch.randn(5, generator=g)}
+    assert [needs_lift(v) for v in P.values()] == [True, True, False, True, True, False]
+    Q = lift_params(P)
+    assert Q["iso"] is P["iso"] and Q["bias"] is P["bias"] and Q["c2d"].shape == (5, 3, 3, 3, 3) and Q["ct2d"].shape == (3, 5, 1, 2, 2)
+    x2 = torch.randn(2, 3, 9, 11, generator=g)
+    assert torch.allclose(F.conv3d(x2.unsqueeze(2), Q["c2d"], padding=1)[:, :, 0], F.conv2d(x2, P["c2d"], padding=1), atol=1e-6)
+    x3 = torch.randn(2, 3, 5, 9, 11, generator=g)
+    assert torch.allclose(F.conv3d(x3, Q["aniso"], padding=1), F.conv3d(x3, P["aniso"], padding=(0, 1, 1)), atol=1e-6)
+    assert torch.allclose(F.conv_transpose3d(x2.unsqueeze(2), Q["ct2d"], stride=(1, 2, 2))[:, :, 0], F.conv_transpose2d(x2, P["ct2d"], stride=2), atol=1e-6)
+    G = {k: torch.randn(v.shape, generator=g) for k, v in Q.items()}
+    U = unlift_grads(G, P)
+    assert all(U[k].shape == P[k].shape for k in P)
+    assert torch.equal(U["c2d"], G["c2d"][:, :, 1]) and torch.equal(U["aniso"][:, :, 0], G["aniso"][:, :, 1]) and torch.equal(U["k1"], G["k1"][:, :, 0])
