@@ -99,3 +99,10 @@ def rcan_golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "rcan_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def resunetpp_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunetpp_golden.npz"))

@@ -553,8 +553,64 @@ def rcan_fixtures():
     print("rcan_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "rcan_golden.npz")) // 1024, "KiB")
 
 
+def resunetpp_fixtures():
+    """ResUNet++ (row X, cfg 4 family; not yet on the device - the fixture pins the oracle the device path will be checked with):
+    reference ``ResUNetPlusPlus`` with fm 16-32-64 on a 16x32x32 patch, B = 2, three output channels (B, C: ce_sigmoid; D: tanh
+    are head activations outside the model): logits, an MSE loss and all gradient norms + a few full gradients."""
+    rmod = shim.load("biapy.models.resunet++")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import resunetpp_oracle
+
+    fm = [16, 32, 64]          # depth 1: every block type once or twice, 0.7 M parameters (a 4-level net is a 5.7 MB fixture)
+    torch.manual_seed(51)
+    with quiet():
+        net = rmod.ResUNetPlusPlus(
+            image_shape=(16, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in", k_size=3,
+            upsample_layer="convtranspose", yx_down=[2, 2], z_down=[2, 2], output_channels=[3], output_channel_info=["BCD"],
+            head_activations=["ce_sigmoid", "ce_sigmoid", "linear"], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3,
+        )
+    g = torch.Generator().manual_seed(151)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if v.ndim == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    xl = torch.randn(2, 16, 32, 32, 1, generator=g)
+    x = xl.permute(0, 4, 1, 2, 3)
+    tgt = torch.randn(2, 3, 16, 32, 32, generator=g)
+    net.train()
+    logits = net(x)
+    loss = torch.nn.MSELoss()(logits, tgt)
+    loss.backward()
+    out = {"feature_maps": np.array(fm), "x": xl.numpy(), "target": tgt.numpy().astype(np.float16), "logits": logits.detach().numpy(),
+           "loss": np.array(loss.item(), dtype=np.float64)}
+    for k, v in net.state_dict().items():
+        out[f"sd/{k}"] = v.numpy().astype(np.float16) if v.numel() > 20000 else v.numpy()
+    # big weights are stored as fp16: re-run the reference on the rounded weights / target so that outputs belong to the stored data
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            v.copy_(torch.from_numpy(out[f"sd/{k}"].astype(np.float32)))
+    tgt = torch.from_numpy(out["target"].astype(np.float32))
+    net.zero_grad()
+    logits = net(x)
+    loss = torch.nn.MSELoss()(logits, tgt)
+    loss.backward()
+    out["logits"], out["loss"] = logits.detach().numpy(), np.array(loss.item(), dtype=np.float64)
+    names = dict(net.named_parameters())
+    for k, p_ in names.items():
+        out[f"gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+    for k in ["down_path.0.shortcut.0.weight", "sqex_blocks.0.excitation.0.weight", "attentions.0.0.conv_attn.2.weight",
+              "aspp_out.0.aspp_block2.0.weight", "aspp_out.0.output.weight", "up_paths.0.0.conv_block.shortcut.1.weight", "heads.0.weight"]:
+        out[f"grad/{k}"] = names[k].grad.numpy()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    err = (resunetpp_oracle.resunetpp_forward(sd, x, fm) - logits.detach()).abs().max().item()
+    print("resunet++: params", sum(p_.numel() for p_ in net.parameters()), "oracle vs reference", err)
+    assert err < 2e-5
+    np.savez_compressed(os.path.join(HERE, "resunetpp_golden.npz"), **out)
+    print("resunetpp_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunetpp_golden.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -575,3 +631,5 @@ if __name__ == "__main__":
         chunked_fixtures()
     if "rcan" in which:
         rcan_fixtures()
+    if "resunetpp" in which:
+        resunetpp_fixtures()

@@ -399,3 +399,26 @@ def test_rcan_oracle_and_module_match_reference(rcan_golden):
         kw.update(bad)
         with pytest.raises(NotImplementedError):
             rcan(**kw)
+
+
+def test_resunetpp_oracle_matches_reference(resunetpp_golden):
+    """oracle/resunetpp_oracle.py (row X: SE, ASPP with dilated convs, attention, 3x3x3 shortcuts with norm) vs the reference's
+    ResUNetPlusPlus: logits, MSE loss and gradients.  The device path for this model is the open row; the oracle is pinned ahead."""
+    import torch
+
+    from oracle import resunetpp_oracle as RO
+
+    g = resunetpp_golden
+    fm = [int(v) for v in g["feature_maps"]]
+    sd = {k[3:]: torch.from_numpy(g[k].astype(np.float32)).requires_grad_(True) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3)
+    logits = RO.resunetpp_forward(sd, x, fm)
+    loss = torch.nn.MSELoss()(logits, torch.from_numpy(g["target"].astype(np.float32)))
+    loss.backward()
+    assert (logits.detach() - torch.from_numpy(g["logits"])).abs().max().item() < 2e-5 and abs(loss.item() - float(g["loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(g[k])
+            assert (sd[k[5:]].grad - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
+        if k.startswith("gradnorm/") and float(g[k]) > 1e-6:
+            assert abs(sd[k[9:]].grad.norm().item() - float(g[k])) <= 1e-3 * float(g[k]), k
