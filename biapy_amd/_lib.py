@@ -77,6 +77,7 @@ _SIGS = {
     "bpx_tensor_stats_tiles": ([_i64], _i),
     "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_gather3d_tables": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], _i),
+    "bpx_scatter3d_tables": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "bpx_scatter3d_regions": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),
     "bpx_wgrad_defer_begin": ([], _i),
     "bpx_wgrad_defer_flush": ([_vp], _i),

@@ -96,7 +96,27 @@ __global__ void __launch_bounds__(256) gather3d_tables_kernel(const E* __restric
     const int y = (int)(r % Py);
     const int z = (int)(r / Py);
     const int* t = tables + b * (int64_t)(Pz + Py + Px);
-    out[i] = vol[(((size_t)t[z] * Y + t[Pz + y]) * X + t[Pz + Py + x]) * C + c];
+    const int sz = t[z], sy = t[Pz + y], sx = t[Pz + Py + x];     // a negative index = outside the volume: zero (space-to-batch padding)
+    out[i] = (sz | sy | sx) < 0 ? (E)0 : vol[(((size_t)sz * Y + sy) * X + sx) * C + c];
+  }
+}
+
+// inverse of the gather: vol[tz[z], ty[y], tx[x], c] = in[b, z, y, x, c] for non-negative table entries (batch-to-space of the
+// dilated convolutions: every destination voxel belongs to exactly one (b, z, y, x))
+template <typename E>
+__global__ void __launch_bounds__(256) scatter3d_tables_kernel(const E* __restrict__ in, const int* __restrict__ tables, int Pz, int Py, int Px,
+                                                               E* __restrict__ vol, int Y, int X, int C, int64_t total) {
+  const int64_t per = (int64_t)Pz * Py * Px * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per;
+    int64_t r = i - b * per;
+    const int c = (int)(r % C); r /= C;
+    const int x = (int)(r % Px); r /= Px;
+    const int y = (int)(r % Py);
+    const int z = (int)(r / Py);
+    const int* t = tables + b * (int64_t)(Pz + Py + Px);
+    const int sz = t[z], sy = t[Pz + y], sx = t[Pz + Py + x];
+    if ((sz | sy | sx) >= 0) vol[(((size_t)sz * Y + sy) * X + sx) * C + c] = in[i];
   }
 }
 
@@ -131,6 +151,23 @@ extern "C" int bpx_gather3d_tables(const void* vol_d, int elem_size, int Z, int 
   if (elem_size == 4) gather3d_tables_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint32_t*)out_d, total);
   else if (elem_size == 2) gather3d_tables_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint16_t*)out_d, total);
   else gather3d_tables_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint8_t*)out_d, total);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_scatter3d_tables(const void* in_d, int elem_size, const int* tables_d, int n, int Pz, int Py, int Px, void* vol_d, int Z, int Y,
+                                    int X, int C, bpx_stream_t stream) {
+  const char* fn = "bpx_scatter3d_tables";
+  BPX_CHECK(vol_d && in_d && tables_d, "%s: null pointer", fn);
+  BPX_CHECK(elem_size == 1 || elem_size == 2 || elem_size == 4, "%s: elem_size %d unsupported", fn, elem_size);
+  BPX_CHECK(Z > 0 && Y > 0 && X > 0 && C > 0 && n >= 0 && Pz > 0 && Py > 0 && Px > 0, "%s: bad extents", fn);
+  const int64_t total = (int64_t)n * Pz * Py * Px * C;
+  if (total == 0) return 0;
+  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (elem_size == 4) scatter3d_tables_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)in_d, tables_d, Pz, Py, Px, (uint32_t*)vol_d, Y, X, C, total);
+  else if (elem_size == 2) scatter3d_tables_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)in_d, tables_d, Pz, Py, Px, (uint16_t*)vol_d, Y, X, C, total);
+  else scatter3d_tables_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)in_d, tables_d, Pz, Py, Px, (uint8_t*)vol_d, Y, X, C, total);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

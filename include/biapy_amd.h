@@ -85,6 +85,11 @@ int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int Py, int Px, 
  * {first kept voxel of the patch z,y,x ; destination z,y,x ; extent z,y,x}.  Regions of different patches are disjoint. */
 int bpx_gather3d_tables(const void* vol_d, int elem_size, int Z, int Y, int X, int C, const int* tables_d, int n, int Pz, int Py, int Px,
                         void* out_d, bpx_stream_t stream);
+/* Inverse of bpx_gather3d_tables: vol[tz[z], ty[y], tx[x], c] = in[b,z,y,x,c] for the non-negative table entries (negative entries
+ * of either call mean "outside the volume": the gather returns 0 there, the scatter skips them).  Together they are the
+ * space-to-batch / batch-to-space pair that turns a dilated 3x3x3 convolution (ASPP, heads.py:77-104) into ordinary ones. */
+int bpx_scatter3d_tables(const void* in_d, int elem_size, const int* tables_d, int n, int Pz, int Py, int Px, void* vol_d, int Z, int Y,
+                         int X, int C, bpx_stream_t stream);
 int bpx_scatter3d_regions(const float* pred_d, int n, int Pz, int Py, int Px, int C, const int* regions_d, float* out_d, int Z, int Y,
                           int X, bpx_stream_t stream);
 

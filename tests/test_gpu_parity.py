@@ -645,3 +645,32 @@ def test_graphed_step_refuses_a_stale_autograd_graph():
     opt.step()
     with pytest.raises(RuntimeError, match="earlier backward is still alive"):
         GraphedTrainStep(m, BCEWithLogitsLoss(), opt, x, t, warmup=1)
+
+
+@pytest.mark.parametrize("d,dim", [(6, (10, 14, 20)), (2, (8, 16, 16)), (18, (20, 20, 36))])
+def test_dilated_conv_through_space_to_batch(K, d, dim):
+    """A dilated 3x3x3 convolution (ASPP rates, heads.py:77-104) = space-to-batch (bpx_gather3d_tables, zero fill) -> the ordinary
+    conv kernel on N*d^3 samples -> batch-to-space (bpx_scatter3d_tables), against torch's dilated convolution on the CPU."""
+    import torch.nn.functional as F
+
+    from biapy_amd import _lib as L
+    from biapy_amd import dilation as DL
+
+    g = torch.Generator().manual_seed(d)
+    N, Cin, Cout = 2, 32, 16
+    x = torch.randn(N, *dim, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv3d(x.permute(0, 4, 1, 2, 3), w, b, padding=d, dilation=d).permute(0, 2, 3, 4, 1)
+    xd = x.cuda()
+    xs = DL.space_to_batch(xd, d)
+    assert xs.shape == (N * d ** 3,) + DL.lattice_shape(dim, d) + (Cin,)
+    assert torch.equal(DL.batch_to_space(xs, d, dim), xd)                      # the pair is the identity on the volume
+    nb, nz, ny, nx = xs.shape[0], xs.shape[1], xs.shape[2], xs.shape[3]
+    wp = K.pack(w, L.PK_K3, Cin, Cout, L.F32)
+    ys = torch.empty((nb, nz, ny, nx, Cout), dtype=torch.float32, device="cuda")
+    bd = b.cuda()
+    L.check(L.lib.bpx_conv3d_fwd(L.F32, nb, nz, ny, nx, L.tview(xs), None, 0, wp.data_ptr(), bd.data_ptr(), L.NULL_T, None, None, L.tview(ys), None,
+                                 L.stream_ptr()))
+    got = DL.batch_to_space(ys, d, dim).cpu()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

@@ -196,3 +196,38 @@ def test_lift_params_is_the_same_convolution():
     U = unlift_grads(G, P)
     assert all(U[k].shape == P[k].shape for k in P)
     assert torch.equal(U["c2d"], G["c2d"][:, :, 1]) and torch.equal(U["aniso"][:, :, 0], G["aniso"][:, :, 1]) and torch.equal(U["k1"], G["k1"][:, :, 0])
+
+
+@pytest.mark.parametrize("dim,d", [((10, 13, 16), 3), ((8, 8, 8), 6), ((5, 20, 7), 2)])
+def test_dilated_conv_is_conv_on_sublattices(dim, d):
+    """biapy_amd.dilation.lattice_tables: gathering the d^3 sub-lattices into the batch (zeros where a table says -1), an ordinary
+    'same' 3x3x3 convolution and the inverse scatter reproduce torch's dilated convolution (padding = dilation) - the property the
+    device path of ASPP (heads.py:77-104) rests on.  NumPy stands in for the two HIP kernels here."""
+    import torch.nn.functional as F
+
+    from biapy_amd.dilation import lattice_shape, lattice_tables
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, *dim, generator=g)
+    w = torch.randn(4, 3, 3, 3, 3, generator=g)
+    ref = F.conv3d(x, w, padding=d, dilation=d)
+    T = lattice_tables(dim, d)
+    nz, ny, nx = lattice_shape(dim, d)
+    assert T.shape == (d ** 3, nz + ny + nx)
+    xs = torch.zeros(2 * d ** 3, 3, nz, ny, nx)
+    for n in range(2):
+        for q in range(d ** 3):
+            tz, ty, tx = T[q, :nz], T[q, nz:nz + ny], T[q, nz + ny:]
+            sub = x[n][:, np.clip(tz, 0, None)][:, :, np.clip(ty, 0, None)][:, :, :, np.clip(tx, 0, None)].clone()
+            sub[:, tz < 0] = 0
+            sub[:, :, ty < 0] = 0
+            sub[:, :, :, tx < 0] = 0
+            xs[n * d ** 3 + q] = sub
+    ys = F.conv3d(xs, w, padding=1)
+    out = torch.zeros_like(ref)
+    for n in range(2):
+        for q in range(d ** 3):
+            tz, ty, tx = T[q, :nz], T[q, nz:nz + ny], T[q, nz + ny:]
+            kz, ky, kx = np.where(tz >= 0)[0], np.where(ty >= 0)[0], np.where(tx >= 0)[0]
+            out[n][:, tz[kz][:, None, None], ty[ky][None, :, None], tx[kx][None, None, :]] = ys[n * d ** 3 + q][:, kz][:, :, ky][:, :, :, kx]
+    assert torch.allclose(out, ref, atol=1e-5)
