@@ -30,6 +30,19 @@ from . import _lib as L
 lib = L.lib
 EPS = 1e-5
 
+# Packed-operand caches are keyed by (storage address, tensor version) - but a HIP-graph replay of an optimizer step rewrites the
+# parameters WITHOUT bumping ``_version``.  Every replaying object of this package (graphs.GraphedTrainStep /
+# DataParallelTrainStep, train_engine._restore) therefore bumps this process-wide counter, which is part of every cache key.
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch() -> None:
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch() -> int:
+    return _WEIGHTS_EPOCH[0]
+
 
 @dataclass
 class NetConfig:
@@ -157,7 +170,13 @@ class ResUNetEngine:
         self.use_side_stream = False  # measured on cfg 2: 19.5 vs 18.1 ms/step (early kernels, eager); 11.13 vs 11.18 with the final kernels
         # under graph replay, 21 vs 15 ms eager - every kernel already launches one resident wave of workgroups
         self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
-        self._pack_versions: Dict[Tuple[int, int, int], int] = {}
+        self._pack_versions: Dict[Tuple[int, int, int], Tuple[int, int]] = {}
+
+    def clear_caches(self) -> None:
+        """Drop the packed / lifted weight copies kept for inference (ResUNet.train() calls this)."""
+        self._pack_cache.clear()
+        self._pack_versions.clear()
+        self._lift_cache = None
 
     # ---- weight-gradient side stream ------------------------------------------------------------------
     # The wgrad kernels only produce parameter gradients; nothing on the dgrad chain waits for them.  They run on a second
@@ -261,7 +280,8 @@ class ResUNetEngine:
             if hit is not None:
                 return hit
         key = (w.data_ptr(), mode, self.dt)
-        if cache and key in self._pack_cache and self._pack_versions.get(key) == w._version:
+        stamp = (w._version, _WEIGHTS_EPOCH[0])
+        if cache and key in self._pack_cache and self._pack_versions.get(key) == stamp:
             return self._pack_cache[key]
         n = lib.bpx_packed_weight_elems(mode, cin, cout, self.dt)
         out = torch.empty(n, dtype=self.dtype, device=w.device)
@@ -271,7 +291,7 @@ class ResUNetEngine:
         L.check(lib.bpx_pack_weight(mode, wc.data_ptr(), cin, cout, self.dt, out.data_ptr(), L.stream_ptr()))
         if cache:
             self._pack_cache[key] = out
-            self._pack_versions[key] = w._version
+            self._pack_versions[key] = stamp
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -328,10 +348,14 @@ class ResUNetEngine:
         if cfg.ndim == 2:
             x = x.unsqueeze(2)
         P_orig = P
+        if cache_weights and torch.cuda.is_current_stream_capturing():
+            # a captured forward must contain its own pack kernels: operands cached during the warm-up would freeze the
+            # weights of every later replay at their capture-time values (graphs.GraphedInference)
+            cache_weights = False
         if any(needs_lift(w) for w in P.values()):
             # 2D / anisotropic levels: zero-padded 3x3x3 weights.  Inference keeps the lifted copies while the parameters
             # are unchanged, so that the packed-operand cache (keyed by storage) keeps hitting.
-            vers = tuple((w.data_ptr(), w._version) for w in P.values())
+            vers = (_WEIGHTS_EPOCH[0],) + tuple((w.data_ptr(), w._version) for w in P.values())
             hit = getattr(self, "_lift_cache", None)
             if cache_weights and hit is not None and hit[0] == vers:
                 P = hit[1]
@@ -351,8 +375,8 @@ class ResUNetEngine:
         st = L.stream_ptr()
         fm = list(cfg.feature_maps)
         T = self.dtype
-        if save and not cache_weights:
-            self._prepack(P, True, dev)
+        if not cache_weights:
+            self._prepack(P, save, dev)       # ONE batched pack launch (training re-packs every step; so does a captured inference)
         else:
             self._prepacked = {}
         if Cin == 1:

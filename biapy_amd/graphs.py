@@ -28,6 +28,38 @@ _STALE_GRAPH = (
 )
 
 
+class _LrTensors:
+    """A capturable Adam(W) given a Python-float ``lr`` bakes it (and ``1 - lr * weight_decay``) into the captured kernels, so a
+    scheduler stepping between epochs would be ignored by the replays.  The learning rates therefore become 0-d device
+    tensors before capture: PyTorch's schedulers update tensor learning rates in place (``lr_scheduler._update_param_group_val``),
+    and a caller (or one of the reference's warm-up schedules) that ASSIGNS ``group["lr"] = value`` is caught by ``sync()``,
+    which every replay calls: the value is copied into the captured tensor and the tensor is put back.
+    ``weight_decay`` and the betas stay compile-time constants of the captured step."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer, device):
+        self.opt = optimizer
+        self.lrs = []
+        for g in optimizer.param_groups:
+            lr = g["lr"]
+            if not torch.is_tensor(lr):
+                lr = torch.tensor(float(lr), dtype=torch.float32, device=device)
+                g["lr"] = lr
+            self.lrs.append(lr)
+
+    def sync(self) -> None:
+        for g, t in zip(self.opt.param_groups, self.lrs):
+            cur = g["lr"]
+            if cur is not t:
+                t.fill_(float(cur))                    # host scalar -> device tensor, no synchronisation
+                g["lr"] = t
+
+
+def _bump() -> None:
+    from .engine import bump_weights_epoch
+
+    bump_weights_epoch()
+
+
 def _warm(fn, iters: int = 3, side=None) -> None:
     """Eager warm-up on the stream the capture will use.  PyTorch warns when a parameter's AccumulateGrad node belongs to
     another stream; followed by a capture that situation dumped core (measured), so it is turned into an error here."""
@@ -69,10 +101,13 @@ class GraphedTrainStep:
                 raise ValueError("build the optimizer with capturable=True to capture its step")
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.x, self.target = x.clone(), target.clone()
+        self._lr = _LrTensors(optimizer, x.device)
+        self._out = None
 
         def eager():
             optimizer.zero_grad(set_to_none=True)
-            loss = loss_fn(model(self.x), self.target)
+            self._out = model(self.x)
+            loss = loss_fn(self._out, self.target)
             loss.backward()
             optimizer.step()
             return loss
@@ -84,13 +119,21 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = eager()
         torch.cuda.synchronize()
+        _bump()
+
+    @property
+    def outputs(self) -> torch.Tensor:
+        """The model output of the last replay (static memory of the graph: valid until the next call)."""
+        return self._out.detach()
 
     def __call__(self, x: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None) -> torch.Tensor:
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if target is not None:
             self.target.copy_(target, non_blocking=True)
+        self._lr.sync()
         self.graph.replay()
+        _bump()                                        # parameters changed without a version bump: packed-weight caches are stale
         return self.loss
 
 
@@ -117,8 +160,10 @@ class DataParallelTrainStep:
     pass: 26.8 MB is ~0.2 ms on 7 x 153 GB/s links against a 13 ms step, less than what eager hooks cost on the host.
     InstanceNorm has no cross-rank statistics and there are no buffers to synchronise.
 
-    ``graph=False`` runs the same three phases eagerly (any device / backend; this is what the gloo tests drive).
-    The caller must not call ``optimizer.zero_grad()``: the gradients live in ``self.flat_grad``.
+    ``graph=False`` runs the same three phases eagerly (any device / backend; this is what the gloo tests drive); that form
+    needs ``p.grad`` to stay views of ``self.flat_grad`` and re-binds them at every call, so an ``optimizer.zero_grad()`` by the
+    caller is harmless.  The replayed form does not depend on ``p.grad`` at all (the graphs hold raw addresses and
+    ``self.flat_grad`` keeps the slab alive).
     """
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer, x: torch.Tensor,
@@ -145,11 +190,14 @@ class DataParallelTrainStep:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.x, self.target = x.clone(), target.clone()
+        self._lr = _LrTensors(optimizer, dev) if graph else None
+        self._out = None
         inv = 1.0 / self.world
 
         def fwd_bwd():
             self.flat_grad.zero_()
-            loss = loss_fn(model(self.x), self.target)
+            self._out = model(self.x)
+            loss = loss_fn(self._out, self.target)
             loss.backward()                                              # AccumulateGrad adds in place: grads stay in flat_grad
             return loss
 
@@ -169,7 +217,8 @@ class DataParallelTrainStep:
             # and no per-parameter accumulate kernels (98 small launches, ~0.3 ms per step for cfg 2).
             def fwd_bwd_adopt():
                 optimizer.zero_grad(set_to_none=True)
-                loss = loss_fn(model(self.x), self.target)
+                self._out = model(self.x)
+                loss = loss_fn(self._out, self.target)
                 loss.backward()
                 return loss
 
@@ -208,6 +257,7 @@ class DataParallelTrainStep:
             torch.cuda.synchronize()
             self._check_views()
             self.graphs = (g1, g2)
+            _bump()
 
     def _adopted_flat(self) -> Optional[torch.Tensor]:
         """The gradients as one flat tensor if they are consecutive contiguous fp32 views of one allocation, in parameter order."""
@@ -222,6 +272,19 @@ class DataParallelTrainStep:
                 return None
             off += p.numel()
         return torch.empty(0, dtype=torch.float32, device=g0.device).set_(store, g0.storage_offset(), (off,), (1,))
+
+    @property
+    def outputs(self) -> torch.Tensor:
+        """The model output of the last step (static memory under graphs: valid until the next call)."""
+        return self._out.detach()
+
+    def _bind_views(self):
+        """Make every ``p.grad`` a view of ``self.flat_grad`` again (the eager form accumulates into them)."""
+        base, off = self.flat_grad.data_ptr(), 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
 
     def _check_views(self):
         base = self.flat_grad.data_ptr()
@@ -241,13 +304,16 @@ class DataParallelTrainStep:
         if target is not None:
             self.target.copy_(target, non_blocking=True)
         if self.graphs is None:
+            self._bind_views()                                           # the caller may have dropped or replaced p.grad
             loss = self._fwd_bwd()
             self._all_reduce()
             self._update()
             return loss
+        self._lr.sync()
         self.graphs[0].replay()
         self._all_reduce()
         self.graphs[1].replay()
+        _bump()
         return self.loss
 
 

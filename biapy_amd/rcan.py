@@ -42,6 +42,7 @@ class RG(nn.Module):
 
 
 class rcan(nn.Module):
+    _bpx_dropin = True   # train_engine: the training-time model_call_func of this class is to_pytorch_format -> forward
     _HEAD = {"linear": 0, "sigmoid": 1, "tanh": 2}
 
     def __init__(self, ndim, num_channels=3, filters=64, scale=2, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=True,

@@ -120,6 +120,8 @@ class _GraphedResUNetFn(torch.autograd.Function):
 
 
 class ResUNet(nn.Module):
+    _bpx_dropin = True   # train_engine: the training-time model_call_func of this class is to_pytorch_format -> forward
+
     def __init__(
         self,
         image_shape=(256, 256, 1),
@@ -230,6 +232,13 @@ class ResUNet(nn.Module):
         if self._engine is None or self._engine.dtype != self.compute_dtype:
             self._engine = ResUNetEngine(self.cfg, self.compute_dtype)
         return self._engine
+
+    def train(self, mode: bool = True):
+        """Entering training mode drops the packed / lifted weight copies the inference path keeps (they are also keyed by
+        tensor version and by engine.weights_epoch(), which every graph replay of this package bumps)."""
+        if self._engine is not None:
+            self._engine.clear_caches()
+        return super().train(mode)
 
     def _named(self):
         names, params = [], []

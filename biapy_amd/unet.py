@@ -53,6 +53,8 @@ class UpBlock(nn.Module):
 
 
 class U_Net(nn.Module):
+    _bpx_dropin = True   # train_engine: the training-time model_call_func of this class is to_pytorch_format -> forward
+
     def __init__(
         self,
         image_shape=(256, 256, 1),

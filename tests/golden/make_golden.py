@@ -609,8 +609,77 @@ def resunetpp_fixtures():
     print("resunetpp_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunetpp_golden.npz")) // 1024, "KiB")
 
 
+def train_loop_case(name):
+    """Seeded toy problem of the train-loop fixture: (net, data, val data, cfg values).  Tests rebuild exactly this."""
+    import types
+
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.ELU(), torch.nn.Conv3d(4, 1, 1))
+    g = torch.Generator().manual_seed(12)
+    data = [(torch.randn(2, 4, 6, 6, 1, generator=g), (torch.rand(2, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(13)]
+    val = [(torch.randn(2, 4, 6, 6, 1, generator=g), (torch.rand(2, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(4)]
+    clip, sched = {"plain": (0.0, ""), "clip_onecycle": (0.05, "onecycle"), "plateau": (0.0, "reduceonplateau")}[name]
+    cfg = types.SimpleNamespace(DATA=types.SimpleNamespace(PATCH_SIZE=(4, 6, 6, 1)),
+                                TRAIN=types.SimpleNamespace(GRADIENT_CLIP_NORM=clip, LR_SCHEDULER=types.SimpleNamespace(NAME=sched), VERBOSE=False))
+    return net, data, val, cfg
+
+
+def train_loop_fixtures():
+    """Row T: the reference's own train_one_epoch / evaluate (biapy/engine/train_engine.py) run on a toy CPU problem, called
+    exactly as Base_Workflow.train does (base_workflow.py:1070-1088, :1114-1126).  Stored: the returned stats, the step index
+    and the trained weights of three cases (plain; gradient clipping + one-cycle schedule; reduce-on-plateau over 3 epochs)."""
+    import typing
+
+    shim.install()
+    sys.modules["biapy.engine"].Scheduler = typing.Any
+    te = shim.load("biapy.engine.train_engine")
+    dev = torch.device("cpu")
+    out = {}
+    for name in ("plain", "clip_onecycle", "plateau"):
+        net, data, val, cfg = train_loop_case(name)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+        sched = None
+        if name == "clip_onecycle":
+            sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-2, total_steps=len(data) * 2)
+        if name == "plateau":
+            sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=10.0)   # reduces after every epoch
+        loss_fn = torch.nn.BCEWithLogitsLoss()
+
+        def call(batch, is_train=False):
+            return net(batch.permute(0, 4, 1, 2, 3))
+
+        def prep(targets, batch):
+            return targets.permute(0, 4, 1, 2, 3)
+
+        def metric(outputs, targets, metric_logger=None):
+            p_ = (torch.sigmoid(outputs) > 0.5).float()
+            iou = ((p_ * targets).sum() / torch.clamp(((p_ + targets) > 0).float().sum(), min=1.0)).item()
+            if metric_logger:
+                metric_logger.meters["IoU"].update(iou)
+
+        epochs = 3 if name == "plateau" else 2
+        for epoch in range(epochs):
+            with quiet():
+                stats, step = te.train_one_epoch(cfg, model=net, model_call_func=call, loss_function=loss_fn, metric_function=metric,
+                                                 prepare_targets=prep, data_loader=data, optimizer=[opt], device=dev, epoch=epoch, log_writer=None,
+                                                 lr_scheduler=[sched], verbose=False, memory_bank=None, total_iters=0, contrast_warmup_iters=0,
+                                                 loss_names=["loss"])
+                ev = te.evaluate(cfg, model=net, model_call_func=call, loss_function=loss_fn, metric_function=metric, prepare_targets=prep,
+                                 epoch=epoch, data_loader=val, lr_scheduler=[sched], memory_bank=None, loss_names=["loss"])
+            for k, v in stats.items():
+                out[f"{name}/e{epoch}/train/{k}"] = np.float64(v)
+            for k, v in ev.items():
+                out[f"{name}/e{epoch}/val/{k}"] = np.float64(v)
+            out[f"{name}/e{epoch}/step"] = np.int64(step)
+        for k, v in net.state_dict().items():
+            out[f"{name}/w/{k}"] = v.numpy().copy()
+        print(name, {k: float(v) for k, v in stats.items()}, {k: float(v) for k, v in ev.items()}, "lr", opt.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(HERE, "train_loop_golden.npz"), **out)
+    print("train_loop_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -633,3 +702,5 @@ if __name__ == "__main__":
         rcan_fixtures()
     if "resunetpp" in which:
         resunetpp_fixtures()
+    if "train_loop" in which:
+        train_loop_fixtures()

@@ -228,7 +228,7 @@ def _epoch_worker(rank, world, port, q):
     loss_fn = torch.nn.BCEWithLogitsLoss()
     with torch.no_grad():
         local = [loss_fn(net(x.permute(0, 4, 1, 2, 3)), t.permute(0, 4, 1, 2, 3)).item() for x, t in data]
-    ev = TE.evaluate(net, loss_fn, data, torch.device("cpu"), epoch=0)
+    ev = TE.evaluate(None, net, None, loss_fn, None, None, 0, data, loss_names=["loss"], device=torch.device("cpu"))
     q.put((rank, ev["loss"], sum(local), len(local)))
     dist.barrier()
     dist.destroy_process_group()

@@ -385,35 +385,98 @@ def test_unet2d_cfg1_train_step(K, dtype):
     _assert_all(K.check_unet_cfg1(dtype))
 
 
-def test_train_one_epoch_graph_replay_equals_eager():
-    """biapy_amd.train_engine.train_one_epoch: the HIP-graph replay path (incl. the undo of the capture warm-up and the eager
-    fallback for a ragged last batch) trains exactly like the eager loop of the reference (train_engine.py:127-180)."""
-    from biapy_amd import train_engine as TE
-    from biapy_amd.losses import BCEWithLogitsLoss
+def _te_cfg(patch):
+    import types
+
+    return types.SimpleNamespace(DATA=types.SimpleNamespace(PATCH_SIZE=patch),
+                                 TRAIN=types.SimpleNamespace(GRADIENT_CLIP_NORM=0.0, LR_SCHEDULER=types.SimpleNamespace(NAME="reduceonplateau"), VERBOSE=False))
+
+
+def _small_resunet(dtype=torch.float32, seed=0):
     from biapy_amd.resunet import ResUNet
 
+    torch.manual_seed(seed)
+    return ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
+                   z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=dtype).cuda()
+
+
+def test_train_one_epoch_on_device_vs_cpu_oracle_loop():
+    """biapy_amd.train_engine.train_one_epoch / evaluate at the reference's call site (base_workflow.py:1070-1088, :1114-1126) with the
+    drop-in ResUNet on the device - eager AND replayed from HIP graphs (incl. the undo of the capture warm-up, an eager ragged last
+    batch, a ReduceLROnPlateau step between the epochs that must reach the captured optimizer, and a validation pass after
+    graph-replayed steps, which must see the NEW weights - ADVICE r1) - against the same two epochs done by the CPU oracle network
+    (oracle/net_oracle.py, pinned to the reference) in a plain PyTorch loop: epoch losses, validation losses and final weights."""
+    from biapy_amd import train_engine as TE
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from oracle import net_oracle
+
     g = torch.Generator().manual_seed(3)
-    data = [(torch.randn(2, 16, 16, 16, 1, generator=g), (torch.rand(2, 16, 16, 16, 1, generator=g) > 0.5).float()) for _ in range(5)]
-    data.append((torch.randn(1, 16, 16, 16, 1, generator=g), (torch.rand(1, 16, 16, 16, 1, generator=g) > 0.5).float()))   # ragged last batch
-    nets, stats = [], []
+    mk = lambda b: (torch.randn(b, 16, 16, 16, 1, generator=g), (torch.rand(b, 16, 16, 16, 1, generator=g) > 0.5).float())  # noqa: E731
+    data = [mk(2) for _ in range(5)] + [mk(1)]                           # ragged last batch
+    val = [mk(2) for _ in range(2)]                                      # fixed size: no eager step bumps the tensor versions in between
+    cfg = _te_cfg((16, 16, 16, 1))
+    fm = [16, 32]
+    # ---- CPU oracle loop -----------------------------------------------------------------------------------------------
+    sd0 = {k: v.detach().cpu().clone() for k, v in _small_resunet().state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    oopt = torch.optim.AdamW(list(params.values()), lr=1e-3)
+    osched = torch.optim.lr_scheduler.ReduceLROnPlateau(oopt, factor=0.5, patience=0, threshold=10.0)
+    want = []
+    for epoch in range(2):
+        tot = 0.0
+        for x, t in data:
+            oopt.zero_grad()
+            loss = net_oracle.bce_with_logits(net_oracle.resunet_forward(params, x.permute(0, 4, 1, 2, 3), fm), t.permute(0, 4, 1, 2, 3))
+            loss.backward()
+            oopt.step()
+            tot += loss.item()
+        with torch.no_grad():
+            v = sum(net_oracle.bce_with_logits(net_oracle.resunet_forward(params, x.permute(0, 4, 1, 2, 3), fm), t.permute(0, 4, 1, 2, 3)).item()
+                    for x, t in val) / len(val)
+        osched.step(v)
+        want.append((tot / len(data), v))
+    # ---- device, eager and graph -------------------------------------------------------------------------------------------
     for mode in ("off", "on"):
-        torch.manual_seed(0)
-        m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
-                    z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda()
+        m = _small_resunet()
         opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=10.0)
         loss_fn = BCEWithLogitsLoss()
-        for epoch in range(2):                                          # the second epoch replays the graphs captured in the first
-            s, last = TE.train_one_epoch(m, loss_fn, data, opt, torch.device("cuda"), epoch=epoch, patch_size=(16, 16, 16, 1), graph=mode, sync_every=4)
+        call = lambda b, is_train=False, m=m: m(TE.to_pytorch_format(b, "cuda"))  # noqa: E731
+        prep = lambda t, b: TE.to_pytorch_format(t, "cuda")  # noqa: E731
+        for epoch in range(2):                                          # the second epoch replays the graphs captured in the first one
+            s, last = TE.train_one_epoch(cfg, model=m, model_call_func=call, loss_function=loss_fn, metric_function=None, prepare_targets=prep,
+                                         data_loader=data, optimizer=[opt], device=torch.device("cuda"), epoch=epoch, log_writer=None,
+                                         lr_scheduler=[sched], verbose=False, memory_bank=None, total_iters=0, contrast_warmup_iters=0,
+                                         loss_names=["loss"], graph=mode, sync_every=4)
+            ev = TE.evaluate(cfg, model=m, model_call_func=call, loss_function=loss_fn, metric_function=None, prepare_targets=prep, epoch=epoch,
+                             data_loader=val, lr_scheduler=[sched], memory_bank=None, loss_names=["loss"])
             assert last == 5
+            assert abs(s["loss"] - want[epoch][0]) < 2e-5, (mode, epoch, s, want)
+            assert abs(ev["loss"] - want[epoch][1]) < 2e-5, (mode, epoch, ev, want)   # stale packed weights would show here
+            assert abs(s["lr"] - 1e-3 * 0.5 ** epoch) < 1e-9, (mode, epoch, s)
         assert (mode == "on") == hasattr(m, "_bpx_graph_step")
-        nets.append(m)
-        stats.append(s)
-    assert abs(stats[0]["loss"] - stats[1]["loss"]) < 1e-5, stats
-    for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        if p.dim() == 5:
-            assert (p - q).abs().max().item() <= 2e-5 * max(1.0, p.abs().max().item()), k
-    ev = TE.evaluate(nets[1], BCEWithLogitsLoss(), data[:2], torch.device("cuda"), epoch=0)
-    assert 0.0 < ev["loss"] < 2.0
+        assert abs(float(opt.param_groups[0]["lr"]) - 2.5e-4) < 1e-10
+        for k, p in m.named_parameters():
+            if p.dim() == 5:     # conv weights (a conv bias in front of an InstanceNorm has a zero gradient: Adam turns its rounding noise into steps)
+                w = params[k].detach()
+                assert (p.detach().cpu() - w).abs().max().item() <= 1e-4 * max(1.0, w.abs().max().item()), (mode, k)
+
+
+def test_graphed_inference_follows_weight_updates():
+    """GraphedInference must not freeze the packed weights at capture time (its warm-up fills the inference cache): after
+    an in-place parameter update the replay equals a fresh eager forward."""
+    from biapy_amd.graphs import GraphedInference
+
+    m = _small_resunet().eval()
+    x = torch.randn(2, 1, 16, 16, 16, device="cuda")
+    gi = GraphedInference(m.predict_proba, x)
+    y0 = gi(x).clone()
+    assert torch.equal(y0, m.predict_proba(x))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.1)
+    y1 = gi(x).clone()
+    assert not torch.equal(y0, y1) and torch.equal(y1, m.predict_proba(x))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -537,7 +600,8 @@ def _dp2_worker(rank, world, port, q):
     m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2],
                 z_down=[2], isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32).cuda()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
-    stats, _ = TE.train_one_epoch(m, BCEWithLogitsLoss(), data, opt, torch.device("cuda"), epoch=0, patch_size=(16, 16, 16, 1), graph="on")
+    stats, _ = TE.train_one_epoch(_te_cfg((16, 16, 16, 1)), m, None, BCEWithLogitsLoss(), None, None, data, [opt], torch.device("cuda"), 0,
+                                  loss_names=["loss"], graph="on")
     q.put((rank, stats["loss"], {k: p.detach().cpu().numpy() for k, p in m.named_parameters() if p.dim() == 5}))   # arrays pickle by value
     dist.barrier()
     dist.destroy_process_group()

@@ -98,58 +98,184 @@ def test_prepost_fails_loudly_without_gpu():
 
 
 # ---- train_engine: step drivers (row T) -------------------------------------------------------------------------------
-def _toy_loader(n, B=2, seed=0):
-    g = torch.Generator().manual_seed(seed)
-    return [(torch.randn(B, 4, 6, 6, 1, generator=g), (torch.rand(B, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(n)]
+def _train_loop_case(name):
+    """The seeded toy problem of tests/golden/make_golden.py::train_loop_case (kept in step with it)."""
+    import types
+
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.ELU(), torch.nn.Conv3d(4, 1, 1))
+    g = torch.Generator().manual_seed(12)
+    data = [(torch.randn(2, 4, 6, 6, 1, generator=g), (torch.rand(2, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(13)]
+    val = [(torch.randn(2, 4, 6, 6, 1, generator=g), (torch.rand(2, 4, 6, 6, 1, generator=g) > 0.5).float()) for _ in range(4)]
+    clip, sched = {"plain": (0.0, ""), "clip_onecycle": (0.05, "onecycle"), "plateau": (0.0, "reduceonplateau")}[name]
+    cfg = types.SimpleNamespace(DATA=types.SimpleNamespace(PATCH_SIZE=(4, 6, 6, 1)),
+                                TRAIN=types.SimpleNamespace(GRADIENT_CLIP_NORM=clip, LR_SCHEDULER=types.SimpleNamespace(NAME=sched), VERBOSE=False))
+    return net, data, val, cfg
 
 
-def _toy_net(seed=0):
-    torch.manual_seed(seed)
-    return torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, padding=1), torch.nn.ELU(), torch.nn.Conv3d(4, 1, 1))
-
-
-def test_train_one_epoch_matches_a_plain_loop():
-    """biapy_amd.train_engine.train_one_epoch (eager form, the one that runs without a GPU) == the reference loop's arithmetic
-    (train_engine.py:127-180): zero_grad, forward on (B,C,Z,Y,X), loss, backward, step; returns ({loss, lr}, last step)."""
+@pytest.mark.parametrize("name", ["plain", "clip_onecycle", "plateau"])
+def test_train_one_epoch_and_evaluate_at_the_reference_call_site(name):
+    """biapy_amd.train_engine.train_one_epoch / evaluate called EXACTLY as Base_Workflow.train calls the reference's
+    (base_workflow.py:1070-1088, :1114-1126: positional cfg, optimizer / lr_scheduler lists, log_writer, memory_bank, total_iters,
+    contrast_warmup_iters, loss_names) reproduce what the reference's own functions returned on the same seeded problem
+    (tests/golden/train_loop_golden.npz, generated by importing biapy/engine/train_engine.py): every returned meter (loss, the
+    metric the workflow's metric_function records, lr), the step index and the trained weights - incl. gradient clipping + the
+    per-step one-cycle schedule and ReduceLROnPlateau driven by evaluate()."""
     from biapy_amd import train_engine as TE
 
-    data = _toy_loader(7)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_golden.npz"))
+    net, data, val, cfg = _train_loop_case(name)
+    dev = torch.device("cpu")
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    sched = None
+    if name == "clip_onecycle":
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-2, total_steps=len(data) * 2)
+    if name == "plateau":
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0, threshold=10.0)
     loss_fn = torch.nn.BCEWithLogitsLoss()
-    a, b = _toy_net(), _toy_net()
-    oa, ob = torch.optim.AdamW(a.parameters(), lr=1e-2), torch.optim.AdamW(b.parameters(), lr=1e-2)
-    stats, last = TE.train_one_epoch(a, loss_fn, data, oa, torch.device("cpu"), epoch=0, patch_size=(4, 6, 6, 1), graph="off", sync_every=3)
-    tot = 0.0
-    for x, t in data:
-        ob.zero_grad()
-        loss = loss_fn(b(x.permute(0, 4, 1, 2, 3)), t.permute(0, 4, 1, 2, 3))
-        loss.backward()
-        ob.step()
-        tot += loss.item()
-    assert last == 6 and abs(stats["loss"] - tot / 7) < 1e-6 and stats["lr"] == 1e-2
-    for p, q in zip(a.parameters(), b.parameters()):
-        assert torch.allclose(p, q, atol=1e-7)
-    ev = TE.evaluate(a, loss_fn, data[:3], torch.device("cpu"), epoch=0)
-    with torch.no_grad():
-        ref = sum(loss_fn(b(x.permute(0, 4, 1, 2, 3)), t.permute(0, 4, 1, 2, 3)).item() for x, t in data[:3]) / 3
-    assert abs(ev["loss"] - ref) < 1e-6
+
+    def call(batch, is_train=False):
+        return net(batch.permute(0, 4, 1, 2, 3))
+
+    def prep(targets, batch):
+        return targets.permute(0, 4, 1, 2, 3)
+
+    def metric(outputs, targets, metric_logger=None):
+        p_ = (torch.sigmoid(outputs) > 0.5).float()
+        iou = ((p_ * targets).sum() / torch.clamp(((p_ + targets) > 0).float().sum(), min=1.0)).item()
+        if metric_logger:
+            metric_logger.meters["IoU"].update(iou)
+
+    class Writer:
+        def __init__(self):
+            self.heads = []
+
+        def update(self, head="scalar", step=None, **kw):
+            self.heads.append((head, sorted(kw)))
+
+    w = Writer()
+    for epoch in range(3 if name == "plateau" else 2):
+        stats, step = TE.train_one_epoch(
+            cfg,
+            model=net,
+            model_call_func=call,
+            loss_function=loss_fn,
+            metric_function=metric,
+            prepare_targets=prep,
+            data_loader=data,
+            optimizer=[opt],
+            device=dev,
+            epoch=epoch,
+            log_writer=w,
+            lr_scheduler=[sched],
+            verbose=False,
+            memory_bank=None,
+            total_iters=0,
+            contrast_warmup_iters=0,
+            loss_names=["loss"],
+        )
+        ev = TE.evaluate(
+            cfg,
+            model=net,
+            model_call_func=call,
+            loss_function=loss_fn,
+            metric_function=metric,
+            prepare_targets=prep,
+            epoch=epoch,
+            data_loader=val,
+            lr_scheduler=[sched],
+            memory_bank=None,
+            loss_names=["loss"],
+        )
+        assert step == int(gold[f"{name}/e{epoch}/step"])
+        assert set(stats) == {"loss", "IoU", "lr"} and set(ev) == {"loss", "IoU"}
+        for k, v in stats.items():
+            assert abs(v - float(gold[f"{name}/e{epoch}/train/{k}"])) < 1e-6, (epoch, k, v)
+        for k, v in ev.items():
+            assert abs(v - float(gold[f"{name}/e{epoch}/val/{k}"])) < 1e-6, (epoch, k, v)
+    for k, v in net.state_dict().items():
+        assert np.allclose(v.numpy(), gold[f"{name}/w/{k}"], atol=1e-6), k
+    assert ("loss", ["loss"]) in w.heads and ("opt", ["lr"]) in w.heads
+
+
+def test_train_one_epoch_multiple_losses_and_optimizers():
+    """The dict form of a loss (train_engine.py:152-158: {"losses": [...], "metrics": {...}}): one backward / step per loss with
+    its own optimizer, one meter per loss name and per lr name (loss_x -> lr_x), precalculated metrics instead of metric_function."""
+    from biapy_amd import train_engine as TE
+
+    net, data, _, cfg = _train_loop_case("plain")
+    ref, _, _, _ = _train_loop_case("plain")
+    bce = torch.nn.BCEWithLogitsLoss()
+
+    def two_of(n):
+        def two(outputs, targets):                                      # two losses with separate autograd graphs
+            return {"losses": [bce(outputs, targets), (n[2].weight ** 2).sum() + (n[2].bias ** 2).sum()], "metrics": {"m": 0.25}}
+        return two
+
+    def make(n):
+        ps = list(n.parameters())
+        return [torch.optim.SGD(ps[:2], lr=0.1), torch.optim.SGD(ps[2:], lr=0.05)]
+
+    oa, ob = make(net), make(ref)
+    stats, step = TE.train_one_epoch(cfg, net, lambda b, is_train=False: net(b.permute(0, 4, 1, 2, 3)), two_of(net), None,
+                                     lambda t, b: t.permute(0, 4, 1, 2, 3), data, oa, torch.device("cpu"), 0, None, [None, None], False, None, 0, 0,
+                                     ["loss_a", "loss_b"])
+    tot = [0.0, 0.0]
+    for x, t in data:                                                   # the reference loop, written out (train_engine.py:127-180)
+        out = ref(x.permute(0, 4, 1, 2, 3))
+        r = two_of(ref)(out, t.permute(0, 4, 1, 2, 3))
+        for i, l in enumerate(r["losses"]):
+            l.backward()
+            ob[i].step()
+            ob[i].zero_grad()
+            tot[i] += l.item()
+    assert step == 12 and set(stats) == {"loss_a", "loss_b", "m", "lr_a", "lr_b"}
+    assert abs(stats["loss_a"] - tot[0] / 13) < 1e-6 and abs(stats["loss_b"] - tot[1] / 13) < 1e-6 and abs(stats["m"] - 0.25) < 1e-12
+    assert abs(stats["lr_a"] - 0.1) < 1e-9 and abs(stats["lr_b"] - 0.05) < 1e-9
 
 
 def test_train_one_epoch_error_behaviour():
     """Same failures as the reference: wrong patch shape -> ValueError with its message (train_engine.py:139-143); a non-finite
-    loss -> sys.exit(1) (:166-169)."""
+    loss -> sys.exit(1) (:160-164); plus the errors of the acceleration switches."""
+    import types
+
     from biapy_amd import train_engine as TE
 
-    net, loss_fn = _toy_net(), torch.nn.BCEWithLogitsLoss()
+    net, data, _, cfg = _train_loop_case("plain")
+    loss_fn = torch.nn.BCEWithLogitsLoss()
     opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    call, prep = (lambda b, is_train=False: net(b.permute(0, 4, 1, 2, 3))), (lambda t, b: t.permute(0, 4, 1, 2, 3))
+    bad_cfg = types.SimpleNamespace(DATA=types.SimpleNamespace(PATCH_SIZE=(8, 6, 6, 1)), TRAIN=cfg.TRAIN)
     with pytest.raises(ValueError, match="different shape than 'DATA.PATCH_SIZE'"):
-        TE.train_one_epoch(net, loss_fn, _toy_loader(2), opt, "cpu", 0, patch_size=(8, 6, 6, 1), graph="off")
-    bad = _toy_loader(4)
+        TE.train_one_epoch(bad_cfg, net, call, loss_fn, None, prep, data[:2], [opt], torch.device("cpu"), 0, loss_names=["loss"])
+    bad = list(data[:4])
     bad[1] = (bad[1][0] * float("nan"), bad[1][1])
     with pytest.raises(SystemExit) as e:
-        TE.train_one_epoch(net, loss_fn, bad, opt, "cpu", 0, patch_size=(4, 6, 6, 1), graph="off", sync_every=2)
+        TE.train_one_epoch(cfg, net, call, loss_fn, None, prep, bad, [opt], torch.device("cpu"), 0, loss_names=["loss"], sync_every=2)
     assert e.value.code == 1
     with pytest.raises(ValueError, match="graph='on'"):
-        TE.train_one_epoch(net, loss_fn, _toy_loader(1), opt, "cpu", 0, graph="on")
+        TE.train_one_epoch(cfg, net, call, loss_fn, None, prep, data[:1], [opt], torch.device("cpu"), 0, loss_names=["loss"], graph="on")
+    with pytest.raises(NotImplementedError, match="memory_bank"):
+        TE.train_one_epoch(cfg, net, call, loss_fn, None, prep, data[:1], [opt], torch.device("cpu"), 0, memory_bank=object(), loss_names=["loss"])
+
+
+def test_graph_lr_tensors_follow_schedulers_and_assignments():
+    """graphs._LrTensors (a float lr is baked into a captured optimizer step): the learning rates become tensors that
+    PyTorch's schedulers update in place, and a plain assignment ``group["lr"] = v`` is folded back into the captured tensor."""
+    from biapy_amd.graphs import _LrTensors
+
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    lt = _LrTensors(opt, "cpu")
+    t = opt.param_groups[0]["lr"]
+    assert torch.is_tensor(t) and t is lt.lrs[0] and abs(t.item() - 1e-2) < 1e-9
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0)
+    sched.step(1.0)
+    sched.step(2.0)                                                     # worse: halves the lr - in place
+    assert opt.param_groups[0]["lr"] is t and abs(t.item() - 5e-3) < 1e-9
+    opt.param_groups[0]["lr"] = 1e-3                                    # what the reference's warm-up schedules do
+    lt.sync()
+    assert opt.param_groups[0]["lr"] is t and abs(t.item() - 1e-3) < 1e-9
 
 
 def test_chunk_grid_rank_partition_covers_every_chunk_once():
