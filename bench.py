@@ -1,20 +1,27 @@
 #!/usr/bin/env python
-"""bench.py - voxels/s of the 3D ResUNet hot path on MI355X (BASELINE.json metric).
+"""bench.py - voxels/s of the 3D ResUNet hot path on MI355X (BASELINE.json metric: "train+infer" at 1/2/4/8 GPUs).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3                 # train step (fwd+bwd+AdamW), cfg 2
+    python bench.py --gpus 1 --steps 10 --warmup 3                 # train step (fwd+bwd+AdamW) of cfg 2, then inference + cfg 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W                      # data parallel over RCCL, weak scaling
-    python bench.py --mode infer                                    # forward only (sigmoid head fused)
-    python bench.py --breakdown                                     # per-kernel event timing table (not timed run)
+        bench.py --gpus N --steps K --warmup W                      # data parallel over RCCL (weak scaling); sliding window sharded
+    python bench.py --mode infer | --mode sliding                   # one section only (its own JSON line)
+    python bench.py --breakdown                                     # per-kernel event timing table (not a timed run)
 
-Workload = BASELINE.json configs[1]: 3D ResUNet (feature maps 16-32-64-128-256, InstanceNorm, ELU), 128^3
-1-channel patches, batch 4 per GPU, bf16 storage / fp32 accumulate, synthetic data, random-init weights.
-One step = one pass over one batch.  Prints ONE JSON line on rank 0.
+ONE JSON line on rank 0.  ``value`` = the TRAIN throughput (the timed region the driver's clock brackets: W warm-up steps, then
+exactly K steps between barriers + synchronize, max over ranks).  The same process then measures, each bracketed the same way
+and reported as a sub-record with its own roofline entry:
+  ``infer``   - forward + fused sigmoid of the same batch (weak scaling: every rank its own batch);
+  ``sliding`` - cfg 3, crop -> forward -> blend of a 1024^3 synthetic volume, 4096 patches sharded over the ranks by Z-slab, each
+                rank holding only its input slab; strong scaling (N = 1 measures one GPU's share of the 8-GPU job, a 512^3 volume,
+                unless --sliding-vol is given).
+Workload = BASELINE.json configs[1]: 3D ResUNet (feature maps 16-32-64-128-256, InstanceNorm, ELU), 128^3 1-channel patches,
+batch 4 per GPU, bf16 storage / fp32 accumulate, synthetic data, random-init weights.  One step = one pass over one batch.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +35,7 @@ FM = [16, 32, 64, 128, 256]
 FLOP_PER_VOXEL_FWD = 144832       # BASELINE.md section 3 (2*MAC of all Conv3d/ConvTranspose3d), per input voxel
 MFMA_PEAK_BF16 = 2.5e15           # dense bf16 peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
+CONV_ENTRIES = ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad", "bpx_wgrad_defer_flush")
 
 
 def synth_batch(B, P, device, seed):
@@ -59,14 +67,12 @@ def conv_flops(name, key):
         return 2 * vox * (27 * cin + csc) * cout
     if name == "bpx_conv3d_dgrad":    # dy, t, g
         return 2 * vox * 27 * cs[0] * cs[2]
-    if name == "bpx_conv3d_wgrad":    # x, act, dy, k[, small workspace size]
-        k = wgrad_k(key)
-        return 2 * vox * (k ** 3) * cs[0] * cs[1]
-    return 0
+    k = wgrad_k(key)                  # wgrad: x, act, dy, k[, small workspace size]
+    return 2 * vox * (k ** 3) * cs[0] * cs[1]
 
 
 def conv_bytes(name, key, es):
-    """Algorithmic HBM bytes of one conv launch: every activation operand read once, the result written once (DESIGN.md section 5)."""
+    """Algorithmic HBM bytes of one conv launch: every activation operand read once, the result written once (DESIGN.md section 6)."""
     if name not in ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad"):
         return 0
     ints = [k for k in key if isinstance(k, int)]
@@ -80,64 +86,101 @@ def conv_bytes(name, key, es):
     return vox * (cs[0] + cs[1]) * es  # wgrad: read x and dy
 
 
-def cpu_baseline(P, train):
-    """The oracle (plain PyTorch CPU fp32 restatement of the reference graph) on this host's cores, batch 1."""
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (PyTorch CPU fp32 restatement of the reference graph, NumPy restatement of crop / merge) on this host
+# ------------------------------------------------------------------------------------------------------------------------
+def _cpu_net_leg(P, train, threads, reps_cap=2):
     from oracle import net_oracle
 
-    torch.manual_seed(0)
-    sd = net_oracle.init_state_dict(1, FM, seed=0)
-    x = torch.randn(1, 1, P, P, P)
-    tgt = (torch.rand(1, 1, P, P, P) > 0.5).float()
-    params = {k: v.clone().requires_grad_(train) for k, v in sd.items()}
-    opt = torch.optim.AdamW(list(params.values()), lr=1e-3) if train else None
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(0)
+        sd = net_oracle.init_state_dict(1, FM, seed=0)
+        x = torch.randn(1, 1, P, P, P)
+        tgt = (torch.rand(1, 1, P, P, P) > 0.5).float()
+        params = {k: v.clone().requires_grad_(train) for k, v in sd.items()}
+        opt = torch.optim.AdamW(list(params.values()), lr=1e-3) if train else None
 
-    def step():
-        if train:
-            opt.zero_grad(set_to_none=True)
-            loss = net_oracle.bce_with_logits(net_oracle.resunet_forward(params, x, FM), tgt)
-            loss.backward()
-            opt.step()
-        else:
-            with torch.no_grad():
-                net_oracle.resunet_forward(params, x, FM)
+        def step():
+            if train:
+                opt.zero_grad(set_to_none=True)
+                loss = net_oracle.bce_with_logits(net_oracle.resunet_forward(params, x, FM), tgt)
+                loss.backward()
+                opt.step()
+            else:
+                with torch.no_grad():
+                    net_oracle.resunet_forward(params, x, FM)
 
-    t0 = time.time(); step(); warm = time.time() - t0
-    reps = 1 if warm > 12 else 2
-    t0 = time.time()
-    for _ in range(reps):
-        step()
-    dt = (time.time() - t0) / reps
-    return dict(value=P ** 3 / dt, unit="voxels/s", cores=torch.get_num_threads(), kind="port",
+        t0 = time.time(); step(); warm = time.time() - t0
+        reps = 1 if warm > 8 else reps_cap
+        t0 = time.time()
+        for _ in range(reps):
+            step()
+        dt = (time.time() - t0) / reps
+    finally:
+        torch.set_num_threads(old)
+    return dict(value=P ** 3 / dt, unit="voxels/s", cores=threads, kind="port",
                 sample=f"{reps} {'train steps (fwd+BCE+bwd+AdamW)' if train else 'forwards'} of one {P}^3 patch, batch 1, fp32, after 1 warm-up "
                        f"({dt:.2f} s each)")
 
 
-def synth_volume(V, dev, seed=3):
-    """SURVEY.md 8(d) cfg 3: closed-form sin/cos lattice + seeded noise, generated on the device (no 4.3 GB transfer)."""
+def _cpu_tiling_leg(V=256, P=128):
+    """crop + merge of a V^3 volume (256^3, 64 patches) with the NumPy oracle: single-threaded, as the reference is."""
+    import numpy as np
+
+    from oracle import tiling_oracle
+
+    vol = np.random.RandomState(0).rand(V, V, V, 1).astype(np.float32)
+    t0 = time.time()
+    p, _ = tiling_oracle.crop(vol, (P, P, P, 1), (0.5, 0.5, 0.5))
+    t1 = time.time()
+    tiling_oracle.merge(p, vol.shape, overlap=(0.5, 0.5, 0.5))
+    t2 = time.time()
+    n = p.shape[0]
+    return dict(value=n * P ** 3 / (t2 - t0), unit="patch voxels/s", cores=1, kind="port",
+                sample=f"crop ({t1 - t0:.2f} s) + merge ({t2 - t1:.2f} s) of one {V}^3 volume, {n} patches of {P}^3, 50 % overlap, fp32",
+                crop_s=round(t1 - t0, 3), merge_s=round(t2 - t1, 3), patches=n)
+
+
+def cpu_baseline(P, quick=False):
+    """the reference's CPU path beside the GPU numbers, on this host, core count stated.  Bounded samples
+    (about 40 s in total): train at every core and at BiaPy's default ``min(4, ncpu)`` threads (biapy/_biapy.py:333-346; on a
+    64^3 patch there - same network, 1/8 of the voxels), inference at every core, crop + merge single-threaded."""
+    ncpu = torch.get_num_threads()
+    legs = {"train_all_cores": _cpu_net_leg(P, True, ncpu, reps_cap=1)}
+    if not quick:
+        legs["train_biapy_default_threads"] = _cpu_net_leg(min(P, 64), True, min(4, ncpu), reps_cap=1)
+        legs["infer_all_cores"] = _cpu_net_leg(P, False, ncpu)
+        legs["crop_merge_numpy"] = _cpu_tiling_leg()
+    head = dict(legs["train_all_cores"])
+    head["legs"] = legs
+    return head
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def synth_volume(V, dev, z0=0, z1=None, seed=3):
+    """SURVEY.md 8(d) cfg 3: closed-form sin/cos lattice + seeded noise, generated on the device slice by slice (one generator
+    seed per z slice), so that a rank can build exactly its input slab [z0, z1) of the V^3 volume."""
+    z1 = V if z1 is None else z1
     ax = torch.arange(V, device=dev, dtype=torch.float32)
-    g = torch.Generator(device=dev).manual_seed(seed)
-    vol = torch.sin(ax * 0.11)[:, None, None] * torch.cos(ax * 0.07)[None, :, None] + torch.sin(ax * 0.05)[None, None, :]
-    vol = vol + 0.3 * torch.randn(V, V, V, generator=g, device=dev)
+    az = torch.arange(z0, z1, device=dev, dtype=torch.float32)
+    vol = torch.sin(az * 0.11)[:, None, None] * torch.cos(ax * 0.07)[None, :, None] + torch.sin(ax * 0.05)[None, None, :]
+    g = torch.Generator(device=dev)
+    for k in range(z1 - z0):
+        g.manual_seed(seed * 100003 + z0 + k)
+        vol[k] += 0.3 * torch.randn(V, V, generator=g, device=dev)
     return vol.unsqueeze(-1).contiguous()
 
 
-def bench_sliding(a, model, dev, rank, world):
-    """cfg 3: crop -> forward -> blend of one volume; patches sharded over the ranks (strong scaling)."""
-    from biapy_amd.workflow import SlidingWindowPredictor
-
-    model.eval()
-    V = a.vol
-    vol = synth_volume(V, dev)
-    sw = SlidingWindowPredictor(model, (a.patch,) * 3, (0.5, 0.5, 0.5), (0, 0, 0), batch_size=a.batch)
-    out = None
-    for _ in range(a.warmup):
-        out = sw.predict(vol, rank=rank, world=world, gather="rank0")
+def _timed(fn, steps, world, dev):
+    """The contract's timed region: barrier + synchronize on both sides, MAX over ranks."""
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = sw.predict(vol, rank=rank, world=world, gather="rank0")
+    for _ in range(steps):
+        fn()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -146,19 +189,107 @@ def bench_sliding(a, model, dev, rank, world):
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+    return elapsed
+
+
+def run_sliding(a, model, dev, rank, world, V, warmup, steps):
+    """cfg 3: crop -> forward -> blend of one volume; patches sharded over the ranks (strong scaling), slab-only inputs."""
+    from biapy_amd import _lib as L
+    from biapy_amd import tiling
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    model.eval()
+    sw = SlidingWindowPredictor(model, (a.patch,) * 3, (0.5, 0.5, 0.5), (0, 0, 0), batch_size=a.batch)
+    z_lo, z_hi = sw.input_slab((V, V, V), rank, world)
+    slab = synth_volume(V, dev, z_lo, z_hi) if z_hi > z_lo else torch.zeros((1, V, V, 1), device=dev)
+    out = [None]
+
+    def once():
+        out[0] = sw.predict(slab, rank=rank, world=world, gather="rank0", z_offset=z_lo, full_z=V)
+
+    for _ in range(warmup):
+        once()
+    elapsed = _timed(once, steps, world, dev)
+    # per-kernel times of the blend and the gather of the last pass's geometry, on this rank (events on the launch stream)
+    prof = L.Profile(names=("bpx_merge3d_blend", "bpx_crop3d_gather"))
+    L.lib.prof = prof
+    once()
+    torch.cuda.synchronize()
+    L.lib.prof = None
+    ms = {"bpx_merge3d_blend": 0.0, "bpx_crop3d_gather": 0.0}
+    cnt = {"bpx_merge3d_blend": 0, "bpx_crop3d_gather": 0}
+    for (name, _), (c, t) in prof.summary().items():
+        ms[name] += t
+        cnt[name] += c
+    from biapy_amd.workflow import plan_slabs
+
+    plan = tiling.MergePlan((V, V, V), (a.patch,) * 3, (0.5, 0.5, 0.5), (0, 0, 0), dev)
+    mine = plan_slabs([plan.row_start(i) for i in range(plan.grid[0].n)], a.patch, V, world)[rank]
+    n_mine = (mine.rows[1] - mine.rows[0]) * plan.grid[1].n * plan.grid[2].n
+    pv = plan.n_patches * a.patch ** 3
+    # algorithmic bytes of this rank's blend: its predictions read once + the slices it produces written once (fp32, C = 1);
+    # the boundary partial sums (numerator + weights, written and re-read) are overhead, not algorithmic bytes
+    merge_bytes = n_mine * a.patch ** 3 * 4 + (mine.own[1] - mine.own[0]) * V * V * 4
+    crop_bytes = 2 * n_mine * a.patch ** 3 * 4
+    rec = None
     if rank == 0:
-        from biapy_amd import tiling
-        plan = tiling.MergePlan((V, V, V), (a.patch,) * 3, (0.5, 0.5, 0.5), (0, 0, 0), dev)
-        pv = plan.n_patches * a.patch ** 3
-        print(json.dumps(dict(
+        mb = merge_bytes / (ms["bpx_merge3d_blend"] * 1e-3) / 1e9 if ms["bpx_merge3d_blend"] else None
+        cb = crop_bytes / (ms["bpx_crop3d_gather"] * 1e-3) / 1e9 if ms["bpx_crop3d_gather"] else None
+        rec = dict(
             metric="voxels/sec 3D ResUNet 128^3 patch (sliding-window inference: crop+forward+blend, patch voxels)",
-            value=pv * a.steps / elapsed, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
-            higher_is_better=True, scaling="strong", vs_baseline=None, dtype=a.dtype, data="synthetic",
-            config=dict(workload="cfg3: %d^3 volume, %d^3 patches, 50%% overlap, %d patches sharded over %d GPU(s)" % (V, a.patch, plan.n_patches, world),
-                        patches=plan.n_patches, volume=V, parallelism="z-slab x%d" % world),
-            output_voxels_per_s=V ** 3 * a.steps / elapsed, checksum=float(out.double().mean().item()) if out is not None else None)))
-    if world > 1:
-        dist.destroy_process_group()
+            value=pv * steps / elapsed, unit="voxels/s", n_gpus=world, steps=steps, warmup=warmup, ms_per_step=1e3 * elapsed / steps,
+            scaling="strong", output_voxels_per_s=V ** 3 * steps / elapsed,
+            config=dict(workload="cfg3%s: %d^3 volume, %d^3 patches, 50%% overlap, %d patches sharded over %d GPU(s), slab-only inputs"
+                                 % ("" if V == 1024 else " (one GPU's share of the 8-GPU job)", V, a.patch, plan.n_patches, world),
+                        patches=plan.n_patches, volume=V, parallelism="z-slab x%d" % world, input_slices_rank0=[z_lo, z_hi]),
+            mfma_frac_end_to_end=round(pv * steps / elapsed * FLOP_PER_VOXEL_FWD / (world * MFMA_PEAK_BF16), 5),
+            roofline=dict(bound="hbm", kernel="bpx_merge3d_blend", achieved=round(mb, 1) if mb else None, peak=HBM_PEAK / 1e9, unit="GB/s",
+                          frac=round(mb / (HBM_PEAK / 1e9), 4) if mb else None, traffic=None,
+                          algorithmic_bytes_per_pass=merge_bytes, launches=cnt["bpx_merge3d_blend"], ms_per_pass=round(ms["bpx_merge3d_blend"], 3),
+                          crop=dict(kernel="bpx_crop3d_gather", GBps=round(cb, 1) if cb else None, launches=cnt["bpx_crop3d_gather"],
+                                    ms_per_pass=round(ms["bpx_crop3d_gather"], 3), algorithmic_bytes_per_pass=crop_bytes),
+                          timed_on="one extra pass after the timed region, rank 0's share"),
+            checksum=float(out[0].double().mean().item()) if out[0] is not None else None)
+    return rec
+
+
+def conv_roofline(prof, prof_steps, dtype, timed_on):
+    """Roofline entry of the dominant conv entry point from per-launch HIP events (bytes / flops per launch from its shape)."""
+    summ = prof.summary()
+    per = {}
+    for (name, key), (cnt, ms) in summ.items():
+        if name == "bpx_wgrad_defer_flush":      # the batched reduction of the step's partial slabs is part of the wgrad calls' time
+            per.setdefault("bpx_conv3d_wgrad", [0.0, 0.0, 0, 0.0])[1] += ms
+            continue
+        d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
+        d[0] += conv_flops(name, key) * cnt
+        d[1] += ms
+        d[2] += cnt
+        d[3] += conv_bytes(name, key, 2 if dtype == "bf16" else 4) * cnt
+    per = {k: v for k, v in per.items() if v[2] > 0}
+    if not per:
+        return None
+    name, (fl, ms, cnt, by) = max(per.items(), key=lambda kv: kv[1][1])
+    peak = MFMA_PEAK_BF16 / 1e12 if dtype == "bf16" else 157.3
+    ach_f = fl / (ms * 1e-3) / 1e12                 # TFLOP/s
+    ach_b = by / (ms * 1e-3) / 1e9                  # GB/s of algorithmic bytes
+    # the binding roof is the one whose minimum time (work / peak) is larger for this kernel's launches
+    hbm_bound = by / HBM_PEAK > fl / (peak * 1e12)
+    traffic, src = None, os.path.join("profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/pmc_traffic.py
+    try:
+        traffic = (json.load(open(os.path.join(ROOT, src))).get(name) or {}).get("total_bytes")
+    except (OSError, ValueError):
+        traffic = None
+    return dict(bound="hbm" if hbm_bound else "mfma", kernel=name,
+                achieved=round(ach_b if hbm_bound else ach_f, 2), peak=HBM_PEAK / 1e9 if hbm_bound else peak,
+                unit="GB/s" if hbm_bound else "TFLOP/s",
+                frac=round(ach_b / (HBM_PEAK / 1e9) if hbm_bound else ach_f / peak, 4),
+                traffic=traffic, traffic_source=src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, committed; not measured in this run)",
+                algorithmic_bytes_per_launch=round(by / cnt), flops_per_launch=round(fl / cnt),
+                launches=cnt, avg_launch_ms=round(ms / cnt, 4), tflops=round(ach_f, 2), algorithmic_GBps=round(ach_b, 1),
+                all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), GBps=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                             ms_per_step=round(v[1] / prof_steps, 3)) for k, v in per.items()},
+                timed_on=timed_on)
 
 
 def main():
@@ -166,19 +297,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["train", "infer", "sliding"], default="train")
-    ap.add_argument("--vol", type=int, default=1024, help="sliding mode: edge of the synthetic volume (cfg 3 = 1024)")
+    ap.add_argument("--mode", choices=["all", "train", "infer", "sliding"], default="all",
+                    help="all = train (the headline value) + the infer and sliding sub-records; one name = that section only")
+    ap.add_argument("--vol", type=int, default=None, help="edge of the synthetic sliding-window volume (cfg 3 = 1024; default: 1024 for N > 1, "
+                                                          "512 = one GPU's share for N = 1)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel timing table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true", help="only the all-core train leg")
     ap.add_argument("--force-ddp", action="store_true", help="testing aid: take the multi-GPU code path (RCCL process group) even with one rank")
     ap.add_argument("--dp", choices=["flat", "ddp"], default="flat",
                     help="multi-GPU gradient exchange: flat = two HIP-graph replays around ONE flat-gradient all-reduce "
                          "(biapy_amd.graphs.DataParallelTrainStep); ddp = torch DistributedDataParallel with eager hooks")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step from a captured HIP graph (auto: single-GPU runs; the ~230 launches of a step are host-bound otherwise)")
+                    help="replay the step from a captured HIP graph (auto: on; the ~230 launches of a step are host-bound otherwise)")
+    ap.add_argument("--sliding-timeout", type=float, default=240.0,
+                    help="N > 1: seconds after which a hung sliding-window section is abandoned (the line is printed without it)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,13 +341,25 @@ def main():
     torch.manual_seed(0)
     model = ResUNet(image_shape=(a.patch,) * 3 + (1,), activation="elu", feature_maps=FM, drop_values=[0.0] * 5, normalization="in",
                     yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev)
+    V = a.vol if a.vol is not None else (1024 if world > 1 else 512)
     if a.mode == "sliding":
-        return bench_sliding(a, model, dev, rank, world)
-    train = a.mode == "train"
-    net = model
+        rec = run_sliding(a, model, dev, rank, world, V, a.warmup, a.steps)
+        if rank == 0:
+            rec.update(higher_is_better=True, vs_baseline=None, dtype=a.dtype, data="synthetic")
+            print(json.dumps(rec))
+        if multi:
+            dist.destroy_process_group()
+        return
+
     x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
-    if train:
+    from biapy_amd.losses import BCEWithLogitsLoss
+    loss_fn = BCEWithLogitsLoss()                                      # LOSS.TYPE="CE" -> BCEWithLogits (metrics.py:543-544), fused HIP passes
+    line = None
+
+    # ======================================================= train =======================================================
+    if a.mode in ("all", "train") or a.breakdown and a.mode != "infer":
         model.train()
+        net = model
         use_ddp = multi and (a.dp == "ddp" or a.graph == "off" or a.breakdown)
         if use_ddp:
             if a.graph != "off":
@@ -230,162 +378,189 @@ def main():
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=want_graph)
         except Exception:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=want_graph)
-    else:
-        model.eval()
-        want_graph = a.graph == "on" or (a.graph == "auto" and not a.breakdown)   # no collective inside an inference step
-    from biapy_amd.losses import BCEWithLogitsLoss
-    loss_fn = BCEWithLogitsLoss()                                      # LOSS.TYPE="CE" -> BCEWithLogits (metrics.py:543-544), fused HIP passes
 
-    def step():
-        if train:
+        def eager_step():
             opt.zero_grad(set_to_none=True)
             loss = loss_fn(net(x), tgt)
             loss.backward()
             opt.step()
             return loss
-        return model.predict_proba(x)
 
-    eager_step = step
-    graphed = False
-    if want_graph:
-        # HIP-graph capture of the whole step (forward, loss, backward, AdamW): one launch per step instead of ~170
-        # (biapy_amd/graphs.py).
-        try:
-            from biapy_amd.graphs import GraphedInference, GraphedTrainStep
-
-            if train and multi:
-                from biapy_amd.graphs import DataParallelTrainStep
-
-                gstep = DataParallelTrainStep(net, loss_fn, opt, x, tgt)
-            elif train:
-                gstep = GraphedTrainStep(net, loss_fn, opt, x, tgt)
-            else:
-                gstep = GraphedInference(model.predict_proba, x)
-
-            def step():  # noqa: F811
-                return gstep()
-
-            graphed = True
-        except Exception as e:  # capture is an optimisation, never a requirement
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            step = eager_step
-            torch.cuda.synchronize()
-            if train and multi:                                        # still exchange gradients: same three phases, eager
-                from biapy_amd.graphs import DataParallelTrainStep
-
-                estep = DataParallelTrainStep(net, loss_fn, opt, x, tgt, graph=False, broadcast_parameters=False)
-                step = lambda: estep()  # noqa: E731
-
-    for _ in range(a.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if train and not torch.isfinite(out.detach()).all():
-        raise SystemExit("non-finite loss in warm-up")
-
-    if a.breakdown:
-        prof = L.Profile()
-        L.lib.prof = prof
-        step()
-        torch.cuda.synchronize()
-        L.lib.prof = None
-        rows = sorted(prof.summary().items(), key=lambda kv: -kv[1][1])
-        tot = sum(v[1] for _, v in rows)
-        print(f"# per-call event timing of one {a.mode} step (B={a.batch}, {a.patch}^3, {a.dtype}); sum = {tot:.3f} ms")
-        for (name, key), (cnt, ms) in rows:
-            fl = conv_flops(name, key) * cnt
-            tf = f"{fl / (ms * 1e-3) / 1e12:8.1f} TF/s" if fl else " " * 13
-            print(f"{ms:9.3f} ms {100 * ms / tot:5.1f}% x{cnt:<3d} {tf} {name} {key}")
-        return
-
-    prof = L.Profile(names=("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad", "bpx_wgrad_defer_flush"))
-    if not graphed:
-        L.lib.prof = prof
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    L.lib.prof = None
-    prof_steps = a.steps
-    fb_graphs = train and getattr(model, "_graphs", None) is not None
-    if fb_graphs:
-        model.release_graphs()
-    if graphed or fb_graphs:
-        # a graph replay has no per-launch events: time the same launches on the same stream in eager steps right after
-        # the timed region (same kernels, same shapes; `value` above is NOT taken from these steps)
-        prof_steps = min(a.steps, 5)
-        L.lib.prof = prof
-        for _ in range(prof_steps):
-            eager_step()
-        torch.cuda.synchronize()
-        L.lib.prof = None
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-
-    vox_step = world * a.batch * a.patch ** 3
-    value = vox_step * a.steps / elapsed
-    if rank == 0:
-        # dominant kernel = the conv entry point with the largest summed event time inside the timed region
-        summ = prof.summary()
-        per = {}
-        for (name, key), (cnt, ms) in summ.items():
-            if name == "bpx_wgrad_defer_flush":      # the batched reduction of the step's partial slabs is part of the wgrad calls' time
-                per.setdefault("bpx_conv3d_wgrad", [0.0, 0.0, 0, 0.0])[1] += ms
-                continue
-            d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
-            d[0] += conv_flops(name, key) * cnt
-            d[1] += ms
-            d[2] += cnt
-            d[3] += conv_bytes(name, key, 2 if a.dtype == "bf16" else 4) * cnt
-        dom = max(per.items(), key=lambda kv: kv[1][1]) if per else None
-        roofline = None
-        if dom:
-            name, (fl, ms, cnt, by) = dom
-            peak = MFMA_PEAK_BF16 / 1e12 if a.dtype == "bf16" else 157.3
-            ach_f = fl / (ms * 1e-3) / 1e12                 # TFLOP/s
-            ach_b = by / (ms * 1e-3) / 1e9                  # GB/s of algorithmic bytes
-            # the binding roof is the one whose minimum time (work / peak) is larger for this kernel's launches
-            hbm_bound = by / HBM_PEAK > fl / (peak * 1e12)
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/pmc_traffic.py
+        step = eager_step
+        graphed = False
+        if want_graph:
+            # HIP-graph capture of the whole step (forward, loss, backward, AdamW): one launch per step instead of ~170
             try:
-                traffic = (json.load(open(tf)).get(name) or {}).get("total_bytes")
-            except (OSError, ValueError):
-                traffic = None
-            roofline = dict(bound="hbm" if hbm_bound else "mfma", kernel=name,
-                            achieved=round(ach_b if hbm_bound else ach_f, 2), peak=HBM_PEAK / 1e9 if hbm_bound else peak,
-                            unit="GB/s" if hbm_bound else "TFLOP/s",
-                            frac=round(ach_b / (HBM_PEAK / 1e9) if hbm_bound else ach_f / peak, 4),
-                            traffic=traffic, algorithmic_bytes_per_launch=round(by / cnt), flops_per_launch=round(fl / cnt),
-                            launches=cnt, avg_launch_ms=round(ms / cnt, 4), tflops=round(ach_f, 2), algorithmic_GBps=round(ach_b, 1),
-                            all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), GBps=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
-                                         ms_per_step=round(v[1] / prof_steps, 3)) for k, v in per.items()},
-                            timed_on="eager steps right after the timed region (the timed region replays HIP graphs)" if (graphed or fb_graphs) else "the timed region")
-        mult = 3 if train else 1
-        line = dict(
-            metric="voxels/sec 3D ResUNet 128^3 patch (%s)" % ("train: fwd+bwd+AdamW" if train else "inference forward"),
-            value=value, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
-            higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
-            config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, %s" % (a.patch, a.batch, a.mode),
-                        global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode=a.mode),
-            launch=("hip-graph replays (forward+loss+backward | optimizer) around one flat-gradient RCCL all-reduce" if multi else
-                    "hip-graph replay (whole step)") if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
-                                                                    if fb_graphs else "eager"),
-            mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * mult / (world * MFMA_PEAK_BF16), 5),
-            roofline=roofline,
-        )
+                from biapy_amd.graphs import DataParallelTrainStep, GraphedTrainStep
+
+                gstep = DataParallelTrainStep(net, loss_fn, opt, x, tgt) if multi else GraphedTrainStep(net, loss_fn, opt, x, tgt)
+                step = lambda: gstep()  # noqa: E731
+                graphed = True
+            except Exception as e:  # capture is an optimisation, never a requirement
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
+                if multi:                                              # still exchange gradients: same three phases, eager
+                    from biapy_amd.graphs import DataParallelTrainStep
+
+                    estep = DataParallelTrainStep(net, loss_fn, opt, x, tgt, graph=False, broadcast_parameters=False)
+                    step = lambda: estep()  # noqa: E731
+        for _ in range(a.warmup):
+            out = step()
+        torch.cuda.synchronize()
+        if a.warmup and not torch.isfinite(out.detach()).all():
+            raise SystemExit("non-finite loss in warm-up")
+
+        if a.breakdown:
+            return breakdown(a, L, step, "train")
+
+        prof = L.Profile(names=CONV_ENTRIES)
+        if not graphed:
+            L.lib.prof = prof
+        elapsed = _timed(step, a.steps, world, dev)
+        L.lib.prof = None
+        prof_steps = a.steps
+        fb_graphs = getattr(model, "_graphs", None) is not None
+        if fb_graphs:
+            model.release_graphs()
+        if graphed or fb_graphs:
+            # a graph replay has no per-launch events: time the same launches on the same stream in eager steps right after
+            # the timed region (same kernels, same shapes; `value` above is NOT taken from these steps)
+            prof_steps = min(a.steps, 5)
+            L.lib.prof = prof
+            for _ in range(prof_steps):
+                eager_step()
+            torch.cuda.synchronize()
+            L.lib.prof = None
+        value = world * a.batch * a.patch ** 3 * a.steps / elapsed
+        if rank == 0:
+            line = dict(
+                metric="voxels/sec 3D ResUNet 128^3 patch (train: fwd+bwd+AdamW; sub-records: infer, sliding)",
+                value=value, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+                config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, train" % (a.patch, a.batch),
+                            global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode="train"),
+                launch=("hip-graph replays (forward+loss+backward | optimizer) around one flat-gradient RCCL all-reduce" if multi else
+                        "hip-graph replay (whole step)") if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
+                                                                        if fb_graphs else "eager"),
+                mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * 3 / (world * MFMA_PEAK_BF16), 5),
+                roofline=conv_roofline(prof, prof_steps, a.dtype,
+                                       "eager steps right after the timed region (the timed region replays HIP graphs)" if (graphed or fb_graphs)
+                                       else "the timed region"),
+            )
+        del step, eager_step, opt
+        if graphed:
+            del gstep
+        net = None
+        for p in model.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    # ======================================================= infer =======================================================
+    infer_rec = None
+    if a.mode in ("all", "infer"):
+        model.eval()
+        want_graph = a.graph == "on" or (a.graph == "auto" and not a.breakdown)   # no collective inside an inference step
+        eager_inf = lambda: model.predict_proba(x)  # noqa: E731
+        step = eager_inf
+        graphed = False
+        if want_graph:
+            try:
+                from biapy_amd.graphs import GraphedInference
+
+                ginf = GraphedInference(model.predict_proba, x)
+                step = lambda: ginf()  # noqa: E731
+                graphed = True
+            except Exception as e:
+                print(f"[bench] inference graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if a.breakdown:
+            return breakdown(a, L, step, "infer")
+        prof = L.Profile(names=CONV_ENTRIES)
+        if not graphed:
+            L.lib.prof = prof
+        elapsed = _timed(step, a.steps, world, dev)
+        L.lib.prof = None
+        prof_steps = a.steps
+        if graphed:
+            prof_steps = min(a.steps, 5)
+            L.lib.prof = prof
+            for _ in range(prof_steps):
+                eager_inf()
+            torch.cuda.synchronize()
+            L.lib.prof = None
+        value = world * a.batch * a.patch ** 3 * a.steps / elapsed
+        if rank == 0:
+            infer_rec = dict(
+                metric="voxels/sec 3D ResUNet 128^3 patch (inference forward + fused sigmoid)", value=value, unit="voxels/s", n_gpus=world,
+                steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, scaling="weak",
+                config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, infer" % (a.patch, a.batch),
+                            global_batch=world * a.batch, patch=a.patch, parallelism="replicas x%d" % world, mode="infer"),
+                launch="hip-graph replay (weights packed inside the graph)" if graphed else "eager",
+                mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD / (world * MFMA_PEAK_BF16), 5),
+                roofline=conv_roofline(prof, prof_steps, a.dtype,
+                                       "eager forwards right after the timed region (the timed region replays a HIP graph)" if graphed else "the timed region"))
+        if graphed:
+            del ginf
+        del step
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if a.mode == "infer":
+            if rank == 0:
+                infer_rec.update(higher_is_better=True, vs_baseline=None, dtype=a.dtype, data="synthetic")
+                print(json.dumps(infer_rec))
+            if multi:
+                dist.destroy_process_group()
+            return
+
+    # ====================================================== sliding ======================================================
+    sliding_rec = None
+    if a.mode == "all":
+        # Never lose the train line to a hung exchange (the multi-GPU sliding path has not seen an 8-GPU node before the driver's
+        # scaling run): a watchdog prints the line without the sliding record and ends the process.
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(a.sliding_timeout):
+                if rank == 0 and line is not None:
+                    line["infer"] = infer_rec
+                    line["sliding"] = dict(error="timed out after %.0f s" % a.sliding_timeout)
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+        if world > 1:
+            threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            sliding_rec = run_sliding(a, model, dev, rank, world, V, 1, max(1, min(a.steps, 2)))
+        except Exception as e:  # the headline line must survive
+            sliding_rec = dict(error=f"{type(e).__name__}: {e}")
+        done.set()
+
+    if rank == 0 and line is not None:
+        line["infer"] = infer_rec
+        line["sliding"] = sliding_rec
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.patch, train)
+            line["cpu_baseline"] = cpu_baseline(a.patch, quick=a.quick_cpu_baseline)
         print(json.dumps(line))
     if multi:
         dist.destroy_process_group()
+
+
+def breakdown(a, L, step, mode):
+    prof = L.Profile()
+    L.lib.prof = prof
+    step()
+    torch.cuda.synchronize()
+    L.lib.prof = None
+    rows = sorted(prof.summary().items(), key=lambda kv: -kv[1][1])
+    tot = sum(v[1] for _, v in rows)
+    print(f"# per-call event timing of one {mode} step (B={a.batch}, {a.patch}^3, {a.dtype}); sum = {tot:.3f} ms")
+    for (name, key), (cnt, ms) in rows:
+        fl = conv_flops(name, key) * cnt
+        tf = f"{fl / (ms * 1e-3) / 1e12:8.1f} TF/s" if fl else " " * 13
+        print(f"{ms:9.3f} ms {100 * ms / tot:5.1f}% x{cnt:<3d} {tf} {name} {key}")
 
 
 if __name__ == "__main__":

@@ -39,6 +39,7 @@ _SIGS = {
     "bpx_debug_set_wgrad_tr": ([_i], _i),
     "bpx_debug_set_conv_ws": ([_i], _i),
     "bpx_debug_set_conv_stamps": ([_vp], _i),
+    "bpx_debug_set_tiling_scalar": ([_i], _i),
     "bpx_crop3d_gather": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _i64, _i64, _vp, _vp], _i),
     "bpx_merge3d_blend": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                            _vp, _vp, _i, _vp, _i, _vp], _i),
@@ -75,7 +76,7 @@ _SIGS = {
     "bpx_norm_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _f, _i, _vp, _i, _i, _vp], _i),
     "bpx_tensor_stats": ([_i, _i, _i64, Tensor, _vp, _vp], _i),
     "bpx_tensor_stats_tiles": ([_i64], _i),
-    "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "bpx_gather3d_tables": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp], _i),
     "bpx_scatter3d_tables": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "bpx_scatter3d_regions": ([_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp], _i),

@@ -58,55 +58,63 @@ static int compact_stats(float* part, int N, int tiles, int C, hipStream_t s) {
   return seg;
 }
 
-// part: [N][tiles][2][C].  One 256-thread block per (n, 16-channel group): thread = (tile lane, channel).
+// part: [N][tiles][2][C].  One 1024-thread block per (n, CB-channel block): thread = (tile lane, channel); CB = 16, or the
+// channels per group of a GroupNorm with wider groups (32 / 64), so that a group never straddles two blocks.
+__device__ __forceinline__ void tile_sums(const float* __restrict__ pp, int C, int nt, size_t ts, int tl, int lanes, double& s1, double& s2) {
+  // `lanes` tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  int t = tl;
+  for (; t + 3 * lanes < nt; t += 4 * lanes) {
+    a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
+    a1 = pp[(size_t)(t + lanes) * ts]; b1 = pp[(size_t)(t + lanes) * ts + C];
+    a2 = pp[(size_t)(t + 2 * lanes) * ts]; b2 = pp[(size_t)(t + 2 * lanes) * ts + C];
+    a3 = pp[(size_t)(t + 3 * lanes) * ts]; b3 = pp[(size_t)(t + 3 * lanes) * ts + C];
+    s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+  }
+  for (; t < nt; t += lanes) {
+    s1 += (double)pp[(size_t)t * ts];
+    s2 += (double)pp[(size_t)t * ts + C];
+  }
+}
+
+// block-wide reduction over the tile lanes: red[k][0 .. cb) holds the channel totals afterwards (all barriers are uniform)
+__device__ __forceinline__ void lane_reduce(double (*red)[1024], int cb, int lanes, double s1, double s2) {
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  const bool mine = (int)threadIdx.x < 2 * cb;
+  const int k = mine ? threadIdx.x / cb : 0, cc = mine ? threadIdx.x % cb : 0;
+  double s = 0.0;
+  if (mine)
+    for (int t = 0; t < lanes; ++t) s += red[k][t * cb + cc];
+  __syncthreads();                                        // every total is read before any is overwritten
+  if (mine) red[k][cc] = s;
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(1024) norm_finalize_kernel(const float* __restrict__ part, int tiles, int tstride, int C, double inv_count,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                            int cpg /* channels per group */, bpx_norm_rec* __restrict__ out,
+                                                            int cpg /* channels per group */, int cb, bpx_norm_rec* __restrict__ out,
                                                             int out_ld, int out_off) {
-  __shared__ double red[2][64][16];
-  const int n = blockIdx.y, c0 = blockIdx.x * 16;
-  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  __shared__ double red[2][1024];
+  const int lanes = 1024 / cb;
+  const int n = blockIdx.y, c0 = blockIdx.x * cb;
+  const int c = threadIdx.x % cb, tl = threadIdx.x / cb;
   double s1 = 0.0, s2 = 0.0;
-  if (c0 + c < C) {
-    const float* pp = part + (size_t)n * tiles * 2 * C + c0 + c;
-    const size_t ts = (size_t)tstride * 2 * C;   // distance between the tiles that hold sums
-    // 64 tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    const int nt = (tiles + tstride - 1) / tstride;
-    int t = tl;
-    for (; t + 192 < nt; t += 256) {
-      a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
-      a1 = pp[(size_t)(t + 64) * ts]; b1 = pp[(size_t)(t + 64) * ts + C];
-      a2 = pp[(size_t)(t + 128) * ts]; b2 = pp[(size_t)(t + 128) * ts + C];
-      a3 = pp[(size_t)(t + 192) * ts]; b3 = pp[(size_t)(t + 192) * ts + C];
-      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
-    }
-    for (; t < nt; t += 64) {
-      s1 += (double)pp[(size_t)t * ts];
-      s2 += (double)pp[(size_t)t * ts + C];
-    }
-  }
-  red[0][tl][c] = s1;
-  red[1][tl][c] = s2;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
-    double s = 0.0;
-    for (int t = 0; t < 64; ++t) s += red[k][t][cc];
-    red[k][0][cc] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 16 && c0 + threadIdx.x < C) {
+  if (c0 + c < C)
+    tile_sums(part + (size_t)n * tiles * 2 * C + c0 + c, C, (tiles + tstride - 1) / tstride, (size_t)tstride * 2 * C, tl, lanes, s1, s2);
+  lane_reduce(red, cb, lanes, s1, s2);
+  if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
     const int cc = threadIdx.x;
     double m, v;
     if (cpg == 1) {
-      m = red[0][0][cc] * inv_count;
-      v = red[1][0][cc] * inv_count - m * m;
-    } else {  // GroupNorm: cpg divides 16 or is a multiple of 16 handled by the host (cpg <= 16 here)
-      int gb = (cc / cpg) * cpg;
+      m = red[0][cc] * inv_count;
+      v = red[1][cc] * inv_count - m * m;
+    } else {  // GroupNorm: a group lies inside this block (cpg divides cb)
+      const int gb = (cc / cpg) * cpg;
       double a = 0.0, b = 0.0;
-      for (int q = 0; q < cpg; ++q) { a += red[0][0][gb + q]; b += red[1][0][gb + q]; }
+      for (int q = 0; q < cpg; ++q) { a += red[0][gb + q]; b += red[1][gb + q]; }
       m = a * inv_count / cpg;
       v = b * inv_count / cpg - m * m;
     }
@@ -135,62 +143,63 @@ __global__ void __launch_bounds__(64) tensor_stats_kernel(const T* __restrict__ 
   }
 }
 
-// InstanceNorm backward finalize.  red: [N][tiles][2][C] partials of S1 = sum g, S2 = sum g*xhat.
-//   dx = (gamma*rstd) * (g - S1/M - xhat*S2/M),  xhat = (t-mean)*rstd
-//      = a*g + b*t + c0 with a = gamma*rstd, b = -a*rstd*S2/M, c0 = -a*S1/M + a*mean*rstd*S2/M
-//   dgamma[c] += sum_n S2, dbeta[c] += sum_n S1
+// InstanceNorm / GroupNorm backward finalize.  red: [N][tiles][2][C] partials of S1 = sum_v g, S2 = sum_v g*xhat per channel
+// (g = dL/dy of the normalised tensor, xhat = (t - mean)*rstd with the GROUP's statistics).  With m1 = mean over the group of
+// gamma*g and m2 = mean over the group of gamma*g*xhat (group = Cg channels x M voxels; Cg = 1 is InstanceNorm):
+//   dx = rstd * (gamma*g - m1 - xhat*m2) = a*g + b*t + c0,  a = gamma*rstd, b = -rstd^2*m2, c0 = -rstd*m1 + rstd^2*mean*m2
+//   dgamma[c] += sum_n S2[n][c], dbeta[c] += sum_n S1[n][c]
+// One block per channel block walks the samples in order, so the two parameter gradients are sums in a FIXED order written by a
+// single thread: deterministic, no atomics.
 __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int tstride, int C,
                                                                 double inv_count, const bpx_norm_rec* __restrict__ rec,
                                                                 const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, bpx_nbwd_coef* __restrict__ coef) {
-  __shared__ double red[2][64][16];
-  const int n = blockIdx.y, c0 = blockIdx.x * 16;
-  const int c = threadIdx.x & 15, tl = threadIdx.x >> 4;
-  double s1 = 0.0, s2 = 0.0;
-  if (c0 + c < C) {
-    const float* pp = red_part + (size_t)n * tiles * 2 * C + c0 + c;
-    const size_t ts = (size_t)tstride * 2 * C;
-    // 64 tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    const int nt = (tiles + tstride - 1) / tstride;
-    int t = tl;
-    for (; t + 192 < nt; t += 256) {
-      a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
-      a1 = pp[(size_t)(t + 64) * ts]; b1 = pp[(size_t)(t + 64) * ts + C];
-      a2 = pp[(size_t)(t + 128) * ts]; b2 = pp[(size_t)(t + 128) * ts + C];
-      a3 = pp[(size_t)(t + 192) * ts]; b3 = pp[(size_t)(t + 192) * ts + C];
-      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+                                                                float* __restrict__ dbeta, int cpg, int cb, bpx_nbwd_coef* __restrict__ coef) {
+  __shared__ double red[2][1024];
+  const int lanes = 1024 / cb;
+  const int c0 = blockIdx.x * cb;
+  const int c = threadIdx.x % cb, tl = threadIdx.x / cb;
+  double dg = 0.0, db = 0.0;
+  for (int n = 0; n < N; ++n) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c0 + c < C)
+      tile_sums(red_part + (size_t)n * tiles * 2 * C + c0 + c, C, (tiles + tstride - 1) / tstride, (size_t)tstride * 2 * C, tl, lanes, s1, s2);
+    lane_reduce(red, cb, lanes, s1, s2);
+    if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
+      const int lc = threadIdx.x, cc = c0 + lc;
+      const double S1 = red[0][lc], S2 = red[1][lc];
+      const bpx_norm_rec r = rec[(size_t)n * C + cc];
+      const double ga = gamma ? (double)gamma[cc] : 1.0;
+      double m1, m2;
+      if (cpg == 1) {
+        m1 = ga * S1 * inv_count;
+        m2 = ga * S2 * inv_count;
+      } else {
+        const int gb = (lc / cpg) * cpg;
+        double a1 = 0.0, a2 = 0.0;
+        for (int q = 0; q < cpg; ++q) {
+          const double gq = gamma ? (double)gamma[c0 + gb + q] : 1.0;
+          a1 += gq * red[0][gb + q];
+          a2 += gq * red[1][gb + q];
+        }
+        m1 = a1 * inv_count / cpg;
+        m2 = a2 * inv_count / cpg;
+      }
+      const double rs = (double)r.rstd;
+      bpx_nbwd_coef k;
+      k.a = (float)(ga * rs);
+      k.b = (float)(-rs * rs * m2);
+      k.c0 = (float)(-rs * m1 + rs * rs * (double)r.mean * m2);
+      k.pad = 0.f;
+      coef[(size_t)n * C + cc] = k;
+      dg += (double)(float)S2;                          // the per-sample terms enter as floats, as they did with the former atomics
+      db += (double)(float)S1;
     }
-    for (; t < nt; t += 64) {
-      s1 += (double)pp[(size_t)t * ts];
-      s2 += (double)pp[(size_t)t * ts + C];
-    }
+    __syncthreads();                                    // red is rewritten by the next sample
   }
-  red[0][tl][c] = s1;
-  red[1][tl][c] = s2;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
-    double s = 0.0;
-    for (int t = 0; t < 64; ++t) s += red[k][t][cc];
-    red[k][0][cc] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 16 && c0 + threadIdx.x < C) {
+  if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
     const int cc = c0 + threadIdx.x;
-    double S1 = red[0][0][threadIdx.x], S2 = red[1][0][threadIdx.x];
-    bpx_norm_rec r = rec[(size_t)n * C + cc];
-    double ga = gamma ? (double)gamma[cc] : 1.0;
-    double a = ga * r.rstd;
-    bpx_nbwd_coef k;
-    k.a = (float)a;
-    k.b = (float)(-a * r.rstd * S2 * inv_count);
-    k.c0 = (float)(-a * S1 * inv_count + a * r.mean * r.rstd * S2 * inv_count);
-    k.pad = 0.f;
-    coef[(size_t)n * C + cc] = k;
-    if (dgamma) atomicAdd(dgamma + cc, (float)S2);
-    if (dbeta) atomicAdd(dbeta + cc, (float)S1);
+    if (dgamma) dgamma[cc] += (float)dg;
+    if (dbeta) dbeta[cc] += (float)db;
   }
 }
 
@@ -1090,11 +1099,12 @@ extern "C" int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, i
   BPX_CHECK(stats_part_d && out_d, "%s: null pointer", fn);
   BPX_CHECK(groups >= 1 && C % groups == 0, "%s: groups %d must divide C %d", fn, groups, C);
   int cpg = C / groups;
-  BPX_CHECK(cpg == 1 || (16 % cpg == 0), "%s: channels per group %d unsupported (must divide 16)", fn, cpg);
-  dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
+  BPX_CHECK(cpg == 1 || 16 % cpg == 0 || cpg == 32 || cpg == 64, "%s: channels per group %d unsupported (1, 2, 4, 8, 16, 32, 64)", fn, cpg);
+  const int cb = cpg > 16 ? cpg : 16;
+  dim3 grid((unsigned)cdiv(C, cb), (unsigned)N);
   const int tstride = compact_stats(stats_part_d, N, tiles, C, (hipStream_t)stream);   // consumes the partials
   norm_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(stats_part_d, tiles, tstride, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
-                                                              cpg, out_d, out_ld, out_off);
+                                                              cpg, cb, out_d, out_ld, out_off);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -1114,13 +1124,17 @@ extern "C" int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, 
 }
 
 extern "C" int bpx_norm_bwd_finalize(float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
-                                     const float* gamma_d, float* dgamma_d, float* dbeta_d, bpx_nbwd_coef* coef_d, bpx_stream_t stream) {
+                                     const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d,
+                                     bpx_stream_t stream) {
   const char* fn = "bpx_norm_bwd_finalize";
   BPX_CHECK(red_part_d && rec_d && coef_d, "%s: null pointer", fn);
-  dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
+  BPX_CHECK(groups >= 1 && C % groups == 0, "%s: groups %d must divide C %d", fn, groups, C);
+  const int cpg = C / groups;
+  BPX_CHECK(cpg == 1 || 16 % cpg == 0 || cpg == 32 || cpg == 64, "%s: channels per group %d unsupported (1, 2, 4, 8, 16, 32, 64)", fn, cpg);
+  const int cb = cpg > 16 ? cpg : 16;
   const int tstride = compact_stats(red_part_d, N, tiles, C, (hipStream_t)stream);     // consumes the partials
-  norm_bwd_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, tstride, C, 1.0 / (double)count_per_channel, rec_d, gamma_d,
-                                                                  dgamma_d, dbeta_d, coef_d);
+  norm_bwd_finalize_kernel<<<(unsigned)cdiv(C, cb), 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, tstride, C, 1.0 / (double)count_per_channel,
+                                                                                   rec_d, gamma_d, dgamma_d, dbeta_d, cpg, cb, coef_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -18,6 +18,10 @@ struct AxisG {
 };
 static inline AxisG to_axis(const bpx_axis_grid& g) { return AxisG{g.n, g.step, g.last, g.patch, g.limit}; }
 
+// test / A-B hook: 1 = force the element-per-thread kernels of round 1 (bpx_debug_set_tiling_scalar)
+static int g_tiling_scalar = 0;
+extern "C" int bpx_debug_set_tiling_scalar(int on) { g_tiling_scalar = on; return 0; }
+
 // ------------------------------------------------------------------------------------------------
 // crop
 // ------------------------------------------------------------------------------------------------
@@ -54,6 +58,64 @@ __global__ void __launch_bounds__(256) crop3d_kernel(const E* __restrict__ vol, 
   }
 }
 
+
+// Vectorised form (the production path): one thread moves 16 bytes of one patch row.  An output row (Px*C elements) is a shifted
+// copy of a run of the source row in the flattened (x, c) index, so whenever the 16 bytes lie inside the volume they are ONE
+// (possibly misaligned) 16-byte load; only vectors that touch the padded border go element by element.  The z / y source rows,
+// the patch index decomposition and the pad rule are evaluated once per 16 bytes instead of once per element, with 32-bit math.
+template <int ES> struct CropElem;
+template <> struct CropElem<1> { typedef uint8_t type; };
+template <> struct CropElem<2> { typedef uint16_t type; };
+template <> struct CropElem<4> { typedef uint32_t type; };
+
+template <int ES>
+__global__ void __launch_bounds__(256) crop3d_row_kernel(const unsigned char* __restrict__ vol, unsigned char* __restrict__ out, int Z, int Y,
+                                                         int X, int C, int pz, int py, int px, int mode, AxisG gz, AxisG gy, AxisG gx,
+                                                         int64_t c_begin, int64_t total_vec, int qpr) {
+  typedef typename CropElem<ES>::type E;
+  constexpr int VEC = 16 / ES;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total_vec) return;
+  const int64_t rowid = t / qpr;
+  const int q = (int)(t - rowid * qpr);
+  const int Pz = gz.patch, Py = gy.patch;
+  const int64_t r1 = rowid / Py;
+  const int ly = (int)(rowid - r1 * Py);
+  const int64_t r2 = r1 / Pz;
+  const int lz = (int)(r1 - r2 * Pz);
+  const int64_t c = c_begin + r2;
+  const int64_t c1 = c / gx.n;
+  const int ix = (int)(c - c1 * gx.n);
+  const int iz = (int)(c1 / gy.n);
+  const int iy = (int)(c1 - (int64_t)iz * gy.n);
+  bool inside = true;
+  const int sz = pad_src(gz.start(iz) + lz - pz, Z, mode, inside);
+  const int sy = pad_src(gy.start(iy) + ly - py, Y, mode, inside);
+  const int e0 = q * VEC;
+  const int x0 = e0 / C, ch0 = e0 - x0 * C;
+  const int xs = gx.start(ix) - px;                                // source x of patch column 0
+  const int xl = x0 + (ch0 + VEC - 1) / C;                         // patch column of the vector's last element
+  const unsigned char* srow = vol + ((size_t)sz * Y + sy) * (size_t)X * C * ES;
+  u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+  if (inside) {
+    if (xs + x0 >= 0 && xs + xl < X) {
+      __builtin_memcpy(&v, srow + ((size_t)(xs + x0) * C + ch0) * ES, 16);   // misaligned 16-byte load
+    } else {
+      E tmp[VEC];
+      int x = x0, ch = ch0;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        bool in2 = true;
+        const int sx = pad_src(xs + x, X, mode, in2);
+        tmp[k] = in2 ? reinterpret_cast<const E*>(srow)[(size_t)sx * C + ch] : (E)0;
+        if (++ch == C) { ch = 0; ++x; }
+      }
+      __builtin_memcpy(&v, tmp, 16);
+    }
+  }
+  *reinterpret_cast<u32x4_t*>(out + (size_t)t * 16) = v;
+}
+
 extern "C" int bpx_crop3d_gather(const void* vol_d, int elem_size, int Z, int Y, int X, int C, int pad_z, int pad_y, int pad_x,
                                  int pad_mode, const bpx_axis_grid* g, int64_t c_begin, int64_t c_count, void* out_d,
                                  bpx_stream_t stream) {
@@ -65,9 +127,23 @@ extern "C" int bpx_crop3d_gather(const void* vol_d, int elem_size, int Z, int Y,
   BPX_CHECK(c_begin >= 0 && c_count >= 0 && c_begin + c_count <= n_all, "bpx_crop3d_gather: patch range out of grid");
   int64_t total = c_count * g[0].patch * g[1].patch * g[2].patch * C;
   if (total == 0) return 0;
-  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   hipStream_t s = (hipStream_t)stream;
   AxisG gz = to_axis(g[0]), gy = to_axis(g[1]), gx = to_axis(g[2]);
+  const int64_t row_bytes = (int64_t)g[2].patch * C * elem_size;
+  if (row_bytes % 16 == 0 && ((uintptr_t)out_d & 15) == 0 && !g_tiling_scalar) {
+    const int64_t total_vec = total * elem_size / 16;
+    const int qpr = (int)(row_bytes / 16);
+    const int64_t nb = cdiv64(total_vec, 256);
+    BPX_CHECK(nb < (1ll << 31), "bpx_crop3d_gather: too many patches for one launch");
+    const unsigned char* v8 = (const unsigned char*)vol_d;
+    unsigned char* o8 = (unsigned char*)out_d;
+    if (elem_size == 4) crop3d_row_kernel<4><<<(unsigned)nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total_vec, qpr);
+    else if (elem_size == 2) crop3d_row_kernel<2><<<(unsigned)nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total_vec, qpr);
+    else crop3d_row_kernel<1><<<(unsigned)nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total_vec, qpr);
+    BPX_LAUNCH_CHECK("bpx_crop3d_gather");
+    return 0;
+  }
+  int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   if (elem_size == 4)
     crop3d_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)vol_d, (uint32_t*)out_d, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total);
   else if (elem_size == 2)
@@ -257,6 +333,122 @@ __global__ void __launch_bounds__(256) merge3d_kernel(const EI* __restrict__ pat
   }
 }
 
+
+// Vectorised form (the production path).  A thread owns VEC consecutive elements of one output row in the flattened (x, c)
+// index.  For a covering patch the same VEC elements are consecutive in the patch row as well (the patch row is the output
+// row shifted by start(ix)), so a vector whose first and last element lie inside the patch is ONE (possibly misaligned) wide
+// load; vectors straddling a patch edge go element by element.  The patch cover of the row (z and y ranges, the row weight
+// fl(wz*wy), the row base pointers) is evaluated once per vector, not per element; indices inside a patch are 32-bit.  The
+// accumulation order per element - patches in z-major order, num = fl(num + fl(v*w)), ws = fl(ws + w) - is the reference's.
+constexpr int MERGE_WXMAX = 2048;
+template <typename E> struct MergeVec;
+template <> struct MergeVec<float> { static constexpr int VEC = 4; };
+template <> struct MergeVec<__half> { static constexpr int VEC = 8; };
+template <> struct MergeVec<uint8_t> { static constexpr int VEC = 8; };
+
+template <typename EI, typename EO>
+__global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__ patches, int Pzf, int Pyf, int Pxf, int C, int pz, int py,
+                                                          int px, AxisG gz, AxisG gy, AxisG gx, const float* __restrict__ wz,
+                                                          const float* __restrict__ wy, const float* __restrict__ wx, int Y, int X,
+                                                          int z_lo, int zrow_lo, int zrow_hi, float* acc, float* wacc, int flags,
+                                                          EO* __restrict__ out, int64_t total_vec, int qpr) {
+  constexpr int VEC = MergeVec<EI>::VEC;
+  __shared__ float swx[MERGE_WXMAX];                              // the x taper (the launcher checks gx.patch <= MERGE_WXMAX)
+  for (int i = threadIdx.x; i < gx.patch; i += 256) swx[i] = wx[i];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total_vec) return;
+  const int64_t row = t / qpr;                                    // (z - z_lo) * Y + y
+  const int q = (int)(t - row * qpr);
+  const int zr = (int)(row / Y);
+  const int y = (int)(row - (int64_t)zr * Y);
+  const int z = zr + z_lo;
+  const int e0 = q * VEC;
+  const int x0 = e0 / C, ch0 = e0 - x0 * C;
+  int xk[VEC];
+  {
+    int x = x0, ch = ch0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      xk[k] = x;
+      if (++ch == C) { ch = 0; ++x; }
+    }
+  }
+  const int64_t i0 = row * (int64_t)X * C + e0;                   // flat index of element 0 in the [z_hi-z_lo][Y][X][C] arrays
+  const int64_t v0 = row * (int64_t)X;                            // voxel index of x = 0 of this row
+  float num[VEC], ws[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) { num[k] = 0.f; ws[k] = 0.f; }
+  if (flags & 2) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { num[k] = acc[i0 + k]; ws[k] = wacc[v0 + xk[k]]; }
+  }
+  int zl, zh, yl, yh, xl, xh, dummy;
+  cover_range(gz, z, zl, zh);
+  cover_range(gy, y, yl, yh);
+  cover_range(gx, xk[0], xl, dummy);
+  cover_range(gx, xk[VEC - 1], dummy, xh);
+  if (zl < zrow_lo) zl = zrow_lo;
+  if (zh > zrow_hi - 1) zh = zrow_hi - 1;
+  const int pstride_y = Pxf * C, pstride_z = pstride_y * Pyf;
+  const int64_t pstride_c = (int64_t)pstride_z * Pzf;
+  for (int iz = zl; iz <= zh; ++iz) {
+    const int lz = z - gz.start(iz);
+    if (lz < 0 || lz >= gz.patch) continue;
+    const float wzv = wz[lz];
+    for (int iy = yl; iy <= yh; ++iy) {
+      const int ly = y - gy.start(iy);
+      if (ly < 0 || ly >= gy.patch) continue;
+      const float wzy = __fmul_rn(wzv, wy[ly]);
+      const EI* prow = patches + ((int64_t)(iz - zrow_lo) * gy.n + iy) * gx.n * pstride_c + ((lz + pz) * pstride_z + (ly + py) * pstride_y);
+      for (int ix = xl; ix <= xh; ++ix) {
+        const int sx = gx.start(ix);
+        const int l0 = xk[0] - sx, l1 = xk[VEC - 1] - sx;
+        if (l1 < 0 || l0 >= gx.patch) continue;
+        const EI* pp = prow + (int64_t)ix * pstride_c + ((px - sx) * C + e0);   // element k of the vector is pp[k] when it is inside
+        if (l0 >= 0 && l1 < gx.patch) {
+          EI v[VEC];
+          __builtin_memcpy(v, pp, sizeof(v));                       // one wide (possibly misaligned) load
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const int lx = xk[k] - sx;
+            const float w = __fmul_rn(wzy, swx[lx]);
+            num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(&v[k]), w));
+            ws[k] = __fadd_rn(ws[k], w);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const int lx = xk[k] - sx;
+            if (lx >= 0 && lx < gx.patch) {
+              const float w = __fmul_rn(wzy, swx[lx]);
+              num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(pp + k), w));
+              ws[k] = __fadd_rn(ws[k], w);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (flags & 1) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[i0 + k] = num[k];
+    {
+      int x = x0, ch = ch0;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (ch == 0) wacc[v0 + x] = ws[k];
+        if (++ch == C) { ch = 0; ++x; }
+      }
+    }
+  } else {
+    EO o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) store_from_f32<EO>(&o[k], __fdiv_rn(num[k], __fadd_rn(ws[k], 1e-18f)));
+    __builtin_memcpy(__builtin_assume_aligned(out + i0, sizeof(EO) * VEC >= 16 ? 16 : sizeof(EO) * VEC), o, sizeof(o));
+  }
+}
+
 extern "C" int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int Py, int Px, int C, int pad_z, int pad_y, int pad_x,
                                  const bpx_axis_grid* g, const float* wz_d, const float* wy_d, const float* wx_d, int Z, int Y, int X,
                                  int z_lo, int z_hi, int zrow_lo, int zrow_hi, float* acc_d, float* wacc_d, int flags,
@@ -274,6 +466,35 @@ extern "C" int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int P
   int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   hipStream_t s = (hipStream_t)stream;
   AxisG gz = to_axis(g[0]), gy = to_axis(g[1]), gx = to_axis(g[2]);
+  {
+    // vector path: rows of whole vectors, 16-byte aligned output, patch strides that fit 32 bits
+    const int vec = dtype == BPX_F32 ? 4 : 8;
+    const size_t oes = dtype_size(out_dtype);
+    const bool row_ok = ((int64_t)X * C) % vec == 0 && (int64_t)Px * Py * Pz * C < (1ll << 31) && g[2].patch <= MERGE_WXMAX;
+    const bool al_ok = (flags & 1) ? (((uintptr_t)acc_d & 15) == 0) : (((uintptr_t)out_d & 15) == 0);
+    if (row_ok && al_ok && !g_tiling_scalar) {
+      const int qpr = (int)(((int64_t)X * C) / vec);
+      const int64_t total_vec = total / vec;
+      const int64_t nb = cdiv64(total_vec, 256);
+      BPX_CHECK(nb < (1ll << 31), "bpx_merge3d_blend: volume too large for one launch");
+      (void)oes;
+#define MERGE_ROW(EI, EO)                                                                                                              \
+  merge3d_row_kernel<EI, EO><<<(unsigned)nb, 256, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, \
+                                                          wx_d, Y, X, z_lo, zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d, total_vec, qpr)
+      bool done = true;
+      if (dtype == BPX_F32 && out_dtype == BPX_F32) MERGE_ROW(float, float);
+      else if (dtype == BPX_U8 && out_dtype == BPX_U8) MERGE_ROW(uint8_t, uint8_t);
+      else if (dtype == BPX_F16 && out_dtype == BPX_F16) MERGE_ROW(__half, __half);
+      else if (dtype == BPX_F16 && out_dtype == BPX_F32) MERGE_ROW(__half, float);
+      else if (dtype == BPX_U8 && out_dtype == BPX_F32) MERGE_ROW(uint8_t, float);
+      else done = false;
+#undef MERGE_ROW
+      if (done) {
+        BPX_LAUNCH_CHECK("bpx_merge3d_blend");
+        return 0;
+      }
+    }
+  }
 #define MERGE_LAUNCH(EI, EO)                                                                                                   \
   merge3d_kernel<EI, EO><<<blocks, 256, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, \
                                                 wx_d, Y, X, z_lo, z_hi, zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d)

@@ -510,7 +510,7 @@ class ResUNetEngine:
                                      L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
-                                          G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), coef.data_ptr(), st))
+                                          G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), C1, coef.data_ptr(), st))
         L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g1), L.tview(blk.h), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         dH = L.tview(g1)
         # conv1
@@ -535,7 +535,7 @@ class ResUNetEngine:
                                          red0.data_ptr(), st))
             coef0 = torch.empty((B, Cx, 4), dtype=torch.float32, device=dev)
             L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
-                                              G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), coef0.data_ptr(), st))
+                                              G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), Cx, coef0.data_ptr(), st))
             if isinstance(dx_out, tuple):   # decoder block: the gradient of the concatenated input leaves as its (up, skip) parts
                 assert dx_extra is None
                 L.check(lib.bpx_conv1x1_fwd_split(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),

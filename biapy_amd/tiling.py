@@ -21,7 +21,7 @@ from . import _lib as L
 
 __all__ = [
     "PatchCoords", "crop_3D_data_with_overlap", "merge_3D_data_with_overlap", "axis_grid", "crop_grid", "merge_grid",
-    "taper_1d", "crop_device", "merge_device",
+    "taper_1d", "crop_device", "crop_rows_needed", "merge_device",
 ]
 
 
@@ -101,11 +101,32 @@ def _device() -> torch.device:
 # ---------------------------------------------------------------------------------------------------
 # device-level API
 # ---------------------------------------------------------------------------------------------------
+def crop_rows_needed(vol_zyx, patch_zyx, overlap, padding, zrow_lo: int, zrow_hi: int, reflect: bool = True):
+    """Input slices [z_lo, z_hi) of the UN-padded volume that the patches of z-rows [zrow_lo, zrow_hi) read, including the
+    sources of the reflect padding at the two ends of the volume (np.pad "reflect", data_3D_manipulation.py:505-515)."""
+    Z, pz, Pz = int(vol_zyx[0]), int(padding[0]), int(patch_zyx[0])
+    g = axis_grid(Z, Pz, pz, overlap[0], False)
+    a = _start(g, zrow_lo) - pz
+    b = _start(g, zrow_hi - 1) - pz + Pz
+    lo, hi = max(a, 0), min(b, Z)
+    if reflect and a < 0:
+        hi = max(hi, min(Z, -a + 1))
+    if reflect and b > Z:
+        lo = min(lo, max(0, 2 * (Z - 1) - (b - 1)))
+    return lo, hi
+
+
 def crop_device(vol: torch.Tensor, patch_zyx: Sequence[int], overlap=(0, 0, 0), padding=(0, 0, 0), pad_type: str = "reflect",
-                c_begin: int = 0, c_count: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """vol: (Z,Y,X,C) device tensor (1/2/4-byte dtype) -> (n,Pz,Py,Px,C) patches [c_begin, c_begin+c_count)."""
+                c_begin: int = 0, c_count: Optional[int] = None, out: Optional[torch.Tensor] = None, z_offset: int = 0,
+                full_z: Optional[int] = None) -> torch.Tensor:
+    """vol: (Z,Y,X,C) device tensor (1/2/4-byte dtype) -> (n,Pz,Py,Px,C) patches [c_begin, c_begin+c_count).
+
+    Slab form (sharded sliding window: a rank holds only the input slices its patches read): ``vol`` holds the slices
+    [z_offset, z_offset + vol.shape[0]) of a volume with ``full_z`` slices; the patch grid is that of the full volume and the
+    requested patches must only read slices of the slab (``crop_rows_needed``) - checked here, not in the kernel."""
     assert vol.is_cuda and vol.dim() == 4 and vol.is_contiguous()
-    Z, Y, X, Cc = vol.shape
+    Zs, Y, X, Cc = vol.shape
+    Z = Zs if full_z is None else int(full_z)
     g = crop_grid((Z, Y, X), patch_zyx, overlap, padding)
     n_all = g[0].n * g[1].n * g[2].n
     if c_count is None:
@@ -115,7 +136,17 @@ def crop_device(vol: torch.Tensor, patch_zyx: Sequence[int], overlap=(0, 0, 0), 
     mode = 1 if pad_type == "zeros" else 0
     if pad_type not in ("reflect", "zeros"):
         raise ValueError(f"pad_type {pad_type!r} is not supported on the device path (reflect|zeros)")
-    L.check(L.lib.bpx_crop3d_gather(vol.data_ptr(), vol.element_size(), Z, Y, X, Cc, padding[0], padding[1], padding[2], mode, g,
+    base = vol.data_ptr()
+    if z_offset or Z != Zs:
+        if c_count > 0:
+            per_row = g[1].n * g[2].n
+            lo, hi = crop_rows_needed((Z, Y, X), patch_zyx, overlap, padding, c_begin // per_row, (c_begin + c_count - 1) // per_row + 1,
+                                      reflect=(mode == 0))
+            if lo < z_offset or hi > z_offset + Zs:
+                raise ValueError(f"patches [{c_begin}, {c_begin + c_count}) read slices [{lo}, {hi}) but the slab holds "
+                                 f"[{z_offset}, {z_offset + Zs})")
+        base -= z_offset * Y * X * Cc * vol.element_size()             # virtual origin of the full volume: only slab rows are dereferenced
+    L.check(L.lib.bpx_crop3d_gather(base, vol.element_size(), Z, Y, X, Cc, padding[0], padding[1], padding[2], mode, g,
                                     c_begin, c_count, out.data_ptr(), L.stream_ptr()))
     return out
 

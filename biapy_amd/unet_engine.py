@@ -176,7 +176,7 @@ class UNetEngine(ResUNetEngine):
         g = torch.empty(raw.shape, dtype=self.dtype, device=dev)
         L.check(lib.bpx_norm_act_bwd(self.dt, B, vox, dA, L.tview(raw), rec.data_ptr(), self.act, L.NULL_T, L.tview(g), red.data_ptr(), st))
         coef = torch.empty((B, C, 4), dtype=torch.float32, device=dev)
-        L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C, vox, rec.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+        L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C, vox, rec.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C,
                                           coef.data_ptr(), st))
         L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g), L.tview(raw), coef.data_ptr(), L.NULL_T, L.tview(g), st))
         return g
@@ -200,7 +200,7 @@ class UNetEngine(ResUNetEngine):
                                      L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, cb.rec[0].data_ptr(), Pw[k(0, "1.weight")].data_ptr(),
-                                          G[k(0, "1.weight")].data_ptr(), G[k(0, "1.bias")].data_ptr(), coef.data_ptr(), st))
+                                          G[k(0, "1.weight")].data_ptr(), G[k(0, "1.bias")].data_ptr(), C1, coef.data_ptr(), st))
         L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g1), L.tview(cb.h[0]), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         # conv 1
         if img is not None:

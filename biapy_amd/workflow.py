@@ -86,9 +86,26 @@ class DeviceBlend:
     def __init__(self, plan: tiling.MergePlan):
         self.plan = plan
 
-    def blend(self, patches, z_lo, z_hi, rows, acc=None, wacc=None, seed=False, write_partial=False, out_dtype=None):
+    def blend(self, patches, z_lo, z_hi, rows, acc=None, wacc=None, seed=False, write_partial=False, out_dtype=None, out=None):
         return tiling.merge_device(patches, self.plan, out_dtype=out_dtype, z_lo=z_lo, z_hi=z_hi, zrow_lo=rows[0], zrow_hi=rows[1],
-                                   acc=acc, wacc=wacc, seed=seed, write_partial=write_partial)
+                                   acc=acc, wacc=wacc, seed=seed, write_partial=write_partial, out=out)
+
+
+def _peer(group, r: int) -> int:
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def _exchange(ops):
+    """One grouped launch of the given point-to-point operations (RCCL runs the sends and receives of a group concurrently, so
+    a rank's send never queues behind its own receive); returns the requests."""
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def _partial(n_slices: int, Y: int, X: int, C: int, dev, zero: bool):
+    """Numerator and weight-sum partials of ``n_slices`` output slices in ONE buffer (one message per boundary)."""
+    nvox = n_slices * Y * X
+    buf = (torch.zeros if zero else torch.empty)(nvox * (C + 1), dtype=torch.float32, device=dev)
+    return buf, buf[: nvox * C].view(n_slices, Y, X, C), buf[nvox * C:].view(n_slices, Y, X, 1)
 
 
 def sharded_blend(backend, patches: torch.Tensor, plans: List[SlabPlan], rank: int, world: int, Y: int, X: int, C: int,
@@ -97,66 +114,80 @@ def sharded_blend(backend, patches: torch.Tensor, plans: List[SlabPlan], rank: i
 
     ``patches`` holds the predictions of the rank's patch rows only.  Returns the full volume (Z,Y,X,C) on every
     rank (gather="all"), on rank 0 only ("rank0"), or just the rank's own slab ("none").
+
+    Order of work on a rank (the first three steps do not wait for anybody):
+      1. the partial sums of the slices handed to the next rank - at cfg 3 they never depend on what the previous rank
+         sends (68 received slices end before the 68 sent ones begin), so all boundaries of the node travel at once instead of
+         as a chain through the ranks;
+      2. ONE grouped send + receive (numerator and weight sums share a buffer: one message per boundary);
+      3. the part of the own slab no neighbour contributes to, blended while the exchange is in flight;
+      4. the seeded part, after the receive.
+    The own slab is blended straight into its place in the result volume where the rank holds one (no staging copy); the
+    slabs are disjoint Z-ranges of a (Z,Y,X,C) array, i.e. contiguous, so the final gather receives / broadcasts directly into
+    views of that volume - exact sizes, no padding to the largest slab, no concatenation.
     """
     me = plans[rank]
     dev = patches.device
     Z = max(p.own[1] for p in plans)
+    active = me.rows[1] > me.rows[0]
+    z0, z1 = me.own
+    holds_full = world > 1 and (gather == "all" or (gather == "rank0" and rank == 0))
+    full = torch.empty((Z, Y, X, C), dtype=torch.float32, device=dev) if holds_full else None
     slab = None
-    if me.rows[1] > me.rows[0]:
-        z0, z1 = me.own
-        pieces = []
+    if active:
+        slab = full[z0:z1] if holds_full else torch.empty((z1 - z0, Y, X, C), dtype=torch.float32, device=dev)
+        buf_in = acc = wacc = buf_out = sacc = swacc = None
         seed_hi = z0
         if me.recv is not None:
-            r0, r1 = me.recv
-            acc = torch.empty((r1 - r0, Y, X, C), dtype=torch.float32, device=dev)
-            wacc = torch.empty((r1 - r0, Y, X, 1), dtype=torch.float32, device=dev)
-            if world > 1:
-                dist.recv(acc, src=me.prev, group=group)
-                dist.recv(wacc, src=me.prev, group=group)
-            seed_hi = r1
+            buf_in, acc, wacc = _partial(me.recv[1] - me.recv[0], Y, X, C, dev, zero=False)
+            seed_hi = me.recv[1]
         if me.send is not None:
+            buf_out, sacc, swacc = _partial(me.send[1] - me.send[0], Y, X, C, dev, zero=True)
+        dependent = me.recv is not None and me.send is not None and seed_hi > me.send[0]   # > 50 % overlap with one row per rank
+        reqs = []
+        if dependent:
+            for r in _exchange([dist.P2POp(dist.irecv, buf_in, _peer(group, me.prev), group)] if world > 1 else []):
+                r.wait()
             s0, s1 = me.send
-            sacc = torch.zeros((s1 - s0, Y, X, C), dtype=torch.float32, device=dev)
-            swacc = torch.zeros((s1 - s0, Y, X, 1), dtype=torch.float32, device=dev)
-            if me.recv is not None and seed_hi > s0:       # a previous rank's terms reach into what we hand over
-                k = seed_hi - s0
-                sacc[:k] = acc[s0 - me.recv[0]:seed_hi - me.recv[0]]
-                swacc[:k] = wacc[s0 - me.recv[0]:seed_hi - me.recv[0]]
-                backend.blend(patches, s0, seed_hi, me.rows, acc=sacc[:k], wacc=swacc[:k], seed=True, write_partial=True)
-                if s1 > seed_hi:
-                    backend.blend(patches, seed_hi, s1, me.rows, acc=sacc[k:], wacc=swacc[k:], write_partial=True)
-            else:
-                backend.blend(patches, s0, s1, me.rows, acc=sacc, wacc=swacc, write_partial=True)
+            k = seed_hi - s0                                  # a previous rank's terms reach into what we hand over
+            sacc[:k] = acc[s0 - me.recv[0]:seed_hi - me.recv[0]]
+            swacc[:k] = wacc[s0 - me.recv[0]:seed_hi - me.recv[0]]
+            backend.blend(patches, s0, seed_hi, me.rows, acc=sacc[:k], wacc=swacc[:k], seed=True, write_partial=True)
+            if s1 > seed_hi:
+                backend.blend(patches, seed_hi, s1, me.rows, acc=sacc[k:], wacc=swacc[k:], write_partial=True)
             if world > 1:
-                dist.send(sacc, dst=me.next, group=group)
-                dist.send(swacc, dst=me.next, group=group)
-        # own slab: seeded part first, then the rest
-        if me.recv is not None:
-            e = min(seed_hi, z1)
-            if e > z0:
-                pieces.append(backend.blend(patches, z0, e, me.rows, acc=acc[: e - z0], wacc=wacc[: e - z0], seed=True))
-            if z1 > e:
-                pieces.append(backend.blend(patches, e, z1, me.rows))
+                reqs = _exchange([dist.P2POp(dist.isend, buf_out, _peer(group, me.next), group)])
         else:
-            pieces.append(backend.blend(patches, z0, z1, me.rows))
-        slab = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0)
+            ops = []
+            if me.send is not None:
+                backend.blend(patches, me.send[0], me.send[1], me.rows, acc=sacc, wacc=swacc, write_partial=True)
+                ops.append(dist.P2POp(dist.isend, buf_out, _peer(group, me.next), group))
+            if me.recv is not None:
+                ops.append(dist.P2POp(dist.irecv, buf_in, _peer(group, me.prev), group))
+            if world > 1:
+                reqs = _exchange(ops)
+        e = min(max(seed_hi, z0), z1)                         # [z0, e) is seeded by the previous rank, [e, z1) is ours alone
+        if z1 > e:
+            backend.blend(patches, e, z1, me.rows, out=slab[e - z0:])
+        for r in reqs:
+            r.wait()
+        if e > z0:
+            backend.blend(patches, z0, e, me.rows, acc=acc[: e - z0], wacc=wacc[: e - z0], seed=True, out=slab[: e - z0])
     if gather == "none" or world == 1:
         return slab
-    # the slabs are disjoint and ordered: exchange them padded to the largest one
-    sizes = [p.own[1] - p.own[0] for p in plans]
-    mx = max(sizes)
-    buf = torch.zeros((mx, Y, X, C), dtype=slab.dtype if slab is not None else torch.float32, device=dev)
-    if slab is not None:
-        buf[: slab.shape[0]] = slab
+    owners = [(r, p.own) for r, p in enumerate(plans) if p.rows[1] > p.rows[0] and p.own[1] > p.own[0]]
     if gather == "all":
-        outs = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(outs, buf, group=group)
+        reqs = [dist.broadcast(full[o[0]:o[1]], src=_peer(group, r), group=group, async_op=True) for r, o in owners]
+        for r in reqs:
+            r.wait()
+        return full
+    if rank == 0:
+        ops = [dist.P2POp(dist.irecv, full[o[0]:o[1]], _peer(group, r), group) for r, o in owners if r != 0]
     else:
-        outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, outs, dst=0, group=group)
-        if rank != 0:
-            return None
-    return torch.cat([o[:s] for o, s in zip(outs, sizes) if s > 0], 0)[:Z]
+        ops = [dist.P2POp(dist.isend, slab, _peer(group, 0), group)] if slab is not None and slab.numel() else []
+    for r in _exchange(ops):
+        r.wait()
+    return full
 
 
 class SlidingWindowPredictor:
@@ -174,11 +205,26 @@ class SlidingWindowPredictor:
         # forward: (B,C,Z,Y,X) fp32 -> (B,Cout,Z,Y,X) fp32 probabilities (ce_sigmoid head)
         self.forward = forward or (lambda x: model.predict_proba(x))
 
+    def input_slab(self, vol_zyx: Sequence[int], rank: int, world: int):
+        """Input slices [z_lo, z_hi) of a (Z,Y,X) volume that ``rank`` of ``world`` reads: the extent of its patch rows plus the
+        reflect-padding sources at the volume ends ("each GPU reads only its input slab (+halo)").  Ranks without
+        patch rows get (0, 0)."""
+        Z, Y, X = (int(v) for v in vol_zyx)
+        g = tiling.merge_grid((Z, Y, X), self.patch, self.overlap, self.padding)
+        lo, hi = split_rows(g[0].n, world)[rank]
+        if hi <= lo:
+            return 0, 0
+        return tiling.crop_rows_needed((Z, Y, X), self.patch, self.overlap, self.padding, lo, hi, reflect=self.pad_type != "zeros")
+
     @torch.no_grad()
-    def predict(self, vol: torch.Tensor, rank: int = 0, world: int = 1, gather: str = "all", group=None) -> Optional[torch.Tensor]:
-        """vol: (Z,Y,X,C) float32 on this rank's device.  Returns the blended probability volume (Z,Y,X,Cout)."""
+    def predict(self, vol: torch.Tensor, rank: int = 0, world: int = 1, gather: str = "all", group=None, z_offset: int = 0,
+                full_z: Optional[int] = None) -> Optional[torch.Tensor]:
+        """vol: (Z,Y,X,C) float32 on this rank's device - the whole volume, or (``full_z`` given) only the slices
+        [z_offset, z_offset + vol.shape[0]) of a volume of ``full_z`` slices, which must cover ``input_slab(...)`` of this rank.
+        Returns the blended probability volume (Z,Y,X,Cout)."""
         assert vol.is_cuda and vol.dim() == 4 and vol.dtype == torch.float32
-        Z, Y, X, Cin = vol.shape
+        Zs, Y, X, Cin = vol.shape
+        Z = Zs if full_z is None else int(full_z)
         plan = tiling.MergePlan((Z, Y, X), self.patch, self.overlap, self.padding, vol.device)
         nz, ny, nx = plan.grid[0].n, plan.grid[1].n, plan.grid[2].n
         row_starts = [plan.row_start(i) for i in range(nz)]
@@ -189,7 +235,8 @@ class SlidingWindowPredictor:
         pred = None
         for b0 in range(0, n_mine, self.batch):
             nb = min(self.batch, n_mine - b0)
-            xb = tiling.crop_device(vol, self.patch, self.overlap, self.padding, self.pad_type, c_begin=lo * ny * nx + b0, c_count=nb)
+            xb = tiling.crop_device(vol, self.patch, self.overlap, self.padding, self.pad_type, c_begin=lo * ny * nx + b0, c_count=nb,
+                                    z_offset=z_offset, full_z=Z)
             if self.tta:
                 from . import tta as _tta
 

@@ -40,6 +40,7 @@ int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
 int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test hook: 0 = plain 4-wave conv kernel instead of the wave-specialised one (bf16) */
+int bpx_debug_set_tiling_scalar(int on); /* test / A-B hook: 1 = crop / merge through the element-per-thread kernels instead of the 16-byte row kernels */
 
 /* ------------------------------------------------------------------------------------------------
  * Tiling.  Patch placement along one axis, exactly the reference's integer rule
@@ -220,10 +221,13 @@ int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, int64_t coun
 int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, float* stats_part_d, bpx_stream_t stream);
 int bpx_tensor_stats_tiles(int64_t voxels);
 
-/* Backward of InstanceNorm given the partials from bpx_conv3d_dgrad:
- *   coef[n*C+c] = {a, b, c0} with dx = a*g + b*t + c0 ;  dgamma[c] += sum_n S2 ; dbeta[c] += sum_n S1 */
+/* Backward of InstanceNorm (groups == C) / GroupNorm(groups) (blocks.py:2117-2125) given the per-channel partials from
+ * bpx_conv3d_dgrad / bpx_norm_act_bwd (S1 = sum g, S2 = sum g*xhat with the group's statistics in rec_d):
+ *   coef[n*C+c] = {a, b, c0} with dx = a*g + b*t + c0 ;  dgamma[c] += sum_n S2 ; dbeta[c] += sum_n S1
+ * (sums over the samples in a fixed order by one thread per channel: deterministic).  Channels per group: 1, 2, 4, 8, 16, 32, 64;
+ * count_per_channel = voxels per sample. */
 int bpx_norm_bwd_finalize(float* red_part_d /* consumed, see bpx_norm_finalize */, int N, int tiles, int C, int64_t count_per_channel,
-                          const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d,
+                          const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups,
                           bpx_nbwd_coef* coef_d, bpx_stream_t stream);
 /* dx = a*g + b*t + c0 (+ addend): applies the coefficients above elementwise. dx may alias g. */
 int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,

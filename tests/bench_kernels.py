@@ -127,12 +127,19 @@ def main():
         plan = tiling.MergePlan(vol, (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0), torch.device(DEV))
         patches = torch.rand(plan.n_patches, 128, 128, 128, 1, device=DEV)
         out = torch.empty(vol + (1,), device=DEV)
-        ms = timeit(lambda: tiling.merge_device(patches, plan, out=out), max(3, a.reps // 4))
         by = patches.numel() * 4 + out.numel() * 4
-        print(f"merge 512^3 from {plan.n_patches} x 128^3: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)")
         v = torch.rand(vol + (1,), device=DEV)
-        ms = timeit(lambda: tiling.crop_device(v, (128, 128, 128), (0.5, 0.5, 0.5), out=patches), max(3, a.reps // 4))
-        print(f"crop  512^3 -> {plan.n_patches} x 128^3: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)")
+        for scalar, tag in ((1, "element-per-thread kernels (round 1)"), (0, "16-byte row kernels")):
+            lib.bpx_debug_set_tiling_scalar(scalar)
+            ms = timeit(lambda: tiling.merge_device(patches, plan, out=out), max(3, a.reps // 4))
+            print(f"merge 512^3 from {plan.n_patches} x 128^3 [{tag}]: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)  = {by / ms / 1e6 / 8000:.3f} of 8 TB/s")
+            ms = timeit(lambda: tiling.crop_device(v, (128, 128, 128), (0.5, 0.5, 0.5), out=patches), max(3, a.reps // 4))
+            print(f"crop  512^3 -> {plan.n_patches} x 128^3 [{tag}]: {ms:9.3f} ms  {by / ms / 1e6:8.1f} GB/s(alg)  = {by / ms / 1e6 / 8000:.3f} of 8 TB/s")
+        lib.bpx_debug_set_tiling_scalar(0)
+        # what the sliding-window predictor launches per batch: 4 patches gathered from the volume
+        small = torch.empty((4, 128, 128, 128, 1), device=DEV)
+        ms = timeit(lambda: tiling.crop_device(v, (128, 128, 128), (0.5, 0.5, 0.5), c_begin=100, c_count=4, out=small), a.reps)
+        print(f"crop  4 x 128^3 (one batch of the predictor): {ms * 1e3:9.1f} us  {2 * small.numel() * 4 / ms / 1e6:8.1f} GB/s(alg)")
 
 
 def bench_convt(reps=20):

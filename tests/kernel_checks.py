@@ -142,6 +142,80 @@ def check_tiling(golden):
     return res
 
 
+def check_tiling_row_kernels(n_cases=40, seed=7):
+    """The 16-byte row kernels of crop / merge (the production path) against the oracle AND against the element-per-thread
+    kernels of round 1 (bpx_debug_set_tiling_scalar), bit for bit, over random geometries: channel counts 1-4 (vectors that
+    straddle voxels and patch edges), odd volume / patch extents, overlaps, padding with reflect / zeros, f32 / f16 / u8,
+    sharded blends (row range + z range, seeded and partial-sum modes)."""
+    from biapy_amd import _lib as L
+
+    rs = np.random.RandomState(seed)
+    res, bad_crop, bad_merge, bad_shard, n_vec = [], 0, 0, 0, 0
+    for case in range(n_cases):
+        C = int(rs.choice([1, 1, 2, 3, 4]))
+        patch = tuple(int(v) for v in (rs.randint(4, 13), rs.randint(4, 13), 4 * rs.randint(2, 7)))
+        if C == 3:
+            patch = patch[:2] + (4 * int(rs.randint(2, 7)),)          # x*C must be a multiple of 4 for the vector path
+        pad = tuple(int(rs.randint(0, max(1, p // 2 - 1))) if rs.rand() < 0.5 else 0 for p in patch)
+        vol = tuple(int(p + rs.randint(0, 2 * p)) for p in patch)
+        if rs.rand() < 0.7:                                             # the merge's vector path needs X*C % 4 == 0
+            vol = vol[:2] + (int(-(-vol[2] // 4) * 4),)
+        ov = tuple(float(rs.choice([0.0, 0.25, 0.5, 0.6])) for _ in range(3))
+        pad_type = str(rs.choice(["reflect", "zeros"]))
+        np_dt = [np.float32, np.float32, np.float16, np.uint8][int(rs.randint(0, 4))]
+        v = (rs.rand(*vol, C) * (255 if np_dt == np.uint8 else 1)).astype(np_dt)
+        try:
+            p_ref, _ = TO.crop(v, patch + (C,), ov, pad, pad_type=pad_type)
+        except (ValueError, AssertionError):
+            continue
+        tv = torch.from_numpy(v.view({1: np.uint8, 2: np.int16, 4: np.int32}[v.dtype.itemsize])).to(DEV)
+        outs = []
+        for scalar in (0, 1):
+            L.lib.bpx_debug_set_tiling_scalar(scalar)
+            outs.append(tiling.crop_device(tv, patch, ov, pad, pad_type).cpu().numpy().view(np_dt))
+        L.lib.bpx_debug_set_tiling_scalar(0)
+        bad_crop += int((outs[0] != p_ref).sum()) + int((outs[0] != outs[1]).sum())
+        # merge: random predictions shaped like the patches
+        pred = (rs.rand(*p_ref.shape) * (255 if np_dt == np.uint8 else 1)).astype(np_dt)
+        m_ref = TO.merge(pred, vol + (C,), overlap=ov, padding=pad)
+        plan = tiling.MergePlan(vol, patch, ov, pad, torch.device(DEV))
+        tp = torch.from_numpy(pred).to(DEV)
+        outs = []
+        for scalar in (0, 1):
+            L.lib.bpx_debug_set_tiling_scalar(scalar)
+            outs.append(tiling.merge_device(tp, plan).cpu().numpy())
+        L.lib.bpx_debug_set_tiling_scalar(0)
+        as_bits = lambda a: a.view({1: np.uint8, 2: np.uint16, 4: np.uint32}[a.dtype.itemsize])  # noqa: E731
+        bad_merge += int((as_bits(outs[0]) != as_bits(m_ref)).sum()) + int((as_bits(outs[0]) != as_bits(outs[1])).sum())
+        n_vec += int((vol[2] * C) % (4 if np_dt == np.float32 else 8) == 0)
+        # sharded: two row ranges, the boundary handed over as partial sums
+        nz = plan.grid[0].n
+        if nz >= 2 and np_dt == np.float32:
+            ny, nx = plan.grid[1].n, plan.grid[2].n
+            h = nz // 2
+            core = patch[0] - 2 * pad[0]
+            z_split, z0_hi = plan.row_start(h), min(plan.row_start(h - 1) + core, vol[0])
+            r0, r1 = tp[: h * ny * nx].contiguous(), tp[h * ny * nx:].contiguous()
+            out = np.empty(vol + (C,), np.float32)
+            if z_split > 0:
+                out[:z_split] = tiling.merge_device(r0, plan, z_lo=0, z_hi=z_split, zrow_lo=0, zrow_hi=h).cpu().numpy()
+            if z0_hi > z_split:
+                nb = z0_hi - z_split
+                acc = torch.zeros((nb, vol[1], vol[2], C), dtype=torch.float32, device=DEV)
+                wacc = torch.zeros((nb, vol[1], vol[2], 1), dtype=torch.float32, device=DEV)
+                tiling.merge_device(r0, plan, z_lo=z_split, z_hi=z0_hi, zrow_lo=0, zrow_hi=h, acc=acc, wacc=wacc, write_partial=True)
+                out[z_split:z0_hi] = tiling.merge_device(r1, plan, z_lo=z_split, z_hi=z0_hi, zrow_lo=h, zrow_hi=nz, acc=acc, wacc=wacc, seed=True).cpu().numpy()
+            if vol[0] > max(z0_hi, z_split):
+                lo = max(z0_hi, z_split)
+                out[lo:] = tiling.merge_device(r1, plan, z_lo=lo, z_hi=vol[0], zrow_lo=h, zrow_hi=nz).cpu().numpy()
+            bad_shard += int((out.view(np.uint32) != m_ref.view(np.uint32)).sum())
+    res.append(_res("crop_row_kernel_vs_oracle_and_scalar", bad_crop, 0))
+    res.append(_res("merge_row_kernel_vs_oracle_and_scalar", bad_merge, 0, f"{n_vec} cases on the vector path"))
+    res.append(_res("merge_row_kernel_sharded", bad_shard, 0))
+    res.append(_res("row_kernel_cases_on_vector_path", 0 if n_vec >= n_cases // 3 else 1, 0))
+    return res
+
+
 def check_merge_sharded():
     """Two Z-slabs with the boundary partial sums handed over must equal the single-device merge bit for bit."""
     rs = np.random.RandomState(11)
@@ -486,7 +560,7 @@ def check_norm_pool_head(dt, seed=0):
     red = torch.stack([gsig.sum((1, 2, 3)), (gsig * xh).sum((1, 2, 3))], 1).view(B, 1, 2, Cc).contiguous().to(DEV)
     coef = torch.zeros(B, Cc, 4, dtype=torch.float32, device=DEV)
     dgm = torch.zeros(Cc, dtype=torch.float32, device=DEV); dbt = torch.zeros(Cc, dtype=torch.float32, device=DEV)
-    L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, 1, Cc, vox, rec.data_ptr(), gamma_d.data_ptr(), dgm.data_ptr(), dbt.data_ptr(),
+    L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, 1, Cc, vox, rec.data_ptr(), gamma_d.data_ptr(), dgm.data_ptr(), dbt.data_ptr(), Cc,
                                       coef.data_ptr(), L.stream_ptr()))
     dxn = torch.empty(B, D, H, W, Cc, dtype=tdtype(dt), device=DEV)
     gsig_d = to_dev(gsig, dt)
@@ -656,8 +730,9 @@ def check_network_aniso(dtype, golden):
     return res
 
 
-def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0):
-    """bpx_norm_act_fwd / bpx_norm_act_bwd (+ finalize + apply) against autograd through act(instance_norm(x))."""
+def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0, groups=None):
+    """bpx_norm_act_fwd / bpx_norm_act_bwd (+ finalize + apply) against autograd through act(instance_norm(x)) - or, with
+    ``groups``, through act(torch group_norm(x, groups)): GroupNorm(G < C) forward AND backward (blocks.py:2117-2125)."""
     D, H, W = S
     vox = D * H * W
     g = torch.Generator().manual_seed(seed)
@@ -667,9 +742,10 @@ def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0):
     xr = ncdhw(x).requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     fn = {"elu": F.elu, "relu": F.relu, "silu": F.silu}[act]
-    y_ref = fn(F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    G_ = Cc if groups is None else groups
+    y_ref = fn(F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5)) if groups is None else fn(F.group_norm(xr, groups, gr, br, 1e-5))
     y_ref.backward(ncdhw(dy))
-    tag = f"norm_act[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc} {act}]"
+    tag = f"norm_act[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} C{Cc} {act}{'' if groups is None else ' GN%d' % groups}]"
     st = L.stream_ptr()
     xd, dyd = to_dev(x, dt), to_dev(dy, dt)
     tiles = lib.bpx_tensor_stats_tiles(vox)
@@ -677,7 +753,7 @@ def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0):
     L.check(lib.bpx_tensor_stats(dt, B, vox, L.tview(xd), part.data_ptr(), st))
     rec = torch.empty(B, Cc, 4, dtype=torch.float32, device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
-    L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, Cc, vox, gd.data_ptr(), bd.data_ptr(), 1e-5, Cc, rec.data_ptr(), Cc, 0, st))
+    L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, Cc, vox, gd.data_ptr(), bd.data_ptr(), 1e-5, G_, rec.data_ptr(), Cc, 0, st))
     extra = 16
     yb = torch.full((B, D, H, W, Cc + extra), 3.0, dtype=tdtype(dt), device=DEV)
     code = L.ACT[act]
@@ -691,7 +767,7 @@ def check_norm_act(dt, B=2, S=(6, 10, 12), Cc=48, act="elu", seed=0):
     L.check(lib.bpx_norm_act_bwd(dt, B, vox, L.tview(dyd), L.tview(xd), rec.data_ptr(), code, L.NULL_T, L.tview(gbuf), red.data_ptr(), st))
     coef = torch.empty(B, Cc, 4, dtype=torch.float32, device=DEV)
     dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
-    L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, nt, Cc, vox, rec.data_ptr(), gd.data_ptr(), dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st))
+    L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, nt, Cc, vox, rec.data_ptr(), gd.data_ptr(), dg.data_ptr(), db.data_ptr(), G_, coef.data_ptr(), st))
     L.check(lib.bpx_norm_bwd_apply(dt, B, vox, L.tview(gbuf), L.tview(xd), coef.data_ptr(), L.NULL_T, L.tview(gbuf), st))
     torch.cuda.synchronize()
     tol = 3e-2 if dt == L.BF16 else 2e-4

@@ -22,7 +22,7 @@ class NumpyBlend:
         self.P = tuple(patch_zyx)
         self.win = T.spline_window(self.P, tuple(g.ov_pixels for g in self.g))[..., 0]
 
-    def blend(self, patches, z_lo, z_hi, rows, acc=None, wacc=None, seed=False, write_partial=False, out_dtype=None):
+    def blend(self, patches, z_lo, z_hi, rows, acc=None, wacc=None, seed=False, write_partial=False, out_dtype=None, out=None):
         gz, gy, gx = self.g
         p = patches.numpy()
         C = p.shape[-1]
@@ -47,7 +47,11 @@ class NumpyBlend:
             acc.copy_(torch.from_numpy(num))
             wacc.copy_(torch.from_numpy(ws))
             return None
-        return torch.from_numpy(np.true_divide(num, ws + 1e-18).astype(np.float32))
+        res = torch.from_numpy(np.true_divide(num, ws + 1e-18).astype(np.float32))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
 
 def _free_port():
@@ -85,6 +89,7 @@ def _worker(rank, world, port, vshape, pshape, ov, q):
     (2, (72, 40, 40, 1), (32, 32, 32, 1), (0.5, 0.5, 0.5)),
     (3, (80, 24, 28, 2), (32, 16, 16, 2), (0.6, 0.25, 0.0)),     # overlap > 50 %: three patch rows cover one slice
     (4, (40, 20, 20, 1), (32, 16, 16, 1), (0.5, 0.0, 0.5)),      # more ranks than patch rows: idle ranks must not dead-lock
+    (8, (1024, 24, 24, 1), (128, 16, 16, 1), (0.5, 0.5, 0.5)),   # cfg 3's exact Z plan on 8 ranks: 2 patch rows per rank, 68-slice hand-over
 ])
 def test_sharded_blend_bit_exact_gloo(world, vshape, pshape, ov):
     ctx = mp.get_context("spawn")
@@ -97,6 +102,35 @@ def test_sharded_blend_bit_exact_gloo(world, vshape, pshape, ov):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def test_input_slab_is_what_the_ranks_patches_read():
+    """SlidingWindowPredictor.input_slab / tiling.crop_rows_needed (each GPU holds only its input slab + halo)
+    against the oracle's crop coordinates: the slab is exactly the hull of the slices the rank's patches read, reflect-padding
+    sources at the volume ends included; at cfg 3 a rank reads 188 of 1024 slices."""
+    from biapy_amd import tiling
+    from biapy_amd.workflow import SlidingWindowPredictor, split_rows
+
+    for vol, patch, ov, pad in (((1024, 64, 64), (128, 32, 32), (0.5, 0.5, 0.5), (0, 0, 0)), ((100, 40, 40), (32, 16, 16), (0.25, 0, 0), (6, 2, 2)),
+                                ((77, 20, 20), (24, 16, 16), (0.5, 0, 0), (4, 0, 0)), ((48, 20, 20), (48, 16, 16), (0, 0, 0), (10, 0, 0))):
+        coords = T.crop_coords(vol, patch, ov, pad)                    # patch extents in PADDED coordinates
+        g = T.crop_grid(vol, patch, ov, pad)
+        per_row = g[1].n * g[2].n
+        for world in (1, 2, 3, 8):
+            sw = SlidingWindowPredictor(None, patch, ov, pad, forward=lambda x: x)
+            for rank, (lo, hi) in enumerate(split_rows(g[0].n, world)):
+                got = sw.input_slab(vol, rank, world)
+                if hi <= lo:
+                    assert got == (0, 0)
+                    continue
+                zs = set()
+                for c in coords[lo * per_row:hi * per_row]:
+                    for z in range(int(c[0]) - pad[0], int(c[1]) - pad[0]):
+                        zs.add(-z if z < 0 else (2 * (vol[0] - 1) - z if z >= vol[0] else z))    # np.pad "reflect"
+                assert got == (min(zs), max(zs) + 1), (vol, patch, world, rank, got, (min(zs), max(zs) + 1))
+    sw = SlidingWindowPredictor(None, (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0), forward=lambda x: x)
+    assert [sw.input_slab((1024, 1024, 1024), r, 8) for r in (0, 3, 7)] == [(0, 188), (360, 548), (840, 1024)]
+    assert tiling.crop_rows_needed((1024, 1024, 1024), (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0), 0, 16) == (0, 1024)
 
 
 def test_plan_slabs_cfg3():

@@ -29,6 +29,11 @@ def test_merge_two_slabs_bit_exact(K):
     _assert_all(K.check_merge_sharded())
 
 
+def test_tiling_row_kernels_random_geometries(K):
+    """The vectorised crop / merge kernels vs the oracle and vs the element-per-thread kernels, 40 random geometries."""
+    _assert_all(K.check_tiling_row_kernels())
+
+
 @pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
 def test_conv3d_fwd(K, dt):
     rows = []
@@ -364,6 +369,21 @@ def test_norm_act_kernels(K, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_groupnorm_forward_and_backward(K, dt):
+    """GroupNorm(G < C) (blocks.py:2117-2125; north_star names GroupNorm): statistics finalize, materialised forward, and the
+    backward finalize + apply (dx, dgamma, dbeta) against torch.nn.functional.group_norm on the CPU - GroupNorm(8) at the
+    network's widths (2 ... 32 channels per group), GroupNorm(16), and groups that do not fill a 16-channel block."""
+    from biapy_amd import _lib as L
+
+    d = L.F32 if dt == "f32" else L.BF16
+    rows = []
+    for Cc, G, act, seed in ((16, 8, "elu", 0), (32, 8, "relu", 1), (64, 8, "elu", 2), (128, 8, "silu", 3), (256, 8, "elu", 4), (64, 16, "elu", 5),
+                             (48, 3, "elu", 6), (384, 6, "elu", 7)):
+        rows += K.check_norm_act(d, 2, (4, 6, 10), Cc, act, seed=seed, groups=G)
+    _assert_all(rows)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_convT_channel_changing(K, dt):
     """ConvTranspose(in -> out != in): the plain U-Net's UpBlock (blocks.py:603), 3D (2,2,2) and the 2D-as-one-slice (1,2,2)."""
     from biapy_amd import _lib as L
@@ -652,6 +672,69 @@ def test_two_process_data_parallel_training_on_one_gpu():
         a, b = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
         assert torch.equal(a, b), k                                            # the ranks stay bit-identical
         assert (a - w).abs().max().item() <= 2e-5 * max(1.0, w.abs().max().item()), k
+
+
+def _sw2_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors too: the ranks share the one GPU of the box
+    torch.cuda.set_device(0)
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    m = _small_resunet().eval()
+    vol = _sw2_volume()
+    sw = SlidingWindowPredictor(m, (16, 16, 16), (0.5, 0.5, 0.5), (2, 0, 0), batch_size=3)
+    z_lo, z_hi = sw.input_slab(vol.shape[:3], rank, world)
+    slab = vol[z_lo:z_hi].contiguous().cuda()                          # the rank holds ONLY the slices its patches read
+    out = sw.predict(slab, rank=rank, world=world, gather="all", z_offset=z_lo, full_z=vol.shape[0])
+    out0 = sw.predict(slab, rank=rank, world=world, gather="rank0", z_offset=z_lo, full_z=vol.shape[0])
+    q.put((rank, (z_lo, z_hi), out.cpu().numpy(), None if out0 is None else out0.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _sw2_volume():
+    g = torch.Generator().manual_seed(77)
+    return torch.randn(52, 24, 32, 1, generator=g)
+
+
+def test_sharded_sliding_window_from_input_slabs_equals_single_device():
+    """SURVEY.md 8e end to end on device kernels: three ranks (one GPU, gloo) each hold ONLY their input slab (+ halo), crop from
+    it with the full volume's grid, run their forwards, exchange the boundary partial sums with one grouped send/receive and
+    gather the disjoint output slabs in place.  Every rank's volume must equal - bit for bit - what one process computes from
+    the whole volume."""
+    import socket
+
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sw2_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    m = _small_resunet().eval()
+    vol = _sw2_volume()
+    sw = SlidingWindowPredictor(m, (16, 16, 16), (0.5, 0.5, 0.5), (2, 0, 0), batch_size=3)
+    ref = sw.predict(vol.cuda()).cpu().numpy()
+    assert all(0 < (hi - lo) < vol.shape[0] for _, (lo, hi), _, _ in res), [r[1] for r in res]   # genuinely partial inputs
+    for rank, _, out, out0 in res:
+        assert (out.view(np.uint32) == ref.view(np.uint32)).all(), rank
+        assert (out0 is None) == (rank != 0)
+    assert (res[0][3].view(np.uint32) == ref.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
