@@ -451,13 +451,13 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 }  // namespace
 
 // bf16 kernel selection: 0 = automatic (lean persistent kernel of conv3d_lean.hip for >= 64^3 volumes, the double-buffered
-// kernel of this file below that),
-// 1 = wave-specialised persistent (conv3d_ws.hip), 2 = persistent 4-wave with a cross-tile stage pipeline
-// (conv3d_persist.hip), 4 = always double-buffered, 5 = always lean persistent.  A/B of 4 | 1 | 2 on the cfg-2 layers, B=4 (us):
+// kernel of this file below that), 4 = always double-buffered, 5 = always lean persistent.
+// Record of two schedules that were measured in round 1 and removed from the library in round 2 (wave-specialised 8-wave
+// persistent | persistent 4-wave with a cross-tile stage pipeline), against the double-buffered kernel, cfg-2 layers, B=4 (us):
 //   fwd 48->16@128^3: 781 | 868 | 1006     fwd 16->16+img@128^3: 463 | 481 | 484     dgrad 16->48@128^3: 1077 | 2373 | 1205
-// Both lose to the double-buffered kernel: they hold a second stage in registers and either spill or drop to fewer
-// co-resident workgroups.  The lean kernel goes the other way (3-4 workgroups per CU, nothing pipelined inside a
-// workgroup) and wins wherever a CU gets >= 4 rounds of tiles: 725 / 342 / 944 us on the same three layers.
+// Both lost: they hold a second stage in registers and either spill or drop to fewer co-resident workgroups.  The lean kernel
+// goes the other way (3-4 workgroups per CU, nothing pipelined inside a workgroup) and wins wherever a CU gets >= 4 rounds of
+// tiles: 725 / 342 / 944 us on the same three layers.
 extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
 
 // Lean persistent kernel (conv3d_lean.hip) where a CU gets >= 4 rounds of tiles; it uses 32-bit element offsets and
@@ -473,8 +473,8 @@ static bool use_lean(int dtype, const Conv3Params& p) {
 extern "C" int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout) {
   TileCfg c = pick_cfg(dtype, D, H, W, Cout);
   int t = cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, c.tx);
-  if (dtype == BPX_BF16 && g_use_ws == 2) return 4 * conv3_persist_groups(N * t, Cout / (16 * c.ns));  // one partial per (workgroup, wave)
-  return (dtype == BPX_BF16 && g_use_ws == 1) ? 4 * t : t;
+  (void)N;
+  return t;
 }
 
 static int check_tensor(const char* fn, const char* name, const bpx_tensor& t, int esize, bool need16) {
@@ -516,8 +516,7 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
     p.pool = pooled.ptr; p.pool_ld = pooled.ld; p.pool_sz = pool_sz; p.pool_part = pool_stats_part_d;
   }
   int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
-           : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_FWD, p, c, (hipStream_t)stream)
-                                  : g_use_ws == 1 ? launch_conv3_ws(EPI_FWD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream))
+           : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream)
                                : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
@@ -564,8 +563,7 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
   int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
-           : (dtype == BPX_BF16) ? (g_use_ws == 2 ? launch_conv3_persist(EPI_DGRAD, p, c, (hipStream_t)stream)
-                                  : g_use_ws == 1 ? launch_conv3_ws(EPI_DGRAD, p, c, (hipStream_t)stream) : launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream))
+           : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream)
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);

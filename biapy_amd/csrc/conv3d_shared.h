@@ -1,6 +1,5 @@
 // Declarations shared by the implicit-GEMM conv kernels (conv3d_igemm.hip: double-buffered 4-wave kernel, fp32 exact mode
-// and small bf16 layers; conv3d_lean.hip: lean persistent bf16 kernel for the large layers; conv3d_ws.hip /
-// conv3d_persist.hip: measured alternatives, off by default).
+// and small bf16 layers; conv3d_lean.hip: lean persistent bf16 kernel for the large layers).
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -76,14 +75,7 @@ inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
 
 extern long long* g_conv_stamps;  // profiling hook (bpx_debug_set_conv_stamps)
 
-// persistent workgroups per launch (~2 per CU); also fixes the layout of the statistics partials of conv3d_persist.hip
-inline int conv3_persist_groups(int totalTiles, int gy) { return std::max(1, std::min(totalTiles, (2 * 256 + gy - 1) / gy)); }
-
-// persistent 4-wave bf16 kernel (conv3d_persist.hip)
-int launch_conv3_persist(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 // lean persistent bf16 kernel (conv3d_lean.hip) - the production kernel of the >= 64^3 layers
 int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
-// wave-specialised bf16 kernel (conv3d_ws.hip)
-int launch_conv3_ws(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 
 }  // namespace bpxconv

@@ -39,7 +39,7 @@ int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
  * bits 8..: windowed kernel workgroups in percent of the co-resident capacity. */
 int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
-int bpx_debug_set_conv_ws(int on);     /* test hook: 0 = plain 4-wave conv kernel instead of the wave-specialised one (bf16) */
+int bpx_debug_set_conv_ws(int on);     /* test / A-B hook of the bf16 3x3x3 conv schedule: 0 = automatic, 4 = always the double-buffered kernel, 5 = always the lean persistent one */
 int bpx_debug_set_tiling_scalar(int on); /* test / A-B hook: 1 = crop / merge through the element-per-thread kernels instead of the 16-byte row kernels */
 
 /* ------------------------------------------------------------------------------------------------

@@ -632,6 +632,32 @@ def check_norm_pool_head(dt, seed=0):
 
 
 # ---------------------------------------------------------------------------------------------------
+# Stated parity bar per storage mode (north_star: "Dice delta < 1e-4, integer label maps bit-exact"):
+#   f32 mode : |Dice delta| < 1e-4 against the fp32 CPU oracle and identical label maps except where the oracle's probability is
+#              within 1e-5 of the threshold;
+#   bf16 mode: the throughput mode.  bf16 storage, bf16 MFMA operands and bf16 packed weights each contribute (CPU emulation of the
+#              data path, scripts/bf16_error_budget.py: mean 0.6e-4, max 1.3e-4 over seeds on a trained network; fp32 weights
+#              alone still leave 0.7e-4), so the bar is STATED, not met: |Dice delta| < 3e-4 on a trained network, and label maps
+#              identical wherever the oracle's probability is more than BF16_UNDECIDED away from the threshold.
+BF16_DICE_TOL = 3e-4
+BF16_UNDECIDED = 2e-2
+
+
+def parity_rows(tag, logits, lo_ref, tgt, dtype, trained=False):
+    """Rows of the stated parity bar for one prediction (CPU tensors)."""
+    f32 = dtype == torch.float32
+    p_ref = torch.sigmoid(lo_ref)
+    lab_ref, lab_got = p_ref > 0.5, torch.sigmoid(logits) > 0.5
+    near = (p_ref - 0.5).abs() < (1e-5 if f32 else BF16_UNDECIDED)
+    wrong = int(((lab_ref != lab_got) & ~near).sum())
+    rows = [_res(tag + ".labels_away_from_threshold", wrong, 0,
+                 extra=f"{int((lab_ref != lab_got).sum())} of {lab_ref.numel()} voxels differ in all, {int(near.sum())} lie within the undecided band")]
+    if f32 or trained:          # on a random-init network every probability sits at the threshold: Dice is only meaningful after training
+        d_ref, d_got = net_oracle.dice(p_ref, tgt), net_oracle.dice(torch.sigmoid(logits), tgt)
+        rows.append(_res(tag + ".dice_delta", abs(d_ref - d_got), 1e-4 if f32 else BF16_DICE_TOL, extra=f"dice_ref={d_ref:.6f} dice_got={d_got:.6f}"))
+    return rows
+
+
 def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
     """Whole network vs the oracle: logits, Dice, loss and every parameter gradient."""
     tagd = "bf16" if dtype == torch.bfloat16 else "f32"
@@ -659,12 +685,7 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
     scale = lo_ref.abs().max().item()
     err = (logits.cpu() - lo_ref).abs().max().item() / scale
     res.append(_res(tag + ".logits_rel", err, 6e-2 if dtype == torch.bfloat16 else 2e-4, extra=f"scale={scale:.3f}"))
-    # Dice parity: both predictions against the same target (north_star: |delta| < 1e-4 ... stated here per mode)
-    d_ref = net_oracle.dice(torch.sigmoid(lo_ref), tgt)
-    d_got = net_oracle.dice(torch.sigmoid(logits.cpu()), tgt)
-    agree = net_oracle.dice(torch.sigmoid(logits.cpu()), (torch.sigmoid(lo_ref) > 0.5).float())
-    res.append(_res(tag + ".dice_delta", abs(d_ref - d_got), 1e-4 if dtype == torch.float32 else 5e-3, extra=f"dice_ref={d_ref:.6f} dice_got={d_got:.6f}"))
-    res.append(_res(tag + ".label_disagreement", 1 - agree, 1e-4 if dtype == torch.float32 else 3e-2))
+    res += parity_rows(tag, logits.cpu(), lo_ref, tgt, dtype)
     if not train:
         return res
     lg = logits.detach().clone().requires_grad_(True)
@@ -685,6 +706,124 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
         if e > worst:
             worst, worst_name = e, k
     res.append(_res(tag + ".grads_rel_l2_worst", worst, gtol, extra=worst_name))
+    return res
+
+
+_CFG2_CACHE = {}
+
+
+def _cfg2_oracle():
+    """One CPU oracle train step of the cfg-2 network on ONE 128^3 patch (about 10 s on the GPU box's cores), shared by the
+    f32 and bf16 tests; plus three more seeded samples (inputs only) for the batch-4 consistency check."""
+    if "ref" not in _CFG2_CACHE:
+        fm = [16, 32, 64, 128, 256]
+        sd = net_oracle.init_state_dict(1, fm, seed=0)
+        g = torch.Generator().manual_seed(41)
+        x = torch.randn(4, 1, 128, 128, 128, generator=g)
+        n = torch.randn(4, 1, 128, 128, 128, generator=g)
+        tgt = (F.avg_pool3d(n, 9, stride=1, padding=4) > 0).float()          # bench.py's blob targets
+        loss_ref, lo_ref, grads_ref = net_oracle.train_step_grads(sd, x[:1], tgt[:1], feature_maps=fm)
+        _CFG2_CACHE["ref"] = (fm, sd, x, tgt, loss_ref, lo_ref, grads_ref)
+    return _CFG2_CACHE["ref"]
+
+
+def check_network_cfg2_benched_shape(dtype):
+    """The benched workload AT ITS OWN SIZE: cfg 2 = fm 16-32-64-128-256 on 128^3 patches, batch 4 - the
+    (4,8,16) big-tile kernels, the XCD tile walk over 8192 tiles per sample, byte offsets up to 805 MB.
+      * sample 0 alone (batch 1): logits, BCE loss and every parameter gradient against the CPU oracle;
+      * the batch of 4: per-sample logits must equal - bit for bit - the four batch-1 forwards (InstanceNorm is per sample), and
+        the batch gradient must equal the mean of the four batch-1 gradients."""
+    fm, sd, x, tgt, loss_ref, lo_ref, grads_ref = _cfg2_oracle()
+    f32 = dtype == torch.float32
+    tagd = "f32" if f32 else "bf16"
+    tag = f"cfg2_128^3[{tagd}]"
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm), dtype)
+    P = {k: v.to(DEV) for k, v in sd.items()}
+
+    def step(xb, tb):
+        logits, ctx = eng.forward(P, xb.to(DEV), head_act=0, save=True)
+        lg = logits.detach().clone().requires_grad_(True)
+        loss = F.binary_cross_entropy_with_logits(lg, tb.to(DEV))
+        loss.backward()
+        G = eng.backward(P, ctx, lg.grad)
+        torch.cuda.synchronize()
+        return logits.cpu(), loss.item(), {k: v.cpu() for k, v in G.items()}
+
+    lo1, loss1, G1 = step(x[:1], tgt[:1])
+    scale = lo_ref.abs().max().item()
+    res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, 2e-4 if f32 else 6e-2, extra=f"scale={scale:.3f}")]
+    res += parity_rows(tag + ".b1", lo1, lo_ref, tgt[:1], dtype)
+    res.append(_res(tag + ".b1.loss", abs(loss1 - loss_ref.item()), 1e-5 if f32 else 2e-2))
+    worst, wname = 0.0, ""
+    for k, gr in grads_ref.items():
+        denom = gr.norm().item()
+        e = (G1[k] - gr).norm().item() / (denom + 1e-6 * max(1.0, gr.numel() ** 0.5))
+        if denom < 1e-7:
+            e = (G1[k] - gr).abs().max().item() / 1e-3
+        if e > worst:
+            worst, wname = e, k
+    res.append(_res(tag + ".b1.grads_rel_l2_worst", worst, 2e-3 if f32 else 0.15, extra=wname))
+    # batch 4 == four batch-1 steps
+    lo4, loss4, G4 = step(x, tgt)
+    singles = [(lo1, loss1, G1)] + [step(x[b:b + 1], tgt[b:b + 1]) for b in range(1, 4)]
+    res.append(_res(tag + ".b4.logits_equal_batch1_runs", sum(int((lo4[b] != singles[b][0][0]).sum()) for b in range(4)), 0))
+    res.append(_res(tag + ".b4.loss", abs(loss4 - sum(s_[1] for s_ in singles) / 4), 1e-6 if f32 else 1e-5))
+    worst, wname = 0.0, ""
+    for k in G4:
+        mean = sum(s_[2][k] for s_ in singles) / 4
+        e = (G4[k] - mean).norm().item() / (mean.norm().item() + 1e-6 * max(1.0, mean.numel() ** 0.5))
+        if e > worst:
+            worst, wname = e, k
+    res.append(_res(tag + ".b4.grads_vs_mean_of_batch1_grads", worst, 1e-4 if f32 else 2e-3, extra=wname))
+    return res
+
+
+def check_sliding_window_cfg3_shape(dtype):
+    """A cfg-3-shaped sliding window against the oracle pipeline: the cfg-2 network, 128^3 patches, 50 %
+    overlap along z, a (320,128,128) volume = 5 patch rows (the reference's rule shrinks the step to 48, so up to three patches
+    cover a slice - as at cfg 3, where overlap 68 > P/2), blended as TWO Z-slabs with the boundary partial sums handed over - against crop -> oracle forward -> sigmoid -> merge on the CPU."""
+    from biapy_amd.resunet import ResUNet
+
+    fm = [16, 32, 64, 128, 256]
+    sd = net_oracle.init_state_dict(1, fm, seed=0)
+    m = ResUNet(image_shape=(128, 128, 128, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4,
+                z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    rs = np.random.RandomState(9)
+    vshape, patch, ov = (320, 128, 128, 1), (128, 128, 128), (0.5, 0.0, 0.0)
+    vol = rs.randn(*vshape).astype(np.float32)
+    if "sw" not in _CFG2_CACHE:
+        p, _ = TO.crop(vol, patch + (1,), ov)
+        with torch.no_grad():
+            pr = torch.cat([torch.sigmoid(net_oracle.resunet_forward(sd, torch.from_numpy(p[i:i + 1]).permute(0, 4, 1, 2, 3), fm)) for i in range(p.shape[0])])
+        _CFG2_CACHE["sw"] = TO.merge(pr.permute(0, 2, 3, 4, 1).contiguous().numpy(), vshape, overlap=ov)
+    ref = _CFG2_CACHE["sw"]
+    plan = tiling.MergePlan(vshape[:3], patch, ov, (0, 0, 0), torch.device(DEV))
+    nz = plan.grid[0].n
+    tv = torch.from_numpy(vol).to(DEV)
+    with torch.no_grad():
+        pred = torch.cat([m.predict_proba(tiling.crop_device(tv, patch, ov, c_begin=i, c_count=1).permute(0, 4, 1, 2, 3)) for i in range(nz)])
+    pred = pred.permute(0, 2, 3, 4, 1).contiguous()
+    h = nz // 2
+    z_split, z0_hi = plan.row_start(h), plan.row_start(h - 1) + patch[0]
+    got = np.empty(vshape, np.float32)
+    r0, r1 = pred[:h].contiguous(), pred[h:].contiguous()
+    got[:z_split] = tiling.merge_device(r0, plan, z_lo=0, z_hi=z_split, zrow_lo=0, zrow_hi=h).cpu().numpy()
+    nb = z0_hi - z_split
+    acc = torch.zeros((nb, vshape[1], vshape[2], 1), dtype=torch.float32, device=DEV)
+    wacc = torch.zeros((nb, vshape[1], vshape[2], 1), dtype=torch.float32, device=DEV)
+    tiling.merge_device(r0, plan, z_lo=z_split, z_hi=z0_hi, zrow_lo=0, zrow_hi=h, acc=acc, wacc=wacc, write_partial=True)
+    got[z_split:z0_hi] = tiling.merge_device(r1, plan, z_lo=z_split, z_hi=z0_hi, zrow_lo=h, zrow_hi=nz, acc=acc, wacc=wacc, seed=True).cpu().numpy()
+    got[z0_hi:] = tiling.merge_device(r1, plan, z_lo=z0_hi, z_hi=vshape[0], zrow_lo=h, zrow_hi=nz).cpu().numpy()
+    f32 = dtype == torch.float32
+    tagd = "f32" if f32 else "bf16"
+    res = [_res(f"sliding_cfg3_shape_prob[{tagd}]", float(np.abs(got - ref).max()), 2e-5 if f32 else 3e-2, extra=f"{nz} patches of 128^3, two slabs")]
+    near = np.abs(ref - 0.5) < (1e-5 if f32 else BF16_UNDECIDED)
+    res.append(_res(f"sliding_cfg3_shape_labels_away_from_threshold[{tagd}]", int((((ref > 0.5) != (got > 0.5)) & ~near).sum()), 0,
+                    extra=f"undecided band: {int(near.sum())} of {near.size} voxels"))
+    full = tiling.merge_device(pred, plan).cpu().numpy()
+    res.append(_res(f"sliding_cfg3_shape_two_slabs_equal_one[{tagd}]", int((full.view(np.uint32) != got.view(np.uint32)).sum()), 0))
     return res
 
 
@@ -1002,11 +1141,11 @@ def check_dice_parity_trained(steps=120):
     with torch.no_grad():
         lo_ref = net_oracle.resunet_forward(sd, x.cpu(), fm)
     d_ref = net_oracle.dice(torch.sigmoid(lo_ref), t.cpu())
-    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 1e-3)):
+    del d_ref
+    for dtype in (torch.float32, torch.bfloat16):
         m.compute_dtype = dtype
         with torch.no_grad():
             lo = m(x).cpu()
-        d = net_oracle.dice(torch.sigmoid(lo), t.cpu())
         tagd = "bf16" if dtype == torch.bfloat16 else "f32"
-        res.append(_res(f"dice_delta_trained_model[{tagd}]", abs(d - d_ref), tol, extra=f"dice_ref={d_ref:.6f} dice={d:.6f}"))
+        res += parity_rows(f"trained_model[{tagd}]", lo, lo_ref, t.cpu(), dtype, trained=True)
     return res

@@ -45,7 +45,7 @@ def test_conv3d_fwd(K, dt):
     _assert_all(rows)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 5], ids=["wave-specialised", "persistent", "double-buffered", "lean-persistent"])
+@pytest.mark.parametrize("variant", [4, 5], ids=["double-buffered", "lean-persistent"])
 def test_conv3d_bf16_kernel_variants(K, variant):
     """Every schedule of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) computes the same convolution."""
     from biapy_amd import _lib as L
@@ -127,6 +127,18 @@ def test_anisotropic_network_against_reference_golden(K, resunet_aniso_golden, d
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_network_cfg2_architecture(K, dtype):
     _assert_all(K.check_network(dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_network_cfg2_at_the_benched_shape(K, dtype):
+    """cfg 2 at 128^3 (batch 1 vs the CPU oracle; batch 4 vs four batch-1 runs) - the size bench.py times."""
+    _assert_all(K.check_network_cfg2_benched_shape(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_sliding_window_cfg3_shape(K, dtype):
+    """cfg-3-shaped sliding window (128^3 patches of the cfg-2 network, 50 % z overlap, two slabs) vs the oracle pipeline."""
+    _assert_all(K.check_sliding_window_cfg3_shape(dtype))
 
 
 def test_module_is_a_dropin(resunet_golden):
