@@ -40,6 +40,7 @@ _SIGS = {
     "bpx_debug_set_conv_ws": ([_i], _i),
     "bpx_debug_set_conv_stamps": ([_vp], _i),
     "bpx_debug_set_tiling_scalar": ([_i], _i),
+    "bpx_debug_set_conv_occ": ([_i], _i),
     "bpx_crop3d_gather": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _i64, _i64, _vp, _vp], _i),
     "bpx_merge3d_blend": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                            _vp, _vp, _i, _vp, _i, _vp], _i),
@@ -56,6 +57,11 @@ _SIGS = {
     "bpx_clip_affine_f32": ([_vp, _i64, _f, _f, _f, _f, _vp, _vp], _i),
     "bpx_tta_orient": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "bpx_tta_accumulate": ([_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "bpx_chan_loss_blocks": ([_i64], _i),
+    "bpx_chan_loss_sums": ([_vp, _vp, _i, _i, _i64, C.c_uint, _vp, _vp], _i),
+    "bpx_chan_loss_bwd": ([_vp, _vp, _i, _i, _i64, C.c_uint, _vp, _vp, _vp], _i),
+    "bpx_gate_mul_fwd": ([_i, _i64, Tensor, Tensor, Tensor, _vp], _i),
+    "bpx_gate_mul_bwd": ([_i, _i64, Tensor, Tensor, Tensor, Tensor, _vp, _vp], _i),
     "bpx_seg_loss_blocks": ([_i64], _i),
     "bpx_seg_loss_sums": ([_vp, _vp, _i64, _vp, _vp], _i),
     "bpx_seg_loss_bwd": ([_vp, _vp, _i64, _vp, _vp, _vp], _i),

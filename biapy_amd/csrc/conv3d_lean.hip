@@ -379,6 +379,10 @@ int cu_count() {
   return n;
 }
 
+// test / A-B hook: persistent workgroups per CU of the lean kernel (0 = the table above).  The register budget is fixed at compile
+// time by lp_occ(); launching more workgroups only helps where the kernel's actual VGPR / LDS use admits them.
+int g_lp_occ_override = 0;
+
 template <int EPI>
 int launch_lp(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   Conv3Params p = p0;
@@ -391,7 +395,7 @@ int launch_lp(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.stamps = g_conv_stamps;
   const int gy = p.Cout / (16 * c.ns);
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
-  const int occ = lp_occ(c.tz * c.ty * c.tx, c.ns, EPI, elu ? 1 : 0);
+  const int occ = g_lp_occ_override > 0 ? g_lp_occ_override : lp_occ(c.tz * c.ty * c.tx, c.ns, EPI, elu ? 1 : 0);
   int gx = std::max(8, (cu_count() * occ / gy) & ~7);
   gx = std::min(gx, 8 * p.tilesPerXcd);
   dim3 grid((unsigned)gx, (unsigned)gy);
@@ -407,6 +411,8 @@ int launch_lp(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int bpx_debug_set_conv_occ(int wg_per_cu) { g_lp_occ_override = wg_per_cu; return 0; }
 
 namespace bpxconv {
 int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s) {

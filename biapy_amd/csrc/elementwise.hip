@@ -1195,6 +1195,109 @@ __global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restri
   }
 }
 
+// ---- per-channel losses of a multi-channel head (instance segmentation: B, C, D ... channels) -----------------------------------
+// biapy/engine/metrics.py:1418-1810 (instance_segmentation_loss, plain channels: no masks / re-balancing / border weights) composed
+// with the training-time head activation of the workflow (base_workflow.py:1403-1457: ce_* channels stay logits, the 'D' channel
+// goes through tanh - instance_seg.py:405-409).  code[c] = kind | act << 2, kind: 0 BCE-with-logits, 1 MSE, 2 L1; act (applied to
+// the logit before MSE / L1): 0 linear, 1 tanh, 2 sigmoid.  Planar fp32 tensors [N][C][vox].
+__device__ __forceinline__ float chan_act(float z, int act, float& dact) {
+  if (act == 1) { const float y = tanhf(z); dact = 1.f - y * y; return y; }
+  if (act == 2) { const float en = expf(-fabsf(z)); const float p = z >= 0.f ? 1.f / (1.f + en) : en / (1.f + en); dact = p * (1.f - p); return p; }
+  dact = 1.f;
+  return z;
+}
+__device__ __forceinline__ float chan_loss_term(float z, float t, int code, float& dz) {
+  const int kind = code & 3, act = (code >> 2) & 3;
+  if (kind == 0) {
+    const float en = expf(-fabsf(z));
+    const float p = z >= 0.f ? 1.f / (1.f + en) : en / (1.f + en);
+    dz = p - t;
+    return fmaxf(z, 0.f) - z * t + log1pf(en);
+  }
+  float da;
+  const float d = chan_act(z, act, da) - t;
+  if (kind == 1) { dz = 2.f * d * da; return d * d; }
+  dz = (d > 0.f ? 1.f : d < 0.f ? -1.f : 0.f) * da;
+  return fabsf(d);
+}
+
+// grid (blocks, N*C): partial sum of the loss terms of plane (n, c) per block -> part[(n*C + c) * gridDim.x + blockIdx.x]
+__global__ void __launch_bounds__(256) chan_loss_sums_kernel(const float* __restrict__ z, const float* __restrict__ t, int64_t vox, int C,
+                                                             unsigned codes, float* __restrict__ part) {
+  const int plane = blockIdx.y, c = plane % C;
+  const int code = (codes >> (4 * c)) & 15;
+  const float* zp = z + (size_t)plane * vox;
+  const float* tp = t + (size_t)plane * vox;
+  float s = 0.f, dz;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vox; i += (int64_t)gridDim.x * 256) s += chan_loss_term(zp[i], tp[i], code, dz);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dlogits[n][c][v] = coef[c] * d term / d logit
+__global__ void __launch_bounds__(256) chan_loss_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t, int64_t vox, int C,
+                                                            unsigned codes, const float* __restrict__ coef, float* __restrict__ dzo) {
+  const int plane = blockIdx.y, c = plane % C;
+  const int code = (codes >> (4 * c)) & 15;
+  const float k = coef[c];
+  const size_t off = (size_t)plane * vox;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vox; i += (int64_t)gridDim.x * 256) {
+    float dz;
+    chan_loss_term(z[off + i], t[off + i], code, dz);
+    dzo[off + i] = k * dz;
+  }
+}
+
+// ---- gate multiply of ResUNet++'s attention block (blocks.py:2168-2298: `out = conv_attn(...) * x2`, a 1-channel map times a
+// C-channel tensor) and its two gradients.  a: channel `a_ch` of an NDHWC tensor with channel stride a.ld.
+template <typename T>
+__global__ void __launch_bounds__(256) gate_mul_fwd_kernel(const T* __restrict__ a, int a_ld, const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
+                                                           int C, int64_t total_vox) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int G = C / KPL;
+  const int64_t total = total_vox * G;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / G;
+    const int gidx = (int)(i - v * G);
+    const float av = ElemTraits<T>::ld(a + v * a_ld);
+    float f[8];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + v * x_ld + gidx * KPL), f);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) f[e] *= av;
+    *reinterpret_cast<u32x4_t*>(y + v * y_ld + gidx * KPL) = pack16<T>(f);
+  }
+}
+
+// dx = dy * a (C channels);  da[v] = sum_c dy[v][c] * x[v][c] written to channel 0 of a 16-channel tensor whose other channels are
+// zeroed (it is the gradient of the zero-padded 16-output 1x1 convolution that produced the gate).  One wave-quarter (16 lanes) per
+// voxel would waste lanes for small C; instead a thread owns one voxel and walks its channels (C * 2 B <= a few cache lines).
+template <typename T>
+__global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ a, int a_ld, const T* __restrict__ x,
+                                                           int x_ld, T* __restrict__ dx, int dx_ld, T* __restrict__ da16, int C, int64_t total_vox) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total_vox; v += (int64_t)gridDim.x * 256) {
+    const float av = ElemTraits<T>::ld(a + v * a_ld);
+    float dot = 0.f;
+    for (int c0 = 0; c0 < C; c0 += KPL) {
+      float g[8], xv[8];
+      unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + c0), g);
+      unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + v * x_ld + c0), xv);
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) { dot += g[e] * xv[e]; g[e] *= av; }
+      *reinterpret_cast<u32x4_t*>(dx + v * dx_ld + c0) = pack16<T>(g);
+    }
+    float o[8] = {dot, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<u32x4_t*>(da16 + v * 16) = pack16<T>(o);
+#pragma unroll
+    for (int q = 1; q < 16 / KPL; ++q) *reinterpret_cast<u32x4_t*>(da16 + v * 16 + q * KPL) = pack16<T>(zz);
+  }
+}
+
 static int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16); }
 
 extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
@@ -1526,6 +1629,60 @@ extern "C" int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* d
   if (src_dtype == BPX_F32 && dst_dtype == BPX_BF16) cast_kernel<float, uint16_t><<<grid_for(n), 256, 0, s>>>((const float*)src_d, (uint16_t*)dst_d, n);
   else if (src_dtype == BPX_BF16 && dst_dtype == BPX_F32) cast_kernel<uint16_t, float><<<grid_for(n), 256, 0, s>>>((const uint16_t*)src_d, (float*)dst_d, n);
   else BPX_FAIL("%s: unsupported conversion %d -> %d", fn, src_dtype, dst_dtype);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_chan_loss_blocks(int64_t voxels) { return (int)std::min<int64_t>(std::max<int64_t>(1, cdiv64(voxels, 1024)), 512); }
+
+extern "C" int bpx_chan_loss_sums(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, float* partials_d,
+                                  bpx_stream_t stream) {
+  const char* fn = "bpx_chan_loss_sums";
+  BPX_CHECK(logits_d && target_d && partials_d, "%s: null pointer", fn);
+  BPX_CHECK(N > 0 && C >= 1 && C <= 8 && voxels > 0, "%s: 1 <= C <= 8 channels", fn);
+  for (int c = 0; c < C; ++c) BPX_CHECK(((codes >> (4 * c)) & 3) <= 2 && ((codes >> (4 * c + 2)) & 3) <= 2, "%s: bad code of channel %d", fn, c);
+  dim3 grid((unsigned)bpx_chan_loss_blocks(voxels), (unsigned)(N * C));
+  chan_loss_sums_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits_d, target_d, voxels, C, codes, partials_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_chan_loss_bwd(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, const float* coef_d,
+                                 float* dlogits_d, bpx_stream_t stream) {
+  const char* fn = "bpx_chan_loss_bwd";
+  BPX_CHECK(logits_d && target_d && coef_d && dlogits_d, "%s: null pointer", fn);
+  BPX_CHECK(N > 0 && C >= 1 && C <= 8 && voxels > 0, "%s: 1 <= C <= 8 channels", fn);
+  dim3 grid((unsigned)std::min<int64_t>(cdiv64(voxels, 256), 1024), (unsigned)(N * C));
+  chan_loss_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits_d, target_d, voxels, C, codes, coef_d, dlogits_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_gate_mul_fwd(int dtype, int64_t total_voxels, bpx_tensor a, bpx_tensor x, bpx_tensor y, bpx_stream_t stream) {
+  const char* fn = "bpx_gate_mul_fwd";
+  BPX_CHECK(a.ptr && x.ptr && y.ptr, "%s: null pointer", fn);
+  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  BPX_CHECK(x.C == y.C && x.C % kpl == 0 && x.ld % kpl == 0 && y.ld % kpl == 0, "%s: channel counts / strides must be multiples of %d", fn, kpl);
+  if (total_voxels == 0) return 0;
+  const int blocks = grid_for(total_voxels * (x.C / kpl));
+  if (dtype == BPX_BF16) gate_mul_fwd_kernel<uint16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)a.ptr, a.ld, (const uint16_t*)x.ptr, x.ld, (uint16_t*)y.ptr, y.ld, x.C, total_voxels);
+  else if (dtype == BPX_F32) gate_mul_fwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)a.ptr, a.ld, (const float*)x.ptr, x.ld, (float*)y.ptr, y.ld, x.C, total_voxels);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_gate_mul_bwd(int dtype, int64_t total_voxels, bpx_tensor dy, bpx_tensor a, bpx_tensor x, bpx_tensor dx, void* da16_d, bpx_stream_t stream) {
+  const char* fn = "bpx_gate_mul_bwd";
+  BPX_CHECK(dy.ptr && a.ptr && x.ptr && dx.ptr && da16_d, "%s: null pointer", fn);
+  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  BPX_CHECK(x.C == dy.C && x.C == dx.C && x.C % kpl == 0 && x.ld % kpl == 0 && dy.ld % kpl == 0 && dx.ld % kpl == 0,
+            "%s: channel counts / strides must be multiples of %d", fn, kpl);
+  if (total_voxels == 0) return 0;
+  const int blocks = grid_for(total_voxels);
+  if (dtype == BPX_BF16) gate_mul_bwd_kernel<uint16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)dy.ptr, dy.ld, (const uint16_t*)a.ptr, a.ld, (const uint16_t*)x.ptr, x.ld, (uint16_t*)dx.ptr, dx.ld, (uint16_t*)da16_d, x.C, total_voxels);
+  else if (dtype == BPX_F32) gate_mul_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dy.ptr, dy.ld, (const float*)a.ptr, a.ld, (const float*)x.ptr, x.ld, (float*)dx.ptr, dx.ld, (float*)da16_d, x.C, total_voxels);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -18,6 +18,24 @@ struct AxisG {
 };
 static inline AxisG to_axis(const bpx_axis_grid& g) { return AxisG{g.n, g.step, g.last, g.patch, g.limit}; }
 
+// Division of a 31-bit index by a launch-uniform divisor as multiply + shift (the row kernels decompose a flat thread index
+// five times; a runtime 64-bit division is ~100 VALU instructions, this is 3): q = (n * m) >> p with p = 31 + ceil(log2 d),
+// m = floor(2^p / d) + 1 - exact for 0 <= n < 2^31 (the launchers check the range).
+struct FastDiv {
+  uint32_t d, m, p;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)n * m) >> p); }
+  __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t k = 0;
+  while ((1ull << k) < d) ++k;
+  f.p = 31 + k;
+  f.m = (uint32_t)(((1ull << f.p) / d) + 1);
+  return f;
+}
+
 // test / A-B hook: 1 = force the element-per-thread kernels of round 1 (bpx_debug_set_tiling_scalar)
 static int g_tiling_scalar = 0;
 extern "C" int bpx_debug_set_tiling_scalar(int on) { g_tiling_scalar = on; return 0; }
@@ -71,30 +89,25 @@ template <> struct CropElem<4> { typedef uint32_t type; };
 template <int ES>
 __global__ void __launch_bounds__(256) crop3d_row_kernel(const unsigned char* __restrict__ vol, unsigned char* __restrict__ out, int Z, int Y,
                                                          int X, int C, int pz, int py, int px, int mode, AxisG gz, AxisG gy, AxisG gx,
-                                                         int64_t c_begin, int64_t total_vec, int qpr) {
+                                                         uint32_t c_begin_lo, uint32_t total_vec, FastDiv dq, FastDiv dPy, FastDiv dPz, FastDiv dnx,
+                                                         FastDiv dny, FastDiv dC) {
   typedef typename CropElem<ES>::type E;
   constexpr int VEC = 16 / ES;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= total_vec) return;
-  const int64_t rowid = t / qpr;
-  const int q = (int)(t - rowid * qpr);
-  const int Pz = gz.patch, Py = gy.patch;
-  const int64_t r1 = rowid / Py;
-  const int ly = (int)(rowid - r1 * Py);
-  const int64_t r2 = r1 / Pz;
-  const int lz = (int)(r1 - r2 * Pz);
-  const int64_t c = c_begin + r2;
-  const int64_t c1 = c / gx.n;
-  const int ix = (int)(c - c1 * gx.n);
-  const int iz = (int)(c1 / gy.n);
-  const int iy = (int)(c1 - (int64_t)iz * gy.n);
+  uint32_t rowid, q, r1, ly, r2, lz, c1, ix, iz, iy;
+  dq.divmod(t, rowid, q);
+  dPy.divmod(rowid, r1, ly);
+  dPz.divmod(r1, r2, lz);
+  dnx.divmod(c_begin_lo + r2, c1, ix);
+  dny.divmod(c1, iz, iy);
   bool inside = true;
-  const int sz = pad_src(gz.start(iz) + lz - pz, Z, mode, inside);
-  const int sy = pad_src(gy.start(iy) + ly - py, Y, mode, inside);
-  const int e0 = q * VEC;
-  const int x0 = e0 / C, ch0 = e0 - x0 * C;
-  const int xs = gx.start(ix) - px;                                // source x of patch column 0
-  const int xl = x0 + (ch0 + VEC - 1) / C;                         // patch column of the vector's last element
+  const int sz = pad_src(gz.start((int)iz) + (int)lz - pz, Z, mode, inside);
+  const int sy = pad_src(gy.start((int)iy) + (int)ly - py, Y, mode, inside);
+  const int e0 = (int)q * VEC;
+  const int x0 = (int)dC.div((uint32_t)e0), ch0 = e0 - x0 * C;
+  const int xs = gx.start((int)ix) - px;                           // source x of patch column 0
+  const int xl = (int)dC.div((uint32_t)(e0 + VEC - 1));            // patch column of the vector's last element
   const unsigned char* srow = vol + ((size_t)sz * Y + sy) * (size_t)X * C * ES;
   u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
   if (inside) {
@@ -130,16 +143,25 @@ extern "C" int bpx_crop3d_gather(const void* vol_d, int elem_size, int Z, int Y,
   hipStream_t s = (hipStream_t)stream;
   AxisG gz = to_axis(g[0]), gy = to_axis(g[1]), gx = to_axis(g[2]);
   const int64_t row_bytes = (int64_t)g[2].patch * C * elem_size;
-  if (row_bytes % 16 == 0 && ((uintptr_t)out_d & 15) == 0 && !g_tiling_scalar) {
-    const int64_t total_vec = total * elem_size / 16;
+  if (row_bytes % 16 == 0 && ((uintptr_t)out_d & 15) == 0 && !g_tiling_scalar && n_all < (1ll << 30)) {
+    // 31-bit thread indices per launch (FastDiv): a larger request is cut into launches of whole patches
+    const int64_t vec_per_patch = (int64_t)g[0].patch * g[1].patch * g[2].patch * C * elem_size / 16;
     const int qpr = (int)(row_bytes / 16);
-    const int64_t nb = cdiv64(total_vec, 256);
-    BPX_CHECK(nb < (1ll << 31), "bpx_crop3d_gather: too many patches for one launch");
-    const unsigned char* v8 = (const unsigned char*)vol_d;
-    unsigned char* o8 = (unsigned char*)out_d;
-    if (elem_size == 4) crop3d_row_kernel<4><<<(unsigned)nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total_vec, qpr);
-    else if (elem_size == 2) crop3d_row_kernel<2><<<(unsigned)nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total_vec, qpr);
-    else crop3d_row_kernel<1><<<(unsigned)nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, c_begin, total_vec, qpr);
+    BPX_CHECK(vec_per_patch < (1ll << 30), "bpx_crop3d_gather: patch too large");
+    const int64_t per_launch = std::max<int64_t>(1, ((1ll << 30) - 1) / vec_per_patch);
+    const FastDiv dq = make_fastdiv((uint32_t)qpr), dPy = make_fastdiv((uint32_t)g[1].patch), dPz = make_fastdiv((uint32_t)g[0].patch),
+                  dnx = make_fastdiv((uint32_t)g[2].n), dny = make_fastdiv((uint32_t)g[1].n), dC = make_fastdiv((uint32_t)C);
+    for (int64_t c0 = 0; c0 < c_count; c0 += per_launch) {
+      const int64_t cn = std::min(per_launch, c_count - c0);
+      const uint32_t total_vec = (uint32_t)(cn * vec_per_patch);
+      const unsigned nb = (unsigned)cdiv64(total_vec, 256);
+      const unsigned char* v8 = (const unsigned char*)vol_d;
+      unsigned char* o8 = (unsigned char*)out_d + (size_t)c0 * vec_per_patch * 16;
+      const uint32_t cb = (uint32_t)(c_begin + c0);
+      if (elem_size == 4) crop3d_row_kernel<4><<<nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, cb, total_vec, dq, dPy, dPz, dnx, dny, dC);
+      else if (elem_size == 2) crop3d_row_kernel<2><<<nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, cb, total_vec, dq, dPy, dPz, dnx, dny, dC);
+      else crop3d_row_kernel<1><<<nb, 256, 0, s>>>(v8, o8, Z, Y, X, C, pad_z, pad_y, pad_x, pad_mode, gz, gy, gx, cb, total_vec, dq, dPy, dPz, dnx, dny, dC);
+    }
     BPX_LAUNCH_CHECK("bpx_crop3d_gather");
     return 0;
   }
@@ -346,25 +368,45 @@ template <> struct MergeVec<float> { static constexpr int VEC = 4; };
 template <> struct MergeVec<__half> { static constexpr int VEC = 8; };
 template <> struct MergeVec<uint8_t> { static constexpr int VEC = 8; };
 
+__device__ __forceinline__ void cover_range_fast(const AxisG& g, const FastDiv& ds, int q, int& lo, int& hi) {
+  const int t = q - g.patch;
+  lo = t < 0 ? 0 : (int)ds.div((uint32_t)t) + 1;
+  hi = (int)ds.div((uint32_t)(q + g.last));
+  if (hi > g.n - 1) hi = g.n - 1;
+}
+
+struct MergeDivs { FastDiv q, Y, C, sz, sy, sx; };
+
+// One covering patch of a vector: its VEC values (zero where the element lies outside the patch), the row weight fl(wz*wy),
+// the patch start along x and the per-element validity mask.  Up to 3 x 3 (y, x) patches of one z row are LOADED FIRST (nine
+// independent wide loads in flight per thread - the kernel is a latency-bound gather otherwise) and then accumulated in the
+// reference's order; geometries with more than three covering patches along y or x (overlap > 2/3) take the sequential path.
+template <typename EI, int VEC> struct MergeSlot {
+  EI v[VEC];
+  float wzy;
+  int sx;
+  unsigned mask;
+};
+
 template <typename EI, typename EO>
 __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__ patches, int Pzf, int Pyf, int Pxf, int C, int pz, int py,
                                                           int px, AxisG gz, AxisG gy, AxisG gx, const float* __restrict__ wz,
                                                           const float* __restrict__ wy, const float* __restrict__ wx, int Y, int X,
                                                           int z_lo, int zrow_lo, int zrow_hi, float* acc, float* wacc, int flags,
-                                                          EO* __restrict__ out, int64_t total_vec, int qpr) {
+                                                          EO* __restrict__ out, uint32_t total_vec, uint32_t t_base, MergeDivs dv) {
   constexpr int VEC = MergeVec<EI>::VEC;
   __shared__ float swx[MERGE_WXMAX];                              // the x taper (the launcher checks gx.patch <= MERGE_WXMAX)
   for (int i = threadIdx.x; i < gx.patch; i += 256) swx[i] = wx[i];
   __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total_vec) return;
-  const int64_t row = t / qpr;                                    // (z - z_lo) * Y + y
-  const int q = (int)(t - row * qpr);
-  const int zr = (int)(row / Y);
-  const int y = (int)(row - (int64_t)zr * Y);
-  const int z = zr + z_lo;
-  const int e0 = q * VEC;
-  const int x0 = e0 / C, ch0 = e0 - x0 * C;
+  const uint32_t tl = blockIdx.x * 256u + threadIdx.x;
+  if (tl >= total_vec) return;
+  uint32_t row, q, zr, yu;
+  dv.q.divmod(tl, row, q);                                        // row = (z - z_lo') * Y + y inside this launch
+  dv.Y.divmod(row, zr, yu);
+  const int y = (int)yu;
+  const int z = (int)zr + z_lo;
+  const int e0 = (int)q * VEC;
+  const int x0 = (int)dv.C.div((uint32_t)e0), ch0 = e0 - x0 * C;
   int xk[VEC];
   {
     int x = x0, ch = ch0;
@@ -374,8 +416,9 @@ __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__
       if (++ch == C) { ch = 0; ++x; }
     }
   }
-  const int64_t i0 = row * (int64_t)X * C + e0;                   // flat index of element 0 in the [z_hi-z_lo][Y][X][C] arrays
-  const int64_t v0 = row * (int64_t)X;                            // voxel index of x = 0 of this row
+  const int64_t grow = (int64_t)(t_base / dv.q.d) + row;           // row index inside the [z_hi-z_lo][Y][X][C] arrays of the CALL
+  const int64_t i0 = grow * (int64_t)X * C + e0;                   // flat index of element 0
+  const int64_t v0 = grow * (int64_t)X;                            // voxel index of x = 0 of this row
   float num[VEC], ws[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) { num[k] = 0.f; ws[k] = 0.f; }
@@ -384,48 +427,84 @@ __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__
     for (int k = 0; k < VEC; ++k) { num[k] = acc[i0 + k]; ws[k] = wacc[v0 + xk[k]]; }
   }
   int zl, zh, yl, yh, xl, xh, dummy;
-  cover_range(gz, z, zl, zh);
-  cover_range(gy, y, yl, yh);
-  cover_range(gx, xk[0], xl, dummy);
-  cover_range(gx, xk[VEC - 1], dummy, xh);
+  cover_range_fast(gz, dv.sz, z, zl, zh);
+  cover_range_fast(gy, dv.sy, y, yl, yh);
+  cover_range_fast(gx, dv.sx, xk[0], xl, dummy);
+  cover_range_fast(gx, dv.sx, xk[VEC - 1], dummy, xh);
   if (zl < zrow_lo) zl = zrow_lo;
   if (zh > zrow_hi - 1) zh = zrow_hi - 1;
   const int pstride_y = Pxf * C, pstride_z = pstride_y * Pyf;
   const int64_t pstride_c = (int64_t)pstride_z * Pzf;
+  const bool batched = (yh - yl) < 3 && (xh - xl) < 3;
+
+  auto accumulate = [&](const EI* v, float wzy, int sx, unsigned mask) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (mask & (1u << k)) {
+        const float w = __fmul_rn(wzy, swx[xk[k] - sx]);
+        num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(&v[k]), w));
+        ws[k] = __fadd_rn(ws[k], w);
+      }
+    }
+  };
+  // loads the VEC values of patch (row pointer prow, column ix) that cover this vector; returns the validity mask (0 = none)
+  auto fetch = [&](const EI* prow, int ix, EI* v, int& sx_out) -> unsigned {
+    const int sx = gx.start(ix);
+    sx_out = sx;
+    const int l0 = xk[0] - sx, l1 = xk[VEC - 1] - sx;
+    if (l1 < 0 || l0 >= gx.patch) return 0u;
+    const EI* pp = prow + (int64_t)ix * pstride_c + ((px - sx) * C + e0);   // element k of the vector is pp[k] when it is inside
+    if (l0 >= 0 && l1 < gx.patch) {
+      __builtin_memcpy(v, pp, sizeof(EI) * VEC);                    // one wide (possibly misaligned) load
+      return (1u << VEC) - 1u;
+    }
+    unsigned mask = 0u;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int lx = xk[k] - sx;
+      v[k] = EI(0);
+      if (lx >= 0 && lx < gx.patch) { v[k] = pp[k]; mask |= 1u << k; }
+    }
+    return mask;
+  };
+
   for (int iz = zl; iz <= zh; ++iz) {
     const int lz = z - gz.start(iz);
     if (lz < 0 || lz >= gz.patch) continue;
     const float wzv = wz[lz];
-    for (int iy = yl; iy <= yh; ++iy) {
-      const int ly = y - gy.start(iy);
-      if (ly < 0 || ly >= gy.patch) continue;
-      const float wzy = __fmul_rn(wzv, wy[ly]);
-      const EI* prow = patches + ((int64_t)(iz - zrow_lo) * gy.n + iy) * gx.n * pstride_c + ((lz + pz) * pstride_z + (ly + py) * pstride_y);
-      for (int ix = xl; ix <= xh; ++ix) {
-        const int sx = gx.start(ix);
-        const int l0 = xk[0] - sx, l1 = xk[VEC - 1] - sx;
-        if (l1 < 0 || l0 >= gx.patch) continue;
-        const EI* pp = prow + (int64_t)ix * pstride_c + ((px - sx) * C + e0);   // element k of the vector is pp[k] when it is inside
-        if (l0 >= 0 && l1 < gx.patch) {
+    const EI* pz_base = patches + (int64_t)(iz - zrow_lo) * gy.n * gx.n * pstride_c + (lz + pz) * pstride_z;
+    if (batched) {
+      MergeSlot<EI, VEC> slot[9];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int iy = yl + j;
+        const int ly = y - gy.start(iy);
+        const bool oky = iy <= yh && ly >= 0 && ly < gy.patch;
+        const float wzy = oky ? __fmul_rn(wzv, wy[ly]) : 0.f;
+        const EI* prow = pz_base + (int64_t)iy * gx.n * pstride_c + (ly + py) * pstride_y;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          MergeSlot<EI, VEC>& sl = slot[j * 3 + i];
+          sl.mask = 0u;
+          sl.wzy = wzy;
+          sl.sx = 0;
+          if (oky && xl + i <= xh) sl.mask = fetch(prow, xl + i, sl.v, sl.sx);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 9; ++b)
+        if (slot[b].mask) accumulate(slot[b].v, slot[b].wzy, slot[b].sx, slot[b].mask);
+    } else {
+      for (int iy = yl; iy <= yh; ++iy) {
+        const int ly = y - gy.start(iy);
+        if (ly < 0 || ly >= gy.patch) continue;
+        const float wzy = __fmul_rn(wzv, wy[ly]);
+        const EI* prow = pz_base + (int64_t)iy * gx.n * pstride_c + (ly + py) * pstride_y;
+        for (int ix = xl; ix <= xh; ++ix) {
           EI v[VEC];
-          __builtin_memcpy(v, pp, sizeof(v));                       // one wide (possibly misaligned) load
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) {
-            const int lx = xk[k] - sx;
-            const float w = __fmul_rn(wzy, swx[lx]);
-            num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(&v[k]), w));
-            ws[k] = __fadd_rn(ws[k], w);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < VEC; ++k) {
-            const int lx = xk[k] - sx;
-            if (lx >= 0 && lx < gx.patch) {
-              const float w = __fmul_rn(wzy, swx[lx]);
-              num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(pp + k), w));
-              ws[k] = __fadd_rn(ws[k], w);
-            }
-          }
+          int sx;
+          const unsigned mask = fetch(prow, ix, v, sx);
+          if (mask) accumulate(v, wzy, sx, mask);
         }
       }
     }
@@ -470,29 +549,39 @@ extern "C" int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int P
     // vector path: rows of whole vectors, 16-byte aligned output, patch strides that fit 32 bits
     const int vec = dtype == BPX_F32 ? 4 : 8;
     const size_t oes = dtype_size(out_dtype);
-    const bool row_ok = ((int64_t)X * C) % vec == 0 && (int64_t)Px * Py * Pz * C < (1ll << 31) && g[2].patch <= MERGE_WXMAX;
+    const bool row_ok = ((int64_t)X * C) % vec == 0 && (int64_t)Px * Py * Pz * C < (1ll << 31) && g[2].patch <= MERGE_WXMAX && Z < (1 << 29) &&
+                        Y < (1 << 29) && X < (1 << 29);
     const bool al_ok = (flags & 1) ? (((uintptr_t)acc_d & 15) == 0) : (((uintptr_t)out_d & 15) == 0);
-    if (row_ok && al_ok && !g_tiling_scalar) {
-      const int qpr = (int)(((int64_t)X * C) / vec);
-      const int64_t total_vec = total / vec;
-      const int64_t nb = cdiv64(total_vec, 256);
-      BPX_CHECK(nb < (1ll << 31), "bpx_merge3d_blend: volume too large for one launch");
+    const int combo = dtype == BPX_F32 && out_dtype == BPX_F32 ? 0 : dtype == BPX_U8 && out_dtype == BPX_U8 ? 1 : dtype == BPX_F16 && out_dtype == BPX_F16 ? 2
+                      : dtype == BPX_F16 && out_dtype == BPX_F32 ? 3 : dtype == BPX_U8 && out_dtype == BPX_F32 ? 4 : -1;
+    const int qpr = row_ok ? (int)(((int64_t)X * C) / vec) : 0;
+    if (row_ok && al_ok && combo >= 0 && !g_tiling_scalar && (int64_t)Y * qpr < (1ll << 30)) {
       (void)oes;
-#define MERGE_ROW(EI, EO)                                                                                                              \
-  merge3d_row_kernel<EI, EO><<<(unsigned)nb, 256, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, \
-                                                          wx_d, Y, X, z_lo, zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d, total_vec, qpr)
-      bool done = true;
-      if (dtype == BPX_F32 && out_dtype == BPX_F32) MERGE_ROW(float, float);
-      else if (dtype == BPX_U8 && out_dtype == BPX_U8) MERGE_ROW(uint8_t, uint8_t);
-      else if (dtype == BPX_F16 && out_dtype == BPX_F16) MERGE_ROW(__half, __half);
-      else if (dtype == BPX_F16 && out_dtype == BPX_F32) MERGE_ROW(__half, float);
-      else if (dtype == BPX_U8 && out_dtype == BPX_F32) MERGE_ROW(uint8_t, float);
-      else done = false;
+      // 31-bit thread indices per launch (FastDiv): a taller slab is cut into launches of whole z slices
+      const int64_t vec_per_slice = (int64_t)Y * qpr;
+      const int slices_per_launch = (int)std::max<int64_t>(1, ((1ll << 30) - 1) / vec_per_slice);
+      MergeDivs dv{make_fastdiv((uint32_t)qpr), make_fastdiv((uint32_t)Y), make_fastdiv((uint32_t)C), make_fastdiv((uint32_t)g[0].step),
+                   make_fastdiv((uint32_t)g[1].step), make_fastdiv((uint32_t)g[2].step)};
+      for (int za = z_lo; za < z_hi; za += slices_per_launch) {
+        const int zn = std::min(slices_per_launch, z_hi - za);
+        const uint32_t total_vec = (uint32_t)(zn * vec_per_slice);
+        const unsigned nb = (unsigned)cdiv64(total_vec, 256);
+        // element / voxel offsets of this launch inside the call's arrays are carried by t_base (in vectors of the call)
+        const int64_t tb64 = (int64_t)(za - z_lo) * vec_per_slice;
+        BPX_CHECK(tb64 < (1ll << 32), "bpx_merge3d_blend: slab too large");
+        const uint32_t tb = (uint32_t)tb64;
+#define MERGE_ROW(EI, EO)                                                                                                                   \
+  merge3d_row_kernel<EI, EO><<<nb, 256, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, wx_d, Y, X, za, \
+                                                zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d, total_vec, tb, dv)
+        if (combo == 0) MERGE_ROW(float, float);
+        else if (combo == 1) MERGE_ROW(uint8_t, uint8_t);
+        else if (combo == 2) MERGE_ROW(__half, __half);
+        else if (combo == 3) MERGE_ROW(__half, float);
+        else MERGE_ROW(uint8_t, float);
 #undef MERGE_ROW
-      if (done) {
-        BPX_LAUNCH_CHECK("bpx_merge3d_blend");
-        return 0;
       }
+      BPX_LAUNCH_CHECK("bpx_merge3d_blend");
+      return 0;
     }
   }
 #define MERGE_LAUNCH(EI, EO)                                                                                                   \

@@ -53,7 +53,13 @@ class SlabPlan:
 
 
 def plan_slabs(row_starts: Sequence[int], core_patch_z: int, Z: int, world: int) -> List[SlabPlan]:
+    """Z-slab partition of the patch rows.  Needs non-decreasing row starts: the reference's placement rule shifts EVERY patch that
+    would cross the volume end back by ``last`` (data_3D_manipulation.py:596-598), so with overlaps above 50 % on a volume of only
+    a few patch lengths the starts can run backwards (e.g. 0,2,4,6,4,6,8) and a slice is no longer owned by consecutive ranks -
+    such a volume is blended on one rank (it is tiny by construction)."""
     n_rows = len(row_starts)
+    if world > 1 and any(row_starts[i] > row_starts[i + 1] for i in range(n_rows - 1)):
+        raise ValueError(f"patch rows start at {list(row_starts)}: not monotonic, this geometry cannot be sharded by Z-slab (use world = 1)")
     ranges = split_rows(n_rows, world)
     active = [r for r in range(world) if ranges[r][1] > ranges[r][0]]
     plans: List[SlabPlan] = []

@@ -40,6 +40,7 @@ int bpx_selftest_layouts(float* out_d /* 1024 floats */, bpx_stream_t stream);
 int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test / A-B hook of the bf16 3x3x3 conv schedule: 0 = automatic, 4 = always the double-buffered kernel, 5 = always the lean persistent one */
+int bpx_debug_set_conv_occ(int wg_per_cu); /* test / A-B hook: persistent workgroups per CU of the lean bf16 conv kernel (0 = built-in table) */
 int bpx_debug_set_tiling_scalar(int on); /* test / A-B hook: 1 = crop / merge through the element-per-thread kernels instead of the 16-byte row kernels */
 
 /* ------------------------------------------------------------------------------------------------
@@ -296,6 +297,28 @@ int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64
 int bpx_seg_loss_blocks(int64_t n);
 int bpx_seg_loss_sums(const float* logits_d, const float* target_d, int64_t n, float* partials_d, bpx_stream_t stream);
 int bpx_seg_loss_bwd(const float* logits_d, const float* target_d, int64_t n, const float* coef_d, float* dlogits_d, bpx_stream_t stream);
+
+/* ---- per-channel losses of a multi-channel head (row X / cfg 4: instance segmentation with B, C, D channels) ------------------------------
+ * Replaces biapy/engine/metrics.py:1418-1810 (instance_segmentation_loss; plain channels: no masks, class re-balancing or border
+ * weights) composed with the training-time head activation the workflow applies before it (base_workflow.py:1403-1457: ce_* channels
+ * stay logits, other channels - 'D': tanh, instance_seg.py:405-409 - are activated).  codes: one 4-bit code per channel (channel 0
+ * in the low nibble) = kind | act << 2; kind 0 = BCE with logits, 1 = MSE, 2 = L1; act (of the logit, for MSE / L1) 0 = linear,
+ * 1 = tanh, 2 = sigmoid.  Planar fp32 logits / targets [N][C][voxels], C <= 8.
+ *   bpx_chan_loss_sums: partials_d[(n*C + c) * bpx_chan_loss_blocks(voxels) + b] = partial sums of the per-element loss terms;
+ *                       the caller reduces them (deterministic) and forms  sum_c w_c * S_c / (N * voxels).
+ *   bpx_chan_loss_bwd : dlogits = coef_d[c] * d term / d logit  with coef_d[c] = upstream gradient * w_c / (N * voxels) on the device. */
+int bpx_chan_loss_blocks(int64_t voxels);
+int bpx_chan_loss_sums(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, float* partials_d,
+                       bpx_stream_t stream);
+int bpx_chan_loss_bwd(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, const float* coef_d,
+                      float* dlogits_d, bpx_stream_t stream);
+
+/* ---- attention gate of ResUNet++ (biapy/models/blocks.py:2168-2298, `return out * x2`: a 1-channel map times a C-channel tensor) ----
+ * fwd: y[v][c] = a[v] * x[v][c], a = the FIRST channel of tensor `a` (channel stride a.ld);  bwd: dx = dy * a and
+ * da16[v][0] = sum_c dy[v][c] * x[v][c], da16[v][1..15] = 0 (a dense 16-channel tensor: the gradient of the zero-padded 16-output
+ * 1x1 convolution that produced the gate).  total_voxels = N * voxels per sample. */
+int bpx_gate_mul_fwd(int dtype, int64_t total_voxels, bpx_tensor a, bpx_tensor x, bpx_tensor y, bpx_stream_t stream);
+int bpx_gate_mul_bwd(int dtype, int64_t total_voxels, bpx_tensor dy, bpx_tensor a, bpx_tensor x, bpx_tensor dx, void* da16_d, bpx_stream_t stream);
 
 /* ---- scans either side of the network ---------------------------------------------------------------
  * Input normalisation (biapy/data/norm.py: percentile_clip :395-473 -> np.percentile, zero_mean_unit_variance_normalization

@@ -47,6 +47,8 @@ def main():
     st = L.stream_ptr()
     if os.environ.get('BPX_WS') is not None:
         lib.bpx_debug_set_conv_ws(int(os.environ['BPX_WS']))
+    if os.environ.get('BPX_OCC') is not None:
+        lib.bpx_debug_set_conv_occ(int(os.environ['BPX_OCC']))
 
     def pack(w, mode, cin, cout):
         n = lib.bpx_packed_weight_elems(mode, cin, cout, dt)

@@ -60,12 +60,18 @@ def install():
         stub("torchvision.ops")
         stub("torchvision.ops.stochastic_depth", StochasticDepth=_Identity)
         stub("torchvision.ops.misc", Permute=_Identity)
+        tv = sys.modules["torchvision"]
+        tv.transforms = stub("torchvision.transforms")                       # biapy/engine/metrics.py:21-22 (perceptual losses only)
+        stub("torchvision.models", vgg16=None, VGG16_Weights=None)
     for mod, attrs in [
         ("h5py", dict(File=object, Dataset=object, Group=object)),
         ("zarr", dict(Array=object, Group=object)),
         ("tensorboardX", dict(SummaryWriter=object)),
         ("yacs", {}),
         ("yacs.config", dict(CfgNode=type("CfgNode", (dict,), {}))),
+        ("torchmetrics", dict(JaccardIndex=object)),                           # biapy/engine/metrics.py:16-18: metric classes the loss
+        ("torchmetrics.image", dict(StructuralSimilarityIndexMeasure=object)),  # classes pinned here never touch
+        ("pytorch_msssim", dict(SSIM=object)),
     ]:
         try:
             importlib.import_module(mod)

@@ -609,6 +609,51 @@ def resunetpp_fixtures():
     print("resunetpp_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunetpp_golden.npz")) // 1024, "KiB")
 
 
+def loss_inputs(seed=61, shape=(2, 6, 10, 12)):
+    """Seeded logits / targets of the loss fixture (tests rebuild exactly these)."""
+    g = torch.Generator().manual_seed(seed)
+    B = shape[0]
+    z1 = torch.randn(B, 1, *shape[1:], generator=g) * 2.0
+    t1 = (torch.rand(B, 1, *shape[1:], generator=g) > 0.6).float()
+    z3 = torch.randn(B, 3, *shape[1:], generator=g) * 1.5
+    t3 = torch.cat([(torch.rand(B, 2, *shape[1:], generator=g) > 0.5).float(), torch.rand(B, 1, *shape[1:], generator=g) * 2 - 1], 1)
+    return z1, t1, z3, t3
+
+
+def losses_fixtures():
+    """Rows L and X: the reference's own loss classes (biapy/engine/metrics.py) on seeded inputs - value and gradient w.r.t. the
+    logits of CrossEntropyLoss_wrapper (binary), DiceLoss, DiceCELoss (two weightings) and instance_segmentation_loss for the
+    B, C, D channels (bce, bce, mse|l1; the D channel through tanh as the workflow applies it in training)."""
+    met = shim.load("biapy.engine.metrics")
+    z1, t1, z3, t3 = loss_inputs()
+    out = {}
+
+    def rec(name, fn, z):
+        zz = z.clone().requires_grad_(True)
+        val = fn(zz)
+        val.backward()
+        out[f"{name}/value"] = np.float64(val.item())
+        out[f"{name}/grad"] = zz.grad.numpy().copy()
+        print(name, val.item())
+
+    rec("bce", lambda z: met.CrossEntropyLoss_wrapper(num_classes=2, ndim=3)(z, t1), z1)
+    rec("dice", lambda z: met.DiceLoss(batch_dice=True)(z, t1), z1)
+    rec("dice_ce_1_1", lambda z: met.DiceCELoss(num_classes=2, ndim=3)(z, t1), z1)
+    rec("dice_ce_03_17", lambda z: met.DiceCELoss(num_classes=2, ndim=3, w_ce=0.3, w_dice=1.7)(z, t1), z1)
+    acts = ["ce_sigmoid", "ce_sigmoid", "tanh"]
+
+    def train_act(z):           # what model_call_func(is_train=True) does to the logits (base_workflow.py:1403-1457)
+        return torch.cat([z[:, 0:1], z[:, 1:2], torch.tanh(z[:, 2:3])], 1)
+
+    for tag, losses, w in (("bcd_mse", ["bce", "bce", "mse"], (1, 1, 1)), ("bcd_l1_w", ["bce", "bce", "l1"], (0.5, 0.25, 2.0))):
+        crit = met.instance_segmentation_loss(channel_weights=w, ndim=3, out_channels=["B", "C", "D"], losses_to_use=losses,
+                                              channel_extra_opts={}, gt_channels_expected=3)
+        rec(f"instance_{tag}", lambda z, crit=crit: crit(train_act(z), t3), z3)
+    del acts
+    np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
+    print("losses_golden.npz:", len(out), "arrays")
+
+
 def train_loop_case(name):
     """Seeded toy problem of the train-loop fixture: (net, data, val data, cfg values).  Tests rebuild exactly this."""
     import types
@@ -679,7 +724,7 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -704,3 +749,5 @@ if __name__ == "__main__":
         resunetpp_fixtures()
     if "train_loop" in which:
         train_loop_fixtures()
+    if "losses" in which:
+        losses_fixtures()

@@ -190,7 +190,8 @@ def check_tiling_row_kernels(n_cases=40, seed=7):
         n_vec += int((vol[2] * C) % (4 if np_dt == np.float32 else 8) == 0)
         # sharded: two row ranges, the boundary handed over as partial sums
         nz = plan.grid[0].n
-        if nz >= 2 and np_dt == np.float32:
+        starts = [plan.row_start(i) for i in range(nz)]
+        if nz >= 2 and np_dt == np.float32 and starts == sorted(starts):     # (non-monotonic starts cannot be sharded: workflow.plan_slabs)
             ny, nx = plan.grid[1].n, plan.grid[2].n
             h = nz // 2
             core = patch[0] - 2 * pad[0]
@@ -754,12 +755,12 @@ def check_network_cfg2_benched_shape(dtype):
     res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, 2e-4 if f32 else 6e-2, extra=f"scale={scale:.3f}")]
     res += parity_rows(tag + ".b1", lo1, lo_ref, tgt[:1], dtype)
     res.append(_res(tag + ".b1.loss", abs(loss1 - loss_ref.item()), 1e-5 if f32 else 2e-2))
+    # conv biases in front of an InstanceNorm have a ZERO true gradient (what both sides hold is rounding noise of 2 M-term sums):
+    # errors are measured against max(|g_ref|, 1e-4 * the largest gradient norm of the network)
+    gmax = max(gr.norm().item() for gr in grads_ref.values())
     worst, wname = 0.0, ""
     for k, gr in grads_ref.items():
-        denom = gr.norm().item()
-        e = (G1[k] - gr).norm().item() / (denom + 1e-6 * max(1.0, gr.numel() ** 0.5))
-        if denom < 1e-7:
-            e = (G1[k] - gr).abs().max().item() / 1e-3
+        e = (G1[k] - gr).norm().item() / max(gr.norm().item(), 1e-4 * gmax)
         if e > worst:
             worst, wname = e, k
     res.append(_res(tag + ".b1.grads_rel_l2_worst", worst, 2e-3 if f32 else 0.15, extra=wname))
@@ -769,9 +770,10 @@ def check_network_cfg2_benched_shape(dtype):
     res.append(_res(tag + ".b4.logits_equal_batch1_runs", sum(int((lo4[b] != singles[b][0][0]).sum()) for b in range(4)), 0))
     res.append(_res(tag + ".b4.loss", abs(loss4 - sum(s_[1] for s_ in singles) / 4), 1e-6 if f32 else 1e-5))
     worst, wname = 0.0, ""
+    gmax4 = max(v.norm().item() for v in G4.values())
     for k in G4:
         mean = sum(s_[2][k] for s_ in singles) / 4
-        e = (G4[k] - mean).norm().item() / (mean.norm().item() + 1e-6 * max(1.0, mean.numel() ** 0.5))
+        e = (G4[k] - mean).norm().item() / max(mean.norm().item(), 1e-4 * gmax4)
         if e > worst:
             worst, wname = e, k
     res.append(_res(tag + ".b4.grads_vs_mean_of_batch1_grads", worst, 1e-4 if f32 else 2e-3, extra=wname))

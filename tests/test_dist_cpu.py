@@ -133,6 +133,15 @@ def test_input_slab_is_what_the_ranks_patches_read():
     assert tiling.crop_rows_needed((1024, 1024, 1024), (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0), 0, 16) == (0, 1024)
 
 
+def test_plan_slabs_rejects_backward_running_rows():
+    """The reference's shift-back rule can make patch starts non-monotonic (overlap > 50 % on a short axis): not shardable."""
+    g = T.merge_grid((14, 10, 40), (6, 9, 20), (0.6, 0.25, 0.6), (0, 2, 0))
+    assert list(g[0].starts()) == [0, 2, 4, 6, 4, 6, 8]
+    workflow.plan_slabs(g[0].starts(), 6, 14, 1)
+    with pytest.raises(ValueError, match="not monotonic"):
+        workflow.plan_slabs(g[0].starts(), 6, 14, 2)
+
+
 def test_plan_slabs_cfg3():
     """cfg 3: 16 patch rows (starts 0,60,..,840,896), 8 GPUs -> two rows each, 68-slice hand-over, disjoint cover of [0,1024)."""
     g = T.merge_grid((1024, 1024, 1024), (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0))

@@ -422,3 +422,31 @@ def test_resunetpp_oracle_matches_reference(resunetpp_golden):
             assert (sd[k[5:]].grad - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
         if k.startswith("gradnorm/") and float(g[k]) > 1e-6:
             assert abs(sd[k[9:]].grad.norm().item() - float(g[k])) <= 1e-3 * float(g[k]), k
+
+
+def test_loss_oracle_matches_the_reference_loss_classes():
+    """oracle/loss_oracle.py against the reference's own CrossEntropyLoss_wrapper / DiceLoss / DiceCELoss /
+    instance_segmentation_loss (biapy/engine/metrics.py:493-586, :726-762, :764-973, :1418-1810) on seeded inputs: value and the
+    gradient w.r.t. the logits (tests/golden/losses_golden.npz, generated by importing the reference)."""
+    import os
+
+    from make_golden import loss_inputs
+    from oracle import loss_oracle as LO
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses_golden.npz"))
+    z1, t1, z3, t3 = loss_inputs()
+
+    def check(name, fn, z):
+        zz = z.clone().requires_grad_(True)
+        val = fn(zz)
+        val.backward()
+        assert abs(val.item() - float(gold[f"{name}/value"])) < 1e-6, name
+        assert np.abs(zz.grad.numpy() - gold[f"{name}/grad"]).max() < 1e-8 + 1e-5 * np.abs(gold[f"{name}/grad"]).max(), name
+
+    check("bce", lambda z: LO.bce(z, t1), z1)
+    check("dice", lambda z: LO.dice(z, t1), z1)
+    check("dice_ce_1_1", lambda z: LO.dice_ce(z, t1), z1)
+    check("dice_ce_03_17", lambda z: LO.dice_ce(z, t1, 0.3, 1.7), z1)
+    acts = ["ce_sigmoid", "ce_sigmoid", "tanh"]
+    check("instance_bcd_mse", lambda z: LO.instance_channels(LO.apply_head_activations(z, acts), t3, ["bce", "bce", "mse"], (1, 1, 1)), z3)
+    check("instance_bcd_l1_w", lambda z: LO.instance_channels(LO.apply_head_activations(z, acts), t3, ["bce", "bce", "l1"], (0.5, 0.25, 2.0)), z3)
