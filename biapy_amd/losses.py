@@ -102,3 +102,73 @@ def hard_dice(logits: torch.Tensor, target: torch.Tensor, smooth: float = 1e-5) 
     z, t = _prep(logits, target)
     s = _sums(z, t)
     return ((2.0 * s[4] + smooth) / (s[4] + s[5] + smooth)).to(torch.float32)   # |P| + |T| = |P&T| + |P|T|
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# multi-channel heads (row X / cfg 4: instance segmentation with B, C, D channels)
+# ---------------------------------------------------------------------------------------------------------------------------
+_KIND = {"bce": 0, "mse": 1, "l1": 2, "mae": 2}
+_ACT = {"linear": 0, "ce_sigmoid": 0, "ce_softmax": 0, "tanh": 1, "sigmoid": 2}
+
+
+class _ChanLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, codes, weights):
+        if not logits.is_cuda:
+            raise RuntimeError("biapy_amd.losses run on the MI355X only (logits are on %s); there is no CPU path" % logits.device)
+        z, t = logits.contiguous().to(torch.float32), target.contiguous().to(torch.float32)
+        N, Cc = z.shape[:2]
+        vox = z[0, 0].numel()
+        nb = lib.bpx_chan_loss_blocks(vox)
+        part = torch.empty((N, Cc, nb), dtype=torch.float32, device=z.device)
+        L.check(lib.bpx_chan_loss_sums(z.data_ptr(), t.data_ptr(), N, Cc, vox, codes, part.data_ptr(), L.stream_ptr()))
+        per_ch = part.to(torch.float64).sum((0, 2)) / float(N * vox)                 # mean of every channel's terms (metrics.py:1784-1788)
+        ctx.save_for_backward(z, t, weights)
+        ctx.cfg = (codes, N, Cc, vox)
+        return (per_ch * weights.to(torch.float64)).sum().to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, t, weights = ctx.saved_tensors
+        codes, N, Cc, vox = ctx.cfg
+        coef = (g.to(torch.float32) * weights / float(N * vox)).contiguous()
+        dz = torch.empty_like(z)
+        L.check(lib.bpx_chan_loss_bwd(z.data_ptr(), t.data_ptr(), N, Cc, vox, codes, coef.data_ptr(), dz.data_ptr(), L.stream_ptr()))
+        return dz, None, None, None
+
+
+class InstanceChannelsLoss(torch.nn.Module):
+    """``instance_segmentation_loss`` (biapy/engine/metrics.py:1418-1810) for plain channels - e.g. ``out_channels=["B","C","D"]``,
+    ``losses_to_use=["bce","bce","mse"]`` - as one fused pass each way, taking the model's RAW logits: the head activation the
+    workflow applies before the loss in training (``head_activations``, base_workflow.py:1403-1457; 'D' -> tanh,
+    instance_seg.py:405-409) is part of the kernel.  Masks (``mask_values``), class re-balancing, border weights ('We'),
+    multi-width channels ('R', 'A', discretised 'Db') and the separate class head stay on the reference implementation."""
+
+    def __init__(self, channel_weights=(1, 1), out_channels=("F", "C"), losses_to_use=(), head_activations=None, channel_extra_opts=None,
+                 class_rebalance_within_channels: bool = False, separated_class_channel: bool = False, ignore_index: int = -1, **_unused):
+        super().__init__()
+        chans = [c for c in out_channels if c not in ("We", "I")]
+        if len(chans) != len(out_channels) or separated_class_channel or class_rebalance_within_channels or ignore_index != -1:
+            raise NotImplementedError("InstanceChannelsLoss: border weights, class heads, re-balancing and ignore_index stay on the reference loss")
+        if any(c in ("R", "A", "E_offset", "E_sigma", "E_seediness") for c in chans) or any((channel_extra_opts or {}).get(c, {}).get("mask_values") for c in chans):
+            raise NotImplementedError("InstanceChannelsLoss: multi-width channels and masked channels stay on the reference loss")
+        if len(losses_to_use) != len(chans) or len(channel_weights) != len(chans) or len(chans) > 8:
+            raise ValueError("one loss and one weight per output channel (at most 8 channels)")
+        acts = list(head_activations) if head_activations is not None else ["tanh" if c == "D" else "ce_sigmoid" for c in chans]
+        codes = 0
+        for i, (name, a) in enumerate(zip(losses_to_use, acts)):
+            if name not in _KIND or a.lower() not in _ACT:
+                raise NotImplementedError(f"loss {name!r} / head activation {a!r} is not implemented on the MI355X path")
+            kind = _KIND[name]
+            act = _ACT[a.lower()] if kind != 0 else 0
+            if kind == 0 and a.lower() not in ("ce_sigmoid", "linear"):
+                raise NotImplementedError("a BCE channel takes logits (head activation ce_sigmoid)")
+            codes |= (kind | (act << 2)) << (4 * i)
+        self.codes = codes
+        self.register_buffer("weights", torch.tensor([float(w) for w in channel_weights], dtype=torch.float32))
+
+    def forward(self, logits, target):
+        logits = logits["pred"] if isinstance(logits, dict) else logits
+        if logits.shape != target.shape or logits.shape[1] != self.weights.numel():
+            raise ValueError(f"logits {tuple(logits.shape)} / target {tuple(target.shape)} do not match the {self.weights.numel()} configured channels")
+        return _ChanLossFn.apply(logits, target, self.codes, self.weights.to(logits.device))
