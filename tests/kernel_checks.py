@@ -829,6 +829,81 @@ def check_sliding_window_cfg3_shape(dtype):
     return res
 
 
+def check_resunetpp(dtype, golden):
+    """biapy_amd.resunetpp.ResUNetPlusPlus (row X) against the reference's own ResUNetPlusPlus outputs
+    (tests/golden/resunetpp_golden.npz: fm 16-32-64 on a 16x32x32 patch, B = 2, three output channels): logits, MSE loss, every
+    gradient norm and the stored full gradients (residual block with 3x3x3 shortcut + norm, SE, ASPP with dilations 6/12/18,
+    attention gate, transposed conv, heads), through the module and torch's autograd boundary."""
+    from biapy_amd.resunetpp import ResUNetPlusPlus
+
+    g = golden
+    fm = [int(v) for v in g["feature_maps"]]
+    m = ResUNetPlusPlus(image_shape=(16, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in", k_size=3,
+                        upsample_layer="convtranspose", yx_down=[2, 2], z_down=[2, 2], output_channels=[3], output_channel_info=["BCD"],
+                        head_activations=["ce_sigmoid", "ce_sigmoid", "linear"], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3,
+                        compute_dtype=dtype)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k].astype(np.float32)) for k in g.files if k.startswith("sd/")}, strict=True)
+    m = m.to(DEV).train()
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3).to(DEV)
+    tgt = torch.from_numpy(g["target"].astype(np.float32)).to(DEV)
+    logits = m(x)
+    loss = torch.nn.MSELoss()(logits, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    tag = f"resunet++[{'f32' if f32 else 'bf16'}]"
+    lo_ref = torch.from_numpy(g["logits"])
+    res = [_res(tag + ".logits_rel", (logits.detach().cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 3e-4 if f32 else 8e-2)]
+    res.append(_res(tag + ".loss", abs(loss.item() - float(g["loss"])) / float(g["loss"]), 1e-5 if f32 else 3e-2))
+    names = dict(m.named_parameters())
+    gmax = max(float(g[k]) for k in g.files if k.startswith("gradnorm/"))
+    worst, wname = 0.0, ""
+    for k in g.files:
+        if k.startswith("gradnorm/"):
+            ref = float(g[k])
+            e = abs(names[k[9:]].grad.norm().item() - ref) / max(ref, 1e-4 * gmax)
+            if e > worst:
+                worst, wname = e, k[9:]
+    res.append(_res(tag + ".gradnorms_rel_worst", worst, 3e-3 if f32 else 0.25, extra=wname))
+    worst, wname = 0.0, ""
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(g[k])
+            e = (names[k[5:]].grad.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-4 * gmax)
+            if e > worst:
+                worst, wname = e, k[5:]
+    res.append(_res(tag + ".full_grads_rel_l2_worst", worst, 3e-3 if f32 else 0.25, extra=wname))
+    with torch.no_grad():
+        pr = m.eval().predict_proba(x, ["ce_sigmoid", "ce_sigmoid", "tanh"]).cpu()
+    want = torch.cat([torch.sigmoid(lo_ref[:, :2]), torch.tanh(lo_ref[:, 2:])], 1)
+    res.append(_res(tag + ".predict_proba(sigmoid,sigmoid,tanh)", (pr - want).abs().max().item(), 2e-5 if f32 else 3e-2))
+    return res
+
+
+def check_instance_loss():
+    """biapy_amd.losses.InstanceChannelsLoss (B, C, D channels; fused tanh + BCE / MSE / L1) against the reference's own
+    instance_segmentation_loss outputs (tests/golden/losses_golden.npz): value and gradient w.r.t. the raw logits."""
+    import os
+
+    from make_golden import loss_inputs
+
+    from biapy_amd.losses import InstanceChannelsLoss
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_golden.npz"))
+    _, _, z3, t3 = loss_inputs()
+    res = []
+    for tag, losses, w in (("bcd_mse", ["bce", "bce", "mse"], (1, 1, 1)), ("bcd_l1_w", ["bce", "bce", "l1"], (0.5, 0.25, 2.0))):
+        crit = InstanceChannelsLoss(channel_weights=w, out_channels=["B", "C", "D"], losses_to_use=losses).to(DEV)
+        z = z3.to(DEV).requires_grad_(True)
+        val = crit(z, t3.to(DEV))
+        val.backward()
+        torch.cuda.synchronize()
+        res.append(_res(f"instance_loss[{tag}].value", abs(val.item() - float(gold[f"instance_{tag}/value"])), 2e-6))
+        gr = gold[f"instance_{tag}/grad"]
+        res.append(_res(f"instance_loss[{tag}].grad", float(np.abs(z.grad.cpu().numpy() - gr).max() / np.abs(gr).max()), 2e-5))
+    return res
+
+
 def check_network_aniso(dtype, golden):
     """Anisotropic ResUNet (Z_DOWN = [1, 2]) against the reference fixture tests/golden/resunet_aniso_golden.npz: logits, loss
     and every gradient norm + the stored full gradients."""

@@ -786,6 +786,17 @@ def test_rcan_trunk_matches_reference_fixture(rcan_golden, dtype):
         assert (m.eval()(x).cpu() - yr).abs().max().item() / yr.abs().max().item() < (6e-2 if bf else 2e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_resunetpp_matches_reference_fixture(K, resunetpp_golden, dtype):
+    """Row X (cfg 4 family): the ResUNet++ drop-in on the device vs the reference's own outputs, loss and gradients."""
+    _assert_all(K.check_resunetpp(dtype, resunetpp_golden))
+
+
+def test_instance_channels_loss_matches_reference(K):
+    """The B / C / D channel loss of cfg 4 (fused kernels) vs the reference's instance_segmentation_loss values and gradients."""
+    _assert_all(K.check_instance_loss())
+
+
 def test_graphed_step_refuses_a_stale_autograd_graph():
     """Building a graphed step while a loss of an earlier eager backward is still referenced used to kill the process during
     capture (its AccumulateGrad nodes belong to another stream); graphs._warm turns PyTorch's warning into a RuntimeError."""
