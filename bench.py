@@ -313,6 +313,9 @@ def main():
                          "(biapy_amd.graphs.DataParallelTrainStep); ddp = torch DistributedDataParallel with eager hooks")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured HIP graph (auto: on; the ~230 launches of a step are host-bound otherwise)")
+    ap.add_argument("--arch", choices=["resunet", "resunetpp"], default="resunet",
+                    help="resunetpp = cfg 4 (3D instance segmentation, B/C/D channels, ResUNet++ fm 16-32-64-128-256, 80^3 patches): its own JSON "
+                         "line, train mode only - a second-tier configuration, not the headline")
     ap.add_argument("--sliding-timeout", type=float, default=240.0,
                     help="N > 1: seconds after which a hung sliding-window section is abandoned (the line is printed without it)")
     a = ap.parse_args()
@@ -338,6 +341,8 @@ def main():
     from biapy_amd.resunet import ResUNet
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.arch == "resunetpp":
+        return run_resunetpp(a, dev, rank, world, multi, dtype)
     torch.manual_seed(0)
     model = ResUNet(image_shape=(a.patch,) * 3 + (1,), activation="elu", feature_maps=FM, drop_values=[0.0] * 5, normalization="in",
                     yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev)
@@ -544,6 +549,54 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.patch, quick=a.quick_cpu_baseline)
         print(json.dumps(line))
+    if multi:
+        dist.destroy_process_group()
+
+
+def run_resunetpp(a, dev, rank, world, multi, dtype):
+    """cfg 4: ResUNet++ (fm 16-32-64-128-256), 80^3 x 1 patches, three output channels (B, C: BCE on logits; D: MSE through tanh),
+    batch --batch per GPU, one step = fwd + loss + bwd + AdamW; data parallel = DistributedDataParallel over RCCL (the module is an
+    ordinary nn.Module with one autograd.Function)."""
+    from biapy_amd.losses import InstanceChannelsLoss
+    from biapy_amd.resunetpp import ResUNetPlusPlus
+
+    P = 80 if a.patch == 128 else a.patch
+    torch.manual_seed(0)
+    fm = [16, 32, 64, 128, 256]
+    model = ResUNetPlusPlus(image_shape=(P, P, P, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4,
+                            z_down=[2] * 4, output_channels=[3], output_channel_info=["BCD"], head_activations=["ce_sigmoid", "ce_sigmoid", "tanh"],
+                            isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev).train()
+    g = torch.Generator(device=dev).manual_seed(rank)
+    x = torch.randn(a.batch, 1, P, P, P, generator=g, device=dev)
+    n = torch.randn(a.batch, 2, P, P, P, generator=g, device=dev)
+    tgt = torch.cat([(F.avg_pool3d(n, 9, stride=1, padding=4) > 0).float(), torch.rand(a.batch, 1, P, P, P, generator=g, device=dev) * 2 - 1], 1)
+    loss_fn = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).to(dev)
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True, bucket_cap_mb=64) if multi else model
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(net(x), tgt)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if a.warmup and not torch.isfinite(out.detach()).all():
+        raise SystemExit("non-finite loss in warm-up")
+    elapsed = _timed(step, a.steps, world, dev)
+    nparams = sum(p.numel() for p in model.parameters())
+    value = world * a.batch * P ** 3 * a.steps / elapsed
+    if rank == 0:
+        print(json.dumps(dict(
+            metric="voxels/sec 3D ResUNet++ %d^3 patch (train: fwd + B/C/D loss + bwd + AdamW)" % P, value=value, unit="voxels/s", n_gpus=world,
+            steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype,
+            data="synthetic", launch="eager (tape engine; DistributedDataParallel for N > 1)",
+            config=dict(workload="cfg4: 3D ResUNet++ fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, 3 channels (B,C,D), batch %d/GPU, train" % (P, a.batch),
+                        global_batch=world * a.batch, patch=P, parameters=nparams, parallelism="dp%d" % world, mode="train"),
+            mfma_frac_end_to_end=round(value * 1044917 * 3 / (world * MFMA_PEAK_BF16), 5))))
     if multi:
         dist.destroy_process_group()
 

@@ -104,6 +104,9 @@ _SIGS = {
     "bpx_conv3d_c1_wgrad": ([_i, _i, _i, _i, _i, _vp, Tensor, _vp, _vp, _vp], _i),
     "bpx_conv1x1_c1_wgrad": ([_i, _i64, _vp, Tensor, _vp, _vp], _i),
     "bpx_cast": ([_i, _vp, _i, _vp, _i64, _vp], _i),
+    "bpx_upsample_c1_fwd": ([_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "bpx_upsample_c1_blocks": ([_i64], _i),
+    "bpx_upsample_c1_bwd": ([_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
 }
 
 EXPORTS = tuple(_SIGS.keys())

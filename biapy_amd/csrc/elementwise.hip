@@ -1298,6 +1298,59 @@ __global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const T* __restrict__
   }
 }
 
+// ---- super-resolution "pre" up-sampling of the 1-channel input image (biapy/models/resunet.py:206-213, :368-369):
+// ConvTranspose3d(1, 1, kernel = stride = (fz, fy, fx)), out[n, fz*z+a, fy*y+b, fx*x+c] = img[n,z,y,x] * w[a][b][c] + bias, written as
+// channel 0 of a 16-channel NDHWC tensor of the storage dtype (channels 1..15 = 0): the first residual block then runs on the
+// generic 16-channel kernels (its 1-input-channel weights zero-padded), which also yield the gradient of the up-sampled image.
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ b,
+                                                              T* __restrict__ out16, int D, int H, int W, int fz, int fy, int fx, int64_t total) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int Ho = H * fy, Wo = W * fx, Do = D * fz;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+    int64_t r = v;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho); r /= Ho;
+    const int zo = (int)(r % Do);
+    const int64_t n = r / Do;
+    const int z = zo / fz, a = zo - z * fz, y = yo / fy, bb = yo - y * fy, x = xo / fx, c = xo - x * fx;
+    const float val = img[((n * D + z) * H + y) * (int64_t)W + x] * w[(a * fy + bb) * fx + c] + b[0];
+    float f[8] = {val, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float zz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<u32x4_t*>(out16 + v * 16) = pack16<T>(f);
+#pragma unroll
+    for (int q = 1; q < 16 / KPL; ++q) *reinterpret_cast<u32x4_t*>(out16 + v * 16 + q * KPL) = pack16<T>(zz);
+  }
+}
+
+// gradients of the layer above: grid (blocks, taps): block (bx, t) sums img * g and g over its share of the INPUT voxels for tap
+// t = (a*fy + b)*fx + c, g = channel 0 of dx16 at the tap's output voxel -> part[(t*gridDim.x + bx)*2 + {0,1}] (deterministic).
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_c1_bwd_kernel(const float* __restrict__ img, const T* __restrict__ dx16, int D, int H, int W, int fz,
+                                                              int fy, int fx, int64_t total_in, float* __restrict__ part) {
+  const int t = blockIdx.y;
+  const int c = t % fx, bb = (t / fx) % fy, a = t / (fx * fy);
+  const int Ho = H * fy, Wo = W * fx, Do = D * fz;
+  float sw = 0.f, sg = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total_in; v += (int64_t)gridDim.x * 256) {
+    int64_t r = v;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int z = (int)(r % D);
+    const int64_t n = r / D;
+    const int64_t vo = ((n * Do + (int64_t)z * fz + a) * Ho + (int64_t)y * fy + bb) * Wo + (int64_t)x * fx + c;
+    const float g = ElemTraits<T>::ld(dx16 + vo * 16);
+    sw += img[v] * g;
+    sg += g;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { sw += __shfl_xor(sw, m, 64); sg += __shfl_xor(sg, m, 64); }
+  __shared__ float red[4][2];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sw; red[threadIdx.x >> 6][1] = sg; }
+  __syncthreads();
+  if (threadIdx.x < 2) part[((size_t)t * gridDim.x + blockIdx.x) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 static int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16); }
 
 extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
@@ -1682,6 +1735,37 @@ extern "C" int bpx_gate_mul_bwd(int dtype, int64_t total_voxels, bpx_tensor dy, 
   const int blocks = grid_for(total_voxels);
   if (dtype == BPX_BF16) gate_mul_bwd_kernel<uint16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)dy.ptr, dy.ld, (const uint16_t*)a.ptr, a.ld, (const uint16_t*)x.ptr, x.ld, (uint16_t*)dx.ptr, dx.ld, (uint16_t*)da16_d, x.C, total_voxels);
   else if (dtype == BPX_F32) gate_mul_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dy.ptr, dy.ld, (const float*)a.ptr, a.ld, (const float*)x.ptr, x.ld, (float*)dx.ptr, dx.ld, (float*)da16_d, x.C, total_voxels);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_upsample_c1_fwd(int dtype, int N, int D, int H, int W, int fz, int fy, int fx, const float* img_d, const float* w_d, const float* bias_d,
+                                   void* out16_d, bpx_stream_t stream) {
+  const char* fn = "bpx_upsample_c1_fwd";
+  BPX_CHECK(img_d && w_d && bias_d && out16_d, "%s: null pointer", fn);
+  BPX_CHECK(fz >= 1 && fy >= 1 && fx >= 1 && fz * fy * fx <= 512, "%s: bad factors (%d,%d,%d)", fn, fz, fy, fx);
+  const int64_t total = (int64_t)N * D * fz * H * fy * W * fx;
+  if (total == 0) return 0;
+  if (dtype == BPX_BF16) upsample_c1_fwd_kernel<uint16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(img_d, w_d, bias_d, (uint16_t*)out16_d, D, H, W, fz, fy, fx, total);
+  else if (dtype == BPX_F32) upsample_c1_fwd_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(img_d, w_d, bias_d, (float*)out16_d, D, H, W, fz, fy, fx, total);
+  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_upsample_c1_blocks(int64_t voxels_in) { return (int)std::min<int64_t>(std::max<int64_t>(1, cdiv64(voxels_in, 2048)), 256); }
+
+extern "C" int bpx_upsample_c1_bwd(int dtype, int N, int D, int H, int W, int fz, int fy, int fx, const float* img_d, const void* dx16_d, float* partials_d,
+                                   bpx_stream_t stream) {
+  const char* fn = "bpx_upsample_c1_bwd";
+  BPX_CHECK(img_d && dx16_d && partials_d, "%s: null pointer", fn);
+  BPX_CHECK(fz >= 1 && fy >= 1 && fx >= 1 && fz * fy * fx <= 512, "%s: bad factors (%d,%d,%d)", fn, fz, fy, fx);
+  const int64_t total_in = (int64_t)N * D * H * W;
+  if (total_in == 0) return 0;
+  dim3 grid((unsigned)bpx_upsample_c1_blocks(total_in), (unsigned)(fz * fy * fx));
+  if (dtype == BPX_BF16) upsample_c1_bwd_kernel<uint16_t><<<grid, 256, 0, (hipStream_t)stream>>>(img_d, (const uint16_t*)dx16_d, D, H, W, fz, fy, fx, total_in, partials_d);
+  else if (dtype == BPX_F32) upsample_c1_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(img_d, (const float*)dx16_d, D, H, W, fz, fy, fx, total_in, partials_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

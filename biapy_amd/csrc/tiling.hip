@@ -379,160 +379,157 @@ __device__ __forceinline__ void cover_range_fast(const AxisG& g, const FastDiv& 
   if (hi > g.n - 1) hi = g.n - 1;
 }
 
-struct MergeDivs { FastDiv Y, C, sz, sy, sx; };
+struct MergeDivs { FastDiv q, Y, C, sz, sy, sx; };
 
-// One covering patch of a vector: its VEC values (zero where the element lies outside the patch), the patch start along x and the
-// per-element validity mask.  Up to 3 x 3 (y, x) patches of one z row are LOADED FIRST (nine independent wide loads in flight per
-// thread) and then accumulated in the reference's order; geometries with more than three covering patches along y or x
-// (overlap > 2/3) take the sequential path.
+// One covering patch of a vector: its VEC values (zero where the element lies outside the patch), the row weight fl(wz*wy),
+// the patch start along x and the per-element validity mask.  Up to 3 x 3 (y, x) patches of one z row are LOADED FIRST (nine
+// independent wide loads in flight per thread - the kernel is a latency-bound gather otherwise) and then accumulated in the
+// reference's order; geometries with more than three covering patches along y or x (overlap > 2/3) take the sequential path.
 template <typename EI, int VEC> struct MergeSlot {
   EI v[VEC];
+  float wzy;
   int sx;
   unsigned mask;
 };
 
-// ONE WORKGROUP PER OUTPUT ROW (z, y): everything that depends only on the row - the covering patch rows along z and y, their
-// taper products fl(wz*wy), their base pointers - is wave-uniform, i.e. scalar registers and scalar-unit arithmetic; a thread
-// computes only what depends on x (measured: with per-thread row arithmetic the kernel was VALU-bound at ~2000 vector
-// instructions per wave).
 template <typename EI, typename EO>
 __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__ patches, int Pzf, int Pyf, int Pxf, int C, int pz, int py,
                                                           int px, AxisG gz, AxisG gy, AxisG gx, const float* __restrict__ wz,
                                                           const float* __restrict__ wy, const float* __restrict__ wx, int Y, int X,
                                                           int z_lo, int zrow_lo, int zrow_hi, float* acc, float* wacc, int flags,
-                                                          EO* __restrict__ out, int qpr, uint32_t row_base, MergeDivs dv) {
+                                                          EO* __restrict__ out, uint32_t total_vec, uint32_t t_base, MergeDivs dv) {
   constexpr int VEC = MergeVec<EI>::VEC;
-  __shared__ float swx[MERGE_WXMAX];                              // the x taper (the launcher checks gx.patch <= MERGE_WXMAX)
-  for (int i = threadIdx.x; i < gx.patch; i += blockDim.x) swx[i] = wx[i];
-  __syncthreads();
-  uint32_t zr, yu;
-  dv.Y.divmod(blockIdx.x, zr, yu);                                // row of this launch = (z - z_lo') * Y + y
-  const int y = (int)yu, z = (int)zr + z_lo;
-  const int64_t grow = (int64_t)row_base + blockIdx.x;             // row index inside the [z_hi-z_lo][Y][X][C] arrays of the CALL
-  int zl, zh, yl, yh;
+  // The x taper is read through the vector L1 (a few hundred bytes, always resident).  Staging it in LDS put a global load + a
+  // barrier in front of every workgroup's first patch loads; a workgroup-per-output-row variant (row arithmetic on the scalar unit)
+  // was measured too and is slower than this flat form (2.16 vs 1.73 ms on 512 x 128^3 -> 512^3).
+  const float* __restrict__ swx = wx;
+  const uint32_t tl = blockIdx.x * 256u + threadIdx.x;
+  if (tl >= total_vec) return;
+  uint32_t row, q, zr, yu;
+  dv.q.divmod(tl, row, q);                                        // row = (z - z_lo') * Y + y inside this launch
+  dv.Y.divmod(row, zr, yu);
+  const int y = (int)yu;
+  const int z = (int)zr + z_lo;
+  const int e0 = (int)q * VEC;
+  const int x0 = (int)dv.C.div((uint32_t)e0), ch0 = e0 - x0 * C;
+  int xk[VEC];
+  {
+    int x = x0, ch = ch0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      xk[k] = x;
+      if (++ch == C) { ch = 0; ++x; }
+    }
+  }
+  const int64_t grow = (int64_t)(t_base / dv.q.d) + row;           // row index inside the [z_hi-z_lo][Y][X][C] arrays of the CALL
+  const int64_t i0 = grow * (int64_t)X * C + e0;                   // flat index of element 0
+  const int64_t v0 = grow * (int64_t)X;                            // voxel index of x = 0 of this row
+  float num[VEC], ws[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) { num[k] = 0.f; ws[k] = 0.f; }
+  if (flags & 2) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { num[k] = acc[i0 + k]; ws[k] = wacc[v0 + xk[k]]; }
+  }
+  int zl, zh, yl, yh, xl, xh, dummy;
   cover_range_fast(gz, dv.sz, z, zl, zh);
   cover_range_fast(gy, dv.sy, y, yl, yh);
+  cover_range_fast(gx, dv.sx, xk[0], xl, dummy);
+  cover_range_fast(gx, dv.sx, xk[VEC - 1], dummy, xh);
   if (zl < zrow_lo) zl = zrow_lo;
   if (zh > zrow_hi - 1) zh = zrow_hi - 1;
   const int pstride_y = Pxf * C, pstride_z = pstride_y * Pyf;
   const int64_t pstride_c = (int64_t)pstride_z * Pzf;
-  const bool y_batched = (yh - yl) < 3;
+  const bool batched = (yh - yl) < 3 && (xh - xl) < 3;
 
-  for (int q = threadIdx.x; q < qpr; q += blockDim.x) {
-    const int e0 = q * VEC;
-    const int x0 = (int)dv.C.div((uint32_t)e0), ch0 = e0 - x0 * C;
-    int xk[VEC];
+  auto accumulate = [&](const EI* v, float wzy, int sx, unsigned mask) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (mask & (1u << k)) {
+        const float w = __fmul_rn(wzy, swx[xk[k] - sx]);
+        num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(&v[k]), w));
+        ws[k] = __fadd_rn(ws[k], w);
+      }
+    }
+  };
+  // loads the VEC values of patch (row pointer prow, column ix) that cover this vector; returns the validity mask (0 = none)
+  auto fetch = [&](const EI* prow, int ix, EI* v, int& sx_out) -> unsigned {
+    const int sx = gx.start(ix);
+    sx_out = sx;
+    const int l0 = xk[0] - sx, l1 = xk[VEC - 1] - sx;
+    if (l1 < 0 || l0 >= gx.patch) return 0u;
+    const EI* pp = prow + (int64_t)ix * pstride_c + ((px - sx) * C + e0);   // element k of the vector is pp[k] when it is inside
+    if (l0 >= 0 && l1 < gx.patch) {
+      __builtin_memcpy(v, pp, sizeof(EI) * VEC);                    // one wide (possibly misaligned) load
+      return (1u << VEC) - 1u;
+    }
+    unsigned mask = 0u;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int lx = xk[k] - sx;
+      v[k] = EI(0);
+      if (lx >= 0 && lx < gx.patch) { v[k] = pp[k]; mask |= 1u << k; }
+    }
+    return mask;
+  };
+
+  for (int iz = zl; iz <= zh; ++iz) {
+    const int lz = z - gz.start(iz);
+    if (lz < 0 || lz >= gz.patch) continue;
+    const float wzv = wz[lz];
+    const EI* pz_base = patches + (int64_t)(iz - zrow_lo) * gy.n * gx.n * pstride_c + (lz + pz) * pstride_z;
+    if (batched) {
+      MergeSlot<EI, VEC> slot[9];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int iy = yl + j;
+        const int ly = y - gy.start(iy);
+        const bool oky = iy <= yh && ly >= 0 && ly < gy.patch;
+        const float wzy = oky ? __fmul_rn(wzv, wy[ly]) : 0.f;
+        const EI* prow = pz_base + (int64_t)iy * gx.n * pstride_c + (ly + py) * pstride_y;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          MergeSlot<EI, VEC>& sl = slot[j * 3 + i];
+          sl.mask = 0u;
+          sl.wzy = wzy;
+          sl.sx = 0;
+          if (oky && xl + i <= xh) sl.mask = fetch(prow, xl + i, sl.v, sl.sx);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 9; ++b)
+        if (slot[b].mask) accumulate(slot[b].v, slot[b].wzy, slot[b].sx, slot[b].mask);
+    } else {
+      for (int iy = yl; iy <= yh; ++iy) {
+        const int ly = y - gy.start(iy);
+        if (ly < 0 || ly >= gy.patch) continue;
+        const float wzy = __fmul_rn(wzv, wy[ly]);
+        const EI* prow = pz_base + (int64_t)iy * gx.n * pstride_c + (ly + py) * pstride_y;
+        for (int ix = xl; ix <= xh; ++ix) {
+          EI v[VEC];
+          int sx;
+          const unsigned mask = fetch(prow, ix, v, sx);
+          if (mask) accumulate(v, wzy, sx, mask);
+        }
+      }
+    }
+  }
+  if (flags & 1) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[i0 + k] = num[k];
     {
       int x = x0, ch = ch0;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        xk[k] = x;
+        if (ch == 0) wacc[v0 + x] = ws[k];
         if (++ch == C) { ch = 0; ++x; }
       }
     }
-    const int64_t i0 = grow * (int64_t)X * C + e0;                 // flat index of element 0
-    const int64_t v0 = grow * (int64_t)X;                          // voxel index of x = 0 of this row
-    float num[VEC], ws[VEC];
+  } else {
+    EO o[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { num[k] = 0.f; ws[k] = 0.f; }
-    if (flags & 2) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) { num[k] = acc[i0 + k]; ws[k] = wacc[v0 + xk[k]]; }
-    }
-    int xl, xh, dummy;
-    cover_range_fast(gx, dv.sx, xk[0], xl, dummy);
-    cover_range_fast(gx, dv.sx, xk[VEC - 1], dummy, xh);
-    const bool batched = y_batched && (xh - xl) < 3;
-
-    auto accumulate = [&](const EI* v, float wzy, int sx, unsigned mask) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        if (mask & (1u << k)) {
-          const float w = __fmul_rn(wzy, swx[xk[k] - sx]);
-          num[k] = __fadd_rn(num[k], __fmul_rn(load_as_f32<EI>(&v[k]), w));
-          ws[k] = __fadd_rn(ws[k], w);
-        }
-      }
-    };
-    // loads the VEC values of patch (row pointer prow, column ix) that cover this vector; returns the validity mask (0 = none)
-    auto fetch = [&](const EI* prow, int ix, EI* v, int& sx_out) -> unsigned {
-      const int sx = gx.start(ix);
-      sx_out = sx;
-      const int l0 = xk[0] - sx, l1 = xk[VEC - 1] - sx;
-      if (l1 < 0 || l0 >= gx.patch) return 0u;
-      const EI* pp = prow + (int64_t)ix * pstride_c + ((px - sx) * C + e0);   // element k of the vector is pp[k] when it is inside
-      if (l0 >= 0 && l1 < gx.patch) {
-        __builtin_memcpy(v, pp, sizeof(EI) * VEC);                  // one wide (possibly misaligned) load
-        return (1u << VEC) - 1u;
-      }
-      unsigned mask = 0u;
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const int lx = xk[k] - sx;
-        v[k] = EI(0);
-        if (lx >= 0 && lx < gx.patch) { v[k] = pp[k]; mask |= 1u << k; }
-      }
-      return mask;
-    };
-
-    for (int iz = zl; iz <= zh; ++iz) {                             // uniform
-      const int lz = z - gz.start(iz);
-      if (lz < 0 || lz >= gz.patch) continue;
-      const float wzv = wz[lz];
-      const EI* pz_base = patches + (int64_t)(iz - zrow_lo) * gy.n * gx.n * pstride_c + (lz + pz) * pstride_z;
-      if (batched) {
-        MergeSlot<EI, VEC> slot[9];
-        float wzy3[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int iy = yl + j;                                    // uniform
-          const int ly = y - gy.start(iy);
-          const bool oky = iy <= yh && ly >= 0 && ly < gy.patch;
-          wzy3[j] = oky ? __fmul_rn(wzv, wy[ly]) : 0.f;
-          const EI* prow = pz_base + (int64_t)iy * gx.n * pstride_c + (ly + py) * pstride_y;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            MergeSlot<EI, VEC>& sl = slot[j * 3 + i];
-            sl.mask = 0u;
-            sl.sx = 0;
-            if (oky && xl + i <= xh) sl.mask = fetch(prow, xl + i, sl.v, sl.sx);
-          }
-        }
-#pragma unroll
-        for (int b = 0; b < 9; ++b)
-          if (slot[b].mask) accumulate(slot[b].v, wzy3[b / 3], slot[b].sx, slot[b].mask);
-      } else {
-        for (int iy = yl; iy <= yh; ++iy) {
-          const int ly = y - gy.start(iy);
-          if (ly < 0 || ly >= gy.patch) continue;
-          const float wzy = __fmul_rn(wzv, wy[ly]);
-          const EI* prow = pz_base + (int64_t)iy * gx.n * pstride_c + (ly + py) * pstride_y;
-          for (int ix = xl; ix <= xh; ++ix) {
-            EI v[VEC];
-            int sx;
-            const unsigned mask = fetch(prow, ix, v, sx);
-            if (mask) accumulate(v, wzy, sx, mask);
-          }
-        }
-      }
-    }
-    if (flags & 1) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) acc[i0 + k] = num[k];
-      {
-        int x = x0, ch = ch0;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          if (ch == 0) wacc[v0 + x] = ws[k];
-          if (++ch == C) { ch = 0; ++x; }
-        }
-      }
-    } else {
-      EO o[VEC];
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) store_from_f32<EO>(&o[k], __fdiv_rn(num[k], __fadd_rn(ws[k], 1e-18f)));
-      __builtin_memcpy(__builtin_assume_aligned(out + i0, sizeof(EO) * VEC >= 16 ? 16 : sizeof(EO) * VEC), o, sizeof(o));
-    }
+    for (int k = 0; k < VEC; ++k) store_from_f32<EO>(&o[k], __fdiv_rn(num[k], __fadd_rn(ws[k], 1e-18f)));
+    __builtin_memcpy(__builtin_assume_aligned(out + i0, sizeof(EO) * VEC >= 16 ? 16 : sizeof(EO) * VEC), o, sizeof(o));
   }
 }
 
@@ -563,22 +560,24 @@ extern "C" int bpx_merge3d_blend(const void* patches_d, int dtype, int Pz, int P
     const int combo = dtype == BPX_F32 && out_dtype == BPX_F32 ? 0 : dtype == BPX_U8 && out_dtype == BPX_U8 ? 1 : dtype == BPX_F16 && out_dtype == BPX_F16 ? 2
                       : dtype == BPX_F16 && out_dtype == BPX_F32 ? 3 : dtype == BPX_U8 && out_dtype == BPX_F32 ? 4 : -1;
     const int qpr = row_ok ? (int)(((int64_t)X * C) / vec) : 0;
-    if (row_ok && al_ok && combo >= 0 && !g_tiling_scalar && Y < (1 << 30)) {
+    if (row_ok && al_ok && combo >= 0 && !g_tiling_scalar && (int64_t)Y * qpr < (1ll << 30)) {
       (void)oes;
-      // one workgroup per output row; 31-bit row indices per launch (FastDiv): a taller slab is cut into launches of whole slices
-      const int slices_per_launch = (int)std::max<int64_t>(1, ((1ll << 30) - 1) / Y);
-      const unsigned bs = (unsigned)std::min(256, (qpr + 63) / 64 * 64);
-      MergeDivs dv{make_fastdiv((uint32_t)Y), make_fastdiv((uint32_t)C), make_fastdiv((uint32_t)g[0].step), make_fastdiv((uint32_t)g[1].step),
-                   make_fastdiv((uint32_t)g[2].step)};
+      // 31-bit thread indices per launch (FastDiv): a taller slab is cut into launches of whole z slices
+      const int64_t vec_per_slice = (int64_t)Y * qpr;
+      const int slices_per_launch = (int)std::max<int64_t>(1, ((1ll << 30) - 1) / vec_per_slice);
+      MergeDivs dv{make_fastdiv((uint32_t)qpr), make_fastdiv((uint32_t)Y), make_fastdiv((uint32_t)C), make_fastdiv((uint32_t)g[0].step),
+                   make_fastdiv((uint32_t)g[1].step), make_fastdiv((uint32_t)g[2].step)};
       for (int za = z_lo; za < z_hi; za += slices_per_launch) {
         const int zn = std::min(slices_per_launch, z_hi - za);
-        const unsigned nb = (unsigned)((int64_t)zn * Y);
-        const int64_t rb64 = (int64_t)(za - z_lo) * Y;
-        BPX_CHECK(rb64 < (1ll << 32), "bpx_merge3d_blend: slab too large");
-        const uint32_t rb = (uint32_t)rb64;
-#define MERGE_ROW(EI, EO)                                                                                                                  \
-  merge3d_row_kernel<EI, EO><<<nb, bs, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, wx_d, Y, X, za, \
-                                               zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d, qpr, rb, dv)
+        const uint32_t total_vec = (uint32_t)(zn * vec_per_slice);
+        const unsigned nb = (unsigned)cdiv64(total_vec, 256);
+        // element / voxel offsets of this launch inside the call's arrays are carried by t_base (in vectors of the call)
+        const int64_t tb64 = (int64_t)(za - z_lo) * vec_per_slice;
+        BPX_CHECK(tb64 < (1ll << 32), "bpx_merge3d_blend: slab too large");
+        const uint32_t tb = (uint32_t)tb64;
+#define MERGE_ROW(EI, EO)                                                                                                                   \
+  merge3d_row_kernel<EI, EO><<<nb, 256, 0, s>>>((const EI*)patches_d, Pz, Py, Px, C, pad_z, pad_y, pad_x, gz, gy, gx, wz_d, wy_d, wx_d, Y, X, za, \
+                                                zrow_lo, zrow_hi, acc_d, wacc_d, flags, (EO*)out_d, total_vec, tb, dv)
         if (combo == 0) MERGE_ROW(float, float);
         else if (combo == 1) MERGE_ROW(uint8_t, uint8_t);
         else if (combo == 2) MERGE_ROW(__half, __half);

@@ -53,6 +53,8 @@ class NetConfig:
     normalization: str = "in"
     z_down: Optional[Sequence[int]] = None    # MODEL.Z_DOWN per level (1 or 2; None = 2 everywhere); YX_DOWN is always 2
     ndim: int = 3                             # 2: (B,C,Y,X) tensors, run as one-z-slice volumes (z_down is then 1 everywhere)
+    post_up: int = 0                          # super-resolution "post" up-sampling ConvTranspose3d(fm0, fm0, k = s = (post_up, 2, 2)) in front
+    #                                           of the heads (resunet.py:326-333, :399-400); 0 = none, else the z factor (1 or 2)
 
     def __post_init__(self):
         fm = list(self.feature_maps)
@@ -68,6 +70,8 @@ class NetConfig:
             raise NotImplementedError(f"feature_maps {fm} must be multiples of 16 (MFMA tile)")
         if self.in_ch != 1 and self.in_ch % 16:
             raise NotImplementedError("input channels must be 1 or a multiple of 16")
+        if self.post_up not in (0, 1, 2):
+            raise NotImplementedError("post up-sampling: z factor 1 or 2 (y / x factor 2)")
         if sum(self.out_channels) > 4 or fm[0] not in (16, 32):
             raise NotImplementedError("output head supports <= 4 channels from 16 or 32 features")
         self.depth = len(fm) - 1
@@ -340,11 +344,18 @@ class ResUNetEngine:
         return part2, tiles2
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
+    def forward(self, P: Dict[str, torch.Tensor], x: Optional[torch.Tensor], head_act: int = 0, save: bool = False, cache_weights: bool = False,
+                x_ndhwc: Optional[torch.Tensor] = None, want_dx: bool = False):
         """x: (B,C,Z,Y,X) fp32 with channels_last_3d strides (or any layout for C == 1).  Returns logits
-        (B,sum(out_ch),Z,Y,X) fp32 in channels-first planar layout, and the saved context (or None)."""
+        (B,sum(out_ch),Z,Y,X) fp32 in channels-first planar layout, and the saved context (or None).
+        ``x_ndhwc``: the input already as a dense (B,Z,Y,X,C) tensor of the storage dtype (``x`` is then ignored); ``want_dx``: the
+        backward also returns the gradient of that tensor under the key "__dx__" (super-resolution pre-up-sampling, resunet_sr)."""
         cfg = self.cfg
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == cfg.ndim + 2
+        if x_ndhwc is not None:
+            assert x_ndhwc.is_cuda and x_ndhwc.dtype == self.dtype and x_ndhwc.dim() == 5 and x_ndhwc.is_contiguous() and cfg.in_ch != 1
+            x = x_ndhwc.permute(0, 4, 1, 2, 3)           # only its shape is used below
+        else:
+            assert x.is_cuda and x.dtype == torch.float32 and x.dim() == cfg.ndim + 2
         if cfg.ndim == 2:
             x = x.unsqueeze(2)
         P_orig = P
@@ -382,6 +393,8 @@ class ResUNetEngine:
         if Cin == 1:
             img = x.reshape(B, D0, H0, W0).contiguous()
             x_ndhwc = None
+        elif x_ndhwc is not None:
+            img = None
         else:
             img = None
             xin = x.permute(0, 2, 3, 4, 1).contiguous()
@@ -471,16 +484,25 @@ class ResUNetEngine:
             hw = torch.cat([P[f"heads.{h}.weight"].reshape(-1, fm[0]) for h in range(len(cfg.out_channels))], 0)
             hb = torch.cat([P[f"heads.{h}.bias"] for h in range(len(cfg.out_channels))], 0)
         hw = hw.reshape(n_out, fm[0]).contiguous()
-        logits = torch.empty((B, n_out, D0, H0, W0), dtype=torch.float32, device=dev)
-        vox0 = D0 * H0 * W0
-        L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(dec_in), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(),
+        feat, So = dec_in, (D0, H0, W0)
+        if cfg.post_up:
+            # super-resolution: ConvTranspose3d(fm0, fm0, k = s = (post_up, 2, 2)) on the decoder output (resunet.py:399-400)
+            So = (D0 * cfg.post_up, H0 * 2, W0 * 2)
+            wpu = self._pack(P["post_upsampling.weight"], L.PK_CT if cfg.post_up == 2 else L.PK_CT4, fm[0], fm[0], cache_weights)
+            feat = torch.empty((B,) + So + (fm[0],), dtype=T, device=dev)
+            pupart = _Stats.alloc(B, lib.bpx_convT3d_stats_tiles(D0, H0, W0, cfg.post_up), fm[0], dev)       # statistics unused
+            L.check(lib.bpx_convT3d_k2s2_fwd(self.dt, B, D0, H0, W0, cfg.post_up, L.tview(dec_in), wpu.data_ptr(), P["post_upsampling.bias"].data_ptr(),
+                                             L.tview(feat), pupart.data_ptr(), st))
+        logits = torch.empty((B, n_out) + So, dtype=torch.float32, device=dev)
+        vox0 = So[0] * So[1] * So[2]
+        L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(feat), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(),
                                  n_out * vox0, vox0, st))
         if cfg.ndim == 2:
-            logits = logits.reshape(B, n_out, H0, W0)
+            logits = logits.reshape(B, n_out, So[1], So[2])
         ctx = None
         if save:
-            ctx = dict(B=B, S=S, img=img, x_ndhwc=x_ndhwc, blocks=blocks, cat=cat, pools=pools, ups=ups, feat=dec_in, hw=hw,
-                       Pw=(P if P is not P_orig else None))
+            ctx = dict(B=B, S=S, So=So, img=img, x_ndhwc=x_ndhwc, blocks=blocks, cat=cat, pools=pools, ups=ups, feat=feat, dec_out=dec_in, hw=hw,
+                       Pw=(P if P is not P_orig else None), want_dx=want_dx)
         return logits, ctx
 
     # ------------------------------------------------------------------------------------------
@@ -585,13 +607,24 @@ class ResUNetEngine:
         # ---- head -------------------------------------------------------------------------------
         n_out = sum(cfg.out_channels)
         D0, H0, W0 = S[0]
-        vox0 = D0 * H0 * W0
+        So = ctx.get("So", S[0])
+        vox0 = So[0] * So[1] * So[2]
         dl = dlogits.contiguous().float()
-        dfeat = torch.empty((B, D0, H0, W0, fm[0]), dtype=T, device=dev)
+        dfeat = torch.empty((B,) + tuple(So) + (fm[0],), dtype=T, device=dev)
         hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
         hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
         L.check(lib.bpx_head_bwd(self.dt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
                                  L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), st))
+        if cfg.post_up:
+            dec_out, dup_feat = ctx["dec_out"], dfeat
+            wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, D0, H0, W0, cfg.post_up, fm[0], fm[0])
+            ws = self._workspace(wsn, dev)
+            L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, D0, H0, W0, cfg.post_up, L.tview(dec_out), L.tview(dup_feat), G["post_upsampling.weight"].data_ptr(),
+                                               G["post_upsampling.bias"].data_ptr(), ws.data_ptr(), ws.numel(), st))
+            dfeat = torch.empty((B, D0, H0, W0, fm[0]), dtype=T, device=dev)
+            wt = self._pack(P["post_upsampling.weight"], L.PK_CT_T if cfg.post_up == 2 else L.PK_CT4_T, fm[0], fm[0], False)
+            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, D0, H0, W0, cfg.post_up, L.tview(dup_feat), wt.data_ptr(), L.tview(dfeat), st))
+            self._keep.append(dup_feat)
         o = 0
         for h, oc in enumerate(cfg.out_channels):
             G[f"heads.{h}.weight"].copy_(hwg[o:o + oc].view(G[f"heads.{h}.weight"].shape))
@@ -635,6 +668,10 @@ class ResUNetEngine:
                 self._block_bwd(P, G, blocks[i], B, skipv, img, st, None, L.tview(dPn))
                 keep.append(dP)
                 dP = dPn
+            elif ctx.get("want_dx"):
+                dx0 = torch.empty((B,) + S[0] + (cfg.in_ch,), dtype=T, device=dev)
+                self._block_bwd(P, G, blocks[0], B, skipv, img, st, None, L.tview(dx0))
+                G["__dx__"] = dx0
             else:
                 self._block_bwd(P, G, blocks[0], B, skipv, img, st, None, None)  # the image needs no gradient
         side = self._side(dev)

@@ -100,6 +100,66 @@ class _ResUNetFn(torch.autograd.Function):
         return (None, None, None) + tuple(G[n] for n in ctx.names)
 
 
+_SR_W1, _SR_WSC = "down_path.0.block.0.block.0.weight", "down_path.0.shortcut.0.weight"
+
+
+def _sr_pre_forward(engine: ResUNetEngine, P, x, factor, head_act, save):
+    """Super-resolution "pre" up-sampling (resunet.py:206-213, :368-369) + the network: the 1-channel image goes through
+    ``bpx_upsample_c1_fwd`` into channel 0 of a 16-channel tensor and the first block's 1-input-channel weights are zero-padded to
+    16 input channels, so that the generic kernels run the first block and hand back the gradient of the up-sampled image."""
+    from . import _lib as L
+
+    B, _, D, H, W = x.shape
+    fz, fy, fx = factor
+    img = x.reshape(B, D, H, W).contiguous()
+    x16 = torch.empty((B, D * fz, H * fy, W * fx, 16), dtype=engine.dtype, device=x.device)
+    L.check(L.lib.bpx_upsample_c1_fwd(engine.dt, B, D, H, W, fz, fy, fx, img.data_ptr(), P["pre_upsampling.weight"].contiguous().data_ptr(),
+                                      P["pre_upsampling.bias"].data_ptr(), x16.data_ptr(), L.stream_ptr()))
+    Pc = {k: v for k, v in P.items() if not k.startswith("pre_upsampling.")}
+    for k in (_SR_W1, _SR_WSC):
+        w = P[k]
+        wp = torch.zeros((w.shape[0], 16) + tuple(w.shape[2:]), dtype=torch.float32, device=w.device)
+        wp[:, :1] = w
+        Pc[k] = wp
+    logits, saved = engine.forward(Pc, None, head_act=head_act, save=save, cache_weights=False, x_ndhwc=x16, want_dx=save)
+    return logits, (saved, Pc, img)
+
+
+class _ResUNetSRPreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine: ResUNetEngine, names: List[str], factor, *params):
+        P = dict(zip(names, (p.detach() for p in params)))
+        logits, (saved, Pc, img) = _sr_pre_forward(engine, P, x.detach(), factor, 0, True)
+        ctx.engine, ctx.names, ctx.saved, ctx.Pc, ctx.img, ctx.factor, ctx.P = engine, names, saved, Pc, img, factor, P
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        from . import _lib as L
+
+        eng = ctx.engine
+        G = eng.backward(ctx.Pc, ctx.saved, dlogits)
+        dx16 = G.pop("__dx__")
+        fz, fy, fx = ctx.factor
+        B, D, H, W = ctx.img.shape
+        nb = L.lib.bpx_upsample_c1_blocks(B * D * H * W)
+        part = torch.empty((fz * fy * fx, nb, 2), dtype=torch.float32, device=dx16.device)
+        L.check(L.lib.bpx_upsample_c1_bwd(eng.dt, B, D, H, W, fz, fy, fx, ctx.img.data_ptr(), dx16.data_ptr(), part.data_ptr(), L.stream_ptr()))
+        sums = part.to(torch.float64).sum(1)
+        out = {}
+        for n in ctx.names:
+            if n == "pre_upsampling.weight":
+                out[n] = sums[:, 0].to(torch.float32).reshape(ctx.P[n].shape)
+            elif n == "pre_upsampling.bias":
+                out[n] = sums[:, 1].sum().to(torch.float32).reshape(1)
+            elif n in (_SR_W1, _SR_WSC):
+                out[n] = G[n][:, :1].contiguous()
+            else:
+                out[n] = G[n]
+        ctx.saved = None
+        return (None, None, None, None) + tuple(out[n] for n in ctx.names)
+
+
 class _GraphedResUNetFn(torch.autograd.Function):
     """Forward / backward of the whole network as two HIP-graph replays (ResUNet.capture_graphs).  Anything around it -
     loss, DistributedDataParallel's gradient hooks and all-reduce, the optimizer - stays eager and unchanged."""
@@ -169,8 +229,24 @@ class ResUNet(nn.Module):
             unsupported("Z_DOWN other than 1 or 2")
         if upsample_layer != "convtranspose":
             unsupported("upsample_layer != 'convtranspose'")
-        if separated_decoders or contrast or larger_io or len(upsampling_factor) > 0:
-            unsupported("separated decoders / contrastive head / larger_io / super-resolution up-sampling")
+        if separated_decoders or contrast or larger_io:
+            unsupported("separated decoders / contrastive head / larger_io")
+        up = tuple(int(v) for v in upsampling_factor)
+        self.sr_pre, self.sr_post = None, 0
+        if len(up) > 0:
+            # super-resolution (resunet.py:206-213 pre / :326-333 post): ConvTranspose with kernel = stride = the up-scaling factor
+            if ndim != 3 or len(up) != 3 or not all(iso):
+                unsupported("super-resolution up-sampling of 2D / anisotropic-kernel networks")
+            if upsampling_position == "pre":
+                if image_shape[-1] != 1 or any(v < 1 for v in up) or up[0] * up[1] * up[2] > 512:
+                    unsupported("pre up-sampling of multi-channel images")
+                self.sr_pre = up
+            elif upsampling_position == "post":
+                if up[1:] != (2, 2) or up[0] not in (1, 2):
+                    unsupported(f"post up-sampling by {up} (the transposed-conv kernels are (1|2, 2, 2))")
+                self.sr_post = up[0]
+            else:
+                raise ValueError(f"upsampling_position={upsampling_position!r}")
         if conv_block_order != "conv_norm_act" or list(conv_layers)[: depth + 1] != [2] * (depth + 1):
             unsupported("conv_block_order != 'conv_norm_act' or conv_layers != 2")
         if any(float(d) > 0 for d in drop_values):
@@ -189,14 +265,14 @@ class ResUNet(nn.Module):
         self.return_one_tensor = return_one_tensor
         in_ch = image_shape[-1]
         zd = [int(v) for v in list(z_down)[:depth]] if ndim == 3 else [1] * depth
-        self.cfg = NetConfig(in_ch=in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
-                             normalization=normalization, z_down=zd, ndim=ndim)
+        self.cfg = NetConfig(in_ch=16 if self.sr_pre else in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
+                             normalization=normalization, z_down=zd, ndim=ndim, post_up=self.sr_post)
         # kernel of level i (resunet.py:239-241, :260-262, :282-284): (3,3) in 2D, (1,3,3) where MODEL.ISOTROPY[i] is False
         ks = [(3, 3) if ndim == 2 else ((3, 3, 3) if iso[i] else (1, 3, 3)) for i in range(depth + 1)]
         self.compute_dtype = compute_dtype
         self._engine: Optional[ResUNetEngine] = None
 
-        self.pre_upsampling = None
+        self.pre_upsampling = nn.ConvTranspose3d(in_ch, in_ch, kernel_size=self.sr_pre, stride=self.sr_pre) if self.sr_pre else None
         self.conv_in = None
         self.down_path = nn.ModuleList()
         self.mpooling_layers = nn.ModuleList()
@@ -213,7 +289,8 @@ class ResUNet(nn.Module):
             self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], ks[i], act, zd[i], ndim))
             c = feature_maps[i]
         self.conv_out = None
-        self.post_upsampling = None
+        self.post_upsampling = (nn.ConvTranspose3d(feature_maps[0], feature_maps[0], kernel_size=(self.sr_post, 2, 2), stride=(self.sr_post, 2, 2))
+                                if self.sr_post else None)
         self.heads = nn.Sequential()
         for oc in output_channels:
             self.heads.append(_conv(ndim)(feature_maps[0], oc, kernel_size=1, padding="same"))
@@ -252,6 +329,12 @@ class ResUNet(nn.Module):
             raise RuntimeError("biapy_amd.ResUNet runs on the MI355X only (input is on %s); there is no CPU path" % x.device)
         names, params = self._named()
         x = x.to(torch.float32)
+        if self.sr_pre:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                return _ResUNetSRPreFn.apply(x, self.engine(), names, self.sr_pre, *params)
+            P = {n: p.detach() for n, p in zip(names, params)}
+            logits, _ = _sr_pre_forward(self.engine(), P, x, self.sr_pre, 0, False)
+            return logits
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             gr = getattr(self, "_graphs", None)
             if gr is not None and tuple(x.shape) == gr["shape"] and x.stride() == gr["stride"] and not torch.cuda.is_current_stream_capturing():
@@ -322,6 +405,8 @@ class ResUNet(nn.Module):
         """Inference with the head activations (``ce_sigmoid`` by default; base_workflow.py:1403-1457) fused into the head kernel."""
         names, params = self._named()
         P = {n: p.detach() for n, p in zip(names, params)}
+        if self.sr_pre:
+            return _sr_pre_forward(self.engine(), P, x.to(torch.float32), self.sr_pre, self.head_activation_code(head_activations), False)[0]
         out, _ = self.engine().forward(P, x.to(torch.float32), head_act=self.head_activation_code(head_activations), save=False,
                                        cache_weights=True)
         return out

@@ -284,6 +284,18 @@ int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_
  * dw_d must be zeroed by the caller. */
 int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, bpx_stream_t stream);
 
+/* Super-resolution "pre" up-sampling of the 1-channel image: ConvTranspose3d(1, 1, kernel = stride = (fz, fy, fx))
+ * (biapy/models/resunet.py:206-213, :368-369).  fwd writes channel 0 of a dense 16-channel NDHWC tensor of the storage dtype
+ * (extents fz*D, fy*H, fx*W; channels 1..15 = 0) so that the first residual block can run on the 16-channel kernels with its weights
+ * zero-padded.  bwd: partials_d[(t * bpx_upsample_c1_blocks(N*D*H*W) + b) * 2 + {0, 1}] = partial sums of img * g and of g for tap
+ * t = (a*fy + b)*fx + c, g = channel 0 of the gradient of that tensor; the caller reduces them (dW[t] = sum of the first, dbias = sum
+ * over all taps of the second). */
+int bpx_upsample_c1_fwd(int dtype, int N, int D, int H, int W, int fz, int fy, int fx, const float* img_d, const float* w_d, const float* bias_d,
+                        void* out16_d, bpx_stream_t stream);
+int bpx_upsample_c1_blocks(int64_t voxels_in);
+int bpx_upsample_c1_bwd(int dtype, int N, int D, int H, int W, int fz, int fy, int fx, const float* img_d, const void* dx16_d, float* partials_d,
+                        bpx_stream_t stream);
+
 /* dtype conversion helpers (NDHWC, strided channel slices) */
 int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64_t n, bpx_stream_t stream);
 

@@ -94,6 +94,9 @@ def resunet_forward(
     yx_down = list(yx_down) if yx_down is not None else [2] * depth
     skips: List[torch.Tensor] = []
     two_d = x.dim() == 4                               # 2D network (resunet.py:195-207 picks the 2D layer classes)
+    if "pre_upsampling.weight" in sd:                  # super-resolution, resunet.py:206-213 / :368-369: ConvTranspose(k = s = factor)
+        w = sd["pre_upsampling.weight"]
+        x = F.conv_transpose3d(x, w, sd["pre_upsampling.bias"], stride=tuple(w.shape[2:]))
     for i in range(depth):
         x = res_conv_block(x, sd, f"down_path.{i}", i == 0, activation, normalization)
         skips.append(x)
@@ -107,6 +110,9 @@ def resunet_forward(
             up = F.conv_transpose3d(x, sd[f"up_paths.0.{j}.up.weight"], sd[f"up_paths.0.{j}.up.bias"], stride=s)
         x = torch.cat([up, skips[i]], 1)
         x = res_conv_block(x, sd, f"up_paths.0.{j}.conv_block", False, activation, normalization)
+    if "post_upsampling.weight" in sd:                 # resunet.py:326-333 / :399-400
+        w = sd["post_upsampling.weight"]
+        x = F.conv_transpose3d(x, w, sd["post_upsampling.bias"], stride=tuple(w.shape[2:]))
     outs = [_conv(x, sd, f"heads.{h}") for h in range(n_heads)]
     return torch.cat(outs, 1)
 

@@ -106,3 +106,10 @@ def resunetpp_golden():
     import numpy as np
 
     return np.load(os.path.join(ROOT, "tests", "golden", "resunetpp_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def resunet_sr_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunet_sr_golden.npz"))

@@ -609,6 +609,58 @@ def resunetpp_fixtures():
     print("resunetpp_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunetpp_golden.npz")) // 1024, "KiB")
 
 
+def resunet_sr_fixtures():
+    """Row S, the 3-D super-resolution route that works in the reference: ``ResUNet(upsampling_factor=...,
+    upsampling_position="pre" | "post")`` (resunet.py:206-213, :326-333, :368-369, :399-400).  Reference outputs, L1 loss (the SR
+    workflows' MAE), gradient norms and a few full gradients of a small 3-D net: pre x(1,2,2), pre x(2,3,2), post x(2,2,2), post x(1,2,2)."""
+    rmod = shim.load("biapy.models.resunet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import net_oracle
+
+    out = {}
+    fm = [16, 32]
+    for tag, patch, factor, pos, seed in (("pre122", (8, 16, 16), (1, 2, 2), "pre", 71), ("pre232", (4, 8, 16), (2, 3, 2), "pre", 72),
+                                          ("post222", (8, 16, 16), (2, 2, 2), "post", 73), ("post122", (8, 16, 16), (1, 2, 2), "post", 74)):
+        torch.manual_seed(seed)
+        with quiet():
+            net = rmod.ResUNet(
+                image_shape=tuple(patch) + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * 2, normalization="in", k_size=3,
+                upsample_layer="convtranspose", yx_down=[2], z_down=[2], output_channels=[1], output_channel_info=["F"], head_activations=["linear"],
+                upsampling_factor=factor, upsampling_position=pos, isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2,
+            )
+        g = torch.Generator().manual_seed(100 + seed)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if v.ndim == 1:
+                    v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+        xl = torch.rand(2, *patch, 1, generator=g)
+        x = xl.permute(0, 4, 1, 2, 3)
+        hi = tuple(p * f for p, f in zip(patch, factor))
+        tgt = torch.rand(2, 1, *hi, generator=g)
+        net.train()
+        y = net(x)
+        assert tuple(y.shape[2:]) == hi
+        loss = torch.nn.L1Loss()(y, tgt)
+        loss.backward()
+        out[f"{tag}/factor"], out[f"{tag}/pos"] = np.array(factor), np.array(pos)
+        out[f"{tag}/x"], out[f"{tag}/target"] = xl.numpy(), tgt.numpy()
+        out[f"{tag}/out"], out[f"{tag}/loss"] = y.detach().numpy(), np.array(loss.item(), dtype=np.float64)
+        for k, v in net.state_dict().items():
+            out[f"{tag}/sd/{k}"] = v.numpy()
+        names = dict(net.named_parameters())
+        for k, p_ in names.items():
+            out[f"{tag}/gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+        full = ["down_path.0.block.0.block.0.weight", "down_path.0.shortcut.0.weight", "heads.0.weight", f"{pos}_upsampling.weight", f"{pos}_upsampling.bias"]
+        for k in full:
+            out[f"{tag}/grad/{k}"] = names[k].grad.numpy()
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        err = (net_oracle.resunet_forward(sd, x, fm) - y.detach()).abs().max().item()
+        print(f"resunet SR {tag}: out {tuple(y.shape)}, oracle vs reference {err:.3e}")
+        assert err < 2e-5
+    np.savez_compressed(os.path.join(HERE, "resunet_sr_golden.npz"), **out)
+    print("resunet_sr_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_sr_golden.npz")) // 1024, "KiB")
+
+
 def loss_inputs(seed=61, shape=(2, 6, 10, 12)):
     """Seeded logits / targets of the loss fixture (tests rebuild exactly these)."""
     g = torch.Generator().manual_seed(seed)
@@ -724,7 +776,7 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -751,3 +803,5 @@ if __name__ == "__main__":
         train_loop_fixtures()
     if "losses" in which:
         losses_fixtures()
+    if "resunet_sr" in which:
+        resunet_sr_fixtures()

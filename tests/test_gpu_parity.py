@@ -792,6 +792,13 @@ def test_resunetpp_matches_reference_fixture(K, resunetpp_golden, dtype):
     _assert_all(K.check_resunetpp(dtype, resunetpp_golden))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("tag", ["pre122", "pre232", "post222", "post122"])
+def test_resunet_super_resolution_paths(K, resunet_sr_golden, tag, dtype):
+    """Row S: ResUNet pre / post up-sampling (the 3-D SR route that works in the reference) vs the reference's own outputs."""
+    _assert_all(K.check_resunet_sr(dtype, tag, resunet_sr_golden))
+
+
 def test_instance_channels_loss_matches_reference(K):
     """The B / C / D channel loss of cfg 4 (fused kernels) vs the reference's instance_segmentation_loss values and gradients."""
     _assert_all(K.check_instance_loss())

@@ -450,3 +450,56 @@ def test_loss_oracle_matches_the_reference_loss_classes():
     acts = ["ce_sigmoid", "ce_sigmoid", "tanh"]
     check("instance_bcd_mse", lambda z: LO.instance_channels(LO.apply_head_activations(z, acts), t3, ["bce", "bce", "mse"], (1, 1, 1)), z3)
     check("instance_bcd_l1_w", lambda z: LO.instance_channels(LO.apply_head_activations(z, acts), t3, ["bce", "bce", "l1"], (0.5, 0.25, 2.0)), z3)
+
+
+def test_resunetpp_module_keeps_the_reference_state_dict(resunetpp_golden):
+    """biapy_amd.resunetpp.ResUNetPlusPlus (parameter holder of row X): same state_dict keys, order and shapes as the reference's
+    ResUNetPlusPlus (the fixture's), strict loading works, and the cfg-4 architecture has the reference's 11,148,710 parameters
+    (SURVEY.md 8a row X)."""
+    import torch
+
+    from biapy_amd.resunetpp import ResUNetPlusPlus
+
+    g = resunetpp_golden
+    fm = [int(v) for v in g["feature_maps"]]
+    kw = dict(activation="elu", drop_values=[0.0] * 5, normalization="in", k_size=3, upsample_layer="convtranspose", yx_down=[2] * 4, z_down=[2] * 4,
+              output_channels=[3], output_channel_info=["BCD"], head_activations=["ce_sigmoid", "ce_sigmoid", "tanh"], isotropy=[True] * 5,
+              larger_io=False, conv_layers=[2] * 5)
+    m = ResUNetPlusPlus(image_shape=(16, 32, 32, 1), feature_maps=fm, **kw)
+    ref = [(k[3:], g[k].shape) for k in g.files if k.startswith("sd/")]
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in ref]
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k].astype(np.float32)) for k in g.files if k.startswith("sd/")}, strict=True)
+    big = ResUNetPlusPlus(image_shape=(80, 80, 80, 1), feature_maps=[16, 32, 64, 128, 256], **kw)
+    assert sum(p.numel() for p in big.parameters()) == 11148710
+    with pytest.raises(NotImplementedError):
+        ResUNetPlusPlus(image_shape=(64, 64, 1), feature_maps=fm, **kw)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 1, 16, 32, 32))
+
+
+@pytest.mark.parametrize("tag,shape", [("pre122", (8, 16, 16, 1)), ("pre232", (4, 8, 16, 1)), ("post222", (8, 16, 16, 1)), ("post122", (8, 16, 16, 1))])
+def test_resunet_sr_oracle_and_module(resunet_sr_golden, tag, shape):
+    """Row S (3-D super-resolution through ResUNet.pre/post_upsampling, resunet.py:206-213, :326-333): the oracle reproduces the
+    reference's output, L1 loss and gradients, and the drop-in owns the reference's parameters (names, order, shapes)."""
+    import torch
+
+    from biapy_amd.resunet import ResUNet
+    from oracle import net_oracle
+
+    g = resunet_sr_golden
+    pre = f"{tag}/sd/"
+    sd = {k[len(pre):]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith(pre)}
+    x = torch.from_numpy(g[f"{tag}/x"]).permute(0, 4, 1, 2, 3)
+    y = net_oracle.resunet_forward(sd, x, [16, 32])
+    loss = torch.nn.L1Loss()(y, torch.from_numpy(g[f"{tag}/target"]))
+    loss.backward()
+    assert (y.detach() - torch.from_numpy(g[f"{tag}/out"])).abs().max().item() < 2e-5 and abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith(f"{tag}/grad/"):
+            ref = torch.from_numpy(g[k])
+            assert (sd[k[len(tag) + 6:]].grad - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
+    m = ResUNet(image_shape=shape, activation="elu", feature_maps=[16, 32], drop_values=[0.0] * 2, normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2, head_activations=["linear"],
+                upsampling_factor=tuple(int(v) for v in g[f"{tag}/factor"]), upsampling_position=str(g[f"{tag}/pos"]))
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
