@@ -13,7 +13,7 @@ and reported as a sub-record with its own roofline entry:
   ``infer``   - forward + fused sigmoid of the same batch (weak scaling: every rank its own batch);
   ``sliding`` - cfg 3, crop -> forward -> blend of a 1024^3 synthetic volume, 4096 patches sharded over the ranks by Z-slab, each
                 rank holding only its input slab; strong scaling (N = 1 measures one GPU's share of the 8-GPU job, a 512^3 volume,
-                unless --sliding-vol is given).
+                unless --vol is given).
 Workload = BASELINE.json configs[1]: 3D ResUNet (feature maps 16-32-64-128-256, InstanceNorm, ELU), 128^3 1-channel patches,
 batch 4 per GPU, bf16 storage / fp32 accumulate, synthetic data, random-init weights.  One step = one pass over one batch.
 """
@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel timing table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-events", action="store_true",
+                    help="skip the eager per-launch event steps after a graph-replayed timed region (no roofline entry): a rocprofv3 kernel trace "
+                         "of the command then holds the capture warm-up and graph-replayed steps only")
     ap.add_argument("--quick-cpu-baseline", action="store_true", help="only the all-core train leg")
     ap.add_argument("--force-ddp", action="store_true", help="testing aid: take the multi-GPU code path (RCCL process group) even with one rank")
     ap.add_argument("--dp", choices=["flat", "ddp"], default="flat",
@@ -427,7 +430,7 @@ def main():
         fb_graphs = getattr(model, "_graphs", None) is not None
         if fb_graphs:
             model.release_graphs()
-        if graphed or fb_graphs:
+        if (graphed or fb_graphs) and not a.no_launch_events:
             # a graph replay has no per-launch events: time the same launches on the same stream in eager steps right after
             # the timed region (same kernels, same shapes; `value` above is NOT taken from these steps)
             prof_steps = min(a.steps, 5)
@@ -489,7 +492,7 @@ def main():
         elapsed = _timed(step, a.steps, world, dev)
         L.lib.prof = None
         prof_steps = a.steps
-        if graphed:
+        if graphed and not a.no_launch_events:
             prof_steps = min(a.steps, 5)
             L.lib.prof = prof
             for _ in range(prof_steps):

