@@ -20,21 +20,22 @@ namespace {
 
 // workgroups per CU the register budget is set for; every configuration must compile WITHOUT scratch (a spilling kernel
 // runs up to 2x slower inside the network than alone: measured)
-constexpr int lp_occ(int vox, int ns, int epi, int actk, int pf = 0) {
-  // the prefetch variant keeps a chunk's pieces live across the MFMA steps (+36 VGPRs): two workgroups per CU
-  return (pf || ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
+constexpr int lp_occ(int vox, int ns, int epi, int actk) {
+  return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
 }
 
-// PF = 1 (measured in round 2, NOT instantiated in the library): the halo pieces of the NEXT chunk (or of the next tile's first
-// chunk) are requested right after this chunk's pieces have been written to LDS, i.e. before the barrier and the 14 MFMA steps,
-// and are consumed at the top of the next iteration - the global-load latency of a chunk is then covered by the MFMA phase of the
-// previous one at the price of NP x 4 live VGPRs.  The kernels sit at 159-166 VGPRs of the 168 that three workgroups per CU
-// allow, so the variant only compiles without scratch at two workgroups per CU, and there it loses on every cfg-2 layer (us,
-// B = 4): fwd 48->16 @128^3 755 -> 808, 16->16+sc48 436 -> 466, 96->32 @64^3 287 -> 311; dgrad 16->48 908 -> 1082, 16->16
-// 293 -> 332: residency covers more latency than an in-workgroup prefetch.  (s_setprio 1 around the MFMA steps, BPX_CONV_DBG=16:
-// -1..-5 % forward, +-2 % dgrad - left off.)
-template <int TZ, int TY, int TX, int NS, int EPI, int ACTK, int PF = 0>
-__global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK, PF)) conv3_lp_kernel(const Conv3Params p) {
+// Measured in round 2 and NOT adopted (the code is in the history, commit "lean conv: piece validity mask ..."):
+//   * next-chunk prefetch: the halo pieces of the next chunk (or of the next tile's first chunk) requested right after this chunk's
+//     pieces are in LDS and consumed at the top of the next iteration, so that the global-load latency is covered by the 14 MFMA
+//     steps in between, at the price of NP x 4 live VGPRs.  The kernels sit at 154-166 VGPRs of the 168 that three workgroups per
+//     CU allow, so the variant only compiles without scratch at two workgroups per CU, and there it loses on every cfg-2 layer
+//     (us, B = 4): fwd 48->16 @128^3 755 -> 808, 16->16+sc48 436 -> 466, 96->32 @64^3 287 -> 311; dgrad 16->48 908 -> 1082,
+//     16->16 293 -> 332.  Residency covers more latency than an in-workgroup prefetch;
+//   * more workgroups per CU than lp_occ() (bpx_debug_set_conv_occ 4 / 5 / 6): the extra ones queue (VGPR-limited residency):
+//     +0..+10 %;
+//   * s_setprio 1 around the MFMA steps (BPX_CONV_DBG=16, still selectable): -1..-5 % forward, +-2 % dgrad - left off.
+template <int TZ, int TY, int TX, int NS, int EPI, int ACTK>
+__global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv3_lp_kernel(const Conv3Params p) {
   using T = uint16_t;
   constexpr int KPL = 8, VB = 32;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
@@ -90,53 +91,30 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK, PF)) 
   const int nchunks = p.Cin / 16;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
 
-  // coordinates of tile `local` of this XCD, the byte offset of its halo origin and the validity mask of this thread's pieces
-  // (bit u = piece u lies inside the volume); returns false past the end of the tile list.  A piece's address is halo origin +
-  // rel[u] (+ chunk * 32 bytes): nothing per piece is kept in registers besides rel[].
-  struct TileAt { int n, tile, z0, y0, x0; uint32_t base_b, ok; };
-  auto tile_at = [&](int local, TileAt& t) -> bool {
+  for (int local = slot; local < p.tilesPerXcd; local += spx, ++it) {
     const int tileId = xcd * p.tilesPerXcd + local;
-    if (local >= p.tilesPerXcd || tileId >= p.totalTiles) return false;
-    t.n = tileId / p.tilesPerSample;
-    t.tile = tileId - t.n * p.tilesPerSample;
-    const int txi = t.tile % p.tilesX, tyi = (t.tile / p.tilesX) % p.tilesY, tzi = t.tile / (p.tilesX * p.tilesY);
-    t.z0 = tzi * TZ; t.y0 = tyi * TY; t.x0 = txi * TX;
-    t.base_b = (uint32_t)(((t.n * D + t.z0 - 1) * H + (t.y0 - 1)) * W + (t.x0 - 1)) * (uint32_t)p.x_ld * 2u;
-    const bool interior = t.z0 >= 1 && t.z0 + TZ + 1 <= D && t.y0 >= 1 && t.y0 + TY + 1 <= H && t.x0 >= 1 && t.x0 + TX + 1 <= W;
-    uint32_t ok = last_ok ? (1u << NP) - 1u : (1u << (NP - 1)) - 1u;
-    if (!interior) {  // border tiles only: re-derive the pieces' halo coordinates (kept out of registers on purpose)
+    if (tileId >= p.totalTiles) break;
+    BPX_STAMP();  // 0: tile start
+    const int n = tileId / p.tilesPerSample, tile = tileId - n * p.tilesPerSample;
+    const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+
+    // ---- global offsets (elements) of this thread's halo pieces: tile base + per-lane constant --------------------
+    const uint32_t base_b = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.x_ld * 2u;
+    const bool interior = z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+    uint32_t goff[NP];
 #pragma unroll
-      for (int u = 0; u < NP; ++u) {
+    for (int u = 0; u < NP; ++u) {
+      bool ok = (u < NP - 1) || last_ok;
+      if (!interior) {  // border tiles only: re-derive the piece's halo coordinates (kept out of registers on purpose)
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
         const int hv = (u * 256 + tid_o) >> 1;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-        const bool in = (unsigned)(t.z0 - 1 + hz) < (unsigned)D && (unsigned)(t.y0 - 1 + hy) < (unsigned)H && (unsigned)(t.x0 - 1 + hx) < (unsigned)W;
-        if (!in) ok &= ~(1u << u);
+        ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
       }
+      goff[u] = ok ? base_b + rel[u] : 0xFFFFFFFFu;
     }
-    t.ok = ok;
-    return true;
-  };
-  auto load_pieces = [&](u32x4_t* pb, uint32_t base_b, uint32_t ok, int chunk) {
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      pb[u] = u32x4_t{0u, 0u, 0u, 0u};
-      if (ok & (1u << u)) pb[u] = *reinterpret_cast<const u32x4_t*>(xin + (base_b + rel[u] + (uint32_t)chunk * 32u));
-    }
-  };
-
-  TileAt cur;
-  u32x4_t pbuf[NP];
-  bool have = tile_at(slot, cur);
-  if (PF && have) load_pieces(pbuf, cur.base_b, cur.ok, 0);
-  for (int local = slot; have; local += spx, ++it) {
-    BPX_STAMP();  // 0: tile start
-    const int n = cur.n, tile = cur.tile, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
-    const uint32_t okmask = cur.ok;
-    TileAt nxt;
-    bool have_n = false;
-    if (PF) have_n = tile_at(local + spx, nxt);
     // dgrad never normalises its input (dy): the prologue code is compiled out of those kernels
     const bpx_norm_rec* __restrict__ nrec = (EPI == EPI_FWD && p.in_norm) ? p.in_norm + (size_t)n * p.Cin + sub * KPL : nullptr;
 
@@ -149,7 +127,12 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK, PF)) 
     // ---- K loop over 16-channel chunks: stage -> barrier -> 14 MFMA steps ------------------------------------------
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       __syncthreads();  // every wave is done reading the halo buffer (previous chunk / previous tile)
-      if (!PF) load_pieces(pbuf, cur.base_b, okmask, chunk);
+      u32x4_t pbuf[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
+        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + (goff[u] + (uint32_t)chunk * 32u));
+      }
       float psc[KPL], psh[KPL];
       if (nrec) {
 #pragma unroll
@@ -168,7 +151,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK, PF)) 
       for (int u = 0; u < NP; ++u) {
         if (u < NP - 1 || last_ok) {
           u32x4_t v = pbuf[u];
-          if (nrec && (okmask & (1u << u))) {  // zero padding applies to the ACTIVATED tensor: out-of-volume stays 0
+          if (nrec && goff[u] != 0xFFFFFFFFu) {  // zero padding applies to the ACTIVATED tensor: out-of-volume stays 0
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               float a = fmaf(psc[2 * i], bf16lo(v[i]), psh[2 * i]), b = fmaf(psc[2 * i + 1], bf16hi(v[i]), psh[2 * i + 1]);
@@ -178,11 +161,6 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK, PF)) 
           }
           *reinterpret_cast<u32x4_t*>(smem + (size_t)(u * 256 + tid) * 16) = v;
         }
-      }
-      if (PF) {  // request what the next iteration stages; the loads stay in flight across the barrier and the MFMA steps
-        if (chunk + 1 < nchunks) load_pieces(pbuf, cur.base_b, okmask, chunk + 1);
-        else if (have_n) load_pieces(pbuf, nxt.base_b, nxt.ok, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
       if (chunk == 0) BPX_STAMP();  // 1: first chunk staged
       __syncthreads();
@@ -399,13 +377,6 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK, PF)) 
       }
     }
     BPX_STAMP();  // 6: tile done
-    // advance: the next tile's coordinates / offsets were computed one iteration ahead when prefetching
-    if (PF) {
-      have = have_n;
-      cur = nxt;
-    } else {
-      have = tile_at(local + spx, cur);
-    }
   }
 #undef BPX_STAMP
 }
