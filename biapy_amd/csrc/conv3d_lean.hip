@@ -20,9 +20,17 @@ namespace {
 
 // workgroups per CU the register budget is set for; every configuration must compile WITHOUT scratch (a spilling kernel
 // runs up to 2x slower inside the network than alone: measured)
+#ifndef BPX_DGRAD_BIG_OCC
+#define BPX_DGRAD_BIG_OCC 4
+#endif
 constexpr int lp_occ(int vox, int ns, int epi, int actk) {
-  return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2 : (ns == 1 && vox <= 256) ? 4 : 3;
+  return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2
+         : (ns == 1 && vox <= 256)                                                                 ? 4
+         : (ns == 1 && epi == EPI_DGRAD)                                                           ? BPX_DGRAD_BIG_OCC
+                                                                                                   : 3;
 }
+// the 4x8x16 dgrad tile fits the 128 VGPRs of four workgroups per CU when its eight A fragments are read in two halves
+constexpr int lp_ahalf(int ms, int ns, int epi) { return (ms > 4 && ns == 1 && epi == EPI_DGRAD && BPX_DGRAD_BIG_OCC == 4) ? ms / 2 : ms; }
 
 // Measured in round 2 and NOT adopted (the code is in the history, commit "lean conv: piece validity mask ..."):
 //   * next-chunk prefetch: the halo pieces of the next chunk (or of the next tile's first chunk) requested right after this chunk's
@@ -33,6 +41,8 @@ constexpr int lp_occ(int vox, int ns, int epi, int actk) {
 //     16->16 293 -> 332.  Residency covers more latency than an in-workgroup prefetch;
 //   * more workgroups per CU than lp_occ() (bpx_debug_set_conv_occ 4 / 5 / 6): the extra ones queue (VGPR-limited residency):
 //     +0..+10 %;
+//   * ADOPTED: four workgroups per CU for the 4x8x16 dgrad tile (A fragments read in two halves -> 119 VGPRs, no scratch):
+//     dgrad 16->16 @128^3 257 -> 241 us; the same for the forward tile still spills 150 B/lane at 128 VGPRs (staging peak) and stays at 3;
 //   * s_setprio 1 around the MFMA steps (BPX_CONV_DBG=16, still selectable): -1..-5 % forward, +-2 % dgrad - left off.
 template <int TZ, int TY, int TX, int NS, int EPI, int ACTK>
 __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv3_lp_kernel(const Conv3Params p) {
@@ -175,14 +185,18 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         }
         const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
         const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
-        u32x4_t af[MS];
+        constexpr int MH = lp_ahalf(MS, NS, EPI);
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int h = 0; h < MS; h += MH) {
+          u32x4_t af[MH];
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
+          for (int ms = 0; ms < MH; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + (h + ms) * HSTR + imm);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[ms][ns]);
+          for (int ms = 0; ms < MH; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) acc[h + ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[h + ms][ns]);
+        }
       }
       if (p.dbg & 16) __builtin_amdgcn_s_setprio(0);
       if (chunk == 0) BPX_STAMP();  // 3: first step loop
