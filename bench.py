@@ -574,8 +574,10 @@ def run_resunetpp(a, dev, rank, world, multi, dtype):
     n = torch.randn(a.batch, 2, P, P, P, generator=g, device=dev)
     tgt = torch.cat([(F.avg_pool3d(n, 9, stride=1, padding=4) > 0).float(), torch.rand(a.batch, 1, P, P, P, generator=g, device=dev) * 2 - 1], 1)
     loss_fn = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).to(dev)
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True, bucket_cap_mb=64) if multi else model
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    want_graph = a.graph != "off" and a.dp != "ddp"
+    use_ddp = multi and not want_graph
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True, bucket_cap_mb=64) if use_ddp else model
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=want_graph)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -583,6 +585,27 @@ def run_resunetpp(a, dev, rank, world, multi, dtype):
         loss.backward()
         opt.step()
         return loss
+
+    launch = "eager (tape engine%s)" % ("; DistributedDataParallel" if use_ddp else "")
+    if a.breakdown:
+        from biapy_amd import _lib as L
+        for _ in range(2):
+            step()
+        return breakdown(a, L, step, "ResUNet++ train")
+    if want_graph:
+        # the tape engine issues ~1500 launches per step from Python: replay them (same classes as the ResUNet bench line)
+        try:
+            from biapy_amd.graphs import DataParallelTrainStep, GraphedTrainStep
+            g_step = (DataParallelTrainStep(model, loss_fn, opt, x, tgt, graph=True, warmup=max(2, a.warmup)) if multi
+                      else GraphedTrainStep(model, loss_fn, opt, x, tgt, warmup=max(2, a.warmup)))
+            step = lambda: g_step()
+            launch = ("hip-graph replays (forward+loss+backward | optimizer) around one flat-gradient RCCL all-reduce" if multi
+                      else "hip-graph replay (whole step)")
+        except Exception as e:  # noqa: BLE001 - the eager tape is the fallback of the bench, never of the product
+            if multi:
+                raise
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
 
     for _ in range(a.warmup):
         out = step()
@@ -596,7 +619,7 @@ def run_resunetpp(a, dev, rank, world, multi, dtype):
         print(json.dumps(dict(
             metric="voxels/sec 3D ResUNet++ %d^3 patch (train: fwd + B/C/D loss + bwd + AdamW)" % P, value=value, unit="voxels/s", n_gpus=world,
             steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype,
-            data="synthetic", launch="eager (tape engine; DistributedDataParallel for N > 1)",
+            data="synthetic", launch=launch,
             config=dict(workload="cfg4: 3D ResUNet++ fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, 3 channels (B,C,D), batch %d/GPU, train" % (P, a.batch),
                         global_batch=world * a.batch, patch=P, parameters=nparams, parallelism="dp%d" % world, mode="train"),
             mfma_frac_end_to_end=round(value * 1044917 * 3 / (world * MFMA_PEAK_BF16), 5))))

@@ -98,11 +98,14 @@ _SIGS = {
     "bpx_maxpool3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_maxpool3d_bwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp], _i),
     "bpx_head_fwd": ([_i, _i64, _i, Tensor, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp], _i),
-    "bpx_head_bwd": ([_i, _i64, _i, Tensor, _vp, _i, _vp, _i64, _i64, Tensor, _vp, _vp, _vp], _i),
+    "bpx_head_bwd": ([_i, _i64, _i, Tensor, _vp, _i, _vp, _i64, _i64, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
+    "bpx_head_bwd_workspace": ([_i, _i], _i64),
+    "bpx_conv3d_c1_wgrad_workspace": ([_i], _i64),
+    "bpx_conv1x1_c1_wgrad_workspace": ([_i], _i64),
     "bpx_conv3d_c1_fwd": ([_i, _i, _i, _i, _i, _vp, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_c1_stats_tiles": ([_i, _i, _i], _i),
-    "bpx_conv3d_c1_wgrad": ([_i, _i, _i, _i, _i, _vp, Tensor, _vp, _vp, _vp], _i),
-    "bpx_conv1x1_c1_wgrad": ([_i, _i64, _vp, Tensor, _vp, _vp], _i),
+    "bpx_conv3d_c1_wgrad": ([_i, _i, _i, _i, _i, _vp, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
+    "bpx_conv1x1_c1_wgrad": ([_i, _i64, _vp, Tensor, _vp, _vp, _i64, _vp], _i),
     "bpx_cast": ([_i, _vp, _i, _vp, _i64, _vp], _i),
     "bpx_upsample_c1_fwd": ([_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_upsample_c1_blocks": ([_i64], _i),

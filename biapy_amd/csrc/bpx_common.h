@@ -163,3 +163,10 @@ static inline size_t dtype_size(int dt) {
   }
   return 0;
 }
+
+// wgrad.hip: dw[ci*si + co*sj + tap*st] = sum over the `groups` partial slabs [groups][taps][Cin][Cout] (fixed order, no atomics) and
+// db[c] += sum of the rows [groups][ndb] (ndb = 0: Cout); may_defer: queued with the other weight-gradient reductions while the deferred mode is on
+namespace bpxred {
+int reduce_partials(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
+                    const float* dbpart, float* db, int ndb, bool may_defer, hipStream_t s);
+}

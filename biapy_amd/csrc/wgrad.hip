@@ -34,7 +34,8 @@ struct WgradParams {
   int dy_vz;               // z stride of that mapping (0 = same as dy_vs): kernel (1,2,2) has vz = 1
   float* part;                                   // [groups][taps][Cin][Cout] per-block partial sums (workspace)
   float* dw; int64_t si, sj, st; int64_t off;   // final dW index = ci*si + co*sj + tap*st + off (reduce kernel)
-  float* db;
+  float* db;                                     // bias gradient (accumulated into by the reduce kernel), or null
+  float* dbpart;                                 // [groups][Cout] per-group column sums of dy (workspace, behind `part`): no atomics
   int tilesY, tilesX, tilesPerSample, totalTiles, groups;
 };
 
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     if (tid < CB) {
       float s = 0.f;
       for (int k = tid; k < 256; k += CB) s += red[k];
-      atomicAdd(p.db + co_base + tid, s);
+      p.dbpart[(size_t)grp * p.Cout + co_base + tid] = s;   // one writer per (group, channel)
     }
   }
   (void)sB;
@@ -562,7 +563,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
     if (tid < CB) {
       float s = 0.f;
       for (int k = tid; k < 256; k += CB) s += red[k];
-      atomicAdd(p.db + co_base + tid, s);
+      p.dbpart[(size_t)grp * p.Cout + co_base + tid] = s;   // one writer per (group, channel)
     }
   }
 }
@@ -790,7 +791,7 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
     if (tid < CB) {
       float s = 0.f;
       for (int k = tid; k < 256; k += CB) s += red[k];
-      atomicAdd(p.db + co_base + tid, s);
+      p.dbpart[(size_t)grp * p.Cout + co_base + tid] = s;   // one writer per (group, channel)
     }
   }
 }
@@ -931,7 +932,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
       const int sg = tid / KPL, e = tid % KPL;
       float sum = 0.f;
       for (int k = sg; k < 256; k += PPVG) sum += red[k * KPL + e];
-      atomicAdd(p.db + co_base + tid, sum);
+      p.dbpart[(size_t)grp * p.Cout + co_base + tid] = sum;
     }
   }
 }
@@ -958,7 +959,7 @@ inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
 // 1024 threads = 32 consecutive elements x 32 group lanes, four loads in flight per thread: the smallest dW has only 6912
 // elements (216 blocks) against up to 1024 partial slabs, so the kernel is a latency chain per block - with 8 group lanes
 // and two loads in flight it took ~70 us for the 16->16 layers, more than a quarter of their MFMA kernel.
-struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; };
+struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; const float* dbpart; float* db; int ndb; };   // ndb: length of a bias row (0 = Cout)
 
 // 1024 threads = EL consecutive elements x GL group lanes (GL = reduce_glanes(groups), EL = 1024 / GL), up to four loads in
 // flight per thread; lane sums are combined in a fixed order, so the result does not depend on scheduling.
@@ -967,34 +968,45 @@ __host__ __device__ inline int reduce_glanes(int groups) {
   while (gl < 32 && gl * 4 < groups) gl <<= 1;   // ~4 slabs per thread and more for the many-group layers
   return gl;
 }
-inline int reduce_blocks(const ReduceJob& j) { return (int)cdiv64((int64_t)j.taps * j.Cin * j.Cout, 1024 / reduce_glanes(j.groups)); }
+// elements of a job: the dW entries, then (with a bias gradient) the Cout column sums
+inline int reduce_blocks(const ReduceJob& j) {
+  return (int)cdiv64((int64_t)j.taps * j.Cin * j.Cout + (j.db ? (j.ndb ? j.ndb : j.Cout) : 0), 1024 / reduce_glanes(j.groups));
+}
 
 __device__ __forceinline__ void wgrad_reduce_block(const ReduceJob& j, int block) {
   __shared__ float red[1024];
   const float* __restrict__ part = j.part;
   const int groups = j.groups;
   const int GL = reduce_glanes(groups), EL = 1024 / GL;
-  const int64_t total = (int64_t)j.taps * j.Cin * j.Cout;
+  const int ndb = j.ndb ? j.ndb : j.Cout;
+  const int64_t total = (int64_t)j.taps * j.Cin * j.Cout, all = total + (j.db ? ndb : 0);
   const int e = threadIdx.x % EL, gl = threadIdx.x / EL;
   const int64_t idx = (int64_t)block * EL + e;
+  // element idx of slab g: a dW entry, or (idx >= total) a column sum of the bias-gradient partials [groups][Cout]
+  const float* __restrict__ src = idx < total ? part + idx : j.dbpart + (idx - total);
+  const int64_t stride = idx < total ? total : ndb;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (idx < total) {
+  if (idx < all) {
     int gq = gl;
     for (; gq + 3 * GL < groups; gq += 4 * GL) {
-      s0 += part[(size_t)gq * total + idx];
-      s1 += part[(size_t)(gq + GL) * total + idx];
-      s2 += part[(size_t)(gq + 2 * GL) * total + idx];
-      s3 += part[(size_t)(gq + 3 * GL) * total + idx];
+      s0 += src[(size_t)gq * stride];
+      s1 += src[(size_t)(gq + GL) * stride];
+      s2 += src[(size_t)(gq + 2 * GL) * stride];
+      s3 += src[(size_t)(gq + 3 * GL) * stride];
     }
-    for (; gq < groups; gq += GL) s0 += part[(size_t)gq * total + idx];
+    for (; gq < groups; gq += GL) s0 += src[(size_t)gq * stride];
   }
   red[gl * EL + e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (gl == 0 && idx < total) {
+  if (gl == 0 && idx < all) {
     float s = red[e];
     for (int q = 1; q < GL; ++q) s += red[q * EL + e];
-    int co = (int)(idx % j.Cout), ci = (int)((idx / j.Cout) % j.Cin), tap = (int)(idx / ((int64_t)j.Cout * j.Cin));
-    j.dw[ci * j.si + co * j.sj + tap * j.st + j.off] = s;
+    if (idx < total) {
+      int co = (int)(idx % j.Cout), ci = (int)((idx / j.Cout) % j.Cin), tap = (int)(idx / ((int64_t)j.Cout * j.Cin));
+      j.dw[ci * j.si + co * j.sj + tap * j.st + j.off] = s;
+    } else {
+      j.db[idx - total] += s;   // accumulated like the former atomics (the caller zeroes db), single writer, fixed order
+    }
   }
 }
 
@@ -1061,6 +1073,7 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
   int nchunks = p.Cin / 16, nb = p.Cout / (16 * c.ns);
   int groups = c.groups;
   p.groups = groups;
+  p.dbpart = p.part + (size_t)groups * TAPS * p.Cin * p.Cout;
   const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
   dim3 grid((unsigned)(((groups + 7) & ~7) * nchunks * nb));
 #define L(TZY, TX, NS)                                                                              \
@@ -1117,6 +1130,7 @@ int launch_wgrad_sd(const WgradParams& p0, WCfg& c, hipStream_t s) {
   if (ns == 1 && mc > 0) {
     c.groups = q.groups;                                   // the reduce that follows reads this many partial slabs
     p.groups = q.groups;
+    p.dbpart = p.part + (size_t)p.groups * 27 * p.Cin * p.Cout;
     dim3 gridm((unsigned)(((c.groups + 7) & ~7) * (nchunks / mc) * nb));
     if (mc == 1) { if (elu) wgrad_sdm_kernel<1, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<1, 0><<<gridm, 256, 0, s>>>(p); }
     else if (mc == 2) { if (elu) wgrad_sdm_kernel<2, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<2, 0><<<gridm, 256, 0, s>>>(p); }
@@ -1125,6 +1139,7 @@ int launch_wgrad_sd(const WgradParams& p0, WCfg& c, hipStream_t s) {
     return 0;
   }
   p.groups = c.groups;
+  p.dbpart = p.part + (size_t)p.groups * 27 * p.Cin * p.Cout;
   dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
   if (ns == 1) { if (elu) wgrad_sd_kernel<1, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<1, 0><<<grid, 256, 0, s>>>(p); }
   else { if (elu) wgrad_sd_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<2, 0><<<grid, 256, 0, s>>>(p); }
@@ -1133,8 +1148,9 @@ int launch_wgrad_sd(const WgradParams& p0, WCfg& c, hipStream_t s) {
 
 int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int64_t ws_bytes, hipStream_t s) {
   WCfg c = pick_wcfg(p.N, p.D, p.H, p.W, p.Cin, p.Cout, taps, false);  // 8x8x16 tiles for k=1 measured slower (convT wgrad 0.76 -> 1.02 ms): off
-  int64_t need = (int64_t)c.groups * taps * p.Cin * p.Cout * 4;
-  if (taps == 27) need = std::max(need, (int64_t)sdm_plan(p.N, p.D, p.H, p.W, p.Cin, p.Cout).groups * taps * p.Cin * p.Cout * 4);
+  const int64_t slab = ((int64_t)taps * p.Cin + 1) * p.Cout * 4;   // dW partials + the bias-gradient row of a group
+  int64_t need = (int64_t)c.groups * slab;
+  if (taps == 27) need = std::max(need, (int64_t)sdm_plan(p.N, p.D, p.H, p.W, p.Cin, p.Cout).groups * slab);
   BPX_CHECK(ws != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   p.part = reinterpret_cast<float*>(ws);
   int rc;
@@ -1146,22 +1162,36 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   else rc = (taps == 27) ? launch_wgrad<float, 27>(p, c, false, s) : launch_wgrad<float, 1>(p, c, false, s);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
-  return finish_wgrad(fn, ReduceJob{p.part, p.dw, c.groups, taps, p.Cin, p.Cout, p.si, p.sj, p.st, p.off}, s);
+  const float* dbpart = p.db ? p.part + (size_t)c.groups * taps * p.Cin * p.Cout : nullptr;   // where the launcher pointed the kernel
+  return finish_wgrad(fn, ReduceJob{p.part, p.dw, c.groups, taps, p.Cin, p.Cout, p.si, p.sj, p.st, p.off, dbpart, p.db, 0}, s);
 }
 
 }  // namespace
+
+// for the small weight-gradient kernels of elementwise.hip (first layer, rank-1 shortcut, head): the same fixed-order reduction of
+// per-workgroup partials, queued with the others while the deferred mode is on
+namespace bpxred {
+int reduce_partials(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
+                    const float* dbpart, float* db, int ndb, bool may_defer, hipStream_t s) {
+  const ReduceJob j{part, dw, groups, taps, Cin, Cout, si, sj, st, 0, db ? dbpart : nullptr, db, ndb};
+  if (may_defer) return finish_wgrad(fn, j, s);
+  wgrad_reduce_kernel<<<reduce_blocks(j), 1024, 0, s>>>(j);   // the caller reads the result right away (head gradients)
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+}  // namespace bpxred
 
 extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout, int k) {
   int taps = k * k * k;
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, taps, false);  // small tiles give the larger group count: an upper bound
   int64_t groups = c.groups;
   if (taps == 27) groups = std::max<int64_t>(groups, sdm_plan(N, D, H, W, Cin, Cout).groups);
-  return groups * taps * Cin * Cout * 4;
+  return groups * ((int64_t)taps * Cin + 1) * Cout * 4;   // per group: the dW partials and one row of bias-gradient column sums
 }
 extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);           // fp32: one launch per sub-position
   CtCfg t = pick_ct(N, D, H, W, sz, Cin, Cout);                  // bf16: single pass, [groups][4*sz][Cin][Cout]
-  return std::max((int64_t)c.groups * Cin * Cout * 4, (int64_t)t.groups * 4 * sz * Cin * Cout * 4);
+  return std::max((int64_t)c.groups * ((int64_t)Cin + 1) * Cout * 4, (int64_t)t.groups * ((int64_t)4 * sz * Cin + 1) * Cout * 4);
 }
 
 // test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 in the bf16 wgrad
@@ -1203,13 +1233,14 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
   if (dtype == BPX_BF16 && g_use_tr != 0 && (int64_t)N * D * H * W * nsub * std::max(x.ld, dy.ld) < (1ll << 31)) {
     CtCfg c = pick_ct(N, D, H, W, sz, x.C, dy.C);
-    const int64_t need = (int64_t)c.groups * nsub * x.C * dy.C * 4;
+    const int64_t need = (int64_t)c.groups * ((int64_t)nsub * x.C + 1) * dy.C * 4;
     BPX_CHECK(ws_d != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
     p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C;
     p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C;
     p.part = reinterpret_cast<float*>(ws_d); p.db = db_d;
+    p.dbpart = p.part + (size_t)c.groups * nsub * x.C * dy.C;
     p.tilesY = c.tilesY; p.tilesX = c.tilesX; p.tilesPerSample = c.tilesPerSample; p.totalTiles = c.totalTiles; p.groups = c.groups;
     const int nchunks = x.C / 16, nb = dy.C / (16 * c.ns);
     dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
@@ -1218,7 +1249,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     else { if (c.ns == 2) wgrad_ct_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 1><<<grid, 256, 0, s>>>(p); }
     BPX_LAUNCH_CHECK(fn);
     // (Cin, Cout, sz, 2, 2): index = ci*Cout*nsub + co*nsub + sub
-    return finish_wgrad(fn, ReduceJob{p.part, dw_d, c.groups, nsub, x.C, dy.C, (int64_t)dy.C * nsub, nsub, 1, 0}, s);
+    return finish_wgrad(fn, ReduceJob{p.part, dw_d, c.groups, nsub, x.C, dy.C, (int64_t)dy.C * nsub, nsub, 1, 0, db_d ? p.dbpart : nullptr, db_d, 0}, s);
   }
   // one launch per sub-position, all through the same workspace: these reductions cannot wait
   struct NoDefer { bool was; NoDefer() : was(t_defer.active) { t_defer.active = false; } ~NoDefer() { t_defer.active = was; } } no_defer;

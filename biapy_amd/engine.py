@@ -518,10 +518,17 @@ class ResUNetEngine:
         # conv2 weight/bias grad, shortcut weight grad
         self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev)
         if blk.first and self.cfg.in_ch == 1:
-            self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.dt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(), s_)))
+            ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
+            self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.dt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
+                                                                            ws1.data_ptr(), ws1.numel(), s_)))
         else:
             self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
-        self._run_side(dev, lambda s_: G[k["bsc"]].copy_(G[k["b2"]]))  # both biases add to the same tensor: identical gradient
+        # both biases add to the same tensor: identical gradient.  The bias gradient of conv2 is complete once its partial sums have
+        # been combined - at the flush while the reductions are deferred
+        if self._deferred:
+            self._after_flush.append(lambda: G[k["bsc"]].copy_(G[k["b2"]]))
+        else:
+            self._run_side(dev, lambda s_: G[k["bsc"]].copy_(G[k["b2"]]))
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
         self._keep.append(g1)   # read by the side-stream wgrad of conv1
@@ -537,8 +544,9 @@ class ResUNetEngine:
         dH = L.tview(g1)
         # conv1
         if blk.first and self.cfg.in_ch == 1:
+            wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(C1), dev)
             self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), dH, G[k["w1"]].data_ptr(),
-                                                                           G[k["b1"]].data_ptr(), s_)))
+                                                                           G[k["b1"]].data_ptr(), wsc.data_ptr(), wsc.numel(), s_)))
             self._keep.append(g1)
             return
         xv = L.tview(blk.x, blk.x_c0, blk.cin)
@@ -574,6 +582,7 @@ class ResUNetEngine:
         # the ~29 weight-gradient reductions of a step run as one batched launch at the end (they are latency chains of a
         # few hundred blocks each; back to back they cost 0.6 ms).  Not with the side stream: the flush is stream-ordered.
         self._deferred = self._side(dlogits.device) is None
+        self._after_flush = []
         if self._deferred:
             L.check(lib.bpx_wgrad_defer_begin())
         Pw = ctx.get("Pw")
@@ -584,6 +593,9 @@ class ResUNetEngine:
                 self._deferred = False
                 L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
             self._keep = []
+        for fn in self._after_flush:
+            fn()
+        self._after_flush = []
         return G if Pw is None else unlift_grads(G, P)      # after the flush: it is the flush that writes the conv gradients
 
     def _backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -613,8 +625,9 @@ class ResUNetEngine:
         dfeat = torch.empty((B,) + tuple(So) + (fm[0],), dtype=T, device=dev)
         hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
         hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
+        hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
         L.check(lib.bpx_head_bwd(self.dt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
-                                 L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), st))
+                                 L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
         if cfg.post_up:
             dec_out, dup_feat = ctx["dec_out"], dfeat
             wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, D0, H0, W0, cfg.post_up, fm[0], fm[0])

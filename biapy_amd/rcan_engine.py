@@ -177,8 +177,9 @@ class RCANEngine(ResUNetEngine):
             hwg = torch.zeros((self.n_out, 16), dtype=torch.float32, device=dev)
             hbg = torch.zeros((self.n_out,), dtype=torch.float32, device=dev)
             dl = dy_out.contiguous().float()
+            hws = self._workspace(lib.bpx_head_bwd_workspace(16, self.n_out), dev)
             L.check(lib.bpx_head_bwd(self.dt, vox, B, L.tview(ctx["o16"]), ctx["hw"].data_ptr(), self.n_out, dl.data_ptr(), self.n_out * vox, vox,
-                                     L.tview(do16), hwg.data_ptr(), hbg.data_ptr(), st))
+                                     L.tview(do16), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
             dw16 = torch.zeros((16, Fc, 3, 3, 3), dtype=torch.float32, device=dev)
             db16 = torch.zeros(16, dtype=torch.float32, device=dev)
             wgrad(ctx["t"], None, 0, do16, dw16, db16)
@@ -210,7 +211,9 @@ class RCANEngine(ResUNetEngine):
                     dz = add(dz, dgrad(dh1, P[f"{p}.module.0.weight"]))
                 dcur = add(dz, dcur)                                           # through the RCABs + the group's identity path
             df0 = add(dcur, dt)                                                # + the trunk's `x += residual`
-            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, ctx["img"].data_ptr(), L.tview(df0), G["sf.weight"].data_ptr(), G["sf.bias"].data_ptr(), st))
+            wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(self.Fc), dev)
+            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, ctx["img"].data_ptr(), L.tview(df0), G["sf.weight"].data_ptr(), G["sf.bias"].data_ptr(),
+                                            wsc.data_ptr(), wsc.numel(), st))
         finally:
             self._deferred = False
             L.check(lib.bpx_wgrad_defer_flush(st))

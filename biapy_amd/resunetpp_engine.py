@@ -226,7 +226,9 @@ class ResUNetPPEngine(ResUNetEngine):
         L.check(lib.bpx_conv3d_c1_fwd(self.dt, B, D, H, W, img.data_ptr(), P[wk].data_ptr(), P[bk].data_ptr(), y.view(), part.data_ptr(), self._st))
         if G is not None:
             def bwd():
-                L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), L.tview(y.grad), G[wk].data_ptr(), G[bk].data_ptr(), self._st))
+                wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(y.C), self._dev)
+                L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), L.tview(y.grad), G[wk].data_ptr(), G[bk].data_ptr(),
+                                                wsc.data_ptr(), wsc.numel(), self._st))
                 self._keep.append(y.grad)
             self._tape.append(bwd)
         return y, part, tiles
@@ -339,6 +341,20 @@ class ResUNetPPEngine(ResUNetEngine):
         for j, d in enumerate(rates):
             wk, bk = f"{prefix}.aspp_block{j + 1}.0.weight", f"{prefix}.aspp_block{j + 1}.0.bias"
             gk, bek = f"{prefix}.aspp_block{j + 1}.2.weight", f"{prefix}.aspp_block{j + 1}.2.bias"
+            if all(d >= n for n in x.S):
+                # every off-centre tap of a rate-d kernel lands in the zero padding of a volume that is at most d wide (the bridge of
+                # cfg 4: 5^3 at rates 6/12/18): the convolution IS the 1x1x1 convolution with the centre tap, and the other 26 taps
+                # have an exactly-zero gradient, as in the reference
+                wc = P[wk][:, :, 1:2, 1:2, 1:2].contiguous()
+                raw = self._new(x.S, Cout)
+                L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, x.view(), self._pack(wc, L.PK_DENSE, x.C, Cout, False).data_ptr(), P[bk].data_ptr(),
+                                            L.NULL_T, L.NULL_T, None, L.NULL_T, raw.view(), self._st))
+                r = self._new(x.S, Cout)
+                L.check(lib.bpx_norm_act_fwd(self.dt, B, x.vox, raw.view(), self._ident_rec(Cout).data_ptr(), self.relu, r.view(), self._st))
+                rec = self._stats_rec(r, P[gk], P[bek])
+                L.check(lib.bpx_norm_act_fwd(self.dt, B, x.vox, r.view(), rec.data_ptr(), 0, L.tview(cat.buf, j * Cout, Cout), self._st))
+                branches.append((0, wc, None, raw, r, rec, wk, bk, gk, bek))
+                continue
             tables = self._c(("lattice", x.S, d), lambda: torch.from_numpy(dilation.lattice_tables(x.S, d)).to(self._dev))
             xs = dilation.space_to_batch(x.buf, d, tables)                                   # (B * d^3, nz, ny, nx, Cin)
             q = d ** 3
@@ -359,6 +375,22 @@ class ResUNetPPEngine(ResUNetEngine):
                     L.check(lib.bpx_norm_act_fwd(self.dt, B, x.vox, L.tview(cat.grad, j * Cout, Cout), self._ident_rec(Cout).data_ptr(), 0, L.tview(dslice), self._st))
                     dr = self._in_bwd(r, rec, 0, dslice, P[gk], G[gk], G[bek])
                     draw = self._act_bwd(raw, self.relu, dr)
+                    if d == 0:                                                               # centre-tap branch (tables = the centre tap)
+                        dwc = torch.zeros((Cout, x.C, 1, 1, 1), dtype=torch.float32, device=self._dev)
+                        dbc = torch.zeros((Cout,), dtype=torch.float32, device=self._dev)
+                        self._wgrad(B, x.S, x.view(), None, 0, L.tview(draw), 1, dwc, dbc, self._st, self._dev)
+                        g = torch.empty((B,) + x.S + (x.C,), dtype=self.dtype, device=self._dev)
+                        L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, L.tview(draw), self._pack(tables, L.PK_DENSE_T, x.C, Cout, False).data_ptr(), None,
+                                                    L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(g), self._st))
+
+                        def late(wk=wk, bk=bk, dwc=dwc, dbc=dbc):                            # after the deferred wgrad reductions have run
+                            G[wk].zero_()
+                            G[wk][:, :, 1:2, 1:2, 1:2] = dwc
+                            G[bk].copy_(dbc)
+                        self._late.append(late)
+                        self._keep += [draw, dslice]
+                        self._accum(x, g)
+                        continue
                     dys = dilation.space_to_batch(draw, d, tables)
                     nb = dys.shape[0]
                     self._wgrad(nb, xsv.S, xsv.view(), None, 0, L.tview(dys), 3, G[wk], G[bk], self._st, self._dev)
@@ -539,8 +571,9 @@ class ResUNetPPEngine(ResUNetEngine):
             feat.grad = torch.empty((B, D0, H0, W0, fm[0]), dtype=self.dtype, device=self._dev)
             hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=self._dev)
             hbg = torch.zeros((n_out,), dtype=torch.float32, device=self._dev)
+            hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), self._dev)
             L.check(lib.bpx_head_bwd(self.dt, vox0, B, feat.view(), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0, L.tview(feat.grad),
-                                     hwg.data_ptr(), hbg.data_ptr(), self._st))
+                                     hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), self._st))
             o = 0
             for h, oc in enumerate(cfg.out_channels):
                 G[f"heads.{h}.weight"].copy_(hwg[o:o + oc].view(G[f"heads.{h}.weight"].shape))

@@ -204,8 +204,9 @@ class UNetEngine(ResUNetEngine):
         L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g1), L.tview(cb.h[0]), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         # conv 1
         if img is not None:
+            wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(C1), dev)
             L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), L.tview(g1), G[k(0, "0.weight")].data_ptr(),
-                                            G[k(0, "0.bias")].data_ptr(), st))
+                                            G[k(0, "0.bias")].data_ptr(), wsc.data_ptr(), wsc.numel(), st))
             return
         self._wgrad(B, cb.S, L.tview(cb.x), None, 0, L.tview(g1), 3, G[k(0, "0.weight")], G[k(0, "0.bias")], st, dev)
         if dx_out is not None:
@@ -236,8 +237,9 @@ class UNetEngine(ResUNetEngine):
         dfeat = torch.empty((B, D0, H0, W0, fm[0]), dtype=T, device=dev)
         hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
         hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
+        hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
         L.check(lib.bpx_head_bwd(self.dt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
-                                 L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), st))
+                                 L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
         o = 0
         for h, oc in enumerate(cfg.out_channels):
             G[f"heads.{h}.weight"].copy_(hwg[o:o + oc].view(G[f"heads.{h}.weight"].shape))

@@ -269,20 +269,28 @@ int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor 
 int bpx_head_fwd(int dtype, int64_t voxels_per_sample, int N, bpx_tensor x, const float* w_d /* [Cout][Cin] */,
                  const float* b_d, int Cout, int head_act, float* out_d, int64_t out_stride_n, int64_t out_stride_c,
                  bpx_stream_t stream);
+/* bwd: dx, dW (overwritten) and db (added to).  The parameter gradients are sums of per-workgroup partials held in ws_d
+ * (>= bpx_head_bwd_workspace bytes) and combined in a fixed order right after the kernel - no atomics, bit-reproducible from run to run. */
+int64_t bpx_head_bwd_workspace(int Cin, int Cout);
 int bpx_head_bwd(int dtype, int64_t voxels_per_sample, int N, bpx_tensor x, const float* w_d, int Cout,
                  const float* dout_d, int64_t stride_n, int64_t stride_c, bpx_tensor dx, float* dw_d, float* db_d,
-                 bpx_stream_t stream);
+                 void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* First layer, Cin = 1 (fp32 image in, blocks.py:154 with in_size = 1): direct convolution. */
 int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d /* (Cout,1,3,3,3) */,
                       const float* bias_d, bpx_tensor y, float* stats_part_d, bpx_stream_t stream);
 int bpx_conv3d_c1_stats_tiles(int D, int H, int W);
+/* dW (Cout,1,3,3,3) is overwritten, db is added to; partial sums in ws_d (deterministic).  With bpx_wgrad_defer_begin active the
+ * combination runs at the flush, like that of bpx_conv3d_wgrad: ws_d must stay untouched until then. */
+int64_t bpx_conv3d_c1_wgrad_workspace(int Cout);
 int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy,
-                        float* dw_d, float* db_d, bpx_stream_t stream);
+                        float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
-/* Shortcut of the first block (Conv3d 1 -> Cout, k = 1, blocks.py:1372 with in_size = 1): dW[co] += sum_v img[v]*dy[v][co].
- * dw_d must be zeroed by the caller. */
-int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, bpx_stream_t stream);
+/* Shortcut of the first block (Conv3d 1 -> Cout, k = 1, blocks.py:1372 with in_size = 1): dW[co] = sum_v img[v]*dy[v][co]
+ * (overwritten; partial sums in ws_d as for bpx_conv3d_c1_wgrad, deterministic, deferrable). */
+int64_t bpx_conv1x1_c1_wgrad_workspace(int Cout);
+int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, void* ws_d, int64_t ws_bytes,
+                         bpx_stream_t stream);
 
 /* Super-resolution "pre" up-sampling of the 1-channel image: ConvTranspose3d(1, 1, kernel = stride = (fz, fy, fx))
  * (biapy/models/resunet.py:206-213, :368-369).  fwd writes channel 0 of a dense 16-channel NDHWC tensor of the storage dtype

@@ -121,7 +121,8 @@ def main():
         ms = timeit(lambda: L.check(lib.bpx_conv3d_c1_fwd(dt, B, S, S, S, img.data_ptr(), w.data_ptr(), b.data_ptr(), L.tview(y), part.data_ptr(), st)), a.reps)
         print(f"c1_fwd 128^3 1->16: {ms * 1e3:9.1f} us  {(B * S ** 3 * (4 + 16 * y.element_size())) / ms / 1e6:8.1f} GB/s(alg)")
         dw = torch.zeros(16, 1, 3, 3, 3, device=DEV); db = torch.zeros(16, device=DEV)
-        ms = timeit(lambda: L.check(lib.bpx_conv3d_c1_wgrad(dt, B, S, S, S, img.data_ptr(), L.tview(y), dw.data_ptr(), db.data_ptr(), st)), a.reps)
+        wsc = torch.empty(lib.bpx_conv3d_c1_wgrad_workspace(16), dtype=torch.uint8, device=DEV)
+        ms = timeit(lambda: L.check(lib.bpx_conv3d_c1_wgrad(dt, B, S, S, S, img.data_ptr(), L.tview(y), dw.data_ptr(), db.data_ptr(), wsc.data_ptr(), wsc.numel(), st)), a.reps)
         print(f"c1_wgrad 128^3: {ms * 1e3:9.1f} us")
     if a.what in ("merge", "all"):
         from biapy_amd import tiling

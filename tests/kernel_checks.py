@@ -530,6 +530,18 @@ def check_norm_pool_head(dt, seed=0):
     mean = xf.mean(1); var = xf.var(1, unbiased=False); rstd = (var + 1e-5).rsqrt()
     ref = torch.stack([mean, rstd, gamma[None] * rstd, beta[None] - mean * gamma[None] * rstd], -1)
     res.append(_res(f"norm_finalize[{tagd}]", relerr(rec, ref), 1e-5))
+    # the partial sums themselves for channel slices: 24 channels (3 vectors: 85 voxel slots), a 16-channel slice at offset 8 of the
+    # 32-channel rows (ld != C), and 5 channels (one-channel-per-lane fallback); a ragged last tile (vox = 1536 + 40)
+    xs = rnd(torch.randn(B, 1576, Cc, generator=g), dt)
+    xsd = to_dev(xs, dt)
+    for c0, cn in ((0, 24), (8, 16), (3, 5), (0, 32)):
+        tl = lib.bpx_tensor_stats_tiles(1576)
+        pp = torch.zeros(B, tl, 2, cn, dtype=torch.float32, device=DEV)
+        L.check(lib.bpx_tensor_stats(dt, B, 1576, L.tview(xsd, c0, cn), pp.data_ptr(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        sl = xs[..., c0:c0 + cn].double()
+        want = torch.stack([sl.sum(1), (sl * sl).sum(1)], 1)                     # (B, 2, cn)
+        res.append(_res(f"tensor_stats[{tagd}].c{c0}+{cn}", relerr(pp.double().sum(1).cpu(), want), 1e-5))
     # max pool (sz,2,2) fwd + stats, bwd with addend (ties are likely in bf16: the first maximum must win as in PyTorch)
     for sz in (2, 1):
         y = torch.empty(B, D // sz, H // 2, W // 2, Cc, dtype=tdtype(dt), device=DEV)
@@ -600,8 +612,9 @@ def check_norm_pool_head(dt, seed=0):
     dfe = torch.empty(B, D, H, W, Cf, dtype=tdtype(dt), device=DEV)
     dhw = torch.zeros(Co, Cf, dtype=torch.float32, device=DEV); dhb = torch.zeros(Co, dtype=torch.float32, device=DEV)
     dlo_d = dlo.to(DEV).contiguous()
+    hws = torch.empty(lib.bpx_head_bwd_workspace(Cf, Co), dtype=torch.uint8, device=DEV)
     L.check(lib.bpx_head_bwd(dt, vox, B, L.tview(fd), hw_d.data_ptr(), Co, dlo_d.data_ptr(), Co * vox, vox, L.tview(dfe), dhw.data_ptr(),
-                             dhb.data_ptr(), L.stream_ptr()))
+                             dhb.data_ptr(), hws.data_ptr(), hws.numel(), L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(f"head_bwd_dx[{tagd}]", relerr(dfe, ndhwc(fr.grad)), tol_for(dt)))
     res.append(_res(f"head_bwd_dw[{tagd}]", relerr(dhw, hwr.grad), 1e-4))
@@ -625,11 +638,41 @@ def check_norm_pool_head(dt, seed=0):
     y1_ref.backward(ncdhw(dy1))
     dw1 = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float32, device=DEV); db1 = torch.zeros(16, dtype=torch.float32, device=DEV)
     dy1_d = to_dev(dy1, dt)
-    L.check(lib.bpx_conv3d_c1_wgrad(dt, B, D, H, W, imgd.data_ptr(), L.tview(dy1_d), dw1.data_ptr(), db1.data_ptr(), L.stream_ptr()))
+    wsc = torch.empty(lib.bpx_conv3d_c1_wgrad_workspace(16), dtype=torch.uint8, device=DEV)
+    L.check(lib.bpx_conv3d_c1_wgrad(dt, B, D, H, W, imgd.data_ptr(), L.tview(dy1_d), dw1.data_ptr(), db1.data_ptr(), wsc.data_ptr(), wsc.numel(),
+                                    L.stream_ptr()))
     torch.cuda.synchronize()
     res.append(_res(f"conv_c1_wgrad[{tagd}]", relerr(dw1, w1r.grad), 1e-4))
     res.append(_res(f"conv_c1_bgrad[{tagd}]", relerr(db1, b1r.grad), 1e-4))
+    # rank-1 shortcut of the first block: dW[co] = sum_v img[v] * dy[v][co]
+    dws = torch.full((16,), 7.0, dtype=torch.float32, device=DEV)                 # overwritten, not accumulated
+    ws1 = torch.empty(lib.bpx_conv1x1_c1_wgrad_workspace(16), dtype=torch.uint8, device=DEV)
+    L.check(lib.bpx_conv1x1_c1_wgrad(dt, B * D * H * W, imgd.data_ptr(), L.tview(dy1_d), dws.data_ptr(), ws1.data_ptr(), ws1.numel(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(f"conv1x1_c1_wgrad[{tagd}]", relerr(dws, (img[..., None].double() * dy1.double()).sum((0, 1, 2, 3))), 1e-4))
     return res
+
+
+def check_parameter_gradients_are_reproducible(dtype):
+    """No atomics anywhere in the parameter gradients: conv / transposed-conv bias gradients are column sums of
+    per-workgroup partials combined in a fixed order (wgrad.hip), the first layer, the rank-1 shortcut and the head likewise
+    (elementwise.hip).  Two backward passes over the same tensors give bit-identical gradients for EVERY parameter."""
+    from biapy_amd.resunet import ResUNet
+
+    torch.manual_seed(0)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=[16, 32, 64], drop_values=[0.0] * 3, normalization="in",
+                yx_down=[2] * 2, z_down=[2] * 2, isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3, compute_dtype=dtype).to(DEV).train()
+    x = torch.randn(2, 1, 32, 32, 32, device=DEV)
+    t = (torch.rand(2, 1, 32, 32, 32, device=DEV) > 0.5).float()
+    runs = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        F.binary_cross_entropy_with_logits(m(x), t).backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    bad = [n for n in runs[0] if not (torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]))]
+    tag = "f32" if dtype == torch.float32 else "bf16"
+    return [_res(f"reproducible_grads[{tag}].params_that_differ", float(len(bad)), 0.5, extra=", ".join(bad[:8]))]
 
 
 # ---------------------------------------------------------------------------------------------------
