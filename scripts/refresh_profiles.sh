@@ -15,6 +15,7 @@ python bench.py --mode sliding --vol 1024 --steps 1 --warmup 1 --no-cpu-baseline
 BPX_BENCH_ONE_DEVICE=1 BPX_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
    bench.py --gpus 2 --steps 5 --warmup 2 --vol 512 > $O/${R}_bench_2ranks_one_gpu_gloo.json 2> $O/bench_2rank.err
 python bench.py --arch resunetpp --batch 4 --steps 5 --warmup 2 > $O/${R}_bench_resunetpp_80.json 2> $O/bench_pp.err
+python bench.py --arch resunetpp --batch 4 --breakdown --graph off > $O/${R}_breakdown_resunetpp_events.txt 2> /dev/null
 python bench.py --breakdown --graph off --mode train > $O/${R}_breakdown_train_events.txt 2> /dev/null
 python bench.py --breakdown --graph off --mode infer > $O/${R}_breakdown_infer_events.txt 2> /dev/null
 python tests/bench_kernels.py merge > $O/${R}_merge_crop.txt 2>&1
