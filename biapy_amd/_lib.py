@@ -25,10 +25,10 @@ class AxisGrid(C.Structure):
 
 
 class Tensor(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("cs", C.c_int64)]
 
 
-NULL_T = Tensor(None, 0, 0)
+NULL_T = Tensor(None, 0, 0, 0)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -216,11 +216,50 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def tview(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Tensor:
-    """bpx_tensor for an NDHWC torch tensor (last dim = channels, contiguous), optionally a channel slice."""
+PLANE_PAD_BYTES = int(os.environ.get("BPX_PLANE_PAD", "0"))   # test hook (multiple of 16): extra distance between the planes of a Planar buffer
+
+
+class Planar:
+    """Chunk-planar NDHWC buffer (``bpx_tensor.cs != 0``): the 16-channel chunk ``k`` of every voxel lives in plane ``k`` of a
+    ``(C/16, B, D, H, W, 16)`` tensor.  The decoder's ``torch.cat([up, skip], 1)`` buffers are kept this way: the transposed conv and the
+    encoder write whole planes (full cache lines) instead of 64 of every 96 bytes, pooling reads a dense plane, and the consumers,
+    which walk their input in 16-channel chunks anyway, add a plane stride instead of 32 bytes per chunk."""
+
+    def __init__(self, B: int, S, C: int, dtype, device):
+        assert C % 16 == 0
+        n = B * 16
+        for v in S:
+            n *= v
+        es = torch.empty((), dtype=dtype).element_size()
+        # planes of a 128^3 x 4 patch batch are exactly 2^28 bytes apart; padding them (256 B ... 1 MB, BPX_PLANE_PAD) was measured and
+        # changes nothing - no channel / bank aliasing between the planes of a voxel
+        self.plane = n + PLANE_PAD_BYTES // es             # elements between consecutive chunks (bpx_tensor.cs)
+        self._flat = torch.empty((C // 16) * self.plane, dtype=dtype, device=device)
+        self.t = self._flat.as_strided((C // 16, B) + tuple(S) + (16,), (self.plane,) + torch.empty((B,) + tuple(S) + (16,), device="meta").stride())
+        self.shape = (B,) + tuple(S) + (C,)
+        self.device, self.dtype = self.t.device, dtype
+
+    def dense(self) -> torch.Tensor:
+        """The same data as an ordinary (B, D, H, W, C) tensor (tests, debugging)."""
+        n = self.t.dim()
+        return self.t.permute(*range(1, n - 1), 0, n - 1).reshape(self.shape).contiguous()
+
+    def copy_from_dense(self, x: torch.Tensor) -> "Planar":
+        n = self.t.dim()
+        self.t.copy_(x.reshape(self.shape[:-1] + (self.shape[-1] // 16, 16)).permute(n - 2, *range(0, n - 2), n - 1))
+        return self
+
+
+def tview(t, c0: int = 0, c: Optional[int] = None) -> Tensor:
+    """bpx_tensor for an NDHWC torch tensor (last dim = channels, contiguous) or a ``Planar`` buffer, optionally a channel slice."""
     if t is None:
         return NULL_T
+    if isinstance(t, Planar):
+        C = t.shape[-1]
+        cc = C - c0 if c is None else c
+        assert c0 % 16 == 0 and cc % 16 == 0 and c0 + cc <= C, "slices of a chunk-planar buffer are whole 16-channel chunks"
+        return Tensor(t.t.data_ptr() + (c0 // 16) * t.plane * t.t.element_size(), 16, cc, t.plane)
     assert t.is_contiguous(), "NDHWC buffers must be contiguous"
     ld = t.shape[-1]
     cc = ld - c0 if c is None else c
-    return Tensor(t.data_ptr() + c0 * t.element_size(), ld, cc)
+    return Tensor(t.data_ptr() + c0 * t.element_size(), ld, cc, 0)

@@ -31,7 +31,7 @@ namespace {
 // Voxel (0,0,0) of the block sits at volume coordinate (oz,oy,ox); out-of-volume voxels are ZERO
 // (Conv3d zero padding applies to the activated tensor, so the zero is written after the prologue).
 template <typename T, int EZ, int EY, int EX>
-__device__ __forceinline__ void stage_block(unsigned char* smem, const T* __restrict__ src, int ld, int chunk, int n, int D, int H,
+__device__ __forceinline__ void stage_block(unsigned char* smem, const T* __restrict__ src, int ld, int cs, int chunk, int n, int D, int H,
                                             int W, int oz, int oy, int ox, const bpx_norm_rec* __restrict__ norm, int C_norm,
                                             int act, int tid) {
   constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
@@ -46,7 +46,7 @@ __device__ __forceinline__ void stage_block(unsigned char* smem, const T* __rest
       sc[e] = r.scale; sh[e] = r.shift;
     }
   }
-  const T* sbase = src + chunk * 16 + sub * KPL;
+  const T* sbase = src + (size_t)chunk * cs + sub * KPL;
   for (int base = 0; base < PIECES; base += 256 * UNR) {
     u32x4_t buf[UNR];
     bool ok[UNR];
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
       }                                                                                                       \
       *reinterpret_cast<u32x4_t*>(smem + (wbuf) + (size_t)idx_ * 16) = v_;                                    \
       if ((next_chunk) < nchunks && goff[u] != 0xFFFFFFFFu && !(p.dbg & 4))                                   \
-        pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (next_chunk) * 16);                       \
+        pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (size_t)(next_chunk) * p.x_cs);                       \
     }                                                                                                         \
   } while (0)
 #define BPX_LOAD_NORM(chunk_)                                                                                 \
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     const int nch = p.sc_C / 16;
     for (int chunk = 0; chunk < nch; ++chunk) {
       __syncthreads();
-      stage_block<T, TZ, TY, TX>(smem, scin, p.sc_ld, chunk, n, p.D, p.H, p.W, z0, y0, x0, nullptr, 0, 0, tid);
+      stage_block<T, TZ, TY, TX>(smem, scin, p.sc_ld, p.sc_cs, chunk, n, p.D, p.H, p.W, z0, y0, x0, nullptr, 0, 0, tid);
       __syncthreads();
       const T* wl = wsc + ((size_t)chunk * 4 * Cout + (size_t)g * Cout + co_base + j) * KPL;
       u32x4_t wf[NS];
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
           }
         } else {
           if (p.t_norm) {
-            const T* tp = reinterpret_cast<const T*>(p.t) + vox * (size_t)p.t_ld + co;
+            const T* tp = reinterpret_cast<const T*>(p.t) + vox * (size_t)p.t_ld + (size_t)(co >> 4) * p.t_cs + (co & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float tv = Tr::ld(tp + r);
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
             for (int r = 0; r < 4; ++r) v[r] = acc[ms][ns][r];
           }
         }
-        T* yp = yout + vox * (size_t)p.y_ld + co;
+        T* yp = yout + vox * (size_t)p.y_ld + (size_t)(co >> 4) * p.y_cs + (co & 15);
         if (p.dbg & 8) continue;
         if (std::is_same<T, float>::value) {
           *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -467,7 +467,10 @@ static bool use_lean(int dtype, const Conv3Params& p) {
   const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
   const int64_t ldmax = std::max<int64_t>(std::max(p.x_ld, p.y_ld), std::max(p.sc ? p.sc_ld : 0, p.t ? p.t_ld : 0));
   auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-  return p.W > 8 && vox * ldmax < (1ll << 31) && vox < (1ll << 30) && al(p.bias) && al(p.bias_sc) && al(p.wsc) && al(p.in_norm) && al(p.t_norm);
+  // 32-bit byte offsets: a chunk-planar tensor extends over (channels / 16) planes
+  auto ext = [](int cs, int C) { return cs == 16 ? (int64_t)0 : (int64_t)cs * (C / 16); };
+  const int64_t planar = std::max(std::max(ext(p.x_cs, p.Cin), ext(p.y_cs, p.Cout)), std::max(p.sc ? ext(p.sc_cs, p.sc_C) : 0, p.t ? ext(p.t_cs, p.Cout) : 0));
+  return p.W > 8 && vox * ldmax < (1ll << 31) && planar < (1ll << 31) && vox < (1ll << 30) && al(p.bias) && al(p.bias_sc) && al(p.wsc) && al(p.in_norm) && al(p.t_norm);
 }
 
 extern "C" int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout) {
@@ -479,11 +482,20 @@ extern "C" int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int
 
 static int check_tensor(const char* fn, const char* name, const bpx_tensor& t, int esize, bool need16) {
   BPX_CHECK(t.ptr != nullptr, "%s: %s.ptr is null", fn, name);
-  BPX_CHECK(t.C >= 1 && t.ld >= t.C, "%s: %s has ld %d < C %d", fn, name, t.ld, t.C);
+  BPX_CHECK(t.C >= 1 && t.ld >= (t.cs ? 16 : t.C), "%s: %s has ld %d < C %d", fn, name, t.ld, t.C);
   if (need16) {
     BPX_CHECK(t.C % 16 == 0, "%s: %s.C = %d must be a multiple of 16", fn, name, t.C);
     BPX_CHECK(((uintptr_t)t.ptr % 16) == 0 && ((size_t)t.ld * esize) % 16 == 0, "%s: %s must be 16-byte aligned (ptr and ld)", fn, name);
   }
+  return 0;
+}
+
+// chunk-planar operand (bpx_tensor.cs != 0): planes must hold every voxel and keep 16-byte alignment
+static int check_planar(const char* fn, const char* name, const bpx_tensor& t, int N, int D, int H, int W) {
+  if (t.ptr == nullptr || t.cs == 0) return 0;
+  const int64_t vox = (int64_t)N * D * H * W;
+  BPX_CHECK(t.ld >= 16 && t.cs % 8 == 0 && t.cs >= (vox - 1) * t.ld + 16 && t.cs < (1ll << 31), "%s: %s has chunk stride %lld for %lld voxels of pitch %d", fn,
+            name, (long long)t.cs, (long long)vox, t.ld);
   return 0;
 }
 
@@ -506,6 +518,8 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
   p.wp = w_packed_d; p.bias = bias_d;
   p.sc = sc.ptr; p.sc_ld = sc.ld; p.sc_C = sc.ptr ? sc.C : 0; p.wsc = w_sc_d; p.bias_sc = bias_sc_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
+  if (check_planar(fn, "x", x, N, D, H, W) || check_planar(fn, "sc", sc, N, D, H, W) || check_planar(fn, "y", y, N, D, H, W)) return 1;
+  p.x_cs = chunk_stride(x); p.sc_cs = chunk_stride(sc); p.y_cs = chunk_stride(y); p.t_cs = 16;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
   if (pool_sz) {
     BPX_CHECK(use_lean(dtype, p) && c.tx == 16, "%s: the fused pooling needs the lean bf16 kernel (bpx_conv3d_fwd_pool_supported)", fn);
@@ -534,6 +548,7 @@ extern "C" int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_te
                                    const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
                                    const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
                                    float* pool_stats_part_d, bpx_stream_t stream) {
+  BPX_CHECK(pooled.cs == 0, "bpx_conv3d_fwd_pool: the pooled output cannot be chunk-planar");
   return conv3d_fwd_impl("bpx_conv3d_fwd_pool", dtype, N, D, H, W, x, in_norm_d, act, w_packed_d, bias_d, sc, w_sc_d, bias_sc_d, y, stats_part_d,
                          pool_sz, pooled, pool_stats_part_d, stream);
 }
@@ -546,6 +561,7 @@ extern "C" int bpx_conv3d_fwd_pool_supported(int dtype, int N, int D, int H, int
 
 extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,
                                 const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0 && g.cs == 0, "bpx_conv3d_dgrad: only t may be chunk-planar");
   const char* fn = "bpx_conv3d_dgrad";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   int es = (int)dtype_size(dtype);
@@ -561,6 +577,8 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.wp = w_packed_T_d;
   p.y = g.ptr; p.y_ld = g.ld; p.Cout = g.C; p.part = t_norm_d ? red_part_d : nullptr;
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
+  if (t_norm_d && check_planar(fn, "t", t, N, D, H, W)) return 1;
+  p.x_cs = 16; p.sc_cs = 16; p.y_cs = 16; p.t_cs = chunk_stride(t);
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
   int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream)

@@ -99,6 +99,8 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
   const char* __restrict__ wp = reinterpret_cast<const char*>(p.wp);
   const uint32_t wlane = (uint32_t)((g * Cout + co_base + j) * KPL) * 2u;  // this lane's 16-byte operand inside a [4][Cout][8] k-group block
   const int nchunks = p.Cin / 16;
+  // bytes between the 16-channel chunks of a voxel: 32 (interleaved) or a plane (chunk-planar operands, bpx_tensor.cs)
+  const uint32_t x_csb = (uint32_t)p.x_cs * 2u, sc_csb = (uint32_t)p.sc_cs * 2u, y_csb = (uint32_t)p.y_cs * 2u, t_csb = (uint32_t)p.t_cs * 2u;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
 
   for (int local = slot; local < p.tilesPerXcd; local += spx, ++it) {
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
         pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
-        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + (goff[u] + (uint32_t)chunk * 32u));
+        if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + (goff[u] + (uint32_t)chunk * x_csb));
       }
       float psc[KPL], psh[KPL];
       if (nrec) {
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
           bq[ms] = u32x4_t{0u, 0u, 0u, 0u};
-          if (okzx && RS * ms < yrem) bq[ms] = *reinterpret_cast<const u32x4_t*>(scin + (sb0 + ms * srow + (uint32_t)chunk * 32u));
+          if (okzx && RS * ms < yrem) bq[ms] = *reinterpret_cast<const u32x4_t*>(scin + (sb0 + ms * srow + (uint32_t)chunk * sc_csb));
         }
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wsc + (size_t)chunk * 4 * Cout * 16 + (wlane + ns * 256u));
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     // ---- epilogue: all loads first, then math + one 8-byte store per (m-subtile, 16-channel group) ------------------
     char* __restrict__ yout = reinterpret_cast<char*>(p.y);
     const uint32_t yrow = (uint32_t)(RS * W * p.y_ld) * 2u;                                  // bytes between m-subtiles
-    const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + co_base + g * 4) * 2u;
+    const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * y_csb;   // co_base is a multiple of 16
     // statistics partials of one 16-channel group: 16 lanes (DPP) -> this wave's slot of the LDS scratch [wave][NS*16][2]
     float* red = reinterpret_cast<float*>(smem + BUFB);
     auto flush_stats = [&](int ns, const float* s1, const float* s2, int which = 0) {
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               s2[r] += v[r] * v[r];
             }
             pk[ms] = u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = pk[ms];
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) = pk[ms];
           }
         }
         if (TX == 16 && p.pool != nullptr) {
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     } else {
       const bool has_t = p.t_norm != nullptr;
       const char* __restrict__ tin = reinterpret_cast<const char*>(p.t);
-      const uint32_t trow = (uint32_t)(RS * W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + co_base + g * 4) * 2u;
+      const uint32_t trow = (uint32_t)(RS * W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * t_csb;
       // operands of channel group ns+1 are requested before group ns is computed (register double buffer over ns)
       u32x2_t tv[NS > 1 ? 2 : 1][MS];
       auto fetch = [&](int ns, int b) {
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
           tv[b][ms] = u32x2_t{0u, 0u};
-          if (okzx && RS * ms < yrem) tv[b][ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * 32u));
+          if (okzx && RS * ms < yrem) tv[b][ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * t_csb));
         }
       };
       fetch(0, 0);
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
           if (okzx && RS * ms < yrem)
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) =
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) =
                 u32x2_t{cvt_pk_bf16(acc[ms][ns][0], acc[ms][ns][1]), cvt_pk_bf16(acc[ms][ns][2], acc[ms][ns][3])};
         flush_stats(ns, s1, s2);
       }

@@ -25,7 +25,11 @@ struct Conv3Params {
   int tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd;
   long long* stamps;  // profiling: per-workgroup s_memtime stamps [block][16] (BPX_CONV_STAMPS), else null
   int dbg;  // ablation switches for profiling (BPX_CONV_DBG): 1 = skip MFMA steps, 2 = skip staging transform+loads
+  // distance in ELEMENTS between consecutive 16-channel chunks of a voxel: 16 for the ordinary interleaved layout, the plane size for
+  // chunk-planar tensors (bpx_tensor.cs)
+  int x_cs, sc_cs, y_cs, t_cs;
 };
+inline int chunk_stride(const bpx_tensor& t) { return t.cs ? (int)t.cs : 16; }
 
 // ACTK = 1: ELU known at compile time (the reference default) - no per-element control flow; ACTK = 0: runtime switch.
 template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_rt(float u, int act) {

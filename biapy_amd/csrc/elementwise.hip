@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) dot_stats_kernel(const T* __restrict__ a,
 constexpr int POOL_IPT = 4;  // items (output voxel x 16-byte channel group) per thread
 
 template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld, int C, int D, int H, int W, int sz,
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, int x_cs, T* __restrict__ y, int y_ld, int C, int D, int H, int W, int sz,
                                    int tiles, float* __restrict__ part) {  // window (sz,2,2): sz = z_down of the level (1 or 2)
   constexpr int KPL = ElemTraits<T>::KPL;
   extern __shared__ float red[];  // [blockDim][2*KPL]
@@ -463,6 +463,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restr
   const int64_t items = (int64_t)Do * Ho * Wo * G;
   const int n = blockIdx.y, tile = blockIdx.x;
   const int cg = threadIdx.x % G;
+  const size_t xc = (size_t)((cg * KPL) >> 4) * x_cs + ((cg * KPL) & 15);   // x may be chunk-planar (x_cs: elements between 16-channel chunks)
   float s1[KPL], s2[KPL];
 #pragma unroll
   for (int e = 0; e < KPL; ++e) s1[e] = s2[e] = 0.f;
@@ -478,7 +479,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restr
     for (int k = 0; k < 8; ++k) {
       if (k >= 4 * sz) break;
       size_t vox = (((size_t)n * D + sz * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL);
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + vox * x_ld + xc);
       float f[KPL];
       unpack16<T>(v, f);
 #pragma unroll
@@ -504,7 +505,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, T* __restr
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, int x_ld, int x_cs, const T* __restrict__ dy, int dy_ld,
                                                           const T* __restrict__ addend, int a_ld, T* __restrict__ dx, int dx_ld, int C,
                                                           int D, int H, int W, int sz, int N) {
   constexpr int KPL = ElemTraits<T>::KPL;
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       if (k >= 4 * sz) break;
       voxk[k] = (((size_t)n * D + sz * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + voxk[k] * x_ld + cg * KPL);
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + voxk[k] * x_ld + (size_t)((cg * KPL) >> 4) * x_cs + ((cg * KPL) & 15));
       unpack16<T>(v, f[k]);
 #pragma unroll
       for (int e = 0; e < KPL; ++e)
@@ -1150,6 +1151,7 @@ extern "C" int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, i
 extern "C" int bpx_tensor_stats_tiles(int64_t voxels) { return (int)cdiv64(voxels, 256); }
 
 extern "C" int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, float* stats_part_d, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0, "bpx_tensor_stats: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_tensor_stats";
   BPX_CHECK(x.ptr && stats_part_d, "%s: null pointer", fn);
   int tiles = (int)cdiv64(voxels, 256);
@@ -1397,6 +1399,7 @@ static int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv64(total,
 
 extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
                                   bpx_tensor addend, bpx_tensor dx, bpx_stream_t stream) {
+  BPX_CHECK(g.cs == 0 && t.cs == 0 && addend.cs == 0 && dx.cs == 0, "bpx_norm_bwd_apply: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_norm_bwd_apply";
   BPX_CHECK(g.ptr && t.ptr && dx.ptr && coef_d, "%s: null pointer", fn);
   BPX_CHECK(g.C == t.C && g.C == dx.C && g.C % 16 == 0, "%s: channel mismatch", fn);
@@ -1434,6 +1437,7 @@ extern "C" int bpx_norm_act_tiles(int dtype, int64_t voxels, int C) { return na_
 
 extern "C" int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, bpx_tensor y,
                                 bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0 && y.cs == 0, "bpx_norm_act_fwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_norm_act_fwd";
   BPX_CHECK(x.ptr && y.ptr && rec_d, "%s: null pointer", fn);
   BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
@@ -1453,6 +1457,7 @@ extern "C" int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, 
 
 extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act,
                                 bpx_tensor addend, bpx_tensor g, float* red_part_d, bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0 && x.cs == 0 && addend.cs == 0 && g.cs == 0, "bpx_norm_act_bwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_norm_act_bwd";
   BPX_CHECK(dy.ptr && x.ptr && g.ptr && rec_d && red_part_d, "%s: null pointer", fn);
   BPX_CHECK(x.C == dy.C && x.C == g.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
@@ -1475,6 +1480,7 @@ extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy,
 
 extern "C" int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x, bpx_tensor h, const float* scale_d, const float* offset_d,
                                   bpx_tensor y, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0 && h.cs == 0 && y.cs == 0, "bpx_channel_affine: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_channel_affine";
   BPX_CHECK(h.ptr && y.ptr && scale_d, "%s: null pointer", fn);
   BPX_CHECK(h.C == y.C && h.C % 16 == 0 && h.C <= 2048 && (x.ptr == nullptr || x.C == h.C), "%s: channels must match and be a multiple of 16", fn);
@@ -1494,6 +1500,7 @@ extern "C" int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x
 }
 
 extern "C" int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx_tensor b, float* part_d, bpx_stream_t stream) {
+  BPX_CHECK(a.cs == 0 && b.cs == 0, "bpx_dot_stats: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_dot_stats";
   BPX_CHECK(a.ptr && b.ptr && part_d, "%s: null pointer", fn);
   BPX_CHECK(a.C == b.C && a.C % 16 == 0 && a.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
@@ -1520,6 +1527,9 @@ extern "C" int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int sz,
 
 extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor y, float* stats_part_d,
                                  bpx_stream_t stream) {
+  BPX_CHECK(y.cs == 0, "bpx_maxpool3d_fwd: only x may be chunk-planar");
+  BPX_CHECK(x.cs == 0 || (x.cs % 8 == 0 && x.cs >= ((int64_t)N * D * H * W - 1) * x.ld + 16), "bpx_maxpool3d_fwd: x has chunk stride %lld", (long long)x.cs);
+  const int xcs = x.cs ? (int)x.cs : 16;
   const char* fn = "bpx_maxpool3d_fwd";
   BPX_CHECK(x.ptr && y.ptr, "%s: null pointer", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
@@ -1532,9 +1542,9 @@ extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, 
   size_t shm = (size_t)bd * 2 * kpl * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
-    maxpool_fwd_kernel<uint16_t><<<grid, bd, shm, s>>>((const uint16_t*)x.ptr, x.ld, (uint16_t*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
+    maxpool_fwd_kernel<uint16_t><<<grid, bd, shm, s>>>((const uint16_t*)x.ptr, x.ld, xcs, (uint16_t*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
   else if (dtype == BPX_F32)
-    maxpool_fwd_kernel<float><<<grid, bd, shm, s>>>((const float*)x.ptr, x.ld, (float*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
+    maxpool_fwd_kernel<float><<<grid, bd, shm, s>>>((const float*)x.ptr, x.ld, xcs, (float*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -1542,6 +1552,9 @@ extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, 
 
 extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, bpx_tensor addend, bpx_tensor dx,
                                  bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0 && addend.cs == 0 && dx.cs == 0, "bpx_maxpool3d_bwd: only x may be chunk-planar");
+  BPX_CHECK(x.cs == 0 || (x.cs % 8 == 0 && x.cs >= ((int64_t)N * D * H * W - 1) * x.ld + 16), "bpx_maxpool3d_bwd: x has chunk stride %lld", (long long)x.cs);
+  const int xcs = x.cs ? (int)x.cs : 16;
   const char* fn = "bpx_maxpool3d_bwd";
   BPX_CHECK(x.ptr && dy.ptr && dx.ptr, "%s: null pointer", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
@@ -1551,10 +1564,10 @@ extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, 
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
-    maxpool_bwd_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, (const uint16_t*)dy.ptr, dy.ld,
+    maxpool_bwd_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, xcs, (const uint16_t*)dy.ptr, dy.ld,
                                                                  (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
   else if (dtype == BPX_F32)
-    maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)x.ptr, x.ld, (const float*)dy.ptr, dy.ld, (const float*)addend.ptr,
+    maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)x.ptr, x.ld, xcs, (const float*)dy.ptr, dy.ld, (const float*)addend.ptr,
                                                               addend.ld, (float*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
@@ -1563,6 +1576,7 @@ extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, 
 
 extern "C" int bpx_head_fwd(int dtype, int64_t vps, int N, bpx_tensor x, const float* w_d, const float* b_d, int Cout, int head_act,
                             float* out_d, int64_t sn, int64_t sc, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0, "bpx_head_fwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_head_fwd";
   BPX_CHECK(x.ptr && w_d && out_d, "%s: null pointer", fn);
   BPX_CHECK(Cout >= 1 && Cout <= 4, "%s: Cout must be 1..4 (got %d)", fn, Cout);
@@ -1585,6 +1599,7 @@ extern "C" int64_t bpx_conv1x1_c1_wgrad_workspace(int Cout) { return (int64_t)10
 
 extern "C" int bpx_head_bwd(int dtype, int64_t vps, int N, bpx_tensor x, const float* w_d, int Cout, const float* dout_d, int64_t sn,
                             int64_t sc, bpx_tensor dx, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0 && dx.cs == 0, "bpx_head_bwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_head_bwd";
   BPX_CHECK(x.ptr && w_d && dout_d && dx.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(Cout >= 1 && Cout <= 4, "%s: Cout must be 1..4 (got %d)", fn, Cout);
@@ -1611,6 +1626,7 @@ extern "C" int bpx_conv3d_c1_stats_tiles(int D, int H, int W) { return cdiv(D, 4
 
 extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d, const float* bias_d,
                                  bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
+  BPX_CHECK(y.cs == 0, "bpx_conv3d_c1_fwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_conv3d_c1_fwd";
   BPX_CHECK(img_d && w_d && y.ptr, "%s: null pointer", fn);
   BPX_CHECK(y.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
@@ -1627,6 +1643,7 @@ extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const fl
 
 extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy, float* dw_d, float* db_d,
                                    void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0, "bpx_conv3d_c1_wgrad: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_conv3d_c1_wgrad";
   BPX_CHECK(img_d && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(dy.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
@@ -1656,6 +1673,7 @@ extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const 
 
 extern "C" int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, void* ws_d, int64_t ws_bytes,
                                     bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0, "bpx_conv1x1_c1_wgrad: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_conv1x1_c1_wgrad";
   BPX_CHECK(img_d && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(dy.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
@@ -1774,6 +1792,7 @@ extern "C" int bpx_chan_loss_bwd(const float* logits_d, const float* target_d, i
 }
 
 extern "C" int bpx_gate_mul_fwd(int dtype, int64_t total_voxels, bpx_tensor a, bpx_tensor x, bpx_tensor y, bpx_stream_t stream) {
+  BPX_CHECK(a.cs == 0 && x.cs == 0 && y.cs == 0, "bpx_gate_mul_fwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_gate_mul_fwd";
   BPX_CHECK(a.ptr && x.ptr && y.ptr, "%s: null pointer", fn);
   const int kpl = dtype == BPX_BF16 ? 8 : 4;
@@ -1788,6 +1807,7 @@ extern "C" int bpx_gate_mul_fwd(int dtype, int64_t total_voxels, bpx_tensor a, b
 }
 
 extern "C" int bpx_gate_mul_bwd(int dtype, int64_t total_voxels, bpx_tensor dy, bpx_tensor a, bpx_tensor x, bpx_tensor dx, void* da16_d, bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0 && a.cs == 0 && x.cs == 0 && dx.cs == 0, "bpx_gate_mul_bwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_gate_mul_bwd";
   BPX_CHECK(dy.ptr && a.ptr && x.ptr && dx.ptr && da16_d, "%s: null pointer", fn);
   const int kpl = dtype == BPX_BF16 ? 8 : 4;

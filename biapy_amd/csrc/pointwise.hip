@@ -62,6 +62,26 @@ template <> __device__ __forceinline__ void storeq<uint16_t, 2>(uint16_t* p, con
 template <> __device__ __forceinline__ void storeq<uint16_t, 3>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); store4_bf16(p + 8, f[2]); }
 template <> __device__ __forceinline__ void storeq<uint16_t, 4>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); store8_bf16(p + 8, f[2], f[3]); }
 
+// The same 4*NQ consecutive channels c0.. of a voxel of a CHUNK-PLANAR tensor (channel c of a voxel at (c/16)*cs + c%16 from the voxel's
+// base): the widest accesses that stay inside one 16-channel chunk.  c0 is a multiple of 4*NQ for NQ = 1, 2, 4 (never straddles); for
+// NQ = 3 the 12 channels split as 8 + 4 or 4 + 8 depending on the lane.
+template <typename T, int NQ> __device__ __forceinline__ void loadq_planar(const T* vbase, int c0, int cs, float (*f)[4]) {
+  auto at = [&](int c) { return vbase + (size_t)(c >> 4) * cs + (c & 15); };
+  if (NQ == 1) loadq<T, 1>(at(c0), f);
+  else if (NQ == 2) loadq<T, 2>(at(c0), f);
+  else if (NQ == 4) { loadq<T, 2>(at(c0), f); loadq<T, 2>(at(c0 + 8), f + 2); }
+  else if ((c0 & 7) == 0) { loadq<T, 2>(at(c0), f); loadq<T, 1>(at(c0 + 8), f + 2); }
+  else { loadq<T, 1>(at(c0), f); loadq<T, 2>(at(c0 + 4), f + 1); }
+}
+template <typename T, int NQ> __device__ __forceinline__ void storeq_planar(T* vbase, int c0, int cs, const float (*f)[4]) {
+  auto at = [&](int c) { return vbase + (size_t)(c >> 4) * cs + (c & 15); };
+  if (NQ == 1) storeq<T, 1>(at(c0), f);
+  else if (NQ == 2) storeq<T, 2>(at(c0), f);
+  else if (NQ == 4) { storeq<T, 2>(at(c0), f); storeq<T, 2>(at(c0 + 8), f + 2); }
+  else if ((c0 & 7) == 0) { storeq<T, 2>(at(c0), f); storeq<T, 1>(at(c0 + 8), f + 2); }
+  else { storeq<T, 1>(at(c0), f); storeq<T, 2>(at(c0 + 4), f + 1); }
+}
+
 struct PwParams {
   int N, D, H, W;        // voxel grid of v (the low-res grid for the transposed conv)
   int sz;                // transposed conv: kernel = stride = (sz,2,2), sz = 1 or 2 -> 4*sz sub-positions, sub = (a*2+b)*2+c
@@ -73,6 +93,7 @@ struct PwParams {
   void* y2; int y2_ld; int ysplit;         // CONV1, optional: columns >= ysplit go to y2 (column - ysplit); ysplit % 4 == 0
   // CONV1 extras
   const void* g; int g_ld; const void* t; int t_ld; const bpx_nbwd_coef* coef;
+  int t_cs, y_cs;                          // elements between 16-channel chunks of t / y: 16, or the plane of a chunk-planar tensor
   const void* addend; int addend_ld;
   float* part; int mblocks;                // CONVT stats: [N][mblocks*8][2][Csub]
 };
@@ -191,7 +212,11 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       if (p.coef) {
         float gq[NS][4], tq[NS][4];
         loadq<T, NS>(reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co0, gq);
-        loadq<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
+        if (p.t_cs == 16) {
+          loadq<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
+        } else {   // chunk-planar t (the decoder's concat buffer)
+          loadq_planar<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld, co0, p.t_cs, tq);
+        }
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -219,8 +244,10 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
         T* dst = col < p.ysplit ? yout + ovox * (size_t)p.y_ld + col : reinterpret_cast<T*>(p.y2) + ovox * (size_t)p.y2_ld + (col - p.ysplit);
         storeq<T, 1>(dst, val + ns);
       }
-    } else {
+    } else if (p.y_cs == 16) {
       storeq<T, NS>(yout + ovox * (size_t)p.y_ld + co0, val);
+    } else {     // chunk-planar y (the transposed conv writes its planes of the concat buffer)
+      storeq_planar<T, NS>(yout + ovox * (size_t)p.y_ld, co0, p.y_cs, val);
     }
   }
 
@@ -266,7 +293,8 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
 
 int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
   BPX_CHECK(t.ptr != nullptr, "%s: %s.ptr is null", fn, name);
-  BPX_CHECK(t.C % 16 == 0 && t.ld >= t.C, "%s: %s needs C %% 16 == 0 and ld >= C (C=%d ld=%d)", fn, name, t.C, t.ld);
+  BPX_CHECK(t.C % 16 == 0 && t.ld >= (t.cs ? 16 : t.C), "%s: %s needs C %% 16 == 0 and ld >= C (C=%d ld=%d)", fn, name, t.C, t.ld);
+  BPX_CHECK(t.cs == 0 || t.cs % 8 == 0, "%s: %s has chunk stride %lld (must be a multiple of 8 elements)", fn, name, (long long)t.cs);
   BPX_CHECK(((uintptr_t)t.ptr % 16) == 0 && ((size_t)t.ld * es) % 16 == 0, "%s: %s must be 16-byte aligned", fn, name);
   return 0;
 }
@@ -294,6 +322,9 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
   p.y = y.ptr; p.y_ld = y.ld; p.Ncols = ncols; p.Csub = ncols;
   p.y2 = y2.ptr; p.y2_ld = y2.ld; p.ysplit = y.C;
   p.g = g.ptr; p.g_ld = g.ld; p.t = t.ptr; p.t_ld = t.ld; p.coef = coef_d;
+  p.t_cs = t.cs ? (int)t.cs : 16; p.y_cs = 16;
+  BPX_CHECK(t.cs == 0 || (t.cs >= ((int64_t)N * vps - 1) * t.ld + 16 && t.cs < (1ll << 31)), "%s: t has chunk stride %lld for %lld voxels", fn, (long long)t.cs,
+            (long long)N * vps);
   p.addend = addend.ptr; p.addend_ld = addend.ld;
   int ns = pw_ns(ncols);
   if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
@@ -304,12 +335,14 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
 extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                                bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y,
                                bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0 && g.cs == 0 && addend.cs == 0 && y.cs == 0, "bpx_conv1x1_fwd: only t may be chunk-planar");
   return conv1x1_impl("bpx_conv1x1_fwd", dtype, N, vps, x, w_packed_d, bias_d, g, t, coef_d, addend, y, bpx_tensor{nullptr, 0, 0}, stream);
 }
 
 extern "C" int bpx_conv1x1_fwd_split(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                                      bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y_lo,
                                      bpx_tensor y_hi, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0 && g.cs == 0 && addend.cs == 0 && y_lo.cs == 0 && y_hi.cs == 0, "bpx_conv1x1_fwd_split: only t may be chunk-planar");
   const char* fn = "bpx_conv1x1_fwd_split";
   BPX_CHECK(y_hi.ptr != nullptr, "%s: y_hi null", fn);
   return conv1x1_impl(fn, dtype, N, vps, x, w_packed_d, bias_d, g, t, coef_d, addend, y_lo, y_hi, stream);
@@ -317,6 +350,9 @@ extern "C" int bpx_conv1x1_fwd_split(int dtype, int N, int64_t vps, bpx_tensor x
 
 extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                                     bpx_tensor y, float* stats_part_d, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0, "bpx_convT3d_k2s2_fwd: only y may be chunk-planar");
+  BPX_CHECK(y.cs == 0 || (y.cs >= ((int64_t)N * D * H * W * 4 * sz - 1) * y.ld + 16 && y.cs < (1ll << 31)), "bpx_convT3d_k2s2_fwd: y has chunk stride %lld",
+            (long long)y.cs);
   const char* fn = "bpx_convT3d_k2s2_fwd";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
@@ -327,6 +363,7 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
   p.N = N; p.D = D; p.H = H; p.W = W; p.sz = sz; p.vps = (int64_t)D * H * W;
   p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Ncols = 4 * sz * y.C; p.Csub = y.C; p.part = stats_part_d;
+  p.t_cs = 16; p.y_cs = y.cs ? (int)y.cs : 16;
   int ns = pw_ns(y.C);
   if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
@@ -335,6 +372,7 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
 
 extern "C" int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, int sz, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor dx,
                                       bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0 && dx.cs == 0, "bpx_convT3d_k2s2_dgrad: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_convT3d_k2s2_dgrad";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
@@ -344,7 +382,7 @@ extern "C" int bpx_convT3d_k2s2_dgrad(int dtype, int N, int D, int H, int W, int
   PwParams p{};
   p.N = N; p.D = D; p.H = H; p.W = W; p.sz = sz; p.vps = (int64_t)D * H * W;
   p.x = dy.ptr; p.x_ld = dy.ld; p.K = 4 * sz * dy.C; p.Csub = dy.C; p.wp = w_packed_T_d;
-  p.y = dx.ptr; p.y_ld = dx.ld; p.Ncols = dx.C;
+  p.y = dx.ptr; p.y_ld = dx.ld; p.Ncols = dx.C; p.t_cs = 16; p.y_cs = 16;
   int ns = pw_ns(dx.C);
   if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVTD>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONVTD>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);

@@ -30,6 +30,7 @@ namespace {
 struct WgradParams {
   int N, D, H, W;          // logical voxel grid of the reduction
   const void* x; int x_ld; int Cin; const bpx_norm_rec* in_norm; int act;
+  int x_cs;                // elements between the 16-channel chunks of an x voxel: 16, or the plane size of a chunk-planar tensor
   const void* dy; int dy_ld; int Cout; int dy_vs; int dy_oz, dy_oy, dy_ox;  // dy voxel = vs*v + off (ConvTranspose)
   int dy_vz;               // z stride of that mapping (0 = same as dy_vs): kernel (1,2,2) has vz = 1
   float* part;                                   // [groups][taps][Cin][Cout] per-block partial sums (workspace)
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       const int gz = z0 - HALO + hv / (HX * HY), gy = y0 - HALO + (hv / HX) % HY, gx = x0 - HALO + hv % HX;
       pa[u] = u32x4_t{0u, 0u, 0u, 0u};
       if (idx < HV * GPT && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-        pa[u] = *reinterpret_cast<const u32x4_t*>(xin + ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * (size_t)p.x_ld + chunk * 16 + subA * KPL);
+        pa[u] = *reinterpret_cast<const u32x4_t*>(xin + ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * (size_t)p.x_ld + (size_t)chunk * p.x_cs + subA * KPL);
         va |= 1u << u;
       }
     }
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 #pragma unroll
   for (int u = 0; u < NPA; ++u) {
     const int t = (u * 256 + tid) >> 1;
-    rel_a[u] = (uint32_t)((((t >> 6) * H + ((t >> 4) & 3)) * W + (t & 15)) * p.x_ld + chunk * 16 + (tid & 1) * KPL) * 2u;
+    rel_a[u] = (uint32_t)((((t >> 6) * H + ((t >> 4) & 3)) * W + (t & 15)) * p.x_ld + chunk * p.x_cs + (tid & 1) * KPL) * 2u;
     asm volatile("" : "+v"(rel_a[u]));
   }
   const int subG = tid % PPVG;
@@ -666,7 +667,7 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
 #pragma unroll
   for (int u = 0; u < NPA; ++u) {
     const int t = (u * 256 + tid) >> 1;
-    rel_a[u] = (uint32_t)((((t >> 6) * H + ((t >> 4) & 3)) * W + (t & 15)) * p.x_ld + ci_base + (tid & 1) * KPL) * 2u;
+    rel_a[u] = (uint32_t)((((t >> 6) * H + ((t >> 4) & 3)) * W + (t & 15)) * p.x_ld + cgi * MC * p.x_cs + (tid & 1) * KPL) * 2u;
     asm volatile("" : "+v"(rel_a[u]));
   }
   const int subG = tid % PPVG;
@@ -700,7 +701,7 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
 #pragma unroll
       for (int c = 0; c < MC; ++c) {
         pa[c][u] = u32x4_t{0u, 0u, 0u, 0u};
-        if (oka[u]) pa[c][u] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a[u]) + c * 32);
+        if (oka[u]) pa[c][u] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a[u]) + (uint32_t)c * ((uint32_t)p.x_cs * 2u));
       }
     }
 #pragma unroll
@@ -841,7 +842,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   const char* __restrict__ gin = reinterpret_cast<const char*>(p.dy);
   // this thread's x piece: voxel t = tid>>1 of the tile, 8 channels
   const int ta = tid >> 1, taz = ta >> 6, tay = (ta >> 4) & 3, tax = ta & 15;
-  const uint32_t rel_a = (uint32_t)(((taz * H + tay) * W + tax) * p.x_ld + chunk * 16 + (tid & 1) * KPL) * 2u;
+  const uint32_t rel_a = (uint32_t)(((taz * H + tay) * W + tax) * p.x_ld + chunk * p.x_cs + (tid & 1) * KPL) * 2u;
   const int subG = tid % PPVG, qlane = tid / PPVG;                 // dy piece u: block voxel q = u*(256/PPVG) + qlane
   const int trl = (i >> 2), trc = (i & 3) * 8;
   const int a_base = (g * 8 + trl) * VBA + trc;
@@ -1208,6 +1209,9 @@ extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
 
 extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                                 bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0, "bpx_conv3d_wgrad: only x may be chunk-planar");
+  BPX_CHECK(x.cs == 0 || (x.ld >= 16 && x.cs % 8 == 0 && x.cs >= ((int64_t)N * D * H * W - 1) * x.ld + 16 && x.cs * (x.C / 16) < (1ll << 31)),
+            "bpx_conv3d_wgrad: bad chunk stride %lld", (long long)x.cs);
   const char* fn = "bpx_conv3d_wgrad";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   BPX_CHECK(k == 1 || k == 3, "%s: k must be 1 or 3", fn);
@@ -1216,6 +1220,7 @@ extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   WgradParams p{};
   p.N = N; p.D = D; p.H = H; p.W = W;
   p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = in_norm_d; p.act = act;
+  p.x_cs = x.cs ? (int)x.cs : 16;
   p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 1;
   int taps = k * k * k;
   p.dw = dw_d; p.si = taps; p.sj = (int64_t)x.C * taps; p.st = 1; p.off = 0;  // (Cout,Cin,k,k,k)
@@ -1225,6 +1230,7 @@ extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tenso
 
 extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, float* dw_d, float* db_d,
                                       void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(x.cs == 0 && dy.cs == 0, "bpx_convT3d_k2s2_wgrad: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_convT3d_k2s2_wgrad";
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
@@ -1237,7 +1243,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     BPX_CHECK(ws_d != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
-    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C;
+    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.x_cs = 16;
     p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C;
     p.part = reinterpret_cast<float*>(ws_d); p.db = db_d;
     p.dbpart = p.part + (size_t)c.groups * nsub * x.C * dy.C;
@@ -1256,7 +1262,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   for (int sub = 0; sub < nsub; ++sub) {
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
-    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = nullptr; p.act = 0;
+    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = nullptr; p.act = 0; p.x_cs = 16;
     p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 2; p.dy_vz = sz;
     p.dy_oz = (sub >> 2) & 1; p.dy_oy = (sub >> 1) & 1; p.dy_ox = sub & 1;
     p.dw = dw_d; p.si = (int64_t)dy.C * nsub; p.sj = nsub; p.st = 0; p.off = sub;  // (Cin,Cout,sz,2,2)

@@ -23,6 +23,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -171,6 +173,7 @@ class ResUNetEngine:
         self.act = L.ACT[cfg.activation]
         self._ws: Optional[torch.Tensor] = None
         self._side_stream = None
+        self.planar_cat = os.environ.get("BPX_PLANAR_CAT", "1") != "0"
         self.use_side_stream = False  # measured on cfg 2: 19.5 vs 18.1 ms/step (early kernels, eager); 11.13 vs 11.18 with the final kernels
         # under graph replay, 21 vs 15 ms eager - every kernel already launches one resident wave of workgroups
         self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
@@ -411,7 +414,9 @@ class ResUNetEngine:
         def buf(i, C):
             return torch.empty((B,) + S[i] + (C,), dtype=T, device=dev)
 
-        cat = [buf(i, fm[i + 1] + fm[i]) for i in range(Lv)]
+        # torch.cat([up, skip], 1) buffers, chunk-planar (L.Planar): the transposed conv and the encoder block write whole planes
+        # instead of 64 / 32 of every 96 bytes, pooling reads a dense plane (A/B switch: self.planar_cat)
+        cat = [L.Planar(B, S[i], fm[i + 1] + fm[i], T, dev) if self.planar_cat else buf(i, fm[i + 1] + fm[i]) for i in range(Lv)]
         blocks: List[_Blk] = []
         pools = []
         out_stats = []

@@ -109,6 +109,10 @@ typedef struct bpx_tensor {
   void* ptr;   /* device; element (n,z,y,x,c) at ((((n*D+z)*H+y)*W+x)*ld + c) */
   int32_t ld;  /* channel stride in elements */
   int32_t C;   /* channels used */
+  int64_t cs;  /* 0: the C channels of a voxel are contiguous (above).  != 0: CHUNK-PLANAR - the 16-channel chunk c/16 of every voxel
+                * lives in its own plane, element (voxel v, channel c) at v*ld + (c/16)*cs + c%16 (cs in elements, a multiple of 8;
+                * ptr 16-byte aligned at channel 0 of a chunk).  The engine keeps the torch.cat buffers of the decoder this way (planes
+                * written by different producers are whole cache lines).  Accepted only where an entry point says so. */
 } bpx_tensor;
 
 /* Weight packing: PyTorch fp32 weights -> MFMA operand order (DESIGN.md "packed weights").

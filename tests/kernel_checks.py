@@ -653,6 +653,130 @@ def check_norm_pool_head(dt, seed=0):
     return res
 
 
+def check_planar_layouts(dt, S=(8, 16, 32), lean=False):
+    """Chunk-planar operands (bpx_tensor.cs != 0, the layout of the decoder's concat buffers) against the ordinary interleaved layout:
+    every entry point that accepts them must produce BIT-IDENTICAL results, the arithmetic does not change.  Covered: conv forward
+    (x with the fused norm prologue, the fused 1x1x1 shortcut operand, the output), dgrad's t operand, wgrad's x operand for k = 3 and
+    k = 1, the t operand of the fused shortcut-dgrad / norm-backward GEMM, the transposed conv's output, pooling forward / backward."""
+    g = torch.Generator().manual_seed(11)
+    T = tdtype(dt)
+    tagd = ("bf16" if dt == L.BF16 else "f32") + ("-lean" if lean else "")
+    st = L.stream_ptr()
+    B = 1 if lean else 2
+    D, H, W = S
+    vox = D * H * W
+    Cx, Cy = 48, 32                                         # Cy = 32: the output spans two planes
+    res = []
+
+    def dev_pair(shape_c):
+        x = rnd(torch.randn(B, D, H, W, shape_c, generator=g), dt)
+        xd = to_dev(x, dt)
+        return xd, L.Planar(B, S, shape_c, T, DEV).copy_from_dense(xd)
+
+    def same(name, a, b):
+        a, b = (t.dense() if isinstance(t, L.Planar) else t for t in (a, b))
+        res.append(_res(f"planar[{tagd}].{name}", float((a.contiguous().view(torch.uint8) != b.contiguous().view(torch.uint8)).sum()), 0))
+
+    def pack(w, mode, cin, cout):
+        out = torch.empty(lib.bpx_packed_weight_elems(mode, cin, cout, dt), dtype=T, device=DEV)
+        L.check(lib.bpx_pack_weight(mode, w.data_ptr(), cin, cout, dt, out.data_ptr(), st))
+        return out
+
+    xd, xp = dev_pair(Cx)
+    rec = torch.rand(B, Cx, 4, generator=g).to(DEV)
+    w3 = (torch.randn(Cy, Cx, 3, 3, 3, generator=g) * 0.05).to(DEV)
+    wk3, wk1 = pack(w3, L.PK_K3, Cx, Cy), pack((torch.randn(Cy, Cx, 1, 1, 1, generator=g) * 0.1).to(DEV), L.PK_K1, Cx, Cy)
+    bias = torch.randn(Cy, generator=g).to(DEV)
+    tiles = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, Cy)
+    outs = []
+    for xin, yout in ((xd, torch.empty(B, D, H, W, Cy, dtype=T, device=DEV)), (xp, L.Planar(B, S, Cy, T, DEV))):
+        part = torch.zeros(B, tiles, 2, Cy, device=DEV)
+        L.check(lib.bpx_conv3d_fwd(dt, B, D, H, W, L.tview(xin), rec.data_ptr(), L.ACT["elu"], wk3.data_ptr(), bias.data_ptr(), L.tview(xin), wk1.data_ptr(),
+                                   bias.data_ptr(), L.tview(yout), part.data_ptr(), st))
+        outs.append((yout, part))
+    torch.cuda.synchronize()
+    same("conv_fwd.y", outs[0][0], outs[1][0])
+    same("conv_fwd.stats", outs[0][1], outs[1][1])
+    # dgrad: dy (Cy) -> g (Cx), t = the conv input (planar) with its norm record
+    dyd = to_dev(rnd(torch.randn(B, D, H, W, Cy, generator=g), dt), dt)
+    wt = pack(w3, L.PK_K3_T, Cx, Cy)
+    rt = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, Cx)
+    outs = []
+    for tin in (xd, xp):
+        gq = torch.empty(B, D, H, W, Cx, dtype=T, device=DEV)
+        red = torch.zeros(B, rt, 2, Cx, device=DEV)
+        L.check(lib.bpx_conv3d_dgrad(dt, B, D, H, W, L.tview(dyd), wt.data_ptr(), L.tview(tin), rec.data_ptr(), L.ACT["elu"], L.tview(gq), red.data_ptr(), st))
+        outs.append((gq, red))
+    torch.cuda.synchronize()
+    same("dgrad.g", outs[0][0], outs[1][0])
+    same("dgrad.red", outs[0][1], outs[1][1])
+    # wgrad k = 3 (with the prologue) and k = 1
+    for k in (3, 1):
+        outs = []
+        for xin in (xd, xp):
+            dw = torch.zeros(Cy, Cx, k, k, k, device=DEV)
+            db = torch.zeros(Cy, device=DEV)
+            ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, D, H, W, Cx, Cy, k)), dtype=torch.uint8, device=DEV)
+            L.check(lib.bpx_conv3d_wgrad(dt, B, D, H, W, L.tview(xin), rec.data_ptr() if k == 3 else None, L.ACT["elu"] if k == 3 else 0, L.tview(dyd), k,
+                                         dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            outs.append((dw, db))
+        torch.cuda.synchronize()
+        same(f"wgrad_k{k}.dw", outs[0][0], outs[1][0])
+        same(f"wgrad_k{k}.db", outs[0][1], outs[1][1])
+    # shortcut dgrad fused with the norm-backward affine: y = dy * Wsc^T + a*g + b*t + c0, split into (32, 16) channels
+    wsct = pack((torch.randn(Cy, Cx, 1, 1, 1, generator=g) * 0.1).to(DEV), L.PK_DENSE_T, Cx, Cy)
+    coef = torch.randn(B, Cx, 4, generator=g).to(DEV)
+    g0 = to_dev(rnd(torch.randn(B, D, H, W, Cx, generator=g), dt), dt)
+    outs = []
+    for tin in (xd, xp):
+        lo = torch.empty(B, D, H, W, 32, dtype=T, device=DEV)
+        hi = torch.empty(B, D, H, W, 16, dtype=T, device=DEV)
+        L.check(lib.bpx_conv1x1_fwd_split(dt, B, vox, L.tview(dyd), wsct.data_ptr(), None, L.tview(g0), L.tview(tin), coef.data_ptr(), L.NULL_T,
+                                          L.tview(lo), L.tview(hi), st))
+        one = torch.empty(B, D, H, W, Cx, dtype=T, device=DEV)
+        L.check(lib.bpx_conv1x1_fwd(dt, B, vox, L.tview(dyd), wsct.data_ptr(), None, L.tview(g0), L.tview(tin), coef.data_ptr(), L.NULL_T, L.tview(one), st))
+        outs.append((lo, hi, one))
+    torch.cuda.synchronize()
+    for i, nm in enumerate(("split.lo", "split.hi", "conv1x1")):
+        same("nbwd_gemm." + nm, outs[0][i], outs[1][i])
+    # transposed conv k2s2: 32 -> 32 channels written into channels [0, 32) of a 48-channel buffer at twice the extent
+    if not lean:
+        xl = to_dev(rnd(torch.randn(B, D, H, W, 32, generator=g), dt), dt)
+        wT = pack((torch.randn(32, 32, 2, 2, 2, generator=g) * 0.1).to(DEV), L.PK_CT, 32, 32)
+        bT = torch.randn(32, generator=g).to(DEV)
+        S2 = (2 * D, 2 * H, 2 * W)
+        ct = lib.bpx_convT3d_stats_tiles(D, H, W, 2)
+        outs = []
+        for cat in (torch.zeros((B,) + S2 + (48,), dtype=T, device=DEV), L.Planar(B, S2, 48, T, DEV)):
+            if isinstance(cat, L.Planar):
+                cat.t.zero_()
+            part = torch.zeros(B, ct, 2, 32, device=DEV)
+            L.check(lib.bpx_convT3d_k2s2_fwd(dt, B, D, H, W, 2, L.tview(xl), wT.data_ptr(), bT.data_ptr(), L.tview(cat, 0, 32), part.data_ptr(), st))
+            outs.append((cat, part))
+        torch.cuda.synchronize()
+        same("convT.y", outs[0][0], outs[1][0])
+        same("convT.stats", outs[0][1], outs[1][1])
+    # pooling of the skip slice [32, 48) of the concat buffer, forward and backward
+    pt = lib.bpx_maxpool3d_stats_tiles(dt, D, H, W, 2, 16)
+    dyp = to_dev(rnd(torch.randn(B, D // 2, H // 2, W // 2, 16, generator=g), dt), dt)
+    outs = []
+    for xin in (xd, xp):
+        y = torch.empty(B, D // 2, H // 2, W // 2, 16, dtype=T, device=DEV)
+        part = torch.zeros(B, pt, 2, 16, device=DEV)
+        L.check(lib.bpx_maxpool3d_fwd(dt, B, D, H, W, 2, L.tview(xin, 32, 16), L.tview(y), part.data_ptr(), st))
+        dx = torch.empty(B, D, H, W, 16, dtype=T, device=DEV)
+        L.check(lib.bpx_maxpool3d_bwd(dt, B, D, H, W, 2, L.tview(xin, 32, 16), L.tview(dyp), L.NULL_T, L.tview(dx), st))
+        outs.append((y, part, dx))
+    torch.cuda.synchronize()
+    for i, nm in enumerate(("fwd.y", "fwd.stats", "bwd.dx")):
+        same("maxpool." + nm, outs[0][i], outs[1][i])
+    # an entry point without support must refuse the layout instead of reading it as interleaved
+    y = torch.empty(B, D, H, W, Cx, dtype=T, device=DEV)
+    rc = lib.bpx_norm_act_fwd(dt, B, vox, L.tview(xp), rec.data_ptr(), 0, L.tview(y), st)
+    res.append(_res(f"planar[{tagd}].unsupported_entry_refuses", 0.0 if rc != 0 else 1.0, 0))
+    return res
+
+
 def check_parameter_gradients_are_reproducible(dtype):
     """No atomics anywhere in the parameter gradients: conv / transposed-conv bias gradients are column sums of
     per-workgroup partials combined in a fixed order (wgrad.hip), the first layer, the rank-1 shortcut and the head likewise
