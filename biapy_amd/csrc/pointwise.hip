@@ -9,6 +9,8 @@
 //   PW_CONVTD : A gathered from dy[2v+sub] over the 8 sub-positions (K = 8*Cout), store dx[v]
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "bpx_common.h"
 
 namespace {
@@ -364,7 +366,12 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
   p.x = x.ptr; p.x_ld = x.ld; p.K = x.C; p.wp = w_packed_d; p.bias = bias_d;
   p.y = y.ptr; p.y_ld = y.ld; p.Ncols = 4 * sz * y.C; p.Csub = y.C; p.part = stats_part_d;
   p.t_cs = 16; p.y_cs = y.cs ? (int)y.cs : 16;
-  int ns = pw_ns(y.C);
+  // 64 columns per workgroup column block for dense and chunk-planar outputs: the 16 columns of lanes g and g + 2 are then the two x
+  // sub-positions (2x, 2x + 1) of the same channels, i.e. ONE contiguous 64 / 128-byte piece of the output per input voxel and store
+  // instruction instead of two half-written lines from different workgroups (32 -> 32 channels, 64^3 -> 128^3, B = 4: 308 -> 256 us;
+  // into a 32-of-48-channel slice of an interleaved buffer the wide form is slower, 362 -> 415 us, and is not used)
+  static const bool wide = getenv("BPX_CONVT_NS") == nullptr;
+  int ns = (wide && (y.cs != 0 || y.ld == y.C) && (4 * sz * y.C) % 64 == 0) ? 4 : pw_ns(y.C);
   if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
