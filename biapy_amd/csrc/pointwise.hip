@@ -72,8 +72,22 @@ template <typename T, int NQ> __device__ __forceinline__ void loadq_planar(const
   if (NQ == 1) loadq<T, 1>(at(c0), f);
   else if (NQ == 2) loadq<T, 2>(at(c0), f);
   else if (NQ == 4) { loadq<T, 2>(at(c0), f); loadq<T, 2>(at(c0 + 8), f + 2); }
-  else if ((c0 & 7) == 0) { loadq<T, 2>(at(c0), f); loadq<T, 1>(at(c0 + 8), f + 2); }
-  else { loadq<T, 1>(at(c0), f); loadq<T, 2>(at(c0 + 4), f + 1); }
+  else if (sizeof(T) == 4) { loadq<T, 1>(at(c0), f); loadq<T, 1>(at(c0 + 4), f + 1); loadq<T, 1>(at(c0 + 8), f + 2); }   // fp32 quads are 16 bytes
+  else {
+    // bf16, 12 channels from c0 = 12 g: every lane reads the TWO aligned 8-channel blocks that hold them (same two instructions for the
+    // whole wave, no divergence) and keeps channels [0, 12) of the 16 (c0 % 8 == 0) or [4, 16) (c0 % 8 == 4)
+    const int b0 = c0 & ~7;
+    float a[2][4], b[2][4];
+    loadq<T, 2>(at(b0), a);
+    loadq<T, 2>(at(b0 + 8), b);
+    const bool odd = (c0 & 7) != 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f[0][r] = odd ? a[1][r] : a[0][r];
+      f[1][r] = odd ? b[0][r] : a[1][r];
+      f[2][r] = odd ? b[1][r] : b[0][r];
+    }
+  }
 }
 template <typename T, int NQ> __device__ __forceinline__ void storeq_planar(T* vbase, int c0, int cs, const float (*f)[4]) {
   auto at = [&](int c) { return vbase + (size_t)(c >> 4) * cs + (c & 15); };
@@ -100,7 +114,9 @@ struct PwParams {
   float* part; int mblocks;                // CONVT stats: [N][mblocks*8][2][Csub]
 };
 
-template <typename T, int MS, int NS, int MODE>
+// PL: chunk-planar t (PW_CONV1) / y (PW_CONVT) operand.  A compile-time switch on purpose: with a run-time test the interleaved instance
+// of the 48-column GEMM went from 116 to 128 VGPRs and from 0.62 to 0.75 ms (cfg 2, level 0).
+template <typename T, int MS, int NS, int MODE, bool PL>
 __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL;
@@ -214,11 +230,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       if (p.coef) {
         float gq[NS][4], tq[NS][4];
         loadq<T, NS>(reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co0, gq);
-        if (p.t_cs == 16) {
-          loadq<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
-        } else {   // chunk-planar t (the decoder's concat buffer)
-          loadq_planar<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld, co0, p.t_cs, tq);
-        }
+        if (!PL) loadq<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
+        else loadq_planar<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld, co0, p.t_cs, tq);   // the decoder's concat buffer
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -246,7 +259,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
         T* dst = col < p.ysplit ? yout + ovox * (size_t)p.y_ld + col : reinterpret_cast<T*>(p.y2) + ovox * (size_t)p.y2_ld + (col - p.ysplit);
         storeq<T, 1>(dst, val + ns);
       }
-    } else if (p.y_cs == 16) {
+    } else if (!PL) {
       storeq<T, NS>(yout + ovox * (size_t)p.y_ld + co0, val);
     } else {     // chunk-planar y (the transposed conv writes its planes of the concat buffer)
       storeq_planar<T, NS>(yout + ovox * (size_t)p.y_ld, co0, p.y_cs, val);
@@ -286,10 +299,19 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   p.mblocks = (int)cdiv64(p.vps, 64 * PW_MS);
   int nbk = p.Ncols / (16 * ns);
   dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
-  if (ns == 4) pw_kernel<T, PW_MS, 4, MODE><<<grid, 256, 0, s>>>(p);
-  else if (ns == 3) pw_kernel<T, PW_MS, 3, MODE><<<grid, 256, 0, s>>>(p);
-  else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE><<<grid, 256, 0, s>>>(p);
-  else pw_kernel<T, PW_MS, 1, MODE><<<grid, 256, 0, s>>>(p);
+  const bool planar = (MODE == PW_CONV1 && p.coef != nullptr && p.t_cs != 16) || (MODE == PW_CONVT && p.y_cs != 16);
+  if (MODE != PW_CONVTD && planar) {
+    constexpr bool PL = MODE != PW_CONVTD;    // no planar instances of the transposed-conv dgrad
+    if (ns == 4) pw_kernel<T, PW_MS, 4, MODE, PL><<<grid, 256, 0, s>>>(p);
+    else if (ns == 3) pw_kernel<T, PW_MS, 3, MODE, PL><<<grid, 256, 0, s>>>(p);
+    else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE, PL><<<grid, 256, 0, s>>>(p);
+    else pw_kernel<T, PW_MS, 1, MODE, PL><<<grid, 256, 0, s>>>(p);
+    return 0;
+  }
+  if (ns == 4) pw_kernel<T, PW_MS, 4, MODE, false><<<grid, 256, 0, s>>>(p);
+  else if (ns == 3) pw_kernel<T, PW_MS, 3, MODE, false><<<grid, 256, 0, s>>>(p);
+  else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE, false><<<grid, 256, 0, s>>>(p);
+  else pw_kernel<T, PW_MS, 1, MODE, false><<<grid, 256, 0, s>>>(p);
   return 0;
 }
 
