@@ -171,8 +171,9 @@ int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const
 
 /* wgrad: dW[co][ci][tap] = sum_v act(norm(x))[v+tap][ci] * dy[v][co] written (overwritten) in the PyTorch
  * layout (Cout,Cin,k,k,k); db[co] += sum_v dy[v][co] (db_d must be zeroed by the caller, may be NULL).
- * k = 3 or 1.  Deterministic: per-workgroup partial sums go to the caller-provided workspace and are
- * summed in a fixed order.  ws_bytes >= bpx_conv3d_wgrad_workspace(...). */
+ * k = 3 or 1.  Deterministic: per-workgroup partial sums of dW AND of the bias column sums go to the caller-provided workspace
+ * and are summed in a fixed order (no atomics; db is updated by the reduction, i.e. at the flush in the deferred mode).
+ * ws_bytes >= bpx_conv3d_wgrad_workspace(...).  x may be chunk-planar (bpx_tensor.cs). */
 int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout, int k);
 int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                      bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
@@ -180,7 +181,8 @@ int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const 
 /* Deferred reduction of the weight-gradient partials.  Between bpx_wgrad_defer_begin() and bpx_wgrad_defer_flush() (same
  * host thread) bpx_conv3d_wgrad and the bf16 bpx_convT3d_k2s2_wgrad write only their partial slabs and queue the reduction;
  * the flush finishes up to 32 of them per launch (dw_d is written then).  Every deferred call needs its OWN workspace, alive
- * and untouched until the flush has run on the stream.  db_d is not affected (accumulated by the MFMA kernels). */
+ * and untouched until the flush has run on the stream; dw_d AND db_d are complete only after the flush (a caller that copies a
+ * bias gradient elsewhere does so after it).  bpx_conv3d_c1_wgrad and bpx_conv1x1_c1_wgrad queue their reductions the same way. */
 int bpx_wgrad_defer_begin(void);
 int bpx_wgrad_defer_flush(bpx_stream_t stream);
 
