@@ -66,6 +66,8 @@ inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   // halo is staged once instead of three times
   c.ns = (Cout % 64 == 0) ? 4 : (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
   if (c.ns == 4 && (int64_t)D * H * W <= 512) c.ns = 2;   // 8^3 bottleneck: twice the workgroups (29 -> 23, 62 -> 48 us)
+  // NS = 2 at 16^3 too was measured (round 2): fwd 384->128 92 -> 84 us, 128->128+sc 49 -> 44, but dgrad 128->384 61 -> 76: a wash; at
+  // 32^3 it loses 25-35 % everywhere
   // <= 16^3 volumes: 4x4x8 tiles double the workgroup count of these latency-bound launches (measured 114 -> 92, 61 -> 48 us)
   if (W > 8 && (int64_t)D * H * W > 4096) {
     c.tx = 16; c.tz = 4;
