@@ -244,13 +244,28 @@ def run_sliding(a, model, dev, rank, world, V, warmup, steps):
                         patches=plan.n_patches, volume=V, parallelism="z-slab x%d" % world, input_slices_rank0=[z_lo, z_hi]),
             mfma_frac_end_to_end=round(pv * steps / elapsed * FLOP_PER_VOXEL_FWD / (world * MFMA_PEAK_BF16), 5),
             roofline=dict(bound="hbm", kernel="bpx_merge3d_blend", achieved=round(mb, 1) if mb else None, peak=HBM_PEAK / 1e9, unit="GB/s",
-                          frac=round(mb / (HBM_PEAK / 1e9), 4) if mb else None, traffic=None,
+                          frac=round(mb / (HBM_PEAK / 1e9), 4) if mb else None, **_tiling_traffic(V, world, plan.n_patches),
                           algorithmic_bytes_per_pass=merge_bytes, launches=cnt["bpx_merge3d_blend"], ms_per_pass=round(ms["bpx_merge3d_blend"], 3),
                           crop=dict(kernel="bpx_crop3d_gather", GBps=round(cb, 1) if cb else None, launches=cnt["bpx_crop3d_gather"],
                                     ms_per_pass=round(ms["bpx_crop3d_gather"], 3), algorithmic_bytes_per_pass=crop_bytes),
                           timed_on="one extra pass after the timed region, rank 0's share"),
             checksum=float(out[0].double().mean().item()) if out[0] is not None else None)
     return rec
+
+
+def _tiling_traffic(V, world, n_patches):
+    """HBM bytes per blend / gather pass from the committed PMC passes (profiles/pmc_traffic_tiling.json: 512 patches of 128^3 <-> 512^3,
+    tests/bench_kernels.py merge_rows under rocprofv3 --pmc); only quoted for that shape - the default 1-GPU sub-record."""
+    src = os.path.join("profiles", "pmc_traffic_tiling.json")
+    if not (V == 512 and world == 1 and n_patches == 512):
+        return dict(traffic=None)
+    try:
+        d = json.load(open(os.path.join(ROOT, src)))
+        return dict(traffic=(d.get("bpx_merge3d_blend") or {}).get("total_bytes"), crop_traffic=(d.get("bpx_crop3d_gather") or {}).get("total_bytes"),
+                    traffic_source=src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tests/bench_kernels.py merge_rows, committed; "
+                                         "bytes per whole-volume pass: the gather is issued per batch in the predictor)")
+    except (OSError, ValueError):
+        return dict(traffic=None)
 
 
 def conv_roofline(prof, prof_steps, dtype, timed_on):

@@ -20,6 +20,9 @@ GROUPS = [
     ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+>")),
     ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+>")),
     ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel<|wgrad_reduce(_batch)?_kernel")),
+    # the sliding-window blend / gather (tests/bench_kernels.py merge: 512 x 128^3 <-> 512^3; 16 B/lane row kernels, same doubling)
+    ("bpx_merge3d_blend", re.compile(r"merge3d_row_kernel<")),
+    ("bpx_crop3d_gather", re.compile(r"crop3d_row_kernel<")),
 ]
 
 

@@ -32,12 +32,15 @@ timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_V
    -d $ROOT/$O/pmc_a -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_a.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace \
    -d $ROOT/$O/pmc_b -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_b.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_tf -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tf.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tw.log 2>&1
 cd $ROOT
 python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
+python scripts/pmc_traffic.py $(find $O/pmc_tf -name "p_results.db" | head -1) $(find $O/pmc_tw -name "p_results.db" | head -1) > $O/pmc_traffic_tiling.json 2>> $O/pmc_traffic.err
 for k in conv3_lp_kernel wgrad_sdm_kernel; do
   python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
   python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
 done > $O/${R}_pmc_sq_conv_wgrad.txt 2>&1
-rm -rf $O/kt $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b
+rm -rf $O/kt $O/pmc_f $O/pmc_w $O/pmc_a $O/pmc_b $O/pmc_tf $O/pmc_tw
 ls -la $O
 tail -3 $O/${R}_gpu_tests.txt; tail -c 400 $O/${R}_bench.json; cat $O/pmc_traffic.json | head -c 700

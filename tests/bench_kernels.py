@@ -124,6 +124,18 @@ def main():
         wsc = torch.empty(lib.bpx_conv3d_c1_wgrad_workspace(16), dtype=torch.uint8, device=DEV)
         ms = timeit(lambda: L.check(lib.bpx_conv3d_c1_wgrad(dt, B, S, S, S, img.data_ptr(), L.tview(y), dw.data_ptr(), db.data_ptr(), wsc.data_ptr(), wsc.numel(), st)), a.reps)
         print(f"c1_wgrad 128^3: {ms * 1e3:9.1f} us")
+    if a.what == "merge_rows":      # PMC passes (scripts/refresh_profiles.sh): only the production kernels, whole-volume launches
+        from biapy_amd import tiling
+        vol = (512, 512, 512)
+        plan = tiling.MergePlan(vol, (128, 128, 128), (0.5, 0.5, 0.5), (0, 0, 0), torch.device(DEV))
+        patches = torch.rand(plan.n_patches, 128, 128, 128, 1, device=DEV)
+        out = torch.empty(vol + (1,), device=DEV)
+        v = torch.rand(vol + (1,), device=DEV)
+        for _ in range(a.reps):
+            tiling.merge_device(patches, plan, out=out)
+            tiling.crop_device(v, (128, 128, 128), (0.5, 0.5, 0.5), out=patches)
+        torch.cuda.synchronize()
+        return
     if a.what in ("merge", "all"):
         from biapy_amd import tiling
         vol = (512, 512, 512)
