@@ -401,7 +401,9 @@ __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__
   constexpr int VEC = MergeVec<EI>::VEC;
   // The x taper lives in LDS.  Measured alternatives on 512 x 128^3 -> 512^3 (this form: 1.73 ms): reading the taper through the
   // vector L1 instead (four strided dword loads per patch: 2.73 ms - the texture path is the bottleneck then), and a
-  // workgroup-per-output-row variant with the row arithmetic on the scalar unit (2.16 ms).
+  // workgroup-per-output-row variant with the row arithmetic on the scalar unit (2.16 ms), and four workgroups per CU instead of three
+  // (__launch_bounds__(256, 4), with the slot records slimmed to values + mask: 88 B/lane of scratch and 2.72 ms - the 141 VGPRs are the
+  // nine loads in flight per thread, which is what the kernel lives on).
   __shared__ float swx[MERGE_WXMAX];                              // (the launcher checks gx.patch <= MERGE_WXMAX)
   for (int i = threadIdx.x; i < gx.patch; i += 256) swx[i] = wx[i];
   __syncthreads();
