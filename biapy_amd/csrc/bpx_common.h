@@ -57,6 +57,17 @@ template <> struct ElemTraits<uint16_t> {
   __device__ static __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
   __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
+// fp16 storage (inference only: same 16 bits per element, 11-bit mantissa instead of 8 - the mode whose Dice matches the fp32 reference
+// to < 1e-4; gradients would need loss scaling, so no backward kernels are instantiated for it).  A distinct element type: _Float16.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <> struct ElemTraits<f16_t> {
+  static constexpr int KPL = 8;
+  static constexpr int DT = BPX_F16;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+};
 
 // 16 bytes of T -> up to 8 floats and back
 template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& v, float* f);
@@ -66,6 +77,14 @@ template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& v, fl
 template <> __device__ __forceinline__ void unpack16<uint16_t>(const u32x4_t& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(v[i]); f[2 * i + 1] = bf16hi(v[i]); }
+}
+template <> __device__ __forceinline__ void unpack16<f16_t>(const u32x4_t& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w = v[i];   // a copy first: __builtin_bit_cast applied to the vector ELEMENT v[i] reads element 0 for every i (hipcc 7.2)
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+    f[2 * i] = (float)h[0]; f[2 * i + 1] = (float)h[1];          // v_cvt_f32_f16 (+ SDWA for the high half)
+  }
 }
 template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* f);
 template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* f) {
@@ -85,6 +104,24 @@ template <> __device__ __forceinline__ u32x4_t pack16<uint16_t>(const float* f) 
   return v;
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
+// v_cvt_pk_f16_f32 (RNE)
+__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) { return __builtin_bit_cast(uint32_t, f16x2_t{(f16_t)lo, (f16_t)hi}); }
+template <> __device__ __forceinline__ u32x4_t pack16<f16_t>(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = cvt_pk_f16(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+// the two halves of a packed pair and the packing itself, by 16-bit storage type (uint16_t = bf16 bits, f16_t = fp16)
+template <typename T> __device__ __forceinline__ float lo16(uint32_t w);
+template <typename T> __device__ __forceinline__ float hi16(uint32_t w);
+template <typename T> __device__ __forceinline__ uint32_t pk16(float lo, float hi);
+template <> __device__ __forceinline__ float lo16<uint16_t>(uint32_t w) { return bf16lo(w); }
+template <> __device__ __forceinline__ float hi16<uint16_t>(uint32_t w) { return bf16hi(w); }
+template <> __device__ __forceinline__ uint32_t pk16<uint16_t>(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
+template <> __device__ __forceinline__ float lo16<f16_t>(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+template <> __device__ __forceinline__ float hi16<f16_t>(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+template <> __device__ __forceinline__ uint32_t pk16<f16_t>(float lo, float hi) { return cvt_pk_f16(lo, hi); }
 
 // K order of the 27 taps for bf16 storage: one MFMA step = two taps x 16 channels.  Taps are paired so that
 // the LDS address difference between the two taps of a step is one of three constants (+1 voxel in x for the
@@ -144,6 +181,9 @@ template <int ACTK> __device__ __forceinline__ void act_pair(float& a, float& b,
 template <typename T> __device__ __forceinline__ f32x4_t mfma_step(const u32x4_t& a, const u32x4_t& b, f32x4_t c);
 template <> __device__ __forceinline__ f32x4_t mfma_step<uint16_t>(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma_step<f16_t>(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 template <> __device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& a, const u32x4_t& b, f32x4_t c) {
 #pragma unroll

@@ -389,10 +389,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
         }
         T* yp = yout + vox * (size_t)p.y_ld + (size_t)(co >> 4) * p.y_cs + (co & 15);
         if (p.dbg & 8) continue;
-        if (std::is_same<T, float>::value) {
+        if constexpr (std::is_same<T, float>::value) {
           *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v[0], v[1], v[2], v[3]};
         } else {
-          *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pk16<T>(v[0], v[1]), pk16<T>(v[2], v[3])};
         }
       }
     }
@@ -463,7 +463,7 @@ extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
 // Lean persistent kernel (conv3d_lean.hip) where a CU gets >= 4 rounds of tiles; it uses 32-bit element offsets and
 // 16-byte vector loads of the per-channel parameter arrays.
 static bool use_lean(int dtype, const Conv3Params& p) {
-  if (dtype != BPX_BF16 || !(g_use_ws == 5 || (g_use_ws == 0 && (int64_t)p.D * p.H * p.W >= 262144))) return false;
+  if ((dtype != BPX_BF16 && dtype != BPX_F16) || !(g_use_ws == 5 || (g_use_ws == 0 && (int64_t)p.D * p.H * p.W >= 262144))) return false;
   const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
   const int64_t ldmax = std::max<int64_t>(std::max(p.x_ld, p.y_ld), std::max(p.sc ? p.sc_ld : 0, p.t ? p.t_ld : 0));
   auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
@@ -503,7 +503,7 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
                            const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
                            const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
                            float* pool_stats_part_d, bpx_stream_t stream) {
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16, "%s: dtype must be BF16, F16 (forward only) or F32", fn);
   int es = (int)dtype_size(dtype);
   BPX_CHECK(N > 0 && D > 0 && H > 0 && W > 0, "%s: empty volume", fn);
   if (check_tensor(fn, "x", x, es, true) || check_tensor(fn, "y", y, es, true)) return 1;
@@ -520,6 +520,7 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
   p.y = y.ptr; p.y_ld = y.ld; p.Cout = y.C; p.part = stats_part_d;
   if (check_planar(fn, "x", x, N, D, H, W) || check_planar(fn, "sc", sc, N, D, H, W) || check_planar(fn, "y", y, N, D, H, W)) return 1;
   p.x_cs = chunk_stride(x); p.sc_cs = chunk_stride(sc); p.y_cs = chunk_stride(y); p.t_cs = 16;
+  p.f16 = dtype == BPX_F16 ? 1 : 0;
   TileCfg c = pick_cfg(dtype, D, H, W, y.C);
   if (pool_sz) {
     BPX_CHECK(use_lean(dtype, p) && c.tx == 16, "%s: the fused pooling needs the lean bf16 kernel (bpx_conv3d_fwd_pool_supported)", fn);
@@ -531,7 +532,8 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
   }
   int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream)
-                               : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
+           : (dtype == BPX_F16)  ? launch_conv3<f16_t, EPI_FWD>(p, c, (hipStream_t)stream)
+                                 : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -554,7 +556,7 @@ extern "C" int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_te
 }
 
 extern "C" int bpx_conv3d_fwd_pool_supported(int dtype, int N, int D, int H, int W, int x_ld, int y_ld, int Cout) {
-  if (dtype != BPX_BF16 || g_use_ws != 0 || (int64_t)D * H * W < 262144 || W <= 8) return 0;
+  if ((dtype != BPX_BF16 && dtype != BPX_F16) || g_use_ws != 0 || (int64_t)D * H * W < 262144 || W <= 8) return 0;
   TileCfg c = pick_cfg(dtype, D, H, W, Cout);
   return c.tx == 16 && (int64_t)N * D * H * W * std::max(x_ld, y_ld) < (1ll << 31) ? 1 : 0;
 }

@@ -44,9 +44,11 @@ constexpr int lp_ahalf(int ms, int ns, int epi) { return (ms > 4 && ns == 1 && e
 //   * ADOPTED: four workgroups per CU for the 4x8x16 dgrad tile (A fragments read in two halves -> 119 VGPRs, no scratch):
 //     dgrad 16->16 @128^3 257 -> 241 us; the same for the forward tile still spills 150 B/lane at 128 VGPRs (staging peak) and stays at 3;
 //   * s_setprio 1 around the MFMA steps (BPX_CONV_DBG=16, still selectable): -1..-5 % forward, +-2 % dgrad - left off.
-template <int TZ, int TY, int TX, int NS, int EPI, int ACTK>
+// F16: fp16 storage instead of bf16 (inference: forward instances only) - same instruction counts (v_cvt_f32_f16 / v_cvt_pk_f16_f32 in
+// place of the shifts / v_cvt_pk_bf16_f32, v_mfma_f32_16x16x32_f16)
+template <int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool F16 = false>
 __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv3_lp_kernel(const Conv3Params p) {
-  using T = uint16_t;
+  using T = typename std::conditional<F16, f16_t, uint16_t>::type;
   constexpr int KPL = 8, VB = 32;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int STEPS = 14, QPAD = 56;
@@ -166,9 +168,9 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
           if (nrec && goff[u] != 0xFFFFFFFFu) {  // zero padding applies to the ACTIVATED tensor: out-of-volume stays 0
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              float a = fmaf(psc[2 * i], bf16lo(v[i]), psh[2 * i]), b = fmaf(psc[2 * i + 1], bf16hi(v[i]), psh[2 * i + 1]);
+              float a = fmaf(psc[2 * i], lo16<T>(v[i]), psh[2 * i]), b = fmaf(psc[2 * i + 1], hi16<T>(v[i]), psh[2 * i + 1]);
               act_pair<ACTK>(a, b, p.act);
-              v[i] = cvt_pk_bf16(a, b);
+              v[i] = pk16<T>(a, b);
             }
           }
           *reinterpret_cast<u32x4_t*>(smem + (size_t)(u * 256 + tid) * 16) = v;
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               s1[r] += v[r];
               s2[r] += v[r] * v[r];
             }
-            pk[ms] = u32x2_t{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])};
+            pk[ms] = u32x2_t{pk16<T>(v[0], v[1]), pk16<T>(v[2], v[3])};
             *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) = pk[ms];
           }
         }
@@ -288,8 +290,8 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
           for (int k = 0; k < MS / 2; ++k) {
             const u32x2_t a = pk[2 * k], b = pk[2 * k + 1];
-            m[k][0] = fmaxf(bf16lo(a[0]), bf16lo(b[0])); m[k][1] = fmaxf(bf16hi(a[0]), bf16hi(b[0]));
-            m[k][2] = fmaxf(bf16lo(a[1]), bf16lo(b[1])); m[k][3] = fmaxf(bf16hi(a[1]), bf16hi(b[1]));
+            m[k][0] = fmaxf(lo16<T>(a[0]), lo16<T>(b[0])); m[k][1] = fmaxf(hi16<T>(a[0]), hi16<T>(b[0]));
+            m[k][2] = fmaxf(lo16<T>(a[1]), lo16<T>(b[1])); m[k][3] = fmaxf(hi16<T>(a[1]), hi16<T>(b[1]));
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               m[k][r] = fmaxf(m[k][r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[k][r]), 0xB1, 0xF, 0xF, true)));
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               if (y0 + 2 * k < H) {
                 const int py = (y0 >> 1) + k;
                 *reinterpret_cast<u32x2_t*>(pout + (uint32_t)((((n * Dp + pz) * Hp + py) * Wp + px) * p.pool_ld + co) * 2u) =
-                    u32x2_t{cvt_pk_bf16(m[k][0], m[k][1]), cvt_pk_bf16(m[k][2], m[k][3])};
+                    u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { q1[r] += m[k][r]; q2[r] += m[k][r] * m[k][r]; }
               }
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
               const uint32_t w = tv[b][ms][r >> 1];
-              const float tf = (r & 1) ? bf16hi(w) : bf16lo(w);
+              const float tf = (r & 1) ? hi16<T>(w) : lo16<T>(w);
               const float u = fmaf(rec[2], tf, rec[3]);
               const float gv = (okzx && RS * ms < yrem) ? acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act) : 0.f;
               acc[ms][ns][r] = gv;
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         for (int ms = 0; ms < MS; ++ms)
           if (okzx && RS * ms < yrem)
             *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) =
-                u32x2_t{cvt_pk_bf16(acc[ms][ns][0], acc[ms][ns][1]), cvt_pk_bf16(acc[ms][ns][2], acc[ms][ns][3])};
+                u32x2_t{pk16<T>(acc[ms][ns][0], acc[ms][ns][1]), pk16<T>(acc[ms][ns][2], acc[ms][ns][3])};
         flush_stats(ns, s1, s2);
       }
     }
@@ -430,6 +432,14 @@ int launch_lp(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   dim3 grid((unsigned)gx, (unsigned)gy);
 #define L(TZ, TY, TX, NS)                                                          \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                      \
+    if (p.f16) {                                                                   \
+      if constexpr (EPI == EPI_FWD) {                                              \
+        if (elu) conv3_lp_kernel<TZ, TY, TX, NS, EPI_FWD, 1, true><<<grid, 256, 0, s>>>(p);   \
+        else conv3_lp_kernel<TZ, TY, TX, NS, EPI_FWD, 0, true><<<grid, 256, 0, s>>>(p);       \
+        return 0;                                                                  \
+      }                                                                            \
+      return 1;                                                                    \
+    }                                                                              \
     if (elu) conv3_lp_kernel<TZ, TY, TX, NS, EPI, 1><<<grid, 256, 0, s>>>(p);      \
     else conv3_lp_kernel<TZ, TY, TX, NS, EPI, 0><<<grid, 256, 0, s>>>(p);          \
     return 0;                                                                      \

@@ -28,6 +28,7 @@ struct Conv3Params {
   // distance in ELEMENTS between consecutive 16-channel chunks of a voxel: 16 for the ordinary interleaved layout, the plane size for
   // chunk-planar tensors (bpx_tensor.cs)
   int x_cs, sc_cs, y_cs, t_cs;
+  int f16;   // 16-bit storage is fp16 instead of bf16 (forward only)
 };
 inline int chunk_stride(const bpx_tensor& t) { return t.cs ? (int)t.cs : 16; }
 
@@ -71,7 +72,7 @@ inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   // <= 16^3 volumes: 4x4x8 tiles double the workgroup count of these latency-bound launches (measured 114 -> 92, 61 -> 48 us)
   if (W > 8 && (int64_t)D * H * W > 4096) {
     c.tx = 16; c.tz = 4;
-    bool big = (dtype == BPX_BF16) && c.ns == 1 && (int64_t)D * H * W >= 32768 && H >= 8 && getenv("BPX_SMALL_TILE") == nullptr;
+    bool big = (dtype == BPX_BF16 || dtype == BPX_F16) && c.ns == 1 && (int64_t)D * H * W >= 32768 && H >= 8 && getenv("BPX_SMALL_TILE") == nullptr;
     c.ty = big ? 8 : 4;
   } else {
     c.tx = 8; c.tz = 4; c.ty = 4;

@@ -668,7 +668,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w /* (Cout,1,27) */,
                                                           const float* __restrict__ bias, T* __restrict__ y, int y_ld, int Cout, int D,
                                                           int H, int W, int tilesY, int tilesX, int tilesPerSample, float* __restrict__ part) {
-  constexpr bool BF = std::is_same<T, uint16_t>::value;
+  constexpr bool BF = sizeof(T) == 2;   // 16-bit storage (bf16 bits or fp16): hi + lo split of the fp32 image, two MFMAs
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX, MS = 8;
   __shared__ float simg[HV];
   __shared__ float red[4][32];
@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
   u32x4_t wa = u32x4_t{0u, 0u, 0u, 0u};
   float wf32[7];
   int toff[BF ? 8 : 7];
-  if (BF) {
+  if constexpr (BF) {
     float wv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
       int tc = t < 27 ? t : 26;
       toff[e] = ((tc / 9) * HY + (tc / 3) % 3) * HX + tc % 3;
     }
-    wa = pack16<uint16_t>(wv);
+    wa = pack16<T>(wv);
   } else {
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
@@ -714,18 +714,18 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
     int tz = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
     const float* base = simg + (tz * HY + ty) * HX + tx;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (BF) {
+    if constexpr (BF) {
       float v[8], lo[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = base[toff[e]];
-      u32x4_t hi = pack16<uint16_t>(v);
+      u32x4_t hi = pack16<T>(v);
       float hf[8];
-      unpack16<uint16_t>(hi, hf);
+      unpack16<T>(hi, hf);
 #pragma unroll
       for (int e = 0; e < 8; ++e) lo[e] = v[e] - hf[e];
-      u32x4_t lov = pack16<uint16_t>(lo);
-      acc = mfma_step<uint16_t>(wa, hi, acc);
-      acc = mfma_step<uint16_t>(wa, lov, acc);
+      u32x4_t lov = pack16<T>(lo);
+      acc = mfma_step<T>(wa, hi, acc);
+      acc = mfma_step<T>(wa, lov, acc);
     } else {
 #pragma unroll
       for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf32[s], base[toff[s]], acc, 0, 0, 0);
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v4[r] = acc[r] + bsv[r]; s1[r] += v4[r]; s2[r] += v4[r] * v4[r]; }
       T* yp = y + ((((size_t)n * D + z) * H + yy) * W + x) * (size_t)y_ld + cb + 4 * g;
-      if (BF) *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pack_bf16x2(v4[0], v4[1]), pack_bf16x2(v4[2], v4[3])};
+      if constexpr (BF) *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pk16<T>(v4[0], v4[1]), pk16<T>(v4[2], v4[3])};
       else *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v4[0], v4[1], v4[2], v4[3]};
     }
   }
@@ -1061,7 +1061,7 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch b) {   
 }
 
 inline int64_t packed_elems(int mode, int Cin, int Cout, int dtype) {
-  const int KPL = dtype == BPX_BF16 ? 8 : 4, GPT = 16 / KPL;
+  const int KPL = dtype == BPX_F32 ? 4 : 8, GPT = 16 / KPL;
   const int QPAD3 = ((27 * GPT + 3) / 4) * 4;
   auto r4 = [](int64_t q) { return (q + 3) / 4 * 4; };
   switch (mode) {
@@ -1519,7 +1519,7 @@ extern "C" int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx
 static int pool_block(int C, int kpl) { int G = C / kpl; return (256 / G) * G; }
 
 extern "C" int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int sz, int C) {
-  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int kpl = dtype == BPX_F32 ? 4 : 8;
   int bd = pool_block(C, kpl);
   int64_t items = (int64_t)(D / (sz == 1 ? 1 : 2)) * (H / 2) * (W / 2) * (C / kpl);
   return (int)cdiv64(items, (int64_t)bd * POOL_IPT);
@@ -1535,7 +1535,7 @@ extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, 
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   BPX_CHECK(D % sz == 0 && H % 2 == 0 && W % 2 == 0, "%s: extents must be divisible by the window (%d,2,2) (got %d,%d,%d)", fn, sz, D, H, W);
   BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
-  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int kpl = dtype == BPX_F32 ? 4 : 8;
   int bd = pool_block(x.C, kpl);
   int tiles = bpx_maxpool3d_stats_tiles(dtype, D, H, W, sz, x.C);
   dim3 grid((unsigned)tiles, (unsigned)N);
@@ -1543,6 +1543,8 @@ extern "C" int bpx_maxpool3d_fwd(int dtype, int N, int D, int H, int W, int sz, 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
     maxpool_fwd_kernel<uint16_t><<<grid, bd, shm, s>>>((const uint16_t*)x.ptr, x.ld, xcs, (uint16_t*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
+  else if (dtype == BPX_F16)
+    maxpool_fwd_kernel<f16_t><<<grid, bd, shm, s>>>((const f16_t*)x.ptr, x.ld, xcs, (f16_t*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
   else if (dtype == BPX_F32)
     maxpool_fwd_kernel<float><<<grid, bd, shm, s>>>((const float*)x.ptr, x.ld, xcs, (float*)y.ptr, y.ld, x.C, D, H, W, sz, tiles, stats_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
@@ -1585,8 +1587,9 @@ extern "C" int bpx_head_fwd(int dtype, int64_t vps, int N, bpx_tensor x, const f
   hipStream_t s = (hipStream_t)stream;
 #define HL(T, CIN) head_fwd_kernel<T, CIN><<<grid_for(total), 256, 0, s>>>((const T*)x.ptr, x.ld, w_d, b_d, Cout, head_act, out_d, sn, sc, vps, N)
   if (dtype == BPX_BF16) { if (x.C == 16) HL(uint16_t, 16); else HL(uint16_t, 32); }
+  else if (dtype == BPX_F16) { if (x.C == 16) HL(f16_t, 16); else HL(f16_t, 32); }
   else if (dtype == BPX_F32) { if (x.C == 16) HL(float, 16); else HL(float, 32); }
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  else BPX_FAIL("%s: dtype must be BF16, F16 or F32", fn);
 #undef HL
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -1635,6 +1638,7 @@ extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const fl
   dim3 grid((unsigned)(tiles * N), (unsigned)(y.C / 16));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
+  else if (dtype == BPX_F16) conv_c1_fwd_kernel<f16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (f16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
   else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
@@ -1694,12 +1698,13 @@ extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, in
   const char* fn = "bpx_pack_weight";
   BPX_CHECK(w_d && packed_d, "%s: null pointer", fn);
   BPX_CHECK(mode >= PK_K3 && mode <= PK_CT4_T, "%s: bad mode %d", fn, mode);
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16, "%s: dtype must be BF16, F16 or F32", fn);
   if (mode <= PK_K1) BPX_CHECK(Cin % 16 == 0 && Cout % 16 == 0, "%s: Cin/Cout must be multiples of 16", fn);
   if (mode == PK_K3_T) BPX_CHECK(Cout % 16 == 0, "%s: Cout must be a multiple of 16", fn);
   int64_t total = packed_elems(mode, Cin, Cout, dtype);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16) pack_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>(w_d, (uint16_t*)packed_d, mode, Cin, Cout, total);
+  else if (dtype == BPX_F16) pack_kernel<f16_t><<<grid_for(total), 256, 0, s>>>(w_d, (f16_t*)packed_d, mode, Cin, Cout, total);
   else pack_kernel<float><<<grid_for(total), 256, 0, s>>>(w_d, (float*)packed_d, mode, Cin, Cout, total);
   BPX_LAUNCH_CHECK(fn);
   return 0;
@@ -1707,7 +1712,7 @@ extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, in
 
 extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job* jobs, bpx_stream_t stream) {
   const char* fn = "bpx_pack_weights_batched";
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16, "%s: dtype must be BF16, F16 or F32", fn);
   BPX_CHECK(count >= 0 && (count == 0 || jobs != nullptr), "%s: bad job list", fn);
   hipStream_t s = (hipStream_t)stream;
   for (int base = 0; base < count; base += 64) {
@@ -1725,6 +1730,7 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
     }
     dim3 grid(256, (unsigned)n);   // the largest operands (256x256x27) are ~1.8 M elements: 27 per thread
     if (dtype == BPX_BF16) pack_batch_kernel<uint16_t><<<grid, 256, 0, s>>>(b);
+    else if (dtype == BPX_F16) pack_batch_kernel<f16_t><<<grid, 256, 0, s>>>(b);
     else pack_batch_kernel<float><<<grid, 256, 0, s>>>(b);
     BPX_LAUNCH_CHECK(fn);
   }
@@ -1760,6 +1766,7 @@ extern "C" int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* d
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (src_dtype == BPX_F32 && dst_dtype == BPX_BF16) cast_kernel<float, uint16_t><<<grid_for(n), 256, 0, s>>>((const float*)src_d, (uint16_t*)dst_d, n);
+  else if (src_dtype == BPX_F32 && dst_dtype == BPX_F16) cast_kernel<float, f16_t><<<grid_for(n), 256, 0, s>>>((const float*)src_d, (f16_t*)dst_d, n);
   else if (src_dtype == BPX_BF16 && dst_dtype == BPX_F32) cast_kernel<uint16_t, float><<<grid_for(n), 256, 0, s>>>((const uint16_t*)src_d, (float*)dst_d, n);
   else BPX_FAIL("%s: unsupported conversion %d -> %d", fn, src_dtype, dst_dtype);
   BPX_LAUNCH_CHECK(fn);

@@ -64,6 +64,31 @@ template <> __device__ __forceinline__ void storeq<uint16_t, 2>(uint16_t* p, con
 template <> __device__ __forceinline__ void storeq<uint16_t, 3>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); store4_bf16(p + 8, f[2]); }
 template <> __device__ __forceinline__ void storeq<uint16_t, 4>(uint16_t* p, const float (*f)[4]) { store8_bf16(p, f[0], f[1]); store8_bf16(p + 8, f[2], f[3]); }
 
+// fp16 storage (forward kernels only): same access widths as bf16
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float* f) {
+  u32x2_t v = *reinterpret_cast<const u32x2_t*>(p);
+  f[0] = lo16<f16_t>(v[0]); f[1] = hi16<f16_t>(v[0]); f[2] = lo16<f16_t>(v[1]); f[3] = hi16<f16_t>(v[1]);
+}
+__device__ __forceinline__ void load8_f16(const f16_t* p, float* f0, float* f1) {
+  u32x4_t v = *reinterpret_cast<const u32x4_t*>(p);
+  f0[0] = lo16<f16_t>(v[0]); f0[1] = hi16<f16_t>(v[0]); f0[2] = lo16<f16_t>(v[1]); f0[3] = hi16<f16_t>(v[1]);
+  f1[0] = lo16<f16_t>(v[2]); f1[1] = hi16<f16_t>(v[2]); f1[2] = lo16<f16_t>(v[3]); f1[3] = hi16<f16_t>(v[3]);
+}
+template <> __device__ __forceinline__ void loadq<f16_t, 1>(const f16_t* p, float (*f)[4]) { load4<f16_t>(p, f[0]); }
+template <> __device__ __forceinline__ void loadq<f16_t, 2>(const f16_t* p, float (*f)[4]) { load8_f16(p, f[0], f[1]); }
+template <> __device__ __forceinline__ void loadq<f16_t, 3>(const f16_t* p, float (*f)[4]) { load8_f16(p, f[0], f[1]); load4<f16_t>(p + 8, f[2]); }
+template <> __device__ __forceinline__ void loadq<f16_t, 4>(const f16_t* p, float (*f)[4]) { load8_f16(p, f[0], f[1]); load8_f16(p + 8, f[2], f[3]); }
+__device__ __forceinline__ void store4_f16(f16_t* p, const float* f) {
+  *reinterpret_cast<u32x2_t*>(p) = u32x2_t{cvt_pk_f16(f[0], f[1]), cvt_pk_f16(f[2], f[3])};
+}
+__device__ __forceinline__ void store8_f16(f16_t* p, const float* f0, const float* f1) {
+  *reinterpret_cast<u32x4_t*>(p) = u32x4_t{cvt_pk_f16(f0[0], f0[1]), cvt_pk_f16(f0[2], f0[3]), cvt_pk_f16(f1[0], f1[1]), cvt_pk_f16(f1[2], f1[3])};
+}
+template <> __device__ __forceinline__ void storeq<f16_t, 1>(f16_t* p, const float (*f)[4]) { store4_f16(p, f[0]); }
+template <> __device__ __forceinline__ void storeq<f16_t, 2>(f16_t* p, const float (*f)[4]) { store8_f16(p, f[0], f[1]); }
+template <> __device__ __forceinline__ void storeq<f16_t, 3>(f16_t* p, const float (*f)[4]) { store8_f16(p, f[0], f[1]); store4_f16(p + 8, f[2]); }
+template <> __device__ __forceinline__ void storeq<f16_t, 4>(f16_t* p, const float (*f)[4]) { store8_f16(p, f[0], f[1]); store8_f16(p + 8, f[2], f[3]); }
+
 // The same 4*NQ consecutive channels c0.. of a voxel of a CHUNK-PLANAR tensor (channel c of a voxel at (c/16)*cs + c%16 from the voxel's
 // base): the widest accesses that stay inside one 16-channel chunk.  c0 is a multiple of 4*NQ for NQ = 1, 2, 4 (never straddles); for
 // NQ = 3 the 12 channels split as 8 + 4 or 4 + 8 depending on the lane.
@@ -378,7 +403,7 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
   BPX_CHECK(y.cs == 0 || (y.cs >= ((int64_t)N * D * H * W * 4 * sz - 1) * y.ld + 16 && y.cs < (1ll << 31)), "bpx_convT3d_k2s2_fwd: y has chunk stride %lld",
             (long long)y.cs);
   const char* fn = "bpx_convT3d_k2s2_fwd";
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16, "%s: dtype must be BF16, F16 or F32", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   int es = (int)dtype_size(dtype);
   if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
@@ -394,7 +419,9 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
   // into a 32-of-48-channel slice of an interleaved buffer the wide form is slower, 362 -> 415 us, and is not used)
   static const bool wide = getenv("BPX_CONVT_NS") == nullptr;
   int ns = (wide && (y.cs != 0 || y.ld == y.C) && (4 * sz * y.C) % 64 == 0) ? 4 : pw_ns(y.C);
-  if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream)) != 0) return 1;
+  if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream)
+       : dtype == BPX_F16 ? launch_pw<f16_t, PW_CONVT>(p, ns, (hipStream_t)stream)
+                          : launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -166,10 +166,12 @@ class _Blk:
 
 class ResUNetEngine:
     def __init__(self, cfg: NetConfig, dtype: torch.dtype = torch.bfloat16):
-        assert dtype in (torch.bfloat16, torch.float32)
+        assert dtype in (torch.bfloat16, torch.float32, torch.float16)
         self.cfg = cfg
         self.dtype = dtype
-        self.dt = L.BF16 if dtype == torch.bfloat16 else L.F32
+        # float16 = the same 16 bits per element with an 11-bit mantissa: INFERENCE ONLY (forward kernels; gradients would need loss
+        # scaling) - the mode whose Dice agrees with the fp32 reference to < 1e-4 at the speed of the bf16 mode
+        self.dt = {torch.bfloat16: L.BF16, torch.float32: L.F32, torch.float16: L.F16}[dtype]
         self.act = L.ACT[cfg.activation]
         self._ws: Optional[torch.Tensor] = None
         self._side_stream = None
@@ -354,6 +356,8 @@ class ResUNetEngine:
         ``x_ndhwc``: the input already as a dense (B,Z,Y,X,C) tensor of the storage dtype (``x`` is then ignored); ``want_dx``: the
         backward also returns the gradient of that tensor under the key "__dx__" (super-resolution pre-up-sampling, resunet_sr)."""
         cfg = self.cfg
+        if save and self.dtype == torch.float16:
+            raise NotImplementedError("compute_dtype=torch.float16 is an inference mode (no backward kernels): train in bfloat16 or float32")
         if x_ndhwc is not None:
             assert x_ndhwc.is_cuda and x_ndhwc.dtype == self.dtype and x_ndhwc.dim() == 5 and x_ndhwc.is_contiguous() and cfg.in_ch != 1
             x = x_ndhwc.permute(0, 4, 1, 2, 3)           # only its shape is used below
@@ -405,7 +409,7 @@ class ResUNetEngine:
             if T == torch.float32:
                 x_ndhwc.copy_(xin)
             else:
-                L.check(lib.bpx_cast(L.F32, xin.data_ptr(), L.BF16, x_ndhwc.data_ptr(), xin.numel(), st))
+                L.check(lib.bpx_cast(L.F32, xin.data_ptr(), self.dt, x_ndhwc.data_ptr(), xin.numel(), st))
 
         S = [(D0, H0, W0)]
         for i in range(Lv):

@@ -190,7 +190,7 @@ def test_network_cfg2_at_the_benched_shape(K, dtype):
     _assert_all(K.check_network_cfg2_benched_shape(dtype))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_sliding_window_cfg3_shape(K, dtype):
     """cfg-3-shaped sliding window (128^3 patches of the cfg-2 network, 50 % z overlap, two slabs) vs the oracle pipeline."""
     _assert_all(K.check_sliding_window_cfg3_shape(dtype))
@@ -221,6 +221,36 @@ def test_module_is_a_dropin(resunet_golden):
 def test_sliding_window_pipeline(K, dtype):
     """crop -> forward -> merge on the device == the oracle's pipeline (process_test_sample per-patch branch)."""
     _assert_all(K.check_sliding_window(dtype))
+
+
+def test_fp16_inference_mode(K, resunet_golden):
+    """compute_dtype=torch.float16: the inference mode that meets the north-star bar (Dice delta < 1e-4 is asserted on the trained model
+    in test_dice_parity_on_a_trained_model).  Here: logits against the reference fixture, the cfg-2 architecture at 64^3 against the
+    oracle, and the refusal to train."""
+    from biapy_amd.engine import NetConfig, ResUNetEngine
+    from biapy_amd.resunet import ResUNet
+
+    g = resunet_golden
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+    x = torch.from_numpy(g["small/x"]).permute(0, 4, 1, 2, 3).contiguous().cuda()
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm), torch.float16)
+    P = {k: v.cuda() for k, v in sd.items()}
+    lo, _ = eng.forward(P, x, save=False)
+    ref = torch.from_numpy(g["small/logits"])
+    rel = ((lo.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert rel < 2e-3, rel
+    with pytest.raises(NotImplementedError):
+        eng.forward(P, x, save=True)
+    m = ResUNet(image_shape=(64, 64, 64, 1), activation="elu", feature_maps=[16, 32, 64, 128, 256], drop_values=[0.0] * 5, normalization="in",
+                yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=torch.float16).cuda().eval()
+    from oracle import net_oracle
+    xs = torch.randn(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        got = m(xs.cuda()).cpu()
+        want = net_oracle.resunet_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, xs, [16, 32, 64, 128, 256])
+    rel = ((got - want).abs().max() / want.abs().max()).item()
+    assert rel < 3e-3, rel
 
 
 def test_dice_parity_on_a_trained_model(K):
