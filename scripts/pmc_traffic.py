@@ -17,8 +17,9 @@ from collections import defaultdict
 
 # kernel name -> C-ABI entry point.  conv3_kernel<T,TZ,TY,TX,NS,EPI,ACTK> and conv3_lp_kernel<TZ,TY,TX,NS,EPI,ACTK>: EPI 0 = fwd, 1 = dgrad
 GROUPS = [
-    ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+>")),
-    ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+>")),
+    # the lean kernel carries a trailing bool (fp16 storage) since round 2: <TZ, TY, TX, NS, EPI, ACTK, F16>
+    ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+(, (true|false))?>")),
+    ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+(, (true|false))?>")),
     ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel<|wgrad_reduce(_batch)?_kernel")),
     # the sliding-window blend / gather (tests/bench_kernels.py merge: 512 x 128^3 <-> 512^3; 16 B/lane row kernels, same doubling)
     ("bpx_merge3d_blend", re.compile(r"merge3d_row_kernel<")),
