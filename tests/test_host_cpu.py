@@ -357,3 +357,22 @@ def test_dilated_conv_is_conv_on_sublattices(dim, d):
             kz, ky, kx = np.where(tz >= 0)[0], np.where(ty >= 0)[0], np.where(tx >= 0)[0]
             out[n][:, tz[kz][:, None, None], ty[ky][None, :, None], tx[kx][None, None, :]] = ys[n * d ** 3 + q][:, kz][:, :, ky][:, :, :, kx]
     assert torch.allclose(out, ref, atol=1e-5)
+
+
+def test_chunk_planar_buffer_views():
+    """_lib.Planar (bpx_tensor.cs != 0): the (C/16, B, D, H, W, 16) planes round-trip a dense NDHWC tensor, and channel slices are
+    whole chunks addressed by (plane pointer, voxel pitch 16, plane stride) - what the kernels read as v*ld + (c/16)*cs + c%16."""
+    from biapy_amd import _lib as L
+
+    x = torch.randn(2, 3, 4, 5, 48)
+    p = L.Planar(2, (3, 4, 5), 48, torch.float32, "cpu").copy_from_dense(x)
+    assert torch.equal(p.dense(), x) and p.shape == (2, 3, 4, 5, 48)
+    t = L.tview(p, 16, 32)
+    assert (t.ld, t.C, t.cs) == (16, 32, p.plane) and t.ptr == p.t.data_ptr() + p.plane * 4
+    flat = p.t.reshape(-1) if p.t.is_contiguous() else p._flat
+    v, c = 37, 29                                              # voxel 37 of the (2,3,4,5) grid, channel 29 = chunk 1, lane 13
+    assert flat[v * 16 + (c // 16) * p.plane + c % 16] == x.reshape(-1, 48)[v, c]
+    with pytest.raises(AssertionError):
+        L.tview(p, 8, 16)                                       # slices are whole 16-channel chunks
+    d = L.tview(x, 8, 16)
+    assert (d.ld, d.C, d.cs) == (48, 16, 0)
