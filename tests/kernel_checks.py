@@ -1381,12 +1381,19 @@ def check_sliding_window(dtype=torch.float32):
     with torch.no_grad():
         pr = torch.sigmoid(net_oracle.resunet_forward(sd, torch.from_numpy(p).permute(0, 4, 1, 2, 3), fm)).permute(0, 2, 3, 4, 1).contiguous().numpy()
     ref = TO.merge(pr, vol.shape, overlap=ov, padding=pad)
-    sw = SlidingWindowPredictor(m, patch, ov, pad, batch_size=5)
+    if dtype == torch.float16:
+        # the way it is used after bf16 training: the predictor switches the model to the fp16 inference mode and back
+        m.compute_dtype = torch.bfloat16
+        sw = SlidingWindowPredictor(m, patch, ov, pad, batch_size=5, compute_dtype=torch.float16)
+    else:
+        sw = SlidingWindowPredictor(m, patch, ov, pad, batch_size=5)
     got = sw.predict(torch.from_numpy(vol).cuda()).cpu().numpy()
-    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
-    res = [_res(f"sliding_window_prob[{tagd}]", np.abs(got - ref).max(), 2e-5 if dtype == torch.float32 else 3e-2)]
+    tagd, band, _ = _mode(dtype)
+    res = [_res(f"sliding_window_prob[{tagd}]", np.abs(got - ref).max(), {"f32": 2e-5, "bf16": 3e-2, "f16": 4e-3}[tagd])]
+    if dtype == torch.float16:
+        res.append(_res("sliding_window[f16].model_dtype_restored", 0.0 if m.compute_dtype == torch.bfloat16 else 1.0, 0))
     lab_ref, lab_got = (ref > 0.5), (got > 0.5)
-    near = np.abs(ref - 0.5) < (1e-5 if dtype == torch.float32 else 2e-2)        # voxels whose label is decided by the last bits
+    near = np.abs(ref - 0.5) < band                                              # voxels whose label is decided by the last bits
     res.append(_res(f"sliding_window_labels_away_from_threshold[{tagd}]", int(((lab_ref != lab_got) & ~near).sum()), 0,
                     extra=f"undecidable voxels: {int(near.sum())} of {near.size}"))
     return res

@@ -217,7 +217,7 @@ def test_module_is_a_dropin(resunet_golden):
         assert abs(p.grad.norm().item() - ref) <= 2e-3 * max(ref, 1e-3), k
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_sliding_window_pipeline(K, dtype):
     """crop -> forward -> merge on the device == the oracle's pipeline (process_test_sample per-patch branch)."""
     _assert_all(K.check_sliding_window(dtype))
