@@ -153,8 +153,9 @@ def test_norm_pool_head_first_layer(K, dt):
     _assert_all(K.check_norm_pool_head(dt))
 
 
-@pytest.mark.parametrize("dt,S,lean", [(0, (8, 16, 32), False), (1, (8, 16, 32), False), (1, (64, 64, 64), True), (0, (4, 8, 8), False)],
-                         ids=["f32", "bf16", "bf16-lean-64^3", "f32-w8"])
+@pytest.mark.parametrize("dt,S,lean", [(0, (8, 16, 32), False), (1, (8, 16, 32), False), (1, (64, 64, 64), True), (0, (4, 8, 8), False),
+                                       (1, (6, 10, 18), False), (1, (66, 70, 72), True)],
+                         ids=["f32", "bf16", "bf16-lean-64^3", "f32-w8", "bf16-ragged-tiles", "bf16-lean-ragged-tiles"])
 def test_chunk_planar_operands_equal_interleaved(K, dt, S, lean):
     """bpx_tensor.cs: the decoder's concat buffers are chunk-planar; every kernel that takes them gives bit-identical results."""
     _assert_all(K.check_planar_layouts(dt, S, lean))
