@@ -9,10 +9,10 @@ Restated reference code (paths relative to /root/reference):
                                         (_pad_for_orientations, _crop_padding, _reduce_orientations, ensemble_predictions
                                         with tta_spec=None)
 
-Parity status: the orientation group and the transforms are PINNED against tta.py itself (it imports here; fixture
-tests/golden/tta_golden.npz).  post_processing.py cannot be imported in this image (cv2, h5py, zarr, scikit-image are
-missing), so the pad / reduce steps are restated from the source text and checked only for self-consistency: PARITY UNPINNED
-for those lines.
+Parity status: PINNED.  The orientation group and the transforms against tta.py itself (tests/golden/tta_golden.npz); the pad /
+predict / undo / reduce / crop pipeline against ``ensemble_predictions`` of post_processing.py run in the build container
+(tests/golden/tta_ensemble_golden.npz, made by ``make_golden.py tta_ensemble``: the module imports once the third-party packages it
+never calls on this path - cv2, fill_voids, scikit-image, numba ... - are replaced by stand-ins, tests/golden/_ref_shim.py).
 """
 from __future__ import annotations
 
@@ -83,3 +83,18 @@ def ensemble(img: np.ndarray, pred_func, ndim: int, mode: str = "mean", level: s
     if pad_before is not None:
         out = out[tuple(slice(q, None) for q in pad_before) + (slice(None),)]
     return out
+
+
+def standin_pred(batch: np.ndarray) -> np.ndarray:
+    """A predictor that is NOT equivariant (it depends on the position inside the oriented patch), two output channels, exact float32
+    products and sums only - the same function produced the fixture through the reference and serves the tests.
+    batch: (n, spatial..., C) -> (n, spatial..., 2)."""
+    ramp = np.linspace(0.0, 1.0, batch[0, ..., 0].size, dtype=np.float32).reshape(batch.shape[1:-1])
+    return np.stack([np.stack([batch[k, ..., 0] * ramp + np.float32(0.25) * batch[k, ..., -1], batch[k, ..., 0] * batch[k, ..., 0] - ramp], -1)
+                     for k in range(batch.shape[0])], 0).astype(np.float32)
+
+
+ENSEMBLE_CASES = [  # (name, shape (spatial..., C), ndim)
+    ("cube", (6, 8, 8, 1), 3), ("reflect_pad", (5, 6, 9, 2), 3), ("edge_pad", (4, 3, 9, 1), 3), ("plane", (7, 10, 1), 2), ("square", (12, 12, 3), 2),
+]
+ENSEMBLE_SETTINGS = [("mean", "full", 3), ("min", "full", 1), ("max", "flips", 2), ("mean", "flips", 16), ("max", "full", 5)]

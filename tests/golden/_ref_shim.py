@@ -82,3 +82,40 @@ def install():
 def load(modname):
     install()
     return importlib.import_module(modname)
+
+
+class _Soft(types.ModuleType):
+    """Stand-in for a third-party module that a reference file imports at its top but never calls on the pinned path: every attribute
+    is a callable that also works as a decorator (``@numba.njit(...)``)."""
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+
+        def deco(*a, **kw):
+            if len(a) == 1 and callable(a[0]) and not kw:
+                return a[0]
+            return lambda f: f
+        return deco
+
+
+def load_post_processing():
+    """biapy/data/post_processing/post_processing.py (ensemble_predictions, _pad_for_orientations, _reduce_orientations).  Its top-level
+    imports of cv2, fill_voids, scikit-image, numba, ... are not installed here and are not touched by the TTA routine: soft stand-ins."""
+    install()
+    for n in ["cv2", "fill_voids", "skimage", "skimage.morphology", "skimage.segmentation", "skimage.filters", "skimage.measure", "skimage.exposure",
+              "skimage.feature", "skimage.io", "skimage.transform", "skimage.util", "skimage.draw", "skimage.color", "imagecodecs", "tifffile",
+              "nibabel", "numba", "edt", "pooch", "xarray", "bioimageio", "bioimageio.core", "bioimageio.spec", "PIL", "PIL.Image",
+              "PIL.ImageEnhance", "imageio", "matplotlib", "matplotlib.pyplot", "matplotlib.transforms", "pydot", "torchinfo"]:
+        try:
+            importlib.import_module(n)
+        except Exception:
+            m = _Soft(n)
+            m.__path__ = []
+            sys.modules[n] = m
+    for pk in ["biapy.data.post_processing", "biapy.data.generators"]:
+        if pk not in sys.modules:
+            m = types.ModuleType(pk)
+            m.__path__ = [os.path.join(REF, *pk.split("."))]
+            sys.modules[pk] = m
+    return importlib.import_module("biapy.data.post_processing.post_processing")

@@ -252,6 +252,33 @@ def tta_fixtures():
     print("tta_golden.npz:", len(out), "arrays")
 
 
+def tta_ensemble_fixtures():
+    """ensemble_predictions of biapy/data/post_processing/post_processing.py:1386-1540 (tta_spec=None) with the stand-in predictor of
+    oracle/tta_oracle.py: padding to square (reflect / edge), every orientation predicted, undone, reduced (mean / min / max), cropped."""
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import tta_oracle as TO
+
+    pp = shim.load_post_processing()
+    out = {}
+    rs = np.random.RandomState(6100)
+    for name, shape, ndim in TO.ENSEMBLE_CASES:
+        img = rs.rand(*shape).astype(np.float32)
+        out[f"{name}/img"] = img
+        back = (0, 2, 3, 1) if ndim == 2 else (0, 2, 3, 4, 1)          # tensor (B,C,spatial) -> numpy (B,spatial,C)
+        fwd = (0, 3, 1, 2) if ndim == 2 else (0, 4, 1, 2, 3)
+
+        def pred_func(batch):                                             # what model_call_func does: numpy batch in, channel-first tensor out
+            return torch.from_numpy(TO.standin_pred(np.asarray(batch))).permute(*fwd)
+
+        for mode, level, bs in TO.ENSEMBLE_SETTINGS:
+            r = pp.ensemble_predictions(img, pred_func, back, fwd, torch.device("cpu"), ndim, batch_size_value=bs, mode=mode, group=level)
+            out[f"{name}/{mode}/{level}/{bs}"] = r.permute(*back)[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "tta_ensemble_golden.npz"), **out)
+    print("tta_ensemble_golden.npz:", len(out), "arrays")
+
+
 def synth_prepost(seed, shape):
     """Seeded intensity volume with a heavy tail (so that percentile clipping matters) - tests regenerate it."""
     rs = np.random.RandomState(5000 + seed)
@@ -776,11 +803,13 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
         tta_fixtures()
+    if "tta_ensemble" in which:
+        tta_ensemble_fixtures()
     if "tiling" in which:
         tiling_fixtures()
     if "tiling2d" in which:

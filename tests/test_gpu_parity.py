@@ -476,6 +476,26 @@ def test_sliding_window_tta(K):
 
 
 @pytest.mark.gpu
+def test_tta_ensemble_matches_the_reference_routine(tta_ensemble_golden):
+    """biapy_amd.tta.ensemble_predictions on the device against the outputs of the reference's ``ensemble_predictions``
+    (post_processing.py:1386-1540, generated in the build container): padding, 8 / 16 orientations, undo, reduce, crop - bit-exact."""
+    import numpy as np
+
+    from biapy_amd import tta as T
+    from oracle import tta_oracle as TO
+
+    g = tta_ensemble_golden
+
+    def pred_t(batch):
+        return torch.from_numpy(TO.standin_pred(batch.cpu().numpy())).cuda()
+
+    for name, shape, ndim in TO.ENSEMBLE_CASES:
+        vol = torch.from_numpy(g[f"{name}/img"]).cuda()
+        for mode, level, bs in TO.ENSEMBLE_SETTINGS:
+            got = T.ensemble_predictions(vol, pred_t, ndim, batch_size_value=bs, mode=mode, group=level)
+            np.testing.assert_array_equal(got.cpu().numpy(), g[f"{name}/{mode}/{level}/{bs}"], err_msg=f"{name} {mode} {level} {bs}")
+
+
 def test_tta_on_device(tta_golden):
     """biapy_amd.tta: orient kernel vs the reference's AxisTransform.apply outputs (bit-exact), and the ensembled prediction
     vs the oracle pipeline with a position-dependent stand-in predictor (mean / min / max, 2D with padding, 3D)."""

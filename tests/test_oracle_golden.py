@@ -216,6 +216,20 @@ def test_tta_group_and_transforms_match_reference(tta_golden):
             np.testing.assert_array_equal(TO.apply(TO.apply(arr, p, s), ip, is_), g[f"roundtrip/{name}/{n}"])
 
 
+def test_tta_ensemble_oracle_matches_reference(tta_ensemble_golden):
+    """The whole scalar-field TTA routine - pad to square (reflect / edge), predict every orientation, undo, mean / min / max, crop -
+    against ``ensemble_predictions`` of the reference (post_processing.py:1386-1540) on five shapes x five settings: bit-exact."""
+    from oracle import tta_oracle as TO
+
+    g = tta_ensemble_golden
+    for name, shape, ndim in TO.ENSEMBLE_CASES:
+        img = g[f"{name}/img"]
+        assert img.shape == shape
+        for mode, level, bs in TO.ENSEMBLE_SETTINGS:
+            np.testing.assert_array_equal(TO.ensemble(img, TO.standin_pred, ndim, mode, level, bs), g[f"{name}/{mode}/{level}/{bs}"],
+                                          err_msg=f"{name} {mode} {level} {bs}")
+
+
 @pytest.mark.parametrize("tag", ["2d", "3d"])
 def test_unet_oracle_matches_reference(unet_golden, tag):
     """oracle/unet_oracle.py (plain U-Net, row U) vs the reference's U_Net outputs: logits, BCE loss and gradients."""
