@@ -53,6 +53,13 @@ def tta_golden():
 
 
 @pytest.fixture(scope="session")
+def harness_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "harness_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def tta_ensemble_golden():
     import numpy as np
 

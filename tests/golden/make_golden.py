@@ -279,6 +279,73 @@ def tta_ensemble_fixtures():
     print("tta_ensemble_golden.npz:", len(out), "arrays")
 
 
+def harness_fixtures():
+    """Rows P / B / F / A of SURVEY 8a pinned to the reference harness ITSELF: ``Base_Workflow.process_test_sample`` (per-patch branch,
+    base_workflow.py:1874-2131) is run unbound on a stand-in ``self`` that carries only the attributes the branch reads (a namespace cfg
+    with the TEST / DATA / TRAIN fields, the reference ResUNet with the weights of resunet_golden.npz on the CPU, axes orders); it calls the
+    reference's own crop_3D_data_with_overlap -> predict_batches_in_test -> model_call_func -> apply_model_activations ->
+    merge_3D_data_with_overlap (and ensemble_predictions with TEST.AUGMENTATION).  The run is stopped after the raw prediction has been
+    recorded (``return_prediction``), before the post-processing that is out of scope."""
+    import contextlib
+    import io
+    import types
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    bw = shim.load_full_reference()
+    from biapy.models.resunet import ResUNet
+
+    g = np.load(os.path.join(HERE, "resunet_golden.npz"))
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", k_size=3,
+                        upsample_layer="convtranspose", yx_down=[2] * (len(fm) - 1), z_down=[2] * (len(fm) - 1), output_channels=[1],
+                        output_channel_info=["F"], head_activations=["ce_sigmoid"], isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+
+    def run(vol, ov, pad, bs, aug=False, group="auto", mode="mean"):
+        cfg = NS(TEST=NS(FULL_IMG=False, REUSE_PREDICTIONS=False, VERBOSE=False, REDUCE_MEMORY=False, AUGMENTATION=aug, AUGMENTATION_MODE=mode,
+                         AUGMENTATION_GROUP=group, SAVE_MODEL_RAW_OUTPUT=False),
+                 PROBLEM=NS(NDIM="3D", TYPE="SEMANTIC_SEG", SELF_SUPERVISED=NS(PRETEXT_TASK="")),
+                 DATA=NS(PATCH_SIZE=(32, 32, 32, 1), TEST=NS(OVERLAP=ov, PADDING=pad, MEDIAN_PADDING=False), PREPROCESS=NS(TEST=False),
+                         REFLECT_TO_COMPLETE_SHAPE=False),
+                 TRAIN=NS(BATCH_SIZE=bs), MODEL=NS(SOURCE="biapy"), LOSS=NS(CONTRAST=NS(ENABLE=False)), PATHS=NS(RESULT_DIR=NS(PER_IMAGE="")))
+        s = NS(cfg=cfg, model=model, device=torch.device("cpu"), test_device=torch.device("cpu"), axes_order=(0, 4, 1, 2, 3), axes_order_back=(0, 2, 3, 4, 1),
+               dtype=np.float32, stats={"per_crop": {}, "merge_patches": {}, "patch_by_batch_counter": 0}, apply_activations=True,
+               head_activations=["ce_sigmoid"], model_output_channels=[1], model_output_channel_info=["F"], padding_type="reflect",
+               separated_class_channel=False, return_prediction=True, _predictions=[], dims=3, save_to_disk=False)
+        B = bw.Base_Workflow
+        for name in ("model_call_func", "apply_model_activations", "predict_batches_in_test"):
+            setattr(s, name, types.MethodType(getattr(B, name), s))
+        s.apply_roi_mask = lambda p: p
+        s._log_tta_once = lambda: False
+        s.current_sample = {"X": vol[None].copy(), "Y": None, "X_filename": "v.tif"}
+        try:
+            with torch.no_grad(), contextlib.redirect_stderr(io.StringIO()):
+                B.process_test_sample(s)
+        except AttributeError as e:              # the first attribute of the post-processing part that the stand-in does not carry
+            assert s._predictions, e
+        return s._predictions[0]["data"][0], s.stats["patch_by_batch_counter"]
+
+    out = {}
+    rs = np.random.RandomState(2)
+    vol = rs.randn(48, 40, 56, 1).astype(np.float32)
+    out["vol"] = vol
+    out["plain/params"] = np.array([0.5, 0.25, 0.5, 0, 4, 0, 5], dtype=np.float64)        # overlap zyx, padding zyx, batch
+    out["plain/pred"], n = run(vol, (0.5, 0.25, 0.5), (0, 4, 0), 5)
+    out["plain/batches"] = np.array(n)
+    small = vol[:40, :32, :48].copy()                                                         # TTA: 16 forwards per patch on the CPU
+    out["tta/vol"] = small
+    out["tta/params"] = np.array([0.25, 0.0, 0.5, 0, 0, 0, 3], dtype=np.float64)
+    out["tta/flips_mean"], _ = run(small, (0.25, 0.0, 0.5), (0, 0, 0), 3, aug=True, group="flips", mode="mean")
+    out["tta/full_max"], _ = run(small, (0.25, 0.0, 0.5), (0, 0, 0), 3, aug=True, group="auto", mode="max")
+    np.savez_compressed(os.path.join(HERE, "harness_golden.npz"), **out)
+    print("harness_golden.npz:", {k: v.shape for k, v in out.items()})
+
+
 def synth_prepost(seed, shape):
     """Seeded intensity volume with a heavy tail (so that percentile clipping matters) - tests regenerate it."""
     rs = np.random.RandomState(5000 + seed)
@@ -810,6 +877,8 @@ if __name__ == "__main__":
         tta_fixtures()
     if "tta_ensemble" in which:
         tta_ensemble_fixtures()
+    if "harness" in which:                      # imports the whole reference package: run it on its own (python make_golden.py harness)
+        harness_fixtures()
     if "tiling" in which:
         tiling_fixtures()
     if "tiling2d" in which:

@@ -476,6 +476,34 @@ def test_sliding_window_tta(K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)], ids=["f32", "f16", "bf16"])
+def test_sliding_window_against_the_reference_harness(harness_golden, resunet_golden, dtype, tol):
+    """SlidingWindowPredictor (crop -> forward -> fused sigmoid -> blend on the device, optionally with test-time augmentation) against
+    what the reference's own ``Base_Workflow.process_test_sample`` produced for the same volume, weights and TEST settings
+    (tests/golden/harness_golden.npz: per-patch branch with TRAIN.BATCH_SIZE 5; TTA flips / mean and full / max)."""
+    import numpy as np
+
+    from biapy_amd.resunet import ResUNet
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    h, g = harness_golden, resunet_golden
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", yx_down=[2] * (len(fm) - 1),
+                z_down=[2] * (len(fm) - 1), isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm), compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    q = h["plain/params"]
+    sw = SlidingWindowPredictor(m, (32, 32, 32), tuple(q[:3]), tuple(int(v) for v in q[3:6]), batch_size=int(q[6]))
+    got = sw.predict(torch.from_numpy(h["vol"]).cuda()).cpu().numpy()
+    assert np.abs(got - h["plain/pred"]).max() < tol
+    q = h["tta/params"]
+    for key, mode, level in (("tta/flips_mean", "mean", "flips"), ("tta/full_max", "max", "full")):
+        sw = SlidingWindowPredictor(m, (32, 32, 32), tuple(q[:3]), tuple(int(v) for v in q[3:6]), batch_size=int(q[6]), tta=level, tta_mode=mode)
+        got = sw.predict(torch.from_numpy(h["tta/vol"]).cuda()).cpu().numpy()
+        assert np.abs(got - h[key]).max() < tol, key
+
+
 def test_tta_ensemble_matches_the_reference_routine(tta_ensemble_golden):
     """biapy_amd.tta.ensemble_predictions on the device against the outputs of the reference's ``ensemble_predictions``
     (post_processing.py:1386-1540, generated in the build container): padding, 8 / 16 orientations, undo, reduce, crop - bit-exact."""

@@ -216,6 +216,36 @@ def test_tta_group_and_transforms_match_reference(tta_golden):
             np.testing.assert_array_equal(TO.apply(TO.apply(arr, p, s), ip, is_), g[f"roundtrip/{name}/{n}"])
 
 
+def test_oracle_pipeline_matches_the_reference_harness(harness_golden, resunet_golden):
+    """the oracle's crop -> forward -> sigmoid -> merge (and its TTA) against the output of the reference's
+    own ``Base_Workflow.process_test_sample`` (tests/golden/harness_golden.npz).  fp32 on both sides; the reference forwards the patches
+    in mini-batches of TRAIN.BATCH_SIZE, the oracle all at once, so oneDNN may sum in a different order: 5e-6 absolute."""
+    from oracle import net_oracle, tiling_oracle, tta_oracle
+
+    h, g = harness_golden, resunet_golden
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+    patch = (32, 32, 32)
+
+    def fwd(batch):                                          # (n, z, y, x, c) numpy -> probabilities, same layout
+        with torch.no_grad():
+            return torch.sigmoid(net_oracle.resunet_forward(sd, torch.from_numpy(np.ascontiguousarray(batch)).permute(0, 4, 1, 2, 3), fm)).permute(0, 2, 3, 4, 1).contiguous().numpy()
+
+    q = h["plain/params"]
+    ov, pad = tuple(q[:3]), tuple(int(v) for v in q[3:6])
+    p, _ = tiling_oracle.crop(h["vol"], patch + (1,), ov, pad)
+    assert int(h["plain/batches"]) == -(-p.shape[0] // int(q[6]))
+    got = tiling_oracle.merge(fwd(p), h["vol"].shape, overlap=ov, padding=pad)
+    assert np.abs(got - h["plain/pred"]).max() < 5e-6
+    q = h["tta/params"]
+    ov, pad, bs = tuple(q[:3]), tuple(int(v) for v in q[3:6]), int(q[6])
+    p, _ = tiling_oracle.crop(h["tta/vol"], patch + (1,), ov, pad)
+    for key, mode, level in (("tta/flips_mean", "mean", "flips"), ("tta/full_max", "max", "full")):
+        pr = np.stack([tta_oracle.ensemble(p[k], fwd, 3, mode, level, bs) for k in range(p.shape[0])], 0)
+        got = tiling_oracle.merge(pr, h["tta/vol"].shape, overlap=ov, padding=pad)
+        assert np.abs(got - h[key]).max() < 5e-6, key
+
+
 def test_tta_ensemble_oracle_matches_reference(tta_ensemble_golden):
     """The whole scalar-field TTA routine - pad to square (reflect / edge), predict every orientation, undo, mean / min / max, crop -
     against ``ensemble_predictions`` of the reference (post_processing.py:1386-1540) on five shapes x five settings: bit-exact."""
