@@ -53,6 +53,13 @@ def tta_golden():
 
 
 @pytest.fixture(scope="session")
+def head_acts_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "head_acts_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def harness_golden():
     import numpy as np
 

@@ -346,6 +346,40 @@ def harness_fixtures():
     print("harness_golden.npz:", {k: v.shape for k, v in out.items()})
 
 
+HEAD_ACT_CASES = [  # (name, PROBLEM.TYPE, model_output_channels, model_output_channel_info, head_activations - one per channel)
+    ("sem1", "SEMANTIC_SEG", [1], ["F"], ["ce_sigmoid"]),
+    ("sem3", "SEMANTIC_SEG", [3], ["F"], ["ce_softmax", "ce_softmax", "ce_softmax"]),
+    ("bcd", "INSTANCE_SEG", [1, 1, 1], ["B", "C", "D"], ["ce_sigmoid", "ce_sigmoid", "tanh"]),
+    ("f_db", "INSTANCE_SEG", [1, 3], ["F", "Db"], ["ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"]),
+    ("lin", "INSTANCE_SEG", [1, 1], ["F", "D"], ["linear", "ce_sigmoid"]),
+    ("two_groups", "INSTANCE_SEG", [2, 1, 2], ["Db", "D", "Dc"], ["ce_softmax", "ce_softmax", "tanh", "ce_softmax", "ce_softmax"]),
+]
+
+
+def head_acts_fixtures():
+    """Row A: ``Base_Workflow.apply_model_activations`` (base_workflow.py:1367-1470) run unbound on a stand-in self, inference and training."""
+    import types
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    bw = shim.load_full_reference()
+    out = {}
+    g = torch.Generator().manual_seed(6200)
+    for name, ptype, chans, infos, acts in HEAD_ACT_CASES:
+        C = sum(chans)
+        x = torch.randn(2, C, 4, 5, 6, generator=g) * 3
+        out[f"{name}/logits"] = x.numpy()
+        out[f"{name}/acts"] = np.array(acts)
+        s = NS(apply_activations=True, cfg=NS(PROBLEM=NS(TYPE=ptype, SELF_SUPERVISED=NS(PRETEXT_TASK=""))), model_output_channel_info=infos,
+               model_output_channels=chans, head_activations=acts)
+        f = types.MethodType(bw.Base_Workflow.apply_model_activations, s)
+        out[f"{name}/infer"] = f(x.clone(), training=False).numpy()
+        out[f"{name}/train"] = f(x.clone(), training=True).numpy()
+    np.savez_compressed(os.path.join(HERE, "head_acts_golden.npz"), **out)
+    print("head_acts_golden.npz:", len(out), "arrays")
+
+
 def synth_prepost(seed, shape):
     """Seeded intensity volume with a heavy tail (so that percentile clipping matters) - tests regenerate it."""
     rs = np.random.RandomState(5000 + seed)
@@ -877,6 +911,8 @@ if __name__ == "__main__":
         tta_fixtures()
     if "tta_ensemble" in which:
         tta_ensemble_fixtures()
+    if "head_acts" in which:                    # full import as well: on its own
+        head_acts_fixtures()
     if "harness" in which:                      # imports the whole reference package: run it on its own (python make_golden.py harness)
         harness_fixtures()
     if "tiling" in which:

@@ -476,6 +476,41 @@ def test_sliding_window_tta(K):
 
 
 @pytest.mark.gpu
+def test_head_kernel_activations_match_the_reference_method(head_acts_golden):
+    """Row A on the device: bpx_head_fwd's fused per-channel activations (codes from ResUNet._HEAD_CODES, consecutive softmax channels one
+    group) against ``Base_Workflow.apply_model_activations`` of the reference (tests/golden/head_acts_golden.npz), the logits fed through an
+    identity head."""
+    import numpy as np
+
+    from biapy_amd import _lib as L
+    from biapy_amd.resunet import ResUNet
+
+    g = head_acts_golden
+    done = 0
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        acts = [str(a) for a in g[f"{name}/acts"]]
+        lo = torch.from_numpy(g[f"{name}/logits"])
+        B, C = lo.shape[:2]
+        if C > 4:
+            continue                                         # the head kernel serves up to four output channels
+        sp = tuple(lo.shape[2:])
+        vox = sp[0] * sp[1] * sp[2]
+        feat = torch.zeros((B,) + sp + (16,), dtype=torch.float32, device="cuda")
+        feat[..., :C] = lo.permute(0, 2, 3, 4, 1).cuda()
+        w = torch.zeros(C, 16, device="cuda")
+        w[torch.arange(C), torch.arange(C)] = 1.0
+        b = torch.zeros(C, device="cuda")
+        code = 0
+        for c, a in enumerate(acts):
+            code |= ResUNet._HEAD_CODES[a] << (4 * c)
+        out = torch.empty((B, C) + sp, dtype=torch.float32, device="cuda")
+        L.check(L.lib.bpx_head_fwd(L.F32, vox, B, L.tview(feat), w.data_ptr(), b.data_ptr(), C, code, out.data_ptr(), C * vox, vox, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - g[f"{name}/infer"]).max() < 2e-6, name
+        done += 1
+    assert done == 5
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)], ids=["f32", "f16", "bf16"])
 def test_sliding_window_against_the_reference_harness(harness_golden, resunet_golden, dtype, tol):
     """SlidingWindowPredictor (crop -> forward -> fused sigmoid -> blend on the device, optionally with test-time augmentation) against

@@ -216,6 +216,21 @@ def test_tta_group_and_transforms_match_reference(tta_golden):
             np.testing.assert_array_equal(TO.apply(TO.apply(arr, p, s), ip, is_), g[f"roundtrip/{name}/{n}"])
 
 
+def test_head_activations_oracle_matches_the_reference_method(head_acts_golden):
+    """Row A: oracle.loss_oracle.apply_head_activations against ``Base_Workflow.apply_model_activations`` itself (inference and
+    training, sigmoid / tanh / linear channels, one and two softmax groups, semantic "class" blocks): bit-exact."""
+    from oracle import loss_oracle as LO
+
+    g = head_acts_golden
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) == 6
+    for name in names:
+        acts = [str(a) for a in g[f"{name}/acts"]]
+        x = torch.from_numpy(g[f"{name}/logits"])
+        for training, key in ((False, "infer"), (True, "train")):
+            np.testing.assert_array_equal(LO.apply_head_activations(x, acts, training=training).numpy(), g[f"{name}/{key}"], err_msg=f"{name} {key}")
+
+
 def test_oracle_pipeline_matches_the_reference_harness(harness_golden, resunet_golden):
     """the oracle's crop -> forward -> sigmoid -> merge (and its TTA) against the output of the reference's
     own ``Base_Workflow.process_test_sample`` (tests/golden/harness_golden.npz).  fp32 on both sides; the reference forwards the patches
