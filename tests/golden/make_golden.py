@@ -2,7 +2,9 @@
 
 Runs ONLY in the build container (needs /root/reference, imported through _ref_shim).  The
 fixtures are data: seeded inputs and the reference's outputs.  Re-run with
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 # every fixture that imports single reference modules through the namespace shim
+    python tests/golden/make_golden.py harness         # harness_golden.npz: Base_Workflow.process_test_sample (imports the WHOLE package
+    python tests/golden/make_golden.py head_acts       # head_acts_golden.npz  behind stand-ins for missing third-party modules: run alone)
 The GPU box never runs this file; tests read the committed .npz files.
 """
 import contextlib
