@@ -5,6 +5,7 @@ fixtures are data: seeded inputs and the reference's outputs.  Re-run with
     python tests/golden/make_golden.py                 # every fixture that imports single reference modules through the namespace shim
     python tests/golden/make_golden.py harness         # harness_golden.npz: Base_Workflow.process_test_sample (imports the WHOLE package
     python tests/golden/make_golden.py head_acts       # head_acts_golden.npz  behind stand-ins for missing third-party modules: run alone)
+    python tests/golden/make_golden.py build_model     # build_model_kwargs.json (same)
 The GPU box never runs this file; tests read the committed .npz files.
 """
 import contextlib
@@ -356,6 +357,55 @@ HEAD_ACT_CASES = [  # (name, PROBLEM.TYPE, model_output_channels, model_output_c
     ("lin", "INSTANCE_SEG", [1, 1], ["F", "D"], ["linear", "ce_sigmoid"]),
     ("two_groups", "INSTANCE_SEG", [2, 1, 2], ["Db", "D", "Dc"], ["ce_softmax", "ce_softmax", "tanh", "ce_softmax", "ce_softmax"]),
 ]
+
+
+def build_model_kwargs_fixture():
+    """SURVEY 8b, model registry: the keyword arguments ``biapy.models.build_model`` (models/__init__.py:84-179) passes to the class it finds
+    under the fixed name in ``biapy.models.<architecture>`` - recorded by putting a recorder class under that name, exactly where the
+    maintainer patch of INTEGRATION.md puts the MI355X class - for cfg 2 (resunet), cfg 4 (resunet++) and the super-resolution form."""
+    import importlib
+    import json
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    shim.load_full_reference()
+    import biapy.models as M
+
+    rec = {}
+
+    def recorder(tag):
+        class Rec(torch.nn.Module):
+            def __init__(self, **kw):
+                super().__init__()
+                rec[tag[0]] = kw
+
+        return Rec
+
+    tag = [""]
+    importlib.import_module("biapy.models.resunet").ResUNet = recorder(tag)
+    importlib.import_module("biapy.models.resunet++").ResUNetPlusPlus = recorder(tag)
+
+    def cfg(arch, ptype, patch):
+        return NS(MODEL=NS(ARCHITECTURE=arch, ACTIVATION="ELU", FEATURE_MAPS=[16, 32, 64, 128, 256], DROPOUT_VALUES=[0.0] * 5, NORMALIZATION="in", KERNEL_SIZE=3,
+                           UPSAMPLE_LAYER="convtranspose", YX_DOWN=[2] * 4, Z_DOWN=[2] * 4, ISOTROPY=[True] * 5, LARGER_IO=False, CONV_LAYERS=[2] * 5,
+                           CONV_BLOCK_ORDER="conv_norm_act", UNET_SR_UPSAMPLE_POSITION="pre", SOURCE="biapy"),
+                  PROBLEM=NS(NDIM="3D", TYPE=ptype, IMAGE_TO_IMAGE=NS(SEPARATED_DECODERS_PER_HEAD=False), INSTANCE_SEG=NS(SEPARATED_DECODERS_PER_HEAD=False),
+                             DETECTION=NS(SEPARATED_DECODERS_PER_HEAD=False), SUPER_RESOLUTION=NS(UPSCALING=(2, 2, 2))),
+                  DATA=NS(PATCH_SIZE=patch), LOSS=NS(CONTRAST=NS(ENABLE=False, PROJ_DIM=256)))
+
+    for name, c, oc, oi, ha in (("cfg2_resunet", cfg("resunet", "SEMANTIC_SEG", (128, 128, 128, 1)), [1], ["F"], ["ce_sigmoid"]),
+                                ("cfg4_resunet++", cfg("resunet++", "INSTANCE_SEG", (80, 80, 80, 1)), [3], ["BCD"], ["ce_sigmoid", "ce_sigmoid", "tanh"]),
+                                ("sr_resunet", cfg("resunet", "SUPER_RESOLUTION", (64, 64, 64, 1)), [1], ["F"], ["linear"])):
+        tag[0] = name
+        try:
+            M.build_model(c, oc, oi, ha, torch.device("cpu"))
+        except AttributeError:
+            pass                                     # the stand-in cfg ends where build_model turns to its model summary
+        assert name in rec, name
+    with open(os.path.join(HERE, "build_model_kwargs.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("build_model_kwargs.json:", {k: len(v) for k, v in rec.items()})
 
 
 def head_acts_fixtures():
@@ -913,6 +963,8 @@ if __name__ == "__main__":
         tta_fixtures()
     if "tta_ensemble" in which:
         tta_ensemble_fixtures()
+    if "build_model" in which:                  # full import: on its own
+        build_model_kwargs_fixture()
     if "head_acts" in which:                    # full import as well: on its own
         head_acts_fixtures()
     if "harness" in which:                      # imports the whole reference package: run it on its own (python make_golden.py harness)
