@@ -582,6 +582,11 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 // (v_alignbit_b32 for the odd shift) instead of 6 reads.  Wave w owns the taps [7w, 7w+7) in (dz, dy, dx) order, i.e. 2-3 row
 // segments; the four waves run four compile-time specialisations of the MFMA phase.  LDS reads per K-chunk and workgroup:
 // 64 -> 39 (MC = 1), 72 -> 47 (MC = 2), 80 -> 55 (MC = 3).
+// the two-voxel shift of the window is an odd-aligned register quad (not a legal MFMA operand: the compiler copies it with four v_mov);
+// reading it again from LDS instead measured 1-2.5 % faster on the 128^3 / 64^3 layers (16->16 256 -> 251 us, 96->32 256 -> 250), flat elsewhere
+#ifndef BPX_WGRAD_REREAD
+#define BPX_WGRAD_REREAD 1
+#endif
 template <int W, int MC, int HY, int HX, int VBA, int VBG, int TV, int NKC>
 __device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC]) {
   constexpr int T0 = 7 * W, T1 = (T0 + 7 < 27) ? T0 + 7 : 27;
@@ -619,7 +624,15 @@ __device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const uns
         const int rs = (2 - dx) - smin;   // window shift of this tap in voxels: 0, 1 or 2
         u32x4_t gf;
         if (rs == 0) gf = u32x4_t{w[0], w[1], w[2], w[3]};
-        else if (rs == 2) gf = u32x4_t{w[1], w[2], w[3], w[4]};
+        else if (rs == 2) {
+          if (BPX_WGRAD_REREAD) {
+            u32x2_t s0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 2 * VBG)));
+            u32x2_t s1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 6 * VBG)));
+            gf = u32x4_t{s0[0], s0[1], s1[0], s1[1]};
+          } else {
+            gf = u32x4_t{w[1], w[2], w[3], w[4]};
+          }
+        }
         else gf = u32x4_t{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
                           __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w[4], w[3], 16)};
         const int a = 3 * row + dx - T0;
