@@ -403,8 +403,12 @@ def evaluate(
     loss_names: Optional[List[str]] = None,
     *,
     device=None,
+    eval_dtype: Optional[torch.dtype] = None,
 ) -> Dict[str, float]:
-    """Validation pass (train_engine.py:210-330): eval mode, the losses and whatever ``metric_function`` records averaged over
+    """``eval_dtype``: storage type of the drop-in model for the duration of the pass (restored afterwards), e.g. ``torch.float16`` - the
+    inference mode whose outputs agree with the fp32 reference to Dice 1e-4 - for a model that trains in bfloat16.  None: unchanged.
+
+    Validation pass (train_engine.py:210-330): eval mode, the losses and whatever ``metric_function`` records averaged over
     the loader and over the ranks; steps ``ReduceLROnPlateau`` schedulers with their loss (:323-328).  ``model_call_func`` is
     called with ``is_train=True`` exactly as the reference does (:276).  The losses are accumulated on the device and read back
     once, at the end of the pass."""
@@ -427,6 +431,21 @@ def evaluate(
     for name in loss_names:
         logger.add_meter(name, SmoothedValue())
     model.eval()
+    inner = getattr(model, "module", model)                           # DistributedDataParallel keeps the drop-in under .module
+    keep_dtype = getattr(inner, "compute_dtype", None)
+    switch = eval_dtype is not None and keep_dtype is not None and keep_dtype != eval_dtype
+    if switch:
+        inner.compute_dtype = eval_dtype
+    try:
+        return _evaluate_pass(cfg, model, model_call_func, loss_function, metric_function, prepare_targets, epoch, data_loader, schedulers, sched_name,
+                              loss_names, logger, device)
+    finally:
+        if switch:
+            inner.compute_dtype = keep_dtype
+
+
+def _evaluate_pass(cfg, model, model_call_func, loss_function, metric_function, prepare_targets, epoch, data_loader, schedulers, sched_name, loss_names,
+                   logger, device):
     win = _Window(len(loss_names), device)
     for batch in data_loader:
         images, targets = batch[0], batch[1]

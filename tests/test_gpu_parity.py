@@ -725,6 +725,37 @@ def test_train_one_epoch_on_device_vs_cpu_oracle_loop():
                 assert (p.detach().cpu() - w).abs().max().item() <= 1e-4 * max(1.0, w.abs().max().item()), (mode, k)
 
 
+def test_evaluate_in_the_fp16_inference_mode():
+    """train_engine.evaluate(eval_dtype=torch.float16): the validation pass of a bf16-training model runs in the fp16 inference mode (and the
+    model is handed back in bf16); its loss is closer to the fp32 oracle's than the bf16 pass is."""
+    import torch.nn.functional as F
+
+    from biapy_amd.resunet import ResUNet
+    from biapy_amd.train_engine import evaluate
+    from oracle import net_oracle
+
+    torch.manual_seed(0)
+    fm = [16, 32, 64]
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in", yx_down=[2] * 2, z_down=[2] * 2,
+                isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3, compute_dtype=torch.bfloat16).cuda()
+    g = torch.Generator().manual_seed(4)
+    data = [(torch.randn(2, 32, 32, 32, 1, generator=g), (torch.rand(2, 32, 32, 32, 1, generator=g) > 0.5).float()) for _ in range(3)]
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = sum(F.binary_cross_entropy_with_logits(net_oracle.resunet_forward(sd, x.permute(0, 4, 1, 2, 3), fm), t.permute(0, 4, 1, 2, 3)).item()
+                   for x, t in data) / len(data)
+
+    def loss_fn(out, tgt):
+        return F.binary_cross_entropy_with_logits(out, tgt)
+
+    cfg = {}
+    l16 = evaluate(cfg, m, None, loss_fn, None, None, 0, data, eval_dtype=torch.float16)["loss"]
+    assert m.compute_dtype == torch.bfloat16
+    lbf = evaluate(cfg, m, None, loss_fn, None, None, 0, data)["loss"]
+    assert abs(l16 - want) < 2e-5, (l16, want)
+    assert abs(l16 - want) < abs(lbf - want) + 1e-7, (l16, lbf, want)
+
+
 def test_graphed_inference_follows_weight_updates():
     """GraphedInference must not freeze the packed weights at capture time (its warm-up fills the inference cache): after
     an in-place parameter update the replay equals a fresh eager forward."""
