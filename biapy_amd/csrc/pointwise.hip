@@ -315,28 +315,34 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 }
 
 constexpr int PW_MS = 2;  // 4 waves x 2 x 16 = 128 voxels per workgroup
+#ifndef BPX_PW_MS_CT
+#define BPX_PW_MS_CT 2
+#endif
+constexpr int PW_MS_CT = BPX_PW_MS_CT;   // the same for the transposed-conv forward.  Measured (32 -> 32 channels, 64^3 -> 128^3, planar output):
+                                         // 1 (78 VGPRs, 5 waves / SIMD) 266 us, 2 266 us, 4 (162 VGPRs) 271 us - neither tile size nor residency binds
 
 inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 : (ncols_per_group % 48 == 0) ? 3 : (ncols_per_group % 32 == 0) ? 2 : 1; }
 
 template <typename T, int MODE>
 int launch_pw(PwParams& p, int ns, hipStream_t s) {
-  if (p.vps >= (1ll << 31) - 64 * PW_MS) { bpx_set_error("pointwise kernels: more than 2^31 voxels per sample"); return 1; }
-  p.mblocks = (int)cdiv64(p.vps, 64 * PW_MS);
+  constexpr int MSK = (MODE == PW_CONVT) ? PW_MS_CT : PW_MS;
+  if (p.vps >= (1ll << 31) - 64 * MSK) { bpx_set_error("pointwise kernels: more than 2^31 voxels per sample"); return 1; }
+  p.mblocks = (int)cdiv64(p.vps, 64 * MSK);
   int nbk = p.Ncols / (16 * ns);
   dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
   const bool planar = (MODE == PW_CONV1 && p.coef != nullptr && p.t_cs != 16) || (MODE == PW_CONVT && p.y_cs != 16);
   if (MODE != PW_CONVTD && planar) {
     constexpr bool PL = MODE != PW_CONVTD;    // no planar instances of the transposed-conv dgrad
-    if (ns == 4) pw_kernel<T, PW_MS, 4, MODE, PL><<<grid, 256, 0, s>>>(p);
-    else if (ns == 3) pw_kernel<T, PW_MS, 3, MODE, PL><<<grid, 256, 0, s>>>(p);
-    else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE, PL><<<grid, 256, 0, s>>>(p);
-    else pw_kernel<T, PW_MS, 1, MODE, PL><<<grid, 256, 0, s>>>(p);
+    if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL><<<grid, 256, 0, s>>>(p);
+    else if (ns == 3) pw_kernel<T, MSK, 3, MODE, PL><<<grid, 256, 0, s>>>(p);
+    else if (ns == 2) pw_kernel<T, MSK, 2, MODE, PL><<<grid, 256, 0, s>>>(p);
+    else pw_kernel<T, MSK, 1, MODE, PL><<<grid, 256, 0, s>>>(p);
     return 0;
   }
-  if (ns == 4) pw_kernel<T, PW_MS, 4, MODE, false><<<grid, 256, 0, s>>>(p);
-  else if (ns == 3) pw_kernel<T, PW_MS, 3, MODE, false><<<grid, 256, 0, s>>>(p);
-  else if (ns == 2) pw_kernel<T, PW_MS, 2, MODE, false><<<grid, 256, 0, s>>>(p);
-  else pw_kernel<T, PW_MS, 1, MODE, false><<<grid, 256, 0, s>>>(p);
+  if (ns == 4) pw_kernel<T, MSK, 4, MODE, false><<<grid, 256, 0, s>>>(p);
+  else if (ns == 3) pw_kernel<T, MSK, 3, MODE, false><<<grid, 256, 0, s>>>(p);
+  else if (ns == 2) pw_kernel<T, MSK, 2, MODE, false><<<grid, 256, 0, s>>>(p);
+  else pw_kernel<T, MSK, 1, MODE, false><<<grid, 256, 0, s>>>(p);
   return 0;
 }
 
@@ -350,7 +356,7 @@ int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
 
 }  // namespace
 
-extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS) * 4 * (sz == 1 ? 1 : 2); }
+extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS_CT) * 4 * (sz == 1 ? 1 : 2); }
 
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                         bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y, bpx_tensor y2,
