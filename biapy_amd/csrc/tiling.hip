@@ -219,6 +219,45 @@ __global__ void __launch_bounds__(256) scatter3d_tables_kernel(const E* __restri
   }
 }
 
+// 16-byte forms of the two table kernels (channels-last tensors whose voxel is a whole number of 16-byte vectors: the space-to-batch
+// transport of the dilated convolutions moves 16 / 32-channel bf16 voxels).  One thread moves one vector; the flat index is decomposed
+// with 32-bit multiply-shift divisions.  ASPP of cfg 4 (80^3 x 32 channels, rate 18): 87 -> see profiles/r02_breakdown_resunetpp_events.txt
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) tables3d_vec_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int Y, int X, int cv,
+                                                           const int* __restrict__ tables, int Pz, int Py, int Px, uint32_t total, FastDiv dcv,
+                                                           FastDiv dPx, FastDiv dPy, FastDiv dPz) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= total) return;
+  uint32_t vox, c, r1, x, r2, y, b, z;
+  dcv.divmod(t, vox, c);
+  dPx.divmod(vox, r1, x);
+  dPy.divmod(r1, r2, y);
+  dPz.divmod(r2, b, z);
+  const int* tt = tables + (size_t)b * (size_t)(Pz + Py + Px);
+  const int sz = tt[z], sy = tt[Pz + y], sx = tt[Pz + Py + x];
+  const bool in = (sz | sy | sx) >= 0;
+  const size_t vi = (((size_t)sz * Y + sy) * X + sx) * (size_t)cv + c;      // vector index inside the volume (used when in)
+  if (SCATTER) {
+    if (in) dst[vi] = src[t];
+  } else {
+    dst[t] = in ? src[vi] : u32x4_t{0u, 0u, 0u, 0u};
+  }
+}
+
+static bool tables_vec_ok(const void* a, const void* b, int elem_size, int C, int64_t total_elems) {
+  return ((int64_t)C * elem_size) % 16 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0 && total_elems * elem_size / 16 < (1ll << 31) && !g_tiling_scalar;
+}
+
+template <bool SCATTER>
+static void launch_tables_vec(const void* src, void* dst, int elem_size, int Y, int X, int C, const int* tables_d, int Pz, int Py, int Px,
+                              int64_t total_elems, hipStream_t s) {
+  const int cv = C * elem_size / 16;
+  const uint32_t total = (uint32_t)(total_elems * elem_size / 16);
+  tables3d_vec_kernel<SCATTER><<<(unsigned)cdiv64(total, 256), 256, 0, s>>>((const u32x4_t*)src, (u32x4_t*)dst, Y, X, cv, tables_d, Pz, Py, Px, total,
+                                                                              make_fastdiv((uint32_t)cv), make_fastdiv((uint32_t)Px),
+                                                                              make_fastdiv((uint32_t)Py), make_fastdiv((uint32_t)Pz));
+}
+
 // regions: per patch {src z0,y0,x0 (first voxel kept, i.e. the padding stripped), dst z0,y0,x0, length z,y,x}
 __global__ void __launch_bounds__(256) scatter3d_regions_kernel(const float* __restrict__ pred, int Py, int Px, int C, int64_t patch_elems,
                                                                 const int* __restrict__ regions, float* __restrict__ out, int Y, int X) {
@@ -245,8 +284,13 @@ extern "C" int bpx_gather3d_tables(const void* vol_d, int elem_size, int Z, int 
   BPX_CHECK(Z > 0 && Y > 0 && X > 0 && C > 0 && n >= 0 && Pz > 0 && Py > 0 && Px > 0, "%s: bad extents", fn);
   const int64_t total = (int64_t)n * Pz * Py * Px * C;
   if (total == 0) return 0;
-  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   hipStream_t s = (hipStream_t)stream;
+  if (tables_vec_ok(vol_d, out_d, elem_size, C, total)) {
+    launch_tables_vec<false>(vol_d, out_d, elem_size, Y, X, C, tables_d, Pz, Py, Px, total, s);
+    BPX_LAUNCH_CHECK(fn);
+    return 0;
+  }
+  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   if (elem_size == 4) gather3d_tables_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint32_t*)out_d, total);
   else if (elem_size == 2) gather3d_tables_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint16_t*)out_d, total);
   else gather3d_tables_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)vol_d, Y, X, C, tables_d, Pz, Py, Px, (uint8_t*)out_d, total);
@@ -262,8 +306,13 @@ extern "C" int bpx_scatter3d_tables(const void* in_d, int elem_size, const int* 
   BPX_CHECK(Z > 0 && Y > 0 && X > 0 && C > 0 && n >= 0 && Pz > 0 && Py > 0 && Px > 0, "%s: bad extents", fn);
   const int64_t total = (int64_t)n * Pz * Py * Px * C;
   if (total == 0) return 0;
-  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   hipStream_t s = (hipStream_t)stream;
+  if (tables_vec_ok(in_d, vol_d, elem_size, C, total)) {
+    launch_tables_vec<true>(in_d, vol_d, elem_size, Y, X, C, tables_d, Pz, Py, Px, total, s);
+    BPX_LAUNCH_CHECK(fn);
+    return 0;
+  }
+  const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 16);
   if (elem_size == 4) scatter3d_tables_kernel<uint32_t><<<blocks, 256, 0, s>>>((const uint32_t*)in_d, tables_d, Pz, Py, Px, (uint32_t*)vol_d, Y, X, C, total);
   else if (elem_size == 2) scatter3d_tables_kernel<uint16_t><<<blocks, 256, 0, s>>>((const uint16_t*)in_d, tables_d, Pz, Py, Px, (uint16_t*)vol_d, Y, X, C, total);
   else scatter3d_tables_kernel<uint8_t><<<blocks, 256, 0, s>>>((const uint8_t*)in_d, tables_d, Pz, Py, Px, (uint8_t*)vol_d, Y, X, C, total);

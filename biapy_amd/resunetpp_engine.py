@@ -355,14 +355,15 @@ class ResUNetPPEngine(ResUNetEngine):
                 L.check(lib.bpx_norm_act_fwd(self.dt, B, x.vox, r.view(), rec.data_ptr(), 0, L.tview(cat.buf, j * Cout, Cout), self._st))
                 branches.append((0, wc, None, raw, r, rec, wk, bk, gk, bek))
                 continue
-            tables = self._c(("lattice", x.S, d), lambda: torch.from_numpy(dilation.lattice_tables(x.S, d)).to(self._dev))
-            xs = dilation.space_to_batch(x.buf, d, tables)                                   # (B * d^3, nz, ny, nx, Cin)
-            q = d ** 3
+            # the d^3 sub-lattices of a sample side by side in one volume with zero separator planes (dilation.packed_tables): one ordinary
+            # convolution per branch on full tiles instead of B * d^3 convolutions of n^3 <= 14^3 voxels
+            tables = self._c(("packed", x.S, d), lambda: torch.from_numpy(dilation.packed_tables(x.S, d)).to(self._dev))
+            xs = dilation.space_to_packed(x.buf, d, tables)                                  # (B, pz, py, px, Cin)
             xsv = _V(xs, tuple(xs.shape[1:4]))
-            self._G, keepG = None, self._G                                                   # the sub-lattice conv is differentiated by hand below
-            ys, _, _ = self._conv3(xsv, wk, bk, Cout, None, want_stats=False, batch=B * q)
+            self._G, keepG = None, self._G                                                   # the packed conv is differentiated by hand below
+            ys, _, _ = self._conv3(xsv, wk, bk, Cout, None, want_stats=False, batch=B)
             self._G = keepG
-            raw = _V(dilation.batch_to_space(ys.buf, d, x.S, tables), x.S)
+            raw = _V(dilation.packed_to_space(ys.buf, d, x.S, tables), x.S)
             r = self._new(x.S, Cout)
             L.check(lib.bpx_norm_act_fwd(self.dt, B, x.vox, raw.view(), self._ident_rec(Cout).data_ptr(), self.relu, r.view(), self._st))
             rec = self._stats_rec(r, P[gk], P[bek])
@@ -391,14 +392,14 @@ class ResUNetPPEngine(ResUNetEngine):
                         self._keep += [draw, dslice]
                         self._accum(x, g)
                         continue
-                    dys = dilation.space_to_batch(draw, d, tables)
+                    dys = dilation.space_to_packed(draw, d, tables)                          # zero on the separators: they add nothing to dW, db
                     nb = dys.shape[0]
                     self._wgrad(nb, xsv.S, xsv.view(), None, 0, L.tview(dys), 3, G[wk], G[bk], self._st, self._dev)
                     wt = self._pack(P[wk], L.PK_K3_T, x.C, Cout, False)
                     gs = torch.empty(tuple(xsv.buf.shape), dtype=self.dtype, device=self._dev)
                     L.check(lib.bpx_conv3d_dgrad(self.dt, nb, xsv.S[0], xsv.S[1], xsv.S[2], L.tview(dys), wt.data_ptr(), L.NULL_T, None, 0, L.tview(gs), None, self._st))
                     self._keep += [draw, dys, gs]
-                    self._accum(x, dilation.batch_to_space(gs, d, x.S, tables))
+                    self._accum(x, dilation.packed_to_space(gs, d, x.S, tables))
                 self._keep.append(cat.grad)
             self._tape.append(bwd)                                                           # runs AFTER the 1x1 conv's closure (pushed next)
         ow, ob = f"{prefix}.output.weight", f"{prefix}.output.bias"

@@ -1113,3 +1113,23 @@ def test_dilated_conv_through_space_to_batch(K, d, dim):
                                  L.stream_ptr()))
     got = DL.batch_to_space(ys, d, dim).cpu()
     assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # the packed form (what the ResUNet++ engine runs): one conv of N samples of extent d*(n+1)-1, same result
+    xp = DL.space_to_packed(xd, d)
+    assert xp.shape == (N,) + DL.packed_shape(dim, d) + (Cin,)
+    assert torch.equal(DL.packed_to_space(xp, d, dim), xd)
+    assert int((xp != 0).sum()) == int((xd != 0).sum())                        # the separators and the overhang are exact zeros
+    pz, py, px = xp.shape[1:4]
+    yp = torch.empty((N, pz, py, px, Cout), dtype=torch.float32, device="cuda")
+    L.check(L.lib.bpx_conv3d_fwd(L.F32, N, pz, py, px, L.tview(xp), None, 0, wp.data_ptr(), bd.data_ptr(), L.NULL_T, None, None, L.tview(yp), None,
+                                 L.stream_ptr()))
+    got = DL.packed_to_space(yp, d, dim).cpu()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # bf16 tensors take the 16-byte table kernels (32 channels x 2 bytes = 4 vectors per voxel); f32 above did too (8 vectors)
+    xb = xd.to(torch.bfloat16)
+    assert torch.equal(DL.packed_to_space(DL.space_to_packed(xb, d), d, dim), xb)
+    L.check(L.lib.bpx_debug_set_tiling_scalar(1))
+    try:
+        ref_p = DL.space_to_packed(xb, d)
+    finally:
+        L.check(L.lib.bpx_debug_set_tiling_scalar(0))
+    assert torch.equal(DL.space_to_packed(xb, d), ref_p)                        # vector kernel == element-per-thread kernel

@@ -359,6 +359,49 @@ def test_dilated_conv_is_conv_on_sublattices(dim, d):
     assert torch.allclose(out, ref, atol=1e-5)
 
 
+@pytest.mark.parametrize("dim,d", [((10, 13, 16), 3), ((8, 8, 8), 6), ((5, 20, 7), 2), ((10, 10, 10), 18)])
+def test_dilated_conv_is_one_conv_of_the_packed_volume(dim, d):
+    """biapy_amd.dilation.packed_tables (the layout the ResUNet++ engine uses): the d^3 sub-lattices side by side with one zero plane
+    between them; ONE 'same' 3x3x3 convolution of that volume, read back through the same tables, is torch's dilated convolution,
+    and so are its input and weight gradients (zero separators contribute nothing)."""
+    import torch.nn.functional as F
+
+    from biapy_amd.dilation import lattice_shape, packed_shape, packed_tables
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 3, *dim, generator=g, requires_grad=True)
+    w = torch.randn(4, 3, 3, 3, 3, generator=g, requires_grad=True)
+    gy = torch.randn(2, 4, *dim, generator=g)
+    ref = F.conv3d(x, w, padding=d, dilation=d)
+    gx_ref, gw_ref = torch.autograd.grad(ref, (x, w), gy)
+    T = packed_tables(dim, d)
+    P = packed_shape(dim, d)
+    assert T.shape == (1, sum(P)) and P == tuple(d * (n + 1) - 1 for n in lattice_shape(dim, d))
+    tz, ty, tx = T[0, :P[0]], T[0, P[0]:P[0] + P[1]], T[0, P[0] + P[1]:]
+    for t, lim in zip((tz, ty, tx), dim):
+        assert sorted(t[t >= 0].tolist()) == list(range(lim))                  # every source index exactly once
+    kz, ky, kx = (torch.from_numpy(np.where(t >= 0)[0]) for t in (tz, ty, tx))
+    sz, sy, sx = (torch.from_numpy(t[t >= 0].astype(np.int64)) for t in (tz, ty, tx))
+
+    def pack(v):
+        out = torch.zeros(v.shape[:2] + P, dtype=v.dtype)
+        out[:, :, kz[:, None, None], ky[None, :, None], kx[None, None, :]] = v[:, :, sz[:, None, None], sy[None, :, None], sx[None, None, :]]
+        return out
+
+    def unpack(v):
+        out = torch.zeros(v.shape[:2] + tuple(dim), dtype=v.dtype)
+        out[:, :, sz[:, None, None], sy[None, :, None], sx[None, None, :]] = v[:, :, kz[:, None, None], ky[None, :, None], kx[None, None, :]]
+        return out
+
+    xp = pack(x.detach()).requires_grad_(True)
+    wp = w.detach().clone().requires_grad_(True)
+    yp = F.conv3d(xp, wp, padding=1)
+    assert torch.allclose(unpack(yp.detach()), ref.detach(), atol=1e-5)
+    gxp, gwp = torch.autograd.grad(yp, (xp, wp), pack(gy))
+    assert torch.allclose(unpack(gxp), gx_ref, atol=1e-5)
+    assert torch.allclose(gwp, gw_ref, atol=1e-4)
+
+
 def test_chunk_planar_buffer_views():
     """_lib.Planar (bpx_tensor.cs != 0): the (C/16, B, D, H, W, 16) planes round-trip a dense NDHWC tensor, and channel slices are
     whole chunks addressed by (plane pointer, voxel pitch 16, plane stride) - what the kernels read as v*ld + (c/16)*cs + c%16."""
