@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--arch", choices=["resunet", "resunetpp"], default="resunet",
                     help="resunetpp = cfg 4 (3D instance segmentation, B/C/D channels, ResUNet++ fm 16-32-64-128-256, 80^3 patches): its own JSON "
                          "line, train mode only - a second-tier configuration, not the headline")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the ResUNet++ (cfg 4) sub-record of the single-GPU line")
     ap.add_argument("--sliding-timeout", type=float, default=240.0,
                     help="N > 1: seconds after which a hung sliding-window section is abandoned (the line is printed without it)")
     a = ap.parse_args()
@@ -572,9 +573,23 @@ def main():
             sliding_rec = dict(error=f"{type(e).__name__}: {e}")
         done.set()
 
+    # cfg 4 (ResUNet++ 80^3, B/C/D loss) as a sub-record of the single-GPU line: the second model family the path covers
+    cfg4_rec = None
+    if a.mode == "all" and world == 1 and not multi and not a.no_cfg4:
+        try:
+            del model
+            torch.cuda.empty_cache()
+            cfg4_rec = run_resunetpp(a, dev, rank, world, multi, dtype, as_record=True)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 - the headline line must survive
+            cfg4_rec = dict(error=f"{type(e).__name__}: {e}")
+
     if rank == 0 and line is not None:
         line["infer"] = infer_rec
         line["sliding"] = sliding_rec
+        if cfg4_rec is not None:
+            line["cfg4_resunetpp"] = cfg4_rec
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.patch, quick=a.quick_cpu_baseline)
         print(json.dumps(line))
@@ -582,7 +597,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_resunetpp(a, dev, rank, world, multi, dtype):
+def run_resunetpp(a, dev, rank, world, multi, dtype, as_record=False):
     """cfg 4: ResUNet++ (fm 16-32-64-128-256), 80^3 x 1 patches, three output channels (B, C: BCE on logits; D: MSE through tanh),
     batch --batch per GPU, one step = fwd + loss + bwd + AdamW; data parallel = DistributedDataParallel over RCCL (the module is an
     ordinary nn.Module with one autograd.Function)."""
@@ -641,14 +656,17 @@ def run_resunetpp(a, dev, rank, world, multi, dtype):
     elapsed = _timed(step, a.steps, world, dev)
     nparams = sum(p.numel() for p in model.parameters())
     value = world * a.batch * P ** 3 * a.steps / elapsed
+    rec = dict(
+        metric="voxels/sec 3D ResUNet++ %d^3 patch (train: fwd + B/C/D loss + bwd + AdamW)" % P, value=value, unit="voxels/s", n_gpus=world,
+        steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype,
+        data="synthetic", launch=launch,
+        config=dict(workload="cfg4: 3D ResUNet++ fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, 3 channels (B,C,D), batch %d/GPU, train" % (P, a.batch),
+                    global_batch=world * a.batch, patch=P, parameters=nparams, parallelism="dp%d" % world, mode="train"),
+        mfma_frac_end_to_end=round(value * 1044917 * 3 / (world * MFMA_PEAK_BF16), 5))
+    if as_record:                                           # the sub-record of the default line (main): the caller prints
+        return rec
     if rank == 0:
-        print(json.dumps(dict(
-            metric="voxels/sec 3D ResUNet++ %d^3 patch (train: fwd + B/C/D loss + bwd + AdamW)" % P, value=value, unit="voxels/s", n_gpus=world,
-            steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps, higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype,
-            data="synthetic", launch=launch,
-            config=dict(workload="cfg4: 3D ResUNet++ fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, 3 channels (B,C,D), batch %d/GPU, train" % (P, a.batch),
-                        global_batch=world * a.batch, patch=P, parameters=nparams, parallelism="dp%d" % world, mode="train"),
-            mfma_frac_end_to_end=round(value * 1044917 * 3 / (world * MFMA_PEAK_BF16), 5))))
+        print(json.dumps(rec))
     if multi:
         dist.destroy_process_group()
 
