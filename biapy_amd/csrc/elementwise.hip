@@ -256,8 +256,11 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict
     ka[e] = k.a; kb[e] = k.b; kc[e] = k.c0;
   }
   const size_t base = (size_t)n * vps;
-  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    size_t vox = base + (size_t)(i / G);
+  // the launchers make gridDim.x * 256 a multiple of G (na_blocks): a thread keeps its channel group and its voxel advances by a constant -
+  // no 64-bit division per element
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     u32x4_t gv = *reinterpret_cast<const u32x4_t*>(g + vox * g_ld + cg * KPL);
     u32x4_t tv = *reinterpret_cast<const u32x4_t*>(t + vox * t_ld + cg * KPL);
     float gf[KPL], tf[KPL], of[KPL];
@@ -302,8 +305,11 @@ __global__ void __launch_bounds__(256) norm_act_fwd_kernel(const T* __restrict__
     sc[e] = r.scale; sh[e] = r.shift;
   }
   const size_t base = (size_t)n * vps;
-  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    size_t vox = base + (size_t)(i / G);
+  // the launchers make gridDim.x * 256 a multiple of G (na_blocks): a thread keeps its channel group and its voxel advances by a constant -
+  // no 64-bit division per element
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     float f[KPL];
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
 #pragma unroll
@@ -336,8 +342,11 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__
     s1[e] = s2[e] = 0.f;
   }
   const size_t base = (size_t)n * vps;
-  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    size_t vox = base + (size_t)(i / G);
+  // the launchers make gridDim.x * 256 a multiple of G (na_blocks): a thread keeps its channel group and its voxel advances by a constant -
+  // no 64-bit division per element
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     float d[KPL], f[KPL], o[KPL];
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + vox * dy_ld + cg * KPL), d);
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
@@ -398,8 +407,11 @@ __global__ void __launch_bounds__(256) channel_affine_kernel(const T* __restrict
     ko[e] = off ? off[(size_t)n * C + cg * KPL + e] : 0.f;
   }
   const size_t base = (size_t)n * vps;
-  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const size_t vox = base + (size_t)(i / G);
+  // the launchers make gridDim.x * 256 a multiple of G (na_blocks): a thread keeps its channel group and its voxel advances by a constant -
+  // no 64-bit division per element
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     float hf[KPL], o[KPL];
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(h + vox * h_ld + cg * KPL), hf);
 #pragma unroll
@@ -428,8 +440,11 @@ __global__ void __launch_bounds__(256) dot_stats_kernel(const T* __restrict__ a,
 #pragma unroll
   for (int e = 0; e < KPL; ++e) s[e] = 0.f;
   const size_t base = (size_t)n * vps;
-  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const size_t vox = base + (size_t)(i / G);
+  // the launchers make gridDim.x * 256 a multiple of G (na_blocks): a thread keeps its channel group and its voxel advances by a constant -
+  // no 64-bit division per element
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     float af[KPL], bf[KPL];
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(a + vox * a_ld + cg * KPL), af);
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(b + vox * b_ld + cg * KPL), bf);

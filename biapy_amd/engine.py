@@ -261,11 +261,13 @@ class ResUNetEngine:
             block(f"up_paths.0.{j}.conv_block", False, cup + fm[i], fm[i])
         return plan
 
-    def _prepack(self, P: Dict[str, torch.Tensor], train: bool, dev) -> None:
+    def _prepack(self, P: Dict[str, torch.Tensor], train: bool, dev, plan=None) -> None:
         """Pack every MFMA weight operand of the step with ONE launch into one buffer (the weights change after every
-        optimizer step, so training re-packs ~60 small tensors per step)."""
+        optimizer step, so training re-packs ~60 small tensors per step).  plan: the (name, mode, Cin, Cout) list to use instead of
+        this engine's own (the ResUNet++ engine records its list on the first step)."""
         self._prepacked = {}
-        plan = self._pack_plan(train)
+        if plan is None:
+            plan = self._pack_plan(train)
         if any(P[name].dtype != torch.float32 or not P[name].is_contiguous() for name, _, _, _ in plan):
             return  # _pack() falls back to per-tensor packing (with the conversion copy)
         sizes = [int(lib.bpx_packed_weight_elems(mode, cin, cout, self.dt)) for _, mode, cin, cout in plan]

@@ -103,6 +103,9 @@ class ResUNetPPEngine(ResUNetEngine):
         self.pp = cfg
         self.relu = L.ACT["relu"]
         self._const: Dict = {}
+        self._pack_plans: Dict = {}                                # {training?: {(parameter name, pack mode, Cin, Cout): True}} - see forward
+        self._pack_names: Dict = {}
+        self._pack_seen: Dict = {}
 
     # ------------------------------------------------------------------------------------------------------------------
     # helpers
@@ -186,6 +189,12 @@ class ResUNetPPEngine(ResUNetEngine):
     # ------------------------------------------------------------------------------------------------------------------
     # tape operations: forward now, the backward closure goes onto self._tape (when training)
     # ------------------------------------------------------------------------------------------------------------------
+    def _pack(self, w: torch.Tensor, mode: int, cin: int, cout: int, cache: bool) -> torch.Tensor:
+        name = self._pack_names.get(w.data_ptr())
+        if name is not None and (w.data_ptr(), mode) not in self._prepacked:
+            self._pack_seen[(name, mode, cin, cout)] = True          # a parameter (not a per-step temporary): part of the next step's batch
+        return super()._pack(w, mode, cin, cout, cache)
+
     def _conv3(self, x: _V, wk: str, bk: str, Cout: int, nrm: Optional[_Nrm] = None, want_stats: bool = True, batch: Optional[int] = None):
         """y = conv3x3x3(act(IN(x))) with the normalisation + activation as the conv's prologue (nrm given), or conv3x3x3(x)."""
         P, G, B = self._P, self._G, (self._B if batch is None else batch)
@@ -503,7 +512,13 @@ class ResUNetPPEngine(ResUNetEngine):
         if D0 % zdiv or H0 % (2 ** depth) or W0 % (2 ** depth):
             raise ValueError(f"patch {D0, H0, W0} must be divisible by {(zdiv, 2 ** depth, 2 ** depth)} (DATA.PATCH_SIZE rule, check_configuration.py:3156-3202)")
         self._B, self._dev, self._st, self._P = B, x.device, L.stream_ptr(), P
+        # weight operands: the first step of a kind (inference / training) packs them one by one and records which parameters were
+        # packed how; later steps pack the whole list with ONE launch up front (78 launches -> 1 per training step)
+        self._pack_names = {v.data_ptr(): k for k, v in P.items()}
+        self._pack_seen = self._pack_plans.setdefault(bool(save), {})
         self._prepacked = {}
+        if self._pack_seen and not cache_weights:
+            self._prepack(P, save, x.device, plan=list(self._pack_seen))
         self._tape: List[Callable[[], None]] = []
         self._late: List[Callable[[], None]] = []
         self._keep = []
