@@ -618,7 +618,10 @@ def run_resunetpp(a, dev, rank, world, multi, dtype, as_record=False):
     want_graph = a.graph != "off" and a.dp != "ddp"
     use_ddp = multi and not want_graph
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True, bucket_cap_mb=64) if use_ddp else model
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=want_graph)
+    try:                                                     # the fused multi-tensor AdamW, as on the ResUNet line (the unfused capturable one
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True, capturable=want_graph)   # issues two strided divisions per parameter tensor)
+    except Exception:  # noqa: BLE001
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=want_graph)
 
     def step():
         opt.zero_grad(set_to_none=True)
