@@ -91,6 +91,8 @@ _SIGS = {
     "bpx_norm_bwd_apply": ([_i, _i, _i64, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
     "bpx_channel_affine": ([_i, _i, _i64, Tensor, Tensor, _vp, _vp, Tensor, _vp], _i),
     "bpx_dot_stats": ([_i, _i, _i64, Tensor, Tensor, _vp, _vp], _i),
+    "bpx_gate_mlp_fwd": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
+    "bpx_gate_mlp_bwd": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_norm_act_tiles": ([_i, _i64, _i], _i),
     "bpx_norm_act_fwd": ([_i, _i, _i64, Tensor, _vp, _i, Tensor, _vp], _i),
     "bpx_norm_act_bwd": ([_i, _i, _i64, Tensor, Tensor, _vp, _i, Tensor, Tensor, _vp, _vp], _i),

@@ -1514,6 +1514,145 @@ extern "C" int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The gate of channel attention / squeeze-excite on the pooled (N, C) vector (biapy/models/rcan.py ChannelAttention,
+// blocks.py:1119-1191 SqExBlock): a few hundred FLOPs that were ~8 PyTorch launches each way - one block per sample forward,
+// one block for the whole batch backward (the sums over samples run in a fixed order: deterministic).
+//   m[c] = sum_tiles part[n][t][0][c] / voxels;  u1 = W1 m + b1;  a1 = act(u1);  s = sigmoid(W2 a1 + b2)
+// saved[n] = { m[C], u1[R], a1[R] }.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gate_act(float u, int act) {
+  return act == BPX_ACT_RELU ? fmaxf(u, 0.f) : act == BPX_ACT_SILU ? u / (1.f + expf(-u)) : act == BPX_ACT_ELU ? (u > 0.f ? u : expm1f(u)) : u;
+}
+__device__ __forceinline__ float gate_act_bwd(float u, int act) {
+  if (act == BPX_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == BPX_ACT_SILU) { const float sg = 1.f / (1.f + expf(-u)); return sg * (1.f + u * (1.f - sg)); }
+  if (act == BPX_ACT_ELU) return u > 0.f ? 1.f : expf(u);
+  return 1.f;
+}
+
+// sum over the tiles of one (sample, channel) column, 256 / C lanes per channel, combined through LDS in lane order
+__device__ __forceinline__ float gate_column_sum(const float* col, int tiles, size_t tstride, int C, double* red /* [256] */) {
+  const int c = threadIdx.x % C, l = threadIdx.x / C, lanes = 256 / C;
+  double a = 0.0;
+  if (l < lanes)
+    for (int t = l; t < tiles; t += lanes) a += (double)col[(size_t)t * tstride + c];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  double tot = 0.0;
+  if ((int)threadIdx.x < C)
+    for (int q = 0; q < lanes; ++q) tot += red[q * C + threadIdx.x];
+  __syncthreads();
+  return (float)tot;                                      // valid in threads < C
+}
+
+__global__ void __launch_bounds__(256) gate_mlp_fwd_kernel(const float* __restrict__ part, int tiles, int C, float inv_vox, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int R,
+                                                           int act, float* __restrict__ s_out, float* __restrict__ saved) {
+  __shared__ double red[256];
+  __shared__ float m[256], a1[64];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const float tot = gate_column_sum(part + (size_t)n * tiles * 2 * C, tiles, (size_t)2 * C, C, red);
+  float* sv = saved + (size_t)n * (C + 2 * R);
+  if (t < C) { m[t] = tot * inv_vox; sv[t] = m[t]; }
+  __syncthreads();
+  if (t < R) {
+    float u = b1 ? b1[t] : 0.f;
+    for (int c = 0; c < C; ++c) u += w1[(size_t)t * C + c] * m[c];
+    const float a = gate_act(u, act);
+    a1[t] = a;
+    sv[C + t] = u; sv[C + R + t] = a;
+  }
+  __syncthreads();
+  if (t < C) {
+    float u = b2 ? b2[t] : 0.f;
+    for (int r = 0; r < R; ++r) u += w2[(size_t)t * R + r] * a1[r];
+    s_out[(size_t)n * C + t] = 1.f / (1.f + expf(-u));
+  }
+}
+
+__global__ void __launch_bounds__(256) gate_mlp_bwd_kernel(const float* __restrict__ dpart, int N, int tiles, int C, float inv_vox, const float* __restrict__ s_in,
+                                                           const float* __restrict__ saved, const float* __restrict__ w1, const float* __restrict__ w2, int R,
+                                                           int act, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                           float* __restrict__ db2, float* __restrict__ off) {
+  __shared__ double red[256];
+  __shared__ float du2[256], du1[64];
+  const int t = threadIdx.x;
+  float aw1[64], aw2[64];                                 // this thread's column of dW1 ([r][c = t]) and row of dW2 ([c = t][r]); R <= 64
+  float ab2 = 0.f, ab1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 64; ++r) aw1[r] = aw2[r] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float ds = gate_column_sum(dpart + (size_t)n * tiles * C, tiles, (size_t)C, C, red);
+    const float* sv = saved + (size_t)n * (C + 2 * R);
+    if (t < C) {
+      const float sg = s_in[(size_t)n * C + t];
+      du2[t] = ds * sg * (1.f - sg);
+    }
+    __syncthreads();
+    if (t < R) {
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a += du2[c] * w2[(size_t)c * R + t];
+      a *= gate_act_bwd(sv[C + t], act);
+      du1[t] = a;
+      ab1 += a;
+    }
+    __syncthreads();
+    if (t < C) {
+      const float d2 = du2[t], mc = sv[t];
+      ab2 += d2;
+      float dm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 64; ++r)
+        if (r < R) {
+          aw2[r] += d2 * sv[C + R + r];
+          aw1[r] += du1[r] * mc;
+          dm += du1[r] * w1[(size_t)r * C + t];
+        }
+      off[(size_t)n * C + t] = dm * inv_vox;
+    }
+    __syncthreads();
+  }
+  if (t < C) {
+#pragma unroll
+    for (int r = 0; r < 64; ++r)
+      if (r < R) {
+        dw2[(size_t)t * R + r] += aw2[r];
+        dw1[(size_t)r * C + t] += aw1[r];
+      }
+    if (db2) db2[t] += ab2;
+  }
+  if (t < R && db1) db1[t] += ab1;
+}
+
+extern "C" int bpx_gate_mlp_fwd(const float* part_d, int N, int tiles, int C, int64_t voxels, const float* w1_d, const float* b1_d, const float* w2_d,
+                                const float* b2_d, int R, int act, float* s_d, float* saved_d, bpx_stream_t stream) {
+  const char* fn = "bpx_gate_mlp_fwd";
+  BPX_CHECK(part_d && w1_d && w2_d && s_d && saved_d, "%s: null pointer", fn);
+  BPX_CHECK(N >= 0 && tiles > 0 && voxels > 0, "%s: bad extents", fn);
+  BPX_CHECK(C >= 1 && C <= 256 && R >= 1 && R <= 64 && R <= C, "%s: C must be <= 256 and R <= 64 (got C=%d R=%d)", fn, C, R);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  if (N == 0) return 0;
+  gate_mlp_fwd_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(part_d, tiles, C, (float)(1.0 / (double)voxels), w1_d, b1_d, w2_d, b2_d, R, act, s_d, saved_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_gate_mlp_bwd(const float* dpart_d, int N, int tiles, int C, int64_t voxels, const float* s_d, const float* saved_d, const float* w1_d,
+                                const float* w2_d, int R, int act, float* dw1_d, float* db1_d, float* dw2_d, float* db2_d, float* off_d,
+                                bpx_stream_t stream) {
+  const char* fn = "bpx_gate_mlp_bwd";
+  BPX_CHECK(dpart_d && s_d && saved_d && w1_d && w2_d && dw1_d && dw2_d && off_d, "%s: null pointer", fn);
+  BPX_CHECK(N >= 0 && tiles > 0 && voxels > 0, "%s: bad extents", fn);
+  BPX_CHECK(C >= 1 && C <= 256 && R >= 1 && R <= 64 && R <= C, "%s: C must be <= 256 and R <= 64 (got C=%d R=%d)", fn, C, R);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  if (N == 0) return 0;
+  gate_mlp_bwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(dpart_d, N, tiles, C, (float)(1.0 / (double)voxels), s_d, saved_d, w1_d, w2_d, R, act, dw1_d, db1_d,
+                                                          dw2_d, db2_d, off_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
 extern "C" int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx_tensor b, float* part_d, bpx_stream_t stream) {
   BPX_CHECK(a.cs == 0 && b.cs == 0, "bpx_dot_stats: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_dot_stats";

@@ -284,12 +284,29 @@ class ResUNetEngine:
             self._prepacked[(w.data_ptr(), mode)] = buf[off:off + sizes[q]]
         L.check(lib.bpx_pack_weights_batched(self.dt, len(plan), C.cast(jobs, C.c_void_p), L.stream_ptr()))
 
+    def _begin_recorded_packs(self, P: Dict[str, torch.Tensor], train: bool, dev, cache_weights: bool) -> None:
+        """For the tape engines (ResUNet++, RCAN), whose list of packed operands is not written down: the first step of a kind
+        (inference / training) packs its weights one by one and ``_pack`` records which PARAMETERS were packed how; every later step
+        packs that list with one launch up front (78 launches -> 1 per ResUNet++ training step, ~820 -> 1 for the RCAN trunk)."""
+        if not hasattr(self, "_pack_plans"):
+            self._pack_plans = {}
+        self._pack_names = {v.data_ptr(): k for k, v in P.items()}
+        self._pack_seen = self._pack_plans.setdefault(bool(train), {})
+        self._prepacked = {}
+        if self._pack_seen and not cache_weights:
+            self._prepack(P, train, dev, plan=list(self._pack_seen))
+
     def _pack(self, w: torch.Tensor, mode: int, cin: int, cout: int, cache: bool) -> torch.Tensor:
         pre = getattr(self, "_prepacked", None)
         if pre:
             hit = pre.get((w.data_ptr(), mode))
             if hit is not None:
                 return hit
+        names = getattr(self, "_pack_names", None)
+        if names:
+            name = names.get(w.data_ptr())
+            if name is not None:
+                self._pack_seen[(name, mode, cin, cout)] = True       # a parameter (not a per-step temporary): part of the next step's batch
         key = (w.data_ptr(), mode, self.dt)
         stamp = (w._version, _WEIGHTS_EPOCH[0])
         if cache and key in self._pack_cache and self._pack_versions.get(key) == stamp:

@@ -8,24 +8,24 @@ graph, from the same C-ABI kernels as the U-Nets:
   * the residual additions of ``RG`` (``x + module(x)``) and of the trunk (``x += residual``) are extra K-steps of the producing
     convolution: its fused 1x1x1 shortcut operand with an identity matrix;
   * channel attention: the global average pool comes out of the second convolution's statistics epilogue, the two 1x1 "convs"
-    on the pooled (B, C) vector are a few hundred FLOPs and stay PyTorch device ops (backward written out by hand), the recalibration and the RCAB
-    residual are one streaming pass (``bpx_channel_affine``: y = x + s[n,c] * h); the backward needs one reduction
+    on the pooled (B, C) vector are one small kernel each way (``bpx_gate_mlp_fwd`` / ``_bwd``: pooled mean -> SiLU MLP -> sigmoid and
+    its hand-written gradient; they were ~8 + ~15 PyTorch launches per RCAB, which bound the 200-RCAB trunk), the recalibration and the
+    RCAB residual are one streaming pass (``bpx_channel_affine``: y = x + s[n,c] * h); the backward needs one reduction
     (``bpx_dot_stats``: ds[n,c] = sum dy*h) and the same affine pass (dh = s*dy + dmean/voxels);
   * the last convolution (filters -> out_channels <= 4) runs with its output channels zero-padded to 16 and the head kernel picks
     the real ones and applies the output activation.
 
 The reference's 3-D up-scaling branch (``nn.PixelShuffle`` on 5-D tensors) raises, so only ``upscaling_layer=False`` exists here.
-This is a correctness-first path (parity with the reference trunk); it is not tuned.
+Weights are packed with one launch per step from the second step on (``ResUNetEngine._begin_recorded_packs``).
 """
 from __future__ import annotations
 
 from typing import Dict, List, Optional
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib as L
-from .engine import NetConfig, ResUNetEngine, _recs, _Stats
+from .engine import NetConfig, ResUNetEngine, _Stats
 
 lib = L.lib
 
@@ -66,33 +66,15 @@ class RCANEngine(ResUNetEngine):
             L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(x), L.ptr(rec), act, wp.data_ptr(), b.data_ptr(), L.tview(sc),
                                        c["eye_packed"].data_ptr(), c["zeros"].data_ptr(), L.tview(y), L.ptr(part), L.stream_ptr()))
 
-    def _attention(self, P, p, mean):
-        """s = sigmoid(W2 SiLU(W1 mean + b1) + b2) on the pooled (B, C) vector: a few hundred FLOPs, done with PyTorch device ops.
-        Returns s and what the hand-written backward below needs (no nested autograd: it would re-enter the autograd engine from
-        inside ``Function.backward``, which HIP-graph capture does not survive)."""
-        Fc, r = self.Fc, self.red
-        names = [f"{p}.module.3.module.1.weight", f"{p}.module.3.module.1.bias", f"{p}.module.3.module.3.weight", f"{p}.module.3.module.3.bias"]
-        w1, b1, w2, b2 = P[names[0]].reshape(r, Fc), P[names[1]], P[names[2]].reshape(Fc, r), P[names[3]]
-        u1 = mean @ w1.t() + b1
-        a1 = F.silu(u1)
-        s = torch.sigmoid(a1 @ w2.t() + b2).contiguous()
-        return s, dict(m=mean, u1=u1, a1=a1, w1=w1, w2=w2), names
-
-    @staticmethod
-    def _attention_bwd(s, sv, ds):
-        """Gradients of the pooled-vector MLP: (d mean, dW1, db1, dW2, db2)."""
-        du2 = ds * s * (1.0 - s)
-        dw2, db2 = du2.t() @ sv["a1"], du2.sum(0)
-        sg = torch.sigmoid(sv["u1"])
-        du1 = (du2 @ sv["w2"]) * (sg * (1.0 + sv["u1"] * (1.0 - sg)))
-        return du1 @ sv["w1"], du1.t() @ sv["m"], du1.sum(0), dw2, db2
+    def _gate_names(self, p):
+        return [f"{p}.module.3.module.1.weight", f"{p}.module.3.module.1.bias", f"{p}.module.3.module.3.weight", f"{p}.module.3.module.3.bias"]
 
     # ---- forward -----------------------------------------------------------------------------------------------------------
     def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 1
         B, _, D, H, W = x.shape
         S, vox, Fc, T, dev, st = (D, H, W), D * H * W, self.Fc, self.dtype, x.device, L.stream_ptr()
-        self._prepacked = {}
+        self._begin_recorded_packs(P, save, dev, cache_weights)
         c = self._consts(B, dev)
         img = x.reshape(B, D, H, W).contiguous()
 
@@ -112,9 +94,11 @@ class RCANEngine(ResUNetEngine):
                 self._conv(B, S, z, None, 0, P[f"{p}.module.0.weight"], P[f"{p}.module.0.bias"], h1)
                 part2 = _Stats.alloc(B, tiles, Fc, dev)
                 self._conv(B, S, h1, c["rec"], self.silu, P[f"{p}.module.2.weight"], P[f"{p}.module.2.bias"], h2, part=part2)
-                recm = _recs(B, Fc, dev)
-                _Stats.finalize(part2, B, tiles, Fc, vox, c["ones"], c["zeros"], recm, Fc, 0, st)
-                sd, sv, names = self._attention(P, p, recm[:, :, 0].contiguous())
+                names = self._gate_names(p)                                   # s = sigmoid(W2 SiLU(W1 mean + b1) + b2) from the statistics partials
+                sd = torch.empty((B, Fc), dtype=torch.float32, device=dev)
+                sv = torch.empty((B, Fc + 2 * self.red), dtype=torch.float32, device=dev)
+                L.check(lib.bpx_gate_mlp_fwd(part2.data_ptr(), B, tiles, Fc, vox, P[names[0]].data_ptr(), P[names[1]].data_ptr(), P[names[2]].data_ptr(),
+                                             P[names[3]].data_ptr(), self.red, self.silu, sd.data_ptr(), sv.data_ptr(), st))
                 zn = buf()
                 L.check(lib.bpx_channel_affine(self.dt, B, vox, L.tview(z), L.tview(h2), sd.data_ptr(), None, L.tview(zn), st))
                 blocks.append(dict(p=p, z=z, h1=h1, h2=h2, sd=sd, sv=sv, names=names))
@@ -197,14 +181,14 @@ class RCANEngine(ResUNetEngine):
                     nt = lib.bpx_norm_act_tiles(self.dt, vox, Fc)
                     dpart = torch.empty((B, nt, Fc), dtype=torch.float32, device=dev)
                     L.check(lib.bpx_dot_stats(self.dt, B, vox, L.tview(dz), L.tview(blk["h2"]), dpart.data_ptr(), st))
-                    ds = dpart.sum(1)
-                    grads = self._attention_bwd(blk["sd"], blk["sv"], ds)
-                    for n, gv in zip(blk["names"], grads[1:]):
-                        G[n] += gv.reshape(G[n].shape)
-                    off = (grads[0] / float(vox)).contiguous()                  # d mean -> every voxel of the channel
+                    nm = blk["names"]
+                    off = torch.empty((B, Fc), dtype=torch.float32, device=dev)   # d mean / voxels -> every voxel of the channel
+                    L.check(lib.bpx_gate_mlp_bwd(dpart.data_ptr(), B, nt, Fc, vox, blk["sd"].data_ptr(), blk["sv"].data_ptr(), P[nm[0]].data_ptr(),
+                                                 P[nm[2]].data_ptr(), self.red, self.silu, G[nm[0]].data_ptr(), G[nm[1]].data_ptr(), G[nm[2]].data_ptr(),
+                                                 G[nm[3]].data_ptr(), off.data_ptr(), st))
                     dh2 = buf()
                     L.check(lib.bpx_channel_affine(self.dt, B, vox, L.NULL_T, L.tview(dz), blk["sd"].data_ptr(), off.data_ptr(), L.tview(dh2), st))
-                    self._keep += [off, ds]
+                    self._keep += [off, dpart]
                     wgrad(blk["h1"], c["rec"], self.silu, dh2, G[f"{p}.module.2.weight"], G[f"{p}.module.2.bias"])
                     dh1 = dgrad(dh2, P[f"{p}.module.2.weight"], blk["h1"], c["rec"], self.silu)
                     wgrad(blk["z"], None, 0, dh1, G[f"{p}.module.0.weight"], G[f"{p}.module.0.bias"])

@@ -103,9 +103,6 @@ class ResUNetPPEngine(ResUNetEngine):
         self.pp = cfg
         self.relu = L.ACT["relu"]
         self._const: Dict = {}
-        self._pack_plans: Dict = {}                                # {training?: {(parameter name, pack mode, Cin, Cout): True}} - see forward
-        self._pack_names: Dict = {}
-        self._pack_seen: Dict = {}
 
     # ------------------------------------------------------------------------------------------------------------------
     # helpers
@@ -189,12 +186,6 @@ class ResUNetPPEngine(ResUNetEngine):
     # ------------------------------------------------------------------------------------------------------------------
     # tape operations: forward now, the backward closure goes onto self._tape (when training)
     # ------------------------------------------------------------------------------------------------------------------
-    def _pack(self, w: torch.Tensor, mode: int, cin: int, cout: int, cache: bool) -> torch.Tensor:
-        name = self._pack_names.get(w.data_ptr())
-        if name is not None and (w.data_ptr(), mode) not in self._prepacked:
-            self._pack_seen[(name, mode, cin, cout)] = True          # a parameter (not a per-step temporary): part of the next step's batch
-        return super()._pack(w, mode, cin, cout, cache)
-
     def _conv3(self, x: _V, wk: str, bk: str, Cout: int, nrm: Optional[_Nrm] = None, want_stats: bool = True, batch: Optional[int] = None):
         """y = conv3x3x3(act(IN(x))) with the normalisation + activation as the conv's prologue (nrm given), or conv3x3x3(x)."""
         P, G, B = self._P, self._G, (self._B if batch is None else batch)
@@ -276,15 +267,17 @@ class ResUNetPPEngine(ResUNetEngine):
         return self._add_in(main, s, rec_s, f"{prefix}.shortcut.1.weight", f"{prefix}.shortcut.1.bias")
 
     def _sqex(self, x: _V, prefix: str) -> _V:
-        """blocks.py:1119-1191: x * sigmoid(W2 relu(W1 mean(x)))."""
+        """blocks.py:1119-1191: x * sigmoid(W2 relu(W1 mean(x))) - the gate on the pooled vector is one small kernel each way."""
         P, G, B = self._P, self._G, self._B
         C = x.C
-        w1, w2 = P[f"{prefix}.excitation.0.weight"], P[f"{prefix}.excitation.2.weight"]
-        recm = self._stats_rec(x, self._vec(C, 1.0), self._vec(C, 0.0))
-        m = recm[:, :, 0].contiguous()
-        u1 = m @ w1.t()
-        a1 = torch.relu(u1)
-        s = torch.sigmoid(a1 @ w2.t()).contiguous()
+        k1, k2 = f"{prefix}.excitation.0.weight", f"{prefix}.excitation.2.weight"
+        w1, w2 = P[k1], P[k2]
+        R = w1.shape[0]
+        part, tiles = self._tensor_part(x)
+        s = torch.empty((B, C), dtype=torch.float32, device=self._dev)
+        sv = torch.empty((B, C + 2 * R), dtype=torch.float32, device=self._dev)
+        L.check(lib.bpx_gate_mlp_fwd(part.data_ptr(), B, tiles, C, x.vox, w1.data_ptr(), None, w2.data_ptr(), None, R, self.relu, s.data_ptr(), sv.data_ptr(),
+                                     self._st))
         out = self._new(x.S, C)
         L.check(lib.bpx_channel_affine(self.dt, B, x.vox, L.NULL_T, x.view(), s.data_ptr(), None, out.view(), self._st))
         if G is not None:
@@ -292,12 +285,9 @@ class ResUNetPPEngine(ResUNetEngine):
                 nt = lib.bpx_norm_act_tiles(self.dt, x.vox, C)
                 dpart = torch.empty((B, nt, C), dtype=torch.float32, device=self._dev)
                 L.check(lib.bpx_dot_stats(self.dt, B, x.vox, L.tview(out.grad), x.view(), dpart.data_ptr(), self._st))
-                ds = dpart.sum(1)
-                du2 = ds * s * (1.0 - s)
-                G[f"{prefix}.excitation.2.weight"] += du2.t() @ a1
-                du1 = (du2 @ w2) * (u1 > 0).to(torch.float32)
-                G[f"{prefix}.excitation.0.weight"] += du1.t() @ m
-                off = ((du1 @ w1) / float(x.vox)).contiguous()          # d mean -> every voxel of the channel
+                off = torch.empty((B, C), dtype=torch.float32, device=self._dev)         # d mean / voxels -> every voxel of the channel
+                L.check(lib.bpx_gate_mlp_bwd(dpart.data_ptr(), B, nt, C, x.vox, s.data_ptr(), sv.data_ptr(), w1.data_ptr(), w2.data_ptr(), R, self.relu,
+                                             G[k1].data_ptr(), None, G[k2].data_ptr(), None, off.data_ptr(), self._st))
                 g = torch.empty((B,) + x.S + (C,), dtype=self.dtype, device=self._dev)
                 L.check(lib.bpx_channel_affine(self.dt, B, x.vox, L.NULL_T, L.tview(out.grad), s.data_ptr(), off.data_ptr(), L.tview(g), self._st))
                 self._keep += [out.grad, off, dpart]
@@ -512,13 +502,7 @@ class ResUNetPPEngine(ResUNetEngine):
         if D0 % zdiv or H0 % (2 ** depth) or W0 % (2 ** depth):
             raise ValueError(f"patch {D0, H0, W0} must be divisible by {(zdiv, 2 ** depth, 2 ** depth)} (DATA.PATCH_SIZE rule, check_configuration.py:3156-3202)")
         self._B, self._dev, self._st, self._P = B, x.device, L.stream_ptr(), P
-        # weight operands: the first step of a kind (inference / training) packs them one by one and records which parameters were
-        # packed how; later steps pack the whole list with ONE launch up front (78 launches -> 1 per training step)
-        self._pack_names = {v.data_ptr(): k for k, v in P.items()}
-        self._pack_seen = self._pack_plans.setdefault(bool(save), {})
-        self._prepacked = {}
-        if self._pack_seen and not cache_weights:
-            self._prepack(P, save, x.device, plan=list(self._pack_seen))
+        self._begin_recorded_packs(P, save, x.device, cache_weights)   # one batched weight-pack launch from the second step on
         self._tape: List[Callable[[], None]] = []
         self._late: List[Callable[[], None]] = []
         self._keep = []

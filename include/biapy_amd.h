@@ -258,6 +258,19 @@ int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor
 int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x, bpx_tensor h, const float* scale_d, const float* offset_d,
                        bpx_tensor y, bpx_stream_t stream);
 int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx_tensor b, float* part_d, bpx_stream_t stream);
+/* The gate itself, on the pooled (N, C) vector (rcan.py ChannelAttention.module: Conv 1x1 -> SiLU -> Conv 1x1 -> Sigmoid;
+ * blocks.py:1119-1191 SqExBlock.excitation: Linear -> ReLU -> Linear -> Sigmoid, no biases):
+ *   m[n,c] = sum_t part_d[n][t][0][c] / voxels   (part_d: [N][tiles][2][C] statistics partials of the producing kernel, NOT consumed)
+ *   u1 = W1 m + b1 (R values; w1_d [R][C]),  a1 = act(u1),  s = sigmoid(W2 a1 + b2) (w2_d [C][R]);  b1_d / b2_d may be null
+ *   saved_d [N][C + 2R] = m, u1, a1 (read by the backward).  C <= 256, R <= 64.
+ * Backward: dpart_d [N][tiles][C] partial sums of dy*h (bpx_dot_stats) -> ds[n,c]; dW1 / db1 / dW2 / db2 are ACCUMULATED (+=; db may be
+ * null) with the samples summed in index order (deterministic); off_d[n][c] = d mean[n,c] / voxels, the offset of the affine pass
+ * that carries the pooled gradient back to every voxel. */
+int bpx_gate_mlp_fwd(const float* part_d, int N, int tiles, int C, int64_t voxels, const float* w1_d, const float* b1_d, const float* w2_d,
+                     const float* b2_d, int R, int act, float* s_d, float* saved_d, bpx_stream_t stream);
+int bpx_gate_mlp_bwd(const float* dpart_d, int N, int tiles, int C, int64_t voxels, const float* s_d, const float* saved_d, const float* w1_d,
+                     const float* w2_d, int R, int act, float* dw1_d, float* db1_d, float* dw2_d, float* db2_d, float* off_d,
+                     bpx_stream_t stream);
 
 /* MaxPool3d (sz,2,2), sz = z_down of the level = 1 or 2 (resunet.py:256-257) + statistics of the pooled tensor.
  * (D,H,W) = input extents. */

@@ -1133,3 +1133,52 @@ def test_dilated_conv_through_space_to_batch(K, d, dim):
     finally:
         L.check(L.lib.bpx_debug_set_tiling_scalar(0))
     assert torch.equal(DL.space_to_packed(xb, d), ref_p)                        # vector kernel == element-per-thread kernel
+
+
+@pytest.mark.parametrize("C,R,act,bias", [(16, 1, "silu", True), (32, 2, "silu", True), (64, 8, "relu", False), (48, 6, "relu", False)])
+def test_gate_mlp_kernels_match_autograd(K, C, R, act, bias):
+    """bpx_gate_mlp_fwd / _bwd (rcan.py ChannelAttention.module, blocks.py:1119-1191 SqExBlock.excitation on the pooled vector):
+    mean from the statistics partials -> W1 (+b1) -> act -> W2 (+b2) -> sigmoid, and the hand-written gradient (dW1, db1, dW2, db2
+    accumulated, d mean / voxels), against the same few lines of PyTorch autograd in float64 on the CPU."""
+    from biapy_amd import _lib as L
+
+    g = torch.Generator().manual_seed(C + R)
+    N, tiles, vox = 3, 37, 5000
+    part = torch.randn(N, tiles, 2, C, generator=g)
+    w1 = torch.randn(R, C, generator=g) * 0.3
+    w2 = torch.randn(C, R, generator=g) * 0.3
+    b1 = torch.randn(R, generator=g) * 0.1 if bias else None
+    b2 = torch.randn(C, generator=g) * 0.1 if bias else None
+    dpart = torch.randn(N, 11, C, generator=g)
+    # reference
+    f = torch.nn.functional.silu if act == "silu" else torch.relu
+    m = (part[:, :, 0, :].double().sum(1) / vox).requires_grad_(True)
+    W1, W2 = w1.double().requires_grad_(True), w2.double().requires_grad_(True)
+    B1 = b1.double().requires_grad_(True) if bias else None
+    B2 = b2.double().requires_grad_(True) if bias else None
+    u1 = m @ W1.t() + (B1 if bias else 0)
+    s_ref = torch.sigmoid(f(u1) @ W2.t() + (B2 if bias else 0))
+    ds = dpart.double().sum(1)
+    grads = torch.autograd.grad(s_ref, [m, W1, W2] + ([B1, B2] if bias else []), ds)
+    # device
+    d = lambda t: t.cuda() if t is not None else None  # noqa: E731
+    pd, w1d, w2d, b1d, b2d, dpd = d(part), d(w1), d(w2), d(b1), d(b2), d(dpart)
+    s = torch.empty(N, C, device="cuda")
+    sv = torch.empty(N, C + 2 * R, device="cuda")
+    L.check(L.lib.bpx_gate_mlp_fwd(pd.data_ptr(), N, tiles, C, vox, w1d.data_ptr(), L.ptr(b1d), w2d.data_ptr(), L.ptr(b2d), R, L.ACT[act], s.data_ptr(),
+                                   sv.data_ptr(), L.stream_ptr()))
+    assert torch.allclose(s.cpu().double(), s_ref.detach(), atol=2e-6)
+    assert torch.allclose(sv[:, :C].cpu().double(), m.detach(), atol=1e-7)
+    seed = 0.25                                                                   # the parameter gradients are ACCUMULATED
+    dw1, dw2 = torch.full((R, C), seed, device="cuda"), torch.full((C, R), seed, device="cuda")
+    db1, db2 = (torch.full((R,), seed, device="cuda"), torch.full((C,), seed, device="cuda")) if bias else (None, None)
+    off = torch.empty(N, C, device="cuda")
+    L.check(L.lib.bpx_gate_mlp_bwd(dpd.data_ptr(), N, 11, C, vox, s.data_ptr(), sv.data_ptr(), w1d.data_ptr(), w2d.data_ptr(), R, L.ACT[act], dw1.data_ptr(),
+                                   L.ptr(db1), dw2.data_ptr(), L.ptr(db2), off.data_ptr(), L.stream_ptr()))
+    tol = dict(rtol=1e-4, atol=1e-5)
+    assert torch.allclose(off.cpu().double() * vox, grads[0], **tol)
+    assert torch.allclose(dw1.cpu().double() - seed, grads[1], **tol)
+    assert torch.allclose(dw2.cpu().double() - seed, grads[2], **tol)
+    if bias:
+        assert torch.allclose(db1.cpu().double() - seed, grads[3], **tol)
+        assert torch.allclose(db2.cpu().double() - seed, grads[4], **tol)
