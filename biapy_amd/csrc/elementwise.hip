@@ -1535,8 +1535,18 @@ __device__ __forceinline__ float gate_act_bwd(float u, int act) {
 __device__ __forceinline__ float gate_column_sum(const float* col, int tiles, size_t tstride, int C, double* red /* [256] */) {
   const int c = threadIdx.x % C, l = threadIdx.x / C, lanes = 256 / C;
   double a = 0.0;
-  if (l < lanes)
-    for (int t = l; t < tiles; t += lanes) a += (double)col[(size_t)t * tstride + c];
+  if (l < lanes) {
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;                  // four loads in flight: the kernel is one latency chain otherwise
+    int t = l;
+    for (; t + 3 * lanes < tiles; t += 4 * lanes) {
+      a += (double)col[(size_t)t * tstride + c];
+      a1 += (double)col[(size_t)(t + lanes) * tstride + c];
+      a2 += (double)col[(size_t)(t + 2 * lanes) * tstride + c];
+      a3 += (double)col[(size_t)(t + 3 * lanes) * tstride + c];
+    }
+    for (; t < tiles; t += lanes) a += (double)col[(size_t)t * tstride + c];
+    a = (a + a1) + (a2 + a3);
+  }
   red[threadIdx.x] = a;
   __syncthreads();
   double tot = 0.0;

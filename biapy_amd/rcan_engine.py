@@ -132,7 +132,11 @@ class RCANEngine(ResUNetEngine):
         D, H, W = S
         vox, Fc, T, dev, st, c = D * H * W, self.Fc, self.dtype, dy_out.device, L.stream_ptr(), self._c
         self._keep = []
-        G = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in P.items()}
+        flat = torch.zeros(sum(p.numel() for p in P.values()), dtype=torch.float32, device=dev)   # ONE fill for the ~1,650 parameter gradients
+        G, o = {}, 0
+        for n, p in P.items():
+            G[n] = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
         self._deferred = True
         L.check(lib.bpx_wgrad_defer_begin())
         try:

@@ -186,7 +186,7 @@ def bench_rcan():
     m = rcan(ndim=3, num_channels=1, filters=16, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"]).cuda()
     x = torch.randn(1, 1, 64, 64, 64, device=DEV)
     t = torch.randn(1, 1, 64, 64, 64, device=DEV)
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
     with torch.no_grad():
         m.eval()(x)
         torch.cuda.synchronize()
@@ -230,7 +230,7 @@ def bench_rcan():
     torch.cuda.empty_cache()
     torch.manual_seed(0)
     m2 = rcan(ndim=3, num_channels=1, filters=16, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"]).cuda().train()
-    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-4, capturable=True)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-4, capturable=True, fused=True)   # unfused capturable AdamW: two strided divisions per parameter tensor
     gs = GraphedTrainStep(m2, torch.nn.functional.l1_loss, opt2, x, t, warmup=1)
     gs()
     torch.cuda.synchronize()
