@@ -19,12 +19,15 @@ python bench.py --arch resunetpp --batch 4 --breakdown --graph off > $O/${R}_bre
 python bench.py --breakdown --graph off --mode train > $O/${R}_breakdown_train_events.txt 2> /dev/null
 python bench.py --breakdown --graph off --mode infer > $O/${R}_breakdown_infer_events.txt 2> /dev/null
 python tests/bench_kernels.py merge > $O/${R}_merge_crop.txt 2>&1
+python tests/bench_kernels.py rcan 2>&1 | grep -v "Warning\|run_backward" > $O/${R}_rcan_trunk_64.txt
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o train -- python $ROOT/bench.py --mode train --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_train.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o resunetpp -- python $ROOT/bench.py --arch resunetpp --batch 4 --steps 20 --warmup 3 > $ROOT/$O/kt_pp.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o infer -- python $ROOT/bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_infer.log 2>&1
 cd $ROOT
 cp $(find $O/kt -name "train_kernel_stats.csv" | head -1) $O/${R}_bench_train_kernel_stats.csv
 cp $(find $O/kt -name "infer_kernel_stats.csv" | head -1) $O/${R}_bench_infer_kernel_stats.csv
+cp $(find $O/kt -name "resunetpp_kernel_stats.csv" | head -1) $O/${R}_bench_resunetpp_kernel_stats.csv
 cd /tmp
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_f -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_f.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_w -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_w.log 2>&1
