@@ -584,11 +584,19 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 // 64 -> 39 (MC = 1), 72 -> 47 (MC = 2), 80 -> 55 (MC = 3).
 // the two-voxel shift of the window is an odd-aligned register quad (not a legal MFMA operand: the compiler copies it with four v_mov);
 // reading it again from LDS instead measured 1-2.5 % faster on the 128^3 / 64^3 layers (16->16 256 -> 251 us, 96->32 256 -> 250), flat elsewhere
+#ifndef BPX_WGRAD_HC
+#define BPX_WGRAD_HC 2
+#endif
 #ifndef BPX_WGRAD_REREAD
 #define BPX_WGRAD_REREAD 1
 #endif
+// Bias gradient (column sums of dy over the tile's own voxels) on the matrix unit: wave 3 owns six taps, its seventh accumulator is
+// free.  One MFMA per K-chunk of an all-ones A operand with the UN-shifted dy fragment (halo offset (1, 1, 1)) leaves sum_v dy[v][co]
+// in every row of acc[6][0] (bf16 1.0 x dy is exact, the sums are fp32 like the weight gradients) - no extra registers, and it replaces
+// a 16-iteration scalar-load loop over the dy tile that every wave of the workgroup ran per tile (~150 of the kernel's ~540 VALU
+// instructions per tile and wave; the kernel is VALU-bound).
 template <int W, int MC, int HY, int HX, int VBA, int VBG, int TV, int NKC>
-__device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC]) {
+__device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC], bool want_b) {
   constexpr int T0 = 7 * W, T1 = (T0 + 7 < 27) ? T0 + 7 : 27;
   typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
 #pragma unroll
@@ -641,6 +649,14 @@ __device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const uns
           acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf), acc[a][c], 0, 0, 0);
       }
     }
+    if (W == 3 && want_b) {
+      const unsigned char* q = sG + g_lane + kg + (((1 * HY + 1) * HX + 1) * VBG);
+      u32x2_t r0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+      u32x2_t r1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBG)));
+      const u32x4_t gf = u32x4_t{r0[0], r0[1], r1[0], r1[1]};
+      const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+      acc[6][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, gf), acc[6][0], 0, 0, 0);
+    }
   }
 }
 
@@ -652,6 +668,9 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
   constexpr int NKC = TV / 32, NT = 7;
   constexpr int NPA = TV * 2 / 256, NPGT = HV * PPVG, NPG = (NPGT + 255) / 256;
   __shared__ __attribute__((aligned(16))) unsigned char smem[MC * TV * VBA + HV * VBG + 64 + MC * 16 * 8];   // 64: window over-read of the last halo row
+#if BPX_WGRAD_HC == 2
+  __shared__ u32x4_t sHC[256];   // halo coordinates of every thread's dy pieces (16 bits each: hz | hy << 4 | hx << 8), read by the edge tiles only
+#endif
   unsigned char* sA = smem;                                   // [MC][TV][32 B]
   unsigned char* sG = smem + MC * TV * VBA;
   float* sN = reinterpret_cast<float*>(smem + MC * TV * VBA + HV * VBG + 64);   // [MC*16][scale, shift]
@@ -672,11 +691,15 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
   for (int a = 0; a < NT; ++a)
 #pragma unroll
     for (int c = 0; c < MC; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  const bool want_b = p.db != nullptr && cgi == 0;            // wave 3 keeps the column sums of dy (the bias gradient) in acc[6][0], see sd_mfma_phase
 
   const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
   const char* __restrict__ gin = reinterpret_cast<const char*>(p.dy);
-  uint32_t rel_a[NPA], rel_g[NPG];
+  static_assert(NPG <= 8, "eight 16-bit coordinate fields per thread");
+  uint32_t rel_a[NPA], rel_g[NPG], hc_g[BPX_WGRAD_HC == 2 ? 4 : (NPG + 1) / 2];   // hc_g: halo coordinates of the thread's dy pieces, two per register, 16 bits each:
+  //                                                          hz | hy << 4 | hx << 8 (edge tiles test them)
+#pragma unroll
+  for (int u = 0; u < (BPX_WGRAD_HC == 2 ? 4 : (NPG + 1) / 2); ++u) hc_g[u] = 0u;
 #pragma unroll
   for (int u = 0; u < NPA; ++u) {
     const int t = (u * 256 + tid) >> 1;
@@ -689,8 +712,17 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
     const int hv = (u * 256 + tid) / PPVG;
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     rel_g[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.dy_ld + co_base + subG * KPL) * 2u;
+#if BPX_WGRAD_HC
+    hc_g[u >> 1] |= ((uint32_t)hz | ((uint32_t)hy << 4) | ((uint32_t)hx << 8)) << (16 * (u & 1));
+#endif
     asm volatile("" : "+v"(rel_g[u]));
   }
+#if BPX_WGRAD_HC == 1
+#pragma unroll
+  for (int u = 0; u < (NPG + 1) / 2; ++u) asm volatile("" : "+v"(hc_g[u]));
+#elif BPX_WGRAD_HC == 2
+  sHC[tid] = u32x4_t{hc_g[0], hc_g[1], hc_g[2], hc_g[3]};   // read back by the same thread: no barrier needed
+#endif
   const bool last_ok = (NPG - 1) * 256 + tid < NPGT;
   const int trl = (i >> 2), trc = (i & 3) * 8;
   const int a_base = g * 8 * VBA + trl * VBA + trc;
@@ -717,16 +749,26 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
         if (oka[u]) pa[c][u] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a[u]) + (uint32_t)c * ((uint32_t)p.x_cs * 2u));
       }
     }
+#if BPX_WGRAD_HC == 2
+    u32x4_t hcv = u32x4_t{0u, 0u, 0u, 0u};
+    if (!interior) hcv = sHC[tid];
+#endif
 #pragma unroll
     for (int u = 0; u < NPG; ++u) {
       pg[u] = u32x4_t{0u, 0u, 0u, 0u};
       bool ok = (u < NPG - 1) || last_ok;
-      if (!interior) {
+      if (!interior) {   // a third of the 128^3 tiles: three field extracts per piece (the divisions by the halo extents were ~40 VALU instructions each)
+#if BPX_WGRAD_HC
+        const uint32_t c = (BPX_WGRAD_HC == 2 ? hcv[u >> 1] : hc_g[u >> 1]) >> (16 * (u & 1));
+        ok = ok && (unsigned)(z0 - 1 + (int)(c & 15u)) < (unsigned)D && (unsigned)(y0 - 1 + (int)((c >> 4) & 15u)) < (unsigned)H &&
+             (unsigned)(x0 - 1 + (int)((c >> 8) & 255u)) < (unsigned)W;
+#else
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
         const int hv = (u * 256 + tid_o) / PPVG;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         ok = ok && (unsigned)(z0 - 1 + hz) < (unsigned)D && (unsigned)(y0 - 1 + hy) < (unsigned)H && (unsigned)(x0 - 1 + hx) < (unsigned)W;
+#endif
       }
       if (ok) pg[u] = *reinterpret_cast<const u32x4_t*>(gin + (base_g + rel_g[u]));
     }
@@ -768,19 +810,11 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
       if (u < NPG - 1 || last_ok) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[u];
     __syncthreads();
 
-    if (p.db != nullptr && cgi == 0) {  // bias gradient: column sums of dy over the tile's own voxels
-      const int c = tid % CB;
-      for (int v = tid / CB; v < TV; v += 256 / CB) {
-        const int hidx = (((v >> 6) + 1) * HY + ((v >> 4) & 3) + 1) * HX + (v & 15) + 1;
-        bsum += bf16_to_f32(*reinterpret_cast<const uint16_t*>(sG + (size_t)hidx * VBG + c * 2));
-      }
-    }
-
     switch (wave) {   // wave-uniform
-      case 0: sd_mfma_phase<0, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
-      case 1: sd_mfma_phase<1, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
-      case 2: sd_mfma_phase<2, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
-      default: sd_mfma_phase<3, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc); break;
+      case 0: sd_mfma_phase<0, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc, want_b); break;
+      case 1: sd_mfma_phase<1, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc, want_b); break;
+      case 2: sd_mfma_phase<2, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc, want_b); break;
+      default: sd_mfma_phase<3, MC, HY, HX, VBA, VBG, TV, NKC>(sA, sG, a_base, g_lane, acc, want_b); break;
     }
   }
 
@@ -797,17 +831,7 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
         pp[((size_t)tap * p.Cin + ci) * p.Cout + co] = acc[a][c][r];
       }
   }
-  if (p.db != nullptr && cgi == 0) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    red[tid] = bsum;
-    __syncthreads();
-    if (tid < CB) {
-      float s = 0.f;
-      for (int k = tid; k < 256; k += CB) s += red[k];
-      p.dbpart[(size_t)grp * p.Cout + co_base + tid] = s;   // one writer per (group, channel)
-    }
-  }
+  if (want_b && wave == 3 && g == 0) p.dbpart[(size_t)grp * p.Cout + co_base + i] = acc[6][0][0];   // row 0 of D: one writer per (group, channel)
 }
 
 
