@@ -583,12 +583,14 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 // segments; the four waves run four compile-time specialisations of the MFMA phase.  LDS reads per K-chunk and workgroup:
 // 64 -> 39 (MC = 1), 72 -> 47 (MC = 2), 80 -> 55 (MC = 3).
 // the two-voxel shift of the window is an odd-aligned register quad (not a legal MFMA operand: the compiler copies it with four v_mov);
-// reading it again from LDS instead measured 1-2.5 % faster on the 128^3 / 64^3 layers (16->16 256 -> 251 us, 96->32 256 -> 250), flat elsewhere
+// reading it again from LDS instead measured 1-2.5 % faster on the 128^3 / 64^3 layers (16->16 256 -> 251 us, 96->32 256 -> 250), flat elsewhere.
+// BPX_WGRAD_REREAD = 2 reads the one-voxel shift from LDS too (two reads instead of a third window read + four v_alignbit per tap; the
+// kernel is VALU-bound, the LDS has slack): 48->16 @128^3 508 -> 477 us, 96->32 @64^3 231 -> 224, 32->32 88 -> 84.5, 16->16 flat
 #ifndef BPX_WGRAD_HC
 #define BPX_WGRAD_HC 2
 #endif
 #ifndef BPX_WGRAD_REREAD
-#define BPX_WGRAD_REREAD 1
+#define BPX_WGRAD_REREAD 2
 #endif
 // Bias gradient (column sums of dy over the tile's own voxels) on the matrix unit: wave 3 owns six taps, its seventh accumulator is
 // free.  One MFMA per K-chunk of an all-ones A operand with the UN-shifted dy fragment (halo offset (1, 1, 1)) leaves sum_v dy[v][co]
@@ -622,7 +624,7 @@ __device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const uns
         u32x2_t r0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
         u32x2_t r1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBG)));
         w[0] = r0[0]; w[1] = r0[1]; w[2] = r1[0]; w[3] = r1[1]; w[4] = 0u; w[5] = 0u;
-        if (nt > 1) {
+        if (nt > 1 && BPX_WGRAD_REREAD != 2) {
           u32x2_t r2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 8 * VBG)));
           w[4] = r2[0]; w[5] = r2[1];
         }
@@ -640,6 +642,11 @@ __device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const uns
           } else {
             gf = u32x4_t{w[1], w[2], w[3], w[4]};
           }
+        }
+        else if (BPX_WGRAD_REREAD == 2) {   // the one-voxel shift from LDS as well (two reads instead of a third window read + four v_alignbit)
+          u32x2_t s0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 1 * VBG)));
+          u32x2_t s1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 5 * VBG)));
+          gf = u32x4_t{s0[0], s0[1], s1[0], s1[1]};
         }
         else gf = u32x4_t{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
                           __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w[4], w[3], 16)};
