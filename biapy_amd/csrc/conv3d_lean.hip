@@ -43,7 +43,10 @@ constexpr int lp_ahalf(int ms, int ns, int epi) { return (ms > 4 && ns == 1 && e
 //     +0..+10 %;
 //   * ADOPTED: four workgroups per CU for the 4x8x16 dgrad tile (A fragments read in two halves -> 119 VGPRs, no scratch):
 //     dgrad 16->16 @128^3 257 -> 241 us; the same for the forward tile still spills 150 B/lane at 128 VGPRs (staging peak) and stays at 3;
-//   * s_setprio 1 around the MFMA steps (BPX_CONV_DBG=16, still selectable): -1..-5 % forward, +-2 % dgrad - left off.
+//   * s_setprio 1 around the MFMA steps (BPX_CONV_DBG=16, still selectable): -1..-5 % forward, +-2 % dgrad - left off;
+//   * border tiles (38 % of the 128^3 tiles) reading their pieces' halo coordinates from a u16 LDS table instead of re-deriving them
+//     with three divisions per piece (the change that made the VALU-bound wgrad kernel 9-15 % faster): flat here (fwd 48->16 756 ->
+//     748 us, dgrad 16->48 863 -> 899, 16->16 237 -> 234, train step 10.41 -> 10.48 ms) - this kernel waits, it does not issue-bind.
 // F16: fp16 storage instead of bf16 (inference: forward instances only) - same instruction counts (v_cvt_f32_f16 / v_cvt_pk_f16_f32 in
 // place of the shifts / v_cvt_pk_bf16_f32, v_mfma_f32_16x16x32_f16)
 template <int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool F16 = false>
