@@ -1182,3 +1182,37 @@ def test_gate_mlp_kernels_match_autograd(K, C, R, act, bias):
     if bias:
         assert torch.allclose(db1.cpu().double() - seed, grads[3], **tol)
         assert torch.allclose(db2.cpu().double() - seed, grads[4], **tol)
+
+
+@pytest.mark.parametrize("family", ["rcan", "resunetpp"])
+def test_recorded_batched_weight_packing_reproduces_the_first_step(family):
+    """ResUNetEngine._begin_recorded_packs (tape engines): the first training step packs its weight operands one by one and records
+    them, the second packs the recorded list with ONE launch.  With unchanged weights both steps must give the same output and the
+    same gradients bit for bit (every kernel is deterministic), i.e. the batched operands equal the one-by-one ones."""
+    torch.manual_seed(5)
+    if family == "rcan":
+        from biapy_amd.rcan import rcan
+
+        m = rcan(ndim=3, num_channels=1, filters=16, scale=2, num_rg=2, num_rcab=2, reduction=16, upscaling_layer=False, out_channels=1,
+                 head_activations=["linear"]).cuda().train()
+        x = torch.randn(2, 1, 16, 16, 16, device="cuda")
+    else:
+        from biapy_amd.resunetpp import ResUNetPlusPlus
+
+        m = ResUNetPlusPlus(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=[16, 32, 64], drop_values=[0.0] * 3, normalization="in",
+                            yx_down=[2] * 2, z_down=[2] * 2, output_channels=[1], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3).cuda().train()
+        x = torch.randn(2, 1, 16, 16, 16, device="cuda")
+    outs, grads = [], []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        y = y if torch.is_tensor(y) else y[0]
+        y.square().mean().backward()
+        outs.append(y.detach().clone())
+        grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    plans = [v._pack_plans for v in vars(m).values() if hasattr(v, "_pack_plans")]
+    assert plans and all(len(p.get(True, {})) > 4 for p in plans), "the engine did not record its packed operands"
+    for s in (1, 2):
+        assert torch.equal(outs[s], outs[0])
+        for k in grads[0]:
+            assert torch.equal(grads[s][k], grads[0][k]), (s, k)
