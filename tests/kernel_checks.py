@@ -1067,6 +1067,111 @@ def check_resunetpp(dtype, golden):
     return res
 
 
+_CFG4_CACHE = {}
+
+
+def _cfg4_oracle():
+    """One CPU oracle step (forward, MSE loss, every gradient) of the cfg-4 ResUNet++ on ONE 80^3 patch, shared by the f32 and bf16
+    tests: seeded module weights, three output channels."""
+    if "ref" not in _CFG4_CACHE:
+        from biapy_amd.resunetpp import ResUNetPlusPlus
+        from oracle import resunetpp_oracle
+
+        fm = [16, 32, 64, 128, 256]
+        torch.manual_seed(11)
+        m = ResUNetPlusPlus(image_shape=(80, 80, 80, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4,
+                            z_down=[2] * 4, output_channels=[3], output_channel_info=["BCD"], head_activations=["ce_sigmoid", "ce_sigmoid", "linear"],
+                            isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        g = torch.Generator().manual_seed(12)
+        x = torch.randn(2, 1, 80, 80, 80, generator=g)
+        tgt = torch.randn(2, 3, 80, 80, 80, generator=g)
+        P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        lo = resunetpp_oracle.resunetpp_forward(P, x[:1], fm)
+        loss = F.mse_loss(lo, tgt[:1])
+        names = [k for k, v in P.items() if v.requires_grad]
+        grads = dict(zip(names, torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)))
+        _CFG4_CACHE["ref"] = (fm, sd, x, tgt, loss.detach(), lo.detach(), {k: v for k, v in grads.items() if v is not None})
+    return _CFG4_CACHE["ref"]
+
+
+def check_resunetpp_cfg4_shape(dtype):
+    """Row X AT THE BENCHED SIZE: cfg 4 = ResUNet++ fm 16-32-64-128-256 on an 80^3 patch - the ASPP's packed dilated convolutions at
+    the real rates (6 / 12 / 18 on 80^3 -> 89^3 / 95^3 / 107^3 packed volumes; rate 6 on the 10^3 bridge -> 17^3, rates 12 / 18 there
+    as the centre tap), squeeze-excite and attention gates at their true sizes - against the CPU oracle: logits, MSE loss and every
+    parameter gradient of sample 0; then the batch of 2 against its two batch-1 runs (every normalisation / gate is per sample).
+
+    bf16 bars at this size are wide on purpose, and measured: this randomly initialised network (un-squashed attention gates, SE
+    products, five levels) amplifies rounding - in the f32 mode, rounding ONLY the input to bf16 moves the logits by 2.2 % (relative
+    L2) and rounding ONLY the weights by 4.0 %; the bf16 mode does both and rounds every activation (9.2 %), and the weight gradients
+    inherit it (norms within 6 %, directions within 0.54 relative L2).  What the bf16 rows pin down is therefore: the loss (1.5e-4),
+    bounded logits / gradient error, and - exactly - that a batch is the same as its samples run alone."""
+    from biapy_amd.resunetpp import ResUNetPlusPlus
+
+    fm, sd, x, tgt, loss_ref, lo_ref, grads_ref = _cfg4_oracle()
+    f32 = dtype == torch.float32
+    tag = f"cfg4_80^3[{'f32' if f32 else 'bf16'}]"
+    m = ResUNetPlusPlus(image_shape=(80, 80, 80, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4,
+                        z_down=[2] * 4, output_channels=[3], output_channel_info=["BCD"], head_activations=["ce_sigmoid", "ce_sigmoid", "linear"],
+                        isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+
+    def step(xb, tb):
+        m.zero_grad(set_to_none=True)
+        lo = m(xb.to(DEV))
+        loss = F.mse_loss(lo, tb.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        return lo.detach().cpu(), loss.item(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+
+    lo1, loss1, G1 = step(x[:1], tgt[:1])
+    scale = lo_ref.abs().max().item()
+    res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, 3e-4 if f32 else 0.2, extra=f"scale={scale:.3f}")]
+    res.append(_res(tag + ".b1.logits_rel_l2", ((lo1 - lo_ref).norm() / lo_ref.norm()).item(), 1e-4 if f32 else 0.15))
+    res.append(_res(tag + ".b1.loss_rel", abs(loss1 - loss_ref.item()) / loss_ref.item(), 1e-5 if f32 else 5e-3))
+    floor = GRAD_FLOOR_F32 if f32 else GRAD_FLOOR_BF16
+    gmax = max(gr.norm().item() for gr in grads_ref.values())
+    nworst, nname = 0.0, ""
+    for k, gr in grads_ref.items():                       # gradient NORMS of the parameters that carry the gradient (> 5 % of the largest)
+        if gr.norm().item() > 0.05 * gmax:
+            e = abs(G1[k].norm().item() - gr.norm().item()) / gr.norm().item()
+            if e > nworst:
+                nworst, nname = e, k
+    res.append(_res(tag + ".b1.gradnorms_rel_worst", nworst, 2e-3 if f32 else 0.15, extra=nname))
+    # Biases of convolutions that feed an InstanceNorm directly (the shortcut conv, the first conv of a residual block, the two
+    # attention branches whose sum is normalised) have a true gradient of exactly zero: what the oracle and the device hold there is the
+    # rounding noise of 0.5 M-term sums (1e-4 on the CPU side at this size).  They are checked to BE noise on both sides; every other
+    # parameter against max(|g_ref|, floor * the largest gradient norm) - the fp32 noise of these sums is ~1e-5 of the largest norm.
+    import re
+    zero = re.compile(r".*(\.shortcut\.0\.bias|\.block\.[02]\.block\.0\.bias|\.conv_(encoder|decoder)\.2\.bias)$")
+    worst, wname, zworst, zname = 0.0, "", 0.0, ""
+    for k, gr in grads_ref.items():
+        if zero.match(k):
+            e = max(G1[k].norm().item(), gr.norm().item()) / gmax
+            if e > zworst:
+                zworst, zname = e, k
+            continue
+        e = (G1[k] - gr).norm().item() / max(gr.norm().item(), floor * gmax)
+        if e > worst:
+            worst, wname = e, k
+    res.append(_res(tag + ".b1.grads_rel_l2_worst", worst, 2e-2 if f32 else 0.7, extra=wname))
+    res.append(_res(tag + ".b1.zero_gradient_biases_are_noise", zworst, 1e-3 if f32 else 5e-2, extra=zname))
+    lo2, loss2, G2 = step(x, tgt)
+    lo1b, loss1b, G1b = step(x[1:2], tgt[1:2])
+    res.append(_res(tag + ".b2.logits_equal_batch1_runs", int((lo2[0] != lo1[0]).sum()) + int((lo2[1] != lo1b[0]).sum()), 0))
+    res.append(_res(tag + ".b2.loss", abs(loss2 - (loss1 + loss1b) / 2), 1e-6 if f32 else 1e-5))
+    worst, wname = 0.0, ""
+    gmax2 = max(v.norm().item() for v in G2.values())
+    for k in G2:
+        mean = (G1[k] + G1b[k]) / 2
+        e = (G2[k] - mean).norm().item() / max(mean.norm().item(), floor * gmax2)
+        if e > worst:
+            worst, wname = e, k
+    res.append(_res(tag + ".b2.grads_vs_mean_of_batch1_grads", worst, 2e-3 if f32 else 2e-2, extra=wname))
+    return res
+
+
 def check_instance_loss():
     """biapy_amd.losses.InstanceChannelsLoss (B, C, D channels; fused tanh + BCE / MSE / L1) against the reference's own
     instance_segmentation_loss outputs (tests/golden/losses_golden.npz): value and gradient w.r.t. the raw logits."""

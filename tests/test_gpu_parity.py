@@ -1055,6 +1055,12 @@ def test_resunetpp_matches_reference_fixture(K, resunetpp_golden, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_resunetpp_cfg4_at_the_benched_shape(K, dtype):
+    """cfg 4 (ResUNet++ 80^3, fm 16-32-64-128-256) at its own size against the CPU oracle; batch 2 against its batch-1 runs."""
+    _assert_all(K.check_resunetpp_cfg4_shape(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("tag", ["pre122", "pre232", "post222", "post122"])
 def test_resunet_super_resolution_paths(K, resunet_sr_golden, tag, dtype):
     """Row S: ResUNet pre / post up-sampling (the 3-D SR route that works in the reference) vs the reference's own outputs."""
