@@ -23,6 +23,9 @@ namespace {
 #ifndef BPX_DGRAD_BIG_OCC
 #define BPX_DGRAD_BIG_OCC 4
 #endif
+#ifndef BPX_DGRAD_PK_EPI
+#define BPX_DGRAD_PK_EPI 1
+#endif
 constexpr int lp_occ(int vox, int ns, int epi, int actk) {
   return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2
          : (ns == 1 && vox <= 256)                                                                 ? 4
@@ -356,7 +359,38 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         const int b = (NS > 1) ? (ns & 1) : 0;
         if (ns + 1 < NS) fetch(ns + 1, (b ^ 1) & (NS > 1 ? 1 : 0));
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        if (has_t) {
+        if (has_t && ACTK == 1 && BPX_DGRAD_PK_EPI) {
+          // ELU, two adjacent channels (r, r + 1: neighbouring accumulator registers, the two halves of one t word) at a time so that the
+          // arithmetic packs (v_pk_fma / v_pk_mul / v_pk_add_f32):
+          //   u = scale*t + shift, xhat = rstd*t - mean*rstd, ELU'(u) = min(exp(u), 1) = med3(exp(u), 0, 1), g = acc * ELU'(u),
+          //   S1 += g, S2 += g * xhat
+          // instead of compare + select, three separate multiplies and the (t - mean) * rstd form per element; out-of-volume voxels of
+          // edge tiles are masked by a 0 / 1 factor
+          {
+#pragma unroll
+            for (int rp = 0; rp < 4; rp += 2) {
+              const f32x4_t ra = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + rp]);
+              const f32x4_t rb = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + rp + 1]);
+              const f32x2_t sc2{ra[2], rb[2]}, sh2{ra[3], rb[3]}, rs2{ra[1], rb[1]}, nm2{-ra[0] * ra[1], -rb[0] * rb[1]};
+              f32x2_t s1p{0.f, 0.f}, s2p{0.f, 0.f};
+#pragma unroll
+              for (int ms = 0; ms < MS; ++ms) {
+                const uint32_t w = tv[b][ms][rp >> 1];
+                const f32x2_t tt{lo16<T>(w), hi16<T>(w)};
+                const f32x2_t u = __builtin_elementwise_fma(sc2, tt, sh2);
+                const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
+                const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
+                f32x2_t a{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
+                const bool in = okzx && RS * ms < yrem;            // out-of-volume voxels of edge tiles carry no gradient
+                const f32x2_t gv = in ? f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a : f32x2_t{0.f, 0.f};
+                acc[ms][ns][rp] = gv[0]; acc[ms][ns][rp + 1] = gv[1];
+                s1p = s1p + gv;
+                s2p = __builtin_elementwise_fma(gv, xh, s2p);
+              }
+              s1[rp] = s1p[0]; s1[rp + 1] = s1p[1]; s2[rp] = s2p[0]; s2[rp + 1] = s2p[1];
+            }
+          }
+        } else if (has_t) {
           // channel by channel (one {mean, rstd, scale, shift} record live at a time), gradients replace acc in place
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
