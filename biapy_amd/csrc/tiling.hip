@@ -452,7 +452,8 @@ __global__ void __launch_bounds__(256) merge3d_row_kernel(const EI* __restrict__
   // vector L1 instead (four strided dword loads per patch: 2.73 ms - the texture path is the bottleneck then), and a
   // workgroup-per-output-row variant with the row arithmetic on the scalar unit (2.16 ms), and four workgroups per CU instead of three
   // (__launch_bounds__(256, 4), with the slot records slimmed to values + mask: 88 B/lane of scratch and 2.72 ms - the 141 VGPRs are the
-  // nine loads in flight per thread, which is what the kernel lives on).
+  // nine loads in flight per thread, which is what the kernel lives on), and patches placed 64 ... 65,728 elements further apart than their
+  // 8 MiB (a power of two: would the up to 27 simultaneous gathers meet on the same HBM channels?): 1.77 ms at every padding - they do not.
   __shared__ float swx[MERGE_WXMAX];                              // (the launcher checks gx.patch <= MERGE_WXMAX)
   for (int i = threadIdx.x; i < gx.patch; i += 256) swx[i] = wx[i];
   __syncthreads();
