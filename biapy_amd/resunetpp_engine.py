@@ -127,9 +127,6 @@ class ResUNetPPEngine(ResUNetEngine):
     def _ones_bc(self, C):
         return self._c(("ones_bc", self._B, C), lambda: torch.ones((self._B, C), dtype=torch.float32, device=self._dev))
 
-    def _vec(self, C, val):
-        return self._c(("vec", C, val), lambda: torch.full((C,), float(val), dtype=torch.float32, device=self._dev))
-
     def _accum(self, v: _V, g: torch.Tensor, c0: int = 0) -> None:
         """v.grad += g[..., c0:c0+v.C].  A dense first contribution is adopted (the caller gives up ownership)."""
         dense = g.shape[-1] == v.C and c0 == 0
