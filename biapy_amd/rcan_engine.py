@@ -20,7 +20,7 @@ Weights are packed with one launch per step from the second step on (``ResUNetEn
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 
