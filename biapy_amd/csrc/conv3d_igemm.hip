@@ -94,7 +94,8 @@ __host__ __device__ constexpr int wreg_next(int s, int np, int per) {
   return k;
 }
 
-template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK>
+// TT: element type of the dgrad epilogue's activation operand t (BPX_MIX16: fp16 beside bf16 gradients), else T
+template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK, typename TT = T>
 __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
@@ -372,10 +373,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
           }
         } else {
           if (p.t_norm) {
-            const T* tp = reinterpret_cast<const T*>(p.t) + vox * (size_t)p.t_ld + (size_t)(co >> 4) * p.t_cs + (co & 15);
+            const TT* tp = reinterpret_cast<const TT*>(p.t) + vox * (size_t)p.t_ld + (size_t)(co >> 4) * p.t_cs + (co & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float tv = Tr::ld(tp + r);
+              float tv = ElemTraits<TT>::ld(tp + r);
               float u = fmaf(rec[r].scale, tv, rec[r].shift);
               v[r] = acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act);
               float xh = (tv - rec[r].mean) * rec[r].rstd;
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, typename TT = T>
 int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   Conv3Params p = p0;
   int tilesZ = cdiv(p.D, c.tz);
@@ -436,8 +437,8 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
 #define L(TZ, TY, TX, NS)                                                        \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
-    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1><<<grid, 256, 0, s>>>(p);    \
-    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0><<<grid, 256, 0, s>>>(p);        \
+    if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, TT><<<grid, 256, 0, s>>>(p);    \
+    else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0, TT><<<grid, 256, 0, s>>>(p);        \
     return 0;                                                                    \
   }
   if constexpr (sizeof(T) == 2) {  // the 512-voxel tile's fp32 halo (69 KB) exceeds static LDS; bf16 only
@@ -565,7 +566,9 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
                                 const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, bpx_stream_t stream) {
   BPX_CHECK(dy.cs == 0 && g.cs == 0, "bpx_conv3d_dgrad: only t may be chunk-planar");
   const char* fn = "bpx_conv3d_dgrad";
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16, "%s: dtype must be BF16, F32 or MIX16 (t fp16; dy, weights, g bf16)", fn);
+  const bool mix = dtype == BPX_MIX16;
+  if (mix) dtype = BPX_BF16;
   int es = (int)dtype_size(dtype);
   if (check_tensor(fn, "dy", dy, es, true) || check_tensor(fn, "g", g, es, true)) return 1;
   BPX_CHECK(w_packed_T_d != nullptr, "%s: packed weights are null", fn);
@@ -581,8 +584,10 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.t = t.ptr; p.t_ld = t.ld; p.t_norm = t_norm_d; p.t_act = act;
   if (t_norm_d && check_planar(fn, "t", t, N, D, H, W)) return 1;
   p.x_cs = 16; p.sc_cs = 16; p.y_cs = 16; p.t_cs = chunk_stride(t);
+  p.t_f16 = (mix && t_norm_d) ? 1 : 0;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
   int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
+           : p.t_f16             ? launch_conv3<uint16_t, EPI_DGRAD, f16_t>(p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream)
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);

@@ -52,9 +52,11 @@ constexpr int lp_ahalf(int ms, int ns, int epi) { return (ms > 4 && ns == 1 && e
 //     748 us, dgrad 16->48 863 -> 899, 16->16 237 -> 234, train step 10.41 -> 10.48 ms) - this kernel waits, it does not issue-bind.
 // F16: fp16 storage instead of bf16 (inference: forward instances only) - same instruction counts (v_cvt_f32_f16 / v_cvt_pk_f16_f32 in
 // place of the shifts / v_cvt_pk_bf16_f32, v_mfma_f32_16x16x32_f16)
-template <int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool F16 = false>
+// TF16 (dgrad, BPX_MIX16): the activation operand t of the epilogue is fp16 while dy, the weights and g stay bf16
+template <int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool F16 = false, bool TF16 = F16>
 __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv3_lp_kernel(const Conv3Params p) {
   using T = typename std::conditional<F16, f16_t, uint16_t>::type;
+  using TT = typename std::conditional<TF16, f16_t, uint16_t>::type;
   constexpr int KPL = 8, VB = 32;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int STEPS = 14, QPAD = 56;
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
               for (int ms = 0; ms < MS; ++ms) {
                 const uint32_t w = tv[b][ms][rp >> 1];
-                const f32x2_t tt{lo16<T>(w), hi16<T>(w)};
+                const f32x2_t tt{lo16<TT>(w), hi16<TT>(w)};
                 const f32x2_t u = __builtin_elementwise_fma(sc2, tt, sh2);
                 const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
                 const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
               const uint32_t w = tv[b][ms][r >> 1];
-              const float tf = (r & 1) ? hi16<T>(w) : lo16<T>(w);
+              const float tf = (r & 1) ? hi16<TT>(w) : lo16<TT>(w);
               const float u = fmaf(rec[2], tf, rec[3]);
               const float gv = (okzx && RS * ms < yrem) ? acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act) : 0.f;
               acc[ms][ns][r] = gv;
@@ -473,6 +475,14 @@ int launch_lp(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
       if constexpr (EPI == EPI_FWD) {                                              \
         if (elu) conv3_lp_kernel<TZ, TY, TX, NS, EPI_FWD, 1, true><<<grid, 256, 0, s>>>(p);   \
         else conv3_lp_kernel<TZ, TY, TX, NS, EPI_FWD, 0, true><<<grid, 256, 0, s>>>(p);       \
+        return 0;                                                                  \
+      }                                                                            \
+      return 1;                                                                    \
+    }                                                                              \
+    if (p.t_f16) {                                                                 \
+      if constexpr (EPI == EPI_DGRAD) {                                            \
+        if (elu) conv3_lp_kernel<TZ, TY, TX, NS, EPI_DGRAD, 1, false, true><<<grid, 256, 0, s>>>(p);   \
+        else conv3_lp_kernel<TZ, TY, TX, NS, EPI_DGRAD, 0, false, true><<<grid, 256, 0, s>>>(p);       \
         return 0;                                                                  \
       }                                                                            \
       return 1;                                                                    \

@@ -29,6 +29,7 @@ struct Conv3Params {
   // chunk-planar tensors (bpx_tensor.cs)
   int x_cs, sc_cs, y_cs, t_cs;
   int f16;   // 16-bit storage is fp16 instead of bf16 (forward only)
+  int t_f16; // dgrad, BPX_MIX16: the activation operand `t` is fp16 while dy / weights / g are bf16
 };
 inline int chunk_stride(const bpx_tensor& t) { return t.cs ? (int)t.cs : 16; }
 

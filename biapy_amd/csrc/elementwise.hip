@@ -237,8 +237,9 @@ __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict__ g, int g_ld, const T* __restrict__ t, int t_ld,
+// TT: element type of the activation tensor t (BPX_MIX16: fp16 beside bf16 gradients), else T
+template <typename T, typename TT = T>
+__global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict__ g, int g_ld, const TT* __restrict__ t, int t_ld,
                                                              const bpx_nbwd_coef* __restrict__ coef, const T* __restrict__ addend,
                                                              int a_ld, T* __restrict__ dx, int dx_ld, int C, int64_t vps, int N) {
   // one sample per blockIdx.y; blockDim.x * gridDim.x is a multiple of G, so a thread keeps its channel group and holds its
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict
     u32x4_t tv = *reinterpret_cast<const u32x4_t*>(t + vox * t_ld + cg * KPL);
     float gf[KPL], tf[KPL], of[KPL];
     unpack16<T>(gv, gf);
-    unpack16<T>(tv, tf);
+    unpack16<TT>(tv, tf);
 #pragma unroll
     for (int e = 0; e < KPL; ++e) of[e] = ka[e] * gf[e] + kb[e] * tf[e] + kc[e];
     if (addend) {
@@ -519,8 +520,9 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, int x_cs, 
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, int x_ld, int x_cs, const T* __restrict__ dy, int dy_ld,
+// TX: element type of the pooled layer's INPUT x (BPX_MIX16: fp16 beside bf16 gradients), else T
+template <typename T, typename TX = T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const TX* __restrict__ x, int x_ld, int x_cs, const T* __restrict__ dy, int dy_ld,
                                                           const T* __restrict__ addend, int a_ld, T* __restrict__ dx, int dx_ld, int C,
                                                           int D, int H, int W, int sz, int N) {
   constexpr int KPL = ElemTraits<T>::KPL;
@@ -542,7 +544,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
       if (k >= 4 * sz) break;
       voxk[k] = (((size_t)n * D + sz * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
       u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + voxk[k] * x_ld + (size_t)((cg * KPL) >> 4) * x_cs + ((cg * KPL) & 15));
-      unpack16<T>(v, f[k]);
+      unpack16<TX>(v, f[k]);
 #pragma unroll
       for (int e = 0; e < KPL; ++e)
         if (f[k][e] > m[e]) { m[e] = f[k][e]; am[e] = k; }  // strict >: first maximum wins, as in PyTorch
@@ -610,8 +612,9 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const T* __restrict__ x, 
   }
 }
 
-template <typename T, int CIN, int COUT>
-__global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w, int Cout,
+// TX: element type of the head's input x (BPX_MIX16: fp16 beside the bf16 gradient dx), else T
+template <typename T, int CIN, int COUT, typename TX = T>
+__global__ void __launch_bounds__(256) head_bwd_kernel(const TX* __restrict__ x, int x_ld, const float* __restrict__ w, int Cout,
                                                        const float* __restrict__ dout, int64_t sn, int64_t sc, T* __restrict__ dx,
                                                        int dx_ld, float* __restrict__ dw, float* __restrict__ db, int64_t vps, int N) {
   constexpr int KPL = ElemTraits<T>::KPL;
@@ -630,7 +633,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float f[CIN], o[CIN];
 #pragma unroll
-    for (int q = 0; q < CIN / KPL; ++q) unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (size_t)i * x_ld + q * KPL), f + q * KPL);
+    for (int q = 0; q < CIN / KPL; ++q) unpack16<TX>(*reinterpret_cast<const u32x4_t*>(x + (size_t)i * x_ld + q * KPL), f + q * KPL);
 #pragma unroll
     for (int c = 0; c < CIN; ++c) o[c] = 0.f;
     int n = (int)(i / vps);
@@ -1075,6 +1078,15 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch b) {   
                 (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
+// BPX_MIX16 (fp16 forward / bf16 backward training): the forward operators' weights are fp16, the transposed (backward) operators' bf16
+__host__ __device__ inline bool mix_mode_is_bf16(int mode) { return mode == PK_K3_T || mode == PK_DENSE_T || mode == PK_CT_T || mode == PK_CT4_T; }
+__global__ void __launch_bounds__(256) pack_batch_mix_kernel(const PackBatch b) {   // blockIdx.y = job
+  const bpx_pack_job j = b.job[blockIdx.y];
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  if (mix_mode_is_bf16(j.mode)) pack_elems<uint16_t>(j.w_d, reinterpret_cast<uint16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[blockIdx.y], first, step);
+  else pack_elems<f16_t>(j.w_d, reinterpret_cast<f16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[blockIdx.y], first, step);
+}
+
 inline int64_t packed_elems(int mode, int Cin, int Cout, int dtype) {
   const int KPL = dtype == BPX_F32 ? 4 : 8, GPT = 16 / KPL;
   const int QPAD3 = ((27 * GPT + 3) / 4) * 4;
@@ -1418,7 +1430,7 @@ extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g
   const char* fn = "bpx_norm_bwd_apply";
   BPX_CHECK(g.ptr && t.ptr && dx.ptr && coef_d, "%s: null pointer", fn);
   BPX_CHECK(g.C == t.C && g.C == dx.C && g.C % 16 == 0, "%s: channel mismatch", fn);
-  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int kpl = (dtype == BPX_BF16 || dtype == BPX_MIX16) ? 8 : 4;
   int64_t total = (int64_t)N * voxels * (g.C / kpl);
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -1432,10 +1444,13 @@ extern "C" int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g
   if (dtype == BPX_BF16)
     norm_bwd_apply_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)g.ptr, g.ld, (const uint16_t*)t.ptr, t.ld, coef_d,
                                                                     (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, g.C, voxels, N);
+  else if (dtype == BPX_MIX16)   // t = the forward pass's fp16 tensor; g, addend, dx bf16
+    norm_bwd_apply_kernel<uint16_t, f16_t><<<grid, 256, 0, s>>>((const uint16_t*)g.ptr, g.ld, (const f16_t*)t.ptr, t.ld, coef_d,
+                                                                (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, g.C, voxels, N);
   else if (dtype == BPX_F32)
     norm_bwd_apply_kernel<float><<<grid, 256, 0, s>>>((const float*)g.ptr, g.ld, (const float*)t.ptr, t.ld, coef_d,
                                                                  (const float*)addend.ptr, addend.ld, (float*)dx.ptr, dx.ld, g.C, voxels, N);
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  else BPX_FAIL("%s: dtype must be BF16, F32 or MIX16", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -1725,17 +1740,20 @@ extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, 
   BPX_CHECK(x.ptr && dy.ptr && dx.ptr, "%s: null pointer", fn);
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   BPX_CHECK(x.C == dy.C && x.C == dx.C && x.C % 16 == 0, "%s: channel mismatch", fn);
-  int kpl = dtype == BPX_BF16 ? 8 : 4;
+  int kpl = (dtype == BPX_BF16 || dtype == BPX_MIX16) ? 8 : 4;
   int64_t total = (int64_t)N * (D / sz) * (H / 2) * (W / 2) * (x.C / kpl);
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
     maxpool_bwd_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, xcs, (const uint16_t*)dy.ptr, dy.ld,
                                                                  (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
+  else if (dtype == BPX_MIX16)   // x = the forward pass's fp16 tensor; dy, addend, dx bf16
+    maxpool_bwd_kernel<uint16_t, f16_t><<<grid_for(total), 256, 0, s>>>((const f16_t*)x.ptr, x.ld, xcs, (const uint16_t*)dy.ptr, dy.ld,
+                                                                        (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
   else if (dtype == BPX_F32)
     maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)x.ptr, x.ld, xcs, (const float*)dy.ptr, dy.ld, (const float*)addend.ptr,
                                                               addend.ld, (float*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  else BPX_FAIL("%s: dtype must be BF16, F32 or MIX16", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -1777,12 +1795,13 @@ extern "C" int bpx_head_bwd(int dtype, int64_t vps, int N, bpx_tensor x, const f
   hipStream_t s = (hipStream_t)stream;
   float* pw = reinterpret_cast<float*>(ws_d);
   float* pb = db_d ? pw + (size_t)blocks * Cout * x.C : nullptr;
-#define HL2(T, CIN, CO) head_bwd_kernel<T, CIN, CO><<<blocks, 256, 0, s>>>((const T*)x.ptr, x.ld, w_d, Cout, dout_d, sn, sc, (T*)dx.ptr, dx.ld, pw, pb, vps, N)
-#define HL(T, CIN) do { if (Cout == 1) HL2(T, CIN, 1); else if (Cout == 2) HL2(T, CIN, 2); else if (Cout == 3) HL2(T, CIN, 3); else HL2(T, CIN, 4); } while (0)
-  if (dtype == BPX_BF16) { if (x.C == 16) HL(uint16_t, 16); else HL(uint16_t, 32); }
-  else if (dtype == BPX_F32) { if (x.C == 16) HL(float, 16); else HL(float, 32); }
+#define HL2(T, CIN, CO, TX) head_bwd_kernel<T, CIN, CO, TX><<<blocks, 256, 0, s>>>((const TX*)x.ptr, x.ld, w_d, Cout, dout_d, sn, sc, (T*)dx.ptr, dx.ld, pw, pb, vps, N)
+#define HL(T, CIN, TX) do { if (Cout == 1) HL2(T, CIN, 1, TX); else if (Cout == 2) HL2(T, CIN, 2, TX); else if (Cout == 3) HL2(T, CIN, 3, TX); else HL2(T, CIN, 4, TX); } while (0)
+  if (dtype == BPX_BF16) { if (x.C == 16) HL(uint16_t, 16, uint16_t); else HL(uint16_t, 32, uint16_t); }
+  else if (dtype == BPX_MIX16) { if (x.C == 16) HL(uint16_t, 16, f16_t); else HL(uint16_t, 32, f16_t); }   // x fp16, dx bf16
+  else if (dtype == BPX_F32) { if (x.C == 16) HL(float, 16, float); else HL(float, 32, float); }
+  else BPX_FAIL("%s: dtype must be BF16, F32 or MIX16", fn);
 #undef HL2
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
 #undef HL
   BPX_LAUNCH_CHECK(fn);
   // dw[co][ci] flat = one "tap", one "input channel", Cout*Cin outputs; bias rows of Cout values
@@ -1862,7 +1881,8 @@ extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, in
   const char* fn = "bpx_pack_weight";
   BPX_CHECK(w_d && packed_d, "%s: null pointer", fn);
   BPX_CHECK(mode >= PK_K3 && mode <= PK_CT4_T, "%s: bad mode %d", fn, mode);
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16, "%s: dtype must be BF16, F16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16 || dtype == BPX_MIX16, "%s: dtype must be BF16, F16, F32 or MIX16", fn);
+  if (dtype == BPX_MIX16) dtype = mix_mode_is_bf16(mode) ? BPX_BF16 : BPX_F16;   // forward operators fp16, transposed (backward) operators bf16
   if (mode <= PK_K1) BPX_CHECK(Cin % 16 == 0 && Cout % 16 == 0, "%s: Cin/Cout must be multiples of 16", fn);
   if (mode == PK_K3_T) BPX_CHECK(Cout % 16 == 0, "%s: Cout must be a multiple of 16", fn);
   int64_t total = packed_elems(mode, Cin, Cout, dtype);
@@ -1876,7 +1896,7 @@ extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, in
 
 extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job* jobs, bpx_stream_t stream) {
   const char* fn = "bpx_pack_weights_batched";
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16, "%s: dtype must be BF16, F16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_F16 || dtype == BPX_MIX16, "%s: dtype must be BF16, F16, F32 or MIX16", fn);
   BPX_CHECK(count >= 0 && (count == 0 || jobs != nullptr), "%s: bad job list", fn);
   hipStream_t s = (hipStream_t)stream;
   for (int base = 0; base < count; base += 64) {
@@ -1894,6 +1914,7 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
     }
     dim3 grid(256, (unsigned)n);   // the largest operands (256x256x27) are ~1.8 M elements: 27 per thread
     if (dtype == BPX_BF16) pack_batch_kernel<uint16_t><<<grid, 256, 0, s>>>(b);
+    else if (dtype == BPX_MIX16) pack_batch_mix_kernel<<<grid, 256, 0, s>>>(b);
     else if (dtype == BPX_F16) pack_batch_kernel<f16_t><<<grid, 256, 0, s>>>(b);
     else pack_batch_kernel<float><<<grid, 256, 0, s>>>(b);
     BPX_LAUNCH_CHECK(fn);
@@ -2001,6 +2022,7 @@ extern "C" int bpx_upsample_c1_fwd(int dtype, int N, int D, int H, int W, int fz
   const int64_t total = (int64_t)N * D * fz * H * fy * W * fx;
   if (total == 0) return 0;
   if (dtype == BPX_BF16) upsample_c1_fwd_kernel<uint16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(img_d, w_d, bias_d, (uint16_t*)out16_d, D, H, W, fz, fy, fx, total);
+  else if (dtype == BPX_F16) upsample_c1_fwd_kernel<f16_t><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(img_d, w_d, bias_d, (f16_t*)out16_d, D, H, W, fz, fy, fx, total);
   else if (dtype == BPX_F32) upsample_c1_fwd_kernel<float><<<grid_for(total), 256, 0, (hipStream_t)stream>>>(img_d, w_d, bias_d, (float*)out16_d, D, H, W, fz, fy, fx, total);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);

@@ -141,7 +141,9 @@ struct PwParams {
 
 // PL: chunk-planar t (PW_CONV1) / y (PW_CONVT) operand.  A compile-time switch on purpose: with a run-time test the interleaved instance
 // of the 48-column GEMM went from 116 to 128 VGPRs and from 0.62 to 0.75 ms (cfg 2, level 0).
-template <typename T, int MS, int NS, int MODE, bool PL>
+// TT: element type of the t operand of PW_CONV1's fused InstanceNorm-backward affine (BPX_MIX16: the forward pass's fp16 activations beside
+// bf16 gradients), else T
+template <typename T, int MS, int NS, int MODE, bool PL, typename TT = T>
 __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL;
@@ -255,8 +257,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       if (p.coef) {
         float gq[NS][4], tq[NS][4];
         loadq<T, NS>(reinterpret_cast<const T*>(p.g) + ovox * (size_t)p.g_ld + co0, gq);
-        if (!PL) loadq<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
-        else loadq_planar<T, NS>(reinterpret_cast<const T*>(p.t) + ovox * (size_t)p.t_ld, co0, p.t_cs, tq);   // the decoder's concat buffer
+        if (!PL) loadq<TT, NS>(reinterpret_cast<const TT*>(p.t) + ovox * (size_t)p.t_ld + co0, tq);
+        else loadq_planar<TT, NS>(reinterpret_cast<const TT*>(p.t) + ovox * (size_t)p.t_ld, co0, p.t_cs, tq);   // the decoder's concat buffer
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -323,7 +325,7 @@ constexpr int PW_MS_CT = BPX_PW_MS_CT;   // the same for the transposed-conv for
 
 inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 : (ncols_per_group % 48 == 0) ? 3 : (ncols_per_group % 32 == 0) ? 2 : 1; }
 
-template <typename T, int MODE>
+template <typename T, int MODE, typename TT = T>
 int launch_pw(PwParams& p, int ns, hipStream_t s) {
   constexpr int MSK = (MODE == PW_CONVT) ? PW_MS_CT : PW_MS;
   if (p.vps >= (1ll << 31) - 64 * MSK) { bpx_set_error("pointwise kernels: more than 2^31 voxels per sample"); return 1; }
@@ -333,16 +335,16 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   const bool planar = (MODE == PW_CONV1 && p.coef != nullptr && p.t_cs != 16) || (MODE == PW_CONVT && p.y_cs != 16);
   if (MODE != PW_CONVTD && planar) {
     constexpr bool PL = MODE != PW_CONVTD;    // no planar instances of the transposed-conv dgrad
-    if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL><<<grid, 256, 0, s>>>(p);
-    else if (ns == 3) pw_kernel<T, MSK, 3, MODE, PL><<<grid, 256, 0, s>>>(p);
-    else if (ns == 2) pw_kernel<T, MSK, 2, MODE, PL><<<grid, 256, 0, s>>>(p);
-    else pw_kernel<T, MSK, 1, MODE, PL><<<grid, 256, 0, s>>>(p);
+    if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
+    else if (ns == 3) pw_kernel<T, MSK, 3, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
+    else if (ns == 2) pw_kernel<T, MSK, 2, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
+    else pw_kernel<T, MSK, 1, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     return 0;
   }
-  if (ns == 4) pw_kernel<T, MSK, 4, MODE, false><<<grid, 256, 0, s>>>(p);
-  else if (ns == 3) pw_kernel<T, MSK, 3, MODE, false><<<grid, 256, 0, s>>>(p);
-  else if (ns == 2) pw_kernel<T, MSK, 2, MODE, false><<<grid, 256, 0, s>>>(p);
-  else pw_kernel<T, MSK, 1, MODE, false><<<grid, 256, 0, s>>>(p);
+  if (ns == 4) pw_kernel<T, MSK, 4, MODE, false, TT><<<grid, 256, 0, s>>>(p);
+  else if (ns == 3) pw_kernel<T, MSK, 3, MODE, false, TT><<<grid, 256, 0, s>>>(p);
+  else if (ns == 2) pw_kernel<T, MSK, 2, MODE, false, TT><<<grid, 256, 0, s>>>(p);
+  else pw_kernel<T, MSK, 1, MODE, false, TT><<<grid, 256, 0, s>>>(p);
   return 0;
 }
 
@@ -361,7 +363,9 @@ extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return (in
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                         bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y, bpx_tensor y2,
                         bpx_stream_t stream) {
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16, "%s: dtype must be BF16, F32 or MIX16 (t fp16, everything else bf16)", fn);
+  const bool mix = dtype == BPX_MIX16 && coef_d != nullptr;
+  if (dtype == BPX_MIX16) dtype = BPX_BF16;
   int es = (int)dtype_size(dtype);
   if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
   BPX_CHECK(w_packed_d, "%s: weights null", fn);
@@ -382,7 +386,8 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
             (long long)N * vps);
   p.addend = addend.ptr; p.addend_ld = addend.ld;
   int ns = pw_ns(ncols);
-  if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
+  if ((mix ? launch_pw<uint16_t, PW_CONV1, f16_t>(p, ns, (hipStream_t)stream)
+       : dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -31,6 +31,7 @@ struct WgradParams {
   int N, D, H, W;          // logical voxel grid of the reduction
   const void* x; int x_ld; int Cin; const bpx_norm_rec* in_norm; int act;
   int x_cs;                // elements between the 16-channel chunks of an x voxel: 16, or the plane size of a chunk-planar tensor
+  int x_f16;               // BPX_MIX16: x (the forward pass's activation tensor) is fp16; it is converted to bf16 while it is staged, dy is bf16
   const void* dy; int dy_ld; int Cout; int dy_vs; int dy_oz, dy_oy, dy_ox;  // dy voxel = vs*v + off (ConvTranspose)
   int dy_vz;               // z stride of that mapping (0 = same as dy_vs): kernel (1,2,2) has vz = 1
   float* part;                                   // [groups][taps][Cin][Cout] per-block partial sums (workspace)
@@ -229,11 +230,17 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       const int idx = u * 256 + tid;
       if (idx < HV * GPT) {
         u32x4_t v = pa[u];
-        if (p.in_norm && ((va >> u) & 1u)) {
+        if ((p.in_norm || (BF && p.x_f16)) && ((va >> u) & 1u)) {
           float f[KPL];
-          unpack16<T>(v, f);
+          if constexpr (BF) {   // fp16 activations beside bf16 gradients (uniform switch): convert on the way to the bf16 MFMA operand
+            if (p.x_f16) unpack16<f16_t>(v, f); else unpack16<T>(v, f);
+          } else {
+            unpack16<T>(v, f);
+          }
+          if (p.in_norm) {
 #pragma unroll
-          for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, ACTK>(fmaf(psc[e], f[e], psh[e]), p.act);
+            for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, ACTK>(fmaf(psc[e], f[e], psh[e]), p.act);
+          }
           v = pack16<T>(f);
         }
         *reinterpret_cast<u32x4_t*>(sA + (size_t)idx * 16) = v;
@@ -357,9 +364,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // copy.  The activation fragment of a K-chunk is then shared by all taps; each tap reads its own shifted dy fragment.
 // Lean schedule as in conv3d_lean.hip: no register prefetch across the MFMA phase, <= 128 (NS=1) / 168 VGPRs, 29 / 50 KB
 // LDS -> 4 / 3 workgroups per CU; 32-bit byte offsets; per-tile index math reduced to base + per-lane constants.
-template <int NS, int ACTK>
+template <int NS, int ACTK, bool XF16 = false>
 __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const WgradParams p) {
   using T = uint16_t;
+  using TXE = typename std::conditional<XF16, f16_t, uint16_t>::type;   // element type of x (BPX_MIX16: fp16)
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int KPL = 8, VBA = 32, CB = 16 * NS, VBG = CB * 2, PPVG = 2 * NS;
@@ -482,11 +490,14 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
       u32x4_t v = pa[u];
-      if (p.in_norm && oka[u]) {
+      if ((p.in_norm || XF16) && oka[u]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float a = fmaf(psc[2 * q], bf16lo(v[q]), psh[2 * q]), b = fmaf(psc[2 * q + 1], bf16hi(v[q]), psh[2 * q + 1]);
-          act_pair<ACTK>(a, b, p.act);
+          float a = lo16<TXE>(v[q]), b = hi16<TXE>(v[q]);
+          if (p.in_norm) {
+            a = fmaf(psc[2 * q], a, psh[2 * q]); b = fmaf(psc[2 * q + 1], b, psh[2 * q + 1]);
+            act_pair<ACTK>(a, b, p.act);
+          }
           v[q] = cvt_pk_bf16(a, b);
         }
       }
@@ -667,8 +678,9 @@ __device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const uns
   }
 }
 
-template <int MC, int ACTK>
+template <int MC, int ACTK, bool XF16 = false>
 __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_kernel(const WgradParams p) {
+  using TXE = typename std::conditional<XF16, f16_t, uint16_t>::type;   // element type of x (BPX_MIX16: fp16)
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int KPL = 8, VBA = 32, CB = 16, VBG = CB * 2, PPVG = 2;
@@ -801,11 +813,14 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
 #pragma unroll
       for (int u = 0; u < NPA; ++u) {
         u32x4_t v = pa[c][u];
-        if (p.in_norm && oka[u]) {
+        if ((p.in_norm || XF16) && oka[u]) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float a = fmaf(psc[2 * q], bf16lo(v[q]), psh[2 * q]), b = fmaf(psc[2 * q + 1], bf16hi(v[q]), psh[2 * q + 1]);
-            act_pair<ACTK>(a, b, p.act);
+            float a = lo16<TXE>(v[q]), b = hi16<TXE>(v[q]);
+            if (p.in_norm) {
+              a = fmaf(psc[2 * q], a, psh[2 * q]); b = fmaf(psc[2 * q + 1], b, psh[2 * q + 1]);
+              act_pair<ACTK>(a, b, p.act);
+            }
             v[q] = cvt_pk_bf16(a, b);
           }
         }
@@ -901,6 +916,10 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
 
     u32x4_t pa = u32x4_t{0u, 0u, 0u, 0u};
     if (full || (z0 + taz < D && y0 + tay < H && x0 + tax < W)) pa = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a));
+    if (p.x_f16) {   // BPX_MIX16 (uniform): x is the forward pass's fp16 tensor, the MFMA operands are bf16
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pa[q] = cvt_pk_bf16(lo16<f16_t>(pa[q]), hi16<f16_t>(pa[q]));
+    }
     __syncthreads();  // previous tile's MFMA phase is done with LDS
     *reinterpret_cast<u32x4_t*>(sA + (size_t)tid * 16) = pa;
 #pragma unroll
@@ -1186,18 +1205,28 @@ int launch_wgrad_sd(const WgradParams& p0, WCfg& c, hipStream_t s) {
     p.groups = q.groups;
     p.dbpart = p.part + (size_t)p.groups * 27 * p.Cin * p.Cout;
     dim3 gridm((unsigned)(((c.groups + 7) & ~7) * (nchunks / mc) * nb));
-    if (mc == 1) { if (elu) wgrad_sdm_kernel<1, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<1, 0><<<gridm, 256, 0, s>>>(p); }
-    else if (mc == 2) { if (elu) wgrad_sdm_kernel<2, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<2, 0><<<gridm, 256, 0, s>>>(p); }
-    else if (mc == 3) { if (elu) wgrad_sdm_kernel<3, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<3, 0><<<gridm, 256, 0, s>>>(p); }
-    else return 1;
-    return 0;
+#define SDM(MC_)                                                                                   \
+    if (mc == MC_) {                                                                               \
+      if (p.x_f16) { if (elu) wgrad_sdm_kernel<MC_, 1, true><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<MC_, 0, true><<<gridm, 256, 0, s>>>(p); } \
+      else { if (elu) wgrad_sdm_kernel<MC_, 1><<<gridm, 256, 0, s>>>(p); else wgrad_sdm_kernel<MC_, 0><<<gridm, 256, 0, s>>>(p); }                     \
+      return 0;                                                                                    \
+    }
+    SDM(1) SDM(2) SDM(3)
+#undef SDM
+    return 1;
   }
   p.groups = c.groups;
   p.dbpart = p.part + (size_t)p.groups * 27 * p.Cin * p.Cout;
   dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
-  if (ns == 1) { if (elu) wgrad_sd_kernel<1, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<1, 0><<<grid, 256, 0, s>>>(p); }
-  else { if (elu) wgrad_sd_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<2, 0><<<grid, 256, 0, s>>>(p); }
-  return 0;
+#define SD(NS_)                                                                                    \
+  if (ns == NS_) {                                                                                 \
+    if (p.x_f16) { if (elu) wgrad_sd_kernel<NS_, 1, true><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<NS_, 0, true><<<grid, 256, 0, s>>>(p); } \
+    else { if (elu) wgrad_sd_kernel<NS_, 1><<<grid, 256, 0, s>>>(p); else wgrad_sd_kernel<NS_, 0><<<grid, 256, 0, s>>>(p); }                     \
+    return 0;                                                                                      \
+  }
+  SD(1) SD(2)
+#undef SD
+  return 1;
 }
 
 int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int64_t ws_bytes, hipStream_t s) {
@@ -1266,7 +1295,9 @@ extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   BPX_CHECK(x.cs == 0 || (x.ld >= 16 && x.cs % 8 == 0 && x.cs >= ((int64_t)N * D * H * W - 1) * x.ld + 16 && x.cs * (x.C / 16) < (1ll << 31)),
             "bpx_conv3d_wgrad: bad chunk stride %lld", (long long)x.cs);
   const char* fn = "bpx_conv3d_wgrad";
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16, "%s: dtype must be BF16, F32 or MIX16 (x fp16, dy bf16)", fn);
+  const bool mix = dtype == BPX_MIX16;
+  if (mix) dtype = BPX_BF16;
   BPX_CHECK(k == 1 || k == 3, "%s: k must be 1 or 3", fn);
   BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
@@ -1274,6 +1305,7 @@ extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.N = N; p.D = D; p.H = H; p.W = W;
   p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = in_norm_d; p.act = act;
   p.x_cs = x.cs ? (int)x.cs : 16;
+  p.x_f16 = mix ? 1 : 0;
   p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 1;
   int taps = k * k * k;
   p.dw = dw_d; p.si = taps; p.sj = (int64_t)x.C * taps; p.st = 1; p.off = 0;  // (Cout,Cin,k,k,k)
@@ -1285,7 +1317,9 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
                                       void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
   BPX_CHECK(x.cs == 0 && dy.cs == 0, "bpx_convT3d_k2s2_wgrad: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_convT3d_k2s2_wgrad";
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16, "%s: dtype must be BF16, F32 or MIX16 (x fp16, dy bf16)", fn);
+  const bool mix = dtype == BPX_MIX16;
+  if (mix) dtype = BPX_BF16;
   BPX_CHECK(sz == 1 || sz == 2, "%s: z stride must be 1 or 2 (got %d)", fn, sz);
   const int nsub = 4 * sz;
   BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
@@ -1296,7 +1330,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     BPX_CHECK(ws_d != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
-    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.x_cs = 16;
+    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.x_cs = 16; p.x_f16 = mix ? 1 : 0;
     p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C;
     p.part = reinterpret_cast<float*>(ws_d); p.db = db_d;
     p.dbpart = p.part + (size_t)c.groups * nsub * x.C * dy.C;
@@ -1315,7 +1349,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   for (int sub = 0; sub < nsub; ++sub) {
     WgradParams p{};
     p.N = N; p.D = D; p.H = H; p.W = W;
-    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = nullptr; p.act = 0; p.x_cs = 16;
+    p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = nullptr; p.act = 0; p.x_cs = 16; p.x_f16 = mix ? 1 : 0;
     p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 2; p.dy_vz = sz;
     p.dy_oz = (sub >> 2) & 1; p.dy_oy = (sub >> 1) & 1; p.dy_ox = sub & 1;
     p.dw = dw_d; p.si = (int64_t)dy.C * nsub; p.sj = nsub; p.st = 0; p.off = sub;  // (Cin,Cout,sz,2,2)

@@ -79,6 +79,17 @@ class NetConfig:
         self.depth = len(fm) - 1
 
 
+def set_compute_dtype(model, dtype: torch.dtype) -> torch.dtype:
+    """Switch the storage type of a drop-in model (workflow.SlidingWindowPredictor, train_engine.evaluate); returns the previous one.
+    Refused up front - not by a kernel in the middle of a predict call - when the model's engine has no kernels for it."""
+    ok = getattr(model, "supported_compute_dtypes", (torch.float32, torch.bfloat16))
+    if dtype not in ok:
+        raise NotImplementedError(f"{type(model).__name__}: compute_dtype={dtype} is not implemented for this model (supported: {', '.join(str(d) for d in ok)})")
+    keep = model.compute_dtype
+    model.compute_dtype = dtype
+    return keep
+
+
 def needs_lift(w: torch.Tensor) -> bool:
     return w.dim() == 4 or (w.dim() == 5 and w.shape[2] == 1 and w.shape[-1] == 3)
 
@@ -169,9 +180,16 @@ class ResUNetEngine:
         assert dtype in (torch.bfloat16, torch.float32, torch.float16)
         self.cfg = cfg
         self.dtype = dtype
-        # float16 = the same 16 bits per element with an 11-bit mantissa: INFERENCE ONLY (forward kernels; gradients would need loss
-        # scaling) - the mode whose Dice agrees with the fp32 reference to < 1e-4 at the speed of the bf16 mode
+        # float16 = the same 16 bits per element with an 11-bit mantissa: the mode whose forward agrees with the fp32 reference to Dice
+        # delta < 1e-4 at the speed of the bf16 mode.  Its TRAINING form is mixed (BPX_MIX16): the forward pass and every stored
+        # activation are fp16, every gradient tensor and the backward MFMA operands are bf16 (fp32 exponent range: no loss scaling) -
+        # the backward kernels read the fp16 activations and convert on the way to their bf16 operands.
         self.dt = {torch.bfloat16: L.BF16, torch.float32: L.F32, torch.float16: L.F16}[dtype]
+        mixed = dtype == torch.float16
+        self.gdtype = torch.bfloat16 if mixed else dtype         # storage type of gradient tensors
+        self.gdt = L.BF16 if mixed else self.dt                  # dtype code of kernels that touch gradient tensors only
+        self.bdt = L.MIX16 if mixed else self.dt                 # dtype code of backward kernels that also read a forward activation
+        self.pdt = L.MIX16 if mixed else self.dt                 # weight packing: forward operators in the forward type, transposed ones in bf16
         self.act = L.ACT[cfg.activation]
         self._ws: Optional[torch.Tensor] = None
         self._side_stream = None
@@ -228,7 +246,7 @@ class ResUNetEngine:
         D, H, W = S
         nb = lib.bpx_conv3d_wgrad_workspace(B, D, H, W, x.C, dy.C, k)
         ws = self._workspace(nb, dev)
-        self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_wgrad(self.dt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db),
+        self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_wgrad(self.bdt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db),
                                                                     ws.data_ptr(), ws.numel(), s_)))
 
     # ------------------------------------------------------------------------------------------
@@ -282,7 +300,7 @@ class ResUNetEngine:
             w = P[name]
             jobs[q] = L.PackJob(w.data_ptr(), buf.data_ptr() + off * es, mode, cin, cout, 0)
             self._prepacked[(w.data_ptr(), mode)] = buf[off:off + sizes[q]]
-        L.check(lib.bpx_pack_weights_batched(self.dt, len(plan), C.cast(jobs, C.c_void_p), L.stream_ptr()))
+        L.check(lib.bpx_pack_weights_batched(self.pdt, len(plan), C.cast(jobs, C.c_void_p), L.stream_ptr()))
 
     def _begin_recorded_packs(self, P: Dict[str, torch.Tensor], train: bool, dev, cache_weights: bool) -> None:
         """For the tape engines (ResUNet++, RCAN), whose list of packed operands is not written down: the first step of a kind
@@ -316,7 +334,7 @@ class ResUNetEngine:
         wc = w.detach()
         if wc.dtype != torch.float32 or not wc.is_contiguous():
             wc = wc.float().contiguous()
-        L.check(lib.bpx_pack_weight(mode, wc.data_ptr(), cin, cout, self.dt, out.data_ptr(), L.stream_ptr()))
+        L.check(lib.bpx_pack_weight(mode, wc.data_ptr(), cin, cout, self.pdt, out.data_ptr(), L.stream_ptr()))
         if cache:
             self._pack_cache[key] = out
             self._pack_versions[key] = stamp
@@ -375,8 +393,6 @@ class ResUNetEngine:
         ``x_ndhwc``: the input already as a dense (B,Z,Y,X,C) tensor of the storage dtype (``x`` is then ignored); ``want_dx``: the
         backward also returns the gradient of that tensor under the key "__dx__" (super-resolution pre-up-sampling, resunet_sr)."""
         cfg = self.cfg
-        if save and self.dtype == torch.float16:
-            raise NotImplementedError("compute_dtype=torch.float16 is an inference mode (no backward kernels): train in bfloat16 or float32")
         if x_ndhwc is not None:
             assert x_ndhwc.is_cuda and x_ndhwc.dtype == self.dtype and x_ndhwc.dim() == 5 and x_ndhwc.is_contiguous() and cfg.in_ch != 1
             x = x_ndhwc.permute(0, 4, 1, 2, 3)           # only its shape is used below
@@ -542,12 +558,12 @@ class ResUNetEngine:
         dev = blk.h.device
         C1 = blk.cout
         vox = D * H * W
-        T = self.dtype
+        T = self.gdtype
         # conv2 weight/bias grad, shortcut weight grad
         self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev)
         if blk.first and self.cfg.in_ch == 1:
             ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
-            self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.dt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
+            self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.gdt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
                                                                             ws1.data_ptr(), ws1.numel(), s_)))
         else:
             self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
@@ -563,17 +579,17 @@ class ResUNetEngine:
         tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
         red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
         w2t = self._pack(P[k["w2"]], L.PK_K3_T, C1, C1, False)
-        L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
+        L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
                                      L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
                                           G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), C1, coef.data_ptr(), st))
-        L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g1), L.tview(blk.h), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
+        L.check(lib.bpx_norm_bwd_apply(self.bdt, B, vox, L.tview(g1), L.tview(blk.h), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         dH = L.tview(g1)
         # conv1
         if blk.first and self.cfg.in_ch == 1:
             wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(C1), dev)
-            self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), dH, G[k["w1"]].data_ptr(),
+            self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_c1_wgrad(self.gdt, B, D, H, W, img.data_ptr(), dH, G[k["w1"]].data_ptr(),
                                                                            G[k["b1"]].data_ptr(), wsc.data_ptr(), wsc.numel(), s_)))
             self._keep.append(g1)
             return
@@ -589,21 +605,21 @@ class ResUNetEngine:
         wsct = self._pack(P[k["wsc"]], L.PK_DENSE_T, Cx, C1, False)
         if has_norm:
             red0 = torch.empty((B, tiles0, 2, Cx), dtype=torch.float32, device=dev)
-            L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dH, w1t.data_ptr(), xv, blk.rec_x.data_ptr(), self.act, L.tview(g0),
+            L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dH, w1t.data_ptr(), xv, blk.rec_x.data_ptr(), self.act, L.tview(g0),
                                          red0.data_ptr(), st))
             coef0 = torch.empty((B, Cx, 4), dtype=torch.float32, device=dev)
             L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
                                               G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), Cx, coef0.data_ptr(), st))
             if isinstance(dx_out, tuple):   # decoder block: the gradient of the concatenated input leaves as its (up, skip) parts
                 assert dx_extra is None
-                L.check(lib.bpx_conv1x1_fwd_split(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
+                L.check(lib.bpx_conv1x1_fwd_split(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
                                                   L.NULL_T, dx_out[0], dx_out[1], st))
             else:
-                L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
+                L.check(lib.bpx_conv1x1_fwd(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
                                             dx_extra if dx_extra is not None else L.NULL_T, dx_out, st))
         else:
-            L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dH, w1t.data_ptr(), L.NULL_T, None, 0, L.tview(g0), None, st))
-            L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox, dOut, wsct.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.tview(g0), dx_out, st))
+            L.check(lib.bpx_conv3d_dgrad(self.gdt, B, D, H, W, dH, w1t.data_ptr(), L.NULL_T, None, 0, L.tview(g0), None, st))
+            L.check(lib.bpx_conv1x1_fwd(self.gdt, B, vox, dOut, wsct.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.tview(g0), dx_out, st))
 
     def backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
         self._keep = []   # buffers the side stream may still be reading; released after the final stream join
@@ -635,7 +651,7 @@ class ResUNetEngine:
         Lv = cfg.depth
         dev = dlogits.device
         st = L.stream_ptr()
-        T = self.dtype
+        T = self.gdtype
         names = list(P.keys())
         sizes = [P[n].numel() for n in names]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -654,17 +670,17 @@ class ResUNetEngine:
         hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
         hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
         hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
-        L.check(lib.bpx_head_bwd(self.dt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
+        L.check(lib.bpx_head_bwd(self.bdt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
                                  L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
         if cfg.post_up:
             dec_out, dup_feat = ctx["dec_out"], dfeat
             wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, D0, H0, W0, cfg.post_up, fm[0], fm[0])
             ws = self._workspace(wsn, dev)
-            L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, D0, H0, W0, cfg.post_up, L.tview(dec_out), L.tview(dup_feat), G["post_upsampling.weight"].data_ptr(),
+            L.check(lib.bpx_convT3d_k2s2_wgrad(self.bdt, B, D0, H0, W0, cfg.post_up, L.tview(dec_out), L.tview(dup_feat), G["post_upsampling.weight"].data_ptr(),
                                                G["post_upsampling.bias"].data_ptr(), ws.data_ptr(), ws.numel(), st))
             dfeat = torch.empty((B, D0, H0, W0, fm[0]), dtype=T, device=dev)
             wt = self._pack(P["post_upsampling.weight"], L.PK_CT_T if cfg.post_up == 2 else L.PK_CT4_T, fm[0], fm[0], False)
-            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, D0, H0, W0, cfg.post_up, L.tview(dup_feat), wt.data_ptr(), L.tview(dfeat), st))
+            L.check(lib.bpx_convT3d_k2s2_dgrad(self.gdt, B, D0, H0, W0, cfg.post_up, L.tview(dup_feat), wt.data_ptr(), L.tview(dfeat), st))
             self._keep.append(dup_feat)
         o = 0
         for h, oc in enumerate(cfg.out_channels):
@@ -688,10 +704,10 @@ class ResUNetEngine:
             wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, Sl[0], Sl[1], Sl[2], szl, Cup, Cup)
             ws = self._workspace(wsn, dev)
             self._run_side(dev, lambda s_, x_in=x_in, dUp=dUp, wk=wk, bk=bk, Sl=Sl, ws=ws, szl=szl: L.check(lib.bpx_convT3d_k2s2_wgrad(
-                self.dt, B, Sl[0], Sl[1], Sl[2], szl, L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), ws.data_ptr(), ws.numel(), s_)))
+                self.bdt, B, Sl[0], Sl[1], Sl[2], szl, L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), ws.data_ptr(), ws.numel(), s_)))
             dxin = torch.empty((B,) + Sl + (Cup,), dtype=T, device=dev)
             wt = self._pack(P[wk], L.PK_CT_T if szl == 2 else L.PK_CT4_T, Cup, Cup, False)
-            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Sl[0], Sl[1], Sl[2], szl, dUp, wt.data_ptr(), L.tview(dxin), st))
+            L.check(lib.bpx_convT3d_k2s2_dgrad(self.gdt, B, Sl[0], Sl[1], Sl[2], szl, dUp, wt.data_ptr(), L.tview(dxin), st))
             dOut = L.tview(dxin)
             keep.append(dxin)
         # ---- bottleneck -------------------------------------------------------------------------
@@ -703,7 +719,7 @@ class ResUNetEngine:
             Cup = fm[i + 1]
             # dOut_i = dSkip + unpool(dP); written in place over dSkip
             skipv = L.tview(dskip[i])
-            L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
+            L.check(lib.bpx_maxpool3d_bwd(self.bdt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
             if i > 0:
                 dPn = torch.empty((B,) + S[i] + (fm[i - 1],), dtype=T, device=dev)
                 self._block_bwd(P, G, blocks[i], B, skipv, img, st, None, L.tview(dPn))

@@ -144,7 +144,7 @@ class _ResUNetSRPreFn(torch.autograd.Function):
         B, D, H, W = ctx.img.shape
         nb = L.lib.bpx_upsample_c1_blocks(B * D * H * W)
         part = torch.empty((fz * fy * fx, nb, 2), dtype=torch.float32, device=dx16.device)
-        L.check(L.lib.bpx_upsample_c1_bwd(eng.dt, B, D, H, W, fz, fy, fx, ctx.img.data_ptr(), dx16.data_ptr(), part.data_ptr(), L.stream_ptr()))
+        L.check(L.lib.bpx_upsample_c1_bwd(eng.gdt, B, D, H, W, fz, fy, fx, ctx.img.data_ptr(), dx16.data_ptr(), part.data_ptr(), L.stream_ptr()))
         sums = part.to(torch.float64).sum(1)
         out = {}
         for n in ctx.names:
@@ -208,7 +208,7 @@ class ResUNet(nn.Module):
         contrast_proj_dim: int = 256,
         return_one_tensor: bool = False,
         conv_block_order: str = "conv_norm_act",
-        compute_dtype: torch.dtype = torch.bfloat16,
+        compute_dtype: torch.dtype = torch.float16,
     ):
         super().__init__()
         if len(output_channels) == 0:
@@ -306,15 +306,20 @@ class ResUNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def engine(self) -> ResUNetEngine:
+        # one engine per storage type: switching compute_dtype for an evaluation pass and back keeps both engines' packed-weight caches
         if self._engine is None or self._engine.dtype != self.compute_dtype:
-            self._engine = ResUNetEngine(self.cfg, self.compute_dtype)
+            if not hasattr(self, "_engines"):
+                self._engines = {}
+            if self.compute_dtype not in self._engines:
+                self._engines[self.compute_dtype] = ResUNetEngine(self.cfg, self.compute_dtype)
+            self._engine = self._engines[self.compute_dtype]
         return self._engine
 
     def train(self, mode: bool = True):
         """Entering training mode drops the packed / lifted weight copies the inference path keeps (they are also keyed by
         tensor version and by engine.weights_epoch(), which every graph replay of this package bumps)."""
-        if self._engine is not None:
-            self._engine.clear_caches()
+        for eng in getattr(self, "_engines", {}).values():
+            eng.clear_caches()
         return super().train(mode)
 
     def _named(self):
@@ -383,6 +388,8 @@ class ResUNet(nn.Module):
 
     def release_graphs(self) -> None:
         self._graphs = None
+
+    supported_compute_dtypes = (torch.float32, torch.bfloat16, torch.float16)   # float16: fp16 forward, bf16 gradients (engine.py)
 
     _HEAD_CODES = {"linear": 0, "ce_sigmoid": 1, "sigmoid": 1, "tanh": 2, "ce_softmax": 3, "softmax": 3}
 

@@ -435,7 +435,8 @@ def evaluate(
     keep_dtype = getattr(inner, "compute_dtype", None)
     switch = eval_dtype is not None and keep_dtype is not None and keep_dtype != eval_dtype
     if switch:
-        inner.compute_dtype = eval_dtype
+        from .engine import set_compute_dtype
+        set_compute_dtype(inner, eval_dtype)
     try:
         return _evaluate_pass(cfg, model, model_call_func, loss_function, metric_function, prepare_targets, epoch, data_loader, schedulers, sched_name,
                               loss_names, logger, device)

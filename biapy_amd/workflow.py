@@ -234,8 +234,8 @@ class SlidingWindowPredictor:
         Returns the blended probability volume (Z,Y,X,Cout)."""
         assert vol.is_cuda and vol.dim() == 4 and vol.dtype == torch.float32
         if self.compute_dtype is not None and getattr(self.model, "compute_dtype", self.compute_dtype) != self.compute_dtype:
-            keep = self.model.compute_dtype
-            self.model.compute_dtype = self.compute_dtype
+            from .engine import set_compute_dtype
+            keep = set_compute_dtype(self.model, self.compute_dtype)
             try:
                 return self.predict(vol, rank, world, gather, group, z_offset, full_z)
             finally:

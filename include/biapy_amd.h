@@ -24,7 +24,13 @@ extern "C" {
 
 typedef void* bpx_stream_t; /* hipStream_t */
 
-enum bpx_dtype { BPX_F32 = 0, BPX_BF16 = 1, BPX_F16 = 2, BPX_U8 = 3 };
+enum bpx_dtype { BPX_F32 = 0, BPX_BF16 = 1, BPX_F16 = 2, BPX_U8 = 3,
+                 /* BPX_MIX16: the mixed 16-bit TRAINING mode, accepted by the backward entry points only.  Activation tensors (the forward
+                  * pass's raw outputs: the `t` / `x` operands below) are fp16 - written by the BPX_F16 forward kernels, whose logits
+                  * agree with the fp32 reference to Dice delta < 1e-4 - while every GRADIENT tensor (dy, g, dx, addend) and the MFMA
+                  * operands of the backward kernels are bf16 (fp32 exponent range: no loss scaling).  Each backward entry says which of
+                  * its operands are activations. */
+                 BPX_MIX16 = 4 };
 enum bpx_act { BPX_ACT_NONE = 0, BPX_ACT_ELU = 1, BPX_ACT_RELU = 2, BPX_ACT_SILU = 3 };
 enum bpx_pad_mode { BPX_PAD_REFLECT = 0, BPX_PAD_ZEROS = 1 };
 
@@ -124,7 +130,8 @@ typedef struct bpx_tensor {
  *   mode 5 BPX_PK_CT     ConvTranspose3d (Cin,Cout,2,2,2) -> [ceil4(Cin/KPL)][8*Cout][KPL] (bpx_convT3d_k2s2_fwd)
  *   mode 6 BPX_PK_CT_T   same weight, dgrad operator   -> [8*Cout/KPL][Cin][KPL]           (bpx_convT3d_k2s2_dgrad)
  *   mode 7 / 8 BPX_PK_CT4 / _T   the same for the anisotropic kernel (1,2,2) (Z_DOWN = 1): 4 sub-positions instead of 8
- * KPL = 8 (bf16) / 4 (f32) elements per 16-byte lane operand; QPAD = 56 (bf16) / 108 (f32). */
+ * KPL = 8 (bf16) / 4 (f32) elements per 16-byte lane operand; QPAD = 56 (bf16) / 108 (f32).
+ * dtype BPX_MIX16: the forward operators (modes 0, 2, 3, 5, 7) are packed as fp16, the transposed / backward ones (1, 4, 6, 8) as bf16. */
 enum bpx_pack_mode { BPX_PK_K3 = 0, BPX_PK_K3_T = 1, BPX_PK_K1 = 2, BPX_PK_DENSE = 3, BPX_PK_DENSE_T = 4, BPX_PK_CT = 5, BPX_PK_CT_T = 6,
                      BPX_PK_CT4 = 7, BPX_PK_CT4_T = 8 };
 int64_t bpx_packed_weight_elems(int mode, int Cin, int Cout, int dtype);

@@ -27,7 +27,7 @@ def _res(name, err, tol, extra=""):
 
 
 def tdtype(dt):
-    return {L.BF16: torch.bfloat16, L.F16: torch.float16}.get(dt, torch.float32)
+    return {L.BF16: torch.bfloat16, L.F16: torch.float16, L.MIX16: torch.bfloat16}.get(dt, torch.float32)   # MIX16: a 16-bit container (packed weights)
 
 
 def rnd(t, dt):
@@ -653,6 +653,130 @@ def check_norm_pool_head(dt, seed=0):
     return res
 
 
+def check_mix16_kernels(S=(8, 16, 32), B=2, Cin=32, Cout=16, seed=0):
+    """BPX_MIX16 - the backward entry points of the mixed 16-bit training mode: ACTIVATION operands (t / x: what the fp16 forward pass
+    stored) are fp16, GRADIENT operands (dy, g, dx, addend) and the MFMA operands bf16.  Each entry against the fp32 PyTorch operator on
+    the same (rounded) inputs: conv dgrad (+ ELU', reductions), conv wgrad k = 3 / k = 1 with and without the fused normalisation, the
+    shortcut-dgrad GEMM with the InstanceNorm-backward affine, norm_bwd_apply, pooling backward, transposed-conv wgrad, head backward."""
+    D, H, W = S
+    vox = D * H * W
+    g = torch.Generator().manual_seed(seed)
+    A, G_ = L.F16, L.BF16                      # activation / gradient storage
+    st = L.stream_ptr()
+    tag = f"mix16[B{B} {S} {Cin}->{Cout}]"
+    res = []
+    rec_t, _, _ = make_recs(B, Cin, seed + 1)
+    # ---- dgrad: g = convT(dy, W) * ELU'(scale t + shift) ------------------------------------------------------------------
+    dy = rnd(torch.randn(B, D, H, W, Cout, generator=g), G_)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cout) ** 0.5
+    t = rnd(torch.randn(B, D, H, W, Cin, generator=g), A)
+    dA = ndhwc(F.conv_transpose3d(ncdhw(dy), rnd(w, G_), padding=1))
+    u = t * rec_t[:, None, None, None, :, 2] + rec_t[:, None, None, None, :, 3]
+    g_ref = dA * torch.where(u > 0, torch.ones_like(u), torch.exp(u))
+    xh = (t - rec_t[:, None, None, None, :, 0]) * rec_t[:, None, None, None, :, 1]
+    gd = torch.empty(B, D, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+    tiles = lib.bpx_conv3d_stats_tiles(G_, B, D, H, W, Cin)
+    red = torch.zeros(B, tiles, 2, Cin, dtype=torch.float32, device=DEV)
+    wpt = pack(w, L.PK_K3_T, Cin, Cout, L.MIX16)
+    dyd, td, recd = to_dev(dy, G_), to_dev(t, A), rec_t.to(DEV)
+    L.check(lib.bpx_conv3d_dgrad(L.MIX16, B, D, H, W, L.tview(dyd), wpt.data_ptr(), L.tview(td), recd.data_ptr(), 1, L.tview(gd), red.data_ptr(), st))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".dgrad", relerr(gd, g_ref), tol_for(G_)))
+    res.append(_res(tag + ".dgrad.reductions", relerr(red.sum(1).cpu(), torch.stack([g_ref.sum((1, 2, 3)), (g_ref * xh).sum((1, 2, 3))], 1)), 1e-2))
+    # the transposed pack of MIX16 is the bf16 pack, bit for bit; the forward pack the fp16 one
+    same_t = torch.equal(wpt.view(torch.int16), pack(w, L.PK_K3_T, Cin, Cout, L.BF16).view(torch.int16))
+    same_f = torch.equal(pack(w, L.PK_K3, Cin, Cout, L.MIX16).view(torch.int16), pack(w, L.PK_K3, Cin, Cout, L.F16).view(torch.int16))
+    res.append(_res(tag + ".pack_types", 0 if (same_t and same_f) else 1, 0))
+    # ---- wgrad, k = 3 with the fused normalise + ELU prologue, k = 1 raw (the shortcut) -----------------------------------------
+    for k, norm in ((3, True), (3, False), (1, False)):
+        x = t
+        a = _act_ref(x * rec_t[:, None, None, None, :, 2] + rec_t[:, None, None, None, :, 3], 1) if norm else x
+        a = rnd(a, G_)                                                    # the MFMA operand is bf16
+        wz = torch.zeros(Cout, Cin, k, k, k, requires_grad=True)
+        bz = torch.zeros(Cout, requires_grad=True)
+        F.conv3d(ncdhw(a), wz, bz, padding=k // 2).backward(ncdhw(dy))
+        dw = torch.full((Cout, Cin, k, k, k), 7.0, dtype=torch.float32, device=DEV)
+        db = torch.zeros(Cout, dtype=torch.float32, device=DEV)
+        ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, D, H, W, Cin, Cout, k)), dtype=torch.uint8, device=DEV)
+        L.check(lib.bpx_conv3d_wgrad(L.MIX16, B, D, H, W, L.tview(td), recd.data_ptr() if norm else None, 1 if norm else 0, L.tview(dyd), k,
+                                     dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        res.append(_res(tag + f".wgrad[k{k} norm={int(norm)}]", relerr(dw, wz.grad), 2e-3))
+        res.append(_res(tag + f".wgrad[k{k} norm={int(norm)}].bias", relerr(db, bz.grad), 2e-3))
+    # ---- shortcut dgrad GEMM + InstanceNorm-backward affine: dx = dOut W + a g + b t + c0 (t fp16, the rest bf16) -------------------
+    dOut = dy.reshape(B, vox, Cout)
+    wsc = torch.randn(Cout, Cin, generator=g) / Cout ** 0.5
+    gg = rnd(torch.randn(B, vox, Cin, generator=g), G_)
+    coef = torch.randn(B, Cin, 4, generator=g)
+    tt = t.reshape(B, vox, Cin)
+    y_ref = dOut @ rnd(wsc, G_) + coef[:, None, :, 0] * gg + coef[:, None, :, 1] * tt + coef[:, None, :, 2]
+    wpd = pack(wsc.view(Cout, Cin, 1, 1, 1), L.PK_DENSE_T, Cin, Cout, L.MIX16)
+    yd = torch.empty(B, vox, Cin, dtype=torch.bfloat16, device=DEV)
+    ggd, cd = to_dev(gg, G_), coef.to(DEV)
+    dOd = dyd.view(B, vox, Cout)
+    ttd = td.view(B, vox, Cin)
+    L.check(lib.bpx_conv1x1_fwd(L.MIX16, B, vox, L.tview(dOd), wpd.data_ptr(), None, L.tview(ggd), L.tview(ttd), cd.data_ptr(), L.NULL_T, L.tview(yd), st))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".conv1x1_affine", relerr(yd, y_ref), tol_for(G_)))
+    if Cin % 48 == 0:
+        lo = Cin * 2 // 3
+        y_lo = torch.empty(B, vox, lo, dtype=torch.bfloat16, device=DEV)
+        y_hi = torch.empty(B, vox, Cin - lo, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bpx_conv1x1_fwd_split(L.MIX16, B, vox, L.tview(dOd), wpd.data_ptr(), None, L.tview(ggd), L.tview(ttd), cd.data_ptr(), L.NULL_T,
+                                          L.tview(y_lo), L.tview(y_hi), st))
+        torch.cuda.synchronize()
+        res.append(_res(tag + ".conv1x1_affine.split_identical", 0 if torch.equal(torch.cat([y_lo, y_hi], -1).view(torch.int16), yd.view(torch.int16)) else 1, 0))
+    # ---- norm_bwd_apply: dx = a g + b t + c0 --------------------------------------------------------------------------------------
+    dxn = torch.empty(B, vox, Cin, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.bpx_norm_bwd_apply(L.MIX16, B, vox, L.tview(ggd), L.tview(ttd), cd.data_ptr(), L.NULL_T, L.tview(dxn), st))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".norm_bwd_apply", relerr(dxn, coef[:, None, :, 0] * gg + coef[:, None, :, 1] * tt + coef[:, None, :, 2]), tol_for(G_)))
+    # ---- pooling backward: the arg-max comes from the fp16 input, the gradient is bf16 -----------------------------------------------
+    for sz in (2, 1):
+        xr = ncdhw(t).requires_grad_(True)
+        y_ref = F.max_pool3d(xr, (sz, 2, 2))
+        dyp = rnd(torch.randn(B, D // sz, H // 2, W // 2, Cin, generator=g), G_)
+        add = rnd(torch.randn(B, D, H, W, Cin, generator=g), G_)
+        y_ref.backward(ncdhw(dyp))
+        dx = torch.empty(B, D, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+        dypd, addd = to_dev(dyp, G_), to_dev(add, G_)
+        L.check(lib.bpx_maxpool3d_bwd(L.MIX16, B, D, H, W, sz, L.tview(td), L.tview(dypd), L.tview(addd), L.tview(dx), st))
+        torch.cuda.synchronize()
+        res.append(_res(tag + f".maxpool_bwd[sz{sz}]", relerr(dx, rnd(ndhwc(xr.grad) + add, G_)), 1e-6))
+    # ---- transposed-conv wgrad: x fp16 (raw), dy bf16 ---------------------------------------------------------------------------
+    for sz in (2, 1):
+        wt = torch.zeros(Cin, Cin, sz, 2, 2, requires_grad=True)
+        bt = torch.zeros(Cin, requires_grad=True)
+        dyt = rnd(torch.randn(B, sz * D, 2 * H, 2 * W, Cin, generator=g), G_)
+        F.conv_transpose3d(ncdhw(rnd(t, G_)), wt, bt, stride=(sz, 2, 2)).backward(ncdhw(dyt))
+        dw = torch.zeros(Cin, Cin, sz, 2, 2, dtype=torch.float32, device=DEV)
+        db = torch.zeros(Cin, dtype=torch.float32, device=DEV)
+        ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, sz, Cin, Cin)), dtype=torch.uint8, device=DEV)
+        dytd = to_dev(dyt, G_)
+        L.check(lib.bpx_convT3d_k2s2_wgrad(L.MIX16, B, D, H, W, sz, L.tview(td), L.tview(dytd), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        res.append(_res(tag + f".convT_wgrad[sz{sz}]", relerr(dw, wt.grad), 2e-3))
+        res.append(_res(tag + f".convT_bgrad[sz{sz}]", relerr(db, bt.grad), 2e-3))
+    # ---- head backward: features fp16, feature gradient bf16 ----------------------------------------------------------------------
+    if Cin in (16, 32):
+        Co = 2
+        hw = torch.randn(Co, Cin, generator=g) * 0.3
+        fr = ncdhw(t).requires_grad_(True); hwr = hw.clone().requires_grad_(True); hbr = torch.zeros(Co, requires_grad=True)
+        lo_ref = F.conv3d(fr, hwr.view(Co, Cin, 1, 1, 1), hbr)
+        dlo = torch.randn(B, Co, D, H, W, generator=g)
+        lo_ref.backward(dlo)
+        dfe = torch.empty(B, D, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+        dhw = torch.zeros(Co, Cin, dtype=torch.float32, device=DEV); dhb = torch.zeros(Co, dtype=torch.float32, device=DEV)
+        dlo_d, hw_d = dlo.to(DEV).contiguous(), hw.to(DEV)
+        hws = torch.empty(lib.bpx_head_bwd_workspace(Cin, Co), dtype=torch.uint8, device=DEV)
+        L.check(lib.bpx_head_bwd(L.MIX16, vox, B, L.tview(td), hw_d.data_ptr(), Co, dlo_d.data_ptr(), Co * vox, vox, L.tview(dfe), dhw.data_ptr(),
+                                 dhb.data_ptr(), hws.data_ptr(), hws.numel(), st))
+        torch.cuda.synchronize()
+        res.append(_res(tag + ".head_bwd_dx", relerr(dfe, ndhwc(fr.grad)), tol_for(G_)))
+        res.append(_res(tag + ".head_bwd_dw", relerr(dhw, hwr.grad), 1e-4))
+    return res
+
+
 def check_planar_layouts(dt, S=(8, 16, 32), lean=False):
     """Chunk-planar operands (bpx_tensor.cs != 0, the layout of the decoder's concat buffers) against the ordinary interleaved layout:
     every entry point that accepts them must produce BIT-IDENTICAL results, the arithmetic does not change.  Covered: conv forward
@@ -795,7 +919,7 @@ def check_parameter_gradients_are_reproducible(dtype):
         torch.cuda.synchronize()
         runs.append({n: p.grad.clone() for n, p in m.named_parameters()})
     bad = [n for n in runs[0] if not (torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]))]
-    tag = "f32" if dtype == torch.float32 else "bf16"
+    tag = _mode(dtype)[0]
     return [_res(f"reproducible_grads[{tag}].params_that_differ", float(len(bad)), 0.5, extra=", ".join(bad[:8]))]
 
 
@@ -803,14 +927,13 @@ def check_parameter_gradients_are_reproducible(dtype):
 # Stated parity bar per storage mode (north_star: "Dice delta < 1e-4, integer label maps bit-exact"):
 #   f32 mode : |Dice delta| < 1e-4 against the fp32 CPU oracle and identical label maps except where the oracle's probability is
 #              within 1e-5 of the threshold;
-#   bf16 mode: the throughput mode.  bf16 storage, bf16 MFMA operands and bf16 packed weights each contribute (CPU emulation of the
-#              data path, scripts/bf16_error_budget.py: mean 0.6e-4, max 1.3e-4 over seeds on a trained network; fp32 weights
-#              alone still leave 0.7e-4), so the bar is STATED, not met: |Dice delta| < 3e-4 on a trained network, and label maps
-#              identical wherever the oracle's probability is more than BF16_UNDECIDED away from the threshold.
-BF16_DICE_TOL = 3e-4
+#   fp16 mode (compute_dtype=torch.float16, the ResUNet default and what bench.py times): forward pass and stored activations in fp16
+#              (11-bit mantissa), gradients and backward MFMA operands in bf16 (BPX_MIX16).  MEETS the north-star bar: |Dice delta| < 1e-4
+#              asserted, label maps identical wherever the oracle's probability is more than F16_UNDECIDED from 0.5.
+#   bf16 mode: the storage type of round 1-2, kept as the A/B baseline and for the engines whose backward is bf16-only.  Its forward
+#              cannot meet 1e-4 (bf16 storage, operands and weights contribute ~0.3e-4 each: scripts/bf16_error_budget.py), so NO Dice
+#              claim is made for it: its rows check logits / labels outside the undecided band only.
 BF16_UNDECIDED = 2e-2
-#   fp16 mode: inference only (compute_dtype=torch.float16: the same 16 bits per element, 11-bit mantissa).  MEETS the north-star bar:
-#              |Dice delta| < 1e-4 asserted, label maps identical wherever the oracle's probability is more than F16_UNDECIDED from 0.5.
 F16_UNDECIDED = 2.5e-3
 
 
@@ -820,11 +943,16 @@ def _mode(dtype):
         return "f32", 1e-5, 1e-4
     if dtype == torch.float16:
         return "f16", F16_UNDECIDED, 1e-4
-    return "bf16", BF16_UNDECIDED, BF16_DICE_TOL
+    return "bf16", BF16_UNDECIDED, None                      # no Dice claim in bf16 storage (see above)
 # Parameters whose true gradient is zero (a conv bias in front of an InstanceNorm) hold rounding noise on both sides; relative
 # gradient errors are therefore measured against max(|g_ref|, floor * largest gradient norm of the network).
 GRAD_FLOOR_F32 = 1e-3
 GRAD_FLOOR_BF16 = 5e-2
+# network-level tolerances per storage mode: max |logit error| / max |logit|, |loss error|, worst relative L2 error of a parameter
+# gradient.  fp16 mode: fp16 forward (logits ~1e-3), gradients carried in bf16 (same bar as the bf16 mode)
+LOGITS_TOL = {"f32": 2e-4, "bf16": 6e-2, "f16": 4e-3}
+LOSS_TOL = {"f32": 1e-5, "bf16": 2e-2, "f16": 2e-3}
+GRAD_TOL = {"f32": 2e-3, "bf16": 0.15, "f16": 0.15}
 
 
 def parity_rows(tag, logits, lo_ref, tgt, dtype, trained=False):
@@ -837,7 +965,7 @@ def parity_rows(tag, logits, lo_ref, tgt, dtype, trained=False):
     wrong = int(((lab_ref != lab_got) & ~near).sum())
     rows = [_res(tag + ".labels_away_from_threshold", wrong, 0,
                  extra=f"{int((lab_ref != lab_got).sum())} of {lab_ref.numel()} voxels differ in all, {int(near.sum())} lie within the undecided band")]
-    if f32 or trained:          # on a random-init network every probability sits at the threshold: Dice is only meaningful after training
+    if (f32 or trained) and dice_tol is not None:   # on a random-init network every probability sits at the threshold: Dice is only meaningful after training
         d_ref, d_got = net_oracle.dice(p_ref, tgt), net_oracle.dice(torch.sigmoid(logits), tgt)
         rows.append(_res(tag + ".dice_delta", abs(d_ref - d_got), dice_tol, extra=f"dice_ref={d_ref:.6f} dice_got={d_got:.6f}"))
     return rows
@@ -845,7 +973,7 @@ def parity_rows(tag, logits, lo_ref, tgt, dtype, trained=False):
 
 def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
     """Whole network vs the oracle: logits, Dice, loss and every parameter gradient."""
-    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+    tagd = _mode(dtype)[0]
     if golden is not None:
         sd = {k[len("small/sd/"):]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("small/sd/")}
         x = torch.from_numpy(golden["small/x"]).permute(0, 4, 1, 2, 3).contiguous()
@@ -869,7 +997,7 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
         lo_ref = net_oracle.resunet_forward(sd, x, fm)
     scale = lo_ref.abs().max().item()
     err = (logits.cpu() - lo_ref).abs().max().item() / scale
-    res.append(_res(tag + ".logits_rel", err, 6e-2 if dtype == torch.bfloat16 else 2e-4, extra=f"scale={scale:.3f}"))
+    res.append(_res(tag + ".logits_rel", err, LOGITS_TOL[tagd], extra=f"scale={scale:.3f}"))
     res += parity_rows(tag, logits.cpu(), lo_ref, tgt, dtype)
     if not train:
         return res
@@ -879,9 +1007,9 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
     G = eng.backward(P, ctx, lg.grad)
     torch.cuda.synchronize()
     loss_ref, _, grads_ref = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm)
-    res.append(_res(tag + ".loss", abs(loss.item() - loss_ref.item()), 2e-2 if dtype == torch.bfloat16 else 1e-5))
+    res.append(_res(tag + ".loss", abs(loss.item() - loss_ref.item()), LOSS_TOL[tagd]))
     worst, worst_name = 0.0, ""
-    gtol = 0.15 if dtype == torch.bfloat16 else 2e-3
+    gtol = GRAD_TOL[tagd]
     for k, gr in grads_ref.items():
         gg = G[k].cpu()
         denom = gr.norm().item()
@@ -920,7 +1048,7 @@ def check_network_cfg2_benched_shape(dtype):
         the batch gradient must equal the mean of the four batch-1 gradients."""
     fm, sd, x, tgt, loss_ref, lo_ref, grads_ref = _cfg2_oracle()
     f32 = dtype == torch.float32
-    tagd = "f32" if f32 else "bf16"
+    tagd = _mode(dtype)[0]
     tag = f"cfg2_128^3[{tagd}]"
     eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm), dtype)
     P = {k: v.to(DEV) for k, v in sd.items()}
@@ -936,9 +1064,9 @@ def check_network_cfg2_benched_shape(dtype):
 
     lo1, loss1, G1 = step(x[:1], tgt[:1])
     scale = lo_ref.abs().max().item()
-    res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, 2e-4 if f32 else 6e-2, extra=f"scale={scale:.3f}")]
+    res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, LOGITS_TOL[tagd], extra=f"scale={scale:.3f}")]
     res += parity_rows(tag + ".b1", lo1, lo_ref, tgt[:1], dtype)
-    res.append(_res(tag + ".b1.loss", abs(loss1 - loss_ref.item()), 1e-5 if f32 else 2e-2))
+    res.append(_res(tag + ".b1.loss", abs(loss1 - loss_ref.item()), LOSS_TOL[tagd]))
     # conv biases in front of an InstanceNorm have a ZERO true gradient (what both sides hold is rounding noise of 2 M-term sums):
     # errors are measured against max(|g_ref|, GRAD_FLOOR * the largest gradient norm of the network)
     floor = GRAD_FLOOR_F32 if f32 else GRAD_FLOOR_BF16
@@ -948,7 +1076,7 @@ def check_network_cfg2_benched_shape(dtype):
         e = (G1[k] - gr).norm().item() / max(gr.norm().item(), floor * gmax)
         if e > worst:
             worst, wname = e, k
-    res.append(_res(tag + ".b1.grads_rel_l2_worst", worst, 2e-3 if f32 else 0.15, extra=wname))
+    res.append(_res(tag + ".b1.grads_rel_l2_worst", worst, GRAD_TOL[tagd], extra=wname))
     # batch 4 == four batch-1 steps
     lo4, loss4, G4 = step(x, tgt)
     singles = [(lo1, loss1, G1)] + [step(x[b:b + 1], tgt[b:b + 1]) for b in range(1, 4)]
@@ -1247,7 +1375,7 @@ def check_resunet_sr(dtype, tag, golden):
 def check_network_aniso(dtype, golden):
     """Anisotropic ResUNet (Z_DOWN = [1, 2]) against the reference fixture tests/golden/resunet_aniso_golden.npz: logits, loss
     and every gradient norm + the stored full gradients."""
-    tagd = "bf16" if dtype == torch.bfloat16 else "f32"
+    tagd = _mode(dtype)[0]
     fm = [int(v) for v in golden["feature_maps"]]
     zd = [int(v) for v in golden["z_down"]]
     sd = {k[3:]: torch.from_numpy(golden[k].astype(np.float32)) for k in golden.files if k.startswith("sd/")}
@@ -1263,9 +1391,9 @@ def check_network_aniso(dtype, golden):
     torch.cuda.synchronize()
     tag = f"resunet_aniso[{tagd} fm={fm} z_down={zd}]"
     lo_ref = torch.from_numpy(golden["logits"])
-    res = [_res(tag + ".logits_rel", (logits.cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 6e-2 if dtype == torch.bfloat16 else 2e-4)]
-    res.append(_res(tag + ".loss", abs(loss.item() - float(golden["loss"])), 2e-2 if dtype == torch.bfloat16 else 1e-5))
-    gtol = 0.15 if dtype == torch.bfloat16 else 2e-3
+    res = [_res(tag + ".logits_rel", (logits.cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), LOGITS_TOL[tagd])]
+    res.append(_res(tag + ".loss", abs(loss.item() - float(golden["loss"])), LOSS_TOL[tagd]))
+    gtol = GRAD_TOL[tagd]
     worst, wname = 0.0, ""
     for k in golden.files:
         if k.startswith("grad/"):
@@ -1532,14 +1660,16 @@ def check_sliding_window_tta():
 
 
 def check_dice_parity_trained(steps=120):
-    """Train a small ResUNet on synthetic blobs with the MI355X engine, then compare Dice of the bf16 / f32 device
-    forward with the fp32 CPU oracle using the SAME weights (north_star: |Dice delta| < 1e-4)."""
+    """Train a small ResUNet on synthetic blobs with the MI355X engine in its default (benched) mode - fp16 forward, bf16 gradients -
+    then compare Dice of the device forward in every storage mode with the fp32 CPU oracle using the SAME weights (north_star:
+    |Dice delta| < 1e-4, asserted for f32 and fp16; bf16 storage makes no Dice claim)."""
     from biapy_amd.resunet import ResUNet
 
     fm = [16, 32, 64]
     torch.manual_seed(0)
     m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 3, normalization="in", yx_down=[2, 2],
-                z_down=[2, 2], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3, compute_dtype=torch.bfloat16).cuda().train()
+                z_down=[2, 2], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3).cuda().train()
+    assert m.compute_dtype == torch.float16
     opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
     g = torch.Generator(device="cuda").manual_seed(1)
 
@@ -1558,7 +1688,7 @@ def check_dice_parity_trained(steps=120):
         opt.step()
         first = loss.item() if first is None else first
         last = loss.item()
-    res = [_res("train_loss_decreases[bf16 engine]", last / first, 0.6, extra=f"loss {first:.4f} -> {last:.4f} in {steps} steps")]
+    res = [_res("train_loss_decreases[fp16 forward / bf16 gradients]", last / first, 0.6, extra=f"loss {first:.4f} -> {last:.4f} in {steps} steps")]
     m.eval()
     x, t = batch(4)
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}

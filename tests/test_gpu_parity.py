@@ -153,6 +153,14 @@ def test_norm_pool_head_first_layer(K, dt):
     _assert_all(K.check_norm_pool_head(dt))
 
 
+@pytest.mark.parametrize("S,B,Cin,Cout", [((8, 16, 32), 2, 32, 16), ((6, 10, 18), 1, 48, 16), ((64, 64, 64), 1, 16, 16), ((64, 64, 64), 1, 48, 32),
+                                         ((66, 70, 72), 1, 32, 32)],
+                         ids=["small", "ragged-48", "lean-64^3", "lean-64^3-48->32", "lean-ragged"])
+def test_mix16_backward_kernels(K, S, B, Cin, Cout):
+    """BPX_MIX16: fp16 activations, bf16 gradients - every backward entry point of the mixed training mode vs the fp32 operator."""
+    _assert_all(K.check_mix16_kernels(S, B, Cin, Cout))
+
+
 @pytest.mark.parametrize("dt,S,lean", [(0, (8, 16, 32), False), (1, (8, 16, 32), False), (1, (64, 64, 64), True), (0, (4, 8, 8), False),
                                        (1, (6, 10, 18), False), (1, (66, 70, 72), True)],
                          ids=["f32", "bf16", "bf16-lean-64^3", "f32-w8", "bf16-ragged-tiles", "bf16-lean-ragged-tiles"])
@@ -161,31 +169,31 @@ def test_chunk_planar_operands_equal_interleaved(K, dt, S, lean):
     _assert_all(K.check_planar_layouts(dt, S, lean))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_parameter_gradients_are_bit_reproducible(K, dtype):
     """Three backward passes over the same batch: every parameter gradient (conv / transposed-conv / first-layer / head weights and
     biases, norm affine) is bit-identical - the sums are fixed-order reductions of per-workgroup partials, no atomics."""
     _assert_all(K.check_parameter_gradients_are_reproducible(dtype))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_network_against_reference_golden(K, resunet_golden, dtype):
     """Logits, loss, Dice and all parameter gradients vs the fixture captured from the reference ResUNet."""
     _assert_all(K.check_network(dtype, None, None, None, golden=resunet_golden))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_anisotropic_network_against_reference_golden(K, resunet_aniso_golden, dtype):
     """MODEL.Z_DOWN = [1, 2]: pooling and transposed conv (1,2,2) at the first level (blocks.py:1607, resunet.py:256-257)."""
     _assert_all(K.check_network_aniso(dtype, resunet_aniso_golden))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_network_cfg2_architecture(K, dtype):
     _assert_all(K.check_network(dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_network_cfg2_at_the_benched_shape(K, dtype):
     """cfg 2 at 128^3 (batch 1 vs the CPU oracle; batch 4 vs four batch-1 runs) - the size bench.py times."""
     _assert_all(K.check_network_cfg2_benched_shape(dtype))
@@ -227,7 +235,7 @@ def test_sliding_window_pipeline(K, dtype):
 def test_fp16_inference_mode(K, resunet_golden):
     """compute_dtype=torch.float16: the inference mode that meets the north-star bar (Dice delta < 1e-4 is asserted on the trained model
     in test_dice_parity_on_a_trained_model).  Here: logits against the reference fixture, the cfg-2 architecture at 64^3 against the
-    oracle, and the refusal to train."""
+    oracle (training in this mode - bf16 gradients - is covered by the network tests above)."""
     from biapy_amd.engine import NetConfig, ResUNetEngine
     from biapy_amd.resunet import ResUNet
 
@@ -241,8 +249,6 @@ def test_fp16_inference_mode(K, resunet_golden):
     ref = torch.from_numpy(g["small/logits"])
     rel = ((lo.cpu() - ref).abs().max() / ref.abs().max()).item()
     assert rel < 2e-3, rel
-    with pytest.raises(NotImplementedError):
-        eng.forward(P, x, save=True)
     m = ResUNet(image_shape=(64, 64, 64, 1), activation="elu", feature_maps=[16, 32, 64, 128, 256], drop_values=[0.0] * 5, normalization="in",
                 yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=torch.float16).cuda().eval()
     from oracle import net_oracle
