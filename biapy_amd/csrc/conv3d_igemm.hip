@@ -459,7 +459,11 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 // Both lost: they hold a second stage in registers and either spill or drop to fewer co-resident workgroups.  The lean kernel
 // goes the other way (3-4 workgroups per CU, nothing pipelined inside a workgroup) and wins wherever a CU gets >= 4 rounds of
 // tiles: 725 / 342 / 944 us on the same three layers.
-extern "C" int bpx_debug_set_conv_ws(int on) { g_use_ws = on; return 0; }
+extern "C" int bpx_debug_set_conv_ws(int on) {
+  if (on == 6 || on == 7) { bpxconv::g_conv_dma = on == 6 ? 1 : 0; return 0; }   // 6 / 7: DMA-pipelined kernel on / off (the other selections stay)
+  g_use_ws = on;
+  return 0;
+}
 
 // Lean persistent kernel (conv3d_lean.hip) where a CU gets >= 4 rounds of tiles; it uses 32-bit element offsets and
 // 16-byte vector loads of the per-channel parameter arrays.
@@ -531,7 +535,8 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
     BPX_CHECK(pooled.C == y.C, "%s: pooled.C %d != y.C %d", fn, pooled.C, y.C);
     p.pool = pooled.ptr; p.pool_ld = pooled.ld; p.pool_sz = pool_sz; p.pool_part = pool_stats_part_d;
   }
-  int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
+  int rc = (use_lean(dtype, p) && c.tx == 16) ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_FWD, p, c, (hipStream_t)stream)
+                                                                         : launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream))
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream)
            : (dtype == BPX_F16)  ? launch_conv3<f16_t, EPI_FWD>(p, c, (hipStream_t)stream)
                                  : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
@@ -586,7 +591,8 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.x_cs = 16; p.sc_cs = 16; p.y_cs = 16; p.t_cs = chunk_stride(t);
   p.t_f16 = (mix && t_norm_d) ? 1 : 0;
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
-  int rc = (use_lean(dtype, p) && c.tx == 16) ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
+  int rc = (use_lean(dtype, p) && c.tx == 16) ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_DGRAD, p, c, (hipStream_t)stream)
+                                                                         : launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream))
            : p.t_f16             ? launch_conv3<uint16_t, EPI_DGRAD, f16_t>(p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream)
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);

@@ -61,6 +61,7 @@ template <int HY, int HX, int VB> __device__ __forceinline__ constexpr int tap_o
 }
 
 struct TileCfg { int tz, ty, tx, ns; };
+extern int g_conv_dma;   // conv3d_dma.hip: the DMA-pipelined kernel is selectable (bpx_debug_set_conv_ws 6 / 7)
 
 inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   TileCfg c;
@@ -85,5 +86,8 @@ extern long long* g_conv_stamps;  // profiling hook (bpx_debug_set_conv_stamps)
 
 // lean persistent bf16 kernel (conv3d_lean.hip) - the production kernel of the >= 64^3 layers
 int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
+// DMA-pipelined kernel (conv3d_dma.hip, round 3): 4x8x16 tiles with 16 / 32 output channels at >= 64^3
+bool conv3_dma_applies(const Conv3Params& p, const TileCfg& c);
+int launch_conv3_dma(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
 
 }  // namespace bpxconv

@@ -86,12 +86,14 @@ def test_conv3d_fwd(K, dt):
     _assert_all(rows)
 
 
-@pytest.mark.parametrize("variant", [4, 5], ids=["double-buffered", "lean-persistent"])
-def test_conv3d_bf16_kernel_variants(K, variant):
-    """Every schedule of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) computes the same convolution."""
+@pytest.mark.parametrize("variant,dma", [(4, 6), (5, 7), (5, 6)], ids=["double-buffered", "lean-persistent", "dma-pipelined"])
+def test_conv3d_bf16_kernel_variants(K, variant, dma):
+    """Every schedule of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) computes the same convolution: the double-buffered kernel
+    of the small layers, the lean persistent kernel, and (round 3) the DMA-pipelined kernel that replaces it for 16 output channels."""
     from biapy_amd import _lib as L
 
     L.lib.bpx_debug_set_conv_ws(variant)
+    L.lib.bpx_debug_set_conv_ws(dma)          # 6 / 7: DMA-pipelined kernel on / off wherever the lean kernel would run
     try:
         rows = []
         rows += K.check_conv3d_fwd(1, 1, (8, 12, 20), 48, 16, norm=True, sc_C=48, slices=True)
@@ -104,8 +106,13 @@ def test_conv3d_bf16_kernel_variants(K, variant):
         rows += K.check_conv3d_dgrad(1, 1, (32, 32, 32), 32, 16)
         rows += K.check_conv3d_fwd(1, 2, (12, 20, 24), 32, 32, norm=True, sc_C=32)     # ragged: partial tiles on every axis
         rows += K.check_conv3d_dgrad(1, 2, (12, 20, 24), 32, 32)
+        rows += K.check_conv3d_fwd(1, 2, (12, 20, 24), 48, 16, norm=True, sc_C=48)     # 16 output channels, ragged, three chunks + shortcut
+        rows += K.check_conv3d_fwd(1, 3, (9, 17, 33), 16, 16, norm=True, sc_C=1)       # one voxel past the tile on every axis, batch 3
+        rows += K.check_conv3d_dgrad(1, 2, (12, 20, 24), 16, 16)
+        rows += K.check_conv3d_dgrad(1, 3, (9, 17, 33), 16, 48)                        # dy 48 channels (three chunks) -> g 16
     finally:
         L.lib.bpx_debug_set_conv_ws(0)
+        L.lib.bpx_debug_set_conv_ws(6)
     _assert_all(rows)
 
 
