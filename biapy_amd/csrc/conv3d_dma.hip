@@ -123,6 +123,11 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   };
 
   if (!has_tile(slot)) return;
+  // profiling (scripts/dma_stamps.py): cycle stamps of one steady-state stage of this workgroup, the last chunk of a tile
+  long long* stamps = (p.stamps && tid == 0 && blockIdx.y == 0) ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  int stamp_i = 0, it = 0;
+  const int stamp_it = 2 * nchunks + nchunks - 1;
+#define BPX_STAMP() do { if (stamps && it == stamp_it && stamp_i < 15) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
   int local = slot, chunk = 0, cbuf = 0;
   TileInfo cur = decode(local);
   uint32_t vm_cur = issue(cur, 0, 0), vm_next = 0;
@@ -149,11 +154,13 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
       hasnext = has_tile(nlocal);
       if (hasnext) nxt = decode(nlocal);
     }
+    BPX_STAMP();                                     // 0: top of the stage
     if (nchunks > 1) load_w(chunk);                  // before the wait below: it covers them too
     f32x2_t nrec_next = f32x2_t{0.f, 0.f};
     if (has_norm && hasnext && tid < 16) nrec_next = norm_rec(nxt.n, nchunk);
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's pieces of the stage are in LDS (and the weights in registers)
     asm volatile("" ::: "memory");
+    BPX_STAMP();                                     // 1: DMA of this stage (and the weights) landed
     if (has_norm) {
       if (hasnext && tid < 16) ntab[(sp ^ 1) * 16 + tid] = nrec_next;
       float nsc[KPL], nsh[KPL];
@@ -181,29 +188,69 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         }
       }
     }
+    BPX_STAMP();                                     // 2: in-place prologue done
     __syncthreads();   // the whole halo image of this stage is in LDS; every wave is done reading the other buffer
+    BPX_STAMP();                                     // 3: barrier
     if (hasnext) {
       vm_next = issue(nxt, nchunk, cbuf ^ 1);
     }
+    // Operands of the epilogue, requested BEHIND the DMA and consumed after the MFMA phase (hipcc waits at the first use, i.e. there; by then
+    // the DMA in front of them has landed as well): the un-normalised activation t of the dgrad epilogue, the image of the rank-1 shortcut.
+    // Without this the epilogue starts with a full HBM round trip that two workgroups per CU do not cover (A/B: BPX_CONV_DBG=1 turns it off).
+    const bool last_chunk = chunk == nchunks - 1;
+    const bool pre_epi = last_chunk && !(p.dbg & 1);
+    u32x2_t tv0[MS];
+    float img0[MS];
+    if (pre_epi) {
+      const int n = cur.n, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
+      const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+      const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;
+      const bool okzx = full || (z0 + wave < D && x0 + ex < W);
+      const int yrem = full ? (1 << 20) : H - y0;
+      if (EPI == EPI_DGRAD && p.t_norm != nullptr) {
+        const char* __restrict__ tin = reinterpret_cast<const char*>(p.t);
+        const uint32_t trow = (uint32_t)(W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * t_csb;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          tv0[ms] = u32x2_t{0u, 0u};
+          if (okzx && ms < yrem) tv0[ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow));
+        }
+      }
+      if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C == 1) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          img0[ms] = (okzx && ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * W) * 4u) : 0.f;
+      }
+    }
+    BPX_STAMP();                                     // 4: next stage's DMA issued
     // ---- 14 MFMA steps over the staged chunk: no VMEM instruction in here ----------------------------------------------
     {
+      // software pipeline over the steps (the 256-VGPR budget of two workgroups per CU pays for a second fragment set): the LDS reads of
+      // step s + 1 are in flight while the MFMAs of step s issue
       const unsigned char* hb = smem + cbuf * BUFB;
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
+      u32x4_t af[2][MS];
+      auto fetch = [&](int s, u32x4_t* dst) {
         const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
         const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
-        u32x4_t af[MS];
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(hb + lbase[cls] + ms * HSTR + imm);
+        for (int ms = 0; ms < MS; ++ms) dst[ms] = *reinterpret_cast<const u32x4_t*>(hb + lbase[cls] + ms * HSTR + imm);
+      };
+      fetch(0, af[0]);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        if (s + 1 < STEPS && !(p.dbg & 2)) fetch(s + 1, af[(s + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wreg[s][ns], af[ms], acc[ms][ns]);
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wreg[s][ns], af[s & 1][ms], acc[ms][ns]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < STEPS && (p.dbg & 2)) fetch(s + 1, af[(s + 1) & 1]);   // A/B (BPX_CONV_DBG=2): no overlap of the fragment reads
       }
     }
 
-    if (chunk == nchunks - 1) {
+    BPX_STAMP();                                     // 5: MFMA phase
+    if (last_chunk) {
       // =================================================== epilogue of tile `cur` ===================================================
       const int n = cur.n, tile = cur.tile, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
       __builtin_amdgcn_sched_barrier(0);
@@ -233,6 +280,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         }
       }
 
+      BPX_STAMP();                                   // 6: fused shortcut
       char* __restrict__ yout = reinterpret_cast<char*>(p.y);
       const uint32_t yrow = (uint32_t)(W * p.y_ld) * 2u;                                       // bytes between m-subtiles
       const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * y_csb;
@@ -250,8 +298,10 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         const bool rank1 = p.sc != nullptr && p.sc_C == 1;
         float img[MS];
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-          img[ms] = (rank1 && okzx && ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * W) * 4u) : 0.f;
+        for (int ms = 0; ms < MS; ++ms) {
+          if (pre_epi) img[ms] = rank1 ? img0[ms] : 0.f;
+          else img[ms] = (rank1 && okzx && ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * W) * 4u) : 0.f;
+        }
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
           const int co = co_base + ns * 16 + g * 4;
@@ -336,6 +386,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
           if (has_t) {
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
+              if (pre_epi && ns == 0) { tv[ms] = tv0[ms]; continue; }
               tv[ms] = u32x2_t{0u, 0u};
               if (okzx && ms < yrem) tv[ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * t_csb));
             }
@@ -391,6 +442,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         }
       }
 
+      BPX_STAMP();                                   // 7: epilogue math + stores issued
       // ---- statistics partials: 4 waves (LDS) -> global [n][tile][2][Cout] ------------------------------------------------
       if (p.part != nullptr || (EPI == EPI_FWD && p.pool_part != nullptr)) {
         __syncthreads();
@@ -411,10 +463,13 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
+    BPX_STAMP();                                     // 8: stage done
     if (!hasnext) break;
+    ++it;
     // ---- advance: the buffers swap roles (every ds_read base moves by +-BUFB) -----------------------------------------------
     cbuf ^= 1; sp ^= 1; vm_cur = vm_next; chunk = nchunk; local = nlocal; cur = nxt;
   }
+#undef BPX_STAMP
 }
 
 int cu_count_dma() {
@@ -436,6 +491,8 @@ int launch_dma(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.tilesPerSample = tilesZ * p.tilesY * p.tilesX;
   p.totalTiles = p.N * p.tilesPerSample;
   p.tilesPerXcd = cdiv(p.totalTiles, 8);
+  p.stamps = g_conv_stamps;
+  { static const char* e = getenv("BPX_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int gy = p.Cout / (16 * c.ns);
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
   int gx = std::max(8, (cu_count_dma() * 2 / gy) & ~7);

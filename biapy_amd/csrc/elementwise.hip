@@ -1266,6 +1266,80 @@ __global__ void __launch_bounds__(256) seg_loss_bwd_kernel(const float* __restri
   }
 }
 
+// The scalar tail of the loss on the device, in ONE block each way (round 3: it was ~25 float64 PyTorch element-wise launches inside the
+// captured step).  finish: the partial rows are summed in a fixed order in double (thread k owns rows k, k + 256, ...; then a fixed-order
+// combination of the 256 thread sums) -> sums[6] (double) and loss = w_ce * S0 / n + w_dice * (1 - (2 S1 + smooth) / (S2 + S3 + smooth)).
+__global__ void __launch_bounds__(256) seg_loss_finish_kernel(const float* __restrict__ part, int blocks, double n, double w_ce, double w_dice,
+                                                              double smooth, double* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double red[256][6];
+  double s[6] = {0., 0., 0., 0., 0., 0.};
+  for (int b = threadIdx.x; b < blocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += (double)part[(size_t)b * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) red[threadIdx.x][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double a = 0.;
+    for (int q = 0; q < 256; ++q) a += red[q][threadIdx.x];
+    red[0][threadIdx.x] = a;
+    sums[threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double inter = red[0][1], uni = red[0][2] + red[0][3];
+    *loss = (float)(w_ce * red[0][0] / n + w_dice * (1.0 - (2.0 * inter + smooth) / (uni + smooth)));
+  }
+}
+
+// backward with the three coefficients formed in the kernel from the saved sums and the upstream gradient (a 0-d device tensor)
+__global__ void __launch_bounds__(256) seg_loss_bwd_fused_kernel(const float* __restrict__ z, const float* __restrict__ t, int64_t n,
+                                                                 const double* __restrict__ sums, const float* __restrict__ gup, double w_ce,
+                                                                 double w_dice, double smooth, float* __restrict__ dz) {
+  const double g = (double)gup[0], den = sums[2] + sums[3] + smooth;
+  const float a = (float)(w_ce * g / (double)n), b = (float)(2.0 * w_dice * g / den), c = (float)(w_dice * g * (2.0 * sums[1] + smooth) / (den * den));
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4_t zv = reinterpret_cast<const f32x4_t*>(z)[i], tv = reinterpret_cast<const f32x4_t*>(t)[i];
+    f32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float zz = zv[e], tt = tv[e];
+      const float en = expf(-fabsf(zz));
+      const float p = zz >= 0.f ? 1.f / (1.f + en) : en / (1.f + en);
+      o[e] = a * (p - tt) - p * (1.f - p) * (b * tt - c);
+    }
+    reinterpret_cast<f32x4_t*>(dz)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    const float zz = z[i], tt = t[i];
+    const float en = expf(-fabsf(zz));
+    const float p = zz >= 0.f ? 1.f / (1.f + en) : en / (1.f + en);
+    dz[i] = a * (p - tt) - p * (1.f - p) * (b * tt - c);
+  }
+}
+
+// per-channel losses: loss = sum_c w_c * (sum of the channel's partial sums) / (N * vox), partials [N][C][nb]; fixed-order double sums
+__global__ void __launch_bounds__(256) chan_loss_finish_kernel(const float* __restrict__ part, int N, int C, int nb, double inv_count,
+                                                               const float* __restrict__ weights, float* __restrict__ loss) {
+  __shared__ double red[256];
+  double total = 0.;
+  for (int c = 0; c < C; ++c) {
+    double s = 0.;
+    for (int q = threadIdx.x; q < N * nb; q += 256) s += (double)part[((size_t)(q / nb) * C + c) * nb + q % nb];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.;
+      for (int q = 0; q < 256; ++q) a += red[q];
+      total += a * inv_count * (double)weights[c];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = (float)total;
+}
+
 // ---- per-channel losses of a multi-channel head (instance segmentation: B, C, D ... channels) -----------------------------------
 // biapy/engine/metrics.py:1418-1810 (instance_segmentation_loss, plain channels: no masks / re-balancing / border weights) composed
 // with the training-time head activation of the workflow (base_workflow.py:1403-1457: ce_* channels stay logits, the 'D' channel
@@ -1309,12 +1383,14 @@ __global__ void __launch_bounds__(256) chan_loss_sums_kernel(const float* __rest
   if (threadIdx.x == 0) part[(size_t)plane * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// dlogits[n][c][v] = coef[c] * d term / d logit
+// dlogits[n][c][v] = coef[c] * d term / d logit;  gup != null: coef[c] holds the channel WEIGHT and the kernel forms
+// weight * upstream gradient * inv_count itself (no element-wise launches on the host side)
 __global__ void __launch_bounds__(256) chan_loss_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t, int64_t vox, int C,
-                                                            unsigned codes, const float* __restrict__ coef, float* __restrict__ dzo) {
+                                                            unsigned codes, const float* __restrict__ coef, float* __restrict__ dzo,
+                                                            const float* __restrict__ gup = nullptr, float inv_count = 1.f) {
   const int plane = blockIdx.y, c = plane % C;
   const int code = (codes >> (4 * c)) & 15;
-  const float k = coef[c];
+  const float k = gup ? gup[0] * coef[c] * inv_count : coef[c];
   const size_t off = (size_t)plane * vox;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vox; i += (int64_t)gridDim.x * 256) {
     float dz;
@@ -1941,6 +2017,47 @@ extern "C" int bpx_seg_loss_bwd(const float* logits_d, const float* target_d, in
   BPX_CHECK(logits_d && target_d && coef_d && dlogits_d, "%s: null pointer", fn);
   BPX_CHECK(n > 0, "%s: empty input", fn);
   seg_loss_bwd_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(logits_d, target_d, n, coef_d, dlogits_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_seg_loss_finish(const float* partials_d, int blocks, int64_t n, float w_ce, float w_dice, float smooth, double* sums_d,
+                                   float* loss_d, bpx_stream_t stream) {
+  const char* fn = "bpx_seg_loss_finish";
+  BPX_CHECK(partials_d && sums_d && loss_d && blocks > 0 && n > 0, "%s: bad arguments", fn);
+  seg_loss_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials_d, blocks, (double)n, (double)w_ce, (double)w_dice, (double)smooth, sums_d, loss_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_seg_loss_bwd_fused(const float* logits_d, const float* target_d, int64_t n, const double* sums_d, const float* gup_d, float w_ce,
+                                      float w_dice, float smooth, float* dlogits_d, bpx_stream_t stream) {
+  const char* fn = "bpx_seg_loss_bwd_fused";
+  BPX_CHECK(logits_d && target_d && sums_d && gup_d && dlogits_d, "%s: null pointer", fn);
+  BPX_CHECK(n > 0, "%s: empty input", fn);
+  BPX_CHECK((((uintptr_t)logits_d | (uintptr_t)target_d | (uintptr_t)dlogits_d) & 15) == 0, "%s: tensors must be 16-byte aligned", fn);
+  seg_loss_bwd_fused_kernel<<<grid_for(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(logits_d, target_d, n, sums_d, gup_d, (double)w_ce, (double)w_dice,
+                                                                                (double)smooth, dlogits_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_chan_loss_finish(const float* partials_d, int N, int C, int64_t voxels, const float* weights_d, float* loss_d, bpx_stream_t stream) {
+  const char* fn = "bpx_chan_loss_finish";
+  BPX_CHECK(partials_d && weights_d && loss_d && N > 0 && C > 0 && C <= 8, "%s: bad arguments", fn);
+  chan_loss_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials_d, N, C, bpx_chan_loss_blocks(voxels), 1.0 / ((double)N * (double)voxels), weights_d, loss_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_chan_loss_bwd_fused(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, const float* weights_d,
+                                       const float* gup_d, float* dlogits_d, bpx_stream_t stream) {
+  const char* fn = "bpx_chan_loss_bwd_fused";
+  BPX_CHECK(logits_d && target_d && weights_d && gup_d && dlogits_d, "%s: null pointer", fn);
+  BPX_CHECK(N > 0 && C > 0 && C <= 8 && voxels > 0, "%s: bad shape", fn);
+  dim3 grid((unsigned)bpx_chan_loss_blocks(voxels), (unsigned)(N * C));
+  chan_loss_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits_d, target_d, voxels, C, codes, weights_d, dlogits_d, gup_d,
+                                                              (float)(1.0 / ((double)N * (double)voxels)));
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -343,6 +343,14 @@ int bpx_cast(int src_dtype, const void* src_d, int dst_dtype, void* dst_d, int64
 int bpx_seg_loss_blocks(int64_t n);
 int bpx_seg_loss_sums(const float* logits_d, const float* target_d, int64_t n, float* partials_d, bpx_stream_t stream);
 int bpx_seg_loss_bwd(const float* logits_d, const float* target_d, int64_t n, const float* coef_d, float* dlogits_d, bpx_stream_t stream);
+/* The scalar tail of the same losses on the device (no host-side element-wise launches inside a captured training step):
+ *   bpx_seg_loss_finish   : sums_d[6] (double) = the fixed-order column sums of the `blocks` partial rows; loss_d (float) =
+ *                           w_ce * S0 / n + w_dice * (1 - (2 S1 + smooth) / (S2 + S3 + smooth))
+ *   bpx_seg_loss_bwd_fused: bpx_seg_loss_bwd with a, b, c formed in the kernel from sums_d and the upstream gradient gup_d[0] (device float). */
+int bpx_seg_loss_finish(const float* partials_d, int blocks, int64_t n, float w_ce, float w_dice, float smooth, double* sums_d, float* loss_d,
+                        bpx_stream_t stream);
+int bpx_seg_loss_bwd_fused(const float* logits_d, const float* target_d, int64_t n, const double* sums_d, const float* gup_d, float w_ce, float w_dice,
+                           float smooth, float* dlogits_d, bpx_stream_t stream);
 
 /* ---- per-channel losses of a multi-channel head (row X / cfg 4: instance segmentation with B, C, D channels) ------------------------------
  * Replaces biapy/engine/metrics.py:1418-1810 (instance_segmentation_loss; plain channels: no masks, class re-balancing or border
@@ -358,6 +366,11 @@ int bpx_chan_loss_sums(const float* logits_d, const float* target_d, int N, int 
                        bpx_stream_t stream);
 int bpx_chan_loss_bwd(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, const float* coef_d,
                       float* dlogits_d, bpx_stream_t stream);
+/*   bpx_chan_loss_finish  : loss_d = sum_c weights_d[c] * (fixed-order double sum of channel c's partials) / (N * voxels)
+ *   bpx_chan_loss_bwd_fused: bpx_chan_loss_bwd with coef[c] = gup_d[0] * weights_d[c] / (N * voxels) formed in the kernel. */
+int bpx_chan_loss_finish(const float* partials_d, int N, int C, int64_t voxels, const float* weights_d, float* loss_d, bpx_stream_t stream);
+int bpx_chan_loss_bwd_fused(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, const float* weights_d,
+                            const float* gup_d, float* dlogits_d, bpx_stream_t stream);
 
 /* ---- attention gate of ResUNet++ (biapy/models/blocks.py:2168-2298, `return out * x2`: a 1-channel map times a C-channel tensor) ----
  * fwd: y[v][c] = a[v] * x[v][c], a = the FIRST channel of tensor `a` (channel stride a.ld);  bwd: dx = dy * a and
