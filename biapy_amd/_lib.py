@@ -65,6 +65,10 @@ _SIGS = {
     "bpx_seg_loss_blocks": ([_i64], _i),
     "bpx_seg_loss_sums": ([_vp, _vp, _i64, _vp, _vp], _i),
     "bpx_seg_loss_bwd": ([_vp, _vp, _i64, _vp, _vp, _vp], _i),
+    "bpx_seg_loss_finish": ([_vp, _i, _i64, _f, _f, _f, _vp, _vp, _vp], _i),
+    "bpx_seg_loss_bwd_fused": ([_vp, _vp, _i64, _vp, _vp, _f, _f, _f, _vp, _vp], _i),
+    "bpx_chan_loss_finish": ([_vp, _i, _i, _i64, _vp, _vp, _vp], _i),
+    "bpx_chan_loss_bwd_fused": ([_vp, _vp, _i, _i, _i64, C.c_uint, _vp, _vp, _vp, _vp], _i),
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_fwd_pool": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
     "bpx_conv3d_fwd_pool_supported": ([_i, _i, _i, _i, _i, _i, _i, _i], _i),

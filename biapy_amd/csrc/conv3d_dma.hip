@@ -56,15 +56,9 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   const int evox_rel = (wave * H) * W + ex;
 
   const int sub = tid & 1;
-  uint32_t rel[NP], hc[NP];   // byte offset of this thread's piece u relative to the halo origin of a tile; its halo coordinates (hz | hy << 8 | hx << 16)
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    const int idx = u * 256 + tid;
-    const int hv = idx >> 1;
-    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    rel[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.x_ld + sub * KPL) * 2u;
-    hc[u] = idx < NPIECE ? ((uint32_t)hz | ((uint32_t)hy << 8) | ((uint32_t)hx << 16)) : 0xFFu;   // hz = 255: never inside the volume
-  }
+  // the halo coordinates of this thread's piece u are re-derived at every issue (divisions by constants: a few VALU instructions, and
+  // the kernel has issue slots to spare but no registers: 256 VGPRs is the budget of two workgroups per CU)
+  const uint32_t ld2 = (uint32_t)p.x_ld * 2u, sub16 = (uint32_t)sub * 16u;
   const char* __restrict__ wp = reinterpret_cast<const char*>(p.wp);
   const uint32_t wlane = (uint32_t)((g * Cout + co_base + j) * KPL) * 2u;
   const int nchunks = p.Cin / 16;
@@ -72,6 +66,11 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
   // every byte offset of x is < 2^31 (checked by the launcher): a piece outside the volume gets offset 2^31 = out of range = zeros
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)0x80000000u, 0x00020000);
+  // The epilogue's operands (t of the dgrad, the shortcut tensor / image) go through buffer descriptors too: a voxel outside the volume is an
+  // out-of-range OFFSET (-> zeros) instead of a select on the loaded DATA - hipcc answers `cond ? load : 0` with a branch around the load and
+  // an immediate vmcnt(0) per element, which would drain the DMA queue in front of the MFMA phase
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(EPI == EPI_DGRAD ? p.t : p.sc), 0, (int)0x80000000u, 0x00020000);
+  constexpr uint32_t OOB = 0x80000000u;
   const bool has_norm = EPI == EPI_FWD && p.in_norm != nullptr;
 
   struct TileInfo { int n, tile, z0, y0, x0; };
@@ -85,23 +84,35 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   };
   auto has_tile = [&](int local) { return local < p.tilesPerXcd && xcd * p.tilesPerXcd + local < p.totalTiles; };
 
-  // DMA of one stage (tile t, input-channel chunk) into halo buffer `buf`; returns the mask of this thread's in-volume pieces
+  // DMA of one stage (tile t, input-channel chunk) into halo buffer `buf`, one 16-byte piece per lane and call; returns whether this thread's
+  // piece u lies inside the volume.  The pieces of the NEXT stage are issued one per MFMA step of the current one (an LDS-DMA instruction
+  // costs its wave 100-250 issue cycles: nine of them in a row were 2 K cycles per stage, scripts/dma_stamps.py)
+  struct StageBase { uint32_t base_b; int zm, ym, xm; bool interior; };
+  auto stage_base = [&](const TileInfo& t, int chunk) {
+    StageBase b;
+    b.base_b = (uint32_t)(((t.n * D + t.z0 - 1) * H + (t.y0 - 1)) * W + (t.x0 - 1)) * (uint32_t)p.x_ld * 2u + (uint32_t)chunk * x_csb;
+    b.zm = t.z0 - 1; b.ym = t.y0 - 1; b.xm = t.x0 - 1;
+    b.interior = t.z0 >= 1 && t.z0 + TZ + 1 <= D && t.y0 >= 1 && t.y0 + TY + 1 <= H && t.x0 >= 1 && t.x0 + TX + 1 <= W;
+    return b;
+  };
+  auto issue_piece = [&](const StageBase& b, int buf, int u) {
+    bool ok = (u < NP - 1) || (NP - 1) * 256 + tid < NPIECE;
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));                  // keep the coordinates out of loop-invariant registers
+    const uint32_t hv = (uint32_t)(u * 256 + tid_o) >> 1;
+    const uint32_t hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    const bool in = (unsigned)(b.zm + (int)hz) < (unsigned)D && (unsigned)(b.ym + (int)hy) < (unsigned)H && (unsigned)(b.xm + (int)hx) < (unsigned)W;
+    ok = ok && (b.interior || in);
+    const uint32_t relb = ((hz * (uint32_t)H + hy) * (uint32_t)W + hx) * ld2 + sub16;
+    const uint32_t off = ok ? b.base_b + relb : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + buf * BUFB + u * 4096 + wave * 1024), 16, off, 0, 0, 0);
+    return ok ? (1u << u) : 0u;
+  };
   auto issue = [&](const TileInfo& t, int chunk, int buf) {
-    const uint32_t base_b = (uint32_t)(((t.n * D + t.z0 - 1) * H + (t.y0 - 1)) * W + (t.x0 - 1)) * (uint32_t)p.x_ld * 2u + (uint32_t)chunk * x_csb;
-    const bool interior = t.z0 >= 1 && t.z0 + TZ + 1 <= D && t.y0 >= 1 && t.y0 + TY + 1 <= H && t.x0 >= 1 && t.x0 + TX + 1 <= W;
+    const StageBase b = stage_base(t, chunk);
     uint32_t vm = 0;
 #pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      bool ok = (u < NP - 1) || (NP - 1) * 256 + tid < NPIECE;
-      if (!interior) {
-        const uint32_t c = hc[u];
-        ok = ok && (unsigned)(t.z0 - 1 + (int)(c & 255u)) < (unsigned)D && (unsigned)(t.y0 - 1 + (int)((c >> 8) & 255u)) < (unsigned)H &&
-             (unsigned)(t.x0 - 1 + (int)(c >> 16)) < (unsigned)W;
-      }
-      const uint32_t off = ok ? base_b + rel[u] : 0x80000000u;
-      vm |= ok ? (1u << u) : 0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + buf * BUFB + u * 4096 + wave * 1024), 16, off, 0, 0, 0);
-    }
+    for (int u = 0; u < NP; ++u) vm |= issue_piece(b, buf, u);
     return vm;
   };
   // the chunk's weight fragments: [step][NS] 16-byte operands of this lane
@@ -117,7 +128,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   // stage's records at the top of a stage (in front of the wait for this stage's DMA, which covers them), write them behind it, and the
   // stage's barrier publishes them.  A register prefetch behind the DMA is no alternative: hipcc waits for such a load at once (vmcnt is
   // in order, so that wait would drain the DMA before the MFMA phase it is meant to overlap).
-  f32x2_t* ntab = reinterpret_cast<f32x2_t*>(smem + 2 * BUFB + RED_BYTES);   // [2][16]
+  float* ntab = reinterpret_cast<float*>(smem + 2 * BUFB + RED_BYTES);   // [2 stages][scale | shift][16]: pairs of channels are adjacent (v_pk_fma)
   auto norm_rec = [&](int n, int chunk) {
     return *reinterpret_cast<const f32x2_t*>(&p.in_norm[(size_t)n * p.Cin + chunk * 16 + (tid & 15)].scale);
   };
@@ -131,10 +142,9 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   int local = slot, chunk = 0, cbuf = 0;
   TileInfo cur = decode(local);
   uint32_t vm_cur = issue(cur, 0, 0), vm_next = 0;
-  if (nchunks == 1) load_w(0);
   int sp = 0;                                        // parity of the stage: which half of the table holds its records
   if (has_norm) {
-    if (tid < 16) ntab[tid] = norm_rec(cur.n, 0);
+    if (tid < 16) { const f32x2_t r = norm_rec(cur.n, 0); ntab[tid] = r[0]; ntab[16 + tid] = r[1]; }
     __syncthreads();
   }
 
@@ -155,52 +165,66 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
       if (hasnext) nxt = decode(nlocal);
     }
     BPX_STAMP();                                     // 0: top of the stage
-    if (nchunks > 1) load_w(chunk);                  // before the wait below: it covers them too
+    load_w(chunk);                                   // every stage (L1 / L2 hits), in front of the wait below, which covers them: the 56 registers are
+                                                     // then free during the epilogue, which needs them for the shortcut operands
     f32x2_t nrec_next = f32x2_t{0.f, 0.f};
     if (has_norm && hasnext && tid < 16) nrec_next = norm_rec(nxt.n, nchunk);
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's pieces of the stage are in LDS (and the weights in registers)
     asm volatile("" ::: "memory");
     BPX_STAMP();                                     // 1: DMA of this stage (and the weights) landed
     if (has_norm) {
-      if (hasnext && tid < 16) ntab[(sp ^ 1) * 16 + tid] = nrec_next;
-      float nsc[KPL], nsh[KPL];
+      if (hasnext && tid < 16) { ntab[(sp ^ 1) * 32 + tid] = nrec_next[0]; ntab[(sp ^ 1) * 32 + 16 + tid] = nrec_next[1]; }
+      f32x2_t sc2[4], sh2[4];
       {
-        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(ntab + sp * 16 + sub * KPL);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f32x4_t v = q[e];
-          nsc[2 * e] = v[0]; nsh[2 * e] = v[1]; nsc[2 * e + 1] = v[2]; nsh[2 * e + 1] = v[3];
-        }
+        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(ntab + sp * 32 + sub * KPL);
+        const f32x4_t a0 = q[0], a1 = q[1], b0 = q[4], b1 = q[5];
+        sc2[0] = f32x2_t{a0[0], a0[1]}; sc2[1] = f32x2_t{a0[2], a0[3]}; sc2[2] = f32x2_t{a1[0], a1[1]}; sc2[3] = f32x2_t{a1[2], a1[3]};
+        sh2[0] = f32x2_t{b0[0], b0[1]}; sh2[1] = f32x2_t{b0[2], b0[3]}; sh2[2] = f32x2_t{b1[0], b1[1]}; sh2[3] = f32x2_t{b1[2], b1[3]};
       }
-      // in-place prologue: every thread transforms the pieces its own wave's DMA wrote (no barrier needed in between)
+      // in-place prologue: every thread transforms the pieces its own wave's DMA wrote (no barrier needed in between).  Three pieces per
+      // round: the reads of a round are issued together and the math is branch-free (one piece at a time under an exec branch ran at one
+      // LDS round trip + 35 dependent VALU instructions per piece: 4.5 K cycles per stage, scripts/dma_stamps.py); only the write-back is
+      // predicated - zero padding applies to the ACTIVATED tensor, so out-of-volume pieces keep the zeros the DMA wrote
       unsigned char* hb = smem + cbuf * BUFB;
+      constexpr int RB = 3;
 #pragma unroll
-      for (int u = 0; u < NP; ++u) {
-        if ((vm_cur >> u) & 1u) {                    // zero padding applies to the ACTIVATED tensor: out-of-volume pieces stay 0
-          u32x4_t v = *reinterpret_cast<const u32x4_t*>(hb + (size_t)(u * 256 + tid) * 16);
+      for (int u0 = 0; u0 < NP; u0 += RB) {
+        u32x4_t v[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+          if (u0 + q < NP) v[q] = *reinterpret_cast<const u32x4_t*>(hb + (size_t)((u0 + q) * 256 + tid) * 16);
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          if (u0 + q >= NP) continue;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float a = fmaf(nsc[2 * i], lo16<T>(v[i]), nsh[2 * i]), b = fmaf(nsc[2 * i + 1], hi16<T>(v[i]), nsh[2 * i + 1]);
+            const f32x2_t x2{lo16<T>(v[q][i]), hi16<T>(v[q][i])};
+            const f32x2_t a2 = __builtin_elementwise_fma(sc2[i], x2, sh2[i]);
+            float a = a2[0], b = a2[1];
             act_pair<ACTK>(a, b, p.act);
-            v[i] = pk16<T>(a, b);
+            v[q][i] = pk16<T>(a, b);
           }
-          *reinterpret_cast<u32x4_t*>(hb + (size_t)(u * 256 + tid) * 16) = v;
         }
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+          if (u0 + q < NP && ((vm_cur >> (u0 + q)) & 1u)) *reinterpret_cast<u32x4_t*>(hb + (size_t)((u0 + q) * 256 + tid) * 16) = v[q];
       }
     }
     BPX_STAMP();                                     // 2: in-place prologue done
     __syncthreads();   // the whole halo image of this stage is in LDS; every wave is done reading the other buffer
     BPX_STAMP();                                     // 3: barrier
-    if (hasnext) {
-      vm_next = issue(nxt, nchunk, cbuf ^ 1);
-    }
-    // Operands of the epilogue, requested BEHIND the DMA and consumed after the MFMA phase (hipcc waits at the first use, i.e. there; by then
-    // the DMA in front of them has landed as well): the un-normalised activation t of the dgrad epilogue, the image of the rank-1 shortcut.
-    // Without this the epilogue starts with a full HBM round trip that two workgroups per CU do not cover (A/B: BPX_CONV_DBG=1 turns it off).
+    // Operands of the epilogue, requested at the top of the MFMA phase and consumed after it (hipcc waits at the first use, i.e. there; by then
+    // the DMA pieces issued behind them have landed as well): the un-normalised activation t of the dgrad epilogue, the image of the
+    // rank-1 shortcut, the first chunk of a 1x1x1 shortcut.  Without this the epilogue starts with a full HBM round trip that two workgroups
+    // per CU do not cover (A/B: BPX_CONV_DBG=1 turns it off).  16-byte accesses: lane (j, g) fetches voxel row 2k + (g & 1), channels
+    // (g >> 1) * 8 .. + 7 and v_permlane16_swap moves the halves to the MFMA layout (4 consecutive channels of rows 2k and 2k + 1).
     const bool last_chunk = chunk == nchunks - 1;
-    const bool pre_epi = last_chunk && !(p.dbg & 1);
-    u32x2_t tv0[MS];
+    const bool pre_epi = last_chunk;
+    const int gh = g >> 1, go = g & 1;
+    u32x4_t tq0[MS / 2];
     float img0[MS];
+    u32x4_t bq0[MS];
+    const bool sc_mm = EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16;
     if (pre_epi) {
       const int n = cur.n, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
       const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
@@ -208,47 +232,46 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
       const bool okzx = full || (z0 + wave < D && x0 + ex < W);
       const int yrem = full ? (1 << 20) : H - y0;
       if (EPI == EPI_DGRAD && p.t_norm != nullptr) {
-        const char* __restrict__ tin = reinterpret_cast<const char*>(p.t);
-        const uint32_t trow = (uint32_t)(W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * t_csb;
+        const uint32_t trow = (uint32_t)(W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + gh * 8) * 2u + (uint32_t)(co_base >> 4) * t_csb;
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-          tv0[ms] = u32x2_t{0u, 0u};
-          if (okzx && ms < yrem) tv0[ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow));
-        }
+        for (int k = 0; k < MS / 2; ++k)
+          tq0[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (okzx && 2 * k + go < yrem) ? tb + (2 * k + go) * trow : OOB, 0, 0);
       }
       if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C == 1) {
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
-          img0[ms] = (okzx && ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * W) * 4u) : 0.f;
+          img0[ms] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_t, (okzx && ms < yrem) ? (uint32_t)(vox0 + ms * W) * 4u : OOB, 0, 0));
+      }
+      if (sc_mm) {
+        const uint32_t sb0 = (uint32_t)(vox0 * p.sc_ld) * 2u + (uint32_t)cg_off, srow = (uint32_t)(W * p.sc_ld) * 2u;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) bq0[ms] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (okzx && ms < yrem) ? sb0 + ms * srow : OOB, 0, 0);
       }
     }
-    BPX_STAMP();                                     // 4: next stage's DMA issued
-    // ---- 14 MFMA steps over the staged chunk: no VMEM instruction in here ----------------------------------------------
+    BPX_STAMP();                                     // 4: epilogue operands requested
+    // ---- 14 MFMA steps over the staged chunk; one DMA piece of the next stage behind the MFMAs of each of the first NP steps ----------
     {
-      // software pipeline over the steps (the 256-VGPR budget of two workgroups per CU pays for a second fragment set): the LDS reads of
-      // step s + 1 are in flight while the MFMAs of step s issue
+      StageBase nb{};
+      if (hasnext) nb = stage_base(nxt, nchunk);
+      vm_next = 0;
       const unsigned char* hb = smem + cbuf * BUFB;
-      u32x4_t af[2][MS];
-      auto fetch = [&](int s, u32x4_t* dst) {
-        const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
-        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms) dst[ms] = *reinterpret_cast<const u32x4_t*>(hb + lbase[cls] + ms * HSTR + imm);
-      };
-      fetch(0, af[0]);
+      static_assert(NP <= STEPS, "one DMA piece per MFMA step");
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
-        if (s + 1 < STEPS && !(p.dbg & 2)) fetch(s + 1, af[(s + 1) & 1]);
+        const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
+        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
+        u32x4_t af[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(hb + lbase[cls] + ms * HSTR + imm);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wreg[s][ns], af[s & 1][ms], acc[ms][ns]);
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wreg[s][ns], af[ms], acc[ms][ns]);
+        if (s < NP && hasnext) vm_next |= issue_piece(nb, cbuf ^ 1, s);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < STEPS && (p.dbg & 2)) fetch(s + 1, af[(s + 1) & 1]);   // A/B (BPX_CONV_DBG=2): no overlap of the fragment reads
       }
     }
-
     BPX_STAMP();                                     // 5: MFMA phase
     if (last_chunk) {
       // =================================================== epilogue of tile `cur` ===================================================
@@ -260,30 +283,52 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
       const int yrem = full ? (1 << 20) : H - y0;                    // m-subtile ms (= tile row) is inside the volume iff ms < yrem
       // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only): extra K steps, operands straight from global memory ----
       if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16) {
-        const char* __restrict__ scin = reinterpret_cast<const char*>(p.sc);
         const char* __restrict__ wsc = reinterpret_cast<const char*>(p.wsc);
         const uint32_t sb0 = (uint32_t)(vox0 * p.sc_ld) * 2u + (uint32_t)cg_off, srow = (uint32_t)(W * p.sc_ld) * 2u;
         const int nch = p.sc_C / 16;
-        for (int c = 0; c < nch; ++c) {
-          u32x4_t bq[MS], wf[NS];
+        // chunk 0 was requested before the MFMA phase (bq0); chunk c + 1 is requested before the MFMAs of chunk c and chunk c + 2 right behind
+        // them, so that the HBM round trips of a 48-channel shortcut overlap instead of following each other (they were 8.6 K cycles per tile)
+        auto sc_fetch = [&](int c, u32x4_t* dst) {
 #pragma unroll
-          for (int ms = 0; ms < MS; ++ms) {
-            bq[ms] = u32x4_t{0u, 0u, 0u, 0u};
-            if (okzx && ms < yrem) bq[ms] = *reinterpret_cast<const u32x4_t*>(scin + (sb0 + ms * srow + (uint32_t)c * sc_csb));
-          }
+          for (int ms = 0; ms < MS; ++ms)
+            dst[ms] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (okzx && ms < yrem) ? sb0 + ms * srow + (uint32_t)c * sc_csb : OOB, 0, 0);
+        };
+        // the weights of chunk c + 1 are requested IN FRONT of its operands: the counted wait for chunk c's MFMAs then leaves both in flight
+        auto sc_w = [&](int c, u32x4_t* wf) {
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wsc + (size_t)c * 4 * Cout * 16 + (wlane + ns * 256u));
+        };
+        auto sc_mfma = [&](const u32x4_t* wf, const u32x4_t* src) {
 #pragma unroll
           for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-            for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], bq[ms], acc[ms][ns]);
+            for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], src[ms], acc[ms][ns]);
+        };
+        u32x4_t bqb[MS], wfa[NS], wfb[NS];
+        sc_w(0, wfa);
+        for (int c = 0; c < nch; c += 2) {
+          if (c + 1 < nch) { sc_w(c + 1, wfb); sc_fetch(c + 1, bqb); }
+          sc_mfma(wfa, bq0);
+          if (c + 2 < nch) { sc_w(c + 2, wfa); sc_fetch(c + 2, bq0); }
+          if (c + 1 < nch) sc_mfma(wfb, bqb);
         }
       }
 
       BPX_STAMP();                                   // 6: fused shortcut
       char* __restrict__ yout = reinterpret_cast<char*>(p.y);
       const uint32_t yrow = (uint32_t)(W * p.y_ld) * 2u;                                       // bytes between m-subtiles
-      const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * y_csb;
+      // 16-byte stores: after v_permlane16_swap lane (j, g) holds the 8 channels (g >> 1) * 8 .. + 7 of voxel row 2k + (g & 1) - half the store
+      // instructions of the 8-byte MFMA layout (the store tail is issue-bound: 8 dwordx2 per lane were ~4.5 K cycles per tile)
+      const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + gh * 8) * 2u + (uint32_t)(co_base >> 4) * y_csb;
+      auto store_rows = [&](int ns, const u32x2_t* pk) {
+#pragma unroll
+        for (int k = 0; k < MS / 2; ++k) {
+          const auto r0 = __builtin_amdgcn_permlane16_swap(pk[2 * k][0], pk[2 * k + 1][0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane16_swap(pk[2 * k][1], pk[2 * k + 1][1], false, false);
+          if (okzx && 2 * k + go < yrem)
+            *reinterpret_cast<u32x4_t*>(yout + (yb0 + (2 * k + go) * yrow + ns * y_csb)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+        }
+      };
       float* red = reinterpret_cast<float*>(smem + 2 * BUFB);
       auto flush_stats = [&](int ns, const float* s1, const float* s2, int which = 0) {
         if ((which ? (float*)p.pool_part : p.part) == nullptr) return;
@@ -298,10 +343,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         const bool rank1 = p.sc != nullptr && p.sc_C == 1;
         float img[MS];
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-          if (pre_epi) img[ms] = rank1 ? img0[ms] : 0.f;
-          else img[ms] = (rank1 && okzx && ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * W) * 4u) : 0.f;
-        }
+        for (int ms = 0; ms < MS; ++ms) img[ms] = rank1 ? img0[ms] : 0.f;
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
           const int co = co_base + ns * 16 + g * 4;
@@ -323,9 +365,9 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
                 s2[r] += v[r] * v[r];
               }
               pk[ms] = u32x2_t{pk16<T>(v[0], v[1]), pk16<T>(v[2], v[3])};
-              *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) = pk[ms];
             }
           }
+          store_rows(ns, pk);
           if (p.pool != nullptr) {
             // fused MaxPool3d (pool_sz,2,2) of the values just written: y pairs = two m-subtiles of this lane, x pairs = lanes j / j^1 (DPP),
             // z pairs = waves w / w+1 (through LDS, in the halo buffer this stage just finished reading)
@@ -378,17 +420,21 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
         }
       } else {
         const bool has_t = p.t_norm != nullptr;
-        const char* __restrict__ tin = reinterpret_cast<const char*>(p.t);
-        const uint32_t trow = (uint32_t)(W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * t_csb;
+        const uint32_t trow = (uint32_t)(W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + gh * 8) * 2u + (uint32_t)(co_base >> 4) * t_csb;
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
           u32x2_t tv[MS];
           if (has_t) {
 #pragma unroll
-            for (int ms = 0; ms < MS; ++ms) {
-              if (pre_epi && ns == 0) { tv[ms] = tv0[ms]; continue; }
-              tv[ms] = u32x2_t{0u, 0u};
-              if (okzx && ms < yrem) tv[ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * t_csb));
+            for (int k = 0; k < MS / 2; ++k) {
+              u32x4_t q;
+              if (ns == 0) q = tq0[k];
+              else q = __builtin_amdgcn_raw_buffer_load_b128(rs_t, (okzx && 2 * k + go < yrem) ? tb + (2 * k + go) * trow + ns * t_csb : OOB, 0, 0);
+              // loaded: channels (g >> 1) * 8 .. + 7 of row 2k + (g & 1); wanted: channels 4g .. 4g + 3 of rows 2k and 2k + 1
+              const auto r0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+              const auto r1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+              tv[2 * k] = u32x2_t{r0[0], r1[0]};
+              tv[2 * k + 1] = u32x2_t{r0[1], r1[1]};
             }
           }
           float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -433,11 +479,10 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
               }
             }
           }
+          u32x2_t gk[MS];
 #pragma unroll
-          for (int ms = 0; ms < MS; ++ms)
-            if (okzx && ms < yrem)
-              *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) =
-                  u32x2_t{pk16<T>(acc[ms][ns][0], acc[ms][ns][1]), pk16<T>(acc[ms][ns][2], acc[ms][ns][3])};
+          for (int ms = 0; ms < MS; ++ms) gk[ms] = u32x2_t{pk16<T>(acc[ms][ns][0], acc[ms][ns][1]), pk16<T>(acc[ms][ns][2], acc[ms][ns][3])};
+          store_rows(ns, gk);
           flush_stats(ns, s1, s2);
         }
       }
@@ -534,7 +579,9 @@ int g_conv_dma = 1;   // the DMA-pipelined kernel where it applies (bpx_debug_se
 bool conv3_dma_applies(const Conv3Params& p, const TileCfg& c) {
   const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
   const int64_t xbytes = (p.x_cs == 16 ? vox * p.x_ld : (int64_t)p.x_cs * (p.Cin / 16)) * 2;
-  return g_conv_dma != 0 && c.tz == 4 && c.tx == 16 && c.ty == 8 && c.ns == 1 && xbytes < (1ll << 31);
+  const int64_t tbytes = p.t ? (p.t_cs == 16 ? vox * p.t_ld : (int64_t)p.t_cs * (p.Cout / 16)) * 2 : 0;
+  const int64_t sbytes = p.sc ? (p.sc_C == 1 ? vox * 4 : (p.sc_cs == 16 ? vox * p.sc_ld : (int64_t)p.sc_cs * (p.sc_C / 16)) * 2) : 0;
+  return g_conv_dma != 0 && c.tz == 4 && c.tx == 16 && c.ty == 8 && c.ns == 1 && std::max(xbytes, std::max(tbytes, sbytes)) < (1ll << 31);
 }
 int launch_conv3_dma(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s) {
   return epi == EPI_FWD ? launch_dma<EPI_FWD>(p, c, s) : launch_dma<EPI_DGRAD>(p, c, s);

@@ -15,12 +15,22 @@ from . import _lib as L
 lib = L.lib
 
 
-def _sums(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-    """{sum bce, sum p*t, sum p, sum t, |P&T|, |P|T|} as a float64 device tensor (no host sync)."""
+def _sums_and_loss(logits: torch.Tensor, target: torch.Tensor, w_ce: float = 1.0, w_dice: float = 0.0, smooth: float = 1e-5):
+    """({sum bce, sum p*t, sum p, sum t, |P&T|, |P|T|} as a float64 device tensor, the loss as a 0-d float32 device tensor): one streaming
+    pass + one single-block kernel that sums the partial rows in a fixed order in double and forms the loss (no host sync, no PyTorch
+    element-wise launches: round 2's profile showed ~25 of them per training step)."""
     n = logits.numel()
-    part = torch.empty((lib.bpx_seg_loss_blocks(n), 6), dtype=torch.float32, device=logits.device)
+    nb = lib.bpx_seg_loss_blocks(n)
+    part = torch.empty((nb, 6), dtype=torch.float32, device=logits.device)
     L.check(lib.bpx_seg_loss_sums(logits.data_ptr(), target.data_ptr(), n, part.data_ptr(), L.stream_ptr()))
-    return part.to(torch.float64).sum(0)
+    sums = torch.empty(6, dtype=torch.float64, device=logits.device)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    L.check(lib.bpx_seg_loss_finish(part.data_ptr(), nb, n, w_ce, w_dice, smooth, sums.data_ptr(), loss.data_ptr(), L.stream_ptr()))
+    return sums, loss
+
+
+def _sums(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    return _sums_and_loss(logits, target)[0]
 
 
 def _prep(logits: torch.Tensor, target: torch.Tensor):
@@ -37,23 +47,20 @@ class _SegLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, w_ce, w_dice, smooth):
         z, t = _prep(logits, target)
-        s = _sums(z, t)
-        n = z.numel()
-        inter, union = s[1], s[2] + s[3]
-        loss = w_ce * s[0] / n + w_dice * (1.0 - (2.0 * inter + smooth) / (union + smooth))
+        s, loss = _sums_and_loss(z, t, w_ce, w_dice, smooth)
         ctx.save_for_backward(z, t, s)
-        ctx.cfg = (w_ce, w_dice, smooth, n)
-        return loss.to(torch.float32)
+        ctx.cfg = (w_ce, w_dice, smooth, z.numel())
+        return loss
 
     @staticmethod
     def backward(ctx, g):
         z, t, s = ctx.saved_tensors
         w_ce, w_dice, smooth, n = ctx.cfg
-        g = g.to(torch.float64)
-        den = s[2] + s[3] + smooth
-        coef = torch.stack([w_ce * g / n, 2.0 * w_dice * g / den, w_dice * g * (2.0 * s[1] + smooth) / (den * den)]).to(torch.float32)
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
         dz = torch.empty_like(z)
-        L.check(lib.bpx_seg_loss_bwd(z.data_ptr(), t.data_ptr(), n, coef.data_ptr(), dz.data_ptr(), L.stream_ptr()))
+        # the three coefficients a = w_ce g / n, b = 2 w_dice g / (U + s), c = w_dice g (2 I + s) / (U + s)^2 are formed inside the kernel
+        L.check(lib.bpx_seg_loss_bwd_fused(z.data_ptr(), t.data_ptr(), n, s.data_ptr(), g.data_ptr(), w_ce, w_dice, smooth, dz.data_ptr(), L.stream_ptr()))
         return dz, None, None, None, None
 
 
@@ -122,18 +129,22 @@ class _ChanLossFn(torch.autograd.Function):
         nb = lib.bpx_chan_loss_blocks(vox)
         part = torch.empty((N, Cc, nb), dtype=torch.float32, device=z.device)
         L.check(lib.bpx_chan_loss_sums(z.data_ptr(), t.data_ptr(), N, Cc, vox, codes, part.data_ptr(), L.stream_ptr()))
-        per_ch = part.to(torch.float64).sum((0, 2)) / float(N * vox)                 # mean of every channel's terms (metrics.py:1784-1788)
-        ctx.save_for_backward(z, t, weights)
+        # mean of every channel's terms (metrics.py:1784-1788), weighted and summed, by one single-block kernel (fixed-order double sums)
+        w32 = weights if (weights.dtype == torch.float32 and weights.is_contiguous()) else weights.to(torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        L.check(lib.bpx_chan_loss_finish(part.data_ptr(), N, Cc, vox, w32.data_ptr(), loss.data_ptr(), L.stream_ptr()))
+        ctx.save_for_backward(z, t, w32)
         ctx.cfg = (codes, N, Cc, vox)
-        return (per_ch * weights.to(torch.float64)).sum().to(torch.float32)
+        return loss
 
     @staticmethod
     def backward(ctx, g):
         z, t, weights = ctx.saved_tensors
         codes, N, Cc, vox = ctx.cfg
-        coef = (g.to(torch.float32) * weights / float(N * vox)).contiguous()
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
         dz = torch.empty_like(z)
-        L.check(lib.bpx_chan_loss_bwd(z.data_ptr(), t.data_ptr(), N, Cc, vox, codes, coef.data_ptr(), dz.data_ptr(), L.stream_ptr()))
+        L.check(lib.bpx_chan_loss_bwd_fused(z.data_ptr(), t.data_ptr(), N, Cc, vox, codes, weights.data_ptr(), g.data_ptr(), dz.data_ptr(), L.stream_ptr()))
         return dz, None, None, None
 
 
@@ -152,6 +163,12 @@ class InstanceChannelsLoss(torch.nn.Module):
             raise NotImplementedError("InstanceChannelsLoss: border weights, class heads, re-balancing and ignore_index stay on the reference loss")
         if any(c in ("R", "A", "E_offset", "E_sigma", "E_seediness") for c in chans) or any((channel_extra_opts or {}).get(c, {}).get("mask_values") for c in chans):
             raise NotImplementedError("InstanceChannelsLoss: multi-width channels and masked channels stay on the reference loss")
+        if any(c in ("Gv", "Gh", "Gz") for c in chans):
+            # the reference multiplies the flow TARGET by flow_target_scale (5 for cellpose / omnipose fields, metrics.py:235-246, :1700-1705)
+            raise NotImplementedError("InstanceChannelsLoss: flow channels (Gv / Gh / Gz: scaled targets) stay on the reference loss")
+        if "Db" in chans and (channel_extra_opts or {}).get("Db", {}).get("val_type", "norm") == "discretize":
+            # 11 prediction channels against one index channel, cross-entropy (metrics.py:1679-1688)
+            raise NotImplementedError("InstanceChannelsLoss: a discretised 'Db' channel stays on the reference loss")
         if len(losses_to_use) != len(chans) or len(channel_weights) != len(chans) or len(chans) > 8:
             raise ValueError("one loss and one weight per output channel (at most 8 channels)")
         acts = list(head_activations) if head_activations is not None else ["tanh" if c == "D" else "ce_sigmoid" for c in chans]

@@ -87,6 +87,24 @@ def test_losses_fail_loudly_without_gpu():
         losses.DiceLoss(batch_dice=False)
 
 
+def test_instance_channels_loss_refuses_what_it_does_not_reproduce():
+    """channels whose reference loss is not the plain per-channel term must be refused at construction, not computed wrongly:
+    flow channels (targets scaled by flow_target_scale, metrics.py:235-246, :1700-1705), a discretised 'Db' (11 prediction channels, CE),
+    multi-width and masked channels; every accepted letter is a plain one-channel term."""
+    from biapy_amd.losses import InstanceChannelsLoss
+
+    InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"])
+    InstanceChannelsLoss(channel_weights=(1, 1), out_channels=["F", "Db"], losses_to_use=["bce", "mse"], head_activations=["ce_sigmoid", "linear"])
+    for ch in ("Gv", "Gh", "Gz", "R", "A"):
+        with pytest.raises(NotImplementedError):
+            InstanceChannelsLoss(channel_weights=(1, 1), out_channels=["F", ch], losses_to_use=["bce", "mse"], head_activations=["ce_sigmoid", "linear"])
+    with pytest.raises(NotImplementedError):
+        InstanceChannelsLoss(channel_weights=(1, 1), out_channels=["F", "Db"], losses_to_use=["bce", "bce"], channel_extra_opts={"Db": {"val_type": "discretize"}})
+    with pytest.raises(NotImplementedError):
+        InstanceChannelsLoss(channel_weights=(1, 1), out_channels=["F", "Dc"], losses_to_use=["bce", "mse"], head_activations=["ce_sigmoid", "linear"],
+                             channel_extra_opts={"Dc": {"mask_values": True}})
+
+
 def test_prepost_fails_loudly_without_gpu():
     import pytest
     import torch
