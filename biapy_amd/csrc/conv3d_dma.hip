@@ -56,8 +56,13 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   const int evox_rel = (wave * H) * W + ex;
 
   const int sub = tid & 1;
-  // the halo coordinates of this thread's piece u are re-derived at every issue (divisions by constants: a few VALU instructions, and
-  // the kernel has issue slots to spare but no registers: 256 VGPRs is the budget of two workgroups per CU)
+  // Halo coordinates of this thread's pieces: piece u is halo voxel (u * 256 + tid) / 2, i.e. 128 voxels = (7 rows, 2 columns) past piece
+  // u - 1.  Only piece 0's coordinates are kept; a stage walks them forward with two conditional wraps per piece (the kernel is bound by
+  // the number of instructions a wave issues - ~4 cycles each whatever the unit - so neither divisions per piece nor nine more
+  // loop-invariant registers are affordable in the forward instances)
+  static_assert(128 / HX == 7 && 128 % HX == 2 && HY >= 8 && HY <= 15, "piece walk: +2 columns, +7 rows, at most one wrap each");
+  const int hv0 = tid >> 1;
+  const int hx0 = hv0 % HX, hy0 = (hv0 / HX) % HY, hz0 = hv0 / (HX * HY);
   const uint32_t ld2 = (uint32_t)p.x_ld * 2u, sub16 = (uint32_t)sub * 16u;
   const char* __restrict__ wp = reinterpret_cast<const char*>(p.wp);
   const uint32_t wlane = (uint32_t)((g * Cout + co_base + j) * KPL) * 2u;
@@ -73,6 +78,9 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   constexpr uint32_t OOB = 0x80000000u;
   const bool has_norm = EPI == EPI_FWD && p.in_norm != nullptr;
 
+  // Workgroup (xcd, slot) owns the CONTIGUOUS run of tiles [slot * run, (slot + 1) * run) of its XCD's range (x fastest, then y, z, sample):
+  // the next tile follows from the current one by counter increments (a division-based decode per tile was ~150 scalar instructions), and
+  // consecutive tiles of a workgroup share a halo face that is still in the XCD's L2
   struct TileInfo { int n, tile, z0, y0, x0; };
   auto decode = [&](int local) {
     const int tileId = xcd * p.tilesPerXcd + local;
@@ -82,34 +90,56 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
     t.z0 = tzi * TZ; t.y0 = tyi * TY; t.x0 = txi * TX;
     return t;
   };
-  auto has_tile = [&](int local) { return local < p.tilesPerXcd && xcd * p.tilesPerXcd + local < p.totalTiles; };
+  auto advance = [&](const TileInfo& c) {
+    TileInfo t = c;
+    t.tile = c.tile + 1; t.x0 = c.x0 + TX;
+    if (t.x0 >= p.tilesX * TX) {
+      t.x0 = 0; t.y0 = c.y0 + TY;
+      if (t.y0 >= p.tilesY * TY) {
+        t.y0 = 0; t.z0 = c.z0 + TZ;
+        if (t.tile >= p.tilesPerSample) { t.z0 = 0; t.tile = 0; t.n = c.n + 1; }
+      }
+    }
+    return t;
+  };
+  const int run = (p.tilesPerXcd + spx - 1) / spx;
+  const int local_end = min(min((slot + 1) * run, p.tilesPerXcd), p.totalTiles - xcd * p.tilesPerXcd);
+  auto is_interior = [&](const TileInfo& t) {
+    return t.z0 >= 1 && t.z0 + TZ + 1 <= D && t.y0 >= 1 && t.y0 + TY + 1 <= H && t.x0 >= 1 && t.x0 + TX + 1 <= W;
+  };
 
   // DMA of one stage (tile t, input-channel chunk) into halo buffer `buf`, one 16-byte piece per lane and call; returns whether this thread's
   // piece u lies inside the volume.  The pieces of the NEXT stage are issued one per MFMA step of the current one (an LDS-DMA instruction
   // costs its wave 100-250 issue cycles: nine of them in a row were 2 K cycles per stage, scripts/dma_stamps.py)
-  struct StageBase { uint32_t base_b; int zm, ym, xm; bool interior; };
+  struct StageBase { uint32_t base_b; int zm, ym, xm; bool interior; int hx, hy, hz; };
   auto stage_base = [&](const TileInfo& t, int chunk) {
     StageBase b;
     b.base_b = (uint32_t)(((t.n * D + t.z0 - 1) * H + (t.y0 - 1)) * W + (t.x0 - 1)) * (uint32_t)p.x_ld * 2u + (uint32_t)chunk * x_csb;
     b.zm = t.z0 - 1; b.ym = t.y0 - 1; b.xm = t.x0 - 1;
-    b.interior = t.z0 >= 1 && t.z0 + TZ + 1 <= D && t.y0 >= 1 && t.y0 + TY + 1 <= H && t.x0 >= 1 && t.x0 + TX + 1 <= W;
+    b.interior = is_interior(t);
+    b.hx = hx0; b.hy = hy0; b.hz = hz0;
     return b;
   };
-  auto issue_piece = [&](const StageBase& b, int buf, int u) {
+  auto issue_piece = [&](StageBase& b, int buf, int u) {      // pieces in order u = 0, 1, ...: b carries the walking coordinates
     bool ok = (u < NP - 1) || (NP - 1) * 256 + tid < NPIECE;
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));                  // keep the coordinates out of loop-invariant registers
-    const uint32_t hv = (uint32_t)(u * 256 + tid_o) >> 1;
-    const uint32_t hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    const bool in = (unsigned)(b.zm + (int)hz) < (unsigned)D && (unsigned)(b.ym + (int)hy) < (unsigned)H && (unsigned)(b.xm + (int)hx) < (unsigned)W;
-    ok = ok && (b.interior || in);
-    const uint32_t relb = ((hz * (uint32_t)H + hy) * (uint32_t)W + hx) * ld2 + sub16;
+    const int hx = b.hx, hy = b.hy, hz = b.hz;
+    // bitwise, not short-circuit: straight-line code instead of an exec-mask branch per comparison
+    const bool in = ((unsigned)(b.zm + hz) < (unsigned)D) & ((unsigned)(b.ym + hy) < (unsigned)H) & ((unsigned)(b.xm + hx) < (unsigned)W);
+    ok = ok & (b.interior | in);
+    const uint32_t relb = (uint32_t)((hz * H + hy) * W + hx) * ld2 + sub16;
+    {   // next piece: 128 halo voxels further
+      int nx = hx + 2, ny = hy + 7;
+      const bool wx = nx >= HX;
+      nx = wx ? nx - HX : nx; ny = wx ? ny + 1 : ny;
+      const bool wy = ny >= HY;
+      b.hx = nx; b.hy = wy ? ny - HY : ny; b.hz = wy ? hz + 1 : hz;
+    }
     const uint32_t off = ok ? b.base_b + relb : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + buf * BUFB + u * 4096 + wave * 1024), 16, off, 0, 0, 0);
     return ok ? (1u << u) : 0u;
   };
   auto issue = [&](const TileInfo& t, int chunk, int buf) {
-    const StageBase b = stage_base(t, chunk);
+    StageBase b = stage_base(t, chunk);
     uint32_t vm = 0;
 #pragma unroll
     for (int u = 0; u < NP; ++u) vm |= issue_piece(b, buf, u);
@@ -133,13 +163,13 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
     return *reinterpret_cast<const f32x2_t*>(&p.in_norm[(size_t)n * p.Cin + chunk * 16 + (tid & 15)].scale);
   };
 
-  if (!has_tile(slot)) return;
+  if (slot * run >= local_end) return;
   // profiling (scripts/dma_stamps.py): cycle stamps of one steady-state stage of this workgroup, the last chunk of a tile
   long long* stamps = (p.stamps && tid == 0 && blockIdx.y == 0) ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
   int stamp_i = 0, it = 0;
   const int stamp_it = 2 * nchunks + nchunks - 1;
 #define BPX_STAMP() do { if (stamps && it == stamp_it && stamp_i < 15) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
-  int local = slot, chunk = 0, cbuf = 0;
+  int local = slot * run, chunk = 0, cbuf = 0;
   TileInfo cur = decode(local);
   uint32_t vm_cur = issue(cur, 0, 0), vm_next = 0;
   int sp = 0;                                        // parity of the stage: which half of the table holds its records
@@ -160,10 +190,11 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
     bool hasnext = true;
     TileInfo nxt = cur;
     if (nchunk == nchunks) {
-      nchunk = 0; nlocal = local + spx;
-      hasnext = has_tile(nlocal);
-      if (hasnext) nxt = decode(nlocal);
+      nchunk = 0; nlocal = local + 1;
+      hasnext = nlocal < local_end;
+      if (hasnext) nxt = advance(cur);
     }
+    const bool int_cur = is_interior(cur);
     BPX_STAMP();                                     // 0: top of the stage
     load_w(chunk);                                   // every stage (L1 / L2 hits), in front of the wait below, which covers them: the 56 registers are
                                                      // then free during the epilogue, which needs them for the shortcut operands
@@ -205,9 +236,15 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
             v[q][i] = pk16<T>(a, b);
           }
         }
+        if (int_cur) {             // every piece lies inside the volume (61 % of the 128^3 tiles): no exec-mask juggling around the write-back
 #pragma unroll
-        for (int q = 0; q < RB; ++q)
-          if (u0 + q < NP && ((vm_cur >> (u0 + q)) & 1u)) *reinterpret_cast<u32x4_t*>(hb + (size_t)((u0 + q) * 256 + tid) * 16) = v[q];
+          for (int q = 0; q < RB; ++q)
+            if (u0 + q < NP) *reinterpret_cast<u32x4_t*>(hb + (size_t)((u0 + q) * 256 + tid) * 16) = v[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < RB; ++q)
+            if (u0 + q < NP && ((vm_cur >> (u0 + q)) & 1u)) *reinterpret_cast<u32x4_t*>(hb + (size_t)((u0 + q) * 256 + tid) * 16) = v[q];
+        }
       }
     }
     BPX_STAMP();                                     // 2: in-place prologue done
@@ -264,6 +301,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(hb + lbase[cls] + ms * HSTR + imm);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) once per step instead of one counted wait in front of every MFMA (112 -> 14 issue slots)
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll

@@ -73,8 +73,8 @@ s = s[s[:, 0] != 0][:, :15]
 nz = int((s != 0).sum(1).max())
 s = s[(s[:, :nz] != 0).all(1)]
 d = np.diff(s[:, :nz], axis=1).astype(np.float64)
-names = ["weights of the chunk requested + wait for this stage's DMA (vmcnt 0)", "in-place normalise + ELU (LDS -> LDS)", "barrier", "issue next stage's DMA",
-         "14 MFMA steps", "fused 1x1x1 shortcut (global -> MFMA)", "epilogue operands + math + stores", "statistics barrier + store"]
+names = ["weights of the chunk requested + wait for this stage's DMA (vmcnt 0)", "in-place normalise + ELU (LDS -> LDS)", "barrier",
+         "request the epilogue operands (t / image / shortcut chunk 0)", "14 MFMA steps + the next stage's DMA pieces", "fused 1x1x1 shortcut (chunks overlapped)", "epilogue math + 16-byte stores", "statistics barrier + store"]
 print(f"{what}: {len(s)} workgroups, {nz} stamps; cycles (median / mean / p90) per phase of one steady-state last-chunk stage, wave 0")
 for i in range(d.shape[1]):
     print(f"  {names[i] if i < len(names) else str(i):72s} {np.median(d[:, i]):9.0f} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 90):9.0f}")
