@@ -55,6 +55,7 @@ _SIGS = {
     "bpx_histogram_f32": ([_vp, _i64, _f, _f, _i, _vp, _vp, _vp], _i),
     "bpx_threshold_u8": ([_vp, _i64, _f, _vp, _vp], _i),
     "bpx_clip_affine_f32": ([_vp, _i64, _f, _f, _f, _f, _vp, _vp], _i),
+    "bpx_class_argmax": ([_vp, _i64, _i, _i, _vp, _vp], _i),
     "bpx_tta_orient": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "bpx_tta_accumulate": ([_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_chan_loss_blocks": ([_i64], _i),
@@ -84,6 +85,9 @@ _SIGS = {
     "bpx_convT3d_k2s2_dgrad": ([_i, _i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp], _i),
     "bpx_convT3d_k2s2_wgrad": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_norm_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _f, _i, _vp, _i, _i, _vp], _i),
+    "bpx_norm_channel_sums": ([_vp, _i, _i, _i, _vp, _i, _i, _vp], _i),
+    "bpx_groupnorm_finalize": ([_vp, _i, _i, _i64, _vp, _vp, _f, _i, _vp, _vp], _i),
+    "bpx_groupnorm_bwd_finalize": ([_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "bpx_tensor_stats": ([_i, _i, _i64, Tensor, _vp, _vp], _i),
     "bpx_tensor_stats_tiles": ([_i64], _i),
     "bpx_norm_bwd_finalize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp], _i),

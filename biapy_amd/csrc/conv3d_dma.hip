@@ -26,7 +26,7 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int TZ, int TY, int TX, int NS, int EPI, int ACTK, bool F16, bool TF16>
-__global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) {
+__global__ void __launch_bounds__(256, TY == 8 ? 2 : 3) conv3_dma_kernel(const Conv3Params p) {
   using T = typename std::conditional<F16, f16_t, uint16_t>::type;
   using TT = typename std::conditional<TF16, f16_t, uint16_t>::type;
   constexpr int KPL = 8, VB = 32;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
   // u - 1.  Only piece 0's coordinates are kept; a stage walks them forward with two conditional wraps per piece (the kernel is bound by
   // the number of instructions a wave issues - ~4 cycles each whatever the unit - so neither divisions per piece nor nine more
   // loop-invariant registers are affordable in the forward instances)
-  static_assert(128 / HX == 7 && 128 % HX == 2 && HY >= 8 && HY <= 15, "piece walk: +2 columns, +7 rows, at most one wrap each");
+  static_assert(128 / HX == 7 && 128 % HX == 2 && HY >= 6 && HY <= 15, "piece walk: +2 columns, +7 rows (+1 with the column wrap), then rows modulo HY");
   const int hv0 = tid >> 1;
   const int hx0 = hv0 % HX, hy0 = (hv0 / HX) % HY, hz0 = hv0 / (HX * HY);
   const uint32_t ld2 = (uint32_t)p.x_ld * 2u, sub16 = (uint32_t)sub * 16u;
@@ -131,8 +131,10 @@ __global__ void __launch_bounds__(256, 2) conv3_dma_kernel(const Conv3Params p) 
       int nx = hx + 2, ny = hy + 7;
       const bool wx = nx >= HX;
       nx = wx ? nx - HX : nx; ny = wx ? ny + 1 : ny;
+      int nz = hz;
+      if (HY < 8) { const bool w0 = ny >= 2 * HY; ny = w0 ? ny - HY : ny; nz = w0 ? nz + 1 : nz; }   // 4x4x16 tile: HY = 6, up to two wraps
       const bool wy = ny >= HY;
-      b.hx = nx; b.hy = wy ? ny - HY : ny; b.hz = wy ? hz + 1 : hz;
+      b.hx = nx; b.hy = wy ? ny - HY : ny; b.hz = wy ? nz + 1 : nz;
     }
     const uint32_t off = ok ? b.base_b + relb : 0x80000000u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + buf * BUFB + u * 4096 + wave * 1024), 16, off, 0, 0, 0);
@@ -578,7 +580,7 @@ int launch_dma(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   { static const char* e = getenv("BPX_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int gy = p.Cout / (16 * c.ns);
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
-  int gx = std::max(8, (cu_count_dma() * 2 / gy) & ~7);
+  int gx = std::max(8, (cu_count_dma() * (c.ty == 8 ? 2 : 3) / gy) & ~7);
   gx = std::min(gx, 8 * p.tilesPerXcd);
   dim3 grid((unsigned)gx, (unsigned)gy);
 #define L(TY, NS)                                                                                      \
@@ -603,7 +605,7 @@ int launch_dma(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
     else conv3_dma_kernel<4, TY, 16, NS, EPI, 0, false, false><<<grid, 256, 0, s>>>(p);                 \
     return 0;                                                                                          \
   }
-  L(8, 1)   // NS = 2 (32 output channels, 4x4x16 tile) compiles with scratch at 256 VGPRs (112 weight registers): those layers stay on conv3_lp_kernel
+  L(8, 1) L(4, 1)   // NS = 2 (32 output channels, 4x4x16 tile) compiles with scratch at 256 VGPRs (112 weight registers): those layers stay on conv3_lp_kernel
 #undef L
   return 1;
 }
@@ -619,7 +621,7 @@ bool conv3_dma_applies(const Conv3Params& p, const TileCfg& c) {
   const int64_t xbytes = (p.x_cs == 16 ? vox * p.x_ld : (int64_t)p.x_cs * (p.Cin / 16)) * 2;
   const int64_t tbytes = p.t ? (p.t_cs == 16 ? vox * p.t_ld : (int64_t)p.t_cs * (p.Cout / 16)) * 2 : 0;
   const int64_t sbytes = p.sc ? (p.sc_C == 1 ? vox * 4 : (p.sc_cs == 16 ? vox * p.sc_ld : (int64_t)p.sc_cs * (p.sc_C / 16)) * 2) : 0;
-  return g_conv_dma != 0 && c.tz == 4 && c.tx == 16 && c.ty == 8 && c.ns == 1 && std::max(xbytes, std::max(tbytes, sbytes)) < (1ll << 31);
+  return g_conv_dma != 0 && c.tz == 4 && c.tx == 16 && (c.ty == 8 || c.ty == 4) && c.ns == 1 && std::max(xbytes, std::max(tbytes, sbytes)) < (1ll << 31);
 }
 int launch_conv3_dma(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s) {
   return epi == EPI_FWD ? launch_dma<EPI_FWD>(p, c, s) : launch_dma<EPI_DGRAD>(p, c, s);

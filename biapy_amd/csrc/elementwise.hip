@@ -237,6 +237,79 @@ __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __
   }
 }
 
+// ---- GroupNorm with ANY group width, over a tensor that may be the concatenation of two producers' outputs (round 3) -------------------
+// The decoder's first norm sees torch.cat([up, skip], 1): with 8 groups over 3 fm channels a group is 6 / 12 / 24 / 48 channels wide and one of
+// them straddles the concat boundary, i.e. draws its statistics from the partial sums of TWO producer kernels.  Two small steps replace
+// norm_finalize there: every producer's partials -> per-channel totals in one (N, C, 2) array of doubles (its columns at out_off), then one
+// block per sample forms the group statistics from the channel totals and writes all C records.  The backward mirrors it.
+__global__ void __launch_bounds__(1024) chan_sums_kernel(const float* __restrict__ part, int tiles, int tstride, int C, double* __restrict__ sums,
+                                                        int out_ld, int out_off) {
+  __shared__ double red[2][1024];
+  const int cb = 16, lanes = 1024 / cb;
+  const int n = blockIdx.y, c0 = blockIdx.x * cb;
+  const int c = threadIdx.x % cb, tl = threadIdx.x / cb;
+  double s1 = 0.0, s2 = 0.0;
+  if (c0 + c < C)
+    tile_sums(part + (size_t)n * tiles * 2 * C + c0 + c, C, (tiles + tstride - 1) / tstride, (size_t)tstride * 2 * C, tl, lanes, s1, s2);
+  lane_reduce(red, cb, lanes, s1, s2);
+  if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
+    double* o = sums + ((size_t)n * out_ld + out_off + c0 + threadIdx.x) * 2;
+    o[0] = red[0][threadIdx.x]; o[1] = red[1][threadIdx.x];
+  }
+}
+
+__global__ void __launch_bounds__(512) gn_finalize_kernel(const double* __restrict__ sums, int C, double inv_count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int cpg, bpx_norm_rec* __restrict__ out) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int gb = (c / cpg) * cpg;
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < cpg; ++q) { a += sums[((size_t)n * C + gb + q) * 2]; b += sums[((size_t)n * C + gb + q) * 2 + 1]; }   // fixed order
+    const double m = a * inv_count / cpg;
+    double v = b * inv_count / cpg - m * m;
+    if (v < 0.0) v = 0.0;
+    const float rstd = (float)(1.0 / sqrt(v + (double)eps));
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    bpx_norm_rec r;
+    r.mean = (float)m; r.rstd = rstd; r.scale = ga * rstd; r.shift = be - (float)m * ga * rstd;
+    out[(size_t)n * C + c] = r;
+  }
+}
+
+// sums: per-channel totals {S1 = sum g, S2 = sum g * xhat}; same formulas as norm_bwd_finalize_kernel; one block, the samples in index
+// order, so that dgamma / dbeta are fixed-order sums (deterministic)
+__global__ void __launch_bounds__(512) gn_bwd_finalize_kernel(const double* __restrict__ sums, int N, int C, double inv_count,
+                                                             const bpx_norm_rec* __restrict__ rec, const float* __restrict__ gamma,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int cpg,
+                                                             bpx_nbwd_coef* __restrict__ coef) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int gb = (c / cpg) * cpg;
+    const double ga = gamma ? (double)gamma[c] : 1.0;
+    double dg = 0.0, db = 0.0;
+    for (int n = 0; n < N; ++n) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int q = 0; q < cpg; ++q) {
+        const double gq = gamma ? (double)gamma[gb + q] : 1.0;
+        a1 += gq * sums[((size_t)n * C + gb + q) * 2];
+        a2 += gq * sums[((size_t)n * C + gb + q) * 2 + 1];
+      }
+      const double m1 = a1 * inv_count / cpg, m2 = a2 * inv_count / cpg;
+      const bpx_norm_rec r = rec[(size_t)n * C + c];
+      const double rs = (double)r.rstd;
+      bpx_nbwd_coef k;
+      k.a = (float)(ga * rs);
+      k.b = (float)(-rs * rs * m2);
+      k.c0 = (float)(-rs * m1 + rs * rs * (double)r.mean * m2);
+      k.pad = 0.f;
+      coef[(size_t)n * C + c] = k;
+      db += (double)(float)sums[((size_t)n * C + c) * 2];
+      dg += (double)(float)sums[((size_t)n * C + c) * 2 + 1];
+    }
+    if (dgamma) dgamma[c] += (float)dg;
+    if (dbeta) dbeta[c] += (float)db;
+  }
+}
+
 // TT: element type of the activation tensor t (BPX_MIX16: fp16 beside bf16 gradients), else T
 template <typename T, typename TT = T>
 __global__ void __launch_bounds__(256) norm_bwd_apply_kernel(const T* __restrict__ g, int g_ld, const TT* __restrict__ t, int t_ld,
@@ -1171,6 +1244,37 @@ extern "C" int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, i
   const int tstride = compact_stats(stats_part_d, N, tiles, C, (hipStream_t)stream);   // consumes the partials
   norm_finalize_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(stats_part_d, tiles, tstride, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps,
                                                               cpg, cb, out_d, out_ld, out_off);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_norm_channel_sums(float* stats_part_d, int N, int tiles, int C, double* sums_d, int out_ld, int out_off, bpx_stream_t stream) {
+  const char* fn = "bpx_norm_channel_sums";
+  BPX_CHECK(stats_part_d && sums_d, "%s: null pointer", fn);
+  BPX_CHECK(C >= 1 && out_off >= 0 && out_off + C <= out_ld, "%s: columns [%d, %d) do not fit a row of %d", fn, out_off, out_off + C, out_ld);
+  dim3 grid((unsigned)cdiv(C, 16), (unsigned)N);
+  const int tstride = compact_stats(stats_part_d, N, tiles, C, (hipStream_t)stream);   // consumes the partials
+  chan_sums_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(stats_part_d, tiles, tstride, C, sums_d, out_ld, out_off);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_groupnorm_finalize(const double* sums_d, int N, int C, int64_t count_per_channel, const float* gamma_d, const float* beta_d, float eps,
+                                      int groups, bpx_norm_rec* out_d, bpx_stream_t stream) {
+  const char* fn = "bpx_groupnorm_finalize";
+  BPX_CHECK(sums_d && out_d, "%s: null pointer", fn);
+  BPX_CHECK(groups >= 1 && C % groups == 0, "%s: groups %d must divide C %d", fn, groups, C);
+  gn_finalize_kernel<<<(unsigned)N, 512, 0, (hipStream_t)stream>>>(sums_d, C, 1.0 / (double)count_per_channel, gamma_d, beta_d, eps, C / groups, out_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_groupnorm_bwd_finalize(const double* sums_d, int N, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d, const float* gamma_d,
+                                          float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d, bpx_stream_t stream) {
+  const char* fn = "bpx_groupnorm_bwd_finalize";
+  BPX_CHECK(sums_d && rec_d && coef_d, "%s: null pointer", fn);
+  BPX_CHECK(groups >= 1 && C % groups == 0, "%s: groups %d must divide C %d", fn, groups, C);
+  gn_bwd_finalize_kernel<<<1, 512, 0, (hipStream_t)stream>>>(sums_d, N, C, 1.0 / (double)count_per_channel, rec_d, gamma_d, dgamma_d, dbeta_d, C / groups, coef_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

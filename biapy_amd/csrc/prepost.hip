@@ -233,6 +233,34 @@ extern "C" int bpx_clip_affine_f32(const float* x_d, int64_t n, float lo, float 
   return 0;
 }
 
+// ---- class head of the sliding-window harness (base_workflow.py:2135-2141): the last k channels of the blended prediction become ONE
+// channel holding np.argmax over them (first maximum wins), the leading C - k channels pass through:
+//   out[v][0 .. C-k) = in[v][0 .. C-k),  out[v][C-k] = (float) argmax_q in[v][C-k+q]
+__global__ void __launch_bounds__(256) class_argmax_kernel(const float* __restrict__ in, int64_t vox, int C, int k, float* __restrict__ out) {
+  const int Co = C - k + 1;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < vox; v += (int64_t)gridDim.x * 256) {
+    const float* p = in + v * C;
+    float* o = out + v * Co;
+    for (int c = 0; c < C - k; ++c) o[c] = p[c];
+    int best = 0;
+    float bv = p[C - k];
+    for (int q = 1; q < k; ++q) {
+      const float x = p[C - k + q];
+      if (x > bv) { bv = x; best = q; }      // strict >: the first maximum, as np.argmax (a NaN never wins here; np.argmax returns the first NaN)
+    }
+    o[C - k] = (float)best;
+  }
+}
+
+extern "C" int bpx_class_argmax(const float* in_d, int64_t voxels, int C, int k, float* out_d, bpx_stream_t stream) {
+  const char* fn = "bpx_class_argmax";
+  BPX_CHECK(in_d && out_d && voxels > 0, "%s: bad arguments", fn);
+  BPX_CHECK(k >= 1 && k <= C, "%s: %d class channels of %d", fn, k, C);
+  class_argmax_kernel<<<blocks_for(voxels), 256, 0, (hipStream_t)stream>>>(in_d, voxels, C, k, out_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
 // ---- test-time augmentation: signed axis permutations of (Z,Y,X,C) volumes ---------------------------
 // biapy/data/post_processing/tta.py:64-196 (AxisTransform: output axis a comes from input axis perm[a], reversed when
 // sign[a] == -1) and post_processing.py:1386-1540 (ensemble_predictions: predict every orientation, undo it, reduce).

@@ -64,8 +64,11 @@ class NetConfig:
         if len(zd) != len(fm) - 1 or any(v not in (1, 2) for v in zd):
             raise NotImplementedError(f"z_down={self.z_down!r}: one value per level, each 1 or 2")
         self.z_down = tuple(zd)
-        if self.normalization != "in":
-            raise NotImplementedError(f"normalization={self.normalization!r}: the MI355X engine implements 'in' (the reference default)")
+        if self.normalization not in ("in", "gn"):
+            raise NotImplementedError(f"normalization={self.normalization!r}: the MI355X engine implements 'in' (the reference default) and 'gn'")
+        # 'gn': torch.nn.GroupNorm(8, C) for every norm layer - what blocks.py:2122-2125 means (the reference's own call,
+        # nn.GroupNorm(out_channels, num_groups=8), raises a TypeError, so there is no reference output to pin this mode to)
+        self.gn_groups = 8 if self.normalization == "gn" else 0
         if self.activation not in L.ACT:
             raise NotImplementedError(f"activation={self.activation!r} is not implemented on the MI355X engine")
         if any(c % 16 for c in fm):
@@ -149,9 +152,23 @@ class _Stats:
         return torch.empty((B, tiles, 2, C), dtype=torch.float32, device=dev)
 
     @staticmethod
-    def finalize(part, B, tiles, C, count, gamma, beta, rec, rec_ld, rec_off, st):
-        L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, C, count, gamma.data_ptr(), beta.data_ptr(), EPS, C,
+    def finalize(part, B, tiles, C, count, gamma, beta, rec, rec_ld, rec_off, st, groups=0):
+        """InstanceNorm records (groups = 0 -> one group per channel) or GroupNorm(groups) records of ONE producer's tensor."""
+        L.check(lib.bpx_norm_finalize(part.data_ptr(), B, tiles, C, count, gamma.data_ptr(), beta.data_ptr(), EPS, groups or C,
                                       rec.data_ptr(), rec_ld, rec_off, st))
+
+    @staticmethod
+    def finalize_cat(parts, B, count, gamma, beta, rec, groups, st):
+        """GroupNorm(groups) records of torch.cat(producers, 1): parts = [(partials, tiles, C), ...] in channel order.  A group may straddle
+        the boundary between two producers (8 groups over 48 channels = 6 per group), so the per-channel totals of all of them are
+        gathered first (bpx_norm_channel_sums) and one more kernel forms the group statistics (bpx_groupnorm_finalize)."""
+        Ct = sum(c for _, _, c in parts)
+        sums = torch.empty((B, Ct, 2), dtype=torch.float64, device=rec.device)
+        off = 0
+        for part, tiles, c in parts:
+            L.check(lib.bpx_norm_channel_sums(part.data_ptr(), B, tiles, c, sums.data_ptr(), Ct, off, st))
+            off += c
+        L.check(lib.bpx_groupnorm_finalize(sums.data_ptr(), B, Ct, count, gamma.data_ptr(), beta.data_ptr(), EPS, groups, rec.data_ptr(), st))
 
 
 def _recs(B, C, dev):
@@ -364,7 +381,7 @@ class ResUNetEngine:
                                        L.ptr(blk.rec_x), self.act if blk.rec_x is not None else 0, wp.data_ptr(), P[k["b1"]].data_ptr(),
                                        L.NULL_T, None, None, L.tview(blk.h), part.data_ptr(), st))
         blk.rec_h = _recs(B, C1, dev)
-        _Stats.finalize(part, B, tiles, C1, vox, P[k["g1"]], P[k["be1"]], blk.rec_h, C1, 0, st)
+        _Stats.finalize(part, B, tiles, C1, vox, P[k["g1"]], P[k["be1"]], blk.rec_h, C1, 0, st, self.cfg.gn_groups)
         # ---- conv2 (+ shortcut, + residual add) -> out (+ stats) ----------------------------------
         wp2 = self._pack(P[k["w2"]], L.PK_K3, C1, C1, cache)
         tiles2 = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
@@ -485,7 +502,7 @@ class ResUNetEngine:
             nxt = "bottleneck" if i == Lv - 1 else f"down_path.{i + 1}"
             rec = _recs(B, fm[i], dev)
             _Stats.finalize(ppart, B, ptiles, fm[i], S[i + 1][0] * S[i + 1][1] * S[i + 1][2], P[f"{nxt}.block.0.weight"],
-                            P[f"{nxt}.block.0.bias"], rec, fm[i], 0, st)
+                            P[f"{nxt}.block.0.bias"], rec, fm[i], 0, st, cfg.gn_groups)
             pools.append(pooled)
             cur, cur_rec = pooled, rec
         # ---------------- bottleneck ----------------------------------------------------------------
@@ -511,9 +528,12 @@ class ResUNetEngine:
             vox = S[i][0] * S[i][1] * S[i][2]
             rec = _recs(B, Ccat, dev)
             g0, be0 = P[f"{pre}.block.0.weight"], P[f"{pre}.block.0.bias"]
-            _Stats.finalize(upart, B, utiles, Cup, vox, g0[:Cup], be0[:Cup], rec, Ccat, 0, st)
             spart, stiles = out_stats[i]
-            _Stats.finalize(spart, B, stiles, fm[i], vox, g0[Cup:], be0[Cup:], rec, Ccat, Cup, st)
+            if cfg.gn_groups:
+                _Stats.finalize_cat([(upart, utiles, Cup), (spart, stiles, fm[i])], B, vox, g0, be0, rec, cfg.gn_groups, st)
+            else:
+                _Stats.finalize(upart, B, utiles, Cup, vox, g0[:Cup], be0[:Cup], rec, Ccat, 0, st)
+                _Stats.finalize(spart, B, stiles, fm[i], vox, g0[Cup:], be0[Cup:], rec, Ccat, Cup, st)
             blk = _Blk(keys=block_keys(pre, False), first=False, S=S[i], cin=Ccat, cout=fm[i], x=cat[i], x_c0=0, rec_x=rec,
                        h=buf(i, fm[i]), out=buf(i, fm[i]), out_c0=0)
             self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=False)
@@ -583,7 +603,7 @@ class ResUNetEngine:
                                      L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
-                                          G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), C1, coef.data_ptr(), st))
+                                          G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), self.cfg.gn_groups or C1, coef.data_ptr(), st))
         L.check(lib.bpx_norm_bwd_apply(self.bdt, B, vox, L.tview(g1), L.tview(blk.h), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         dH = L.tview(g1)
         # conv1
@@ -608,8 +628,16 @@ class ResUNetEngine:
             L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dH, w1t.data_ptr(), xv, blk.rec_x.data_ptr(), self.act, L.tview(g0),
                                          red0.data_ptr(), st))
             coef0 = torch.empty((B, Cx, 4), dtype=torch.float32, device=dev)
-            L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
-                                              G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), Cx, coef0.data_ptr(), st))
+            gng = self.cfg.gn_groups
+            if gng and (Cx // gng) not in (1, 2, 4, 8, 16, 32, 64):
+                # the concatenated decoder input: 6 / 12 / 24 / 48 channels per group -> per-channel totals, then the general group kernel
+                sums0 = torch.empty((B, Cx, 2), dtype=torch.float64, device=dev)
+                L.check(lib.bpx_norm_channel_sums(red0.data_ptr(), B, tiles0, Cx, sums0.data_ptr(), Cx, 0, st))
+                L.check(lib.bpx_groupnorm_bwd_finalize(sums0.data_ptr(), B, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(), G[k["g0"]].data_ptr(),
+                                                       G[k["be0"]].data_ptr(), gng, coef0.data_ptr(), st))
+            else:
+                L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
+                                                  G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), gng or Cx, coef0.data_ptr(), st))
             if isinstance(dx_out, tuple):   # decoder block: the gradient of the concatenated input leaves as its (up, skip) parts
                 assert dx_extra is None
                 L.check(lib.bpx_conv1x1_fwd_split(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),

@@ -41,7 +41,9 @@ def _conv(ndim: int):
     return nn.Conv2d if ndim == 2 else nn.Conv3d
 
 
-def _inorm(ndim: int, c: int) -> nn.Module:
+def _inorm(ndim: int, c: int, kind: str = "in") -> nn.Module:
+    if kind == "gn":          # what blocks.py:2122-2125 means by 'gn' (its own call raises): GroupNorm(8, C); same parameter names and shapes
+        return nn.GroupNorm(8, c)
     return (nn.InstanceNorm2d if ndim == 2 else nn.InstanceNorm3d)(c, affine=True, momentum=0.1)
 
 
@@ -49,23 +51,23 @@ class ConvBlock(nn.Module):
     """Parameter holder named like blocks.py:25-192: ``block = Sequential(conv[, norm, act])``.  ``k`` is an int or the
     reference's kernel tuple ((3,3) in 2D, (1,3,3) for an anisotropic level)."""
 
-    def __init__(self, cin: int, cout: int, k, with_norm_act: bool, act: str, ndim: int = 3):
+    def __init__(self, cin: int, cout: int, k, with_norm_act: bool, act: str, ndim: int = 3, norm: str = "in"):
         super().__init__()
         layers: List[nn.Module] = [_conv(ndim)(cin, cout, kernel_size=k, padding="same")]
         if with_norm_act:
-            layers += [_inorm(ndim, cout), _act_layer(act)]
+            layers += [_inorm(ndim, cout, norm), _act_layer(act)]
         self.block = nn.Sequential(*layers)
 
 
 class ResConvBlock(nn.Module):
     """Parameter holder named like blocks.py:1194-1459 (post-activation order, two convolutions)."""
 
-    def __init__(self, cin: int, cout: int, k, act: str, first_block: bool, ndim: int = 3):
+    def __init__(self, cin: int, cout: int, k, act: str, first_block: bool, ndim: int = 3, norm: str = "in"):
         super().__init__()
         layers: List[nn.Module] = []
         if not first_block:
-            layers += [_inorm(ndim, cin), _act_layer(act)]
-        layers += [ConvBlock(cin, cout, k, True, act, ndim), ConvBlock(cout, cout, k, False, act, ndim)]
+            layers += [_inorm(ndim, cin, norm), _act_layer(act)]
+        layers += [ConvBlock(cin, cout, k, True, act, ndim, norm), ConvBlock(cout, cout, k, False, act, ndim, norm)]
         self.block = nn.Sequential(*layers)
         self.shortcut = nn.Sequential(_conv(ndim)(cin, cout, kernel_size=1, padding="same"))
 
@@ -73,13 +75,13 @@ class ResConvBlock(nn.Module):
 class ResUpBlock(nn.Module):
     """Parameter holder named like blocks.py:1462-1655."""
 
-    def __init__(self, cin: int, cbridge: int, cout: int, k, act: str, z_down: int = 2, ndim: int = 3):
+    def __init__(self, cin: int, cbridge: int, cout: int, k, act: str, z_down: int = 2, ndim: int = 3, norm: str = "in"):
         super().__init__()
         if ndim == 2:
             self.up = nn.ConvTranspose2d(cin, cin, kernel_size=(2, 2), stride=(2, 2))
         else:
             self.up = nn.ConvTranspose3d(cin, cin, kernel_size=(z_down, 2, 2), stride=(z_down, 2, 2))   # k = s = (z_down, yx, yx), blocks.py:1607
-        self.conv_block = ResConvBlock(cin + cbridge, cout, k, act, False, ndim)
+        self.conv_block = ResConvBlock(cin + cbridge, cout, k, act, False, ndim, norm)
 
 
 class _ResUNetFn(torch.autograd.Function):
@@ -278,15 +280,15 @@ class ResUNet(nn.Module):
         self.mpooling_layers = nn.ModuleList()
         c = in_ch
         for i in range(depth):
-            self.down_path.append(ResConvBlock(c, feature_maps[i], ks[i], act, first_block=(i == 0), ndim=ndim))
+            self.down_path.append(ResConvBlock(c, feature_maps[i], ks[i], act, first_block=(i == 0), ndim=ndim, norm=normalization))
             self.mpooling_layers.append(nn.MaxPool2d((2, 2)) if ndim == 2 else nn.MaxPool3d((zd[i], 2, 2)))
             c = feature_maps[i]
-        self.bottleneck = ResConvBlock(c, feature_maps[-1], ks[-1], act, False, ndim)
+        self.bottleneck = ResConvBlock(c, feature_maps[-1], ks[-1], act, False, ndim, normalization)
         self.num_decoders = 1
         self.up_paths = nn.ModuleList([nn.ModuleList()])
         c = feature_maps[-1]
         for i in range(depth - 1, -1, -1):
-            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], ks[i], act, zd[i], ndim))
+            self.up_paths[0].append(ResUpBlock(c, feature_maps[i], feature_maps[i], ks[i], act, zd[i], ndim, normalization))
             c = feature_maps[i]
         self.conv_out = None
         self.post_upsampling = (nn.ConvTranspose3d(feature_maps[0], feature_maps[0], kernel_size=(self.sr_post, 2, 2), stride=(self.sr_post, 2, 2))

@@ -215,6 +215,65 @@ class SlidingWindowPredictor:
         # forward: (B,C,Z,Y,X) fp32 -> (B,Cout,Z,Y,X) fp32 probabilities (ce_sigmoid head)
         self.forward = forward or (lambda x: model.predict_proba(x))
 
+    # ---- the steps of process_test_sample around the blended prediction (base_workflow.py:2089-2141; the padding itself is
+    #      pad_to_shape, data_manipulation.py:3218-3300, called by the test generators with DATA.REFLECT_TO_COMPLETE_SHAPE) ----------------
+    @staticmethod
+    def _gather_axes(vol: torch.Tensor, idx_zyx) -> torch.Tensor:
+        """out[z, y, x, :] = vol[iz[z], iy[y], ix[x], :] by the table-gather kernel (no PyTorch indexing on the volume)."""
+        import numpy as np
+
+        from . import _lib as L
+
+        Z, Y, X, C = vol.shape
+        tabs = torch.from_numpy(np.concatenate([np.asarray(t, dtype=np.int32) for t in idx_zyx])).to(vol.device)
+        Pz, Py, Px = (len(t) for t in idx_zyx)
+        out = torch.empty((Pz, Py, Px, C), dtype=vol.dtype, device=vol.device)
+        L.check(L.lib.bpx_gather3d_tables(vol.data_ptr(), vol.element_size(), Z, Y, X, C, tabs.data_ptr(), 1, Pz, Py, Px, out.data_ptr(), L.stream_ptr()))
+        return out
+
+    def pad_to_shape(self, vol: torch.Tensor, mode: str = "reflect") -> torch.Tensor:
+        """``pad_to_shape(img, crop_shape)`` of the reference: every spatial axis shorter than the patch is extended IN FRONT (the image stays in
+        the bottom-right corner) with ``np.pad(..., mode)``; the source indices come from NumPy itself (np.pad of an index ramp), so repeated
+        reflections of very short axes are the reference's own."""
+        import numpy as np
+
+        if mode != "reflect":
+            raise NotImplementedError("pad_to_shape: only the reference's default mode 'reflect' is implemented on the device")
+        idx = []
+        for n, p in zip(vol.shape[:3], self.patch):
+            ramp = np.arange(int(n))
+            idx.append(np.pad(ramp, (p - int(n), 0), "reflect") if n < p else ramp)
+        if all(len(t) == n for t, n in zip(idx, vol.shape[:3])):
+            return vol
+        return self._gather_axes(vol.contiguous(), idx)
+
+    @torch.no_grad()
+    def process_test_sample(self, vol: torch.Tensor, reflect_to_complete_shape: bool = True, class_channels: int = 0, **predict_kw) -> Optional[torch.Tensor]:
+        """The per-patch branch of ``Base_Workflow.process_test_sample`` around ``predict`` (base_workflow.py:1874-2141) for a whole volume
+        on this rank: DATA.REFLECT_TO_COMPLETE_SHAPE padding of axes shorter than the patch (what the test generator does before the
+        workflow sees the sample), crop -> forward -> blend, the crop back to ``reflected_orig_shape`` (:2089-2131: the LAST n voxels of every
+        axis), and the class head (:2135-2141, ``class_channels`` = the width of the separated class block: the trailing channels
+        become one arg-max channel).  Returns (Z, Y, X, C') float32, or None on ranks that do not hold the gathered result."""
+        from . import _lib as L
+
+        assert vol.is_cuda and vol.dim() == 4 and vol.dtype == torch.float32
+        orig = tuple(int(v) for v in vol.shape[:3])
+        work = self.pad_to_shape(vol) if reflect_to_complete_shape else vol
+        pred = self.predict(work, **predict_kw)
+        if pred is None:
+            return None
+        if tuple(pred.shape[:3]) != orig:
+            import numpy as np
+
+            pred = self._gather_axes(pred.contiguous(), [np.arange(p - n, p) for p, n in zip(pred.shape[:3], orig)])
+        if class_channels:
+            C = pred.shape[-1]
+            out = torch.empty(pred.shape[:3] + (C - class_channels + 1,), dtype=torch.float32, device=pred.device)
+            pred = pred.contiguous()
+            L.check(L.lib.bpx_class_argmax(pred.data_ptr(), out.numel() // out.shape[-1], C, int(class_channels), out.data_ptr(), L.stream_ptr()))
+            pred = out
+        return pred
+
     def input_slab(self, vol_zyx: Sequence[int], rank: int, world: int):
         """Input slices [z_lo, z_hi) of a (Z,Y,X) volume that ``rank`` of ``world`` reads: the extent of its patch rows plus the
         reflect-padding sources at the volume ends ("each GPU reads only its input slab (+halo)").  Ranks without

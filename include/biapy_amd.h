@@ -231,6 +231,19 @@ int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int sz, bpx_te
 int bpx_norm_finalize(float* stats_part_d, int N, int tiles, int C, int64_t count_per_channel,
                       const float* gamma_d, const float* beta_d, float eps, int groups,
                       bpx_norm_rec* out_d, int out_ld, int out_off, bpx_stream_t stream);
+/* GroupNorm(groups) with ANY channels-per-group, also over the concatenation of two producers' outputs (torch.cat([up, skip], 1) in front of
+ * the decoder's first norm, blocks.py:1653: with 8 groups over 48 / 96 / 192 / 384 channels one group straddles the boundary).
+ *   bpx_norm_channel_sums     : a producer's partials [N][tiles][2][C] (CONSUMED like in bpx_norm_finalize) -> per-channel totals
+ *                               sums_d[(n*out_ld + out_off + c)*2 + {0, 1}] (double): each producer fills its columns of one (N, out_ld, 2) array
+ *   bpx_groupnorm_finalize    : the records of all C channels from those totals (group statistics = fixed-order sums of the group's channels)
+ *   bpx_groupnorm_bwd_finalize: bpx_norm_bwd_finalize for the same layout: sums_d = per-channel totals of {S1 = sum g, S2 = sum g*xhat}
+ * The reference's "gn" (nn.GroupNorm(out_channels, num_groups=8), blocks.py:2122-2125) raises a TypeError; what it means - GroupNorm(8, C) -
+ * is what these implement, checked against torch.nn.GroupNorm. */
+int bpx_norm_channel_sums(float* stats_part_d, int N, int tiles, int C, double* sums_d, int out_ld, int out_off, bpx_stream_t stream);
+int bpx_groupnorm_finalize(const double* sums_d, int N, int C, int64_t count_per_channel, const float* gamma_d, const float* beta_d, float eps,
+                           int groups, bpx_norm_rec* out_d, bpx_stream_t stream);
+int bpx_groupnorm_bwd_finalize(const double* sums_d, int N, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d, const float* gamma_d,
+                               float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d, bpx_stream_t stream);
 /* Stand-alone statistics of a tensor (used for tensors no conv kernel produced, and in tests). */
 int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, float* stats_part_d, bpx_stream_t stream);
 int bpx_tensor_stats_tiles(int64_t voxels);
@@ -399,6 +412,9 @@ int bpx_histogram_f32(const float* x_d, int64_t n, float first_edge, float last_
                       unsigned long long* counts_d, bpx_stream_t stream);
 int bpx_threshold_u8(const float* x_d, int64_t n, float thr, uint8_t* out_d, bpx_stream_t stream);
 int bpx_clip_affine_f32(const float* x_d, int64_t n, float lo, float hi, float sub, float div, float* out_d, bpx_stream_t stream);
+/* Class head of the sliding-window harness (biapy/engine/base_workflow.py:2135-2141, `separated_class_channel`): the last k channels of a
+ * (voxels, C) float32 volume are replaced by ONE channel holding np.argmax over them (first maximum), out_d is (voxels, C - k + 1). */
+int bpx_class_argmax(const float* in_d, int64_t voxels, int C, int k, float* out_d, bpx_stream_t stream);
 
 /* ---- test-time augmentation -------------------------------------------------------------------------
  * Signed axis permutations of a (Z,Y,X,C) float32 volume (biapy/data/post_processing/tta.py:64-196, AxisTransform: output

@@ -195,3 +195,29 @@ def merge2d(data: np.ndarray, original_shape, data_mask: Optional[np.ndarray] = 
     """(n,Py,Px,C) patches -> (N,Y,X,C) images (+ mask)."""
     dm = None if data_mask is None else data_mask[:, None]
     return merge(data[:, None], tuple(original_shape), dm, (0.0, overlap[0], overlap[1]), (0, padding[0], padding[1]))
+
+
+# ---- the steps of process_test_sample around the blended prediction -----------------------------------------------------------------
+def pad_to_shape(img: np.ndarray, crop_shape) -> np.ndarray:
+    """biapy/data/data_manipulation.py:3218-3300 (mode "reflect"): every spatial axis shorter than ``crop_shape`` is extended IN FRONT with
+    np.pad(..., "reflect"), one axis after the other (the image stays in the bottom-right corner).  Called by the test generators with
+    DATA.REFLECT_TO_COMPLETE_SHAPE (generators/test_pair_data_generators.py:299-314)."""
+    for ax in range(img.ndim - 1):
+        if img.shape[ax] < crop_shape[ax]:
+            pw = [(0, 0)] * img.ndim
+            pw[ax] = (crop_shape[ax] - img.shape[ax], 0)
+            img = np.pad(img, pw, "reflect")
+    return img
+
+
+def crop_to_reflected_orig_shape(pred: np.ndarray, orig_shape) -> np.ndarray:
+    """biapy/engine/base_workflow.py:2089-2131 (3D branch): ``pred[-Z:, -Y:, -X:]`` - the prediction of the padded sample back to the
+    sample's own extents (``pred`` here without the leading batch axis)."""
+    z, y, x = orig_shape[:3]
+    return pred[-z:, -y:, -x:]
+
+
+def class_argmax(pred: np.ndarray, class_channels: int) -> np.ndarray:
+    """biapy/engine/base_workflow.py:2135-2141: the trailing ``class_channels`` channels become one np.argmax channel (the concatenation
+    with the float prediction makes it float)."""
+    return np.concatenate((pred[..., :-class_channels], np.expand_dims(np.argmax(pred[..., -class_channels:], axis=-1), axis=-1)), axis=-1)

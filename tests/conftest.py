@@ -67,6 +67,15 @@ def harness_golden():
 
 
 @pytest.fixture(scope="session")
+def harness_tail_golden():
+    """process_test_sample past the blended prediction (reflect-to-complete-shape crop, class arg-max) from the reference itself:
+    tests/golden/make_golden.py harness_tail."""
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "harness_tail_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def tta_ensemble_golden():
     import numpy as np
 

@@ -349,6 +349,101 @@ def harness_fixtures():
     print("harness_golden.npz:", {k: v.shape for k, v in out.items()})
 
 
+def harness_tail_fixtures():
+    """The steps of ``Base_Workflow.process_test_sample`` PAST the blended prediction, from the reference itself:
+      * reflect: DATA.REFLECT_TO_COMPLETE_SHAPE - the test generator pads axes shorter than the patch in front with ``pad_to_shape``
+        (data_manipulation.py:3218-3300), the workflow crops the prediction back to ``reflected_orig_shape`` (base_workflow.py:2089-2131);
+      * class: ``separated_class_channel`` - the model returns {"pred", "class"}, the harness concatenates them per batch (:1677) and turns
+        the trailing class block of the BLENDED volume into one arg-max channel (:2135-2141)."""
+    import contextlib
+    import io
+    import types
+    from types import SimpleNamespace as NS
+
+    import torch
+
+    bw = shim.load_full_reference()
+    from biapy.data.data_manipulation import pad_to_shape
+    from biapy.models.resunet import ResUNet
+
+    g = np.load(os.path.join(HERE, "resunet_golden.npz"))
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+
+    def build(out_channels):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", k_size=3,
+                        upsample_layer="convtranspose", yx_down=[2] * (len(fm) - 1), z_down=[2] * (len(fm) - 1), output_channels=out_channels,
+                        output_channel_info=["F", "Db"][: len(out_channels)], head_activations=["ce_sigmoid"] * sum(out_channels), isotropy=[True] * len(fm),
+                        larger_io=False, conv_layers=[2] * len(fm))
+        return m
+
+    def run(model, vol, ov, pad, bs, reflect_shape=None, class_block=0, acts=("ce_sigmoid",), ch=(1,), info=("F",)):
+        cfg = NS(TEST=NS(FULL_IMG=False, REUSE_PREDICTIONS=False, VERBOSE=False, REDUCE_MEMORY=False, AUGMENTATION=False, AUGMENTATION_MODE="mean",
+                         AUGMENTATION_GROUP="auto", SAVE_MODEL_RAW_OUTPUT=False),
+                 PROBLEM=NS(NDIM="3D", TYPE="SEMANTIC_SEG" if not class_block else "INSTANCE_SEG", SELF_SUPERVISED=NS(PRETEXT_TASK="")),
+                 DATA=NS(PATCH_SIZE=(32, 32, 32, 1), TEST=NS(OVERLAP=ov, PADDING=pad, MEDIAN_PADDING=False), PREPROCESS=NS(TEST=False),
+                         REFLECT_TO_COMPLETE_SHAPE=reflect_shape is not None),
+                 TRAIN=NS(BATCH_SIZE=bs), MODEL=NS(SOURCE="biapy"), LOSS=NS(CONTRAST=NS(ENABLE=False)), PATHS=NS(RESULT_DIR=NS(PER_IMAGE="")))
+        s = NS(cfg=cfg, model=model, device=torch.device("cpu"), test_device=torch.device("cpu"), axes_order=(0, 4, 1, 2, 3), axes_order_back=(0, 2, 3, 4, 1),
+               dtype=np.float32, stats={"per_crop": {}, "merge_patches": {}, "patch_by_batch_counter": 0}, apply_activations=True,
+               head_activations=list(acts), model_output_channels=list(ch), model_output_channel_info=list(info), padding_type="reflect",
+               separated_class_channel=bool(class_block), return_prediction=True, _predictions=[], dims=3, save_to_disk=False)
+        B = bw.Base_Workflow
+        for name in ("model_call_func", "apply_model_activations", "predict_batches_in_test"):
+            setattr(s, name, types.MethodType(getattr(B, name), s))
+        s.apply_roi_mask = lambda p: p
+        s._log_tta_once = lambda: False
+        s.current_sample = {"X": vol[None].copy(), "Y": None, "X_filename": "v.tif"}
+        if reflect_shape is not None:
+            s.current_sample["reflected_orig_shape"] = tuple(reflect_shape)
+        try:
+            with torch.no_grad(), contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+                B.process_test_sample(s)
+        except AttributeError as e:
+            assert s._predictions, e
+        return s._predictions[0]["data"][0]
+
+    out = {}
+    rs = np.random.RandomState(12)
+    # ---- reflect: z and x shorter than the 32^3 patch, y longer -----------------------------------------------------------------
+    m1 = build([1]); m1.load_state_dict(sd, strict=True); m1.eval()
+    vol = rs.randn(20, 44, 25, 1).astype(np.float32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        padded = pad_to_shape(vol, (32, 32, 32, 1))
+    out["reflect/vol"], out["reflect/padded"] = vol, padded
+    out["reflect/params"] = np.array([0.0, 0.5, 0.0, 0, 0, 0, 3], dtype=np.float64)
+    out["reflect/pred"] = run(m1, padded, (0.0, 0.5, 0.0), (0, 0, 0), 3, reflect_shape=vol.shape)
+    assert out["reflect/pred"].shape == vol.shape, out["reflect/pred"].shape
+    # ---- class: a second head of 3 channels is the class block ---------------------------------------------------------------------
+    m2 = build([1, 3])
+    sd2 = dict(sd)
+    gen = torch.Generator().manual_seed(5)
+    sd2["heads.1.weight"] = 0.5 * torch.randn(m2.state_dict()["heads.1.weight"].shape, generator=gen)
+    sd2["heads.1.bias"] = 0.1 * torch.randn(3, generator=gen)
+    m2.load_state_dict(sd2, strict=True); m2.eval()
+
+    class Split(torch.nn.Module):          # what a reference model with a separated class head returns
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            y = self.net(x)
+            y = y["pred"] if isinstance(y, dict) else y
+            return {"pred": y[:, :1], "class": y[:, 1:]}
+
+    vol2 = rs.randn(40, 32, 48, 1).astype(np.float32)
+    out["class/vol"] = vol2
+    out["class/heads.1.weight"], out["class/heads.1.bias"] = sd2["heads.1.weight"].numpy(), sd2["heads.1.bias"].numpy()
+    out["class/params"] = np.array([0.25, 0.0, 0.5, 0, 0, 0, 4], dtype=np.float64)
+    out["class/pred"] = run(Split(m2), vol2, (0.25, 0.0, 0.5), (0, 0, 0), 4, class_block=3, acts=("ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"),
+                            ch=(1, 3), info=("F", "class"))
+    assert out["class/pred"].shape == vol2.shape[:3] + (2,), out["class/pred"].shape
+    np.savez_compressed(os.path.join(HERE, "harness_tail_golden.npz"), **out)
+    print("harness_tail_golden.npz:", {k: v.shape for k, v in out.items()})
+
+
 HEAD_ACT_CASES = [  # (name, PROBLEM.TYPE, model_output_channels, model_output_channel_info, head_activations - one per channel)
     ("sem1", "SEMANTIC_SEG", [1], ["F"], ["ce_sigmoid"]),
     ("sem3", "SEMANTIC_SEG", [3], ["F"], ["ce_softmax", "ce_softmax", "ce_softmax"]),
@@ -969,6 +1064,8 @@ if __name__ == "__main__":
         head_acts_fixtures()
     if "harness" in which:                      # imports the whole reference package: run it on its own (python make_golden.py harness)
         harness_fixtures()
+    if "harness_tail" in which:                 # likewise on its own
+        harness_tail_fixtures()
     if "tiling" in which:
         tiling_fixtures()
     if "tiling2d" in which:

@@ -971,8 +971,10 @@ def parity_rows(tag, logits, lo_ref, tgt, dtype, trained=False):
     return rows
 
 
-def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
-    """Whole network vs the oracle: logits, Dice, loss and every parameter gradient."""
+def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True, normalization="in"):
+    """Whole network vs the oracle: logits, Dice, loss and every parameter gradient.  normalization="gn": torch.nn.GroupNorm(8, C) for every
+    norm layer (what the reference's 'gn' means; its own call raises) - the oracle then runs F.group_norm, incl. the groups of 6 / 12 / 24
+    channels that straddle the up / skip boundary of the decoder's concatenated inputs."""
     tagd = _mode(dtype)[0]
     if golden is not None:
         sd = {k[len("small/sd/"):]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("small/sd/")}
@@ -984,17 +986,23 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
         g = torch.Generator().manual_seed(seed + 7)
         x = torch.randn(B, 1, *patch, generator=g)
         tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).float()
-    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm), dtype)
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, normalization=normalization), dtype)
     P = {k: v.to(DEV) for k, v in sd.items()}
+    if normalization != "in":           # non-trivial affine parameters (the default initialisation is gamma = 1, beta = 0)
+        g = torch.Generator().manual_seed(seed + 99)
+        for k in sd:
+            if sd[k].dim() == 1 and (".block.1." in k or k.endswith("block.0.weight") or k.endswith("block.0.bias")) and "block.0.block" not in k:
+                sd[k] = sd[k] + 0.2 * torch.randn(sd[k].shape, generator=g)
+        P = {k: v.to(DEV) for k, v in sd.items()}
     xd = x.to(DEV)
     logits, ctx = eng.forward(P, xd, head_act=0, save=train)
     torch.cuda.synchronize()
-    tag = f"resunet[{tagd} fm={fm} {tuple(x.shape)}{' golden' if golden is not None else ''}]"
+    tag = f"resunet[{tagd} {normalization} fm={fm} {tuple(x.shape)}{' golden' if golden is not None else ''}]"
     res = []
     if golden is not None:
         lo_ref = torch.from_numpy(golden["small/logits"])
     else:
-        lo_ref = net_oracle.resunet_forward(sd, x, fm)
+        lo_ref = net_oracle.resunet_forward(sd, x, fm, normalization=normalization)
     scale = lo_ref.abs().max().item()
     err = (logits.cpu() - lo_ref).abs().max().item() / scale
     res.append(_res(tag + ".logits_rel", err, LOGITS_TOL[tagd], extra=f"scale={scale:.3f}"))
@@ -1006,7 +1014,7 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True):
     loss.backward()
     G = eng.backward(P, ctx, lg.grad)
     torch.cuda.synchronize()
-    loss_ref, _, grads_ref = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm)
+    loss_ref, _, grads_ref = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm, normalization=normalization)
     res.append(_res(tag + ".loss", abs(loss.item() - loss_ref.item()), LOSS_TOL[tagd]))
     worst, worst_name = 0.0, ""
     gtol = GRAD_TOL[tagd]

@@ -200,6 +200,16 @@ def test_network_cfg2_architecture(K, dtype):
     _assert_all(K.check_network(dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_network_with_groupnorm(K, dtype):
+    """MODEL.NORMALIZATION = "gn" through the whole network (north_star names GroupNorm): GroupNorm(8, C) for every norm
+    layer, forward and backward, against torch's F.group_norm in the oracle graph - the cfg-2 architecture at 32^3 and a 3-level network
+    on a ragged patch; the decoder's concatenated inputs have 6 / 12 / 24 / 48 channels per group, one group across the up / skip boundary."""
+    rows = K.check_network(dtype, [16, 32, 64, 128, 256], (32, 32, 32), 2, seed=5, normalization="gn")
+    rows += K.check_network(dtype, [16, 32, 64], (24, 40, 16), 1, seed=6, normalization="gn")
+    _assert_all(rows)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_network_cfg2_at_the_benched_shape(K, dtype):
     """cfg 2 at 128^3 (batch 1 vs the CPU oracle; batch 4 vs four batch-1 runs) - the size bench.py times."""
@@ -550,6 +560,44 @@ def test_sliding_window_against_the_reference_harness(harness_golden, resunet_go
         sw = SlidingWindowPredictor(m, (32, 32, 32), tuple(q[:3]), tuple(int(v) for v in q[3:6]), batch_size=int(q[6]), tta=level, tta_mode=mode)
         got = sw.predict(torch.from_numpy(h["tta/vol"]).cuda()).cpu().numpy()
         assert np.abs(got - h[key]).max() < tol, key
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.float16, 4e-3)], ids=["f32", "f16"])
+def test_process_test_sample_tail_against_the_reference(harness_tail_golden, resunet_golden, dtype, tol):
+    """SlidingWindowPredictor.process_test_sample past the blended prediction, against the reference's own
+    ``Base_Workflow.process_test_sample``: DATA.REFLECT_TO_COMPLETE_SHAPE (pad axes shorter than the patch in front, crop the prediction
+    back: base_workflow.py:2089-2131) and the separated class block (arg-max channel, :2135-2141)."""
+    import numpy as np
+
+    from biapy_amd.resunet import ResUNet
+    from biapy_amd.workflow import SlidingWindowPredictor
+
+    h, g = harness_tail_golden, resunet_golden
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+    kw = dict(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", yx_down=[2] * (len(fm) - 1),
+              z_down=[2] * (len(fm) - 1), isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm), compute_dtype=dtype)
+    m = ResUNet(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    q = h["reflect/params"]
+    sw = SlidingWindowPredictor(m, (32, 32, 32), tuple(q[:3]), tuple(int(v) for v in q[3:6]), batch_size=int(q[6]))
+    vol = torch.from_numpy(h["reflect/vol"]).cuda()
+    np.testing.assert_array_equal(sw.pad_to_shape(vol).cpu().numpy(), h["reflect/padded"])          # np.pad's own reflection, bit for bit
+    got = sw.process_test_sample(vol).cpu().numpy()
+    assert got.shape == h["reflect/pred"].shape and np.abs(got - h["reflect/pred"]).max() < tol
+    # class block: a second head of three channels
+    m2 = ResUNet(output_channels=[1, 3], output_channel_info=["F", "Db"], head_activations=["ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"], **kw)
+    sd2 = dict(sd)
+    sd2["heads.1.weight"], sd2["heads.1.bias"] = torch.from_numpy(h["class/heads.1.weight"]), torch.from_numpy(h["class/heads.1.bias"])
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.cuda().eval()
+    q = h["class/params"]
+    sw = SlidingWindowPredictor(m2, (32, 32, 32), tuple(q[:3]), tuple(int(v) for v in q[3:6]), batch_size=int(q[6]))
+    got = sw.process_test_sample(torch.from_numpy(h["class/vol"]).cuda(), class_channels=3).cpu().numpy()
+    ref = h["class/pred"]
+    assert got.shape == ref.shape and np.abs(got[..., 0] - ref[..., 0]).max() < tol
+    assert (got[..., 1] != ref[..., 1]).mean() < (1e-4 if dtype == torch.float32 else 5e-3)     # arg-max labels: only near-ties may differ
 
 
 def test_tta_ensemble_matches_the_reference_routine(tta_ensemble_golden):

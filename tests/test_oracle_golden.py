@@ -261,6 +261,40 @@ def test_oracle_pipeline_matches_the_reference_harness(harness_golden, resunet_g
         assert np.abs(got - h[key]).max() < 5e-6, key
 
 
+def test_oracle_harness_tail_matches_the_reference(harness_tail_golden, resunet_golden):
+    """process_test_sample past the blend: pad_to_shape, the crop back to reflected_orig_shape and the class arg-max of the
+    oracle against what the reference produced (harness_tail_golden.npz)."""
+    from oracle import loss_oracle, net_oracle, tiling_oracle
+
+    h, g = harness_tail_golden, resunet_golden
+    sd = {k[len("small/sd/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("small/sd/")}
+    fm = [int(v) for v in g["small/feature_maps"]]
+    patch = (32, 32, 32)
+    # reflect
+    padded = tiling_oracle.pad_to_shape(h["reflect/vol"], patch + (1,))
+    np.testing.assert_array_equal(padded, h["reflect/padded"])
+    q = h["reflect/params"]
+    ov, pad = tuple(q[:3]), tuple(int(v) for v in q[3:6])
+    p, _ = tiling_oracle.crop(padded, patch + (1,), ov, pad)
+    with torch.no_grad():
+        pr = torch.sigmoid(net_oracle.resunet_forward(sd, torch.from_numpy(np.ascontiguousarray(p)).permute(0, 4, 1, 2, 3), fm)).permute(0, 2, 3, 4, 1).contiguous().numpy()
+    got = tiling_oracle.crop_to_reflected_orig_shape(tiling_oracle.merge(pr, padded.shape, overlap=ov, padding=pad), h["reflect/vol"].shape)
+    assert got.shape == h["reflect/pred"].shape and np.abs(got - h["reflect/pred"]).max() < 5e-6
+    # class block
+    sd2 = dict(sd)
+    sd2["heads.1.weight"], sd2["heads.1.bias"] = torch.from_numpy(h["class/heads.1.weight"]), torch.from_numpy(h["class/heads.1.bias"])
+    q = h["class/params"]
+    ov, pad = tuple(q[:3]), tuple(int(v) for v in q[3:6])
+    p, _ = tiling_oracle.crop(h["class/vol"], patch + (1,), ov, pad)
+    with torch.no_grad():
+        lo = net_oracle.resunet_forward(sd2, torch.from_numpy(np.ascontiguousarray(p)).permute(0, 4, 1, 2, 3), fm, n_heads=2)
+        pr = loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"], training=False).permute(0, 2, 3, 4, 1).contiguous().numpy()
+    got = tiling_oracle.class_argmax(tiling_oracle.merge(pr, h["class/vol"].shape[:3] + (4,), overlap=ov, padding=pad), 3)
+    ref = h["class/pred"]
+    assert np.abs(got[..., 0] - ref[..., 0]).max() < 5e-6
+    assert (got[..., 1] != ref[..., 1]).mean() < 1e-4          # arg-max of blended softmax values: ties within rounding are the only differences
+
+
 def test_tta_ensemble_oracle_matches_reference(tta_ensemble_golden):
     """The whole scalar-field TTA routine - pad to square (reflect / edge), predict every orientation, undo, mean / min / max, crop -
     against ``ensemble_predictions`` of the reference (post_processing.py:1386-1540) on five shapes x five settings: bit-exact."""
