@@ -73,6 +73,7 @@ _SIGS = {
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_fwd_pool": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
     "bpx_conv3d_fwd_pool_supported": ([_i, _i, _i, _i, _i, _i, _i, _i], _i),
+    "bpx_conv3d_fwd_shuffle": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, _i, Tensor, _vp], _i),
     "bpx_conv3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_conv3d_dgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp], _i),
     "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _i64, _vp], _i),

@@ -552,6 +552,34 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
                          bpx_tensor{nullptr, 0, 0}, nullptr, stream);
 }
 
+// Conv3d k = 3 (16 -> 16 * s^3 channels) + 3-D pixel shuffle by s in one pass: the up-scaling stage of the RCAN super-resolution network
+// (biapy/models/rcan.py:317-319 `conv(filters, filters * scale**2) + nn.PixelShuffle(scale)` is 2-D only; the 3-D form - s^3 sub-positions,
+// out[n, c, s z + a, s y + b, s x + e] = conv[n, c s^3 + (a s + b) s + e, z, y, x] - is defined here, see rcan.py of this package).
+// w_packed_d: BPX_PK_K3 of the weight with its output channels re-ordered [sub-position][channel] (the engine does that), bias likewise.
+// y: the (N, sD, sH, sW, 16) tensor.  Large volumes only (the lean kernel: D*H*W >= 64^3, W > 8).
+extern "C" int bpx_conv3d_fwd_shuffle(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act, const void* w_packed_d,
+                                      const float* bias_d, int s, bpx_tensor y, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_fwd_shuffle";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F16, "%s: dtype must be BF16 or F16", fn);
+  BPX_CHECK(s >= 2 && s <= 4, "%s: shuffle factor %d (2..4)", fn, s);
+  BPX_CHECK(x.cs == 0 && y.cs == 0 && y.C == 16 && y.ld == 16 && x.C % 16 == 0, "%s: dense tensors, 16 output channels (got C=%d ld=%d)", fn, y.C, y.ld);
+  if (check_tensor(fn, "x", x, 2, true) || check_tensor(fn, "y", y, 2, true)) return 1;
+  BPX_CHECK(w_packed_d != nullptr, "%s: packed weights are null", fn);
+  Conv3Params p{};
+  p.N = N; p.D = D; p.H = H; p.W = W;
+  p.x = x.ptr; p.x_ld = x.ld; p.Cin = x.C; p.in_norm = in_norm_d; p.act = act;
+  p.wp = w_packed_d; p.bias = bias_d;
+  p.y = y.ptr; p.y_ld = 16; p.Cout = 16 * s * s * s; p.part = nullptr;
+  p.x_cs = 16; p.sc_cs = 16; p.y_cs = 16; p.t_cs = 16;
+  p.f16 = dtype == BPX_F16 ? 1 : 0;
+  p.ps = s;
+  TileCfg c = pick_cfg(dtype, D, H, W, p.Cout);
+  BPX_CHECK(use_lean(dtype, p) && c.tx == 16 && (int64_t)N * D * H * W * s * s * s * 16 < (1ll << 30), "%s: needs the lean kernel (volume >= 64^3, W > 8, output < 2 GB)", fn);
+  BPX_CHECK(launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream) == 0, "%s: no kernel for tile config", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
 extern "C" int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                                    const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_d,
                                    const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,

@@ -247,8 +247,25 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 
     // ---- epilogue: all loads first, then math + one 8-byte store per (m-subtile, 16-channel group) ------------------
     char* __restrict__ yout = reinterpret_cast<char*>(p.y);
-    const uint32_t yrow = (uint32_t)(RS * W * p.y_ld) * 2u;                                  // bytes between m-subtiles
-    const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * y_csb;   // co_base is a multiple of 16
+    uint32_t yrow = (uint32_t)(RS * W * p.y_ld) * 2u;                                        // bytes between m-subtiles
+    uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * y_csb;        // co_base is a multiple of 16
+    uint32_t ysub[NS];                                                                       // byte offset of output-channel block ns
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) ysub[ns] = ns * y_csb;
+    if (EPI == EPI_FWD && p.ps > 1) {
+      // fused 3-D pixel shuffle (bpx_conv3d_fwd_shuffle): this lane's voxel (n, z, y, x) owns the ps^3 block of output voxels at
+      // (ps z, ps y, ps x); channel block co_base / 16 + ns is sub-position (a, b, e) of it, 16 channels = 32 contiguous bytes
+      const int s_ = p.ps, Hs = H * s_, Ws = W * s_;
+      const int vz = z0 + wave, vy = y0 + ey, vx = x0 + ex;
+      yb0 = (uint32_t)((((n * D + vz) * s_ * Hs + vy * s_) * Ws + vx * s_) * 16 + g * 4) * 2u;
+      yrow = (uint32_t)(RS * s_ * Ws * 16) * 2u;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int sub = (co_base >> 4) + ns;
+        const int a = sub / (s_ * s_), b = (sub / s_) % s_, e = sub % s_;
+        ysub[ns] = (uint32_t)(((a * Hs + b) * Ws + e) * 16) * 2u;
+      }
+    }
     // statistics partials of one 16-channel group: 16 lanes (DPP) -> this wave's slot of the LDS scratch [wave][NS*16][2]
     float* red = reinterpret_cast<float*>(smem + BUFB);
     auto flush_stats = [&](int ns, const float* s1, const float* s2, int which = 0) {
@@ -287,7 +304,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               s2[r] += v[r] * v[r];
             }
             pk[ms] = u32x2_t{pk16<T>(v[0], v[1]), pk16<T>(v[2], v[3])};
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) = pk[ms];
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ysub[ns])) = pk[ms];
           }
         }
         if (TX == 16 && p.pool != nullptr) {
@@ -412,7 +429,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
           if (okzx && RS * ms < yrem)
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * y_csb)) =
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ysub[ns])) =
                 u32x2_t{pk16<T>(acc[ms][ns][0], acc[ms][ns][1]), pk16<T>(acc[ms][ns][2], acc[ms][ns][3])};
         flush_stats(ns, s1, s2);
       }

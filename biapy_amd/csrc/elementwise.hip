@@ -1695,12 +1695,15 @@ extern "C" int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x
   BPX_CHECK(h.ptr && y.ptr && scale_d, "%s: null pointer", fn);
   BPX_CHECK(h.C == y.C && h.C % 16 == 0 && h.C <= 2048 && (x.ptr == nullptr || x.C == h.C), "%s: channels must match and be a multiple of 16", fn);
   if ((int64_t)N * voxels == 0) return 0;
-  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  const int kpl = (dtype == BPX_BF16 || dtype == BPX_F16) ? 8 : 4;
   dim3 grid((unsigned)na_blocks(voxels, h.C, kpl) * 4, (unsigned)N);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
     channel_affine_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, (const uint16_t*)h.ptr, h.ld, scale_d, offset_d, (uint16_t*)y.ptr,
                                                          y.ld, h.C, voxels);
+  else if (dtype == BPX_F16)     // fp16 storage (the super-resolution trunk's inference mode, cfg 5)
+    channel_affine_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x.ptr, x.ld, (const f16_t*)h.ptr, h.ld, scale_d, offset_d, (f16_t*)y.ptr, y.ld, h.C,
+                                                      voxels);
   else if (dtype == BPX_F32)
     channel_affine_kernel<float><<<grid, 256, 0, s>>>((const float*)x.ptr, x.ld, (const float*)h.ptr, h.ld, scale_d, offset_d, (float*)y.ptr, y.ld, h.C,
                                                       voxels);

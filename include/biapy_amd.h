@@ -167,6 +167,15 @@ int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_tensor x, con
                         const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
                         float* pool_stats_part_d, bpx_stream_t stream);
 int bpx_conv3d_fwd_pool_supported(int dtype, int N, int D, int H, int W, int x_ld, int y_ld, int Cout);
+/* Conv3d k = 3 from x.C to 16 * s^3 channels followed by a 3-D pixel shuffle by s, in one pass (the up-scaling stage of the RCAN
+ * super-resolution network, cfg 5).  biapy/models/rcan.py:317-319 builds `conv(filters, filters * scale**2) + nn.PixelShuffle(scale)`, which is
+ * 2-D only (on 5-D tensors it raises); the 3-D form is DEFINED here as its natural extension:
+ *   out[n, c, s z + a, s y + b, s x + e] = conv[n, c s^3 + (a s + b) s + e, z, y, x]        (a, b, e in [0, s))
+ * The kernel takes the conv's output channels in the order [sub-position (a, b, e)][c] (w_packed_d = BPX_PK_K3 of the re-ordered weight, bias_d
+ * re-ordered alike) and stores block (a, b, e) of voxel (z, y, x) to voxel (s z + a, s y + b, s x + e) of y = (N, sD, sH, sW, 16): the
+ * 16 s^3-channel tensor never exists in memory.  dtype BF16 / F16; volumes the lean kernel takes (D*H*W >= 64^3, W > 8); s = 2, 3, 4. */
+int bpx_conv3d_fwd_shuffle(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act, const void* w_packed_d,
+                           const float* bias_d, int s, bpx_tensor y, bpx_stream_t stream);
 
 /* dgrad of the conv above w.r.t. its (normalised+activated) input, fused with the backward of that
  * activation:  g = convT(dy, W) * act'(scale*t+shift),  t = the conv's raw input tensor.
