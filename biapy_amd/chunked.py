@@ -8,11 +8,18 @@ into chunks of ``PATCH - 2*PADDING`` voxels; every chunk is read with its paddin
 the spline-blended merge there is no arithmetic on the way back and the route is the reference's multi-GPU one: chunks are
 dealt to the ranks in ``DistributedSampler`` order and each rank writes its own chunks.
 
-What is MI355X-specific: the volume and the result live in HBM (288 GB hold a 4096^3 uint8 volume or a 2048^3 float32
-one next to its prediction), the gather and the write-back are two HIP kernels (``bpx_gather3d_tables`` /
-``bpx_scatter3d_regions``) and the ranks' disjoint results are combined by one RCCL reduction instead of a Zarr file on disk.
-The Zarr / HDF5 reading and writing of the reference (its on-disk format) and ``TEST.BY_CHUNKS.WORKFLOW_PROCESS`` tiles of
-several patches are not part of this module.
+Two predictors:
+
+* ``ChunkedPredictor`` - the volume and the result live in HBM (288 GB hold a 4096^3 uint8 volume or a 2048^3 float32 one next to
+  its prediction), the gather and the write-back are two HIP kernels (``bpx_gather3d_tables`` / ``bpx_scatter3d_regions``) and the ranks'
+  disjoint results are combined by one RCCL reduction;
+* ``StreamedChunkedPredictor`` (round 3) - OUT OF CORE, what by-chunks inference is for: the volume stays on the HOST side (any array-like
+  with NumPy slicing: ``np.memmap`` of a raw / ``.npy`` file on disk, an in-memory array; ``zarr`` / ``h5py`` datasets have the same slicing
+  interface but are not installed in this image), the prediction is written to a host-side array-like in CHUNK-ALIGNED regions (the
+  reference's Zarr output is chunked by the write tile for the same reason: chunked_test_pair_data_generator.py:714-760), and the device
+  only ever holds one work tile of ``patches_per_tile`` patches (``TEST.BY_CHUNKS.WORKFLOW_PROCESS`` tiles, :331-357) twice:
+  pinned-memory staging, H2D of tile i + 1 and D2H of tile i - 1 on a copy stream while tile i computes.  The HBM footprint is
+  bounded by the tile size, not by the volume.
 """
 from __future__ import annotations
 
@@ -159,3 +166,166 @@ class ChunkedPredictor:
                 if rank != 0:
                     return None
         return out
+
+
+class TileGrid:
+    """Work tiles of ``patches_per_tile`` consecutive chunks of the global grid (chunked_test_pair_data_generator.py:331-357): every chunk
+    belongs to exactly one tile, tiles (not chunks) are dealt to the ranks (:608-624)."""
+
+    def __init__(self, grid: ChunkGrid, patches_per_tile: Sequence[int] = (1, 1, 1)):
+        self.grid = grid
+        self.ppt = tuple(max(1, int(v)) for v in patches_per_tile)
+        self.tiles = tuple(math.ceil(v / p) for v, p in zip(grid.vols, self.ppt))
+        self.patches_of_tile = {}
+        for vol_id in range(grid.total):
+            z, y, x = (int(v) for v in np.unravel_index(vol_id, grid.vols))
+            tid = int(np.ravel_multi_index((z // self.ppt[0], y // self.ppt[1], x // self.ppt[2]), self.tiles))
+            self.patches_of_tile.setdefault(tid, []).append(vol_id)
+        self.tile_ids = sorted(self.patches_of_tile)
+
+    def rank_order(self, world: int, rank: int) -> List[int]:
+        """Tiles of one rank in processing order: DistributedSampler(tile_ids, shuffle=False) without the repeats that even out the ranks
+        (the reference predicts them twice and overwrites identical data)."""
+        n = len(self.tile_ids)
+        return [self.tile_ids[k] for k in range(rank, n, world)]
+
+    def write_region(self, tile_id: int) -> PatchCoords:
+        """The voxels the tile's chunks write (the union of their ``real_patch_in_data``): a box aligned to the chunk grid."""
+        tz, ty, tx = (int(v) for v in np.unravel_index(tile_id, self.tiles))
+        g = self.grid
+        lo = [q * p * s for q, p, s in zip((tz, ty, tx), self.ppt, g.step)]
+        hi = [min((q + 1) * p * s, d) for q, p, s, d in zip((tz, ty, tx), self.ppt, g.step, g.dim)]
+        return PatchCoords(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+
+    def read_region(self, tile_id: int) -> PatchCoords:
+        """What the tile's chunks read: the write region grown by the padding, clipped to the volume."""
+        w, g = self.write_region(tile_id), self.grid
+        lo = [max(0, a - p) for a, p in zip(w[0::2], g.padding)]
+        hi = [min(d, b + p) for b, p, d in zip(w[1::2], g.padding, g.dim)]
+        return PatchCoords(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+
+
+class StreamedChunkedPredictor:
+    """Out-of-core by-chunks prediction: ``predict(vol_host, out_host)`` with both arrays on the HOST side (``np.memmap`` / ndarray / anything
+    with NumPy basic slicing), any size; the device holds two work tiles.  Bit-identical to ``ChunkedPredictor`` on the same volume: a chunk's
+    padded patch only draws on voxels of its own clipped read region, which lies inside its tile's read region, and the forward of a
+    sample does not depend on what else is in the batch (InstanceNorm is per sample)."""
+
+    def __init__(self, forward: Callable[[torch.Tensor], torch.Tensor], crop_zyx: Sequence[int], padding: Sequence[int], batch_size: int = 4,
+                 patches_per_tile: Sequence[int] = (1, 1, 1), out_channels: int = 1, max_device_bytes: Optional[int] = None):
+        self.forward, self.crop, self.padding, self.batch = forward, tuple(int(v) for v in crop_zyx[:3]), tuple(int(v) for v in padding), int(batch_size)
+        self.ppt = tuple(int(v) for v in patches_per_tile)
+        self.out_channels = int(out_channels)
+        self.max_device_bytes = max_device_bytes
+        self.device_bytes = 0          # bytes of the predictor's own device buffers (two tiles in, two tiles out, one batch of patches)
+
+    def _tile_bytes(self, tg: TileGrid, C: int, esize: int):
+        g = tg.grid
+        rd = [min(d, p * s + 2 * pad) for d, p, s, pad in zip(g.dim, tg.ppt, g.step, g.padding)]
+        wr = [min(d, p * s) for d, p, s in zip(g.dim, tg.ppt, g.step)]
+        return rd[0] * rd[1] * rd[2] * C * esize, wr[0] * wr[1] * wr[2] * self.out_channels * 4
+
+    @torch.no_grad()
+    def predict(self, vol_host, out_host, device=None, rank: int = 0, world: int = 1):
+        """vol_host: (Z, Y, X, C) array-like of uint8 / float16 / float32; out_host: writable (Z, Y, X, out_channels) float32 array-like.  Every rank
+        writes the regions of its own tiles (chunk-aligned, disjoint between ranks: a shared file needs no further coordination); returns the
+        number of tiles this rank wrote."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("StreamedChunkedPredictor computes on the MI355X only; there is no CPU path")
+        Z, Y, X, C = (int(v) for v in vol_host.shape)
+        if tuple(int(v) for v in out_host.shape) != (Z, Y, X, self.out_channels):
+            raise ValueError(f"out_host must be {(Z, Y, X, self.out_channels)}, got {tuple(out_host.shape)}")
+        grid = ChunkGrid((Z, Y, X), self.crop, self.padding)
+        tg = TileGrid(grid, self.ppt)
+        np_dtype = np.dtype(vol_host.dtype)
+        tdtype = {np.dtype(np.uint8): torch.uint8, np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32}.get(np_dtype)
+        if tdtype is None:
+            raise ValueError(f"volume dtype {np_dtype} is not supported (uint8, float16, float32)")
+        in_bytes, out_bytes = self._tile_bytes(tg, C, np_dtype.itemsize)
+        Pz, Py, Px = self.crop
+        self.device_bytes = 2 * (in_bytes + out_bytes) + self.batch * Pz * Py * Px * (C * np_dtype.itemsize + self.out_channels * 4)
+        if self.max_device_bytes is not None and self.device_bytes > self.max_device_bytes:
+            raise MemoryError(f"work tiles need {self.device_bytes} bytes of HBM, the budget is {self.max_device_bytes}: reduce patches_per_tile / batch_size")
+        # two slots: pinned staging + device buffers for the tile read region and the tile result
+        slots = [dict(h_in=torch.empty(in_bytes, dtype=torch.uint8).pin_memory(), d_in=torch.empty(in_bytes, dtype=torch.uint8, device=device),
+                      h_out=torch.empty(out_bytes, dtype=torch.uint8).pin_memory(), d_out=torch.empty(out_bytes, dtype=torch.uint8, device=device),
+                      ready=torch.cuda.Event(), done=torch.cuda.Event(), out_ready=torch.cuda.Event(), pending=None) for _ in range(2)]
+        h2d, d2h = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)      # separate queues: an upload never waits behind a download
+        main = torch.cuda.current_stream(device)
+        mine = tg.rank_order(world, rank)
+
+        def stage_in(k):
+            sl, rr = slots[k % 2], tg.read_region(mine[k])
+            ext = (rr.z_end - rr.z_start, rr.y_end - rr.y_start, rr.x_end - rr.x_start)
+            n = ext[0] * ext[1] * ext[2] * C
+            if k >= 2:
+                sl["ready"].synchronize()                                       # the upload that last read this pinned buffer has finished
+            src = np.ascontiguousarray(vol_host[rr.z_start:rr.z_end, rr.y_start:rr.y_end, rr.x_start:rr.x_end])   # host read (disk for a memmap)
+            sl["h_in"][: n * np_dtype.itemsize].view(tdtype).copy_(torch.from_numpy(src).reshape(-1))
+            with torch.cuda.stream(h2d):
+                h2d.wait_event(sl["done"])                                      # the tile that used this device buffer two tiles ago has been computed
+                sl["d_in"][: n * np_dtype.itemsize].copy_(sl["h_in"][: n * np_dtype.itemsize], non_blocking=True)
+                sl["ready"].record(h2d)
+            sl["ext"], sl["rr"] = ext, rr
+
+        def flush_out(sl):
+            """The finished result of a slot: wait for its download, then write it to its chunk-aligned place in the host array."""
+            if sl["pending"] is None:
+                return
+            wr, n = sl["pending"]
+            sl["out_ready"].synchronize()
+            ext = (wr.z_end - wr.z_start, wr.y_end - wr.y_start, wr.x_end - wr.x_start, self.out_channels)
+            out_host[wr.z_start:wr.z_end, wr.y_start:wr.y_end, wr.x_start:wr.x_end] = sl["h_out"][: n * 4].view(torch.float32).reshape(ext).numpy()
+            sl["pending"] = None
+
+        for sl in slots:
+            sl["done"].record(main)
+            sl["out_ready"].record(main)
+        if mine:
+            stage_in(0)
+        st = L.stream_ptr()
+        for k, tid in enumerate(mine):
+            sl = slots[k % 2]
+            main.wait_event(sl["ready"])                                        # this tile's input is on the device
+            main.wait_event(sl["out_ready"])                                    # the result that occupied this slot's device buffer has been downloaded
+            rr, ext = sl["rr"], sl["ext"]
+            wr = tg.write_region(tid)
+            wext = (wr.z_end - wr.z_start, wr.y_end - wr.y_start, wr.x_end - wr.x_start)
+            tin = sl["d_in"][: ext[0] * ext[1] * ext[2] * C * np_dtype.itemsize].view(tdtype)
+            tout = sl["d_out"][: wext[0] * wext[1] * wext[2] * self.out_channels * 4].view(torch.float32)
+            ids = tg.patches_of_tile[tid]
+            for b0 in range(0, len(ids), self.batch):
+                sub = ids[b0:b0 + self.batch]
+                n = len(sub)
+                tabs = np.stack([grid.index_tables(v) for v in sub]).astype(np.int32)
+                tabs[:, :Pz] -= rr.z_start
+                tabs[:, Pz:Pz + Py] -= rr.y_start
+                tabs[:, Pz + Py:] -= rr.x_start
+                regs = np.stack([grid.region(v) for v in sub]).astype(np.int32)
+                regs[:, 3] -= wr.z_start
+                regs[:, 4] -= wr.y_start
+                regs[:, 5] -= wr.x_start
+                tables = torch.from_numpy(tabs).to(device, non_blocking=True)
+                regions = torch.from_numpy(regs).to(device, non_blocking=True)
+                patches = torch.empty((n, Pz, Py, Px, C), dtype=tdtype, device=device)
+                L.check(lib.bpx_gather3d_tables(tin.data_ptr(), np_dtype.itemsize, ext[0], ext[1], ext[2], C, tables.data_ptr(), n, Pz, Py, Px, patches.data_ptr(), st))
+                pred = self.forward(patches.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).contiguous().to(torch.float32)
+                if pred.shape[-1] != self.out_channels:
+                    raise ValueError(f"the forward returned {pred.shape[-1]} channels, out_channels is {self.out_channels}")
+                L.check(lib.bpx_scatter3d_regions(pred.data_ptr(), n, Pz, Py, Px, self.out_channels, regions.data_ptr(), tout.data_ptr(), wext[0], wext[1], wext[2], st))
+            sl["done"].record(main)
+            nout = wext[0] * wext[1] * wext[2] * self.out_channels
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(sl["done"])
+                sl["h_out"][: nout * 4].copy_(sl["d_out"][: nout * 4], non_blocking=True)          # the download overlaps the next tile's compute
+                sl["out_ready"].record(d2h)
+            sl["pending"] = (wr, nout)
+            # while the device works on tile k: the previous tile's result goes to the host array, the next tile's input comes up
+            other = slots[(k + 1) % 2]
+            flush_out(other)
+            if k + 1 < len(mine):
+                stage_in(k + 1)
+        for sl in slots:
+            flush_out(sl)
+        return len(mine)

@@ -613,7 +613,7 @@ int launch_dma(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 }  // namespace
 
 namespace bpxconv {
-int g_conv_dma = 1;   // the DMA-pipelined kernel where it applies (bpx_debug_set_conv_ws: 7 = off, 6 = on)
+int g_conv_dma = 0;   // the DMA-pipelined kernel is an A/B variant (bpx_debug_set_conv_ws: 6 = on, 7 = off): measured equal to the lean kernel within +-4 %, DESIGN.md section 6
 
 // byte offsets < 2^31 for the operand that goes through the buffer descriptor; 4x8x16 tiles, 16 output channels
 bool conv3_dma_applies(const Conv3Params& p, const TileCfg& c) {

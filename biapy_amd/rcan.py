@@ -1,11 +1,19 @@
-"""Drop-in for ``biapy.models.rcan.rcan`` - the 3-D trunk without the up-scaling layer (cfg 5 family).
+"""Drop-in for ``biapy.models.rcan.rcan`` in 3-D (cfg 5): the trunk, and (round 3) the x``scale`` up-scaling stage.
 
 Same constructor keywords as the reference (biapy/models/rcan.py:241-300), same ``state_dict`` keys and shapes (``sf``,
 ``rgs.g.module.r.module.{0,2}`` convolutions, ``rgs.g.module.r.module.3.module.{1,3}`` channel attention, ``rgs.g.module.n``
 group tail, ``conv1``, ``conv2``), ordinary ``nn.Parameter``s; ``forward`` hands them to :class:`biapy_amd.rcan_engine.RCANEngine`.
 
-Not covered (``NotImplementedError`` at construction): 2D, ``upscaling_layer=True`` (the reference's own 3-D branch raises:
-``nn.PixelShuffle`` on 5-D tensors), more than one input channel, filters other than 16 / 32, more than 4 output channels.
+``upscaling_layer=True`` in 3-D: the reference builds ``conv(filters, filters * scale**2) + nn.PixelShuffle(scale)`` (rcan.py:317-319), which is
+2-D only - ``nn.PixelShuffle`` on 5-D tensors raises - so there is no reference behaviour to reproduce.  This class DEFINES the 3-D form as
+the same rule with one more axis: ``upscale.0 = Conv3d(filters, filters * scale**3, 3)`` followed by a 3-D pixel shuffle
+(out[n, c, s z + a, s y + b, s x + e] = conv[n, c s^3 + (a s + b) s + e, z, y, x]; oracle/rcan_oracle.py::pixel_shuffle3d), fused into the store
+of the convolution (``bpx_conv3d_fwd_shuffle``: the 16 s^3-channel tensor never exists), filters = 16, scale 2..4, patches >= 64^3.  It is
+an inference path (cfg 5: 64^3 -> 256^3 in fp16); training it raises ``NotImplementedError``.  Parity: unpinned against BiaPy by
+construction, checked against the oracle's restatement of the defined semantics.
+
+Not covered (``NotImplementedError`` at construction): 2D, more than one input channel, filters other than 16 / 32, more than 4 output
+channels.
 Training goes through the linear output (``head_activations=["linear"]``, what the SR workflows use); other head activations
 are inference-only (``predict``).
 """
@@ -50,9 +58,10 @@ class rcan(nn.Module):
         super().__init__()
         if type(scale) is not int and isinstance(scale, Sequence):
             scale = scale[0]
-        if ndim != 3 or upscaling_layer:
-            raise NotImplementedError("biapy_amd.rcan: the 3-D trunk without the up-scaling layer is what runs on the MI355X path "
-                                      "(the reference's own 3-D up-scaling branch raises)")
+        if ndim != 3:
+            raise NotImplementedError("biapy_amd.rcan: the 3-D network is what runs on the MI355X path")
+        if upscaling_layer and (filters != 16 or int(scale) not in (2, 3, 4)):
+            raise NotImplementedError("biapy_amd.rcan: the up-scaling stage takes 16 filters and scale 2, 3 or 4 (3-D pixel shuffle fused into the conv store)")
         if out_channels is None:
             out_channels = num_channels
         self.ndim, self.upscaling_layer = ndim, upscaling_layer
@@ -60,19 +69,25 @@ class rcan(nn.Module):
         if act_name not in self._HEAD:
             raise NotImplementedError(f"biapy_amd.rcan: output activation {act_name!r}")
         self.head_code = self._HEAD[act_name]
-        self.cfg = dict(num_channels=num_channels, filters=filters, num_rg=num_rg, num_rcab=num_rcab, reduction=reduction, out_channels=out_channels)
+        self.scale = int(scale) if upscaling_layer else 0
+        self.cfg = dict(num_channels=num_channels, filters=filters, num_rg=num_rg, num_rcab=num_rcab, reduction=reduction, out_channels=out_channels,
+                        scale=self.scale)
         self.compute_dtype = compute_dtype
         self._engine: Optional[RCANEngine] = None
         RCANEngine(dtype=compute_dtype, **self.cfg)                      # validates the configuration (raises NotImplementedError)
         self.sf = nn.Conv3d(num_channels, filters, kernel_size=3, padding="same")
         self.rgs = nn.Sequential(*[RG(filters, num_rcab, reduction) for _ in range(num_rg)])
         self.conv1 = nn.Conv3d(filters, filters, kernel_size=3, padding="same")
+        if upscaling_layer:                      # 3-D form of rcan.py:317-319 (see the module docstring): s^3 sub-positions per feature channel
+            self.upscale = nn.Sequential(nn.Conv3d(filters, filters * self.scale ** 3, kernel_size=3, padding="same"))
         self.conv2 = nn.Conv3d(filters, out_channels, kernel_size=3, padding="same")
 
     def engine(self) -> RCANEngine:
         if self._engine is None or self._engine.dtype != self.compute_dtype:
             self._engine = RCANEngine(dtype=self.compute_dtype, **self.cfg)
         return self._engine
+
+    supported_compute_dtypes = (torch.float32, torch.bfloat16, torch.float16)   # float16: inference (forward kernels only)
 
     def forward(self, x) -> torch.Tensor:
         if not x.is_cuda:
@@ -81,6 +96,9 @@ class rcan(nn.Module):
         params = [p for _, p in self.named_parameters()]
         x = x.to(torch.float32)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if self.scale:
+                raise NotImplementedError("biapy_amd.rcan: the x%d up-scaling stage is an inference path (no backward kernels); train the trunk "
+                                          "(upscaling_layer=False) or run under torch.no_grad()" % self.scale)
             if self.head_code != 0:
                 raise NotImplementedError("biapy_amd.rcan trains through the linear output; use head_activations=['linear']")
             return _ResUNetFn.apply(x, self.engine(), names, *params)

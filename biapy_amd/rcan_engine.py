@@ -32,7 +32,7 @@ lib = L.lib
 
 class RCANEngine(ResUNetEngine):
     def __init__(self, num_channels: int, filters: int, num_rg: int, num_rcab: int, reduction: int, out_channels: int,
-                 dtype: torch.dtype = torch.bfloat16):
+                 dtype: torch.dtype = torch.bfloat16, scale: int = 0):
         if num_channels != 1:
             raise NotImplementedError("RCANEngine: one input channel (the first layer kernel is the Cin = 1 one)")
         if filters not in (16, 32) or not 1 <= out_channels <= 4:
@@ -40,6 +40,9 @@ class RCANEngine(ResUNetEngine):
         super().__init__(NetConfig(in_ch=1, feature_maps=[filters, filters], out_channels=(out_channels,), activation="silu"), dtype)
         self.Fc, self.num_rg, self.num_rcab, self.red, self.n_out = filters, num_rg, num_rcab, max(1, filters // reduction), out_channels
         self.silu = L.ACT["silu"]
+        self.scale = int(scale)          # > 0: conv(filters -> filters * scale^3) + 3-D pixel shuffle in front of the last conv (rcan.py:344-345)
+        if self.scale and (filters != 16 or self.scale not in (2, 3, 4) or dtype == torch.float32):
+            raise NotImplementedError("RCANEngine: the up-scaling stage needs 16 filters, scale 2..4 and 16-bit storage (bpx_conv3d_fwd_shuffle)")
 
     # ---- small helpers -----------------------------------------------------------------------------------------------------
     def _consts(self, B, dev):
@@ -110,6 +113,24 @@ class RCANEngine(ResUNetEngine):
             cur = out
         t = buf()
         self._conv(B, S, cur, None, 0, P["conv1.weight"], P["conv1.bias"], t, sc=f0)
+        if self.scale:
+            # x scale: the conv's 16 s^3 output channels in the order [sub-position][channel] (PyTorch's pixel-shuffle order is
+            # [channel][sub-position]: a permutation of the weight's rows), each 16-channel block stored to its sub-position of the
+            # (B, sD, sH, sW, 16) tensor - the 1024-channel tensor of cfg 5 (x4) is never written
+            if save:
+                raise NotImplementedError("RCANEngine: the up-scaling stage has no backward kernels (inference path)")
+            s_ = self.scale
+            s3 = s_ ** 3
+            wu = P["upscale.0.weight"].reshape(Fc, s3, Fc, 3, 3, 3).transpose(0, 1).reshape(s3 * Fc, Fc, 3, 3, 3).contiguous()
+            bu = P["upscale.0.bias"].reshape(Fc, s3).t().reshape(-1).contiguous()
+            wpu = self._pack(wu, L.PK_K3, Fc, s3 * Fc, False)
+            D, H, W = D * s_, H * s_, W * s_
+            up = torch.empty((B, D, H, W, Fc), dtype=T, device=dev)
+            L.check(lib.bpx_conv3d_fwd_shuffle(self.dt, B, S[0], S[1], S[2], L.tview(t), None, 0, wpu.data_ptr(), bu.data_ptr(), s_, L.tview(up), st))
+            t, S, vox = up, (D, H, W), D * H * W
+
+            def buf(C=Fc):                                                   # buffers of the high-resolution grid from here on
+                return torch.empty((B, D, H, W, C), dtype=T, device=dev)
         # last conv: out_channels (<= 4) zero-padded to 16 output channels; the head kernel picks them and applies the activation
         w2p = torch.zeros((16, Fc, 3, 3, 3), dtype=torch.float32, device=dev)
         b2p = torch.zeros(16, dtype=torch.float32, device=dev)

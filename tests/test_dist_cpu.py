@@ -259,6 +259,81 @@ def test_flat_gradient_data_parallel_step_matches_ddp():
     assert all(err < 1e-6 and same for _, err, same in res), res
 
 
+class _PPOnCpu(torch.nn.Module):
+    """The ResUNet++ drop-in's PARAMETERS (biapy_amd.resunetpp.ResUNetPlusPlus is an ordinary parameter holder: same names, shapes and order as
+    the reference) driven by the CPU oracle graph: what the multi-process CPU tests can run of cfg 4 - the device engine needs the GPU."""
+
+    def __init__(self, seed):
+        super().__init__()
+        from biapy_amd.resunetpp import ResUNetPlusPlus
+
+        torch.manual_seed(seed)
+        self.fm = [16, 32, 64]
+        self.net = ResUNetPlusPlus(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=self.fm, drop_values=[0.0] * 3, normalization="in", k_size=3,
+                                   upsample_layer="convtranspose", yx_down=[2, 2], z_down=[2, 2], output_channels=[3], output_channel_info=["BCD"],
+                                   head_activations=["ce_sigmoid", "ce_sigmoid", "tanh"], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3)
+
+    def forward(self, x):
+        from oracle import resunetpp_oracle
+
+        return resunetpp_oracle.resunetpp_forward(dict(self.net.named_parameters()), x, self.fm)
+
+
+def _bcd_loss(logits, target):
+    """instance_segmentation_loss for B, C (BCE on logits) and D (MSE through tanh): the CPU statement of biapy_amd.losses.InstanceChannelsLoss."""
+    from oracle import loss_oracle
+
+    pred = loss_oracle.apply_head_activations(logits, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True)
+    return loss_oracle.instance_channels(pred, target, ["bce", "bce", "mse"], [1.0, 1.0, 1.0])
+
+
+def _dp_pp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from biapy_amd.graphs import DataParallelTrainStep
+
+    g = torch.Generator().manual_seed(40 + rank)
+    xs = [torch.randn(1, 1, 16, 16, 16, generator=g) for _ in range(2)]
+    ts = [torch.cat([(torch.rand(1, 2, 16, 16, 16, generator=g) > 0.5).float(), torch.rand(1, 1, 16, 16, 16, generator=g) * 2 - 1], 1) for _ in range(2)]
+    ref = torch.nn.parallel.DistributedDataParallel(_PPOnCpu(0))                      # the reference's route: base_workflow.py:952-958
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    for x, t in zip(xs, ts):
+        ropt.zero_grad(set_to_none=True)
+        _bcd_loss(ref(x), t).backward()
+        ropt.step()
+    net = _PPOnCpu(0 if rank == 0 else 7)                                             # rank 1 starts elsewhere: rank 0's weights must be broadcast
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    step = DataParallelTrainStep(net, _bcd_loss, opt, xs[0], ts[0], graph=False)
+    for x, t in zip(xs, ts):
+        step(x, t)
+    step._check_views()                                                               # every p.grad is still a view of the ONE flat all-reduce buffer
+    nparam = sum(1 for _ in net.parameters())
+    err = max((a - b).abs().max().item() for a, b in zip(net.parameters(), ref.module.parameters()))
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, err, all(torch.equal(gathered[0], o) for o in gathered), nparam, step.flat_grad.numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_data_parallel_step_on_the_resunetpp_parameter_set():
+    """cfg 4 is the "DDP training" configuration: DataParallelTrainStep over the ResUNet++ drop-in's own parameter set
+    (80 tensors at three levels: residual blocks with normalised 3x3x3 shortcuts, bias-free squeeze-excite Linears, ASPP, attention gates, 3-channel
+    head) and the B / C / D channel loss - one flat gradient slab, rank 0's weights broadcast, the same weights as DistributedDataParallel
+    after two AdamW steps on disjoint shards, identical on both ranks.  The graph (CPU oracle) stands in for the device engine here."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_pp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(err < 2e-6 and same and npar >= 80 and nflat > 100000 for _, err, same, npar, nflat in res), res
+
+
 def _epoch_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -600,6 +600,55 @@ def test_process_test_sample_tail_against_the_reference(harness_tail_golden, res
     assert (got[..., 1] != ref[..., 1]).mean() < (1e-4 if dtype == torch.float32 else 5e-3)     # arg-max labels: only near-ties may differ
 
 
+def _rcan_sr(scale, num_rg, num_rcab, dtype, seed):
+    from biapy_amd.rcan import rcan
+
+    torch.manual_seed(seed)
+    m = rcan(ndim=3, num_channels=1, filters=16, scale=scale, num_rg=num_rg, num_rcab=num_rcab, reduction=16, upscaling_layer=True, out_channels=1,
+             head_activations=["linear"], compute_dtype=dtype)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for v in m.state_dict().values():
+            if v.ndim == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    return m
+
+
+@pytest.mark.parametrize("scale,dtype,tol", [(2, torch.float16, 4e-3), (3, torch.bfloat16, 4e-2), (4, torch.float16, 4e-3)], ids=["x2-f16", "x3-bf16", "x4-f16"])
+def test_rcan_upscaling_stage(scale, dtype, tol):
+    """cfg 5 family: rcan(upscaling_layer=True) in 3-D - conv(16 -> 16 s^3) + 3-D pixel shuffle fused into the conv's store
+    (bpx_conv3d_fwd_shuffle) + the last conv on the s-times finer grid - against the oracle's restatement of the DEFINED semantics
+    (oracle/rcan_oracle.py::pixel_shuffle3d; parity unpinned against BiaPy: its own 3-D branch raises).  A short trunk on a 64^3 patch."""
+    from oracle import rcan_oracle
+
+    m = _rcan_sr(scale, 1, 2, dtype, seed=scale)
+    x = torch.randn(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        want = rcan_oracle.rcan_forward({k: v.detach() for k, v in m.state_dict().items()}, x, 1, 2, scale=scale)
+        got = m.cuda().eval()(x.cuda()).cpu()
+    assert got.shape == want.shape == (1, 1, 64 * scale, 64 * scale, 64 * scale)
+    rel = ((got - want).abs().max() / want.abs().max()).item()
+    assert rel < tol, rel
+    with pytest.raises(NotImplementedError):                    # inference path: no backward kernels for the up-scaling stage
+        m.train()(x.cuda())
+
+
+def test_rcan_cfg5_at_the_stated_size():
+    """cfg 5 as BASELINE.json states it: RCAN-3D x4, 10 groups x 20 RCABs, 16 filters, one 64^3 patch -> 256^3, fp16 - the whole network
+    against the fp32 CPU oracle (about a minute of CPU time)."""
+    from oracle import rcan_oracle
+
+    m = _rcan_sr(4, 10, 20, torch.float16, seed=55)
+    x = torch.randn(1, 1, 64, 64, 64, generator=torch.Generator().manual_seed(56))
+    with torch.no_grad():
+        got = m.cuda().eval()(x.cuda()).cpu()
+        want = rcan_oracle.rcan_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, x, 10, 20, scale=4)
+    assert got.shape == want.shape == (1, 1, 256, 256, 256)
+    rel = ((got - want).abs().max() / want.abs().max()).item()
+    rel2 = ((got - want).norm() / want.norm()).item()
+    assert rel < 2e-2 and rel2 < 5e-3, (rel, rel2)             # 400 stacked fp16 convolutions: accumulated rounding
+
+
 def test_tta_ensemble_matches_the_reference_routine(tta_ensemble_golden):
     """biapy_amd.tta.ensemble_predictions on the device against the outputs of the reference's ``ensemble_predictions``
     (post_processing.py:1386-1540, generated in the build container): padding, 8 / 16 orientations, undo, reduce, crop - bit-exact."""
@@ -900,6 +949,52 @@ def test_chunked_predictor_matches_oracle_pipeline():
     assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("ppt,batch,dtype", [((1, 1, 1), 3, "f32"), ((2, 1, 2), 4, "f32"), ((1, 2, 3), 5, "u8")], ids=["tile=1-chunk", "tile=2x1x2", "tile=1x2x3-uint8"])
+def test_streamed_chunked_predictor_is_out_of_core_and_bit_identical(tmp_path, ppt, batch, dtype):
+    """StreamedChunkedPredictor: the volume is a raw file on DISK (np.memmap; zarr / h5py are not installed - they expose
+    the same slicing), the prediction is written chunk-aligned into another memmap, the device holds two work tiles of `patches_per_tile`
+    chunks.  (i) bit-identical to ChunkedPredictor with the whole volume in HBM; (ii) the predictor's device buffers stay below a budget
+    that is a fraction of the volume; (iii) two ranks' tile lists write disjoint regions that together are the single-rank result."""
+    import numpy as np
+
+    from biapy_amd.chunked import ChunkedPredictor, StreamedChunkedPredictor
+    from biapy_amd.resunet import ResUNet
+    from oracle import net_oracle
+
+    fm = [16, 32]
+    sd = net_oracle.init_state_dict(1, fm, seed=9)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=fm, drop_values=[0.0, 0.0], normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    shape, crop, pad = (88, 120, 136, 1), (32, 32, 32), (4, 8, 4)
+    rs = np.random.RandomState(4)
+    vol = np.lib.format.open_memmap(str(tmp_path / "vol.npy"), mode="w+", dtype=np.uint8 if dtype == "u8" else np.float32, shape=shape)
+    vol[:] = rs.randint(0, 255, size=shape).astype(np.uint8) if dtype == "u8" else rs.randn(*shape).astype(np.float32)
+    vol.flush()
+    vol = np.load(str(tmp_path / "vol.npy"), mmap_mode="r")                      # read-only view of the file
+    fwd = (lambda p: m.predict_proba(p.float() / 255.0)) if dtype == "u8" else m.predict_proba
+    want = ChunkedPredictor(fwd, crop, pad, batch_size=batch).predict(torch.from_numpy(np.ascontiguousarray(vol)).cuda()).cpu().numpy()
+    out = np.lib.format.open_memmap(str(tmp_path / "pred.npy"), mode="w+", dtype=np.float32, shape=shape[:3] + (1,))
+    vol_bytes = vol.size * vol.itemsize + out.size * 4
+    budget = vol_bytes // 3
+    sp = StreamedChunkedPredictor(fwd, crop, pad, batch_size=batch, patches_per_tile=ppt, out_channels=1, max_device_bytes=budget)
+    n = sp.predict(vol, out)
+    out.flush()
+    assert n > 4 and sp.device_bytes <= budget < vol_bytes
+    got = np.load(str(tmp_path / "pred.npy"), mmap_mode="r")
+    assert np.array_equal(np.asarray(got).view(np.uint32), want.view(np.uint32))
+    # two "ranks" one after the other into a fresh file: disjoint chunk-aligned regions, together the same volume
+    out2 = np.lib.format.open_memmap(str(tmp_path / "pred2.npy"), mode="w+", dtype=np.float32, shape=shape[:3] + (1,))
+    out2[:] = np.nan
+    n0 = sp.predict(vol, out2, rank=0, world=2)
+    assert np.isnan(out2).any()
+    n1 = sp.predict(vol, out2, rank=1, world=2)
+    assert n0 + n1 == n and np.array_equal(np.asarray(out2).view(np.uint32), want.view(np.uint32))
+    with pytest.raises(MemoryError):
+        StreamedChunkedPredictor(fwd, crop, pad, batch_size=batch, patches_per_tile=(4, 4, 4), out_channels=1, max_device_bytes=1 << 20).predict(vol, out)
+
+
 def test_data_parallel_step_adopts_the_engine_gradient_slab():
     """graphs.DataParallelTrainStep in graph mode: the engine's one-slab gradients are adopted as the flat all-reduce buffer
     (no accumulate kernels) and three replayed steps equal three eager steps."""
@@ -1007,6 +1102,128 @@ def test_two_process_data_parallel_training_on_one_gpu():
         a, b = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
         assert torch.equal(a, b), k                                            # the ranks stay bit-identical
         assert (a - w).abs().max().item() <= 2e-5 * max(1.0, w.abs().max().item()), k
+
+
+def _pp_model(seed, dtype=torch.float32, patch=16):
+    from biapy_amd.resunetpp import ResUNetPlusPlus
+
+    torch.manual_seed(seed)
+    return ResUNetPlusPlus(image_shape=(patch, patch, patch, 1), activation="elu", feature_maps=[16, 32, 64], drop_values=[0.0] * 3, normalization="in", k_size=3,
+                           upsample_layer="convtranspose", yx_down=[2, 2], z_down=[2, 2], output_channels=[3], output_channel_info=["BCD"],
+                           head_activations=["ce_sigmoid", "ce_sigmoid", "tanh"], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3,
+                           compute_dtype=dtype).cuda()
+
+
+def _pp_data(seed, n, B=1, patch=16):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(B, patch, patch, patch, 1, generator=g),
+             torch.cat([(torch.rand(B, patch, patch, patch, 2, generator=g) > 0.5).float(), torch.rand(B, patch, patch, patch, 1, generator=g) * 2 - 1], -1)) for _ in range(n)]
+
+
+def _dp2_pp_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from biapy_amd import train_engine as TE
+    from biapy_amd.losses import InstanceChannelsLoss
+
+    data = _pp_data(60 + rank, 3)
+    m = _pp_model(0 if rank == 0 else 7)                                 # rank 1 starts elsewhere: the step must broadcast rank 0's weights
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+    loss_fn = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).cuda()
+    stats, _ = TE.train_one_epoch(_te_cfg((16, 16, 16, 1)), m, None, loss_fn, None, None, data, [opt], torch.device("cuda"), 0, loss_names=["loss"], graph="on")
+    q.put((rank, stats["loss"], {k: p.detach().cpu().numpy() for k, p in m.named_parameters() if p.dim() >= 2}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_data_parallel_training_of_resunetpp_on_one_gpu():
+    """cfg 4 = "DDP training" (VERDICT r2 weak #3 / item 4): ResUNetPlusPlus + InstanceChannelsLoss (B, C: BCE; D: MSE through tanh) through
+    train_one_epoch's graph path on TWO ranks (gloo, both on cuda:0) - parameters broadcast from rank 0, one flat all-reduce between the two graph
+    replays - against a single process trained on the concatenated batches: both ranks bit-identical, equal to the single process."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from biapy_amd.losses import InstanceChannelsLoss
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp2_pp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    per_rank = [_pp_data(60 + r, 3) for r in range(2)]
+    m = _pp_model(0).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+    loss_fn, tot = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).cuda(), 0.0
+    for k in range(3):
+        x = torch.cat([per_rank[0][k][0], per_rank[1][k][0]]).permute(0, 4, 1, 2, 3).cuda()
+        t = torch.cat([per_rank[0][k][1], per_rank[1][k][1]]).permute(0, 4, 1, 2, 3).contiguous().cuda()
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(m(x), t)
+        loss.backward()
+        opt.step()
+        tot += loss.item()
+    ref = {k: p.detach().cpu() for k, p in m.named_parameters() if p.dim() >= 2}
+    assert abs(res[0][1] - res[1][1]) < 1e-7 and abs(res[0][1] - tot / 3) < 2e-5, (res[0][1], res[1][1], tot / 3)
+    for k, w in ref.items():
+        a, b = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
+        assert torch.equal(a, b), k
+        assert (a - w).abs().max().item() <= 5e-5 * max(1.0, w.abs().max().item()), k
+
+
+def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve():
+    """the cfg-4 family in bf16 is guarded by wide per-step gradient bars (random-init amplification), so a wrong tap in
+    one branch could hide there.  This trains ResUNet++ (fm 16-32-64, 32^3, B / C / D loss) for 30 AdamW steps on the device in bf16 and the
+    CPU oracle graph in fp32 from the same weights on the same batches: the two loss CURVES must stay together (a wrong gradient anywhere
+    makes them part within a few steps), and both must go down."""
+    from biapy_amd.losses import InstanceChannelsLoss
+    from oracle import loss_oracle, resunetpp_oracle
+
+    fm, steps = [16, 32, 64], 30
+    dev_m = _pp_model(3, torch.bfloat16, patch=32).train()
+    cpu_p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dev_m.named_parameters()}
+    g = torch.Generator().manual_seed(8)
+    blobs = lambda: (F_.avg_pool3d(torch.randn(2, 2, 32, 32, 32, generator=g), 5, stride=1, padding=2) > 0.02).float()   # noqa: E731
+    import torch.nn.functional as F_
+    batches = []
+    for _ in range(4):
+        t_bc = blobs()
+        t_d = torch.tanh(F_.avg_pool3d(torch.randn(2, 1, 32, 32, 32, generator=g), 5, stride=1, padding=2) * 4)
+        x = t_bc[:, :1] * 1.5 + 0.5 * t_d + 0.6 * torch.randn(2, 1, 32, 32, 32, generator=g)
+        batches.append((x, torch.cat([t_bc, t_d], 1)))
+    loss_fn = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).cuda()
+    opt_d = torch.optim.AdamW(dev_m.parameters(), lr=2e-3)
+    opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=2e-3)
+    curve_d, curve_c = [], []
+    for it in range(steps):
+        x, t = batches[it % len(batches)]
+        opt_d.zero_grad(set_to_none=True)
+        ld = loss_fn(dev_m(x.cuda()), t.cuda())
+        ld.backward()
+        opt_d.step()
+        opt_c.zero_grad(set_to_none=True)
+        lo = resunetpp_oracle.resunetpp_forward(cpu_p, x, fm)
+        lc = loss_oracle.instance_channels(loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True), t, ["bce", "bce", "mse"], [1, 1, 1])
+        lc.backward()
+        opt_c.step()
+        curve_d.append(ld.item())
+        curve_c.append(lc.item())
+    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+    assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
+    rel = ((cd - cc).abs() / cc).max().item()
+    assert rel < 0.05, (rel, curve_c, curve_d)
 
 
 def _sw2_worker(rank, world, port, q):

@@ -318,6 +318,34 @@ def test_chunk_grid_rank_partition_covers_every_chunk_once():
         assert (cover == 1).all()
 
 
+def test_work_tiles_partition_the_chunk_grid():
+    """chunked.TileGrid (TEST.BY_CHUNKS.WORKFLOW_PROCESS tiles, chunked_test_pair_data_generator.py:331-357): every chunk in exactly one tile,
+    tile write regions tile the volume, a tile's read region contains the read regions of its chunks, ranks get disjoint tile lists."""
+    from biapy_amd.chunked import ChunkGrid, TileGrid
+
+    for dim, crop, pad, ppt in (((70, 64, 90), (32, 32, 32), (4, 4, 4), (2, 1, 2)), ((33, 50, 41), (16, 24, 16), (2, 0, 5), (3, 2, 1)),
+                                ((64, 64, 64), (32, 32, 32), (0, 0, 0), (1, 1, 1))):
+        g = ChunkGrid(dim, crop, pad)
+        t = TileGrid(g, ppt)
+        seen = sorted(v for tid in t.tile_ids for v in t.patches_of_tile[tid])
+        assert seen == list(range(g.total))
+        cov = np.zeros(dim, np.int32)
+        for tid in t.tile_ids:
+            w, r = t.write_region(tid), t.read_region(tid)
+            cov[w.z_start:w.z_end, w.y_start:w.y_end, w.x_start:w.x_end] += 1
+            for v in t.patches_of_tile[tid]:
+                _, _, _, ext, real = g.patch_coords(v)
+                assert r.z_start <= ext.z_start and ext.z_end <= r.z_end and r.y_start <= ext.y_start and ext.y_end <= r.y_end
+                assert r.x_start <= ext.x_start and ext.x_end <= r.x_end
+                assert w.z_start <= real.z_start and real.z_end <= w.z_end and w.x_start <= real.x_start and real.x_end <= w.x_end
+                tab = g.index_tables(v)
+                assert tab[: crop[0]].min() >= r.z_start and tab[: crop[0]].max() < r.z_end          # the reflection stays inside the tile's read region
+        assert cov.min() == 1 and cov.max() == 1
+        for world in (1, 2, 3, 5):
+            lists = [t.rank_order(world, r) for r in range(world)]
+            assert sorted(v for l in lists for v in l) == t.tile_ids
+
+
 def test_lift_params_is_the_same_convolution():
     """engine.lift_params / unlift_grads (2D and (1,3,3) weights -> zero-padded 3x3x3): the lifted weights compute the same
     convolution on a one-slice / any volume, and gradients map back to the centre z-tap - checked with PyTorch's CPU convs."""

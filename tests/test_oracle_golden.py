@@ -295,6 +295,29 @@ def test_oracle_harness_tail_matches_the_reference(harness_tail_golden, resunet_
     assert (got[..., 1] != ref[..., 1]).mean() < 1e-4          # arg-max of blended softmax values: ties within rounding are the only differences
 
 
+def test_pixel_shuffle3d_extends_pixel_shuffle():
+    """The 3-D pixel shuffle of the cfg-5 up-scaling stage is DEFINED by this package (the reference applies nn.PixelShuffle, a 2-D operator,
+    and raises on 5-D tensors: rcan.py:317-319): check that the definition is nn.PixelShuffle's rule with one more axis - for every z
+    sub-position a, the (b, e) sub-positions of a z-slice are F.pixel_shuffle of the channels that carry that a - and that it is a bijection."""
+    import torch.nn.functional as F
+
+    from oracle.rcan_oracle import pixel_shuffle3d
+
+    s, C, Z, Y, X = 3, 2, 2, 4, 5
+    x = torch.arange(C * s ** 3 * Z * Y * X, dtype=torch.float32).reshape(1, C * s ** 3, Z, Y, X)
+    y = pixel_shuffle3d(x, s)
+    assert y.shape == (1, C, Z * s, Y * s, X * s)
+    assert torch.equal(torch.sort(y.flatten())[0], x.flatten())                       # a permutation of the elements
+    xr = x.reshape(1, C, s, s * s, Z, Y, X)
+    for a in range(s):
+        for z in range(Z):
+            plane = xr[:, :, a, :, z].reshape(1, C * s * s, Y, X)                    # channels c s^2 + b s + e of z sub-position a
+            assert torch.equal(y[:, :, z * s + a], F.pixel_shuffle(plane, s))
+    # the element the formula names
+    n, c, z, yy, xx, a, b_, e = 0, 1, 1, 3, 2, 2, 0, 1
+    assert y[n, c, s * z + a, s * yy + b_, s * xx + e] == x[n, c * s ** 3 + (a * s + b_) * s + e, z, yy, xx]
+
+
 def test_tta_ensemble_oracle_matches_reference(tta_ensemble_golden):
     """The whole scalar-field TTA routine - pad to square (reflect / edge), predict every orientation, undo, mean / min / max, crop -
     against ``ensemble_predictions`` of the reference (post_processing.py:1386-1540) on five shapes x five settings: bit-exact."""
