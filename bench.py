@@ -91,7 +91,7 @@ def conv_bytes(name, key, es):
 # ------------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (PyTorch CPU fp32 restatement of the reference graph, NumPy restatement of crop / merge) on this host
 # ------------------------------------------------------------------------------------------------------------------------
-def _cpu_net_leg(P, train, threads, reps_cap=2):
+def _cpu_net_leg(P, train, threads, reps=3):
     from oracle import net_oracle
 
     old = torch.get_num_threads()
@@ -115,16 +115,21 @@ def _cpu_net_leg(P, train, threads, reps_cap=2):
                     net_oracle.resunet_forward(params, x, FM)
 
         t0 = time.time(); step(); warm = time.time() - t0
-        reps = 1 if warm > 8 else reps_cap
-        t0 = time.time()
-        for _ in range(reps):
+        if warm > 30:                       # a very slow host: one timed repetition keeps the default run within minutes
+            reps = 1
+        times = []
+        for _ in range(reps):               # >= 3 timed repetitions after the warm-up; mean, spread stated
+            t0 = time.time()
             step()
-        dt = (time.time() - t0) / reps
+            times.append(time.time() - t0)
+        dt = sum(times) / len(times)
     finally:
         torch.set_num_threads(old)
-    return dict(value=P ** 3 / dt, unit="voxels/s", cores=threads, kind="port",
-                sample=f"{reps} {'train steps (fwd+BCE+bwd+AdamW)' if train else 'forwards'} of one {P}^3 patch, batch 1, fp32, after 1 warm-up "
-                       f"({dt:.2f} s each)")
+    sd = (sum((t - dt) ** 2 for t in times) / len(times)) ** 0.5
+    return dict(value=P ** 3 / dt, unit="voxels/s", cores=threads, kind="port", reps=len(times), seconds_per_rep=[round(t, 3) for t in times],
+                rel_std=round(sd / dt, 4),
+                sample=f"{len(times)} {'train steps (fwd+BCE+bwd+AdamW)' if train else 'forwards'} of one {P}^3 patch, batch 1, fp32, after 1 warm-up "
+                       f"(mean {dt:.2f} s, min {min(times):.2f} s, max {max(times):.2f} s)")
 
 
 def _cpu_tiling_leg(V=256, P=128):
@@ -150,10 +155,10 @@ def cpu_baseline(P, quick=False):
     (about 40 s in total): train at every core and at BiaPy's default ``min(4, ncpu)`` threads (biapy/_biapy.py:333-346; on a
     64^3 patch there - same network, 1/8 of the voxels), inference at every core, crop + merge single-threaded."""
     ncpu = torch.get_num_threads()
-    legs = {"train_all_cores": _cpu_net_leg(P, True, ncpu, reps_cap=1)}
+    legs = {"train_all_cores": _cpu_net_leg(P, True, ncpu, reps=1 if quick else 3)}
     if not quick:
-        legs["train_biapy_default_threads"] = _cpu_net_leg(min(P, 64), True, min(4, ncpu), reps_cap=1)
-        legs["infer_all_cores"] = _cpu_net_leg(P, False, ncpu)
+        legs["train_biapy_default_threads"] = _cpu_net_leg(min(P, 64), True, min(4, ncpu), reps=3)
+        legs["infer_all_cores"] = _cpu_net_leg(P, False, ncpu, reps=3)
         legs["crop_merge_numpy"] = _cpu_tiling_leg()
     head = dict(legs["train_all_cores"])
     head["legs"] = legs
@@ -270,43 +275,81 @@ def _tiling_traffic(V, world, n_patches):
         return dict(traffic=None)
 
 
+def pmc_traffic(entry, src=os.path.join("profiles", "pmc_traffic.json")):
+    """HBM bytes per call of a C-ABI entry from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py) - quoted only while the file's
+    stamp (sha256 of biapy_amd/csrc) equals the tree's: counters of other kernels than the ones being timed are refused, loudly."""
+    try:
+        from biapy_amd._lib import source_digest
+
+        d = json.load(open(os.path.join(ROOT, src)))
+        stamp = (d.get("_meta") or {}).get("csrc_sha256")
+        if stamp != source_digest():
+            print(f"[bench] {src} is STALE: it was collected for other kernel sources (stamp {str(stamp)[:12]} != tree {source_digest()[:12]}); "
+                  f"roofline.traffic is null until scripts/refresh_profiles.sh is re-run", file=sys.stderr)
+            return dict(traffic=None, traffic_error=f"{src} is stale (collected for other kernel sources); re-run scripts/refresh_profiles.sh")
+        return dict(traffic=(d.get(entry) or {}).get("total_bytes"),
+                    traffic_source=src + " (separate rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes over this command, committed with the stamp "
+                                         "of the kernel sources; per call of the entry point, not measured in this run)")
+    except (OSError, ValueError) as e:
+        return dict(traffic=None, traffic_error=f"{src}: {e}")
+
+
+def _shape_name(name, key):
+    """'bpx_conv3d_fwd[4x128^3 C48+0->C16]' from a profile key (dtype, N, D, H, W, 'Cx', ...)."""
+    ints = [k for k in key if isinstance(k, int)]
+    cs = [int(k[1:]) for k in key if isinstance(k, str)]
+    N, D, H, W = ints[1:5]
+    vol = f"{D}^3" if D == H == W else f"{D}x{H}x{W}"
+    if name == "bpx_conv3d_fwd":
+        return f"{name}[{N}x{vol} C{cs[0]}" + (f"+sc{cs[1]}" if cs[1] else "") + f"->C{cs[2]}]"
+    if name == "bpx_conv3d_dgrad":
+        return f"{name}[{N}x{vol} dy C{cs[0]}->g C{cs[2]}]"
+    return f"{name}[{N}x{vol} C{cs[0]}->C{cs[1]} k{wgrad_k(key)}]"
+
+
 def conv_roofline(prof, prof_steps, dtype, timed_on):
-    """Roofline entry of the dominant conv entry point from per-launch HIP events (bytes / flops per launch from its shape)."""
+    """Roofline entries from per-launch HIP events on the launch stream: `roofline` = the launch SHAPE (entry point + tensor shape = one
+    kernel instance) with the most time per step, `top3` the three heaviest shapes, `families` the per-entry-point totals of round 2.
+    Algorithmic bytes / flops per launch follow from the shape; the binding roof is the larger of bytes / 8 TB/s
+    and flops / the dense MFMA peak."""
     summ = prof.summary()
-    per = {}
+    es = 4 if dtype == "f32" else 2
+    peak = 157.3 if dtype == "f32" else MFMA_PEAK_BF16 / 1e12      # dense fp16 MFMA peak = dense bf16 peak
+    fam, shapes = {}, []
+    flush_ms = 0.0
     for (name, key), (cnt, ms) in summ.items():
         if name == "bpx_wgrad_defer_flush":      # the batched reduction of the step's partial slabs is part of the wgrad calls' time
-            per.setdefault("bpx_conv3d_wgrad", [0.0, 0.0, 0, 0.0])[1] += ms
+            flush_ms += ms
             continue
-        d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
-        d[0] += conv_flops(name, key) * cnt
-        d[1] += ms
-        d[2] += cnt
-        d[3] += conv_bytes(name, key, 4 if dtype == "f32" else 2) * cnt
-    per = {k: v for k, v in per.items() if v[2] > 0}
-    if not per:
-        return None
-    name, (fl, ms, cnt, by) = max(per.items(), key=lambda kv: kv[1][1])
-    peak = 157.3 if dtype == "f32" else MFMA_PEAK_BF16 / 1e12      # dense fp16 MFMA peak = dense bf16 peak
-    ach_f = fl / (ms * 1e-3) / 1e12                 # TFLOP/s
-    ach_b = by / (ms * 1e-3) / 1e9                  # GB/s of algorithmic bytes
-    # the binding roof is the one whose minimum time (work / peak) is larger for this kernel's launches
-    hbm_bound = by / HBM_PEAK > fl / (peak * 1e12)
-    traffic, src = None, os.path.join("profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/pmc_traffic.py
-    try:
-        traffic = (json.load(open(os.path.join(ROOT, src))).get(name) or {}).get("total_bytes")
-    except (OSError, ValueError):
-        traffic = None
-    return dict(bound="hbm" if hbm_bound else "mfma", kernel=name,
-                achieved=round(ach_b if hbm_bound else ach_f, 2), peak=HBM_PEAK / 1e9 if hbm_bound else peak,
-                unit="GB/s" if hbm_bound else "TFLOP/s",
-                frac=round(ach_b / (HBM_PEAK / 1e9) if hbm_bound else ach_f / peak, 4),
-                traffic=traffic, traffic_source=src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, committed; not measured in this run)",
-                algorithmic_bytes_per_launch=round(by / cnt), flops_per_launch=round(fl / cnt),
-                launches=cnt, avg_launch_ms=round(ms / cnt, 4), tflops=round(ach_f, 2), algorithmic_GBps=round(ach_b, 1),
-                all={k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), GBps=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
-                             ms_per_step=round(v[1] / prof_steps, 3)) for k, v in per.items()},
-                timed_on=timed_on)
+        fl, by = conv_flops(name, key) * cnt, conv_bytes(name, key, es) * cnt
+        d = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
+        d[0] += fl; d[1] += ms; d[2] += cnt; d[3] += by
+        if cnt and fl:
+            shapes.append((ms, name, key, cnt, fl, by))
+    if "bpx_conv3d_wgrad" in fam:
+        fam["bpx_conv3d_wgrad"][1] += flush_ms
+    fam = {k: v for k, v in fam.items() if v[2] > 0}
+    if not shapes:
+        return None, None
+
+    def entry(ms, name, key, cnt, fl, by):
+        ach_f, ach_b = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+        hbm = by / HBM_PEAK > fl / (peak * 1e12)
+        return dict(bound="hbm" if hbm else "mfma", kernel=_shape_name(name, key), achieved=round(ach_b if hbm else ach_f, 2),
+                    peak=HBM_PEAK / 1e9 if hbm else peak, unit="GB/s" if hbm else "TFLOP/s", frac=round(ach_b / (HBM_PEAK / 1e9) if hbm else ach_f / peak, 4),
+                    algorithmic_bytes_per_launch=round(by / cnt), flops_per_launch=round(fl / cnt), launches=cnt, avg_launch_ms=round(ms / cnt, 4),
+                    ms_per_step=round(ms / prof_steps, 3), tflops=round(ach_f, 2), algorithmic_GBps=round(ach_b, 1), mfma_frac=round(ach_f / peak, 4),
+                    hbm_frac=round(ach_b / (HBM_PEAK / 1e9), 4))
+
+    shapes.sort(key=lambda t: -t[0])
+    top = [entry(*t) for t in shapes[:3]]
+    head = dict(top[0])
+    head.update(pmc_traffic(shapes[0][1]))
+    head["traffic_is_for"] = "the average call of entry point %s (all its shapes), not this shape alone" % shapes[0][1]
+    head["families"] = {k: dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 2), GBps=round(v[3] / (v[1] * 1e-3) / 1e9, 1), ms_per_step=round(v[1] / prof_steps, 3),
+                                hbm_frac=round(v[3] / (v[1] * 1e-3) / HBM_PEAK, 4)) for k, v in fam.items()}
+    head["timed_on"] = timed_on
+    return head, top
 
 
 def main():
@@ -344,6 +387,11 @@ def main():
                     help="resunetpp = cfg 4 (3D instance segmentation, B/C/D channels, ResUNet++ fm 16-32-64-128-256, 80^3 patches): its own JSON "
                          "line, train mode only - a second-tier configuration, not the headline")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the ResUNet++ (cfg 4) sub-record of the single-GPU line")
+    ap.add_argument("--self-check", action="store_true",
+                    help="verify (also with one rank under --force-ddp) that every rank's post-all-reduce gradient / parameter checksum agrees and that "
+                         "the gathered cfg-3 volume has the checksum of the single-GPU run committed in profiles/sliding_checksums.json; at N > 1 the "
+                         "checks run by default")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the RCAN x4 super-resolution (cfg 5) sub-record of the single-GPU line")
     ap.add_argument("--sliding-timeout", type=float, default=240.0,
                     help="N > 1: seconds after which a hung sliding-window section is abandoned (the line is printed without it)")
     a = ap.parse_args()
@@ -374,6 +422,7 @@ def main():
     torch.manual_seed(0)
     model = ResUNet(image_shape=(a.patch,) * 3 + (1,), activation="elu", feature_maps=FM, drop_values=[0.0] * 5, normalization="in",
                     yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev)
+    init_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}     # the sliding-window sections run with THESE weights at every N
     V = a.vol if a.vol is not None else (1024 if world > 1 else 512)
     inf_name = {"mix16": "f16"}.get(a.dtype, a.dtype) if (a.infer_dtype == "same" or a.dtype == "f32") else a.infer_dtype
     inf_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[inf_name]
@@ -449,6 +498,23 @@ def main():
         if a.breakdown:
             return breakdown(a, L, step, "train")
 
+        self_check = None
+        if multi and (a.self_check or world > 1):
+            # every rank must hold the SAME averaged gradients and the same parameters after a step (all-reduce + identical optimizer steps):
+            # rank-local double checksums are gathered and compared on every rank; a mismatch fails the run instead of producing a number
+            gsum = torch.zeros((), dtype=torch.float64, device=dev)
+            for p_ in model.parameters():
+                gsum += p_.detach().double().sum() * 1e-3
+                if p_.grad is not None:
+                    gsum += p_.grad.detach().double().abs().sum()
+            allsums = [torch.zeros_like(gsum) for _ in range(world)]
+            dist.all_gather(allsums, gsum)
+            vals = [float(v) for v in allsums]
+            agree = all(v == vals[0] for v in vals)
+            self_check = dict(ranks=world, gradient_and_parameter_checksums_agree=agree, checksum=vals[0])
+            if not agree:
+                raise SystemExit(f"[bench] self-check FAILED: the ranks' gradient / parameter checksums differ after the all-reduce: {vals}")
+
         prof = L.Profile(names=CONV_ENTRIES)
         if not graphed:
             L.lib.prof = prof
@@ -479,10 +545,15 @@ def main():
                         "hip-graph replay (whole step)") if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
                                                                         if fb_graphs else "eager"),
                 mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * 3 / (world * MFMA_PEAK_BF16), 5),
-                roofline=conv_roofline(prof, prof_steps, a.dtype,
-                                       "eager steps right after the timed region (the timed region replays HIP graphs)" if (graphed or fb_graphs)
-                                       else "the timed region"),
             )
+            line["roofline"], line["roofline_top3"] = conv_roofline(prof, prof_steps, a.dtype,
+                                                                    "eager steps right after the timed region (the timed region replays HIP graphs)"
+                                                                    if (graphed or fb_graphs) else "the timed region")
+            if self_check is not None:
+                line["self_check"] = self_check
+            # insurance for the first multi-GPU run: the train record is on stderr before the sliding-window exchange starts
+            print("[bench] train record (the JSON line follows at the end): " + json.dumps({k: line[k] for k in ("value", "ms_per_step", "n_gpus", "self_check") if k in line}),
+                  file=sys.stderr, flush=True)
         del step, eager_step, opt
         if graphed:
             del gstep
@@ -536,9 +607,9 @@ def main():
                 config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, infer" % (a.patch, a.batch),
                             global_batch=world * a.batch, patch=a.patch, parallelism="replicas x%d" % world, mode="infer"),
                 launch="hip-graph replay (weights packed inside the graph)" if graphed else "eager", dtype=inf_name,
-                mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD / (world * MFMA_PEAK_BF16), 5),
-                roofline=conv_roofline(prof, prof_steps, inf_name,
-                                       "eager forwards right after the timed region (the timed region replays a HIP graph)" if graphed else "the timed region"))
+                mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD / (world * MFMA_PEAK_BF16), 5))
+            infer_rec["roofline"], infer_rec["roofline_top3"] = conv_roofline(
+                prof, prof_steps, inf_name, "eager forwards right after the timed region (the timed region replays a HIP graph)" if graphed else "the timed region")
         if graphed:
             del ginf
         del step
@@ -570,7 +641,8 @@ def main():
         if world > 1:
             threading.Thread(target=watchdog, daemon=True).start()
         try:
-            model.compute_dtype = inf_dtype
+            model.load_state_dict(init_sd)               # the initial weights (same seed on every rank): the checksum of the blended volume is then
+            model.compute_dtype = inf_dtype              # comparable between N = 1 and N = 8 (profiles/sliding_checksums.json)
             sliding_rec = run_sliding(a, model, dev, rank, world, V, 1, max(1, min(a.steps, 2)))
             if sliding_rec is not None:
                 sliding_rec["dtype"] = inf_name
@@ -590,14 +662,53 @@ def main():
         except Exception as e:  # noqa: BLE001 - the headline line must survive
             cfg4_rec = dict(error=f"{type(e).__name__}: {e}")
 
+    # cfg 5 (RCAN-3D x4, 64^3 -> 256^3, fp16 inference) as a sub-record of the single-GPU line
+    cfg5_rec = None
+    if a.mode == "all" and world == 1 and not multi and not a.no_cfg5:
+        try:
+            cfg5_rec = run_rcan_sr(a, dev)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 - the headline line must survive
+            cfg5_rec = dict(error=f"{type(e).__name__}: {e}")
+
     if rank == 0 and line is not None:
-        line["infer"] = infer_rec
-        line["sliding"] = sliding_rec
+        # the sliding-window checksum against the single-GPU run of the same volume (profiles/sliding_checksums.json, committed)
+        if sliding_rec is not None and sliding_rec.get("checksum") is not None:
+            try:
+                ref = json.load(open(os.path.join(ROOT, "profiles", "sliding_checksums.json"))).get(str(V))
+            except (OSError, ValueError):
+                ref = None
+            if ref is not None:
+                ok = abs(sliding_rec["checksum"] - ref["checksum"]) <= 1e-9 * max(1.0, abs(ref["checksum"]))
+                sliding_rec["checksum_matches_single_gpu_run"] = ok
+                sliding_rec["checksum_reference"] = ref
+                if not ok:
+                    print(f"[bench] self-check: the gathered cfg-3 volume's checksum {sliding_rec['checksum']!r} differs from the single-GPU run's {ref['checksum']!r}",
+                          file=sys.stderr)
+        # flat sub-record values FIRST (a truncated tail of the line still carries them), the long objects behind
+        flat = {}
+        for tag, rec in (("infer", infer_rec), ("sliding", sliding_rec), ("cfg4", cfg4_rec), ("cfg5", cfg5_rec)):
+            if isinstance(rec, dict) and "value" in rec:
+                flat[f"{tag}_value"] = rec["value"]
+                flat[f"{tag}_ms_per_step"] = rec.get("ms_per_step")
+                flat[f"{tag}_unit"] = rec.get("unit")
+            elif isinstance(rec, dict) and "error" in rec:
+                flat[f"{tag}_error"] = rec["error"]
+        long_keys = ("roofline", "roofline_top3")
+        out = {k: v for k, v in line.items() if k not in long_keys}
+        out.update(flat)
+        for k in long_keys:
+            if k in line:
+                out[k] = line[k]
+        out["infer"], out["sliding"] = infer_rec, sliding_rec
         if cfg4_rec is not None:
-            line["cfg4_resunetpp"] = cfg4_rec
+            out["cfg4_resunetpp"] = cfg4_rec
+        if cfg5_rec is not None:
+            out["cfg5_rcan_sr"] = cfg5_rec
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.patch, quick=a.quick_cpu_baseline)
-        print(json.dumps(line))
+            out["cpu_baseline"] = cpu_baseline(a.patch, quick=a.quick_cpu_baseline)
+        print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
 
@@ -679,6 +790,40 @@ def run_resunetpp(a, dev, rank, world, multi, dtype, as_record=False):
         print(json.dumps(rec))
     if multi:
         dist.destroy_process_group()
+
+
+def run_rcan_sr(a, dev):
+    """cfg 5: 3D super-resolution x4 with RCAN-3D (10 groups x 20 RCABs, 16 filters), one 64^3 patch -> 256^3, fp16, inference: the
+    trunk at 64^3, the up-scaling stage (conv 16 -> 1024 channels with the 3-D pixel shuffle fused into its store) and the last conv at
+    256^3.  One step = one forward of one patch, replayed from a HIP graph (the trunk is a chain of ~800 dependent kernels)."""
+    from biapy_amd.rcan import rcan
+
+    torch.manual_seed(0)
+    m = rcan(ndim=3, num_channels=1, filters=16, scale=4, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=True, out_channels=1,
+             head_activations=["linear"], compute_dtype=torch.float16).to(dev).eval()
+    x = torch.randn(1, 1, 64, 64, 64, device=dev)
+    step, launch = (lambda: m(x)), "eager"
+    with torch.no_grad():
+        y = m(x)
+        try:
+            from biapy_amd.graphs import GraphedInference
+
+            ginf = GraphedInference(lambda t: m(t), x)
+            step, launch = (lambda: ginf()), "hip-graph replay"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] cfg5 graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        for _ in range(2):
+            step()
+        steps = max(3, min(a.steps, 10))
+        elapsed = _timed(step, steps, 1, dev)
+    out_vox = 256 ** 3
+    # forward FLOPs: 401 convs 16->16 + sf (1->16) at 64^3, 16 -> 1024 at 64^3, 16 -> 1 at 256^3 (2 * 27 * Cin * Cout per voxel)
+    flops = 2 * 27 * (64 ** 3 * (401 * 256 + 16 + 16 * 1024) + 256 ** 3 * 16)
+    return dict(metric="voxels/sec 3D RCAN x4 super-resolution 64^3 -> 256^3 (inference forward, output voxels)", value=out_vox * steps / elapsed, unit="voxels/s",
+                n_gpus=1, steps=steps, ms_per_step=1e3 * elapsed / steps, dtype="f16", launch=launch, input_voxels_per_s=64 ** 3 * steps / elapsed,
+                config=dict(workload="cfg5: RCAN-3D x4 (10 x 20 RCABs, 16 filters), one 64^3 patch -> 256^3, fp16, inference", patch=64, scale=4),
+                mfma_frac_end_to_end=round(flops * steps / elapsed / MFMA_PEAK_BF16, 5), output_checksum=float(y.double().mean().item()),
+                note="3-D pixel shuffle is defined by this package (the reference's 3-D up-scaling branch raises): parity unpinned against BiaPy")
 
 
 def breakdown(a, L, step, mode):

@@ -209,6 +209,19 @@ class _LibProxy:
 lib = _LibProxy(_load())
 
 
+def source_digest() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp in name order): stamped into the PMC summaries under profiles/ so that bench.py
+    can tell when a committed counter file no longer belongs to the kernels it is quoted for."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def check(rc: int) -> None:
     if rc != 0:
         raise BpxError(lib.bpx_last_error().decode())

@@ -182,6 +182,7 @@ class InstanceChannelsLoss(torch.nn.Module):
                 raise NotImplementedError("a BCE channel takes logits (head activation ce_sigmoid)")
             codes |= (kind | (act << 2)) << (4 * i)
         self.codes = codes
+        self.fused_head_activations = [a.lower() for a in acts]          # train_engine: the graph path hands this loss the raw logits
         self.register_buffer("weights", torch.tensor([float(w) for w in channel_weights], dtype=torch.float32))
 
     def forward(self, logits, target):

@@ -23,7 +23,8 @@ What is different, because the step is ~10 ms on an MI355X and a host round trip
     averaged by one flat all-reduce per step, which is what the DDP wrap of ``base_workflow.py:952-958`` does for the
     reference).  The replayed step bypasses ``model_call_func``, which is only legal where that function is the identity around
     the model in training mode (``to_pytorch_format`` -> model -> no resize, no training-time activation:
-    ``base_workflow.py:855-892`` with ``ce_sigmoid`` / ``ce_softmax`` / ``linear`` heads, :1427) - anything else, a ragged last
+    ``base_workflow.py:855-892`` with ``ce_sigmoid`` / ``ce_softmax`` / ``linear`` heads, :1427; or a loss that applies the model's head
+    activations inside its own kernel, ``losses.InstanceChannelsLoss`` built with the same list) - anything else, a ragged last
     batch, gradient clipping, per-step schedulers, several losses or a memory bank run the eager step.  The optimizer's ``lr``
     is turned into a device scalar so that scheduler updates between epochs reach the captured optimizer step.
 Contrastive memory banks stay on the reference's loop (``NotImplementedError`` here, as the model classes raise for ``contrast``).
@@ -142,12 +143,17 @@ def _losses_of(result) -> Tuple[List[torch.Tensor], Dict]:
 _GRAPH_SAFE_ACTS = ("ce_sigmoid", "ce_softmax", "linear")
 
 
-def _graphable_model(inner) -> bool:
-    """A biapy_amd drop-in whose training-time ``model_call_func`` is the identity around the model (see the module docstring)."""
+def _graphable_model(inner, criterion=None) -> bool:
+    """A biapy_amd drop-in whose training-time ``model_call_func`` is the identity around the model (see the module docstring): every
+    head is linear at training time, or the criterion applies the model's head activations itself (``InstanceChannelsLoss``: the
+    'D' channel's tanh is part of the loss kernel) and was built with the same list."""
     if not getattr(inner, "_bpx_dropin", False):
         return False
     acts = [str(a).lower() for a in getattr(inner, "head_activations", ["ce_sigmoid"])]
-    return all(a in _GRAPH_SAFE_ACTS for a in acts)
+    if all(a in _GRAPH_SAFE_ACTS for a in acts):
+        return True
+    fused = getattr(criterion, "fused_head_activations", None)
+    return fused is not None and [str(a).lower() for a in fused] == acts
 
 
 class _Window:
@@ -224,9 +230,9 @@ def train_one_epoch(
     capturable = all(g.get("capturable", False) for o in optimizers for g in o.param_groups)
     single = len(optimizers) == 1 and len(loss_names) == 1
     can_graph = (device.type == "cuda" and capturable and single and clip <= 0 and not per_step_sched and not per_iter_warmup
-                 and _graphable_model(inner))
+                 and _graphable_model(inner, loss_function))
     if graph == "on" and not can_graph:
-        raise ValueError("graph='on' needs a CUDA/HIP device, a biapy_amd model with training-time-linear heads, ONE capturable "
+        raise ValueError("graph='on' needs a CUDA/HIP device, a biapy_amd model with training-time-linear heads (or a loss fusing them), ONE capturable "
                          "optimizer and loss, no gradient clipping and no per-step scheduler")
     use_graph = can_graph and graph in ("on", "auto")
 

@@ -58,6 +58,13 @@ def main():
         write = 1024.0 * sum(w[g]) / nw if nw else None
         out[g] = dict(launches=nf, fetch_raw_bytes=round(fetch_raw), fetch_bytes=round(2 * fetch_raw), write_bytes=round(write) if write else None,
                       total_bytes=round(2 * fetch_raw + (write or 0)))
+    try:   # stamp the kernel sources the counters belong to (bench.py refuses to quote a file whose stamp differs from the tree's)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from biapy_amd._lib import source_digest
+        out["_meta"] = dict(csrc_sha256=source_digest())
+    except Exception as e:  # noqa: BLE001
+        out["_meta"] = dict(csrc_sha256=None, error=str(e))
     json.dump(out, sys.stdout, indent=1)
     print()
 

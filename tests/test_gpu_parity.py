@@ -1135,7 +1135,11 @@ def _dp2_pp_worker(rank, world, port, q):
     m = _pp_model(0 if rank == 0 else 7)                                 # rank 1 starts elsewhere: the step must broadcast rank 0's weights
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
     loss_fn = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).cuda()
-    stats, _ = TE.train_one_epoch(_te_cfg((16, 16, 16, 1)), m, None, loss_fn, None, None, data, [opt], torch.device("cuda"), 0, loss_names=["loss"], graph="on")
+    try:
+        stats, _ = TE.train_one_epoch(_te_cfg((16, 16, 16, 1)), m, None, loss_fn, None, None, data, [opt], torch.device("cuda"), 0, loss_names=["loss"], graph="on")
+    except Exception as e:                                               # the parent must not sit out its queue time-out on a dead worker
+        q.put((rank, repr(e), None))
+        raise
     q.put((rank, stats["loss"], {k: p.detach().cpu().numpy() for k, p in m.named_parameters() if p.dim() >= 2}))
     dist.barrier()
     dist.destroy_process_group()
@@ -1160,9 +1164,17 @@ def test_two_process_data_parallel_training_of_resunetpp_on_one_gpu():
     procs = [ctx.Process(target=_dp2_pp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
+    res = []
+    try:
+        for _ in range(2):
+            res.append(q.get(timeout=240))
+            assert res[-1][2] is not None, "worker %d: %s" % (res[-1][0], res[-1][1])
+    finally:
+        for p in procs:
+            p.join(timeout=60 if len(res) == 2 and res[-1][2] is not None else 1)
+            if p.is_alive():
+                p.terminate()
+    res.sort(key=lambda t: t[0])
     per_rank = [_pp_data(60 + r, 3) for r in range(2)]
     m = _pp_model(0).train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)

@@ -510,7 +510,7 @@ def test_rcan_oracle_and_module_match_reference(rcan_golden):
     m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
     with pytest.raises(RuntimeError, match="no CPU path"):
         m(torch.zeros(1, 1, 8, 8, 8))
-    for bad in (dict(ndim=2), dict(upscaling_layer=True), dict(filters=64), dict(num_channels=3)):
+    for bad in (dict(ndim=2), dict(upscaling_layer=True, filters=32), dict(upscaling_layer=True, scale=5), dict(filters=64), dict(num_channels=3)):
         kw = dict(ndim=3, num_channels=1, filters=16, num_rg=1, num_rcab=1, upscaling_layer=False)
         kw.update(bad)
         with pytest.raises(NotImplementedError):
