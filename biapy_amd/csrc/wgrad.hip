@@ -38,6 +38,7 @@ struct WgradParams {
   float* dw; int64_t si, sj, st; int64_t off;   // final dW index = ci*si + co*sj + tap*st + off (reduce kernel)
   float* db;                                     // bias gradient (accumulated into by the reduce kernel), or null
   float* dbpart;                                 // [groups][Cout] per-group column sums of dy (workspace, behind `part`): no atomics
+  float* db2;                                    // host side only: a second destination of the bias gradient (reduce kernel), or null
   int tilesY, tilesX, tilesPerSample, totalTiles, groups;
 };
 
@@ -1023,7 +1024,7 @@ inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
 // 1024 threads = 32 consecutive elements x 32 group lanes, four loads in flight per thread: the smallest dW has only 6912
 // elements (216 blocks) against up to 1024 partial slabs, so the kernel is a latency chain per block - with 8 group lanes
 // and two loads in flight it took ~70 us for the 16->16 layers, more than a quarter of their MFMA kernel.
-struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; const float* dbpart; float* db; int ndb; };   // ndb: length of a bias row (0 = Cout)
+struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; const float* dbpart; float* db; int ndb; float* db2 = nullptr; };   // ndb: length of a bias row (0 = Cout); db2: a second tensor that takes the same sums
 
 // 1024 threads = EL consecutive elements x GL group lanes (GL = reduce_glanes(groups), EL = 1024 / GL), up to four loads in
 // flight per thread; lane sums are combined in a fixed order, so the result does not depend on scheduling.
@@ -1078,6 +1079,7 @@ __device__ __forceinline__ void wgrad_reduce_block(const ReduceJob& j, int block
         j.dw[ci * j.si + co * j.sj + tap * j.st + j.off] = s[k];
       } else {
         j.db[i - total] += s[k];   // accumulated like the former atomics (the caller zeroes db), single writer, fixed order
+        if (j.db2) j.db2[i - total] += s[k];
       }
     }
   }
@@ -1246,7 +1248,7 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   BPX_CHECK(rc == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   const float* dbpart = p.db ? p.part + (size_t)c.groups * taps * p.Cin * p.Cout : nullptr;   // where the launcher pointed the kernel
-  return finish_wgrad(fn, ReduceJob{p.part, p.dw, c.groups, taps, p.Cin, p.Cout, p.si, p.sj, p.st, p.off, dbpart, p.db, 0}, s);
+  return finish_wgrad(fn, ReduceJob{p.part, p.dw, c.groups, taps, p.Cin, p.Cout, p.si, p.sj, p.st, p.off, dbpart, p.db, 0, p.db ? p.db2 : nullptr}, s);
 }
 
 }  // namespace
@@ -1291,6 +1293,12 @@ extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
 
 extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                                 bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  return bpx_conv3d_wgrad_db2(dtype, N, D, H, W, x, in_norm_d, act, dy, k, dw_d, db_d, nullptr, ws_d, ws_bytes, stream);
+}
+
+extern "C" int bpx_conv3d_wgrad_db2(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                                    bpx_tensor dy, int k, float* dw_d, float* db_d, float* db2_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(db2_d == nullptr || db_d != nullptr, "bpx_conv3d_wgrad_db2: db2_d needs db_d");
   BPX_CHECK(dy.cs == 0, "bpx_conv3d_wgrad: only x may be chunk-planar");
   BPX_CHECK(x.cs == 0 || (x.ld >= 16 && x.cs % 8 == 0 && x.cs >= ((int64_t)N * D * H * W - 1) * x.ld + 16 && x.cs * (x.C / 16) < (1ll << 31)),
             "bpx_conv3d_wgrad: bad chunk stride %lld", (long long)x.cs);
@@ -1309,7 +1317,7 @@ extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   p.dy = dy.ptr; p.dy_ld = dy.ld; p.Cout = dy.C; p.dy_vs = 1;
   int taps = k * k * k;
   p.dw = dw_d; p.si = taps; p.sj = (int64_t)x.C * taps; p.st = 1; p.off = 0;  // (Cout,Cin,k,k,k)
-  p.db = db_d;
+  p.db = db_d; p.db2 = db2_d;
   return run_wgrad(fn, dtype, p, taps, ws_d, ws_bytes, (hipStream_t)stream);
 }
 

@@ -259,12 +259,13 @@ class ResUNetEngine:
             self._ws = torch.empty(max(nbytes, 32 << 20), dtype=torch.uint8, device=dev)
         return self._ws
 
-    def _wgrad(self, B, S, x: "L.Tensor", rec, act, dy: "L.Tensor", k, dw, db, st, dev):
+    def _wgrad(self, B, S, x: "L.Tensor", rec, act, dy: "L.Tensor", k, dw, db, st, dev, db2=None):
+        """db2: a second bias gradient that takes the same sums (the shortcut bias of a residual block)."""
         D, H, W = S
         nb = lib.bpx_conv3d_wgrad_workspace(B, D, H, W, x.C, dy.C, k)
         ws = self._workspace(nb, dev)
-        self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_wgrad(self.bdt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db),
-                                                                    ws.data_ptr(), ws.numel(), s_)))
+        self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_wgrad_db2(self.bdt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db),
+                                                                        L.ptr(db2), ws.data_ptr(), ws.numel(), s_)))
 
     # ------------------------------------------------------------------------------------------
     def _pack_plan(self, train: bool):
@@ -580,19 +581,14 @@ class ResUNetEngine:
         vox = D * H * W
         T = self.gdtype
         # conv2 weight/bias grad, shortcut weight grad
-        self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev)
+        # both biases add to the same tensor: identical gradients, written by the same reduction
+        self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
         if blk.first and self.cfg.in_ch == 1:
             ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
             self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.gdt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
                                                                             ws1.data_ptr(), ws1.numel(), s_)))
         else:
             self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
-        # both biases add to the same tensor: identical gradient.  The bias gradient of conv2 is complete once its partial sums have
-        # been combined - at the flush while the reductions are deferred
-        if self._deferred:
-            self._after_flush.append(lambda: G[k["bsc"]].copy_(G[k["b2"]]))
-        else:
-            self._run_side(dev, lambda s_: G[k["bsc"]].copy_(G[k["b2"]]))
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
         self._keep.append(g1)   # read by the side-stream wgrad of conv1
@@ -695,8 +691,9 @@ class ResUNetEngine:
         vox0 = So[0] * So[1] * So[2]
         dl = dlogits.contiguous().float()
         dfeat = torch.empty((B,) + tuple(So) + (fm[0],), dtype=T, device=dev)
-        hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
-        hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
+        one_head = len(cfg.out_channels) == 1                     # its gradients are written in place (G is zeroed); several heads: split below
+        hwg = G["heads.0.weight"] if one_head else torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
+        hbg = G["heads.0.bias"] if one_head else torch.zeros((n_out,), dtype=torch.float32, device=dev)
         hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
         L.check(lib.bpx_head_bwd(self.bdt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
                                  L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
@@ -711,7 +708,7 @@ class ResUNetEngine:
             L.check(lib.bpx_convT3d_k2s2_dgrad(self.gdt, B, D0, H0, W0, cfg.post_up, L.tview(dup_feat), wt.data_ptr(), L.tview(dfeat), st))
             self._keep.append(dup_feat)
         o = 0
-        for h, oc in enumerate(cfg.out_channels):
+        for h, oc in enumerate(cfg.out_channels if not one_head else ()):
             G[f"heads.{h}.weight"].copy_(hwg[o:o + oc].view(G[f"heads.{h}.weight"].shape))
             G[f"heads.{h}.bias"].copy_(hbg[o:o + oc])
             o += oc

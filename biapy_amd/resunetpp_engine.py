@@ -546,7 +546,10 @@ class ResUNetPPEngine(ResUNetEngine):
         L.check(lib.bpx_head_fwd(self.dt, vox0, B, feat.view(), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(), n_out * vox0, vox0, self._st))
         ctx = None
         if save:
-            ctx = dict(tape=self._tape, late=self._late, G=self._G, feat=feat, hw=hw, B=B, S0=S[0], P=P)
+            # the packed operands and the parameter versions they were made from travel with the context: a later forward() replaces the
+            # engine's own map, and an optimizer step between this forward and its backward would leave the map stale
+            ctx = dict(tape=self._tape, late=self._late, G=self._G, feat=feat, hw=hw, B=B, S0=S[0], P=P, prepacked=self._prepacked,
+                       pack_names=self._pack_names, pack_seen=self._pack_seen, versions={n: t._version for n, t in P.items()})
         self._tape, self._late, self._G = [], [], None
         self._keep = []
         return logits, ctx
@@ -557,6 +560,10 @@ class ResUNetPPEngine(ResUNetEngine):
         self._B, self._dev, self._st, self._P, self._G = B, dlogits.device, L.stream_ptr(), ctx["P"], G
         self._late = ctx["late"]
         self._keep = []
+        stale = [n for n, v in ctx["versions"].items() if ctx["P"][n]._version != v]
+        if stale:
+            raise RuntimeError(f"ResUNet++ backward: {len(stale)} parameters (first: {stale[0]}) were modified in place after the forward pass of this context")
+        self._prepacked, self._pack_names, self._pack_seen = ctx["prepacked"], ctx["pack_names"], ctx["pack_seen"]
         fm = list(cfg.feature_maps)
         n_out = sum(cfg.out_channels)
         D0, H0, W0 = ctx["S0"]

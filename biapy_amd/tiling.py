@@ -106,8 +106,10 @@ def crop_rows_needed(vol_zyx, patch_zyx, overlap, padding, zrow_lo: int, zrow_hi
     sources of the reflect padding at the two ends of the volume (np.pad "reflect", data_3D_manipulation.py:505-515)."""
     Z, pz, Pz = int(vol_zyx[0]), int(padding[0]), int(patch_zyx[0])
     g = axis_grid(Z, Pz, pz, overlap[0], False)
-    a = _start(g, zrow_lo) - pz
-    b = _start(g, zrow_hi - 1) - pz + Pz
+    # the hull over EVERY row: the reference's shift-back of the last rows can make the starts non-monotonic (0, 2, 4, 6, 4, 6, 8)
+    starts = [_start(g, r) for r in range(zrow_lo, zrow_hi)]
+    a = min(starts) - pz
+    b = max(starts) - pz + Pz
     lo, hi = max(a, 0), min(b, Z)
     if reflect and a < 0:
         hi = max(hi, min(Z, -a + 1))

@@ -333,6 +333,8 @@ def _graph_step(inner, model, loss_function, optimizer, x, t):
     if isinstance(probe, dict):
         return None, None
     del probe
+    if not optimizer.state and not isinstance(optimizer, _ZERO_INIT_OPTIMIZERS):
+        return None, None                                              # its fresh state is not all-zero: the warm-up could not be undone
     multi = _world() > 1
     if multi and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
         graphs.broadcast_parameters_from_rank0(inner.parameters())     # a DDP wrap has done this already
@@ -346,21 +348,33 @@ def _graph_step(inner, model, loss_function, optimizer, x, t):
     return gstep, (tuple(x.shape), tuple(t.shape))
 
 
+# optimizers whose freshly created per-parameter state is all zeros (step counters, moments, accumulators): what _restore relies on
+# for state that did not exist before the capture warm-up.  ASGD (eta = lr, mu = 1), Rprop (step_size = lr) and Adagrad
+# (initial_accumulator_value) do not qualify and keep the eager step when they arrive without state.
+_ZERO_INIT_OPTIMIZERS = (torch.optim.Adam, torch.optim.AdamW, torch.optim.NAdam, torch.optim.RAdam, torch.optim.Adamax, torch.optim.Adadelta,
+                         torch.optim.RMSprop, torch.optim.SGD)
+
+
 def _snapshot(model, optimizer):
     params = [p.detach().clone() for p in model.parameters()]
+    buffers = [b.detach().clone() for b in model.buffers()]
     state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in optimizer.state.items()}
-    return params, state
+    return params, buffers, state
 
 
 @torch.no_grad()
 def _restore(model, optimizer, snap) -> None:
-    """Puts parameters and optimizer state back IN PLACE (the captured graphs hold their addresses).  State that did not
-    exist before the warm-up (a fresh optimizer) is zeroed, which is its initial value for Adam(W) / momentum SGD."""
+    """Puts parameters, module buffers and optimizer state back IN PLACE (the captured graphs hold their addresses).  State that did
+    not exist before the warm-up (a fresh optimizer) is zeroed - its initial value for the classes of ``_ZERO_INIT_OPTIMIZERS``,
+    the only ones ``_graph_step`` lets through without state.  The loss function must be pure: a loss that keeps running state
+    (moving averages, counters) has seen the warm-up batches and is not rolled back."""
     from .engine import bump_weights_epoch
 
-    params, state = snap
+    params, buffers, state = snap
     for p, s in zip(model.parameters(), params):
         p.copy_(s)
+    for b, s in zip(model.buffers(), buffers):
+        b.copy_(s)
     for p, st in optimizer.state.items():
         old = state.get(id(p))
         for k, v in st.items():

@@ -193,6 +193,11 @@ int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tensor dy, const
 int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout, int k);
 int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                      bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
+/* The same with a second bias-gradient destination: db2_d[co] += the same column sums (needs db_d).  A residual block adds the biases of its
+ * second convolution and of its 1x1x1 shortcut to the same tensor (biapy/models/blocks.py:1456-1459), so the two bias gradients are equal:
+ * the reduction writes both instead of the caller copying one onto the other after the flush. */
+int bpx_conv3d_wgrad_db2(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
+                         bpx_tensor dy, int k, float* dw_d, float* db_d, float* db2_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* Deferred reduction of the weight-gradient partials.  Between bpx_wgrad_defer_begin() and bpx_wgrad_defer_flush() (same
  * host thread) bpx_conv3d_wgrad and the bf16 bpx_convT3d_k2s2_wgrad write only their partial slabs and queue the reduction;
