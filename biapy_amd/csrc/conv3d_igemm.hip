@@ -535,7 +535,8 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
     BPX_CHECK(pooled.C == y.C, "%s: pooled.C %d != y.C %d", fn, pooled.C, y.C);
     p.pool = pooled.ptr; p.pool_ld = pooled.ld; p.pool_sz = pool_sz; p.pool_part = pool_stats_part_d;
   }
-  int rc = (use_lean(dtype, p) && c.tx == 16) ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_FWD, p, c, (hipStream_t)stream)
+  const bool lean_ok = use_lean(dtype, p) && c.tx == 16;
+  int rc = lean_ok ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_FWD, p, c, (hipStream_t)stream)
                                                                          : launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream))
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream)
            : (dtype == BPX_F16)  ? launch_conv3<f16_t, EPI_FWD>(p, c, (hipStream_t)stream)
@@ -618,8 +619,14 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   if (t_norm_d && check_planar(fn, "t", t, N, D, H, W)) return 1;
   p.x_cs = 16; p.sc_cs = 16; p.y_cs = 16; p.t_cs = chunk_stride(t);
   p.t_f16 = (mix && t_norm_d) ? 1 : 0;
+  {   // buffer addressing of the LDS-DMA: every byte of t the kernel touches within 2 GB of t.ptr
+    const int64_t vox = (int64_t)N * D * H * W;
+    const int64_t tbytes = 2 * (t.cs ? (int64_t)t.cs * (g.C / 16 - 1) + (vox - 1) * t.ld + 16 : vox * (int64_t)t.ld);
+    p.t_dma = (t_norm_d && tbytes < (1ll << 31)) ? 1 : 0;
+  }
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
-  int rc = (use_lean(dtype, p) && c.tx == 16) ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_DGRAD, p, c, (hipStream_t)stream)
+  const bool lean_ok = use_lean(dtype, p) && c.tx == 16 && !(c.ns >= 2 && t_norm_d && !p.t_dma);
+  int rc = lean_ok ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_DGRAD, p, c, (hipStream_t)stream)
                                                                          : launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream))
            : p.t_f16             ? launch_conv3<uint16_t, EPI_DGRAD, f16_t>(p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream)

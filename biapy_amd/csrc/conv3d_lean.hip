@@ -69,7 +69,16 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
   constexpr int RS = (TX == 16) ? 1 : 2;                          // tile rows covered by one 16-voxel m-subtile
   constexpr int HSTR = RS * HX * VB;                              // LDS stride between m-subtiles of the halo image
   constexpr int WD = (NS == 1 || (NS == 2 && EPI == EPI_FWD)) ? 2 : 1;                           // weight prefetch distance (steps)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[BUFB + RED_BYTES];
+  // TDMA (dgrad with two or more 16-channel output groups): the t operand of the epilogue (ELU' and the normalised value need the conv's raw
+  // input at every output voxel) used to be loaded group by group AFTER the MFMA steps - three exposed memory latencies for the 48-channel
+  // gradients of the concat buffers, 20 of the tile's 30 K cycles (scripts/dgrad_stamps.py).  Each wave now requests the rows of its own
+  // z-slice with `buffer_load ... lds` at the top of the tile - no VGPRs (the kernel sits at 160 of 168), no barrier (a wave reads only what
+  // it requested) - and the epilogue reads them from LDS.
+  constexpr bool TDMA = EPI == EPI_DGRAD && NS >= 2 && TX == 16;
+  constexpr int TPW = TY * TX / 32;                               // 1 KB pieces (32 voxels x 16 channels) per wave and channel group
+  constexpr int TDMA_T = TDMA ? 4 * NS * TPW * 1024 : 0;           // [wave][group][piece] t rows
+  constexpr int TDMA_BYTES = TDMA ? TDMA_T + 4 * 1024 : 0;         // + [wave][64] {mean, rstd, scale, shift} records of this block's channels (a copy per wave: no barrier)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BUFB + RED_BYTES + TDMA_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -120,6 +129,25 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     const int n = tileId / p.tilesPerSample, tile = tileId - n * p.tilesPerSample;
     const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
     const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+
+    if (TDMA && p.t_norm != nullptr) {
+      typedef __attribute__((address_space(3))) void* lds_ptr_t;
+      const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t), 0, (int)0x80000000u, 0x00020000);
+      const int l2 = lane >> 1;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          const int ty = q * 2 + (l2 >> 4), tx = l2 & 15;
+          const bool ok = z0 + wave < D && y0 + ty < H && x0 + tx < W;
+          const uint32_t off = ok ? (uint32_t)((((n * D + z0 + wave) * H + y0 + ty) * W + x0 + tx) * p.t_ld) * 2u + (uint32_t)((co_base >> 4) + ns) * t_csb + (uint32_t)(lane & 1) * 16u
+                                  : 0x80000000u;   // out of range: the DMA writes zeros (those voxels are masked in the epilogue anyway)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(smem + BUFB + RED_BYTES + ((wave * NS + ns) * TPW + q) * 1024), 16, off, 0, 0, 0);
+        }
+      const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bpx_norm_rec*>(p.t_norm), 0, (int)0x80000000u, 0x00020000);
+      const uint32_t roff = lane < NS * 16 ? (uint32_t)((n * Cout + co_base + lane) * 16) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_ptr_t)(smem + BUFB + RED_BYTES + TDMA_T + wave * 1024), 16, roff, 0, 0, 0);
+    }
 
     // ---- global offsets (elements) of this thread's halo pieces: tile base + per-lane constant --------------------
     const uint32_t base_b = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.x_ld * 2u;
@@ -364,12 +392,18 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
       const uint32_t trow = (uint32_t)(RS * W * p.t_ld) * 2u, tb = (uint32_t)(vox0 * p.t_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * t_csb;
       // operands of channel group ns+1 are requested before group ns is computed (register double buffer over ns)
       u32x2_t tv[NS > 1 ? 2 : 1][MS];
+      if (TDMA && has_t) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's t rows are in LDS (long since: the halo loads were requested after them)
+      const unsigned char* tl = smem + BUFB + RED_BYTES + wave * NS * TPW * 1024 + j * 32 + g * 8;
       auto fetch = [&](int ns, int b) {
         if (!has_t) return;
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
-          tv[b][ms] = u32x2_t{0u, 0u};
-          if (okzx && RS * ms < yrem) tv[b][ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * t_csb));
+          if constexpr (TDMA) {
+            tv[b][ms] = *reinterpret_cast<const u32x2_t*>(tl + ns * TPW * 1024 + ms * 512);
+          } else {
+            tv[b][ms] = u32x2_t{0u, 0u};
+            if (okzx && RS * ms < yrem) tv[b][ms] = *reinterpret_cast<const u32x2_t*>(tin + (tb + ms * trow + ns * t_csb));
+          }
         }
       };
       fetch(0, 0);
@@ -388,8 +422,9 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
           {
 #pragma unroll
             for (int rp = 0; rp < 4; rp += 2) {
-              const f32x4_t ra = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + rp]);
-              const f32x4_t rb = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + rp + 1]);
+              const f32x4_t* rsrc = TDMA ? reinterpret_cast<const f32x4_t*>(smem + BUFB + RED_BYTES + TDMA_T + wave * 1024) + (ns * 16 + g * 4 + rp)
+                                         : reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + rp]);
+              const f32x4_t ra = rsrc[0], rb = rsrc[1];
               const f32x2_t sc2{ra[2], rb[2]}, sh2{ra[3], rb[3]}, rs2{ra[1], rb[1]}, nm2{-ra[0] * ra[1], -rb[0] * rb[1]};
               f32x2_t s1p{0.f, 0.f}, s2p{0.f, 0.f};
 #pragma unroll
@@ -413,7 +448,8 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
           // channel by channel (one {mean, rstd, scale, shift} record live at a time), gradients replace acc in place
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const f32x4_t rec = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + r]);
+            const f32x4_t rec = TDMA ? reinterpret_cast<const f32x4_t*>(smem + BUFB + RED_BYTES + TDMA_T + wave * 1024)[ns * 16 + g * 4 + r]
+                                     : *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Cout + co_base + ns * 16 + g * 4 + r]);
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
               const uint32_t w = tv[b][ms][r >> 1];

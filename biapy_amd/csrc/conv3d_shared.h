@@ -30,6 +30,8 @@ struct Conv3Params {
   int x_cs, sc_cs, y_cs, t_cs;
   int f16;   // 16-bit storage is fp16 instead of bf16 (forward only)
   int t_f16; // dgrad, BPX_MIX16: the activation operand `t` is fp16 while dy / weights / g are bf16
+  int t_dma; // dgrad: t lies within 2 GB of its base, i.e. the lean kernel's >= 32-channel instances can fetch their t tile with `buffer_load ... lds`
+             // (they have no other path: the launcher keeps tensors beyond that on the plain kernel)
   int ps;    // forward, lean kernel only: 3-D pixel shuffle by `ps` fused into the store (bpx_conv3d_fwd_shuffle).  Cout = 16 * ps^3 ordered
              // [sub-position (a, b, e)][16 channels]; y is the (N, ps*D, ps*H, ps*W, 16) tensor, block (a, b, e) of voxel (z, y, x) goes to
              // voxel (ps*z + a, ps*y + b, ps*x + e): the ps^3-fold channel tensor never exists in memory

@@ -154,6 +154,14 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const int mb = (blockIdx.x / nbk) % p.mblocks;
   const int n = blockIdx.x / (nbk * p.mblocks);
   const int col_base = nb * 16 * NS;
+  // PERM (transposed conv into a chunk-planar buffer, 64 columns per block, Cout % 32 == 0): the block is the x pair of sub-positions
+  // (2 sp, 2 sp + 1) of the 32 channels [32 pp, 32 pp + 32), and lane row g owns 8 channels of EACH of the two 16-channel planes at
+  // sub-position 2 sp + (g >> 1): channels 32 pp + (ns >> 1) * 16 + (g & 1) * 8 + (ns & 1) * 4 + r.  One store instruction then writes, per
+  // input voxel, 64 contiguous bytes of one plane (lanes g = 0..3: two voxels x 32 bytes) and 1 KB per 16-voxel lane row - full 64-byte
+  // requests - where the plain binding (lane row g = 16 consecutive channels) leaves every request half empty until the second store.
+  constexpr bool PERM = MODE == PW_CONVT && PL && NS == 4;
+  const int ppb = PERM ? p.Csub / 32 : 1;
+  const int sp = nb / ppb, pp = nb - sp * ppb;
 
   // voxel of lane (j) for each m-subtile
   // voxels per sample < 2^31 (checked on the host): 32-bit index math - the 64-bit div/mod sequences of the transposed-conv
@@ -195,7 +203,12 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     u32x4_t wf[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
-      wf[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)(4 * s + g) * p.Ncols + col_base + (j >> 2) * (4 * NS) + ns * 4 + (j & 3)) * KPL);
+    {
+      const int gq = j >> 2;
+      const int colw = PERM ? (2 * sp + (gq >> 1)) * p.Csub + pp * 32 + (ns >> 1) * 16 + (gq & 1) * 8 + (ns & 1) * 4 + (j & 3)
+                            : col_base + gq * (4 * NS) + ns * 4 + (j & 3);
+      wf[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)(4 * s + g) * p.Ncols + colw) * KPL);
+    }
     size_t koff;
     if (MODE == PW_CONVTD) {
       int sub = kin ? k / p.Csub : 0, c = kin ? k % p.Csub : 0;
@@ -228,13 +241,15 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const int col0 = col_base + g * 4 * NS;        // first of this lane's columns
   int sub = 0, co0 = col0;
   if (MODE == PW_CONVT) { sub = col0 / p.Csub; co0 = col0 % p.Csub; }
+  if (PERM) { sub = 2 * sp + (g >> 1); co0 = pp * 32 + (g & 1) * 8; }
+  auto cof = [&](int ns) { return PERM ? co0 + (ns >> 1) * 16 + (ns & 1) * 4 : co0 + ns * 4; };   // first channel of column quad ns
   float add[NS][4];
   bpx_nbwd_coef cf[NS][4];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      add[ns][r] = p.bias ? p.bias[co0 + ns * 4 + r] : 0.f;
+      add[ns][r] = p.bias ? p.bias[cof(ns) + r] : 0.f;
       if (MODE == PW_CONV1 && p.coef) cf[ns][r] = p.coef[(size_t)n * p.Ncols + co0 + ns * 4 + r];
     }
 #pragma unroll
@@ -288,6 +303,10 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       }
     } else if (!PL) {
       storeq<T, NS>(yout + ovox * (size_t)p.y_ld + co0, val);
+    } else if (PERM) {   // two 16-byte pieces, one per plane
+      T* vb = yout + ovox * (size_t)p.y_ld;
+      storeq<T, 2>(vb + (size_t)(co0 >> 4) * p.y_cs + (co0 & 15), val);
+      storeq<T, 2>(vb + (size_t)((co0 >> 4) + 1) * p.y_cs + (co0 & 15), val + (NS > 2 ? 2 : 0));
     } else {     // chunk-planar y (the transposed conv writes its planes of the concat buffer)
       storeq_planar<T, NS>(yout + ovox * (size_t)p.y_ld, co0, p.y_cs, val);
     }
@@ -311,6 +330,11 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
                 red[(3 * NS * 16 + c) * 2 + k];
       int col = col_base + c, sub = col / p.Csub, co = col % p.Csub;
+      if (PERM) {   // slot c = g * 16 + ns * 4 + r of the permuted binding
+        const int gg = c >> 4, ns = (c >> 2) & 3;
+        sub = 2 * sp + (gg >> 1);
+        co = pp * 32 + (ns >> 1) * 16 + (gg & 1) * 8 + (ns & 1) * 4 + (c & 3);
+      }
       p.part[((((size_t)n * p.mblocks + mb) * (4 * p.sz) + sub) * 2 + k) * p.Csub + co] = a;
     }
   }
@@ -333,6 +357,7 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   int nbk = p.Ncols / (16 * ns);
   dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
   const bool planar = (MODE == PW_CONV1 && p.coef != nullptr && p.t_cs != 16) || (MODE == PW_CONVT && p.y_cs != 16);
+  if (MODE == PW_CONVT && planar && ns == 4 && p.Csub % 32 != 0) { bpx_set_error("transposed conv: the 64-column planar form needs Cout % 32 == 0"); return 1; }
   if (MODE != PW_CONVTD && planar) {
     constexpr bool PL = MODE != PW_CONVTD;    // no planar instances of the transposed-conv dgrad
     if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
@@ -429,7 +454,7 @@ extern "C" int bpx_convT3d_k2s2_fwd(int dtype, int N, int D, int H, int W, int s
   // instruction instead of two half-written lines from different workgroups (32 -> 32 channels, 64^3 -> 128^3, B = 4: 308 -> 256 us;
   // into a 32-of-48-channel slice of an interleaved buffer the wide form is slower, 362 -> 415 us, and is not used)
   static const bool wide = getenv("BPX_CONVT_NS") == nullptr;
-  int ns = (wide && (y.cs != 0 || y.ld == y.C) && (4 * sz * y.C) % 64 == 0) ? 4 : pw_ns(y.C);
+  int ns = (wide && (y.cs != 0 ? y.C % 32 == 0 : y.ld == y.C) && (4 * sz * y.C) % 64 == 0) ? 4 : pw_ns(y.C);
   if ((dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONVT>(p, ns, (hipStream_t)stream)
        : dtype == BPX_F16 ? launch_pw<f16_t, PW_CONVT>(p, ns, (hipStream_t)stream)
                           : launch_pw<float, PW_CONVT>(p, ns, (hipStream_t)stream)) != 0) return 1;
