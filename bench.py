@@ -37,7 +37,7 @@ MFMA_PEAK_BF16 = 2.5e15           # dense bf16 peak, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 # `dtype` of the JSON line: the arithmetic types of the timed path (accumulation is fp32 everywhere)
 DTYPE_NAMES = {"mix16": "f16 forward/activations + bf16 gradients (MFMA f16 / bf16, fp32 accumulate)", "bf16": "bf16", "f32": "f32"}
-CONV_ENTRIES = ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad", "bpx_wgrad_defer_flush")
+CONV_ENTRIES = ("bpx_conv3d_fwd", "bpx_conv3d_dgrad", "bpx_conv3d_wgrad", "bpx_conv3d_wgrad_db2", "bpx_wgrad_defer_flush")
 
 
 def synth_batch(B, P, device, seed):
@@ -318,6 +318,8 @@ def conv_roofline(prof, prof_steps, dtype, timed_on):
     fam, shapes = {}, []
     flush_ms = 0.0
     for (name, key), (cnt, ms) in summ.items():
+        if name == "bpx_conv3d_wgrad_db2":       # the same entry with a second bias-gradient destination (same key layout)
+            name = "bpx_conv3d_wgrad"
         if name == "bpx_wgrad_defer_flush":      # the batched reduction of the step's partial slabs is part of the wgrad calls' time
             flush_ms += ms
             continue

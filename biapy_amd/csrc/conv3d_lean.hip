@@ -311,13 +311,24 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms)
         img[ms] = (rank1 && okzx && RS * ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * RS * W) * 4u) : 0.f;
+      f32x4_t addv[NS], w1v[NS];
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         const int co = co_base + ns * 16 + g * 4;
-        f32x4_t add = f32x4_t{0.f, 0.f, 0.f, 0.f}, w1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) add += *reinterpret_cast<const f32x4_t*>(p.bias + co);
-        if (p.sc && p.bias_sc) add += *reinterpret_cast<const f32x4_t*>(p.bias_sc + co);
-        if (rank1) w1 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.wsc) + co);
+        addv[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f}; w1v[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) addv[ns] += *reinterpret_cast<const f32x4_t*>(p.bias + co);
+        if (p.sc && p.bias_sc) addv[ns] += *reinterpret_cast<const f32x4_t*>(p.bias_sc + co);
+        if (rank1) w1v[ns] = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.wsc) + co);
+      }
+      // Every operand of the epilogue has arrived HERE, outside the predicated per-row blocks below.  Without this the compiler waits for
+      // them with `s_waitcnt vmcnt(0)` inside each block (a wait in a predicated region does not count at the join), and on gfx9 that
+      // counter also holds the STORES: every row's store then waited for the previous row's write acknowledgement - 8.5 K of the
+      // 58 K cycles of a 48 -> 16 tile (scripts/conv_stamps.py), 14 such waits in the 16-channel kernel's epilogue.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int co = co_base + ns * 16 + g * 4;
+        const f32x4_t add = addv[ns], w1 = w1v[ns];
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         u32x2_t pk[MS];
 #pragma unroll
@@ -407,6 +418,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         }
       };
       fetch(0, 0);
+      if (!TDMA && NS == 1) __builtin_amdgcn_s_waitcnt(0x0F70);   // as in the forward epilogue: no load is pending inside the predicated store blocks
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         const int b = (NS > 1) ? (ns & 1) : 0;
