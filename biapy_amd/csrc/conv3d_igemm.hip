@@ -340,46 +340,75 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
 
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  // Every operand of the epilogue is requested first, unconditionally (out-of-volume lanes read the tile's first voxel) and awaited ONCE:
+  // with the loads inside the predicated per-voxel blocks the compiler put an `s_waitcnt vmcnt(0)` into each block, and that counter also holds
+  // the stores - the epilogue was a chain of MS x NS [load, wait for it AND the previous store's acknowledgement, store] rounds.
+  using TRaw = typename std::conditional<sizeof(TT) == 2, u32x2_t, f32x4_t>::type;
+  const bool rank1 = EPI == EPI_FWD && p.sc != nullptr && p.sc_C == 1;
+  const bool has_t = EPI != EPI_FWD && p.t_norm != nullptr;
+  const size_t vox00 = (((size_t)n * p.D + z0) * p.H + y0) * p.W + x0;
+  bool okv[MS];
+  size_t voxv[MS];
+  float imgv[MS];
+  TRaw traw[MS][NS];
+  float addv[NS][4], w1v[NS][4];
+  bpx_norm_rec recv[(EPI == EPI_FWD) ? 1 : NS][4];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    const int t = (wave * MS + ms) * 16 + j;
+    const int z = z0 + t / (TY * TX), y = y0 + (t / TX) % TY, x = x0 + t % TX;
+    okv[ms] = z < p.D && y < p.H && x < p.W;
+    voxv[ms] = okv[ms] ? (((size_t)n * p.D + z) * p.H + y) * p.W + x : vox00;
+    imgv[ms] = rank1 ? reinterpret_cast<const float*>(p.sc)[voxv[ms]] : 0.f;
+    if (has_t) {
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int co = co_base + ns * 16 + g * 4;
+        traw[ms][ns] = *reinterpret_cast<const TRaw*>(reinterpret_cast<const TT*>(p.t) + voxv[ms] * (size_t)p.t_ld + (size_t)(co >> 4) * p.t_cs + (co & 15));
+      }
+    }
+  }
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const int co = co_base + ns * 16 + g * 4;
-    float add[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f};
-    bpx_norm_rec rec[4];
-    if (EPI == EPI_FWD) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (p.bias) add[r] += p.bias[co + r];
-        if (p.sc && p.bias_sc) add[r] += p.bias_sc[co + r];
-        if (p.sc && p.sc_C == 1) w1[r] = reinterpret_cast<const float*>(p.wsc)[co + r];
+    for (int r = 0; r < 4; ++r) {
+      addv[ns][r] = 0.f; w1v[ns][r] = 0.f;
+      if (EPI == EPI_FWD) {
+        if (p.bias) addv[ns][r] += p.bias[co + r];
+        if (p.sc && p.bias_sc) addv[ns][r] += p.bias_sc[co + r];
+        if (rank1) w1v[ns][r] = reinterpret_cast<const float*>(p.wsc)[co + r];
+      } else if (has_t) {
+        recv[ns][r] = p.t_norm[(size_t)n * Cout + co + r];
       }
-    } else if (p.t_norm) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rec[r] = p.t_norm[(size_t)n * Cout + co + r];
     }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), once
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int co = co_base + ns * 16 + g * 4;
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
-      int t = (wave * MS + ms) * 16 + j;
-      int z = z0 + t / (TY * TX), y = y0 + (t / TX) % TY, x = x0 + t % TX;
-      if (z < p.D && y < p.H && x < p.W) {
-        size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
+      if (okv[ms]) {
         float v[4];
         if (EPI == EPI_FWD) {
-          float img = (p.sc && p.sc_C == 1) ? reinterpret_cast<const float*>(p.sc)[vox] : 0.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = acc[ms][ns][r] + add[r] + img * w1[r];
+            v[r] = acc[ms][ns][r] + addv[ns][r] + imgv[ms] * w1v[ns][r];
             s1[ns][r] += v[r];
             s2[ns][r] += v[r] * v[r];
           }
         } else {
-          if (p.t_norm) {
-            const TT* tp = reinterpret_cast<const TT*>(p.t) + vox * (size_t)p.t_ld + (size_t)(co >> 4) * p.t_cs + (co & 15);
+          if (has_t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float tv = ElemTraits<TT>::ld(tp + r);
-              float u = fmaf(rec[r].scale, tv, rec[r].shift);
+              float tv;
+              if constexpr (sizeof(TT) == 2) tv = (r & 1) ? hi16<TT>(traw[ms][ns][r >> 1]) : lo16<TT>(traw[ms][ns][r >> 1]);
+              else tv = traw[ms][ns][r];
+              const bpx_norm_rec& rc = recv[(EPI == EPI_FWD) ? 0 : ns][r];
+              float u = fmaf(rc.scale, tv, rc.shift);
               v[r] = acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act);
-              float xh = (tv - rec[r].mean) * rec[r].rstd;
+              float xh = (tv - rc.mean) * rc.rstd;
               s1[ns][r] += v[r];
               s2[ns][r] += v[r] * xh;
             }
@@ -388,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
             for (int r = 0; r < 4; ++r) v[r] = acc[ms][ns][r];
           }
         }
-        T* yp = yout + vox * (size_t)p.y_ld + (size_t)(co >> 4) * p.y_cs + (co & 15);
+        T* yp = yout + voxv[ms] * (size_t)p.y_ld + (size_t)(co >> 4) * p.y_cs + (co & 15);
         if (p.dbg & 8) continue;
         if constexpr (std::is_same<T, float>::value) {
           *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v[0], v[1], v[2], v[3]};
