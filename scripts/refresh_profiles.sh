@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates every file of profiles/ in ONE run on one GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r03'
 # Outputs land in gpurun_out/profiles_new/ (merged back by gpurun); copy them into profiles/ afterwards.
 # PMC counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa trace domains).
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/profiles_new
 mkdir -p $O
 export TMPDIR=/tmp
@@ -12,6 +12,19 @@ ROOT=$(pwd)
 python bench.py > $O/${R}_bench.json 2> $O/bench.err
 python bench.py --force-ddp --mode train --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
 python bench.py --mode sliding --vol 1024 --steps 1 --warmup 1 --no-cpu-baseline > $O/${R}_bench_sliding_1024.json 2> $O/bench_sliding.err
+# the single-GPU checksums of the blended cfg-3 volumes (initial weights of seed 0): what `bench.py --gpus N` compares its gathered volume with
+python - "$O" "$R" <<'PY' > $O/sliding_checksums.json
+import json, sys
+O, R = sys.argv[1:3]
+out = {}
+for vol, path, pick in ((512, f"{O}/{R}_bench.json", lambda d: d.get("sliding")), (1024, f"{O}/{R}_bench_sliding_1024.json", lambda d: d.get("sliding") or d)):
+    try:
+        rec = pick(json.loads(open(path).read().strip().splitlines()[-1]))
+        out[str(vol)] = dict(checksum=rec["checksum"], dtype=rec.get("dtype"), patches=rec.get("config", {}).get("patches"), source=path.split("/")[-1])
+    except Exception as e:  # noqa: BLE001
+        print(f"sliding_checksums: {vol}: {e}", file=sys.stderr)
+print(json.dumps(out, indent=1))
+PY
 BPX_BENCH_ONE_DEVICE=1 BPX_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29577 \
    bench.py --gpus 2 --steps 5 --warmup 2 --vol 512 > $O/${R}_bench_2ranks_one_gpu_gloo.json 2> $O/bench_2rank.err
 python bench.py --arch resunetpp --batch 4 --steps 5 --warmup 2 > $O/${R}_bench_resunetpp_80.json 2> $O/bench_pp.err
@@ -19,6 +32,7 @@ python bench.py --arch resunetpp --batch 4 --breakdown --graph off > $O/${R}_bre
 python bench.py --breakdown --graph off --mode train > $O/${R}_breakdown_train_events.txt 2> /dev/null
 python bench.py --breakdown --graph off --mode infer > $O/${R}_breakdown_infer_events.txt 2> /dev/null
 python tests/bench_kernels.py merge > $O/${R}_merge_crop.txt 2>&1
+( python scripts/dgrad_stamps.py 128 48 16; python scripts/dgrad_stamps.py 128 16 16; python scripts/dgrad_stamps.py 64 96 32; python scripts/conv_stamps.py 0; python scripts/hbm_rw_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_fwd_dgrad.txt
 python tests/bench_kernels.py rcan 2>&1 | grep -v "Warning\|run_backward" > $O/${R}_rcan_trunk_64.txt
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o train -- python $ROOT/bench.py --mode train --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_train.log 2>&1
