@@ -16,11 +16,18 @@ import sys
 from collections import defaultdict
 
 # kernel name -> C-ABI entry point.  conv3_kernel<T,TZ,TY,TX,NS,EPI,ACTK> and conv3_lp_kernel<TZ,TY,TX,NS,EPI,ACTK>: EPI 0 = fwd, 1 = dgrad
+def _conv_rx(epi):
+    """conv3_lp_kernel<TZ, TY, TX, NS, EPI, ACTK, F16, TF16> and conv3_kernel<T, TZ, TY, TX, NS, EPI, ACTK, TT>, demangled or - rocprofv3 leaves the
+    names with _Float16 arguments mangled - as conv3_kernelIDF16_Li4ELi4ELi8ELi4ELi<EPI>E... / conv3_lp_kernelILi4E...Li<EPI>E..."""
+    e = str(epi)
+    return re.compile(r"conv3_lp_kernel<\d+, \d+, \d+, \d+, " + e + r",|conv3_kernel<[^,>]+, \d+, \d+, \d+, \d+, " + e + r","
+                      r"|conv3_lp_kernelI(?:Li\d+E){4}Li" + e + r"E|conv3_kernelI(?:DF16_|t|f)(?:Li\d+E){4}Li" + e + r"E|conv3_dma_kernel<\d+, \d+, \d+, \d+, " + e + r",")
+
+
 GROUPS = [
-    # the lean kernel carries a trailing bool (fp16 storage) since round 2: <TZ, TY, TX, NS, EPI, ACTK, F16>
-    ("bpx_conv3d_fwd", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 0, \d+(, (true|false))?>")),
-    ("bpx_conv3d_dgrad", re.compile(r"conv3(_lp)?_kernel<[^>]*?, 1, \d+(, (true|false))?>")),
-    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel<|wgrad_reduce(_batch)?_kernel")),
+    ("bpx_conv3d_fwd", _conv_rx(0)),
+    ("bpx_conv3d_dgrad", _conv_rx(1)),
+    ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel(<|I)|wgrad_reduce(_batch)?_kernel")),
     # the sliding-window blend / gather (tests/bench_kernels.py merge: 512 x 128^3 <-> 512^3; 16 B/lane row kernels, same doubling)
     ("bpx_merge3d_blend", re.compile(r"merge3d_row_kernel<")),
     ("bpx_crop3d_gather", re.compile(r"crop3d_row_kernel<")),

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 ( time python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/${R}_gpu_tests.txt 2>&1
 python bench.py > $O/${R}_bench.json 2> $O/bench.err
-python bench.py --force-ddp --mode train --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
+python bench.py --force-ddp --self-check --mode train --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
 python bench.py --mode sliding --vol 1024 --steps 1 --warmup 1 --no-cpu-baseline > $O/${R}_bench_sliding_1024.json 2> $O/bench_sliding.err
 # the single-GPU checksums of the blended cfg-3 volumes (initial weights of seed 0): what `bench.py --gpus N` compares its gathered volume with
 python - "$O" "$R" <<'PY' > $O/sliding_checksums.json
