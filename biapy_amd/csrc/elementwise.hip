@@ -184,23 +184,36 @@ __global__ void __launch_bounds__(256) tensor_stats_vec_kernel(const T* __restri
 //   dgamma[c] += sum_n S2[n][c], dbeta[c] += sum_n S1[n][c]
 // One block per channel block walks the samples in order, so the two parameter gradients are sums in a FIXED order written by a
 // single thread: deterministic, no atomics.
+// Round 3: NB samples at a time - thread = (sample slot, tile lane, channel) - instead of one sample after the other: the four samples of a
+// cfg-2 batch were four dependent rounds of tile_sums + two block reductions (10.5 us average over the step's 17 launches).  The
+// per-sample totals still enter dgamma / dbeta in sample order.
 __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __restrict__ red_part, int N, int tiles, int tstride, int C,
                                                                 double inv_count, const bpx_norm_rec* __restrict__ rec,
                                                                 const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int cpg, int cb, bpx_nbwd_coef* __restrict__ coef) {
+                                                                float* __restrict__ dbeta, int cpg, int cb, int NB, bpx_nbwd_coef* __restrict__ coef) {
   __shared__ double red[2][1024];
-  const int lanes = 1024 / cb;
+  __shared__ double tot[2][16][64];                       // [S1 | S2][sample slot][channel of the block]
+  const int lanes = 1024 / (cb * NB);
   const int c0 = blockIdx.x * cb;
-  const int c = threadIdx.x % cb, tl = threadIdx.x / cb;
+  const int c = threadIdx.x % cb, tl = (threadIdx.x / cb) % lanes, ns = threadIdx.x / (cb * lanes);
   double dg = 0.0, db = 0.0;
-  for (int n = 0; n < N; ++n) {
+  for (int n0 = 0; n0 < N; n0 += NB) {
+    const int n = n0 + ns;
     double s1 = 0.0, s2 = 0.0;
-    if (c0 + c < C)
+    if (c0 + c < C && n < N)
       tile_sums(red_part + (size_t)n * tiles * 2 * C + c0 + c, C, (tiles + tstride - 1) / tstride, (size_t)tstride * 2 * C, tl, lanes, s1, s2);
-    lane_reduce(red, cb, lanes, s1, s2);
-    if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
-      const int lc = threadIdx.x, cc = c0 + lc;
-      const double S1 = red[0][lc], S2 = red[1][lc];
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (tl < 2) {                                         // two threads per (slot, channel): one total each, lanes in a fixed order
+      double a = 0.0;
+      for (int q = 0; q < lanes; ++q) a += red[tl][(ns * lanes + q) * cb + c];
+      tot[tl][ns][c] = a;
+    }
+    __syncthreads();
+    if (tl == 0 && c0 + c < C && n < N) {
+      const int cc = c0 + c;
+      const double S1 = tot[0][ns][c], S2 = tot[1][ns][c];
       const bpx_norm_rec r = rec[(size_t)n * C + cc];
       const double ga = gamma ? (double)gamma[cc] : 1.0;
       double m1, m2;
@@ -208,12 +221,12 @@ __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __
         m1 = ga * S1 * inv_count;
         m2 = ga * S2 * inv_count;
       } else {
-        const int gb = (lc / cpg) * cpg;
+        const int gb = (c / cpg) * cpg;
         double a1 = 0.0, a2 = 0.0;
         for (int q = 0; q < cpg; ++q) {
           const double gq = gamma ? (double)gamma[c0 + gb + q] : 1.0;
-          a1 += gq * red[0][gb + q];
-          a2 += gq * red[1][gb + q];
+          a1 += gq * tot[0][ns][gb + q];
+          a2 += gq * tot[1][ns][gb + q];
         }
         m1 = a1 * inv_count / cpg;
         m2 = a2 * inv_count / cpg;
@@ -225,13 +238,17 @@ __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __
       k.c0 = (float)(-rs * m1 + rs * rs * (double)r.mean * m2);
       k.pad = 0.f;
       coef[(size_t)n * C + cc] = k;
-      dg += (double)(float)S2;                          // the per-sample terms enter as floats, as they did with the former atomics
-      db += (double)(float)S1;
     }
-    __syncthreads();                                    // red is rewritten by the next sample
+    if (ns == 0 && tl == 0 && c0 + c < C) {               // dgamma / dbeta: the samples of this pass in index order
+      for (int q = 0; q < NB && n0 + q < N; ++q) {
+        dg += (double)(float)tot[1][q][c];                // the per-sample terms enter as floats, as they did with the former atomics
+        db += (double)(float)tot[0][q][c];
+      }
+    }
+    __syncthreads();                                      // red / tot are rewritten by the next pass
   }
-  if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
-    const int cc = c0 + threadIdx.x;
+  if (ns == 0 && tl == 0 && c0 + c < C) {
+    const int cc = c0 + c;
     if (dgamma) dgamma[cc] += (float)dg;
     if (dbeta) dbeta[cc] += (float)db;
   }
@@ -1308,8 +1325,10 @@ extern "C" int bpx_norm_bwd_finalize(float* red_part_d, int N, int tiles, int C,
   BPX_CHECK(cpg == 1 || 16 % cpg == 0 || cpg == 32 || cpg == 64, "%s: channels per group %d unsupported (1, 2, 4, 8, 16, 32, 64)", fn, cpg);
   const int cb = cpg > 16 ? cpg : 16;
   const int tstride = compact_stats(red_part_d, N, tiles, C, (hipStream_t)stream);     // consumes the partials
+  int NB = 1;                                                                          // samples per pass: keep >= 8 tile lanes per sample
+  while (NB * 2 <= N && NB * 2 <= 16 && 1024 / (cb * NB * 2) >= 8) NB *= 2;
   norm_bwd_finalize_kernel<<<(unsigned)cdiv(C, cb), 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, tstride, C, 1.0 / (double)count_per_channel,
-                                                                                   rec_d, gamma_d, dgamma_d, dbeta_d, cpg, cb, coef_d);
+                                                                                   rec_d, gamma_d, dgamma_d, dbeta_d, cpg, cb, NB, coef_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

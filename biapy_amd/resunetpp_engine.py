@@ -76,6 +76,7 @@ class _V:
     def __init__(self, buf: torch.Tensor, S: Tuple[int, int, int]):
         self.buf, self.S, self.C = buf, tuple(S), buf.shape[-1]
         self.grad: Optional[torch.Tensor] = None
+        self.grad_shared = False        # grad is ALSO another tensor's gradient (read-only): anything that adds to it in place copies it first
 
     def view(self) -> "L.Tensor":
         return L.tview(self.buf)
@@ -138,8 +139,20 @@ class ResUNetPPEngine(ResUNetEngine):
             v.grad = torch.empty((self._B,) + v.S + (v.C,), dtype=self.dtype, device=self._dev)
             L.check(lib.bpx_norm_act_fwd(self.dt, self._B, v.vox, gv, self._ident_rec(v.C).data_ptr(), 0, L.tview(v.grad), self._st))   # copy of a slice
         else:
+            if v.grad_shared:
+                v.grad, v.grad_shared = v.grad.clone(), False
             L.check(lib.bpx_channel_affine(self.dt, self._B, v.vox, L.tview(v.grad), gv, self._ones_bc(v.C).data_ptr(), None, L.tview(v.grad), self._st))
         self._keep.append(g)
+
+    def _acc_target(self, v: _V):
+        """For a kernel that can ADD to an existing tensor while it writes its result (norm_bwd_apply, channel_affine, conv1x1): the
+        (addend view, destination tensor, fresh?) that make it leave ``v.grad (+)= result`` - the gradient so far as the addend and the
+        destination, or a new tensor the caller adopts as ``v.grad``.  Saves the separate accumulation pass of ``_accum``."""
+        if v.grad is None:
+            return L.NULL_T, torch.empty_like(v.buf), True
+        if v.grad_shared:
+            v.grad, v.grad_shared = v.grad.clone(), False
+        return L.tview(v.grad), v.grad, False
 
     def _tensor_part(self, v: _V):
         tiles = lib.bpx_tensor_stats_tiles(v.vox)
@@ -206,9 +219,13 @@ class ResUNetPPEngine(ResUNetEngine):
                     coef = torch.empty((B, x.C, 4), dtype=torch.float32, device=self._dev)
                     L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, rt, x.C, x.vox, nrm.rec.data_ptr(), nrm.gamma.data_ptr(), L.ptr(nrm.dgamma),
                                                       L.ptr(nrm.dbeta), x.C, coef.data_ptr(), self._st))
-                    L.check(lib.bpx_norm_bwd_apply(self.dt, B, x.vox, L.tview(g), x.view(), coef.data_ptr(), L.NULL_T, L.tview(g), self._st))
-                else:
-                    L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dy, wt.data_ptr(), L.NULL_T, None, 0, L.tview(g), None, self._st))
+                    add, dst, fresh = self._acc_target(x)             # the InstanceNorm-backward affine adds to the gradient x already has
+                    L.check(lib.bpx_norm_bwd_apply(self.dt, B, x.vox, L.tview(g), x.view(), coef.data_ptr(), add, L.tview(dst), self._st))
+                    if fresh:
+                        x.grad = dst
+                    self._keep += [y.grad, g]
+                    return
+                L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dy, wt.data_ptr(), L.NULL_T, None, 0, L.tview(g), None, self._st))
                 self._keep.append(y.grad)
                 self._accum(x, g)
             self._tape.append(bwd)
@@ -285,10 +302,11 @@ class ResUNetPPEngine(ResUNetEngine):
                 off = torch.empty((B, C), dtype=torch.float32, device=self._dev)         # d mean / voxels -> every voxel of the channel
                 L.check(lib.bpx_gate_mlp_bwd(dpart.data_ptr(), B, nt, C, x.vox, s.data_ptr(), sv.data_ptr(), w1.data_ptr(), w2.data_ptr(), R, self.relu,
                                              G[k1].data_ptr(), None, G[k2].data_ptr(), None, off.data_ptr(), self._st))
-                g = torch.empty((B,) + x.S + (C,), dtype=self.dtype, device=self._dev)
-                L.check(lib.bpx_channel_affine(self.dt, B, x.vox, L.NULL_T, L.tview(out.grad), s.data_ptr(), off.data_ptr(), L.tview(g), self._st))
+                add, dst, fresh = self._acc_target(x)
+                L.check(lib.bpx_channel_affine(self.dt, B, x.vox, add, L.tview(out.grad), s.data_ptr(), off.data_ptr(), L.tview(dst), self._st))
+                if fresh:
+                    x.grad = dst
                 self._keep += [out.grad, off, dpart]
-                self._accum(x, g)
             self._tape.append(bwd)
         return out
 
@@ -320,11 +338,12 @@ class ResUNetPPEngine(ResUNetEngine):
                 db = torch.zeros((Cout,), dtype=torch.float32, device=self._dev)
                 self._wgrad(B, x.S, x.view(), None, 0, L.tview(y.grad), 1, dw, db, self._st, self._dev)
                 wt = self._pack(w, L.PK_DENSE_T, Cin, Cout, False)
-                g = torch.empty((B,) + x.S + (Cin,), dtype=self.dtype, device=self._dev)
-                L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, L.tview(y.grad), wt.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(g), self._st))
+                add, dst, fresh = self._acc_target(x)
+                L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, L.tview(y.grad), wt.data_ptr(), None, L.NULL_T, L.NULL_T, None, add, L.tview(dst), self._st))
+                if fresh:
+                    x.grad = dst
                 self._keep.append(y.grad)
                 self._late.append(lambda: on_grads(dw, db))              # after the deferred wgrad reductions have run
-                self._accum(x, g)
             self._tape.append(bwd)
         return y
 
@@ -376,9 +395,11 @@ class ResUNetPPEngine(ResUNetEngine):
                         dwc = torch.zeros((Cout, x.C, 1, 1, 1), dtype=torch.float32, device=self._dev)
                         dbc = torch.zeros((Cout,), dtype=torch.float32, device=self._dev)
                         self._wgrad(B, x.S, x.view(), None, 0, L.tview(draw), 1, dwc, dbc, self._st, self._dev)
-                        g = torch.empty((B,) + x.S + (x.C,), dtype=self.dtype, device=self._dev)
+                        add, dst, fresh = self._acc_target(x)
                         L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, L.tview(draw), self._pack(tables, L.PK_DENSE_T, x.C, Cout, False).data_ptr(), None,
-                                                    L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(g), self._st))
+                                                    L.NULL_T, L.NULL_T, None, add, L.tview(dst), self._st))
+                        if fresh:
+                            x.grad = dst
 
                         def late(wk=wk, bk=bk, dwc=dwc, dbc=dbc):                            # after the deferred wgrad reductions have run
                             G[wk].zero_()
@@ -386,7 +407,6 @@ class ResUNetPPEngine(ResUNetEngine):
                             G[bk].copy_(dbc)
                         self._late.append(late)
                         self._keep += [draw, dslice]
-                        self._accum(x, g)
                         continue
                     dys = dilation.space_to_packed(draw, d, tables)                          # zero on the separators: they add nothing to dW, db
                     nb = dys.shape[0]
@@ -428,6 +448,7 @@ class ResUNetPPEngine(ResUNetEngine):
                 dsm = self._in_bwd(sm, rec, self.relu, m.grad, P[gk], G[gk], G[bk])
                 self._accum(e, dsm)
                 self._accum(d, dsm)                                   # shared, read-only from here on
+                e.grad_shared = d.grad_shared = e.grad is d.grad
             self._tape.append(bwd_sum)
         wk, wbk = f"{prefix}.conv_attn.2.weight", f"{prefix}.conv_attn.2.bias"
         w16 = torch.zeros((16, C, 1, 1, 1), dtype=torch.float32, device=self._dev)
