@@ -136,7 +136,9 @@ struct PwParams {
   const void* g; int g_ld; const void* t; int t_ld; const bpx_nbwd_coef* coef;
   int t_cs, y_cs;                          // elements between 16-channel chunks of t / y: 16, or the plane of a chunk-planar tensor
   const void* addend; int addend_ld;
-  float* part; int mblocks;                // CONVT stats: [N][mblocks*8][2][Csub]
+  float* part; int mblocks;                // voxel blocks (64 * MS voxels each) per sample
+  int mgroups;                             // CONVT: persistent workgroups per (sample, column block), each walking blocks grp, grp + mgroups, ..;
+                                           // stats: [N][mgroups * 4 sz][2][Csub]; the other modes: mgroups = mblocks (one block per workgroup)
 };
 
 // PL: chunk-planar t (PW_CONV1) / y (PW_CONVT) operand.  A compile-time switch on purpose: with a run-time test the interleaved instance
@@ -151,8 +153,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const int j = lane & 15, g = lane >> 4;
   const int nbk = p.Ncols / (16 * NS);
   const int nb = blockIdx.x % nbk;
-  const int mb = (blockIdx.x / nbk) % p.mblocks;
-  const int n = blockIdx.x / (nbk * p.mblocks);
+  const int grp = (blockIdx.x / nbk) % p.mgroups;
+  const int n = blockIdx.x / (nbk * p.mgroups);
   const int col_base = nb * 16 * NS;
   // PERM (transposed conv into a chunk-planar buffer, 64 columns per block, Cout % 32 == 0): the block is the x pair of sub-positions
   // (2 sp, 2 sp + 1) of the 32 channels [32 pp, 32 pp + 32), and lane row g owns 8 channels of EACH of the two 16-channel planes at
@@ -163,6 +165,18 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const int ppb = PERM ? p.Csub / 32 : 1;
   const int sp = nb / ppb, pp = nb - sp * ppb;
 
+  // statistics of the transposed conv accumulate over every voxel block this workgroup walks (one reduction and one partial row per
+  // workgroup: with a row per 128-voxel block the 16-lane reductions, the LDS exchange and the barrier cost more than the block's 8 MFMAs)
+  float s1[NS][4], s2[NS][4];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
+  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+
+  for (int mb = grp; mb < p.mblocks; mb += p.mgroups) {
   // voxel of lane (j) for each m-subtile
   // voxels per sample < 2^31 (checked on the host): 32-bit index math - the 64-bit div/mod sequences of the transposed-conv
   // coordinates were ~300 of the kernel's ~490 VALU instructions per wave, which bound it
@@ -194,8 +208,6 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
   const int ksteps = (p.K / KPL + 3) / 4;
   for (int s = 0; s < ksteps; ++s) {
     const int k = (4 * s + g) * KPL;  // first reduction channel of this lane's operand
@@ -231,13 +243,6 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   // lane (g, j) ends up with the 4*NS CONSECUTIVE columns col_base + g*4NS .. of voxel j: its g / t / addend operands and
   // its results move as 16-byte (two column quads) + 8-byte accesses, and the 4 lanes of a voxel cover 16*NS contiguous
   // channels.
-  T* __restrict__ yout = reinterpret_cast<T*>(p.y);
-  float s1[NS][4], s2[NS][4];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
-
   const int col0 = col_base + g * 4 * NS;        // first of this lane's columns
   int sub = 0, co0 = col0;
   if (MODE == PW_CONVT) { sub = col0 / p.Csub; co0 = col0 % p.Csub; }
@@ -312,6 +317,9 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     }
   }
 
+  }   // voxel blocks of this workgroup
+
+  const int mb = grp;                            // row of this workgroup's partial sums
   if (MODE == PW_CONVT && p.part != nullptr) {
     __shared__ float red[4 * NS * 16 * 2];
 #pragma unroll
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
         sub = 2 * sp + (gg >> 1);
         co = pp * 32 + (ns >> 1) * 16 + (gg & 1) * 8 + (ns & 1) * 4 + (c & 3);
       }
-      p.part[((((size_t)n * p.mblocks + mb) * (4 * p.sz) + sub) * 2 + k) * p.Csub + co] = a;
+      p.part[((((size_t)n * p.mgroups + mb) * (4 * p.sz) + sub) * 2 + k) * p.Csub + co] = a;
     }
   }
 }
@@ -347,6 +355,10 @@ constexpr int PW_MS = 2;  // 4 waves x 2 x 16 = 128 voxels per workgroup
 constexpr int PW_MS_CT = BPX_PW_MS_CT;   // the same for the transposed-conv forward.  Measured (32 -> 32 channels, 64^3 -> 128^3, planar output):
                                          // 1 (78 VGPRs, 5 waves / SIMD) 266 us, 2 266 us, 4 (162 VGPRs) 271 us - neither tile size nor residency binds
 
+// transposed conv forward: at most this many persistent workgroups per (sample, 64-column block); with 4 samples x 4 column blocks (32 -> 32
+// channels, level 0) that is 1024 workgroups of 4 waves, four per CU
+inline int convt_groups(int64_t vps) { return (int)std::min<int64_t>(cdiv64(vps, 64 * PW_MS_CT), 64); }
+
 inline int pw_ns(int ncols_per_group) { return (ncols_per_group % 64 == 0) ? 4 : (ncols_per_group % 48 == 0) ? 3 : (ncols_per_group % 32 == 0) ? 2 : 1; }
 
 template <typename T, int MODE, typename TT = T>
@@ -354,8 +366,9 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   constexpr int MSK = (MODE == PW_CONVT) ? PW_MS_CT : PW_MS;
   if (p.vps >= (1ll << 31) - 64 * MSK) { bpx_set_error("pointwise kernels: more than 2^31 voxels per sample"); return 1; }
   p.mblocks = (int)cdiv64(p.vps, 64 * MSK);
+  p.mgroups = MODE == PW_CONVT ? convt_groups(p.vps) : p.mblocks;
   int nbk = p.Ncols / (16 * ns);
-  dim3 grid((unsigned)((int64_t)p.N * p.mblocks * nbk));
+  dim3 grid((unsigned)((int64_t)p.N * p.mgroups * nbk));
   const bool planar = (MODE == PW_CONV1 && p.coef != nullptr && p.t_cs != 16) || (MODE == PW_CONVT && p.y_cs != 16);
   if (MODE == PW_CONVT && planar && ns == 4 && p.Csub % 32 != 0) { bpx_set_error("transposed conv: the 64-column planar form needs Cout % 32 == 0"); return 1; }
   if (MODE != PW_CONVTD && planar) {
@@ -383,7 +396,7 @@ int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
 
 }  // namespace
 
-extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return (int)cdiv64((int64_t)D * H * W, 64 * PW_MS_CT) * 4 * (sz == 1 ? 1 : 2); }
+extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return convt_groups((int64_t)D * H * W) * 4 * (sz == 1 ? 1 : 2); }
 
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                         bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y, bpx_tensor y2,
