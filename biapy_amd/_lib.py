@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbiapy_amd.so")
+# BPX_LIB_PATH: A/B aid - another build of the same library (scripts/ab_build.sh builds the kernel sources of a git revision next to the tree's)
+LIB_PATH = os.environ.get("BPX_LIB_PATH") or os.path.join(_HERE, "libbiapy_amd.so")
 
 F32, BF16, F16, U8, MIX16 = 0, 1, 2, 3, 4   # MIX16: backward entries only - fp16 activations, bf16 gradients (include/biapy_amd.h)
 ACT = {"none": 0, "linear": 0, "elu": 1, "relu": 2, "silu": 3}

@@ -176,7 +176,11 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 
     // ---- K loop over 16-channel chunks: stage -> barrier -> 14 MFMA steps ------------------------------------------
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-      __syncthreads();  // every wave is done reading the halo buffer (previous chunk / previous tile)
+      // forward: the halo pieces are requested BEFORE the barrier - the loads fly while this wave waits for the slower waves' MFMA steps (same-box
+      // A/B: 48 -> 16 @128^3 754 -> 737 us, 96 -> 32 @64^3 244 -> 230).  Not in dgrad: the four-workgroups-per-CU instance (128 VGPRs) would spill,
+      // and the 32 -> 96 @64^3 instance got 9 % slower with it (its t-tile DMA is already in flight at that point)
+      constexpr bool EARLY = EPI == EPI_FWD;
+      if (!EARLY) __syncthreads();
       u32x4_t pbuf[NP];
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
@@ -197,6 +201,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
       for (int d = 0; d < WD; ++d)
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)d * 4 * Cout * 16 + (wlane + ns * 256u));
+      if (EARLY) __syncthreads();  // every wave is done reading the halo buffer (previous chunk / previous tile)
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
         if (u < NP - 1 || last_ok) {
