@@ -26,9 +26,12 @@ namespace {
 #ifndef BPX_DGRAD_PK_EPI
 #define BPX_DGRAD_PK_EPI 1
 #endif
+#ifndef BPX_LP_REUSE
+#define BPX_LP_REUSE 1
+#endif
 constexpr int lp_occ(int vox, int ns, int epi, int actk) {
   return (ns == 4 || (ns == 2 && epi == EPI_DGRAD) || (ns == 3 && (actk == 0 || epi == EPI_FWD))) ? 2
-         : (ns == 1 && vox <= 256)                                                                 ? 4
+         : (ns == 1 && vox <= 256)                                                                 ? (actk == 1 || epi == EPI_DGRAD ? 4 : 3)   // the run-time-activation forward needs 130 VGPRs
          : (ns == 1 && epi == EPI_DGRAD)                                                           ? BPX_DGRAD_BIG_OCC
                                                                                                    : 3;
 }
@@ -221,8 +224,37 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
       __syncthreads();
       if (chunk == 0) BPX_STAMP();  // 2: barrier
       if (p.dbg & 16) __builtin_amdgcn_s_setprio(1);   // A/B (BPX_CONV_DBG=16): the MFMA phase outranks the other workgroups' staging VALU
+      // Steps 0..8 are the (dx0, dx1) tap pairs of the nine (dz, dy) rows: step 3 dz + dy reads the fragment rows ms + dy of plane dz, so the three
+      // steps of a plane need MS + 2 distinct rows, not 3 MS - they are read once and slid (72 -> 30 ds_read_b128 of the 112 per chunk stage; the
+      // first MFMA of a step then no longer waits for eight fresh LDS reads).  Whole-tile fragment sets only (not the halved 128-VGPR dgrad instance).  Costs 8 VGPRs.
+      // Same-box A/B: NS = 1 instances gain (fwd 48 -> 16 @128^3 749 -> 717 us, dgrad 32 -> 16 @64^3 45.5 -> 40.8), NS = 2 lose (dgrad 32 -> 32 @64^3 83 -> 90):
+      // one output-channel group only.
+      constexpr bool REUSE = BPX_LP_REUSE && TX == 16 && NS == 1 && lp_ahalf(MS, NS, EPI) == MS;
+      if constexpr (REUSE) {
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
+        for (int dz = 0; dz < 3; ++dz) {
+          u32x4_t row[MS + 2];
+#pragma unroll
+          for (int r = 0; r < MS + 2; ++r)
+            row[r] = *reinterpret_cast<const u32x4_t*>(smem + lbase[0] + r * HSTR + tap_off<HY, HX, VB>(9 * dz));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int s = 3 * dz + dy;
+            if (s + WD < STEPS) {
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns)
+                wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)(s + WD) * 4 * Cout * 16 + (wlane + ns * 256u));
+            }
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], row[ms + dy], acc[ms][ns]);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = REUSE ? 9 : 0; s < STEPS; ++s) {
         if (s + WD < STEPS) {
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns)
@@ -423,7 +455,6 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         }
       };
       fetch(0, 0);
-      if (!TDMA && NS == 1) __builtin_amdgcn_s_waitcnt(0x0F70);   // as in the forward epilogue: no load is pending inside the predicated store blocks
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         const int b = (NS > 1) ? (ns & 1) : 0;
