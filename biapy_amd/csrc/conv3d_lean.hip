@@ -125,6 +125,22 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
   const uint32_t x_csb = (uint32_t)p.x_cs * 2u, sc_csb = (uint32_t)p.sc_cs * 2u, y_csb = (uint32_t)p.y_cs * 2u, t_csb = (uint32_t)p.t_cs * 2u;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
 
+  // forward, one or two output-channel groups: bias (+ shortcut bias) and the rank-1 shortcut weights of this lane's channels are per-workgroup
+  // constants - loaded once here instead of after every tile's MFMA steps (an exposed L2 latency per tile); 4-8 VGPRs per group
+  constexpr bool HOIST = EPI == EPI_FWD && NS <= 2 && ACTK == 1;   // (the run-time-activation instances have no registers to spare)
+  f32x4_t addk[HOIST ? NS : 1], w1k[HOIST ? NS : 1];
+  if (HOIST) {
+    const bool rank1 = p.sc != nullptr && p.sc_C == 1;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const int co = co_base + ns * 16 + g * 4;
+      addk[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f}; w1k[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) addk[ns] += *reinterpret_cast<const f32x4_t*>(p.bias + co);
+      if (p.sc && p.bias_sc) addk[ns] += *reinterpret_cast<const f32x4_t*>(p.bias_sc + co);
+      if (rank1) w1k[ns] = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.wsc) + co);
+    }
+  }
+
   for (int local = slot; local < p.tilesPerXcd; local += spx, ++it) {
     const int tileId = xcd * p.tilesPerXcd + local;
     if (tileId >= p.totalTiles) break;
@@ -352,6 +368,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         const int co = co_base + ns * 16 + g * 4;
+        if (HOIST) { addv[ns] = addk[ns]; w1v[ns] = w1k[ns]; continue; }
         addv[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f}; w1v[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (p.bias) addv[ns] += *reinterpret_cast<const f32x4_t*>(p.bias + co);
         if (p.sc && p.bias_sc) addv[ns] += *reinterpret_cast<const f32x4_t*>(p.bias_sc + co);
