@@ -24,6 +24,7 @@ namespace bpxconv { long long* g_conv_stamps = nullptr; }  // profiling hook: de
 #define g_stamps bpxconv::g_conv_stamps
 extern "C" int bpx_debug_set_conv_stamps(void* p) { g_stamps = (long long*)p; return 0; }
 static int g_use_ws = 0;  // bf16 kernel selection, see bpx_debug_set_conv_ws below
+static int64_t g_lean_min_vps = 32768;   // voxels per sample from which the lean kernel is used (test hook: bpx_debug_set_conv_ws 10 = 64^3 as in round 2, 11 = 32^3)
 
 namespace {
 
@@ -489,6 +490,7 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 // goes the other way (3-4 workgroups per CU, nothing pipelined inside a workgroup) and wins wherever a CU gets >= 4 rounds of
 // tiles: 725 / 342 / 944 us on the same three layers.
 extern "C" int bpx_debug_set_conv_ws(int on) {
+  if (on == 10 || on == 11) { g_lean_min_vps = on == 10 ? 262144 : 32768; return 0; }
   if (on == 6 || on == 7) { bpxconv::g_conv_dma = on == 6 ? 1 : 0; return 0; }   // 6 / 7: DMA-pipelined kernel on / off (the other selections stay)
   g_use_ws = on;
   return 0;
@@ -497,8 +499,11 @@ extern "C" int bpx_debug_set_conv_ws(int on) {
 // Lean persistent kernel (conv3d_lean.hip) where a CU gets >= 4 rounds of tiles; it uses 32-bit element offsets and
 // 16-byte vector loads of the per-channel parameter arrays.
 static bool use_lean(int dtype, const Conv3Params& p) {
-  if ((dtype != BPX_BF16 && dtype != BPX_F16) || !(g_use_ws == 5 || (g_use_ws == 0 && (int64_t)p.D * p.H * p.W >= 262144))) return false;
-  const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
+  // >= 32^3 voxels per sample (64^3 until round 3: after the epilogue / fragment-reuse work on the lean kernel it wins at 32^3 too - B = 4, same process: fwd 192 -> 64 98 -> 88 us, 64 -> 64 + sc192 59 -> 50, dgrad 64 -> 64 43.8 -> 35.2, 64 -> 32 27.6 -> 21.0)
+  // The choice must NOT depend on the batch size: a sample's result has to be the same bits whatever batch it travels in (sharded sliding windows
+  // compare checksums across different batch compositions).
+  const int64_t vps = (int64_t)p.D * p.H * p.W, vox = vps * p.N;
+  if ((dtype != BPX_BF16 && dtype != BPX_F16) || !(g_use_ws == 5 || (g_use_ws == 0 && vps >= g_lean_min_vps))) return false;
   const int64_t ldmax = std::max<int64_t>(std::max(p.x_ld, p.y_ld), std::max(p.sc ? p.sc_ld : 0, p.t ? p.t_ld : 0));
   auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   // 32-bit byte offsets: a chunk-planar tensor extends over (channels / 16) planes

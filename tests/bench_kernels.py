@@ -43,7 +43,7 @@ def main():
     a = ap.parse_args()
     dt = L.BF16 if a.dtype == "bf16" else L.F32
     T = torch.bfloat16 if dt == L.BF16 else torch.float32
-    B = 4
+    B = int(os.environ.get("BPX_BENCH_B", "4"))
     st = L.stream_ptr()
     if os.environ.get('BPX_WS') is not None:
         lib.bpx_debug_set_conv_ws(int(os.environ['BPX_WS']))
