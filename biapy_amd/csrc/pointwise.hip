@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const T* __restrict__ xin = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
 
-  for (int mb = grp; mb < p.mblocks; mb += p.mgroups) {
+  int mb = grp;
+  do {   // one pass for every mode but the transposed-conv forward (a compile-time fact: as a run-time loop it cost the 48-column GEMM 40 VGPRs and a wave per SIMD)
   // voxel of lane (j) for each m-subtile
   // voxels per sample < 2^31 (checked on the host): 32-bit index math - the 64-bit div/mod sequences of the transposed-conv
   // coordinates were ~300 of the kernel's ~490 VALU instructions per wave, which bound it
@@ -317,9 +318,9 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     }
   }
 
-  }   // voxel blocks of this workgroup
+  } while (MODE == PW_CONVT && (mb += p.mgroups) < p.mblocks);   // voxel blocks of this workgroup
 
-  const int mb = grp;                            // row of this workgroup's partial sums
+  mb = grp;                                      // row of this workgroup's partial sums
   if (MODE == PW_CONVT && p.part != nullptr) {
     __shared__ float red[4 * NS * 16 * 2];
 #pragma unroll
