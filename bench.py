@@ -433,9 +433,7 @@ def main():
         rec = run_sliding(a, model, dev, rank, world, V, a.warmup, a.steps)
         if rank == 0:
             rec.update(higher_is_better=True, vs_baseline=None, dtype=inf_name, data="synthetic")
-            print(json.dumps(rec))
-        if multi:
-            dist.destroy_process_group()
+        finish(rec, multi, rank)
         return
 
     x, tgt = synth_batch(a.batch, a.patch, dev, seed=rank)
@@ -620,9 +618,7 @@ def main():
         if a.mode == "infer":
             if rank == 0:
                 infer_rec.update(higher_is_better=True, vs_baseline=None, data="synthetic")
-                print(json.dumps(infer_rec))
-            if multi:
-                dist.destroy_process_group()
+            finish(infer_rec, multi, rank)
             return
 
     # ====================================================== sliding ======================================================
@@ -710,9 +706,31 @@ def main():
             out["cfg5_rcan_sr"] = cfg5_rec
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.patch, quick=a.quick_cpu_baseline)
-        print(json.dumps(out))
+        finish(out, multi, rank)
+        return
+    finish(None, multi, rank)
+
+
+def finish(rec, multi, rank):
+    """The ONE JSON line as the LAST line of stdout.  RCCL writes a version banner through C stdio when the first communicator comes up; with stdout
+    redirected that buffer is flushed at process exit, i.e. AFTER a line printed from Python (seen in profiles/r03_bench_train_dp_1rank.json before
+    this function existed).  So: drain C stdio first, print the line, tear the process group down, and leave without running exit handlers that
+    could print again."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    if rank == 0 and rec is not None:
+        sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+    sys.stderr.flush()
     if multi:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        os._exit(0)
 
 
 def run_resunetpp(a, dev, rank, world, multi, dtype, as_record=False):
@@ -788,10 +806,7 @@ def run_resunetpp(a, dev, rank, world, multi, dtype, as_record=False):
         mfma_frac_end_to_end=round(value * 1044917 * 3 / (world * MFMA_PEAK_BF16), 5))
     if as_record:                                           # the sub-record of the default line (main): the caller prints
         return rec
-    if rank == 0:
-        print(json.dumps(rec))
-    if multi:
-        dist.destroy_process_group()
+    finish(rec, multi, rank)
 
 
 def run_rcan_sr(a, dev):
