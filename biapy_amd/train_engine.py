@@ -143,6 +143,19 @@ def _losses_of(result) -> Tuple[List[torch.Tensor], Dict]:
 _GRAPH_SAFE_ACTS = ("ce_sigmoid", "ce_softmax", "linear")
 
 
+def _check_fused_activations(model_call_func, loss_function) -> None:
+    """A loss that applies the head activations inside its kernel (``losses.InstanceChannelsLoss``: tanh of the 'D' channel, ...) takes the model's
+    RAW output.  The reference's ``model_call_func`` applies those activations itself in training (``apply_model_activations``,
+    base_workflow.py:1403-1457), so the pair would apply them twice - silently.  Refused unless the function declares that it returns raw logits
+    (attribute ``returns_raw_logits = True``) or is left to the default (``None``: to_pytorch_format -> model)."""
+    fused = getattr(loss_function, "fused_head_activations", None)
+    if model_call_func is None or not fused or getattr(model_call_func, "returns_raw_logits", False):
+        return
+    if any(str(a).lower() not in _GRAPH_SAFE_ACTS for a in fused):
+        raise ValueError("the loss applies the head activations %s itself and needs the model's raw output, but a model_call_func was given (the reference's "
+                         "applies them too): pass model_call_func=None, or mark yours with returns_raw_logits = True" % ([str(a) for a in fused],))
+
+
 def _graphable_model(inner, criterion=None) -> bool:
     """A biapy_amd drop-in whose training-time ``model_call_func`` is the identity around the model (see the module docstring): every
     head is linear at training time, or the criterion applies the model's head activations itself (``InstanceChannelsLoss``: the
@@ -219,6 +232,7 @@ def train_one_epoch(
     sched_name = _cfg_get(cfg, "TRAIN.LR_SCHEDULER.NAME", "") or ""
     per_iter_warmup = sched_name in ("warmupcosine", "warmupreduceonplateau")
     inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+    _check_fused_activations(model_call_func, loss_function)
     if model_call_func is None:
         def model_call_func(batch, is_train=True):  # noqa: E306 - the default of a stand-alone caller
             return model(to_pytorch_format(batch, device))
@@ -441,6 +455,7 @@ def evaluate(
         p0 = next(iter(model.parameters()), None)
         device = p0.device if p0 is not None else torch.device("cpu")
     device = torch.device(device)
+    _check_fused_activations(model_call_func, loss_function)
     if model_call_func is None:
         def model_call_func(batch, is_train=True):  # noqa: E306
             return model(to_pytorch_format(batch, device))

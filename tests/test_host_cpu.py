@@ -484,3 +484,27 @@ def test_modules_take_the_keyword_arguments_build_model_passes():
     assert sum(p.numel() for p in mpp.parameters()) == 11148710
     msr = ResUNet(**{k: (tuple(v) if k in ("image_shape", "upsampling_factor") else v) for k, v in rec["sr_resunet"].items()})
     assert any(k.startswith("pre_upsampling.") for k in msr.state_dict())
+
+
+def test_epoch_drivers_refuse_a_model_call_func_beside_a_loss_that_fuses_the_head_activations():
+    """InstanceChannelsLoss applies tanh to the 'D' channel inside its kernel; the reference's model_call_func applies it too (base_workflow.py:1403-1457):
+    together they would do it twice without any error.  train_one_epoch / evaluate refuse the pair unless the function says it returns raw logits."""
+    from biapy_amd import train_engine as TE
+
+    class _Loss:
+        fused_head_activations = ["ce_sigmoid", "ce_sigmoid", "tanh"]
+
+    def mcf(batch, is_train=True):
+        return batch
+
+    with pytest.raises(ValueError, match="raw output"):
+        TE._check_fused_activations(mcf, _Loss())
+    TE._check_fused_activations(None, _Loss())                      # the default call is the identity around the model
+    mcf.returns_raw_logits = True
+    TE._check_fused_activations(mcf, _Loss())
+
+    class _Plain:
+        fused_head_activations = ["ce_sigmoid", "linear"]           # nothing is applied at training time: any model_call_func is fine
+    mcf2 = lambda b, is_train=True: b                               # noqa: E731
+    TE._check_fused_activations(mcf2, _Plain())
+    TE._check_fused_activations(mcf2, object())
