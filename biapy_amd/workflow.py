@@ -258,6 +258,9 @@ class SlidingWindowPredictor:
 
         assert vol.is_cuda and vol.dim() == 4 and vol.dtype == torch.float32
         orig = tuple(int(v) for v in vol.shape[:3])
+        if predict_kw.get("full_z") is not None or predict_kw.get("z_offset", 0):
+            raise ValueError("process_test_sample takes the WHOLE volume (its reflect completion and the crop back work on the full extent); "
+                             "slab inputs (z_offset / full_z) go to predict() directly")
         work = self.pad_to_shape(vol) if reflect_to_complete_shape else vol
         pred = self.predict(work, **predict_kw)
         if pred is None:
