@@ -8,13 +8,21 @@ rotations, Z is never swapped), undo each orientation, reduce with mean / min / 
 The volume stays on the MI355X: one gather per orientation (``bpx_tta_orient``) and one fused un-orient + reduce pass
 (``bpx_tta_accumulate``) instead of the reference's NumPy stack of 16 copies; the reduction runs in the reference's orientation
 order, so the float32 mean is the same sequential sum ``np.mean(stack, axis=0)`` forms.
-Direction-carrying channels (flows, rays, offsets: ``tta_spec``) are not handled here - NotImplementedError.
+Direction-carrying channels (round 3; ``tta_spec``, tta.py:270-640): flows / offsets (``VectorChannels`` signed), per-axis magnitudes
+(unsigned), StarDist rays (``RayChannels``) and affinities (``AffinityChannels``) - the spec drops the orientations a representation cannot
+express, the volume is padded with zeros instead of reflections, every un-oriented prediction gets the group's channel remap (a signed
+permutation of components, a permutation of ray channels, a permutation + roll of affinity maps) before the reduction, and min / max
+apply to the mode-reducible channels only.  ``tta_spec`` may be the reference's ``TTASpec`` object or the plain dataclasses below (the
+same field names); pinned to the reference's classes driven through its ``ensemble_predictions`` (tests/golden/tta_spec_golden.npz).
 """
 from __future__ import annotations
 
 import ctypes as C
 import itertools
-from typing import Callable, List, Sequence, Tuple
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
 
 import torch
 import torch.nn.functional as F
@@ -50,6 +58,163 @@ def build_axis_transform_group(ndim: int, level: str = "full", interchangeable_a
     return out
 
 
+# ---- channel groups of a TTA spec (host-side descriptions; field names of biapy/data/post_processing/tta.py:318-540) -------------------
+@dataclass
+class ScalarChannels:
+    channels: Tuple[int, ...] = ()
+    name: str = "scalar"
+
+
+@dataclass
+class VectorChannels:
+    axis_channels: Tuple[Optional[int], ...] = ()
+    signed: bool = True
+    axis_scale: Optional[Tuple[float, ...]] = None
+    name: str = "vector"
+
+
+@dataclass
+class RayChannels:
+    start: int = 0
+    dirs: "np.ndarray" = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+    name: str = "rays"
+
+
+@dataclass
+class AffinityChannels:
+    layout: Dict[Tuple[int, int], int] = field(default_factory=dict)
+    name: str = "affinities"
+
+
+@dataclass
+class TTASpec:
+    ndim: int
+    n_channels: int
+    groups: List[object] = field(default_factory=list)
+
+
+def _inverse(perm, sign):
+    """tta.py:125-137."""
+    n = len(perm)
+    pinv = [0] * n
+    for a, p in enumerate(perm):
+        pinv[p] = a
+    return tuple(pinv), tuple(sign[pinv[b]] for b in range(n))
+
+
+def _kind(g) -> str:
+    k = getattr(g, "name", None)
+    if k in ("scalar", "vector", "rays", "affinities"):
+        return k
+    raise NotImplementedError(f"TTA channel group {type(g).__name__!r} (name={k!r}) is not known to biapy_amd.tta")
+
+
+def _ray_permutation(dirs, perm, sign):
+    """dest[j] = k with dirs[k] == t.inverse(dirs[j]) or None (tta.py:440-463)."""
+    dirs = np.asarray(dirs)
+    if len(dirs) == 0:
+        return None
+    pinv, sinv = _inverse(perm, sign)
+    target = np.empty_like(dirs)
+    for a in range(len(perm)):
+        target[..., a] = sinv[a] * dirs[..., pinv[a]]
+    dots = target @ dirs.T
+    dest = np.argmax(dots, axis=1)
+    if np.allclose(dots[np.arange(len(dest)), dest], 1.0, atol=1e-4) and len(np.unique(dest)) == len(dest):
+        return dest.astype(np.int64)
+    return None
+
+
+def _supports(g, perm, sign) -> bool:
+    """ChannelGroup.supports (tta.py:378-391, :465-471, :512-519)."""
+    k = _kind(g)
+    if k == "vector":
+        pinv, _ = _inverse(perm, sign)
+        ac, sc = g.axis_channels, g.axis_scale
+        for a in range(len(perm)):
+            src = pinv[a]
+            if (ac[a] is None) != (ac[src] is None):
+                return False
+            if sc is not None and src != a and not np.isclose(sc[a], sc[src]):
+                return False
+        return True
+    if k == "rays":
+        return len(g.dirs) == 0 or _ray_permutation(g.dirs, perm, sign) is not None
+    if k == "affinities":
+        return all((perm[axis], off) in g.layout for (axis, off) in g.layout)
+    return True
+
+
+def filter_orientations(spec, orientations: Sequence[Orientation]) -> List[Orientation]:
+    """TTASpec.filter_orientations (tta.py:589-621): the orientations every group can represent exactly; at least the identity."""
+    kept = [(p, s) for p, s in orientations if all(_supports(g, p, s) for g in spec.groups)]
+    n = len(orientations[0][0])
+    return kept or [(tuple(range(n)), (1,) * n)]
+
+
+def _mode_reducible(spec) -> List[int]:
+    """TTASpec.mode_reducible_channels (tta.py:580-587): everything but signed vector components."""
+    out: List[int] = []
+    for g in spec.groups:
+        k = _kind(g)
+        if k == "scalar":
+            out += list(g.channels)
+        elif k == "vector":
+            out += [] if g.signed else [c for c in g.axis_channels if c is not None]
+        elif k == "rays":
+            out += list(range(g.start, g.start + len(g.dirs)))
+        else:
+            out += sorted(g.layout.values())
+    return sorted(out)
+
+
+def _remap_channels(spec, pred: torch.Tensor, perm, sign) -> None:
+    """TTASpec.remap_channels on a spatially restored device prediction (spatial..., C), in place (tta.py:393-402, :473-481, :521-544)."""
+    n = len(perm)
+    if tuple(perm) == tuple(range(n)) and all(v == 1 for v in sign):
+        return
+    if pred.shape[-1] != spec.n_channels:
+        raise ValueError("TTA spec describes {} output channels but the model returned {}".format(spec.n_channels, pred.shape[-1]))
+    pinv, sinv = _inverse(perm, sign)
+    for g in spec.groups:
+        k = _kind(g)
+        if k == "vector":
+            ac = g.axis_channels
+            src = [pred[..., c].clone() if c is not None else None for c in ac]
+            for a, dst in enumerate(ac):
+                if dst is None:
+                    continue
+                comp = src[pinv[a]]
+                pred[..., dst] = comp if (sinv[a] > 0 or not g.signed) else -comp
+        elif k == "rays":
+            dest = _ray_permutation(g.dirs, perm, sign)
+            if dest is None:
+                raise RuntimeError("remap called with an unsupported orientation")
+            s0, nr = g.start, len(g.dirs)
+            block = pred[..., s0:s0 + nr].clone()
+            pred[..., (s0 + torch.from_numpy(dest)).to(pred.device)] = block
+        elif k == "affinities":
+            src = {key: pred[..., ch].clone() for key, ch in g.layout.items()}
+            for (axis, off), block in src.items():
+                dst_axis = perm[axis]
+                dst = g.layout[(dst_axis, off)]
+                if sign[axis] > 0:
+                    pred[..., dst] = block
+                else:   # aff_{b,-d} = aff_{b,+d} shifted by -d: roll by +d, rebuild the wrapped border from the first valid slice
+                    rolled = torch.roll(block, shifts=off, dims=dst_axis)
+                    if 0 < off < rolled.shape[dst_axis]:
+                        lead = [slice(None)] * rolled.dim()
+                        lead[dst_axis] = slice(0, off)
+                        fv = [slice(None)] * rolled.dim()
+                        fv[dst_axis] = slice(off, off + 1)
+                        rolled[tuple(lead)] = rolled[tuple(fv)]
+                    pred[..., dst] = rolled
+
+
+def _is_scalar_only(spec) -> bool:
+    return all(_kind(g) == "scalar" for g in spec.groups)
+
+
 def _c3(perm, sign):
     """2D orientations act on (Y, X): embed as a 3D one on (Z=1, Y, X)."""
     if len(perm) == 2:
@@ -65,13 +230,16 @@ def ensemble_predictions(vol: torch.Tensor, pred_func: Callable[[torch.Tensor], 
     assert mode in ["mean", "min", "max"], "Get unknown ensemble mode {}".format(mode)
     assert ndim in (2, 3), "ndim must be 2 or 3, got {}".format(ndim)
     assert group in TTA_GROUPS, "group must be one of {}, got '{}'".format(TTA_GROUPS, group)
-    if tta_spec is not None:
-        raise NotImplementedError("biapy_amd.tta handles scalar-field predictions (tta_spec=None); use the reference for flows / rays / offsets")
+    spec = None if (tta_spec is None or _is_scalar_only(tta_spec)) else tta_spec      # an all-scalar spec IS the classic ensemble (tta.py:575-578)
     if not vol.is_cuda:
         raise RuntimeError("biapy_amd.tta runs on the MI355X only (volume is on %s); there is no CPU path" % vol.device)
     if vol.dim() != ndim + 1:
         raise ValueError("Expected a {}D input (spatial..., channels); got shape {}".format(ndim, tuple(vol.shape)))
     orientations = build_axis_transform_group(ndim, level=("full" if group == "auto" else group))
+    if spec is not None:
+        if spec.ndim != ndim:
+            raise ValueError("TTA spec is {}D, the data {}D".format(spec.ndim, ndim))
+        orientations = filter_orientations(spec, orientations)
     img = vol.to(torch.float32)
     # square off the axes that get swapped (post_processing.py:1285-1339): front padding, reflect (edge if too short)
     moved = sorted({a for p, _ in orientations for a in range(ndim) if p[a] != a} | {p[a] for p, _ in orientations for a in range(ndim) if p[a] != a})
@@ -80,7 +248,8 @@ def ensemble_predictions(vol: torch.Tensor, pred_func: Callable[[torch.Tensor], 
         target = max(img.shape[a] for a in moved)
         if not all(img.shape[a] == target for a in moved):
             pad_before = [target - img.shape[a] if a in moved else 0 for a in range(ndim)]
-            pmode = "replicate" if any(pad_before[a] >= img.shape[a] for a in moved) else "reflect"
+            # reflections mirror the cells on the border and corrupt their flows / offsets / rays: zeros for a non-scalar spec (post_processing.py:1488-1491)
+            pmode = "constant" if spec is not None else ("replicate" if any(pad_before[a] >= img.shape[a] for a in moved) else "reflect")
             t = img.movedim(-1, 0).unsqueeze(0)                       # (1, C, spatial...)
             pads = []
             for a in reversed(range(ndim)):
@@ -109,11 +278,35 @@ def ensemble_predictions(vol: torch.Tensor, pred_func: Callable[[torch.Tensor], 
         Cout = pred.shape[-1]
         if acc is None:
             acc = torch.empty(sp + (Cout,), dtype=torch.float32, device=img.device)
+            if spec is not None:
+                tmp = torch.empty_like(acc)
+                acc_m = torch.empty_like(acc) if mode != "mean" else None
         for q, (perm, sign) in enumerate(chunk):
             k = b0 + q
             cp, cs, _ = _c3(perm, sign)
+            if spec is not None:
+                # generic path: un-orient into a scratch volume, remap the channels there, then reduce in orientation order (the sequential float32 sum
+                # np.mean forms; min / max kept beside it for the mode-reducible channels)
+                L.check(lib.bpx_tta_accumulate(pred[q].data_ptr(), Z, Y, X, Cout, cp, cs, 0, 1, 0, tmp.data_ptr(), st))
+                _remap_channels(spec, tmp, perm, sign)
+                if k == 0:
+                    acc.copy_(tmp)
+                    if acc_m is not None:
+                        acc_m.copy_(tmp)
+                else:
+                    acc.add_(tmp)
+                    if acc_m is not None:
+                        (torch.minimum if mode == "min" else torch.maximum)(acc_m, tmp, out=acc_m)
+                continue
             L.check(lib.bpx_tta_accumulate(pred[q].data_ptr(), Z, Y, X, Cout, cp, cs, {"mean": 0, "min": 1, "max": 2}[mode], 1 if k == 0 else 0,
                                            n_or if (mode == "mean" and k == n_or - 1) else 0, acc.data_ptr(), st))
+    if spec is not None:
+        acc = acc / float(n_or)                                       # np.mean: the float32 sum divided by n
+        if mode != "mean":
+            idx = _mode_reducible(spec)
+            if idx:
+                ii = torch.tensor(idx, dtype=torch.long, device=acc.device)
+                acc[..., ii] = acc_m[..., ii]
     if pad_before is not None:
         acc = acc[tuple(slice(p, None) for p in pad_before) + (slice(None),)].contiguous()
     return acc

@@ -76,6 +76,12 @@ def harness_tail_golden():
 
 
 @pytest.fixture(scope="session")
+def tta_spec_golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "tta_spec_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def tta_ensemble_golden():
     import numpy as np
 

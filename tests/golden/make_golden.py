@@ -282,6 +282,51 @@ def tta_ensemble_fixtures():
     print("tta_ensemble_golden.npz:", len(out), "arrays")
 
 
+def tta_spec_fixtures():
+    """ensemble_predictions with a TTASpec (direction-carrying channels: flows / per-axis magnitudes, rays, affinities): the reference's own channel
+    groups (tta.py:318-540) built from the plain descriptions of oracle/tta_oracle.spec_cases(), driven through post_processing.ensemble_predictions
+    with the exact-arithmetic stand-in predictor."""
+    import importlib
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import tta_oracle as TO
+
+    pp = shim.load_post_processing()
+    tt = importlib.import_module("biapy.data.post_processing.tta")      # the module post_processing itself imported (isinstance checks)
+    out = {}
+    rs = np.random.RandomState(6200)
+    for name, shape, ndim, cout, groups in TO.spec_cases():
+        ref_groups = []
+        for g in groups:
+            if g["kind"] == "scalar":
+                ref_groups.append(tt.ScalarChannels(channels=tuple(g["channels"])))
+            elif g["kind"] == "vector":
+                ref_groups.append(tt.VectorChannels(axis_channels=tuple(g["axis_channels"]), signed=g["signed"],
+                                                    axis_scale=None if g["axis_scale"] is None else tuple(g["axis_scale"])))
+            elif g["kind"] == "rays":
+                ref_groups.append(tt.RayChannels(start=g["start"], dirs=np.asarray(g["dirs"])))
+            else:
+                ref_groups.append(tt.AffinityChannels(layout=dict(g["layout"])))
+        spec = tt.TTASpec(ndim=ndim, n_channels=cout, groups=ref_groups)
+        img = rs.rand(*shape).astype(np.float32)
+        out[f"{name}/img"] = img
+        back = (0, 2, 3, 1) if ndim == 2 else (0, 2, 3, 4, 1)
+        fwd = (0, 3, 1, 2) if ndim == 2 else (0, 4, 1, 2, 3)
+
+        def pred_func(batch, cout=cout, fwd=fwd):
+            return torch.from_numpy(TO.standin_pred_multi(np.asarray(batch), cout)).permute(*fwd)
+
+        for mode, level, bs in TO.SPEC_SETTINGS:
+            r = pp.ensemble_predictions(img, pred_func, back, fwd, torch.device("cpu"), ndim, batch_size_value=bs, mode=mode, tta_spec=spec, group=level)
+            out[f"{name}/{mode}/{level}/{bs}"] = r.permute(*back)[0].numpy()
+            kept, _ = spec.filter_orientations(tt.build_axis_transform_group(ndim, level=level))
+            out[f"{name}/kept/{level}"] = np.array([list(t.perm) + list(t.sign) for t in kept], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "tta_spec_golden.npz"), **out)
+    print("tta_spec_golden.npz:", len(out), "arrays")
+
+
 def harness_fixtures():
     """Rows P / B / F / A of SURVEY 8a pinned to the reference harness ITSELF: ``Base_Workflow.process_test_sample`` (per-patch branch,
     base_workflow.py:1874-2131) is run unbound on a stand-in ``self`` that carries only the attributes the branch reads (a namespace cfg
@@ -1051,13 +1096,15 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
         tta_fixtures()
     if "tta_ensemble" in which:
         tta_ensemble_fixtures()
+    if "tta_spec" in which:
+        tta_spec_fixtures()
     if "build_model" in which:                  # full import: on its own
         build_model_kwargs_fixture()
     if "head_acts" in which:                    # full import as well: on its own

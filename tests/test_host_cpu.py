@@ -508,3 +508,33 @@ def test_epoch_drivers_refuse_a_model_call_func_beside_a_loss_that_fuses_the_hea
     mcf2 = lambda b, is_train=True: b                               # noqa: E731
     TE._check_fused_activations(mcf2, _Plain())
     TE._check_fused_activations(mcf2, object())
+
+
+def _tta_spec_of(T, ndim, cout, groups):
+    """biapy_amd.tta's spec dataclasses from the plain descriptions of oracle/tta_oracle.spec_cases()."""
+    out = []
+    for g in groups:
+        if g["kind"] == "scalar":
+            out.append(T.ScalarChannels(channels=tuple(g["channels"])))
+        elif g["kind"] == "vector":
+            out.append(T.VectorChannels(axis_channels=tuple(g["axis_channels"]), signed=g["signed"], axis_scale=None if g["axis_scale"] is None else tuple(g["axis_scale"])))
+        elif g["kind"] == "rays":
+            out.append(T.RayChannels(start=g["start"], dirs=np.asarray(g["dirs"])))
+        else:
+            out.append(T.AffinityChannels(layout=dict(g["layout"])))
+    return T.TTASpec(ndim=ndim, n_channels=cout, groups=out)
+
+
+def test_tta_spec_host_logic_matches_the_reference(tta_spec_golden):
+    """The product's orientation filter and mode-reducible channel list (host logic of biapy_amd.tta) against what the reference's TTASpec kept."""
+    from biapy_amd import tta as T
+    from oracle import tta_oracle as TO
+
+    for name, shape, ndim, cout, groups in TO.spec_cases():
+        spec = _tta_spec_of(T, ndim, cout, groups)
+        for level in ("full", "flips"):
+            kept = T.filter_orientations(spec, T.build_axis_transform_group(ndim, level))
+            np.testing.assert_array_equal(np.array([list(p) + list(s) for p, s in kept]), tta_spec_golden[f"{name}/kept/{level}"], err_msg=f"{name} {level}")
+        assert T._mode_reducible(spec) == TO.mode_reducible_channels(groups)
+    with pytest.raises(NotImplementedError):
+        T._kind(object())

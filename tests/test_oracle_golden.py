@@ -619,3 +619,20 @@ def test_resunet_sr_oracle_and_module(resunet_sr_golden, tag, shape):
                 upsampling_factor=tuple(int(v) for v in g[f"{tag}/factor"]), upsampling_position=str(g[f"{tag}/pos"]))
     assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
     m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+
+
+def test_tta_spec_oracle_matches_the_reference_classes(tta_spec_golden):
+    """Direction-carrying channels (flows, per-axis magnitudes, anisotropic offsets, rays, affinities): the oracle's restatement of the
+    channel groups' supports / remap and of the spec-aware ensemble against the reference's own classes driven through its
+    ensemble_predictions (make_golden.py tta_spec) - kept orientations and every ensembled prediction, bit-exact."""
+    from oracle import tta_oracle as TO
+
+    g = tta_spec_golden
+    for name, shape, ndim, cout, groups in TO.spec_cases():
+        img = g[f"{name}/img"]
+        assert img.shape == shape
+        for mode, level, bs in TO.SPEC_SETTINGS:
+            kept = TO.filter_orientations(groups, TO.group(ndim, level))
+            np.testing.assert_array_equal(np.array([list(p) + list(s) for p, s in kept]), g[f"{name}/kept/{level}"], err_msg=f"{name} {level}")
+            got = TO.ensemble_spec(img, lambda b: TO.standin_pred_multi(b, cout), ndim, groups, mode, level, bs)
+            np.testing.assert_array_equal(got, g[f"{name}/{mode}/{level}/{bs}"], err_msg=f"{name} {mode} {level} {bs}")
