@@ -726,10 +726,16 @@ def finish(rec, multi, rank):
     sys.stdout.flush()
     sys.stderr.flush()
     if multi:
-        try:
-            dist.destroy_process_group()
-        except Exception:  # noqa: BLE001
-            pass
+        import threading
+
+        def teardown():
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+        t = threading.Thread(target=teardown, daemon=True)     # the line is out: a communicator teardown that hangs must not hold the launcher
+        t.start()
+        t.join(20.0)
         os._exit(0)
 
 
