@@ -200,15 +200,15 @@ def _remap_channels(spec, pred: torch.Tensor, perm, sign) -> None:
                 dst = g.layout[(dst_axis, off)]
                 if sign[axis] > 0:
                     pred[..., dst] = block
-                else:   # aff_{b,-d} = aff_{b,+d} shifted by -d: roll by +d, rebuild the wrapped border from the first valid slice
-                    rolled = torch.roll(block, shifts=off, dims=dst_axis)
-                    if 0 < off < rolled.shape[dst_axis]:
-                        lead = [slice(None)] * rolled.dim()
-                        lead[dst_axis] = slice(0, off)
-                        fv = [slice(None)] * rolled.dim()
-                        fv[dst_axis] = slice(off, off + 1)
-                        rolled[tuple(lead)] = rolled[tuple(fv)]
-                    pred[..., dst] = rolled
+                else:
+                    # a reversed axis turns offset +d into -d, and aff_{b,-d}(p) = aff_{b,+d}(p + d e_b): the map moves d voxels up the axis; the d
+                    # leading slices that have no source repeat the first one (what seg2aff_pni's padding of the starting border amounts to)
+                    n_b = block.shape[dst_axis]
+                    if 0 < off < n_b:
+                        head = block.narrow(dst_axis, 0, 1).expand(*[off if a == dst_axis else block.shape[a] for a in range(block.dim())])
+                        pred[..., dst] = torch.cat([head, block.narrow(dst_axis, 0, n_b - off)], dim=dst_axis)
+                    else:                                       # offsets outside the volume wrap around, as np.roll does in the reference
+                        pred[..., dst] = torch.roll(block, shifts=off, dims=dst_axis)
 
 
 def _is_scalar_only(spec) -> bool:

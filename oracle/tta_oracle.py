@@ -182,15 +182,13 @@ def remap_channels(groups, pred: np.ndarray, perm, sign) -> None:
                 dst = g["layout"][(dst_axis, off)]
                 if sign[axis] > 0:
                     pred[..., dst] = block
-                else:
-                    rolled = np.roll(block, shift=off, axis=dst_axis)
-                    if 0 < off < rolled.shape[dst_axis]:
-                        lead = [slice(None)] * rolled.ndim
-                        lead[dst_axis] = slice(0, off)
-                        fv = [slice(None)] * rolled.ndim
-                        fv[dst_axis] = slice(off, off + 1)
-                        rolled[tuple(lead)] = rolled[tuple(fv)]
-                    pred[..., dst] = rolled
+                else:   # the map shifted `off` voxels up the axis, its first slice repeated into the `off` slices without a source (tta.py:531-543)
+                    n_b = block.shape[dst_axis]
+                    if 0 < off < n_b:
+                        shifted = np.take(block, np.maximum(np.arange(n_b) - off, 0), axis=dst_axis)
+                    else:
+                        shifted = np.roll(block, shift=off, axis=dst_axis)
+                    pred[..., dst] = shifted
 
 
 def mode_reducible_channels(groups):
