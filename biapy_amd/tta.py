@@ -103,10 +103,17 @@ def _inverse(perm, sign):
 
 
 def _kind(g) -> str:
-    k = getattr(g, "name", None)
-    if k in ("scalar", "vector", "rays", "affinities"):
-        return k
-    raise NotImplementedError(f"TTA channel group {type(g).__name__!r} (name={k!r}) is not known to biapy_amd.tta")
+    """By the data a group carries, not by its ``name`` (the reference's build_tta_spec names vector groups after their family - "flow", "hover",
+    "E_offset", "E_sigma" - tta.py:759, :786-793)."""
+    if hasattr(g, "axis_channels"):
+        return "vector"
+    if hasattr(g, "dirs") and hasattr(g, "start"):
+        return "rays"
+    if hasattr(g, "layout"):
+        return "affinities"
+    if hasattr(g, "channels") and type(g).__name__ in ("ScalarChannels",):
+        return "scalar"
+    raise NotImplementedError(f"TTA channel group {type(g).__name__!r} is not known to biapy_amd.tta")
 
 
 def _ray_permutation(dirs, perm, sign):

@@ -323,6 +323,16 @@ def tta_spec_fixtures():
             out[f"{name}/{mode}/{level}/{bs}"] = r.permute(*back)[0].numpy()
             kept, _ = spec.filter_orientations(tt.build_axis_transform_group(ndim, level=level))
             out[f"{name}/kept/{level}"] = np.array([list(t.perm) + list(t.sign) for t in kept], dtype=np.int64)
+    # the spec as the workflows build it: build_tta_spec from the channel names (its vector groups are NAMED after their family, "flow" / "E_sigma")
+    names = ["Gz", "Gv", "Gh", "B", "E_sigma_0", "E_sigma_1", "E_sigma_2"]
+    spec = tt.build_tta_spec(names, 3)
+    out["from_names/kinds"] = np.array([type(g).__name__ + ":" + g.name for g in spec.groups])
+    img = rs.rand(4, 6, 6, 1).astype(np.float32)
+    out["from_names/img"] = img
+    back, fwd = (0, 2, 3, 4, 1), (0, 4, 1, 2, 3)
+    r = pp.ensemble_predictions(img, lambda b: torch.from_numpy(TO.standin_pred_multi(np.asarray(b), len(names))).permute(*fwd), back, fwd, torch.device("cpu"), 3,
+                                batch_size_value=4, mode="max", tta_spec=spec, group="full")
+    out["from_names/max/full/4"] = r.permute(*back)[0].numpy()
     np.savez_compressed(os.path.join(HERE, "tta_spec_golden.npz"), **out)
     print("tta_spec_golden.npz:", len(out), "arrays")
 

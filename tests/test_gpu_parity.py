@@ -691,6 +691,12 @@ def test_tta_with_direction_carrying_channels_matches_the_reference(tta_spec_gol
         for mode, level, bs in TO.SPEC_SETTINGS:
             got = T.ensemble_predictions(vol, pred_t, ndim, batch_size_value=bs, mode=mode, tta_spec=spec, group=level)
             np.testing.assert_array_equal(got.cpu().numpy(), g[f"{name}/{mode}/{level}/{bs}"], err_msg=f"{name} {mode} {level} {bs}")
+    # the spec as build_tta_spec hands it over (vector groups named after their family, sigmas in Cartesian order)
+    specn = T.TTASpec(ndim=3, n_channels=7, groups=[T.VectorChannels(axis_channels=(0, 1, 2), signed=True, name="flow"),
+                                                    T.VectorChannels(axis_channels=(6, 5, 4), signed=False, name="E_sigma"), T.ScalarChannels(channels=(3,))])
+    got = T.ensemble_predictions(torch.from_numpy(g["from_names/img"]).cuda(), lambda b: torch.from_numpy(TO.standin_pred_multi(b.cpu().numpy(), 7)).cuda(), 3,
+                                 batch_size_value=4, mode="max", tta_spec=specn, group="full")
+    np.testing.assert_array_equal(got.cpu().numpy(), g["from_names/max/full/4"])
     # an all-scalar spec is the classic ensemble
     spec0 = T.TTASpec(ndim=3, n_channels=2, groups=[T.ScalarChannels(channels=(0, 1))])
     v = torch.rand(4, 6, 6, 1, device="cuda")

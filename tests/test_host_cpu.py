@@ -538,3 +538,6 @@ def test_tta_spec_host_logic_matches_the_reference(tta_spec_golden):
         assert T._mode_reducible(spec) == TO.mode_reducible_channels(groups)
     with pytest.raises(NotImplementedError):
         T._kind(object())
+    # the reference names vector groups after their family ("flow", "E_sigma", ...): the kind comes from the fields, not from the name
+    assert T._kind(T.VectorChannels(axis_channels=(0, 1, 2), name="flow")) == "vector" and T._kind(T.RayChannels(name="stardist")) == "rays"
+    assert T._kind(T.AffinityChannels(name="aff")) == "affinities" and T._kind(T.ScalarChannels(channels=(0,))) == "scalar"

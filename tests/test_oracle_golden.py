@@ -636,3 +636,10 @@ def test_tta_spec_oracle_matches_the_reference_classes(tta_spec_golden):
             np.testing.assert_array_equal(np.array([list(p) + list(s) for p, s in kept]), g[f"{name}/kept/{level}"], err_msg=f"{name} {level}")
             got = TO.ensemble_spec(img, lambda b: TO.standin_pred_multi(b, cout), ndim, groups, mode, level, bs)
             np.testing.assert_array_equal(got, g[f"{name}/{mode}/{level}/{bs}"], err_msg=f"{name} {mode} {level} {bs}")
+    # the spec the workflows get from build_tta_spec(["Gz", "Gv", "Gh", "B", "E_sigma_0..2"], 3): flows on (z, y, x) = channels (0, 1, 2), sigmas in
+    # Cartesian order -> (z, y, x) = channels (6, 5, 4), unsigned; its groups are named "flow" / "E_sigma"
+    assert list(g["from_names/kinds"]) == ["VectorChannels:flow", "VectorChannels:E_sigma", "ScalarChannels:scalar"]
+    groups = [{"kind": "vector", "axis_channels": [0, 1, 2], "signed": True, "axis_scale": None},
+              {"kind": "vector", "axis_channels": [6, 5, 4], "signed": False, "axis_scale": None}, {"kind": "scalar", "channels": [3]}]
+    got = TO.ensemble_spec(g["from_names/img"], lambda b: TO.standin_pred_multi(b, 7), 3, groups, "max", "full", 4)
+    np.testing.assert_array_equal(got, g["from_names/max/full/4"])
