@@ -414,6 +414,17 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         # "nccl" IS RCCL on ROCm; BPX_BENCH_BACKEND=gloo is a testing aid (gloo moves device tensors too, so two ranks can share a GPU)
         dist.init_process_group(os.environ.get("BPX_BENCH_BACKEND", "nccl"), init_method="env://")
+        # Bring the communicator up NOW and drain C stdio on every rank: RCCL writes a version banner through stdio when its first communicator is
+        # created, and a redirected stdout only flushes that buffer at exit - from a rank other than 0 possibly AFTER rank 0 has printed the JSON line.
+        # Ranks other than 0 leave through os._exit (finish()), which drops whatever C stdio still holds.
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
 
     from biapy_amd import _lib as L
     from biapy_amd.resunet import ResUNet
