@@ -481,7 +481,7 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 
 }  // namespace
 
-// bf16 kernel selection: 0 = automatic (lean persistent kernel of conv3d_lean.hip for >= 64^3 volumes, the double-buffered
+// bf16 kernel selection: 0 = automatic (lean persistent kernel of conv3d_lean.hip for >= 32^3 volumes, the double-buffered
 // kernel of this file below that), 4 = always double-buffered, 5 = always lean persistent.
 // Record of two schedules that were measured in round 1 and removed from the library in round 2 (wave-specialised 8-wave
 // persistent | persistent 4-wave with a cross-tile stage pipeline), against the double-buffered kernel, cfg-2 layers, B=4 (us):
@@ -591,7 +591,7 @@ extern "C" int bpx_conv3d_fwd(int dtype, int N, int D, int H, int W, bpx_tensor 
 // (biapy/models/rcan.py:317-319 `conv(filters, filters * scale**2) + nn.PixelShuffle(scale)` is 2-D only; the 3-D form - s^3 sub-positions,
 // out[n, c, s z + a, s y + b, s x + e] = conv[n, c s^3 + (a s + b) s + e, z, y, x] - is defined here, see rcan.py of this package).
 // w_packed_d: BPX_PK_K3 of the weight with its output channels re-ordered [sub-position][channel] (the engine does that), bias likewise.
-// y: the (N, sD, sH, sW, 16) tensor.  Large volumes only (the lean kernel: D*H*W >= 64^3, W > 8).
+// y: the (N, sD, sH, sW, 16) tensor.  Large volumes only (the lean kernel: D*H*W >= 32^3, W > 8).
 extern "C" int bpx_conv3d_fwd_shuffle(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act, const void* w_packed_d,
                                       const float* bias_d, int s, bpx_tensor y, bpx_stream_t stream) {
   const char* fn = "bpx_conv3d_fwd_shuffle";
@@ -609,7 +609,7 @@ extern "C" int bpx_conv3d_fwd_shuffle(int dtype, int N, int D, int H, int W, bpx
   p.f16 = dtype == BPX_F16 ? 1 : 0;
   p.ps = s;
   TileCfg c = pick_cfg(dtype, D, H, W, p.Cout);
-  BPX_CHECK(use_lean(dtype, p) && c.tx == 16 && (int64_t)N * D * H * W * s * s * s * 16 < (1ll << 30), "%s: needs the lean kernel (volume >= 64^3, W > 8, output < 2 GB)", fn);
+  BPX_CHECK(use_lean(dtype, p) && c.tx == 16 && (int64_t)N * D * H * W * s * s * s * 16 < (1ll << 30), "%s: needs the lean kernel (volume >= 32^3, W > 8, output < 2 GB)", fn);
   BPX_CHECK(launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream) == 0, "%s: no kernel for tile config", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

@@ -1,4 +1,4 @@
-// Conv3d 3x3x3 implicit GEMM, bf16 storage: the "lean persistent" schedule used for the large layers (>= 64^3).
+// Conv3d 3x3x3 implicit GEMM, 16-bit storage: the "lean persistent" schedule used for the layers of >= 32^3 voxels per sample (>= 64^3 until round 3).
 //
 // Same GEMM mapping, LDS halo layout, packed-weight order and epilogue semantics as conv3_kernel (conv3d_igemm.hip - read
 // its header first).  What differs is the schedule, chosen from measurements:

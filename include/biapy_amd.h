@@ -161,7 +161,7 @@ int bpx_conv3d_stats_tiles(int dtype, int N, int D, int H, int W, int Cout); /* 
 /* The same convolution with the MaxPool3d (pool_sz,2,2) that follows an encoder block (resunet.py:256-257) fused into the
  * epilogue: `pooled` (extents D/pool_sz, H/2, W/2) and its statistics partials ([n][tiles][2][Cout], same tile count) are
  * written from registers, so the output slice is not read again.  Only where bpx_conv3d_fwd_pool_supported() returns 1
- * (the lean bf16 kernel of the >= 64^3 levels); elsewhere use bpx_conv3d_fwd + bpx_maxpool3d_fwd. */
+ * (the lean 16-bit kernel of the >= 32^3 levels); elsewhere use bpx_conv3d_fwd + bpx_maxpool3d_fwd. */
 int bpx_conv3d_fwd_pool(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                         const void* w_packed_d, const float* bias_d, bpx_tensor sc, const void* w_sc_packed_d,
                         const float* bias_sc_d, bpx_tensor y, float* stats_part_d, int pool_sz, bpx_tensor pooled,
@@ -173,7 +173,7 @@ int bpx_conv3d_fwd_pool_supported(int dtype, int N, int D, int H, int W, int x_l
  *   out[n, c, s z + a, s y + b, s x + e] = conv[n, c s^3 + (a s + b) s + e, z, y, x]        (a, b, e in [0, s))
  * The kernel takes the conv's output channels in the order [sub-position (a, b, e)][c] (w_packed_d = BPX_PK_K3 of the re-ordered weight, bias_d
  * re-ordered alike) and stores block (a, b, e) of voxel (z, y, x) to voxel (s z + a, s y + b, s x + e) of y = (N, sD, sH, sW, 16): the
- * 16 s^3-channel tensor never exists in memory.  dtype BF16 / F16; volumes the lean kernel takes (D*H*W >= 64^3, W > 8); s = 2, 3, 4. */
+ * 16 s^3-channel tensor never exists in memory.  dtype BF16 / F16; volumes the lean kernel takes (D*H*W >= 32^3, W > 8); s = 2, 3, 4. */
 int bpx_conv3d_fwd_shuffle(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act, const void* w_packed_d,
                            const float* bias_d, int s, bpx_tensor y, bpx_stream_t stream);
 
