@@ -93,6 +93,119 @@ class TTASpec:
     groups: List[object] = field(default_factory=list)
 
 
+# ---- the spec from the model's output channel names (tta.py:642-866) ------------------------------------------------------------------
+_AXIS_LETTERS = {2: ("y", "x"), 3: ("z", "y", "x")}
+# single-channel vector components: name -> (family, axis letter).  Flows of Cellpose / Omnipose and the HoVer maps.
+_COMPONENTS = {"Gz": ("flow", "z"), "Gv": ("flow", "y"), "Gh": ("flow", "x"), "Z": ("hover", "z"), "V": ("hover", "y"), "H": ("hover", "x")}
+
+
+def parse_model_output_channel_names(model_output_channel_info: Sequence[str]) -> List[str]:
+    """One name per physical channel of ``pred`` from the per-head "+"-joined descriptions; the separate "class" head is not part of ``pred``
+    (tta.py:674-698)."""
+    return [c for head in model_output_channel_info if head != "class" for c in head.split("+") if c]
+
+
+def _generate_rays(n_rays: int, ndim: int) -> "np.ndarray":
+    """Unit ray directions in Cartesian (x, y[, z]) order, float32: uniform angles in 2-D, the Fibonacci sphere in 3-D
+    (biapy/data/pre_processing.py:2058-2097 without jitter)."""
+    if ndim == 2:
+        a = np.linspace(0, 2 * np.pi, n_rays, endpoint=False, dtype=np.float32)
+        return np.stack([np.cos(a), np.sin(a)], axis=1).astype(np.float32)
+    k = np.arange(n_rays, dtype=np.float32)
+    z = 1 - 2 * (k + 0.5) / n_rays
+    rad = np.sqrt(np.maximum(0.0, 1 - z * z))
+    theta = 2 * np.pi * k / ((1 + np.sqrt(5.0)) / 2.0)
+    d = np.stack([rad * np.cos(theta), rad * np.sin(theta), z], axis=1).astype(np.float32)
+    return d / (np.linalg.norm(d, axis=1, keepdims=True) + 1e-12)
+
+
+def build_tta_spec(channel_names: Sequence[str], ndim: int, channel_extra_opts: Optional[Dict] = None, anisotropy: Optional[Sequence[float]] = None) -> "TTASpec":
+    """The spec of ``build_tta_spec`` (tta.py:700-866) from the physical channel names: flows / HoVer maps -> signed vectors, ``E_offset_i`` /
+    ``E_sigma_i`` (i in Cartesian x, y, z order) -> signed / unsigned vectors with the voxel spacing as their axis scale, ``R_k`` -> rays,
+    ``A{z,y,x}_d`` -> affinities, everything else scalar.  Same group order and group names as the reference."""
+    import re
+
+    letters = _AXIS_LETTERS[ndim]
+    names = list(channel_names)
+    groups: List[object] = []
+    taken = set()
+
+    def axis_of(letter):
+        return letters.index(letter) if letter in letters else None
+
+    for family in ("flow", "hover"):
+        comp = {nm: names.index(nm) for nm, (fam, _) in _COMPONENTS.items() if fam == family and nm in names}
+        if not comp:
+            continue
+        per_axis: List[Optional[int]] = [None] * ndim
+        for nm, ch in comp.items():
+            ax = axis_of(_COMPONENTS[nm][1])
+            taken.add(ch)
+            if ax is None:                                     # a z component declared on 2-D data carries no in-plane direction
+                groups.append(ScalarChannels(channels=(ch,)))
+            else:
+                per_axis[ax] = ch
+        if any(c is not None for c in per_axis):
+            groups.append(VectorChannels(axis_channels=tuple(per_axis), signed=True, name=family))
+    scale = tuple(float(v) for v in anisotropy) if anisotropy is not None and len(anisotropy) == ndim else None
+    for fam in ("E_offset", "E_sigma"):
+        comps = {int(m.group(1)): i for i, nm in enumerate(names) if (m := re.match(r"^%s_(\d+)$" % fam, nm))}
+        if not comps:
+            continue
+        per_axis = [None] * ndim
+        for cart, ch in comps.items():
+            ax = axis_of({0: "x", 1: "y", 2: "z"}.get(cart, "?"))
+            taken.add(ch)
+            if ax is None:
+                groups.append(ScalarChannels(channels=(ch,)))
+            else:
+                per_axis[ax] = ch
+        if any(c is not None for c in per_axis):
+            groups.append(VectorChannels(axis_channels=tuple(per_axis), signed=(fam == "E_offset"), axis_scale=scale, name=fam))
+    rays = sorted((int(m.group(1)), i) for i, nm in enumerate(names) if (m := re.match(r"^R_(\d+)$", nm)))
+    if rays:
+        pos = [i for _, i in rays]
+        if pos != list(range(pos[0], pos[0] + len(pos))):
+            raise ValueError("StarDist ray channels must be contiguous; got positions {}".format(pos))
+        want = int((channel_extra_opts or {}).get("R", {}).get("nrays", len(pos)))
+        if want != len(pos):
+            raise ValueError("'R' declares nrays={} but {} ray output channels were found".format(want, len(pos)))
+        d = np.asarray(_generate_rays(len(pos), ndim), dtype=np.float64)[:, ::-1].copy()        # Cartesian -> spatial-axis order
+        d /= np.linalg.norm(d, axis=1, keepdims=True) + 1e-12
+        groups.append(RayChannels(start=pos[0], dirs=d))
+        taken.update(pos)
+    layout: Dict[Tuple[int, int], int] = {}
+    for i, nm in enumerate(names):
+        m = re.match(r"^A([zyx])_(-?\d+)$", nm)
+        if m:
+            ax = axis_of(m.group(1))
+            taken.add(i)
+            if ax is None:
+                groups.append(ScalarChannels(channels=(i,)))
+            else:
+                layout[(ax, int(m.group(2)))] = i
+    if layout:
+        groups.append(AffinityChannels(layout=layout))
+    rest = tuple(i for i in range(len(names)) if i not in taken)
+    if rest:
+        groups.append(ScalarChannels(channels=rest))
+    covered = sorted(c for g in groups for c in _group_channels(g))
+    if covered != list(range(len(names))):
+        raise ValueError("TTA spec does not cover every output channel exactly once (covered {} of {}); channel names were {}".format(len(covered), len(names), names))
+    return TTASpec(ndim=ndim, n_channels=len(names), groups=groups)
+
+
+def _group_channels(g) -> Tuple[int, ...]:
+    k = _kind(g)
+    if k == "vector":
+        return tuple(c for c in g.axis_channels if c is not None)
+    if k == "rays":
+        return tuple(range(g.start, g.start + len(g.dirs)))
+    if k == "affinities":
+        return tuple(sorted(g.layout.values()))
+    return tuple(g.channels)
+
+
 def _inverse(perm, sign):
     """tta.py:125-137."""
     n = len(perm)

@@ -333,6 +333,28 @@ def tta_spec_fixtures():
     r = pp.ensemble_predictions(img, lambda b: torch.from_numpy(TO.standin_pred_multi(np.asarray(b), len(names))).permute(*fwd), back, fwd, torch.device("cpu"), 3,
                                 batch_size_value=4, mode="max", tta_spec=spec, group="full")
     out["from_names/max/full/4"] = r.permute(*back)[0].numpy()
+    # build_tta_spec itself: the structure of the spec for a set of channel-name lists (what biapy_amd.tta.build_tta_spec has to reproduce)
+    import json
+
+    def dump(spec):
+        gs = []
+        for g in spec.groups:
+            d = {"cls": type(g).__name__, "name": g.name}
+            if isinstance(g, tt.VectorChannels):
+                d.update(axis_channels=list(g.axis_channels), signed=bool(g.signed), axis_scale=None if g.axis_scale is None else [float(v) for v in g.axis_scale])
+            elif isinstance(g, tt.RayChannels):
+                d.update(start=int(g.start), dirs=np.asarray(g.dirs, dtype=np.float64).tolist())
+            elif isinstance(g, tt.AffinityChannels):
+                d.update(layout=[[int(a), int(o), int(c)] for (a, o), c in sorted(g.layout.items())])
+            else:
+                d.update(channels=[int(c) for c in g.channels])
+            gs.append(d)
+        return {"ndim": spec.ndim, "n_channels": spec.n_channels, "groups": gs}
+
+    TO_NAMES = TO.BUILD_SPEC_CASES
+    for k, (cnames, nd, extra, aniso) in enumerate(TO_NAMES):
+        out[f"build/{k}"] = np.array(json.dumps(dump(tt.build_tta_spec(cnames, nd, extra, aniso))))
+    out["parse/0"] = np.array(json.dumps(tt.parse_model_output_channel_names(["Gv+Gh+B", "class"])))
     np.savez_compressed(os.path.join(HERE, "tta_spec_golden.npz"), **out)
     print("tta_spec_golden.npz:", len(out), "arrays")
 

@@ -541,3 +541,35 @@ def test_tta_spec_host_logic_matches_the_reference(tta_spec_golden):
     # the reference names vector groups after their family ("flow", "E_sigma", ...): the kind comes from the fields, not from the name
     assert T._kind(T.VectorChannels(axis_channels=(0, 1, 2), name="flow")) == "vector" and T._kind(T.RayChannels(name="stardist")) == "rays"
     assert T._kind(T.AffinityChannels(name="aff")) == "affinities" and T._kind(T.ScalarChannels(channels=(0,))) == "scalar"
+
+
+def test_build_tta_spec_reproduces_the_reference(tta_spec_golden):
+    """biapy_amd.tta.build_tta_spec / parse_model_output_channel_names (host logic) against the structures the reference's functions returned for the
+    same channel-name lists (flows, HoVer maps incl. a z component on 2-D data, EmbedSeg offsets / sigmas with anisotropy, 2-D and 3-D rays,
+    affinities, plain B/C/D): group order, classes, names and every field; ray directions to 1e-6."""
+    import json
+
+    from biapy_amd import tta as T
+    from oracle import tta_oracle as TO
+
+    for k, (names, ndim, extra, aniso) in enumerate(TO.BUILD_SPEC_CASES):
+        want = json.loads(str(tta_spec_golden[f"build/{k}"]))
+        spec = T.build_tta_spec(names, ndim, extra, aniso)
+        assert (spec.ndim, spec.n_channels, len(spec.groups)) == (want["ndim"], want["n_channels"], len(want["groups"])), names
+        for g, w in zip(spec.groups, want["groups"]):
+            assert type(g).__name__ == w["cls"] and g.name == w["name"], (names, g, w)
+            if w["cls"] == "VectorChannels":
+                assert list(g.axis_channels) == w["axis_channels"] and bool(g.signed) == w["signed"]
+                assert (g.axis_scale is None) == (w["axis_scale"] is None) and (g.axis_scale is None or list(g.axis_scale) == w["axis_scale"])
+            elif w["cls"] == "RayChannels":
+                assert g.start == w["start"]
+                np.testing.assert_allclose(np.asarray(g.dirs), np.asarray(w["dirs"]), atol=1e-6)
+            elif w["cls"] == "AffinityChannels":
+                assert sorted([a, o, c] for (a, o), c in g.layout.items()) == w["layout"]
+            else:
+                assert list(g.channels) == w["channels"]
+    assert T.parse_model_output_channel_names(["Gv+Gh+B", "class"]) == json.loads(str(tta_spec_golden["parse/0"]))
+    with pytest.raises(ValueError, match="contiguous"):
+        T.build_tta_spec(["R_0", "B", "R_1"], 2)
+    with pytest.raises(ValueError, match="nrays"):
+        T.build_tta_spec(["R_0", "R_1"], 2, {"R": {"nrays": 4}})
