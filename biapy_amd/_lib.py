@@ -80,6 +80,12 @@ _SIGS = {
     "bpx_conv3d_wgrad": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_conv3d_wgrad_db2": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_conv3d_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
+    "bpx_conv3d_bwd_fused_supported": ([_i, _i, _i, _i, _i, _i, _i], _i),
+    "bpx_conv3d_bwd_fused_stats_tiles": ([_i, _i, _i], _i),
+    "bpx_conv3d_bwd_fused_workspace": ([_i, _i, _i, _i, _i, _i], _i64),
+    "bpx_conv3d_bwd_fused": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i),
+    "bpx_debug_set_bwd_fused": ([_i], _i),
+    "bpx_debug_set_tile_order": ([_i], _i),
     "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
     "bpx_conv1x1_fwd_split": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, Tensor, _vp], _i),

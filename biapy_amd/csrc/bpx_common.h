@@ -209,4 +209,7 @@ static inline size_t dtype_size(int dt) {
 namespace bpxred {
 int reduce_partials(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
                     const float* dbpart, float* db, int ndb, bool may_defer, hipStream_t s);
+// the same with a second destination db2 of the bias sums (bwd_fused.hip: the shortcut bias of a residual block)
+int reduce_partials2(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
+                     const float* dbpart, float* db, float* db2, int ndb, bool may_defer, hipStream_t s);
 }

@@ -1,0 +1,442 @@
+// Backward of one 3x3x3 convolution in ONE pass over its operands: input gradient (dgrad, fused with the backward of the activation that
+// precedes the conv and with the InstanceNorm reductions) AND weight / bias gradient (wgrad).
+//
+//   g[v][ci]        = sum_{tap,co} W[co][ci][tap] * dy[v - (tap - 1)][co] * act'(scale * t[v][ci] + shift)          (bpx_conv3d_dgrad)
+//   dW[tap][ci][co] = sum_u act(scale * t[u][ci] + shift) * dy[u - (tap - 1)][co]                                    (bpx_conv3d_wgrad, shift-dy form)
+//
+// Both kernels stage the SAME two operands per tile - the haloed dy tile ([voxel][16 ch], 32 B per voxel, raw copy) and the un-haloed raw input
+// tile t - and both are bound by that staging chain / by HBM requests at the 16-channel 128^3 layers, not by the matrix unit (DESIGN.md
+// section 6): 16 -> 16 @128^3 moves 3 U + 2 U (U = 268 MB, one 16-channel tensor) as two kernels and 3 U here; 16 -> 48 moves 7 U + 4 U against 7 U.
+// The kernel is a composition of tested parts: the MFMA step loop and the dgrad epilogue of conv3_lp_kernel (conv3d_lean.hip, 4x4x16 tile) and
+// the windowed shift-dy MFMA phase of wgrad_sdm_kernel (wgrad_shared.h); what is new is the staging:
+//   * dy halo and raw t tile arrive by `buffer_load ... lds` (no staging VGPRs, no ds_write pass; out-of-volume pieces use an out-of-range
+//     buffer offset and land as zeros = the convolution's zero padding);
+//   * a transform pass reads the raw t pieces back (each thread the pieces it requested itself: no barrier), applies normalise + activation
+//     once per voxel and writes the bf16 MFMA operand of the wgrad phase; the raw copy stays in LDS for the dgrad epilogue (ELU' and the
+//     normalised value need the raw t at every output voxel - formerly a second fetch of the tile from L2);
+//   * persistent workgroups, XCD-contiguous tile ranges walked in y-strips (conv3d_shared.h decode_tile) so that halo re-reads hit the XCD's L2.
+// dy has 16 channels (one chunk); t / g have 16 * CT channels.  Per-workgroup wgrad partials [grid][27][16 CT][16] are reduced by the batched
+// fixed-order reduction of wgrad.hip (bpxred), so the parameter gradients stay bit-reproducible.
+#include "conv3d_shared.h"
+#include "wgrad_shared.h"
+
+using namespace bpxconv;
+
+// workgroups per CU the 16-channel instance is compiled for (LDS admits 4: 37.8 KB each)
+#ifndef BPX_BWD_OCC1
+#define BPX_BWD_OCC1 4
+#endif
+
+namespace {
+
+struct BwdParams {
+  int N, D, H, W;
+  const void* dy; int dy_ld;                       // (N, D, H, W, 16) bf16
+  const void* wT;                                  // BPX_PK_K3_T pack of the conv weight: [1][QPAD][Ct][8] bf16
+  const void* t; int t_ld; int t_cs; int Ct;       // the conv's raw input (fp16 with TF16, else bf16), Ct = 16 * CT channels, maybe chunk-planar
+  const bpx_norm_rec* t_norm; int act;
+  void* g; int g_ld;                               // (N, D, H, W, Ct) bf16
+  float* red;                                      // [N][tilesPerSample][2][Ct] partials of sum(g), sum(g * xhat)
+  float* part; float* dbpart; int want_db;         // [grid][27][Ct][16] weight-gradient partials, [grid][16] bias-gradient partials
+  int tilesZ, tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd, stripY;
+};
+
+template <int CT, int ACTK, bool TF16>
+__global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_kernel(const BwdParams p) {
+  using T = uint16_t;                                                   // gradients, weights, MFMA operands: bf16
+  using TT = typename std::conditional<TF16, f16_t, uint16_t>::type;    // storage type of the activation t
+  constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int KPL = 8, VB = 32, NS = CT, MS = 4, STEPS = 14;
+  constexpr int NPGT = HV * 2, NPG = (NPGT + 255) / 256;               // 16-byte pieces of the dy halo; piece idx at LDS byte idx * 16
+  constexpr int SG_BYTES = HV * VB + 64;                                // + window over-read of the last halo row (sd_mfma_phase)
+  constexpr int ST_BYTES = CT * TV * VB;
+  constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
+  constexpr int HSTR = HX * VB;
+  constexpr int WD = NS == 1 ? 2 : 1;
+  constexpr int NKC = TV / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SG_BYTES + 2 * ST_BYTES + RED_BYTES + CT * 16 * 8];
+  unsigned char* sG = smem;                                             // dy halo [HV][32 B]
+  unsigned char* sT = smem + SG_BYTES;                                  // raw t tile [CT][TV][32 B]
+  unsigned char* sA = sT + ST_BYTES;                                    // act(norm(t)) as bf16 [CT][TV][32 B]
+  float* red = reinterpret_cast<float*>(sA + ST_BYTES);                 // statistics scratch [wave][NS * 16][2]
+  float* sN = red + RED_BYTES / 4;                                      // [CT * 16][scale, shift]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W, Ct = p.Ct;
+
+  // ---- per-workgroup constants ------------------------------------------------------------------------------------------------------
+  // dgrad phase (conv3_lp_kernel, TX = 16): this lane's output voxel of m-subtile 0 is (wave, 0, j); m-subtile ms adds ms rows
+  const int cg_off = (g & 1) * 16;
+  const bool hi_tap = (g >> 1) != 0;
+  const int hb0 = ((wave * HY) * HX + j) * VB + cg_off;
+  const int lbase[4] = {hb0 + (hi_tap ? VB : 0), hb0 + (hi_tap ? HX * VB : 0), hb0 + (hi_tap ? HY * HX * VB : 0), hb0};
+  const int evox_rel = (wave * H) * W + j;
+  const char* __restrict__ wp = reinterpret_cast<const char*>(p.wT);
+  const uint32_t wlane = (uint32_t)((g * Ct + j) * KPL) * 2u;
+  // wgrad phase (wgrad_sdm_kernel): transposing-read bases
+  const int trl = (j >> 2), trc = (j & 3) * 8;
+  const int a_base = g * 8 * VB + trl * VB + trc;
+  const int g_lane = (((g >> 1) * HX + (g & 1) * 8) + trl) * VB + trc;
+  // staging: byte offsets of this thread's pieces relative to the halo / tile origin, and the halo coordinates of the dy pieces (edge tiles)
+  const int sub = tid & 1;
+  uint32_t rel_g[NPG], rel_t[2], hc[(NPG + 1) / 2];
+#pragma unroll
+  for (int u = 0; u < (NPG + 1) / 2; ++u) hc[u] = 0u;
+#pragma unroll
+  for (int u = 0; u < NPG; ++u) {
+    const int hv = (u * 256 + tid) >> 1;
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    rel_g[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.dy_ld + sub * KPL) * 2u;
+    hc[u >> 1] |= ((uint32_t)hz | ((uint32_t)hy << 4) | ((uint32_t)hx << 8)) << (16 * (u & 1));
+    asm volatile("" : "+v"(rel_g[u]));
+  }
+#pragma unroll
+  for (int u = 0; u < (NPG + 1) / 2; ++u) asm volatile("" : "+v"(hc[u]));
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tv = (u * 256 + tid) >> 1;
+    rel_t[u] = (uint32_t)((((tv >> 6) * H + ((tv >> 4) & 3)) * W + (tv & 15)) * p.t_ld + sub * KPL) * 2u;
+    asm volatile("" : "+v"(rel_t[u]));
+  }
+  const bool last_ok = (NPG - 1) * 256 + tid < NPGT;
+  const uint32_t t_csb = (uint32_t)p.t_cs * 2u;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t), 0, (int)0x80000000u, 0x00020000);
+  constexpr uint32_t OOR = 0x80000000u;   // out of range of the buffer: the DMA writes zeros
+
+  f32x4_t accw[7][CT];                    // weight-gradient accumulators of this wave's taps [7 wave, 7 wave + 7), kept over all tiles
+#pragma unroll
+  for (int a = 0; a < 7; ++a)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) accw[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool want_b = p.want_db != 0;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
+  int n_cur = -1;
+
+  for (int local = slot; local < p.tilesPerXcd; local += spx) {
+    const int tileId = xcd * p.tilesPerXcd + local;
+    if (tileId >= p.totalTiles) break;
+    int n, tzi, tyi, txi;
+    decode_tile(tileId, p.tilesZ, p.tilesY, p.tilesX, p.tilesPerSample, p.stripY, n, tzi, tyi, txi);
+    const int tile = (tzi * p.tilesY + tyi) * p.tilesX + txi;
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    const bool interior = full && z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+    const uint32_t base_g = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.dy_ld * 2u;
+    const uint32_t base_t = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.t_ld * 2u;
+
+    __syncthreads();   // the previous tile's MFMA phases and epilogue are done with sG / sT / sA
+    // ---- staging: LDS-DMA of the raw t tile and of the dy halo ---------------------------------------------------------------------
+    bool okt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int tv = (u * 256 + tid) >> 1;
+      okt[u] = full || (z0 + (tv >> 6) < D && y0 + ((tv >> 4) & 3) < H && x0 + (tv & 15) < W);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(sT + c * TV * VB + (u * 256 + wave * 64) * 16), 16,
+                                                 okt[u] ? base_t + rel_t[u] + (uint32_t)c * t_csb : OOR, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NPG; ++u) {
+      bool ok = true;
+      if (!interior) {
+        const uint32_t c = hc[u >> 1] >> (16 * (u & 1));
+        ok = (unsigned)(z0 - 1 + (int)(c & 15u)) < (unsigned)D && (unsigned)(y0 - 1 + (int)((c >> 4) & 15u)) < (unsigned)H &&
+             (unsigned)(x0 - 1 + (int)((c >> 8) & 255u)) < (unsigned)W;
+      }
+      const uint32_t off = ok ? base_g + rel_g[u] : OOR;
+      if (u < NPG - 1 || last_ok)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sG + (u * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+    }
+    if (n != n_cur) {   // uniform: a workgroup crosses a sample boundary at most N - 1 times
+      if (tid < CT * 16) {
+        const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(&p.t_norm[(size_t)n * Ct + tid].scale);
+        sN[2 * tid] = ss[0]; sN[2 * tid + 1] = ss[1];
+      }
+      n_cur = n;
+      __syncthreads();
+    }
+    // ---- transform: raw t -> normalise + activation -> bf16 operand of the wgrad phase (own pieces only: no barrier before it) --------
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces have landed
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float psc[KPL], psh[KPL];
+      {
+        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(sN + 2 * (c * 16 + sub * KPL));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x4_t v = q[e];
+          psc[2 * e] = v[0]; psh[2 * e] = v[1]; psc[2 * e + 1] = v[2]; psh[2 * e + 1] = v[3];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(sT + c * TV * VB + (u * 256 + tid) * 16);
+        if (okt[u]) {   // out-of-volume voxels of ragged tiles stay zero: the conv's padding applies to the ACTIVATED tensor
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a = fmaf(psc[2 * q], lo16<TT>(v[q]), psh[2 * q]), b = fmaf(psc[2 * q + 1], hi16<TT>(v[q]), psh[2 * q + 1]);
+            act_pair<ACTK>(a, b, p.act);
+            v[q] = cvt_pk_bf16(a, b);
+          }
+        }
+        *reinterpret_cast<u32x4_t*>(sA + c * TV * VB + (u * 256 + tid) * 16) = v;
+      }
+    }
+    __syncthreads();   // every wave's DMA pieces and activated pieces are visible
+
+    // ---- phase A: dgrad MFMA steps (conv3_lp_kernel's step loop on the dy halo; one input chunk of 16 dy channels) -------------------
+    f32x4_t acc[MS][NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+      // the packed weights are re-read per tile through a base the compiler cannot see through: otherwise it hoists the 14 x NS 64-bit lane
+      // addresses out of the tile loop (84 VGPRs for NS = 3, spilled) instead of forming SGPR base + 32-bit lane offset per step
+      const char* wl = wp;
+      asm volatile("" : "+s"(wl));
+      u32x4_t wq[WD + 1][NS];
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)d * 4 * Ct * 16 + (wlane + ns * 256u));
+      constexpr bool REUSE = NS == 1;
+      if constexpr (REUSE) {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+          u32x4_t row[MS + 2];
+#pragma unroll
+          for (int r = 0; r < MS + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(sG + lbase[0] + r * HSTR + tap_off<HY, HX, VB>(9 * dz));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dyy = 0; dyy < 3; ++dyy) {
+            const int s = 3 * dz + dyy;
+            if (s + WD < STEPS) {
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns)
+                wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)(s + WD) * 4 * Ct * 16 + (wlane + ns * 256u));
+            }
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], row[ms + dyy], acc[ms][ns]);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = REUSE ? 9 : 0; s < STEPS; ++s) {
+        if (s + WD < STEPS) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)(s + WD) * 4 * Ct * 16 + (wlane + ns * 256u));
+        }
+        const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
+        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
+        u32x4_t af[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(sG + lbase[cls] + ms * HSTR + imm);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[ms][ns]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- dgrad epilogue: g = acc * act'(scale t + shift), partials of sum(g) and sum(g xhat), 8-byte stores -----------------------------
+    {
+      const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;
+      const bool okzx = full || (z0 + wave < D && x0 + j < W);
+      const int yrem = full ? (1 << 20) : H - y0;
+      char* __restrict__ yout = reinterpret_cast<char*>(p.g);
+      const uint32_t yrow = (uint32_t)(W * p.g_ld) * 2u;
+      const uint32_t yb0 = (uint32_t)(vox0 * p.g_ld + g * 4) * 2u;
+      const unsigned char* tl = sT + ((wave * MS) * 16 + j) * VB + g * 8;   // raw t of (voxel (wave, ms, j), channels 4 g .. 4 g + 3): + ms * 512 + ns * TV * VB
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        u32x2_t tv[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) tv[ms] = *reinterpret_cast<const u32x2_t*>(tl + ns * TV * VB + ms * 16 * VB);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ACTK == 1) {
+#pragma unroll
+          for (int rp = 0; rp < 4; rp += 2) {
+            const f32x4_t* rsrc = reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + ns * 16 + g * 4 + rp]);
+            const f32x4_t ra = rsrc[0], rb = rsrc[1];
+            const f32x2_t sc2{ra[2], rb[2]}, sh2{ra[3], rb[3]}, rs2{ra[1], rb[1]}, nm2{-ra[0] * ra[1], -rb[0] * rb[1]};
+            f32x2_t s1p{0.f, 0.f}, s2p{0.f, 0.f};
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+              const uint32_t w = tv[ms][rp >> 1];
+              const f32x2_t tt{lo16<TT>(w), hi16<TT>(w)};
+              const f32x2_t u = __builtin_elementwise_fma(sc2, tt, sh2);
+              const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
+              const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
+              f32x2_t a{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
+              const bool in = okzx && ms < yrem;
+              const f32x2_t gv = in ? f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a : f32x2_t{0.f, 0.f};
+              acc[ms][ns][rp] = gv[0]; acc[ms][ns][rp + 1] = gv[1];
+              s1p = s1p + gv;
+              s2p = __builtin_elementwise_fma(gv, xh, s2p);
+            }
+            s1[rp] = s1p[0]; s1[rp + 1] = s1p[1]; s2[rp] = s2p[0]; s2[rp + 1] = s2p[1];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4_t rec = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + ns * 16 + g * 4 + r]);
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+              const uint32_t w = tv[ms][r >> 1];
+              const float tf = (r & 1) ? hi16<TT>(w) : lo16<TT>(w);
+              const float u = fmaf(rec[2], tf, rec[3]);
+              const float gv = (okzx && ms < yrem) ? acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.act) : 0.f;
+              acc[ms][ns][r] = gv;
+              s1[r] += gv;
+              s2[r] += gv * ((tf - rec[0]) * rec[1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          if (okzx && ms < yrem)
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = u32x2_t{cvt_pk_bf16(acc[ms][ns][0], acc[ms][ns][1]), cvt_pk_bf16(acc[ms][ns][2], acc[ms][ns][3])};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
+          if (j == 0) *reinterpret_cast<f32x2_t*>(&red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NS * 16 * 2) {
+      const int c = tid >> 1, k = tid & 1;
+      const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] + red[(3 * NS * 16 + c) * 2 + k];
+      p.red[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Ct + c] = a;
+    }
+
+    // ---- phase B: wgrad MFMA steps (windowed shift-dy phase of wgrad_sdm_kernel) on the same staged operands -----------------------------
+    switch (wave) {   // wave-uniform
+      case 0: bpxwg::sd_mfma_phase<0, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
+      case 1: bpxwg::sd_mfma_phase<1, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
+      case 2: bpxwg::sd_mfma_phase<2, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
+      default: bpxwg::sd_mfma_phase<3, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
+    }
+  }
+
+  // ---- flush of the weight-gradient partials: lane holds D[ci = 4 g + r][co = j] of its taps ---------------------------------------------
+  float* pp = p.part + (size_t)blockIdx.x * 27 * Ct * 16;
+#pragma unroll
+  for (int a = 0; a < 7; ++a) {
+    const int tap = 7 * wave + a;
+    if (tap >= 27) continue;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[((size_t)tap * Ct + c * 16 + 4 * g + r) * 16 + j] = accw[a][c][r];
+  }
+  if (want_b && wave == 3 && g == 0) p.dbpart[(size_t)blockIdx.x * 16 + j] = accw[6][0][0];
+}
+
+int cu_count_() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+int g_bwd_fused = 1;   // test / A-B hook (bpx_debug_set_bwd_fused)
+
+struct BwdPlan { int grid, tilesZ, tilesY, tilesX; };
+BwdPlan bwd_plan(int N, int D, int H, int W, int Ct) {
+  BwdPlan q;
+  q.tilesZ = cdiv(D, 4); q.tilesY = cdiv(H, 4); q.tilesX = cdiv(W, 16);
+  const int total = N * q.tilesZ * q.tilesY * q.tilesX;
+  const int occ = Ct == 16 ? BPX_BWD_OCC1 : 2;
+  int gx = std::max(8, (cu_count_() * occ) & ~7);
+  gx = std::min(gx, 8 * cdiv(total, 8));
+  q.grid = gx;
+  return q;
+}
+
+bool bwd_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) {
+  if (!g_bwd_fused) return false;
+  if (dtype != BPX_BF16 && dtype != BPX_MIX16) return false;
+  if (Cdy != 16 || (Ct != 16 && Ct != 48)) return false;
+  const int64_t vps = (int64_t)D * H * W, vox = vps * N;
+  return W > 8 && vps >= 32768 && vox * 48 * 2 < (1ll << 31);
+}
+
+}  // namespace
+
+extern "C" int bpx_debug_set_bwd_fused(int on) { g_bwd_fused = on; return 0; }
+
+extern "C" int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) { return bwd_supported(dtype, N, D, H, W, Ct, Cdy) ? 1 : 0; }
+
+extern "C" int bpx_conv3d_bwd_fused_stats_tiles(int D, int H, int W) { return cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16); }
+
+extern "C" int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy) {
+  const BwdPlan q = bwd_plan(N, D, H, W, Ct);
+  return (int64_t)q.grid * ((int64_t)27 * Ct + 1) * Cdy * 4;
+}
+
+extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,
+                                    const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, float* dw_d, float* db_d, float* db2_d,
+                                    void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_bwd_fused";
+  BPX_CHECK(bwd_supported(dtype, N, D, H, W, t.C, dy.C), "%s: unsupported configuration (bpx_conv3d_bwd_fused_supported)", fn);
+  BPX_CHECK(dy.ptr && t.ptr && g.ptr && w_packed_T_d && t_norm_d && red_part_d && dw_d && ws_d, "%s: null pointer", fn);
+  BPX_CHECK(db2_d == nullptr || db_d != nullptr, "%s: db2_d needs db_d", fn);
+  BPX_CHECK(dy.cs == 0 && g.cs == 0, "%s: only t may be chunk-planar", fn);
+  BPX_CHECK(g.C == t.C && g.ld >= g.C && dy.ld >= 16, "%s: g.C %d != t.C %d or bad pitch", fn, g.C, t.C);
+  BPX_CHECK(((uintptr_t)dy.ptr % 16) == 0 && ((uintptr_t)t.ptr % 16) == 0 && ((uintptr_t)g.ptr % 8) == 0 && (dy.ld * 2) % 16 == 0 && (t.ld * 2) % 16 == 0 &&
+                (g.ld * 2) % 8 == 0 && ((uintptr_t)t_norm_d % 16) == 0,
+            "%s: operands must be 16-byte aligned", fn);
+  const int64_t vox = (int64_t)N * D * H * W;
+  BPX_CHECK(t.cs == 0 || (t.ld >= 16 && t.cs % 8 == 0 && t.cs >= (vox - 1) * t.ld + 16), "%s: bad chunk stride %lld", fn, (long long)t.cs);
+  const int64_t tbytes = 2 * (t.cs ? (int64_t)t.cs * (t.C / 16 - 1) + (vox - 1) * t.ld + 16 : vox * (int64_t)t.ld);
+  BPX_CHECK(tbytes < (1ll << 31) && vox * dy.ld * 2 < (1ll << 31) && vox * g.ld * 2 < (1ll << 32), "%s: tensors beyond the 32-bit / buffer addressing range", fn);
+  const BwdPlan q = bwd_plan(N, D, H, W, t.C);
+  const int64_t need = (int64_t)q.grid * ((int64_t)27 * t.C + 1) * 16 * 4;
+  BPX_CHECK(ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
+  BwdParams p{};
+  p.N = N; p.D = D; p.H = H; p.W = W;
+  p.dy = dy.ptr; p.dy_ld = dy.ld;
+  p.wT = w_packed_T_d;
+  p.t = t.ptr; p.t_ld = t.ld; p.t_cs = t.cs ? (int)t.cs : 16; p.Ct = t.C;
+  p.t_norm = t_norm_d; p.act = act;
+  p.g = g.ptr; p.g_ld = g.ld;
+  p.red = red_part_d;
+  p.part = reinterpret_cast<float*>(ws_d);
+  p.dbpart = p.part + (size_t)q.grid * 27 * t.C * 16;
+  p.want_db = db_d != nullptr;
+  p.tilesZ = q.tilesZ; p.tilesY = q.tilesY; p.tilesX = q.tilesX;
+  p.tilesPerSample = q.tilesZ * q.tilesY * q.tilesX;
+  p.totalTiles = N * p.tilesPerSample;
+  p.tilesPerXcd = cdiv(p.totalTiles, 8);
+  p.stripY = strip_rows(q.tilesX);
+  const bool mix = dtype == BPX_MIX16, elu = act == BPX_ACT_ELU;
+  hipStream_t s = (hipStream_t)stream;
+#define LB(CT_)                                                                                       \
+  if (t.C == 16 * CT_) {                                                                              \
+    if (mix) { if (elu) conv3_bwd_kernel<CT_, 1, true><<<q.grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CT_, 0, true><<<q.grid, 256, 0, s>>>(p); }   \
+    else { if (elu) conv3_bwd_kernel<CT_, 1, false><<<q.grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CT_, 0, false><<<q.grid, 256, 0, s>>>(p); }     \
+  }
+  LB(1) LB(3)
+#undef LB
+  BPX_LAUNCH_CHECK(fn);
+  // dW in the PyTorch layout (Cout = 16, Cin = Ct, 3, 3, 3): index = ci * 27 + co * Ct * 27 + tap
+  return bpxred::reduce_partials2(fn, p.part, dw_d, q.grid, 27, t.C, 16, 27, (int64_t)t.C * 27, 1, p.dbpart, db_d, db2_d, 0, true, s);
+}

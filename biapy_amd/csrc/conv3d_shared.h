@@ -65,6 +65,25 @@ template <int HY, int HX, int VB> __device__ __forceinline__ constexpr int tap_o
   return (((tap / 9) * HY + ((tap / 3) % 3)) * HX + (tap % 3)) * VB;
 }
 
+// Tile walk of the persistent kernels.  XCD x owns the contiguous id range [x T/8, (x + 1) T/8) and its co-resident workgroups sit on
+// consecutive ids; ids enumerate a sample's tiles in Y-STRIPS: (strip of `stripY` tile rows, z, row inside the strip, x).  The ~100 tiles an
+// XCD works on at a time then form a block of a few z-planes x stripY rows x all x instead of half a z-plane: the y and z neighbours whose
+// halos a tile re-reads were fetched by the same XCD a moment ago and sit in its 4 MB L2 (z-major order: the z neighbour is tilesY * tilesX
+// ids away and long evicted).  strip_rows: ~32 tiles per z step of a strip.
+__host__ __device__ inline int strip_rows(int tilesX) { const int r = 32 / (tilesX > 0 ? tilesX : 1); return r < 1 ? 1 : r; }
+__device__ __forceinline__ void decode_tile(int id, int tilesZ, int tilesY, int tilesX, int tilesPerSample, int stripY, int& n, int& tzi, int& tyi, int& txi) {
+  n = id / tilesPerSample;
+  const int r = id - n * tilesPerSample;
+  const int per_strip = stripY * tilesZ * tilesX;          // tiles of a full strip (every strip before the last one is full)
+  const int s = r / per_strip, rs = r - s * per_strip;
+  const int left = tilesY - s * stripY, sy = left < stripY ? left : stripY;
+  const int row = sy * tilesX;
+  tzi = rs / row;
+  const int r2 = rs - tzi * row, yin = r2 / tilesX;
+  txi = r2 - yin * tilesX;
+  tyi = s * stripY + yin;
+}
+
 struct TileCfg { int tz, ty, tx, ns; };
 extern int g_conv_dma;   // conv3d_dma.hip: the DMA-pipelined kernel is selectable (bpx_debug_set_conv_ws 6 / 7)
 

@@ -23,9 +23,11 @@
 #include <type_traits>
 #include <vector>
 
-#include "bpx_common.h"
+#include "conv3d_shared.h"
+#include "wgrad_shared.h"
 
 namespace {
+using bpxwg::sd_mfma_phase;
 
 struct WgradParams {
   int N, D, H, W;          // logical voxel grid of the reduction
@@ -40,6 +42,7 @@ struct WgradParams {
   float* dbpart;                                 // [groups][Cout] per-group column sums of dy (workspace, behind `part`): no atomics
   float* db2;                                    // host side only: a second destination of the bias gradient (reduce kernel), or null
   int tilesY, tilesX, tilesPerSample, totalTiles, groups;
+  int tilesZ, stripY, order;   // order 1 (windowed shift-dy kernel): XCD-contiguous tile ranges walked in y-strips (conv3d_shared.h decode_tile); 0: tile = group + k * groups
 };
 
 template <typename T, int ACTK = 0> __device__ __forceinline__ float act_rt(float u, int act) {
@@ -598,87 +601,6 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 3) wgrad_sd_kernel(const Wg
 // reading it again from LDS instead measured 1-2.5 % faster on the 128^3 / 64^3 layers (16->16 256 -> 251 us, 96->32 256 -> 250), flat elsewhere.
 // BPX_WGRAD_REREAD = 2 reads the one-voxel shift from LDS too (two reads instead of a third window read + four v_alignbit per tap; the
 // kernel is VALU-bound, the LDS has slack): 48->16 @128^3 508 -> 477 us, 96->32 @64^3 231 -> 224, 32->32 88 -> 84.5, 16->16 flat
-#ifndef BPX_WGRAD_HC
-#define BPX_WGRAD_HC 2
-#endif
-#ifndef BPX_WGRAD_REREAD
-#define BPX_WGRAD_REREAD 2
-#endif
-// Bias gradient (column sums of dy over the tile's own voxels) on the matrix unit: wave 3 owns six taps, its seventh accumulator is
-// free.  One MFMA per K-chunk of an all-ones A operand with the UN-shifted dy fragment (halo offset (1, 1, 1)) leaves sum_v dy[v][co]
-// in every row of acc[6][0] (bf16 1.0 x dy is exact, the sums are fp32 like the weight gradients) - no extra registers, and it replaces
-// a 16-iteration scalar-load loop over the dy tile that every wave of the workgroup ran per tile (~150 of the kernel's ~540 VALU
-// instructions per tile and wave; the kernel is VALU-bound).
-template <int W, int MC, int HY, int HX, int VBA, int VBG, int TV, int NKC>
-__device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC], bool want_b) {
-  constexpr int T0 = 7 * W, T1 = (T0 + 7 < 27) ? T0 + 7 : 27;
-  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
-#pragma unroll
-  for (int kc = 0; kc < NKC; ++kc) {
-    const int ka = kc * 32 * VBA;
-    const int kg = (((kc >> 1) * HY + (kc & 1) * 2) * HX) * VBG;
-    u32x4_t af[MC];
-#pragma unroll
-    for (int c = 0; c < MC; ++c) {
-      const unsigned char* q = sA + c * TV * VBA + a_base + ka;
-      u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
-      u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBA)));
-      af[c] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
-    }
-#pragma unroll
-    for (int row = T0 / 3; row <= (T1 - 1) / 3; ++row) {
-      const int d0 = (T0 > 3 * row ? T0 : 3 * row) - 3 * row, d1 = (T1 < 3 * row + 3 ? T1 : 3 * row + 3) - 1 - 3 * row;   // dx range of this segment
-      const int smin = 2 - d1, nt = d1 - d0 + 1;
-      const int dz = row / 3, dyy = row % 3;
-      const unsigned char* q = sG + g_lane + kg + ((((2 - dz) * HY + (2 - dyy)) * HX + smin) * VBG);
-      uint32_t w[6];
-      {
-        u32x2_t r0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
-        u32x2_t r1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBG)));
-        w[0] = r0[0]; w[1] = r0[1]; w[2] = r1[0]; w[3] = r1[1]; w[4] = 0u; w[5] = 0u;
-        if (nt > 1 && BPX_WGRAD_REREAD != 2) {
-          u32x2_t r2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 8 * VBG)));
-          w[4] = r2[0]; w[5] = r2[1];
-        }
-      }
-#pragma unroll
-      for (int dx = d1; dx >= d0; --dx) {
-        const int rs = (2 - dx) - smin;   // window shift of this tap in voxels: 0, 1 or 2
-        u32x4_t gf;
-        if (rs == 0) gf = u32x4_t{w[0], w[1], w[2], w[3]};
-        else if (rs == 2) {
-          if (BPX_WGRAD_REREAD) {
-            u32x2_t s0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 2 * VBG)));
-            u32x2_t s1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 6 * VBG)));
-            gf = u32x4_t{s0[0], s0[1], s1[0], s1[1]};
-          } else {
-            gf = u32x4_t{w[1], w[2], w[3], w[4]};
-          }
-        }
-        else if (BPX_WGRAD_REREAD == 2) {   // the one-voxel shift from LDS as well (two reads instead of a third window read + four v_alignbit)
-          u32x2_t s0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 1 * VBG)));
-          u32x2_t s1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 5 * VBG)));
-          gf = u32x4_t{s0[0], s0[1], s1[0], s1[1]};
-        }
-        else gf = u32x4_t{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
-                          __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(w[4], w[3], 16)};
-        const int a = 3 * row + dx - T0;
-#pragma unroll
-        for (int c = 0; c < MC; ++c)
-          acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf), acc[a][c], 0, 0, 0);
-      }
-    }
-    if (W == 3 && want_b) {
-      const unsigned char* q = sG + g_lane + kg + (((1 * HY + 1) * HX + 1) * VBG);
-      u32x2_t r0 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
-      u32x2_t r1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VBG)));
-      const u32x4_t gf = u32x4_t{r0[0], r0[1], r1[0], r1[1]};
-      const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-      acc[6][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, gf), acc[6][0], 0, 0, 0);
-    }
-  }
-}
-
 template <int MC, int ACTK, bool XF16 = false>
 __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_kernel(const WgradParams p) {
   using TXE = typename std::conditional<XF16, f16_t, uint16_t>::type;   // element type of x (BPX_MIX16: fp16)
@@ -749,9 +671,24 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
   const int g_lane = (((g >> 1) * HX + (g & 1) * 8) + trl) * VBG + trc;
   int n_cur = -1;
 
-  for (int tt = grp; tt < p.totalTiles; tt += p.groups) {
-    const int n = tt / p.tilesPerSample, tile = tt - n * p.tilesPerSample;
-    const int z0 = (tile / (p.tilesX * p.tilesY)) * TZ, y0 = ((tile / p.tilesX) % p.tilesY) * TY, x0 = (tile % p.tilesX) * TX;
+  // Tile walk.  order 0 (until round 3): tile = group + k * groups - consecutive groups sit on different XCDs (block b runs on XCD b % 8), so the
+  // dy halo a tile shares with its x / y / z neighbours was re-fetched from HBM by up to three XCDs (PMC: 1.65x the algorithmic bytes).
+  // order 1: the groups of XCD x (grp % 8 == x) own the contiguous id range [x T/nx, (x + 1) T/nx) and walk it side by side in y-strips.
+  const int nx = p.groups < 8 ? p.groups : 8;
+  const int wxcd = grp & 7, wslot = grp >> 3, wspx = (p.groups - wxcd + 7) >> 3, tilesPerXcd = (p.totalTiles + nx - 1) / nx;
+  const int k_end = p.order ? tilesPerXcd : p.totalTiles, k_step = p.order ? wspx : p.groups;
+  for (int kk = p.order ? wslot : grp; kk < k_end; kk += k_step) {
+    int n, tzi, tyi, txi;
+    if (p.order) {
+      const int id = wxcd * tilesPerXcd + kk;
+      if (id >= p.totalTiles) break;
+      bpxconv::decode_tile(id, p.tilesZ, p.tilesY, p.tilesX, p.tilesPerSample, p.stripY, n, tzi, tyi, txi);
+    } else {
+      n = kk / p.tilesPerSample;
+      const int tile = kk - n * p.tilesPerSample;
+      tzi = tile / (p.tilesX * p.tilesY); tyi = (tile / p.tilesX) % p.tilesY; txi = tile % p.tilesX;
+    }
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
     const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
     const bool interior = full && z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
     const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
@@ -1170,6 +1107,7 @@ int g_sd_mc = -1;     // input-channel chunks per workgroup of the windowed shif
                       // shift-dy kernel (hook bits 3..5)
 int g_wgrad_sd = -1;  // -1 automatic (wherever it applies), 0 never, 1 always (bpx_debug_set_wgrad_tr bits 1/2)
 
+int g_sd_order = 1;    // windowed kernel: XCD-contiguous y-strip tile walk (bpx_debug_set_tile_order)
 int g_sd_fill = 100;  // windowed kernel: workgroups launched, in percent of the co-resident capacity (256 CUs x occupancy)
 
 // Plan of the windowed shift-dy kernel: chunks per workgroup and tile groups.  Every workgroup is resident at once (one
@@ -1205,6 +1143,7 @@ int launch_wgrad_sd(const WgradParams& p0, WCfg& c, hipStream_t s) {
   if (ns == 1 && mc > 0) {
     c.groups = q.groups;                                   // the reduce that follows reads this many partial slabs
     p.groups = q.groups;
+    p.tilesZ = cdiv(p.D, 4); p.stripY = bpxconv::strip_rows(p.tilesX); p.order = g_sd_order;
     p.dbpart = p.part + (size_t)p.groups * 27 * p.Cin * p.Cout;
     dim3 gridm((unsigned)(((c.groups + 7) & ~7) * (nchunks / mc) * nb));
 #define SDM(MC_)                                                                                   \
@@ -1258,7 +1197,11 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
 namespace bpxred {
 int reduce_partials(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
                     const float* dbpart, float* db, int ndb, bool may_defer, hipStream_t s) {
-  const ReduceJob j{part, dw, groups, taps, Cin, Cout, si, sj, st, 0, db ? dbpart : nullptr, db, ndb};
+  return reduce_partials2(fn, part, dw, groups, taps, Cin, Cout, si, sj, st, dbpart, db, nullptr, ndb, may_defer, s);
+}
+int reduce_partials2(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
+                     const float* dbpart, float* db, float* db2, int ndb, bool may_defer, hipStream_t s) {
+  const ReduceJob j{part, dw, groups, taps, Cin, Cout, si, sj, st, 0, db ? dbpart : nullptr, db, ndb, db ? db2 : nullptr};
   if (may_defer) return finish_wgrad(fn, j, s);
   wgrad_reduce_kernel<<<reduce_blocks(j), 1024, 0, s>>>(j);   // the caller reads the result right away (head gradients)
   BPX_LAUNCH_CHECK(fn);
@@ -1290,6 +1233,9 @@ extern "C" int bpx_debug_set_wgrad_tr(int use_tr) {
   else g_sd_fill = (use_tr >> 8) ? (use_tr >> 8) : 100;   // bits 8..: workgroups in percent of the co-resident capacity
   return 0;
 }
+
+// test / A-B hook: bit 0 = the windowed shift-dy wgrad kernel walks XCD-contiguous tile ranges in y-strips (default 1)
+extern "C" int bpx_debug_set_tile_order(int bits) { g_sd_order = bits & 1; return 0; }
 
 extern "C" int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                                 bpx_tensor dy, int k, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {

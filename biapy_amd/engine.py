@@ -267,6 +267,20 @@ class ResUNetEngine:
         self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_wgrad_db2(self.bdt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db),
                                                                         L.ptr(db2), ws.data_ptr(), ws.numel(), s_)))
 
+    def _bwd_fused_ok(self, B, S, Ct: int, Cdy: int) -> bool:
+        """One-pass dgrad + wgrad (bpx_conv3d_bwd_fused) for this conv?  Not with the weight-gradient side stream (its point is one staging)."""
+        return (os.environ.get("BPX_BWD_FUSED", "1") != "0" and not self.use_side_stream and self.cfg.gn_groups == 0 and self.dtype != torch.float32
+                and bool(lib.bpx_conv3d_bwd_fused_supported(self.bdt, B, S[0], S[1], S[2], Ct, Cdy)))
+
+    def _bwd_fused(self, B, S, dy: "L.Tensor", wt, t: "L.Tensor", rec, g: "L.Tensor", dw, db, db2, st, dev):
+        D, H, W = S
+        tiles = lib.bpx_conv3d_bwd_fused_stats_tiles(D, H, W)
+        red = torch.empty((B, tiles, 2, t.C), dtype=torch.float32, device=dev)
+        ws = self._workspace(lib.bpx_conv3d_bwd_fused_workspace(B, D, H, W, t.C, dy.C), dev)
+        L.check(lib.bpx_conv3d_bwd_fused(self.bdt, B, D, H, W, dy, wt.data_ptr(), t, rec.data_ptr(), self.act, g, red.data_ptr(),
+                                         dw.data_ptr(), L.ptr(db), L.ptr(db2), ws.data_ptr(), ws.numel(), st))
+        return tiles, red
+
     # ------------------------------------------------------------------------------------------
     def _pack_plan(self, train: bool):
         """(parameter name, pack mode, Cin, Cout) of every packed operand one step needs (forward; + backward if train)."""
@@ -582,7 +596,9 @@ class ResUNetEngine:
         T = self.gdtype
         # conv2 weight/bias grad, shortcut weight grad
         # both biases add to the same tensor: identical gradients, written by the same reduction
-        self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
+        fused2 = self._bwd_fused_ok(B, blk.S, C1, dOut.C)
+        if not fused2:
+            self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
         if blk.first and self.cfg.in_ch == 1:
             ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
             self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.gdt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
@@ -592,11 +608,14 @@ class ResUNetEngine:
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
         self._keep.append(g1)   # read by the side-stream wgrad of conv1
-        tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
-        red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
         w2t = self._pack(P[k["w2"]], L.PK_K3_T, C1, C1, False)
-        L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
-                                     L.tview(g1), red.data_ptr(), st))
+        if fused2:   # dgrad + wgrad of conv2 in one pass over (dOut, h)
+            tiles, red = self._bwd_fused(B, blk.S, dOut, w2t, L.tview(blk.h), blk.rec_h, L.tview(g1), G[k["w2"]], G[k["b2"]], G[k["bsc"]], st, dev)
+        else:
+            tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
+            red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
+            L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
+                                         L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
                                           G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), self.cfg.gn_groups or C1, coef.data_ptr(), st))
@@ -611,18 +630,23 @@ class ResUNetEngine:
             return
         xv = L.tview(blk.x, blk.x_c0, blk.cin)
         has_norm = blk.rec_x is not None
-        self._wgrad(B, blk.S, xv, blk.rec_x, self.act if has_norm else 0, dH, 3, G[k["w1"]], G[k["b1"]], st, dev)
+        Cx = blk.cin
+        fused1 = has_norm and dx_out is not None and self._bwd_fused_ok(B, blk.S, Cx, C1)
+        if not fused1:
+            self._wgrad(B, blk.S, xv, blk.rec_x, self.act if has_norm else 0, dH, 3, G[k["w1"]], G[k["b1"]], st, dev)
         if dx_out is None:
             return
-        Cx = blk.cin
         g0 = torch.empty((B, D, H, W, Cx), dtype=T, device=dev)
         tiles0 = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, Cx)
         w1t = self._pack(P[k["w1"]], L.PK_K3_T, Cx, C1, False)
         wsct = self._pack(P[k["wsc"]], L.PK_DENSE_T, Cx, C1, False)
         if has_norm:
-            red0 = torch.empty((B, tiles0, 2, Cx), dtype=torch.float32, device=dev)
-            L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dH, w1t.data_ptr(), xv, blk.rec_x.data_ptr(), self.act, L.tview(g0),
-                                         red0.data_ptr(), st))
+            if fused1:   # dgrad + wgrad of conv1 in one pass over (dH, x)
+                tiles0, red0 = self._bwd_fused(B, blk.S, dH, w1t, xv, blk.rec_x, L.tview(g0), G[k["w1"]], G[k["b1"]], None, st, dev)
+            else:
+                red0 = torch.empty((B, tiles0, 2, Cx), dtype=torch.float32, device=dev)
+                L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dH, w1t.data_ptr(), xv, blk.rec_x.data_ptr(), self.act, L.tview(g0),
+                                             red0.data_ptr(), st))
             coef0 = torch.empty((B, Cx, 4), dtype=torch.float32, device=dev)
             gng = self.cfg.gn_groups
             if gng and (Cx // gng) not in (1, 2, 4, 8, 16, 32, 64):

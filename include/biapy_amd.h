@@ -47,6 +47,7 @@ int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test / A-B hook of the bf16 3x3x3 conv schedule: 0 = automatic, 4 = always the double-buffered kernel, 5 = always the lean persistent one */
 int bpx_debug_set_conv_occ(int wg_per_cu); /* test / A-B hook: persistent workgroups per CU of the lean bf16 conv kernel (0 = built-in table) */
+int bpx_debug_set_tile_order(int bits); /* test / A-B hook: bit 0 = XCD-contiguous y-strip tile walk of the windowed shift-dy wgrad kernel (default 1; 0 = tile = group + k * groups as until round 3) */
 int bpx_debug_set_tiling_scalar(int on); /* test / A-B hook: 1 = crop / merge through the element-per-thread kernels instead of the 16-byte row kernels */
 
 /* ------------------------------------------------------------------------------------------------
@@ -198,6 +199,23 @@ int bpx_conv3d_wgrad(int dtype, int N, int D, int H, int W, bpx_tensor x, const 
  * the reduction writes both instead of the caller copying one onto the other after the flush. */
 int bpx_conv3d_wgrad_db2(int dtype, int N, int D, int H, int W, bpx_tensor x, const bpx_norm_rec* in_norm_d, int act,
                          bpx_tensor dy, int k, float* dw_d, float* db_d, float* db2_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
+
+/* Backward of ONE 3x3x3 convolution in one pass over its operands: bpx_conv3d_dgrad (g, its sum(g) / sum(g*xhat) partials) AND
+ * bpx_conv3d_wgrad_db2 (dW, db, db2) of the same (dy, t) pair - the two Conv3d gradients autograd computes for blocks.py:154-157 under
+ * train_engine.py:173.  Both kernels stage the same haloed dy tile and the same raw input tile t (t is the conv's raw input; the conv saw
+ * act(scale*t+shift)); fused, dy and t are read once (16 -> 16 channels: 3 tensor passes instead of 5; dy 16 -> t 48: 7 instead of 11).
+ * Results are those of the two separate calls: g and its partials bit for bit those of the 4x4x16-tile dgrad kernel, dW / db fixed-order sums
+ * of per-workgroup partials (bit-reproducible; the grouping of the voxels differs from bpx_conv3d_wgrad's, so the fp32 sums differ in the last bits).
+ * Supported (bpx_conv3d_bwd_fused_supported): dtype BF16 or MIX16 (t fp16), dy.C == 16, t.C in {16, 48}, W > 8, >= 32^3 voxels per sample, t_norm_d
+ * given.  red_part_d: [N][bpx_conv3d_bwd_fused_stats_tiles(D, H, W)][2][t.C] floats.  ws_bytes >= bpx_conv3d_bwd_fused_workspace(...); inside a
+ * bpx_wgrad_defer_begin / _flush window the reduction is queued like bpx_conv3d_wgrad's (own workspace per call).  t may be chunk-planar. */
+int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy);
+int bpx_conv3d_bwd_fused_stats_tiles(int D, int H, int W);
+int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy);
+int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,
+                         const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, float* dw_d, float* db_d, float* db2_d,
+                         void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
+int bpx_debug_set_bwd_fused(int on); /* test / A-B hook: 0 = bpx_conv3d_bwd_fused_supported answers 0 everywhere (the engine then takes the two separate kernels) */
 
 /* Deferred reduction of the weight-gradient partials.  Between bpx_wgrad_defer_begin() and bpx_wgrad_defer_flush() (same
  * host thread) bpx_conv3d_wgrad and the bf16 bpx_convT3d_k2s2_wgrad write only their partial slabs and queue the reduction;

@@ -96,6 +96,8 @@ def main():
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * 27 * cin * cout
             print(f"conv_dgrad {S:4d}^3 dy{cout:4d}->g{cin:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s")
+    if os.environ.get('BPX_TILE_ORDER') is not None:
+        lib.bpx_debug_set_tile_order(int(os.environ['BPX_TILE_ORDER']))
     if os.environ.get('BPX_WGRAD') is not None:
         lib.bpx_debug_set_wgrad_tr(int(os.environ['BPX_WGRAD']))   # 1 auto, 3 never shift-dy, 5 always
     if a.what in ("wgrad", "all"):
@@ -111,6 +113,37 @@ def main():
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * 27 * cin * cout
             print(f"wgrad     {S:4d}^3 {cin:4d}->{cout:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s  ws={ws.numel() / 1e6:.1f} MB")
+    if a.what in ("bwd", "all"):
+        # backward of one conv in the mixed training mode (t fp16, gradients bf16): dgrad + wgrad as two kernels vs bpx_conv3d_bwd_fused.
+        # (S, Ct = channels of t / g, Cdy, planar t): the level-0 convs of cfg 2 (decoder conv2 / encoder conv2, decoder conv1)
+        for (S, ct, cdy, planar) in [(128, 16, 16, False), (128, 48, 16, True), (64, 16, 16, False)]:
+            dy = torch.randn(B, S, S, S, cdy, device=DEV).to(torch.bfloat16)
+            tt = torch.randn(B, S, S, S, ct, device=DEV).to(torch.float16)
+            tv = L.tview(L.Planar(B, (S, S, S), ct, torch.float16, DEV).copy_from_dense(tt)) if planar else L.tview(tt)
+            g = torch.empty(B, S, S, S, ct, device=DEV, dtype=torch.bfloat16)
+            n = lib.bpx_packed_weight_elems(L.PK_K3_T, ct, cdy, L.MIX16)
+            wpt = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+            L.check(lib.bpx_pack_weight(L.PK_K3_T, (torch.randn(cdy, ct, 3, 3, 3, device=DEV) * 0.05).data_ptr(), ct, cdy, L.MIX16, wpt.data_ptr(), st))
+            rec = torch.rand(B, ct, 4, device=DEV)
+            tiles = lib.bpx_conv3d_stats_tiles(L.BF16, B, S, S, S, ct)
+            red = torch.empty(B, tiles, 2, ct, device=DEV)
+            dw = torch.empty(cdy, ct, 3, 3, 3, device=DEV); db = torch.zeros(cdy, device=DEV)
+            ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, S, S, S, ct, cdy, 3)), dtype=torch.uint8, device=DEV)
+            fd = lambda: L.check(lib.bpx_conv3d_dgrad(L.MIX16, B, S, S, S, L.tview(dy), wpt.data_ptr(), tv, rec.data_ptr(), 1, L.tview(g), red.data_ptr(), st))
+            fw = lambda: L.check(lib.bpx_conv3d_wgrad(L.MIX16, B, S, S, S, tv, rec.data_ptr(), 1, L.tview(dy), 3, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            md, mw = timeit(fd, a.reps), timeit(fw, a.reps)
+            U = B * S ** 3 * 32 / 1e6   # MB of one 16-channel tensor
+            line = f"bwd {S:4d}^3 dy{cdy}->g{ct:3d}: dgrad {md * 1e3:7.1f} us + wgrad(+reduce) {mw * 1e3:7.1f} us = {(md + mw) * 1e3:7.1f}"
+            if lib.bpx_conv3d_bwd_fused_supported(L.MIX16, B, S, S, S, ct, cdy):
+                ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(S, S, S)
+                red2 = torch.empty(B, ftiles, 2, ct, device=DEV)
+                ws2 = torch.empty(max(1, lib.bpx_conv3d_bwd_fused_workspace(B, S, S, S, ct, cdy)), dtype=torch.uint8, device=DEV)
+                ff = lambda: L.check(lib.bpx_conv3d_bwd_fused(L.MIX16, B, S, S, S, L.tview(dy), wpt.data_ptr(), tv, rec.data_ptr(), 1, L.tview(g), red2.data_ptr(),
+                                                              dw.data_ptr(), db.data_ptr(), None, ws2.data_ptr(), ws2.numel(), st))
+                mf = timeit(ff, a.reps)
+                alg = (cdy / 16 + 2 * ct / 16) * U
+                line += f" | fused(+reduce) {mf * 1e3:7.1f} us = {alg / mf / 1e3:6.2f} TB/s(alg {alg:.0f} MB), x{(md + mw) / mf:.2f}"
+            print(line, flush=True)
     if a.what in ("c1", "all"):
         S = 128
         img = torch.randn(B, S, S, S, device=DEV)

@@ -58,11 +58,14 @@ def main():
         run(K.check_convT, dt, 2, (4, 6, 8), 32)
         run(K.check_convT, dt, 1, (2, 2, 2), 256)
         run(K.check_norm_pool_head, dt)
+    run(K.check_bwd_fused, True, 2, (32, 32, 32), 16)
+    run(K.check_bwd_fused, True, 1, (34, 38, 44), 48, True)
+    run(K.check_bwd_fused, False, 1, (36, 34, 40), 16)
     if a.net:
         run(K.check_sliding_window, torch.float32)
         run(K.check_sliding_window, torch.bfloat16)
         run(K.check_dice_parity_trained)
-        for dtype in (torch.float32, torch.bfloat16):
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):      # float16 = the mixed training mode (fp16 forward, bf16 gradients): the benched one
             run(K.check_network, dtype, None, None, None, golden=gr)
             run(K.check_network, dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3)
     lines = []

@@ -777,6 +777,81 @@ def check_mix16_kernels(S=(8, 16, 32), B=2, Cin=32, Cout=16, seed=0):
     return res
 
 
+def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, act=1):
+    """bpx_conv3d_bwd_fused (dgrad + wgrad of one conv in one pass) against the two separate entry points on the same device operands
+    (g bit for bit, statistics / dW / db to fp32 summation order) and against the fp32 PyTorch operators on the same rounded inputs."""
+    D, H, W = S
+    gen = torch.Generator().manual_seed(seed)
+    A, G_ = (L.F16 if mix else L.BF16), L.BF16
+    dtc = L.MIX16 if mix else L.BF16
+    st = L.stream_ptr()
+    Cdy = 16
+    tag = f"bwd_fused[{'mix16' if mix else 'bf16'} B{B} {S} dy{Cdy}->g{Ct}{' planar' if planar else ''} act{act}]"
+    res = []
+    if not lib.bpx_conv3d_bwd_fused_supported(dtc, B, D, H, W, Ct, Cdy):
+        return [_res(tag + ".supported", 1, 0)]
+    rec, _, _ = make_recs(B, Ct, seed + 1)
+    dy = rnd(torch.randn(B, D, H, W, Cdy, generator=gen), G_)
+    w = torch.randn(Cdy, Ct, 3, 3, 3, generator=gen) / (27 * Cdy) ** 0.5
+    t = rnd(torch.randn(B, D, H, W, Ct, generator=gen), A)
+    # fp32 references
+    dA = ndhwc(F.conv_transpose3d(ncdhw(dy), rnd(w, G_), padding=1))
+    u = t * rec[:, None, None, None, :, 2] + rec[:, None, None, None, :, 3]
+    dact = {1: torch.where(u > 0, torch.ones_like(u), torch.exp(u)), 2: (u > 0).float()}[act]
+    g_ref = dA * dact
+    xh = (t - rec[:, None, None, None, :, 0]) * rec[:, None, None, None, :, 1]
+    a = rnd(_act_ref(u, act), G_)
+    wz = torch.zeros(Cdy, Ct, 3, 3, 3, requires_grad=True)
+    bz = torch.zeros(Cdy, requires_grad=True)
+    F.conv3d(ncdhw(a), wz, bz, padding=1).backward(ncdhw(dy))
+    # device operands
+    dyd, recd = to_dev(dy, G_), rec.to(DEV)
+    if planar:
+        tp = L.Planar(B, S, Ct, tdtype(A), DEV).copy_from_dense(to_dev(t, A))
+        tv = L.tview(tp)
+    else:
+        td = to_dev(t, A)
+        tv = L.tview(td)
+    wpt = pack(w, L.PK_K3_T, Ct, Cdy, dtc)
+    # separate kernels
+    g_sep = torch.empty(B, D, H, W, Ct, dtype=torch.bfloat16, device=DEV)
+    tiles = lib.bpx_conv3d_stats_tiles(G_, B, D, H, W, Ct)
+    red_sep = torch.zeros(B, tiles, 2, Ct, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_conv3d_dgrad(dtc, B, D, H, W, L.tview(dyd), wpt.data_ptr(), tv, recd.data_ptr(), act, L.tview(g_sep), red_sep.data_ptr(), st))
+    dw_sep = torch.full((Cdy, Ct, 3, 3, 3), 7.0, dtype=torch.float32, device=DEV)
+    db_sep = torch.zeros(Cdy, dtype=torch.float32, device=DEV)
+    ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, D, H, W, Ct, Cdy, 3)), dtype=torch.uint8, device=DEV)
+    L.check(lib.bpx_conv3d_wgrad(dtc, B, D, H, W, tv, recd.data_ptr(), act, L.tview(dyd), 3, dw_sep.data_ptr(), db_sep.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    # fused
+    g_f = torch.full((B, D, H, W, Ct), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(D, H, W)
+    red_f = torch.full((B, ftiles, 2, Ct), float("nan"), dtype=torch.float32, device=DEV)
+    dw_f = torch.full((Cdy, Ct, 3, 3, 3), 7.0, dtype=torch.float32, device=DEV)
+    db_f = torch.zeros(Cdy, dtype=torch.float32, device=DEV)
+    db2_f = torch.zeros(Cdy, dtype=torch.float32, device=DEV)
+    ws2 = torch.empty(max(1, lib.bpx_conv3d_bwd_fused_workspace(B, D, H, W, Ct, Cdy)), dtype=torch.uint8, device=DEV)
+    L.check(lib.bpx_conv3d_bwd_fused(dtc, B, D, H, W, L.tview(dyd), wpt.data_ptr(), tv, recd.data_ptr(), act, L.tview(g_f), red_f.data_ptr(),
+                                     dw_f.data_ptr(), db_f.data_ptr(), db2_f.data_ptr(), ws2.data_ptr(), ws2.numel(), st))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".g_bits_equal_separate", 0 if torch.equal(g_f.view(torch.int16), g_sep.view(torch.int16)) else 1, 0))
+    res.append(_res(tag + ".g", relerr(g_f, g_ref), tol_for(G_)))
+    s_ref = torch.stack([g_ref.sum((1, 2, 3)), (g_ref * xh).sum((1, 2, 3))], 1)
+    res.append(_res(tag + ".reductions", relerr(red_f.sum(1).cpu(), s_ref), 1e-2))
+    res.append(_res(tag + ".reductions_vs_separate", relerr(red_f.sum(1), red_sep.sum(1)), 1e-4))
+    res.append(_res(tag + ".dw", relerr(dw_f, wz.grad), 2e-3))
+    res.append(_res(tag + ".dw_vs_separate", relerr(dw_f, dw_sep), 1e-4))
+    res.append(_res(tag + ".db", relerr(db_f, bz.grad), 2e-3))
+    res.append(_res(tag + ".db2_equals_db", 0 if torch.equal(db_f, db2_f) else 1, 0))
+    # a second run must reproduce every bit (fixed-order reductions, no atomics)
+    g2 = torch.empty_like(g_f); red2 = torch.empty_like(red_f); dw2 = torch.empty_like(dw_f); db2 = torch.zeros_like(db_f)
+    L.check(lib.bpx_conv3d_bwd_fused(dtc, B, D, H, W, L.tview(dyd), wpt.data_ptr(), tv, recd.data_ptr(), act, L.tview(g2), red2.data_ptr(),
+                                     dw2.data_ptr(), db2.data_ptr(), None, ws2.data_ptr(), ws2.numel(), st))
+    torch.cuda.synchronize()
+    same = torch.equal(g2.view(torch.int16), g_f.view(torch.int16)) and torch.equal(red2, red_f) and torch.equal(dw2, dw_f) and torch.equal(db2, db_f)
+    res.append(_res(tag + ".reproducible", 0 if same else 1, 0))
+    return res
+
+
 def check_planar_layouts(dt, S=(8, 16, 32), lean=False):
     """Chunk-planar operands (bpx_tensor.cs != 0, the layout of the decoder's concat buffers) against the ordinary interleaved layout:
     every entry point that accepts them must produce BIT-IDENTICAL results, the arithmetic does not change.  Covered: conv forward

@@ -168,6 +168,15 @@ def test_mix16_backward_kernels(K, S, B, Cin, Cout):
     _assert_all(K.check_mix16_kernels(S, B, Cin, Cout))
 
 
+@pytest.mark.parametrize("mix,B,S,Ct,planar,act", [(True, 2, (32, 32, 32), 16, False, 1), (True, 1, (32, 32, 32), 48, True, 1), (False, 1, (36, 34, 40), 16, False, 1),
+                                                   (True, 2, (34, 38, 44), 48, True, 1), (False, 1, (32, 32, 48), 48, False, 2), (True, 1, (64, 64, 64), 16, False, 1)],
+                         ids=["mix-16", "mix-48-planar", "bf16-16-ragged", "mix-48-planar-ragged", "bf16-48-relu", "mix-16-64^3"])
+def test_fused_conv_backward_equals_dgrad_plus_wgrad(K, mix, B, S, Ct, planar, act):
+    """bpx_conv3d_bwd_fused: one pass over (dy, t) gives the dgrad kernel's g bit for bit, and its statistics / dW / db to fp32 summation order;
+    also against the fp32 PyTorch operators, and bit-reproducible."""
+    _assert_all(K.check_bwd_fused(mix, B, S, Ct, planar, act=act))
+
+
 @pytest.mark.parametrize("dt,S,lean", [(0, (8, 16, 32), False), (1, (8, 16, 32), False), (1, (64, 64, 64), True), (0, (4, 8, 8), False),
                                        (1, (6, 10, 18), False), (1, (66, 70, 72), True)],
                          ids=["f32", "bf16", "bf16-lean-64^3", "f32-w8", "bf16-ragged-tiles", "bf16-lean-ragged-tiles"])
