@@ -22,9 +22,15 @@
 
 using namespace bpxconv;
 
-// workgroups per CU the 16-channel instance is compiled for (LDS admits 4: 37.8 KB each)
+// workgroups per CU the 16-channel instance is compiled for.  Measured (same box, 16 -> 16 @128^3): 4 per CU at 128 VGPRs 399 us, 3 per CU at
+// 162 VGPRs 379 us - the third wave's registers buy more than the fourth workgroup; with 3 per CU there is also LDS for the packed weights.
 #ifndef BPX_BWD_OCC1
-#define BPX_BWD_OCC1 4
+#define BPX_BWD_OCC1 3
+#endif
+// CT == 1: the 14 KB of packed dgrad weights (the same for every tile of the persistent workgroup) live in LDS instead of being re-read from
+// L2 per step with two loads in flight (the step loop was 4.1 K of the tile's 18 K cycles for 56 MFMAs = 0.9 K: it waited for its operands)
+#ifndef BPX_BWD_LDSW
+#define BPX_BWD_LDSW 1
 #endif
 
 namespace {
@@ -39,6 +45,7 @@ struct BwdParams {
   float* red;                                      // [N][tilesPerSample][2][Ct] partials of sum(g), sum(g * xhat)
   float* part; float* dbpart; int want_db;         // [grid][27][Ct][16] weight-gradient partials, [grid][16] bias-gradient partials
   int tilesZ, tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd, stripY;
+  long long* stamps;                               // profiling: per-workgroup cycle stamps [block][16] of the 5th tile (scripts/bwd_stamps.py), else null
 };
 
 template <int CT, int ACTK, bool TF16>
@@ -53,16 +60,19 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   constexpr int ST_BYTES = CT * TV * VB;
   constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
   constexpr int HSTR = HX * VB;
-  constexpr int WD = NS == 1 ? 2 : 1;
   constexpr int NKC = TV / 32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SG_BYTES + 2 * ST_BYTES + RED_BYTES + CT * 16 * 8];
+  constexpr bool LDSW = BPX_BWD_LDSW && CT == 1;
+  constexpr int SW_BYTES = LDSW ? STEPS * 1024 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SG_BYTES + 2 * ST_BYTES + RED_BYTES + CT * 16 * 16 + SW_BYTES];
   unsigned char* sG = smem;                                             // dy halo [HV][32 B]
   unsigned char* sT = smem + SG_BYTES;                                  // raw t tile [CT][TV][32 B]
   unsigned char* sA = sT + ST_BYTES;                                    // act(norm(t)) as bf16 [CT][TV][32 B]
   float* red = reinterpret_cast<float*>(sA + ST_BYTES);                 // statistics scratch [wave][NS * 16][2]
-  float* sN = red + RED_BYTES / 4;                                      // [CT * 16][scale, shift]
+  float* sN = red + RED_BYTES / 4;                                      // [CT * 16]{mean, rstd, scale, shift}: the sample's norm records (staging and epilogue)
+  unsigned char* sW = reinterpret_cast<unsigned char*>(sN + CT * 16 * 4); // LDSW: packed weights [14 steps][64 lanes][16 B]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;   // (as an SGPR via readfirstlane the 48-channel instance spills 92 bytes per lane: measured, left a VGPR)
   const int j = lane & 15, g = lane >> 4;
   const int D = p.D, H = p.H, W = p.W, Ct = p.Ct;
 
@@ -73,27 +83,20 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   const int hb0 = ((wave * HY) * HX + j) * VB + cg_off;
   const int lbase[4] = {hb0 + (hi_tap ? VB : 0), hb0 + (hi_tap ? HX * VB : 0), hb0 + (hi_tap ? HY * HX * VB : 0), hb0};
   const int evox_rel = (wave * H) * W + j;
-  const char* __restrict__ wp = reinterpret_cast<const char*>(p.wT);
   const uint32_t wlane = (uint32_t)((g * Ct + j) * KPL) * 2u;
   // wgrad phase (wgrad_sdm_kernel): transposing-read bases
   const int trl = (j >> 2), trc = (j & 3) * 8;
   const int a_base = g * 8 * VB + trl * VB + trc;
   const int g_lane = (((g >> 1) * HX + (g & 1) * 8) + trl) * VB + trc;
-  // staging: byte offsets of this thread's pieces relative to the halo / tile origin, and the halo coordinates of the dy pieces (edge tiles)
+  // staging: this thread's pieces.  The byte offsets and halo coordinates of the dy pieces are RE-DERIVED per tile from an opaque copy of the
+  // thread id (a dozen VALU instructions per piece against ~1000 per tile): as per-workgroup constants they were nine more live registers, the
+  // compiler spilled them, and every reload in the staging section waited with `s_waitcnt vmcnt(0)` - which also waits for the DMA pieces
+  // issued before it (measured: "DMA issue" 2.6 K of a 16-channel tile's 14 K cycles, 9.9 K of 35 K for 48 channels)
   const int sub = tid & 1;
-  uint32_t rel_g[NPG], rel_t[2], hc[(NPG + 1) / 2];
-#pragma unroll
-  for (int u = 0; u < (NPG + 1) / 2; ++u) hc[u] = 0u;
-#pragma unroll
-  for (int u = 0; u < NPG; ++u) {
-    const int hv = (u * 256 + tid) >> 1;
-    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    rel_g[u] = (uint32_t)(((hz * H + hy) * W + hx) * p.dy_ld + sub * KPL) * 2u;
-    hc[u >> 1] |= ((uint32_t)hz | ((uint32_t)hy << 4) | ((uint32_t)hx << 8)) << (16 * (u & 1));
-    asm volatile("" : "+v"(rel_g[u]));
-  }
-#pragma unroll
-  for (int u = 0; u < (NPG + 1) / 2; ++u) asm volatile("" : "+v"(hc[u]));
+  const int hv0 = tid >> 1;                                                      // halo voxel of this thread's dy piece 0
+  const uint32_t hpk0 = (uint32_t)(hv0 / (HX * HY)) | ((uint32_t)((hv0 / HX) % HY) << 8) | ((uint32_t)(hv0 % HX) << 16);
+  const uint32_t dy_ld2 = (uint32_t)p.dy_ld * 2u;
+  uint32_t rel_t[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int tv = (u * 256 + tid) >> 1;
@@ -113,23 +116,68 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
 #pragma unroll
     for (int c = 0; c < CT; ++c) accw[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const bool want_b = p.want_db != 0;
+  // InstanceNorm-backward statistics sum(g), sum(g xhat): per-lane partial sums kept over ALL tiles of a sample; the 16-lane / 4-wave reduction
+  // and the global row are paid once per (workgroup, sample) instead of once per tile (32 DPP adds, an LDS exchange, a barrier and a row store
+  // per tile: 1.5 K + part of the epilogue's 4.1 K of the tile's 18 K cycles)
+  constexpr bool PSTATS = CT == 1;   // the 48-channel instance writes one statistics row per tile (below)
+  float ps1[NS][4], ps2[NS][4];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ps1[ns][r] = 0.f; ps2[ns][r] = 0.f; }
+  int cur_tile = 0;
+  auto flush_stats = [&](int nn) {   // workgroup-uniform call
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(ps1[ns][r]), b = row16_sum(ps2[ns][r]);
+        if (j == 0) *reinterpret_cast<f32x2_t*>(&red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+        ps1[ns][r] = 0.f; ps2[ns][r] = 0.f;
+      }
+    __syncthreads();
+    if (tid < NS * 16 * 2) {
+      const int c = tid >> 1, k = tid & 1;
+      const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] + red[(3 * NS * 16 + c) * 2 + k];
+      p.red[(((size_t)nn * gridDim.x + blockIdx.x) * 2 + k) * Ct + c] = a;
+    }
+    __syncthreads();
+  };
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wT), 0, STEPS * 1024 * CT, 0x00020000);
+  if constexpr (LDSW) {   // this wave's share of the 14 weight pieces; they have landed and are visible after the first tile's staging barrier
+    for (int q = wave; q < STEPS; q += 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sW + q * 1024), 16, (uint32_t)(q * 1024 + lane * 16), 0, 0, 0);
+  }
+  int n_first = -1;
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
   int n_cur = -1;
+  // cycle stamps: only in a profiling build (bash scripts/ab_build_flags.sh stamps -DBPX_BWD_STAMPS; scripts/bwd_stamps.py) - the pointer and
+  // the counters cost the 128-VGPR instance 16 bytes of scratch
+#ifdef BPX_BWD_STAMPS
+  long long* stamps = (p.stamps && tid == 0) ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  int stamp_i = 0, it = 0;
+#define BPX_STAMP() do { if (stamps && it == 4 && stamp_i < 15) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+  int it = 0;
+#define BPX_STAMP() do { } while (0)
+#endif
 
-  for (int local = slot; local < p.tilesPerXcd; local += spx) {
+  for (int local = slot; local < p.tilesPerXcd; local += spx, ++it) {
     const int tileId = xcd * p.tilesPerXcd + local;
     if (tileId >= p.totalTiles) break;
     int n, tzi, tyi, txi;
     decode_tile(tileId, p.tilesZ, p.tilesY, p.tilesX, p.tilesPerSample, p.stripY, n, tzi, tyi, txi);
-    const int tile = (tzi * p.tilesY + tyi) * p.tilesX + txi;
+    cur_tile = (tzi * p.tilesY + tyi) * p.tilesX + txi;
     const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
     const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
     const bool interior = full && z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
     const uint32_t base_g = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.dy_ld * 2u;
     const uint32_t base_t = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.t_ld * 2u;
 
+    BPX_STAMP();   // 0: tile start
     __syncthreads();   // the previous tile's MFMA phases and epilogue are done with sG / sT / sA
+    BPX_STAMP();   // 1: top barrier passed
     // ---- staging: LDS-DMA of the raw t tile and of the dy halo ---------------------------------------------------------------------
     bool okt[2];
 #pragma unroll
@@ -143,37 +191,44 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
       for (int u = 0; u < 2; ++u)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(sT + c * TV * VB + (u * 256 + wave * 64) * 16), 16,
                                                  okt[u] ? base_t + rel_t[u] + (uint32_t)c * t_csb : OOR, 0, 0, 0);
+    {
+      uint32_t pk = hpk0;
+      asm volatile("" : "+v"(pk));   // keeps the piece arithmetic inside the tile loop (see above)
+      int hz = (int)(pk & 255u), hy = (int)((pk >> 8) & 255u), hx = (int)(pk >> 16);
+      static_assert(HX * HY + HX + 2 == 128 && NPG * 128 >= HV, "piece u + 1 = piece u + 128 voxels = one plane + one row + 2");
 #pragma unroll
-    for (int u = 0; u < NPG; ++u) {
-      bool ok = true;
-      if (!interior) {
-        const uint32_t c = hc[u >> 1] >> (16 * (u & 1));
-        ok = (unsigned)(z0 - 1 + (int)(c & 15u)) < (unsigned)D && (unsigned)(y0 - 1 + (int)((c >> 4) & 15u)) < (unsigned)H &&
-             (unsigned)(x0 - 1 + (int)((c >> 8) & 255u)) < (unsigned)W;
+      for (int u = 0; u < NPG; ++u) {
+        // branch-free (bit operators): the short-circuit form compiled to three branches per piece
+        const int ok = (int)interior | ((int)((unsigned)(z0 - 1 + hz) < (unsigned)D) & (int)((unsigned)(y0 - 1 + hy) < (unsigned)H) & (int)((unsigned)(x0 - 1 + hx) < (unsigned)W));
+        const uint32_t inoff = base_g + (uint32_t)((hz * H + hy) * W + hx) * dy_ld2 + (uint32_t)sub * 16u;
+        const uint32_t off = ok ? inoff : OOR;
+        if (u < NPG - 1 || last_ok)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sG + (u * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+        hx += 2; hy += 1; hz += 1;
+        const int cx = hx >= HX; hx -= cx * HX; hy += cx;
+        const int cy = hy >= HY; hy -= cy * HY; hz += cy;
       }
-      const uint32_t off = ok ? base_g + rel_g[u] : OOR;
-      if (u < NPG - 1 || last_ok)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sG + (u * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
     }
     if (n != n_cur) {   // uniform: a workgroup crosses a sample boundary at most N - 1 times
-      if (tid < CT * 16) {
-        const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(&p.t_norm[(size_t)n * Ct + tid].scale);
-        sN[2 * tid] = ss[0]; sN[2 * tid + 1] = ss[1];
-      }
+      if (PSTATS && n_cur >= 0) flush_stats(n_cur);
+      if (n_cur < 0) n_first = n;
+      if (tid < CT * 16) reinterpret_cast<f32x4_t*>(sN)[tid] = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + tid]);
       n_cur = n;
       __syncthreads();
     }
+    BPX_STAMP();   // 2: DMA issued
     // ---- transform: raw t -> normalise + activation -> bf16 operand of the wgrad phase (own pieces only: no barrier before it) --------
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces have landed
+    BPX_STAMP();   // 3: DMA landed
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       float psc[KPL], psh[KPL];
       {
-        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(sN + 2 * (c * 16 + sub * KPL));
+        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(sN) + (c * 16 + sub * KPL);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < KPL; ++e) {
           const f32x4_t v = q[e];
-          psc[2 * e] = v[0]; psh[2 * e] = v[1]; psc[2 * e + 1] = v[2]; psh[2 * e + 1] = v[3];
+          psc[e] = v[2]; psh[e] = v[3];
         }
       }
 #pragma unroll
@@ -190,56 +245,48 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
         *reinterpret_cast<u32x4_t*>(sA + c * TV * VB + (u * 256 + tid) * 16) = v;
       }
     }
+    BPX_STAMP();   // 4: transformed
     __syncthreads();   // every wave's DMA pieces and activated pieces are visible
+    BPX_STAMP();   // 5: barrier
 
-    // ---- phase A: dgrad MFMA steps (conv3_lp_kernel's step loop on the dy halo; one input chunk of 16 dy channels) -------------------
-    f32x4_t acc[MS][NS];
+    // ---- phase A + dgrad epilogue, one 16-channel group of g at a time ------------------------------------------------------------------
+    // (conv3_lp_kernel's step loop on the dy halo; one input chunk of 16 dy channels.)  Group by group - not NS accumulator sets at once - so
+    // that 16 accumulator registers are live instead of 48: the 48-channel instance then has room for the per-lane statistics (its per-tile
+    // statistics row cost 4.5 K of the tile's 29 K cycles) and for fragment reads one stage ahead of the MFMAs; the dy fragments are re-read
+    // from LDS per group (90 instead of 30 ds_read_b128 per wave and tile: the LDS has the slack, two workgroups per CU).
+    const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;
+    const bool okzx = full || (z0 + wave < D && x0 + j < W);
+    const int yrem = full ? (1 << 20) : H - y0;
+    char* __restrict__ yout = reinterpret_cast<char*>(p.g);
+    const uint32_t yrow = (uint32_t)(W * p.g_ld) * 2u;
+    const uint32_t yb0 = (uint32_t)(vox0 * p.g_ld + g * 4) * 2u;
+    const unsigned char* tl = sT + ((wave * MS) * 16 + j) * VB + g * 8;   // raw t of (voxel (wave, ms, j), channels 4 g .. 4 g + 3): + ms * 512 + ns * TV * VB
+    // weights of step s and group ns: LDS (CT == 1), or a BUFFER load - resource + one lane-offset VGPR + the step's byte offset in an SGPR +
+    // the group as immediate.  (As pointer arithmetic the compiler hoists the 14 x NS 64-bit lane addresses out of the tile loop: 84 VGPRs, spilled.)
+    const uint32_t wstep = LDSW ? 1024u : (uint32_t)(4 * Ct * 16);
+    if constexpr (CT > 1) {
+      // NS accumulator sets at once, weights through a one-step register ring (conv3_lp_kernel's form), statistics row per TILE.  Measured
+      // alternatives for the 48-channel instance: the per-group form below + per-lane statistics over all tiles (what the 16-channel instance
+      // does) wants 418 registers and spills 600-750 bytes per lane at the 256 of two workgroups per CU - not usable.
+      f32x4_t acc[MS][NS];
 #pragma unroll
-    for (int ms = 0; ms < MS; ++ms)
+      for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    {
-      // the packed weights are re-read per tile through a base the compiler cannot see through: otherwise it hoists the 14 x NS 64-bit lane
-      // addresses out of the tile loop (84 VGPRs for NS = 3, spilled) instead of forming SGPR base + 32-bit lane offset per step
-      const char* wl = wp;
-      asm volatile("" : "+s"(wl));
-      u32x4_t wq[WD + 1][NS];
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      auto load_w = [&](int s_, int ns) -> u32x4_t {
+        return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)(s_ * wstep), 0));
+      };
+      u32x4_t wq[2][NS];
 #pragma unroll
-      for (int d = 0; d < WD; ++d)
+      for (int ns = 0; ns < NS; ++ns) wq[0][ns] = load_w(0, ns);
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)d * 4 * Ct * 16 + (wlane + ns * 256u));
-      constexpr bool REUSE = NS == 1;
-      if constexpr (REUSE) {
+      for (int s_ = 0; s_ < STEPS; ++s_) {
+        if (s_ + 1 < STEPS) {
 #pragma unroll
-        for (int dz = 0; dz < 3; ++dz) {
-          u32x4_t row[MS + 2];
-#pragma unroll
-          for (int r = 0; r < MS + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(sG + lbase[0] + r * HSTR + tap_off<HY, HX, VB>(9 * dz));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int dyy = 0; dyy < 3; ++dyy) {
-            const int s = 3 * dz + dyy;
-            if (s + WD < STEPS) {
-#pragma unroll
-              for (int ns = 0; ns < NS; ++ns)
-                wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)(s + WD) * 4 * Ct * 16 + (wlane + ns * 256u));
-            }
-#pragma unroll
-            for (int ms = 0; ms < MS; ++ms)
-#pragma unroll
-              for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], row[ms + dyy], acc[ms][ns]);
-          }
+          for (int ns = 0; ns < NS; ++ns) wq[(s_ + 1) & 1][ns] = load_w(s_ + 1, ns);
         }
-      }
-#pragma unroll
-      for (int s = REUSE ? 9 : 0; s < STEPS; ++s) {
-        if (s + WD < STEPS) {
-#pragma unroll
-          for (int ns = 0; ns < NS; ++ns)
-            wq[(s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)(s + WD) * 4 * Ct * 16 + (wlane + ns * 256u));
-        }
-        const int cls = s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3;
-        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s));
+        const int cls = s_ < 9 ? 0 : s_ < 12 ? 1 : s_ == 12 ? 2 : 3;
+        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s_));
         u32x4_t af[MS];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(sG + lbase[cls] + ms * HSTR + imm);
@@ -247,20 +294,10 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s % (WD + 1)][ns], af[ms], acc[ms][ns]);
+          for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wq[s_ & 1][ns], af[ms], acc[ms][ns]);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- dgrad epilogue: g = acc * act'(scale t + shift), partials of sum(g) and sum(g xhat), 8-byte stores -----------------------------
-    {
-      const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;
-      const bool okzx = full || (z0 + wave < D && x0 + j < W);
-      const int yrem = full ? (1 << 20) : H - y0;
-      char* __restrict__ yout = reinterpret_cast<char*>(p.g);
-      const uint32_t yrow = (uint32_t)(W * p.g_ld) * 2u;
-      const uint32_t yb0 = (uint32_t)(vox0 * p.g_ld + g * 4) * 2u;
-      const unsigned char* tl = sT + ((wave * MS) * 16 + j) * VB + g * 8;   // raw t of (voxel (wave, ms, j), channels 4 g .. 4 g + 3): + ms * 512 + ns * TV * VB
+      __builtin_amdgcn_sched_barrier(0);
+      BPX_STAMP();   // 6: dgrad steps done
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         u32x2_t tv[MS];
@@ -270,7 +307,7 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
         if (ACTK == 1) {
 #pragma unroll
           for (int rp = 0; rp < 4; rp += 2) {
-            const f32x4_t* rsrc = reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + ns * 16 + g * 4 + rp]);
+            const f32x4_t* rsrc = reinterpret_cast<const f32x4_t*>(sN) + (ns * 16 + g * 4 + rp);
             const f32x4_t ra = rsrc[0], rb = rsrc[1];
             const f32x2_t sc2{ra[2], rb[2]}, sh2{ra[3], rb[3]}, rs2{ra[1], rb[1]}, nm2{-ra[0] * ra[1], -rb[0] * rb[1]};
             f32x2_t s1p{0.f, 0.f}, s2p{0.f, 0.f};
@@ -281,9 +318,9 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
               const f32x2_t u = __builtin_elementwise_fma(sc2, tt, sh2);
               const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
               const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
-              f32x2_t a{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
+              f32x2_t a_{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
               const bool in = okzx && ms < yrem;
-              const f32x2_t gv = in ? f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a : f32x2_t{0.f, 0.f};
+              const f32x2_t gv = in ? f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a_ : f32x2_t{0.f, 0.f};
               acc[ms][ns][rp] = gv[0]; acc[ms][ns][rp + 1] = gv[1];
               s1p = s1p + gv;
               s2p = __builtin_elementwise_fma(gv, xh, s2p);
@@ -293,7 +330,7 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const f32x4_t rec = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + ns * 16 + g * 4 + r]);
+            const f32x4_t rec = reinterpret_cast<const f32x4_t*>(sN)[ns * 16 + g * 4 + r];
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
               const uint32_t w = tv[ms][r >> 1];
@@ -312,18 +349,138 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
             *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = u32x2_t{cvt_pk_bf16(acc[ms][ns][0], acc[ms][ns][1]), cvt_pk_bf16(acc[ms][ns][2], acc[ms][ns][3])};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
-          if (j == 0) *reinterpret_cast<f32x2_t*>(&red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+          const float a_ = row16_sum(s1[r]), b_ = row16_sum(s2[r]);
+          if (j == 0) *reinterpret_cast<f32x2_t*>(&red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2]) = f32x2_t{a_, b_};
         }
       }
-    }
-    __syncthreads();
-    if (tid < NS * 16 * 2) {
-      const int c = tid >> 1, k = tid & 1;
-      const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] + red[(3 * NS * 16 + c) * 2 + k];
-      p.red[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Ct + c] = a;
-    }
+      BPX_STAMP();   // 7: epilogue stores issued
+      __syncthreads();
+      if (tid < NS * 16 * 2) {
+        const int c = tid >> 1, k = tid & 1;
+        const float a_ = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] + red[(3 * NS * 16 + c) * 2 + k];
+        p.red[(((size_t)n * p.tilesPerSample + cur_tile) * 2 + k) * Ct + c] = a_;
+      }
+    } else {
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      f32x4_t acc[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) acc[ms] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      auto load_w = [&](int s_) -> u32x4_t {
+        if constexpr (LDSW) return *reinterpret_cast<const u32x4_t*>(sW + lane * 16 + s_ * 1024);
+        else return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)(s_ * wstep), 0));
+      };
+      // Fragment reads one stage ahead of the MFMAs.  Stages 0..2 = the three dz planes (steps 3 dz .. 3 dz + 2: MS + 2 fragment rows read once
+      // and slid over the three dy steps, as in conv3_lp_kernel's REUSE form), stages 3..7 = steps 9..13.
+      u32x4_t rowA[MS + 2], rowB[MS + 2], wA[3], wB[3];
+      auto load_plane = [&](int dz, u32x4_t* row, u32x4_t* w) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w[q] = load_w(3 * dz + q);
+#pragma unroll
+        for (int r = 0; r < MS + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(sG + lbase[0] + r * HSTR + tap_off<HY, HX, VB>(9 * dz));
+      };
+      auto load_step = [&](int s_, u32x4_t* af, u32x4_t* w) {
+        const int cls = s_ < 12 ? 1 : s_ == 12 ? 2 : 3;
+        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s_));
+        w[0] = load_w(s_);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(sG + lbase[cls] + ms * HSTR + imm);
+      };
+      auto mma_plane = [&](const u32x4_t* row, const u32x4_t* w) {
+#pragma unroll
+        for (int dyy = 0; dyy < 3; ++dyy)
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(w[dyy], row[ms + dyy], acc[ms]);
+      };
+      auto mma_step = [&](const u32x4_t* af, const u32x4_t* w) {
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(w[0], af[ms], acc[ms]);
+      };
+      __builtin_amdgcn_sched_barrier(0);   // (the next group's first fragment reads stay out of this group's epilogue: register budget)
+      load_plane(0, rowA, wA);
+      load_plane(1, rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_plane(rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      load_plane(2, rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_plane(rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(9, rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_plane(rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(10, rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(11, rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(12, rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(13, rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(rowA, wA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(rowB, wB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ns == NS - 1) BPX_STAMP();   // 6: dgrad steps done (last group)
 
+      // ---- epilogue of the group: g = acc * act'(scale t + shift), per-lane partials of sum(g) and sum(g xhat), 8-byte stores ----------------
+      u32x2_t tv[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) tv[ms] = *reinterpret_cast<const u32x2_t*>(tl + ns * TV * VB + ms * 16 * VB);
+      if (ACTK == 1) {
+#pragma unroll
+        for (int rp = 0; rp < 4; rp += 2) {
+          const f32x4_t* rsrc = reinterpret_cast<const f32x4_t*>(sN) + (ns * 16 + g * 4 + rp);   // from LDS: no L2 latency in the epilogue chain
+          const f32x4_t ra = rsrc[0], rb = rsrc[1];
+          const f32x2_t sc2{ra[2], rb[2]}, sh2{ra[3], rb[3]}, rs2{ra[1], rb[1]}, nm2{-ra[0] * ra[1], -rb[0] * rb[1]};
+          f32x2_t s1p{0.f, 0.f}, s2p{0.f, 0.f};
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) {
+            const uint32_t w = tv[ms][rp >> 1];
+            const f32x2_t tt{lo16<TT>(w), hi16<TT>(w)};
+            const f32x2_t u = __builtin_elementwise_fma(sc2, tt, sh2);
+            const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
+            const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
+            f32x2_t a{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
+            const bool in = okzx && ms < yrem;            // out-of-volume voxels of edge tiles carry no gradient
+            const f32x2_t gv = in ? f32x2_t{acc[ms][rp], acc[ms][rp + 1]} * a : f32x2_t{0.f, 0.f};
+            acc[ms][rp] = gv[0]; acc[ms][rp + 1] = gv[1];
+            s1p = s1p + gv;
+            s2p = __builtin_elementwise_fma(gv, xh, s2p);
+          }
+          ps1[ns][rp] += s1p[0]; ps1[ns][rp + 1] += s1p[1]; ps2[ns][rp] += s2p[0]; ps2[ns][rp + 1] += s2p[1];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4_t rec = reinterpret_cast<const f32x4_t*>(sN)[ns * 16 + g * 4 + r];
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) {
+            const uint32_t w = tv[ms][r >> 1];
+            const float tf = (r & 1) ? hi16<TT>(w) : lo16<TT>(w);
+            const float u = fmaf(rec[2], tf, rec[3]);
+            const float gv = (okzx && ms < yrem) ? acc[ms][r] * apply_act_bwd_rt<T, ACTK>(u, p.act) : 0.f;
+            acc[ms][r] = gv;
+            ps1[ns][r] += gv;
+            ps2[ns][r] += gv * ((tf - rec[0]) * rec[1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+        if (okzx && ms < yrem)
+          *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = u32x2_t{cvt_pk_bf16(acc[ms][0], acc[ms][1]), cvt_pk_bf16(acc[ms][2], acc[ms][3])};
+    }
+    }
+    if (CT == 1) BPX_STAMP();   // 7: epilogue stores issued
+    BPX_STAMP();   // 8: statistics row written (48-channel instance)
     // ---- phase B: wgrad MFMA steps (windowed shift-dy phase of wgrad_sdm_kernel) on the same staged operands -----------------------------
     switch (wave) {   // wave-uniform
       case 0: bpxwg::sd_mfma_phase<0, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
@@ -331,6 +488,15 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
       case 2: bpxwg::sd_mfma_phase<2, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
       default: bpxwg::sd_mfma_phase<3, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
     }
+    BPX_STAMP();   // 9: wgrad steps done
+  }
+#undef BPX_STAMP
+  // statistics rows [N][grid][2][Ct]: the last sample's sums, and zeros for the samples this workgroup never touched
+  if (PSTATS && n_cur >= 0) flush_stats(n_cur);
+  if (PSTATS && tid < NS * 16 * 2) {
+    const int c = tid >> 1, k = tid & 1;
+    for (int nn = 0; nn < p.N; ++nn)
+      if (n_cur < 0 || nn < n_first || nn > n_cur) p.red[(((size_t)nn * gridDim.x + blockIdx.x) * 2 + k) * Ct + c] = 0.f;
   }
 
   // ---- flush of the weight-gradient partials: lane holds D[ci = 4 g + r][co = j] of its taps ---------------------------------------------
@@ -385,7 +551,11 @@ extern "C" int bpx_debug_set_bwd_fused(int on) { g_bwd_fused = on; return 0; }
 
 extern "C" int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) { return bwd_supported(dtype, N, D, H, W, Ct, Cdy) ? 1 : 0; }
 
-extern "C" int bpx_conv3d_bwd_fused_stats_tiles(int D, int H, int W) { return cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16); }
+// rows per sample of red_part_d: one per WORKGROUP of the persistent launch (each sums its tiles of a sample in registers)
+// (t.C == 16; the 48-channel instance writes one row per 4x4x16 tile)
+extern "C" int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct) {
+  return Ct == 16 ? bwd_plan(N, D, H, W, Ct).grid : cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
+}
 
 extern "C" int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy) {
   const BwdPlan q = bwd_plan(N, D, H, W, Ct);
@@ -427,6 +597,7 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   p.totalTiles = N * p.tilesPerSample;
   p.tilesPerXcd = cdiv(p.totalTiles, 8);
   p.stripY = strip_rows(q.tilesX);
+  p.stamps = g_conv_stamps;
   const bool mix = dtype == BPX_MIX16, elu = act == BPX_ACT_ELU;
   hipStream_t s = (hipStream_t)stream;
 #define LB(CT_)                                                                                       \

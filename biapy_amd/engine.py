@@ -274,7 +274,7 @@ class ResUNetEngine:
 
     def _bwd_fused(self, B, S, dy: "L.Tensor", wt, t: "L.Tensor", rec, g: "L.Tensor", dw, db, db2, st, dev):
         D, H, W = S
-        tiles = lib.bpx_conv3d_bwd_fused_stats_tiles(D, H, W)
+        tiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, t.C)
         red = torch.empty((B, tiles, 2, t.C), dtype=torch.float32, device=dev)
         ws = self._workspace(lib.bpx_conv3d_bwd_fused_workspace(B, D, H, W, t.C, dy.C), dev)
         L.check(lib.bpx_conv3d_bwd_fused(self.bdt, B, D, H, W, dy, wt.data_ptr(), t, rec.data_ptr(), self.act, g, red.data_ptr(),

@@ -204,13 +204,13 @@ int bpx_conv3d_wgrad_db2(int dtype, int N, int D, int H, int W, bpx_tensor x, co
  * bpx_conv3d_wgrad_db2 (dW, db, db2) of the same (dy, t) pair - the two Conv3d gradients autograd computes for blocks.py:154-157 under
  * train_engine.py:173.  Both kernels stage the same haloed dy tile and the same raw input tile t (t is the conv's raw input; the conv saw
  * act(scale*t+shift)); fused, dy and t are read once (16 -> 16 channels: 3 tensor passes instead of 5; dy 16 -> t 48: 7 instead of 11).
- * Results are those of the two separate calls: g and its partials bit for bit those of the 4x4x16-tile dgrad kernel, dW / db fixed-order sums
+ * Results are those of the two separate calls: g bit for bit that of bpx_conv3d_dgrad; its partials, dW and db fixed-order sums
  * of per-workgroup partials (bit-reproducible; the grouping of the voxels differs from bpx_conv3d_wgrad's, so the fp32 sums differ in the last bits).
  * Supported (bpx_conv3d_bwd_fused_supported): dtype BF16 or MIX16 (t fp16), dy.C == 16, t.C in {16, 48}, W > 8, >= 32^3 voxels per sample, t_norm_d
- * given.  red_part_d: [N][bpx_conv3d_bwd_fused_stats_tiles(D, H, W)][2][t.C] floats.  ws_bytes >= bpx_conv3d_bwd_fused_workspace(...); inside a
+ * given.  red_part_d: [N][bpx_conv3d_bwd_fused_stats_tiles(N, D, H, W, t.C)][2][t.C] floats - t.C == 16: one row per (sample, persistent WORKGROUP), every row written (zeros where a workgroup had no tile of the sample); t.C == 48: one row per 4x4x16 tile.  ws_bytes >= bpx_conv3d_bwd_fused_workspace(...); inside a
  * bpx_wgrad_defer_begin / _flush window the reduction is queued like bpx_conv3d_wgrad's (own workspace per call).  t may be chunk-planar. */
 int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy);
-int bpx_conv3d_bwd_fused_stats_tiles(int D, int H, int W);
+int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct);
 int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy);
 int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,
                          const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, float* dw_d, float* db_d, float* db2_d,

@@ -135,7 +135,7 @@ def main():
             U = B * S ** 3 * 32 / 1e6   # MB of one 16-channel tensor
             line = f"bwd {S:4d}^3 dy{cdy}->g{ct:3d}: dgrad {md * 1e3:7.1f} us + wgrad(+reduce) {mw * 1e3:7.1f} us = {(md + mw) * 1e3:7.1f}"
             if lib.bpx_conv3d_bwd_fused_supported(L.MIX16, B, S, S, S, ct, cdy):
-                ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(S, S, S)
+                ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, S, S, S, ct)
                 red2 = torch.empty(B, ftiles, 2, ct, device=DEV)
                 ws2 = torch.empty(max(1, lib.bpx_conv3d_bwd_fused_workspace(B, S, S, S, ct, cdy)), dtype=torch.uint8, device=DEV)
                 ff = lambda: L.check(lib.bpx_conv3d_bwd_fused(L.MIX16, B, S, S, S, L.tview(dy), wpt.data_ptr(), tv, rec.data_ptr(), 1, L.tview(g), red2.data_ptr(),

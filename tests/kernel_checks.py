@@ -824,7 +824,7 @@ def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, 
     L.check(lib.bpx_conv3d_wgrad(dtc, B, D, H, W, tv, recd.data_ptr(), act, L.tview(dyd), 3, dw_sep.data_ptr(), db_sep.data_ptr(), ws.data_ptr(), ws.numel(), st))
     # fused
     g_f = torch.full((B, D, H, W, Ct), float("nan"), dtype=torch.bfloat16, device=DEV)
-    ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(D, H, W)
+    ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, Ct)
     red_f = torch.full((B, ftiles, 2, Ct), float("nan"), dtype=torch.float32, device=DEV)
     dw_f = torch.full((Cdy, Ct, 3, 3, 3), 7.0, dtype=torch.float32, device=DEV)
     db_f = torch.zeros(Cdy, dtype=torch.float32, device=DEV)
