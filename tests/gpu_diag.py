@@ -68,6 +68,8 @@ def main():
         for dtype in (torch.float32, torch.bfloat16, torch.float16):      # float16 = the mixed training mode (fp16 forward, bf16 gradients): the benched one
             run(K.check_network, dtype, None, None, None, golden=gr)
             run(K.check_network, dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3)
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):      # the benched shape itself: 128^3, logits / loss / gradients (per level in 16 bit)
+            run(K.check_network_cfg2_benched_shape, dtype)
     lines = []
     nbad = 0
     for r in rows:
