@@ -261,8 +261,13 @@ class StreamedChunkedPredictor:
             n = ext[0] * ext[1] * ext[2] * C
             if k >= 2:
                 sl["ready"].synchronize()                                       # the upload that last read this pinned buffer has finished
-            src = np.ascontiguousarray(vol_host[rr.z_start:rr.z_end, rr.y_start:rr.y_end, rr.x_start:rr.x_end])   # host read (disk for a memmap)
-            sl["h_in"][: n * np_dtype.itemsize].view(tdtype).copy_(torch.from_numpy(src).reshape(-1))
+            # the staging buffers were sized by _tile_bytes(): a read region beyond that bound must fail HERE, not as an opaque size error of a
+            # truncated slice in the middle of a run
+            assert n * np_dtype.itemsize <= in_bytes, f"read region {ext} of tile {mine[k]} exceeds the staging buffer ({n * np_dtype.itemsize} > {in_bytes} bytes)"
+            # host read (disk for a memmap) straight into the pinned buffer through a NumPy view of it: no intermediate copy, and no
+            # torch.from_numpy on a read-only memmap (a non-writable-array warning per tile)
+            np.copyto(sl["h_in"][: n * np_dtype.itemsize].numpy().view(np_dtype).reshape(ext + (C,)),
+                      vol_host[rr.z_start:rr.z_end, rr.y_start:rr.y_end, rr.x_start:rr.x_end].reshape(ext + (C,)))
             with torch.cuda.stream(h2d):
                 h2d.wait_event(sl["done"])                                      # the tile that used this device buffer two tiles ago has been computed
                 sl["d_in"][: n * np_dtype.itemsize].copy_(sl["h_in"][: n * np_dtype.itemsize], non_blocking=True)
@@ -292,6 +297,7 @@ class StreamedChunkedPredictor:
             rr, ext = sl["rr"], sl["ext"]
             wr = tg.write_region(tid)
             wext = (wr.z_end - wr.z_start, wr.y_end - wr.y_start, wr.x_end - wr.x_start)
+            assert wext[0] * wext[1] * wext[2] * self.out_channels * 4 <= out_bytes, f"write region {wext} of tile {tid} exceeds the result buffer"
             tin = sl["d_in"][: ext[0] * ext[1] * ext[2] * C * np_dtype.itemsize].view(tdtype)
             tout = sl["d_out"][: wext[0] * wext[1] * wext[2] * self.out_channels * 4].view(torch.float32)
             ids = tg.patches_of_tile[tid]

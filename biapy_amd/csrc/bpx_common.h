@@ -57,8 +57,10 @@ template <> struct ElemTraits<uint16_t> {
   __device__ static __forceinline__ float ld(const uint16_t* p) { return bf16_to_f32(*p); }
   __device__ static __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 };
-// fp16 storage (inference only: same 16 bits per element, 11-bit mantissa instead of 8 - the mode whose Dice matches the fp32 reference
-// to < 1e-4; gradients would need loss scaling, so no backward kernels are instantiated for it).  A distinct element type: _Float16.
+// fp16 storage: the same 16 bits per element with an 11-bit mantissa instead of 8 - the forward mode whose Dice matches the fp32 reference to
+// < 1e-4.  Inference, and the forward half of the mixed training mode (BPX_MIX16: fp16 activations, bf16 gradient tensors - gradients in fp16
+// would need loss scaling, so the backward kernels take fp16 only as their ACTIVATION operand).  fp16 ends at 65504 where bf16 has the fp32
+// range: producers of RAW (pre-normalisation) tensors store through pk16s / the saturating pack below.  A distinct element type: _Float16.
 typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
@@ -122,6 +124,18 @@ template <> __device__ __forceinline__ uint32_t pk16<uint16_t>(float lo, float h
 template <> __device__ __forceinline__ float lo16<f16_t>(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
 template <> __device__ __forceinline__ float hi16<f16_t>(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
 template <> __device__ __forceinline__ uint32_t pk16<f16_t>(float lo, float hi) { return cvt_pk_f16(lo, hi); }
+// SATURATING pack for the stores of raw conv / transposed-conv / pooling outputs: an fp32 result beyond +-65504 becomes +-65504
+// instead of +-inf (an inf in a stored activation turns the next InstanceNorm's output into NaN for the whole channel and train_engine stops on
+// the non-finite loss; bf16 storage cannot fail that way).  v_cvt_pk_f16_f32 + v_pk_min_f16 + v_pk_max_f16: two more VALU instructions per
+// pair, only in epilogues.  The statistics partials are taken from the UNCLAMPED fp32 values, so a genuinely diverged (NaN) result still
+// poisons the norm record and surfaces as a non-finite loss.  bf16: identical to pk16.
+template <typename T> __device__ __forceinline__ uint32_t pk16s(float lo, float hi) { return pk16<T>(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pk16s<f16_t>(float lo, float hi) {
+  const f16x2_t mx{(f16_t)65504.f, (f16_t)65504.f};
+  f16x2_t h{(f16_t)lo, (f16_t)hi};
+  h = __builtin_elementwise_max(__builtin_elementwise_min(h, mx), -mx);
+  return __builtin_bit_cast(uint32_t, h);
+}
 
 // K order of the 27 taps for bf16 storage: one MFMA step = two taps x 16 channels.  Taps are paired so that
 // the LDS address difference between the two taps of a step is one of three constants (+1 voxel in x for the

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
         if constexpr (std::is_same<T, float>::value) {
           *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v[0], v[1], v[2], v[3]};
         } else {
-          *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pk16<T>(v[0], v[1]), pk16<T>(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
         }
       }
     }
@@ -491,7 +491,6 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
 // tiles: 725 / 342 / 944 us on the same three layers.
 extern "C" int bpx_debug_set_conv_ws(int on) {
   if (on == 10 || on == 11) { g_lean_min_vps = on == 10 ? 262144 : 32768; return 0; }
-  if (on == 6 || on == 7) { bpxconv::g_conv_dma = on == 6 ? 1 : 0; return 0; }   // 6 / 7: DMA-pipelined kernel on / off (the other selections stay)
   g_use_ws = on;
   return 0;
 }
@@ -570,8 +569,7 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
     p.pool = pooled.ptr; p.pool_ld = pooled.ld; p.pool_sz = pool_sz; p.pool_part = pool_stats_part_d;
   }
   const bool lean_ok = use_lean(dtype, p) && c.tx == 16;
-  int rc = lean_ok ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_FWD, p, c, (hipStream_t)stream)
-                                                                         : launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream))
+  int rc = lean_ok ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream)
            : (dtype == BPX_F16)  ? launch_conv3<f16_t, EPI_FWD>(p, c, (hipStream_t)stream)
                                  : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);
@@ -660,8 +658,7 @@ extern "C" int bpx_conv3d_dgrad(int dtype, int N, int D, int H, int W, bpx_tenso
   }
   TileCfg c = pick_cfg(dtype, D, H, W, g.C);
   const bool lean_ok = use_lean(dtype, p) && c.tx == 16 && !(c.ns >= 2 && t_norm_d && !p.t_dma);
-  int rc = lean_ok ? (conv3_dma_applies(p, c) ? launch_conv3_dma(EPI_DGRAD, p, c, (hipStream_t)stream)
-                                                                         : launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream))
+  int rc = lean_ok ? launch_conv3_lean(EPI_DGRAD, p, c, (hipStream_t)stream)
            : p.t_f16             ? launch_conv3<uint16_t, EPI_DGRAD, f16_t>(p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_DGRAD>(p, c, (hipStream_t)stream)
                                : launch_conv3<float, EPI_DGRAD>(p, c, (hipStream_t)stream);

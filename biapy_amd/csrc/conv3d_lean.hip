@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               s1[r] += v[r];
               s2[r] += v[r] * v[r];
             }
-            pk[ms] = u32x2_t{pk16<T>(v[0], v[1]), pk16<T>(v[2], v[3])};
+            pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
             *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ysub[ns])) = pk[ms];
           }
         }

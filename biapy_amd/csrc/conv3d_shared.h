@@ -85,7 +85,6 @@ __device__ __forceinline__ void decode_tile(int id, int tilesZ, int tilesY, int 
 }
 
 struct TileCfg { int tz, ty, tx, ns; };
-extern int g_conv_dma;   // conv3d_dma.hip: the DMA-pipelined kernel is selectable (bpx_debug_set_conv_ws 6 / 7)
 
 inline TileCfg pick_cfg(int dtype, int D, int H, int W, int Cout) {
   TileCfg c;
@@ -110,8 +109,8 @@ extern long long* g_conv_stamps;  // profiling hook (bpx_debug_set_conv_stamps)
 
 // lean persistent bf16 kernel (conv3d_lean.hip) - the production kernel of the >= 64^3 layers
 int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
-// DMA-pipelined kernel (conv3d_dma.hip, round 3): 4x8x16 tiles with 16 / 32 output channels at >= 64^3
-bool conv3_dma_applies(const Conv3Params& p, const TileCfg& c);
-int launch_conv3_dma(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
+// (The DMA-pipelined forward / dgrad schedule of round 3 - conv3d_dma.hip: halo by LDS-DMA into a second buffer, in-place transform - measured
+//  EQUAL to the lean kernel on every cfg-2 layer (profiles/r03_conv_dma_vs_lean.txt) and was deleted in round 4; the LDS-DMA staging lives on in
+//  the fused backward kernel, bwd_fused.hip, where the operands need no transform or are transformed once per voxel.)
 
 }  // namespace bpxconv

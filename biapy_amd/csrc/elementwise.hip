@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v4[r] = acc[r] + bsv[r]; s1[r] += v4[r]; s2[r] += v4[r] * v4[r]; }
       T* yp = y + ((((size_t)n * D + z) * H + yy) * W + x) * (size_t)y_ld + cb + 4 * g;
-      if constexpr (BF) *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pk16<T>(v4[0], v4[1]), pk16<T>(v4[2], v4[3])};
+      if constexpr (BF) *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{pk16s<T>(v4[0], v4[1]), pk16s<T>(v4[2], v4[3])};
       else *reinterpret_cast<f32x4_t*>(yp) = f32x4_t{v4[0], v4[1], v4[2], v4[3]};
     }
   }

@@ -79,10 +79,10 @@ template <> __device__ __forceinline__ void loadq<f16_t, 2>(const f16_t* p, floa
 template <> __device__ __forceinline__ void loadq<f16_t, 3>(const f16_t* p, float (*f)[4]) { load8_f16(p, f[0], f[1]); load4<f16_t>(p + 8, f[2]); }
 template <> __device__ __forceinline__ void loadq<f16_t, 4>(const f16_t* p, float (*f)[4]) { load8_f16(p, f[0], f[1]); load8_f16(p + 8, f[2], f[3]); }
 __device__ __forceinline__ void store4_f16(f16_t* p, const float* f) {
-  *reinterpret_cast<u32x2_t*>(p) = u32x2_t{cvt_pk_f16(f[0], f[1]), cvt_pk_f16(f[2], f[3])};
+  *reinterpret_cast<u32x2_t*>(p) = u32x2_t{pk16s<f16_t>(f[0], f[1]), pk16s<f16_t>(f[2], f[3])};   // saturating: raw outputs (bpx_common.h)
 }
 __device__ __forceinline__ void store8_f16(f16_t* p, const float* f0, const float* f1) {
-  *reinterpret_cast<u32x4_t*>(p) = u32x4_t{cvt_pk_f16(f0[0], f0[1]), cvt_pk_f16(f0[2], f0[3]), cvt_pk_f16(f1[0], f1[1]), cvt_pk_f16(f1[2], f1[3])};
+  *reinterpret_cast<u32x4_t*>(p) = u32x4_t{pk16s<f16_t>(f0[0], f0[1]), pk16s<f16_t>(f0[2], f0[3]), pk16s<f16_t>(f1[0], f1[1]), pk16s<f16_t>(f1[2], f1[3])};
 }
 template <> __device__ __forceinline__ void storeq<f16_t, 1>(f16_t* p, const float (*f)[4]) { store4_f16(p, f[0]); }
 template <> __device__ __forceinline__ void storeq<f16_t, 2>(f16_t* p, const float (*f)[4]) { store8_f16(p, f[0], f[1]); }

@@ -69,6 +69,18 @@ class NetConfig:
         # 'gn': torch.nn.GroupNorm(8, C) for every norm layer - what blocks.py:2122-2125 means (the reference's own call,
         # nn.GroupNorm(out_channels, num_groups=8), raises a TypeError, so there is no reference output to pin this mode to)
         self.gn_groups = 8 if self.normalization == "gn" else 0
+        if self.gn_groups:
+            # checked here, not by a kernel in the middle of the first forward: bpx_norm_finalize / bpx_norm_bwd_finalize take
+            # 1, 2, 4, ... 64 channels per group for the single-producer tensors; the concatenated decoder inputs (any channels per group) go
+            # through the general group kernels, which only need whole groups
+            ok_cpg = (1, 2, 4, 8, 16, 32, 64)
+            for i, c in enumerate(fm):
+                if c % self.gn_groups or (c // self.gn_groups) not in ok_cpg:
+                    raise NotImplementedError(f"normalization='gn': feature_maps[{i}] = {c} gives {c / self.gn_groups:g} channels per group; the kernels "
+                                              f"take {ok_cpg} (GroupNorm(8, C): C in 8 ... 512, a power of two times 8)")
+            for i in range(len(fm) - 1):
+                if (fm[i] + fm[i + 1]) % self.gn_groups:
+                    raise NotImplementedError(f"normalization='gn': the concatenated decoder input of level {i} has {fm[i] + fm[i + 1]} channels, not a multiple of 8")
         if self.activation not in L.ACT:
             raise NotImplementedError(f"activation={self.activation!r} is not implemented on the MI355X engine")
         if any(c % 16 for c in fm):

@@ -76,6 +76,10 @@ class RCANEngine(ResUNetEngine):
     def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 1
         B, _, D, H, W = x.shape
+        if save and self.dtype == torch.float16:
+            # this engine's backward passes self.dt to every kernel and has no BPX_MIX16 plumbing (fp16 activations beside bf16 gradients, as
+            # ResUNetEngine has): refuse before the forward runs instead of failing in the first backward kernel
+            raise NotImplementedError(f"{type(self).__name__}: training with compute_dtype=torch.float16 is not implemented (inference only); train in bfloat16 or float32")
         S, vox, Fc, T, dev, st = (D, H, W), D * H * W, self.Fc, self.dtype, x.device, L.stream_ptr()
         self._begin_recorded_packs(P, save, dev, cache_weights)
         c = self._consts(B, dev)

@@ -513,6 +513,10 @@ class ResUNetPPEngine(ResUNetEngine):
         cfg = self.pp
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 1
         B, _, D0, H0, W0 = x.shape
+        if save and self.dtype == torch.float16:
+            # this engine's backward passes self.dt to every kernel and has no BPX_MIX16 plumbing (fp16 activations beside bf16 gradients, as
+            # ResUNetEngine has): refuse before the forward runs instead of failing in the first backward kernel
+            raise NotImplementedError(f"{type(self).__name__}: training with compute_dtype=torch.float16 is not implemented (inference only); train in bfloat16 or float32")
         fm, depth, zd = list(cfg.feature_maps), cfg.depth, cfg.z_down
         zdiv = 1
         for v in zd[1:]:

@@ -347,7 +347,7 @@ def _graph_step(inner, model, loss_function, optimizer, x, t):
     if isinstance(probe, dict):
         return None, None
     del probe
-    if not optimizer.state and not isinstance(optimizer, _ZERO_INIT_OPTIMIZERS):
+    if not optimizer.state and not _fresh_state_is_zero(optimizer):
         return None, None                                              # its fresh state is not all-zero: the warm-up could not be undone
     multi = _world() > 1
     if multi and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
@@ -363,10 +363,19 @@ def _graph_step(inner, model, loss_function, optimizer, x, t):
 
 
 # optimizers whose freshly created per-parameter state is all zeros (step counters, moments, accumulators): what _restore relies on
-# for state that did not exist before the capture warm-up.  ASGD (eta = lr, mu = 1), Rprop (step_size = lr) and Adagrad
-# (initial_accumulator_value) do not qualify and keep the eager step when they arrive without state.
-_ZERO_INIT_OPTIMIZERS = (torch.optim.Adam, torch.optim.AdamW, torch.optim.NAdam, torch.optim.RAdam, torch.optim.Adamax, torch.optim.Adadelta,
-                         torch.optim.RMSprop, torch.optim.SGD)
+# for state that did not exist before the capture warm-up.  ASGD (eta = lr, mu = 1), Rprop (step_size = lr), Adagrad
+# (initial_accumulator_value) and NAdam (mu_product starts at 1 and is only ever multiplied: zeroed it stays 0 and every bias correction of
+# the run is wrong - ADVICE r3) do not qualify and keep the eager step when they arrive without state; neither does SGD with momentum and a
+# non-zero dampening (torch seeds the momentum buffer with the first gradient, a zeroed buffer gives (1 - dampening) * grad).
+_ZERO_INIT_OPTIMIZERS = (torch.optim.Adam, torch.optim.AdamW, torch.optim.RAdam, torch.optim.Adamax, torch.optim.Adadelta, torch.optim.RMSprop, torch.optim.SGD)
+
+
+def _fresh_state_is_zero(optimizer) -> bool:
+    if not isinstance(optimizer, _ZERO_INIT_OPTIMIZERS):
+        return False
+    if isinstance(optimizer, torch.optim.SGD):
+        return all(not (g.get("momentum", 0) and g.get("dampening", 0)) for g in optimizer.param_groups)
+    return True
 
 
 def _snapshot(model, optimizer):

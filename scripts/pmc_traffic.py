@@ -21,7 +21,7 @@ def _conv_rx(epi):
     names with _Float16 arguments mangled - as conv3_kernelIDF16_Li4ELi4ELi8ELi4ELi<EPI>E... / conv3_lp_kernelILi4E...Li<EPI>E..."""
     e = str(epi)
     return re.compile(r"conv3_lp_kernel<\d+, \d+, \d+, \d+, " + e + r",|conv3_kernel<[^,>]+, \d+, \d+, \d+, \d+, " + e + r","
-                      r"|conv3_lp_kernelI(?:Li\d+E){4}Li" + e + r"E|conv3_kernelI(?:DF16_|t|f)(?:Li\d+E){4}Li" + e + r"E|conv3_dma_kernel<\d+, \d+, \d+, \d+, " + e + r",")
+                      r"|conv3_lp_kernelI(?:Li\d+E){4}Li" + e + r"E|conv3_kernelI(?:DF16_|t|f)(?:Li\d+E){4}Li" + e + r"E")
 
 
 GROUPS = [

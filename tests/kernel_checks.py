@@ -852,6 +852,52 @@ def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, 
     return res
 
 
+def check_f16_saturation(seed=0):
+    """fp16 storage ends at 65504.  Raw conv / transposed-conv / first-layer outputs are stored through a SATURATING pack:
+    an fp32 result beyond the range must land as +-65504 (finite), never as +-inf; the statistics partials still come from the unclamped
+    fp32 values.  Forward conv (lean and double-buffered kernels), first layer, transposed conv with operands scaled far out of range; and a
+    whole ResUNet forward in fp16 on an input of magnitude 3e4 must give finite logits."""
+    res = []
+    g = torch.Generator().manual_seed(seed)
+    st = L.stream_ptr()
+    F16 = L.F16
+    for S, tagk in (((8, 8, 16), "double-buffered"), ((32, 32, 32), "lean")):
+        B, Cin, Cout = 1, 16, 16
+        D, H, W = S
+        x = rnd(torch.randn(B, D, H, W, Cin, generator=g) * 300.0, F16)
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 2.0
+        ref = ndhwc(F.conv3d(ncdhw(x), rnd(w, F16), padding=1))
+        xd = to_dev(x, F16)
+        yd = torch.empty(B, D, H, W, Cout, dtype=torch.float16, device=DEV)
+        wp = pack(w, L.PK_K3, Cin, Cout, F16)
+        bias = torch.zeros(Cout, device=DEV)
+        tiles = lib.bpx_conv3d_stats_tiles(F16, B, D, H, W, Cout)
+        part = torch.zeros(B, tiles, 2, Cout, device=DEV)
+        L.check(lib.bpx_conv3d_fwd(F16, B, D, H, W, L.tview(xd), None, 0, wp.data_ptr(), bias.data_ptr(), L.NULL_T, None, None, L.tview(yd), part.data_ptr(), st))
+        torch.cuda.synchronize()
+        y = yd.float().cpu()
+        over = ref.abs() > 65504
+        tag = f"f16_saturation.conv3d_fwd[{tagk} {S}]"
+        res.append(_res(tag + ".some_results_out_of_range", 0 if over.any() else 1, 0, extra=f"{int(over.sum())} of {over.numel()} beyond 65504, max |ref| {ref.abs().max().item():.3g}"))
+        res.append(_res(tag + ".finite", 0 if torch.isfinite(y).all() else 1, 0))
+        res.append(_res(tag + ".clamped_values", relerr(y, ref.clamp(-65504, 65504)), 2e-3))
+        res.append(_res(tag + ".statistics_unclamped", relerr(part.sum(1)[:, 0].cpu(), ref.sum((1, 2, 3))), 2e-3))
+    # the whole network in fp16 on an un-normalised input (raw 16-bit intensities): finite logits
+    from biapy_amd.resunet import ResUNet
+    torch.manual_seed(seed)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0, 0.0], normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True, True], larger_io=False, conv_layers=[2, 2], compute_dtype=torch.float16).cuda().eval()
+    with torch.no_grad():
+        xin = (torch.randn(1, 1, 32, 32, 32, generator=g) * 3e4).cuda()
+        lo = m(xin)
+        m32 = m
+        m32.compute_dtype = torch.float32
+        lo32 = m32(xin)
+    res.append(_res("f16_saturation.network_logits_finite[input magnitude 3e4]", 0 if torch.isfinite(lo).all() else 1, 0,
+                    extra=f"max |logit| {lo.abs().max().item():.3g}; f32 mode {lo32.abs().max().item():.3g}"))
+    return res
+
+
 def check_planar_layouts(dt, S=(8, 16, 32), lean=False):
     """Chunk-planar operands (bpx_tensor.cs != 0, the layout of the decoder's concat buffers) against the ordinary interleaved layout:
     every entry point that accepts them must produce BIT-IDENTICAL results, the arithmetic does not change.  Covered: conv forward
@@ -1027,7 +1073,7 @@ GRAD_FLOOR_BF16 = 5e-2
 # gradient.  fp16 mode: fp16 forward (logits ~1e-3), gradients carried in bf16 (same bar as the bf16 mode)
 LOGITS_TOL = {"f32": 2e-4, "bf16": 6e-2, "f16": 4e-3}
 LOSS_TOL = {"f32": 1e-5, "bf16": 2e-2, "f16": 2e-3}
-GRAD_TOL = {"f32": 2e-3, "bf16": 0.15, "f16": 0.15}
+GRAD_TOL = {"f32": 2e-3, "bf16": 0.15, "f16": 0.10}   # f16 = the mixed mode: measured worst 0.060 (round 4), 0.15 until round 3
 
 
 def param_level(key, depth):
@@ -1043,11 +1089,14 @@ def param_level(key, depth):
     return 0
 
 
-# 16-bit modes: worst relative L2 error of a parameter gradient PER LEVEL (VERDICT r3 next #4c).  The error grows with depth below the loss -
-# gradients of the deep levels pass through more 16-bit tensors and their statistics come from fewer voxels - so ONE bar set by the worst
-# level (0.15) would let a regression at level 0 hide under the bottleneck's allowance.  Bars = ~1.6x the values measured for the mixed and the
-# bf16 mode on the 3-level golden net, the cfg-2 net at 64^3 and at the benched 128^3 shape (profiles/r04_gpu_diag.txt), capped at 0.15.
-GRAD_TOL_LEVEL_16 = {0: 0.06, 1: 0.08, 2: 0.10, 3: 0.13, 4: 0.15}
+# 16-bit modes: worst relative L2 error of a parameter gradient PER LEVEL (VERDICT r3 next #4c).  The error depends on the depth below the loss and
+# on how many voxels a level's statistics average over, so ONE bar set by the worst level would let a regression at level 0 hide under the
+# allowance of level 2.  Bars = ~1.6x the largest value measured in round 4 over the 3-level golden net (32^3, B = 2), the cfg-2 net at 64^3 and at
+# the benched 128^3 shape (profiles/r04_gpu_diag.txt):
+#   mixed mode (fp16 forward, bf16 gradients - the benched one): level 0 0.018, 1 0.051, 2 0.060, 3 0.047, 4 0.010
+#   pure bf16:                                                    level 0 0.105, 1 0.127, 2 0.140, 3 0.108, 4 0.044
+# (the mixed mode's gradients are 2-3x closer to fp32: only the gradient tensors are bf16, the activations they are multiplied with are fp16)
+GRAD_TOL_LEVEL_16 = {"f16": {0: 0.03, 1: 0.08, 2: 0.10, 3: 0.08, 4: 0.03}, "bf16": {0: 0.15, 1: 0.15, 2: 0.15, 3: 0.15, 4: 0.08}}
 
 
 def grad_rows(tag, G, grads_ref, tagd, depth):
@@ -1070,7 +1119,7 @@ def grad_rows(tag, G, grads_ref, tagd, depth):
     if tagd != "f32":
         for lv in sorted(per_level):
             e, k = per_level[lv]
-            rows.append(_res(tag + f".grads_rel_l2_level{lv}", e, GRAD_TOL_LEVEL_16.get(lv, 0.15), extra=k))
+            rows.append(_res(tag + f".grads_rel_l2_level{lv}", e, GRAD_TOL_LEVEL_16[tagd].get(lv, 0.15), extra=k))
     return rows
 
 
@@ -1199,7 +1248,7 @@ def check_network_cfg2_benched_shape(dtype):
     res.append(_res(tag + ".b1.grads_rel_l2_worst", worst, GRAD_TOL[tagd], extra=wname))
     if not f32:
         for lv in sorted(per_level):
-            res.append(_res(tag + f".b1.grads_rel_l2_level{lv}", per_level[lv][0], GRAD_TOL_LEVEL_16.get(lv, 0.15), extra=per_level[lv][1]))
+            res.append(_res(tag + f".b1.grads_rel_l2_level{lv}", per_level[lv][0], GRAD_TOL_LEVEL_16[tagd].get(lv, 0.15), extra=per_level[lv][1]))
     # batch 4 == four batch-1 steps
     lo4, loss4, G4 = step(x, tgt)
     singles = [(lo1, loss1, G1)] + [step(x[b:b + 1], tgt[b:b + 1]) for b in range(1, 4)]

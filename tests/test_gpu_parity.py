@@ -86,14 +86,13 @@ def test_conv3d_fwd(K, dt):
     _assert_all(rows)
 
 
-@pytest.mark.parametrize("variant,dma", [(4, 6), (5, 7), (5, 6)], ids=["double-buffered", "lean-persistent", "dma-pipelined"])
-def test_conv3d_bf16_kernel_variants(K, variant, dma):
-    """Every schedule of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) computes the same convolution: the double-buffered kernel
-    of the small layers, the lean persistent kernel, and (round 3) the DMA-pipelined kernel that replaces it for 16 output channels."""
+@pytest.mark.parametrize("variant", [4, 5], ids=["double-buffered", "lean-persistent"])
+def test_conv3d_bf16_kernel_variants(K, variant):
+    """Both schedules of the bf16 implicit-GEMM kernel (bpx_debug_set_conv_ws) compute the same convolution: the double-buffered kernel
+    of the small layers and the lean persistent kernel (the DMA-pipelined third one of round 3 measured equal and was deleted in round 4)."""
     from biapy_amd import _lib as L
 
     L.lib.bpx_debug_set_conv_ws(variant)
-    L.lib.bpx_debug_set_conv_ws(dma)          # 6 / 7: DMA-pipelined kernel on / off wherever the lean kernel would run
     try:
         rows = []
         rows += K.check_conv3d_fwd(1, 1, (8, 12, 20), 48, 16, norm=True, sc_C=48, slices=True)
@@ -112,7 +111,6 @@ def test_conv3d_bf16_kernel_variants(K, variant, dma):
         rows += K.check_conv3d_dgrad(1, 3, (9, 17, 33), 16, 48)                        # dy 48 channels (three chunks) -> g 16
     finally:
         L.lib.bpx_debug_set_conv_ws(0)
-        L.lib.bpx_debug_set_conv_ws(6)
     _assert_all(rows)
 
 
@@ -166,6 +164,11 @@ def test_norm_pool_head_first_layer(K, dt):
 def test_mix16_backward_kernels(K, S, B, Cin, Cout):
     """BPX_MIX16: fp16 activations, bf16 gradients - every backward entry point of the mixed training mode vs the fp32 operator."""
     _assert_all(K.check_mix16_kernels(S, B, Cin, Cout))
+
+
+def test_fp16_raw_outputs_saturate_instead_of_overflowing(K):
+    """conv results beyond the fp16 range are stored as +-65504, not +-inf; an fp16 network on raw 16-bit intensities stays finite."""
+    _assert_all(K.check_f16_saturation())
 
 
 @pytest.mark.parametrize("mix,B,S,Ct,planar,act", [(True, 2, (32, 32, 32), 16, False, 1), (True, 1, (32, 32, 32), 48, True, 1), (False, 1, (36, 34, 40), 16, False, 1),
