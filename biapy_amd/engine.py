@@ -223,8 +223,13 @@ class ResUNetEngine:
         self._ws: Optional[torch.Tensor] = None
         self._side_stream = None
         self.planar_cat = os.environ.get("BPX_PLANAR_CAT", "1") != "0"
-        self.use_side_stream = False  # measured on cfg 2: 19.5 vs 18.1 ms/step (early kernels, eager); 11.13 vs 11.18 with the final kernels
-        # under graph replay, 21 vs 15 ms eager - every kernel already launches one resident wave of workgroups
+        self.use_side_stream = False  # ALL weight-gradient kernels on a second stream: measured on cfg 2 19.5 vs 18.1 ms/step (early kernels, eager);
+        # 11.13 vs 11.18 with the final kernels under graph replay, 21 vs 15 ms eager - the big layers already launch one resident wave of workgroups.
+        # Round 4: the same for the SMALL levels only (<= side_small_vps voxels per sample, e.g. 4096 = the 16^3 and 8^3 levels of cfg 2, whose kernels are
+        # latency chains with one workgroup or less per CU) as a parallel branch of the captured graph: measured SLOWER too - same box, 30 graph-replayed
+        # steps: off 9.74 ms, <= 16^3 9.84 ms, <= 32^3 9.91 ms - and left off (BPX_SIDE_VPS=<voxels> switches it on).
+        self.side_small_vps = int(os.environ.get("BPX_SIDE_VPS", "0"))
+        self._side_used = False
         self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._pack_versions: Dict[Tuple[int, int, int], Tuple[int, int]] = {}
 
@@ -240,18 +245,21 @@ class ResUNetEngine:
     # their own).  Ordering: side waits for an event recorded on the main stream when the kernel's inputs exist; the
     # main stream waits for the side stream once, at the end of backward.  Buffers read by side-stream kernels are kept
     # alive in ctx["keep"] until then (PyTorch's allocator is stream-ordered per stream, not across streams).
-    def _side(self, dev):
-        if not self.use_side_stream:
+    def _side(self, dev, S=None):
+        """The side stream for a launch at spatial size S (None: only in the all-launches mode), or None = the current stream."""
+        small = S is not None and S[0] * S[1] * S[2] <= self.side_small_vps
+        if not (self.use_side_stream or small):
             return None
         if self._side_stream is None or self._side_stream.device != dev:
             self._side_stream = torch.cuda.Stream(device=dev)
         return self._side_stream
 
-    def _run_side(self, dev, fn):
-        side = self._side(dev)
+    def _run_side(self, dev, fn, S=None):
+        side = self._side(dev, S)
         if side is None:
             fn(L.stream_ptr())
             return
+        self._side_used = True
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         side.wait_event(ev)
@@ -277,7 +285,7 @@ class ResUNetEngine:
         nb = lib.bpx_conv3d_wgrad_workspace(B, D, H, W, x.C, dy.C, k)
         ws = self._workspace(nb, dev)
         self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_wgrad_db2(self.bdt, B, D, H, W, x, L.ptr(rec), act, dy, k, dw.data_ptr(), L.ptr(db),
-                                                                        L.ptr(db2), ws.data_ptr(), ws.numel(), s_)))
+                                                                        L.ptr(db2), ws.data_ptr(), ws.numel(), s_)), S)
 
     def _bwd_fused_ok(self, B, S, Ct: int, Cdy: int) -> bool:
         """One-pass dgrad + wgrad (bpx_conv3d_bwd_fused) for this conv?  Not with the weight-gradient side stream (its point is one staging)."""
@@ -685,7 +693,8 @@ class ResUNetEngine:
         self._keep = []   # buffers the side stream may still be reading; released after the final stream join
         # the ~29 weight-gradient reductions of a step run as one batched launch at the end (they are latency chains of a
         # few hundred blocks each; back to back they cost 0.6 ms).  Not with the side stream: the flush is stream-ordered.
-        self._deferred = self._side(dlogits.device) is None
+        self._deferred = not self.use_side_stream      # (the small-level side branch is joined at the end of _backward, before the flush)
+        self._side_used = False
         self._after_flush = []
         if self._deferred:
             L.check(lib.bpx_wgrad_defer_begin())
@@ -765,7 +774,7 @@ class ResUNetEngine:
             wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, Sl[0], Sl[1], Sl[2], szl, Cup, Cup)
             ws = self._workspace(wsn, dev)
             self._run_side(dev, lambda s_, x_in=x_in, dUp=dUp, wk=wk, bk=bk, Sl=Sl, ws=ws, szl=szl: L.check(lib.bpx_convT3d_k2s2_wgrad(
-                self.bdt, B, Sl[0], Sl[1], Sl[2], szl, L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), ws.data_ptr(), ws.numel(), s_)))
+                self.bdt, B, Sl[0], Sl[1], Sl[2], szl, L.tview(x_in), dUp, G[wk].data_ptr(), G[bk].data_ptr(), ws.data_ptr(), ws.numel(), s_)), Sl)
             dxin = torch.empty((B,) + Sl + (Cup,), dtype=T, device=dev)
             wt = self._pack(P[wk], L.PK_CT_T if szl == 2 else L.PK_CT4_T, Cup, Cup, False)
             L.check(lib.bpx_convT3d_k2s2_dgrad(self.gdt, B, Sl[0], Sl[1], Sl[2], szl, dUp, wt.data_ptr(), L.tview(dxin), st))
@@ -792,7 +801,6 @@ class ResUNetEngine:
                 G["__dx__"] = dx0
             else:
                 self._block_bwd(P, G, blocks[0], B, skipv, img, st, None, None)  # the image needs no gradient
-        side = self._side(dev)
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
+        if self._side_used and self._side_stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._side_stream)
         return G

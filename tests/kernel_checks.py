@@ -864,8 +864,8 @@ def check_f16_saturation(seed=0):
     for S, tagk in (((8, 8, 16), "double-buffered"), ((32, 32, 32), "lean")):
         B, Cin, Cout = 1, 16, 16
         D, H, W = S
-        x = rnd(torch.randn(B, D, H, W, Cin, generator=g) * 300.0, F16)
-        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 2.0
+        x = rnd(torch.randn(B, D, H, W, Cin, generator=g) * 900.0, F16)
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 4.0
         ref = ndhwc(F.conv3d(ncdhw(x), rnd(w, F16), padding=1))
         xd = to_dev(x, F16)
         yd = torch.empty(B, D, H, W, Cout, dtype=torch.float16, device=DEV)
