@@ -249,37 +249,55 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) wreg[s][ns] = *reinterpret_cast<const u32x4_t*>(wl0 + ((size_t)s * 4 * Cout + ns * 16) * KPL);
   }
+  // Round 4 (cycle stamps of the <= 16^3 layers, one workgroup per CU = one wave per SIMD): a step was ONE exposed latency - 486 cycles per step for
+  // the 8 MFMAs (128 cycles) of the NS = 4 instances, whose next step's weights were requested one step ahead (L2 latency ~500 cycles), and 264
+  // cycles per step for the 4 MFMAs of the register-resident (WREG) instances, which waited for the step's own LDS fragment reads.  Now: the
+  // fragment reads run one step ahead of the MFMAs (two register sets), and the non-WREG weights come through a ring of WD + 1 = 4 steps
+  // (three loads in flight per output-channel group; the ring restarts per chunk: the first WD steps of the next chunk are requested after the
+  // last step's MFMAs and fly across the chunk barrier).
+  // Only for the 4x4x8 tiles of the <= 16^3 layers (two m-subtiles per wave): the 16-wide tiles (the lean kernel's fallback, the fp32 mode) keep one
+  // fragment set and a one-step ring - with four or eight m-subtiles the second set spills.
+  constexpr bool SMALL = TX == 8;
+  constexpr int WD = SMALL ? 3 : 1;
+  constexpr int NAF = SMALL ? 2 : 1;
+  u32x4_t wq[WREG ? 1 : WD + 1][NS];
+  if (!WREG) {
+    const T* wl0 = wp + ((size_t)g * Cout + co_base + j) * KPL;
+#pragma unroll
+    for (int d = 0; d < WD; ++d)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl0 + ((size_t)d * 4 * Cout + ns * 16) * KPL);
+  }
   int cur = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int nxt = BUFB - cur;
     const bool stage_next = chunk + 1 < nchunks;
     const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
     const T* wl1 = wl + (size_t)QPAD * Cout * KPL;   // next chunk
-    u32x4_t wf[NS], wn[NS];
-    if (!WREG) {
+    u32x4_t af[NAF][MS];
+    auto read_frags = [&](int s_, u32x4_t* f) {
+      const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s_) : s_;
+      const int cls = (GPT == 2) ? (s_ < 9 ? 0 : s_ < 12 ? 1 : s_ == 12 ? 2 : 3) : 0;
+      const int imm = tap_off<HY, HX, VB>(tapA);
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns) wf[ns] = *reinterpret_cast<const u32x4_t*>(wl + (size_t)ns * 16 * KPL);
-    }
+      for (int ms = 0; ms < MS; ++ms) f[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
+    };
+    if (NAF == 2) read_frags(0, af[0]);
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      if (!WREG && s + 1 < STEPS) {
+      if (!WREG && s + WD < STEPS) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
-          wn[ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + 1) * 4 * Cout + ns * 16) * KPL);
+          wq[WREG ? 0 : (s + WD) % (WD + 1)][ns] = *reinterpret_cast<const u32x4_t*>(wl + ((size_t)(s + WD) * 4 * Cout + ns * 16) * KPL);
       }
-      const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s) : s;
-      const int cls = (GPT == 2) ? (s < 9 ? 0 : s < 12 ? 1 : s == 12 ? 2 : 3) : 0;
-      const int imm = tap_off<HY, HX, VB>(tapA);
-      // issue ALL of the step's LDS reads before the first MFMA (one lgkmcnt wait per step instead of a serialised
-      // read->wait->mfma chain per fragment); sched_barrier keeps the compiler from re-serialising to save VGPRs
-      u32x4_t af[MS];
-#pragma unroll
-      for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + lbase[cls] + ms * HSTR + imm);
+      // the NEXT step's LDS reads are issued before this step's MFMAs; sched_barrier keeps the compiler from re-serialising to save VGPRs
+      if (NAF == 2) { if (s + 1 < STEPS) read_frags(s + 1, af[(s + 1) % NAF]); }
+      else read_frags(s, af[0]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) {
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(WREG ? wreg[WREG ? s : 0][ns] : wf[ns], af[ms], acc[ms][ns]);
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(WREG ? wreg[WREG ? s : 0][ns] : wq[WREG ? 0 : s % (WD + 1)][ns], af[s % NAF][ms], acc[ms][ns]);
       }
       if (s < NP && stage_next) BPX_STAGE_PIECE(s < NP ? s : 0, nxt, chunk + 2);
       if (WREG && s >= NP && stage_next) {
@@ -292,10 +310,12 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
             wreg[WREG ? (k < STEPS ? k : 0) : 0][ns] = *reinterpret_cast<const u32x4_t*>(wl1 + ((size_t)k * 4 * Cout + ns * 16) * KPL);
         }
       }
-      if (!WREG && s + 1 < STEPS) {
+    }
+    if (!WREG && stage_next) {   // the ring's first WD steps of the next chunk: in flight across the chunk barrier
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) wf[ns] = wn[ns];
-      }
+      for (int d = 0; d < WD; ++d)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) wq[WREG ? 0 : d][ns] = *reinterpret_cast<const u32x4_t*>(wl1 + ((size_t)d * 4 * Cout + ns * 16) * KPL);
     }
     BPX_STAMP();  // 4,6,8..: step loop of the chunk done
     BPX_LOAD_NORM(chunk + 2);

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(1024) stats_compact_kernel(float* __restrict__
 
 // returns the tile stride the finalize kernel has to use (1 = untouched)
 static int compact_stats(float* part, int N, int tiles, int C, hipStream_t s) {
-  if (tiles < 1024) return 1;
+  if (tiles <= 1024) return 1;   // (1024 = LP_ROWS: the per-workgroup rows of the lean conv / fused backward kernels never need the extra pass)
   const int seg = cdiv(tiles, 32);
   dim3 grid((unsigned)cdiv(C, 16), (unsigned)N, (unsigned)cdiv(tiles, seg));
   stats_compact_kernel<<<grid, 1024, 0, s>>>(part, tiles, C, seg);
