@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPX_LIB_PATH") or os.path.join(_HERE, "libbiapy_amd.so")
 
 F32, BF16, F16, U8, MIX16 = 0, 1, 2, 3, 4   # MIX16: backward entries only - fp16 activations, bf16 gradients (include/biapy_amd.h)
-ACT = {"none": 0, "linear": 0, "elu": 1, "relu": 2, "silu": 3}
+# block activations of the reference (blocks.py:1973-1998): every entry of get_activation except "softmax" (a channel reduction, not a per-element prologue)
+ACT = {"none": 0, "linear": 0, "elu": 1, "relu": 2, "silu": 3, "leaky_relu": 4, "gelu": 5, "tanh": 6, "sigmoid": 7, "softplus": 8}
 PK_K3, PK_K3_T, PK_K1, PK_DENSE, PK_DENSE_T, PK_CT, PK_CT_T, PK_CT4, PK_CT4_T = range(9)
 
 

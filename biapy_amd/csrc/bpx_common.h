@@ -160,6 +160,56 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float u) {
   if (ACT == BPX_ACT_SILU) { float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
   return 1.f;
 }
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: below fp32 rounding of the sums it enters; one exp, five fmas) - GELU
+__device__ __forceinline__ float bpx_erf(float x) {
+  const float ax = fabsf(x), t = 1.f / fmaf(0.3275911f, ax, 1.f);
+  const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float r = 1.f - p * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+// ONE run-time switch over every block activation of the reference (blocks.py:1973-1998), used by every kernel's run-time-activation
+// instance (conv prologues, dgrad epilogues, wgrad staging, the materialised norm + act pair, gate MLPs).  PRECISE: fp32 storage mode (libm
+// exp / expm1 instead of the fast forms).
+template <bool PRECISE> __device__ __forceinline__ float bpx_act_rt(float u, int act) {
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
+    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
+    case BPX_ACT_SILU: return u / (1.f + (PRECISE ? expf(-u) : __expf(-u)));
+    case BPX_ACT_LEAKY_RELU: return u > 0.f ? u : 0.01f * u;
+    case BPX_ACT_GELU: return 0.5f * u * (1.f + bpx_erf(u * 0.70710678118654752f));
+    case BPX_ACT_TANH: { const float e = PRECISE ? expf(-2.f * fabsf(u)) : __expf(-2.f * fabsf(u)); return copysignf((1.f - e) / (1.f + e), u); }
+    case BPX_ACT_SIGMOID: return 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u)));
+    case BPX_ACT_SOFTPLUS: return u > 20.f ? u : (PRECISE ? log1pf(expf(u)) : __logf(1.f + __expf(u)));
+    default: return u;
+  }
+}
+// The same for N values at once with the switch OUTSIDE the element loop: a staging loop `for e: f[e] = act(f[e], code)` with the nine-way switch
+// inside is too large to unroll, and the then dynamically indexed f[] lands in scratch memory (measured: 400-576 bytes per lane).
+template <bool PRECISE, int N> __device__ __forceinline__ void bpx_act_vec(float* f, int act) {
+#define BPX_ACT_CASE(CODE)                                                    \
+  case CODE:                                                                  \
+    _Pragma("unroll") for (int e = 0; e < N; ++e) f[e] = bpx_act_rt<PRECISE>(f[e], CODE); \
+    break;
+  switch (act) {
+    BPX_ACT_CASE(BPX_ACT_ELU) BPX_ACT_CASE(BPX_ACT_RELU) BPX_ACT_CASE(BPX_ACT_SILU) BPX_ACT_CASE(BPX_ACT_LEAKY_RELU) BPX_ACT_CASE(BPX_ACT_GELU)
+    BPX_ACT_CASE(BPX_ACT_TANH) BPX_ACT_CASE(BPX_ACT_SIGMOID) BPX_ACT_CASE(BPX_ACT_SOFTPLUS)
+    default: break;
+  }
+#undef BPX_ACT_CASE
+}
+template <bool PRECISE> __device__ __forceinline__ float bpx_act_bwd_rt(float u, int act) {
+  switch (act) {
+    case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
+    case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case BPX_ACT_SILU: { const float s = 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u))); return s * (1.f + u * (1.f - s)); }
+    case BPX_ACT_LEAKY_RELU: return u > 0.f ? 1.f : 0.01f;
+    case BPX_ACT_GELU: return 0.5f * (1.f + bpx_erf(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
+    case BPX_ACT_TANH: { const float e = PRECISE ? expf(-2.f * fabsf(u)) : __expf(-2.f * fabsf(u)); const float th = (1.f - e) / (1.f + e); return 1.f - th * th; }
+    case BPX_ACT_SIGMOID: { const float s = 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u))); return s * (1.f - s); }
+    case BPX_ACT_SOFTPLUS: return u > 20.f ? 1.f : 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u)));
+    default: return 1.f;
+  }
+}
 
 // ---- helpers shared by the bf16 "lean" kernels (conv3d_lean.hip, wgrad.hip) -------------------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
@@ -184,8 +234,8 @@ template <int ACTK> __device__ __forceinline__ void act_pair(float& a, float& b,
     a = __builtin_amdgcn_fmed3f(u[0], e[0], 0.f);
     b = __builtin_amdgcn_fmed3f(u[1], e[1], 0.f);
   } else {
-    a = act == BPX_ACT_ELU ? (a > 0.f ? a : __expf(a) - 1.f) : act == BPX_ACT_RELU ? fmaxf(a, 0.f) : act == BPX_ACT_SILU ? a / (1.f + __expf(-a)) : a;
-    b = act == BPX_ACT_ELU ? (b > 0.f ? b : __expf(b) - 1.f) : act == BPX_ACT_RELU ? fmaxf(b, 0.f) : act == BPX_ACT_SILU ? b / (1.f + __expf(-b)) : b;
+    a = bpx_act_rt<false>(a, act);
+    b = bpx_act_rt<false>(b, act);
   }
 }
 

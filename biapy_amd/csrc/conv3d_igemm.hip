@@ -75,7 +75,8 @@ __device__ __forceinline__ void stage_block(unsigned char* smem, const T* __rest
           float f[KPL];
           unpack16<T>(v, f);
 #pragma unroll
-          for (int e = 0; e < KPL; ++e) f[e] = apply_act_rt<T>(fmaf(sc[e], f[e], sh[e]), act);
+          for (int e = 0; e < KPL; ++e) f[e] = fmaf(sc[e], f[e], sh[e]);
+          bpx_act_vec<std::is_same<T, float>::value, KPL>(f, act);
           v = pack16<T>(f);
         }
         *reinterpret_cast<u32x4_t*>(smem + (size_t)(idx / GPT) * VB + sub * 16) = v;
@@ -196,7 +197,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
       if (nrec && goff[u] != 0xFFFFFFFFu && !(p.dbg & 2)) {                                                   \
         float f_[KPL];                                                                                        \
         unpack16<T>(v_, f_);                                                                                  \
-        _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = apply_act_rt<T, ACTK>(fmaf(psc[e_], f_[e_], psh[e_]), p.act); \
+        if (ACTK == 1) { _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = apply_act_rt<T, 1>(fmaf(psc[e_], f_[e_], psh[e_]), p.act); } \
+        else { _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = fmaf(psc[e_], f_[e_], psh[e_]);                    \
+               bpx_act_vec<std::is_same<T, float>::value, KPL>(f_, p.act); }                                               \
         v_ = pack16<T>(f_);                                                                                   \
       }                                                                                                       \
       *reinterpret_cast<u32x4_t*>(smem + (wbuf) + (size_t)idx_ * 16) = v_;                                    \

@@ -42,22 +42,12 @@ inline int chunk_stride(const bpx_tensor& t) { return t.cs ? (int)t.cs : 16; }
 template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
   if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
-    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
-    default: return u;
-  }
+  return bpx_act_rt<PRECISE>(u, act);
 }
 template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
   if (ACTK == 1) return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
-    case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-    case BPX_ACT_SILU: { float s = 1.f / (1.f + __expf(-u)); return s * (1.f + u * (1.f - s)); }
-    default: return 1.f;
-  }
+  return bpx_act_bwd_rt<PRECISE>(u, act);
 }
 
 

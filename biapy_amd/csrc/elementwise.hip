@@ -8,13 +8,7 @@
 namespace {
 
 template <typename T> __device__ __forceinline__ float elu_like(float u, int act) {
-  constexpr bool PRECISE = std::is_same<T, float>::value;
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
-    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
-    default: return u;
-  }
+  return bpx_act_rt<std::is_same<T, float>::value>(u, act);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,8 +400,7 @@ __global__ void __launch_bounds__(256) norm_act_fwd_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < KPL; ++e) {
       float u = sc[e] * f[e] + sh[e];
-      f[e] = act == BPX_ACT_ELU ? act_fwd<BPX_ACT_ELU>(u) : act == BPX_ACT_RELU ? act_fwd<BPX_ACT_RELU>(u)
-           : act == BPX_ACT_SILU ? act_fwd<BPX_ACT_SILU>(u) : u;
+      f[e] = bpx_act_rt<false>(u, act);
     }
     *reinterpret_cast<u32x4_t*>(y + vox * y_ld + cg * KPL) = pack16<T>(f);
   }
@@ -444,8 +437,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < KPL; ++e) {
       float u = sc[e] * f[e] + sh[e];
-      float da = act == BPX_ACT_ELU ? act_bwd<BPX_ACT_ELU>(u) : act == BPX_ACT_RELU ? act_bwd<BPX_ACT_RELU>(u)
-               : act == BPX_ACT_SILU ? act_bwd<BPX_ACT_SILU>(u) : 1.f;
+      float da = bpx_act_bwd_rt<false>(u, act);
       float gv = d[e] * da;
       s1[e] += gv;
       s2[e] += gv * ((f[e] - mu[e]) * rs[e]);
@@ -1670,7 +1662,7 @@ extern "C" int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, 
   const char* fn = "bpx_norm_act_fwd";
   BPX_CHECK(x.ptr && y.ptr && rec_d, "%s: null pointer", fn);
   BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
-  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
   if ((int64_t)N * voxels == 0) return 0;
   const int kpl = dtype == BPX_BF16 ? 8 : 4;
   dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
@@ -1690,7 +1682,7 @@ extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy,
   const char* fn = "bpx_norm_act_bwd";
   BPX_CHECK(dy.ptr && x.ptr && g.ptr && rec_d && red_part_d, "%s: null pointer", fn);
   BPX_CHECK(x.C == dy.C && x.C == g.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
-  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
   if ((int64_t)N * voxels == 0) return 0;
   const int kpl = dtype == BPX_BF16 ? 8 : 4;
   dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
@@ -1739,13 +1731,10 @@ extern "C" int bpx_channel_affine(int dtype, int N, int64_t voxels, bpx_tensor x
 // saved[n] = { m[C], u1[R], a1[R] }.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gate_act(float u, int act) {
-  return act == BPX_ACT_RELU ? fmaxf(u, 0.f) : act == BPX_ACT_SILU ? u / (1.f + expf(-u)) : act == BPX_ACT_ELU ? (u > 0.f ? u : expm1f(u)) : u;
+  return bpx_act_rt<true>(u, act);
 }
 __device__ __forceinline__ float gate_act_bwd(float u, int act) {
-  if (act == BPX_ACT_RELU) return u > 0.f ? 1.f : 0.f;
-  if (act == BPX_ACT_SILU) { const float sg = 1.f / (1.f + expf(-u)); return sg * (1.f + u * (1.f - sg)); }
-  if (act == BPX_ACT_ELU) return u > 0.f ? 1.f : expf(u);
-  return 1.f;
+  return bpx_act_bwd_rt<true>(u, act);
 }
 
 // sum over the tiles of one (sample, channel) column, 256 / C lanes per channel, combined through LDS in lane order
@@ -1858,7 +1847,7 @@ extern "C" int bpx_gate_mlp_fwd(const float* part_d, int N, int tiles, int C, in
   BPX_CHECK(part_d && w1_d && w2_d && s_d && saved_d, "%s: null pointer", fn);
   BPX_CHECK(N >= 0 && tiles > 0 && voxels > 0, "%s: bad extents", fn);
   BPX_CHECK(C >= 1 && C <= 256 && R >= 1 && R <= 64 && R <= C, "%s: C must be <= 256 and R <= 64 (got C=%d R=%d)", fn, C, R);
-  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
   if (N == 0) return 0;
   gate_mlp_fwd_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(part_d, tiles, C, (float)(1.0 / (double)voxels), w1_d, b1_d, w2_d, b2_d, R, act, s_d, saved_d);
   BPX_LAUNCH_CHECK(fn);
@@ -1872,7 +1861,7 @@ extern "C" int bpx_gate_mlp_bwd(const float* dpart_d, int N, int tiles, int C, i
   BPX_CHECK(dpart_d && s_d && saved_d && w1_d && w2_d && dw1_d && dw2_d && off_d, "%s: null pointer", fn);
   BPX_CHECK(N >= 0 && tiles > 0 && voxels > 0, "%s: bad extents", fn);
   BPX_CHECK(C >= 1 && C <= 256 && R >= 1 && R <= 64 && R <= C, "%s: C must be <= 256 and R <= 64 (got C=%d R=%d)", fn, C, R);
-  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: unknown activation %d", fn, act);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
   if (N == 0) return 0;
   gate_mlp_bwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(dpart_d, N, tiles, C, (float)(1.0 / (double)voxels), s_d, saved_d, w1_d, w2_d, R, act, dw1_d, db1_d,
                                                           dw2_d, db2_d, off_d);

@@ -48,12 +48,7 @@ struct WgradParams {
 template <typename T, int ACTK = 0> __device__ __forceinline__ float act_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
   if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
-    case BPX_ACT_SILU: return u / (1.f + __expf(-u));
-    default: return u;
-  }
+  return bpx_act_rt<PRECISE>(u, act);
 }
 
 // Stage EZ*EY*EX voxels x NCH channels (NCH multiple of 16/GPT pieces) into LDS [voxel][NCH].
@@ -107,7 +102,13 @@ __device__ __forceinline__ void stage_any(unsigned char* smem, const T* __restri
           float f[KPL];
           unpack16<T>(v, f);
 #pragma unroll
-          for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, ACTK>(fmaf(sc[e], f[e], sh[e]), act);
+          for (int e = 0; e < KPL; ++e) f[e] = fmaf(sc[e], f[e], sh[e]);
+          if (ACTK == 1) {
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, 1>(f[e], act);
+          } else {
+            bpx_act_vec<std::is_same<T, float>::value, KPL>(f, act);
+          }
           v = pack16<T>(f);
         }
         *reinterpret_cast<u32x4_t*>(smem + (size_t)(idx / PPV) * VB + sub * 16) = v;
@@ -243,7 +244,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
           }
           if (p.in_norm) {
 #pragma unroll
-            for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, ACTK>(fmaf(psc[e], f[e], psh[e]), p.act);
+            for (int e = 0; e < KPL; ++e) f[e] = fmaf(psc[e], f[e], psh[e]);
+            if (ACTK == 1) {
+#pragma unroll
+              for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, 1>(f[e], p.act);
+            } else {
+              bpx_act_vec<std::is_same<T, float>::value, KPL>(f, p.act);
+            }
           }
           v = pack16<T>(f);
         }

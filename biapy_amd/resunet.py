@@ -18,10 +18,13 @@ forward of a leaf layer is ever called - ``forward`` hands the parameter tensors
 zero-padded taps (``engine.lift_params``): correct, but 2/3 of those layers' MFMA work is spent on zeros - they are accepted
 so that the drop-in covers the reference's templates, the tuned path is the isotropic 3D one.
 
-Configurations outside the accelerated hot path (normalisation other than "in", larger_io,
-separated decoders, contrastive head, SR up-sampling, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2,
-pre-activation order, dropout) raise ``NotImplementedError`` at construction: they stay on the reference's
-plain-PyTorch classes, selected by the same registry.
+Round 4: every per-element block activation of ``get_activation`` (blocks.py:1973-1998: relu, tanh, leaky_relu, elu, gelu, silu, sigmoid,
+softplus, linear / none), the classification head (``"class"`` in ``output_channel_info``: ``forward`` returns ``{"pred", "class"}``) and
+``explicit_activations`` (resunet.py:408-443) are built and pinned to fixtures generated from the reference class.
+
+Configurations outside the accelerated hot path (normalisation other than "in" / "gn", larger_io, separated decoders, contrastive head,
+``upsample_layer="upsampling"``, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2, pre-activation order, dropout, softmax as a BLOCK
+activation) raise ``NotImplementedError`` at construction: they stay on the reference's plain-PyTorch classes, selected by the same registry.
 """
 from __future__ import annotations
 
@@ -34,7 +37,14 @@ from .engine import NetConfig, ResUNetEngine
 
 
 def _act_layer(name: str) -> nn.Module:
-    return {"elu": nn.ELU(alpha=1.0, inplace=True), "relu": nn.ReLU(inplace=True), "silu": nn.SiLU(inplace=True)}[name]
+    # the parameter-free placeholder modules of blocks.py:1986-1998 (they only keep the reference's module tree / state_dict numbering; the
+    # activation itself runs in the kernels' prologues)
+    layers = {"elu": lambda: nn.ELU(alpha=1.0, inplace=True), "relu": lambda: nn.ReLU(inplace=True), "silu": lambda: nn.SiLU(inplace=True),
+              "leaky_relu": lambda: nn.LeakyReLU(inplace=True), "gelu": nn.GELU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "softplus": nn.Softplus,
+              "linear": nn.Identity, "none": nn.Identity}
+    if name not in layers:
+        raise NotImplementedError(f"activation={name!r} is not implemented on the MI355X engine (softmax as a block activation is a channel reduction)")
+    return layers[name]()
 
 
 def _conv(ndim: int):
@@ -253,18 +263,39 @@ class ResUNet(nn.Module):
             unsupported("conv_block_order != 'conv_norm_act' or conv_layers != 2")
         if any(float(d) > 0 for d in drop_values):
             unsupported("dropout")
-        if explicit_activations or "class" in output_channel_info:
-            unsupported("explicit head activations / classification head")
         self.depth = depth
         self.ndim = ndim
         self.z_down, self.yx_down = z_down, yx_down
         self.output_channels = output_channels
         self.output_channel_info = output_channel_info
         self.head_activations = list(head_activations)
-        self.return_class = False
+        # Classification head (resunet.py:180, :408-443): an output head whose output_channel_info entry contains "class" leaves forward() as
+        # out["class"], the others concatenated as out["pred"].  All heads are rows of ONE (sum(output_channels), fm0) matrix in the head
+        # kernel; the split and - with explicit_activations - the per-channel activations of prepare_activation_layers (blocks.py:2001-2051) are
+        # applied to the kernel's fp32 logits with differentiable PyTorch operators (one small elementwise pass per channel: the non-default
+        # configuration), so the gradients of every head reach the head kernel's backward as one dlogits tensor.
+        self.return_class = any("class" in str(info) for info in output_channel_info)
         self.contrast = False
-        self.explicit_activations = False
+        self.explicit_activations = bool(explicit_activations)
         self.return_one_tensor = return_one_tensor
+        chan_info = [str(info) for info, n in zip(output_channel_info, output_channels) for _ in range(int(n))]
+        if len(chan_info) != sum(output_channels):
+            raise ValueError("'output_channel_info' needs one entry per output head")
+        self._class_channels = [c for c, info in enumerate(chan_info) if "class" in info]
+        self._pred_channels = [c for c, info in enumerate(chan_info) if "class" not in info]
+        if not self._pred_channels:
+            raise ValueError("at least one output head must not be a 'class' head")
+        self._explicit_acts = None
+        if self.explicit_activations:
+            assert len(head_activations) == sum(output_channels), ("If 'explicit_activations' is True, 'head_activations' needs to have the same number "
+                                                                   "of values as 'output_channels'")
+            names_ = [a.lower().removeprefix("ce_") for a in head_activations]
+            for a in names_:
+                if a not in ("relu", "tanh", "leaky_relu", "elu", "gelu", "silu", "sigmoid", "softmax", "linear", "softplus", "none"):
+                    raise AssertionError("Get unknown activation key {}".format(a))
+            self._explicit_acts = names_
+            if self.return_class and not self._class_channels:
+                raise ValueError("If 'return_class' is True, 'head_activations' must be provided.")
         in_ch = image_shape[-1]
         zd = [int(v) for v in list(z_down)[:depth]] if ndim == 3 else [1] * depth
         self.cfg = NetConfig(in_ch=16 if self.sr_pre else in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
@@ -345,11 +376,42 @@ class ResUNet(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             gr = getattr(self, "_graphs", None)
             if gr is not None and tuple(x.shape) == gr["shape"] and x.stride() == gr["stride"] and not torch.cuda.is_current_stream_capturing():
-                return _GraphedResUNetFn.apply(x, gr, *params)
-            return _ResUNetFn.apply(x, self.engine(), names, *params)
+                return self._finish_outputs(_GraphedResUNetFn.apply(x, gr, *params))
+            return self._finish_outputs(_ResUNetFn.apply(x, self.engine(), names, *params))
         P = {n: p.detach() for n, p in zip(names, params)}
         logits, _ = self.engine().forward(P, x, head_act=0, save=False, cache_weights=not self.training)
-        return logits
+        return self._finish_outputs(logits)
+
+    @staticmethod
+    def _apply_named(t: torch.Tensor, name: str) -> torch.Tensor:
+        import torch.nn.functional as F_
+        fn = {"relu": torch.relu, "tanh": torch.tanh, "leaky_relu": F_.leaky_relu, "elu": F_.elu, "gelu": F_.gelu, "silu": F_.silu, "sigmoid": torch.sigmoid,
+              "softmax": lambda v: torch.softmax(v, dim=1), "linear": lambda v: v, "softplus": F_.softplus, "none": lambda v: v}[name]
+        return fn(t)
+
+    def _finish_outputs(self, logits: torch.Tensor):
+        """The tail of the reference forward (resunet.py:408-443) on the head kernel's (B, sum(output_channels), ...) logits."""
+        if not self.return_class and not self.explicit_activations:
+            return logits
+        outs = logits[:, self._pred_channels] if self.return_class else logits
+        cls = logits[:, self._class_channels] if self.return_class else None
+        if self.explicit_activations:
+            acts = self._explicit_acts
+            pa = [acts[c] for c in self._pred_channels]
+            if len(pa) == 1:
+                outs = self._apply_named(outs, pa[0])
+            else:                                           # channel by channel, as the reference (a softmax entry acts on its own channel there too)
+                outs = torch.cat([self._apply_named(outs[:, i:i + 1], a) for i, a in enumerate(pa)], dim=1)
+            if cls is not None:
+                # prepare_activation_layers stops collecting at the first softmax: one activation module per collected CLASS channel, each
+                # applied to class_outs[i] = the WHOLE output of class head i (resunet.py:423-425); with one class head that is its first entry
+                ca = [acts[c] for c in self._class_channels]
+                cls = self._apply_named(cls, ca[0])
+        if not self.return_class:
+            return outs
+        if self.return_one_tensor:
+            return torch.cat((outs, torch.argmax(cls, dim=1).unsqueeze(1)), dim=1)
+        return {"pred": outs, "class": cls}
 
     def capture_graphs(self, x_example: torch.Tensor, warmup: int = 3) -> None:
         """Capture the training forward and backward for inputs shaped like ``x_example`` into two HIP graphs; later

@@ -31,7 +31,12 @@ enum bpx_dtype { BPX_F32 = 0, BPX_BF16 = 1, BPX_F16 = 2, BPX_U8 = 3,
                   * operands of the backward kernels are bf16 (fp32 exponent range: no loss scaling).  Each backward entry says which of
                   * its operands are activations. */
                  BPX_MIX16 = 4 };
-enum bpx_act { BPX_ACT_NONE = 0, BPX_ACT_ELU = 1, BPX_ACT_RELU = 2, BPX_ACT_SILU = 3 };
+/* Block activations (biapy/models/blocks.py:1973-1998, get_activation): codes 0-3 since round 1; round 4 adds leaky_relu (slope 0.01, nn.LeakyReLU's
+ * default), gelu (nn.GELU(): the exact erf form), tanh, sigmoid and softplus (beta 1, threshold 20).  "softmax" as a block activation needs a
+ * reduction over channels and is not a per-element prologue: not offered.  ELU (the reference default) has compile-time instances of every
+ * kernel; the other codes take the run-time-switch instances. */
+enum bpx_act { BPX_ACT_NONE = 0, BPX_ACT_ELU = 1, BPX_ACT_RELU = 2, BPX_ACT_SILU = 3, BPX_ACT_LEAKY_RELU = 4, BPX_ACT_GELU = 5, BPX_ACT_TANH = 6,
+               BPX_ACT_SIGMOID = 7, BPX_ACT_SOFTPLUS = 8, BPX_ACT_LAST = 8 };
 enum bpx_pad_mode { BPX_PAD_REFLECT = 0, BPX_PAD_ZEROS = 1 };
 
 int bpx_version(void);

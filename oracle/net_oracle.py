@@ -39,6 +39,16 @@ def _act(x: torch.Tensor, name: str) -> torch.Tensor:
         return F.relu(x)
     if name == "silu":
         return F.silu(x)
+    if name == "leaky_relu":
+        return F.leaky_relu(x)                      # nn.LeakyReLU(): slope 0.01
+    if name == "gelu":
+        return F.gelu(x)                            # nn.GELU(): exact erf form
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "softplus":
+        return F.softplus(x)                        # beta 1, threshold 20
     if name in ("none", "linear"):
         return x
     raise ValueError(name)

@@ -117,6 +117,20 @@ def unet_golden():
 
 
 @pytest.fixture(scope="session")
+def resunet_activations_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunet_activations_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def resunet_class_head_golden():
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunet_class_head_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def resunet_variants_golden():
     import numpy as np
 

@@ -793,6 +793,106 @@ def resunet_variants_fixtures():
     print("resunet_variants_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_variants_golden.npz")) // 1024, "KiB")
 
 
+def resunet_activations_fixtures():
+    """The reference ResUNet with each block activation of get_activation (blocks.py:1973-1998) that the MI355X engine offers beyond ELU - relu,
+    silu, leaky_relu, gelu, tanh, sigmoid, softplus - on a 2-level 3D network: reference logits, loss and all gradient norms.  Pins
+    oracle/net_oracle.py's activation switch (and through it the kernels' run-time-activation instances) to the reference classes."""
+    rmod = shim.load("biapy.models.resunet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import net_oracle
+
+    out = {}
+    fm, patch = [16, 32], (16, 16, 16)
+    for i, act in enumerate(["relu", "silu", "leaky_relu", "gelu", "tanh", "sigmoid", "softplus"]):
+        torch.manual_seed(60)                         # the same weights and the same batch for every activation: stored once
+        with quiet():
+            net = rmod.ResUNet(image_shape=patch + (1,), activation=act, feature_maps=fm, drop_values=[0.0] * 2, normalization="in", k_size=3,
+                               upsample_layer="convtranspose", yx_down=[2], z_down=[2], output_channels=[1], output_channel_info=["F"],
+                               head_activations=["ce_sigmoid"], isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2)
+        g = torch.Generator().manual_seed(160)
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if v.ndim == 1:
+                    v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+        B = 2
+        xl = torch.randn(B, *patch, 1, generator=g)
+        x = xl.permute(0, 4, 1, 2, 3)
+        tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+        net.train()
+        logits = net(x)
+        loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)
+        loss.backward()
+        if i == 0:
+            out["x"], out["target"] = xl.numpy(), tgt.numpy().astype(np.uint8)
+            for k, v in net.state_dict().items():
+                out[f"sd/{k}"] = v.numpy()
+        else:
+            assert all(np.array_equal(out[f"sd/{k}"], v.numpy()) for k, v in net.state_dict().items()) and np.array_equal(out["x"], xl.numpy())
+        out[f"{act}/logits"], out[f"{act}/loss"] = logits.detach().numpy(), np.array(loss.item(), dtype=np.float64)
+        for k, p_ in net.named_parameters():
+            out[f"{act}/gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+        for k in ["down_path.0.block.0.block.0.weight", "down_path.0.block.1.block.0.weight", "up_paths.0.0.conv_block.shortcut.0.weight", "heads.0.weight"]:
+            out[f"{act}/grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        lo = net_oracle.resunet_forward(sd, x, fm, activation=act)
+        err = (lo - logits.detach()).abs().max().item()
+        print(f"resunet activation {act}: oracle vs reference {err:.3e}")
+        assert err < 2e-5
+    out["feature_maps"] = np.array(fm)
+    np.savez_compressed(os.path.join(HERE, "resunet_activations_golden.npz"), **out)
+    print("resunet_activations_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_activations_golden.npz")) // 1024, "KiB")
+
+
+def resunet_class_head_fixtures():
+    """The reference ResUNet with a classification head (output_channels [1, 3], output_channel_info ["F", "class"], resunet.py:180, :408-443): the
+    out dict without and with explicit_activations (sigmoid on the mask channel, softmax over the class block), a loss over both heads
+    (BCE on pred + cross-entropy on class) and all gradient norms - what the drop-in's output tail and head kernel must reproduce."""
+    rmod = shim.load("biapy.models.resunet")
+    out = {}
+    fm, patch = [16, 32], (16, 16, 16)
+    for tag, explicit in (("logits", False), ("explicit", True)):
+        torch.manual_seed(71)
+        with quiet():
+            net = rmod.ResUNet(image_shape=patch + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * 2, normalization="in", k_size=3,
+                               upsample_layer="convtranspose", yx_down=[2], z_down=[2], output_channels=[1, 3], output_channel_info=["F", "class"],
+                               explicit_activations=explicit, head_activations=["ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"],
+                               isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2)
+        g = torch.Generator().manual_seed(171)
+        B = 2
+        xl = torch.randn(B, *patch, 1, generator=g)
+        tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+        cls_t = torch.randint(0, 3, (B,) + patch, generator=g)
+        net.train()
+        o = net(xl.permute(0, 4, 1, 2, 3))
+        assert isinstance(o, dict) and set(o) == {"pred", "class"}
+        if explicit:
+            loss = torch.nn.functional.binary_cross_entropy(o["pred"], tgt) + torch.nn.functional.nll_loss(torch.log(o["class"] + 1e-12), cls_t)
+        else:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(o["pred"], tgt) + torch.nn.functional.cross_entropy(o["class"], cls_t)
+        loss.backward()
+        if tag == "logits":
+            out["x"], out["target"], out["class_target"] = xl.numpy(), tgt.numpy().astype(np.uint8), cls_t.numpy().astype(np.uint8)
+            for k, v in net.state_dict().items():
+                out[f"sd/{k}"] = v.detach().numpy()
+        out[f"{tag}/pred"], out[f"{tag}/class"], out[f"{tag}/loss"] = o["pred"].detach().numpy(), o["class"].detach().numpy(), np.array(loss.item(), dtype=np.float64)
+        for k, p_ in net.named_parameters():
+            out[f"{tag}/gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+        for k in ["heads.0.weight", "heads.1.weight", "heads.1.bias", "down_path.0.block.1.block.0.weight"]:
+            out[f"{tag}/grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+        net.eval()
+        with quiet():
+            net1 = rmod.ResUNet(image_shape=patch + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * 2, normalization="in", k_size=3,
+                                upsample_layer="convtranspose", yx_down=[2], z_down=[2], output_channels=[1, 3], output_channel_info=["F", "class"],
+                                explicit_activations=explicit, head_activations=["ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"],
+                                isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2, return_one_tensor=True)
+        net1.load_state_dict(net.state_dict())
+        with torch.no_grad():
+            out[f"{tag}/one_tensor"] = net1(xl.permute(0, 4, 1, 2, 3)).numpy()
+    out["feature_maps"] = np.array(fm)
+    np.savez_compressed(os.path.join(HERE, "resunet_class_head_golden.npz"), **out)
+    print("resunet_class_head_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_class_head_golden.npz")) // 1024, "KiB")
+
+
 def chunked_fixtures():
     """By-chunks tiler: the reference generator's own ``_patch_coords`` / ``extract_and_prepare_sample`` on seeded uint8
     volumes (the class is loaded with the third-party modules it never calls on this path stubbed; a bare object carrying the
@@ -1128,7 +1228,7 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -1157,6 +1257,10 @@ if __name__ == "__main__":
         unet_fixtures()
     if "resunet_variants" in which:
         resunet_variants_fixtures()
+    if "resunet_activations" in which:
+        resunet_activations_fixtures()
+    if "resunet_class_head" in which:
+        resunet_class_head_fixtures()
     if "chunked" in which:
         chunked_fixtures()
     if "rcan" in which:

@@ -251,7 +251,14 @@ def check_merge_sharded():
 
 # ---------------------------------------------------------------------------------------------------
 def _act_ref(u, act):
-    return {0: lambda v: v, 1: lambda v: F.elu(v), 2: F.relu, 3: F.silu}[act](u)
+    return {0: lambda v: v, 1: lambda v: F.elu(v), 2: F.relu, 3: F.silu, 4: F.leaky_relu, 5: F.gelu, 6: torch.tanh, 7: torch.sigmoid, 8: F.softplus}[act](u)
+
+
+def _dact_ref(u, act):
+    """act'(u) by autograd of the PyTorch operator."""
+    v = u.detach().clone().requires_grad_(True)
+    _act_ref(v, act).sum().backward()
+    return v.grad
 
 
 def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=0, act=1):
@@ -363,7 +370,7 @@ def check_conv3d_dgrad(dt, B, S, Cin, Cout, seed=0, act=1):
     rec, _, _ = make_recs(B, Cin, seed + 1)
     dA = F.conv_transpose3d(ncdhw(dy), rnd(w, dt), padding=1)
     u = t * rec[:, None, None, None, :, 2] + rec[:, None, None, None, :, 3]
-    dact = {1: torch.where(u > 0, torch.ones_like(u), torch.exp(u)), 2: (u > 0).float()}[act]
+    dact = _dact_ref(u, act)
     g_ref = ndhwc(dA) * dact
     xh = (t - rec[:, None, None, None, :, 0]) * rec[:, None, None, None, :, 1]
     gd = torch.empty(B, D, H, W, Cin, dtype=tdtype(dt), device=DEV)
@@ -797,7 +804,7 @@ def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, 
     # fp32 references
     dA = ndhwc(F.conv_transpose3d(ncdhw(dy), rnd(w, G_), padding=1))
     u = t * rec[:, None, None, None, :, 2] + rec[:, None, None, None, :, 3]
-    dact = {1: torch.where(u > 0, torch.ones_like(u), torch.exp(u)), 2: (u > 0).float()}[act]
+    dact = _dact_ref(u, act)
     g_ref = dA * dact
     xh = (t - rec[:, None, None, None, :, 0]) * rec[:, None, None, None, :, 1]
     a = rnd(_act_ref(u, act), G_)
@@ -1139,7 +1146,7 @@ def parity_rows(tag, logits, lo_ref, tgt, dtype, trained=False):
     return rows
 
 
-def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True, normalization="in"):
+def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True, normalization="in", activation="elu"):
     """Whole network vs the oracle: logits, Dice, loss and every parameter gradient.  normalization="gn": torch.nn.GroupNorm(8, C) for every
     norm layer (what the reference's 'gn' means; its own call raises) - the oracle then runs F.group_norm, incl. the groups of 6 / 12 / 24
     channels that straddle the up / skip boundary of the decoder's concatenated inputs."""
@@ -1154,7 +1161,7 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True, normaliz
         g = torch.Generator().manual_seed(seed + 7)
         x = torch.randn(B, 1, *patch, generator=g)
         tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).float()
-    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, normalization=normalization), dtype)
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, normalization=normalization, activation=activation), dtype)
     P = {k: v.to(DEV) for k, v in sd.items()}
     if normalization != "in":           # non-trivial affine parameters (the default initialisation is gamma = 1, beta = 0)
         g = torch.Generator().manual_seed(seed + 99)
@@ -1165,12 +1172,12 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True, normaliz
     xd = x.to(DEV)
     logits, ctx = eng.forward(P, xd, head_act=0, save=train)
     torch.cuda.synchronize()
-    tag = f"resunet[{tagd} {normalization} fm={fm} {tuple(x.shape)}{' golden' if golden is not None else ''}]"
+    tag = f"resunet[{tagd} {normalization}{'' if activation == 'elu' else ' ' + activation} fm={fm} {tuple(x.shape)}{' golden' if golden is not None else ''}]"
     res = []
     if golden is not None:
         lo_ref = torch.from_numpy(golden["small/logits"])
     else:
-        lo_ref = net_oracle.resunet_forward(sd, x, fm, normalization=normalization)
+        lo_ref = net_oracle.resunet_forward(sd, x, fm, normalization=normalization, activation=activation)
     scale = lo_ref.abs().max().item()
     err = (logits.cpu() - lo_ref).abs().max().item() / scale
     res.append(_res(tag + ".logits_rel", err, LOGITS_TOL[tagd], extra=f"scale={scale:.3f}"))
@@ -1182,9 +1189,51 @@ def check_network(dtype, fm, patch, B, golden=None, seed=0, train=True, normaliz
     loss.backward()
     G = eng.backward(P, ctx, lg.grad)
     torch.cuda.synchronize()
-    loss_ref, _, grads_ref = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm, normalization=normalization)
+    loss_ref, _, grads_ref = net_oracle.train_step_grads(sd, x, tgt, feature_maps=fm, normalization=normalization, activation=activation)
     res.append(_res(tag + ".loss", abs(loss.item() - loss_ref.item()), LOSS_TOL[tagd]))
     res += grad_rows(tag, G, grads_ref, tagd, len(fm) - 1)
+    return res
+
+
+def check_network_activation(dtype, golden, act):
+    """The drop-in network with a non-default block activation against the REFERENCE fixture (resunet_activations_golden.npz: logits, loss, all
+    gradient norms, four full gradients of the reference ResUNet built with that activation)."""
+    tagd = _mode(dtype)[0]
+    fm = [int(v) for v in golden["feature_maps"]]
+    sd = {k[3:]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("sd/")}
+    x = torch.from_numpy(golden["x"]).permute(0, 4, 1, 2, 3).contiguous()
+    tgt = torch.from_numpy(golden["target"]).float()
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, activation=act), dtype)
+    P = {k: v.to(DEV) for k, v in sd.items()}
+    logits, ctx = eng.forward(P, x.to(DEV), head_act=0, save=True)
+    lg = logits.detach().clone().requires_grad_(True)
+    loss = F.binary_cross_entropy_with_logits(lg, tgt.to(DEV))
+    loss.backward()
+    G = eng.backward(P, ctx, lg.grad)
+    torch.cuda.synchronize()
+    tag = f"resunet_activation[{tagd} {act}]"
+    lo_ref = torch.from_numpy(golden[f"{act}/logits"])
+    res = [_res(tag + ".logits_rel", (logits.cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), LOGITS_TOL[tagd]),
+           _res(tag + ".loss", abs(loss.item() - float(golden[f"{act}/loss"])), LOSS_TOL[tagd])]
+    gmax = max(float(golden[k]) for k in golden.files if k.startswith(f"{act}/gradnorm/"))
+    worst, wname = 0.0, ""
+    for k in golden.files:
+        if k.startswith(f"{act}/gradnorm/"):
+            name = k[len(f"{act}/gradnorm/"):]
+            ref = float(golden[k])
+            e = abs(G[name].norm().item() - ref) / max(ref, (GRAD_FLOOR_F32 if dtype == torch.float32 else GRAD_FLOOR_BF16) * gmax)
+            if e > worst:
+                worst, wname = e, name
+    res.append(_res(tag + ".grad_norms_rel_worst", worst, GRAD_TOL[tagd], extra=wname))
+    worst, wname = 0.0, ""
+    for k in golden.files:
+        if k.startswith(f"{act}/grad/"):
+            name = k[len(f"{act}/grad/"):]
+            ref = torch.from_numpy(golden[k])
+            e = (G[name].cpu() - ref).norm().item() / max(ref.norm().item(), 1e-6 * gmax)
+            if e > worst:
+                worst, wname = e, name
+    res.append(_res(tag + ".full_grads_rel_l2_worst", worst, GRAD_TOL[tagd], extra=wname))
     return res
 
 

@@ -415,6 +415,39 @@ def test_resunet_variants_oracle_and_module(resunet_variants_golden, tag, shape)
     m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
 
 
+ACTS = ["relu", "silu", "leaky_relu", "gelu", "tanh", "sigmoid", "softplus"]
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_resunet_block_activations_oracle_matches_reference(resunet_activations_golden, act):
+    """Every block activation of the reference's get_activation (blocks.py:1973-1998) that the engine offers: the oracle graph reproduces the
+    reference ResUNet's logits, loss and gradients built with that activation (fixture from tests/golden/make_golden.py resunet_activations),
+    and the drop-in module accepts the name."""
+    import torch
+    import torch.nn.functional as F
+
+    from biapy_amd.resunet import ResUNet
+    from oracle import net_oracle
+
+    g = resunet_activations_golden
+    fm = [int(v) for v in g["feature_maps"]]
+    sd = {k[3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3)
+    logits = net_oracle.resunet_forward(sd, x, fm, activation=act)
+    loss = F.binary_cross_entropy_with_logits(logits, torch.from_numpy(g["target"]).float())
+    loss.backward()
+    assert (logits.detach() - torch.from_numpy(g[f"{act}/logits"])).abs().max().item() < 2e-5
+    assert abs(loss.item() - float(g[f"{act}/loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith(f"{act}/gradnorm/"):
+            name = k[len(f"{act}/gradnorm/"):]
+            ref = float(g[k])
+            assert abs(sd[name].grad.norm().item() - ref) <= 1e-4 * ref + 1e-6, name
+    m = ResUNet(image_shape=(16, 16, 16, 1), activation=act, feature_maps=fm, drop_values=[0.0] * 2, normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2)
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+
+
 def _chunked_case(g, tag):
     dim, crop, pad = tuple(int(v) for v in g[f"{tag}/dim"]), tuple(int(v) for v in g[f"{tag}/crop"]), tuple(int(v) for v in g[f"{tag}/padding"])
     vol = np.random.RandomState(int(g[f"{tag}/seed"])).randint(0, 256, size=dim + (1,)).astype(np.uint8)
