@@ -270,7 +270,13 @@ def _tiling_traffic(V, world, n_patches):
     if not (V == 512 and world == 1 and n_patches == 512):
         return dict(traffic=None)
     try:
+        from biapy_amd._lib import source_digest
+
         d = json.load(open(os.path.join(ROOT, src)))
+        stamp = (d.get("_meta") or {}).get("tiling_sha256")
+        if stamp != source_digest(only=("tiling.hip", "bpx_common.h")):      # the same refusal as for the conv counters
+            print(f"[bench] {src} is STALE: collected for other tiling kernel sources; sliding.traffic is null until scripts/refresh_profiles.sh is re-run", file=sys.stderr)
+            return dict(traffic=None, traffic_error=f"{src} is stale (collected for other kernel sources); re-run scripts/refresh_profiles.sh")
         return dict(traffic=(d.get("bpx_merge3d_blend") or {}).get("total_bytes"), crop_traffic=(d.get("bpx_crop3d_gather") or {}).get("total_bytes"),
                     traffic_source=src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tests/bench_kernels.py merge_rows, committed; "
                                          "bytes per whole-volume pass: the gather is issued per batch in the predictor)")

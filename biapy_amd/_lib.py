@@ -218,14 +218,17 @@ class _LibProxy:
 lib = _LibProxy(_load())
 
 
-def source_digest() -> str:
+def source_digest(only=None) -> str:
     """sha256 over the kernel sources (csrc/*.hip, *.h, *.cpp in name order): stamped into the PMC summaries under profiles/ so that bench.py
-    can tell when a committed counter file no longer belongs to the kernels it is quoted for."""
+    can tell when a committed counter file no longer belongs to the kernels it is quoted for.  ``only``: file names to restrict it to (the
+    blend / gather counters depend on tiling.hip and bpx_common.h alone)."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.cpp"))):
+        if only is not None and os.path.basename(f) not in only:
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()

@@ -28,6 +28,9 @@ GROUPS = [
     ("bpx_conv3d_fwd", _conv_rx(0)),
     ("bpx_conv3d_dgrad", _conv_rx(1)),
     ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel(<|I)|wgrad_reduce(_batch)?_kernel")),
+    # the fused backward (dgrad + wgrad of one conv in one pass, round 4); its partial slabs are summed by the same batched reduce launch as the
+    # wgrad calls' (counted with them above)
+    ("bpx_conv3d_bwd_fused", re.compile(r"conv3_bwd_kernel(<|I)")),
     # the sliding-window blend / gather (tests/bench_kernels.py merge: 512 x 128^3 <-> 512^3; 16 B/lane row kernels, same doubling)
     ("bpx_merge3d_blend", re.compile(r"merge3d_row_kernel<")),
     ("bpx_crop3d_gather", re.compile(r"crop3d_row_kernel<")),
@@ -69,7 +72,7 @@ def main():
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from biapy_amd._lib import source_digest
-        out["_meta"] = dict(csrc_sha256=source_digest())
+        out["_meta"] = dict(csrc_sha256=source_digest(), tiling_sha256=source_digest(only=("tiling.hip", "bpx_common.h")))
     except Exception as e:  # noqa: BLE001
         out["_meta"] = dict(csrc_sha256=None, error=str(e))
     json.dump(out, sys.stdout, indent=1)

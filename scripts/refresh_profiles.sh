@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates every file of profiles/ in ONE run on one GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r04'
 # Outputs land in gpurun_out/profiles_new/ (merged back by gpurun); copy them into profiles/ afterwards.
 # PMC counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa trace domains).
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/profiles_new
 mkdir -p $O
 export TMPDIR=/tmp
@@ -32,7 +32,13 @@ python bench.py --arch resunetpp --batch 4 --breakdown --graph off > $O/${R}_bre
 python bench.py --breakdown --graph off --mode train > $O/${R}_breakdown_train_events.txt 2> /dev/null
 python bench.py --breakdown --graph off --mode infer > $O/${R}_breakdown_infer_events.txt 2> /dev/null
 python tests/bench_kernels.py merge > $O/${R}_merge_crop.txt 2>&1
-( python scripts/dgrad_stamps.py 128 48 16; python scripts/dgrad_stamps.py 128 16 16; python scripts/dgrad_stamps.py 64 96 32; python scripts/conv_stamps.py 0; python scripts/hbm_rw_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_fwd_dgrad.txt
+( python scripts/dgrad_stamps.py 64 96 32; python scripts/dgrad_stamps.py 64 32 32; python scripts/conv_stamps.py 0; python scripts/conv_stamps.py 11; python scripts/hbm_rw_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_fwd_dgrad.txt
+# fused backward: per-phase cycle stamps need the profiling build (bash scripts/ab_build_flags.sh stamps -DBPX_BWD_STAMPS, done before the gpurun call)
+if [ -f biapy_amd/libbiapy_amd_stamps.so ]; then
+  ( BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 16; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 48 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_bwd_fused.txt
+fi
+python tests/bench_kernels.py bwd --reps 10 2>&1 | grep -v amdgpu.ids > $O/${R}_bwd_fused_vs_separate.txt
+python tests/gpu_diag.py --net --out $O/${R}_gpu_diag.txt > /dev/null 2>&1
 python tests/bench_kernels.py rcan 2>&1 | grep -v "Warning\|run_backward" > $O/${R}_rcan_trunk_64.txt
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o train -- python $ROOT/bench.py --mode train --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_train.log 2>&1
@@ -54,7 +60,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p --
 cd $ROOT
 python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 python scripts/pmc_traffic.py $(find $O/pmc_tf -name "p_results.db" | head -1) $(find $O/pmc_tw -name "p_results.db" | head -1) > $O/pmc_traffic_tiling.json 2>> $O/pmc_traffic.err
-for k in conv3_lp_kernel wgrad_sdm_kernel; do
+for k in conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel; do
   python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
   python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
 done > $O/${R}_pmc_sq_conv_wgrad.txt 2>&1
