@@ -82,7 +82,7 @@ _SIGS = {
     "bpx_conv3d_wgrad_db2": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, Tensor, _i, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_conv3d_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv3d_bwd_fused_supported": ([_i, _i, _i, _i, _i, _i, _i], _i),
-    "bpx_conv3d_bwd_fused_stats_tiles": ([_i, _i, _i, _i, _i], _i),
+    "bpx_conv3d_bwd_fused_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
     "bpx_conv3d_bwd_fused_workspace": ([_i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv3d_bwd_fused": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_debug_set_bwd_fused": ([_i], _i),

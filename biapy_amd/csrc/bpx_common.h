@@ -130,7 +130,11 @@ template <> __device__ __forceinline__ uint32_t pk16<f16_t>(float lo, float hi) 
 // pair, only in epilogues.  The statistics partials are taken from the UNCLAMPED fp32 values, so a genuinely diverged (NaN) result still
 // poisons the norm record and surfaces as a non-finite loss.  bf16: identical to pk16.
 template <typename T> __device__ __forceinline__ uint32_t pk16s(float lo, float hi) { return pk16<T>(lo, hi); }
+#ifndef BPX_F16_SATURATE
+#define BPX_F16_SATURATE 1
+#endif
 template <> __device__ __forceinline__ uint32_t pk16s<f16_t>(float lo, float hi) {
+  if (!BPX_F16_SATURATE) return cvt_pk_f16(lo, hi);
   const f16x2_t mx{(f16_t)65504.f, (f16_t)65504.f};
   f16x2_t h{(f16_t)lo, (f16_t)hi};
   h = __builtin_elementwise_max(__builtin_elementwise_min(h, mx), -mx);
@@ -170,45 +174,50 @@ __device__ __forceinline__ float bpx_erf(float x) {
 // ONE run-time switch over every block activation of the reference (blocks.py:1973-1998), used by every kernel's run-time-activation
 // instance (conv prologues, dgrad epilogues, wgrad staging, the materialised norm + act pair, gate MLPs).  PRECISE: fp32 storage mode (libm
 // exp / expm1 instead of the fast forms).
-template <bool PRECISE> __device__ __forceinline__ float bpx_act_rt(float u, int act) {
+// The round-4 codes (leaky_relu ... softplus) OUT OF LINE: inlined at the 36-72 sites of an unrolled staging loop the nine-way switch blew the
+// run-time-activation instance of the lean conv kernel up to 17 K instructions (I-cache misses on the common relu / silu path: the RCAN trunk's
+// SiLU forward went 8.8 -> 10.2 ms).  A real call costs the rare path a few cycles and the common path nothing.  (One copy per translation unit.)
+static __device__ __attribute__((noinline)) float bpx_act_ext(float u, int act) {
   switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-    case BPX_ACT_RELU: return u > 0.f ? u : 0.f;
-    case BPX_ACT_SILU: return u / (1.f + (PRECISE ? expf(-u) : __expf(-u)));
     case BPX_ACT_LEAKY_RELU: return u > 0.f ? u : 0.01f * u;
     case BPX_ACT_GELU: return 0.5f * u * (1.f + bpx_erf(u * 0.70710678118654752f));
-    case BPX_ACT_TANH: { const float e = PRECISE ? expf(-2.f * fabsf(u)) : __expf(-2.f * fabsf(u)); return copysignf((1.f - e) / (1.f + e), u); }
-    case BPX_ACT_SIGMOID: return 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u)));
-    case BPX_ACT_SOFTPLUS: return u > 20.f ? u : (PRECISE ? log1pf(expf(u)) : __logf(1.f + __expf(u)));
+    case BPX_ACT_TANH: { const float e = expf(-2.f * fabsf(u)); return copysignf((1.f - e) / (1.f + e), u); }
+    case BPX_ACT_SIGMOID: return 1.f / (1.f + expf(-u));
+    case BPX_ACT_SOFTPLUS: return u > 20.f ? u : log1pf(expf(u));
     default: return u;
   }
 }
-// The same for N values at once with the switch OUTSIDE the element loop: a staging loop `for e: f[e] = act(f[e], code)` with the nine-way switch
-// inside is too large to unroll, and the then dynamically indexed f[] lands in scratch memory (measured: 400-576 bytes per lane).
-template <bool PRECISE, int N> __device__ __forceinline__ void bpx_act_vec(float* f, int act) {
-#define BPX_ACT_CASE(CODE)                                                    \
-  case CODE:                                                                  \
-    _Pragma("unroll") for (int e = 0; e < N; ++e) f[e] = bpx_act_rt<PRECISE>(f[e], CODE); \
-    break;
+static __device__ __attribute__((noinline)) float bpx_act_ext_bwd(float u, int act) {
   switch (act) {
-    BPX_ACT_CASE(BPX_ACT_ELU) BPX_ACT_CASE(BPX_ACT_RELU) BPX_ACT_CASE(BPX_ACT_SILU) BPX_ACT_CASE(BPX_ACT_LEAKY_RELU) BPX_ACT_CASE(BPX_ACT_GELU)
-    BPX_ACT_CASE(BPX_ACT_TANH) BPX_ACT_CASE(BPX_ACT_SIGMOID) BPX_ACT_CASE(BPX_ACT_SOFTPLUS)
-    default: break;
-  }
-#undef BPX_ACT_CASE
-}
-template <bool PRECISE> __device__ __forceinline__ float bpx_act_bwd_rt(float u, int act) {
-  switch (act) {
-    case BPX_ACT_ELU: return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
-    case BPX_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-    case BPX_ACT_SILU: { const float s = 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u))); return s * (1.f + u * (1.f - s)); }
     case BPX_ACT_LEAKY_RELU: return u > 0.f ? 1.f : 0.01f;
-    case BPX_ACT_GELU: return 0.5f * (1.f + bpx_erf(u * 0.70710678118654752f)) + u * 0.39894228040143268f * __expf(-0.5f * u * u);
-    case BPX_ACT_TANH: { const float e = PRECISE ? expf(-2.f * fabsf(u)) : __expf(-2.f * fabsf(u)); const float th = (1.f - e) / (1.f + e); return 1.f - th * th; }
-    case BPX_ACT_SIGMOID: { const float s = 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u))); return s * (1.f - s); }
-    case BPX_ACT_SOFTPLUS: return u > 20.f ? 1.f : 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u)));
+    case BPX_ACT_GELU: return 0.5f * (1.f + bpx_erf(u * 0.70710678118654752f)) + u * 0.39894228040143268f * expf(-0.5f * u * u);
+    case BPX_ACT_TANH: { const float e = expf(-2.f * fabsf(u)); const float th = (1.f - e) / (1.f + e); return 1.f - th * th; }
+    case BPX_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-u)); return s * (1.f - s); }
+    case BPX_ACT_SOFTPLUS: return u > 20.f ? 1.f : 1.f / (1.f + expf(-u));
     default: return 1.f;
   }
+}
+// ONE run-time form for every block activation of the reference (blocks.py:1973-1998), used by every kernel's run-time-activation instance
+// (conv prologues, dgrad epilogues, wgrad staging, the materialised norm + act pair, gate MLPs).  PRECISE: fp32 storage mode (libm exp / expm1
+// instead of the fast forms).  Codes 0-3 inline (select chain), codes 4-8 through the out-of-line functions above.
+// EXT = false: codes 0-3 only, no call in the kernel at all (measured: even the never-taken call costs the lean conv kernel's SiLU instance 8 % -
+// RCAN trunk forward 8.2 -> 8.9 ms); the tuned kernels (lean conv, shift-dy wgrad, fused backward) are compiled that way and their launchers hand
+// the codes 4-8 to the plain kernels' ACTK = 2 instances, which are compiled with EXT = true.
+template <bool PRECISE, bool EXT = true> __device__ __forceinline__ float bpx_act_rt(float u, int act) {
+  if (EXT && act > BPX_ACT_SILU) return bpx_act_ext(u, act);
+  return act == BPX_ACT_ELU ? (u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f)))
+         : act == BPX_ACT_RELU ? fmaxf(u, 0.f) : act == BPX_ACT_SILU ? u / (1.f + (PRECISE ? expf(-u) : __expf(-u))) : u;
+}
+template <bool PRECISE, int N, bool EXT = true> __device__ __forceinline__ void bpx_act_vec(float* f, int act) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) f[e] = bpx_act_rt<PRECISE, EXT>(f[e], act);
+}
+template <bool PRECISE, bool EXT = true> __device__ __forceinline__ float bpx_act_bwd_rt(float u, int act) {
+  if (EXT && act > BPX_ACT_SILU) return bpx_act_ext_bwd(u, act);
+  if (act == BPX_ACT_ELU) return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
+  if (act == BPX_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == BPX_ACT_SILU) { const float s = 1.f / (1.f + (PRECISE ? expf(-u) : __expf(-u))); return s * (1.f + u * (1.f - s)); }
+  return 1.f;
 }
 
 // ---- helpers shared by the bf16 "lean" kernels (conv3d_lean.hip, wgrad.hip) -------------------------------------------
@@ -234,8 +243,8 @@ template <int ACTK> __device__ __forceinline__ void act_pair(float& a, float& b,
     a = __builtin_amdgcn_fmed3f(u[0], e[0], 0.f);
     b = __builtin_amdgcn_fmed3f(u[1], e[1], 0.f);
   } else {
-    a = bpx_act_rt<false>(a, act);
-    b = bpx_act_rt<false>(b, act);
+    a = bpx_act_rt<false, false>(a, act);     // act_pair serves the tuned kernels only: codes 0-3
+    b = bpx_act_rt<false, false>(b, act);
   }
 }
 

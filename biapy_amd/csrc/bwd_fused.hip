@@ -48,8 +48,11 @@ struct BwdParams {
   long long* stamps;                               // profiling: per-workgroup cycle stamps [block][16] of the 5th tile (scripts/bwd_stamps.py), else null
 };
 
-template <int CT, int ACTK, bool TF16>
-__global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_kernel(const BwdParams p) {
+// CG = 16-channel chunks of dy (1: the 16-channel layers of level 0; 2: the 32-channel layers of level 1), CT = chunks of t / g this workgroup
+// owns; blockIdx.y walks the rest of t's channels (t.C = 16 CT gridDim.y: the 96-channel concat input of level 1 = 3 x CT 2), each y-block
+// stages the whole dy halo and its own CT chunks of t.
+template <int CG, int CT, int ACTK, bool TF16>
+__global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) conv3_bwd_kernel(const BwdParams p) {
   using T = uint16_t;                                                   // gradients, weights, MFMA operands: bf16
   using TT = typename std::conditional<TF16, f16_t, uint16_t>::type;    // storage type of the activation t
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
@@ -61,11 +64,13 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   constexpr int RED_BYTES = 4 * NS * 16 * 2 * 4;
   constexpr int HSTR = HX * VB;
   constexpr int NKC = TV / 32;
-  constexpr bool LDSW = BPX_BWD_LDSW && CT == 1;
+  constexpr bool LDSW = BPX_BWD_LDSW && CT == 1 && CG == 1;
+  constexpr bool ALLNS = CG == 1 && CT == 3;                            // the 48-channel instance of level 0: NS accumulator sets at once (below)
   constexpr int SW_BYTES = LDSW ? STEPS * 1024 : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SG_BYTES + 2 * ST_BYTES + RED_BYTES + CT * 16 * 16 + SW_BYTES];
-  unsigned char* sG = smem;                                             // dy halo [HV][32 B]
-  unsigned char* sT = smem + SG_BYTES;                                  // raw t tile [CT][TV][32 B]
+  constexpr int QPADB = 56;                                             // k-groups of a packed chunk (bf16): 14 steps x 4
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CG * SG_BYTES + 2 * ST_BYTES + RED_BYTES + CT * 16 * 16 + SW_BYTES];
+  unsigned char* sG = smem;                                             // dy halo [CG][HV][32 B]
+  unsigned char* sT = smem + CG * SG_BYTES;                             // raw t tile [CT][TV][32 B]
   unsigned char* sA = sT + ST_BYTES;                                    // act(norm(t)) as bf16 [CT][TV][32 B]
   float* red = reinterpret_cast<float*>(sA + ST_BYTES);                 // statistics scratch [wave][NS * 16][2]
   float* sN = red + RED_BYTES / 4;                                      // [CT * 16]{mean, rstd, scale, shift}: the sample's norm records (staging and epilogue)
@@ -75,6 +80,8 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   const int wave = tid >> 6;   // (as an SGPR via readfirstlane the 48-channel instance spills 92 bytes per lane: measured, left a VGPR)
   const int j = lane & 15, g = lane >> 4;
   const int D = p.D, H = p.H, W = p.W, Ct = p.Ct;
+  const int cb0 = (int)blockIdx.y * CT;                                 // first t / g chunk of this workgroup
+  constexpr int Cdy = 16 * CG;
 
   // ---- per-workgroup constants ------------------------------------------------------------------------------------------------------
   // dgrad phase (conv3_lp_kernel, TX = 16): this lane's output voxel of m-subtile 0 is (wave, 0, j); m-subtile ms adds ms rows
@@ -83,7 +90,7 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   const int hb0 = ((wave * HY) * HX + j) * VB + cg_off;
   const int lbase[4] = {hb0 + (hi_tap ? VB : 0), hb0 + (hi_tap ? HX * VB : 0), hb0 + (hi_tap ? HY * HX * VB : 0), hb0};
   const int evox_rel = (wave * H) * W + j;
-  const uint32_t wlane = (uint32_t)((g * Ct + j) * KPL) * 2u;
+  const uint32_t wlane = (uint32_t)((g * Ct + cb0 * 16 + j) * KPL) * 2u;
   // wgrad phase (wgrad_sdm_kernel): transposing-read bases
   const int trl = (j >> 2), trc = (j & 3) * 8;
   const int a_base = g * 8 * VB + trl * VB + trc;
@@ -110,16 +117,18 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t), 0, (int)0x80000000u, 0x00020000);
   constexpr uint32_t OOR = 0x80000000u;   // out of range of the buffer: the DMA writes zeros
 
-  f32x4_t accw[7][CT];                    // weight-gradient accumulators of this wave's taps [7 wave, 7 wave + 7), kept over all tiles
+  f32x4_t accw[CG][7][CT];                // weight-gradient accumulators of this wave's taps [7 wave, 7 wave + 7), kept over all tiles
 #pragma unroll
-  for (int a = 0; a < 7; ++a)
+  for (int k = 0; k < CG; ++k)
 #pragma unroll
-    for (int c = 0; c < CT; ++c) accw[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool want_b = p.want_db != 0;
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) accw[k][a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool want_b = p.want_db != 0 && blockIdx.y == 0;
   // InstanceNorm-backward statistics sum(g), sum(g xhat): per-lane partial sums kept over ALL tiles of a sample; the 16-lane / 4-wave reduction
   // and the global row are paid once per (workgroup, sample) instead of once per tile (32 DPP adds, an LDS exchange, a barrier and a row store
   // per tile: 1.5 K + part of the epilogue's 4.1 K of the tile's 18 K cycles)
-  constexpr bool PSTATS = CT == 1;   // the 48-channel instance writes one statistics row per tile (below)
+  constexpr bool PSTATS = !ALLNS;    // the 48-channel instance writes one statistics row per tile (below)
   float ps1[NS][4], ps2[NS][4];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns)
@@ -139,11 +148,11 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
     if (tid < NS * 16 * 2) {
       const int c = tid >> 1, k = tid & 1;
       const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] + red[(3 * NS * 16 + c) * 2 + k];
-      p.red[(((size_t)nn * gridDim.x + blockIdx.x) * 2 + k) * Ct + c] = a;
+      p.red[(((size_t)nn * gridDim.x + blockIdx.x) * 2 + k) * Ct + cb0 * 16 + c] = a;
     }
     __syncthreads();
   };
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wT), 0, STEPS * 1024 * CT, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wT), 0, CG * QPADB * Ct * 16, 0x00020000);
   if constexpr (LDSW) {   // this wave's share of the 14 weight pieces; they have landed and are visible after the first tile's staging barrier
     for (int q = wave; q < STEPS; q += 4)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sW + q * 1024), 16, (uint32_t)(q * 1024 + lane * 16), 0, 0, 0);
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(sT + c * TV * VB + (u * 256 + wave * 64) * 16), 16,
-                                                 okt[u] ? base_t + rel_t[u] + (uint32_t)c * t_csb : OOR, 0, 0, 0);
+                                                 okt[u] ? base_t + rel_t[u] + (uint32_t)(cb0 + c) * t_csb : OOR, 0, 0, 0);
     {
       uint32_t pk = hpk0;
       asm volatile("" : "+v"(pk));   // keeps the piece arithmetic inside the tile loop (see above)
@@ -202,8 +211,12 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
         const int ok = (int)interior | ((int)((unsigned)(z0 - 1 + hz) < (unsigned)D) & (int)((unsigned)(y0 - 1 + hy) < (unsigned)H) & (int)((unsigned)(x0 - 1 + hx) < (unsigned)W));
         const uint32_t inoff = base_g + (uint32_t)((hz * H + hy) * W + hx) * dy_ld2 + (uint32_t)sub * 16u;
         const uint32_t off = ok ? inoff : OOR;
-        if (u < NPG - 1 || last_ok)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sG + (u * 256 + wave * 64) * 16), 16, off, 0, 0, 0);
+        if (u < NPG - 1 || last_ok) {
+#pragma unroll
+          for (int k = 0; k < CG; ++k)       // chunk k of the voxel's dy channels: 32 bytes further
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sG + k * SG_BYTES + (u * 256 + wave * 64) * 16), 16, ok ? inoff + (uint32_t)k * 32u : OOR, 0, 0, 0);
+        }
+        (void)off;
         hx += 2; hy += 1; hz += 1;
         const int cx = hx >= HX; hx -= cx * HX; hy += cx;
         const int cy = hy >= HY; hy -= cy * HY; hz += cy;
@@ -212,7 +225,7 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
     if (n != n_cur) {   // uniform: a workgroup crosses a sample boundary at most N - 1 times
       if (PSTATS && n_cur >= 0) flush_stats(n_cur);
       if (n_cur < 0) n_first = n;
-      if (tid < CT * 16) reinterpret_cast<f32x4_t*>(sN)[tid] = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + tid]);
+      if (tid < CT * 16) reinterpret_cast<f32x4_t*>(sN)[tid] = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + cb0 * 16 + tid]);
       n_cur = n;
       __syncthreads();
     }
@@ -259,12 +272,12 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
     const int yrem = full ? (1 << 20) : H - y0;
     char* __restrict__ yout = reinterpret_cast<char*>(p.g);
     const uint32_t yrow = (uint32_t)(W * p.g_ld) * 2u;
-    const uint32_t yb0 = (uint32_t)(vox0 * p.g_ld + g * 4) * 2u;
+    const uint32_t yb0 = (uint32_t)(vox0 * p.g_ld + cb0 * 16 + g * 4) * 2u;
     const unsigned char* tl = sT + ((wave * MS) * 16 + j) * VB + g * 8;   // raw t of (voxel (wave, ms, j), channels 4 g .. 4 g + 3): + ms * 512 + ns * TV * VB
     // weights of step s and group ns: LDS (CT == 1), or a BUFFER load - resource + one lane-offset VGPR + the step's byte offset in an SGPR +
     // the group as immediate.  (As pointer arithmetic the compiler hoists the 14 x NS 64-bit lane addresses out of the tile loop: 84 VGPRs, spilled.)
     const uint32_t wstep = LDSW ? 1024u : (uint32_t)(4 * Ct * 16);
-    if constexpr (CT > 1) {
+    if constexpr (ALLNS) {
       // NS accumulator sets at once, weights through a one-step register ring (conv3_lp_kernel's form), statistics row per TILE.  Measured
       // alternatives for the 48-channel instance: the per-group form below + per-lane statistics over all tiles (what the 16-channel instance
       // does) wants 418 registers and spills 600-750 bytes per lane at the 256 of two workgroups per CU - not usable.
@@ -366,68 +379,90 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
       f32x4_t acc[MS];
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) acc[ms] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      auto load_w = [&](int s_) -> u32x4_t {
-        if constexpr (LDSW) return *reinterpret_cast<const u32x4_t*>(sW + lane * 16 + s_ * 1024);
-        else return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)(s_ * wstep), 0));
-      };
-      // Fragment reads one stage ahead of the MFMAs.  Stages 0..2 = the three dz planes (steps 3 dz .. 3 dz + 2: MS + 2 fragment rows read once
-      // and slid over the three dy steps, as in conv3_lp_kernel's REUSE form), stages 3..7 = steps 9..13.
-      u32x4_t rowA[MS + 2], rowB[MS + 2], wA[3], wB[3];
-      auto load_plane = [&](int dz, u32x4_t* row, u32x4_t* w) {
+      // Fragment reads one stage ahead of the MFMAs (CG == 1).  Stages 0..2 = the three dz planes (steps 3 dz .. 3 dz + 2: MS + 2 fragment rows
+      // read once and slid over the three dy steps, as in conv3_lp_kernel's REUSE form), stages 3..7 = steps 9..13.  With two dy chunks the
+      // second register set does not fit beside twice the weight-gradient accumulators: one set, the K loop runs chunk after chunk.
+      u32x4_t rowA[MS + 2], rowB[CG == 1 ? MS + 2 : 1], wA[3], wB[CG == 1 ? 3 : 1];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) w[q] = load_w(3 * dz + q);
+      for (int ck = 0; ck < CG; ++ck) {
+        const unsigned char* sGk = sG + ck * SG_BYTES;
+        auto load_w = [&](int s_) -> u32x4_t {
+          if constexpr (LDSW) return *reinterpret_cast<const u32x4_t*>(sW + lane * 16 + s_ * 1024);
+          else return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)((ck * QPADB / 4 + s_) * wstep), 0));
+        };
+        auto load_plane = [&](int dz, u32x4_t* row, u32x4_t* w) {
 #pragma unroll
-        for (int r = 0; r < MS + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(sG + lbase[0] + r * HSTR + tap_off<HY, HX, VB>(9 * dz));
-      };
-      auto load_step = [&](int s_, u32x4_t* af, u32x4_t* w) {
-        const int cls = s_ < 12 ? 1 : s_ == 12 ? 2 : 3;
-        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s_));
-        w[0] = load_w(s_);
+          for (int q = 0; q < 3; ++q) w[q] = load_w(3 * dz + q);
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(sG + lbase[cls] + ms * HSTR + imm);
-      };
-      auto mma_plane = [&](const u32x4_t* row, const u32x4_t* w) {
+          for (int r = 0; r < MS + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(sGk + lbase[0] + r * HSTR + tap_off<HY, HX, VB>(9 * dz));
+        };
+        auto load_step = [&](int s_, u32x4_t* af, u32x4_t* w) {
+          const int cls = s_ < 12 ? 1 : s_ == 12 ? 2 : 3;
+          const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s_));
+          w[0] = load_w(s_);
 #pragma unroll
-        for (int dyy = 0; dyy < 3; ++dyy)
+          for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(sGk + lbase[cls] + ms * HSTR + imm);
+        };
+        auto mma_plane = [&](const u32x4_t* row, const u32x4_t* w) {
 #pragma unroll
-          for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(w[dyy], row[ms + dyy], acc[ms]);
-      };
-      auto mma_step = [&](const u32x4_t* af, const u32x4_t* w) {
+          for (int dyy = 0; dyy < 3; ++dyy)
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(w[0], af[ms], acc[ms]);
-      };
-      __builtin_amdgcn_sched_barrier(0);   // (the next group's first fragment reads stay out of this group's epilogue: register budget)
-      load_plane(0, rowA, wA);
-      load_plane(1, rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_plane(rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      load_plane(2, rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_plane(rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      load_step(9, rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_plane(rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      load_step(10, rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      load_step(11, rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      load_step(12, rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      load_step(13, rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(rowA, wA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(rowB, wB);
-      __builtin_amdgcn_sched_barrier(0);
+            for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(w[dyy], row[ms + dyy], acc[ms]);
+        };
+        auto mma_step = [&](const u32x4_t* af, const u32x4_t* w) {
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(w[0], af[ms], acc[ms]);
+        };
+        __builtin_amdgcn_sched_barrier(0);   // (the next group's first fragment reads stay out of this group's epilogue: register budget)
+        if constexpr (CG == 1) {
+          load_plane(0, rowA, wA);
+          load_plane(1, rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_plane(rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          load_plane(2, rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_plane(rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(9, rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_plane(rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(10, rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_step(rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(11, rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_step(rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(12, rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_step(rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(13, rowB, wB);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_step(rowA, wA);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_step(rowB, wB);
+        } else {
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz) {
+            load_plane(dz, rowA, wA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_plane(rowA, wA);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int s_ = 9; s_ < STEPS; ++s_) {
+            load_step(s_, rowA, wA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(rowA, wA);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (ns == NS - 1) BPX_STAMP();   // 6: dgrad steps done (last group)
 
       // ---- epilogue of the group: g = acc * act'(scale t + shift), per-lane partials of sum(g) and sum(g xhat), 8-byte stores ----------------
@@ -482,11 +517,15 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
     if (CT == 1) BPX_STAMP();   // 7: epilogue stores issued
     BPX_STAMP();   // 8: statistics row written (48-channel instance)
     // ---- phase B: wgrad MFMA steps (windowed shift-dy phase of wgrad_sdm_kernel) on the same staged operands -----------------------------
-    switch (wave) {   // wave-uniform
-      case 0: bpxwg::sd_mfma_phase<0, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
-      case 1: bpxwg::sd_mfma_phase<1, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
-      case 2: bpxwg::sd_mfma_phase<2, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
-      default: bpxwg::sd_mfma_phase<3, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw, want_b); break;
+#pragma unroll
+    for (int ck = 0; ck < CG; ++ck) {   // one 16-channel block of dy (= of the conv's output channels) at a time, on the same activated tile
+      const unsigned char* sGk = sG + ck * SG_BYTES;
+      switch (wave) {   // wave-uniform
+        case 0: bpxwg::sd_mfma_phase<0, CT, HY, HX, VB, VB, TV, NKC>(sA, sGk, a_base, g_lane, accw[ck], want_b); break;
+        case 1: bpxwg::sd_mfma_phase<1, CT, HY, HX, VB, VB, TV, NKC>(sA, sGk, a_base, g_lane, accw[ck], want_b); break;
+        case 2: bpxwg::sd_mfma_phase<2, CT, HY, HX, VB, VB, TV, NKC>(sA, sGk, a_base, g_lane, accw[ck], want_b); break;
+        default: bpxwg::sd_mfma_phase<3, CT, HY, HX, VB, VB, TV, NKC>(sA, sGk, a_base, g_lane, accw[ck], want_b); break;
+      }
     }
     BPX_STAMP();   // 9: wgrad steps done
   }
@@ -496,21 +535,26 @@ __global__ void __launch_bounds__(256, CT == 1 ? BPX_BWD_OCC1 : 2) conv3_bwd_ker
   if (PSTATS && tid < NS * 16 * 2) {
     const int c = tid >> 1, k = tid & 1;
     for (int nn = 0; nn < p.N; ++nn)
-      if (n_cur < 0 || nn < n_first || nn > n_cur) p.red[(((size_t)nn * gridDim.x + blockIdx.x) * 2 + k) * Ct + c] = 0.f;
+      if (n_cur < 0 || nn < n_first || nn > n_cur) p.red[(((size_t)nn * gridDim.x + blockIdx.x) * 2 + k) * Ct + cb0 * 16 + c] = 0.f;
   }
 
   // ---- flush of the weight-gradient partials: lane holds D[ci = 4 g + r][co = j] of its taps ---------------------------------------------
-  float* pp = p.part + (size_t)blockIdx.x * 27 * Ct * 16;
+  float* pp = p.part + (size_t)blockIdx.x * 27 * Ct * Cdy;
 #pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    const int tap = 7 * wave + a;
-    if (tap >= 27) continue;
+  for (int ck = 0; ck < CG; ++ck)
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int a = 0; a < 7; ++a) {
+      const int tap = 7 * wave + a;
+      if (tap >= 27) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pp[((size_t)tap * Ct + c * 16 + 4 * g + r) * 16 + j] = accw[a][c][r];
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[((size_t)tap * Ct + (cb0 + c) * 16 + 4 * g + r) * Cdy + ck * 16 + j] = accw[ck][a][c][r];
+    }
+  if (want_b && wave == 3 && g == 0) {
+#pragma unroll
+    for (int ck = 0; ck < CG; ++ck) p.dbpart[(size_t)blockIdx.x * Cdy + ck * 16 + j] = accw[ck][6][0][0];
   }
-  if (want_b && wave == 3 && g == 0) p.dbpart[(size_t)blockIdx.x * 16 + j] = accw[6][0][0];
 }
 
 int cu_count_() {
@@ -525,40 +569,59 @@ int cu_count_() {
 
 int g_bwd_fused = 1;   // test / A-B hook (bpx_debug_set_bwd_fused)
 
-struct BwdPlan { int grid, tilesZ, tilesY, tilesX; };
-BwdPlan bwd_plan(int N, int D, int H, int W, int Ct) {
-  BwdPlan q;
+struct BwdPlan { int cg, ct, gy, grid, tilesZ, tilesY, tilesX; bool per_wg_rows; };
+// instance for (dy.C, t.C): 16 -> {16, 48}: (CG 1, CT 1 | 3); 32 -> {16, 32, ... 128}: (CG 2, CT 1) with t.C / 16 workgroup columns.  (A (CG 2, CT 2)
+// instance - two t chunks per workgroup, half the dy staging - needs 2 x 56 weight-gradient accumulators beside the rest and spilled 312 bytes per
+// lane at the 256 VGPRs of two workgroups per CU, in the staging section too, where a reload serialises the DMA pieces: not built.)
+bool bwd_instance(int Ct, int Cdy, BwdPlan& q) {
+  q.gy = 1;
+  if (Cdy == 16 && Ct == 16) { q.cg = 1; q.ct = 1; }
+  else if (Cdy == 16 && Ct == 48) { q.cg = 1; q.ct = 3; }
+  else if (Cdy == 32 && (Ct == 16 || Ct == 32)) { q.cg = 2; q.ct = 1; q.gy = Ct / 16; }   // (t.C = 96 measured: 457 vs 449 us for the two kernels - six
+  //                                                                                          columns re-stage the dy halo six times: not taken)
+  else return false;
+  q.per_wg_rows = !(q.cg == 1 && q.ct == 3);
+  return true;
+}
+BwdPlan bwd_plan(int N, int D, int H, int W, int Ct, int Cdy) {
+  BwdPlan q{};
+  bwd_instance(Ct, Cdy, q);
   q.tilesZ = cdiv(D, 4); q.tilesY = cdiv(H, 4); q.tilesX = cdiv(W, 16);
   const int total = N * q.tilesZ * q.tilesY * q.tilesX;
-  const int occ = Ct == 16 ? BPX_BWD_OCC1 : 2;
-  int gx = std::max(8, (cu_count_() * occ) & ~7);
+  const int occ = (q.cg == 1 && q.ct == 1) ? BPX_BWD_OCC1 : 2;
+  int gx = std::max(8, (cu_count_() * occ / std::max(1, q.gy)) & ~7);    // a multiple of 8: workgroup (x, y) then runs on XCD x % 8 for every y
   gx = std::min(gx, 8 * cdiv(total, 8));
   q.grid = gx;
   return q;
 }
 
+int g_bwd_level1 = 1;   // test / A-B hook (bpx_debug_set_bwd_fused bit 1 clears it): the dy.C == 32 instances
+
 bool bwd_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) {
   if (!g_bwd_fused) return false;
   if (dtype != BPX_BF16 && dtype != BPX_MIX16) return false;
-  if (Cdy != 16 || (Ct != 16 && Ct != 48)) return false;
+  BwdPlan q{};
+  if (!bwd_instance(Ct, Cdy, q) || (Cdy == 32 && !g_bwd_level1)) return false;
   const int64_t vps = (int64_t)D * H * W, vox = vps * N;
-  return W > 8 && vps >= 32768 && vox * 48 * 2 < (1ll << 31);
+  return W > 8 && vps >= 32768 && vox * std::max(48, Ct) * 2 < (1ll << 31);
 }
 
 }  // namespace
 
-extern "C" int bpx_debug_set_bwd_fused(int on) { g_bwd_fused = on; return 0; }
+// bit 0: the fused backward at all; bit 1 set = without the dy.C == 32 instances (A/B of the level-1 layers)
+extern "C" int bpx_debug_set_bwd_fused(int on) { g_bwd_fused = on & 1; g_bwd_level1 = (on & 2) ? 0 : 1; return 0; }
 
 extern "C" int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) { return bwd_supported(dtype, N, D, H, W, Ct, Cdy) ? 1 : 0; }
 
-// rows per sample of red_part_d: one per WORKGROUP of the persistent launch (each sums its tiles of a sample in registers)
-// (t.C == 16; the 48-channel instance writes one row per 4x4x16 tile)
-extern "C" int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct) {
-  return Ct == 16 ? bwd_plan(N, D, H, W, Ct).grid : cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
+// rows per sample of red_part_d: one per WORKGROUP (column) of the persistent launch - each sums its tiles of a sample in registers - except for the
+// (dy 16, t 48) instance, which writes one row per 4x4x16 tile
+extern "C" int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct, int Cdy) {
+  const BwdPlan q = bwd_plan(N, D, H, W, Ct, Cdy);
+  return q.per_wg_rows ? q.grid : cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
 }
 
 extern "C" int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy) {
-  const BwdPlan q = bwd_plan(N, D, H, W, Ct);
+  const BwdPlan q = bwd_plan(N, D, H, W, Ct, Cdy);
   return (int64_t)q.grid * ((int64_t)27 * Ct + 1) * Cdy * 4;
 }
 
@@ -567,10 +630,11 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
                                     void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
   const char* fn = "bpx_conv3d_bwd_fused";
   BPX_CHECK(bwd_supported(dtype, N, D, H, W, t.C, dy.C), "%s: unsupported configuration (bpx_conv3d_bwd_fused_supported)", fn);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_SILU, "%s: activation code %d is not built into the fused kernel (none / elu / relu / silu); use bpx_conv3d_dgrad + bpx_conv3d_wgrad", fn, act);
   BPX_CHECK(dy.ptr && t.ptr && g.ptr && w_packed_T_d && t_norm_d && red_part_d && dw_d && ws_d, "%s: null pointer", fn);
   BPX_CHECK(db2_d == nullptr || db_d != nullptr, "%s: db2_d needs db_d", fn);
   BPX_CHECK(dy.cs == 0 && g.cs == 0, "%s: only t may be chunk-planar", fn);
-  BPX_CHECK(g.C == t.C && g.ld >= g.C && dy.ld >= 16, "%s: g.C %d != t.C %d or bad pitch", fn, g.C, t.C);
+  BPX_CHECK(g.C == t.C && g.ld >= g.C && dy.ld >= dy.C, "%s: g.C %d != t.C %d or bad pitch", fn, g.C, t.C);
   BPX_CHECK(((uintptr_t)dy.ptr % 16) == 0 && ((uintptr_t)t.ptr % 16) == 0 && ((uintptr_t)g.ptr % 8) == 0 && (dy.ld * 2) % 16 == 0 && (t.ld * 2) % 16 == 0 &&
                 (g.ld * 2) % 8 == 0 && ((uintptr_t)t_norm_d % 16) == 0,
             "%s: operands must be 16-byte aligned", fn);
@@ -578,8 +642,8 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   BPX_CHECK(t.cs == 0 || (t.ld >= 16 && t.cs % 8 == 0 && t.cs >= (vox - 1) * t.ld + 16), "%s: bad chunk stride %lld", fn, (long long)t.cs);
   const int64_t tbytes = 2 * (t.cs ? (int64_t)t.cs * (t.C / 16 - 1) + (vox - 1) * t.ld + 16 : vox * (int64_t)t.ld);
   BPX_CHECK(tbytes < (1ll << 31) && vox * dy.ld * 2 < (1ll << 31) && vox * g.ld * 2 < (1ll << 32), "%s: tensors beyond the 32-bit / buffer addressing range", fn);
-  const BwdPlan q = bwd_plan(N, D, H, W, t.C);
-  const int64_t need = (int64_t)q.grid * ((int64_t)27 * t.C + 1) * 16 * 4;
+  const BwdPlan q = bwd_plan(N, D, H, W, t.C, dy.C);
+  const int64_t need = (int64_t)q.grid * ((int64_t)27 * t.C + 1) * dy.C * 4;
   BPX_CHECK(ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   BwdParams p{};
   p.N = N; p.D = D; p.H = H; p.W = W;
@@ -590,7 +654,7 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   p.g = g.ptr; p.g_ld = g.ld;
   p.red = red_part_d;
   p.part = reinterpret_cast<float*>(ws_d);
-  p.dbpart = p.part + (size_t)q.grid * 27 * t.C * 16;
+  p.dbpart = p.part + (size_t)q.grid * 27 * t.C * dy.C;
   p.want_db = db_d != nullptr;
   p.tilesZ = q.tilesZ; p.tilesY = q.tilesY; p.tilesX = q.tilesX;
   p.tilesPerSample = q.tilesZ * q.tilesY * q.tilesX;
@@ -600,14 +664,15 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   p.stamps = g_conv_stamps;
   const bool mix = dtype == BPX_MIX16, elu = act == BPX_ACT_ELU;
   hipStream_t s = (hipStream_t)stream;
-#define LB(CT_)                                                                                       \
-  if (t.C == 16 * CT_) {                                                                              \
-    if (mix) { if (elu) conv3_bwd_kernel<CT_, 1, true><<<q.grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CT_, 0, true><<<q.grid, 256, 0, s>>>(p); }   \
-    else { if (elu) conv3_bwd_kernel<CT_, 1, false><<<q.grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CT_, 0, false><<<q.grid, 256, 0, s>>>(p); }     \
+  const dim3 grid((unsigned)q.grid, (unsigned)q.gy);
+#define LB(CG_, CT_)                                                                                  \
+  if (q.cg == CG_ && q.ct == CT_) {                                                                   \
+    if (mix) { if (elu) conv3_bwd_kernel<CG_, CT_, 1, true><<<grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CG_, CT_, 0, true><<<grid, 256, 0, s>>>(p); }   \
+    else { if (elu) conv3_bwd_kernel<CG_, CT_, 1, false><<<grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CG_, CT_, 0, false><<<grid, 256, 0, s>>>(p); }     \
   }
-  LB(1) LB(3)
+  LB(1, 1) LB(1, 3) LB(2, 1)
 #undef LB
   BPX_LAUNCH_CHECK(fn);
-  // dW in the PyTorch layout (Cout = 16, Cin = Ct, 3, 3, 3): index = ci * 27 + co * Ct * 27 + tap
-  return bpxred::reduce_partials2(fn, p.part, dw_d, q.grid, 27, t.C, 16, 27, (int64_t)t.C * 27, 1, p.dbpart, db_d, db2_d, 0, true, s);
+  // dW in the PyTorch layout (Cout = dy.C, Cin = Ct, 3, 3, 3): index = ci * 27 + co * Ct * 27 + tap
+  return bpxred::reduce_partials2(fn, p.part, dw_d, q.grid, 27, t.C, dy.C, 27, (int64_t)t.C * 27, 1, p.dbpart, db_d, db2_d, 0, true, s);
 }

@@ -76,7 +76,7 @@ __device__ __forceinline__ void stage_block(unsigned char* smem, const T* __rest
           unpack16<T>(v, f);
 #pragma unroll
           for (int e = 0; e < KPL; ++e) f[e] = fmaf(sc[e], f[e], sh[e]);
-          bpx_act_vec<std::is_same<T, float>::value, KPL>(f, act);
+          bpx_act_vec<std::is_same<T, float>::value, KPL>(f, act);   // (stage_block serves the fused shortcut only, which has no activation)
           v = pack16<T>(f);
         }
         *reinterpret_cast<u32x4_t*>(smem + (size_t)(idx / GPT) * VB + sub * 16) = v;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
         unpack16<T>(v_, f_);                                                                                  \
         if (ACTK == 1) { _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = apply_act_rt<T, 1>(fmaf(psc[e_], f_[e_], psh[e_]), p.act); } \
         else { _Pragma("unroll") for (int e_ = 0; e_ < KPL; ++e_) f_[e_] = fmaf(psc[e_], f_[e_], psh[e_]);                    \
-               bpx_act_vec<std::is_same<T, float>::value, KPL>(f_, p.act); }                                               \
+               bpx_act_vec<std::is_same<T, float>::value, KPL, ACTK == 2>(f_, p.act); }                                               \
         v_ = pack16<T>(f_);                                                                                   \
       }                                                                                                       \
       *reinterpret_cast<u32x4_t*>(smem + (wbuf) + (size_t)idx_ * 16) = v_;                                    \
@@ -488,9 +488,11 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.stamps = g_stamps;  // profiling ablations: 1 no MFMA, 2 no transform, 4 no re-loads, 8 no stores
   dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
+  const bool ext = (EPI == EPI_FWD ? p.act : p.t_act) > BPX_ACT_SILU;   // leaky_relu ... softplus: the ACTK = 2 instances
 #define L(TZ, TY, TX, NS)                                                        \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
     if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, TT><<<grid, 256, 0, s>>>(p);    \
+    else if (ext) conv3_kernel<T, TZ, TY, TX, NS, EPI, 2, TT><<<grid, 256, 0, s>>>(p);   \
     else conv3_kernel<T, TZ, TY, TX, NS, EPI, 0, TT><<<grid, 256, 0, s>>>(p);        \
     return 0;                                                                    \
   }
@@ -526,6 +528,7 @@ static bool use_lean(int dtype, const Conv3Params& p) {
   // compare checksums across different batch compositions).
   const int64_t vps = (int64_t)p.D * p.H * p.W, vox = vps * p.N;
   if ((dtype != BPX_BF16 && dtype != BPX_F16) || !(g_use_ws == 5 || (g_use_ws == 0 && vps >= g_lean_min_vps))) return false;
+  if ((p.in_norm && p.act > BPX_ACT_SILU) || (p.t_norm && p.t_act > BPX_ACT_SILU)) return false;   // the round-4 activation codes: plain kernel only
   const int64_t ldmax = std::max<int64_t>(std::max(p.x_ld, p.y_ld), std::max(p.sc ? p.sc_ld : 0, p.t ? p.t_ld : 0));
   auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
   // 32-bit byte offsets: a chunk-planar tensor extends over (channels / 16) planes

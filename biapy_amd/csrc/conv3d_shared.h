@@ -42,12 +42,12 @@ inline int chunk_stride(const bpx_tensor& t) { return t.cs ? (int)t.cs : 16; }
 template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
   if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-  return bpx_act_rt<PRECISE>(u, act);
+  return bpx_act_rt<PRECISE, ACTK == 2>(u, act);     // ACTK = 2: the plain kernels' instances that also take the codes 4-8
 }
 template <typename T, int ACTK = 0> __device__ __forceinline__ float apply_act_bwd_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
   if (ACTK == 1) return u > 0.f ? 1.f : (PRECISE ? expf(u) : __expf(u));
-  return bpx_act_bwd_rt<PRECISE>(u, act);
+  return bpx_act_bwd_rt<PRECISE, ACTK == 2>(u, act);
 }
 
 

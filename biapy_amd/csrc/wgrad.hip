@@ -48,7 +48,7 @@ struct WgradParams {
 template <typename T, int ACTK = 0> __device__ __forceinline__ float act_rt(float u, int act) {
   constexpr bool PRECISE = std::is_same<T, float>::value;
   if (ACTK == 1) return u > 0.f ? u : (PRECISE ? expm1f(u) : (__expf(u) - 1.f));
-  return bpx_act_rt<PRECISE>(u, act);
+  return bpx_act_rt<PRECISE, ACTK == 2>(u, act);
 }
 
 // Stage EZ*EY*EX voxels x NCH channels (NCH multiple of 16/GPT pieces) into LDS [voxel][NCH].
@@ -107,7 +107,7 @@ __device__ __forceinline__ void stage_any(unsigned char* smem, const T* __restri
 #pragma unroll
             for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, 1>(f[e], act);
           } else {
-            bpx_act_vec<std::is_same<T, float>::value, KPL>(f, act);
+            bpx_act_vec<std::is_same<T, float>::value, KPL, ACTK == 2>(f, act);
           }
           v = pack16<T>(f);
         }
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
               for (int e = 0; e < KPL; ++e) f[e] = act_rt<T, 1>(f[e], p.act);
             } else {
-              bpx_act_vec<std::is_same<T, float>::value, KPL>(f, p.act);
+              bpx_act_vec<std::is_same<T, float>::value, KPL, ACTK == 2>(f, p.act);
             }
           }
           v = pack16<T>(f);
@@ -1094,12 +1094,15 @@ int launch_wgrad(const WgradParams& p0, const WCfg& c, bool use_tr, hipStream_t 
   p.groups = groups;
   p.dbpart = p.part + (size_t)groups * TAPS * p.Cin * p.Cout;
   const bool elu = p.in_norm != nullptr && p.act == BPX_ACT_ELU;
+  const bool ext = p.in_norm != nullptr && p.act > BPX_ACT_SILU;   // leaky_relu ... softplus: the ACTK = 2 instances
   dim3 grid((unsigned)(((groups + 7) & ~7) * nchunks * nb));
 #define L(TZY, TX, NS)                                                                              \
   if (c.tz == TZY && c.tx == TX && c.ns == NS) {                                                    \
     if (use_tr && elu) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, true, 1><<<grid, 256, 0, s>>>(p);     \
+    else if (use_tr && ext) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, true, 2><<<grid, 256, 0, s>>>(p); \
     else if (use_tr) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, true, 0><<<grid, 256, 0, s>>>(p);       \
     else if (elu) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, false, 1><<<grid, 256, 0, s>>>(p);         \
+    else if (ext) wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, false, 2><<<grid, 256, 0, s>>>(p);         \
     else wgrad_kernel<T, TZY, TZY, TX, NS, TAPS, false, 0><<<grid, 256, 0, s>>>(p);                  \
     return 0;                                                                                       \
   }
@@ -1187,7 +1190,8 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   int rc;
   const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
   const bool sd_ok = dtype == BPX_BF16 && taps == 27 && p.dy_vs == 1 && c.tx == 16 && c.tz == 4 && g_use_tr != 0 &&
-                     vox * std::max(p.x_ld, p.dy_ld) < (1ll << 31) && (((uintptr_t)p.in_norm) & 7) == 0;
+                     vox * std::max(p.x_ld, p.dy_ld) < (1ll << 31) && (((uintptr_t)p.in_norm) & 7) == 0 &&
+                     !(p.in_norm != nullptr && p.act > BPX_ACT_SILU);   // the round-4 activation codes take the generic kernel
   if (sd_ok && g_wgrad_sd != 0) rc = launch_wgrad_sd(p, c, s);   // measured faster at every cfg-2 layer with W > 8
   else if (dtype == BPX_BF16) rc = (taps == 27) ? launch_wgrad<uint16_t, 27>(p, c, g_use_tr != 0, s) : launch_wgrad<uint16_t, 1>(p, c, g_use_tr != 0, s);
   else rc = (taps == 27) ? launch_wgrad<float, 27>(p, c, false, s) : launch_wgrad<float, 1>(p, c, false, s);

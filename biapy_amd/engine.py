@@ -289,12 +289,15 @@ class ResUNetEngine:
 
     def _bwd_fused_ok(self, B, S, Ct: int, Cdy: int) -> bool:
         """One-pass dgrad + wgrad (bpx_conv3d_bwd_fused) for this conv?  Not with the weight-gradient side stream (its point is one staging)."""
-        return (os.environ.get("BPX_BWD_FUSED", "1") != "0" and not self.use_side_stream and self.cfg.gn_groups == 0 and self.dtype != torch.float32
+        if os.environ.get("BPX_FUSED_BITS") is not None and not getattr(self, "_fused_bits_set", False):      # A/B aid: bpx_debug_set_bwd_fused bits
+            lib.bpx_debug_set_bwd_fused(int(os.environ["BPX_FUSED_BITS"]))
+            self._fused_bits_set = True
+        return (os.environ.get("BPX_BWD_FUSED", "1") != "0" and self.act <= 3 and not self.use_side_stream and self.cfg.gn_groups == 0 and self.dtype != torch.float32
                 and bool(lib.bpx_conv3d_bwd_fused_supported(self.bdt, B, S[0], S[1], S[2], Ct, Cdy)))
 
     def _bwd_fused(self, B, S, dy: "L.Tensor", wt, t: "L.Tensor", rec, g: "L.Tensor", dw, db, db2, st, dev):
         D, H, W = S
-        tiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, t.C)
+        tiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, t.C, dy.C)
         red = torch.empty((B, tiles, 2, t.C), dtype=torch.float32, device=dev)
         ws = self._workspace(lib.bpx_conv3d_bwd_fused_workspace(B, D, H, W, t.C, dy.C), dev)
         L.check(lib.bpx_conv3d_bwd_fused(self.bdt, B, D, H, W, dy, wt.data_ptr(), t, rec.data_ptr(), self.act, g, red.data_ptr(),
@@ -689,7 +692,12 @@ class ResUNetEngine:
             L.check(lib.bpx_conv3d_dgrad(self.gdt, B, D, H, W, dH, w1t.data_ptr(), L.NULL_T, None, 0, L.tview(g0), None, st))
             L.check(lib.bpx_conv1x1_fwd(self.gdt, B, vox, dOut, wsct.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.tview(g0), dx_out, st))
 
-    def backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor, on_last_block=None) -> Dict[str, torch.Tensor]:
+        """``on_last_block``: called (no arguments) right before the backward of the FIRST encoder block - the last stretch of the pass.  At that
+        point every queued weight-gradient reduction has been flushed, so all parameter gradients except ``down_path.0.*`` are final in the flat
+        slab (``self.last_flat_grad``, parameter order): a data-parallel step starts their all-reduce there and lets it run beside the rest of
+        the backward (graphs.DataParallelTrainStep; what DDP's buckets do for the reference, base_workflow.py:952-958)."""
+        self._on_last_block = on_last_block
         self._keep = []   # buffers the side stream may still be reading; released after the final stream join
         # the ~29 weight-gradient reductions of a step run as one batched launch at the end (they are latency chains of a
         # few hundred blocks each; back to back they cost 0.6 ms).  Not with the side stream: the flush is stream-ordered.
@@ -702,6 +710,7 @@ class ResUNetEngine:
         try:
             G = self._backward(P if Pw is None else Pw, ctx, dlogits)
         finally:
+            self._on_last_block = None
             if self._deferred:
                 self._deferred = False
                 L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
@@ -724,6 +733,7 @@ class ResUNetEngine:
         names = list(P.keys())
         sizes = [P[n].numel() for n in names]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.last_flat_grad = flat
         G: Dict[str, torch.Tensor] = {}
         o = 0
         for n, s in zip(names, sizes):
@@ -790,6 +800,11 @@ class ResUNetEngine:
             # dOut_i = dSkip + unpool(dP); written in place over dSkip
             skipv = L.tview(dskip[i])
             L.check(lib.bpx_maxpool3d_bwd(self.bdt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
+            if i == 0 and getattr(self, "_on_last_block", None) is not None:
+                if self._deferred:      # the reductions queued so far write their gradients now; the last block's are queued afresh
+                    L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
+                    L.check(lib.bpx_wgrad_defer_begin())
+                self._on_last_block()
             if i > 0:
                 dPn = torch.empty((B,) + S[i] + (fm[i - 1],), dtype=T, device=dev)
                 self._block_bwd(P, G, blocks[i], B, skipv, img, st, None, L.tview(dPn))

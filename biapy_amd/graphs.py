@@ -156,9 +156,17 @@ class DataParallelTrainStep:
     What ``DistributedDataParallel`` does for the reference (``base_workflow.py:952-958``: parameters broadcast from rank 0 at
     construction, gradients averaged over ranks every step), laid out for replay: every ``p.grad`` is a view into ONE flat fp32
     buffer (6.69 M elements = 26.8 MB for cfg 2), so a step is two HIP-graph replays with a single ring all-reduce over xGMI
-    between them - no per-bucket hooks, no copies, ~3 host calls per step.  The all-reduce is not overlapped with the backward
-    pass: 26.8 MB is ~0.2 ms on 7 x 153 GB/s links against a 13 ms step, less than what eager hooks cost on the host.
+    between them - no per-bucket hooks, no copies, ~3 host calls per step.
     InstanceNorm has no cross-rank statistics and there are no buffers to synchronise.
+
+    ``overlap`` (round 4): with a drop-in ResUNet the step drives the engine directly (forward, loss, the loss's own small
+    autograd graph for d loss / d logits, the engine's hand-written backward) and splits the backward where its LAST stretch begins - the
+    backward of the first encoder block, ~0.8 ms of kernels at cfg 2.  Every other parameter gradient is final in the flat slab by then (the
+    engine flushes its queued weight-gradient reductions at that point), so their all-reduce (all of the 26.8 MB but the first block's few
+    kilobytes) is started there with ``async_op`` and runs on RCCL's stream beside the rest of the backward; the first block's segment follows.
+    Three graph replays per step (forward + backward head | backward tail | optimizer) instead of two.  This is what DDP's 25 MB buckets
+    firing during backward buy the reference (base_workflow.py:952-958).  ``overlap="auto"`` takes it when the model qualifies; models without
+    an engine (or with dict outputs) keep the serial form, as does ``overlap=False``.
 
     ``graph=False`` runs the same three phases eagerly (any device / backend; this is what the gloo tests drive); that form
     needs ``p.grad`` to stay views of ``self.flat_grad`` and re-binds them at every call, so an ``optimizer.zero_grad()`` by the
@@ -167,8 +175,9 @@ class DataParallelTrainStep:
     """
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer, x: torch.Tensor,
-                 target: torch.Tensor, group=None, graph: bool = True, warmup: int = 3, broadcast_parameters: bool = True):
+                 target: torch.Tensor, group=None, graph: bool = True, warmup: int = 3, broadcast_parameters: bool = True, overlap="auto"):
         self.model, self.loss_fn, self.opt, self.group = model, loss_fn, optimizer, group
+        self.overlapped = False
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
@@ -184,15 +193,20 @@ class DataParallelTrainStep:
                     raise ValueError("build the optimizer with capturable=True to capture its step")
         if self.world > 1 and broadcast_parameters:                      # DDP's construction-time broadcast from rank 0
             broadcast_parameters_from_rank0(self.params, group)
+        self.x, self.target = x.clone(), target.clone()
+        self._lr = _LrTensors(optimizer, dev) if graph else None
+        self._out = None
+        inv = 1.0 / self.world
+        if overlap and self._overlap_ok(model, x):
+            self._init_overlapped(model, loss_fn, optimizer, graph, warmup, inv)
+            return
+        if overlap is True:
+            raise ValueError("overlap=True needs a drop-in ResUNet (biapy_amd.resunet.ResUNet without super-resolution / class heads) on a HIP device")
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self.x, self.target = x.clone(), target.clone()
-        self._lr = _LrTensors(optimizer, dev) if graph else None
-        self._out = None
-        inv = 1.0 / self.world
 
         def fwd_bwd():
             self.flat_grad.zero_()
@@ -259,6 +273,98 @@ class DataParallelTrainStep:
             self.graphs = (g1, g2)
             _bump()
 
+    # ---- overlapped form -------------------------------------------------------------------------------------------------------------
+    def _overlap_ok(self, model, x) -> bool:
+        inner = model.module if hasattr(model, "module") and not hasattr(model, "engine") else model
+        if not (x.is_cuda and hasattr(inner, "engine") and hasattr(inner, "_named") and hasattr(inner, "_finish_outputs")):
+            return False
+        if getattr(inner, "sr_pre", 0) or getattr(inner, "return_class", False) or getattr(inner, "explicit_activations", False):
+            return False
+        names, params = inner._named()
+        if [id(p) for p in params] != [id(p) for p in self.params]:
+            return False
+        first = [n.startswith("down_path.0.") for n in names]
+        k = sum(first)
+        return 0 < k < len(names) and all(first[:k]) and not any(first[k:])      # the first block's parameters are a prefix of the slab
+
+    def _init_overlapped(self, model, loss_fn, optimizer, graph, warmup, inv):
+        inner = model.module if hasattr(model, "module") and not hasattr(model, "engine") else model
+        eng = inner.engine()
+        names, params = inner._named()
+        self._n_first = sum(p.numel() for n, p in zip(names, params) if n.startswith("down_path.0."))
+        self.overlapped = True
+        self._works = []
+        state = {"capturing": None}
+
+        def reduce_rest():          # at the start of the backward's last stretch: everything but the first block's gradients is final
+            cap = state["capturing"]
+            if cap is not None:     # capture: close the first graph here and open the second - nothing is exchanged while capturing
+                cap[0].capture_end()
+                cap[1].capture_begin(pool=cap[0].pool(), capture_error_mode="thread_local")
+                return
+            if self.world > 1:
+                self._works.append(dist.all_reduce(eng.last_flat_grad[self._n_first:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        def fwd_bwd():
+            P = {n: p.detach() for n, p in zip(names, params)}
+            logits, ctx = eng.forward(P, self.x.to(torch.float32), head_act=0, save=True)
+            self._out = logits
+            with torch.enable_grad():
+                lg = logits.detach().requires_grad_(True)
+                loss = loss_fn(lg, self.target)
+                (dl,) = torch.autograd.grad(loss, lg)
+            G = eng.backward(P, ctx, dl, on_last_block=reduce_rest)
+            self.flat_grad = eng.last_flat_grad
+            for n, p in zip(names, params):
+                p.grad = G[n]
+            return loss.detach()
+
+        def finish_reduce():
+            if self.world > 1:
+                self._works.append(dist.all_reduce(self.flat_grad[:self._n_first], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                for w in self._works:
+                    w.wait()
+                self._works.clear()
+
+        def update():
+            if self.world > 1:
+                self.flat_grad.mul_(inv)
+            optimizer.step()
+
+        def eager():
+            loss = fwd_bwd()
+            finish_reduce()
+            update()
+            return loss
+
+        self._eager_overlapped = eager
+        self._finish_reduce, self._update = finish_reduce, update
+        self.graphs = None
+        self.adopted = True
+        if not graph:
+            return
+        side = torch.cuda.Stream()
+        with torch.no_grad():
+            _warm(eager, warmup, side)
+            g1a, g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                state["capturing"] = (g1a, g1b)
+                try:
+                    g1a.capture_begin(capture_error_mode="thread_local")
+                    self.loss = fwd_bwd()                                   # reduce_rest() switches from g1a to g1b inside
+                    g1b.capture_end()
+                finally:
+                    state["capturing"] = None
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(g2, pool=g1a.pool(), stream=side, capture_error_mode="thread_local"):
+                update()
+        torch.cuda.synchronize()
+        self._check_views()
+        self.graphs = (g1a, g1b, g2)
+        _bump()
+
     def _adopted_flat(self) -> Optional[torch.Tensor]:
         """The gradients as one flat tensor if they are consecutive contiguous fp32 views of one allocation, in parameter order."""
         g0 = self.params[0].grad
@@ -303,6 +409,21 @@ class DataParallelTrainStep:
             self.x.copy_(x, non_blocking=True)
         if target is not None:
             self.target.copy_(target, non_blocking=True)
+        if self.overlapped:
+            if self.graphs is None:
+                with torch.no_grad():
+                    loss = self._eager_overlapped()
+                _bump()
+                return loss
+            self._lr.sync()
+            self.graphs[0].replay()                                      # forward, loss, backward up to its last stretch
+            if self.world > 1:                                           # ... whose gradients travel while the last stretch runs
+                self._works.append(dist.all_reduce(self.flat_grad[self._n_first:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.graphs[1].replay()                                      # backward of the first encoder block
+            self._finish_reduce()
+            self.graphs[2].replay()
+            _bump()
+            return self.loss
         if self.graphs is None:
             self._bind_views()                                           # the caller may have dropped or replaced p.grad
             loss = self._fwd_bwd()

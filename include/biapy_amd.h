@@ -211,16 +211,16 @@ int bpx_conv3d_wgrad_db2(int dtype, int N, int D, int H, int W, bpx_tensor x, co
  * act(scale*t+shift)); fused, dy and t are read once (16 -> 16 channels: 3 tensor passes instead of 5; dy 16 -> t 48: 7 instead of 11).
  * Results are those of the two separate calls: g bit for bit that of bpx_conv3d_dgrad; its partials, dW and db fixed-order sums
  * of per-workgroup partials (bit-reproducible; the grouping of the voxels differs from bpx_conv3d_wgrad's, so the fp32 sums differ in the last bits).
- * Supported (bpx_conv3d_bwd_fused_supported): dtype BF16 or MIX16 (t fp16), dy.C == 16, t.C in {16, 48}, W > 8, >= 32^3 voxels per sample, t_norm_d
- * given.  red_part_d: [N][bpx_conv3d_bwd_fused_stats_tiles(N, D, H, W, t.C)][2][t.C] floats - t.C == 16: one row per (sample, persistent WORKGROUP), every row written (zeros where a workgroup had no tile of the sample); t.C == 48: one row per 4x4x16 tile.  ws_bytes >= bpx_conv3d_bwd_fused_workspace(...); inside a
+ * Supported (bpx_conv3d_bwd_fused_supported): dtype BF16 or MIX16 (t fp16); (dy.C, t.C) = (16, 16 | 48) - the level-0 layers of cfg 2 - or
+ * (32, 16 | 32) - level-1 layers (32 -> 96 measured no faster than the two kernels and is not taken); W > 8, >= 32^3 voxels per sample, t_norm_d given.  red_part_d: [N][bpx_conv3d_bwd_fused_stats_tiles(N, D, H, W, t.C, dy.C)][2][t.C] floats - one row per (sample, persistent workgroup column), every row written (zeros where a workgroup had no tile of the sample); (dy 16, t 48): one row per 4x4x16 tile.  ws_bytes >= bpx_conv3d_bwd_fused_workspace(...); inside a
  * bpx_wgrad_defer_begin / _flush window the reduction is queued like bpx_conv3d_wgrad's (own workspace per call).  t may be chunk-planar. */
 int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy);
-int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct);
+int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct, int Cdy);
 int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy);
 int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_tensor dy, const void* w_packed_T_d, bpx_tensor t,
                          const bpx_norm_rec* t_norm_d, int act, bpx_tensor g, float* red_part_d, float* dw_d, float* db_d, float* db2_d,
                          void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
-int bpx_debug_set_bwd_fused(int on); /* test / A-B hook: 0 = bpx_conv3d_bwd_fused_supported answers 0 everywhere (the engine then takes the two separate kernels) */
+int bpx_debug_set_bwd_fused(int bits); /* test / A-B hook: bit 0 clear = bpx_conv3d_bwd_fused_supported answers 0 everywhere (the engine then takes the two separate kernels); bit 1 set = only the dy.C == 16 instances */
 
 /* Deferred reduction of the weight-gradient partials.  Between bpx_wgrad_defer_begin() and bpx_wgrad_defer_flush() (same
  * host thread) bpx_conv3d_wgrad and the bf16 bpx_convT3d_k2s2_wgrad write only their partial slabs and queue the reduction;

@@ -24,7 +24,7 @@ n = lib.bpx_packed_weight_elems(L.PK_K3_T, ct, cdy, L.MIX16)
 wpt = torch.empty(n, dtype=torch.bfloat16, device="cuda")
 L.check(lib.bpx_pack_weight(L.PK_K3_T, (torch.randn(cdy, ct, 3, 3, 3, device="cuda") * 0.05).data_ptr(), ct, cdy, L.MIX16, wpt.data_ptr(), st))
 rec = torch.rand(B, ct, 4, device="cuda")
-red = torch.empty(B, lib.bpx_conv3d_bwd_fused_stats_tiles(B, S, S, S, ct), 2, ct, device="cuda")
+red = torch.empty(B, lib.bpx_conv3d_bwd_fused_stats_tiles(B, S, S, S, ct, cdy), 2, ct, device="cuda")
 dw = torch.empty(cdy, ct, 3, 3, 3, device="cuda"); db = torch.zeros(cdy, device="cuda")
 ws = torch.empty(lib.bpx_conv3d_bwd_fused_workspace(B, S, S, S, ct, cdy), dtype=torch.uint8, device="cuda")
 stamps = torch.zeros(4096, 16, dtype=torch.int64, device="cuda")

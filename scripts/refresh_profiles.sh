@@ -41,7 +41,7 @@ python tests/bench_kernels.py bwd --reps 10 2>&1 | grep -v amdgpu.ids > $O/${R}_
 python tests/gpu_diag.py --net --out $O/${R}_gpu_diag.txt > /dev/null 2>&1
 python tests/bench_kernels.py rcan 2>&1 | grep -v "Warning\|run_backward" > $O/${R}_rcan_trunk_64.txt
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o train -- python $ROOT/bench.py --mode train --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_train.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o train -- python $ROOT/bench.py --mode train --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events --no-bf16-record > $ROOT/$O/kt_train.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o resunetpp -- python $ROOT/bench.py --arch resunetpp --batch 4 --steps 20 --warmup 3 > $ROOT/$O/kt_pp.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/kt -o infer -- python $ROOT/bench.py --mode infer --steps 20 --warmup 3 --no-cpu-baseline --no-launch-events > $ROOT/$O/kt_infer.log 2>&1
 cd $ROOT
@@ -49,12 +49,12 @@ cp $(find $O/kt -name "train_kernel_stats.csv" | head -1) $O/${R}_bench_train_ke
 cp $(find $O/kt -name "infer_kernel_stats.csv" | head -1) $O/${R}_bench_infer_kernel_stats.csv
 cp $(find $O/kt -name "resunetpp_kernel_stats.csv" | head -1) $O/${R}_bench_resunetpp_kernel_stats.csv
 cd /tmp
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_f -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_f.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_w -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_w.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_f -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_w -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_w.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES --kernel-trace \
-   -d $ROOT/$O/pmc_a -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_a.log 2>&1
+   -d $ROOT/$O/pmc_a -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_a.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace \
-   -d $ROOT/$O/pmc_b -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --graph off > $ROOT/$O/pmc_b.log 2>&1
+   -d $ROOT/$O/pmc_b -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_b.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_tf -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tf.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tw.log 2>&1
 cd $ROOT

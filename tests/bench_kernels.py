@@ -116,7 +116,7 @@ def main():
     if a.what in ("bwd", "all"):
         # backward of one conv in the mixed training mode (t fp16, gradients bf16): dgrad + wgrad as two kernels vs bpx_conv3d_bwd_fused.
         # (S, Ct = channels of t / g, Cdy, planar t): the level-0 convs of cfg 2 (decoder conv2 / encoder conv2, decoder conv1)
-        for (S, ct, cdy, planar) in [(128, 16, 16, False), (128, 48, 16, True), (64, 16, 16, False)]:
+        for (S, ct, cdy, planar) in [(128, 16, 16, False), (128, 48, 16, True), (64, 16, 16, False), (64, 32, 32, False), (64, 96, 32, True), (64, 16, 32, False)]:
             dy = torch.randn(B, S, S, S, cdy, device=DEV).to(torch.bfloat16)
             tt = torch.randn(B, S, S, S, ct, device=DEV).to(torch.float16)
             tv = L.tview(L.Planar(B, (S, S, S), ct, torch.float16, DEV).copy_from_dense(tt)) if planar else L.tview(tt)
@@ -135,7 +135,7 @@ def main():
             U = B * S ** 3 * 32 / 1e6   # MB of one 16-channel tensor
             line = f"bwd {S:4d}^3 dy{cdy}->g{ct:3d}: dgrad {md * 1e3:7.1f} us + wgrad(+reduce) {mw * 1e3:7.1f} us = {(md + mw) * 1e3:7.1f}"
             if lib.bpx_conv3d_bwd_fused_supported(L.MIX16, B, S, S, S, ct, cdy):
-                ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, S, S, S, ct)
+                ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, S, S, S, ct, cdy)
                 red2 = torch.empty(B, ftiles, 2, ct, device=DEV)
                 ws2 = torch.empty(max(1, lib.bpx_conv3d_bwd_fused_workspace(B, S, S, S, ct, cdy)), dtype=torch.uint8, device=DEV)
                 ff = lambda: L.check(lib.bpx_conv3d_bwd_fused(L.MIX16, B, S, S, S, L.tview(dy), wpt.data_ptr(), tv, rec.data_ptr(), 1, L.tview(g), red2.data_ptr(),

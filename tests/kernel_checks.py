@@ -784,7 +784,7 @@ def check_mix16_kernels(S=(8, 16, 32), B=2, Cin=32, Cout=16, seed=0):
     return res
 
 
-def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, act=1):
+def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, act=1, Cdy=16):
     """bpx_conv3d_bwd_fused (dgrad + wgrad of one conv in one pass) against the two separate entry points on the same device operands
     (g bit for bit, statistics / dW / db to fp32 summation order) and against the fp32 PyTorch operators on the same rounded inputs."""
     D, H, W = S
@@ -792,7 +792,6 @@ def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, 
     A, G_ = (L.F16 if mix else L.BF16), L.BF16
     dtc = L.MIX16 if mix else L.BF16
     st = L.stream_ptr()
-    Cdy = 16
     tag = f"bwd_fused[{'mix16' if mix else 'bf16'} B{B} {S} dy{Cdy}->g{Ct}{' planar' if planar else ''} act{act}]"
     res = []
     if not lib.bpx_conv3d_bwd_fused_supported(dtc, B, D, H, W, Ct, Cdy):
@@ -831,7 +830,7 @@ def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, 
     L.check(lib.bpx_conv3d_wgrad(dtc, B, D, H, W, tv, recd.data_ptr(), act, L.tview(dyd), 3, dw_sep.data_ptr(), db_sep.data_ptr(), ws.data_ptr(), ws.numel(), st))
     # fused
     g_f = torch.full((B, D, H, W, Ct), float("nan"), dtype=torch.bfloat16, device=DEV)
-    ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, Ct)
+    ftiles = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, Ct, Cdy)
     red_f = torch.full((B, ftiles, 2, Ct), float("nan"), dtype=torch.float32, device=DEV)
     dw_f = torch.full((Cdy, Ct, 3, 3, 3), 7.0, dtype=torch.float32, device=DEV)
     db_f = torch.zeros(Cdy, dtype=torch.float32, device=DEV)

@@ -180,6 +180,15 @@ def test_fused_conv_backward_equals_dgrad_plus_wgrad(K, mix, B, S, Ct, planar, a
     _assert_all(K.check_bwd_fused(mix, B, S, Ct, planar, act=act))
 
 
+@pytest.mark.parametrize("mix,B,S,Ct,planar,act", [(True, 2, (32, 32, 32), 32, False, 1), (True, 1, (32, 32, 32), 32, True, 1), (False, 1, (36, 34, 40), 16, False, 1),
+                                                   (True, 1, (34, 38, 44), 32, True, 1), (False, 1, (32, 32, 48), 32, False, 2), (True, 1, (64, 64, 64), 32, False, 1)],
+                         ids=["mix-32", "mix-32-planar", "bf16-16-ragged", "mix-32-planar-ragged", "bf16-32-relu", "mix-32-64^3"])
+def test_fused_conv_backward_32_channel_gradients(K, mix, B, S, Ct, planar, act):  # noqa
+    """The dy.C == 32 instances of bpx_conv3d_bwd_fused (the level-1 layers of cfg 2: 32 -> 32, 96 -> 32, 16 -> 32): two dy chunks per
+    workgroup, t.C / 16 workgroup columns."""
+    _assert_all(K.check_bwd_fused(mix, B, S, Ct, planar, act=act, Cdy=32))
+
+
 @pytest.mark.parametrize("dt,S,lean", [(0, (8, 16, 32), False), (1, (8, 16, 32), False), (1, (64, 64, 64), True), (0, (4, 8, 8), False),
                                        (1, (6, 10, 18), False), (1, (66, 70, 72), True)],
                          ids=["f32", "bf16", "bf16-lean-64^3", "f32-w8", "bf16-ragged-tiles", "bf16-lean-ragged-tiles"])
@@ -1207,6 +1216,49 @@ def test_two_process_data_parallel_training_on_one_gpu():
         a, b = torch.from_numpy(res[0][2][k]), torch.from_numpy(res[1][2][k])
         assert torch.equal(a, b), k                                            # the ranks stay bit-identical
         assert (a - w).abs().max().item() <= 2e-5 * max(1.0, w.abs().max().item()), k
+
+
+def test_overlapped_data_parallel_step_equals_the_serial_one():
+    """DataParallelTrainStep's overlapped form (engine driven directly, the backward cut where its last stretch - the first
+    encoder block - begins, the other gradients' all-reduce started there) must train exactly like the serial form (autograd, one all-reduce
+    after the whole backward): same losses and bit-identical weights after four graph-replayed steps, and the same again in the eager forms.
+    One process (the reductions are no-ops): what is checked is the split itself - the mid-backward flush of the queued weight-gradient
+    reductions, three graphs instead of two, gradients bound without autograd.  The two-rank exchange is covered by
+    test_two_process_data_parallel_training_on_one_gpu, which now takes the overlapped form."""
+    from biapy_amd.graphs import DataParallelTrainStep
+    from biapy_amd.losses import BCEWithLogitsLoss
+    from biapy_amd.resunet import ResUNet
+
+    g = torch.Generator().manual_seed(12)
+    batches = [(torch.randn(2, 1, 32, 32, 32, generator=g).cuda(), (torch.rand(2, 1, 32, 32, 32, generator=g) > 0.5).float().cuda()) for _ in range(4)]
+
+    def run(overlap, graph):
+        torch.manual_seed(3)
+        m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=[16, 32, 64], drop_values=[0.0] * 3, normalization="in", yx_down=[2, 2],
+                    z_down=[2, 2], isotropy=[True] * 3, larger_io=False, conv_layers=[2] * 3, compute_dtype=torch.float16).cuda().train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+        w0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        step = DataParallelTrainStep(m, BCEWithLogitsLoss(), opt, batches[0][0], batches[0][1], graph=graph, overlap=overlap, broadcast_parameters=False)
+        assert step.overlapped == bool(overlap)
+        if graph:                                          # the capture warm-up took real optimizer steps: start both forms from the same state
+            with torch.no_grad():
+                m.load_state_dict(w0)
+            for st_ in opt.state.values():
+                for v in st_.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            from biapy_amd.engine import bump_weights_epoch
+            bump_weights_epoch()
+        losses = [float(step(x, t)) for x, t in batches]
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    for graph in (True, False):
+        l0, w0 = run(False, graph)
+        l1, w1 = run("auto", graph)
+        assert l0 == l1, (graph, l0, l1)
+        for k in w0:
+            assert torch.equal(w0[k], w1[k]), (graph, k)
 
 
 def _pp_model(seed, dtype=torch.float32, patch=16):
