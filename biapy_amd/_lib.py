@@ -87,6 +87,7 @@ _SIGS = {
     "bpx_conv3d_bwd_fused": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_debug_set_bwd_fused": ([_i], _i),
     "bpx_debug_set_tile_order": ([_i], _i),
+    "bpx_debug_set_wgrad_cap": ([_i], _i),
     "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
     "bpx_conv1x1_fwd_split": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, Tensor, _vp], _i),
@@ -150,6 +151,10 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError = the library does not export what the header declares
         fn.argtypes = args
         fn.restype = res
+    # A/B hooks through the environment: wgrad partial-slab cap in percent
+    for env, hook in (("BPX_WGRAD_CAP", "bpx_debug_set_wgrad_cap"),):
+        if os.environ.get(env) is not None:
+            getattr(lib, hook)(int(os.environ[env]))
     return lib
 
 

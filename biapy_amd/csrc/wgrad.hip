@@ -1055,6 +1055,7 @@ int finish_wgrad(const char* fn, const ReduceJob& j, hipStream_t s) {
   return 0;
 }
 
+int g_cap_pct = 100;   // partial-slab caps of the two plans below in percent (bpx_debug_set_wgrad_cap)
 int g_k1_wgs = 768;    // workgroups targeted by the k = 1 launches: 768 (three per CU) measured best of 256..2048 (test hook: bit 7 + percent of 1024 in bits 8..)
 struct WCfg { int tz, ty, tx, ns, groups; };
 // Deterministic in its arguments: the workspace query and the launch must agree.
@@ -1071,7 +1072,7 @@ inline WCfg pick_wcfg(int N, int D, int H, int W, int Cin, int Cout, int taps, b
   const int nchunks = Cin / 16;
   for (;;) {
     int nb = Cout / (16 * ns);
-    int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / dwElems);           // keep the partial slab <= ~50 MB round trip
+    int64_t cap = std::max<int64_t>(1, (int64_t)64000 * g_cap_pct / dwElems);  // keep the partial slab <= ~50 MB round trip
     int groups = (int)std::min<int64_t>(std::min<int64_t>(totalTiles, cap), std::max(1, cdiv(taps == 1 ? g_k1_wgs : 2048, nchunks * nb)));
     c.ns = ns; c.groups = groups;
     const int minblk = ((int64_t)D * H * W <= 512) ? 128 : 512;   // 8^3 bottleneck: wider co blocks win (82 -> 61 us); elsewhere NS = 1
@@ -1133,7 +1134,7 @@ inline SdmPlan sdm_plan(int N, int D, int H, int W, int Cin, int Cout) {
   const int64_t totalTiles = (int64_t)N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
   int64_t g = cdiv64((int64_t)256 * occ * g_sd_fill / 100, units);
   g = (g + 7) & ~7ll;                                                      // the grid rounds groups up to a multiple of 8 anyway
-  const int64_t cap = std::max<int64_t>(8, ((int64_t)16000000 / ((int64_t)27 * Cin * Cout)) & ~7ll);   // partial slab <= 64 MB
+  const int64_t cap = std::max<int64_t>(8, ((int64_t)160000 * g_cap_pct / ((int64_t)27 * Cin * Cout)) & ~7ll);   // partial slab <= 64 MB
   q.groups = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(g, cap), totalTiles));
   return q;
 }
@@ -1323,6 +1324,8 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   }
   return 0;
 }
+
+extern "C" int bpx_debug_set_wgrad_cap(int percent) { g_cap_pct = percent > 0 ? percent : 100; return 0; }
 
 // ---- deferred reductions -------------------------------------------------------------------------------------------------
 extern "C" int bpx_wgrad_defer_begin(void) {

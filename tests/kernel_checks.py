@@ -310,14 +310,14 @@ def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=
     torch.cuda.synchronize()
     y = ndhwc(y_ref)
     got = yb[..., yo:yo + Cout].float().cpu()
-    tag = f"conv3d_fwd[{'bf16' if dt == L.BF16 else 'f32'} B{B} {S} {Cin}->{Cout} norm={int(norm)} sc={sc_C} sl={int(slices)}]"
+    tag = f"conv3d_fwd[{ {L.BF16: 'bf16', L.F16: 'f16'}.get(dt, 'f32') } B{B} {S} {Cin}->{Cout} norm={int(norm)} sc={sc_C} sl={int(slices)}]"
     res = [_res(tag, relerr(got, y), tol_for(dt))]
     if slices:
         untouched = (yb[..., :yo].float() == 7).all().item() and (yb[..., yo + Cout:].float() == 7).all().item()
         res.append(_res(tag + ".neighbours_untouched", 0 if untouched else 1, 0))
     s = part.sum(1).cpu()
     s_ref = torch.stack([y.sum((1, 2, 3)), (y * y).sum((1, 2, 3))], 1)
-    res.append(_res(tag + ".stats", relerr(s, s_ref), 5e-3 if dt == L.BF16 else 1e-4))
+    res.append(_res(tag + ".stats", relerr(s, s_ref), 5e-3 if dt in (L.BF16, L.F16) else 1e-4))
     return res
 
 
@@ -1925,3 +1925,4 @@ def check_dice_parity_trained(steps=120):
         res.append(_res(f"trained_model[{tagd}].logits_rel", ((lo - lo_ref).abs().max() / lo_ref.abs().max()).item(),
                         {"f32": 1e-5, "bf16": 3e-2, "f16": 3e-3}[tagd]))
     return res
+
