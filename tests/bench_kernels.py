@@ -96,6 +96,35 @@ def main():
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * 27 * cin * cout
             print(f"conv_dgrad {S:4d}^3 dy{cout:4d}->g{cin:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s")
+    if a.what == "prologue":
+        # VERDICT r3 next #5 ("forward prologue diet"): level-0 forward convs with the fused normalise + ELU prologue, against a streaming pass
+        # that materialises a = ELU(scale * x + shift) once (bpx_norm_act_fwd) followed by the same conv WITHOUT a prologue.
+        for (S, cin, cout, csc) in [(128, 16, 16, 48), (128, 16, 16, 1), (128, 48, 16, 0), (64, 32, 32, 96), (64, 96, 32, 0)]:
+            x = torch.randn(B, S, S, S, cin, device=DEV).to(T)
+            av = torch.empty_like(x)
+            y = torch.empty(B, S, S, S, cout, device=DEV, dtype=T)
+            wp = pack(torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05, L.PK_K3, cin, cout)
+            bias = torch.zeros(cout, device=DEV)
+            rec = torch.rand(B, cin, 4, device=DEV)
+            tiles = lib.bpx_conv3d_stats_tiles(dt, B, S, S, S, cout)
+            part = torch.empty(B, tiles, 2, cout, device=DEV)
+            sct, wscp, keep = L.NULL_T, None, []
+            if csc == 1:
+                img = torch.randn(B, S, S, S, device=DEV); wsc = torch.randn(cout, device=DEV)
+                sct, wscp, keep = L.Tensor(img.data_ptr(), 1, 1), wsc.data_ptr(), [img, wsc]
+            elif csc:
+                sc = torch.randn(B, S, S, S, csc, device=DEV).to(T)
+                wk = pack(torch.randn(cout, csc, 1, 1, 1, device=DEV), L.PK_K1, csc, cout)
+                sct, wscp, keep = L.tview(sc), wk.data_ptr(), [sc, wk]
+
+            def conv(src, recp):
+                return lambda: L.check(lib.bpx_conv3d_fwd(dt, B, S, S, S, L.tview(src), recp, 1, wp.data_ptr(), bias.data_ptr(), sct, wscp,
+                                                          bias.data_ptr() if csc else None, L.tview(y), part.data_ptr(), st))
+            fpass = lambda: L.check(lib.bpx_norm_act_fwd(dt, B, S ** 3, L.tview(x), rec.data_ptr(), 1, L.tview(av), st))
+            m_fused, m_plain, m_pass = timeit(conv(x, rec.data_ptr()), a.reps), timeit(conv(av, None), a.reps), timeit(fpass, a.reps)
+            print(f"prologue {S:4d}^3 {cin:3d}->{cout:3d} sc={csc:3d}: fused prologue {m_fused * 1e3:7.1f} us | materialise {m_pass * 1e3:7.1f} + conv without prologue "
+                  f"{m_plain * 1e3:7.1f} = {(m_pass + m_plain) * 1e3:7.1f} us")
+        return
     if os.environ.get('BPX_TILE_ORDER') is not None:
         lib.bpx_debug_set_tile_order(int(os.environ['BPX_TILE_ORDER']))
     if os.environ.get('BPX_WGRAD') is not None:
