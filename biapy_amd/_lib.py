@@ -126,6 +126,8 @@ _SIGS = {
     "bpx_conv3d_c1_fwd": ([_i, _i, _i, _i, _i, _vp, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_conv3d_c1_stats_tiles": ([_i, _i, _i], _i),
     "bpx_conv3d_c1_wgrad": ([_i, _i, _i, _i, _i, _vp, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
+    "bpx_conv3d_c1_wgrad_nb_supported": ([_i, _i], _i),
+    "bpx_conv3d_c1_wgrad_nb": ([_i, _i, _i, _i, _i, _vp, Tensor, Tensor, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_conv1x1_c1_wgrad": ([_i, _i64, _vp, Tensor, _vp, _vp, _i64, _vp], _i),
     "bpx_cast": ([_i, _vp, _i, _vp, _i64, _vp], _i),
     "bpx_upsample_c1_fwd": ([_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),

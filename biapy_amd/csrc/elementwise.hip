@@ -939,9 +939,15 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_kernel(const float* __restr
 // A = image patches (fp32 in LDS, split hi + lo into two bf16 operands exactly like conv_c1_fwd_kernel, so the image keeps
 // ~16 mantissa bits), two 16-row blocks for the 27 taps; row 27 is all ones -> D[27][co] = sum_v dy = the bias gradient.
 // G = dy^T fragments through ds_read_b64_tr_b16.  Wave w owns K-chunks {2w, 2w+1} of every 4x4x16 tile.
+// NB (round 4): dy is not read but formed on the way into LDS from the InstanceNorm-backward operands of the layer's output,
+//   dy = a[n,c] * g + b[n,c] * t + c0[n,c]   (bpx_norm_bwd_finalize's coefficients; t = the conv's raw output, TT = fp16 in the mixed mode)
+// in the arithmetic of norm_bwd_apply_kernel and rounded to bf16 as that kernel's store would: the pass that wrote dy (3 tensor units of
+// traffic at 128^3, 139 us per cfg-2 step) is gone and this kernel reads two units instead of one.
+template <typename TT, bool NB>
 __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __restrict__ img, const uint16_t* __restrict__ dy, int dy_ld,
                                                                  int D, int H, int W, int N, int totalTiles, float* __restrict__ dw,
-                                                                 float* __restrict__ db) {
+                                                                 float* __restrict__ db, const TT* __restrict__ tsrc, int t_ld,
+                                                                 const bpx_nbwd_coef* __restrict__ coef) {
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int VBG = 32;
   __shared__ float simg[HV + 8];
@@ -965,6 +971,8 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
   constexpr int NI = (HV + 255) / 256;
   float pi[NI];
   u32x4_t pg[2];
+  u32x4_t pt[NB ? 2 : 1];
+  f32x4_t pk[NB ? 8 : 1];   // {a, b, c0, -} of this thread's 8 channels in the sample of the tile in flight
   auto issue = [&](int tt) {
     const int n = tt / tps, tile = tt % tps;
     const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
@@ -980,8 +988,32 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
       const int q = u * 256 + tid, t = q >> 1;
       const int x = x0 + (t & 15), y = y0 + ((t >> 4) & 3), z = z0 + (t >> 6);
       pg[u] = u32x4_t{0u, 0u, 0u, 0u};
-      if (z < D && y < H && x < W) pg[u] = *reinterpret_cast<const u32x4_t*>(dy + ((((size_t)n * D + z) * H + y) * W + x) * dy_ld + cb + (q & 1) * 8);
+      if (NB) pt[NB ? u : 0] = u32x4_t{0u, 0u, 0u, 0u};
+      if (z < D && y < H && x < W) {
+        const size_t v = (((size_t)n * D + z) * H + y) * W + x;
+        pg[u] = *reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + cb + (q & 1) * 8);
+        if (NB) pt[NB ? u : 0] = *reinterpret_cast<const u32x4_t*>(tsrc + v * t_ld + cb + (q & 1) * 8);
+      }
     }
+    if (NB) {
+      const f32x4_t* kp = reinterpret_cast<const f32x4_t*>(coef + (size_t)n * (16 * gridDim.y) + cb + (tid & 1) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pk[NB ? e : 0] = kp[e];
+    }
+  };
+  // the staged dy piece: as loaded, or a * g + b * t + c0 (out-of-volume voxels stay zero: their operands were never loaded)
+  auto piece = [&](int u, int tt) -> u32x4_t {
+    if (!NB) return pg[u];
+    const int q = u * 256 + tid, t = q >> 1;
+    const int tile = tt % tps;
+    const int x = (tile % tilesX) * TX + (t & 15), y = ((tile / tilesX) % tilesY) * TY + ((t >> 4) & 3), z = (tile / (tilesX * tilesY)) * TZ + (t >> 6);
+    if (!(z < D && y < H && x < W)) return u32x4_t{0u, 0u, 0u, 0u};
+    float gf[8], tf[8], of[8];
+    unpack16<uint16_t>(pg[u], gf);
+    unpack16<TT>(pt[NB ? u : 0], tf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const f32x4_t k = pk[NB ? e : 0]; of[e] = k[0] * gf[e] + k[1] * tf[e] + k[2]; }
+    return pack16<uint16_t>(of);
   };
   if ((int)blockIdx.x < totalTiles) issue(blockIdx.x);
   for (int tt = blockIdx.x; tt < totalTiles; tt += gridDim.x) {
@@ -990,7 +1022,7 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
     for (int u = 0; u < NI; ++u)
       if (u * 256 + tid < HV) simg[u * 256 + tid] = pi[u];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = pg[u];
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = piece(u, tt);
     __syncthreads();
     if (tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);
 #pragma unroll
@@ -2019,25 +2051,32 @@ extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const fl
   return 0;
 }
 
-extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy, float* dw_d, float* db_d,
-                                   void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
-  BPX_CHECK(dy.cs == 0, "bpx_conv3d_c1_wgrad: chunk-planar tensors (cs != 0) are not accepted here");
-  const char* fn = "bpx_conv3d_c1_wgrad";
+static int c1_wgrad_impl(const char* fn, int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy, bpx_tensor t,
+                         const bpx_nbwd_coef* coef_d, float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(dy.cs == 0, "%s: chunk-planar tensors (cs != 0) are not accepted here", fn);
   BPX_CHECK(img_d && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(dy.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
   BPX_CHECK(ws_d && ws_bytes >= bpx_conv3d_c1_wgrad_workspace(dy.C), "%s: workspace too small (%lld bytes)", fn, (long long)ws_bytes);
+  const bool nb = coef_d != nullptr, mix = dtype == BPX_MIX16;
+  if (mix) dtype = BPX_BF16;
   int totalTiles = N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 8);
   dim3 grid((unsigned)std::min(totalTiles, 1024), (unsigned)(dy.C / 16));
   hipStream_t s = (hipStream_t)stream;
   int groups = (int)grid.x;
   float* pw = reinterpret_cast<float*>(ws_d);
-  if (dtype == BPX_BF16 && W > 8 && ((uintptr_t)dy.ptr & 15) == 0 && (dy.ld & 7) == 0) {
+  const bool mfma_ok = dtype == BPX_BF16 && W > 8 && ((uintptr_t)dy.ptr & 15) == 0 && (dy.ld & 7) == 0;
+  if (nb)
+    BPX_CHECK(mfma_ok && t.ptr && t.cs == 0 && t.C == dy.C && ((uintptr_t)t.ptr & 15) == 0 && (t.ld & 7) == 0 && ((uintptr_t)coef_d & 15) == 0,
+              "%s: needs bf16 gradients (BF16 / MIX16), W > 8 and 16-byte aligned dense g / t (bpx_conv3d_c1_wgrad_nb_supported)", fn);
+  if (mfma_ok) {
     const int tiles = N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
     // 768 workgroups (3 per CU), each looping over its share of the tiles
     dim3 gm((unsigned)std::min(tiles, 768), (unsigned)(dy.C / 16));
     groups = (int)gm.x;
     float* pb = db_d ? pw + (size_t)groups * 27 * dy.C : nullptr;
-    conv_c1_wgrad_mfma_kernel<<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb);
+    if (nb && mix) conv_c1_wgrad_mfma_kernel<f16_t, true><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, (const f16_t*)t.ptr, t.ld, coef_d);
+    else if (nb) conv_c1_wgrad_mfma_kernel<uint16_t, true><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, (const uint16_t*)t.ptr, t.ld, coef_d);
+    else conv_c1_wgrad_mfma_kernel<uint16_t, false><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, nullptr, 0, nullptr);
   } else {
     float* pb = db_d ? pw + (size_t)groups * 27 * dy.C : nullptr;
     if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, pw, pb);
@@ -2047,6 +2086,23 @@ extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const 
   BPX_LAUNCH_CHECK(fn);
   // partials [groups][27][1][Cout] -> dw (Cout,1,3,3,3): index = co*27 + tap
   return bpxred::reduce_partials(fn, pw, dw_d, groups, 27, 1, dy.C, 0, 27, 1, pw + (size_t)groups * 27 * dy.C, db_d, 0, true, s);
+}
+
+extern "C" int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy, float* dw_d, float* db_d,
+                                   void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32, "bpx_conv3d_c1_wgrad: dtype must be BF16 or F32");
+  return c1_wgrad_impl("bpx_conv3d_c1_wgrad", dtype, N, D, H, W, img_d, dy, bpx_tensor{nullptr, 0, 0}, nullptr, dw_d, db_d, ws_d, ws_bytes, stream);
+}
+
+// The same with dy = a * g + b * t + c0 formed inside the kernel (the InstanceNorm backward of the first layer's output: bpx_norm_bwd_apply folded
+// into its only consumer - the first layer has no input gradient).  dtype BF16 (g, t bf16) or MIX16 (t fp16); W > 8.
+extern "C" int bpx_conv3d_c1_wgrad_nb_supported(int dtype, int W) { return (dtype == BPX_BF16 || dtype == BPX_MIX16) && W > 8 ? 1 : 0; }
+extern "C" int bpx_conv3d_c1_wgrad_nb(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
+                                      float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  const char* fn = "bpx_conv3d_c1_wgrad_nb";
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_MIX16, "%s: dtype must be BF16 or MIX16", fn);
+  BPX_CHECK(coef_d != nullptr, "%s: coefficients are null", fn);
+  return c1_wgrad_impl(fn, dtype, N, D, H, W, img_d, g, t, coef_d, dw_d, db_d, ws_d, ws_bytes, stream);
 }
 
 extern "C" int bpx_conv1x1_c1_wgrad(int dtype, int64_t voxels_total, const float* img_d, bpx_tensor dy, float* dw_d, void* ws_d, int64_t ws_bytes,

@@ -642,10 +642,20 @@ class ResUNetEngine:
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
                                           G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), self.cfg.gn_groups or C1, coef.data_ptr(), st))
+        first_c1 = blk.first and self.cfg.in_ch == 1
+        if first_c1 and lib.bpx_conv3d_c1_wgrad_nb_supported(self.bdt, W) and os.environ.get("BPX_C1_NB", "1") != "0":
+            # the first layer has no input gradient: its weight gradient is the only reader of dH = a * g1 + b * h + c0, which is therefore formed
+            # inside that kernel and never stored (bpx_norm_bwd_apply's pass over three tensor units is gone)
+            wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(C1), dev)
+            self._keep.append(coef)
+            self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_c1_wgrad_nb(self.bdt, B, D, H, W, img.data_ptr(), L.tview(g1), L.tview(blk.h), coef.data_ptr(),
+                                                                              G[k["w1"]].data_ptr(), G[k["b1"]].data_ptr(), wsc.data_ptr(), wsc.numel(), s_)))
+            self._keep.append(g1)
+            return
         L.check(lib.bpx_norm_bwd_apply(self.bdt, B, vox, L.tview(g1), L.tview(blk.h), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         dH = L.tview(g1)
         # conv1
-        if blk.first and self.cfg.in_ch == 1:
+        if first_c1:
             wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(C1), dev)
             self._run_side(dev, lambda s_: L.check(lib.bpx_conv3d_c1_wgrad(self.gdt, B, D, H, W, img.data_ptr(), dH, G[k["w1"]].data_ptr(),
                                                                            G[k["b1"]].data_ptr(), wsc.data_ptr(), wsc.numel(), s_)))

@@ -362,6 +362,12 @@ int bpx_conv3d_c1_stats_tiles(int D, int H, int W);
 int64_t bpx_conv3d_c1_wgrad_workspace(int Cout);
 int bpx_conv3d_c1_wgrad(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor dy,
                         float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
+/* bpx_norm_bwd_apply folded into bpx_conv3d_c1_wgrad: dy = a * g + b * t + c0 (coef_d of bpx_norm_bwd_finalize, t = the first conv's raw output)
+ * is formed while the tile is staged and never stored - the first layer has no input gradient, so the weight gradient is dy's only consumer
+ * (blocks.py:154-157 under autograd, first ConvBlock of the encoder).  dtype BF16, or MIX16 (t fp16); needs W > 8 and dense 16-byte aligned g / t. */
+int bpx_conv3d_c1_wgrad_nb_supported(int dtype, int W);
+int bpx_conv3d_c1_wgrad_nb(int dtype, int N, int D, int H, int W, const float* img_d, bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d,
+                           float* dw_d, float* db_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* Shortcut of the first block (Conv3d 1 -> Cout, k = 1, blocks.py:1372 with in_size = 1): dW[co] = sum_v img[v]*dy[v][co]
  * (overwritten; partial sums in ws_d as for bpx_conv3d_c1_wgrad, deterministic, deferrable). */

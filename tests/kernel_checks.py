@@ -1926,3 +1926,44 @@ def check_dice_parity_trained(steps=120):
                         {"f32": 1e-5, "bf16": 3e-2, "f16": 3e-3}[tagd]))
     return res
 
+
+
+def check_c1_wgrad_nb(mix=True, B=2, S=(12, 20, 36), seed=0):
+    """bpx_conv3d_c1_wgrad_nb (dy = a*g + b*t + c0 formed inside the first layer's weight-gradient kernel) against bpx_norm_bwd_apply followed by
+    bpx_conv3d_c1_wgrad - the same bits, the kernels share arithmetic and summation order - and against the fp64 expression."""
+    D, H, W = S
+    gen = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, D, H, W, generator=gen)
+    gq = torch.randn(B, D, H, W, 16, generator=gen).to(torch.bfloat16)
+    tq = (torch.randn(B, D, H, W, 16, generator=gen) * 2).to(torch.float16 if mix else torch.bfloat16)
+    coef = torch.randn(B, 16, 4, generator=gen) * torch.tensor([1.0, 0.3, 0.1, 0.0])
+    dt = L.MIX16 if mix else L.BF16
+    imgd, gd, td, cd = img.to(DEV).contiguous(), gq.to(DEV), tq.to(DEV), coef.to(DEV).contiguous()
+    ws = torch.empty(lib.bpx_conv3d_c1_wgrad_workspace(16), dtype=torch.uint8, device=DEV)
+    res = []
+    tag = f"c1_wgrad_nb[{'mix' if mix else 'bf16'} B{B} {S}]"
+    res.append(_res(tag + ".supported", 0 if lib.bpx_conv3d_c1_wgrad_nb_supported(dt, W) else 1, 0))
+
+    def fused():
+        dw = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float32, device=DEV); db = torch.zeros(16, dtype=torch.float32, device=DEV)
+        L.check(lib.bpx_conv3d_c1_wgrad_nb(dt, B, D, H, W, imgd.data_ptr(), L.tview(gd), L.tview(td), cd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return dw, db
+
+    dwf, dbf = fused()
+    dwf2, dbf2 = fused()
+    res.append(_res(tag + ".run_to_run_bits", 0 if torch.equal(dwf, dwf2) and torch.equal(dbf, dbf2) else 1, 0))
+    dyd = torch.empty_like(gd)
+    L.check(lib.bpx_norm_bwd_apply(dt, B, D * H * W, L.tview(gd), L.tview(td), cd.data_ptr(), L.NULL_T, L.tview(dyd), L.stream_ptr()))
+    dws = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float32, device=DEV); dbs = torch.zeros(16, dtype=torch.float32, device=DEV)
+    L.check(lib.bpx_conv3d_c1_wgrad(L.BF16, B, D, H, W, imgd.data_ptr(), L.tview(dyd), dws.data_ptr(), dbs.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()))
+    torch.cuda.synchronize()
+    res.append(_res(tag + ".same_bits_as_apply_then_wgrad", 0 if torch.equal(dwf, dws) and torch.equal(dbf, dbs) else 1, 0, extra=f"max diff {(dwf - dws).abs().max().item():.2e}"))
+    dy = coef[:, None, None, None, :, 0].double() * gq.double() + coef[:, None, None, None, :, 1].double() * tq.double() + coef[:, None, None, None, :, 2].double()
+    w = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    bb = torch.zeros(16, dtype=torch.float64, requires_grad=True)
+    F.conv3d(img[:, None].double(), w, bb, padding=1).backward(ncdhw(dy))
+    res.append(_res(tag + ".dw_vs_fp64", relerr(dwf, w.grad), 6e-3))      # dy is rounded to bf16 on the way to the MFMA operand, as the stored tensor was
+    res.append(_res(tag + ".db_vs_fp64", relerr(dbf, bb.grad), 6e-3))
+    return res

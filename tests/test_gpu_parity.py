@@ -166,6 +166,13 @@ def test_mix16_backward_kernels(K, S, B, Cin, Cout):
     _assert_all(K.check_mix16_kernels(S, B, Cin, Cout))
 
 
+@pytest.mark.parametrize("mix,S", [(True, (12, 20, 36)), (False, (8, 8, 16)), (True, (32, 32, 32))], ids=["mix-ragged", "bf16", "mix-32^3"])
+def test_first_layer_weight_gradient_with_folded_norm_backward(K, mix, S):
+    """bpx_conv3d_c1_wgrad_nb: the InstanceNorm-backward affine of the first conv's output is formed inside its weight-gradient kernel
+    (its only consumer) - same bits as bpx_norm_bwd_apply followed by bpx_conv3d_c1_wgrad."""
+    _assert_all(K.check_c1_wgrad_nb(mix, 2, S))
+
+
 def test_fp16_raw_outputs_saturate_instead_of_overflowing(K):
     """conv results beyond the fp16 range are stored as +-65504, not +-inf; an fp16 network on raw 16-bit intensities stays finite."""
     _assert_all(K.check_f16_saturation())
