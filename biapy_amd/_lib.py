@@ -49,6 +49,7 @@ _SIGS = {
     "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
     "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_pack_weights_batched": ([_i, _i, _vp, _vp], _i),
+    "bpx_adam_step": ([_i, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp], _i),
     "bpx_scan_blocks": ([_i64], _i),
     "bpx_select_workspace": ([], _i64),
     "bpx_select_kth_f32": ([_vp, _i64, _i64, _vp, _vp, _vp], _i),
@@ -164,6 +165,11 @@ class PackJob(C.Structure):
     """bpx_pack_job (include/biapy_amd.h)."""
     _fields_ = [("w_d", C.c_void_p), ("packed_d", C.c_void_p), ("mode", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class AdamTensor(C.Structure):
+    """bpx_adam_tensor (include/biapy_amd.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("numel", C.c_int64)]
 
 
 class Profile:

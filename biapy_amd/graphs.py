@@ -54,6 +54,13 @@ class _LrTensors:
                 g["lr"] = t
 
 
+def _opt_step(optimizer) -> None:
+    """``optimizer.step()``; Adam / AdamW through ``bpx_adam_step`` once their state exists (optim.py)."""
+    from .optim import step
+
+    step(optimizer)
+
+
 def _bump() -> None:
     from .engine import bump_weights_epoch
 
@@ -109,7 +116,7 @@ class GraphedTrainStep:
             self._out = model(self.x)
             loss = loss_fn(self._out, self.target)
             loss.backward()
-            optimizer.step()
+            _opt_step(optimizer)
             return loss
 
         self.eager = eager
@@ -218,7 +225,7 @@ class DataParallelTrainStep:
         def update():
             if self.world > 1:
                 self.flat_grad.mul_(inv)
-            optimizer.step()
+            _opt_step(optimizer)
 
         self._fwd_bwd, self._update = fwd_bwd, update
         self.graphs = None
@@ -329,7 +336,7 @@ class DataParallelTrainStep:
         def update():
             if self.world > 1:
                 self.flat_grad.mul_(inv)
-            optimizer.step()
+            _opt_step(optimizer)
 
         def eager():
             loss = fwd_bwd()

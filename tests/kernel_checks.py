@@ -1967,3 +1967,56 @@ def check_c1_wgrad_nb(mix=True, B=2, S=(12, 20, 36), seed=0):
     res.append(_res(tag + ".dw_vs_fp64", relerr(dwf, w.grad), 6e-3))      # dy is rounded to bf16 on the way to the MFMA operand, as the stored tensor was
     res.append(_res(tag + ".db_vs_fp64", relerr(dbf, bb.grad), 6e-3))
     return res
+
+
+def check_fused_adam(seed=0):
+    """optim.fused_step (bpx_adam_step) against torch.optim.Adam / AdamW (fused, capturable) on the same tensors: parameters and both moments after
+    four steps, ragged sizes (1 ... 1.7 M elements, an unaligned view), lr as a device scalar that changes between steps; and the refusals."""
+    from biapy_amd import optim as O
+    res = []
+    sizes = [(16,), (1,), (16, 1, 3, 3, 3), (256, 256, 3, 3, 3), (5, 7), (48, 16, 1, 1, 1), (4099,)]
+    for cls, wd in ((torch.optim.AdamW, 1e-2), (torch.optim.Adam, 1e-3), (torch.optim.AdamW, 0.0)):
+        gen = torch.Generator().manual_seed(seed)
+        base = [torch.randn(*s, generator=gen) for s in sizes]
+        slab = torch.zeros(sum(b.numel() for b in base) + 3, device=DEV)          # gradients as (partly unaligned) views of one slab, as in training
+        pa = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+        pb = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+        oa = cls(pa, lr=torch.tensor(1e-2, device=DEV), weight_decay=wd, fused=True, capturable=True, betas=(0.9, 0.99))
+        ob = cls(pb, lr=torch.tensor(1e-2, device=DEV), weight_decay=wd, fused=True, capturable=True, betas=(0.9, 0.99))
+        used = []
+        for it in range(4):
+            off = 3 if it % 2 else 0
+            for a, b in zip(pa, pb):
+                gr = torch.randn(a.shape, generator=gen).to(DEV)
+                a.grad = gr.clone()
+                view = slab[off:off + a.numel()].view_as(a)
+                view.copy_(gr)
+                b.grad = view
+                off += a.numel()
+            oa.step()
+            used.append(O.fused_step(ob))
+            if not used[-1]:
+                ob.step()                                                           # the first step initialises the state: torch's own
+            for o in (oa, ob):
+                o.param_groups[0]["lr"].mul_(0.7)
+        torch.cuda.synchronize()
+        tag = f"fused_adam[{cls.__name__} wd={wd}]"
+        res.append(_res(tag + ".used_from_step_2", 0 if used == [False, True, True, True] else 1, 0, extra=str(used)))
+        worst = {"p": 0.0, "m": 0.0, "v": 0.0, "step": 0.0}
+        for a, b in zip(pa, pb):
+            sa, sb = oa.state[a], ob.state[b]
+            worst["p"] = max(worst["p"], relerr(b, a)); worst["m"] = max(worst["m"], relerr(sb["exp_avg"], sa["exp_avg"]))
+            worst["v"] = max(worst["v"], relerr(sb["exp_avg_sq"], sa["exp_avg_sq"]))
+            worst["step"] = max(worst["step"], abs(float(sa["step"]) - float(sb["step"])))
+        for k, v in worst.items():
+            res.append(_res(f"{tag}.{k}", v, 0 if k == "step" else 2e-6))
+    # refusals: nothing is touched, the caller runs torch's step
+    q = [torch.nn.Parameter(torch.randn(8, device=DEV))]
+    q[0].grad = torch.randn(8, device=DEV)
+    for name, o in (("sgd", torch.optim.SGD(q, lr=0.1)), ("not capturable", torch.optim.AdamW(q, lr=0.1)),
+                    ("amsgrad", torch.optim.AdamW(q, lr=0.1, amsgrad=True, capturable=True))):
+        o.step()
+        before = q[0].detach().clone()
+        took = O.fused_step(o)
+        res.append(_res(f"fused_adam.refuses[{name}]", 0 if (not took and torch.equal(before, q[0])) else 1, 0))
+    return res

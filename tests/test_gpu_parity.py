@@ -173,6 +173,12 @@ def test_first_layer_weight_gradient_with_folded_norm_backward(K, mix, S):
     _assert_all(K.check_c1_wgrad_nb(mix, 2, S))
 
 
+def test_adam_step_kernel_equals_torch_fused_adam(K):
+    """optim.fused_step / bpx_adam_step: the optimizer step of the graphed train steps == torch's fused Adam / AdamW on the optimizer's own state
+    tensors (train_engine.py:173-177 `optimizer.step()`), and it refuses what it does not reproduce."""
+    _assert_all(K.check_fused_adam())
+
+
 def test_fp16_raw_outputs_saturate_instead_of_overflowing(K):
     """conv results beyond the fp16 range are stored as +-65504, not +-inf; an fp16 network on raw 16-bit intensities stays finite."""
     _assert_all(K.check_f16_saturation())

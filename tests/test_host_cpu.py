@@ -573,3 +573,20 @@ def test_build_tta_spec_reproduces_the_reference(tta_spec_golden):
         T.build_tta_spec(["R_0", "B", "R_1"], 2)
     with pytest.raises(ValueError, match="nrays"):
         T.build_tta_spec(["R_0", "R_1"], 2, {"R": {"nrays": 4}})
+
+
+def test_fused_adam_step_refuses_what_it_does_not_reproduce():
+    """optim.fused_step touches nothing and answers False for host tensors, other optimizers and host-side step counters: the caller then
+    runs torch's own ``optimizer.step()`` (train_engine.py:173-177)."""
+    import torch
+    from biapy_amd import optim as O
+
+    p = [torch.nn.Parameter(torch.randn(8))]
+    p[0].grad = torch.randn(8)
+    for opt in (torch.optim.AdamW(p, lr=0.1), torch.optim.SGD(p, lr=0.1), torch.optim.Adam(p, lr=0.1, amsgrad=True)):
+        opt.step()
+        before = p[0].detach().clone()
+        assert O.fused_step(opt) is False
+        assert torch.equal(before, p[0])
+        O.step(opt)                                   # falls through to torch
+        assert not torch.equal(before, p[0])
