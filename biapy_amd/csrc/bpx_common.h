@@ -280,6 +280,8 @@ static inline size_t dtype_size(int dt) {
 // wgrad.hip: dw[ci*si + co*sj + tap*st] = sum over the `groups` partial slabs [groups][taps][Cin][Cout] (fixed order, no atomics) and
 // db[c] += sum of the rows [groups][ndb] (ndb = 0: Cout); may_defer: queued with the other weight-gradient reductions while the deferred mode is on
 namespace bpxred {
+bool defer_active();   // between bpx_wgrad_defer_begin and _flush on this host thread
+int reduce_rows(const char* fn, const float* rows, int groups, int64_t stride, int n, float* dst, hipStream_t s);   // dst[i] += sum_g rows[g * stride + i] (deferrable)
 int reduce_partials(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
                     const float* dbpart, float* db, int ndb, bool may_defer, hipStream_t s);
 // the same with a second destination db2 of the bias sums (bwd_fused.hip: the shortcut bias of a residual block)

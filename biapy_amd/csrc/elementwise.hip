@@ -248,6 +248,54 @@ __global__ void __launch_bounds__(1024) norm_bwd_finalize_kernel(const float* __
   }
 }
 
+// Deferred form (round 4): one block per (channel block, SAMPLE) instead of one per channel block walking the samples - the 768-4096 partial rows of
+// a sample are a latency chain, four of them in one block cost 8.6 us per launch (17 launches per cfg-2 step).  What needs every sample, dgamma /
+// dbeta, leaves the kernel: the block overwrites the first partial row of ITS sample (its own columns; nobody else reads them) with the sample's
+// totals as floats - [S2 total (the dgamma term) | S1 total (the dbeta term)] - and the sum over the samples, in sample order, is queued with the
+// step's weight-gradient reductions (bpxred::reduce_rows; the caller keeps red_part alive until the flush).
+__global__ void __launch_bounds__(1024) norm_bwd_finalize_ps_kernel(float* __restrict__ red_part, int tiles, int tstride, int C, double inv_count,
+                                                                   const bpx_norm_rec* __restrict__ rec, const float* __restrict__ gamma, int cpg, int cb,
+                                                                   bpx_nbwd_coef* __restrict__ coef) {
+  __shared__ double red[2][1024];
+  const int lanes = 1024 / cb;
+  const int n = blockIdx.y, c0 = blockIdx.x * cb;
+  const int c = threadIdx.x % cb, tl = threadIdx.x / cb;
+  double s1 = 0.0, s2 = 0.0;
+  float* pn = red_part + (size_t)n * tiles * 2 * C;
+  if (c0 + c < C) tile_sums(pn + c0 + c, C, (tiles + tstride - 1) / tstride, (size_t)tstride * 2 * C, tl, lanes, s1, s2);
+  lane_reduce(red, cb, lanes, s1, s2);                    // red[0][0 .. cb) = S1, red[1][0 .. cb) = S2 of this sample; every partial row has been read
+  if ((int)threadIdx.x < cb && c0 + (int)threadIdx.x < C) {
+    const int cl = threadIdx.x, cc = c0 + cl;
+    const double S1 = red[0][cl], S2 = red[1][cl];
+    const bpx_norm_rec r = rec[(size_t)n * C + cc];
+    const double ga = gamma ? (double)gamma[cc] : 1.0;
+    double m1, m2;
+    if (cpg == 1) {
+      m1 = ga * S1 * inv_count;
+      m2 = ga * S2 * inv_count;
+    } else {
+      const int gb = (cl / cpg) * cpg;
+      double a1 = 0.0, a2 = 0.0;
+      for (int q = 0; q < cpg; ++q) {
+        const double gq = gamma ? (double)gamma[c0 + gb + q] : 1.0;
+        a1 += gq * red[0][gb + q];
+        a2 += gq * red[1][gb + q];
+      }
+      m1 = a1 * inv_count / cpg;
+      m2 = a2 * inv_count / cpg;
+    }
+    const double rs = (double)r.rstd;
+    bpx_nbwd_coef k;
+    k.a = (float)(ga * rs);
+    k.b = (float)(-rs * rs * m2);
+    k.c0 = (float)(-rs * m1 + rs * rs * (double)r.mean * m2);
+    k.pad = 0.f;
+    coef[(size_t)n * C + cc] = k;
+    pn[cc] = (float)S2;                                   // first partial row of the sample: [dgamma terms | dbeta terms]
+    pn[C + cc] = (float)S1;
+  }
+}
+
 // ---- GroupNorm with ANY group width, over a tensor that may be the concatenation of two producers' outputs (round 3) -------------------
 // The decoder's first norm sees torch.cat([up, skip], 1): with 8 groups over 3 fm channels a group is 6 / 12 / 24 / 48 channels wide and one of
 // them straddles the concat boundary, i.e. draws its statistics from the partial sums of TWO producer kernels.  Two small steps replace
@@ -1339,22 +1387,45 @@ extern "C" int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, 
   return 0;
 }
 
-extern "C" int bpx_norm_bwd_finalize(float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
-                                     const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d,
-                                     bpx_stream_t stream) {
-  const char* fn = "bpx_norm_bwd_finalize";
+static int norm_bwd_finalize_impl(const char* fn, bool deferred, float* red_part_d, int N, int tiles, int C, int64_t count_per_channel,
+                                  const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d,
+                                  bpx_stream_t stream) {
   BPX_CHECK(red_part_d && rec_d && coef_d, "%s: null pointer", fn);
   BPX_CHECK(groups >= 1 && C % groups == 0, "%s: groups %d must divide C %d", fn, groups, C);
   const int cpg = C / groups;
   BPX_CHECK(cpg == 1 || 16 % cpg == 0 || cpg == 32 || cpg == 64, "%s: channels per group %d unsupported (1, 2, 4, 8, 16, 32, 64)", fn, cpg);
   const int cb = cpg > 16 ? cpg : 16;
   const int tstride = compact_stats(red_part_d, N, tiles, C, (hipStream_t)stream);     // consumes the partials
+  if (deferred && bpxred::defer_active() && N > 1) {
+    dim3 grid((unsigned)cdiv(C, cb), (unsigned)N);
+    norm_bwd_finalize_ps_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>(red_part_d, tiles, tstride, C, 1.0 / (double)count_per_channel, rec_d, gamma_d, cpg, cb, coef_d);
+    BPX_LAUNCH_CHECK(fn);
+    const int64_t stride = (int64_t)tiles * 2 * C;
+    if (dgamma_d && dbeta_d == dgamma_d + C) return bpxred::reduce_rows(fn, red_part_d, N, stride, 2 * C, dgamma_d, (hipStream_t)stream);   // adjacent in the gradient slab: one job
+    if (dgamma_d && bpxred::reduce_rows(fn, red_part_d, N, stride, C, dgamma_d, (hipStream_t)stream) != 0) return 1;
+    if (dbeta_d && bpxred::reduce_rows(fn, red_part_d + C, N, stride, C, dbeta_d, (hipStream_t)stream) != 0) return 1;
+    return 0;
+  }
   int NB = 1;                                                                          // samples per pass: keep >= 8 tile lanes per sample
   while (NB * 2 <= N && NB * 2 <= 16 && 1024 / (cb * NB * 2) >= 8) NB *= 2;
   norm_bwd_finalize_kernel<<<(unsigned)cdiv(C, cb), 1024, 0, (hipStream_t)stream>>>(red_part_d, N, tiles, tstride, C, 1.0 / (double)count_per_channel,
                                                                                    rec_d, gamma_d, dgamma_d, dbeta_d, cpg, cb, NB, coef_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;
+}
+
+extern "C" int bpx_norm_bwd_finalize(float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
+                                     const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d,
+                                     bpx_stream_t stream) {
+  return norm_bwd_finalize_impl("bpx_norm_bwd_finalize", false, red_part_d, N, tiles, C, count_per_channel, rec_d, gamma_d, dgamma_d, dbeta_d, groups, coef_d, stream);
+}
+// The same between bpx_wgrad_defer_begin and bpx_wgrad_defer_flush: coef_d is complete when the call's kernel is, dgamma / dbeta take their sums at
+// the flush, and red_part_d must stay untouched until then.  Outside a deferred window it is bpx_norm_bwd_finalize.
+extern "C" int bpx_norm_bwd_finalize_deferred(float* red_part_d, int N, int tiles, int C, int64_t count_per_channel, const bpx_norm_rec* rec_d,
+                                              const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups, bpx_nbwd_coef* coef_d,
+                                              bpx_stream_t stream) {
+  return norm_bwd_finalize_impl("bpx_norm_bwd_finalize_deferred", true, red_part_d, N, tiles, C, count_per_channel, rec_d, gamma_d, dgamma_d, dbeta_d, groups, coef_d,
+                                stream);
 }
 
 

@@ -968,7 +968,7 @@ inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
 // 1024 threads = 32 consecutive elements x 32 group lanes, four loads in flight per thread: the smallest dW has only 6912
 // elements (216 blocks) against up to 1024 partial slabs, so the kernel is a latency chain per block - with 8 group lanes
 // and two loads in flight it took ~70 us for the 16->16 layers, more than a quarter of their MFMA kernel.
-struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; const float* dbpart; float* db; int ndb; float* db2 = nullptr; };   // ndb: length of a bias row (0 = Cout); db2: a second tensor that takes the same sums
+struct ReduceJob { const float* part; float* dw; int groups, taps, Cin, Cout; int64_t si, sj, st, off; const float* dbpart; float* db; int ndb; float* db2 = nullptr; int64_t db_stride = 0; };   // ndb: length of a bias row (0 = Cout); db2: a second tensor that takes the same sums; db_stride: floats between the bias rows of consecutive groups (0 = ndb)
 
 // 1024 threads = EL consecutive elements x GL group lanes (GL = reduce_glanes(groups), EL = 1024 / GL), up to four loads in
 // flight per thread; lane sums are combined in a fixed order, so the result does not depend on scheduling.
@@ -994,7 +994,7 @@ __device__ __forceinline__ void wgrad_reduce_block(const ReduceJob& j, int block
   const int64_t idx = ((int64_t)block * EL + e) * 4;
   // elements idx .. idx+3 of slab g: dW entries, or (idx >= total) column sums of the bias-gradient partials [groups][ndb]
   const float* __restrict__ src = idx < total ? part + idx : j.dbpart + (idx - total);
-  const int64_t stride = idx < total ? total : ndb;
+  const int64_t stride = idx < total ? total : (j.db_stride ? j.db_stride : ndb);
   const int nval = idx >= all ? 0 : (int)(all - idx < 4 ? all - idx : 4);
   const bool vec = nval == 4 && (stride & 3) == 0 && (((uintptr_t)src) & 15) == 0;
   f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -1053,6 +1053,161 @@ int finish_wgrad(const char* fn, const ReduceJob& j, hipStream_t s) {
   wgrad_reduce_kernel<<<reduce_blocks(j), 1024, 0, s>>>(j);
   BPX_LAUNCH_CHECK(fn);
   return 0;
+}
+
+// ---- k = 1 weight gradient of a RAW input (the residual blocks' 1x1x1 shortcut: blocks.py ResConvBlock `shortcut(x)`) as a stream -----------------
+//   dW[ci][co] = sum_v x[v][ci] * dy[v][co]
+// has no halo, no prologue and 0.4 FLOP per byte: it is a reduction over two streams.  The generic kernel above walks it in 256-voxel tiles with a
+// barrier pair per tile and register-staged loads (3.7 TB/s for x 48 . dy 16 at 128^3, 0.29 ms of the cfg-2 step).  Here: persistent workgroups, the
+// two operands of a TV-voxel block brought in by `buffer_load ... lds` through a ring of RING stages (RING - 1 blocks in flight per workgroup,
+// ~96 KB per CU), one barrier per block; wave w multiplies the block's 32-voxel K chunks w, w + 4, ..; the four waves' accumulators meet once, at
+// the end.  x may be fp16 (BPX_MIX16: converted to bf16 after the transposing LDS read) and chunk-planar.
+struct K1Params {
+  const void* x; int x_ld; int x_cs; const void* dy; int dy_ld;
+  int Cin, Cout; int64_t voxels; int nblocks; int groups; float* part;
+};
+__host__ __device__ constexpr int k1_ring(int stage_bytes) { return 4 * stage_bytes <= 131072 ? 4 : 3 * stage_bytes <= 131072 ? 3 : 2; }
+__host__ __device__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n), the other counters open
+
+template <int MC, int NS, int TV, bool XF16>
+__global__ void __launch_bounds__(256) wgrad_k1_dma_kernel(const K1Params p) {
+  constexpr int VB = 32, SUBS = TV / 32;                          // a DMA instruction moves 32 voxels x 32 bytes (lane: voxel l >> 1, half l & 1)
+  constexpr int A_BYTES = MC * TV * VB, STAGE = (MC + NS) * TV * VB, RING = k1_ring(STAGE);
+  constexpr int NI = (MC + NS) * SUBS;                            // instructions per stage, instruction q belongs to wave q & 3
+  static_assert(NI % 4 == 0, "every wave issues the same number of DMA instructions per stage");
+  constexpr int IPW = NI / 4;
+  static_assert((RING - 2) * IPW < 64, "vmcnt range");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * STAGE];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)0x80000000u, 0x00020000);
+  const uint32_t xvb = (uint32_t)p.x_ld * 2u, gvb = (uint32_t)p.dy_ld * 2u, xcb = (uint32_t)p.x_cs * 2u;
+  const uint32_t lane_v = (uint32_t)(lane >> 1), lane_h = (uint32_t)(lane & 1) * 16u;
+  const int64_t voxels = p.voxels;
+  const int groups = p.groups, nblocks = p.nblocks;
+
+  auto issue = [=](int blk, int slot) {
+    const int64_t v0 = (int64_t)blk * TV;
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const int q = wave + 4 * k;                                 // (operand chunk, 32-voxel run) of this instruction
+      const int ch = q / SUBS, sub = q % SUBS;
+      const int64_t v = v0 + sub * 32 + lane_v;
+      const bool in = v < voxels;
+      const uint32_t vv = (uint32_t)v;
+      unsigned char* dst = const_cast<unsigned char*>(smem) + slot * STAGE + ch * TV * VB + sub * 1024;
+      if (ch < MC) {
+        const uint32_t off = in ? vv * xvb + (uint32_t)ch * xcb + lane_h : 0x80000000u;      // out of range: the DMA writes zeros
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+      } else {
+        const uint32_t off = in ? vv * gvb + (uint32_t)(ch - MC) * 32u + lane_h : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4_t acc[MC][NS];
+#pragma unroll
+  for (int c = 0; c < MC; ++c)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[c][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int a_base = (g * 8 + (i >> 2)) * VB + (i & 3) * 8;      // lane (i, g): voxels 8g .. 8g + 7 of a K chunk through ds_read_b64_tr_b16
+
+  const int nst = grp < nblocks ? (nblocks - grp + groups - 1) / groups : 0;    // blocks grp, grp + groups, ..
+#pragma unroll
+  for (int s = 0; s < RING - 1; ++s)
+    if (s < nst) issue(grp + s * groups, s);
+  for (int s = 0; s < nst; ++s) {
+    // this wave's share of block s has landed when at most the shares of the later blocks in flight are outstanding (VMEM returns in order)
+    const int later = nst - 1 - s < RING - 2 ? nst - 1 - s : RING - 2;
+    if (later >= 2 && RING >= 4) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * IPW));
+    else if (later == 1 && RING >= 3) __builtin_amdgcn_s_waitcnt(vmcnt_imm(IPW));
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    __syncthreads();                                              // every wave's share is in LDS; slot (s - 1) % RING is no longer read
+    if (s + RING - 1 < nst) issue(grp + (s + RING - 1) * groups, (s + RING - 1) % RING);
+    const unsigned char* st = smem + (s % RING) * STAGE;
+#pragma unroll
+    for (int kc0 = 0; kc0 < SUBS; kc0 += 4) {
+      const int kc = kc0 + wave;
+      if (SUBS % 4 != 0 && kc >= SUBS) break;
+      u32x4_t gf[NS];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const unsigned char* q = st + A_BYTES + ns * TV * VB + a_base + kc * 32 * VB;
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+        const u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VB)));
+        gf[ns] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const unsigned char* q = st + c * TV * VB + a_base + kc * 32 * VB;
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+        const u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VB)));
+        u32x4_t af = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+        if (XF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) af[e] = cvt_pk_bf16(lo16<f16_t>(af[e]), hi16<f16_t>(af[e]));
+        }
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[c][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[ns]), acc[c][ns], 0, 0, 0);
+      }
+    }
+  }
+  // the four waves' sums (wave order: fixed) -> this workgroup's slab [Cin][Cout]
+  __syncthreads();
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);                // [wave][MC][NS][64 lanes]
+  static_assert(4 * MC * NS * 64 * 16 <= RING * STAGE, "reduction scratch");
+#pragma unroll
+  for (int c = 0; c < MC; ++c)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) red[((wave * MC + c) * NS + ns) * 64 + lane] = acc[c][ns];
+  __syncthreads();
+  float* pp = p.part + (size_t)grp * p.Cin * p.Cout;
+  for (int q = tid; q < MC * NS * 64; q += 256) {
+    const int ln = q & 63, cn = q >> 6, c = cn / NS, ns = cn % NS;
+    const f32x4_t a = (red[((0 * MC + c) * NS + ns) * 64 + ln] + red[((1 * MC + c) * NS + ns) * 64 + ln]) +
+                      (red[((2 * MC + c) * NS + ns) * 64 + ln] + red[((3 * MC + c) * NS + ns) * 64 + ln]);
+    const int gi = ln >> 4, ii = ln & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pp[(size_t)(c * 16 + 4 * gi + r) * p.Cout + ns * 16 + ii] = a[r];
+  }
+}
+
+int g_k1_dma = 1;     // bpx_debug_set_wgrad_k1: 0 = the generic kernel everywhere
+// instance for (Cin / 16, Cout / 16), or 0: the cfg-2 shortcuts at the 128^3 / 64^3 levels (48 . 16, 96 . 32, 16 . 32)
+inline int k1_instance(int mc, int ns) { return (mc == 3 && ns == 1) ? 1 : (mc == 6 && ns == 2) ? 2 : (mc == 1 && ns == 2) ? 3 : 0; }
+inline int k1_tv(int inst) { return inst == 2 ? 128 : 256; }
+inline bool k1_dma_ok(int dtype, const WgradParams& p, int taps) {
+  if (!g_k1_dma || dtype != BPX_BF16 || taps != 1 || p.in_norm != nullptr || p.db != nullptr || p.dy_vs != 1 || p.dy_oz || p.dy_oy || p.dy_ox) return false;
+  if (p.Cin % 16 || p.Cout % 16 || !k1_instance(p.Cin / 16, p.Cout / 16)) return false;
+  const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
+  if (vox < 65536) return false;                                 // small levels: nothing to stream
+  const int64_t xspan = (int64_t)(p.Cin / 16 - 1) * p.x_cs * 2 + vox * p.x_ld * 2, gspan = vox * (int64_t)p.dy_ld * 2;
+  return xspan < (1ll << 31) && gspan < (1ll << 31) && (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0 && (p.x_ld & 7) == 0 && (p.dy_ld & 7) == 0 && (p.x_cs & 7) == 0;
+}
+inline int k1_groups(int64_t vox, int inst) { return (int)std::min<int64_t>(256, cdiv64(vox, k1_tv(inst))); }   // one persistent workgroup per CU (the ring holds ~128 KB)
+
+int launch_wgrad_k1_dma(const WgradParams& w, int groups, hipStream_t s) {
+  const int inst = k1_instance(w.Cin / 16, w.Cout / 16);
+  K1Params p{};
+  p.x = w.x; p.x_ld = w.x_ld; p.x_cs = w.x_cs; p.dy = w.dy; p.dy_ld = w.dy_ld; p.Cin = w.Cin; p.Cout = w.Cout;
+  p.voxels = (int64_t)w.N * w.D * w.H * w.W;
+  p.nblocks = (int)cdiv64(p.voxels, k1_tv(inst));
+  p.groups = groups; p.part = w.part;
+#define K1(I, MC_, NS_, TV_)                                                                                      \
+  if (inst == I) {                                                                                                \
+    if (w.x_f16) wgrad_k1_dma_kernel<MC_, NS_, TV_, true><<<groups, 256, 0, s>>>(p);                              \
+    else wgrad_k1_dma_kernel<MC_, NS_, TV_, false><<<groups, 256, 0, s>>>(p);                                     \
+    return 0;                                                                                                     \
+  }
+  K1(1, 3, 1, 256) K1(2, 6, 2, 128) K1(3, 1, 2, 256)
+#undef K1
+  return 1;
 }
 
 int g_cap_pct = 100;   // partial-slab caps of the two plans below in percent (bpx_debug_set_wgrad_cap)
@@ -1188,6 +1343,13 @@ int run_wgrad(const char* fn, int dtype, WgradParams& p, int taps, void* ws, int
   if (taps == 27) need = std::max(need, (int64_t)sdm_plan(p.N, p.D, p.H, p.W, p.Cin, p.Cout).groups * slab);
   BPX_CHECK(ws != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   p.part = reinterpret_cast<float*>(ws);
+  if (k1_dma_ok(dtype, p, taps)) {   // raw-input k = 1 (the blocks' shortcut) at the large levels: the streaming kernel
+    const int groups = k1_groups((int64_t)p.N * p.D * p.H * p.W, k1_instance(p.Cin / 16, p.Cout / 16));
+    BPX_CHECK(ws_bytes >= (int64_t)groups * p.Cin * p.Cout * 4, "%s: workspace too small (%lld bytes)", fn, (long long)ws_bytes);
+    BPX_CHECK(launch_wgrad_k1_dma(p, groups, s) == 0, "%s: no streaming instance", fn);
+    BPX_LAUNCH_CHECK(fn);
+    return finish_wgrad(fn, ReduceJob{p.part, p.dw, groups, 1, p.Cin, p.Cout, p.si, p.sj, p.st, p.off, nullptr, nullptr, 0, nullptr}, s);
+  }
   int rc;
   const int64_t vox = (int64_t)p.N * p.D * p.H * p.W;
   const bool sd_ok = dtype == BPX_BF16 && taps == 27 && p.dy_vs == 1 && c.tx == 16 && c.tz == 4 && g_use_tr != 0 &&
@@ -1211,6 +1373,12 @@ int reduce_partials(const char* fn, const float* part, float* dw, int groups, in
                     const float* dbpart, float* db, int ndb, bool may_defer, hipStream_t s) {
   return reduce_partials2(fn, part, dw, groups, taps, Cin, Cout, si, sj, st, dbpart, db, nullptr, ndb, may_defer, s);
 }
+bool defer_active() { return t_defer.active; }
+// dst[i] += sum over g < groups of rows[g * stride + i], i < n, in group order; queued like the others while the deferred mode is on
+int reduce_rows(const char* fn, const float* rows, int groups, int64_t stride, int n, float* dst, hipStream_t s) {
+  ReduceJob j{nullptr, nullptr, groups, 0, 0, n, 0, 0, 0, 0, rows, dst, n, nullptr, stride};
+  return finish_wgrad(fn, j, s);
+}
 int reduce_partials2(const char* fn, const float* part, float* dw, int groups, int taps, int Cin, int Cout, int64_t si, int64_t sj, int64_t st,
                      const float* dbpart, float* db, float* db2, int ndb, bool may_defer, hipStream_t s) {
   const ReduceJob j{part, dw, groups, taps, Cin, Cout, si, sj, st, 0, db ? dbpart : nullptr, db, ndb, db ? db2 : nullptr};
@@ -1226,6 +1394,7 @@ extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Ci
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, taps, false);  // small tiles give the larger group count: an upper bound
   int64_t groups = c.groups;
   if (taps == 27) groups = std::max<int64_t>(groups, sdm_plan(N, D, H, W, Cin, Cout).groups);
+  if (taps == 1) groups = std::max<int64_t>(groups, 256);   // the streaming k = 1 kernel: one slab per CU
   return groups * ((int64_t)taps * Cin + 1) * Cout * 4;   // per group: the dW partials and one row of bias-gradient column sums
 }
 extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int sz, int Cin, int Cout) {
@@ -1325,6 +1494,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   return 0;
 }
 
+extern "C" int bpx_debug_set_wgrad_k1(int on) { g_k1_dma = on; return 0; }
 extern "C" int bpx_debug_set_wgrad_cap(int percent) { g_cap_pct = percent > 0 ? percent : 100; return 0; }
 
 // ---- deferred reductions -------------------------------------------------------------------------------------------------

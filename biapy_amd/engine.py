@@ -183,6 +183,10 @@ class _Stats:
         L.check(lib.bpx_groupnorm_finalize(sums.data_ptr(), B, Ct, count, gamma.data_ptr(), beta.data_ptr(), EPS, groups, rec.data_ptr(), st))
 
 
+# InstanceNorm-backward finalize of the residual blocks: per-sample blocks + dgamma / dbeta with the deferred reductions (BPX_NBF_DEFER=0: the plain entry)
+_NBF = lib.bpx_norm_bwd_finalize_deferred if os.environ.get("BPX_NBF_DEFER", "1") != "0" else lib.bpx_norm_bwd_finalize
+
+
 def _recs(B, C, dev):
     return torch.empty((B, C, 4), dtype=torch.float32, device=dev)
 
@@ -640,8 +644,10 @@ class ResUNetEngine:
             L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dOut, w2t.data_ptr(), L.tview(blk.h), blk.rec_h.data_ptr(), self.act,
                                          L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
-        L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
-                                          G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), self.cfg.gn_groups or C1, coef.data_ptr(), st))
+        # (deferred form: dgamma / dbeta arrive with the flush of the weight-gradient reductions; `red` holds their per-sample terms until then)
+        self._keep.append(red)
+        L.check(_NBF(red.data_ptr(), B, tiles, C1, vox, blk.rec_h.data_ptr(), P[k["g1"]].data_ptr(),
+                                                   G[k["g1"]].data_ptr(), G[k["be1"]].data_ptr(), self.cfg.gn_groups or C1, coef.data_ptr(), st))
         first_c1 = blk.first and self.cfg.in_ch == 1
         if first_c1 and lib.bpx_conv3d_c1_wgrad_nb_supported(self.bdt, W) and os.environ.get("BPX_C1_NB", "1") != "0":
             # the first layer has no input gradient: its weight gradient is the only reader of dH = a * g1 + b * h + c0, which is therefore formed
@@ -689,8 +695,9 @@ class ResUNetEngine:
                 L.check(lib.bpx_groupnorm_bwd_finalize(sums0.data_ptr(), B, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(), G[k["g0"]].data_ptr(),
                                                        G[k["be0"]].data_ptr(), gng, coef0.data_ptr(), st))
             else:
-                L.check(lib.bpx_norm_bwd_finalize(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
-                                                  G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), gng or Cx, coef0.data_ptr(), st))
+                self._keep.append(red0)
+                L.check(_NBF(red0.data_ptr(), B, tiles0, Cx, vox, blk.rec_x.data_ptr(), P[k["g0"]].data_ptr(),
+                                                           G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), gng or Cx, coef0.data_ptr(), st))
             if isinstance(dx_out, tuple):   # decoder block: the gradient of the concatenated input leaves as its (up, skip) parts
                 assert dx_extra is None
                 L.check(lib.bpx_conv1x1_fwd_split(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),

@@ -52,6 +52,7 @@ int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test / A-B hook of the bf16 3x3x3 conv schedule: 0 = automatic, 4 = always the double-buffered kernel, 5 = always the lean persistent one */
 int bpx_debug_set_conv_occ(int wg_per_cu); /* test / A-B hook: persistent workgroups per CU of the lean bf16 conv kernel (0 = built-in table) */
+int bpx_debug_set_wgrad_k1(int on); /* test / A-B hook: 1 (default) = the streaming kernel for the k = 1 weight gradients of raw inputs at the large levels, 0 = the generic tile kernel */
 int bpx_debug_set_wgrad_cap(int percent); /* test / A-B hook: size cap of a conv layer's weight-gradient partial slabs in percent of the default (~26 / 64 MB) */
 int bpx_debug_set_tile_order(int bits); /* test / A-B hook: bit 0 = XCD-contiguous y-strip tile walk of the windowed shift-dy wgrad kernel (default 1; 0 = tile = group + k * groups as until round 3) */
 int bpx_debug_set_tiling_scalar(int on); /* test / A-B hook: 1 = crop / merge through the element-per-thread kernels instead of the 16-byte row kernels */
@@ -304,6 +305,13 @@ int bpx_tensor_stats_tiles(int64_t voxels);
  * (sums over the samples in a fixed order by one thread per channel: deterministic).  Channels per group: 1, 2, 4, 8, 16, 32, 64;
  * count_per_channel = voxels per sample. */
 int bpx_norm_bwd_finalize(float* red_part_d /* consumed, see bpx_norm_finalize */, int N, int tiles, int C, int64_t count_per_channel,
+                          const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups,
+                          bpx_nbwd_coef* coef_d, bpx_stream_t stream);
+/* The same inside a bpx_wgrad_defer_begin / _flush window, one block per (channel block, sample): coef_d is complete when the call's kernel is; the
+ * sums over the samples that dgamma / dbeta need are queued with the window's weight-gradient reductions and arrive at the flush (sample order,
+ * fixed: bit-reproducible).  The first partial row of every sample is overwritten with that sample's totals: red_part_d must stay untouched
+ * until the flush.  Outside a window (or for N = 1) it is bpx_norm_bwd_finalize. */
+int bpx_norm_bwd_finalize_deferred(float* red_part_d /* consumed, see bpx_norm_finalize */, int N, int tiles, int C, int64_t count_per_channel,
                           const bpx_norm_rec* rec_d, const float* gamma_d, float* dgamma_d, float* dbeta_d, int groups,
                           bpx_nbwd_coef* coef_d, bpx_stream_t stream);
 /* dx = a*g + b*t + c0 (+ addend): applies the coefficients above elementwise. dx may alias g. */

@@ -96,6 +96,22 @@ def main():
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * 27 * cin * cout
             print(f"conv_dgrad {S:4d}^3 dy{cout:4d}->g{cin:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s")
+    if a.what == "k1":
+        # k = 1 weight gradients of raw inputs (the blocks' shortcuts) in the mixed mode: streaming kernel vs the generic tile kernel
+        for (S, cin, cout, planar) in [(128, 48, 16, True), (64, 96, 32, True), (64, 16, 32, False)]:
+            xx = torch.randn(B, S, S, S, cin, device=DEV).to(torch.float16)
+            xp = L.Planar(B, (S, S, S), cin, torch.float16, DEV).copy_from_dense(xx) if planar else None
+            xv = L.tview(xp) if planar else L.tview(xx)
+            dy = torch.randn(B, S, S, S, cout, device=DEV).to(torch.bfloat16)
+            dw = torch.empty(cout, cin, 1, 1, 1, device=DEV)
+            ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, S, S, S, cin, cout, 1)), dtype=torch.uint8, device=DEV)
+            f = lambda: L.check(lib.bpx_conv3d_wgrad(L.MIX16, B, S, S, S, xv, None, 0, L.tview(dy), 1, dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
+            by = B * S ** 3 * (cin + cout) * 2
+            for on in (0, 1):
+                lib.bpx_debug_set_wgrad_k1(on)
+                ms = timeit(f, a.reps)
+                print(f"wgrad k=1 {S:4d}^3 {cin:3d}.{cout:3d} {'stream' if on else 'tile  '}: {ms * 1e3:8.1f} us (+ reduce) {by / ms / 1e9:7.2f} TB/s")
+        return
     if a.what == "prologue":
         # VERDICT r3 next #5 ("forward prologue diet"): level-0 forward convs with the fused normalise + ELU prologue, against a streaming pass
         # that materialises a = ELU(scale * x + shift) once (bpx_norm_act_fwd) followed by the same conv WITHOUT a prologue.
@@ -148,7 +164,8 @@ def main():
         for (S, ct, cdy, planar) in [(128, 16, 16, False), (128, 48, 16, True), (64, 16, 16, False), (64, 32, 32, False), (64, 96, 32, True), (64, 16, 32, False)]:
             dy = torch.randn(B, S, S, S, cdy, device=DEV).to(torch.bfloat16)
             tt = torch.randn(B, S, S, S, ct, device=DEV).to(torch.float16)
-            tv = L.tview(L.Planar(B, (S, S, S), ct, torch.float16, DEV).copy_from_dense(tt)) if planar else L.tview(tt)
+            tp = L.Planar(B, (S, S, S), ct, torch.float16, DEV).copy_from_dense(tt) if planar else None   # (kept alive: tview holds only the address)
+            tv = L.tview(tp) if planar else L.tview(tt)
             g = torch.empty(B, S, S, S, ct, device=DEV, dtype=torch.bfloat16)
             n = lib.bpx_packed_weight_elems(L.PK_K3_T, ct, cdy, L.MIX16)
             wpt = torch.empty(n, dtype=torch.bfloat16, device=DEV)

@@ -2020,3 +2020,77 @@ def check_fused_adam(seed=0):
         took = O.fused_step(o)
         res.append(_res(f"fused_adam.refuses[{name}]", 0 if (not took and torch.equal(before, q[0])) else 1, 0))
     return res
+
+
+def check_norm_bwd_finalize_deferred(N=4, tiles=768, Cc=16, groups=None, seed=0):
+    """bpx_norm_bwd_finalize_deferred inside a bpx_wgrad_defer_begin / _flush window (one block per sample, dgamma / dbeta summed at the flush)
+    against bpx_norm_bwd_finalize and against the fp64 formulas; bit-reproducible; outside a window it is the plain entry."""
+    gen = torch.Generator().manual_seed(seed)
+    part = torch.randn(N, tiles, 2, Cc, generator=gen)
+    rec = make_recs(N, Cc, seed + 1)[0]
+    gamma = torch.randn(Cc, generator=gen)
+    count = 4096
+    G = groups or Cc
+    res = []
+    tag = f"norm_bwd_finalize_deferred[N{N} tiles{tiles} C{Cc} g{G}]"
+
+    def run(deferred, window):
+        pd = part.to(DEV).clone()
+        slab = torch.zeros(2 * Cc, device=DEV)                       # dgamma | dbeta adjacent, as in the engine's gradient slab
+        coef = torch.zeros(N, Cc, 4, device=DEV)
+        if window:
+            L.check(lib.bpx_wgrad_defer_begin())
+        fn = lib.bpx_norm_bwd_finalize_deferred if deferred else lib.bpx_norm_bwd_finalize
+        L.check(fn(pd.data_ptr(), N, tiles, Cc, count, rec.to(DEV).data_ptr(), gamma.to(DEV).data_ptr(), slab.data_ptr(), slab[Cc:].data_ptr(), G, coef.data_ptr(),
+                   L.stream_ptr()))
+        if window:
+            L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
+        torch.cuda.synchronize()
+        return coef.cpu(), slab.cpu()
+
+    c0, s0 = run(False, False)
+    c1, s1 = run(True, True)
+    c2, s2 = run(True, True)
+    c3, s3 = run(True, False)
+    res.append(_res(tag + ".coef_vs_plain", relerr(c1[..., :3], c0[..., :3]), 2e-6))
+    res.append(_res(tag + ".dgamma_dbeta_vs_plain", relerr(s1, s0), 2e-6))
+    res.append(_res(tag + ".run_to_run_bits", 0 if torch.equal(c1, c2) and torch.equal(s1, s2) else 1, 0))
+    res.append(_res(tag + ".outside_a_window_is_the_plain_entry", 0 if torch.equal(c3, c0) and torch.equal(s3, s0) else 1, 0))
+    S = part.double().sum(1)                                          # (N, 2, C)
+    res.append(_res(tag + ".dbeta_fp64", relerr(s1[Cc:], S[:, 0].sum(0)), 1e-5))
+    res.append(_res(tag + ".dgamma_fp64", relerr(s1[:Cc], S[:, 1].sum(0)), 1e-5))
+    return res
+
+
+def check_wgrad_k1_stream(mix=True, B=2, S=(32, 32, 32), Cin=48, Cout=16, planar=False, seed=0):
+    """The streaming k = 1 weight gradient of a raw input (the residual blocks' shortcut at the 128^3 / 64^3 levels): against the fp64 sum, against
+    the generic tile kernel (bpx_debug_set_wgrad_k1(0)), run to run bits; fp16 x (mixed mode) and chunk-planar x (the decoder's concat buffer)."""
+    D, H, W = S
+    gen = torch.Generator().manual_seed(seed)
+    xdt = torch.float16 if mix else torch.bfloat16
+    xq = torch.randn(B, D, H, W, Cin, generator=gen).to(xdt)
+    dyq = torch.randn(B, D, H, W, Cout, generator=gen).to(torch.bfloat16)
+    ref = torch.einsum("bdhwi,bdhwo->oi", xq.double(), dyq.double())
+    dt = L.MIX16 if mix else L.BF16
+    xd = xq.to(DEV)
+    xp = L.Planar(B, S, Cin, xdt, DEV).copy_from_dense(xd) if planar else None      # (kept alive: tview holds only the address)
+    xv = L.tview(xp) if planar else L.tview(xd)
+    dyd = dyq.to(DEV)
+    ws = torch.empty(max(1, lib.bpx_conv3d_wgrad_workspace(B, D, H, W, Cin, Cout, 1)), dtype=torch.uint8, device=DEV)
+
+    def run():
+        dw = torch.full((Cout, Cin, 1, 1, 1), 7.0, dtype=torch.float32, device=DEV)
+        L.check(lib.bpx_conv3d_wgrad(dt, B, D, H, W, xv, None, 0, L.tview(dyd), 1, dw.data_ptr(), None, ws.data_ptr(), ws.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return dw.view(Cout, Cin)
+
+    tag = f"wgrad_k1_stream[{'mix' if mix else 'bf16'} B{B} {S} {Cin}.{Cout} planar={int(planar)}]"
+    a, b = run(), run()
+    lib.bpx_debug_set_wgrad_k1(0)
+    try:
+        c = run()
+    finally:
+        lib.bpx_debug_set_wgrad_k1(1)
+    # bf16 MFMA operands: in the mixed mode x is rounded fp16 -> bf16 on the way in (both kernels), so the fp64 sum of the fp16 values is ~2^-9 away
+    return [_res(tag + ".vs_fp64", relerr(a, ref), 4e-3 if mix else 1e-4), _res(tag + ".vs_tile_kernel", relerr(a, c), 1e-4),
+            _res(tag + ".run_to_run_bits", 0 if torch.equal(a, b) else 1, 0)]

@@ -173,6 +173,20 @@ def test_first_layer_weight_gradient_with_folded_norm_backward(K, mix, S):
     _assert_all(K.check_c1_wgrad_nb(mix, 2, S))
 
 
+@pytest.mark.parametrize("N,tiles,C,groups", [(4, 768, 16, None), (3, 5000, 48, None), (2, 64, 128, 8), (4, 1, 32, None)], ids=["fused-rows", "compacted-48", "groupnorm", "one-row"])
+def test_deferred_norm_backward_finalize(K, N, tiles, C, groups):
+    """bpx_norm_bwd_finalize_deferred: one block per sample, dgamma / dbeta summed with the step's deferred weight-gradient reductions."""
+    _assert_all(K.check_norm_bwd_finalize_deferred(N, tiles, C, groups))
+
+
+@pytest.mark.parametrize("mix,B,S,Cin,Cout,planar", [(True, 2, (32, 32, 32), 48, 16, True), (False, 1, (34, 38, 52), 48, 16, False), (True, 1, (40, 40, 44), 96, 32, True),
+                                                     (True, 2, (32, 32, 36), 16, 32, False), (False, 1, (64, 64, 64), 96, 32, False)],
+                         ids=["mix-48.16-planar", "bf16-48.16-ragged", "mix-96.32-planar-ragged", "mix-16.32", "bf16-96.32-64^3"])
+def test_streaming_shortcut_weight_gradient(K, mix, B, S, Cin, Cout, planar):
+    """wgrad_k1_dma_kernel: the 1x1x1 shortcut's weight gradient at the large levels as a two-stream reduction (LDS-DMA ring)."""
+    _assert_all(K.check_wgrad_k1_stream(mix, B, S, Cin, Cout, planar))
+
+
 def test_adam_step_kernel_equals_torch_fused_adam(K):
     """optim.fused_step / bpx_adam_step: the optimizer step of the graphed train steps == torch's fused Adam / AdamW on the optimizer's own state
     tensors (train_engine.py:173-177 `optimizer.step()`), and it refuses what it does not reproduce."""
