@@ -349,6 +349,137 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   }
 }
 
+
+// ---- the decoder blocks' input gradient as a stream (round 4) ---------------------------------------------------------------------------------
+//   out[v][0 .. 3K) = Wsc^T dOut[v] + a (.) g[v] + b (.) t[v] + c0,   columns [0, ysplit) -> y_lo, the rest -> y_hi   (K = 16 KC = channels of dOut)
+// is pw_kernel<.., PW_CONV1> with the IN-backward affine and two destinations - 10 tensor units of traffic at level 0 and, as thousands of
+// 128-voxel workgroups that each set up their weights / coefficients and then wait for their loads, 4.0 TB/s (0.66 ms of the cfg-2 step; round 3
+// moved it neither with more or fewer voxels per workgroup nor with all loads up front).  Same arithmetic here, fed like wgrad_k1_dma_kernel:
+// persistent workgroups, the 7 KC 16-channel operand chunks of a TV-voxel block (dOut, g, t) brought in by `buffer_load ... lds` through a ring
+// of stages, weights / coefficients loaded once per workgroup (per sample), one barrier per block.
+struct PwsParams {
+  const void* x; int x_ld;                       // dOut (interleaved)
+  const void* g; int g_ld; const void* t; int t_ld; int t_cs;   // g interleaved; t interleaved (t_cs = 16) or chunk-planar
+  const void* wp; const bpx_nbwd_coef* coef;
+  void* y; int y_ld; void* y2; int y2_ld; int ysplit;            // columns [0, ysplit) -> y, the rest -> y2
+  int64_t vps; int N; int nblocks; int groups; int bps;          // bps = blocks per sample
+};
+__host__ __device__ constexpr int pws_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
+template <int KC, int TV, typename TT>
+__global__ void __launch_bounds__(256) pw_nbs_kernel(const PwsParams p) {
+  constexpr int VB = 32, SUBS = TV / 32, NCH = 7 * KC, NS = 3 * KC, NCOL = 48 * KC, K = 16 * KC;
+  constexpr int STAGE = NCH * TV * VB, RING = 4 * STAGE <= 131072 ? 4 : 3;
+  constexpr int NI = NCH * SUBS;
+  static_assert(NI % 4 == 0 && TV % 64 == 0, "DMA instructions divide over the four waves; every wave owns TV / 4 voxels");
+  constexpr int IPW = NI / 4, MS = TV / 64;                       // 16-voxel m-subtiles per wave
+  constexpr int ST = MS * NS;                                     // store instructions per wave and block (they share the vmcnt queue with the DMAs)
+  static_assert(2 * IPW + 3 * ST < 64 && RING == 4, "vmcnt range; the wait counts below assume three blocks in flight");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * STAGE];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.g), 0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t), 0, (int)0x80000000u, 0x00020000);
+  const uint32_t xvb = (uint32_t)p.x_ld * 2u, gvb = (uint32_t)p.g_ld * 2u, tvb = (uint32_t)p.t_ld * 2u, tcb = (uint32_t)p.t_cs * 2u;
+  const uint32_t lane_v = (uint32_t)(lane >> 1), lane_h = (uint32_t)(lane & 1) * 16u;
+  const int64_t voxels = (int64_t)p.N * p.vps;
+  const int groups = p.groups, nblocks = p.nblocks, bps = p.bps;
+
+  // LDS image of a stage: chunk list [dOut: KC][g: 3 KC][t: 3 KC], each [TV voxels][32 B]
+  auto issue = [=](int blk, int slot) {
+    const int64_t v0 = (int64_t)blk * TV;
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const int q = wave + 4 * k;
+      const int ch = q / SUBS, sub = q % SUBS;
+      const int64_t v = v0 + sub * 32 + lane_v;
+      const bool in = v < voxels;
+      const uint32_t vv = (uint32_t)v;
+      unsigned char* dst = const_cast<unsigned char*>(smem) + slot * STAGE + ch * TV * VB + sub * 1024;
+      if (ch < KC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 16, in ? vv * xvb + (uint32_t)ch * 32u + lane_h : 0x80000000u, 0, 0, 0);
+      else if (ch < KC + NS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)dst, 16, in ? vv * gvb + (uint32_t)(ch - KC) * 32u + lane_h : 0x80000000u, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)dst, 16, in ? vv * tvb + (uint32_t)(ch - KC - NS) * tcb + lane_h : 0x80000000u, 0, 0, 0);
+    }
+  };
+
+  // weights of the 1x1x1 operator, once: MFMA row i of column block ns <-> column (i / 4) * 4 NS + ns * 4 + i % 4, so that lane (g, j) ends up with
+  // the 4 NS consecutive columns g * 4 NS .. of voxel j (pw_kernel's binding)
+  const uint16_t* __restrict__ wp = reinterpret_cast<const uint16_t*>(p.wp);
+  u32x4_t wf[NS];
+  const bool kin = g * 8 < K;
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int colw = (j >> 2) * (4 * NS) + ns * 4 + (j & 3);
+    wf[ns] = kin ? *reinterpret_cast<const u32x4_t*>(wp + ((size_t)g * NCOL + colw) * 8) : u32x4_t{0u, 0u, 0u, 0u};
+  }
+  const int col0 = g * 4 * NS;                                   // first of this lane's columns
+  f32x4_t cf[NS][4];                                             // {a, b, c0, -} of this lane's columns in the current sample
+  int cur_n = -1;
+
+  const int nst = grp < nblocks ? (nblocks - grp + groups - 1) / groups : 0;
+#pragma unroll
+  for (int s = 0; s < RING - 1; ++s)
+    if (s < nst) issue(grp + s * groups, s);
+  for (int s = 0; s < nst; ++s) {
+    const int blk = grp + s * groups;
+    const int n = blk / bps;
+    if (n != cur_n) {                                             // (before the wait: these loads are older than nothing the wait needs)
+      cur_n = n;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cf[ns][r] = *reinterpret_cast<const f32x4_t*>(&p.coef[(size_t)n * NCOL + col0 + ns * 4 + r]);
+    }
+    // block s has landed when only what was issued after it is outstanding: the DMAs of the later blocks in flight and the stores of the blocks
+    // computed since (VMEM operations of a wave retire in order)
+    // (steady state, block s >= 3: after DMA(s) came stores(s-3), DMA(s+1), stores(s-2), DMA(s+2), stores(s-1); the first three blocks had fewer
+    //  stores behind them; the last blocks, with fewer DMAs behind them, simply wait for more than they need)
+    const int later = nst - 1 - s < RING - 2 ? nst - 1 - s : RING - 2;
+    if (later >= 2 && RING >= 4) {
+      if (s >= 3) __builtin_amdgcn_s_waitcnt(pws_vmcnt(2 * IPW + 3 * ST));
+      else if (s == 2) __builtin_amdgcn_s_waitcnt(pws_vmcnt(2 * IPW + 2 * ST));
+      else if (s == 1) __builtin_amdgcn_s_waitcnt(pws_vmcnt(2 * IPW + ST));
+      else __builtin_amdgcn_s_waitcnt(pws_vmcnt(2 * IPW));
+    } else if (later == 1) __builtin_amdgcn_s_waitcnt(pws_vmcnt(IPW));
+    else __builtin_amdgcn_s_waitcnt(pws_vmcnt(0));
+    __syncthreads();
+    if (s + RING - 1 < nst) issue(grp + (s + RING - 1) * groups, (s + RING - 1) % RING);
+    const unsigned char* st = smem + (s % RING) * STAGE;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      const int vl = (wave * MS + ms) * 16 + j;                   // voxel inside the block
+      const int64_t v = (int64_t)blk * TV + vl;
+      f32x4_t acc[NS];
+      const u32x4_t af = kin ? *reinterpret_cast<const u32x4_t*>(st + ((g >> 1) * TV + vl) * VB + (g & 1) * 16) : u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ns] = mfma_step<uint16_t>(wf[ns], af, f32x4_t{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int col = col0 + ns * 4;
+        const u32x2_t gq = *reinterpret_cast<const u32x2_t*>(st + ((KC + (col >> 4)) * TV + vl) * VB + (col & 15) * 2);
+        const u32x2_t tq = *reinterpret_cast<const u32x2_t*>(st + ((KC + NS + (col >> 4)) * TV + vl) * VB + (col & 15) * 2);
+        const float gf[4] = {lo16<uint16_t>(gq[0]), hi16<uint16_t>(gq[0]), lo16<uint16_t>(gq[1]), hi16<uint16_t>(gq[1])};
+        const float tf[4] = {lo16<TT>(tq[0]), hi16<TT>(tq[0]), lo16<TT>(tq[1]), hi16<TT>(tq[1])};
+        float val[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          val[r] = acc[ns][r];
+          val[r] += cf[ns][r][0] * gf[r] + cf[ns][r][1] * tf[r] + cf[ns][r][2];
+        }
+        if (v < voxels) {
+          uint16_t* dst = col < p.ysplit ? reinterpret_cast<uint16_t*>(p.y) + (size_t)v * p.y_ld + col
+                                         : reinterpret_cast<uint16_t*>(p.y2) + (size_t)v * p.y2_ld + (col - p.ysplit);
+          *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk16<uint16_t>(val[0], val[1]), pk16<uint16_t>(val[2], val[3])};
+        }
+      }
+    }
+  }
+}
+
+int g_pw_stream = 1;   // bpx_debug_set_pw_stream
 constexpr int PW_MS = 2;  // 4 waves x 2 x 16 = 128 voxels per workgroup
 #ifndef BPX_PW_MS_CT
 #define BPX_PW_MS_CT 2
@@ -397,6 +528,7 @@ int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
 
 }  // namespace
 
+extern "C" int bpx_debug_set_pw_stream(int on) { g_pw_stream = on; return 0; }
 extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return convt_groups((int64_t)D * H * W) * 4 * (sz == 1 ? 1 : 2); }
 
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
@@ -425,6 +557,29 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
             (long long)N * vps);
   p.addend = addend.ptr; p.addend_ld = addend.ld;
   int ns = pw_ns(ncols);
+  {   // the decoder blocks' input gradient at the large levels: the streaming kernel (pw_nbs_kernel)
+    const int KC = x.C / 16;
+    const int TV = KC == 1 ? 128 : 64;
+    const int64_t vox = (int64_t)N * vps;
+    auto span = [&](const bpx_tensor& q, int chunks) { return (q.cs ? (int64_t)q.cs * (chunks - 1) : 0) * 2 + vox * (int64_t)q.ld * 2; };
+    const bool ok = g_pw_stream && dtype == BPX_BF16 && (KC == 1 || KC == 2) && x.C % 16 == 0 && coef_d != nullptr && y2.ptr != nullptr && y.C + y2.C == 3 * x.C && y.C % 4 == 0 &&
+                    g.C == 3 * x.C && t.C == 3 * x.C && bias_d == nullptr && addend.ptr == nullptr && vps % TV == 0 && vox >= 262144 &&
+                    span(x, 1) < (1ll << 31) && span(g, 1) < (1ll << 31) && span(t, 3 * KC) < (1ll << 31) && (x.ld & 7) == 0 && (g.ld & 7) == 0 && (t.ld & 7) == 0 &&
+                    (y.ld & 3) == 0 && (y2.ld & 3) == 0 && (((uintptr_t)x.ptr | (uintptr_t)g.ptr | (uintptr_t)t.ptr | (uintptr_t)coef_d) & 15) == 0 &&
+                    (((uintptr_t)y.ptr | (uintptr_t)y2.ptr) & 7) == 0;
+    if (ok) {
+      PwsParams q{};
+      q.x = x.ptr; q.x_ld = x.ld; q.g = g.ptr; q.g_ld = g.ld; q.t = t.ptr; q.t_ld = t.ld; q.t_cs = t.cs ? (int)t.cs : 16;
+      q.wp = w_packed_d; q.coef = coef_d; q.y = y.ptr; q.y_ld = y.ld; q.y2 = y2.ptr; q.y2_ld = y2.ld; q.ysplit = y.C;
+      q.vps = vps; q.N = N; q.bps = (int)(vps / TV); q.nblocks = (int)(vox / TV);
+      q.groups = (int)std::min<int64_t>(256, q.nblocks);        // one persistent workgroup per CU (the ring holds ~115 KB)
+      hipStream_t s = (hipStream_t)stream;
+      if (KC == 1) { if (mix) pw_nbs_kernel<1, 128, f16_t><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<1, 128, uint16_t><<<q.groups, 256, 0, s>>>(q); }
+      else { if (mix) pw_nbs_kernel<2, 64, f16_t><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<2, 64, uint16_t><<<q.groups, 256, 0, s>>>(q); }
+      BPX_LAUNCH_CHECK(fn);
+      return 0;
+    }
+  }
   if ((mix ? launch_pw<uint16_t, PW_CONV1, f16_t>(p, ns, (hipStream_t)stream)
        : dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);

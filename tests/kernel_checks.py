@@ -2094,3 +2094,43 @@ def check_wgrad_k1_stream(mix=True, B=2, S=(32, 32, 32), Cin=48, Cout=16, planar
     # bf16 MFMA operands: in the mixed mode x is rounded fp16 -> bf16 on the way in (both kernels), so the fp64 sum of the fp16 values is ~2^-9 away
     return [_res(tag + ".vs_fp64", relerr(a, ref), 4e-3 if mix else 1e-4), _res(tag + ".vs_tile_kernel", relerr(a, c), 1e-4),
             _res(tag + ".run_to_run_bits", 0 if torch.equal(a, b) else 1, 0)]
+
+
+def check_pw_stream(mix=True, B=2, vps=131072, K=16, planar=True, seed=0):
+    """bpx_conv1x1_fwd_split with the IN-backward affine at the large levels (the decoder blocks' input gradient): the streaming kernel against the
+    tile kernel (bpx_debug_set_pw_stream(0)) - the same arithmetic: equal bits - and against the fp32 expression; t fp16 (mixed mode) / planar."""
+    gen = torch.Generator().manual_seed(seed)
+    C3 = 3 * K
+    tdt = torch.float16 if mix else torch.bfloat16
+    x = torch.randn(B, vps, K, generator=gen).to(torch.bfloat16)
+    w = torch.randn(C3, K, generator=gen) / K ** 0.5
+    gg = torch.randn(B, vps, C3, generator=gen).to(torch.bfloat16)
+    tt = (torch.randn(B, vps, C3, generator=gen) * 2).to(tdt)
+    coef = torch.randn(B, C3, 4, generator=gen) * torch.tensor([1.0, 0.3, 0.1, 0.0])
+    y_ref = x.float() @ w.to(torch.bfloat16).float().t() + coef[:, None, :, 0] * gg.float() + coef[:, None, :, 1] * tt.float() + coef[:, None, :, 2]
+    dt = L.MIX16 if mix else L.BF16
+    wp = pack(w.view(C3, K, 1, 1, 1), L.PK_DENSE, K, C3, L.BF16)
+    xd, gd, td, cd = x.to(DEV), gg.to(DEV), tt.to(DEV), coef.to(DEV).contiguous()
+    S = (vps // 1024, 32, 32)
+    tp = L.Planar(B, S, C3, tdt, DEV).copy_from_dense(td.view(B, *S, C3)) if planar else None      # (kept alive: tview holds only the address)
+    tv = L.tview(tp) if planar else L.tview(td)
+    lo = 2 * K
+
+    def run():
+        y_lo = torch.full((B, vps, lo), 7.0, dtype=torch.bfloat16, device=DEV)
+        y_hi = torch.full((B, vps, C3 - lo), 7.0, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.bpx_conv1x1_fwd_split(dt, B, vps, L.tview(xd), wp.data_ptr(), None, L.tview(gd), tv, cd.data_ptr(), L.NULL_T, L.tview(y_lo), L.tview(y_hi),
+                                          L.stream_ptr()))
+        torch.cuda.synchronize()
+        return torch.cat([y_lo, y_hi], -1)
+
+    tag = f"pw_stream[{'mix' if mix else 'bf16'} B{B} v{vps} K{K} planar={int(planar)}]"
+    a, b = run(), run()
+    lib.bpx_debug_set_pw_stream(0)
+    try:
+        c = run()
+    finally:
+        lib.bpx_debug_set_pw_stream(1)
+    return [_res(tag + ".vs_fp32", relerr(a, y_ref), 1.5e-2), _res(tag + ".same_bits_as_tile_kernel", 0 if torch.equal(a.view(torch.int16), c.view(torch.int16)) else 1, 0,
+                                                                   extra=f"max diff {(a.float() - c.float()).abs().max().item():.2e}"),
+            _res(tag + ".run_to_run_bits", 0 if torch.equal(a.view(torch.int16), b.view(torch.int16)) else 1, 0)]

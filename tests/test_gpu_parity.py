@@ -187,6 +187,13 @@ def test_streaming_shortcut_weight_gradient(K, mix, B, S, Cin, Cout, planar):
     _assert_all(K.check_wgrad_k1_stream(mix, B, S, Cin, Cout, planar))
 
 
+@pytest.mark.parametrize("mix,B,vps,Kc,planar", [(True, 2, 131072, 16, True), (False, 1, 262144, 16, False), (True, 3, 98304, 32, True), (False, 2, 131072, 32, False)],
+                         ids=["mix-16-planar", "bf16-16", "mix-32-planar-3samples", "bf16-32"])
+def test_streaming_decoder_input_gradient(K, mix, B, vps, Kc, planar):
+    """pw_nbs_kernel: bpx_conv1x1_fwd_split + IN-backward affine at the large levels through the LDS-DMA ring - the tile kernel's bits."""
+    _assert_all(K.check_pw_stream(mix, B, vps, Kc, planar))
+
+
 def test_adam_step_kernel_equals_torch_fused_adam(K):
     """optim.fused_step / bpx_adam_step: the optimizer step of the graphed train steps == torch's fused Adam / AdamW on the optimizer's own state
     tensors (train_engine.py:173-177 `optimizer.step()`), and it refuses what it does not reproduce."""
