@@ -38,6 +38,7 @@ if [ -f biapy_amd/libbiapy_amd_stamps.so ]; then
   ( BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 16; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 48 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_bwd_fused.txt
 fi
 python tests/bench_kernels.py bwd --reps 10 2>&1 | grep -v amdgpu.ids > $O/${R}_bwd_fused_vs_separate.txt
+( python tests/bench_kernels.py k1 --reps 20; python tests/bench_kernels.py pws --reps 20 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stream_vs_tile.txt
 python tests/gpu_diag.py --net --out $O/${R}_gpu_diag.txt > /dev/null 2>&1
 python tests/bench_kernels.py rcan 2>&1 | grep -v "Warning\|run_backward" > $O/${R}_rcan_trunk_64.txt
 cd /tmp
@@ -60,7 +61,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p --
 cd $ROOT
 python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 python scripts/pmc_traffic.py $(find $O/pmc_tf -name "p_results.db" | head -1) $(find $O/pmc_tw -name "p_results.db" | head -1) > $O/pmc_traffic_tiling.json 2>> $O/pmc_traffic.err
-for k in conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel; do
+for k in conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel pw_nbs_kernel wgrad_k1_dma_kernel; do
   python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
   python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
 done > $O/${R}_pmc_sq_conv_wgrad.txt 2>&1

@@ -112,6 +112,26 @@ def main():
                 ms = timeit(f, a.reps)
                 print(f"wgrad k=1 {S:4d}^3 {cin:3d}.{cout:3d} {'stream' if on else 'tile  '}: {ms * 1e3:8.1f} us (+ reduce) {by / ms / 1e9:7.2f} TB/s")
         return
+    if a.what == "pws":
+        # the decoder blocks' input gradient (bpx_conv1x1_fwd_split + IN-backward affine, mixed mode): streaming kernel vs the tile kernel
+        for (S, K) in [(128, 16), (64, 32)]:
+            vps = S ** 3
+            C3 = 3 * K
+            xx = torch.randn(B, vps, K, device=DEV).to(torch.bfloat16)
+            gg = torch.randn(B, vps, C3, device=DEV).to(torch.bfloat16)
+            tt = torch.randn(B, S, S, S, C3, device=DEV).to(torch.float16)
+            tp = L.Planar(B, (S, S, S), C3, torch.float16, DEV).copy_from_dense(tt)
+            coef = torch.randn(B, C3, 4, device=DEV)
+            wp = pack(torch.randn(C3, K, 1, 1, 1, device=DEV), L.PK_DENSE, K, C3)
+            y_lo = torch.empty(B, vps, 2 * K, device=DEV, dtype=torch.bfloat16); y_hi = torch.empty(B, vps, K, device=DEV, dtype=torch.bfloat16)
+            f = lambda: L.check(lib.bpx_conv1x1_fwd_split(L.MIX16, B, vps, L.tview(xx), wp.data_ptr(), None, L.tview(gg), L.tview(tp), coef.data_ptr(), L.NULL_T,
+                                                          L.tview(y_lo), L.tview(y_hi), st))
+            by = B * vps * (K + 3 * C3) * 2
+            for on in (0, 1):
+                lib.bpx_debug_set_pw_stream(on)
+                ms = timeit(f, a.reps)
+                print(f"1x1x1 + IN-backward {S:4d}^3 {K:3d} -> {C3:3d} {'stream' if on else 'tile  '}: {ms * 1e3:8.1f} us {by / ms / 1e9:7.2f} TB/s")
+        return
     if a.what == "prologue":
         # VERDICT r3 next #5 ("forward prologue diet"): level-0 forward convs with the fused normalise + ELU prologue, against a streaming pass
         # that materialises a = ELU(scale * x + shift) once (bpx_norm_act_fwd) followed by the same conv WITHOUT a prologue.
