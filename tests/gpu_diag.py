@@ -61,6 +61,17 @@ def main():
     run(K.check_bwd_fused, True, 2, (32, 32, 32), 16)
     run(K.check_bwd_fused, True, 1, (34, 38, 44), 48, True)
     run(K.check_bwd_fused, False, 1, (36, 34, 40), 16)
+    run(K.check_bwd_fused, True, 1, (32, 32, 32), 32, False, 0, 1, 32)
+    run(K.check_wgrad_k1_stream, True, 2, (32, 32, 32), 48, 16, True)
+    run(K.check_wgrad_k1_stream, False, 1, (34, 38, 52), 48, 16, False)
+    run(K.check_wgrad_k1_stream, True, 1, (40, 40, 44), 96, 32, True)
+    run(K.check_pw_stream, True, 2, 131072, 16, True)
+    run(K.check_pw_stream, True, 3, 98304, 32, True)
+    run(K.check_c1_wgrad_nb, True, 2, (12, 20, 36))
+    run(K.check_norm_bwd_finalize_deferred, 4, 768, 16)
+    run(K.check_norm_bwd_finalize_deferred, 3, 5000, 48)
+    run(K.check_fused_adam)
+    run(K.check_f16_saturation)
     if a.net:
         run(K.check_sliding_window, torch.float32)
         run(K.check_sliding_window, torch.bfloat16)
