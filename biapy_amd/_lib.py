@@ -91,6 +91,7 @@ _SIGS = {
     "bpx_debug_set_wgrad_cap": ([_i], _i),
     "bpx_debug_set_wgrad_k1": ([_i], _i),
     "bpx_debug_set_pw_stream": ([_i], _i),
+    "bpx_debug_set_c1_persist": ([_i], _i),
     "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
     "bpx_conv1x1_fwd_split": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, Tensor, _vp], _i),
@@ -159,7 +160,7 @@ def _load() -> C.CDLL:
         fn.restype = res
     # A/B hooks through the environment: wgrad partial-slab cap in percent
     for env, hook in (("BPX_WGRAD_CAP", "bpx_debug_set_wgrad_cap"), ("BPX_WGRAD_K1", "bpx_debug_set_wgrad_k1"),
-                      ("BPX_PW_STREAM", "bpx_debug_set_pw_stream")):
+                      ("BPX_PW_STREAM", "bpx_debug_set_pw_stream"), ("BPX_C1_PERSIST", "bpx_debug_set_c1_persist")):
         if os.environ.get(env) is not None:
             getattr(lib, hook)(int(os.environ[env]))
     return lib

@@ -815,19 +815,31 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const TX* __restrict__ x,
 template <typename T>
 __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w /* (Cout,1,27) */,
                                                           const float* __restrict__ bias, T* __restrict__ y, int y_ld, int Cout, int D,
-                                                          int H, int W, int tilesY, int tilesX, int tilesPerSample, float* __restrict__ part) {
+                                                          int H, int W, int tilesY, int tilesX, int tilesPerSample, float* __restrict__ part, int totalTiles) {
   constexpr bool BF = sizeof(T) == 2;   // 16-bit storage (bf16 bits or fp16): hi + lo split of the fp32 image, two MFMAs
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX, MS = 8;
   __shared__ float simg[HV];
   __shared__ float red[4][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x % tilesPerSample, n = blockIdx.x / tilesPerSample, cb = blockIdx.y * 16;
-  const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
-  for (int i = tid; i < HV; i += 256) {
-    int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
-    int z = z0 + hz - 1, yy = y0 + hy - 1, x = x0 + hx - 1;
-    simg[i] = (z >= 0 && z < D && yy >= 0 && yy < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + yy) * W + x] : 0.f;
-  }
+  const int cb = blockIdx.y * 16;
+  // Round 4: persistent workgroups.  As one workgroup per tile the kernel was bound by the LIFE of a workgroup - image load latency, 16 MFMAs,
+  // then its stores' write acknowledgements before the slot frees - at 2.1 TB/s written (0.144 ms at 4 x 128^3).  The image halo of the NEXT tile
+  // is requested into registers (five floats per thread) BEFORE this tile's stores: a wave's VMEM operations retire in order, so the wait for
+  // those loads then leaves the stores outstanding; weights / tap offsets / bias are set up once.
+  constexpr int NI = (HV + 255) / 256;
+  float pi[NI];
+  auto issue = [&](int tt) {
+    const int n_ = tt / tilesPerSample, tile_ = tt - n_ * tilesPerSample;
+    const int x0_ = (tile_ % tilesX) * TX, y0_ = ((tile_ / tilesX) % tilesY) * TY, z0_ = (tile_ / (tilesX * tilesY)) * TZ;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int i = u * 256 + tid;
+      const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+      const int z = z0_ + hz - 1, yy = y0_ + hy - 1, x = x0_ + hx - 1;
+      pi[u] = (i < HV && z >= 0 && z < D && yy >= 0 && yy < H && x >= 0 && x < W) ? img[(((size_t)n_ * D + z) * H + yy) * W + x] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < totalTiles) issue(blockIdx.x);
   // weight operand of this lane: output channel cb + j, taps 8g..8g+7 (bf16) or 4s+g (f32)
   u32x4_t wa = u32x4_t{0u, 0u, 0u, 0u};
   float wf32[7];
@@ -851,10 +863,18 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
       toff[s] = ((tc / 9) * HY + (tc / 3) % 3) * HX + tc % 3;
     }
   }
-  __syncthreads();
   float bsv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bsv[r] = bias ? bias[cb + 4 * g + r] : 0.f;
+  for (int tt = blockIdx.x; tt < totalTiles; tt += gridDim.x) {
+  const int n = tt / tilesPerSample, tile = tt - n * tilesPerSample;
+  const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
+  __syncthreads();                                   // the previous tile's reads of simg / red are done
+#pragma unroll
+  for (int u = 0; u < NI; ++u)
+    if (u * 256 + tid < HV) simg[u * 256 + tid] = pi[u];
+  __syncthreads();
+  if (tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
@@ -903,6 +923,7 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
       part[(((size_t)n * tilesPerSample + tile) * 2 + k) * Cout + cb + c] = s;
     }
   }
+  }   // tiles of this workgroup
 }
 
 // dW[co][tap] += sum_v img[v+tap]*dy[v][co]; thread = (tap, voxel subset), 16 co in registers.
@@ -2166,6 +2187,8 @@ extern "C" int bpx_head_bwd(int dtype, int64_t vps, int N, bpx_tensor x, const f
   return bpxred::reduce_partials(fn, pw, dw_d, blocks, 1, 1, Cout * x.C, 0, 1, 0, pb, db_d, Cout, false, s);
 }
 
+static int g_c1_persist = 2048;   // persistent workgroups of the first-layer forward (bpx_debug_set_c1_persist; 0 = one workgroup per tile, as until round 3)
+extern "C" int bpx_debug_set_c1_persist(int wgs) { g_c1_persist = wgs; return 0; }
 extern "C" int bpx_conv3d_c1_stats_tiles(int D, int H, int W) { return cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16); }
 
 extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d, const float* bias_d,
@@ -2176,11 +2199,12 @@ extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const fl
   BPX_CHECK(y.C % 16 == 0, "%s: Cout must be a multiple of 16", fn);
   int tiles = bpx_conv3d_c1_stats_tiles(D, H, W);
   int tY = cdiv(H, 8), tX = cdiv(W, 16);
-  dim3 grid((unsigned)(tiles * N), (unsigned)(y.C / 16));
+  const int total = tiles * N;
+  dim3 grid((unsigned)std::min(total, g_c1_persist > 0 ? g_c1_persist : total), (unsigned)(y.C / 16));   // persistent: 8 workgroups per CU
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
-  else if (dtype == BPX_F16) conv_c1_fwd_kernel<f16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (f16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
-  else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d);
+  if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total);
+  else if (dtype == BPX_F16) conv_c1_fwd_kernel<f16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (f16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total);
+  else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;

@@ -52,6 +52,7 @@ int bpx_debug_set_wgrad_tr(int use_tr);
 int bpx_debug_set_conv_stamps(void* stamps_d); /* profiling hook: [workgroup][16] int64 cycle stamps of the plain conv kernel, NULL = off */
 int bpx_debug_set_conv_ws(int on);     /* test / A-B hook of the bf16 3x3x3 conv schedule: 0 = automatic, 4 = always the double-buffered kernel, 5 = always the lean persistent one */
 int bpx_debug_set_conv_occ(int wg_per_cu); /* test / A-B hook: persistent workgroups per CU of the lean bf16 conv kernel (0 = built-in table) */
+int bpx_debug_set_c1_persist(int wgs); /* test / A-B hook: persistent workgroups of bpx_conv3d_c1_fwd (default 2048; 0 = one workgroup per tile) */
 int bpx_debug_set_pw_stream(int on); /* test / A-B hook: 1 (default) = the streaming kernel for bpx_conv1x1_fwd_split with the IN-backward affine at the large levels, 0 = the tile kernel */
 int bpx_debug_set_wgrad_k1(int on); /* test / A-B hook: 1 (default) = the streaming kernel for the k = 1 weight gradients of raw inputs at the large levels, 0 = the generic tile kernel */
 int bpx_debug_set_wgrad_cap(int percent); /* test / A-B hook: size cap of a conv layer's weight-gradient partial slabs in percent of the default (~26 / 64 MB) */
