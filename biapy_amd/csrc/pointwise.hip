@@ -145,7 +145,10 @@ struct PwParams {
 // of the 48-column GEMM went from 116 to 128 VGPRs and from 0.62 to 0.75 ms (cfg 2, level 0).
 // TT: element type of the t operand of PW_CONV1's fused InstanceNorm-backward affine (BPX_MIX16: the forward pass's fp16 activations beside
 // bf16 gradients), else T
-template <typename T, int MS, int NS, int MODE, bool PL, typename TT = T>
+// K1STEP (transposed-conv forward into a chunk-planar buffer with Cin = 32, i.e. ONE K step: level 0 of cfg 2): weights kept in registers and the next
+// block's operand requested before this block's stores.  An instance of its own: the 40 extra VGPRs cost the deeper levels a workgroup per CU
+// (58 -> 73 us at 64 -> 64 channels) when every transposed-conv forward carried them.
+template <typename T, int MS, int NS, int MODE, bool PL, typename TT = T, bool K1STEP = false>
 __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL;
@@ -177,6 +180,31 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
 
   int mb = grp;
+  // Transposed-conv forward (the persistent loop), round 4: a wave's VMEM operations retire in order, so the wait for block i + 1's operand - and for
+  // its weight fragments, re-loaded per block - also waited for the write acknowledgement of block i's stores: every iteration was
+  // [load latency + store latency], 2.3 TB/s written.  With one K step (Cin = 32, the level-0 / cfg-2 case) the weights now stay in registers and the
+  // operand of the NEXT block is requested BEFORE this block's stores: its wait leaves the stores outstanding.
+  constexpr bool PRE = MODE == PW_CONVT && K1STEP;
+  constexpr bool pre = PRE;                        // (the launcher picks the instance for K <= 32)
+  u32x4_t af_pre[PRE ? MS : 1], wf_keep[PRE ? NS : 1];
+  auto prefetch = [&](int mbn) {
+#pragma unroll
+    for (int ms = 0; ms < (PRE ? MS : 1); ++ms) {
+      const uint32_t vn = ((uint32_t)mbn * 4u + (uint32_t)wave) * (uint32_t)(MS * 16) + (uint32_t)(ms * 16 + j);
+      af_pre[ms] = u32x4_t{0u, 0u, 0u, 0u};
+      if (g * KPL < p.K && vn < (uint32_t)p.vps) af_pre[ms] = *reinterpret_cast<const u32x4_t*>(xin + ((size_t)n * p.vps + vn) * (size_t)p.x_ld + g * KPL);
+    }
+  };
+  if (pre) {
+    prefetch(mb);
+#pragma unroll
+    for (int ns = 0; ns < (PRE ? NS : 1); ++ns) {
+      const int gq = j >> 2;
+      const int colw = PERM ? (2 * sp + (gq >> 1)) * p.Csub + pp * 32 + (ns >> 1) * 16 + (gq & 1) * 8 + (ns & 1) * 4 + (j & 3)
+                            : col_base + gq * (4 * NS) + ns * 4 + (j & 3);
+      wf_keep[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)g * p.Ncols + colw) * KPL);
+    }
+  }
   do {   // one pass for every mode but the transposed-conv forward (a compile-time fact: as a run-time loop it cost the 48-column GEMM 40 VGPRs and a wave per SIMD)
   // voxel of lane (j) for each m-subtile
   // voxels per sample < 2^31 (checked on the host): 32-bit index math - the 64-bit div/mod sequences of the transposed-conv
@@ -217,6 +245,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
     {
+      if (PRE && pre) { wf[ns] = wf_keep[PRE ? ns : 0]; continue; }
       const int gq = j >> 2;
       const int colw = PERM ? (2 * sp + (gq >> 1)) * p.Csub + pp * 32 + (ns >> 1) * 16 + (gq & 1) * 8 + (ns & 1) * 4 + (j & 3)
                             : col_base + gq * (4 * NS) + ns * 4 + (j & 3);
@@ -233,11 +262,13 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
       u32x4_t af = u32x4_t{0u, 0u, 0u, 0u};
-      if (kin && valid[ms]) af = *reinterpret_cast<const u32x4_t*>(xin + abase[ms] + koff);
+      if (PRE && pre) af = af_pre[PRE ? ms : 0];
+      else if (kin && valid[ms]) af = *reinterpret_cast<const u32x4_t*>(xin + abase[ms] + koff);
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
     }
   }
+  if (PRE && pre && mb + p.mgroups < p.mblocks) prefetch(mb + p.mgroups);   // before the stores below
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------
   // MFMA row i of column block ns is bound to column col_base + (i/4)*4NS + ns*4 + i%4 (see the weight load above), so
@@ -505,7 +536,8 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   if (MODE == PW_CONVT && planar && ns == 4 && p.Csub % 32 != 0) { bpx_set_error("transposed conv: the 64-column planar form needs Cout % 32 == 0"); return 1; }
   if (MODE != PW_CONVTD && planar) {
     constexpr bool PL = MODE != PW_CONVTD;    // no planar instances of the transposed-conv dgrad
-    if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
+    if (ns == 4 && MODE == PW_CONVT && sizeof(T) == 2 && p.K * (int)sizeof(T) <= 64) pw_kernel<T, MSK, 4, MODE, PL, TT, MODE == PW_CONVT && sizeof(T) == 2><<<grid, 256, 0, s>>>(p);
+    else if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else if (ns == 3) pw_kernel<T, MSK, 3, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else if (ns == 2) pw_kernel<T, MSK, 2, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else pw_kernel<T, MSK, 1, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
