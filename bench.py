@@ -494,6 +494,7 @@ def main():
 
         step = eager_step
         graphed = False
+        gstep = None
         if want_graph:
             # HIP-graph capture of the whole step (forward, loss, backward, AdamW): one launch per step instead of ~170
             try:
@@ -562,7 +563,9 @@ def main():
                 higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic",
                 config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, train" % (a.patch, a.batch),
                             global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode="train"),
-                launch=("hip-graph replays (forward+loss+backward | optimizer) around one flat-gradient RCCL all-reduce" if multi else
+                launch=(("hip-graph replays (forward+loss+backward up to the first encoder block | its backward | optimizer), the flat-gradient RCCL all-reduce "
+                         "of everything but the first block running beside the second replay" if getattr(gstep, "overlapped", False) else
+                         "hip-graph replays (forward+loss+backward | optimizer) around one flat-gradient RCCL all-reduce") if multi else
                         "hip-graph replay (whole step)") if graphed else ("hip-graph replay (forward, backward) + eager DDP/optimizer"
                                                                         if fb_graphs else "eager"),
                 mfma_frac_end_to_end=round(value * FLOP_PER_VOXEL_FWD * 3 / (world * MFMA_PEAK_BF16), 5),

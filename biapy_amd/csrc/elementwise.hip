@@ -1035,14 +1035,14 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
   }
   const int tilesX = cdiv(W, TX), tilesY = cdiv(H, TY), tilesZ = cdiv(D, TZ);
   const int tps = tilesX * tilesY * tilesZ;
-  // register-prefetched staging: the loads of tile k+1 are in flight while tile k is multiplied (the MFMA part is tiny, the
-  // kernel is otherwise pure load latency)
+  // register-prefetched staging, TWO tiles ahead (round 4; one tile ahead until then): the MFMA part is tiny, the kernel is pure load latency - with
+  // the operands of one tile in flight per workgroup an iteration was a full memory latency (3.3 TB/s with the folded IN-backward operands)
   constexpr int NI = (HV + 255) / 256;
-  float pi[NI];
-  u32x4_t pg[2];
-  u32x4_t pt[NB ? 2 : 1];
-  f32x4_t pk[NB ? 8 : 1];   // {a, b, c0, -} of this thread's 8 channels in the sample of the tile in flight
-  auto issue = [&](int tt) {
+  struct Stage { float pi[NI]; u32x4_t pg[2]; u32x4_t pt[NB ? 2 : 1]; };
+  Stage st0, st1;
+  f32x4_t ck[NB ? 8 : 1];   // {a, b, c0, -} of this thread's 8 channels in the current sample
+  int cur_n = -1;
+  auto issue = [&](int tt, Stage& sg) {
     const int n = tt / tps, tile = tt % tps;
     const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
 #pragma unroll
@@ -1050,50 +1050,56 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
       const int q = u * 256 + tid;
       const int hx = q % HX, hy = (q / HX) % HY, hz = q / (HX * HY);
       const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-      pi[u] = (q < HV && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
+      sg.pi[u] = (q < HV && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int q = u * 256 + tid, t = q >> 1;
       const int x = x0 + (t & 15), y = y0 + ((t >> 4) & 3), z = z0 + (t >> 6);
-      pg[u] = u32x4_t{0u, 0u, 0u, 0u};
-      if (NB) pt[NB ? u : 0] = u32x4_t{0u, 0u, 0u, 0u};
+      sg.pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+      if (NB) sg.pt[NB ? u : 0] = u32x4_t{0u, 0u, 0u, 0u};
       if (z < D && y < H && x < W) {
         const size_t v = (((size_t)n * D + z) * H + y) * W + x;
-        pg[u] = *reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + cb + (q & 1) * 8);
-        if (NB) pt[NB ? u : 0] = *reinterpret_cast<const u32x4_t*>(tsrc + v * t_ld + cb + (q & 1) * 8);
+        sg.pg[u] = *reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + cb + (q & 1) * 8);
+        if (NB) sg.pt[NB ? u : 0] = *reinterpret_cast<const u32x4_t*>(tsrc + v * t_ld + cb + (q & 1) * 8);
       }
-    }
-    if (NB) {
-      const f32x4_t* kp = reinterpret_cast<const f32x4_t*>(coef + (size_t)n * (16 * gridDim.y) + cb + (tid & 1) * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pk[NB ? e : 0] = kp[e];
     }
   };
   // the staged dy piece: as loaded, or a * g + b * t + c0 (out-of-volume voxels stay zero: their operands were never loaded)
-  auto piece = [&](int u, int tt) -> u32x4_t {
-    if (!NB) return pg[u];
+  auto piece = [&](int u, int tt, const Stage& sg) -> u32x4_t {
+    if (!NB) return sg.pg[u];
     const int q = u * 256 + tid, t = q >> 1;
     const int tile = tt % tps;
     const int x = (tile % tilesX) * TX + (t & 15), y = ((tile / tilesX) % tilesY) * TY + ((t >> 4) & 3), z = (tile / (tilesX * tilesY)) * TZ + (t >> 6);
     if (!(z < D && y < H && x < W)) return u32x4_t{0u, 0u, 0u, 0u};
     float gf[8], tf[8], of[8];
-    unpack16<uint16_t>(pg[u], gf);
-    unpack16<TT>(pt[NB ? u : 0], tf);
+    unpack16<uint16_t>(sg.pg[u], gf);
+    unpack16<TT>(sg.pt[NB ? u : 0], tf);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const f32x4_t k = pk[NB ? e : 0]; of[e] = k[0] * gf[e] + k[1] * tf[e] + k[2]; }
+    for (int e = 0; e < 8; ++e) { const f32x4_t k = ck[NB ? e : 0]; of[e] = k[0] * gf[e] + k[1] * tf[e] + k[2]; }
     return pack16<uint16_t>(of);
   };
-  if ((int)blockIdx.x < totalTiles) issue(blockIdx.x);
-  for (int tt = blockIdx.x; tt < totalTiles; tt += gridDim.x) {
+  const int step = gridDim.x;
+  if ((int)blockIdx.x < totalTiles) issue(blockIdx.x, st0);
+  if ((int)blockIdx.x + step < totalTiles) issue(blockIdx.x + step, st1);
+  auto body = [&](int tt, Stage& sg) {
+    if (NB) {
+      const int n = tt / tps;
+      if (n != cur_n) {                                     // (a handful of times per workgroup)
+        cur_n = n;
+        const f32x4_t* kp = reinterpret_cast<const f32x4_t*>(coef + (size_t)n * (16 * gridDim.y) + cb + (tid & 1) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ck[NB ? e : 0] = kp[e];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NI; ++u)
-      if (u * 256 + tid < HV) simg[u * 256 + tid] = pi[u];
+      if (u * 256 + tid < HV) simg[u * 256 + tid] = sg.pi[u];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = piece(u, tt);
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = piece(u, tt, sg);
     __syncthreads();
-    if (tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);
+    if (tt + 2 * step < totalTiles) issue(tt + 2 * step, sg);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int kc = wave * 2 + kk;
@@ -1123,6 +1129,10 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
         acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, gf), acc[b], 0, 0, 0);
       }
     }
+  };
+  for (int tt = blockIdx.x; tt < totalTiles; tt += 2 * step) {
+    body(tt, st0);
+    if (tt + step < totalTiles) body(tt + step, st1);
   }
   // lane holds D[row = 4g + r][co = i] of each block: sum the four waves, then one partial per (tap, co) and workgroup
 #pragma unroll
