@@ -118,6 +118,9 @@ _SIGS = {
     "bpx_gate_mlp_fwd": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp], _i),
     "bpx_gate_mlp_bwd": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_norm_act_tiles": ([_i, _i64, _i], _i),
+    "bpx_norm_act_dropout_tiles": ([_i, _i64, _i], _i),
+    "bpx_norm_act_dropout_fwd": ([_i, _i, _i64, Tensor, _vp, _i, C.c_float, C.c_uint64, _vp, _i, _vp, _i, Tensor, _vp], _i),
+    "bpx_norm_act_dropout_bwd": ([_i, _i, _i64, Tensor, Tensor, _vp, _i, C.c_float, C.c_uint64, _vp, _i, _vp, _i, Tensor, _vp, _vp], _i),
     "bpx_norm_act_fwd": ([_i, _i, _i64, Tensor, _vp, _i, Tensor, _vp], _i),
     "bpx_norm_act_bwd": ([_i, _i, _i64, Tensor, Tensor, _vp, _i, Tensor, Tensor, _vp, _vp], _i),
     "bpx_maxpool3d_fwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp], _i),

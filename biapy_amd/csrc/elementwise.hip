@@ -516,6 +516,140 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dropout of a residual block (biapy/models/blocks.py:163 `nn.Dropout(p)` after Conv -> Norm -> Act, i.e. on the activated tensor the block's
+// second convolution reads).  With p > 0 that tensor is materialised (the fused prologue of the second convolution cannot carry a mask through
+// its three consumers cheaply, and p = 0 - BiaPy's default - keeps the fused path):
+//   fwd: y = act(scale * x + shift) * keep / (1 - p)
+//   bwd: g = dy * keep / (1 - p) * act'(scale * x + shift), with the S1 / S2 partial sums of norm_act_bwd_kernel
+// keep = Philox4x32-10(key = seed, counter = (element / 4, site, *counter_d)) >= p * 2^32, element = linear NDHWC index of the dense tensor: the mask
+// is a function of (seed, step counter, site, element) only - forward and backward regenerate it, nothing is stored.  *counter_d is a DEVICE
+// value the caller bumps once per forward (a captured graph then draws a new mask at every replay).  mask_io (tests): mode 1 = read the
+// keep flags from it instead of drawing them, mode 2 = also write the drawn flags to it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+struct DropArgs { float p; uint32_t thr; uint64_t seed; const uint64_t* counter; uint32_t site; uint8_t* mask; int mask_mode; };
+// keep flags of the KPL consecutive elements starting at linear element index e0 (a multiple of 4)
+template <int KPL>
+__device__ __forceinline__ void drop_keep(const DropArgs& d, uint64_t ctr, uint64_t e0, bool (&keep)[KPL]) {
+  if (d.mask_mode == 1) {
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) keep[e] = d.mask[e0 + e] != 0;
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < KPL / 4; ++q) {
+    const uint64_t blk = (e0 >> 2) + q;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), d.site, (uint32_t)ctr ^ ((uint32_t)(ctr >> 32) * 0x9E3779B9u), (uint32_t)d.seed, (uint32_t)(d.seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) keep[q * 4 + e] = r[e] >= d.thr;
+  }
+  if (d.mask_mode == 2) {
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) d.mask[e0 + e] = keep[e] ? 1 : 0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) norm_act_drop_fwd_kernel(const T* __restrict__ x, int x_ld, const bpx_norm_rec* __restrict__ rec, int act,
+                                                                T* __restrict__ y, int y_ld, int C, int64_t vps, const DropArgs d) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  const int G = C / KPL;
+  const int n = blockIdx.y;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float sc[KPL], sh[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    bpx_norm_rec r = rec[(size_t)n * C + cg * KPL + e];
+    sc[e] = r.scale; sh[e] = r.shift;
+  }
+  const uint64_t ctr = *d.counter;
+  const float inv = 1.f / (1.f - d.p);
+  const size_t base = (size_t)n * vps;
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
+    float f[KPL];
+    bool keep[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
+    drop_keep<KPL>(d, ctr, (uint64_t)vox * C + cg * KPL, keep);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      const float u = sc[e] * f[e] + sh[e];
+      f[e] = keep[e] ? bpx_act_rt<false>(u, act) * inv : 0.f;
+    }
+    *reinterpret_cast<u32x4_t*>(y + vox * y_ld + cg * KPL) = pack16<T>(f);
+  }
+}
+
+// T: gradients (dy, g); TT: the activation tensor x (fp16 beside bf16 gradients in the mixed mode)
+template <typename T, typename TT>
+__global__ void __launch_bounds__(256) norm_act_drop_bwd_kernel(const T* __restrict__ dy, int dy_ld, const TT* __restrict__ x, int x_ld,
+                                                                const bpx_norm_rec* __restrict__ rec, int act, T* __restrict__ g, int g_ld, int C,
+                                                                int64_t vps, float* __restrict__ red_part, const DropArgs d) {
+  constexpr int KPL = ElemTraits<T>::KPL;
+  extern __shared__ float nred[];   // [256][2*KPL]
+  const int G = C / KPL;
+  const int n = blockIdx.y, tiles = gridDim.x;
+  const int64_t total = vps * G;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(first % G);
+  float sc[KPL], sh[KPL], mu[KPL], rs[KPL], s1[KPL], s2[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    bpx_norm_rec r = rec[(size_t)n * C + cg * KPL + e];
+    sc[e] = r.scale; sh[e] = r.shift; mu[e] = r.mean; rs[e] = r.rstd;
+    s1[e] = s2[e] = 0.f;
+  }
+  const uint64_t ctr = *d.counter;
+  const float inv = 1.f / (1.f - d.p);
+  const size_t base = (size_t)n * vps;
+  const size_t vstep = (size_t)gridDim.x * blockDim.x / G;
+  size_t vox = base + (size_t)(first / G);
+  for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
+    float dv[KPL], f[KPL], o[KPL];
+    bool keep[KPL];
+    unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + vox * dy_ld + cg * KPL), dv);
+    unpack16<TT>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
+    drop_keep<KPL>(d, ctr, (uint64_t)vox * C + cg * KPL, keep);
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      const float u = sc[e] * f[e] + sh[e];
+      const float gv = keep[e] ? dv[e] * inv * bpx_act_bwd_rt<false>(u, act) : 0.f;
+      s1[e] += gv;
+      s2[e] += gv * ((f[e] - mu[e]) * rs[e]);
+      o[e] = gv;
+    }
+    *reinterpret_cast<u32x4_t*>(g + vox * g_ld + cg * KPL) = pack16<T>(o);
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    nred[threadIdx.x * 2 * KPL + e] = s1[e];
+    nred[threadIdx.x * 2 * KPL + KPL + e] = s2[e];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
+    const int which = o / C, c = o % C, grp = c / KPL, e = c % KPL;
+    const int lane0 = (int)(((int64_t)grp - (int64_t)blockIdx.x * blockDim.x % G + G) % G);
+    float acc = 0.f;
+    for (int t = lane0; t < (int)blockDim.x; t += G) acc += nred[t * 2 * KPL + which * KPL + e];
+    red_part[(((size_t)n * tiles + blockIdx.x) * 2 + which) * C + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Channel attention of the RCAN trunk (biapy/models/rcan.py ChannelAttention / RCAB_rcan: x + h * sigmoid(MLP(avgpool(h)))):
 //   channel_affine: y = [x +] s[n,c] * h [+ off[n,c]]     (forward: x + s*h ; backward: dh = s*dy + dmean/voxels)
 //   dot_stats:      part[n][block][c] = sum over the block's voxels of a*b   (ds[n,c] = sum_v dy*h)
@@ -1893,6 +2027,64 @@ extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy,
     norm_act_bwd_kernel<float><<<grid, 256, shm, s>>>((const float*)dy.ptr, dy.ld, (const float*)x.ptr, x.ld, rec_d, act,
                                                       (const float*)addend.ptr, addend.ld, (float*)g.ptr, g.ld, x.C, voxels, red_part_d);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+static int drop_args(const char* fn, float p, uint64_t seed, const uint64_t* counter_d, int site, uint8_t* mask_io_d, int mask_mode, DropArgs& d) {
+  BPX_CHECK(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0, 1)", fn, (double)p);
+  BPX_CHECK(counter_d != nullptr, "%s: the step counter is null", fn);
+  BPX_CHECK(mask_mode >= 0 && mask_mode <= 2 && (mask_mode == 0 || mask_io_d != nullptr), "%s: mask mode %d needs a mask buffer", fn, mask_mode);
+  d.p = p; d.thr = (uint32_t)std::min<double>(4294967295.0, (double)p * 4294967296.0); d.seed = seed; d.counter = counter_d; d.site = (uint32_t)site;
+  d.mask = mask_io_d; d.mask_mode = mask_mode;
+  return 0;
+}
+
+extern "C" int bpx_norm_act_dropout_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, float p, uint64_t seed,
+                                        const uint64_t* counter_d, int site, uint8_t* mask_io_d, int mask_mode, bpx_tensor y, bpx_stream_t stream) {
+  const char* fn = "bpx_norm_act_dropout_fwd";
+  BPX_CHECK(x.cs == 0 && y.cs == 0 && x.ld == x.C && y.ld == y.C, "%s: dense tensors only", fn);
+  BPX_CHECK(x.ptr && y.ptr && rec_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
+  DropArgs d{};
+  if (drop_args(fn, p, seed, counter_d, site, mask_io_d, mask_mode, d)) return 1;
+  if ((int64_t)N * voxels == 0) return 0;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
+  dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16) norm_act_drop_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, rec_d, act, (uint16_t*)y.ptr, y.ld, x.C, voxels, d);
+  else if (dtype == BPX_F16) norm_act_drop_fwd_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x.ptr, x.ld, rec_d, act, (f16_t*)y.ptr, y.ld, x.C, voxels, d);
+  else if (dtype == BPX_F32) norm_act_drop_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x.ptr, x.ld, rec_d, act, (float*)y.ptr, y.ld, x.C, voxels, d);
+  else BPX_FAIL("%s: dtype must be BF16, F16 or F32", fn);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_norm_act_dropout_tiles(int dtype, int64_t voxels, int C) { return na_blocks(voxels, C, dtype == BPX_F32 ? 4 : 8); }
+
+extern "C" int bpx_norm_act_dropout_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act, float p,
+                                        uint64_t seed, const uint64_t* counter_d, int site, uint8_t* mask_io_d, int mask_mode, bpx_tensor g,
+                                        float* red_part_d, bpx_stream_t stream) {
+  const char* fn = "bpx_norm_act_dropout_bwd";
+  BPX_CHECK(dy.cs == 0 && x.cs == 0 && g.cs == 0 && x.ld == x.C && dy.ld == dy.C && g.ld == g.C, "%s: dense tensors only", fn);
+  BPX_CHECK(dy.ptr && x.ptr && g.ptr && rec_d && red_part_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C == dy.C && x.C == g.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
+  BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
+  DropArgs d{};
+  if (drop_args(fn, p, seed, counter_d, site, mask_io_d, mask_mode == 2 ? 0 : mask_mode, d)) return 1;   // (the backward never writes the mask)
+  if ((int64_t)N * voxels == 0) return 0;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
+  dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
+  const size_t shm = (size_t)256 * 2 * kpl * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == BPX_BF16)
+    norm_act_drop_bwd_kernel<uint16_t, uint16_t><<<grid, 256, shm, s>>>((const uint16_t*)dy.ptr, dy.ld, (const uint16_t*)x.ptr, x.ld, rec_d, act, (uint16_t*)g.ptr, g.ld, x.C, voxels, red_part_d, d);
+  else if (dtype == BPX_MIX16)
+    norm_act_drop_bwd_kernel<uint16_t, f16_t><<<grid, 256, shm, s>>>((const uint16_t*)dy.ptr, dy.ld, (const f16_t*)x.ptr, x.ld, rec_d, act, (uint16_t*)g.ptr, g.ld, x.C, voxels, red_part_d, d);
+  else if (dtype == BPX_F32)
+    norm_act_drop_bwd_kernel<float, float><<<grid, 256, shm, s>>>((const float*)dy.ptr, dy.ld, (const float*)x.ptr, x.ld, rec_d, act, (float*)g.ptr, g.ld, x.C, voxels, red_part_d, d);
+  else BPX_FAIL("%s: dtype must be BF16, MIX16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

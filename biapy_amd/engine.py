@@ -57,6 +57,7 @@ class NetConfig:
     ndim: int = 3                             # 2: (B,C,Y,X) tensors, run as one-z-slice volumes (z_down is then 1 everywhere)
     post_up: int = 0                          # super-resolution "post" up-sampling ConvTranspose3d(fm0, fm0, k = s = (post_up, 2, 2)) in front
     #                                           of the heads (resunet.py:326-333, :399-400); 0 = none, else the z factor (1 or 2)
+    dropout: Optional[Sequence[float]] = None # MODEL.DROPOUT_VALUES: one probability per level, the last one for the bottleneck (resunet.py:250, :270, :299); None / 0 = none
 
     def __post_init__(self):
         fm = list(self.feature_maps)
@@ -92,6 +93,10 @@ class NetConfig:
         if sum(self.out_channels) > 4 or fm[0] not in (16, 32):
             raise NotImplementedError("output head supports <= 4 channels from 16 or 32 features")
         self.depth = len(fm) - 1
+        dv = [0.0] * len(fm) if self.dropout is None else [float(v) for v in list(self.dropout)]
+        if len(dv) < len(fm) or any(not (0.0 <= v < 1.0) for v in dv):
+            raise ValueError(f"dropout={self.dropout!r}: one probability in [0, 1) per level and one for the bottleneck")
+        self.dropout = tuple(dv[: len(fm) - 1]) + (dv[-1],)      # levels 0 .. depth-1, bottleneck (the reference indexes drop_values[i] and [-1])
 
 
 def set_compute_dtype(model, dtype: torch.dtype) -> torch.dtype:
@@ -206,6 +211,9 @@ class _Blk:
     rec_h: Optional[torch.Tensor] = None
     out: Optional[torch.Tensor] = None     # buffer holding the block output
     out_c0: int = 0
+    drop_p: float = 0.0                    # dropout of the block (blocks.py:163), active in training mode only
+    site: int = 0                          # index of the block's dropout site (its own random stream)
+    a: Optional[torch.Tensor] = None       # with dropout: the materialised act(norm(h)) * keep / (1 - p) the second convolution read
 
 
 class ResUNetEngine:
@@ -233,6 +241,12 @@ class ResUNetEngine:
         # latency chains with one workgroup or less per CU) as a parallel branch of the captured graph: measured SLOWER too - same box, 30 graph-replayed
         # steps: off 9.74 ms, <= 16^3 9.84 ms, <= 32^3 9.91 ms - and left off (BPX_SIDE_VPS=<voxels> switches it on).
         self.side_small_vps = int(os.environ.get("BPX_SIDE_VPS", "0"))
+        # dropout (p > 0 levels, training mode): see _drop_args
+        self.drop_active = False               # set by the module before every forward (= module.training)
+        self.drop_seed: Optional[int] = None
+        self._drop_counter: Optional[torch.Tensor] = None
+        self.drop_mask_io: Optional[Dict[int, torch.Tensor]] = None   # tests: {site: uint8 keep flags}; drop_mask_mode 1 = use them, 2 = record the drawn ones
+        self.drop_mask_mode = 0
         self._side_used = False
         self._pack_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._pack_versions: Dict[Tuple[int, int, int], Tuple[int, int]] = {}
@@ -282,6 +296,32 @@ class ResUNetEngine:
                 self._keep.append(self._ws)   # a side-stream kernel may still be using the old slab
             self._ws = torch.empty(max(nbytes, 32 << 20), dtype=torch.uint8, device=dev)
         return self._ws
+
+    # ---- dropout --------------------------------------------------------------------------------------
+    # nn.Dropout(p) of a block sits behind Conv -> Norm -> Act of its first ConvBlock (blocks.py:163), i.e. on the tensor the second convolution's
+    # fused prologue would form on the fly.  For p > 0 in training mode that tensor is materialised with the mask applied
+    # (bpx_norm_act_dropout_fwd), the second convolution runs without a prologue, and its backward is the plain dgrad followed by
+    # bpx_norm_act_dropout_bwd (mask, activation derivative, IN-backward sums).  The mask is a counter-based function of (seed, step counter, site,
+    # element): nothing is stored, a replayed graph draws a new mask at every step because the counter lives on the device.
+    def _drop_state(self, dev):
+        if self.drop_seed is None:
+            self.drop_seed = int(torch.initial_seed()) & ((1 << 63) - 1)
+        if self._drop_counter is None or self._drop_counter.device != dev:
+            self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        return self._drop_counter
+
+    def _drop_mask(self, blk: "_Blk", numel: int, dev):
+        """(pointer, mode) of the test hook's keep-flag buffer for this site."""
+        if not self.drop_mask_mode:
+            return None, 0
+        if self.drop_mask_io is None:
+            self.drop_mask_io = {}
+        m = self.drop_mask_io.get(blk.site)
+        if m is None:
+            assert self.drop_mask_mode == 2, f"dropout site {blk.site}: no mask given"
+            m = self.drop_mask_io[blk.site] = torch.zeros(numel, dtype=torch.uint8, device=dev)
+        assert m.numel() == numel and m.dtype == torch.uint8 and m.is_cuda
+        return m.data_ptr(), self.drop_mask_mode
 
     def _wgrad(self, B, S, x: "L.Tensor", rec, act, dy: "L.Tensor", k, dw, db, st, dev, db2=None):
         """db2: a second bias gradient that takes the same sums (the shortcut bias of a residual block)."""
@@ -424,6 +464,15 @@ class ResUNetEngine:
                                        L.NULL_T, None, None, L.tview(blk.h), part.data_ptr(), st))
         blk.rec_h = _recs(B, C1, dev)
         _Stats.finalize(part, B, tiles, C1, vox, P[k["g1"]], P[k["be1"]], blk.rec_h, C1, 0, st, self.cfg.gn_groups)
+        # ---- dropout: conv2 reads the materialised, masked activation instead of forming it in its prologue -------
+        x2, rec2, act2 = L.tview(blk.h), blk.rec_h.data_ptr(), self.act
+        if blk.drop_p > 0.0 and self.drop_active:
+            ctr = self._drop_state(dev)
+            blk.a = torch.empty_like(blk.h)
+            mptr, mmode = self._drop_mask(blk, blk.h.numel(), dev)
+            L.check(lib.bpx_norm_act_dropout_fwd(self.dt, B, vox, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, blk.drop_p, self.drop_seed, ctr.data_ptr(),
+                                                 blk.site, mptr, mmode, L.tview(blk.a), st))
+            x2, rec2, act2 = L.tview(blk.a), None, 0
         # ---- conv2 (+ shortcut, + residual add) -> out (+ stats) ----------------------------------
         wp2 = self._pack(P[k["w2"]], L.PK_K3, C1, C1, cache)
         tiles2 = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
@@ -435,11 +484,11 @@ class ResUNetEngine:
             sc = L.tview(blk.x, blk.x_c0, blk.cin)
             wsc_ptr = self._pack(P[k["wsc"]], L.PK_K1, blk.cin, C1, cache).data_ptr()
         if pool is not None:
-            L.check(lib.bpx_conv3d_fwd_pool(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, wp2.data_ptr(),
+            L.check(lib.bpx_conv3d_fwd_pool(self.dt, B, D, H, W, x2, rec2, act2, wp2.data_ptr(),
                                             P[k["b2"]].data_ptr(), sc, wsc_ptr, P[k["bsc"]].data_ptr(),
                                             L.tview(blk.out, blk.out_c0, C1), L.ptr(part2), pool[0], L.tview(pool[1]), pool[2].data_ptr(), st))
         else:
-            L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, wp2.data_ptr(),
+            L.check(lib.bpx_conv3d_fwd(self.dt, B, D, H, W, x2, rec2, act2, wp2.data_ptr(),
                                        P[k["b2"]].data_ptr(), sc, wsc_ptr, P[k["bsc"]].data_ptr(),
                                        L.tview(blk.out, blk.out_c0, C1), L.ptr(part2), st))
         return part2, tiles2
@@ -459,6 +508,8 @@ class ResUNetEngine:
             assert x.is_cuda and x.dtype == torch.float32 and x.dim() == cfg.ndim + 2
         if cfg.ndim == 2:
             x = x.unsqueeze(2)
+        if self.drop_active and any(v > 0 for v in cfg.dropout):
+            self._drop_state(x.device).add_(1)          # a new mask per forward pass (a device value: replayed graphs advance it too)
         P_orig = P
         if cache_weights and torch.cuda.is_current_stream_capturing():
             # a captured forward must contain its own pack kernels: operands cached during the warm-up would freeze the
@@ -522,7 +573,7 @@ class ResUNetEngine:
         # ---------------- encoder ------------------------------------------------------------------
         for i in range(Lv):
             blk = _Blk(keys=block_keys(f"down_path.{i}", i == 0), first=(i == 0), S=S[i], cin=(cfg.in_ch if i == 0 else fm[i - 1]),
-                       cout=fm[i], x=cur, x_c0=0, rec_x=cur_rec, h=buf(i, fm[i]), out=cat[i], out_c0=fm[i + 1])
+                       cout=fm[i], x=cur, x_c0=0, rec_x=cur_rec, h=buf(i, fm[i]), out=cat[i], out_c0=fm[i + 1], drop_p=cfg.dropout[i], site=i)
             # pool -> P_i (+ stats) and the pre-norm record of the next block; fused into the block's last conv where the
             # lean kernel runs (>= 64^3 levels, bf16): the output slice is then not read again
             pooled = buf(i + 1, fm[i])
@@ -549,7 +600,7 @@ class ResUNetEngine:
             cur, cur_rec = pooled, rec
         # ---------------- bottleneck ----------------------------------------------------------------
         bot = _Blk(keys=block_keys("bottleneck", False), first=False, S=S[Lv], cin=fm[Lv - 1], cout=fm[Lv], x=cur, rec_x=cur_rec,
-                   h=buf(Lv, fm[Lv]), out=buf(Lv, fm[Lv]), out_c0=0)
+                   h=buf(Lv, fm[Lv]), out=buf(Lv, fm[Lv]), out_c0=0, drop_p=cfg.dropout[Lv], site=Lv)
         self._res_block_fwd(P, bot, B, img, st, cache_weights, want_out_stats=False)
         blocks.append(bot)
         # ---------------- decoder -------------------------------------------------------------------
@@ -577,7 +628,7 @@ class ResUNetEngine:
                 _Stats.finalize(upart, B, utiles, Cup, vox, g0[:Cup], be0[:Cup], rec, Ccat, 0, st)
                 _Stats.finalize(spart, B, stiles, fm[i], vox, g0[Cup:], be0[Cup:], rec, Ccat, Cup, st)
             blk = _Blk(keys=block_keys(pre, False), first=False, S=S[i], cin=Ccat, cout=fm[i], x=cat[i], x_c0=0, rec_x=rec,
-                       h=buf(i, fm[i]), out=buf(i, fm[i]), out_c0=0)
+                       h=buf(i, fm[i]), out=buf(i, fm[i]), out_c0=0, drop_p=cfg.dropout[i], site=Lv + 1 + j)
             self._res_block_fwd(P, blk, B, img, st, cache_weights, want_out_stats=False)
             blocks.append(blk)
             ups.append((wk, bk, dec_in, Cup, S[i + 1], szl))
@@ -623,8 +674,11 @@ class ResUNetEngine:
         T = self.gdtype
         # conv2 weight/bias grad, shortcut weight grad
         # both biases add to the same tensor: identical gradients, written by the same reduction
-        fused2 = self._bwd_fused_ok(B, blk.S, C1, dOut.C)
-        if not fused2:
+        dropped = blk.a is not None                      # training-mode dropout: conv2 read the materialised, masked activation blk.a
+        fused2 = not dropped and self._bwd_fused_ok(B, blk.S, C1, dOut.C)
+        if dropped:
+            self._wgrad(B, blk.S, L.tview(blk.a), None, 0, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
+        elif not fused2:
             self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
         if blk.first and self.cfg.in_ch == 1:
             ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
@@ -636,7 +690,14 @@ class ResUNetEngine:
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
         self._keep.append(g1)   # read by the side-stream wgrad of conv1
         w2t = self._pack(P[k["w2"]], L.PK_K3_T, C1, C1, False)
-        if fused2:   # dgrad + wgrad of conv2 in one pass over (dOut, h)
+        if dropped:   # plain dgrad -> gradient of the masked activation; then mask, activation derivative and the IN-backward sums in one pass
+            L.check(lib.bpx_conv3d_dgrad(self.gdt, B, D, H, W, dOut, w2t.data_ptr(), L.NULL_T, None, 0, L.tview(g1), None, st))
+            tiles = lib.bpx_norm_act_dropout_tiles(self.gdt, vox, C1)
+            red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
+            mptr, mmode = self._drop_mask(blk, g1.numel(), dev)
+            L.check(lib.bpx_norm_act_dropout_bwd(self.bdt, B, vox, L.tview(g1), L.tview(blk.h), blk.rec_h.data_ptr(), self.act, blk.drop_p, self.drop_seed,
+                                                 self._drop_counter.data_ptr(), blk.site, mptr, 1 if mmode else 0, L.tview(g1), red.data_ptr(), st))
+        elif fused2:   # dgrad + wgrad of conv2 in one pass over (dOut, h)
             tiles, red = self._bwd_fused(B, blk.S, dOut, w2t, L.tview(blk.h), blk.rec_h, L.tview(g1), G[k["w2"]], G[k["b2"]], G[k["bsc"]], st, dev)
         else:
             tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)

@@ -23,7 +23,7 @@ softplus, linear / none), the classification head (``"class"`` in ``output_chann
 ``explicit_activations`` (resunet.py:408-443) are built and pinned to fixtures generated from the reference class.
 
 Configurations outside the accelerated hot path (normalisation other than "in" / "gn", larger_io, separated decoders, contrastive head,
-``upsample_layer="upsampling"``, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2, pre-activation order, dropout, softmax as a BLOCK
+``upsample_layer="upsampling"``, YX_DOWN != 2, Z_DOWN outside {1,2}, nconvs != 2, pre-activation order, softmax as a BLOCK
 activation) raise ``NotImplementedError`` at construction: they stay on the reference's plain-PyTorch classes, selected by the same registry.
 """
 from __future__ import annotations
@@ -261,8 +261,9 @@ class ResUNet(nn.Module):
                 raise ValueError(f"upsampling_position={upsampling_position!r}")
         if conv_block_order != "conv_norm_act" or list(conv_layers)[: depth + 1] != [2] * (depth + 1):
             unsupported("conv_block_order != 'conv_norm_act' or conv_layers != 2")
-        if any(float(d) > 0 for d in drop_values):
-            unsupported("dropout")
+        dv = [float(d) for d in drop_values]
+        if len(dv) < depth + 1 and any(d > 0 for d in dv):
+            raise ValueError("'drop_values' needs one value per level and one for the bottleneck")
         self.depth = depth
         self.ndim = ndim
         self.z_down, self.yx_down = z_down, yx_down
@@ -299,7 +300,8 @@ class ResUNet(nn.Module):
         in_ch = image_shape[-1]
         zd = [int(v) for v in list(z_down)[:depth]] if ndim == 3 else [1] * depth
         self.cfg = NetConfig(in_ch=16 if self.sr_pre else in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
-                             normalization=normalization, z_down=zd, ndim=ndim, post_up=self.sr_post)
+                             normalization=normalization, z_down=zd, ndim=ndim, post_up=self.sr_post,
+                             dropout=(dv[:depth] + [dv[-1]]) if any(d > 0 for d in dv) else None)
         # kernel of level i (resunet.py:239-241, :260-262, :282-284): (3,3) in 2D, (1,3,3) where MODEL.ISOTROPY[i] is False
         ks = [(3, 3) if ndim == 2 else ((3, 3, 3) if iso[i] else (1, 3, 3)) for i in range(depth + 1)]
         self.compute_dtype = compute_dtype
@@ -346,6 +348,7 @@ class ResUNet(nn.Module):
             if self.compute_dtype not in self._engines:
                 self._engines[self.compute_dtype] = ResUNetEngine(self.cfg, self.compute_dtype)
             self._engine = self._engines[self.compute_dtype]
+        self._engine.drop_active = bool(self.training)      # nn.Dropout semantics: masks in training mode only (blocks.py:163)
         return self._engine
 
     def train(self, mode: bool = True):

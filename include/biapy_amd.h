@@ -331,6 +331,22 @@ int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_n
 int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act,
                      bpx_tensor addend, bpx_tensor g, float* red_part_d, bpx_stream_t stream);
 
+/* Dropout of a residual block (biapy/models/blocks.py:163: `nn.Dropout(p)` after Conv -> Norm -> Act, element-wise) - only for p > 0; p = 0 (BiaPy's
+ * default DROPOUT_VALUES) keeps the fused prologue of the block's second convolution.
+ *   fwd: y = act(scale*x + shift) * keep / (1 - p)        (the tensor the second convolution then reads WITHOUT a prologue)
+ *   bwd: g = dy * keep / (1 - p) * act'(scale*x + shift), red_part_d = [N][bpx_norm_act_dropout_tiles()][2][C] partial sums for bpx_norm_bwd_finalize
+ * keep = Philox4x32-10(key = seed, counter = (element / 4, site, *counter_d)) >= p * 2^32 over the linear index of the dense NDHWC tensor: forward and
+ * backward regenerate the same mask, nothing is stored; *counter_d is a DEVICE uint64 the caller bumps once per forward pass (a replayed graph
+ * draws a new mask each time).  Not the reference's random stream (torch's CPU / CUDA generators cannot be reproduced): parity is held with the
+ * mask made explicit - mask_mode 1 reads the keep flags (uint8 per element) from mask_io_d instead of drawing them, 2 also writes the drawn
+ * flags there (forward only), 0 ignores it.  dtype fwd: BF16, F16, F32; bwd: BF16, MIX16 (x fp16), F32.  Dense tensors (ld == C). */
+int bpx_norm_act_dropout_tiles(int dtype, int64_t voxels, int C);
+int bpx_norm_act_dropout_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, float p, uint64_t seed,
+                             const uint64_t* counter_d, int site, uint8_t* mask_io_d, int mask_mode, bpx_tensor y, bpx_stream_t stream);
+int bpx_norm_act_dropout_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy, bpx_tensor x, const bpx_norm_rec* rec_d, int act, float p,
+                             uint64_t seed, const uint64_t* counter_d, int site, uint8_t* mask_io_d, int mask_mode, bpx_tensor g,
+                             float* red_part_d, bpx_stream_t stream);
+
 /* Channel attention of the RCAN trunk (biapy/models/rcan.py: ChannelAttention.forward `x * module(x)`, RCAB_rcan.forward
  * `x + module(x)`): y = [x +] scale[n,c] * h [+ offset[n,c]] with per-(sample, channel) fp32 factors (x.ptr / offset_d may be
  * null; y may alias h), and the reduction its backward needs: part_d[n][bpx_norm_act_tiles()][C] partial sums of a*b over

@@ -71,8 +71,9 @@ def _conv(x, sd, key):
     return (F.conv2d if w.dim() == 4 else F.conv3d)(x, w, sd.get(key + ".bias"), padding=pad)
 
 
-def res_conv_block(x, sd, prefix: str, first_block: bool, act: str, norm: str):
-    """block(x) + shortcut(x) for the default ``conv_norm_act`` order with two convolutions."""
+def res_conv_block(x, sd, prefix: str, first_block: bool, act: str, norm: str, drop=None):
+    """block(x) + shortcut(x) for the default ``conv_norm_act`` order with two convolutions.
+    ``drop`` = (p, keep mask): ``nn.Dropout(p)`` of the first ConvBlock (blocks.py:163: after Conv -> Norm -> Act) with its mask made explicit."""
     h = x
     i = 0
     if not first_block:
@@ -84,6 +85,9 @@ def res_conv_block(x, sd, prefix: str, first_block: bool, act: str, norm: str):
     h = _conv(h, sd, f"{prefix}.block.{i}.block.0")
     h = _norm(h, sd, f"{prefix}.block.{i}.block.1", norm)
     h = _act(h, act)
+    if drop is not None:
+        p, keep = drop
+        h = h * keep.to(h.dtype) / (1.0 - p)
     h = _conv(h, sd, f"{prefix}.block.{i + 1}.block.0")
     return h + _conv(x, sd, f"{prefix}.shortcut.0")
 
@@ -97,8 +101,12 @@ def resunet_forward(
     activation: str = "elu",
     normalization: str = "in",
     n_heads: int = 1,
+    dropout: Optional[Dict[str, tuple]] = None,
 ) -> torch.Tensor:
-    """x: (B,C,Z,Y,X) fp32 -> logits (B,sum(out_ch),Z,Y,X)."""
+    """x: (B,C,Z,Y,X) fp32 -> logits (B,sum(out_ch),Z,Y,X).
+    ``dropout``: {block prefix ("down_path.0", "bottleneck", "up_paths.0.1.conv_block", ...): (p, keep mask (B,C,Z,Y,X))} - training-mode dropout
+    (resunet.py:250, :270, :299 hand ``drop_values`` to the blocks) with the masks made explicit; None = evaluation mode / p = 0."""
+    dropout = dropout or {}
     depth = len(feature_maps) - 1
     z_down = list(z_down) if z_down is not None else [2] * depth
     yx_down = list(yx_down) if yx_down is not None else [2] * depth
@@ -108,10 +116,10 @@ def resunet_forward(
         w = sd["pre_upsampling.weight"]
         x = F.conv_transpose3d(x, w, sd["pre_upsampling.bias"], stride=tuple(w.shape[2:]))
     for i in range(depth):
-        x = res_conv_block(x, sd, f"down_path.{i}", i == 0, activation, normalization)
+        x = res_conv_block(x, sd, f"down_path.{i}", i == 0, activation, normalization, dropout.get(f"down_path.{i}"))
         skips.append(x)
         x = F.max_pool2d(x, yx_down[i]) if two_d else F.max_pool3d(x, (z_down[i], yx_down[i], yx_down[i]))
-    x = res_conv_block(x, sd, "bottleneck", False, activation, normalization)
+    x = res_conv_block(x, sd, "bottleneck", False, activation, normalization, dropout.get("bottleneck"))
     for j, i in enumerate(range(depth - 1, -1, -1)):
         s = (z_down[i], yx_down[i], yx_down[i])
         if two_d:
@@ -119,7 +127,7 @@ def resunet_forward(
         else:
             up = F.conv_transpose3d(x, sd[f"up_paths.0.{j}.up.weight"], sd[f"up_paths.0.{j}.up.bias"], stride=s)
         x = torch.cat([up, skips[i]], 1)
-        x = res_conv_block(x, sd, f"up_paths.0.{j}.conv_block", False, activation, normalization)
+        x = res_conv_block(x, sd, f"up_paths.0.{j}.conv_block", False, activation, normalization, dropout.get(f"up_paths.0.{j}.conv_block"))
     if "post_upsampling.weight" in sd:                 # resunet.py:326-333 / :399-400
         w = sd["post_upsampling.weight"]
         x = F.conv_transpose3d(x, w, sd["post_upsampling.bias"], stride=tuple(w.shape[2:]))

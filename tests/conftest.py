@@ -117,6 +117,14 @@ def unet_golden():
 
 
 @pytest.fixture(scope="session")
+def resunet_dropout_golden():
+    """Reference ResUNet in training mode with drop_values > 0, the masks torch drew captured (make_golden.py resunet_dropout)."""
+    import numpy as np
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "resunet_dropout_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def resunet_activations_golden():
     import numpy as np
 

@@ -893,6 +893,76 @@ def resunet_class_head_fixtures():
     print("resunet_class_head_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_class_head_golden.npz")) // 1024, "KiB")
 
 
+def resunet_dropout_fixtures():
+    """The reference ResUNet in TRAINING mode with drop_values > 0 (resunet.py:250, :270, :299 -> blocks.py:163 nn.Dropout after Conv -> Norm -> Act of
+    every block's first ConvBlock): the masks torch drew are captured by forward hooks on the nn.Dropout modules (keep = output != 0 where the
+    input != 0), so that the oracle - and the device, through its explicit-mask mode - can be held to the reference's logits, loss and gradients
+    with the random draw taken out of the comparison."""
+    rmod = shim.load("biapy.models.resunet")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import net_oracle
+
+    out = {}
+    fm, patch, drops = [16, 32], (16, 16, 16), [0.1, 0.3]
+    torch.manual_seed(83)
+    with quiet():
+        net = rmod.ResUNet(image_shape=patch + (1,), activation="elu", feature_maps=fm, drop_values=drops, normalization="in", k_size=3,
+                           upsample_layer="convtranspose", yx_down=[2], z_down=[2], output_channels=[1], output_channel_info=["F"],
+                           head_activations=["ce_sigmoid"], isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2)
+    g = torch.Generator().manual_seed(183)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if v.ndim == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    B = 2
+    xl = torch.randn(B, *patch, 1, generator=g)
+    x = xl.permute(0, 4, 1, 2, 3)
+    tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).to(torch.float32)
+    masks, ps = {}, {}
+    for name, m in net.named_modules():
+        if isinstance(m, torch.nn.Dropout):
+            prefix = name.split(".block.")[0]           # "down_path.0" / "bottleneck" / "up_paths.0.1.conv_block"
+
+            def hook(mod, inp, outp, prefix=prefix):
+                if not mod.training:
+                    return
+                assert prefix not in masks, (prefix, sorted(masks))
+                masks[prefix] = (outp != 0) | (inp[0] == 0)
+                ps[prefix] = float(mod.p)
+            m.register_forward_hook(hook)
+    net.train()
+    torch.manual_seed(283)
+    logits = net(x)
+    loss = torch.nn.BCEWithLogitsLoss()(logits, tgt)
+    loss.backward()
+    assert sorted(masks) == sorted(["down_path.0", "bottleneck", "up_paths.0.0.conv_block"]), sorted(masks)
+    out["x"], out["target"] = xl.numpy(), tgt.numpy().astype(np.uint8)
+    for k, v in net.state_dict().items():
+        out[f"sd/{k}"] = v.detach().numpy()
+    for k, mk in masks.items():
+        out[f"mask/{k}"] = np.packbits(mk.numpy().astype(np.uint8).ravel())
+        out[f"mask_shape/{k}"] = np.array(mk.shape)
+        out[f"p/{k}"] = np.array(ps[k], dtype=np.float64)
+        print(f"dropout site {k}: p = {ps[k]}, kept {mk.float().mean().item():.4f}")
+    out["logits"], out["loss"] = logits.detach().numpy(), np.array(loss.item(), dtype=np.float64)
+    for k, p_ in net.named_parameters():
+        out[f"gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
+    for k in ["down_path.0.block.0.block.0.weight", "down_path.0.block.1.block.0.weight", "bottleneck.block.3.block.0.weight", "up_paths.0.0.conv_block.block.2.block.0.weight",
+              "bottleneck.block.2.block.1.weight", "heads.0.weight"]:
+        out[f"grad/{k}"] = dict(net.named_parameters())[k].grad.numpy()
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    lo = net_oracle.resunet_forward(sd, x, fm, dropout={k: (ps[k], masks[k]) for k in masks})
+    err = (lo - logits.detach()).abs().max().item()
+    print(f"resunet dropout: oracle (explicit masks) vs reference {err:.3e}")
+    assert err < 2e-5
+    net.eval()
+    with torch.no_grad():
+        out["logits_eval"] = net(x).numpy()
+    out["feature_maps"], out["drop_values"] = np.array(fm), np.array(drops)
+    np.savez_compressed(os.path.join(HERE, "resunet_dropout_golden.npz"), **out)
+    print("resunet_dropout_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_dropout_golden.npz")) // 1024, "KiB")
+
+
 def chunked_fixtures():
     """By-chunks tiler: the reference generator's own ``_patch_coords`` / ``extract_and_prepare_sample`` on seeded uint8
     volumes (the class is loaded with the third-party modules it never calls on this path stubbed; a bare object carrying the
@@ -1228,7 +1298,7 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "resunet_dropout", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -1259,6 +1329,8 @@ if __name__ == "__main__":
         resunet_variants_fixtures()
     if "resunet_activations" in which:
         resunet_activations_fixtures()
+    if "resunet_dropout" in which:
+        resunet_dropout_fixtures()
     if "resunet_class_head" in which:
         resunet_class_head_fixtures()
     if "chunked" in which:

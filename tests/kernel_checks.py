@@ -2134,3 +2134,127 @@ def check_pw_stream(mix=True, B=2, vps=131072, K=16, planar=True, seed=0):
     return [_res(tag + ".vs_fp32", relerr(a, y_ref), 1.5e-2), _res(tag + ".same_bits_as_tile_kernel", 0 if torch.equal(a.view(torch.int16), c.view(torch.int16)) else 1, 0,
                                                                    extra=f"max diff {(a.float() - c.float()).abs().max().item():.2e}"),
             _res(tag + ".run_to_run_bits", 0 if torch.equal(a.view(torch.int16), b.view(torch.int16)) else 1, 0)]
+
+
+def _dropout_fixture_masks(golden):
+    out = {}
+    for k in golden.files:
+        if k.startswith("mask/"):
+            name = k[5:]
+            shape = tuple(int(v) for v in golden[f"mask_shape/{name}"])
+            n = int(np.prod(shape))
+            out[name] = (float(golden[f"p/{name}"]), torch.from_numpy(np.unpackbits(golden[k])[:n].reshape(shape).astype(bool)))
+    return out
+
+
+def _dropout_sites(depth):
+    """engine site index -> block prefix of the reference module tree"""
+    s = {i: f"down_path.{i}" for i in range(depth)}
+    s[depth] = "bottleneck"
+    for j in range(depth):
+        s[depth + 1 + j] = f"up_paths.0.{j}.conv_block"
+    return s
+
+
+def check_network_dropout(dtype, golden):
+    """MODEL.DROPOUT_VALUES > 0 on the device.  (i) With the reference's own masks given to the kernels (mask mode 1): logits, loss, gradient norms
+    and six full gradients of the REFERENCE's training-mode step (resunet_dropout_golden.npz).  (ii) With the device's random stream (mask mode 2
+    records what was drawn): keep rates, a new mask per forward, forward and backward agree on the mask (the CPU oracle given the recorded
+    masks reproduces logits and gradients), evaluation mode ignores dropout."""
+    tagd = _mode(dtype)[0]
+    fm = [int(v) for v in golden["feature_maps"]]
+    depth = len(fm) - 1
+    drops = [float(v) for v in golden["drop_values"]]
+    sd = {k[3:]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("sd/")}
+    x = torch.from_numpy(golden["x"]).permute(0, 4, 1, 2, 3).contiguous()
+    tgt = torch.from_numpy(golden["target"]).float()
+    masks = _dropout_fixture_masks(golden)
+    sites = _dropout_sites(depth)
+    P = {k: v.to(DEV) for k, v in sd.items()}
+    tag = f"resunet_dropout[{tagd}]"
+    res = []
+
+    def step(eng):
+        logits, ctx = eng.forward(P, x.to(DEV), head_act=0, save=True)
+        lg = logits.detach().clone().requires_grad_(True)
+        loss = F.binary_cross_entropy_with_logits(lg, tgt.to(DEV))
+        loss.backward()
+        G = eng.backward(P, ctx, lg.grad)
+        torch.cuda.synchronize()
+        return logits, loss, G
+
+    # (i) the reference's masks
+    eng = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, dropout=drops[:depth] + [drops[-1]]), dtype)
+    eng.drop_active = True
+    eng.drop_mask_mode = 1
+    eng.drop_mask_io = {s: masks[pre][1].permute(0, 2, 3, 4, 1).contiguous().view(-1).to(torch.uint8).to(DEV) for s, pre in sites.items()}
+    logits, loss, G = step(eng)
+    lo_ref = torch.from_numpy(golden["logits"])
+    res += [_res(tag + ".ref_masks.logits_rel", (logits.cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), LOGITS_TOL[tagd]),
+            _res(tag + ".ref_masks.loss", abs(loss.item() - float(golden["loss"])), LOSS_TOL[tagd])]
+    gmax = max(float(golden[k]) for k in golden.files if k.startswith("gradnorm/"))
+    floor = (GRAD_FLOOR_F32 if dtype == torch.float32 else GRAD_FLOOR_BF16) * gmax
+    worst, wname = 0.0, ""
+    for k in golden.files:
+        if k.startswith("gradnorm/"):
+            ref = float(golden[k])
+            e = abs(G[k[9:]].norm().item() - ref) / max(ref, floor)
+            if e > worst:
+                worst, wname = e, k[9:]
+    res.append(_res(tag + ".ref_masks.grad_norms_rel_worst", worst, GRAD_TOL[tagd], extra=wname))
+    worst, wname = 0.0, ""
+    for k in golden.files:
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(golden[k])
+            e = (G[k[5:]].cpu() - ref).norm().item() / max(ref.norm().item(), 1e-6 * gmax)
+            if e > worst:
+                worst, wname = e, k[5:]
+    res.append(_res(tag + ".ref_masks.full_grads_rel_l2_worst", worst, GRAD_TOL[tagd], extra=wname))
+
+    # (ii) the device's own stream
+    eng2 = ResUNetEngine(NetConfig(in_ch=1, feature_maps=fm, dropout=drops[:depth] + [drops[-1]]), dtype)
+    eng2.drop_active = True
+    eng2.drop_mask_mode = 2
+    logits_a, loss_a, G_a = step(eng2)
+    drawn_a = {s: m.clone() for s, m in eng2.drop_mask_io.items()}
+    worst = 0.0
+    for s, m in drawn_a.items():
+        p = eng2.cfg.dropout[s if s <= depth else depth - 1 - (s - depth - 1)]
+        n = m.numel()
+        z = abs(m.float().mean().item() - (1 - p)) / ((p * (1 - p) / n) ** 0.5)
+        worst = max(worst, z)
+    res.append(_res(tag + ".keep_rate_sigmas_worst", worst, 5.0))
+    from oracle import net_oracle
+    B = x.shape[0]
+
+    def as_ncdhw(s, m):
+        C = fm[s] if s <= depth else fm[depth - 1 - (s - depth - 1)]
+        S = tuple(int(v) >> (s if s <= depth else depth - 1 - (s - depth - 1)) for v in x.shape[2:])
+        return m.view(B, *S, C).permute(0, 4, 1, 2, 3).bool().cpu()
+
+    dm = {sites[s]: (eng2.cfg.dropout[s if s <= depth else depth - 1 - (s - depth - 1)], as_ncdhw(s, m)) for s, m in drawn_a.items()}
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lo = net_oracle.resunet_forward(sdr, x, fm, dropout=dm)
+    lref = F.binary_cross_entropy_with_logits(lo, tgt)
+    lref.backward()
+    res.append(_res(tag + ".own_masks.logits_vs_oracle", (logits_a.cpu() - lo.detach()).abs().max().item() / lo.detach().abs().max().item(), LOGITS_TOL[tagd]))
+    gm = max(v.grad.norm().item() for v in sdr.values())
+    worst, wname = 0.0, ""
+    for kname, v in sdr.items():
+        if v.grad is None or kname not in G_a:
+            continue
+        e = (G_a[kname].cpu() - v.grad).norm().item() / max(v.grad.norm().item(), (1e-3 if dtype == torch.float32 else 5e-2) * gm)
+        if e > worst:
+            worst, wname = e, kname
+    res.append(_res(tag + ".own_masks.grads_vs_oracle_rel_l2_worst", worst, GRAD_TOL[tagd], extra=wname))
+    eng2.drop_mask_io = None
+    logits_b, _, _ = step(eng2)
+    same = all(torch.equal(drawn_a[s], eng2.drop_mask_io[s]) for s in drawn_a)
+    res.append(_res(tag + ".new_mask_every_forward", 1 if same else 0, 0))
+    eng2.drop_active = False
+    eng2.drop_mask_mode = 0
+    lo_eval, _ = eng2.forward(P, x.to(DEV), head_act=0, save=False)
+    torch.cuda.synchronize()
+    le = torch.from_numpy(golden["logits_eval"])
+    res.append(_res(tag + ".eval_mode_ignores_dropout", (lo_eval.cpu() - le).abs().max().item() / le.abs().max().item(), LOGITS_TOL[tagd]))
+    return res

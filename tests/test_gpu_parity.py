@@ -194,6 +194,35 @@ def test_streaming_decoder_input_gradient(K, mix, B, vps, Kc, planar):
     _assert_all(K.check_pw_stream(mix, B, vps, Kc, planar))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "mix16", "bf16"])
+def test_resunet_dropout_against_the_reference_step(K, resunet_dropout_golden, dtype):
+    """MODEL.DROPOUT_VALUES > 0: with the reference's masks handed to the kernels the device reproduces the reference's training-mode logits, loss and
+    gradients; with its own Philox stream the keep rates are right, every forward draws a new mask, forward and backward agree on it (the CPU
+    oracle given the recorded masks), and evaluation mode ignores dropout."""
+    _assert_all(K.check_network_dropout(dtype, resunet_dropout_golden))
+
+
+def test_graphed_train_step_draws_a_new_dropout_mask_at_every_replay(K):
+    """The dropout step counter lives on the device: a replayed HIP graph advances it, so two replays on the same batch give different losses
+    and a model in eval mode gives the same logits twice."""
+    from biapy_amd.graphs import GraphedTrainStep
+    from biapy_amd.resunet import ResUNet
+    torch.manual_seed(5)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.2, 0.3], normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2).cuda()
+    x = torch.randn(2, 1, 32, 32, 32, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    t = (torch.rand(2, 1, 32, 32, 32, device="cuda") > 0.5).float()
+    opt = torch.optim.AdamW(m.parameters(), lr=0.0, fused=True, capturable=True)        # lr = 0: the weights stay put, only the masks change
+    step = GraphedTrainStep(m, torch.nn.BCEWithLogitsLoss(), opt, x, t)
+    losses = [float(step(x, t)) for _ in range(4)]
+    assert len({round(v, 7) for v in losses}) == 4, losses
+    assert max(losses) - min(losses) < 0.05, losses
+    m.eval()
+    with torch.no_grad():
+        a, b = m(x), m(x)
+    assert torch.equal(a, b)
+
+
 def test_adam_step_kernel_equals_torch_fused_adam(K):
     """optim.fused_step / bpx_adam_step: the optimizer step of the graphed train steps == torch's fused Adam / AdamW on the optimizer's own state
     tensors (train_engine.py:173-177 `optimizer.step()`), and it refuses what it does not reproduce."""

@@ -448,6 +448,57 @@ def test_resunet_block_activations_oracle_matches_reference(resunet_activations_
     m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
 
 
+def dropout_masks(g):
+    """{block prefix: (p, keep mask (B, C, Z, Y, X) bool)} of resunet_dropout_golden.npz."""
+    import torch
+    out = {}
+    for k in g.files:
+        if k.startswith("mask/"):
+            name = k[5:]
+            shape = tuple(int(v) for v in g[f"mask_shape/{name}"])
+            n = int(np.prod(shape))
+            out[name] = (float(g[f"p/{name}"]), torch.from_numpy(np.unpackbits(g[k])[:n].reshape(shape).astype(bool)))
+    return out
+
+
+def test_resunet_dropout_oracle_matches_reference(resunet_dropout_golden):
+    """MODEL.DROPOUT_VALUES > 0 (resunet.py:250, :270, :299 -> blocks.py:163): with the masks torch drew for the reference made explicit, the oracle
+    reproduces the reference's training-mode logits, loss and gradients; without masks it is the evaluation-mode forward; and the drop-in
+    module takes the option."""
+    import torch
+    import torch.nn.functional as F
+
+    from biapy_amd.resunet import ResUNet
+    from oracle import net_oracle
+
+    g = resunet_dropout_golden
+    fm = [int(v) for v in g["feature_maps"]]
+    sd = {k[3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(g["x"]).permute(0, 4, 1, 2, 3)
+    masks = dropout_masks(g)
+    assert sorted(masks) == ["bottleneck", "down_path.0", "up_paths.0.0.conv_block"]
+    logits = net_oracle.resunet_forward(sd, x, fm, dropout=masks)
+    loss = F.binary_cross_entropy_with_logits(logits, torch.from_numpy(g["target"]).float())
+    loss.backward()
+    assert (logits.detach() - torch.from_numpy(g["logits"])).abs().max().item() < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    for k in g.files:
+        if k.startswith("gradnorm/"):
+            ref = float(g[k])
+            assert abs(sd[k[9:]].grad.norm().item() - ref) <= 1e-4 * ref + 1e-6, k
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(g[k])
+            assert (sd[k[5:]].grad - ref).norm().item() <= 1e-4 * ref.norm().item() + 1e-7, k
+    with torch.no_grad():
+        ev = net_oracle.resunet_forward(sd, x, fm)
+    assert (ev - torch.from_numpy(g["logits_eval"])).abs().max().item() < 2e-5
+    assert (ev - logits.detach()).abs().max().item() > 1e-2                      # the masks matter
+    m = ResUNet(image_shape=(16, 16, 16, 1), activation="elu", feature_maps=fm, drop_values=[float(v) for v in g["drop_values"]], normalization="in",
+                yx_down=[2], z_down=[2], isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2)
+    m.load_state_dict({k: v.detach() for k, v in sd.items()}, strict=True)
+    assert m.cfg.dropout == (0.1, 0.3)
+
+
 def _chunked_case(g, tag):
     dim, crop, pad = tuple(int(v) for v in g[f"{tag}/dim"]), tuple(int(v) for v in g[f"{tag}/crop"]), tuple(int(v) for v in g[f"{tag}/padding"])
     vol = np.random.RandomState(int(g[f"{tag}/seed"])).randint(0, 256, size=dim + (1,)).astype(np.uint8)
