@@ -1210,6 +1210,142 @@ int launch_wgrad_k1_dma(const WgradParams& w, int groups, hipStream_t s) {
   return 1;
 }
 
+// ---- transposed-conv (k = s = 2) weight gradient as a stream (round 4) ----------------------------------------------------------------------------
+//   dW[sub][ci][co] = sum_v x[v][ci] * dy[2v + sub][co],  db[co] = sum over every dy voxel
+// The tile kernel above (wgrad_ct_kernel) gives a workgroup one (16-channel x chunk, co block): dy is staged once per x chunk, through registers, with
+// a barrier pair per 256-voxel tile - 0.17 ms for 32 -> 32 @64^3 -> 128^3 (2.25 tensor units: 3.6 TB/s).  Same recipe as wgrad_k1_dma_kernel: persistent
+// workgroups, the x chunks and the 8 sub-position gathers of dy of a TV-voxel block through an LDS-DMA ring; a workgroup owns ALL channels (x and dy
+// are read once), wave w owns sub-positions 2w, 2w + 1 - no cross-wave sum for dW.
+struct CtsParams {
+  const void* x; int x_ld; const void* dy; int dy_ld;
+  int Cin, Cout, D, H, W; int64_t voxels; int nblocks; int groups; float* part; float* dbpart;
+};
+
+template <int MC, int NS, int TV, bool XF16>
+__global__ void __launch_bounds__(256) wgrad_ct_dma_kernel(const CtsParams p) {
+  constexpr int VB = 32, SUBS = TV / 32, NCH = MC + 8 * NS, A_BYTES = MC * TV * VB, STAGE = NCH * TV * VB, RING = 3;
+  constexpr int NI = NCH * SUBS;
+  static_assert(NI % 4 == 0, "every wave issues the same number of DMA instructions per stage");
+  constexpr int IPW = NI / 4;
+  static_assert(RING * STAGE <= 131072 && IPW < 64, "ring size / vmcnt range");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RING * STAGE];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)0x80000000u, 0x00020000);
+  const uint32_t xvb = (uint32_t)p.x_ld * 2u, gvb = (uint32_t)p.dy_ld * 2u;
+  const uint32_t lane_v = (uint32_t)(lane >> 1), lane_h = (uint32_t)(lane & 1) * 16u;
+  const int64_t voxels = p.voxels;
+  const int groups = p.groups, nblocks = p.nblocks;
+  const uint32_t W = (uint32_t)p.W, H = (uint32_t)p.H;
+
+  auto issue = [=](int blk, int slot) {
+    const int64_t v0 = (int64_t)blk * TV;
+#pragma unroll
+    for (int k = 0; k < IPW; ++k) {
+      const int q = wave + 4 * k;
+      const int ch = q / SUBS, run = q % SUBS;
+      const int64_t v = v0 + run * 32 + lane_v;
+      const bool in = v < voxels;
+      const uint32_t vv = (uint32_t)v;
+      unsigned char* dst = const_cast<unsigned char*>(smem) + slot * STAGE + ch * TV * VB + run * 1024;
+      if (ch < MC) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)dst, 16, in ? vv * xvb + (uint32_t)ch * 32u + lane_h : 0x80000000u, 0, 0, 0);
+      } else {
+        const int sub = (ch - MC) / NS, ns = (ch - MC) % NS;
+        const uint32_t row = vv / W, xx = vv - row * W, zz = row / H, yy = row - zz * H;      // zz = n * D + z
+        const uint32_t hi = ((zz * 2u + (uint32_t)((sub >> 2) & 1)) * (2u * H) + 2u * yy + (uint32_t)((sub >> 1) & 1)) * (2u * W) + 2u * xx + (uint32_t)(sub & 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)dst, 16, in ? hi * gvb + (uint32_t)ns * 32u + lane_h : 0x80000000u, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4_t acc[2][MC][NS], accb[NS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[a][c][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) accb[ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int a_base = (g * 8 + (i >> 2)) * VB + (i & 3) * 8;
+  const u32x4_t ones = u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bool want_b = p.dbpart != nullptr;
+
+  const int nst = grp < nblocks ? (nblocks - grp + groups - 1) / groups : 0;
+#pragma unroll
+  for (int s = 0; s < RING - 1; ++s)
+    if (s < nst) issue(grp + s * groups, s);
+  for (int s = 0; s < nst; ++s) {
+    if (nst - 1 - s >= 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(IPW));     // block s + 1 may stay in flight
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    __syncthreads();
+    if (s + RING - 1 < nst) issue(grp + (s + RING - 1) * groups, (s + RING - 1) % RING);
+    const unsigned char* st = smem + (s % RING) * STAGE;
+#pragma unroll
+    for (int kc = 0; kc < SUBS; ++kc) {
+      u32x4_t af[MC];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const unsigned char* q = st + c * TV * VB + a_base + kc * 32 * VB;
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+        const u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VB)));
+        af[c] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+        if (XF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) af[c][e] = cvt_pk_bf16(lo16<f16_t>(af[c][e]), hi16<f16_t>(af[c][e]));
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int sub = 2 * wave + a;
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          const unsigned char* q = st + A_BYTES + (sub * NS + ns) * TV * VB + a_base + kc * 32 * VB;
+          const u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+          const u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VB)));
+          const u32x4_t gf = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+#pragma unroll
+          for (int c = 0; c < MC; ++c)
+            acc[a][c][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf), acc[a][c][ns], 0, 0, 0);
+          if (want_b) accb[ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, gf), accb[ns], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial slab [grp][sub][Cin][Cout]: this wave's two sub-positions
+  float* pp = p.part + (size_t)grp * 8 * p.Cin * p.Cout;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[((size_t)(2 * wave + a) * p.Cin + c * 16 + 4 * g + r) * p.Cout + ns * 16 + i] = acc[a][c][ns][r];
+  if (want_b) {   // every row of accb holds the column sums of this wave's sub-positions: row 0, waves in order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [wave][NS * 16]
+    if (g == 0) {
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) red[wave * NS * 16 + ns * 16 + i] = accb[ns][0];
+    }
+    __syncthreads();
+    if (tid < NS * 16) p.dbpart[(size_t)grp * p.Cout + tid] = (red[tid] + red[NS * 16 + tid]) + (red[2 * NS * 16 + tid] + red[3 * NS * 16 + tid]);
+  }
+}
+
+int g_ct_dma = 1;     // bpx_debug_set_wgrad_k1: 1 = both streaming kernels, 0 = neither, 3 = k = 1 only, 5 = transposed conv only
+// (2, 2) = 32 -> 32 @64^3 measured SLOWER than the tile kernel (223 vs 171 us: 18 chunk gathers of 64 B-strided half lines per 36 KB stage, two stages
+// in flight) and is only selectable through the hook value 7; (4, 4) = 64 -> 64 @32^3: 93 -> 59 us
+int g_ct_dma_all = 0;
+inline int cts_instance(int mc, int ns) { return (mc == 2 && ns == 2) ? (g_ct_dma_all ? 1 : 0) : (mc == 4 && ns == 4) ? 2 : 0; }
+inline int cts_tv(int inst) { return inst == 1 ? 64 : 32; }
+
 int g_cap_pct = 100;   // partial-slab caps of the two plans below in percent (bpx_debug_set_wgrad_cap)
 int g_k1_wgs = 768;    // workgroups targeted by the k = 1 launches: 768 (three per CU) measured best of 256..2048 (test hook: bit 7 + percent of 1024 in bits 8..)
 struct WCfg { int tz, ty, tx, ns, groups; };
@@ -1400,7 +1536,8 @@ extern "C" int64_t bpx_conv3d_wgrad_workspace(int N, int D, int H, int W, int Ci
 extern "C" int64_t bpx_convT3d_k2s2_wgrad_workspace(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   WCfg c = pick_wcfg(N, D, H, W, Cin, Cout, 1, false);           // fp32: one launch per sub-position
   CtCfg t = pick_ct(N, D, H, W, sz, Cin, Cout);                  // bf16: single pass, [groups][4*sz][Cin][Cout]
-  return std::max((int64_t)c.groups * ((int64_t)Cin + 1) * Cout * 4, (int64_t)t.groups * ((int64_t)4 * sz * Cin + 1) * Cout * 4);
+  return std::max(std::max((int64_t)c.groups * ((int64_t)Cin + 1) * Cout * 4, (int64_t)t.groups * ((int64_t)4 * sz * Cin + 1) * Cout * 4),
+                  (int64_t)256 * ((int64_t)4 * sz * Cin + 1) * Cout * 4);   // (the streaming kernel: one slab per CU)
 }
 
 // test hook: 0 = scalar LDS gathers instead of ds_read_b64_tr_b16 in the bf16 wgrad
@@ -1459,6 +1596,26 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   const int nsub = 4 * sz;
   BPX_CHECK(x.ptr && dy.ptr && dw_d, "%s: null pointer", fn);
   BPX_CHECK(x.C % 16 == 0 && dy.C % 16 == 0, "%s: channels must be multiples of 16 (got %d, %d)", fn, x.C, dy.C);
+  const int cts = cts_instance(x.C / 16, dy.C / 16);
+  if (dtype == BPX_BF16 && g_use_tr != 0 && g_ct_dma && sz == 2 && cts && x.C % 16 == 0 && dy.C % 16 == 0 && W % 32 == 0 && (int64_t)N * D * H * W >= 65536 &&
+      (int64_t)N * D * H * W * 8 * dy.ld * 2 < (1ll << 31) && (int64_t)N * D * H * W * x.ld * 2 < (1ll << 31) &&
+      (((uintptr_t)x.ptr | (uintptr_t)dy.ptr) & 15) == 0 && (x.ld & 7) == 0 && (dy.ld & 7) == 0) {
+    // the large levels (cfg 2: 32 -> 32 @64^3, 64 -> 64 @32^3): the streaming kernel, one persistent workgroup per CU
+    CtsParams q{};
+    q.x = x.ptr; q.x_ld = x.ld; q.dy = dy.ptr; q.dy_ld = dy.ld; q.Cin = x.C; q.Cout = dy.C; q.D = D; q.H = H; q.W = W;
+    q.voxels = (int64_t)N * D * H * W;
+    q.nblocks = (int)cdiv64(q.voxels, cts_tv(cts));
+    q.groups = (int)std::min<int64_t>(256, q.nblocks);
+    const int64_t need = (int64_t)q.groups * ((int64_t)nsub * x.C + 1) * dy.C * 4;
+    BPX_CHECK(ws_d != nullptr && ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
+    q.part = reinterpret_cast<float*>(ws_d);
+    q.dbpart = db_d ? q.part + (size_t)q.groups * nsub * x.C * dy.C : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (cts == 1) { if (mix) wgrad_ct_dma_kernel<2, 2, 64, true><<<q.groups, 256, 0, s>>>(q); else wgrad_ct_dma_kernel<2, 2, 64, false><<<q.groups, 256, 0, s>>>(q); }
+    else { if (mix) wgrad_ct_dma_kernel<4, 4, 32, true><<<q.groups, 256, 0, s>>>(q); else wgrad_ct_dma_kernel<4, 4, 32, false><<<q.groups, 256, 0, s>>>(q); }
+    BPX_LAUNCH_CHECK(fn);
+    return finish_wgrad(fn, ReduceJob{q.part, dw_d, q.groups, nsub, x.C, dy.C, (int64_t)dy.C * nsub, nsub, 1, 0, q.dbpart, db_d, 0}, s);
+  }
   if (dtype == BPX_BF16 && g_use_tr != 0 && (int64_t)N * D * H * W * nsub * std::max(x.ld, dy.ld) < (1ll << 31)) {
     CtCfg c = pick_ct(N, D, H, W, sz, x.C, dy.C);
     const int64_t need = (int64_t)c.groups * ((int64_t)nsub * x.C + 1) * dy.C * 4;
@@ -1494,7 +1651,7 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
   return 0;
 }
 
-extern "C" int bpx_debug_set_wgrad_k1(int on) { g_k1_dma = on; return 0; }
+extern "C" int bpx_debug_set_wgrad_k1(int on) { g_k1_dma = (on == 1 || on == 3 || on == 7) ? 1 : 0; g_ct_dma = (on == 1 || on == 5 || on == 7) ? 1 : 0; g_ct_dma_all = on == 7; return 0; }
 extern "C" int bpx_debug_set_wgrad_cap(int percent) { g_cap_pct = percent > 0 ? percent : 100; return 0; }
 
 // ---- deferred reductions -------------------------------------------------------------------------------------------------

@@ -54,7 +54,7 @@ int bpx_debug_set_conv_ws(int on);     /* test / A-B hook of the bf16 3x3x3 conv
 int bpx_debug_set_conv_occ(int wg_per_cu); /* test / A-B hook: persistent workgroups per CU of the lean bf16 conv kernel (0 = built-in table) */
 int bpx_debug_set_c1_persist(int wgs); /* test / A-B hook: persistent workgroups of bpx_conv3d_c1_fwd (default 2048; 0 = one workgroup per tile) */
 int bpx_debug_set_pw_stream(int on); /* test / A-B hook: 1 (default) = the streaming kernel for bpx_conv1x1_fwd_split with the IN-backward affine at the large levels, 0 = the tile kernel */
-int bpx_debug_set_wgrad_k1(int on); /* test / A-B hook: 1 (default) = the streaming kernel for the k = 1 weight gradients of raw inputs at the large levels, 0 = the generic tile kernel */
+int bpx_debug_set_wgrad_k1(int on); /* test / A-B hook of the streaming weight-gradient kernels at the large levels: 1 (default) = both on, 0 = the tile kernels, 3 = streaming k = 1 (raw-input shortcut) only, 5 = streaming transposed-conv only, 7 = both and the 32 -> 32 transposed-conv instance too (measured slower than its tile kernel) */
 int bpx_debug_set_wgrad_cap(int percent); /* test / A-B hook: size cap of a conv layer's weight-gradient partial slabs in percent of the default (~26 / 64 MB) */
 int bpx_debug_set_tile_order(int bits); /* test / A-B hook: bit 0 = XCD-contiguous y-strip tile walk of the windowed shift-dy wgrad kernel (default 1; 0 = tile = group + k * groups as until round 3) */
 int bpx_debug_set_tiling_scalar(int on); /* test / A-B hook: 1 = crop / merge through the element-per-thread kernels instead of the 16-byte row kernels */

@@ -2258,3 +2258,38 @@ def check_network_dropout(dtype, golden):
     le = torch.from_numpy(golden["logits_eval"])
     res.append(_res(tag + ".eval_mode_ignores_dropout", (lo_eval.cpu() - le).abs().max().item() / le.abs().max().item(), LOGITS_TOL[tagd]))
     return res
+
+
+def check_convT_wgrad_stream(mix=True, B=2, S=(32, 32, 32), Cc=32, seed=0):
+    """The streaming transposed-conv weight gradient (wgrad_ct_dma_kernel, the 32 -> 32 / 64 -> 64 levels) against the fp64 sums, against the tile
+    kernel (bpx_debug_set_wgrad_k1(3): streaming k = 1 on, streaming transposed-conv off) and run to run; x fp16 in the mixed mode, bias gradient included."""
+    D, H, W = S
+    gen = torch.Generator().manual_seed(seed)
+    xdt = torch.float16 if mix else torch.bfloat16
+    xq = torch.randn(B, D, H, W, Cc, generator=gen).to(xdt)
+    dyq = torch.randn(B, 2 * D, 2 * H, 2 * W, Cc, generator=gen).to(torch.bfloat16)
+    w = torch.zeros(Cc, Cc, 2, 2, 2, dtype=torch.float64, requires_grad=True)
+    bb = torch.zeros(Cc, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose3d(ncdhw(xq.double()), w, bb, stride=2).backward(ncdhw(dyq.double()))
+    dt = L.MIX16 if mix else L.BF16
+    xd, dyd = xq.to(DEV), dyq.to(DEV)
+    ws = torch.empty(max(1, lib.bpx_convT3d_k2s2_wgrad_workspace(B, D, H, W, 2, Cc, Cc)), dtype=torch.uint8, device=DEV)
+
+    def run():
+        dw = torch.full((Cc, Cc, 2, 2, 2), 7.0, dtype=torch.float32, device=DEV)
+        db = torch.zeros(Cc, dtype=torch.float32, device=DEV)
+        L.check(lib.bpx_convT3d_k2s2_wgrad(dt, B, D, H, W, 2, L.tview(xd), L.tview(dyd), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        return dw, db
+
+    tag = f"convT_wgrad_stream[{'mix' if mix else 'bf16'} B{B} {S} C{Cc}]"
+    lib.bpx_debug_set_wgrad_k1(7)            # every streaming instance, incl. the 32 -> 32 one that is off by default
+    (a, ab), (b, bbias) = run(), run()
+    lib.bpx_debug_set_wgrad_k1(3)
+    try:
+        c, cb = run()
+    finally:
+        lib.bpx_debug_set_wgrad_k1(1)
+    return [_res(tag + ".dw_vs_fp64", relerr(a, w.grad), 4e-3 if mix else 1e-4), _res(tag + ".db_vs_fp64", relerr(ab, bb.grad), 1e-4),
+            _res(tag + ".dw_vs_tile_kernel", relerr(a, c), 1e-4), _res(tag + ".db_vs_tile_kernel", relerr(ab, cb), 1e-4),
+            _res(tag + ".run_to_run_bits", 0 if torch.equal(a, b) and torch.equal(ab, bbias) else 1, 0)]

@@ -223,6 +223,13 @@ def test_graphed_train_step_draws_a_new_dropout_mask_at_every_replay(K):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mix,B,S,Cc", [(True, 2, (32, 32, 32), 32), (False, 1, (40, 36, 64), 32), (True, 3, (24, 28, 32), 64), (False, 1, (64, 32, 32), 64)],
+                         ids=["mix-32", "bf16-32-ragged", "mix-64-3samples", "bf16-64"])
+def test_streaming_transposed_conv_weight_gradient(K, mix, B, S, Cc):
+    """wgrad_ct_dma_kernel: the k = s = 2 transposed conv's weight / bias gradient at the large levels through the LDS-DMA ring (x and dy read once)."""
+    _assert_all(K.check_convT_wgrad_stream(mix, B, S, Cc))
+
+
 def test_adam_step_kernel_equals_torch_fused_adam(K):
     """optim.fused_step / bpx_adam_step: the optimizer step of the graphed train steps == torch's fused Adam / AdamW on the optimizer's own state
     tensors (train_engine.py:173-177 `optimizer.step()`), and it refuses what it does not reproduce."""
