@@ -72,6 +72,8 @@ def main():
     run(K.check_norm_bwd_finalize_deferred, 3, 5000, 48)
     run(K.check_fused_adam)
     run(K.check_f16_saturation)
+    run(K.check_convT_wgrad_stream, True, 3, (24, 28, 32), 64)
+    run(K.check_convT_wgrad_stream, False, 1, (40, 36, 64), 32)
     if a.net:
         run(K.check_sliding_window, torch.float32)
         run(K.check_sliding_window, torch.bfloat16)
@@ -79,6 +81,9 @@ def main():
         for dtype in (torch.float32, torch.bfloat16, torch.float16):      # float16 = the mixed training mode (fp16 forward, bf16 gradients): the benched one
             run(K.check_network, dtype, None, None, None, golden=gr)
             run(K.check_network, dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3)
+        gd = np.load(os.path.join(ROOT, "tests", "golden", "resunet_dropout_golden.npz"))
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):      # MODEL.DROPOUT_VALUES > 0: the reference's training-mode step with its masks made explicit
+            run(K.check_network_dropout, dtype, gd)
         for dtype in (torch.float32, torch.bfloat16, torch.float16):      # the benched shape itself: 128^3, logits / loss / gradients (per level in 16 bit)
             run(K.check_network_cfg2_benched_shape, dtype)
     lines = []
