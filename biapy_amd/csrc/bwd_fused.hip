@@ -35,6 +35,9 @@ using namespace bpxconv;
 
 namespace {
 
+#ifdef BPX_TICKET_PROBE
+__device__ unsigned g_probe_ticket = 0u, g_probe_last = 0u;
+#endif
 struct BwdParams {
   int N, D, H, W;
   const void* dy; int dy_ld;                       // (N, D, H, W, 16) bf16
@@ -555,6 +558,16 @@ __global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) 
 #pragma unroll
     for (int ck = 0; ck < CG; ++ck) p.dbpart[(size_t)blockIdx.x * Cdy + ck * 16 + j] = accw[ck][6][0][0];
   }
+#ifdef BPX_TICKET_PROBE
+  // measurement only (profiles/r04_ticket_probe.txt): what a last-arriver finalize would add to every workgroup - an agent-scope RELEASE after its
+  // last store, one ticket; the last arriver alone pays the ACQUIRE
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = atomicAdd(&g_probe_ticket, 1u);
+    if (t == gridDim.x * gridDim.y - 1) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); g_probe_ticket = 0u; g_probe_last = (unsigned)blockIdx.x; }
+  }
+#endif
 }
 
 int cu_count_() {
