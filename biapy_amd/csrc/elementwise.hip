@@ -454,8 +454,8 @@ __global__ void __launch_bounds__(256) norm_act_fwd_kernel(const T* __restrict__
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ x, int x_ld,
+template <typename T, typename TT = T>   // TT: storage type of the activation tensor x (fp16 beside bf16 gradients in the mixed mode)
+__global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__ dy, int dy_ld, const TT* __restrict__ x, int x_ld,
                                                            const bpx_norm_rec* __restrict__ rec, int act, const T* __restrict__ addend,
                                                            int a_ld, T* __restrict__ g, int g_ld, int C, int64_t vps,
                                                            float* __restrict__ red_part) {
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) norm_act_bwd_kernel(const T* __restrict__
   for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     float d[KPL], f[KPL], o[KPL];
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + vox * dy_ld + cg * KPL), d);
-    unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
+    unpack16<TT>(*reinterpret_cast<const u32x4_t*>(x + vox * x_ld + cg * KPL), f);
 #pragma unroll
     for (int e = 0; e < KPL; ++e) {
       float u = sc[e] * f[e] + sh[e];
@@ -1986,7 +1986,7 @@ static int na_blocks(int64_t voxels, int C, int kpl) {
   return (bx + odd - 1) / odd * odd;   // 256 * bx is a multiple of G: a thread keeps its channel group
 }
 
-extern "C" int bpx_norm_act_tiles(int dtype, int64_t voxels, int C) { return na_blocks(voxels, C, dtype == BPX_BF16 ? 8 : 4); }
+extern "C" int bpx_norm_act_tiles(int dtype, int64_t voxels, int C) { return na_blocks(voxels, C, dtype == BPX_F32 ? 4 : 8); }
 
 extern "C" int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, bpx_tensor y,
                                 bpx_stream_t stream) {
@@ -1996,14 +1996,16 @@ extern "C" int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, 
   BPX_CHECK(x.C == y.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
   BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
   if ((int64_t)N * voxels == 0) return 0;
-  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
   dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
     norm_act_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, rec_d, act, (uint16_t*)y.ptr, y.ld, x.C, voxels);
+  else if (dtype == BPX_F16)
+    norm_act_fwd_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x.ptr, x.ld, rec_d, act, (f16_t*)y.ptr, y.ld, x.C, voxels);
   else if (dtype == BPX_F32)
     norm_act_fwd_kernel<float><<<grid, 256, 0, s>>>((const float*)x.ptr, x.ld, rec_d, act, (float*)y.ptr, y.ld, x.C, voxels);
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  else BPX_FAIL("%s: dtype must be BF16, F16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -2016,17 +2018,20 @@ extern "C" int bpx_norm_act_bwd(int dtype, int N, int64_t voxels, bpx_tensor dy,
   BPX_CHECK(x.C == dy.C && x.C == g.C && x.C % 16 == 0 && x.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
   BPX_CHECK(act >= 0 && act <= BPX_ACT_LAST, "%s: unknown activation %d", fn, act);
   if ((int64_t)N * voxels == 0) return 0;
-  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
   dim3 grid((unsigned)na_blocks(voxels, x.C, kpl), (unsigned)N);
   const size_t shm = (size_t)256 * 2 * kpl * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16)
     norm_act_bwd_kernel<uint16_t><<<grid, 256, shm, s>>>((const uint16_t*)dy.ptr, dy.ld, (const uint16_t*)x.ptr, x.ld, rec_d, act,
                                                          (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)g.ptr, g.ld, x.C, voxels, red_part_d);
+  else if (dtype == BPX_MIX16)   // x = the forward pass's fp16 tensor; dy, addend, g bf16
+    norm_act_bwd_kernel<uint16_t, f16_t><<<grid, 256, shm, s>>>((const uint16_t*)dy.ptr, dy.ld, (const f16_t*)x.ptr, x.ld, rec_d, act,
+                                                                (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)g.ptr, g.ld, x.C, voxels, red_part_d);
   else if (dtype == BPX_F32)
     norm_act_bwd_kernel<float><<<grid, 256, shm, s>>>((const float*)dy.ptr, dy.ld, (const float*)x.ptr, x.ld, rec_d, act,
                                                       (const float*)addend.ptr, addend.ld, (float*)g.ptr, g.ld, x.C, voxels, red_part_d);
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  else BPX_FAIL("%s: dtype must be BF16, MIX16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

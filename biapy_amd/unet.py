@@ -54,6 +54,8 @@ class UpBlock(nn.Module):
 
 class U_Net(nn.Module):
     _bpx_dropin = True   # train_engine: the training-time model_call_func of this class is to_pytorch_format -> forward
+    # float16 (round 4) = the mixed training mode of the ResUNet: fp16 forward / activations, bf16 gradients (unet_engine.py uses the same dtype codes)
+    supported_compute_dtypes = (torch.float32, torch.bfloat16, torch.float16)
 
     def __init__(
         self,

@@ -112,7 +112,7 @@ class UNetEngine(ResUNetEngine):
             if T == torch.float32:
                 cur.copy_(xin)
             else:
-                L.check(lib.bpx_cast(L.F32, xin.data_ptr(), L.BF16, cur.data_ptr(), xin.numel(), st))
+                L.check(lib.bpx_cast(L.F32, xin.data_ptr(), self.dt, cur.data_ptr(), xin.numel(), st))
         S = [(D0, H0, W0)]
         for i in range(Lv):
             S.append((S[i][0] // zd[i], S[i][1] // 2, S[i][2] // 2))
@@ -171,14 +171,16 @@ class UNetEngine(ResUNetEngine):
     # ---- backward -------------------------------------------------------------------------------------------------------
     def _norm_act_bwd(self, B, vox, C, dA, raw, rec, gamma, dgamma, dbeta, st, dev):
         """d(act(IN(raw))) -> d(raw): elementwise product with act' + the two InstanceNorm reductions, finalize, apply."""
-        tiles = lib.bpx_norm_act_tiles(self.dt, vox, C)
+        # (mixed mode, compute_dtype float16: `raw` is the forward pass's fp16 tensor, every gradient tensor bf16 - the codes of engine.ResUNetEngine:
+        #  gdt = kernels that touch gradient tensors only, bdt = backward kernels that also read a forward activation)
+        tiles = lib.bpx_norm_act_tiles(self.gdt, vox, C)
         red = torch.empty((B, tiles, 2, C), dtype=torch.float32, device=dev)
-        g = torch.empty(raw.shape, dtype=self.dtype, device=dev)
-        L.check(lib.bpx_norm_act_bwd(self.dt, B, vox, dA, L.tview(raw), rec.data_ptr(), self.act, L.NULL_T, L.tview(g), red.data_ptr(), st))
+        g = torch.empty(raw.shape, dtype=self.gdtype, device=dev)
+        L.check(lib.bpx_norm_act_bwd(self.bdt, B, vox, dA, L.tview(raw), rec.data_ptr(), self.act, L.NULL_T, L.tview(g), red.data_ptr(), st))
         coef = torch.empty((B, C, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C, vox, rec.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), C,
                                           coef.data_ptr(), st))
-        L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g), L.tview(raw), coef.data_ptr(), L.NULL_T, L.tview(g), st))
+        L.check(lib.bpx_norm_bwd_apply(self.bdt, B, vox, L.tview(g), L.tview(raw), coef.data_ptr(), L.NULL_T, L.tview(g), st))
         return g
 
     def _conv_block_bwd(self, Pw, G, cb: _CB, B, dA: "L.Tensor", img, dx_out: Optional["L.Tensor"], st, dev):
@@ -191,27 +193,27 @@ class UNetEngine(ResUNetEngine):
         self._keep.append(g2)
         # conv 2: weights, then the input gradient fused with act' and the reductions of the first norm
         self._wgrad(B, cb.S, L.tview(cb.h[0]), cb.rec[0], self.act, L.tview(g2), 3, G[k(1, "0.weight")], G[k(1, "0.bias")], st, dev)
-        g1 = torch.empty((B, D, H, W, C1), dtype=self.dtype, device=dev)
+        g1 = torch.empty((B, D, H, W, C1), dtype=self.gdtype, device=dev)
         self._keep.append(g1)
         tiles = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, C1)
         red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
         w2t = self._pack(Pw[k(1, "0.weight")], L.PK_K3_T, C1, C1, False)
-        L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, L.tview(g2), w2t.data_ptr(), L.tview(cb.h[0]), cb.rec[0].data_ptr(), self.act,
+        L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, L.tview(g2), w2t.data_ptr(), L.tview(cb.h[0]), cb.rec[0].data_ptr(), self.act,
                                      L.tview(g1), red.data_ptr(), st))
         coef = torch.empty((B, C1, 4), dtype=torch.float32, device=dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C1, vox, cb.rec[0].data_ptr(), Pw[k(0, "1.weight")].data_ptr(),
                                           G[k(0, "1.weight")].data_ptr(), G[k(0, "1.bias")].data_ptr(), C1, coef.data_ptr(), st))
-        L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g1), L.tview(cb.h[0]), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
+        L.check(lib.bpx_norm_bwd_apply(self.bdt, B, vox, L.tview(g1), L.tview(cb.h[0]), coef.data_ptr(), L.NULL_T, L.tview(g1), st))
         # conv 1
         if img is not None:
             wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(C1), dev)
-            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), L.tview(g1), G[k(0, "0.weight")].data_ptr(),
+            L.check(lib.bpx_conv3d_c1_wgrad(self.gdt, B, D, H, W, img.data_ptr(), L.tview(g1), G[k(0, "0.weight")].data_ptr(),
                                             G[k(0, "0.bias")].data_ptr(), wsc.data_ptr(), wsc.numel(), st))
             return
         self._wgrad(B, cb.S, L.tview(cb.x), None, 0, L.tview(g1), 3, G[k(0, "0.weight")], G[k(0, "0.bias")], st, dev)
         if dx_out is not None:
             w1t = self._pack(Pw[k(0, "0.weight")], L.PK_K3_T, cb.cin, C1, False)
-            L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, L.tview(g1), w1t.data_ptr(), L.NULL_T, None, 0, dx_out, None, st))
+            L.check(lib.bpx_conv3d_dgrad(self.gdt, B, D, H, W, L.tview(g1), w1t.data_ptr(), L.NULL_T, None, 0, dx_out, None, st))
 
     def backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
         cfg = self.cfg
@@ -219,7 +221,7 @@ class UNetEngine(ResUNetEngine):
         blocks: List[_CB] = ctx["blocks"]
         cat, ups, feat = ctx["cat"], ctx["ups"], ctx["feat"]
         fm, Lv = list(cfg.feature_maps), cfg.depth
-        dev, st, T = dlogits.device, L.stream_ptr(), self.dtype
+        dev, st, T = dlogits.device, L.stream_ptr(), self.gdtype       # T: storage type of the gradient tensors
         self._keep = []
         # parameter gradients in the LIFTED shapes (one zero-filled slab: the wgrad kernels accumulate), un-lifted at the end
         names = list(Pw.keys())
@@ -238,7 +240,7 @@ class UNetEngine(ResUNetEngine):
         hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
         hbg = torch.zeros((n_out,), dtype=torch.float32, device=dev)
         hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
-        L.check(lib.bpx_head_bwd(self.dt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
+        L.check(lib.bpx_head_bwd(self.bdt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
                                  L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
         o = 0
         for h, oc in enumerate(cfg.out_channels):
@@ -260,11 +262,11 @@ class UNetEngine(ResUNetEngine):
             keep.append(dup)
             Dl, Hl, Wl = S[i + 1]
             ws = self._workspace(lib.bpx_convT3d_k2s2_wgrad_workspace(B, Dl, Hl, Wl, zd[i], Cl, Cup), dev)
-            L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, Dl, Hl, Wl, zd[i], L.tview(x_low), L.tview(dup), G[f"{pre}.0.weight"].data_ptr(),
+            L.check(lib.bpx_convT3d_k2s2_wgrad(self.bdt, B, Dl, Hl, Wl, zd[i], L.tview(x_low), L.tview(dup), G[f"{pre}.0.weight"].data_ptr(),
                                                G[f"{pre}.0.bias"].data_ptr(), ws.data_ptr(), ws.numel(), st))
             dlow = torch.empty((B, Dl, Hl, Wl, Cl), dtype=T, device=dev)
             wt = self._pack(Pw[f"{pre}.0.weight"], L.PK_CT_T if zd[i] == 2 else L.PK_CT4_T, Cl, Cup, False)
-            L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Dl, Hl, Wl, zd[i], L.tview(dup), wt.data_ptr(), L.tview(dlow), st))
+            L.check(lib.bpx_convT3d_k2s2_dgrad(self.gdt, B, Dl, Hl, Wl, zd[i], L.tview(dup), wt.data_ptr(), L.tview(dlow), st))
             dA = L.tview(dlow)
             keep.append(dlow)
         # ---- bottleneck ---------------------------------------------------------------------------------------------
@@ -275,7 +277,7 @@ class UNetEngine(ResUNetEngine):
             D, H, W = S[i]
             # d(skip output) = d(concat)[..., Cup:] + unpool(dP), in place over the skip slice
             skipv = L.tview(dcat[i], fm[i], fm[i])
-            L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, zd[i], L.tview(cat[i], fm[i], fm[i]), L.tview(dP), skipv, skipv, st))
+            L.check(lib.bpx_maxpool3d_bwd(self.bdt, B, D, H, W, zd[i], L.tview(cat[i], fm[i], fm[i]), L.tview(dP), skipv, skipv, st))
             if i > 0:
                 dPn = torch.empty((B,) + S[i] + (fm[i - 1],), dtype=T, device=dev)
                 self._conv_block_bwd(Pw, G, blocks[i], B, skipv, None, L.tview(dPn), st, dev)

@@ -929,10 +929,11 @@ def test_convT_channel_changing(K, dt):
     _assert_all(K.check_convT(d, 2, (4, 6, 8), 64, seed=3, sz=2, Cout=32) + K.check_convT(d, 2, (1, 16, 16), 32, seed=4, sz=1, Cout=16))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "mix16"])
 @pytest.mark.parametrize("tag", ["2d", "3d"])
 def test_unet_matches_reference_fixture(K, unet_golden, tag, dtype):
-    """biapy_amd.unet.U_Net (row U; 2D = cfg 1 family) vs the reference's own outputs: logits, loss, all gradients."""
+    """biapy_amd.unet.U_Net (row U; 2D = cfg 1 family) vs the reference's own outputs: logits, loss, all gradients.  mix16 (round 4) = the ResUNet's
+    mixed training mode for the plain U-Net: fp16 forward and activations, bf16 gradients."""
     _assert_all(K.check_unet(dtype, tag, unet_golden))
 
 
