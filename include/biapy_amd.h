@@ -324,7 +324,8 @@ int bpx_norm_bwd_apply(int dtype, int N, int64_t voxels, bpx_tensor g, bpx_tenso
  * biapy/models/blocks.py:154-166 Conv -> Norm -> Act feeding MaxPool / ConvTranspose / the head, unet.py:382-394).
  *   fwd: y = act(scale*x + shift), rec_d = [N][C] records of bpx_norm_finalize.
  *   bwd: g = dy * act'(scale*x + shift) (+ addend); red_part_d = [N][bpx_norm_act_tiles()][2][C] partial sums of
- *        S1 = sum g, S2 = sum g*xhat of the product term only, the layout bpx_norm_bwd_finalize reads.  g may alias dy. */
+ *        S1 = sum g, S2 = sum g*xhat of the product term only, the layout bpx_norm_bwd_finalize reads.  g may alias dy.
+ * dtype fwd: BF16, F16, F32; bwd: BF16, F32, or MIX16 (x = the forward pass's fp16 tensor; dy, addend, g bf16 - the mixed training mode). */
 int bpx_norm_act_tiles(int dtype, int64_t voxels, int C);
 int bpx_norm_act_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const bpx_norm_rec* rec_d, int act, bpx_tensor y,
                      bpx_stream_t stream);
