@@ -691,8 +691,8 @@ __global__ void __launch_bounds__(256) channel_affine_kernel(const T* __restrict
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) dot_stats_kernel(const T* __restrict__ a, int a_ld, const T* __restrict__ b, int b_ld, int C,
+template <typename T, typename TB = T>   // TB: storage type of b (the forward pass's fp16 tensor beside a bf16 gradient a in the mixed mode)
+__global__ void __launch_bounds__(256) dot_stats_kernel(const T* __restrict__ a, int a_ld, const TB* __restrict__ b, int b_ld, int C,
                                                         int64_t vps, float* __restrict__ part) {
   constexpr int KPL = ElemTraits<T>::KPL;
   extern __shared__ float dred[];   // [256][KPL]
@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(256) dot_stats_kernel(const T* __restrict__ a,
   for (int64_t i = first; i < total; i += (int64_t)gridDim.x * blockDim.x, vox += vstep) {
     float af[KPL], bf[KPL];
     unpack16<T>(*reinterpret_cast<const u32x4_t*>(a + vox * a_ld + cg * KPL), af);
-    unpack16<T>(*reinterpret_cast<const u32x4_t*>(b + vox * b_ld + cg * KPL), bf);
+    unpack16<TB>(*reinterpret_cast<const u32x4_t*>(b + vox * b_ld + cg * KPL), bf);
 #pragma unroll
     for (int e = 0; e < KPL; ++e) s[e] += af[e] * bf[e];
   }
@@ -1541,9 +1541,11 @@ extern "C" int bpx_tensor_stats(int dtype, int N, int64_t voxels, bpx_tensor x, 
   BPX_CHECK(x.ptr && stats_part_d, "%s: null pointer", fn);
   int tiles = (int)cdiv64(voxels, 256);
   dim3 grid((unsigned)tiles, (unsigned)N);
-  const int vec = dtype == BPX_BF16 ? 8 : 4;
-  const bool wide = dtype != BPX_F16 && x.C % vec == 0 && x.ld % vec == 0 && x.C / vec <= 256 && ((uintptr_t)x.ptr & 15) == 0;
+  const int vec = dtype == BPX_F32 ? 4 : 8;
+  const bool wide = x.C % vec == 0 && x.ld % vec == 0 && x.C / vec <= 256 && ((uintptr_t)x.ptr & 15) == 0;
   if (dtype == BPX_BF16 && wide) tensor_stats_vec_kernel<uint16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const uint16_t*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
+  else if (dtype == BPX_F16 && wide) tensor_stats_vec_kernel<f16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const f16_t*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
+  else if (dtype == BPX_F16) tensor_stats_kernel<f16_t><<<grid, 64, 0, (hipStream_t)stream>>>((const f16_t*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
   else if (dtype == BPX_F32 && wide) tensor_stats_vec_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
   else if (dtype == BPX_BF16) tensor_stats_kernel<uint16_t><<<grid, 64, 0, (hipStream_t)stream>>>((const uint16_t*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
   else if (dtype == BPX_F32) tensor_stats_kernel<float><<<grid, 64, 0, (hipStream_t)stream>>>((const float*)x.ptr, x.ld, x.C, voxels, tiles, stats_part_d);
@@ -1869,17 +1871,17 @@ __global__ void __launch_bounds__(256) gate_mul_fwd_kernel(const T* __restrict__
 // dx = dy * a (C channels);  da[v] = sum_c dy[v][c] * x[v][c] written to channel 0 of a 16-channel tensor whose other channels are
 // zeroed (it is the gradient of the zero-padded 16-output 1x1 convolution that produced the gate).  One wave-quarter (16 lanes) per
 // voxel would waste lanes for small C; instead a thread owns one voxel and walks its channels (C * 2 B <= a few cache lines).
-template <typename T>
-__global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ a, int a_ld, const T* __restrict__ x,
+template <typename T, typename TT = T>   // TT: storage type of the forward tensors a, x (fp16 beside bf16 gradients in the mixed mode)
+__global__ void __launch_bounds__(256) gate_mul_bwd_kernel(const T* __restrict__ dy, int dy_ld, const TT* __restrict__ a, int a_ld, const TT* __restrict__ x,
                                                            int x_ld, T* __restrict__ dx, int dx_ld, T* __restrict__ da16, int C, int64_t total_vox) {
   constexpr int KPL = ElemTraits<T>::KPL;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total_vox; v += (int64_t)gridDim.x * 256) {
-    const float av = ElemTraits<T>::ld(a + v * a_ld);
+    const float av = ElemTraits<TT>::ld(a + v * a_ld);
     float dot = 0.f;
     for (int c0 = 0; c0 < C; c0 += KPL) {
       float g[8], xv[8];
       unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + c0), g);
-      unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + v * x_ld + c0), xv);
+      unpack16<TT>(*reinterpret_cast<const u32x4_t*>(x + v * x_ld + c0), xv);
 #pragma unroll
       for (int e = 0; e < KPL; ++e) { dot += g[e] * xv[e]; g[e] *= av; }
       *reinterpret_cast<u32x4_t*>(dx + v * dx_ld + c0) = pack16<T>(g);
@@ -2270,13 +2272,14 @@ extern "C" int bpx_dot_stats(int dtype, int N, int64_t voxels, bpx_tensor a, bpx
   BPX_CHECK(a.ptr && b.ptr && part_d, "%s: null pointer", fn);
   BPX_CHECK(a.C == b.C && a.C % 16 == 0 && a.C <= 2048, "%s: channels must match and be a multiple of 16", fn);
   if ((int64_t)N * voxels == 0) return 0;
-  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
   dim3 grid((unsigned)na_blocks(voxels, a.C, kpl), (unsigned)N);
   const size_t shm = (size_t)256 * kpl * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16) dot_stats_kernel<uint16_t><<<grid, 256, shm, s>>>((const uint16_t*)a.ptr, a.ld, (const uint16_t*)b.ptr, b.ld, a.C, voxels, part_d);
+  else if (dtype == BPX_MIX16) dot_stats_kernel<uint16_t, f16_t><<<grid, 256, shm, s>>>((const uint16_t*)a.ptr, a.ld, (const f16_t*)b.ptr, b.ld, a.C, voxels, part_d);   // a bf16 gradient, b fp16 activation
   else if (dtype == BPX_F32) dot_stats_kernel<float><<<grid, 256, shm, s>>>((const float*)a.ptr, a.ld, (const float*)b.ptr, b.ld, a.C, voxels, part_d);
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  else BPX_FAIL("%s: dtype must be BF16, MIX16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
@@ -2641,11 +2644,12 @@ extern "C" int bpx_gate_mul_fwd(int dtype, int64_t total_voxels, bpx_tensor a, b
   BPX_CHECK(a.cs == 0 && x.cs == 0 && y.cs == 0, "bpx_gate_mul_fwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_gate_mul_fwd";
   BPX_CHECK(a.ptr && x.ptr && y.ptr, "%s: null pointer", fn);
-  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
   BPX_CHECK(x.C == y.C && x.C % kpl == 0 && x.ld % kpl == 0 && y.ld % kpl == 0, "%s: channel counts / strides must be multiples of %d", fn, kpl);
   if (total_voxels == 0) return 0;
   const int blocks = grid_for(total_voxels * (x.C / kpl));
   if (dtype == BPX_BF16) gate_mul_fwd_kernel<uint16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)a.ptr, a.ld, (const uint16_t*)x.ptr, x.ld, (uint16_t*)y.ptr, y.ld, x.C, total_voxels);
+  else if (dtype == BPX_F16) gate_mul_fwd_kernel<f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)a.ptr, a.ld, (const f16_t*)x.ptr, x.ld, (f16_t*)y.ptr, y.ld, x.C, total_voxels);
   else if (dtype == BPX_F32) gate_mul_fwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)a.ptr, a.ld, (const float*)x.ptr, x.ld, (float*)y.ptr, y.ld, x.C, total_voxels);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);
@@ -2656,12 +2660,13 @@ extern "C" int bpx_gate_mul_bwd(int dtype, int64_t total_voxels, bpx_tensor dy, 
   BPX_CHECK(dy.cs == 0 && a.cs == 0 && x.cs == 0 && dx.cs == 0, "bpx_gate_mul_bwd: chunk-planar tensors (cs != 0) are not accepted here");
   const char* fn = "bpx_gate_mul_bwd";
   BPX_CHECK(dy.ptr && a.ptr && x.ptr && dx.ptr && da16_d, "%s: null pointer", fn);
-  const int kpl = dtype == BPX_BF16 ? 8 : 4;
+  const int kpl = dtype == BPX_F32 ? 4 : 8;
   BPX_CHECK(x.C == dy.C && x.C == dx.C && x.C % kpl == 0 && x.ld % kpl == 0 && dy.ld % kpl == 0 && dx.ld % kpl == 0,
             "%s: channel counts / strides must be multiples of %d", fn, kpl);
   if (total_voxels == 0) return 0;
   const int blocks = grid_for(total_voxels);
   if (dtype == BPX_BF16) gate_mul_bwd_kernel<uint16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)dy.ptr, dy.ld, (const uint16_t*)a.ptr, a.ld, (const uint16_t*)x.ptr, x.ld, (uint16_t*)dx.ptr, dx.ld, (uint16_t*)da16_d, x.C, total_voxels);
+  else if (dtype == BPX_MIX16) gate_mul_bwd_kernel<uint16_t, f16_t><<<blocks, 256, 0, (hipStream_t)stream>>>((const uint16_t*)dy.ptr, dy.ld, (const f16_t*)a.ptr, a.ld, (const f16_t*)x.ptr, x.ld, (uint16_t*)dx.ptr, dx.ld, (uint16_t*)da16_d, x.C, total_voxels);
   else if (dtype == BPX_F32) gate_mul_bwd_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>((const float*)dy.ptr, dy.ld, (const float*)a.ptr, a.ld, (const float*)x.ptr, x.ld, (float*)dx.ptr, dx.ld, (float*)da16_d, x.C, total_voxels);
   else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
   BPX_LAUNCH_CHECK(fn);

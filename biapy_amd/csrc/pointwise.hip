@@ -566,9 +566,12 @@ extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return con
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                         bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y, bpx_tensor y2,
                         bpx_stream_t stream) {
-  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16, "%s: dtype must be BF16, F32 or MIX16 (t fp16, everything else bf16)", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16 || dtype == BPX_F16,
+            "%s: dtype must be BF16, F32, MIX16 (t fp16, everything else bf16) or F16 (plain forward GEMM, no IN-backward operands)", fn);
   const bool mix = dtype == BPX_MIX16 && coef_d != nullptr;
   if (dtype == BPX_MIX16) dtype = BPX_BF16;
+  const bool f16 = dtype == BPX_F16;
+  if (f16) BPX_CHECK(coef_d == nullptr, "%s: F16 is the forward GEMM only", fn);
   int es = (int)dtype_size(dtype);
   if (chk(fn, "x", x, es) || chk(fn, "y", y, es)) return 1;
   BPX_CHECK(w_packed_d, "%s: weights null", fn);
@@ -613,6 +616,7 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
     }
   }
   if ((mix ? launch_pw<uint16_t, PW_CONV1, f16_t>(p, ns, (hipStream_t)stream)
+       : f16 ? launch_pw<f16_t, PW_CONV1>(p, ns, (hipStream_t)stream)
        : dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;

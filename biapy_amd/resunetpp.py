@@ -99,6 +99,8 @@ class _PPFn(torch.autograd.Function):
 
 class ResUNetPlusPlus(nn.Module):
     _bpx_dropin = True   # train_engine: the training-time model_call_func of this class is to_pytorch_format -> forward (+ head activations)
+    # float16 (round 4) = the mixed training mode: fp16 forward / activations, bf16 gradients (resunetpp_engine.py on the gdt / bdt codes of engine.py)
+    supported_compute_dtypes = (torch.float32, torch.bfloat16, torch.float16)
 
     def __init__(
         self,

@@ -136,12 +136,12 @@ class ResUNetPPEngine(ResUNetEngine):
             return
         gv = L.tview(g, c0, v.C)
         if v.grad is None:
-            v.grad = torch.empty((self._B,) + v.S + (v.C,), dtype=self.dtype, device=self._dev)
-            L.check(lib.bpx_norm_act_fwd(self.dt, self._B, v.vox, gv, self._ident_rec(v.C).data_ptr(), 0, L.tview(v.grad), self._st))   # copy of a slice
+            v.grad = torch.empty((self._B,) + v.S + (v.C,), dtype=self.gdtype, device=self._dev)
+            L.check(lib.bpx_norm_act_fwd(self.gdt, self._B, v.vox, gv, self._ident_rec(v.C).data_ptr(), 0, L.tview(v.grad), self._st))   # copy of a slice (gradient tensors only)
         else:
             if v.grad_shared:
                 v.grad, v.grad_shared = v.grad.clone(), False
-            L.check(lib.bpx_channel_affine(self.dt, self._B, v.vox, L.tview(v.grad), gv, self._ones_bc(v.C).data_ptr(), None, L.tview(v.grad), self._st))
+            L.check(lib.bpx_channel_affine(self.gdt, self._B, v.vox, L.tview(v.grad), gv, self._ones_bc(v.C).data_ptr(), None, L.tview(v.grad), self._st))
         self._keep.append(g)
 
     def _acc_target(self, v: _V):
@@ -149,7 +149,7 @@ class ResUNetPPEngine(ResUNetEngine):
         (addend view, destination tensor, fresh?) that make it leave ``v.grad (+)= result`` - the gradient so far as the addend and the
         destination, or a new tensor the caller adopts as ``v.grad``.  Saves the separate accumulation pass of ``_accum``."""
         if v.grad is None:
-            return L.NULL_T, torch.empty_like(v.buf), True
+            return L.NULL_T, torch.empty(v.buf.shape, dtype=self.gdtype, device=self._dev), True
         if v.grad_shared:
             v.grad, v.grad_shared = v.grad.clone(), False
         return L.tview(v.grad), v.grad, False
@@ -173,23 +173,25 @@ class ResUNetPPEngine(ResUNetEngine):
     def _in_bwd(self, raw: _V, rec, act, dA: torch.Tensor, gamma, dgamma, dbeta) -> torch.Tensor:
         """Backward of a materialised ``act(IN(raw))``: dA (dense) -> d(raw)."""
         B, C, vox = self._B, raw.C, raw.vox
-        tiles = lib.bpx_norm_act_tiles(self.dt, vox, C)
+        # (mixed mode: raw is the forward pass's fp16 tensor, every gradient tensor bf16 - engine.ResUNetEngine's codes: gdt = kernels on gradient
+        #  tensors only, bdt = backward kernels that also read a forward tensor)
+        tiles = lib.bpx_norm_act_tiles(self.gdt, vox, C)
         red = torch.empty((B, tiles, 2, C), dtype=torch.float32, device=self._dev)
-        g = torch.empty((B,) + raw.S + (C,), dtype=self.dtype, device=self._dev)
-        L.check(lib.bpx_norm_act_bwd(self.dt, B, vox, L.tview(dA), raw.view(), rec.data_ptr(), act, L.NULL_T, L.tview(g), red.data_ptr(), self._st))
+        g = torch.empty((B,) + raw.S + (C,), dtype=self.gdtype, device=self._dev)
+        L.check(lib.bpx_norm_act_bwd(self.bdt, B, vox, L.tview(dA), raw.view(), rec.data_ptr(), act, L.NULL_T, L.tview(g), red.data_ptr(), self._st))
         coef = torch.empty((B, C, 4), dtype=torch.float32, device=self._dev)
         L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, tiles, C, vox, rec.data_ptr(), gamma.data_ptr(), L.ptr(dgamma), L.ptr(dbeta), C,
                                           coef.data_ptr(), self._st))
-        L.check(lib.bpx_norm_bwd_apply(self.dt, B, vox, L.tview(g), raw.view(), coef.data_ptr(), L.NULL_T, L.tview(g), self._st))
+        L.check(lib.bpx_norm_bwd_apply(self.bdt, B, vox, L.tview(g), raw.view(), coef.data_ptr(), L.NULL_T, L.tview(g), self._st))
         self._keep.append(dA)
         return g
 
     def _act_bwd(self, raw: _V, act, dA: torch.Tensor) -> torch.Tensor:
         """Backward of a materialised activation alone: dA * act'(raw)."""
         B, C, vox = self._B, raw.C, raw.vox
-        red = torch.empty((B, lib.bpx_norm_act_tiles(self.dt, vox, C), 2, C), dtype=torch.float32, device=self._dev)
-        g = torch.empty((B,) + raw.S + (C,), dtype=self.dtype, device=self._dev)
-        L.check(lib.bpx_norm_act_bwd(self.dt, B, vox, L.tview(dA), raw.view(), self._ident_rec(C).data_ptr(), act, L.NULL_T, L.tview(g), red.data_ptr(), self._st))
+        red = torch.empty((B, lib.bpx_norm_act_tiles(self.gdt, vox, C), 2, C), dtype=torch.float32, device=self._dev)
+        g = torch.empty((B,) + raw.S + (C,), dtype=self.gdtype, device=self._dev)
+        L.check(lib.bpx_norm_act_bwd(self.bdt, B, vox, L.tview(dA), raw.view(), self._ident_rec(C).data_ptr(), act, L.NULL_T, L.tview(g), red.data_ptr(), self._st))
         self._keep += [dA, red]
         return g
 
@@ -211,21 +213,21 @@ class ResUNetPPEngine(ResUNetEngine):
                 dy = L.tview(y.grad)
                 self._wgrad(B, x.S, x.view(), nrm.rec if nrm else None, nrm.act if nrm else 0, dy, 3, G[wk], G[bk], self._st, self._dev)
                 wt = self._pack(P[wk], L.PK_K3_T, x.C, Cout, False)
-                g = torch.empty((B, D, H, W, x.C), dtype=self.dtype, device=self._dev)
+                g = torch.empty((B, D, H, W, x.C), dtype=self.gdtype, device=self._dev)
                 if nrm is not None:
                     rt = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, x.C)
                     red = torch.empty((B, rt, 2, x.C), dtype=torch.float32, device=self._dev)
-                    L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dy, wt.data_ptr(), x.view(), nrm.rec.data_ptr(), nrm.act, L.tview(g), red.data_ptr(), self._st))
+                    L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dy, wt.data_ptr(), x.view(), nrm.rec.data_ptr(), nrm.act, L.tview(g), red.data_ptr(), self._st))
                     coef = torch.empty((B, x.C, 4), dtype=torch.float32, device=self._dev)
                     L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, rt, x.C, x.vox, nrm.rec.data_ptr(), nrm.gamma.data_ptr(), L.ptr(nrm.dgamma),
                                                       L.ptr(nrm.dbeta), x.C, coef.data_ptr(), self._st))
                     add, dst, fresh = self._acc_target(x)             # the InstanceNorm-backward affine adds to the gradient x already has
-                    L.check(lib.bpx_norm_bwd_apply(self.dt, B, x.vox, L.tview(g), x.view(), coef.data_ptr(), add, L.tview(dst), self._st))
+                    L.check(lib.bpx_norm_bwd_apply(self.bdt, B, x.vox, L.tview(g), x.view(), coef.data_ptr(), add, L.tview(dst), self._st))
                     if fresh:
                         x.grad = dst
                     self._keep += [y.grad, g]
                     return
-                L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, dy, wt.data_ptr(), L.NULL_T, None, 0, L.tview(g), None, self._st))
+                L.check(lib.bpx_conv3d_dgrad(self.gdt, B, D, H, W, dy, wt.data_ptr(), L.NULL_T, None, 0, L.tview(g), None, self._st))
                 self._keep.append(y.grad)
                 self._accum(x, g)
             self._tape.append(bwd)
@@ -241,7 +243,7 @@ class ResUNetPPEngine(ResUNetEngine):
         if G is not None:
             def bwd():
                 wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(y.C), self._dev)
-                L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, img.data_ptr(), L.tview(y.grad), G[wk].data_ptr(), G[bk].data_ptr(),
+                L.check(lib.bpx_conv3d_c1_wgrad(self.gdt, B, D, H, W, img.data_ptr(), L.tview(y.grad), G[wk].data_ptr(), G[bk].data_ptr(),
                                                 wsc.data_ptr(), wsc.numel(), self._st))
                 self._keep.append(y.grad)
             self._tape.append(bwd)
@@ -296,14 +298,14 @@ class ResUNetPPEngine(ResUNetEngine):
         L.check(lib.bpx_channel_affine(self.dt, B, x.vox, L.NULL_T, x.view(), s.data_ptr(), None, out.view(), self._st))
         if G is not None:
             def bwd():
-                nt = lib.bpx_norm_act_tiles(self.dt, x.vox, C)
+                nt = lib.bpx_norm_act_tiles(self.gdt, x.vox, C)
                 dpart = torch.empty((B, nt, C), dtype=torch.float32, device=self._dev)
-                L.check(lib.bpx_dot_stats(self.dt, B, x.vox, L.tview(out.grad), x.view(), dpart.data_ptr(), self._st))
+                L.check(lib.bpx_dot_stats(self.bdt, B, x.vox, L.tview(out.grad), x.view(), dpart.data_ptr(), self._st))
                 off = torch.empty((B, C), dtype=torch.float32, device=self._dev)         # d mean / voxels -> every voxel of the channel
                 L.check(lib.bpx_gate_mlp_bwd(dpart.data_ptr(), B, nt, C, x.vox, s.data_ptr(), sv.data_ptr(), w1.data_ptr(), w2.data_ptr(), R, self.relu,
                                              G[k1].data_ptr(), None, G[k2].data_ptr(), None, off.data_ptr(), self._st))
                 add, dst, fresh = self._acc_target(x)
-                L.check(lib.bpx_channel_affine(self.dt, B, x.vox, add, L.tview(out.grad), s.data_ptr(), off.data_ptr(), L.tview(dst), self._st))
+                L.check(lib.bpx_channel_affine(self.gdt, B, x.vox, add, L.tview(out.grad), s.data_ptr(), off.data_ptr(), L.tview(dst), self._st))
                 if fresh:
                     x.grad = dst
                 self._keep += [out.grad, off, dpart]
@@ -319,8 +321,8 @@ class ResUNetPPEngine(ResUNetEngine):
         if G is not None:
             def bwd():
                 if x.grad is None:
-                    x.grad = torch.zeros((B,) + x.S + (x.C,), dtype=self.dtype, device=self._dev)
-                L.check(lib.bpx_maxpool3d_bwd(self.dt, B, D, H, W, sz, x.view(), L.tview(out.grad), L.tview(x.grad), L.tview(x.grad), self._st))
+                    x.grad = torch.zeros((B,) + x.S + (x.C,), dtype=self.gdtype, device=self._dev)
+                L.check(lib.bpx_maxpool3d_bwd(self.bdt, B, D, H, W, sz, x.view(), L.tview(out.grad), L.tview(x.grad), L.tview(x.grad), self._st))
                 self._keep.append(out.grad)
             self._tape.append(bwd)
         return out
@@ -339,7 +341,7 @@ class ResUNetPPEngine(ResUNetEngine):
                 self._wgrad(B, x.S, x.view(), None, 0, L.tview(y.grad), 1, dw, db, self._st, self._dev)
                 wt = self._pack(w, L.PK_DENSE_T, Cin, Cout, False)
                 add, dst, fresh = self._acc_target(x)
-                L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, L.tview(y.grad), wt.data_ptr(), None, L.NULL_T, L.NULL_T, None, add, L.tview(dst), self._st))
+                L.check(lib.bpx_conv1x1_fwd(self.gdt, B, x.vox, L.tview(y.grad), wt.data_ptr(), None, L.NULL_T, L.NULL_T, None, add, L.tview(dst), self._st))
                 if fresh:
                     x.grad = dst
                 self._keep.append(y.grad)
@@ -387,8 +389,8 @@ class ResUNetPPEngine(ResUNetEngine):
         if G is not None:
             def bwd():
                 for j, (d, tables, xsv, raw, r, rec, wk, bk, gk, bek) in enumerate(branches):
-                    dslice = torch.empty((B,) + x.S + (Cout,), dtype=self.dtype, device=self._dev)   # dense copy of the branch's slice of d(cat)
-                    L.check(lib.bpx_norm_act_fwd(self.dt, B, x.vox, L.tview(cat.grad, j * Cout, Cout), self._ident_rec(Cout).data_ptr(), 0, L.tview(dslice), self._st))
+                    dslice = torch.empty((B,) + x.S + (Cout,), dtype=self.gdtype, device=self._dev)   # dense copy of the branch's slice of d(cat)
+                    L.check(lib.bpx_norm_act_fwd(self.gdt, B, x.vox, L.tview(cat.grad, j * Cout, Cout), self._ident_rec(Cout).data_ptr(), 0, L.tview(dslice), self._st))
                     dr = self._in_bwd(r, rec, 0, dslice, P[gk], G[gk], G[bek])
                     draw = self._act_bwd(raw, self.relu, dr)
                     if d == 0:                                                               # centre-tap branch (tables = the centre tap)
@@ -396,7 +398,7 @@ class ResUNetPPEngine(ResUNetEngine):
                         dbc = torch.zeros((Cout,), dtype=torch.float32, device=self._dev)
                         self._wgrad(B, x.S, x.view(), None, 0, L.tview(draw), 1, dwc, dbc, self._st, self._dev)
                         add, dst, fresh = self._acc_target(x)
-                        L.check(lib.bpx_conv1x1_fwd(self.dt, B, x.vox, L.tview(draw), self._pack(tables, L.PK_DENSE_T, x.C, Cout, False).data_ptr(), None,
+                        L.check(lib.bpx_conv1x1_fwd(self.gdt, B, x.vox, L.tview(draw), self._pack(tables, L.PK_DENSE_T, x.C, Cout, False).data_ptr(), None,
                                                     L.NULL_T, L.NULL_T, None, add, L.tview(dst), self._st))
                         if fresh:
                             x.grad = dst
@@ -412,8 +414,8 @@ class ResUNetPPEngine(ResUNetEngine):
                     nb = dys.shape[0]
                     self._wgrad(nb, xsv.S, xsv.view(), None, 0, L.tview(dys), 3, G[wk], G[bk], self._st, self._dev)
                     wt = self._pack(P[wk], L.PK_K3_T, x.C, Cout, False)
-                    gs = torch.empty(tuple(xsv.buf.shape), dtype=self.dtype, device=self._dev)
-                    L.check(lib.bpx_conv3d_dgrad(self.dt, nb, xsv.S[0], xsv.S[1], xsv.S[2], L.tview(dys), wt.data_ptr(), L.NULL_T, None, 0, L.tview(gs), None, self._st))
+                    gs = torch.empty(tuple(xsv.buf.shape), dtype=self.gdtype, device=self._dev)
+                    L.check(lib.bpx_conv3d_dgrad(self.gdt, nb, xsv.S[0], xsv.S[1], xsv.S[2], L.tview(dys), wt.data_ptr(), L.NULL_T, None, 0, L.tview(gs), None, self._st))
                     self._keep += [draw, dys, gs]
                     self._accum(x, dilation.packed_to_space(gs, d, x.S, tables))
                 self._keep.append(cat.grad)
@@ -464,9 +466,9 @@ class ResUNetPPEngine(ResUNetEngine):
         L.check(lib.bpx_gate_mul_fwd(self.dt, B * x2.vox, a16.view(), x2.view(), out.view(), self._st))
         if G is not None:
             def bwd_gate():
-                dx2 = torch.empty((B,) + x2.S + (C,), dtype=self.dtype, device=self._dev)
-                a16.grad = torch.empty((B,) + x2.S + (16,), dtype=self.dtype, device=self._dev)
-                L.check(lib.bpx_gate_mul_bwd(self.dt, B * x2.vox, L.tview(out.grad), a16.view(), x2.view(), L.tview(dx2), a16.grad.data_ptr(), self._st))
+                dx2 = torch.empty((B,) + x2.S + (C,), dtype=self.gdtype, device=self._dev)
+                a16.grad = torch.empty((B,) + x2.S + (16,), dtype=self.gdtype, device=self._dev)
+                L.check(lib.bpx_gate_mul_bwd(self.bdt, B * x2.vox, L.tview(out.grad), a16.view(), x2.view(), L.tview(dx2), a16.grad.data_ptr(), self._st))
                 self._keep.append(out.grad)
                 self._accum(x2, dx2)
             self._tape.append(bwd_gate)
@@ -497,11 +499,11 @@ class ResUNetPPEngine(ResUNetEngine):
                 dcat = cat.grad
                 self._accum(bridge, dcat, Cup)
                 ws = self._workspace(lib.bpx_convT3d_k2s2_wgrad_workspace(B, Dl, Hl, Wl, sz, Cup, Cup), self._dev)
-                L.check(lib.bpx_convT3d_k2s2_wgrad(self.dt, B, Dl, Hl, Wl, sz, x.view(), L.tview(dcat, 0, Cup), G[wk].data_ptr(), G[bk].data_ptr(),
+                L.check(lib.bpx_convT3d_k2s2_wgrad(self.bdt, B, Dl, Hl, Wl, sz, x.view(), L.tview(dcat, 0, Cup), G[wk].data_ptr(), G[bk].data_ptr(),
                                                    ws.data_ptr(), ws.numel(), self._st))
                 wt = self._pack(P[wk], L.PK_CT_T if sz == 2 else L.PK_CT4_T, Cup, Cup, False)
-                g = torch.empty((B,) + x.S + (Cup,), dtype=self.dtype, device=self._dev)
-                L.check(lib.bpx_convT3d_k2s2_dgrad(self.dt, B, Dl, Hl, Wl, sz, L.tview(dcat, 0, Cup), wt.data_ptr(), L.tview(g), self._st))
+                g = torch.empty((B,) + x.S + (Cup,), dtype=self.gdtype, device=self._dev)
+                L.check(lib.bpx_convT3d_k2s2_dgrad(self.gdt, B, Dl, Hl, Wl, sz, L.tview(dcat, 0, Cup), wt.data_ptr(), L.tview(g), self._st))
                 self._keep.append(dcat)
                 self._accum(x, g)
             self._tape.append(bwd)
@@ -513,10 +515,6 @@ class ResUNetPPEngine(ResUNetEngine):
         cfg = self.pp
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 1
         B, _, D0, H0, W0 = x.shape
-        if save and self.dtype == torch.float16:
-            # this engine's backward passes self.dt to every kernel and has no BPX_MIX16 plumbing (fp16 activations beside bf16 gradients, as
-            # ResUNetEngine has): refuse before the forward runs instead of failing in the first backward kernel
-            raise NotImplementedError(f"{type(self).__name__}: training with compute_dtype=torch.float16 is not implemented (inference only); train in bfloat16 or float32")
         fm, depth, zd = list(cfg.feature_maps), cfg.depth, cfg.z_down
         zdiv = 1
         for v in zd[1:]:
@@ -597,11 +595,11 @@ class ResUNetPPEngine(ResUNetEngine):
         L.check(lib.bpx_wgrad_defer_begin())
         try:
             dl = dlogits.contiguous().float()
-            feat.grad = torch.empty((B, D0, H0, W0, fm[0]), dtype=self.dtype, device=self._dev)
+            feat.grad = torch.empty((B, D0, H0, W0, fm[0]), dtype=self.gdtype, device=self._dev)
             hwg = torch.zeros((n_out, fm[0]), dtype=torch.float32, device=self._dev)
             hbg = torch.zeros((n_out,), dtype=torch.float32, device=self._dev)
             hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), self._dev)
-            L.check(lib.bpx_head_bwd(self.dt, vox0, B, feat.view(), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0, L.tview(feat.grad),
+            L.check(lib.bpx_head_bwd(self.bdt, vox0, B, feat.view(), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0, L.tview(feat.grad),
                                      hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), self._st))
             o = 0
             for h, oc in enumerate(cfg.out_channels):

@@ -1384,10 +1384,11 @@ def check_resunetpp(dtype, golden):
     loss.backward()
     torch.cuda.synchronize()
     f32 = dtype == torch.float32
-    tag = f"resunet++[{'f32' if f32 else 'bf16'}]"
+    mx = dtype == torch.float16      # the mixed mode (round 4): fp16 forward / activations - a forward an order of magnitude closer than bf16's - and bf16 gradients
+    tag = f"resunet++[{'f32' if f32 else 'mix16' if mx else 'bf16'}]"
     lo_ref = torch.from_numpy(g["logits"])
-    res = [_res(tag + ".logits_rel", (logits.detach().cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 3e-4 if f32 else 8e-2)]
-    res.append(_res(tag + ".loss", abs(loss.item() - float(g["loss"])) / float(g["loss"]), 1e-5 if f32 else 3e-2))
+    res = [_res(tag + ".logits_rel", (logits.detach().cpu() - lo_ref).abs().max().item() / lo_ref.abs().max().item(), 3e-4 if f32 else 1.5e-2 if mx else 8e-2)]
+    res.append(_res(tag + ".loss", abs(loss.item() - float(g["loss"])) / float(g["loss"]), 1e-5 if f32 else 8e-3 if mx else 3e-2))
     names = dict(m.named_parameters())
     gmax = max(float(g[k]) for k in g.files if k.startswith("gradnorm/"))
     floor = GRAD_FLOOR_F32 if f32 else GRAD_FLOOR_BF16
@@ -1458,7 +1459,8 @@ def check_resunetpp_cfg4_shape(dtype):
 
     fm, sd, x, tgt, loss_ref, lo_ref, grads_ref = _cfg4_oracle()
     f32 = dtype == torch.float32
-    tag = f"cfg4_80^3[{'f32' if f32 else 'bf16'}]"
+    mx = dtype == torch.float16      # mixed mode: the fp16 forward is held to an eighth of the bf16 forward bars, the bf16 gradient path to the bf16 bars
+    tag = f"cfg4_80^3[{'f32' if f32 else 'mix16' if mx else 'bf16'}]"
     m = ResUNetPlusPlus(image_shape=(80, 80, 80, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4,
                         z_down=[2] * 4, output_channels=[3], output_channel_info=["BCD"], head_activations=["ce_sigmoid", "ce_sigmoid", "linear"],
                         isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype)
@@ -1475,9 +1477,9 @@ def check_resunetpp_cfg4_shape(dtype):
 
     lo1, loss1, G1 = step(x[:1], tgt[:1])
     scale = lo_ref.abs().max().item()
-    res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, 3e-4 if f32 else 0.2, extra=f"scale={scale:.3f}")]
-    res.append(_res(tag + ".b1.logits_rel_l2", ((lo1 - lo_ref).norm() / lo_ref.norm()).item(), 1e-4 if f32 else 0.15))
-    res.append(_res(tag + ".b1.loss_rel", abs(loss1 - loss_ref.item()) / loss_ref.item(), 1e-5 if f32 else 5e-3))
+    res = [_res(tag + ".b1.logits_rel", (lo1 - lo_ref).abs().max().item() / scale, 3e-4 if f32 else 0.025 if mx else 0.2, extra=f"scale={scale:.3f}")]
+    res.append(_res(tag + ".b1.logits_rel_l2", ((lo1 - lo_ref).norm() / lo_ref.norm()).item(), 1e-4 if f32 else 0.02 if mx else 0.15))
+    res.append(_res(tag + ".b1.loss_rel", abs(loss1 - loss_ref.item()) / loss_ref.item(), 1e-5 if f32 else 1e-3 if mx else 5e-3))
     floor = GRAD_FLOOR_F32 if f32 else GRAD_FLOOR_BF16
     gmax = max(gr.norm().item() for gr in grads_ref.values())
     nworst, nname = 0.0, ""

