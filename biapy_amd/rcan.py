@@ -87,7 +87,7 @@ class rcan(nn.Module):
             self._engine = RCANEngine(dtype=self.compute_dtype, **self.cfg)
         return self._engine
 
-    supported_compute_dtypes = (torch.float32, torch.bfloat16, torch.float16)   # float16: inference (forward kernels only)
+    supported_compute_dtypes = (torch.float32, torch.bfloat16, torch.float16)   # float16: fp16 forward / activations; training = the mixed mode (bf16 gradients, round 4)
 
     def forward(self, x) -> torch.Tensor:
         if not x.is_cuda:

@@ -76,10 +76,6 @@ class RCANEngine(ResUNetEngine):
     def forward(self, P: Dict[str, torch.Tensor], x: torch.Tensor, head_act: int = 0, save: bool = False, cache_weights: bool = False):
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] == 1
         B, _, D, H, W = x.shape
-        if save and self.dtype == torch.float16:
-            # this engine's backward passes self.dt to every kernel and has no BPX_MIX16 plumbing (fp16 activations beside bf16 gradients, as
-            # ResUNetEngine has): refuse before the forward runs instead of failing in the first backward kernel
-            raise NotImplementedError(f"{type(self).__name__}: training with compute_dtype=torch.float16 is not implemented (inference only); train in bfloat16 or float32")
         S, vox, Fc, T, dev, st = (D, H, W), D * H * W, self.Fc, self.dtype, x.device, L.stream_ptr()
         self._begin_recorded_packs(P, save, dev, cache_weights)
         c = self._consts(B, dev)
@@ -155,7 +151,9 @@ class RCANEngine(ResUNetEngine):
         assert ctx["head_act"] == 0, "train on the linear output (the reference applies its output activation inside the model; pass head_activations=['linear'])"
         B, S = ctx["B"], ctx["S"]
         D, H, W = S
-        vox, Fc, T, dev, st, c = D * H * W, self.Fc, self.dtype, dy_out.device, L.stream_ptr(), self._c
+        # T: storage type of the gradient tensors (bf16 in the mixed mode, compute_dtype float16: the forward tensors are fp16 - engine.ResUNetEngine's
+        # codes: gdt = kernels on gradient tensors only, bdt = backward kernels that also read a forward tensor)
+        vox, Fc, T, dev, st, c = D * H * W, self.Fc, self.gdtype, dy_out.device, L.stream_ptr(), self._c
         self._keep = []
         flat = torch.zeros(sum(p.numel() for p in P.values()), dtype=torch.float32, device=dev)   # ONE fill for the ~1,650 parameter gradients
         G, o = {}, 0
@@ -176,13 +174,13 @@ class RCANEngine(ResUNetEngine):
             def dgrad(dy, w, t_pre=None, rec=None, act=0):
                 g = buf(w.shape[1])
                 wt = self._pack(w, L.PK_K3_T, w.shape[1], w.shape[0], False)
-                L.check(lib.bpx_conv3d_dgrad(self.dt, B, D, H, W, L.tview(dy), wt.data_ptr(), L.tview(t_pre) if t_pre is not None else L.NULL_T,
+                L.check(lib.bpx_conv3d_dgrad(self.bdt if t_pre is not None else self.gdt, B, D, H, W, L.tview(dy), wt.data_ptr(), L.tview(t_pre) if t_pre is not None else L.NULL_T,
                                              L.ptr(rec), act, L.tview(g), None, st))
                 return g
 
             def add(a, b):                                                     # a + b, elementwise
                 o = buf()
-                L.check(lib.bpx_channel_affine(self.dt, B, vox, L.tview(a), L.tview(b), c["ones_bc"].data_ptr(), None, L.tview(o), st))
+                L.check(lib.bpx_channel_affine(self.gdt, B, vox, L.tview(a), L.tview(b), c["ones_bc"].data_ptr(), None, L.tview(o), st))
                 return o
 
             # head (linear): gradient of the padded 16-channel tensor
@@ -191,7 +189,7 @@ class RCANEngine(ResUNetEngine):
             hbg = torch.zeros((self.n_out,), dtype=torch.float32, device=dev)
             dl = dy_out.contiguous().float()
             hws = self._workspace(lib.bpx_head_bwd_workspace(16, self.n_out), dev)
-            L.check(lib.bpx_head_bwd(self.dt, vox, B, L.tview(ctx["o16"]), ctx["hw"].data_ptr(), self.n_out, dl.data_ptr(), self.n_out * vox, vox,
+            L.check(lib.bpx_head_bwd(self.bdt, vox, B, L.tview(ctx["o16"]), ctx["hw"].data_ptr(), self.n_out, dl.data_ptr(), self.n_out * vox, vox,
                                      L.tview(do16), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
             dw16 = torch.zeros((16, Fc, 3, 3, 3), dtype=torch.float32, device=dev)
             db16 = torch.zeros(16, dtype=torch.float32, device=dev)
@@ -207,16 +205,16 @@ class RCANEngine(ResUNetEngine):
                 dz = dgrad(dcur, P[f"{pt}.weight"])
                 for blk in reversed(grp["blocks"]):
                     p = blk["p"]
-                    nt = lib.bpx_norm_act_tiles(self.dt, vox, Fc)
+                    nt = lib.bpx_norm_act_tiles(self.gdt, vox, Fc)
                     dpart = torch.empty((B, nt, Fc), dtype=torch.float32, device=dev)
-                    L.check(lib.bpx_dot_stats(self.dt, B, vox, L.tview(dz), L.tview(blk["h2"]), dpart.data_ptr(), st))
+                    L.check(lib.bpx_dot_stats(self.bdt, B, vox, L.tview(dz), L.tview(blk["h2"]), dpart.data_ptr(), st))
                     nm = blk["names"]
                     off = torch.empty((B, Fc), dtype=torch.float32, device=dev)   # d mean / voxels -> every voxel of the channel
                     L.check(lib.bpx_gate_mlp_bwd(dpart.data_ptr(), B, nt, Fc, vox, blk["sd"].data_ptr(), blk["sv"].data_ptr(), P[nm[0]].data_ptr(),
                                                  P[nm[2]].data_ptr(), self.red, self.silu, G[nm[0]].data_ptr(), G[nm[1]].data_ptr(), G[nm[2]].data_ptr(),
                                                  G[nm[3]].data_ptr(), off.data_ptr(), st))
                     dh2 = buf()
-                    L.check(lib.bpx_channel_affine(self.dt, B, vox, L.NULL_T, L.tview(dz), blk["sd"].data_ptr(), off.data_ptr(), L.tview(dh2), st))
+                    L.check(lib.bpx_channel_affine(self.gdt, B, vox, L.NULL_T, L.tview(dz), blk["sd"].data_ptr(), off.data_ptr(), L.tview(dh2), st))
                     self._keep += [off, dpart]
                     wgrad(blk["h1"], c["rec"], self.silu, dh2, G[f"{p}.module.2.weight"], G[f"{p}.module.2.bias"])
                     dh1 = dgrad(dh2, P[f"{p}.module.2.weight"], blk["h1"], c["rec"], self.silu)
@@ -225,7 +223,7 @@ class RCANEngine(ResUNetEngine):
                 dcur = add(dz, dcur)                                           # through the RCABs + the group's identity path
             df0 = add(dcur, dt)                                                # + the trunk's `x += residual`
             wsc = self._workspace(lib.bpx_conv3d_c1_wgrad_workspace(self.Fc), dev)
-            L.check(lib.bpx_conv3d_c1_wgrad(self.dt, B, D, H, W, ctx["img"].data_ptr(), L.tview(df0), G["sf.weight"].data_ptr(), G["sf.bias"].data_ptr(),
+            L.check(lib.bpx_conv3d_c1_wgrad(self.gdt, B, D, H, W, ctx["img"].data_ptr(), L.tview(df0), G["sf.weight"].data_ptr(), G["sf.bias"].data_ptr(),
                                             wsc.data_ptr(), wsc.numel(), st))
         finally:
             self._deferred = False

@@ -1577,9 +1577,10 @@ def test_sharded_sliding_window_from_input_slabs_equals_single_device():
     assert (res[0][3].view(np.uint32) == ref.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "mix16"])
 def test_rcan_trunk_matches_reference_fixture(rcan_golden, dtype):
-    """biapy_amd.rcan.rcan (3-D trunk, row S) vs the reference's own output, L1 loss and every gradient."""
+    """biapy_amd.rcan.rcan (3-D trunk, row S) vs the reference's own output, L1 loss and every gradient.  mix16 (round 4): fp16 forward and activations,
+    bf16 gradients."""
     import torch.nn.functional as F
 
     from biapy_amd.rcan import rcan
@@ -1595,10 +1596,11 @@ def test_rcan_trunk_matches_reference_fixture(rcan_golden, dtype):
     loss = F.l1_loss(y, torch.from_numpy(g["target"]).cuda())
     loss.backward()
     torch.cuda.synchronize()
-    bf = dtype == torch.bfloat16
+    bf = dtype in (torch.bfloat16, torch.float16)       # gradient bars: the bf16 ones in both 16-bit modes
+    mx = dtype == torch.float16
     yr = torch.from_numpy(g["y"])
-    assert (y.detach().cpu() - yr).abs().max().item() / yr.abs().max().item() < (6e-2 if bf else 2e-4)
-    assert abs(loss.item() - float(g["loss"])) < (2e-2 if bf else 1e-5)
+    assert (y.detach().cpu() - yr).abs().max().item() / yr.abs().max().item() < (8e-3 if mx else 6e-2 if bf else 2e-4)
+    assert abs(loss.item() - float(g["loss"])) < (3e-3 if mx else 2e-2 if bf else 1e-5)
     gmax = max(float(g[k]) for k in g.files if k.startswith("gradnorm/"))
     worst = 0.0
     for k, p in m.named_parameters():
