@@ -8,9 +8,10 @@ group tail, ``conv1``, ``conv2``), ordinary ``nn.Parameter``s; ``forward`` hands
 2-D only - ``nn.PixelShuffle`` on 5-D tensors raises - so there is no reference behaviour to reproduce.  This class DEFINES the 3-D form as
 the same rule with one more axis: ``upscale.0 = Conv3d(filters, filters * scale**3, 3)`` followed by a 3-D pixel shuffle
 (out[n, c, s z + a, s y + b, s x + e] = conv[n, c s^3 + (a s + b) s + e, z, y, x]; oracle/rcan_oracle.py::pixel_shuffle3d), fused into the store
-of the convolution (``bpx_conv3d_fwd_shuffle``: the 16 s^3-channel tensor never exists), filters = 16, scale 2..4, patches >= 64^3.  It is
-an inference path (cfg 5: 64^3 -> 256^3 in fp16); training it raises ``NotImplementedError``.  Parity: unpinned against BiaPy by
-construction, checked against the oracle's restatement of the defined semantics.
+of the convolution (``bpx_conv3d_fwd_shuffle``: the 16 s^3-channel tensor never exists), filters = 16, scale 2..4, patches >= 32^3, 16-bit
+storage.  Training (round 4): the stage's backward is the shuffle's adjoint (sub-positions gathered back into 16-channel blocks) followed by the
+convolution's own weight / input gradient kernels per block on the low-resolution grid (``RCANEngine.backward``).  Parity: unpinned against BiaPy by
+construction, outputs and every gradient checked against the oracle's restatement of the defined semantics (autograd through ``pixel_shuffle3d``).
 
 Not covered (``NotImplementedError`` at construction): 2D, more than one input channel, filters other than 16 / 32, more than 4 output
 channels.
@@ -96,9 +97,6 @@ class rcan(nn.Module):
         params = [p for _, p in self.named_parameters()]
         x = x.to(torch.float32)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            if self.scale:
-                raise NotImplementedError("biapy_amd.rcan: the x%d up-scaling stage is an inference path (no backward kernels); train the trunk "
-                                          "(upscaling_layer=False) or run under torch.no_grad()" % self.scale)
             if self.head_code != 0:
                 raise NotImplementedError("biapy_amd.rcan trains through the linear output; use head_activations=['linear']")
             return _ResUNetFn.apply(x, self.engine(), names, *params)

@@ -15,11 +15,14 @@ graph, from the same C-ABI kernels as the U-Nets:
   * the last convolution (filters -> out_channels <= 4) runs with its output channels zero-padded to 16 and the head kernel picks
     the real ones and applies the output activation.
 
-The reference's 3-D up-scaling branch (``nn.PixelShuffle`` on 5-D tensors) raises, so only ``upscaling_layer=False`` exists here.
+The reference's 3-D up-scaling branch (``nn.PixelShuffle`` on 5-D tensors) raises; ``scale`` > 0 runs the DEFINED 3-D form (rcan.py docstring):
+forward = ``bpx_conv3d_fwd_shuffle``, backward (round 4) = the shuffle's adjoint (a gather of the sub-positions into channel blocks) + the conv's
+own ``bpx_conv3d_wgrad`` / ``_dgrad`` per block of sub-positions on the low-resolution grid.
 Weights are packed with one launch per step from the second step on (``ResUNetEngine._begin_recorded_packs``).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -40,6 +43,7 @@ class RCANEngine(ResUNetEngine):
         super().__init__(NetConfig(in_ch=1, feature_maps=[filters, filters], out_channels=(out_channels,), activation="silu"), dtype)
         self.Fc, self.num_rg, self.num_rcab, self.red, self.n_out = filters, num_rg, num_rcab, max(1, filters // reduction), out_channels
         self.silu = L.ACT["silu"]
+        self.up_group = int(os.environ.get("BPX_RCAN_UP_GROUP", "8"))   # sub-positions per backward call of the x scale stage (8: 128-channel blocks; 1: 16-channel blocks)
         self.scale = int(scale)          # > 0: conv(filters -> filters * scale^3) + 3-D pixel shuffle in front of the last conv (rcan.py:344-345)
         if self.scale and (filters != 16 or self.scale not in (2, 3, 4) or dtype == torch.float32):
             raise NotImplementedError("RCANEngine: the up-scaling stage needs 16 filters, scale 2..4 and 16-bit storage (bpx_conv3d_fwd_shuffle)")
@@ -117,8 +121,6 @@ class RCANEngine(ResUNetEngine):
             # x scale: the conv's 16 s^3 output channels in the order [sub-position][channel] (PyTorch's pixel-shuffle order is
             # [channel][sub-position]: a permutation of the weight's rows), each 16-channel block stored to its sub-position of the
             # (B, sD, sH, sW, 16) tensor - the 1024-channel tensor of cfg 5 (x4) is never written
-            if save:
-                raise NotImplementedError("RCANEngine: the up-scaling stage has no backward kernels (inference path)")
             s_ = self.scale
             s3 = s_ ** 3
             wu = P["upscale.0.weight"].reshape(Fc, s3, Fc, 3, 3, 3).transpose(0, 1).reshape(s3 * Fc, Fc, 3, 3, 3).contiguous()
@@ -127,6 +129,7 @@ class RCANEngine(ResUNetEngine):
             D, H, W = D * s_, H * s_, W * s_
             up = torch.empty((B, D, H, W, Fc), dtype=T, device=dev)
             L.check(lib.bpx_conv3d_fwd_shuffle(self.dt, B, S[0], S[1], S[2], L.tview(t), None, 0, wpu.data_ptr(), bu.data_ptr(), s_, L.tview(up), st))
+            low = dict(S=S, t=t, wu=wu)                                      # what the stage's backward reads: its input and the re-ordered weight
             t, S, vox = up, (D, H, W), D * H * W
 
             def buf(C=Fc):                                                   # buffers of the high-resolution grid from here on
@@ -142,7 +145,7 @@ class RCANEngine(ResUNetEngine):
         hb = torch.zeros(self.n_out, dtype=torch.float32, device=dev)
         y = torch.empty((B, self.n_out, D, H, W), dtype=torch.float32, device=dev)
         L.check(lib.bpx_head_fwd(self.dt, vox, B, L.tview(o16), hw.data_ptr(), hb.data_ptr(), self.n_out, head_act, y.data_ptr(), self.n_out * vox, vox, st))
-        ctx = dict(B=B, S=S, img=img, f0=f0, groups=groups, last=cur, t=t, o16=o16, w2p=w2p, hw=hw, head_act=head_act) if save else None
+        ctx = dict(B=B, S=S, img=img, f0=f0, groups=groups, last=cur, t=t, o16=o16, w2p=w2p, hw=hw, head_act=head_act, low=low if self.scale else None) if save else None
         return y, ctx
 
     # ---- backward ------------------------------------------------------------------------------------------------------------
@@ -195,6 +198,30 @@ class RCANEngine(ResUNetEngine):
             db16 = torch.zeros(16, dtype=torch.float32, device=dev)
             wgrad(ctx["t"], None, 0, do16, dw16, db16)
             dt = dgrad(do16, ctx["w2p"])
+            if self.scale:
+                # x scale stage: dt is the gradient of the shuffled tensor (B, sD, sH, sW, Fc).  Gathering its s^3 sub-positions back into channel
+                # blocks ([sub-position][channel], the order the forward kernel takes the weight rows in) IS the pixel shuffle's adjoint; the conv's two
+                # gradients then run per group of `up_group` sub-positions on the low-resolution grid: dW / db rows of the group (independent), and
+                # the input gradient as the sum of the groups' dgrads (the convolution is linear in its output-channel blocks)
+                s_, low = self.scale, ctx["low"]
+                s3 = s_ ** 3
+                S = low["S"]
+                D, H, W = S                                                    # the helpers above work on the low-resolution grid from here on
+                vox = D * H * W
+                dsub = dt.view(B, D, s_, H, s_, W, s_, Fc).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, D, H, W, s3, Fc)
+                wu = low["wu"]
+                dwu = torch.zeros_like(wu)
+                dbu = torch.zeros(s3 * Fc, dtype=torch.float32, device=dev)
+                parts, gs = [], max(1, int(self.up_group))
+                for i in range(0, s3, gs):
+                    n = min(gs, s3 - i)
+                    dyb = dsub[..., i:i + n, :].reshape(B, D, H, W, n * Fc).contiguous()
+                    self._keep.append(dyb)
+                    wgrad(low["t"], None, 0, dyb, dwu[i * Fc:(i + n) * Fc], dbu[i * Fc:(i + n) * Fc])
+                    parts.append(dgrad(dyb, wu[i * Fc:(i + n) * Fc]))
+                while len(parts) > 1:                                          # pairwise: log2(groups) roundings of the 16-bit sums
+                    parts = [add(parts[j], parts[j + 1]) if j + 1 < len(parts) else parts[j] for j in range(0, len(parts), 2)]
+                dt = parts[0]
             # conv1 (+ identity from f0)
             wgrad(ctx["last"], None, 0, dt, G["conv1.weight"], G["conv1.bias"])
             dcur = dgrad(dt, P["conv1.weight"])
@@ -230,5 +257,9 @@ class RCANEngine(ResUNetEngine):
             L.check(lib.bpx_wgrad_defer_flush(st))
         G["conv2.weight"].copy_(dw16[: self.n_out])
         G["conv2.bias"].copy_(db16[: self.n_out])
+        if self.scale:                                                       # rows back from [sub-position][channel] to PyTorch's [channel][sub-position]
+            s3 = self.scale ** 3
+            G["upscale.0.weight"].copy_(dwu.reshape(s3, Fc, Fc, 3, 3, 3).transpose(0, 1).reshape(Fc * s3, Fc, 3, 3, 3))
+            G["upscale.0.bias"].copy_(dbu.reshape(s3, Fc).t().reshape(-1))
         self._keep = []
         return G
