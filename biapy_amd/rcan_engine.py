@@ -33,6 +33,26 @@ from .engine import NetConfig, ResUNetEngine, _Stats
 lib = L.lib
 
 
+
+# ---- x scale stage: orders of the 16 s^3 conv channels (pure tensor algebra, checked on the CPU against autograd through the oracle's pixel_shuffle3d) ----
+def rows_to_subposition_major(w: torch.Tensor, b: torch.Tensor, Fc: int, s3: int):
+    """PyTorch's pixel-shuffle channel order [channel][sub-position] -> the kernels' [sub-position][channel] (weight rows and bias alike)."""
+    return (w.reshape(Fc, s3, *w.shape[1:]).transpose(0, 1).reshape(s3 * Fc, *w.shape[1:]).contiguous(), b.reshape(Fc, s3).t().reshape(-1).contiguous())
+
+
+def rows_from_subposition_major(w: torch.Tensor, b: torch.Tensor, Fc: int, s3: int):
+    """Inverse of :func:`rows_to_subposition_major` (what the stage's weight / bias gradients go through)."""
+    return (w.reshape(s3, Fc, *w.shape[1:]).transpose(0, 1).reshape(Fc * s3, *w.shape[1:]), b.reshape(s3, Fc).t().reshape(-1))
+
+
+def gather_subpositions(d_up: torch.Tensor, s: int) -> torch.Tensor:
+    """Adjoint of the 3-D pixel shuffle on channels-last tensors: (B, sD, sH, sW, Fc) -> (B, D, H, W, s^3, Fc), sub-position (a, b, e) of voxel
+    (z, y, x) = voxel (s z + a, s y + b, s x + e) of the fine grid, sub-positions in the order (a s + b) s + e (rcan.py docstring)."""
+    B, Ds, Hs, Ws, Fc = d_up.shape
+    D, H, W = Ds // s, Hs // s, Ws // s
+    return d_up.view(B, D, s, H, s, W, s, Fc).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, D, H, W, s ** 3, Fc)
+
+
 class RCANEngine(ResUNetEngine):
     def __init__(self, num_channels: int, filters: int, num_rg: int, num_rcab: int, reduction: int, out_channels: int,
                  dtype: torch.dtype = torch.bfloat16, scale: int = 0):
@@ -123,8 +143,7 @@ class RCANEngine(ResUNetEngine):
             # (B, sD, sH, sW, 16) tensor - the 1024-channel tensor of cfg 5 (x4) is never written
             s_ = self.scale
             s3 = s_ ** 3
-            wu = P["upscale.0.weight"].reshape(Fc, s3, Fc, 3, 3, 3).transpose(0, 1).reshape(s3 * Fc, Fc, 3, 3, 3).contiguous()
-            bu = P["upscale.0.bias"].reshape(Fc, s3).t().reshape(-1).contiguous()
+            wu, bu = rows_to_subposition_major(P["upscale.0.weight"], P["upscale.0.bias"], Fc, s3)
             wpu = self._pack(wu, L.PK_K3, Fc, s3 * Fc, False)
             D, H, W = D * s_, H * s_, W * s_
             up = torch.empty((B, D, H, W, Fc), dtype=T, device=dev)
@@ -208,7 +227,7 @@ class RCANEngine(ResUNetEngine):
                 S = low["S"]
                 D, H, W = S                                                    # the helpers above work on the low-resolution grid from here on
                 vox = D * H * W
-                dsub = dt.view(B, D, s_, H, s_, W, s_, Fc).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, D, H, W, s3, Fc)
+                dsub = gather_subpositions(dt, s_)
                 wu = low["wu"]
                 dwu = torch.zeros_like(wu)
                 dbu = torch.zeros(s3 * Fc, dtype=torch.float32, device=dev)
@@ -259,7 +278,8 @@ class RCANEngine(ResUNetEngine):
         G["conv2.bias"].copy_(db16[: self.n_out])
         if self.scale:                                                       # rows back from [sub-position][channel] to PyTorch's [channel][sub-position]
             s3 = self.scale ** 3
-            G["upscale.0.weight"].copy_(dwu.reshape(s3, Fc, Fc, 3, 3, 3).transpose(0, 1).reshape(Fc * s3, Fc, 3, 3, 3))
-            G["upscale.0.bias"].copy_(dbu.reshape(s3, Fc).t().reshape(-1))
+            gw, gb = rows_from_subposition_major(dwu, dbu, Fc, s3)
+            G["upscale.0.weight"].copy_(gw)
+            G["upscale.0.bias"].copy_(gb)
         self._keep = []
         return G

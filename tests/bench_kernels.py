@@ -341,6 +341,53 @@ def bench_rcan():
     print(f"  graph replay: train step {gt * 1e3:.1f} ms ({64 ** 3 / gt / 1e6:.2f} Mvox/s)", flush=True)
 
 
+def bench_rcan_x4_train():
+    """cfg 5 as configured (RCAN x4: 10 x 20 RCABs, 16 filters, 64^3 -> 256^3), TRAIN step in the mixed mode: forward + L1 + backward (the x-scale stage's
+    backward = the shuffle's adjoint + wgrad / dgrad per 128-channel block, round 4) + AdamW, eager and replayed from a HIP graph."""
+    import time
+
+    from biapy_amd.graphs import GraphedTrainStep
+    from biapy_amd.rcan import rcan
+
+    torch.manual_seed(0)
+    m = rcan(ndim=3, num_channels=1, filters=16, scale=4, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=True, out_channels=1, head_activations=["linear"],
+             compute_dtype=torch.float16).cuda().train()
+    x = torch.randn(1, 1, 64, 64, 64, device=DEV)
+    t = torch.randn(1, 1, 256, 256, 256, device=DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+    for g in (1, 8):
+        m.engine().up_group = g
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.l1_loss(m(x), t)
+            loss.backward()
+            opt.step()
+            return loss
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            loss = step()
+        torch.cuda.synchronize()
+        tr = (time.perf_counter() - t0) / 3
+        print(f"rcan x4 64^3 -> 256^3 train step, eager, {g} sub-position(s) per backward call: {tr * 1e3:.1f} ms, loss {loss.item():.4f}", flush=True)
+    del opt, m                                                              # a fresh model and optimizer for the capture (see bench_rcan)
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    m2 = rcan(ndim=3, num_channels=1, filters=16, scale=4, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=True, out_channels=1, head_activations=["linear"],
+              compute_dtype=torch.float16).cuda().train()
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-4, capturable=True, fused=True)
+    gs = GraphedTrainStep(m2, torch.nn.functional.l1_loss, opt2, x, t, warmup=1)
+    gs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gs()
+    torch.cuda.synchronize()
+    gt = (time.perf_counter() - t0) / 5
+    print(f"  graph replay: train step {gt * 1e3:.1f} ms ({256 ** 3 / gt / 1e6:.1f} M output voxels/s, {64 ** 3 / gt / 1e6:.2f} M input voxels/s)", flush=True)
+
+
 def bench_chunked():
     """By-chunks inference of a 512^3 float32 volume: 128^3 patches, padding 16 -> 96^3 chunks (216 of them), cfg-2 ResUNet bf16."""
     import time
@@ -401,6 +448,9 @@ def bench_prepost(reps=5):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rcan":
         bench_rcan()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rcan_x4":
+        bench_rcan_x4_train()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "convt":
         bench_convt()

@@ -592,3 +592,33 @@ def test_fused_adam_step_refuses_what_it_does_not_reproduce():
         assert torch.equal(before, p[0])
         O.step(opt)                                   # falls through to torch
         assert not torch.equal(before, p[0])
+
+
+@pytest.mark.parametrize("s", [2, 3])
+def test_rcan_upscale_stage_channel_orders_are_the_shuffles_adjoint(s):
+    """Host algebra of the RCAN x-scale stage (rcan_engine.rows_to_/_from_subposition_major, gather_subpositions): the conv with its rows in the
+    kernels' [sub-position][channel] order + the sub-position gather reproduce the oracle's conv + pixel_shuffle3d, and the stage's backward
+    (gather the fine-grid gradient, the conv's weight / bias gradient per row, rows back to PyTorch's order) reproduces autograd through it."""
+    import torch.nn.functional as F
+
+    from biapy_amd.rcan_engine import gather_subpositions, rows_from_subposition_major, rows_to_subposition_major
+    from oracle.rcan_oracle import pixel_shuffle3d
+
+    g = torch.Generator().manual_seed(s)
+    Fc, D, s3 = 4, 5, s ** 3
+    x = torch.randn(2, Fc, D, D + 1, D + 2, generator=g, dtype=torch.float64)
+    w = torch.randn(Fc * s3, Fc, 3, 3, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(Fc * s3, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = pixel_shuffle3d(F.conv3d(x, w, b, padding=1), s)
+    r = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (y * r).sum().backward()
+    wu, bu = rows_to_subposition_major(w.detach(), b.detach(), Fc, s3)
+    cu = F.conv3d(x, wu, bu, padding=1)                                       # channels [sub-position][channel]
+    B, _, Dz, Dy, Dx = cu.shape
+    assert torch.equal(gather_subpositions(y.detach().permute(0, 2, 3, 4, 1).contiguous(), s), cu.permute(0, 2, 3, 4, 1).reshape(B, Dz, Dy, Dx, s3, Fc))
+    dcu = gather_subpositions(r.permute(0, 2, 3, 4, 1).contiguous(), s).reshape(B, Dz, Dy, Dx, s3 * Fc).permute(0, 4, 1, 2, 3).contiguous()
+    gwu = torch.nn.grad.conv3d_weight(x, wu.shape, dcu, padding=1)
+    gw, gb = rows_from_subposition_major(gwu, dcu.sum((0, 2, 3, 4)), Fc, s3)
+    assert torch.allclose(gw, w.grad, rtol=1e-10, atol=1e-10) and torch.allclose(gb, b.grad, rtol=1e-10, atol=1e-10)
+    w2, b2 = rows_from_subposition_major(wu, bu, Fc, s3)
+    assert torch.equal(w2, w.detach()) and torch.equal(b2, b.detach())
