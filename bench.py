@@ -380,7 +380,7 @@ def main():
                          "bf16: the all-bf16 mode of rounds 1-2 (A/B baseline); f32: the exact mode")
     ap.add_argument("--infer-dtype", choices=["f16", "bf16", "f32", "same"], default="f16",
                     help="storage type of the inference forward and of the sliding window (sub-records `infer`, `sliding`; --mode infer / sliding): "
-                         "f16 = the inference mode that meets the Dice < 1e-4 bar at the speed of bf16 (no backward kernels exist for it); "
+                         "f16 = the fp16 forward that meets the Dice < 1e-4 bar at the speed of bf16 (the forward of the mixed training mode); "
                          "same = --dtype")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel timing table of one step and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")

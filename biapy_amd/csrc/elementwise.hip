@@ -2139,8 +2139,15 @@ __device__ __forceinline__ float gate_column_sum(const float* col, int tiles, si
   const int c = threadIdx.x % C, l = threadIdx.x / C, lanes = 256 / C;
   double a = 0.0;
   if (l < lanes) {
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0;                  // four loads in flight: the kernel is one latency chain otherwise
-    int t = l;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;                  // four accumulators; the kernel is one latency chain of L2 reads otherwise, so
+    int t = l;                                            // sixteen loads are issued before the first add (the adds keep the order of the 4-row loop below: same bits)
+    for (; t + 15 * lanes < tiles; t += 16 * lanes) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = col[(size_t)(t + k * lanes) * tstride + c];
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) { a += (double)v[k]; a1 += (double)v[k + 1]; a2 += (double)v[k + 2]; a3 += (double)v[k + 3]; }
+    }
     for (; t + 3 * lanes < tiles; t += 4 * lanes) {
       a += (double)col[(size_t)t * tstride + c];
       a1 += (double)col[(size_t)(t + lanes) * tstride + c];

@@ -388,6 +388,27 @@ def bench_rcan_x4_train():
     print(f"  graph replay: train step {gt * 1e3:.1f} ms ({256 ** 3 / gt / 1e6:.1f} M output voxels/s, {64 ** 3 / gt / 1e6:.2f} M input voxels/s)", flush=True)
 
 
+def bench_rcan_fwd_only():
+    """The cfg-5 trunk forward replayed from a HIP graph, nothing else (the command `rocprofv3 --kernel-trace --stats` is run on)."""
+    import time
+
+    from biapy_amd.graphs import GraphedInference
+    from biapy_amd.rcan import rcan
+
+    torch.manual_seed(0)
+    m = rcan(ndim=3, num_channels=1, filters=16, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"],
+             compute_dtype=torch.float16).cuda().eval()
+    x = torch.randn(1, 1, 64, 64, 64, device=DEV)
+    gi = GraphedInference(m, x)
+    gi()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        gi()
+    torch.cuda.synchronize()
+    print(f"rcan trunk forward, graph replay: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms", flush=True)
+
+
 def bench_chunked():
     """By-chunks inference of a 512^3 float32 volume: 128^3 patches, padding 16 -> 96^3 chunks (216 of them), cfg-2 ResUNet bf16."""
     import time
@@ -451,6 +472,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rcan_x4":
         bench_rcan_x4_train()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rcan_fwd":
+        bench_rcan_fwd_only()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "convt":
         bench_convt()
