@@ -409,6 +409,29 @@ def bench_rcan_fwd_only():
     print(f"rcan trunk forward, graph replay: {(time.perf_counter() - t0) / 20 * 1e3:.2f} ms", flush=True)
 
 
+def bench_rcan_train_only():
+    """The cfg-5 trunk TRAIN step (mixed mode) replayed from a HIP graph, nothing else (for `rocprofv3 --kernel-trace --stats`)."""
+    import time
+
+    from biapy_amd.graphs import GraphedTrainStep
+    from biapy_amd.rcan import rcan
+
+    torch.manual_seed(0)
+    m = rcan(ndim=3, num_channels=1, filters=16, num_rg=10, num_rcab=20, reduction=16, upscaling_layer=False, out_channels=1, head_activations=["linear"],
+             compute_dtype=torch.float16).cuda().train()
+    x = torch.randn(1, 1, 64, 64, 64, device=DEV)
+    t = torch.randn(1, 1, 64, 64, 64, device=DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, capturable=True, fused=True)
+    gs = GraphedTrainStep(m, torch.nn.functional.l1_loss, opt, x, t, warmup=1)
+    gs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        gs()
+    torch.cuda.synchronize()
+    print(f"rcan trunk train step (mixed mode), graph replay: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms", flush=True)
+
+
 def bench_chunked():
     """By-chunks inference of a 512^3 float32 volume: 128^3 patches, padding 16 -> 96^3 chunks (216 of them), cfg-2 ResUNet bf16."""
     import time
@@ -475,6 +498,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rcan_fwd":
         bench_rcan_fwd_only()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rcan_train":
+        bench_rcan_train_only()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "convt":
         bench_convt()
