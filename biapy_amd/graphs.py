@@ -41,8 +41,8 @@ class _LrTensors:
         self.lrs = []
         for g in optimizer.param_groups:
             lr = g["lr"]
-            if not torch.is_tensor(lr):
-                lr = torch.tensor(float(lr), dtype=torch.float32, device=device)
+            if not torch.is_tensor(lr) or lr.device != torch.device(device) or lr.dtype != torch.float32 or lr.numel() != 1:
+                lr = torch.tensor(float(lr), dtype=torch.float32, device=device)      # also a host / fp64 tensor lr: the captured kernels read a device float
                 g["lr"] = lr
             self.lrs.append(lr)
 

@@ -5,7 +5,8 @@ nothing unusual.  torch's multi-tensor launch gives one 64 K-element chunk to a 
 and three launches of 45 us; ``bpx_adam_step`` uses 4096-element blocks (two launches plus the step increment).
 
 ``fused_step(optimizer)`` returns False - and does nothing - for anything it does not reproduce exactly (another optimizer class, amsgrad,
-maximize, host-side ``step`` counters, state not yet initialised, non-fp32 or non-contiguous tensors, sparse gradients, a missing gradient):
+maximize, host-side ``step`` counters, tensor-valued betas / eps / weight decay, registered step hooks, state not yet initialised, non-fp32 or
+non-contiguous tensors, sparse gradients, a missing gradient) - decided for every group before the first launch, so a step is never half done:
 the caller then runs ``optimizer.step()`` itself.
 """
 from __future__ import annotations
@@ -26,6 +27,11 @@ def _group_ok(opt, g) -> bool:
         return False
     if not g.get("capturable", False):       # host-side step counters: torch's own path
         return False
+    if any(torch.is_tensor(v) for v in (*g["betas"], g["eps"], g["weight_decay"])):
+        return False
+    lr = g["lr"]
+    if torch.is_tensor(lr) and lr.is_cuda and (lr.dtype != torch.float32 or lr.numel() != 1):
+        return False
     for p in g["params"]:
         if p.grad is None:
             return False
@@ -42,17 +48,26 @@ def _group_ok(opt, g) -> bool:
     return True
 
 
+def _has_step_hooks(opt) -> bool:
+    import torch.optim.optimizer as O
+
+    return bool(getattr(opt, "_optimizer_step_pre_hooks", None) or getattr(opt, "_optimizer_step_post_hooks", None)
+                or getattr(O, "_global_optimizer_pre_hooks", None) or getattr(O, "_global_optimizer_post_hooks", None))
+
+
 @torch.no_grad()
 def fused_step(optimizer: torch.optim.Optimizer) -> bool:
     """One optimizer step through ``bpx_adam_step``; False (nothing done) when the optimizer is not an Adam(W) this kernel reproduces."""
     if not _ENABLED or type(optimizer) not in (torch.optim.Adam, torch.optim.AdamW):
         return False
-    groups = optimizer.param_groups
-    if not all(_group_ok(optimizer, g) for g in groups):
+    if _has_step_hooks(optimizer):            # hooks hang on optimizer.step(): torch's own path runs them
         return False
-    decoupled = 1 if isinstance(optimizer, torch.optim.AdamW) or any(g.get("decoupled_weight_decay", False) for g in groups) else 0
+    groups = optimizer.param_groups
+    if not all(_group_ok(optimizer, g) for g in groups):     # every refusal is decided BEFORE the first launch: no partial step
+        return False
     st = L.stream_ptr()
     for g in groups:
+        decoupled = 1 if isinstance(optimizer, torch.optim.AdamW) or g.get("decoupled_weight_decay", False) else 0
         ps = [p for p in g["params"]]
         if not ps:
             continue
@@ -64,9 +79,8 @@ def fused_step(optimizer: torch.optim.Optimizer) -> bool:
         lr = g["lr"]
         lr_d, lr_h = (lr.data_ptr(), 0.0) if torch.is_tensor(lr) and lr.is_cuda else (None, float(lr))
         b1, b2 = g["betas"]
-        if torch.is_tensor(b1) or torch.is_tensor(b2):
-            return False
         L.check(lib.bpx_adam_step(len(ps), arr, lr_d, lr_h, float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), decoupled, st))
+    optimizer._opt_called = True             # what lr_scheduler's wrapper of optimizer.step() records (its "scheduler before optimizer" warning reads it)
     return True
 
 

@@ -592,6 +592,14 @@ def test_fused_adam_step_refuses_what_it_does_not_reproduce():
         assert torch.equal(before, p[0])
         O.step(opt)                                   # falls through to torch
         assert not torch.equal(before, p[0])
+    opt = torch.optim.AdamW(p, lr=0.1, capturable=False)
+    assert O._has_step_hooks(opt) is False
+    h = opt.register_step_post_hook(lambda o, a, k: None)    # hooks hang on optimizer.step(): the kernel path would skip them, so it declines
+    assert O._has_step_hooks(opt) is True
+    h.remove()
+    assert O._has_step_hooks(opt) is False
+    g = dict(opt.param_groups[0], capturable=True, betas=(torch.tensor(0.9), 0.999))
+    assert O._group_ok(opt, g) is False                      # tensor-valued betas: refused before any launch
 
 
 @pytest.mark.parametrize("s", [2, 3])
