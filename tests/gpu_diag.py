@@ -16,10 +16,26 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def _emit(rows, out):
+    lines = []
+    nbad = 0
+    for r in rows:
+        nbad += 0 if r["ok"] else 1
+        lines.append("%-4s %-78s err=%.3e tol=%.1e %s" % ("ok" if r["ok"] else "FAIL", r["name"], r["err"], r["tol"], r.get("extra", "")))
+    lines.append(f"{len(rows) - nbad}/{len(rows)} checks passed")
+    text = "\n".join(lines)
+    print(text)
+    if out:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        open(out, "w").write(text + "\n")
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="run one late-added group alone: rcan_up")
     a = ap.parse_args()
     import kernel_checks as K
 
@@ -35,6 +51,11 @@ def main():
             traceback.print_exc()
         torch.cuda.synchronize()
 
+    RCAN_UP = [(2, torch.bfloat16, 1), (2, torch.float16, 8), (3, torch.bfloat16, 8), (4, torch.float16, 1), (4, torch.float16, 8)]
+    if a.only == "rcan_up":                  # the RCAN x-scale stage's training rows alone (added after the round's full table was collected)
+        for sc, dtype, grp in RCAN_UP:
+            run(K.check_rcan_upscale_train, sc, dtype, grp)
+        return _emit(rows, a.out)
     run(K.check_selftest)
     run(K.check_tiling, gt)
     run(K.check_merge_sharded)
@@ -86,18 +107,9 @@ def main():
             run(K.check_network_dropout, dtype, gd)
         for dtype in (torch.float32, torch.bfloat16, torch.float16):      # the benched shape itself: 128^3, logits / loss / gradients (per level in 16 bit)
             run(K.check_network_cfg2_benched_shape, dtype)
-    lines = []
-    nbad = 0
-    for r in rows:
-        nbad += 0 if r["ok"] else 1
-        lines.append("%-4s %-78s err=%.3e tol=%.1e %s" % ("ok" if r["ok"] else "FAIL", r["name"], r["err"], r["tol"], r.get("extra", "")))
-    lines.append(f"{len(rows) - nbad}/{len(rows)} checks passed")
-    text = "\n".join(lines)
-    print(text)
-    if a.out:
-        os.makedirs(os.path.dirname(a.out), exist_ok=True)
-        open(a.out, "w").write(text + "\n")
-    return 0
+        for sc, dtype, grp in RCAN_UP:
+            run(K.check_rcan_upscale_train, sc, dtype, grp)
+    return _emit(rows, a.out)
 
 
 if __name__ == "__main__":

@@ -2296,3 +2296,52 @@ def check_convT_wgrad_stream(mix=True, B=2, S=(32, 32, 32), Cc=32, seed=0):
     return [_res(tag + ".dw_vs_fp64", relerr(a, w.grad), 4e-3 if mix else 1e-4), _res(tag + ".db_vs_fp64", relerr(ab, bb.grad), 1e-4),
             _res(tag + ".dw_vs_tile_kernel", relerr(a, c), 1e-4), _res(tag + ".db_vs_tile_kernel", relerr(ab, cb), 1e-4),
             _res(tag + ".run_to_run_bits", 0 if torch.equal(a, b) and torch.equal(ab, bbias) else 1, 0)]
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_rcan_upscale_train(scale, dtype, group, seed=None):
+    """Round 4: training through rcan(upscaling_layer=True) in 3-D - a short trunk + conv(16 -> 16 s^3) + 3-D pixel shuffle + last conv on a 32^3 patch:
+    output, MSE loss and EVERY parameter gradient against autograd through the oracle's restatement (oracle/rcan_oracle.py, fp32 on the CPU; the
+    shuffle's semantics are DEFINED there, the reference's own 3-D branch raises).  `group`: sub-positions per backward kernel call of the stage.
+    A wrong sub-position order shows as a relative error of ~1.4 on upscale.0.weight and on everything in front of it."""
+    import torch.nn.functional as F
+
+    from biapy_amd.rcan import rcan
+    from oracle import rcan_oracle
+
+    seed = 10 + scale if seed is None else seed
+    torch.manual_seed(seed)
+    m = rcan(ndim=3, num_channels=1, filters=16, scale=scale, num_rg=1, num_rcab=2, reduction=16, upscaling_layer=True, out_channels=1,
+             head_activations=["linear"], compute_dtype=dtype)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for v in m.state_dict().values():
+            if v.ndim == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    x = torch.randn(1, 1, 32, 32, 32, generator=torch.Generator().manual_seed(19))
+    tgt = torch.randn(1, 1, 32 * scale, 32 * scale, 32 * scale, generator=torch.Generator().manual_seed(20))
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = rcan_oracle.rcan_forward(ref, x, 1, 2, scale=scale)
+    lw = F.mse_loss(want, tgt)
+    lw.backward()
+    m = m.cuda().train()
+    m.engine().up_group = group
+    got = m(x.cuda())
+    lg = F.mse_loss(got, tgt.cuda())
+    lg.backward()
+    torch.cuda.synchronize()
+    tag = f"rcan_x{scale}[{'mix16' if dtype == torch.float16 else 'bf16'} group={group}]"
+    res = [_res(f"{tag}.output_rel_max", ((got.detach().cpu() - want.detach()).abs().max() / want.detach().abs().max()).item(), 1.5e-2),
+           _res(f"{tag}.loss_rel", abs(lg.item() - lw.item()) / lw.item(), 1e-3)]
+    gmax = max(v.grad.norm().item() for v in ref.values())
+    errs = {}
+    for k, p_ in m.named_parameters():
+        gr = ref[k].grad
+        if gr.norm().item() > 1e-4 * gmax:
+            errs[k] = ((p_.grad.cpu() - gr).norm() / gr.norm()).item()
+    stage_keys = ("upscale.0.weight", "upscale.0.bias", "conv2.weight", "conv2.bias", "conv1.weight")
+    for k in stage_keys + ("sf.weight",):
+        res.append(_res(f"{tag}.grad_rel_l2[{k}]", errs.get(k, float("nan")), 0.03 if k in stage_keys else 0.05))
+    worst = max(errs, key=errs.get)
+    res.append(_res(f"{tag}.grads_rel_l2_worst", errs[worst], 0.05, f"{worst} ({len(errs)} tensors)"))   # bars: ~3x the recorded worst values (profiles/r04_gpu_diag_rcan_upscale.txt: 0.010 / 0.006)
+    return res
