@@ -630,3 +630,37 @@ def test_rcan_upscale_stage_channel_orders_are_the_shuffles_adjoint(s):
     assert torch.allclose(gw, w.grad, rtol=1e-10, atol=1e-10) and torch.allclose(gb, b.grad, rtol=1e-10, atol=1e-10)
     w2, b2 = rows_from_subposition_major(wu, bu, Fc, s3)
     assert torch.equal(w2, w.detach()) and torch.equal(b2, b.detach())
+
+
+def test_bench_roofline_arithmetic_is_what_design_states():
+    """bench.py's algorithmic bytes / FLOPs per launch (the numerators of `roofline.achieved`) for the shapes DESIGN.md section 6 quotes: every activation
+    operand read once and the result written once; 2 FLOPs per MAC; the fused backward = the dgrad AND the wgrad of the conv; and the choice of the
+    binding roof (bytes / 8 TB/s against FLOPs / the dense 16-bit MFMA peak)."""
+    import bench
+
+    vox = 4 * 128 ** 3
+    fused = (4, 4, 128, 128, 128, "C16", "C48", 1, "C48")                        # dy 16 -> g 48 at the benched size (the line's `roofline` shape)
+    assert bench.conv_bytes("bpx_conv3d_bwd_fused", fused, 2) == vox * (16 + 2 * 48) * 2 == 1879048192
+    assert bench.conv_flops("bpx_conv3d_bwd_fused", fused) == 2 * 2 * vox * 27 * 16 * 48 == 695784701952
+    fwd = (2, 4, 128, 128, 128, "C48", 1, "C0", "C16")
+    assert bench.conv_bytes("bpx_conv3d_fwd", fwd, 2) == vox * (48 + 0 + 16) * 2
+    assert bench.conv_flops("bpx_conv3d_fwd", fwd) == 2 * vox * 27 * 48 * 16
+    fwd_sc = (2, 4, 128, 128, 128, "C16", 1, "C48", "C16")                      # + the fused 1x1x1 shortcut: csc more K per voxel, its input read once
+    assert bench.conv_flops("bpx_conv3d_fwd", fwd_sc) == 2 * vox * (27 * 16 + 48) * 16
+    assert bench.conv_bytes("bpx_conv3d_fwd", fwd_sc, 2) == vox * (16 + 48 + 16) * 2
+    wg1 = (4, 4, 128, 128, 128, "C48", 0, "C16", 1, 802816)                      # k = 1 weight gradient (trailing int: a small workspace size)
+    assert bench.wgrad_k(wg1) == 1 and bench.conv_flops("bpx_conv3d_wgrad", wg1) == 2 * vox * 48 * 16
+    assert bench.conv_bytes("bpx_conv3d_wgrad", wg1, 2) == vox * (48 + 16) * 2
+    assert bench.conv_flops("bpx_head_fwd", fused) == 0 and bench.conv_bytes("bpx_head_fwd", fused, 2) == 0
+    assert bench._shape_name("bpx_conv3d_bwd_fused", fused) == "bpx_conv3d_bwd_fused[4x128^3 dy C16->g C48]"
+
+    class Prof:                                                                   # what the per-launch HIP events hand to conv_roofline: {(entry, key): (launches, ms)}
+        def summary(self):
+            return {("bpx_conv3d_bwd_fused", fused): (5, 5 * 0.95), ("bpx_conv3d_fwd", fwd): (5, 5 * 0.58), ("bpx_head_fwd", (2, 4, "C16", 1, 1)): (5, 0.3)}
+
+    head, top = bench.conv_roofline(Prof(), 5, "mix16", "test")
+    assert head["kernel"].startswith("bpx_conv3d_bwd_fused") and head["launches"] == 5 and abs(head["avg_launch_ms"] - 0.95) < 1e-9
+    tf, gb = 695784701952 / 0.95e-3 / 1e12, 1879048192 / 0.95e-3 / 1e9
+    assert abs(head["tflops"] - tf) < 0.01 and abs(head["algorithmic_GBps"] - gb) < 0.1
+    assert head["bound"] == "mfma" and abs(head["frac"] - tf / 2500.0) < 1e-3     # 0.29 of the MFMA roof outweighs 0.25 of the HBM roof
+    assert abs(head["hbm_frac"] - gb / 8000.0) < 1e-3 and len(top) == 2 and "families" in head
