@@ -90,8 +90,8 @@ class NetConfig:
             raise NotImplementedError("input channels must be 1 or a multiple of 16")
         if self.post_up not in (0, 1, 2):
             raise NotImplementedError("post up-sampling: z factor 1 or 2 (y / x factor 2)")
-        if sum(self.out_channels) > 4 or fm[0] not in (16, 32):
-            raise NotImplementedError("output head supports <= 4 channels from 16 or 32 features")
+        if sum(self.out_channels) > 4:
+            raise NotImplementedError("output head supports <= 4 channels")
         self.depth = len(fm) - 1
         dv = [0.0] * len(fm) if self.dropout is None else [float(v) for v in list(self.dropout)]
         if len(dv) < len(fm) or any(not (0.0 <= v < 1.0) for v in dv):
@@ -652,14 +652,31 @@ class ResUNetEngine:
                                              L.tview(feat), pupart.data_ptr(), st))
         logits = torch.empty((B, n_out) + So, dtype=torch.float32, device=dev)
         vox0 = So[0] * So[1] * So[2]
-        L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(feat), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(),
-                                 n_out * vox0, vox0, st))
+        wide = None
+        if fm[0] in (16, 32):
+            L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(feat), hw.data_ptr(), hb.data_ptr(), n_out, head_act, logits.data_ptr(),
+                                     n_out * vox0, vox0, st))
+        else:
+            # wider first level (e.g. FEATURE_MAPS [48, 64, 80, 96] of the reference's Ovarian-Reserve template): the heads' (n_out, fm0) matrix,
+            # zero-padded to 16 rows, runs as a 1x1x1 convolution on the pointwise MFMA kernel; the head kernel then picks the real channels of the
+            # 16-channel result (an identity matrix) and applies the output activation.  The logits pass through the 16-bit storage type once.
+            w16 = torch.zeros((16, fm[0]), dtype=torch.float32, device=dev)
+            b16 = torch.zeros((16,), dtype=torch.float32, device=dev)
+            w16[:n_out] = hw
+            b16[:n_out] = hb
+            o16 = torch.empty((B,) + So + (16,), dtype=T, device=dev)
+            wp16 = self._pack(w16, L.PK_DENSE, fm[0], 16, False)
+            L.check(lib.bpx_conv1x1_fwd(self.dt, B, vox0, L.tview(feat), wp16.data_ptr(), b16.data_ptr(), L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(o16), st))
+            eye = torch.eye(n_out, 16, dtype=torch.float32, device=dev).contiguous()
+            zb = torch.zeros((n_out,), dtype=torch.float32, device=dev)
+            L.check(lib.bpx_head_fwd(self.dt, vox0, B, L.tview(o16), eye.data_ptr(), zb.data_ptr(), n_out, head_act, logits.data_ptr(), n_out * vox0, vox0, st))
+            wide = dict(o16=o16, w16=w16, eye=eye)
         if cfg.ndim == 2:
             logits = logits.reshape(B, n_out, So[1], So[2])
         ctx = None
         if save:
             ctx = dict(B=B, S=S, So=So, img=img, x_ndhwc=x_ndhwc, blocks=blocks, cat=cat, pools=pools, ups=ups, feat=feat, dec_out=dec_in, hw=hw,
-                       Pw=(P if P is not P_orig else None), want_dx=want_dx)
+                       Pw=(P if P is not P_orig else None), want_dx=want_dx, wide_head=wide)
         return logits, ctx
 
     # ------------------------------------------------------------------------------------------
@@ -827,9 +844,33 @@ class ResUNetEngine:
         one_head = len(cfg.out_channels) == 1                     # its gradients are written in place (G is zeroed); several heads: split below
         hwg = G["heads.0.weight"] if one_head else torch.zeros((n_out, fm[0]), dtype=torch.float32, device=dev)
         hbg = G["heads.0.bias"] if one_head else torch.zeros((n_out,), dtype=torch.float32, device=dev)
-        hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
-        L.check(lib.bpx_head_bwd(self.bdt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
-                                 L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
+        wide = ctx.get("wide_head")
+        if wide is None:
+            hws = self._workspace(lib.bpx_head_bwd_workspace(fm[0], n_out), dev)
+            L.check(lib.bpx_head_bwd(self.bdt, vox0, B, L.tview(feat), ctx["hw"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
+                                     L.tview(dfeat), hwg.data_ptr(), hbg.data_ptr(), hws.data_ptr(), hws.numel(), st))
+        else:
+            # wide head (forward above): the head kernel's backward on the 16-channel tensor gives its gradient (the identity pick's own gradients are
+            # discarded), then the 1x1x1 convolution's two gradients: k = 1 wgrad (rows 0 .. n_out of the padded matrix are the heads') and the
+            # pointwise GEMM with the transposed matrix.  The weight gradient is reduced right away (not with the step's batch): it is copied below.
+            do16 = torch.empty((B,) + tuple(So) + (16,), dtype=T, device=dev)
+            eg, ebg = torch.zeros((n_out, 16), dtype=torch.float32, device=dev), torch.zeros((n_out,), dtype=torch.float32, device=dev)
+            hws = self._workspace(lib.bpx_head_bwd_workspace(16, n_out), dev)
+            L.check(lib.bpx_head_bwd(self.bdt, vox0, B, L.tview(wide["o16"]), wide["eye"].data_ptr(), n_out, dl.data_ptr(), n_out * vox0, vox0,
+                                     L.tview(do16), eg.data_ptr(), ebg.data_ptr(), hws.data_ptr(), hws.numel(), st))
+            dw16 = torch.zeros((16, fm[0], 1, 1, 1), dtype=torch.float32, device=dev)
+            db16 = torch.zeros((16,), dtype=torch.float32, device=dev)
+            ws16 = self._workspace(lib.bpx_conv3d_wgrad_workspace(B, So[0], So[1], So[2], fm[0], 16, 1), dev)
+            L.check(lib.bpx_conv3d_wgrad_db2(self.bdt, B, So[0], So[1], So[2], L.tview(feat), None, 0, L.tview(do16), 1, dw16.data_ptr(), db16.data_ptr(), None,
+                                             ws16.data_ptr(), ws16.numel(), st))         # on this stream (not the optional side stream): read right below
+            if self._deferred:
+                L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))
+                L.check(lib.bpx_wgrad_defer_begin())
+            hwg.view(n_out, fm[0]).copy_(dw16.view(16, fm[0])[:n_out])
+            hbg.copy_(db16[:n_out])
+            wt16 = self._pack(wide["w16"], L.PK_DENSE_T, fm[0], 16, False)
+            L.check(lib.bpx_conv1x1_fwd(self.gdt, B, vox0, L.tview(do16), wt16.data_ptr(), None, L.NULL_T, L.NULL_T, None, L.NULL_T, L.tview(dfeat), st))
+            self._keep += [do16, dw16, db16, eg, ebg]
         if cfg.post_up:
             dec_out, dup_feat = ctx["dec_out"], dfeat
             wsn = lib.bpx_convT3d_k2s2_wgrad_workspace(B, D0, H0, W0, cfg.post_up, fm[0], fm[0])

@@ -743,15 +743,18 @@ def unet_fixtures():
 
 def resunet_variants_fixtures():
     """ResUNet configurations that run through zero-padded 3x3x3 kernels: a 2D network (fm 16-32-64, 64x64) and a 3D one with
-    anisotropic levels (MODEL.ISOTROPY = [False, False, True] -> (1,3,3) kernels, Z_DOWN = [1, 2]).  Reference logits, loss,
-    gradient norms and a few full gradients."""
+    anisotropic levels (MODEL.ISOTROPY = [False, False, True] -> (1,3,3) kernels, Z_DOWN = [1, 2]); and (round 4) one with
+    feature maps 48-64 (the head reads 48 features).  Reference logits, loss, gradient norms and a few full gradients."""
     rmod = shim.load("biapy.models.resunet")
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from oracle import net_oracle
 
     out = {}
     for tag, fm, patch, zd, iso, seed in (("2d", [16, 32, 64], (64, 64), [2, 2], [True] * 3, 31),
-                                          ("anisok", [16, 32, 64], (8, 32, 32), [1, 2], [False, False, True], 32)):
+                                          ("anisok", [16, 32, 64], (8, 32, 32), [1, 2], [False, False, True], 32),
+                                          # round 4: the first widths of the reference's Ovarian-Reserve template (FEATURE_MAPS [48, 64, 80, 96], Z_DOWN 1):
+                                          # a head fed by 48 features, a 112-channel concatenation (two levels keep the fixture small)
+                                          ("wide48", [48, 64], (8, 32, 32), [1], [True] * 2, 33)):
         depth = len(fm) - 1
         torch.manual_seed(seed)
         with quiet():
@@ -782,8 +785,11 @@ def resunet_variants_fixtures():
         for k, p_ in names.items():
             out[f"{tag}/gradnorm/{k}"] = np.array(p_.grad.norm().item(), dtype=np.float64)
         for k in ["down_path.0.block.0.block.0.weight", "down_path.1.block.2.block.0.weight", "up_paths.0.0.up.weight",
-                  "up_paths.0.1.conv_block.shortcut.0.weight", "heads.0.weight"]:
-            out[f"{tag}/grad/{k}"] = names[k].grad.numpy()
+                  "up_paths.0.1.conv_block.shortcut.0.weight", "heads.0.weight", "heads.0.bias", "bottleneck.block.2.block.0.weight",
+                  "up_paths.0.0.conv_block.shortcut.0.weight"]:
+            if k in names and (tag == "wide48" or k in ("down_path.0.block.0.block.0.weight", "down_path.1.block.2.block.0.weight", "up_paths.0.0.up.weight",
+                                                        "up_paths.0.1.conv_block.shortcut.0.weight", "heads.0.weight")):
+                out[f"{tag}/grad/{k}"] = names[k].grad.numpy()
         sd = {k: v.detach() for k, v in net.state_dict().items()}
         lo = net_oracle.resunet_forward(sd, x, fm, z_down=zd)
         err = (lo - logits.detach()).abs().max().item()

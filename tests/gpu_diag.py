@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", action="store_true")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default=None, help="run one late-added group alone: rcan_up")
+    ap.add_argument("--only", default=None, help="run one late-added group alone: rcan_up | wide48")
     a = ap.parse_args()
     import kernel_checks as K
 
@@ -55,6 +55,11 @@ def main():
     if a.only == "rcan_up":                  # the RCAN x-scale stage's training rows alone (added after the round's full table was collected)
         for sc, dtype, grp in RCAN_UP:
             run(K.check_rcan_upscale_train, sc, dtype, grp)
+        return _emit(rows, a.out)
+    if a.only == "wide48":                   # FEATURE_MAPS [48, 64]: the wide head (48 features), 112-channel concatenation - against the reference fixture
+        gv = np.load(os.path.join(ROOT, "tests", "golden", "resunet_variants_golden.npz"))
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):
+            run(K.check_resunet_variant, dtype, "wide48", gv)
         return _emit(rows, a.out)
     run(K.check_selftest)
     run(K.check_tiling, gt)

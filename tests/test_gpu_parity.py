@@ -1074,10 +1074,13 @@ def test_graphed_inference_follows_weight_updates():
     assert not torch.equal(y0, y1) and torch.equal(y1, m.predict_proba(x))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("tag", ["2d", "anisok"])
+@pytest.mark.parametrize("tag,dtype", [("2d", torch.float32), ("2d", torch.bfloat16), ("anisok", torch.float32), ("anisok", torch.bfloat16),
+                                       ("wide48", torch.float32), ("wide48", torch.bfloat16), ("wide48", torch.float16)],
+                         ids=["f32-2d", "bf16-2d", "f32-anisok", "bf16-anisok", "f32-wide48", "bf16-wide48", "mix16-wide48"])
 def test_resunet_2d_and_anisotropic_kernels(K, resunet_variants_golden, tag, dtype):
-    """biapy_amd.resunet.ResUNet in 2D and with MODEL.ISOTROPY False levels ((1,3,3) kernels) vs the reference's own outputs."""
+    """biapy_amd.resunet.ResUNet in 2D, with MODEL.ISOTROPY False levels ((1,3,3) kernels) and (round 4, "wide48") with FEATURE_MAPS [48, 64] - the first
+    widths of the reference's Ovarian-Reserve template: the head reads 48 features (1x1x1 GEMM to 16 padded outputs + the head kernel) - vs the reference's
+    own outputs, loss and gradients."""
     _assert_all(K.check_resunet_variant(dtype, tag, resunet_variants_golden))
 
 
@@ -1633,6 +1636,39 @@ def test_resunetpp_matches_reference_fixture(K, resunetpp_golden, dtype):
 def test_resunetpp_cfg4_at_the_benched_shape(K, dtype):
     """cfg 4 (ResUNet++ 80^3, fm 16-32-64-128-256) at its own size against the CPU oracle; batch 2 against its batch-1 runs."""
     _assert_all(K.check_resunetpp_cfg4_shape(dtype))
+
+
+def test_resunet_ovarian_reserve_template_widths_at_a_lean_kernel_size():
+    """MODEL.FEATURE_MAPS [48, 64, 80, 96], Z_DOWN [1, 1, 1] (templates/instance_segmentation/Ovarian_Reserve_paper) on a 32 x 64 x 64 patch - large enough for
+    the persistent conv kernels, the streaming k = 1 weight gradient and the wide head (48 features -> 2 channels): the 16-bit modes against the f32 mode of
+    the same module (which the `wide48` fixture pins to the reference): logits, BCE loss and every gradient."""
+    import torch.nn.functional as F
+
+    from biapy_amd.resunet import ResUNet
+
+    kw = dict(image_shape=(32, 64, 64, 1), activation="elu", feature_maps=[48, 64, 80, 96], drop_values=[0.0] * 4, normalization="in", yx_down=[2] * 3, z_down=[1] * 3,
+              isotropy=[True] * 4, larger_io=False, conv_layers=[2] * 4, output_channels=[2], output_channel_info=["B", "C"], head_activations=["ce_sigmoid", "ce_sigmoid"])
+    torch.manual_seed(77)
+    ref = ResUNet(compute_dtype=torch.float32, **kw).cuda().train()
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 1, 32, 64, 64, generator=g).cuda()
+    tgt = (torch.rand(2, 2, 32, 64, 64, generator=g) > 0.5).float().cuda()
+    y0 = ref(x)
+    l0 = F.binary_cross_entropy_with_logits(y0, tgt)
+    l0.backward()
+    g0 = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    assert y0.shape == (2, 2, 32, 64, 64) and all(torch.isfinite(v).all() for v in g0.values())
+    gmax = max(v.norm().item() for v in g0.values())
+    for dtype, ltol, gtol in ((torch.bfloat16, 6e-2, 0.15), (torch.float16, 8e-3, 0.10)):
+        m = ResUNet(compute_dtype=dtype, **kw).cuda().train()
+        m.load_state_dict(ref.state_dict(), strict=True)
+        y = m(x)
+        loss = F.binary_cross_entropy_with_logits(y, tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert ((y - y0).abs().max() / y0.abs().max()).item() < ltol and abs(loss.item() - l0.item()) < (2e-2 if dtype == torch.bfloat16 else 2e-3)
+        worst = max(((p.grad - g0[k]).norm() / g0[k].norm()).item() for k, p in m.named_parameters() if g0[k].norm().item() > 1e-4 * gmax)
+        assert worst < gtol, (dtype, worst)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

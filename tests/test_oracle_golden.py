@@ -381,7 +381,7 @@ def test_unet_module_keeps_the_reference_state_dict(unet_golden, tag, shape):
         U_Net(image_shape=shape, feature_maps=fm, drop_values=[0.0] * len(fm), normalization="bn", larger_io=False)
 
 
-@pytest.mark.parametrize("tag,shape", [("2d", (64, 64, 1)), ("anisok", (8, 32, 32, 1))])
+@pytest.mark.parametrize("tag,shape", [("2d", (64, 64, 1)), ("anisok", (8, 32, 32, 1)), ("wide48", (8, 32, 32, 1))])
 def test_resunet_variants_oracle_and_module(resunet_variants_golden, tag, shape):
     """2D ResUNet and anisotropic (1,3,3)-kernel levels: the oracle reproduces the reference's logits / loss / gradients, and
     biapy_amd.resunet.ResUNet owns parameters of exactly the reference's names and shapes (strict load)."""
