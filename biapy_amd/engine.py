@@ -84,8 +84,16 @@ class NetConfig:
                     raise NotImplementedError(f"normalization='gn': the concatenated decoder input of level {i} has {fm[i] + fm[i + 1]} channels, not a multiple of 8")
         if self.activation not in L.ACT:
             raise NotImplementedError(f"activation={self.activation!r} is not implemented on the MI355X engine")
+        # Widths that are not multiples of 16 (e.g. MODEL.FEATURE_MAPS [52, 68, 84] of the reference's CartoCell template) run zero-padded to the next
+        # multiple (the MFMA tile): `feature_maps` becomes what the kernels see, `true_feature_maps` what the parameters have.  Exact under InstanceNorm:
+        # a padded channel is produced by zero weights and read through zero weights (channel_pad_plan / pad_channels below).
+        self.true_feature_maps = None
         if any(c % 16 for c in fm):
-            raise NotImplementedError(f"feature_maps {fm} must be multiples of 16 (MFMA tile)")
+            if self.gn_groups or self.post_up or self.in_ch != 1:
+                raise NotImplementedError(f"feature_maps {fm} (not multiples of 16) run zero-padded: InstanceNorm, one input channel and no super-resolution stage only")
+            self.true_feature_maps = tuple(fm)
+            fm = [(c + 15) // 16 * 16 for c in fm]
+            self.feature_maps = fm
         if self.in_ch != 1 and self.in_ch % 16:
             raise NotImplementedError("input channels must be 1 or a multiple of 16")
         if self.post_up not in (0, 1, 2):
@@ -143,6 +151,78 @@ def unlift_grads(G: Dict[str, torch.Tensor], P: Dict[str, torch.Tensor]) -> Dict
         if g.shape != p.shape:
             g = g[:, :, 1].reshape(p.shape) if p.shape[-1] == 3 else g.reshape(p.shape)
         out[n] = g if g.is_contiguous() else g.contiguous()
+    return out
+
+
+def channel_pad_plan(cfg: "NetConfig") -> Optional[Dict[str, Tuple]]:
+    """For a configuration whose widths were rounded up to multiples of 16: parameter name -> (segments of dim 0, segments of dim 1), a segment =
+    (true channels, padded channels); dim 1 is None for vectors.  The decoder blocks' input is the concatenation [up-sampled | skip]: two segments."""
+    if cfg.true_feature_maps is None:
+        return None
+    ft, fp, Lv = list(cfg.true_feature_maps), list(cfg.feature_maps), cfg.depth
+    seg = lambda i: (ft[i], fp[i])                                         # noqa: E731
+    plan: Dict[str, Tuple] = {}
+
+    def block(prefix, first, cin, cout):
+        k = block_keys(prefix, first)
+        plan[k["w1"]], plan[k["wsc"]] = ([cout], cin), ([cout], cin)
+        plan[k["w2"]] = ([cout], [cout])
+        for n in ("b1", "g1", "be1", "b2", "bsc"):
+            plan[k[n]] = ([cout], None)
+        if not first:
+            plan[k["g0"]], plan[k["be0"]] = (cin, None), (cin, None)
+
+    for i in range(Lv):
+        block(f"down_path.{i}", i == 0, [(cfg.in_ch, cfg.in_ch)] if i == 0 else [seg(i - 1)], seg(i))
+    block("bottleneck", False, [seg(Lv - 1)], seg(Lv))
+    for j, i in enumerate(range(Lv - 1, -1, -1)):
+        plan[f"up_paths.0.{j}.up.weight"] = ([seg(i + 1)], [seg(i + 1)])   # ConvTranspose: (Cin, Cout, ...)
+        plan[f"up_paths.0.{j}.up.bias"] = ([seg(i + 1)], None)
+        block(f"up_paths.0.{j}.conv_block", False, [seg(i + 1), seg(i)], seg(i))
+    for h in range(len(cfg.out_channels)):
+        plan[f"heads.{h}.weight"] = (None, [seg(0)])
+    return plan
+
+
+def _pad_dim(t: torch.Tensor, dim: int, segs) -> torch.Tensor:
+    if segs is None or all(a == b for a, b in segs):
+        return t
+    parts, o = [], 0
+    for a, b in segs:
+        parts.append(t.narrow(dim, o, a))
+        o += a
+        if b > a:
+            shape = list(t.shape)
+            shape[dim] = b - a
+            parts.append(t.new_zeros(shape))
+    return torch.cat(parts, dim)
+
+
+def _unpad_dim(t: torch.Tensor, dim: int, segs) -> torch.Tensor:
+    if segs is None or all(a == b for a, b in segs):
+        return t
+    parts, o = [], 0
+    for a, b in segs:
+        parts.append(t.narrow(dim, o, a))
+        o += b
+    return torch.cat(parts, dim) if len(parts) > 1 else parts[0]
+
+
+def pad_channels(P: Dict[str, torch.Tensor], plan) -> Dict[str, torch.Tensor]:
+    """Parameters with their channel dimensions zero-padded to the kernels' widths (channel_pad_plan)."""
+    Q = {}
+    for k, w in P.items():
+        s0, s1 = plan.get(k, (None, None))
+        Q[k] = _pad_dim(_pad_dim(w, 0, s0), 1, s1).contiguous()
+    return Q
+
+
+def unpad_channel_grads(G: Dict[str, torch.Tensor], plan) -> Dict[str, torch.Tensor]:
+    """The parameters' own entries of the padded gradients (the padded rows / columns hold gradients of weights that do not exist)."""
+    out = {}
+    for k, g in G.items():
+        s0, s1 = plan.get(k, (None, None))
+        out[k] = _unpad_dim(_unpad_dim(g, 0, s0), 1, s1)
     return out
 
 
@@ -221,6 +301,9 @@ class ResUNetEngine:
         assert dtype in (torch.bfloat16, torch.float32, torch.float16)
         self.cfg = cfg
         self.dtype = dtype
+        self._pad_plan = channel_pad_plan(cfg) if type(self) is ResUNetEngine else None      # zero-padded widths: this engine's own forward / backward only
+        if cfg.true_feature_maps is not None and type(self) is not ResUNetEngine:
+            raise NotImplementedError(f"feature_maps {list(cfg.true_feature_maps)} (not multiples of 16): only the ResUNet engine pads them")
         # float16 = the same 16 bits per element with an 11-bit mantissa: the mode whose forward agrees with the fp32 reference to Dice
         # delta < 1e-4 at the speed of the bf16 mode.  Its TRAINING form is mixed (BPX_MIX16): the forward pass and every stored
         # activation are fp16, every gradient tensor and the backward MFMA operands are bf16 (fp32 exponent range: no loss scaling) -
@@ -515,7 +598,8 @@ class ResUNetEngine:
             # a captured forward must contain its own pack kernels: operands cached during the warm-up would freeze the
             # weights of every later replay at their capture-time values (graphs.GraphedInference)
             cache_weights = False
-        if any(needs_lift(w) for w in P.values()):
+        plan = self._pad_plan
+        if plan is not None or any(needs_lift(w) for w in P.values()):
             # 2D / anisotropic levels: zero-padded 3x3x3 weights.  Inference keeps the lifted copies while the parameters
             # are unchanged, so that the packed-operand cache (keyed by storage) keeps hitting.
             vers = (_WEIGHTS_EPOCH[0],) + tuple((w.data_ptr(), w._version) for w in P.values())
@@ -523,7 +607,7 @@ class ResUNetEngine:
             if cache_weights and hit is not None and hit[0] == vers:
                 P = hit[1]
             else:
-                P = lift_params(P)
+                P = lift_params(P if plan is None else pad_channels(P, plan))
                 self._lift_cache = (vers, P) if cache_weights else None
         B, Cin, D0, H0, W0 = x.shape
         assert Cin == cfg.in_ch, f"expected {cfg.in_ch} input channels, got {Cin}"
@@ -813,7 +897,11 @@ class ResUNetEngine:
         for fn in self._after_flush:
             fn()
         self._after_flush = []
-        return G if Pw is None else unlift_grads(G, P)      # after the flush: it is the flush that writes the conv gradients
+        if Pw is None:
+            return G
+        if self._pad_plan is not None:                        # zero-padded widths: the parameters' own rows / columns of the padded gradients
+            G = unpad_channel_grads(G, self._pad_plan)
+        return unlift_grads(G, P)                            # after the flush: it is the flush that writes the conv gradients
 
     def _backward(self, P: Dict[str, torch.Tensor], ctx, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
         cfg = self.cfg

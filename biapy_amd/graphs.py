@@ -290,6 +290,9 @@ class DataParallelTrainStep:
         names, params = inner._named()
         if [id(p) for p in params] != [id(p) for p in self.params]:
             return False
+        from .engine import needs_lift
+        if getattr(getattr(inner, "cfg", None), "true_feature_maps", None) is not None or any(needs_lift(p) for p in params):
+            return False      # zero-padded widths / 2D or anisotropic kernels: the engine's flat gradient slab has the lifted shapes, not the parameters'
         first = [n.startswith("down_path.0.") for n in names]
         k = sum(first)
         return 0 < k < len(names) and all(first[:k]) and not any(first[k:])      # the first block's parameters are a prefix of the slab

@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", action="store_true")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default=None, help="run one late-added group alone: rcan_up | wide48")
+    ap.add_argument("--only", default=None, help="run one late-added group alone: rcan_up | wide48 | padded")
     a = ap.parse_args()
     import kernel_checks as K
 
@@ -55,6 +55,10 @@ def main():
     if a.only == "rcan_up":                  # the RCAN x-scale stage's training rows alone (added after the round's full table was collected)
         for sc, dtype, grp in RCAN_UP:
             run(K.check_rcan_upscale_train, sc, dtype, grp)
+        return _emit(rows, a.out)
+    if a.only == "padded":                   # FEATURE_MAPS [52, 68, 84] (CartoCell template): zero-padded to [64, 80, 96] inside the engine - module vs the CPU oracle on the true widths
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):
+            run(K.check_network_padded_widths, dtype)
         return _emit(rows, a.out)
     if a.only == "wide48":                   # FEATURE_MAPS [48, 64]: the wide head (48 features), 112-channel concatenation - against the reference fixture
         gv = np.load(os.path.join(ROOT, "tests", "golden", "resunet_variants_golden.npz"))

@@ -2345,3 +2345,53 @@ def check_rcan_upscale_train(scale, dtype, group, seed=None):
     worst = max(errs, key=errs.get)
     res.append(_res(f"{tag}.grads_rel_l2_worst", errs[worst], 0.05, f"{worst} ({len(errs)} tensors)"))   # bars: ~3x the recorded worst values (profiles/r04_gpu_diag_rcan_upscale.txt: 0.010 / 0.006)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_network_padded_widths(dtype, fm=(52, 68, 84), patch=(8, 32, 32), zd=(1, 1), B=2, seed=5):
+    """MODEL.FEATURE_MAPS that are not multiples of 16 (the reference's CartoCell template: [52, 68, 84], Z_DOWN [1, 1]) through the MODULE: the parameters keep
+    the reference's shapes (strict load of a true-width state dict), the engine runs them zero-padded to [64, 80, 96] and hands back gradients in the
+    parameters' shapes; the 64-wide first level also takes the wide head.  Against the CPU oracle on the TRUE widths: logits, BCE loss, every gradient."""
+    from biapy_amd.resunet import ResUNet
+
+    tagd = _mode(dtype)[0]
+    fm, zd = list(fm), list(zd)
+    sd = net_oracle.init_state_dict(1, fm, z_down=zd, seed=seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    with torch.no_grad():
+        for k, v in sd.items():
+            if v.dim() == 1:
+                v.add_(0.1 * (torch.rand(v.shape, generator=g) * 2 - 1))
+    x = torch.randn(B, 1, *patch, generator=g)
+    tgt = (torch.rand(B, 1, *patch, generator=g) > 0.5).float()
+    m = ResUNet(image_shape=tuple(patch) + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * len(fm), normalization="in", yx_down=[2] * (len(fm) - 1),
+                z_down=zd, isotropy=[True] * len(fm), larger_io=False, conv_layers=[2] * len(fm), compute_dtype=dtype)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    logits = m(x.to(DEV))
+    loss = F.binary_cross_entropy_with_logits(logits, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    lo_ref = net_oracle.resunet_forward(ref, x, fm, z_down=zd)
+    l_ref = F.binary_cross_entropy_with_logits(lo_ref, tgt)
+    l_ref.backward()
+    tag = f"resunet_padded[{tagd} fm={fm} -> {list(m.cfg.feature_maps)} {tuple(x.shape)}]"
+    bf, mx = dtype == torch.bfloat16, dtype == torch.float16
+    res = [_res(tag + ".logits_rel", (logits.detach().cpu() - lo_ref.detach()).abs().max().item() / lo_ref.detach().abs().max().item(), 6e-2 if bf else 8e-3 if mx else 2e-4),
+           _res(tag + ".loss", abs(loss.item() - l_ref.item()), 2e-2 if bf else 2e-3 if mx else 1e-5)]
+    gmax = max(v.grad.norm().item() for v in ref.values())
+    worst, wname, shapes_ok = 0.0, "", True
+    for k, p_ in m.named_parameters():
+        shapes_ok &= p_.grad is not None and p_.grad.shape == ref[k].shape
+        gr = ref[k].grad
+        if gr.norm().item() > 1e-4 * gmax:
+            e = ((p_.grad.cpu() - gr).norm() / gr.norm()).item()
+            if e > worst:
+                worst, wname = e, k
+    res.append(_res(tag + ".grad_shapes_are_the_parameters", 0.0 if shapes_ok else 1.0, 0.0))
+    res.append(_res(tag + ".grads_rel_l2_worst", worst, 0.15 if bf else 0.10 if mx else 2e-3, wname))
+    with torch.no_grad():
+        pr = m.eval()(x.to(DEV))
+    res.append(_res(tag + ".eval_logits_rel", (pr.cpu() - lo_ref.detach()).abs().max().item() / lo_ref.detach().abs().max().item(), 6e-2 if bf else 8e-3 if mx else 2e-4))
+    return res

@@ -1638,6 +1638,15 @@ def test_resunetpp_cfg4_at_the_benched_shape(K, dtype):
     _assert_all(K.check_resunetpp_cfg4_shape(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "mix16"])
+def test_resunet_cartocell_template_widths_run_zero_padded(K, dtype):
+    """MODEL.FEATURE_MAPS [52, 68, 84], Z_DOWN [1, 1] (templates/instance_segmentation/CartoCell_paper): widths that are not multiples of 16 run zero-padded to
+    [64, 80, 96] inside the engine (exact under InstanceNorm); parameters, state dict and gradients keep the reference's shapes.  Module vs the CPU oracle
+    on the true widths; and the engine-level check at a second set of widths with Z_DOWN 2."""
+    _assert_all(K.check_network_padded_widths(dtype))
+    _assert_all(K.check_network(dtype, [20, 36, 52], (16, 32, 32), 2, seed=6))
+
+
 def test_resunet_ovarian_reserve_template_widths_at_a_lean_kernel_size():
     """MODEL.FEATURE_MAPS [48, 64, 80, 96], Z_DOWN [1, 1, 1] (templates/instance_segmentation/Ovarian_Reserve_paper) on a 32 x 64 x 64 patch - large enough for
     the persistent conv kernels, the streaming k = 1 weight gradient and the wide head (48 features -> 2 channels): the 16-bit modes against the f32 mode of

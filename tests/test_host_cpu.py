@@ -664,3 +664,35 @@ def test_bench_roofline_arithmetic_is_what_design_states():
     assert abs(head["tflops"] - tf) < 0.01 and abs(head["algorithmic_GBps"] - gb) < 0.1
     assert head["bound"] == "mfma" and abs(head["frac"] - tf / 2500.0) < 1e-3     # 0.29 of the MFMA roof outweighs 0.25 of the HBM roof
     assert abs(head["hbm_frac"] - gb / 8000.0) < 1e-3 and len(top) == 2 and "families" in head
+
+
+def test_channel_pad_plan_covers_every_parameter_and_is_exact_on_the_oracle():
+    """engine.channel_pad_plan / pad_channels / unpad_channel_grads (feature maps that are not multiples of 16, e.g. CartoCell's [52, 68, 84]): every
+    parameter of the module has a plan entry, the padded tensors have exactly the shapes of the padded architecture, un-padding is the inverse, and
+    - on the CPU oracle - the zero-padded network computes what the true-width network computes (a padded channel is written and read through zero weights)."""
+    import torch
+
+    from biapy_amd.engine import channel_pad_plan, pad_channels, unpad_channel_grads
+    from biapy_amd.resunet import ResUNet
+    from oracle import net_oracle
+
+    kw = dict(image_shape=(8, 32, 32, 1), activation="elu", drop_values=[0.0] * 3, normalization="in", yx_down=[2, 2], z_down=[1, 2], isotropy=[True] * 3,
+              larger_io=False, conv_layers=[2] * 3, output_channels=[2, 1], output_channel_info=["B", "C"])
+    torch.manual_seed(3)
+    m = ResUNet(feature_maps=[20, 36, 52], **kw)
+    assert list(m.cfg.feature_maps) == [32, 48, 64] and tuple(m.cfg.true_feature_maps) == (20, 36, 52)
+    plan = channel_pad_plan(m.cfg)
+    P = {n: p.detach() + (0.1 if p.dim() == 1 else 0.0) for n, p in m.named_parameters()}
+    assert all(k in plan for k in P if not k.endswith(".bias") or "heads" not in k)
+    Q = pad_channels(P, plan)
+    big = ResUNet(feature_maps=[32, 48, 64], **kw)
+    assert {n: tuple(p.shape) for n, p in big.named_parameters()} == {n: tuple(q.shape) for n, q in Q.items()}
+    back = unpad_channel_grads(Q, plan)
+    assert all(torch.equal(back[n], P[n]) for n in P)
+    x = torch.randn(1, 1, 8, 32, 32, generator=torch.Generator().manual_seed(4))
+    y_true = net_oracle.resunet_forward(P, x, [20, 36, 52], z_down=[1, 2])
+    y_pad = net_oracle.resunet_forward(Q, x, [32, 48, 64], z_down=[1, 2])
+    assert (y_true - y_pad).abs().max().item() < 2e-5 * y_true.abs().max().item()
+    assert channel_pad_plan(big.cfg) is None
+    with pytest.raises(NotImplementedError):                         # GroupNorm groups would change with the padding
+        ResUNet(feature_maps=[20, 36, 52], **dict(kw, normalization="gn"))
