@@ -304,6 +304,8 @@ class ResUNetEngine:
         self._pad_plan = channel_pad_plan(cfg) if type(self) is ResUNetEngine else None      # zero-padded widths: this engine's own forward / backward only
         if cfg.true_feature_maps is not None and type(self) is not ResUNetEngine:
             raise NotImplementedError(f"feature_maps {list(cfg.true_feature_maps)} (not multiples of 16): only the ResUNet engine pads them")
+        if type(self) is not ResUNetEngine and list(cfg.feature_maps)[0] not in (16, 32):
+            raise NotImplementedError("output head supports 16 or 32 features (the GEMM-fed head for wider first levels is the ResUNet engine's)")
         # float16 = the same 16 bits per element with an 11-bit mantissa: the mode whose forward agrees with the fp32 reference to Dice
         # delta < 1e-4 at the speed of the bf16 mode.  Its TRAINING form is mixed (BPX_MIX16): the forward pass and every stored
         # activation are fp16, every gradient tensor and the backward MFMA operands are bf16 (fp32 exponent range: no loss scaling) -

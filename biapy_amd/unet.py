@@ -123,6 +123,10 @@ class U_Net(nn.Module):
         zd = [int(v) for v in list(z_down)[:depth]] if ndim == 3 else [1] * depth
         self.cfg = NetConfig(in_ch=in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
                              normalization=normalization, z_down=zd)
+        if self.cfg.true_feature_maps is not None:       # only the ResUNet engine runs widths that are not multiples of 16 (zero-padded); refuse here, at construction
+            unsupported(f"feature_maps {list(feature_maps)} (not multiples of 16)")
+        if int(feature_maps[0]) not in (16, 32):          # the head kernel's two instances (the ResUNet engine has a GEMM-fed head for wider first levels)
+            unsupported(f"feature_maps[0] = {feature_maps[0]} (the output head reads 16 or 32 features)")
         self.compute_dtype = compute_dtype
         self._engine: Optional[UNetEngine] = None
 
