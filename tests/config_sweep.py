@@ -25,6 +25,10 @@ CASES = [
     ([32, 32, 64], (8, 64, 64), 1, 1, (1,), "elu", [1, 1]),
     ([16, 32], (64, 64, 64), 1, 1, (1,), "elu", None),          # >= 64^3: lean persistent conv kernels
     ([16, 32], (66, 70, 68), 1, 1, (1,), "elu", None),          # ragged at 64^3+ (partial tiles in the lean kernels)
+    ([48, 64, 80, 96], (32, 64, 64), 1, 1, (2,), "elu", [1, 1, 1]),   # Ovarian-Reserve template widths: GEMM-fed head (48 features), non-power-of-two levels
+    ([52, 68, 84], (16, 64, 64), 2, 1, (2,), "elu", [1, 1]),          # CartoCell template widths: zero-padded to [64, 80, 96] inside the engine
+    ([20, 36], (16, 32, 32), 1, 1, (1,), "gelu", None),                # padded widths under an activation with act(0) == 0 ...
+    ([20, 36], (16, 32, 32), 1, 1, (1,), "sigmoid", None),             # ... and one with act(0) != 0 (the padded channels are read through zero weights)
 ]
 
 
