@@ -694,5 +694,9 @@ def test_channel_pad_plan_covers_every_parameter_and_is_exact_on_the_oracle():
     y_pad = net_oracle.resunet_forward(Q, x, [32, 48, 64], z_down=[1, 2])
     assert (y_true - y_pad).abs().max().item() < 2e-5 * y_true.abs().max().item()
     assert channel_pad_plan(big.cfg) is None
+    for act in ("sigmoid", "softplus"):                              # act(0) != 0: a padded channel holds a constant, and is read through zero weights
+        ya = net_oracle.resunet_forward(P, x, [20, 36, 52], z_down=[1, 2], activation=act)
+        yb = net_oracle.resunet_forward(Q, x, [32, 48, 64], z_down=[1, 2], activation=act)
+        assert (ya - yb).abs().max().item() < 2e-5 * ya.abs().max().item(), act
     with pytest.raises(NotImplementedError):                         # GroupNorm groups would change with the padding
         ResUNet(feature_maps=[20, 36, 52], **dict(kw, normalization="gn"))
