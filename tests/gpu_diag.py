@@ -118,6 +118,10 @@ def main():
             run(K.check_network_cfg2_benched_shape, dtype)
         for sc, dtype, grp in RCAN_UP:
             run(K.check_rcan_upscale_train, sc, dtype, grp)
+        gv = np.load(os.path.join(ROOT, "tests", "golden", "resunet_variants_golden.npz"))
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):      # template widths: GEMM-fed head (fixture), zero-padded widths (oracle on the true widths)
+            run(K.check_resunet_variant, dtype, "wide48", gv)
+            run(K.check_network_padded_widths, dtype)
     return _emit(rows, a.out)
 
 
