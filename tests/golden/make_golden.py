@@ -555,29 +555,44 @@ def build_model_kwargs_fixture():
         return Rec
 
     tag = [""]
-    importlib.import_module("biapy.models.resunet").ResUNet = recorder(tag)
+    rmod = importlib.import_module("biapy.models.resunet")
+    ref_resunet = rmod.ResUNet                       # the reference class itself: its parameter count goes into the record
+    rmod.ResUNet = recorder(tag)
     importlib.import_module("biapy.models.resunet++").ResUNetPlusPlus = recorder(tag)
 
-    def cfg(arch, ptype, patch):
-        return NS(MODEL=NS(ARCHITECTURE=arch, ACTIVATION="ELU", FEATURE_MAPS=[16, 32, 64, 128, 256], DROPOUT_VALUES=[0.0] * 5, NORMALIZATION="in", KERNEL_SIZE=3,
-                           UPSAMPLE_LAYER="convtranspose", YX_DOWN=[2] * 4, Z_DOWN=[2] * 4, ISOTROPY=[True] * 5, LARGER_IO=False, CONV_LAYERS=[2] * 5,
+    def cfg(arch, ptype, patch, fm=(16, 32, 64, 128, 256), zd=None, drop=None):
+        n = len(fm)
+        return NS(MODEL=NS(ARCHITECTURE=arch, ACTIVATION="ELU", FEATURE_MAPS=list(fm), DROPOUT_VALUES=list(drop) if drop is not None else [0.0] * n, NORMALIZATION="in",
+                           KERNEL_SIZE=3, UPSAMPLE_LAYER="convtranspose", YX_DOWN=[2] * (n - 1), Z_DOWN=list(zd) if zd is not None else [2] * (n - 1),
+                           ISOTROPY=[True] * n, LARGER_IO=False, CONV_LAYERS=[2] * n,
                            CONV_BLOCK_ORDER="conv_norm_act", UNET_SR_UPSAMPLE_POSITION="pre", SOURCE="biapy"),
                   PROBLEM=NS(NDIM="3D", TYPE=ptype, IMAGE_TO_IMAGE=NS(SEPARATED_DECODERS_PER_HEAD=False), INSTANCE_SEG=NS(SEPARATED_DECODERS_PER_HEAD=False),
                              DETECTION=NS(SEPARATED_DECODERS_PER_HEAD=False), SUPER_RESOLUTION=NS(UPSCALING=(2, 2, 2))),
                   DATA=NS(PATCH_SIZE=patch), LOSS=NS(CONTRAST=NS(ENABLE=False, PROJ_DIM=256)))
 
+    bcd = ["ce_sigmoid", "ce_sigmoid", "tanh"]
     for name, c, oc, oi, ha in (("cfg2_resunet", cfg("resunet", "SEMANTIC_SEG", (128, 128, 128, 1)), [1], ["F"], ["ce_sigmoid"]),
-                                ("cfg4_resunet++", cfg("resunet++", "INSTANCE_SEG", (80, 80, 80, 1)), [3], ["BCD"], ["ce_sigmoid", "ce_sigmoid", "tanh"]),
-                                ("sr_resunet", cfg("resunet", "SUPER_RESOLUTION", (64, 64, 64, 1)), [1], ["F"], ["linear"])):
+                                ("cfg4_resunet++", cfg("resunet++", "INSTANCE_SEG", (80, 80, 80, 1)), [3], ["BCD"], bcd),
+                                ("sr_resunet", cfg("resunet", "SUPER_RESOLUTION", (64, 64, 64, 1)), [1], ["F"], ["linear"]),
+                                # the MODEL / DATA.PATCH_SIZE lines of two of the reference's own 3-D ResUNet templates (round 4: widths beyond powers of two)
+                                # templates/instance_segmentation/Ovarian_Reserve_paper/ovarian_reserve_training.yaml (DATA_CHANNELS BCD)
+                                ("ovarian_reserve_resunet", cfg("resunet", "INSTANCE_SEG", (40, 128, 128, 1), fm=(48, 64, 80, 96), zd=(1, 1, 1)), [3], ["BCD"], bcd),
+                                # templates/instance_segmentation/CartoCell_paper/cartocell_training_latest.yaml (DATA_CHANNELS BCM)
+                                ("cartocell_resunet", cfg("resunet", "INSTANCE_SEG", (80, 80, 80, 1), fm=(52, 68, 84), zd=(1, 1), drop=(0.1, 0.1, 0.1)), [3], ["BCM"],
+                                 ["ce_sigmoid"] * 3)):
         tag[0] = name
         try:
             M.build_model(c, oc, oi, ha, torch.device("cpu"))
         except AttributeError:
             pass                                     # the stand-in cfg ends where build_model turns to its model summary
         assert name in rec, name
+    rmod.ResUNet = ref_resunet                       # back in place: the class refers to itself by its module-level name
+    with quiet():
+        rec["_reference_parameter_counts"] = {name: sum(p.numel() for p in ref_resunet(**rec[name]).parameters())
+                                              for name in ("cfg2_resunet", "ovarian_reserve_resunet", "cartocell_resunet")}
     with open(os.path.join(HERE, "build_model_kwargs.json"), "w") as f:
         json.dump(rec, f, indent=1, sort_keys=True)
-    print("build_model_kwargs.json:", {k: len(v) for k, v in rec.items()})
+    print("build_model_kwargs.json:", {k: len(v) for k, v in rec.items()}, rec["_reference_parameter_counts"])
 
 
 def head_acts_fixtures():

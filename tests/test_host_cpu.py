@@ -486,6 +486,16 @@ def test_modules_take_the_keyword_arguments_build_model_passes():
     assert sum(p.numel() for p in mpp.parameters()) == 11148710
     msr = ResUNet(**{k: (tuple(v) if k in ("image_shape", "upsampling_factor") else v) for k, v in rec["sr_resunet"].items()})
     assert any(k.startswith("pre_upsampling.") for k in msr.state_dict())
+    # round 4: the MODEL lines of two of the reference's own 3-D ResUNet templates (widths beyond powers of two) - the reference's build_model kwargs,
+    # and the REFERENCE class's parameter counts for them, recorded by the same script
+    counts = rec["_reference_parameter_counts"]
+    assert counts["cfg2_resunet"] == 6693777
+    for name, padded in (("ovarian_reserve_resunet", None), ("cartocell_resunet", [64, 80, 96])):
+        kw = {k: (tuple(v) if k in ("image_shape", "upsampling_factor") else v) for k, v in rec[name].items()}
+        mt = ResUNet(**kw)
+        assert sum(p.numel() for p in mt.parameters()) == counts[name], name        # parameters in the reference's shapes (padding happens inside the engine)
+        assert (list(mt.cfg.feature_maps) == padded) if padded else (mt.cfg.true_feature_maps is None), name
+        assert sum(mt.output_channels) == 3 and mt.heads[0].weight.shape[:2] == (3, kw["feature_maps"][0])
 
 
 def test_epoch_drivers_refuse_a_model_call_func_beside_a_loss_that_fuses_the_head_activations():
