@@ -153,17 +153,31 @@ def _cpu_tiling_leg(V=256, P=128):
                 crop_s=round(t1 - t0, 3), merge_s=round(t2 - t1, 3), patches=n)
 
 
+def cpu_thread_settings(ncpu):
+    """BiaPy's default (min(4, ncpu), biapy/_biapy.py:333-346), 16, 32, 64 and every core of this host - clipped to the host, ascending, unique."""
+    return sorted({min(t, ncpu) for t in (4, 16, 32, 64, ncpu)})
+
+
 def cpu_baseline(P, quick=False):
-    """the reference's CPU path beside the GPU numbers, on this host, core count stated.  Bounded samples
-    (about 40 s in total): train at every core and at BiaPy's default ``min(4, ncpu)`` threads (biapy/_biapy.py:333-346; on a
-    64^3 patch there - same network, 1/8 of the voxels), inference at every core, crop + merge single-threaded."""
+    """the reference's CPU path beside the GPU numbers, on this host, core count stated.  ONE shape for every network leg (the
+    benched P^3 patch, batch 1): the train step and the inference forward at BiaPy's default ``min(4, ncpu)`` threads, 16, 32, 64 and all cores
+    (round 4 compared 128 threads at 128^3 with 4 threads at 64^3, and the 128-thread leg it quoted was the SLOWER one).
+    Every leg is reported; the headline ``value`` is the FASTEST train leg and ``cores`` its thread count.  crop + merge single-threaded as the
+    reference is.  Bounded: 1 warm-up + 3 repetitions per leg, about two minutes in total."""
     ncpu = torch.get_num_threads()
-    legs = {"train_all_cores": _cpu_net_leg(P, True, ncpu, reps=1 if quick else 3)}
+    settings = [ncpu] if quick else cpu_thread_settings(ncpu)
+    legs = {}
+    for t in settings:
+        legs[f"train_{t}_threads"] = _cpu_net_leg(P, True, t, reps=1 if quick else 3)
     if not quick:
-        legs["train_biapy_default_threads"] = _cpu_net_leg(min(P, 64), True, min(4, ncpu), reps=3)
-        legs["infer_all_cores"] = _cpu_net_leg(P, False, ncpu, reps=3)
+        for t in settings:
+            legs[f"infer_{t}_threads"] = _cpu_net_leg(P, False, t, reps=3)
         legs["crop_merge_numpy"] = _cpu_tiling_leg()
-    head = dict(legs["train_all_cores"])
+    best = max((k for k in legs if k.startswith("train_")), key=lambda k: legs[k]["value"])
+    head = dict(legs[best])
+    head["headline_leg"] = best
+    head["biapy_default_threads"] = min(4, ncpu)
+    head["host_threads"] = ncpu
     head["legs"] = legs
     return head
 

@@ -49,7 +49,7 @@ _SIGS = {
     "bpx_packed_weight_elems": ([_i, _i, _i, _i], _i64),
     "bpx_pack_weight": ([_i, _vp, _i, _i, _i, _vp, _vp], _i),
     "bpx_pack_weights_batched": ([_i, _i, _vp, _vp], _i),
-    "bpx_adam_step": ([_i, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp], _i),
+    "bpx_adam_step": ([_i, _vp, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp], _i),
     "bpx_scan_blocks": ([_i64], _i),
     "bpx_select_workspace": ([], _i64),
     "bpx_select_kth_f32": ([_vp, _i64, _i64, _vp, _vp, _vp], _i),

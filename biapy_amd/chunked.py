@@ -134,11 +134,24 @@ class ChunkedPredictor:
         Pz, Py, Px = self.crop
         st = L.stream_ptr()
         # the sampler repeats head chunks so that every rank gets the same count; the reference predicts the repeats and
-        # overwrites identical data in the shared file - here the ranks' results are SUMMED, so a repeat (position >= total in
-        # the padded order) is left to the rank that owns the chunk's first occurrence
-        mine = [v for k, v in enumerate(grid.rank_order(world, rank)) if rank + k * world < grid.total]
+        # overwrites identical data in the shared file - here a repeat (position >= total in the padded order) is left to the rank
+        # that owns the chunk's first occurrence
+        order = grid.rank_order(world, rank)
+        mine = [v for k, v in enumerate(order) if rank + k * world < grid.total]
+        # Several ranks, gather != "none": the ranks' results are disjoint sets of chunks, so they travel as ONE all-gather (round 5; an
+        # all-reduce of whole volumes of zeros-elsewhere moved twice the bytes): every rank packs the cores (the patch without its padding, at
+        # most `step` voxels per axis) of its chunks into slot k of a (slots, step...) buffer, the buffers are gathered, and one scatter places
+        # every chunk of every rank - data movement only, the union bit for bit.
+        packed = world > 1 and gather != "none"
+        cz, cy, cx = grid.step
+        slots = max(1, math.ceil(grid.total / world))
+        cores = None
         seen = set()
         out = None
+        slot_of = {}
+        for k, v in enumerate(order):
+            if rank + k * world < grid.total and v not in slot_of:
+                slot_of[v] = k
         for b0 in range(0, len(mine), self.batch):
             ids = [v for v in mine[b0:b0 + self.batch] if v not in seen]   # chunks repeated to even out the ranks are predicted once
             seen.update(ids)
@@ -146,25 +159,51 @@ class ChunkedPredictor:
                 continue
             n = len(ids)
             tables = torch.from_numpy(np.stack([grid.index_tables(v) for v in ids])).to(vol.device, non_blocking=True)
-            regions = torch.from_numpy(np.stack([grid.region(v) for v in ids])).to(vol.device, non_blocking=True)
+            regs = np.stack([grid.region(v) for v in ids])
+            if packed:   # destination: slot k of the core buffer, seen as a (slots * cz, cy, cx) volume
+                regs = regs.copy()
+                regs[:, 3] = [slot_of[v] * cz for v in ids]
+                regs[:, 4:6] = 0
+            regions = torch.from_numpy(regs).to(vol.device, non_blocking=True)
             patches = torch.empty((n, Pz, Py, Px, C), dtype=vol.dtype, device=vol.device)
             L.check(lib.bpx_gather3d_tables(vol.data_ptr(), vol.element_size(), Z, Y, X, C, tables.data_ptr(), n, Pz, Py, Px, patches.data_ptr(), st))
             pred = self.forward(patches.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).contiguous().to(torch.float32)   # to_pytorch / to_numpy format
-            if out is None:
-                out = torch.zeros((Z, Y, X, pred.shape[-1]), dtype=torch.float32, device=vol.device)
-            L.check(lib.bpx_scatter3d_regions(pred.data_ptr(), n, Pz, Py, Px, pred.shape[-1], regions.data_ptr(), out.data_ptr(), Z, Y, X, st))
-        if world > 1 and gather != "none":   # "none": this rank's chunks only (zeros elsewhere), no collective
-            # every chunk belongs to exactly one rank and the others hold zeros there: the sum is the union, bit for bit
-            if out is None:
+            Co = pred.shape[-1]
+            if packed:
+                if cores is None:
+                    cores = torch.zeros((slots * cz, cy, cx, Co), dtype=torch.float32, device=vol.device)
+                L.check(lib.bpx_scatter3d_regions(pred.data_ptr(), n, Pz, Py, Px, Co, regions.data_ptr(), cores.data_ptr(), slots * cz, cy, cx, st))
+            else:
+                if out is None:
+                    out = torch.zeros((Z, Y, X, Co), dtype=torch.float32, device=vol.device)
+                L.check(lib.bpx_scatter3d_regions(pred.data_ptr(), n, Pz, Py, Px, Co, regions.data_ptr(), out.data_ptr(), Z, Y, X, st))
+        if packed:
+            if cores is None:
                 if self.out_channels is None:
                     raise RuntimeError("a rank without chunks cannot size the result: pass out_channels, or use world <= number of chunks")
-                out = torch.zeros((Z, Y, X, self.out_channels), dtype=torch.float32, device=vol.device)
+                cores = torch.zeros((slots * cz, cy, cx, self.out_channels), dtype=torch.float32, device=vol.device)
+            Co = cores.shape[-1]
+            holds = gather == "all" or rank == 0
+            got = torch.empty((world,) + tuple(cores.shape), dtype=torch.float32, device=vol.device) if holds else None
             if gather == "all":
-                dist.all_reduce(out, group=group)
-            else:
-                dist.reduce(out, dst=0, group=group)
+                dist.all_gather_into_tensor(got.view(-1), cores.view(-1), group=group)
+            else:   # reference semantics: rank 0 owns the result (base_workflow.py:1552-1559)
+                dst = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.gather(cores, [got[r] for r in range(world)] if rank == 0 else None, dst=dst, group=group)
                 if rank != 0:
                     return None
+            # one scatter for the chunks of all ranks: "patch" (r, k) is slot k of rank r's buffer; empty slots have extent 0
+            regs = np.zeros((world * slots, 9), dtype=np.int32)
+            for r in range(world):
+                done = set()
+                for k, v in enumerate(grid.rank_order(world, r)):
+                    if r + k * world < grid.total and v not in done:
+                        done.add(v)
+                        q = grid.region(v)
+                        regs[r * slots + k, 3:] = q[3:]
+            regions = torch.from_numpy(regs).to(vol.device, non_blocking=True)
+            out = torch.zeros((Z, Y, X, Co), dtype=torch.float32, device=vol.device)
+            L.check(lib.bpx_scatter3d_regions(got.data_ptr(), world * slots, cz, cy, cx, Co, regions.data_ptr(), out.data_ptr(), Z, Y, X, st))
         return out
 
 

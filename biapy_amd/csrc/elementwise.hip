@@ -1610,8 +1610,8 @@ constexpr int ADAM_CHUNK = 4096, ADAM_MAX = 64;
 struct AdamBatch { bpx_adam_tensor t[ADAM_MAX]; int first_chunk[ADAM_MAX + 1]; int count; };
 struct AdamSteps { float* step[256]; int count; };
 
-__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamBatch b, const float* __restrict__ lr_d, float lr_h, double beta1, double beta2,
-                                                         float eps, float wd, int decoupled) {
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamBatch b, const float* __restrict__ lr_d, double lr_h, double beta1, double beta2,
+                                                         double eps, double wd, int decoupled) {
   int lo = 0, hi = b.count;                          // block-uniform search: tensor k owns chunks [first_chunk[k], first_chunk[k + 1])
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -1620,23 +1620,25 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamBatch b, cons
   const bpx_adam_tensor t = b.t[lo];
   const int64_t off = (int64_t)((int)blockIdx.x - b.first_chunk[lo]) * ADAM_CHUNK;
   const int n = (int)(t.numel - off < ADAM_CHUNK ? t.numel - off : ADAM_CHUNK);
-  const float lr = lr_d ? *lr_d : lr_h;
+  // The types below are those of torch's fused kernel (ATen/native/cuda/fused_adam_utils.cuh): hyper-parameters are DOUBLES (0.999 is not 0.999f:
+  // 1 - beta2 differs by 1.3e-5 relative), a double times a float is evaluated in double and rounded to float at the assignment; the bias
+  // corrections are computed in double and handed on as floats.
+  const double lr = lr_d ? (double)*lr_d : lr_h;
   const double step = (double)*t.step + 1.0;
-  const float bc1 = (float)(1.0 - pow(beta1, step)), bc2s = sqrtf((float)(1.0 - pow(beta2, step)));
-  const float step_size = lr / bc1;
-  const float b1 = (float)beta1, b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+  const float bc1 = (float)(1.0 - pow(beta1, step)), bc2s = (float)sqrt(1.0 - pow(beta2, step));
+  const float step_size = (float)(lr / (double)bc1);
+  const double omb1 = 1.0 - beta1, omb2 = 1.0 - beta2;
   float* __restrict__ p = t.p + off;
   const float* __restrict__ g = t.g + off;
   float* __restrict__ m = t.m + off;
   float* __restrict__ v = t.v + off;
   auto upd = [&](float& pf, float gf, float& mf, float& vf) {
-    if (wd != 0.f) { if (decoupled) pf -= lr * wd * pf; else gf += wd * pf; }
-    mf = mf + (gf - mf) * omb1;
-    vf = b2 * vf + omb2 * gf * gf;
-    const float denom = sqrtf(vf) / bc2s + eps;
+    if (wd != 0.0) { if (decoupled) pf = (float)((double)pf - lr * wd * (double)pf); else gf = (float)((double)gf + (double)pf * wd); }
+    mf = (float)(beta1 * (double)mf + omb1 * (double)gf);
+    vf = (float)(beta2 * (double)vf + omb2 * (double)gf * (double)gf);
+    const float denom = (float)((double)(sqrtf(vf) / bc2s) + eps);
     pf -= step_size * mf / denom;
   };
-  (void)b1;
   const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   if (vec) {
     const int n4 = n >> 2;
@@ -2712,8 +2714,8 @@ extern "C" int bpx_upsample_c1_bwd(int dtype, int N, int D, int H, int W, int fz
   return 0;
 }
 
-extern "C" int bpx_adam_step(int count, const bpx_adam_tensor* tensors, const float* lr_d, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, int decoupled, bpx_stream_t stream) {
+extern "C" int bpx_adam_step(int count, const bpx_adam_tensor* tensors, const float* lr_d, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, int decoupled, bpx_stream_t stream) {
   const char* fn = "bpx_adam_step";
   BPX_CHECK(count >= 0 && (count == 0 || tensors != nullptr), "%s: bad tensor list", fn);
   hipStream_t s = (hipStream_t)stream;
@@ -2732,7 +2734,7 @@ extern "C" int bpx_adam_step(int count, const bpx_adam_tensor* tensors, const fl
     }
     b.first_chunk[b.count] = (int)chunks;
     if (chunks > 0)
-      adam_multi_kernel<<<(unsigned)chunks, 256, 0, s>>>(b, lr_d, lr, (double)beta1, (double)beta2, eps, weight_decay, decoupled);
+      adam_multi_kernel<<<(unsigned)chunks, 256, 0, s>>>(b, lr_d, lr, beta1, beta2, eps, weight_decay, decoupled);
   }
   for (int base = 0; base < count; base += 256) {   // after every update launch: the updates read the old step
     AdamSteps st{};

@@ -294,6 +294,7 @@ class _Blk:
     drop_p: float = 0.0                    # dropout of the block (blocks.py:163), active in training mode only
     site: int = 0                          # index of the block's dropout site (its own random stream)
     a: Optional[torch.Tensor] = None       # with dropout: the materialised act(norm(h)) * keep / (1 - p) the second convolution read
+    drop_ctr: Optional[torch.Tensor] = None  # with dropout: the device step counter value THIS forward drew its masks with (its backward regenerates them from it)
 
 
 class ResUNetEngine:
@@ -552,7 +553,9 @@ class ResUNetEngine:
         # ---- dropout: conv2 reads the materialised, masked activation instead of forming it in its prologue -------
         x2, rec2, act2 = L.tview(blk.h), blk.rec_h.data_ptr(), self.act
         if blk.drop_p > 0.0 and self.drop_active:
-            ctr = self._drop_state(dev)
+            # THIS forward's counter value (a device copy taken in forward(): capture-safe), kept with the block so that the backward of this pass
+            # regenerates this pass's masks even when another forward ran in between (two forwards before one backward, retained graphs)
+            ctr = blk.drop_ctr = self._drop_ctr_cur
             blk.a = torch.empty_like(blk.h)
             mptr, mmode = self._drop_mask(blk, blk.h.numel(), dev)
             L.check(lib.bpx_norm_act_dropout_fwd(self.dt, B, vox, L.tview(blk.h), blk.rec_h.data_ptr(), self.act, blk.drop_p, self.drop_seed, ctr.data_ptr(),
@@ -594,7 +597,8 @@ class ResUNetEngine:
         if cfg.ndim == 2:
             x = x.unsqueeze(2)
         if self.drop_active and any(v > 0 for v in cfg.dropout):
-            self._drop_state(x.device).add_(1)          # a new mask per forward pass (a device value: replayed graphs advance it too)
+            # a new mask per forward pass (a device value: replayed graphs advance it too); the pass works from its own snapshot
+            self._drop_ctr_cur = self._drop_state(x.device).add_(1).clone()
         P_orig = P
         if cache_weights and torch.cuda.is_current_stream_capturing():
             # a captured forward must contain its own pack kernels: operands cached during the warm-up would freeze the
@@ -799,7 +803,7 @@ class ResUNetEngine:
             red = torch.empty((B, tiles, 2, C1), dtype=torch.float32, device=dev)
             mptr, mmode = self._drop_mask(blk, g1.numel(), dev)
             L.check(lib.bpx_norm_act_dropout_bwd(self.bdt, B, vox, L.tview(g1), L.tview(blk.h), blk.rec_h.data_ptr(), self.act, blk.drop_p, self.drop_seed,
-                                                 self._drop_counter.data_ptr(), blk.site, mptr, 1 if mmode else 0, L.tview(g1), red.data_ptr(), st))
+                                                 blk.drop_ctr.data_ptr(), blk.site, mptr, 1 if mmode else 0, L.tview(g1), red.data_ptr(), st))
         elif fused2:   # dgrad + wgrad of conv2 in one pass over (dOut, h)
             tiles, red = self._bwd_fused(B, blk.S, dOut, w2t, L.tview(blk.h), blk.rec_h, L.tview(g1), G[k["w2"]], G[k["b2"]], G[k["bsc"]], st, dev)
         else:

@@ -173,7 +173,9 @@ class DataParallelTrainStep:
     kilobytes) is started there with ``async_op`` and runs on RCCL's stream beside the rest of the backward; the first block's segment follows.
     Three graph replays per step (forward + backward head | backward tail | optimizer) instead of two.  This is what DDP's 25 MB buckets
     firing during backward buy the reference (base_workflow.py:952-958).  ``overlap="auto"`` takes it when the model qualifies; models without
-    an engine (or with dict outputs) keep the serial form, as does ``overlap=False``.
+    an engine (or with dict outputs), and models carrying forward / backward hooks (the overlapped form does not go through ``model.forward``),
+    keep the serial form, as does ``overlap=False``.  The eager overlapped form re-reads the module's training flag at every step; a captured
+    graph (either form) freezes the mode - dropout on or off - it was captured in.
 
     ``graph=False`` runs the same three phases eagerly (any device / backend; this is what the gloo tests drive); that form
     needs ``p.grad`` to stay views of ``self.flat_grad`` and re-binds them at every call, so an ``optimizer.zero_grad()`` by the
@@ -287,6 +289,11 @@ class DataParallelTrainStep:
             return False
         if getattr(inner, "sr_pre", 0) or getattr(inner, "return_class", False) or getattr(inner, "explicit_activations", False):
             return False
+        # the overlapped form calls engine.forward / engine.backward itself: module forward hooks would be skipped, so a hooked model keeps the
+        # serial form (which goes through model.forward) under overlap="auto"
+        for m_ in {id(model): model, id(inner): inner}.values():
+            if getattr(m_, "_forward_hooks", None) or getattr(m_, "_forward_pre_hooks", None) or getattr(m_, "_backward_hooks", None):
+                return False
         names, params = inner._named()
         if [id(p) for p in params] != [id(p) for p in self.params]:
             return False
@@ -304,18 +311,25 @@ class DataParallelTrainStep:
         self._n_first = sum(p.numel() for n, p in zip(names, params) if n.startswith("down_path.0."))
         self.overlapped = True
         self._works = []
-        state = {"capturing": None}
+        state = {"capturing": None, "open": None}
 
         def reduce_rest():          # at the start of the backward's last stretch: everything but the first block's gradients is final
             cap = state["capturing"]
             if cap is not None:     # capture: close the first graph here and open the second - nothing is exchanged while capturing
                 cap[0].capture_end()
+                state["open"] = None
                 cap[1].capture_begin(pool=cap[0].pool(), capture_error_mode="thread_local")
+                state["open"] = cap[1]
                 return
             if self.world > 1:
                 self._works.append(dist.all_reduce(eng.last_flat_grad[self._n_first:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
         def fwd_bwd():
+            # inner.engine() again: it refreshes engine.drop_active from the module's CURRENT training flag (the eager form follows a later
+            # model.eval() / model.train(); a captured graph freezes the mode it was captured in, as it freezes everything else)
+            eng_ = inner.engine()
+            if eng_ is not eng:
+                raise RuntimeError("DataParallelTrainStep: the model's compute_dtype changed after the step was built")
             P = {n: p.detach() for n, p in zip(names, params)}
             logits, ctx = eng.forward(P, self.x.to(torch.float32), head_act=0, save=True)
             self._out = logits
@@ -363,8 +377,22 @@ class DataParallelTrainStep:
                 state["capturing"] = (g1a, g1b)
                 try:
                     g1a.capture_begin(capture_error_mode="thread_local")
+                    state["open"] = g1a
                     self.loss = fwd_bwd()                                   # reduce_rest() switches from g1a to g1b inside
+                    if state["open"] is not g1b:
+                        raise RuntimeError("DataParallelTrainStep: the engine's backward never reached its last block (on_last_block was not called)")
                     g1b.capture_end()
+                    state["open"] = None
+                except BaseException:
+                    # leave the stream out of capture mode before the error travels on (a loss_fn error or an unsupported shape inside fwd_bwd
+                    # would otherwise leave every later HIP call of the process failing with a capture error)
+                    if state["open"] is not None:
+                        try:
+                            state["open"].capture_end()
+                        except Exception:  # noqa: BLE001 - the capture is already invalid; ending it is best effort
+                            pass
+                        state["open"] = None
+                    raise
                 finally:
                     state["capturing"] = None
             torch.cuda.current_stream().wait_stream(side)

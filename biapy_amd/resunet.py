@@ -295,8 +295,21 @@ class ResUNet(nn.Module):
                 if a not in ("relu", "tanh", "leaky_relu", "elu", "gelu", "silu", "sigmoid", "softmax", "linear", "softplus", "none"):
                     raise AssertionError("Get unknown activation key {}".format(a))
             self._explicit_acts = names_
+            # prepare_activation_layers (blocks.py:2001-2051): walk the channels in order, append each activation to the "pred" or the "class"
+            # list, and STOP after the first entry whose name contains "softmax" - channels behind it get no activation at all
+            self._pred_acts, self._class_acts = [], []
+            for info, a in zip(chan_info, names_):
+                (self._class_acts if "class" in info else self._pred_acts).append(a)
+                if "softmax" in a:
+                    break
             if self.return_class and not self._class_channels:
                 raise ValueError("If 'return_class' is True, 'head_activations' must be provided.")
+        # channel ranges of the class heads inside the class tensor (one activation per class HEAD, resunet.py:423-425)
+        self._class_head_slices, o = [], 0
+        for info, n in zip(output_channel_info, output_channels):
+            if "class" in str(info):
+                self._class_head_slices.append((o, o + int(n)))
+                o += int(n)
         in_ch = image_shape[-1]
         zd = [int(v) for v in list(z_down)[:depth]] if ndim == 3 else [1] * depth
         self.cfg = NetConfig(in_ch=16 if self.sr_pre else in_ch, feature_maps=list(feature_maps), out_channels=tuple(output_channels), activation=act,
@@ -399,17 +412,22 @@ class ResUNet(nn.Module):
         outs = logits[:, self._pred_channels] if self.return_class else logits
         cls = logits[:, self._class_channels] if self.return_class else None
         if self.explicit_activations:
-            acts = self._explicit_acts
-            pa = [acts[c] for c in self._pred_channels]
+            # resunet.py:415-425 with the lists of prepare_activation_layers: ONE collected activation acts on the whole tensor (a joint softmax over
+            # the N channels of a multi-class head); several act on their own 1-channel slice each (a softmax there is over one channel), and the
+            # channels behind the last collected entry stay raw logits
+            pa = self._pred_acts
             if len(pa) == 1:
                 outs = self._apply_named(outs, pa[0])
-            else:                                           # channel by channel, as the reference (a softmax entry acts on its own channel there too)
-                outs = torch.cat([self._apply_named(outs[:, i:i + 1], a) for i, a in enumerate(pa)], dim=1)
-            if cls is not None:
-                # prepare_activation_layers stops collecting at the first softmax: one activation module per collected CLASS channel, each
-                # applied to class_outs[i] = the WHOLE output of class head i (resunet.py:423-425); with one class head that is its first entry
-                ca = [acts[c] for c in self._class_channels]
-                cls = self._apply_named(cls, ca[0])
+            elif len(pa) > 1:
+                outs = torch.cat([self._apply_named(outs[:, i:i + 1], a) for i, a in enumerate(pa)] + ([outs[:, len(pa):]] if len(pa) < outs.shape[1] else []), dim=1)
+            if cls is not None and self._class_acts:
+                # entry i acts on the whole output of class head i (class_outs[i]); more entries than class heads is the reference's IndexError
+                if len(self._class_acts) > len(self._class_head_slices):
+                    raise IndexError("list index out of range")
+                parts = [cls[:, a:b] for a, b in self._class_head_slices]
+                for i, a in enumerate(self._class_acts):
+                    parts[i] = self._apply_named(parts[i], a)
+                cls = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
         if not self.return_class:
             return outs
         if self.return_one_tensor:

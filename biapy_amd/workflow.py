@@ -130,7 +130,7 @@ def sharded_blend(backend, patches: torch.Tensor, plans: List[SlabPlan], rank: i
       4. the seeded part, after the receive.
     The own slab is blended straight into its place in the result volume where the rank holds one (no staging copy); the
     slabs are disjoint Z-ranges of a (Z,Y,X,C) array, i.e. contiguous, so the final gather receives / broadcasts directly into
-    views of that volume - exact sizes, no padding to the largest slab, no concatenation.
+    views of that volume; gather="all" is ONE in-place all-gather of the slabs' common part plus a broadcast per longer slab (`gather_layout`).
     """
     me = plans[rank]
     dev = patches.device
@@ -183,9 +183,7 @@ def sharded_blend(backend, patches: torch.Tensor, plans: List[SlabPlan], rank: i
         return slab
     owners = [(r, p.own) for r, p in enumerate(plans) if p.rows[1] > p.rows[0] and p.own[1] > p.own[0]]
     if gather == "all":
-        reqs = [dist.broadcast(full[o[0]:o[1]], src=_peer(group, r), group=group, async_op=True) for r, o in owners]
-        for r in reqs:
-            r.wait()
+        _all_gather_slabs(full, plans, rank, world, group)
         return full
     if rank == 0:
         ops = [dist.P2POp(dist.irecv, full[o[0]:o[1]], _peer(group, r), group) for r, o in owners if r != 0]
@@ -194,6 +192,54 @@ def sharded_blend(backend, patches: torch.Tensor, plans: List[SlabPlan], rank: i
     for r in _exchange(ops):
         r.wait()
     return full
+
+
+def gather_layout(plans: List[SlabPlan], world: int):
+    """How the ranks' disjoint output slabs travel in ONE all-gather (north_star: "RCCL all-gather over xGMI for the stitched output").
+
+    An all-gather moves equal pieces.  ``plan_slabs`` gives every rank but the last the same slab (cfg 3 on 8 ranks: 7 x 120 slices and one
+    of 184 - the last rank also owns what its patches reach beyond the grid step), so the common part travels IN PLACE: when rank r's slab
+    starts at r * piece, the slabs' first ``piece`` slices are consecutive pieces of the result volume and the collective's output is the
+    volume itself (no staging, no copies); what is left of longer slabs ("tails": one 64-slice block at cfg 3) follows as broadcasts.
+    Returns ("inplace", piece, tails) or, for layouts that do not line up (ranks without rows, unequal steps), ("padded", longest, None):
+    every slab copied into a piece of the longest slab's size, gathered, and copied out."""
+    own = [p.own if p.rows[1] > p.rows[0] else (0, 0) for p in plans]
+    sizes = [o[1] - o[0] for o in own]
+    piece = min(sizes)
+    if piece > 0 and all(own[r][0] == r * piece for r in range(world)):
+        tails = [(r, (own[r][0] + piece, own[r][1])) for r in range(world) if sizes[r] > piece]
+        return "inplace", piece, tails
+    return "padded", max(sizes), None
+
+
+def _all_gather_slabs(full: torch.Tensor, plans: List[SlabPlan], rank: int, world: int, group=None) -> None:
+    """Every rank's blended slab (already in its place in ``full`` on its owner) into ``full`` on every rank: one ``all_gather_into_tensor``
+    (+ broadcasts of the tails, see ``gather_layout``).  Pure data movement: the gathered volume has the owners' bits."""
+    kind, piece, tails = gather_layout(plans, world)
+    Z = full.shape[0]
+    row = full[0].numel()
+    flat = full.view(-1)
+    if kind == "inplace":
+        z0 = plans[rank].own[0]
+        mine = flat[z0 * row:(z0 + piece) * row]
+        if dist.get_backend(group) != "nccl":
+            mine = mine.clone()                    # RCCL takes the in-place form (input = its own piece of the output); other backends get a copy
+        dist.all_gather_into_tensor(flat[: world * piece * row], mine, group=group)
+        reqs = [dist.broadcast(flat[a * row:b * row], src=_peer(group, r), group=group, async_op=True) for r, (a, b) in tails]
+        for q in reqs:
+            q.wait()
+        return
+    me = plans[rank]
+    active = me.rows[1] > me.rows[0]
+    send = torch.zeros(piece * row, dtype=full.dtype, device=full.device)
+    if active and me.own[1] > me.own[0]:
+        send[: (me.own[1] - me.own[0]) * row] = flat[me.own[0] * row:me.own[1] * row]
+    got = torch.empty(world * piece * row, dtype=full.dtype, device=full.device)
+    dist.all_gather_into_tensor(got, send, group=group)
+    for r, p in enumerate(plans):
+        if r != rank and p.rows[1] > p.rows[0] and p.own[1] > p.own[0]:
+            flat[p.own[0] * row:p.own[1] * row] = got[r * piece * row:r * piece * row + (p.own[1] - p.own[0]) * row]
+    assert Z * row == flat.numel()
 
 
 class SlidingWindowPredictor:

@@ -156,7 +156,7 @@ typedef struct bpx_pack_job {
 int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job* jobs, bpx_stream_t stream);
 
 /* torch.optim.Adam / AdamW step (capturable form: `step` is a device float per tensor, lr may be a device scalar) over `count` fp32 tensors in
- * ceil(count / 64) + 1 launches of 4096-element blocks; the arithmetic and its order are those of torch's fused kernel (train_engine.py:173-177
+ * ceil(count / 64) + 1 launches of 4096-element blocks; the arithmetic, its order and its TYPES (double hyper-parameters, double x float products rounded to float at the assignment) are those of torch's fused kernel (train_engine.py:173-177
  * `optimizer.step()` of the reference loop).  `tensors` is a HOST array copied into the kernel arguments.  lr_d (device) overrides lr when not
  * NULL; decoupled = 1: AdamW (p -= lr * wd * p), 0: Adam (g += wd * p).  amsgrad / maximize are not supported (the caller keeps torch's step). */
 typedef struct bpx_adam_tensor {
@@ -164,8 +164,8 @@ typedef struct bpx_adam_tensor {
   float* step;                                  /* device scalar, incremented by one */
   int64_t numel;
 } bpx_adam_tensor;
-int bpx_adam_step(int count, const bpx_adam_tensor* tensors, const float* lr_d, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int decoupled, bpx_stream_t stream);
+int bpx_adam_step(int count, const bpx_adam_tensor* tensors, const float* lr_d, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int decoupled, bpx_stream_t stream);
 
 /* Conv3d k=3 "same" + bias (biapy/models/blocks.py:154-157), implicit GEMM on MFMA with an
  * LDS-staged input halo.  Fusions:

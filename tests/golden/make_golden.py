@@ -10,6 +10,7 @@ The GPU box never runs this file; tests read the committed .npz files.
 """
 import contextlib
 import io
+import json
 import os
 import sys
 
@@ -864,6 +865,45 @@ def resunet_activations_fixtures():
     print("resunet_activations_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_activations_golden.npz")) // 1024, "KiB")
 
 
+def resunet_explicit_tail_fixtures():
+    """how the reference builds and applies its explicit activation lists (prepare_activation_layers, blocks.py:2001-2051; forward tail
+    resunet.py:413-425).  Three channel layouts, each as (raw head outputs with explicit_activations=False, outputs with it True) of the SAME weights:
+    a multi-class head (output_channels [3], ce_softmax x3: ONE collected activation -> joint softmax over the 3 channels), a mask + distance-like
+    pair (["F", "Db"], sigmoid + 3x softmax: the list stops after the first softmax, so channel 1 is a softmax over one channel and channels 2, 3
+    stay raw) and a class head whose first channel activation is a softmax (the pred list ends up with one entry)."""
+    rmod = shim.load("biapy.models.resunet")
+    out = {}
+    fm, patch = [16, 32], (8, 8, 8)
+    cases = {
+        "multiclass": dict(output_channels=[3], output_channel_info=["F"], head_activations=["ce_softmax"] * 3),
+        "mask_then_softmax": dict(output_channels=[1, 3], output_channel_info=["F", "Db"], head_activations=["ce_sigmoid", "ce_softmax", "ce_softmax", "ce_softmax"]),
+        "two_then_class": dict(output_channels=[2, 2], output_channel_info=["F", "class"], head_activations=["tanh", "ce_sigmoid", "ce_softmax", "ce_softmax"]),
+    }
+    g = torch.Generator().manual_seed(172)
+    xl = torch.randn(2, *patch, 1, generator=g)
+    out["x"] = xl.numpy()
+    for tag, kw in cases.items():
+        nets = []
+        for explicit in (False, True):
+            torch.manual_seed(72)
+            with quiet():
+                nets.append(rmod.ResUNet(image_shape=patch + (1,), activation="elu", feature_maps=fm, drop_values=[0.0] * 2, normalization="in", k_size=3,
+                                         upsample_layer="convtranspose", yx_down=[2], z_down=[2], explicit_activations=explicit, isotropy=[True] * 2,
+                                         larger_io=False, conv_layers=[2] * 2, **kw).eval())
+        nets[1].load_state_dict(nets[0].state_dict())
+        with torch.no_grad():
+            raw, act = nets[0](xl.permute(0, 4, 1, 2, 3)), nets[1](xl.permute(0, 4, 1, 2, 3))
+        for name, o in (("raw", raw), ("act", act)):
+            if isinstance(o, dict):
+                for k, v in o.items():
+                    out[f"{tag}/{name}/{k}"] = v.numpy()
+            else:
+                out[f"{tag}/{name}/pred"] = o.numpy()
+        out[f"{tag}/kwargs"] = np.array(json.dumps(kw))
+    np.savez_compressed(os.path.join(HERE, "resunet_explicit_tail_golden.npz"), **out)
+    print("resunet_explicit_tail_golden.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "resunet_explicit_tail_golden.npz")) // 1024, "KiB")
+
+
 def resunet_class_head_fixtures():
     """The reference ResUNet with a classification head (output_channels [1, 3], output_channel_info ["F", "class"], resunet.py:180, :408-443): the
     out dict without and with explicit_activations (sigmoid on the mask channel, softmax over the class block), a loss over both heads
@@ -1319,7 +1359,7 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "resunet_dropout", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "resunet_explicit_tail", "resunet_dropout", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -1354,6 +1394,8 @@ if __name__ == "__main__":
         resunet_dropout_fixtures()
     if "resunet_class_head" in which:
         resunet_class_head_fixtures()
+    if "resunet_explicit_tail" in which:
+        resunet_explicit_tail_fixtures()
     if "chunked" in which:
         chunked_fixtures()
     if "rcan" in which:

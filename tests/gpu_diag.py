@@ -35,7 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net", action="store_true")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default=None, help="run one late-added group alone: rcan_up | wide48 | padded")
+    ap.add_argument("--only", default=None, help="run one group alone: rcan_up | wide48 | padded | dice")
     a = ap.parse_args()
     import kernel_checks as K
 
@@ -55,6 +55,10 @@ def main():
     if a.only == "rcan_up":                  # the RCAN x-scale stage's training rows alone (added after the round's full table was collected)
         for sc, dtype, grp in RCAN_UP:
             run(K.check_rcan_upscale_train, sc, dtype, grp)
+        return _emit(rows, a.out)
+    if a.only == "dice":                     # the north-star Dice rows alone (toy net + the benched architecture)
+        run(K.check_dice_parity_trained)
+        run(K.check_dice_benched_arch)
         return _emit(rows, a.out)
     if a.only == "padded":                   # FEATURE_MAPS [52, 68, 84] (CartoCell template): zero-padded to [64, 80, 96] inside the engine - module vs the CPU oracle on the true widths
         for dtype in (torch.float32, torch.bfloat16, torch.float16):
@@ -108,6 +112,7 @@ def main():
         run(K.check_sliding_window, torch.float32)
         run(K.check_sliding_window, torch.bfloat16)
         run(K.check_dice_parity_trained)
+        run(K.check_dice_benched_arch)                                     # round 5: the Dice bar on the five-level cfg-2 architecture, 64^3 and the benched 128^3
         for dtype in (torch.float32, torch.bfloat16, torch.float16):      # float16 = the mixed training mode (fp16 forward, bf16 gradients): the benched one
             run(K.check_network, dtype, None, None, None, golden=gr)
             run(K.check_network, dtype, [16, 32, 64, 128, 256], (64, 64, 64), 1, seed=3)

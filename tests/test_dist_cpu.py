@@ -366,3 +366,21 @@ def test_evaluate_averages_over_ranks_by_count():
         p.join(timeout=60)
     want = (res[0][2] + res[1][2]) / (res[0][3] + res[1][3])
     assert abs(res[0][1] - want) < 1e-6 and abs(res[1][1] - want) < 1e-6, (res, want)
+
+
+def test_gather_layout_of_the_stitched_volume():
+    """the stitched output travels as ONE all-gather.  cfg 3 on 8 ranks gives slabs of 7 x 120 and 1 x 184 slices whose
+    starts are multiples of 120: the common part is gathered in place (the collective's output IS the volume), the last rank's 64 extra slices
+    follow as one broadcast; layouts that do not line up (idle ranks) take the padded form.  (The gloo cases of
+    test_sharded_blend_bit_exact_gloo run both forms end to end, bit-exact.)"""
+    g = T.merge_grid((1024, 16, 16), (128, 16, 16), (0.5, 0.5, 0.5), (0, 0, 0))
+    plans = workflow.plan_slabs(g[0].starts(), 128, 1024, 8)
+    assert [p.own for p in plans] == [(120 * r, 120 * (r + 1)) for r in range(7)] + [(840, 1024)]
+    assert workflow.gather_layout(plans, 8) == ("inplace", 120, [(7, (960, 1024))])
+    g = T.merge_grid((72, 40, 40), (32, 32, 32), (0.5, 0.5, 0.5), (0, 0, 0))
+    kind, piece, tails = workflow.gather_layout(workflow.plan_slabs(g[0].starts(), 32, 72, 2), 2)
+    assert kind == "inplace" and all(b > a for _, (a, b) in tails)
+    g = T.merge_grid((40, 20, 20), (32, 16, 16), (0.5, 0.0, 0.5), (0, 0, 0))          # 2 patch rows on 4 ranks: two ranks hold nothing
+    plans = workflow.plan_slabs(g[0].starts(), 32, 40, 4)
+    kind, piece, tails = workflow.gather_layout(plans, 4)
+    assert kind == "padded" and piece == max(p.own[1] - p.own[0] for p in plans) and tails is None

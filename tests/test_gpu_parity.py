@@ -10,6 +10,25 @@ def _assert_all(rows):
     assert not bad, "\n".join("%s err=%.3e tol=%.1e %s" % (r["name"], r["err"], r["tol"], r.get("extra", "")) for r in bad)
 
 
+# Relative gap allowed between the mixed-mode device loss curve and the fp32 oracle curve at every one of 30 training steps of the cfg-2 architecture.
+# Round 4 asserted 0.05 under a DESIGN sentence that said "equal to 4 digits" (VERDICT r4 weak #2); the bar is now ~3x the worst gap MEASURED on the
+# device (recorded by the test in gpurun_out/diag_values.txt and copied to profiles/r05_gpu_diag.txt).
+LOSS_CURVE_TOL = 0.01
+
+
+def _record_diag(line):
+    """Measured values of the parity tests, appended to gpurun_out/diag_values.txt on the GPU box (merged back by gpurun) so that the numbers a bar
+    is derived from are recorded numbers, not a pass / fail."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "diag_values.txt"), "a") as f:
+            f.write(line.rstrip() + "\n")
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="module")
 def K():
     import kernel_checks
@@ -200,6 +219,39 @@ def test_resunet_dropout_against_the_reference_step(K, resunet_dropout_golden, d
     gradients; with its own Philox stream the keep rates are right, every forward draws a new mask, forward and backward agree on it (the CPU
     oracle given the recorded masks), and evaluation mode ignores dropout."""
     _assert_all(K.check_network_dropout(dtype, resunet_dropout_golden))
+
+
+def test_dropout_backward_uses_the_masks_of_its_own_forward():
+    """ADVICE r4: two training forwards before the backwards (gradient accumulation with retained graphs, out1 = m(x1); out2 = m(x2);
+    (l1 + l2).backward()).  Every pass regenerates its masks from the counter value IT drew them with: the gradients of pass 1 taken after pass 2
+    ran equal, bit for bit, the gradients of a run in which pass 1 was followed by its backward at once (same counter values: the engine's
+    counter is reset to the same start)."""
+    from biapy_amd.resunet import ResUNet
+    torch.manual_seed(9)
+    m = ResUNet(image_shape=(32, 32, 32, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.3, 0.3], normalization="in", yx_down=[2], z_down=[2],
+                isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2, compute_dtype=torch.float32).cuda().train()
+    x1 = torch.randn(1, 1, 32, 32, 32, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    x2 = torch.randn(1, 1, 32, 32, 32, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    eng = m.engine()
+
+    def grads_of(fn):
+        m.zero_grad(set_to_none=True)
+        eng._drop_state(x1.device).zero_()
+        fn()
+        return [p.grad.clone() for p in m.parameters()]
+
+    def interleaved():
+        o1 = m(x1)
+        o2 = m(x2)                     # advances the device counter before pass 1's backward runs
+        o1.sum().backward()
+        del o2
+
+    def alone():
+        m(x1).sum().backward()
+
+    ga, gb = grads_of(interleaved), grads_of(alone)
+    assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+    assert any(float(g.abs().max()) > 0 for g in ga)
 
 
 def test_graphed_train_step_draws_a_new_dropout_mask_at_every_replay(K):
@@ -1474,10 +1526,18 @@ def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve(dtype):
     cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
     assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
     rel = ((cd - cc).abs() / cc).max().item()
-    assert rel < 0.05, (rel, curve_c, curve_d)
+    print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
+    _record_diag(f"loss_curve[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {LOSS_CURVE_TOL:g})")
+    assert rel < LOSS_CURVE_TOL, (rel, curve_c, curve_d)
+    # the north-star Dice bar on THIS architecture in the benched forward mode, on the weights just trained, held-out batches
+    # at 64^3 and at the benched 128^3 x 1 shape
+    rows = K.check_dice_benched_arch(model=dev_m, S=S, big=128)
+    for r in rows:
+        _record_diag(f"{r['name']} = {r['err']:.3e} (tol {r['tol']:g}) {r.get('extra', '')}")
+    _assert_all(rows)
 
 
-def test_resunet_mixed_training_follows_the_fp32_oracle_loss_curve():
+def test_resunet_mixed_training_follows_the_fp32_oracle_loss_curve(K):
     """VERDICT r3 weak #1 / next #4a: the BENCHED training mode of cfg 2 (fp16 forward, bf16 gradients) against fp32 TRAINING, not only against
     one fp32 gradient: the cfg-2 architecture (fm 16-32-64-128-256) at 64^3 - the size from which the level-0 layers take the fused backward
     kernel and the lean forward kernels - trained for 30 AdamW steps on the device in the mixed mode and as the CPU oracle graph in fp32, from
@@ -1520,7 +1580,15 @@ def test_resunet_mixed_training_follows_the_fp32_oracle_loss_curve():
     print("fp32 oracle loss curve   (cpu):", [round(v, 4) for v in curve_c])
     assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
     rel = ((cd - cc).abs() / cc).max().item()
-    assert rel < 0.05, (rel, curve_c, curve_d)
+    print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
+    _record_diag(f"loss_curve[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {LOSS_CURVE_TOL:g})")
+    assert rel < LOSS_CURVE_TOL, (rel, curve_c, curve_d)
+    # the north-star Dice bar on THIS architecture in the benched forward mode, on the weights just trained, held-out batches
+    # at 64^3 and at the benched 128^3 x 1 shape
+    rows = K.check_dice_benched_arch(model=dev_m, S=S, big=128)
+    for r in rows:
+        _record_diag(f"{r['name']} = {r['err']:.3e} (tol {r['tol']:g}) {r.get('extra', '')}")
+    _assert_all(rows)
 
 
 def _sw2_worker(rank, world, port, q):
@@ -1584,6 +1652,64 @@ def test_sharded_sliding_window_from_input_slabs_equals_single_device():
         assert (out.view(np.uint32) == ref.view(np.uint32)).all(), rank
         assert (out0 is None) == (rank != 0)
     assert (res[0][3].view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def _chunk3_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from biapy_amd.chunked import ChunkedPredictor
+
+    vol = _chunk3_volume().cuda()
+    pred = ChunkedPredictor(lambda x: x.float() * 2.0 + 1.0, (16, 16, 16), (2, 3, 0), batch_size=3, out_channels=2)
+    out = pred.predict(vol, rank=rank, world=world, gather="all")
+    out0 = pred.predict(vol, rank=rank, world=world, gather="rank0")
+    q.put((rank, out.cpu().numpy(), None if out0 is None else out0.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _chunk3_volume():
+    g = torch.Generator().manual_seed(78)
+    return torch.randn(40, 29, 50, 2, generator=g)          # ragged against the (12, 10, 16) chunk step: border chunks are smaller than a slot
+
+
+def test_chunked_prediction_gathers_the_ranks_chunks_bit_exactly():
+    """the by-chunks route exchanges its ranks' DISJOINT chunks with one all-gather of packed chunk cores (it used to
+    all-reduce whole volumes that were zero elsewhere: twice the bytes).  Ranks share the one GPU over gloo: 3 ranks divide the 4 x 3 x 4
+    chunk grid's 48 chunks evenly, 5 ranks do not (the sampler repeats two head chunks; the repeats are left to their first owner and their
+    slots stay empty); every rank's volume (gather = "all") and rank 0's (gather = "rank0") equal the single-process result bit for bit."""
+    import socket
+
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    from biapy_amd.chunked import ChunkedPredictor
+
+    vol = _chunk3_volume()
+    ref = ChunkedPredictor(lambda x: x.float() * 2.0 + 1.0, (16, 16, 16), (2, 3, 0), batch_size=3).predict(vol.cuda()).cpu().numpy()
+    assert np.array_equal(ref, vol.numpy() * 2.0 + 1.0)
+    for world in (3, 5):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_chunk3_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+        for rank, out, out0 in res:
+            assert (out.view(np.uint32) == ref.view(np.uint32)).all(), (world, rank)
+            assert (out0 is None) == (rank != 0)
+        assert (res[0][2].view(np.uint32) == ref.view(np.uint32)).all(), world
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "mix16"])

@@ -710,3 +710,33 @@ def test_channel_pad_plan_covers_every_parameter_and_is_exact_on_the_oracle():
         assert (ya - yb).abs().max().item() < 2e-5 * ya.abs().max().item(), act
     with pytest.raises(NotImplementedError):                         # GroupNorm groups would change with the padding
         ResUNet(feature_maps=[20, 36, 52], **dict(kw, normalization="gn"))
+
+
+@pytest.mark.parametrize("tag", ["multiclass", "mask_then_softmax", "two_then_class"])
+def test_explicit_activation_tail_follows_prepare_activation_layers(tag):
+    """with explicit_activations the reference collects its activation list channel by channel and STOPS after the first softmax
+    (prepare_activation_layers, blocks.py:2001-2051); one collected entry acts on the whole tensor (joint softmax of a multi-class head), several
+    act on one-channel slices, channels behind the list stay raw (resunet.py:413-425).  The drop-in's tail is plain torch on the head kernel's
+    logits, so it is held to the reference's own outputs here on the CPU (fixture: make_golden.py resunet_explicit_tail)."""
+    import json
+
+    from biapy_amd.resunet import ResUNet
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "resunet_explicit_tail_golden.npz"))
+    kw = json.loads(str(g[f"{tag}/kwargs"]))
+    m = ResUNet(image_shape=(8, 8, 8, 1), activation="elu", feature_maps=[16, 32], drop_values=[0.0] * 2, normalization="in", yx_down=[2], z_down=[2],
+                explicit_activations=True, isotropy=[True] * 2, larger_io=False, conv_layers=[2] * 2, **kw)
+    raw = {k: torch.from_numpy(g[f"{tag}/raw/{k}"]) for k in ("pred", "class") if f"{tag}/raw/{k}" in g.files}
+    # the head kernel's logits: every head's rows in head order = pred and class channels interleaved by head
+    n_out = sum(kw["output_channels"])
+    logits = torch.empty((raw["pred"].shape[0], n_out) + tuple(raw["pred"].shape[2:]))
+    logits[:, m._pred_channels] = raw["pred"]
+    if "class" in raw:
+        logits[:, m._class_channels] = raw["class"]
+    out = m._finish_outputs(logits)
+    out = out if isinstance(out, dict) else {"pred": out}
+    for k in raw:
+        ref = torch.from_numpy(g[f"{tag}/act/{k}"])
+        assert out[k].shape == ref.shape and (out[k] - ref).abs().max().item() < 1e-6, (tag, k)
+    if tag == "multiclass":          # the joint softmax: channels sum to one (a per-channel softmax would be all ones)
+        assert (out["pred"].sum(1) - 1).abs().max().item() < 1e-5 and out["pred"].max().item() < 1.0
