@@ -595,7 +595,10 @@ static int conv3d_fwd_impl(const char* fn, int dtype, int N, int D, int H, int W
     p.pool = pooled.ptr; p.pool_ld = pooled.ld; p.pool_sz = pool_sz; p.pool_part = pool_stats_part_d;
   }
   const bool lean_ok = use_lean(dtype, p) && c.tx == 16;
-  int rc = lean_ok ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
+  // the 16-output-channel layers of the big tile march in z (conv3d_zmarch.hip; same bits as the lean kernel); 1 = not applicable
+  int rc = !lean_ok ? 1 : launch_conv3_zm(p, c, (hipStream_t)stream);
+  if (rc != 0)
+    rc = lean_ok ? launch_conv3_lean(EPI_FWD, p, c, (hipStream_t)stream)
            : (dtype == BPX_BF16) ? launch_conv3<uint16_t, EPI_FWD>(p, c, (hipStream_t)stream)
            : (dtype == BPX_F16)  ? launch_conv3<f16_t, EPI_FWD>(p, c, (hipStream_t)stream)
                                  : launch_conv3<float, EPI_FWD>(p, c, (hipStream_t)stream);

@@ -23,6 +23,7 @@ struct Conv3Params {
   // fused MaxPool3d (pool_sz,2,2) of the output (forward, lean kernel only): pooled tensor + its statistics partials
   void* pool; int pool_ld; int pool_sz; float* pool_part;
   int tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd;
+  int tilesZ;  // conv3d_zmarch.hip only
   long long* stamps;  // profiling: per-workgroup s_memtime stamps [block][16] (BPX_CONV_STAMPS), else null
   int dbg;  // ablation switches for profiling (BPX_CONV_DBG): 1 = skip MFMA steps, 2 = skip staging transform+loads
   // distance in ELEMENTS between consecutive 16-channel chunks of a voxel: 16 for the ordinary interleaved layout, the plane size for
@@ -99,6 +100,8 @@ extern long long* g_conv_stamps;  // profiling hook (bpx_debug_set_conv_stamps)
 
 // lean persistent bf16 kernel (conv3d_lean.hip) - the production kernel of the >= 64^3 layers
 int launch_conv3_lean(int epi, const Conv3Params& p, const TileCfg& c, hipStream_t s);
+// z-marching forward kernel (conv3d_zmarch.hip) for the 16-output-channel layers of the big tile; 1 = not applicable, take the lean kernel (same bits)
+int launch_conv3_zm(const Conv3Params& p, const TileCfg& c, hipStream_t s);
 // (The DMA-pipelined forward / dgrad schedule of round 3 - conv3d_dma.hip: halo by LDS-DMA into a second buffer, in-place transform - measured
 //  EQUAL to the lean kernel on every cfg-2 layer (profiles/r03_conv_dma_vs_lean.txt) and was deleted in round 4; the LDS-DMA staging lives on in
 //  the fused backward kernel, bwd_fused.hip, where the operands need no transform or are transformed once per voxel.)

@@ -1,0 +1,509 @@
+// Conv3d 3x3x3 forward, 16-bit storage, 16 output channels: the Z-MARCHING (plane-ring) schedule of the level-0 layers (round 5).
+//
+// Same GEMM mapping, packed-weight order, tap order, epilogue and statistics layout as conv3_lp_kernel<4, 8, 16, 1, EPI_FWD, ...> (conv3d_lean.hip -
+// read its header first): every accumulator sees the same MFMAs in the same order and every statistics row is the same sum, so the output, the
+// fused pool and the partial sums are BIT-IDENTICAL to the lean kernel's (tests: check_conv3d_zmarch).  What differs is how the activated input
+// gets into LDS:
+//   * the lean kernel stages the whole (4+2) x (8+2) x (16+2) halo of every tile: each input voxel is fetched, normalised, activated, converted and
+//     written to LDS 2.11 times, and the cycle stamps put ~70 % of a tile's time into that staging (profiles/r04_stamps_fwd_dgrad.txt);
+//   * here a persistent workgroup owns a run of consecutive z-steps of ONE (y, x) tile column.  The halo's six z-planes live in a RING: a step
+//     stages only its 4 NEW planes, the two overlap planes of the previous step stay where they are (1.41 x per voxel instead of 2.11 x; a run
+//     pays the two extra planes once, at its start and where it crosses into the next column);
+//   * a step's new planes are fewer pieces per thread (6 instead of 9), so the NEXT stage's pieces fit in registers while this stage's MFMA steps
+//     run: the global-load latency that the lean kernel exposes in every chunk stage is off the critical path (the lean kernel's own prefetch
+//     experiment failed on registers: 9 pieces + 168-VGPR budget, conv3d_lean.hip header);
+//   * plane slots are addressed as (uniform slot base) + (per-lane constant) + immediate: the ring costs eight v_add per stage, no unrolled phases.
+// LDS, one 16-channel input chunk (NCH = 1): a ring of 6 plane slots, ring-relative plane q of the step sits in slot (q + off) % 6, off += 4 per step.
+// Three chunks (NCH = 3, the decoder's 48 -> 16): all six planes of all chunks would need 104 KB, so per chunk only what must SURVIVE the step is
+// private - planes {0, 1} (from the previous step) and {4, 5} (for the next one) in two alternating pairs - and the planes {2, 3}, which no later
+// stage reads, share one region W: 2 + 4 * 3 = 14 planes = 81 KB, two workgroups per CU (the lean kernel has three, without any overlap of loads
+// and MFMAs inside a workgroup).
+#include "conv3d_shared.h"
+
+using namespace bpxconv;
+
+namespace {
+
+#ifndef BPX_ZM_IMG_EARLY
+#define BPX_ZM_IMG_EARLY 1
+#endif
+
+#ifndef BPX_ZM_RH
+#define BPX_ZM_RH 4
+#endif
+constexpr int zm_occ(int nch) { return nch == 1 ? 3 : 2; }
+
+template <int NCH, int ACTK, bool F16>
+__global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3Params p) {
+  using T = typename std::conditional<F16, f16_t, uint16_t>::type;
+  constexpr int TZ = 4, TY = 8, TX = 16, MS = 8, KPL = 8, VB = 32, HY = TY + 2, HX = TX + 2;
+  constexpr int PLANE_B = HY * HX * VB;                              // 5760 bytes: one z-plane of a chunk's halo, 32 bytes per voxel
+  constexpr int PP = HY * HX * 2;                                     // 360 16-byte pieces per plane
+  constexpr int PL = PP - 256;                                        // 104 pieces of a plane beyond one per thread
+  static_assert(2 * PL <= 256, "a plane pair's left-over pieces fit one round");
+  constexpr int STEPS = 14, QPAD = 56, HSTR = HX * VB;
+  constexpr int RH = NCH == 1 ? BPX_ZM_RH : MS;                       // m-subtiles per fragment-row batch of the (dz, dy) steps
+  constexpr int PLANES = NCH == 1 ? 6 : 2 + 4 * NCH;
+  constexpr int RING_B = PLANES * PLANE_B;
+  // Weights.  A wave's VMEM operations retire IN ORDER through one counter: a weight fragment requested after the next stage's prefetch could only
+  // be waited for together with that prefetch (the first build did exactly that: `s_waitcnt vmcnt(1)` in front of the first MFMA drained the six
+  // prefetch loads, i.e. exposed the HBM latency the prefetch exists to hide).  So no weight load may follow the prefetch inside a stage:
+  //   NCH == 1: the conv's 14 KB of packed weights are LDS-resident for the whole run (lane-linear [step][lane][16 B] = the packed order itself);
+  //   NCH >  1: the stage's 14 fragments are requested into registers at the top of the stage, BEFORE the prefetch (56 VGPRs of the 256 that two
+  //             workgroups per CU leave).
+  constexpr int WLDS_B = NCH == 1 ? STEPS * 1024 : 0;
+  constexpr int RED_B = (NCH == 1 ? 2 : 1) * 4 * 16 * 2 * 4;           // statistics scratch [which][wave][16][2] floats (the pooled tensor's: NCH == 1 only)
+  constexpr int TAB_B = NCH * 16 * 8 + 128;                           // {scale, shift} of the column's sample, every input channel; + {bias sum, rank-1 weight} per output channel
+  constexpr int POOL_B = NCH == 1 ? 2 * (MS / 2) * 64 * 8 : 0;        // z-pair exchange of the fused max-pool as packed 16-bit values (the ring stays live across the epilogue)
+  constexpr int WOFF = RING_B, ROFF = WOFF + WLDS_B, TOFF = ROFF + RED_B, POFF = TOFF + TAB_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[POFF + POOL_B];      // ONE shared object (a second one costs vmcnt(0) waits before LDS reads)
+  float* const red = reinterpret_cast<float*>(smem + ROFF);
+  float* const tab = reinterpret_cast<float*>(smem + TOFF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W;
+  constexpr int Cout = 16;
+  const int cg_off = (g & 1) * 16;
+  const bool hi_tap = (g >> 1) != 0;
+  const uint32_t hb = (uint32_t)(j * VB + cg_off);                    // this lane's fragment row 0 inside a plane: voxel (row 0, x = j), channel half g & 1
+
+  // ---- staging constants: piece tid of a plane ("A"), and the pair's left-over piece ("L": plane selL of the pair, piece 256 + tid % 104) ----
+  const int sub = tid & 1;                                            // 104 is even: both pieces of a thread cover the same 8 channels of the chunk
+  const int hvA = tid >> 1, hyA = hvA / HX, hxA = hvA - hyA * HX;
+  const int selL = tid / PL, idxL = 256 + (tid - selL * PL), hvL = idxL >> 1, hyL = hvL / HX, hxL = hvL - hyL * HX;
+  const bool hasL = tid < 2 * PL;
+  const uint32_t HWB = (uint32_t)(H * W * p.x_ld) * 2u;                // bytes between z-planes of the input
+  uint32_t relA = (uint32_t)((hyA * W + hxA) * p.x_ld + sub * KPL) * 2u;
+  uint32_t relL = (uint32_t)((hyL * W + hxL) * p.x_ld + sub * KPL) * 2u + (hasL ? (uint32_t)selL * HWB : 0u);
+  asm volatile("" : "+v"(relA), "+v"(relL));
+  const uint32_t ldsA = (uint32_t)tid * 16u, ldsL = (uint32_t)idxL * 16u;
+  const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ wp = reinterpret_cast<const char*>(p.wp);
+  const uint32_t wlane = (uint32_t)((g * Cout + j) * KPL) * 2u;        // this lane's 16-byte operand inside a [4][Cout][8] k-group block
+  const uint32_t x_csb = (uint32_t)p.x_cs * 2u, sc_csb = (uint32_t)p.sc_cs * 2u;
+
+  // bias (+ shortcut bias) and the rank-1 shortcut weights: per-workgroup constants, parked in LDS (the epilogue reads its lane's four channels
+  // with two ds_read_b128: no registers held across the MFMA steps, no L2 latency per step)
+  const bool rank1 = p.sc != nullptr && p.sc_C == 1;
+  float* const ektab = tab + NCH * 16 * 2;                            // [16] bias sums, [16] rank-1 weights
+  if (tid < 16) {
+    float a = 0.f;
+    if (p.bias) a += p.bias[tid];
+    if (p.sc && p.bias_sc) a += p.bias_sc[tid];
+    ektab[tid] = a;
+    ektab[16 + tid] = rank1 ? reinterpret_cast<const float*>(p.wsc)[tid] : 0.f;
+  }
+  if constexpr (NCH == 1) {
+#pragma unroll
+    for (int q = tid; q < STEPS * 64; q += 256)
+      *reinterpret_cast<u32x4_t*>(smem + WOFF + q * 16) = *reinterpret_cast<const u32x4_t*>(wp + (uint32_t)q * 16u);
+  }
+  // (both visible to every wave after the first step's staging barrier)
+
+  // ---- this workgroup's run of z-steps: XCD x owns the id range [x T/8, (x+1) T/8), its workgroups consecutive pieces of it; ids enumerate
+  //      (column = (n, tile row, tile x), z-step) with the z-step fastest ------------------------------------------------------------------------
+  const int tilesZ = p.tilesZ, colsPerSample = p.tilesY * p.tilesX;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
+  const int T8 = p.tilesPerXcd;
+  int L0 = xcd * T8 + (int)(((long long)slot * T8) / spx), L1 = xcd * T8 + (int)(((long long)(slot + 1) * T8) / spx);
+  {
+    const int cap = min((xcd + 1) * T8, p.totalTiles);
+    L1 = min(L1, cap);
+  }
+  if (L0 >= L1) return;
+  int col = L0 / tilesZ, tzi = L0 - col * tilesZ;
+
+  // column state
+  int n = 0, y0 = 0, x0 = 0, tyi = 0, txi = 0;
+  uint32_t colb = 0;                       // byte offset of halo voxel (z = 0, y0 - 1, x0 - 1) of sample n (may wrap below zero: only in-volume pieces are dereferenced)
+  bool okA = false, okL = false;
+  int off = 0;                             // NCH == 1: ring offset;  NCH > 1: parity of the private plane pairs
+  bool newcol = true;
+
+  // prefetched pieces of the next stage's new planes: pair 0 = planes {2, 3}, pair 1 = planes {4, 5}; three pieces each (A of both planes, L)
+  u32x4_t pbuf[2][3];
+  uint32_t pmask = 0;
+
+  // slot base (bytes) of ring-relative plane q of chunk c in the CURRENT step
+  auto sbase = [&](int q, int c) -> uint32_t {
+    if constexpr (NCH == 1) {
+      int s = q + off;
+      s = s >= 6 ? s - 6 : s;
+      return (uint32_t)s * PLANE_B;
+    } else {
+      if (q == 2 || q == 3) return (uint32_t)(q - 2) * PLANE_B;
+      const int par = q < 2 ? off : (off ^ 1);
+      return (uint32_t)(2 + (c * 2 + par) * 2 + (q & 1)) * PLANE_B;
+    }
+  };
+
+  // request the three pieces of the plane pair whose first plane is volume slice z (z, z + 1), chunk c.  Out-of-volume pieces load the tensor's first
+  // 16 bytes instead of branching around the load (a branch per load costs the prefetch its batching) and are zeroed when they are stored.
+  auto load_pair = [&](u32x4_t* v, uint32_t& mask, int bit, int z, int c) {
+    const uint32_t cb = colb + (uint32_t)c * x_csb;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool ok = okA && (unsigned)(z + k) < (unsigned)D;
+      v[k] = *reinterpret_cast<const u32x4_t*>(xin + (ok ? cb + (uint32_t)(z + k) * HWB + relA : 0u));
+      mask |= ok ? 1u << (bit + k) : 0u;
+    }
+    const bool ok = okL && (unsigned)(z + selL) < (unsigned)D;
+    v[2] = *reinterpret_cast<const u32x4_t*>(xin + (ok ? cb + (uint32_t)z * HWB + relL : 0u));
+    mask |= ok ? 1u << (bit + 2) : 0u;
+  };
+
+  const bool has_norm = p.in_norm != nullptr;
+  // normalise + activate (in-volume pieces only: the zero padding applies to the ACTIVATED tensor) and write a pair's pieces to their plane slots
+  auto store_pair = [&](const u32x4_t* v, uint32_t mask, int bit, uint32_t s0, uint32_t s1, const float* psc, const float* psh) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k == 2 && !hasL) break;
+      u32x4_t t = v[k];
+      const bool in = (mask >> (bit + k)) & 1u;
+      if (!in) t = u32x4_t{0u, 0u, 0u, 0u};
+      if (has_norm && in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float a = fmaf(psc[2 * i], lo16<T>(t[i]), psh[2 * i]), b = fmaf(psc[2 * i + 1], hi16<T>(t[i]), psh[2 * i + 1]);
+          act_pair<ACTK>(a, b, p.act);
+          t[i] = pk16<T>(a, b);
+        }
+      }
+      const uint32_t dst = k == 0 ? s0 + ldsA : k == 1 ? s1 + ldsA : (selL ? s1 : s0) + ldsL;
+      *reinterpret_cast<u32x4_t*>(smem + dst) = t;
+    }
+  };
+  auto load_tab = [&](int c, float* psc, float* psh) {
+    if (!has_norm) return;
+    const f32x4_t* tp = reinterpret_cast<const f32x4_t*>(tab + (c * 16 + sub * KPL) * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4_t q = tp[i];
+      psc[2 * i] = q[0]; psh[2 * i] = q[1]; psc[2 * i + 1] = q[2]; psh[2 * i + 1] = q[3];
+    }
+  };
+
+  char* __restrict__ yout = reinterpret_cast<char*>(p.y);
+  const uint32_t yrow = (uint32_t)(W * p.y_ld) * 2u;
+
+  for (int L = L0; L < L1; ++L) {
+    if (newcol) {
+      n = col / colsPerSample;
+      const int r = col - n * colsPerSample;
+      tyi = r / p.tilesX; txi = r - tyi * p.tilesX;
+      y0 = tyi * TY; x0 = txi * TX;
+      colb = (uint32_t)(((n * D) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.x_ld * 2u;
+      okA = (unsigned)(y0 - 1 + hyA) < (unsigned)H && (unsigned)(x0 - 1 + hxA) < (unsigned)W;
+      okL = hasL && (unsigned)(y0 - 1 + hyL) < (unsigned)H && (unsigned)(x0 - 1 + hxL) < (unsigned)W;
+      off = 0;
+    }
+    const int z0 = tzi * TZ;
+    const bool more = (L + 1 < L1) && (tzi + 1 < tilesZ);             // the next step continues this column: its new planes can be prefetched
+
+    f32x4_t acc[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) acc[ms] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float img[MS];
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // NCH > 1: this stage's 14 weight fragments, requested before anything else of the stage (behind them in the VMEM queue: only the pieces
+      // prefetched during the previous stage, which the stage needs first anyway)
+      u32x4_t wall[NCH == 1 ? 1 : STEPS];
+      if constexpr (NCH > 1) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+          uint32_t so = (uint32_t)((c * QPAD + s * 4) * Cout * 16);
+          asm volatile("" : "+s"(so));                                 // opaque and scalar: (uniform pointer + SGPR) + this lane's 32-bit offset, not a hoisted 64-bit VGPR address per step
+          wall[s] = *reinterpret_cast<const u32x4_t*>(wp + so + wlane);
+        }
+      }
+      if (c > 0) __syncthreads();                                     // the shared planes {2, 3} of the previous chunk are no longer read
+      float psc[KPL], psh[KPL];
+      if (newcol) {
+        // ---- a run's first step in a column: all six planes, nothing prefetched (once per ~20-30 steps) ----
+        if (c == 0 && has_norm && tid < NCH * 16) {
+          const f32x2_t ss = *reinterpret_cast<const f32x2_t*>(&p.in_norm[(size_t)n * p.Cin + tid].scale);
+          *reinterpret_cast<f32x2_t*>(tab + tid * 2) = ss;
+        }
+        u32x4_t v0[3];
+        uint32_t m0 = 0;
+        pmask = 0;
+        load_pair(v0, m0, 0, z0 - 1, c);
+        load_pair(pbuf[0], pmask, 0, z0 + 1, c);
+        load_pair(pbuf[1], pmask, 3, z0 + 3, c);
+        if (c == 0 && has_norm) __syncthreads();                      // the table is visible
+        load_tab(c, psc, psh);
+        store_pair(v0, m0, 0, sbase(0, c), sbase(1, c), psc, psh);
+      } else {
+        load_tab(c, psc, psh);
+      }
+      store_pair(pbuf[0], pmask, 0, sbase(2, c), sbase(3, c), psc, psh);
+      store_pair(pbuf[1], pmask, 3, sbase(4, c), sbase(5, c), psc, psh);
+      __syncthreads();                                                // this stage's planes are in LDS
+      // ---- the next stage's new planes fly while this stage's MFMA steps run (nothing the MFMA steps wait for is requested after them) ----
+      pmask = 0;
+      if (!newcol && c + 1 < NCH) {
+        load_pair(pbuf[0], pmask, 0, z0 + 1, c + 1);
+        load_pair(pbuf[1], pmask, 3, z0 + 3, c + 1);
+      } else if (c + 1 == NCH && more) {
+        load_pair(pbuf[0], pmask, 0, z0 + TZ + 1, 0);
+        load_pair(pbuf[1], pmask, 3, z0 + TZ + 3, 0);
+      }
+      if (BPX_ZM_IMG_EARLY && c + 1 == NCH && rank1) {
+        const int vox0 = ((n * D + z0 + wave) * H + y0) * W + x0 + j;
+        const bool okzx = z0 + wave < D && x0 + j < W;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          img[ms] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + ((okzx && y0 + ms < H) ? (uint32_t)(vox0 + ms * W) * 4u : 0u));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- 14 MFMA steps on planes wave .. wave + 2 of the ring ----
+      const uint32_t pz[3] = {sbase(wave, c), sbase(wave + 1, c), sbase(wave + 2, c)};   // uniform
+      const uint32_t hb0 = hb + (hi_tap ? VB : 0), hb1 = hb + (hi_tap ? HX * VB : 0);
+      const uint32_t wl = WOFF + (uint32_t)lane * 16u;
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        // fragment rows ms + dy of plane dz: read once per plane and slid over the three dy steps (conv3d_lean.hip REUSE); RH m-subtiles at a time
+        const uint32_t b0 = pz[dz] + hb0;
+        u32x4_t w3[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+          w3[dy] = NCH == 1 ? *reinterpret_cast<const u32x4_t*>(smem + wl + (3 * dz + dy) * 1024) : wall[NCH == 1 ? 0 : 3 * dz + dy];
+#pragma unroll
+        for (int h = 0; h < MS; h += RH) {
+          u32x4_t row[RH + 2];
+#pragma unroll
+          for (int r = 0; r < RH + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(smem + b0 + (h + r) * HSTR);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ms = 0; ms < RH; ++ms) acc[h + ms] = mfma_step<T>(w3[dy], row[ms + dy], acc[h + ms]);
+        }
+      }
+#pragma unroll
+      for (int s = 9; s < STEPS; ++s) {
+        // steps 9-11: taps (dz, 0, 2) + (dz, 1, 2); step 12: taps (0, 2, 2) + (1, 2, 2); step 13: tap (2, 2, 2) alone
+        const uint32_t base = s < 12 ? pz[s < 12 ? s - 9 : 0] + hb1 : s == 12 ? (hi_tap ? pz[1] : pz[0]) + hb : pz[2] + hb;
+        const int imm = s < 12 ? 2 * VB : (2 * HX + 2) * VB;
+        const u32x4_t ws = NCH == 1 ? *reinterpret_cast<const u32x4_t*>(smem + wl + s * 1024) : wall[NCH == 1 ? 0 : s];
+        u32x4_t af[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + base + ms * HSTR + imm);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(ws, af[ms], acc[ms]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- fused 1x1x1 shortcut on a second raw tensor: extra K steps, operand straight from global memory (as the lean kernel) ----
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    const int vox0 = ((n * D + z0 + wave) * H + y0) * W + x0 + j;     // this lane's voxel for m-subtile 0
+    const bool okzx = full || (z0 + wave < D && x0 + j < W);
+    const int yrem = full ? (1 << 20) : H - y0;                        // m-subtile ms is inside the volume iff ms < yrem
+    if (p.sc != nullptr && p.sc_C >= 16) {
+      const char* __restrict__ scin = reinterpret_cast<const char*>(p.sc);
+      const char* __restrict__ wsc = reinterpret_cast<const char*>(p.wsc);
+      const uint32_t sb0 = (uint32_t)(vox0 * p.sc_ld) * 2u + (uint32_t)cg_off, srow = (uint32_t)(W * p.sc_ld) * 2u;
+      const int nch = p.sc_C / 16;
+      for (int chunk = 0; chunk < nch; ++chunk) {
+        u32x4_t bq[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+          bq[ms] = u32x4_t{0u, 0u, 0u, 0u};
+          if (okzx && ms < yrem) bq[ms] = *reinterpret_cast<const u32x4_t*>(scin + (sb0 + ms * srow + (uint32_t)chunk * sc_csb));
+        }
+        const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wsc + (size_t)chunk * 4 * Cout * 16 + wlane);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(wf, bq[ms], acc[ms]);
+      }
+    }
+
+    // ---- epilogue (the lean kernel's, one output-channel group): bias / rank-1 shortcut, statistics, one 8-byte store per m-subtile ----
+    const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u;
+    if (!(BPX_ZM_IMG_EARLY) || !rank1) {
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+        img[ms] = (rank1 && okzx && ms < yrem) ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + (uint32_t)(vox0 + ms * W) * 4u) : 0.f;
+    }
+    const f32x4_t addk = *reinterpret_cast<const f32x4_t*>(ektab + g * 4), w1k = *reinterpret_cast<const f32x4_t*>(ektab + 16 + g * 4);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) + lgkmcnt(0) here, outside the predicated row blocks (conv3d_lean.hip: stores must not wait for stores)
+    auto flush_stats = [&](const float* s1, const float* s2, int which) {
+      if ((which ? (float*)p.pool_part : p.part) == nullptr) return;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
+        if (j == 0) *reinterpret_cast<f32x2_t*>(&red[which * 4 * 16 * 2 + (wave * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+      }
+    };
+    {
+      const int co = g * 4;
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      u32x2_t pk[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) {
+        pk[ms] = u32x2_t{0u, 0u};
+        if (okzx && ms < yrem) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[ms][r] + addk[r] + img[ms] * w1k[r];
+            s1[r] += v[r];
+            s2[r] += v[r] * v[r];
+          }
+          pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
+          *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
+        }
+      }
+      if constexpr (NCH == 1) {
+        if (p.pool != nullptr) {
+          // fused MaxPool3d (pool_sz, 2, 2): y pairs = two m-subtiles of this lane, x pairs = lanes j / j^1 (DPP), z pairs = waves w / w + 1 (LDS)
+          float m[MS / 2][4];
+#pragma unroll
+          for (int k = 0; k < MS / 2; ++k) {
+            const u32x2_t a = pk[2 * k], b = pk[2 * k + 1];
+            m[k][0] = fmaxf(lo16<T>(a[0]), lo16<T>(b[0])); m[k][1] = fmaxf(hi16<T>(a[0]), hi16<T>(b[0]));
+            m[k][2] = fmaxf(lo16<T>(a[1]), lo16<T>(b[1])); m[k][3] = fmaxf(hi16<T>(a[1]), hi16<T>(b[1]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              m[k][r] = fmaxf(m[k][r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[k][r]), 0xB1, 0xF, 0xF, true)));
+          }
+          if (p.pool_sz == 2) {
+            // [wave pair][k][lane], as packed 16-bit pairs: every m is a maximum of stored 16-bit values, so the round trip is exact.  The region
+            // is this exchange's alone and was last read before the previous step's closing barrier.
+            u32x2_t* ex = reinterpret_cast<u32x2_t*>(smem + POFF);
+            if (wave & 1) {
+#pragma unroll
+              for (int k = 0; k < MS / 2; ++k) ex[((wave >> 1) * (MS / 2) + k) * 64 + lane] = u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
+            }
+            __syncthreads();
+            if (!(wave & 1)) {
+#pragma unroll
+              for (int k = 0; k < MS / 2; ++k) {
+                const u32x2_t o = ex[((wave >> 1) * (MS / 2) + k) * 64 + lane];
+                m[k][0] = fmaxf(m[k][0], lo16<T>(o[0])); m[k][1] = fmaxf(m[k][1], hi16<T>(o[0]));
+                m[k][2] = fmaxf(m[k][2], lo16<T>(o[1])); m[k][3] = fmaxf(m[k][3], hi16<T>(o[1]));
+              }
+            }
+          }
+          float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+          if ((p.pool_sz == 1 || !(wave & 1)) && !(j & 1) && z0 + wave < D && x0 + j < W) {
+            const int Dp = D / p.pool_sz, Hp = H >> 1, Wp = W >> 1;
+            const int pz = (z0 + wave) / p.pool_sz, px = (x0 + j) >> 1;
+            char* __restrict__ pout = reinterpret_cast<char*>(p.pool);
+#pragma unroll
+            for (int k = 0; k < MS / 2; ++k) {
+              if (y0 + 2 * k < H) {
+                const int py = (y0 >> 1) + k;
+                *reinterpret_cast<u32x2_t*>(pout + (uint32_t)((((n * Dp + pz) * Hp + py) * Wp + px) * p.pool_ld + co) * 2u) =
+                    u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q1[r] += m[k][r]; q2[r] += m[k][r] * m[k][r]; }
+              }
+            }
+          }
+          flush_stats(q1, q2, 1);
+        }
+      }
+      flush_stats(s1, s2, 0);
+    }
+
+    // ---- closing barrier of the step: every wave is done with the ring's four oldest planes AND the statistics scratch is complete ----
+    __syncthreads();
+    if (p.part != nullptr || p.pool_part != nullptr) {
+      if (tid < 2 * 16 * 2) {
+        const int which = tid >> 5, q = tid & 31;
+        const int ch = q >> 1, k = q & 1;
+        float* dst = which ? p.pool_part : p.part;
+        if (dst != nullptr) {
+          const float* rd = red + which * 4 * 16 * 2;
+          const float a = rd[(0 * 16 + ch) * 2 + k] + rd[(1 * 16 + ch) * 2 + k] + rd[(2 * 16 + ch) * 2 + k] + rd[(3 * 16 + ch) * 2 + k];
+          const int tile = (tzi * p.tilesY + tyi) * p.tilesX + txi;
+          dst[(((size_t)n * p.tilesPerSample + tile) * 2 + k) * Cout + ch] = a;
+        }
+      }
+    }
+
+    // ---- advance ----
+    if constexpr (NCH == 1) { off += 4; off = off >= 6 ? off - 6 : off; } else { off ^= 1; }
+    newcol = false;
+    if (++tzi == tilesZ) { tzi = 0; ++col; newcol = true; }
+  }
+}
+
+int g_zm_mode = -1;   // -1: from the environment (BPX_CONV_ZM, default 1); 0 off; 1 on where it applies; 2 on even for short runs (tests)
+int g_zm_wgs = 0;     // tests: cap on the number of workgroups (long runs that cross columns on small volumes); 0 = none
+int g_zm_launches = 0;
+
+}  // namespace
+
+extern "C" int bpx_debug_conv_zm_launches(void) { return g_zm_launches; }
+extern "C" int bpx_debug_set_conv_zm(int mode) {
+  g_zm_mode = mode < 0 ? -1 : (mode & 0xFF);
+  g_zm_wgs = mode < 0 ? 0 : (mode >> 8);
+  return 0;
+}
+
+namespace bpxconv {
+
+static int zm_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return n;
+}
+
+// 0 = launched; 1 = not applicable (the caller takes the lean kernel)
+int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
+  int mode = g_zm_mode;
+  if (mode < 0) { static const char* e = getenv("BPX_CONV_ZM"); mode = e ? atoi(e) : 1; }
+  if (mode == 0) return 1;
+  if (!(c.tz == 4 && c.ty == 8 && c.tx == 16 && c.ns == 1) || p0.Cout != 16 || p0.ps > 1) return 1;
+  if (!(p0.Cin == 16 || p0.Cin == 48)) return 1;
+  if (p0.pool != nullptr && p0.Cin != 16) return 1;                    // the fused pool lives in the one-chunk instance only
+  if (p0.in_norm && p0.act > BPX_ACT_SILU) return 1;
+  Conv3Params p = p0;
+  p.tilesZ = cdiv(p.D, c.tz);
+  p.tilesY = cdiv(p.H, c.ty);
+  p.tilesX = cdiv(p.W, c.tx);
+  p.tilesPerSample = p.tilesZ * p.tilesY * p.tilesX;
+  p.totalTiles = p.N * p.tilesPerSample;
+  p.tilesPerXcd = cdiv(p.totalTiles, 8);
+  p.stamps = nullptr;
+  p.dbg = 0;
+  const int nch = p.Cin / 16;
+  const int occ = zm_occ(nch);
+  int gx = std::max(8, (zm_cu_count() * occ) & ~7);
+  if (g_zm_wgs > 0) gx = std::max(8, std::min(gx, g_zm_wgs & ~7));
+  gx = std::min(gx, 8 * p.tilesPerXcd);
+  // the ring pays off over runs of several z-steps; short runs (small volumes) stay on the lean kernel.  Both kernels give the same bits, so
+  // the choice may depend on the batch size.
+  if (mode == 1 && (p.totalTiles < 4 * gx || p.tilesZ < 4)) return 1;
+  const bool elu = p.act == BPX_ACT_ELU;
+  dim3 grid((unsigned)gx, 1);
+#define Z(NCH)                                                                         \
+  if (nch == NCH) {                                                                    \
+    ++g_zm_launches;                                                                   \
+    if (p.f16) {                                                                       \
+      if (elu) conv3_zm_kernel<NCH, 1, true><<<grid, 256, 0, s>>>(p);                  \
+      else conv3_zm_kernel<NCH, 0, true><<<grid, 256, 0, s>>>(p);                      \
+    } else {                                                                           \
+      if (elu) conv3_zm_kernel<NCH, 1, false><<<grid, 256, 0, s>>>(p);                 \
+      else conv3_zm_kernel<NCH, 0, false><<<grid, 256, 0, s>>>(p);                     \
+    }                                                                                  \
+    return 0;                                                                          \
+  }
+  Z(1) Z(3)
+#undef Z
+  return 1;
+}
+
+}  // namespace bpxconv

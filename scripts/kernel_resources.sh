@@ -4,7 +4,7 @@
 # of a shared kernel template can silently cost another instance a wave per SIMD (round 3: a persistent loop added for the transposed-conv
 # forward took the 48-column 1x1x1 GEMM of the same template from 130 to 170 VGPRs and from 402 to 598 us).
 cd "$(dirname "$0")/../biapy_amd/csrc"
-for F in tiling conv3d_igemm conv3d_lean wgrad bwd_fused pointwise elementwise prepost; do
+for F in tiling conv3d_igemm conv3d_lean conv3d_zmarch wgrad bwd_fused pointwise elementwise prepost; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fPIC -c $F.hip -o /tmp/kres_$F.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur=None; rows=[]

@@ -39,10 +39,10 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--only", type=int, default=-1, help="index into the layer table")
+    ap.add_argument("--only", default="-1", help="index (or comma-separated indices) into the layer table")
     a = ap.parse_args()
-    dt = L.BF16 if a.dtype == "bf16" else L.F32
-    T = torch.bfloat16 if dt == L.BF16 else torch.float32
+    dt = {"bf16": L.BF16, "f16": L.F16}.get(a.dtype, L.F32)       # f16: the forward half of the benched mixed mode
+    T = {L.BF16: torch.bfloat16, L.F16: torch.float16}.get(dt, torch.float32)
     B = int(os.environ.get("BPX_BENCH_B", "4"))
     st = L.stream_ptr()
     if os.environ.get('BPX_WS') is not None:
@@ -56,10 +56,14 @@ def main():
         L.check(lib.bpx_pack_weight(mode, w.data_ptr(), cin, cout, dt, out.data_ptr(), st))
         return out
 
-    layers = FWD_LAYERS if a.only < 0 else [FWD_LAYERS[a.only]]
+    only = [int(v) for v in str(a.only).split(",")]
+    layers = FWD_LAYERS if only[0] < 0 else [FWD_LAYERS[k] for k in only]
     if a.what in ("conv_fwd", "all"):
         for (S, cin, cout, csc) in layers:
             x = torch.randn(B, S, S, S, cin, device=DEV).to(T)
+            planar = os.environ.get("BPX_BENCH_PLANAR", "1") != "0" and dt != L.F32      # the decoder's concat tensors are chunk-planar in the network
+            if planar and cin in (48, 96, 192, 384):
+                x = L.Planar(B, (S, S, S), cin, T, DEV).copy_from_dense(x)
             y = torch.empty(B, S, S, S, cout, device=DEV, dtype=T)
             w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05
             wp = pack(w, L.PK_K3, cin, cout)
@@ -73,6 +77,8 @@ def main():
                 sct, wscp, keep = L.Tensor(img.data_ptr(), 1, 1), wsc.data_ptr(), [img, wsc]
             elif csc:
                 sc = torch.randn(B, S, S, S, csc, device=DEV).to(T)
+                if planar and csc in (48, 96, 192, 384):
+                    sc = L.Planar(B, (S, S, S), csc, T, DEV).copy_from_dense(sc)
                 wk = pack(torch.randn(cout, csc, 1, 1, 1, device=DEV), L.PK_K1, csc, cout)
                 sct, wscp, keep = L.tview(sc), wk.data_ptr(), [sc, wk]
             recp = None if os.environ.get('BPX_NO_NORM') else rec.data_ptr()   # ablation: skip the fused normalise+ELU prologue
@@ -80,7 +86,7 @@ def main():
                                                    bias.data_ptr() if csc else None, L.tview(y), part.data_ptr(), st))
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * (27 * cin + csc) * cout
-            by = B * S ** 3 * (cin + cout + csc) * x.element_size()
+            by = B * S ** 3 * (cin + cout + csc) * y.element_size()
             print(f"conv_fwd  {S:4d}^3 {cin:4d}->{cout:4d} sc={csc:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s  {by / ms / 1e6:8.1f} GB/s(alg)")
     if a.what in ("conv_dgrad", "all"):
         for (S, cin, cout, csc) in layers:
@@ -150,6 +156,8 @@ def main():
                 sct, wscp, keep = L.Tensor(img.data_ptr(), 1, 1), wsc.data_ptr(), [img, wsc]
             elif csc:
                 sc = torch.randn(B, S, S, S, csc, device=DEV).to(T)
+                if planar and csc in (48, 96, 192, 384):
+                    sc = L.Planar(B, (S, S, S), csc, T, DEV).copy_from_dense(sc)
                 wk = pack(torch.randn(cout, csc, 1, 1, 1, device=DEV), L.PK_K1, csc, cout)
                 sct, wscp, keep = L.tview(sc), wk.data_ptr(), [sc, wk]
 

@@ -321,6 +321,64 @@ def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=
     return res
 
 
+def check_conv3d_zmarch(f16, B, S, Cin, sc_C=0, pool=0, planar=False, norm=True, act=1, wgs=0, seed=0):
+    """The z-marching forward kernel (conv3d_zmarch.hip, round 5) against the lean kernel it replaces on the same operands: the output, the
+    statistics partial sums and the fused pool's tensor + sums must be BIT-IDENTICAL (same MFMAs in the same order, same reduction order) - so
+    the lean kernel's own parity rows carry over and the choice between the two may depend on the batch size.  wgs: cap on the z-march
+    workgroups, so that a run covers many z-steps and crosses columns on a small volume.  planar: x (and a 16+-channel shortcut operand) as
+    chunk-planar buffers, as the decoder's concat tensors are."""
+    dt = L.F16 if f16 else L.BF16
+    T = tdtype(dt)
+    D, H, W = S
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    w = torch.randn(16, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    bias = (torch.randn(16, generator=g) * 0.1).to(DEV)
+    rec = make_recs(B, Cin, seed + 1)[0].to(DEV) if norm else None
+    wp = pack(w, L.PK_K3, Cin, 16, dt)
+    xd = to_dev(x, dt)
+    xin = L.Planar(B, S, Cin, T, DEV).copy_from_dense(xd) if planar else xd
+    sct, wscp, bscd, keep = L.NULL_T, None, None, []
+    if sc_C == 1:
+        img = torch.randn(B, D, H, W, generator=g).to(DEV).contiguous(); wsc = torch.randn(16, generator=g).to(DEV); bscd = (torch.randn(16, generator=g) * 0.1).to(DEV)
+        sct, wscp, keep = L.Tensor(img.data_ptr(), 1, 1), wsc.data_ptr(), [img, wsc]
+    elif sc_C:
+        scd = to_dev(rnd(torch.randn(B, D, H, W, sc_C, generator=g), dt), dt)
+        scin = L.Planar(B, S, sc_C, T, DEV).copy_from_dense(scd) if planar else scd
+        wk = pack(torch.randn(16, sc_C, 1, 1, 1, generator=g) / sc_C ** 0.5, L.PK_K1, sc_C, 16, dt); bscd = (torch.randn(16, generator=g) * 0.1).to(DEV)
+        sct, wscp, keep = L.tview(scin), wk.data_ptr(), [scin, wk]
+    tiles = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, 16)
+    outs = []
+    n_zm = []
+    for mode in (0, 2 | (wgs << 8)):
+        lib.bpx_debug_set_conv_zm(mode)
+        n_zm.append(lib.bpx_debug_conv_zm_launches())
+        try:
+            y = torch.full((B, D, H, W, 16), 7.0, dtype=T, device=DEV)
+            part = torch.zeros(B, tiles, 2, 16, device=DEV)
+            if pool:
+                Dp = D // pool
+                pooled = torch.full((B, Dp, H // 2, W // 2, 16), 7.0, dtype=T, device=DEV)
+                ppart = torch.zeros(B, tiles, 2, 16, device=DEV)
+                L.check(lib.bpx_conv3d_fwd_pool(dt, B, D, H, W, L.tview(xin), L.ptr(rec), act if norm else 0, wp.data_ptr(), bias.data_ptr(), sct, wscp,
+                                                L.ptr(bscd), L.tview(y), part.data_ptr(), pool, L.tview(pooled), ppart.data_ptr(), L.stream_ptr()))
+                outs.append((y, part, pooled, ppart))
+            else:
+                L.check(lib.bpx_conv3d_fwd(dt, B, D, H, W, L.tview(xin), L.ptr(rec), act if norm else 0, wp.data_ptr(), bias.data_ptr(), sct, wscp, L.ptr(bscd),
+                                           L.tview(y), part.data_ptr(), L.stream_ptr()))
+                outs.append((y, part))
+            torch.cuda.synchronize()
+        finally:
+            lib.bpx_debug_set_conv_zm(-1)
+    tag = f"conv3d_zmarch[{'f16' if f16 else 'bf16'} B{B} {S} {Cin}->16 sc={sc_C} pool={pool} planar={int(planar)} norm={int(norm)} act={act} wgs={wgs}]"
+    res = []
+    for name, a, b in zip(("y", "stats", "pooled", "pool_stats"), outs[0], outs[1]):
+        res.append(_res(f"{tag}.{name}_bits_equal_lean", float((a.contiguous().view(torch.uint8) != b.contiguous().view(torch.uint8)).sum()), 0))
+    res.append(_res(tag + ".wrote_something", 0 if float((outs[1][0].float() != 7).float().mean()) > 0.99 else 1, 0))
+    res.append(_res(tag + ".zmarch_kernel_ran_in_the_second_call_only", 0 if (n_zm[1] == n_zm[0] and lib.bpx_debug_conv_zm_launches() == n_zm[1] + 1) else 1, 0))
+    return res
+
+
 def check_conv3d_fwd_pool(B, S, Cin, Cout, sz, seed=0):
     """bpx_conv3d_fwd_pool (MaxPool3d fused into the lean kernel's epilogue) == bpx_conv3d_fwd followed by bpx_maxpool3d_fwd:
     the same bf16 output bits, the same pooled bits, the same statistics partial sums."""

@@ -133,6 +133,28 @@ def test_conv3d_bf16_kernel_variants(K, variant):
     _assert_all(rows)
 
 
+def test_conv3d_zmarch_kernel_is_bit_identical_to_the_lean_kernel(K):
+    """Round 5: the z-marching forward kernel of the 16-output-channel layers - one and three input chunks, rank-1 / 48-channel
+    shortcut operands, fused pooling, chunk-planar operands, ragged volumes, batches, fp16 and bf16 storage, run-time activation, runs that cross
+    column and sample boundaries - gives the lean kernel's bits."""
+    rows = []
+    rows += K.check_conv3d_zmarch(True, 2, (32, 32, 32), 16)
+    rows += K.check_conv3d_zmarch(False, 2, (32, 32, 32), 16, sc_C=1, wgs=8)
+    rows += K.check_conv3d_zmarch(True, 1, (36, 40, 48), 48, planar=True)
+    rows += K.check_conv3d_zmarch(True, 3, (33, 41, 49), 16, sc_C=1)                     # one voxel past the tile on every axis, batch 3
+    rows += K.check_conv3d_zmarch(False, 2, (28, 36, 40), 48, wgs=8)                     # ragged, three chunks, long runs
+    rows += K.check_conv3d_zmarch(True, 1, (32, 32, 32), 16, sc_C=48, planar=True)
+    rows += K.check_conv3d_zmarch(True, 2, (64, 32, 48), 16, sc_C=48, wgs=16)
+    rows += K.check_conv3d_zmarch(True, 1, (64, 64, 64), 16, sc_C=1, pool=2)              # the encoder's second conv: image shortcut + fused pool
+    rows += K.check_conv3d_zmarch(False, 2, (32, 72, 120), 16, pool=1, wgs=24)            # anisotropic level (no z pooling), partial tiles
+    rows += K.check_conv3d_zmarch(True, 1, (68, 66, 70), 16, sc_C=1, pool=2, wgs=8)       # ragged in every axis
+    rows += K.check_conv3d_zmarch(True, 2, (40, 24, 48), 16, norm=False)                  # raw input (no prologue)
+    rows += K.check_conv3d_zmarch(True, 2, (40, 24, 48), 48, act=3, wgs=16)               # run-time activation (SiLU)
+    rows += K.check_conv3d_zmarch(True, 4, (64, 64, 64), 48, planar=True)                 # production-like: default grid
+    rows += K.check_conv3d_zmarch(True, 4, (64, 64, 64), 16, sc_C=48, planar=True)
+    _assert_all(rows)
+
+
 def test_conv3d_fused_maxpool_is_bit_identical(K):
     rows = []
     rows += K.check_conv3d_fwd_pool(1, (64, 64, 64), 16, 16, 2)          # big tile, z pairs through LDS
