@@ -69,6 +69,11 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
   const bool hi_tap = (g >> 1) != 0;
   const uint32_t hb = (uint32_t)(j * VB + cg_off);                    // this lane's fragment row 0 inside a plane: voxel (row 0, x = j), channel half g & 1
 
+  // profiling: cycle stamps of this workgroup's 5th step (steady state: ring and prefetch running), scripts/zm_stamps.py
+  long long* stamps = (p.stamps && tid == 0) ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  int stamp_i = 0, it = 0;
+#define ZM_STAMP() do { if (stamps && it == 4 && stamp_i < 15) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+
   // ---- staging constants: piece tid of a plane ("A"), and the pair's left-over piece ("L": plane selL of the pair, piece 256 + tid % 104) ----
   const int sub = tid & 1;                                            // 104 is even: both pieces of a thread cover the same 8 channels of the chunk
   const int hvA = tid >> 1, hyA = hvA / HX, hxA = hvA - hyA * HX;
@@ -199,6 +204,7 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
       okL = hasL && (unsigned)(y0 - 1 + hyL) < (unsigned)H && (unsigned)(x0 - 1 + hxL) < (unsigned)W;
       off = 0;
     }
+    ZM_STAMP();   // 0: step start
     const int z0 = tzi * TZ;
     const bool more = (L + 1 < L1) && (tzi + 1 < tilesZ);             // the next step continues this column: its new planes can be prefetched
 
@@ -242,7 +248,9 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
       }
       store_pair(pbuf[0], pmask, 0, sbase(2, c), sbase(3, c), psc, psh);
       store_pair(pbuf[1], pmask, 3, sbase(4, c), sbase(5, c), psc, psh);
+      if (c == 0) ZM_STAMP();   // 1: chunk 0 transformed and written
       __syncthreads();                                                // this stage's planes are in LDS
+      if (c == 0) ZM_STAMP();   // 2: barrier
       // ---- the next stage's new planes fly while this stage's MFMA steps run (nothing the MFMA steps wait for is requested after them) ----
       pmask = 0;
       if (!newcol && c + 1 < NCH) {
@@ -260,6 +268,7 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
           img[ms] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + ((okzx && y0 + ms < H) ? (uint32_t)(vox0 + ms * W) * 4u : 0u));
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (c == 0) ZM_STAMP();   // 3: prefetch requested
 
       // ---- 14 MFMA steps on planes wave .. wave + 2 of the ring ----
       const uint32_t pz[3] = {sbase(wave, c), sbase(wave + 1, c), sbase(wave + 2, c)};   // uniform
@@ -299,8 +308,10 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
         for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(ws, af[ms], acc[ms]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (c == 0) ZM_STAMP();   // 4: chunk 0 MFMA steps
     }
     __builtin_amdgcn_sched_barrier(0);
+    ZM_STAMP();   // 5: all chunks
 
     // ---- fused 1x1x1 shortcut on a second raw tensor: extra K steps, operand straight from global memory (as the lean kernel) ----
     const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
@@ -325,6 +336,7 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
       }
     }
 
+    ZM_STAMP();   // 6: wide shortcut
     // ---- epilogue (the lean kernel's, one output-channel group): bias / rank-1 shortcut, statistics, one 8-byte store per m-subtile ----
     const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u;
     if (!(BPX_ZM_IMG_EARLY) || !rank1) {
@@ -414,8 +426,10 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
       flush_stats(s1, s2, 0);
     }
 
+    ZM_STAMP();   // 7: epilogue (stores issued, statistics in LDS)
     // ---- closing barrier of the step: every wave is done with the ring's four oldest planes AND the statistics scratch is complete ----
     __syncthreads();
+    ZM_STAMP();   // 8: closing barrier
     if (p.part != nullptr || p.pool_part != nullptr) {
       if (tid < 2 * 16 * 2) {
         const int which = tid >> 5, q = tid & 31;
@@ -430,6 +444,8 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
       }
     }
 
+    ZM_STAMP();   // 9: statistics row stored
+    ++it;
     // ---- advance ----
     if constexpr (NCH == 1) { off += 4; off = off >= 6 ? off - 6 : off; } else { off ^= 1; }
     newcol = false;
@@ -468,6 +484,12 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   if (mode == 0) return 1;
   if (!(c.tz == 4 && c.ty == 8 && c.tx == 16 && c.ns == 1) || p0.Cout != 16 || p0.ps > 1) return 1;
   if (!(p0.Cin == 16 || p0.Cin == 48)) return 1;
+  {   // A/B aid: BPX_CONV_ZM_MASK bit 0 = one chunk without a wide shortcut, bit 1 = one chunk + shortcut of >= 16 channels, bit 2 = three chunks
+    static const char* e = getenv("BPX_CONV_ZM_MASK");
+    static const int mask = e ? atoi(e) : 7;
+    const int kind = p0.Cin == 48 ? 4 : (p0.sc != nullptr && p0.sc_C >= 16) ? 2 : 1;
+    if (!(mask & kind)) return 1;
+  }
   if (p0.pool != nullptr && p0.Cin != 16) return 1;                    // the fused pool lives in the one-chunk instance only
   if (p0.in_norm && p0.act > BPX_ACT_SILU) return 1;
   Conv3Params p = p0;
@@ -477,7 +499,7 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.tilesPerSample = p.tilesZ * p.tilesY * p.tilesX;
   p.totalTiles = p.N * p.tilesPerSample;
   p.tilesPerXcd = cdiv(p.totalTiles, 8);
-  p.stamps = nullptr;
+  p.stamps = g_conv_stamps;
   p.dbg = 0;
   const int nch = p.Cin / 16;
   const int occ = zm_occ(nch);
