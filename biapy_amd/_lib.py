@@ -45,6 +45,7 @@ _SIGS = {
     "bpx_debug_set_conv_occ": ([_i], _i),
     "bpx_debug_set_conv_zm": ([_i], _i),
     "bpx_debug_conv_zm_launches": ([], _i),
+    "bpx_debug_conv_zm_occupancy": ([_i], _i),
     "bpx_crop3d_gather": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _i64, _i64, _vp, _vp], _i),
     "bpx_merge3d_blend": ([_vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(AxisGrid), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i,
                            _vp, _vp, _i, _vp, _i, _vp], _i),

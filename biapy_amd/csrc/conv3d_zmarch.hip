@@ -31,6 +31,9 @@ namespace {
 #ifndef BPX_ZM_RH
 #define BPX_ZM_RH 4
 #endif
+#ifndef BPX_ZM_ST16
+#define BPX_ZM_ST16 0
+#endif
 constexpr int zm_occ(int nch) { return nch == 1 ? 3 : 2; }
 
 template <int NCH, int ACTK, bool F16>
@@ -54,7 +57,10 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
   constexpr int WLDS_B = NCH == 1 ? STEPS * 1024 : 0;
   constexpr int RED_B = (NCH == 1 ? 2 : 1) * 4 * 16 * 2 * 4;           // statistics scratch [which][wave][16][2] floats (the pooled tensor's: NCH == 1 only)
   constexpr int TAB_B = NCH * 16 * 8 + 128;                           // {scale, shift} of the column's sample, every input channel; + {bias sum, rank-1 weight} per output channel
-  constexpr int POOL_B = NCH == 1 ? 2 * (MS / 2) * 64 * 8 : 0;        // z-pair exchange of the fused max-pool as packed 16-bit values (the ring stays live across the epilogue)
+  // z-pair exchange of the fused max-pool: packed 16-bit values of the even-x lanes only (after the x-pair maximum lanes j and j ^ 1 hold the same
+  // value) = 2 KB.  Every byte counts here: LDS is granted in 2 KB granules, three workgroups per CU need <= 53,248 bytes each, and the first build
+  // (54,272) silently ran TWO per CU - found with the workgroup-count sweep of profiles/r05_zmarch_ab.txt, not by the compiler's occupancy remark
+  constexpr int POOL_B = NCH == 1 ? 2 * (MS / 2) * 32 * 8 : 0;
   constexpr int WOFF = RING_B, ROFF = WOFF + WLDS_B, TOFF = ROFF + RED_B, POFF = TOFF + TAB_B;
   __shared__ __attribute__((aligned(16))) unsigned char smem[POFF + POOL_B];      // ONE shared object (a second one costs vmcnt(0) waits before LDS reads)
   float* const red = reinterpret_cast<float*>(smem + ROFF);
@@ -70,9 +76,15 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
   const uint32_t hb = (uint32_t)(j * VB + cg_off);                    // this lane's fragment row 0 inside a plane: voxel (row 0, x = j), channel half g & 1
 
   // profiling: cycle stamps of this workgroup's 5th step (steady state: ring and prefetch running), scripts/zm_stamps.py
+#ifdef BPX_ZM_STAMPS   // profiling build only (bash scripts/ab_build_flags.sh zmstamps -DBPX_ZM_STAMPS): the bookkeeping costs the production kernel registers it does not have
   long long* stamps = (p.stamps && tid == 0) ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
   int stamp_i = 0, it = 0;
 #define ZM_STAMP() do { if (stamps && it == 4 && stamp_i < 15) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define ZM_STEP_DONE() ++it
+#else
+#define ZM_STAMP() do { } while (0)
+#define ZM_STEP_DONE() do { } while (0)
+#endif
 
   // ---- staging constants: piece tid of a plane ("A"), and the pair's left-over piece ("L": plane selL of the pair, piece 256 + tid % 104) ----
   const int sub = tid & 1;                                            // 104 is even: both pieces of a thread cover the same 8 channels of the chunk
@@ -246,6 +258,9 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
       } else {
         load_tab(c, psc, psh);
       }
+#ifdef BPX_ZM_SPLIT    // profiling build: an explicit wait for the prefetched pieces (the BPX_ZM_SPLIT stores issued after them may stay outstanding) + a stamp
+      if (c == 0) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPX_ZM_SPLIT) : "memory"); ZM_STAMP(); }
+#endif
       store_pair(pbuf[0], pmask, 0, sbase(2, c), sbase(3, c), psc, psh);
       store_pair(pbuf[1], pmask, 3, sbase(4, c), sbase(5, c), psc, psh);
       if (c == 0) ZM_STAMP();   // 1: chunk 0 transformed and written
@@ -261,6 +276,9 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
         load_pair(pbuf[1], pmask, 3, z0 + TZ + 3, 0);
       }
       if (BPX_ZM_IMG_EARLY && c + 1 == NCH && rank1) {
+        // rank-1 shortcut: the image value of this lane's eight voxels, requested behind the prefetch (8 VGPRs across the MFMA steps).  Measured and
+        // dropped (profiles/r05_zmarch_ab.txt): two requests per lane handed round with v_permlane16/32_swap - the same time, and in combination with
+        // the 16-byte stores below a few rows came out wrong, differently from run to run (an unexplained permlane hazard: scripts/probes/zm_diff.py)
         const int vox0 = ((n * D + z0 + wave) * H + y0) * W + x0 + j;
         const bool okzx = z0 + wave < D && x0 + j < W;
 #pragma unroll
@@ -370,7 +388,21 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
             s2[r] += v[r] * v[r];
           }
           pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
-          *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
+          if (!BPX_ZM_ST16) *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
+        }
+      }
+      if (BPX_ZM_ST16) {
+        // 16-byte stores.  Lanes (j, g) and (j, g ^ 1) - 16 lanes apart - hold the two 8-byte halves of the same 16 bytes of voxel (ms, j).
+        // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second: with (first, second) = the packed
+        // values of m-subtiles (2k, 2k + 1), the even-g lanes end up with 16 contiguous bytes of row 2k ([own | partner's]) and the odd-g lanes with
+        // 16 bytes of row 2k + 1 ([partner's | own]): 4 stores per lane instead of 8, same bytes, same addresses.  Bit-identical on its own, and
+        // MEASURED FLAT (profiles/r05_zmarch_ab.txt: 236.0 / 385.2 / 625.9 us with it, 235.2 / 383.6 / 627.8 without): off by default.
+        const uint32_t yb16 = (uint32_t)(vox0 * p.y_ld + (g & ~1) * 4) * 2u + (uint32_t)(g & 1) * yrow;
+#pragma unroll
+        for (int k = 0; k < MS / 2; ++k) {
+          const u32x2_t a = pk[2 * k], b = pk[2 * k + 1];
+          const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+          if (okzx && 2 * k + (g & 1) < yrem) *reinterpret_cast<u32x4_t*>(yout + (yb16 + 2 * k * yrow)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
         }
       }
       if constexpr (NCH == 1) {
@@ -387,18 +419,18 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
               m[k][r] = fmaxf(m[k][r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[k][r]), 0xB1, 0xF, 0xF, true)));
           }
           if (p.pool_sz == 2) {
-            // [wave pair][k][lane], as packed 16-bit pairs: every m is a maximum of stored 16-bit values, so the round trip is exact.  The region
-            // is this exchange's alone and was last read before the previous step's closing barrier.
+            // [wave pair][k][lane / 2], as packed 16-bit pairs: every m is a maximum of stored 16-bit values, so the round trip is exact; lanes j and
+            // j ^ 1 write the same value to the same slot.  The region is this exchange's alone and was last read before the previous step's closing barrier.
             u32x2_t* ex = reinterpret_cast<u32x2_t*>(smem + POFF);
             if (wave & 1) {
 #pragma unroll
-              for (int k = 0; k < MS / 2; ++k) ex[((wave >> 1) * (MS / 2) + k) * 64 + lane] = u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
+              for (int k = 0; k < MS / 2; ++k) ex[((wave >> 1) * (MS / 2) + k) * 32 + (lane >> 1)] = u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
             }
             __syncthreads();
             if (!(wave & 1)) {
 #pragma unroll
               for (int k = 0; k < MS / 2; ++k) {
-                const u32x2_t o = ex[((wave >> 1) * (MS / 2) + k) * 64 + lane];
+                const u32x2_t o = ex[((wave >> 1) * (MS / 2) + k) * 32 + (lane >> 1)];
                 m[k][0] = fmaxf(m[k][0], lo16<T>(o[0])); m[k][1] = fmaxf(m[k][1], hi16<T>(o[0]));
                 m[k][2] = fmaxf(m[k][2], lo16<T>(o[1])); m[k][3] = fmaxf(m[k][3], hi16<T>(o[1]));
               }
@@ -445,7 +477,7 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
     }
 
     ZM_STAMP();   // 9: statistics row stored
-    ++it;
+    ZM_STEP_DONE();
     // ---- advance ----
     if constexpr (NCH == 1) { off += 4; off = off >= 6 ? off - 6 : off; } else { off ^= 1; }
     newcol = false;
@@ -460,6 +492,14 @@ int g_zm_launches = 0;
 }  // namespace
 
 extern "C" int bpx_debug_conv_zm_launches(void) { return g_zm_launches; }
+// tests / profiling: workgroups of the fp16 ELU instance (nch input chunks) the runtime keeps resident per CU (the compiler's occupancy remark does not
+// see the LDS allocation granule)
+extern "C" int bpx_debug_conv_zm_occupancy(int nch) {
+  int n = 0;
+  hipError_t e = nch == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zm_kernel<1, 1, true>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zm_kernel<3, 1, true>, 256, 0);
+  return e == hipSuccess ? n : -1;
+}
 extern "C" int bpx_debug_set_conv_zm(int mode) {
   g_zm_mode = mode < 0 ? -1 : (mode & 0xFF);
   g_zm_wgs = mode < 0 ? 0 : (mode >> 8);
@@ -479,14 +519,18 @@ static int zm_cu_count() {
 
 // 0 = launched; 1 = not applicable (the caller takes the lean kernel)
 int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
-  int mode = g_zm_mode;
-  if (mode < 0) { static const char* e = getenv("BPX_CONV_ZM"); mode = e ? atoi(e) : 1; }
+  int mode = g_zm_mode, wgs = g_zm_wgs;
+  if (mode < 0) {   // environment: same encoding as the hook (bits 8.. = workgroup cap)
+    static const char* e = getenv("BPX_CONV_ZM");
+    const int v = e ? atoi(e) : 1;
+    mode = v & 0xFF; wgs = v >> 8;
+  }
   if (mode == 0) return 1;
   if (!(c.tz == 4 && c.ty == 8 && c.tx == 16 && c.ns == 1) || p0.Cout != 16 || p0.ps > 1) return 1;
   if (!(p0.Cin == 16 || p0.Cin == 48)) return 1;
   {   // A/B aid: BPX_CONV_ZM_MASK bit 0 = one chunk without a wide shortcut, bit 1 = one chunk + shortcut of >= 16 channels, bit 2 = three chunks
     static const char* e = getenv("BPX_CONV_ZM_MASK");
-    static const int mask = e ? atoi(e) : 7;
+    static const int mask = e ? atoi(e) : 5;   // the wide-shortcut layer stays on the lean kernel (in the network: 8.70 vs 8.73 ms per step, profiles/r05_zmarch_ab.txt)
     const int kind = p0.Cin == 48 ? 4 : (p0.sc != nullptr && p0.sc_C >= 16) ? 2 : 1;
     if (!(mask & kind)) return 1;
   }
@@ -504,7 +548,7 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   const int nch = p.Cin / 16;
   const int occ = zm_occ(nch);
   int gx = std::max(8, (zm_cu_count() * occ) & ~7);
-  if (g_zm_wgs > 0) gx = std::max(8, std::min(gx, g_zm_wgs & ~7));
+  if (wgs > 0) gx = std::max(8, std::min(gx, wgs & ~7));
   gx = std::min(gx, 8 * p.tilesPerXcd);
   // the ring pays off over runs of several z-steps; short runs (small volumes) stay on the lean kernel.  Both kernels give the same bits, so
   // the choice may depend on the batch size.

@@ -1,6 +1,7 @@
 """Per-phase cycle anatomy of the z-marching forward kernel (conv3d_zmarch.hip) from in-kernel cycle stamps of every workgroup's 5th step.
 
-    python scripts/zm_stamps.py [layer index in tests/bench_kernels.FWD_LAYERS: 0 = 48 -> 16, 1 = 16 -> 16 + sc48, 2 = 16 -> 16 + image]
+    bash scripts/ab_build_flags.sh zmstamps -DBPX_ZM_STAMPS          (the stamps are compiled into a profiling build only)
+    BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_zmstamps.so BPX_CONV_ZM=2 python scripts/zm_stamps.py [layer index in tests/bench_kernels.FWD_LAYERS: 0 = 48 -> 16, 1 = 16 -> 16 + sc48, 2 = 16 -> 16 + image]
 """
 import os
 import sys
@@ -59,9 +60,10 @@ run(); torch.cuda.synchronize()
 lib.bpx_debug_set_conv_stamps(None)
 assert lib.bpx_debug_conv_zm_launches() == n0 + 1, "the launch did not take the z-marching kernel"
 s = stamps.cpu().numpy()
-s = s[s[:, 0] != 0][:, :10]
+split = os.environ.get("BPX_STAMP_SPLIT") is not None       # a library built with -DBPX_ZM_SPLIT=<stores after the prefetch> has one more stamp
+s = s[s[:, 0] != 0][:, :11 if split else 10]
 d = np.diff(s, axis=1).astype(np.float64)
-names = ["chunk 0: wait prefetch + transform + LDS write", "barrier (planes in LDS)", "request next stage's planes (+ image)", "chunk 0: 14 MFMA steps",
+names = (["chunk 0: wait for the prefetched pieces", "chunk 0: transform + LDS write"] if split else ["chunk 0: wait prefetch + transform + LDS write"]) + [ "barrier (planes in LDS)", "request next stage's planes (+ image)", "chunk 0: 14 MFMA steps",
          "chunks 1.. (barrier, transform, barrier, requests, MFMA steps)", "wide shortcut K steps", "epilogue (wait, math, stores, statistics to LDS)",
          "closing barrier", "statistics row"]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
