@@ -31,13 +31,23 @@ namespace {
 #ifndef BPX_ZM_RH
 #define BPX_ZM_RH 4
 #endif
+#ifndef BPX_ZM_SCK_AH
+#define BPX_ZM_SCK_AH 2
+#endif
+#ifndef BPX_ZM_SCK_RH
+#define BPX_ZM_SCK_RH 2
+#endif
 #ifndef BPX_ZM_ST16
 #define BPX_ZM_ST16 0
 #endif
-constexpr int zm_occ(int nch) { return nch == 1 ? 3 : 2; }
+constexpr int zm_occ(int nch, bool sck = false) { return (nch == 1 && !sck) ? 3 : 2; }
 
-template <int NCH, int ACTK, bool F16>
-__global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3Params p) {
+// SCK: the launch has a fused 1x1x1 shortcut on a raw tensor of 16 .. 48 channels (the decoder's second conv: its 48-channel operand is three times
+// the conv's own input).  Its own instance at TWO workgroups per CU: the whole operand of the step - up to 96 VGPRs - is requested behind the prefetch
+// and arrives during the MFMA steps (at three per CU there is no room: 144-228 bytes of scratch in every form that was tried), so a workgroup has
+// 23 + 48 KB in flight instead of 23 and the shortcut's K steps wait for nothing.
+template <int NCH, int ACTK, bool F16, bool SCK = false>
+__global__ void __launch_bounds__(256, zm_occ(NCH, SCK)) conv3_zm_kernel(const Conv3Params p) {
   using T = typename std::conditional<F16, f16_t, uint16_t>::type;
   constexpr int TZ = 4, TY = 8, TX = 16, MS = 8, KPL = 8, VB = 32, HY = TY + 2, HX = TX + 2;
   constexpr int PLANE_B = HY * HX * VB;                              // 5760 bytes: one z-plane of a chunk's halo, 32 bytes per voxel
@@ -45,7 +55,7 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
   constexpr int PL = PP - 256;                                        // 104 pieces of a plane beyond one per thread
   static_assert(2 * PL <= 256, "a plane pair's left-over pieces fit one round");
   constexpr int STEPS = 14, QPAD = 56, HSTR = HX * VB;
-  constexpr int RH = NCH == 1 ? BPX_ZM_RH : MS;                       // m-subtiles per fragment-row batch of the (dz, dy) steps
+  constexpr int RH = NCH != 1 ? MS : SCK ? BPX_ZM_SCK_RH : BPX_ZM_RH;                       // m-subtiles per fragment-row batch of the (dz, dy) steps
   constexpr int PLANES = NCH == 1 ? 6 : 2 + 4 * NCH;
   constexpr int RING_B = PLANES * PLANE_B;
   // Weights.  A wave's VMEM operations retire IN ORDER through one counter: a weight fragment requested after the next stage's prefetch could only
@@ -224,6 +234,8 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) acc[ms] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float img[MS];
+    u32x4_t bq[SCK ? 3 : 1][SCK ? MS : 1], bw[SCK ? 3 : 1];
+    const int sck_n = SCK ? p.sc_C / 16 : 0;
 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -275,7 +287,25 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
         load_pair(pbuf[0], pmask, 0, z0 + TZ + 1, 0);
         load_pair(pbuf[1], pmask, 3, z0 + TZ + 3, 0);
       }
-      if (BPX_ZM_IMG_EARLY && c + 1 == NCH && rank1) {
+      // SCK: request chunk q of the shortcut operand (8 m-subtiles x 16 bytes per lane) and its weight fragment.  Out-of-volume lanes read the
+      // tensor's first bytes: their accumulator columns are never stored or summed.
+      auto sc_request = [&](int q) {
+        if constexpr (SCK) {
+          // (no per-load control flow: a chunk beyond the operand's last one re-reads the last chunk and is skipped at the MFMAs)
+          const int qq = q < sck_n ? q : sck_n - 1;
+          const int vox0 = ((n * D + z0 + wave) * H + y0) * W + x0 + j;
+          const bool okzx = (z0 + wave < D) & (x0 + j < W);
+          const uint32_t sb0 = (uint32_t)(vox0 * p.sc_ld) * 2u + (uint32_t)cg_off + (uint32_t)qq * sc_csb, srow = (uint32_t)(W * p.sc_ld) * 2u;
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) {
+            const uint32_t o = (okzx & (y0 + ms < H)) ? sb0 + ms * srow : 0u;
+            bq[q][ms] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.sc) + o);
+          }
+          bw[q] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.wsc) + (uint32_t)(qq * 4 * Cout * 16) + wlane);
+        }
+      };
+      if (SCK && c + 1 == NCH) { sc_request(0); sc_request(1); }        // chunks 0 and 1 behind the prefetch; chunk 2 in front of the last five steps (below)
+      if (!SCK && BPX_ZM_IMG_EARLY && c + 1 == NCH && rank1) {
         // rank-1 shortcut: the image value of this lane's eight voxels, requested behind the prefetch (8 VGPRs across the MFMA steps).  Measured and
         // dropped (profiles/r05_zmarch_ab.txt): two requests per lane handed round with v_permlane16/32_swap - the same time, and in combination with
         // the 16-byte stores below a few rows came out wrong, differently from run to run (an unexplained permlane hazard: scripts/probes/zm_diff.py)
@@ -312,18 +342,27 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
             for (int ms = 0; ms < RH; ++ms) acc[h + ms] = mfma_step<T>(w3[dy], row[ms + dy], acc[h + ms]);
         }
       }
+      if (SCK && c + 1 == NCH) {       // the fragment-row registers of the (dz, dy) steps are free from here on
+        __builtin_amdgcn_sched_barrier(0);
+        sc_request(2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int s = 9; s < STEPS; ++s) {
         // steps 9-11: taps (dz, 0, 2) + (dz, 1, 2); step 12: taps (0, 2, 2) + (1, 2, 2); step 13: tap (2, 2, 2) alone
         const uint32_t base = s < 12 ? pz[s < 12 ? s - 9 : 0] + hb1 : s == 12 ? (hi_tap ? pz[1] : pz[0]) + hb : pz[2] + hb;
         const int imm = s < 12 ? 2 * VB : (2 * HX + 2) * VB;
         const u32x4_t ws = NCH == 1 ? *reinterpret_cast<const u32x4_t*>(smem + wl + s * 1024) : wall[NCH == 1 ? 0 : s];
-        u32x4_t af[MS];
+        constexpr int AH = SCK ? BPX_ZM_SCK_AH : MS;                   // m-subtiles per batch (the wide-shortcut instance has its operand live here)
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + base + ms * HSTR + imm);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int h = 0; h < MS; h += AH) {
+          u32x4_t af[AH];
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(ws, af[ms], acc[ms]);
+          for (int ms = 0; ms < AH; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + base + (h + ms) * HSTR + imm);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ms = 0; ms < AH; ++ms) acc[h + ms] = mfma_step<T>(ws, af[ms], acc[h + ms]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (c == 0) ZM_STAMP();   // 4: chunk 0 MFMA steps
@@ -336,24 +375,16 @@ __global__ void __launch_bounds__(256, zm_occ(NCH)) conv3_zm_kernel(const Conv3P
     const int vox0 = ((n * D + z0 + wave) * H + y0) * W + x0 + j;     // this lane's voxel for m-subtile 0
     const bool okzx = full || (z0 + wave < D && x0 + j < W);
     const int yrem = full ? (1 << 20) : H - y0;                        // m-subtile ms is inside the volume iff ms < yrem
-    if (p.sc != nullptr && p.sc_C >= 16) {
-      const char* __restrict__ scin = reinterpret_cast<const char*>(p.sc);
-      const char* __restrict__ wsc = reinterpret_cast<const char*>(p.wsc);
-      const uint32_t sb0 = (uint32_t)(vox0 * p.sc_ld) * 2u + (uint32_t)cg_off, srow = (uint32_t)(W * p.sc_ld) * 2u;
-      const int nch = p.sc_C / 16;
-      for (int chunk = 0; chunk < nch; ++chunk) {
-        u32x4_t bq[MS];
+    if constexpr (SCK) {
+      // the operand arrived during the MFMA steps; per accumulator the chunks are added in order 0, 1, 2 after the conv's own steps - the lean kernel's bits
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms) {
-          bq[ms] = u32x4_t{0u, 0u, 0u, 0u};
-          if (okzx && ms < yrem) bq[ms] = *reinterpret_cast<const u32x4_t*>(scin + (sb0 + ms * srow + (uint32_t)chunk * sc_csb));
+      for (int q = 0; q < 3; ++q) {
+        if (q < sck_n) {
+#pragma unroll
+          for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(bw[q], bq[q][ms], acc[ms]);
         }
-        const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(wsc + (size_t)chunk * 4 * Cout * 16 + wlane);
-#pragma unroll
-        for (int ms = 0; ms < MS; ++ms) acc[ms] = mfma_step<T>(wf, bq[ms], acc[ms]);
       }
     }
-
     ZM_STAMP();   // 6: wide shortcut
     // ---- epilogue (the lean kernel's, one output-channel group): bias / rank-1 shortcut, statistics, one 8-byte store per m-subtile ----
     const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u;
@@ -528,14 +559,12 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   if (mode == 0) return 1;
   if (!(c.tz == 4 && c.ty == 8 && c.tx == 16 && c.ns == 1) || p0.Cout != 16 || p0.ps > 1) return 1;
   if (!(p0.Cin == 16 || p0.Cin == 48)) return 1;
-  {   // A/B aid: BPX_CONV_ZM_MASK bit 0 = one chunk without a wide shortcut, bit 1 = one chunk + shortcut of >= 16 channels, bit 2 = three chunks
+  {   // A/B aid: BPX_CONV_ZM_MASK bit 0 = one chunk without a wide shortcut, bit 1 = one chunk + shortcut of 16 .. 48 channels, bit 2 = three chunks
     static const char* e = getenv("BPX_CONV_ZM_MASK");
-    static const int mask = e ? atoi(e) : 5;   // the wide-shortcut layer stays on the lean kernel (in the network: 8.70 vs 8.73 ms per step, profiles/r05_zmarch_ab.txt)
+    static const int mask = e ? atoi(e) : 7;
     const int kind = p0.Cin == 48 ? 4 : (p0.sc != nullptr && p0.sc_C >= 16) ? 2 : 1;
     if (!(mask & kind)) return 1;
   }
-  if (p0.pool != nullptr && p0.Cin != 16) return 1;                    // the fused pool lives in the one-chunk instance only
-  if (p0.in_norm && p0.act > BPX_ACT_SILU) return 1;
   Conv3Params p = p0;
   p.tilesZ = cdiv(p.D, c.tz);
   p.tilesY = cdiv(p.H, c.ty);
@@ -546,7 +575,9 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.stamps = g_conv_stamps;
   p.dbg = 0;
   const int nch = p.Cin / 16;
-  const int occ = zm_occ(nch);
+  const bool sck = p.sc != nullptr && p.sc_C >= 16;
+  if (sck && (p.sc_C > 48 || nch != 1)) return 1;                      // wider shortcuts / three chunks + shortcut: the lean kernel
+  const int occ = zm_occ(nch, sck);
   int gx = std::max(8, (zm_cu_count() * occ) & ~7);
   if (wgs > 0) gx = std::max(8, std::min(gx, wgs & ~7));
   gx = std::min(gx, 8 * p.tilesPerXcd);
@@ -555,19 +586,19 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   if (mode == 1 && (p.totalTiles < 4 * gx || p.tilesZ < 4)) return 1;
   const bool elu = p.act == BPX_ACT_ELU;
   dim3 grid((unsigned)gx, 1);
-#define Z(NCH)                                                                         \
-  if (nch == NCH) {                                                                    \
+#define Z(NCH, SCK)                                                                    \
+  if (nch == NCH && sck == SCK) {                                                      \
     ++g_zm_launches;                                                                   \
     if (p.f16) {                                                                       \
-      if (elu) conv3_zm_kernel<NCH, 1, true><<<grid, 256, 0, s>>>(p);                  \
-      else conv3_zm_kernel<NCH, 0, true><<<grid, 256, 0, s>>>(p);                      \
+      if (elu) conv3_zm_kernel<NCH, 1, true, SCK><<<grid, 256, 0, s>>>(p);             \
+      else conv3_zm_kernel<NCH, 0, true, SCK><<<grid, 256, 0, s>>>(p);                 \
     } else {                                                                           \
-      if (elu) conv3_zm_kernel<NCH, 1, false><<<grid, 256, 0, s>>>(p);                 \
-      else conv3_zm_kernel<NCH, 0, false><<<grid, 256, 0, s>>>(p);                     \
+      if (elu) conv3_zm_kernel<NCH, 1, false, SCK><<<grid, 256, 0, s>>>(p);            \
+      else conv3_zm_kernel<NCH, 0, false, SCK><<<grid, 256, 0, s>>>(p);                \
     }                                                                                  \
     return 0;                                                                          \
   }
-  Z(1) Z(3)
+  Z(1, false) Z(1, true) Z(3, false)
 #undef Z
   return 1;
 }
