@@ -33,6 +33,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -211,13 +213,25 @@ class ResUNetPPEngine(ResUNetEngine):
         if G is not None:
             def bwd():
                 dy = L.tview(y.grad)
-                self._wgrad(B, x.S, x.view(), nrm.rec if nrm else None, nrm.act if nrm else 0, dy, 3, G[wk], G[bk], self._st, self._dev)
+                fused = (nrm is not None and nrm.act <= 3 and os.environ.get("BPX_BWD_FUSED", "1") != "0" and self.dtype != torch.float32 and not self.use_side_stream
+                         and x.view().cs == 0 and bool(lib.bpx_conv3d_bwd_fused_supported(self.bdt, B, D, H, W, x.C, Cout)))
+                if not fused:
+                    self._wgrad(B, x.S, x.view(), nrm.rec if nrm else None, nrm.act if nrm else 0, dy, 3, G[wk], G[bk], self._st, self._dev)
                 wt = self._pack(P[wk], L.PK_K3_T, x.C, Cout, False)
                 g = torch.empty((B, D, H, W, x.C), dtype=self.gdtype, device=self._dev)
-                if nrm is not None:
+                if nrm is not None and fused:
+                    # round 5 (first part): dgrad (+ act', + IN-backward sums) and wgrad (+ bias gradient) of the conv in ONE pass
+                    # over (dy, x) - the level-0 / level-1 shapes the cfg-2 engine fuses too (bpx_conv3d_bwd_fused_supported)
+                    rt = lib.bpx_conv3d_bwd_fused_stats_tiles(B, D, H, W, x.C, Cout)
+                    red = torch.empty((B, rt, 2, x.C), dtype=torch.float32, device=self._dev)
+                    ws = self._workspace(lib.bpx_conv3d_bwd_fused_workspace(B, D, H, W, x.C, Cout), self._dev)
+                    L.check(lib.bpx_conv3d_bwd_fused(self.bdt, B, D, H, W, dy, wt.data_ptr(), x.view(), nrm.rec.data_ptr(), nrm.act, L.tview(g), red.data_ptr(),
+                                                     G[wk].data_ptr(), G[bk].data_ptr(), None, ws.data_ptr(), ws.numel(), self._st))
+                elif nrm is not None:
                     rt = lib.bpx_conv3d_stats_tiles(self.dt, B, D, H, W, x.C)
                     red = torch.empty((B, rt, 2, x.C), dtype=torch.float32, device=self._dev)
                     L.check(lib.bpx_conv3d_dgrad(self.bdt, B, D, H, W, dy, wt.data_ptr(), x.view(), nrm.rec.data_ptr(), nrm.act, L.tview(g), red.data_ptr(), self._st))
+                if nrm is not None:
                     coef = torch.empty((B, x.C, 4), dtype=torch.float32, device=self._dev)
                     L.check(lib.bpx_norm_bwd_finalize(red.data_ptr(), B, rt, x.C, x.vox, nrm.rec.data_ptr(), nrm.gamma.data_ptr(), L.ptr(nrm.dgamma),
                                                       L.ptr(nrm.dbeta), x.C, coef.data_ptr(), self._st))
