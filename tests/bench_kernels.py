@@ -102,6 +102,29 @@ def main():
             ms = timeit(f, a.reps)
             fl = 2 * B * S ** 3 * 27 * cin * cout
             print(f"conv_dgrad {S:4d}^3 dy{cout:4d}->g{cin:4d}: {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TF/s")
+    if a.what == "stream":
+        # the materialised streaming passes of the cfg-2 backward at level 0 (mixed mode: fp16 activations, bf16 gradients), GB/s of algorithmic traffic
+        S, C = 128, 16
+        vox = S ** 3
+        gq = torch.randn(B, S, S, S, C, device=DEV).to(torch.bfloat16)
+        tq = torch.randn(B, S, S, S, C, device=DEV).to(torch.float16)
+        out = torch.empty_like(gq)
+        coef = torch.rand(B, C, 4, device=DEV)
+        f = lambda: L.check(lib.bpx_norm_bwd_apply(L.MIX16, B, vox, L.tview(gq), L.tview(tq), coef.data_ptr(), L.NULL_T, L.tview(out), st))
+        ms = timeit(f, a.reps)
+        print(f"norm_bwd_apply {S}^3 C{C}: {ms * 1e3:8.1f} us  {3 * B * vox * C * 2 / ms / 1e6:8.1f} GB/s")
+        f = lambda: L.check(lib.bpx_norm_bwd_apply(L.MIX16, B, vox, L.tview(gq), L.tview(tq), coef.data_ptr(), L.tview(out), L.tview(out), st))
+        ms = timeit(f, a.reps)
+        print(f"norm_bwd_apply {S}^3 C{C} + addend: {ms * 1e3:8.1f} us  {4 * B * vox * C * 2 / ms / 1e6:8.1f} GB/s")
+        w = torch.randn(1, C, device=DEV)
+        dl = torch.randn(B, 1, S, S, S, device=DEV)
+        dw, db = torch.zeros(1, C, device=DEV), torch.zeros(1, device=DEV)
+        ws = torch.empty(lib.bpx_head_bwd_workspace(C, 1), dtype=torch.uint8, device=DEV)
+        f = lambda: L.check(lib.bpx_head_bwd(L.MIX16, vox, B, L.tview(tq), w.data_ptr(), 1, dl.data_ptr(), vox, vox, L.tview(out), dw.data_ptr(), db.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), st))
+        ms = timeit(f, a.reps)
+        print(f"head_bwd {S}^3 C{C} -> 1: {ms * 1e3:8.1f} us  {B * vox * (2 * C * 2 + 4) / ms / 1e6:8.1f} GB/s")
+        return
     if a.what == "k1":
         # k = 1 weight gradients of raw inputs (the blocks' shortcuts) in the mixed mode: streaming kernel vs the generic tile kernel
         for (S, cin, cout, planar) in [(128, 48, 16, True), (64, 96, 32, True), (64, 16, 32, False)]:
