@@ -37,9 +37,6 @@ namespace {
 #ifndef BPX_ZM_SCK_RH
 #define BPX_ZM_SCK_RH 2
 #endif
-#ifndef BPX_ZM_ST16
-#define BPX_ZM_ST16 0
-#endif
 constexpr int zm_occ(int nch, bool sck = false) { return (nch == 1 && !sck) ? 3 : 2; }
 
 // SCK: the launch has a fused 1x1x1 shortcut on a raw tensor of 16 .. 48 channels (the decoder's second conv: its 48-channel operand is three times
@@ -419,23 +416,11 @@ __global__ void __launch_bounds__(256, zm_occ(NCH, SCK)) conv3_zm_kernel(const C
             s2[r] += v[r] * v[r];
           }
           pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
-          if (!BPX_ZM_ST16) *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
+          *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
         }
       }
-      if (BPX_ZM_ST16) {
-        // 16-byte stores.  Lanes (j, g) and (j, g ^ 1) - 16 lanes apart - hold the two 8-byte halves of the same 16 bytes of voxel (ms, j).
-        // v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second: with (first, second) = the packed
-        // values of m-subtiles (2k, 2k + 1), the even-g lanes end up with 16 contiguous bytes of row 2k ([own | partner's]) and the odd-g lanes with
-        // 16 bytes of row 2k + 1 ([partner's | own]): 4 stores per lane instead of 8, same bytes, same addresses.  Bit-identical on its own, and
-        // MEASURED FLAT (profiles/r05_zmarch_ab.txt: 236.0 / 385.2 / 625.9 us with it, 235.2 / 383.6 / 627.8 without): off by default.
-        const uint32_t yb16 = (uint32_t)(vox0 * p.y_ld + (g & ~1) * 4) * 2u + (uint32_t)(g & 1) * yrow;
-#pragma unroll
-        for (int k = 0; k < MS / 2; ++k) {
-          const u32x2_t a = pk[2 * k], b = pk[2 * k + 1];
-          const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-          if (okzx && 2 * k + (g & 1) < yrem) *reinterpret_cast<u32x4_t*>(yout + (yb16 + 2 * k * yrow)) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
-        }
-      }
+      // (Measured and removed: 16-byte stores - lanes (j, g) and (j, g ^ 1) exchange their 8-byte halves with v_permlane16_swap, 4 stores per lane
+      //  instead of 8 - bit-identical on their own and FLAT: 236.0 / 385.2 / 625.9 us with, 235.2 / 383.6 / 627.8 without, profiles/r05_zmarch_ab.txt.)
       if constexpr (NCH == 1) {
         if (p.pool != nullptr) {
           // fused MaxPool3d (pool_sz, 2, 2): y pairs = two m-subtiles of this lane, x pairs = lanes j / j^1 (DPP), z pairs = waves w / w + 1 (LDS)
