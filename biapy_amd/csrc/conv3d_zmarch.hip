@@ -501,6 +501,361 @@ __global__ void __launch_bounds__(256, zm_occ(NCH, SCK)) conv3_zm_kernel(const C
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// conv3_zs_kernel: the z-march with the workgroup's waves SPLIT into roles (round 5, the structure DESIGN.md section 8 names as "not tried").
+// One input chunk, no wide shortcut (the encoder's second conv: image shortcut, fused pool).  512 threads: waves 0-3 are CONSUMERS (one z-slice
+// each: MFMA steps, epilogue, stores), waves 4-7 PRODUCERS (request, normalise + activate, LDS write of the NEXT step's four new planes, and the
+// previous step's statistics row).  The two halves meet at ONE barrier per step (two with the fused z-pooling).  The ring has ten plane slots:
+// the six planes the consumers read and the four the producers write are disjoint, plane a of a column run lives in slot a % 10.  Why: in
+// conv3_zm_kernel every wave runs [stage -> MFMA -> epilogue] as one dependent chain and the stamps show each phase ~2.5 K cycles for a LONE
+// workgroup - nothing is saturated, the chains just do not overlap; here the staging chain and the MFMA chain of a step run side by side.
+// Two workgroups of eight waves per CU (76 KB LDS, <= 128 VGPRs: the accumulators and the prefetched pieces share registers - a thread is either).
+// Same MFMAs in the same order, same epilogue and statistics rows: bit-identical to the other two kernels.
+template <int ACTK, bool F16>
+__global__ void __launch_bounds__(512, 4) conv3_zs_kernel(const Conv3Params p) {
+  using T = typename std::conditional<F16, f16_t, uint16_t>::type;
+  constexpr int TZ = 4, TY = 8, TX = 16, MS = 8, KPL = 8, VB = 32, HY = TY + 2, HX = TX + 2;
+  constexpr int PLANE_B = HY * HX * VB, PP = HY * HX * 2, PL = PP - 256;
+  constexpr int STEPS = 14, HSTR = HX * VB, RH = 4, SLOTS = 10;
+  constexpr int RING_B = SLOTS * PLANE_B;                              // 57,600
+  constexpr int WOFF = RING_B, ROFF = WOFF + STEPS * 1024;             // weights: [step][lane][16 B]
+  constexpr int RED_B = 2 * 2 * 4 * 16 * 2 * 4;                        // statistics scratch [step parity][which][wave][16][2]: written by the consumers, read by a producer wave one step later
+  constexpr int TOFF = ROFF + RED_B, TAB_B = 16 * 8 + 128, POFF = TOFF + TAB_B, POOL_B = 2 * (MS / 2) * 32 * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[POFF + POOL_B];
+  float* const tab = reinterpret_cast<float*>(smem + TOFF);
+  float* const ektab = tab + 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool producer = tid >= 256;                                    // wave-uniform
+  const int ptid = tid & 255;                                          // thread id inside the role
+  const int wave = __builtin_amdgcn_readfirstlane(ptid >> 6);          // consumers: z-slice
+  const int j = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W;
+  constexpr int Cout = 16;
+  const int cg_off = (g & 1) * 16;
+  const bool hi_tap = (g >> 1) != 0;
+  const uint32_t hb = (uint32_t)(j * VB + cg_off);
+
+  // producers' staging constants (conv3_zm_kernel): piece ptid of a plane ("A") and the pair's left-over piece ("L")
+  const int sub = ptid & 1;
+  const int hvA = ptid >> 1, hyA = hvA / HX, hxA = hvA - hyA * HX;
+  const int selL = ptid / PL, idxL = 256 + (ptid - selL * PL), hvL = idxL >> 1, hyL = hvL / HX, hxL = hvL - hyL * HX;
+  const bool hasL = ptid < 2 * PL;
+  const uint32_t HWB = (uint32_t)(H * W * p.x_ld) * 2u;
+  uint32_t relA = (uint32_t)((hyA * W + hxA) * p.x_ld + sub * KPL) * 2u;
+  uint32_t relL = (uint32_t)((hyL * W + hxL) * p.x_ld + sub * KPL) * 2u + (hasL ? (uint32_t)selL * HWB : 0u);
+  asm volatile("" : "+v"(relA), "+v"(relL));
+  const uint32_t ldsA = (uint32_t)ptid * 16u, ldsL = (uint32_t)idxL * 16u;
+  const char* __restrict__ xin = reinterpret_cast<const char*>(p.x);
+  const char* __restrict__ wp = reinterpret_cast<const char*>(p.wp);
+
+  const bool rank1 = p.sc != nullptr && p.sc_C == 1;
+  if (tid < 16) {
+    float a = 0.f;
+    if (p.bias) a += p.bias[tid];
+    if (p.sc && p.bias_sc) a += p.bias_sc[tid];
+    ektab[tid] = a;
+    ektab[16 + tid] = rank1 ? reinterpret_cast<const float*>(p.wsc)[tid] : 0.f;
+  }
+  for (int q = tid; q < STEPS * 64; q += 512)
+    *reinterpret_cast<u32x4_t*>(smem + WOFF + q * 16) = *reinterpret_cast<const u32x4_t*>(wp + (uint32_t)q * 16u);
+
+  const int tilesZ = p.tilesZ, colsPerSample = p.tilesY * p.tilesX;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
+  const int T8 = p.tilesPerXcd;
+  int L0 = xcd * T8 + (int)(((long long)slot * T8) / spx), L1 = xcd * T8 + (int)(((long long)(slot + 1) * T8) / spx);
+  {
+    const int cap = min((xcd + 1) * T8, p.totalTiles);
+    L1 = min(L1, cap);
+  }
+  if (L0 >= L1) return;
+  int col = L0 / tilesZ, tzi = L0 - col * tilesZ;
+  int n = 0, y0 = 0, x0 = 0, tyi = 0, txi = 0;
+  uint32_t colb = 0;
+  bool okA = false, okL = false;
+  int sb = 0;                               // slot of ring-relative plane 0 of the current step
+  int par = 0;                              // statistics scratch half of the current step
+  bool newcol = true;
+  int prev_row = -1;                        // row index (n * tilesPerSample + tile) of the step whose statistics wait in red[par ^ 1]; -1: none
+
+  // Role-shared registers: the consumers' eight accumulators / the producers' six prefetched pieces (+ validity mask).
+  f32x4_t acc[MS];
+  uint32_t pmask = 0;
+  auto PB = [&](int k) -> f32x4_t& { return acc[k]; };   // producer view: pieces 0..2 = planes {2, 3} of the step being prepared, 3..5 = planes {4, 5}
+
+  auto slot_of = [&](int q) -> uint32_t { int s = sb + q; s = s >= SLOTS ? s - SLOTS : s; return (uint32_t)s * PLANE_B; };
+  const bool has_norm = p.in_norm != nullptr;
+
+  auto load3 = [&](f32x4_t* v, uint32_t& mask, int bit, int z) {      // the three pieces of the plane pair (z, z + 1)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool ok = okA && (unsigned)(z + k) < (unsigned)D;
+      v[k] = __builtin_bit_cast(f32x4_t, *reinterpret_cast<const u32x4_t*>(xin + (ok ? colb + (uint32_t)(z + k) * HWB + relA : 0u)));
+      mask |= ok ? 1u << (bit + k) : 0u;
+    }
+    const bool ok = okL && (unsigned)(z + selL) < (unsigned)D;
+    v[2] = __builtin_bit_cast(f32x4_t, *reinterpret_cast<const u32x4_t*>(xin + (ok ? colb + (uint32_t)z * HWB + relL : 0u)));
+    mask |= ok ? 1u << (bit + 2) : 0u;
+  };
+  auto store3 = [&](const f32x4_t* v, uint32_t mask, int bit, uint32_t s0, uint32_t s1, const float* psc, const float* psh) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k == 2 && !hasL) break;
+      u32x4_t t = __builtin_bit_cast(u32x4_t, v[k]);
+      const bool in = (mask >> (bit + k)) & 1u;
+      if (!in) t = u32x4_t{0u, 0u, 0u, 0u};
+      if (has_norm && in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float a = fmaf(psc[2 * i], lo16<T>(t[i]), psh[2 * i]), b = fmaf(psc[2 * i + 1], hi16<T>(t[i]), psh[2 * i + 1]);
+          act_pair<ACTK>(a, b, p.act);
+          t[i] = pk16<T>(a, b);
+        }
+      }
+      const uint32_t dst = k == 0 ? s0 + ldsA : k == 1 ? s1 + ldsA : (selL ? s1 : s0) + ldsL;
+      *reinterpret_cast<u32x4_t*>(smem + dst) = t;
+    }
+  };
+  auto load_tab = [&](float* psc, float* psh) {
+    if (!has_norm) return;
+    const f32x4_t* tp = reinterpret_cast<const f32x4_t*>(tab + (sub * KPL) * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4_t q = tp[i];
+      psc[2 * i] = q[0]; psh[2 * i] = q[1]; psc[2 * i + 1] = q[2]; psh[2 * i + 1] = q[3];
+    }
+  };
+  // the statistics row of the step that finished at the last barrier (producer wave 0 of the role)
+  auto store_row = [&](int row, int half) {
+    if (row < 0 || !producer || ptid >= 64) return;
+    const int which = ptid >> 5, q = ptid & 31, ch = q >> 1, k = q & 1;
+    float* dst = which ? p.pool_part : p.part;
+    if (dst == nullptr) return;
+    const float* rd = reinterpret_cast<const float*>(smem + ROFF) + half * 256 + which * 128;
+    const float a = rd[(0 * 16 + ch) * 2 + k] + rd[(1 * 16 + ch) * 2 + k] + rd[(2 * 16 + ch) * 2 + k] + rd[(3 * 16 + ch) * 2 + k];
+    dst[((size_t)row * 2 + k) * Cout + ch] = a;
+  };
+
+  char* __restrict__ yout = reinterpret_cast<char*>(p.y);
+  const uint32_t yrow = (uint32_t)(W * p.y_ld) * 2u;
+  const bool pool2 = p.pool != nullptr && p.pool_sz == 2;
+
+  // Per-step bookkeeping, identical in both roles (the roles run SEPARATE loops so that each gets its own register allocation - as one loop with
+  // role branches inside, the compiler kept both roles' state live everywhere: 300 bytes of scratch at the 128-VGPR budget; the barriers of the
+  // two loops pair up dynamically: every step has [two at a column start] + [one with the fused z-pooling] + [one at its end] in both)
+#define ZS_STEP_BEGIN()                                                                                                  \
+    if (newcol) {                                                                                                        \
+      n = col / colsPerSample;                                                                                           \
+      const int r_ = col - n * colsPerSample;                                                                            \
+      tyi = r_ / p.tilesX; txi = r_ - tyi * p.tilesX;                                                                    \
+      y0 = tyi * TY; x0 = txi * TX;                                                                                      \
+      sb = 0;                                                                                                            \
+    }                                                                                                                    \
+    const int z0 = tzi * TZ;
+#define ZS_STEP_END()                                                                                                    \
+    prev_row = n * p.tilesPerSample + (tzi * p.tilesY + tyi) * p.tilesX + txi;                                           \
+    par ^= 1;                                                                                                            \
+    sb += 4; sb = sb >= SLOTS ? sb - SLOTS : sb;                                                                         \
+    newcol = false;                                                                                                      \
+    if (++tzi == tilesZ) { tzi = 0; ++col; newcol = true; }
+
+  if (producer) {
+    // ================================================== PRODUCER WAVES ==================================================
+    for (int L = L0; L < L1; ++L) {
+      ZS_STEP_BEGIN()
+      if (newcol) {
+        colb = (uint32_t)(((n * D) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.x_ld * 2u;
+        okA = (unsigned)(y0 - 1 + hyA) < (unsigned)H && (unsigned)(x0 - 1 + hxA) < (unsigned)W;
+        okL = hasL && (unsigned)(y0 - 1 + hyL) < (unsigned)H && (unsigned)(x0 - 1 + hxL) < (unsigned)W;
+      }
+      const bool next1 = (L + 1 < L1) && (tzi + 1 < tilesZ);           // the next step continues this column
+      const bool next2 = (L + 2 < L1) && (tzi + 2 < tilesZ);
+      if (newcol) {
+        // a run's first step in a column: all six planes while the consumers wait (once per column)
+        f32x4_t v0[3];
+        uint32_t m0 = 0;
+        if (has_norm && ptid < 16) *reinterpret_cast<f32x2_t*>(tab + ptid * 2) = *reinterpret_cast<const f32x2_t*>(&p.in_norm[(size_t)n * p.Cin + ptid].scale);
+        pmask = 0;
+        load3(v0, m0, 0, z0 - 1);
+        load3(&PB(0), pmask, 0, z0 + 1);
+        load3(&PB(3), pmask, 3, z0 + 3);
+        __syncthreads();                                               // the table is visible; every consumer is past the previous column
+        float psc[KPL], psh[KPL];
+        load_tab(psc, psh);
+        store3(v0, m0, 0, slot_of(0), slot_of(1), psc, psh);
+        store3(&PB(0), pmask, 0, slot_of(2), slot_of(3), psc, psh);
+        store3(&PB(3), pmask, 3, slot_of(4), slot_of(5), psc, psh);
+        pmask = 0;
+        if (next1) { load3(&PB(0), pmask, 0, z0 + TZ + 1); load3(&PB(3), pmask, 3, z0 + TZ + 3); }
+        __syncthreads();                                               // the six planes are in LDS
+      }
+      // phase 1: the statistics row of the step that ended at the last barrier, then the NEXT step's four new planes
+      store_row(prev_row, par ^ 1);
+      if (next1) {
+        float psc[KPL], psh[KPL];
+        load_tab(psc, psh);
+        // planes {2 .. 5} of step L + 1 = ring-relative planes 6 .. 9 of this step: the four slots the consumers do not read now
+        store3(&PB(0), pmask, 0, slot_of(6), slot_of(7), psc, psh);
+        store3(&PB(3), pmask, 3, slot_of(8), slot_of(9), psc, psh);
+      }
+      if (pool2) __syncthreads();                                      // (the consumers' z-pair exchange)
+      // phase 2: request the planes of step L + 2; they fly across the barrier and the consumers' next MFMA steps
+      pmask = 0;
+      if (next2) { load3(&PB(0), pmask, 0, z0 + 2 * TZ + 1); load3(&PB(3), pmask, 3, z0 + 2 * TZ + 3); }
+      __syncthreads();                                                 // end of the step
+      ZS_STEP_END()
+    }
+    store_row(prev_row, par ^ 1);
+    return;
+  }
+
+  // ==================================================== CONSUMER WAVES ====================================================
+  for (int L = L0; L < L1; ++L) {
+    ZS_STEP_BEGIN()
+    if (newcol) {
+      __syncthreads();
+      __syncthreads();                                                 // the six planes are in LDS
+    }
+    const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+    const int vox0 = ((n * D + z0 + wave) * H + y0) * W + x0 + j;
+    const bool okzx = full || (z0 + wave < D && x0 + j < W);
+    const int yrem = full ? (1 << 20) : H - y0;
+    float m[MS / 2][4];                                                // the pooled y-pair / x-pair maxima, carried over the pool barrier
+    {
+      float img[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+        img[ms] = rank1 ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.sc) + ((okzx && ms < yrem) ? (uint32_t)(vox0 + ms * W) * 4u : 0u)) : 0.f;
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) acc[ms] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const uint32_t pz[3] = {slot_of(wave), slot_of(wave + 1), slot_of(wave + 2)};
+      const uint32_t hb0 = hb + (hi_tap ? VB : 0), hb1 = hb + (hi_tap ? HX * VB : 0);
+      const uint32_t wl = WOFF + (uint32_t)lane * 16u;
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const uint32_t b0 = pz[dz] + hb0;
+        u32x4_t w3[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) w3[dy] = *reinterpret_cast<const u32x4_t*>(smem + wl + (3 * dz + dy) * 1024);
+#pragma unroll
+        for (int h = 0; h < MS; h += RH) {
+          u32x4_t row[RH + 2];
+#pragma unroll
+          for (int r = 0; r < RH + 2; ++r) row[r] = *reinterpret_cast<const u32x4_t*>(smem + b0 + (h + r) * HSTR);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ms = 0; ms < RH; ++ms) acc[h + ms] = mfma_step<T>(w3[dy], row[ms + dy], acc[h + ms]);
+        }
+      }
+#pragma unroll
+      for (int s = 9; s < STEPS; ++s) {
+        const uint32_t base = s < 12 ? pz[s < 12 ? s - 9 : 0] + hb1 : s == 12 ? (hi_tap ? pz[1] : pz[0]) + hb : pz[2] + hb;
+        const int imm = s < 12 ? 2 * VB : (2 * HX + 2) * VB;
+        const u32x4_t ws = *reinterpret_cast<const u32x4_t*>(smem + wl + s * 1024);
+#pragma unroll
+        for (int h = 0; h < MS; h += 4) {
+          u32x4_t af[4];
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) af[ms] = *reinterpret_cast<const u32x4_t*>(smem + base + (h + ms) * HSTR + imm);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) acc[h + ms] = mfma_step<T>(ws, af[ms], acc[h + ms]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // epilogue, first half: bias / rank-1 shortcut, statistics, one 8-byte store per m-subtile (conv3_zm_kernel's arithmetic, two m-subtiles at a time)
+      const uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u;
+      const f32x4_t addk = *reinterpret_cast<const f32x4_t*>(ektab + g * 4), w1k = *reinterpret_cast<const f32x4_t*>(ektab + 16 + g * 4);
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < MS / 2; ++k) {
+        u32x2_t pk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ms = 2 * k + h;
+          pk[h] = u32x2_t{0u, 0u};
+          if (okzx && ms < yrem) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[ms][r] + addk[r] + img[ms] * w1k[r];
+              s1[r] += v[r];
+              s2[r] += v[r] * v[r];
+            }
+            pk[h] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
+            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[h];
+          }
+        }
+        if (p.pool != nullptr) {
+          const u32x2_t a = pk[0], b = pk[1];
+          m[k][0] = fmaxf(lo16<T>(a[0]), lo16<T>(b[0])); m[k][1] = fmaxf(hi16<T>(a[0]), hi16<T>(b[0]));
+          m[k][2] = fmaxf(lo16<T>(a[1]), lo16<T>(b[1])); m[k][3] = fmaxf(hi16<T>(a[1]), hi16<T>(b[1]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            m[k][r] = fmaxf(m[k][r], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[k][r]), 0xB1, 0xF, 0xF, true)));
+        }
+      }
+      if (p.part != nullptr) {   // the output's statistics go to LDS here, before the pool barrier: nothing of them is carried over it
+        float* red = reinterpret_cast<float*>(smem + ROFF) + par * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
+          if (j == 0) *reinterpret_cast<f32x2_t*>(&red[(wave * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+        }
+      }
+      if (pool2 && (wave & 1)) {
+        u32x2_t* ex = reinterpret_cast<u32x2_t*>(smem + POFF);
+#pragma unroll
+        for (int k = 0; k < MS / 2; ++k) ex[((wave >> 1) * (MS / 2) + k) * 32 + (lane >> 1)] = u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
+      }
+    }
+    if (pool2) __syncthreads();                                        // the odd z-slices' pooled rows are in LDS
+    if (p.pool != nullptr) {
+      float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pool2 && !(wave & 1)) {
+        const u32x2_t* ex = reinterpret_cast<const u32x2_t*>(smem + POFF);
+#pragma unroll
+        for (int k = 0; k < MS / 2; ++k) {
+          const u32x2_t o = ex[((wave >> 1) * (MS / 2) + k) * 32 + (lane >> 1)];
+          m[k][0] = fmaxf(m[k][0], lo16<T>(o[0])); m[k][1] = fmaxf(m[k][1], hi16<T>(o[0]));
+          m[k][2] = fmaxf(m[k][2], lo16<T>(o[1])); m[k][3] = fmaxf(m[k][3], hi16<T>(o[1]));
+        }
+      }
+      if ((p.pool_sz == 1 || !(wave & 1)) && !(j & 1) && z0 + wave < D && x0 + j < W) {
+        const int Dp = D / p.pool_sz, Hp = H >> 1, Wp = W >> 1;
+        const int pz_ = (z0 + wave) / p.pool_sz, px = (x0 + j) >> 1;
+        char* __restrict__ pout = reinterpret_cast<char*>(p.pool);
+#pragma unroll
+        for (int k = 0; k < MS / 2; ++k) {
+          if (y0 + 2 * k < H) {
+            const int py = (y0 >> 1) + k;
+            *reinterpret_cast<u32x2_t*>(pout + (uint32_t)((((n * Dp + pz_) * Hp + py) * Wp + px) * p.pool_ld + g * 4) * 2u) =
+                u32x2_t{pk16<T>(m[k][0], m[k][1]), pk16<T>(m[k][2], m[k][3])};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { q1[r] += m[k][r]; q2[r] += m[k][r] * m[k][r]; }
+          }
+        }
+      }
+      if (p.pool_part != nullptr) {
+        float* red = reinterpret_cast<float*>(smem + ROFF) + par * 256 + 128;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(q1[r]), b = row16_sum(q2[r]);
+          if (j == 0) *reinterpret_cast<f32x2_t*>(&red[(wave * 16 + g * 4 + r) * 2]) = f32x2_t{a, b};
+        }
+      }
+    }
+    __syncthreads();                                                   // end of the step: done with the six planes; the next four are written; red[par] complete
+    ZS_STEP_END()
+  }
+#undef ZS_STEP_BEGIN
+#undef ZS_STEP_END
+}
+
 int g_zm_mode = -1;   // -1: from the environment (BPX_CONV_ZM, default 1); 0 off; 1 on where it applies; 2 on even for short runs (tests)
 int g_zm_wgs = 0;     // tests: cap on the number of workgroups (long runs that cross columns on small volumes); 0 = none
 int g_zm_launches = 0;
@@ -512,8 +867,9 @@ extern "C" int bpx_debug_conv_zm_launches(void) { return g_zm_launches; }
 // see the LDS allocation granule)
 extern "C" int bpx_debug_conv_zm_occupancy(int nch) {
   int n = 0;
-  hipError_t e = nch == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zm_kernel<1, 1, true>, 256, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zm_kernel<3, 1, true>, 256, 0);
+  hipError_t e = nch == 0   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zs_kernel<1, true>, 512, 0)     // 0: the role-split form (512 threads)
+                 : nch == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zm_kernel<1, 1, true>, 256, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv3_zm_kernel<3, 1, true>, 256, 0);
   return e == hipSuccess ? n : -1;
 }
 extern "C" int bpx_debug_set_conv_zm(int mode) {
@@ -541,6 +897,8 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
     const int v = e ? atoi(e) : 1;
     mode = v & 0xFF; wgs = v >> 8;
   }
+  const bool no_zs = (mode & 4) != 0;   // bit 2: without the role-split form (conv3_zs_kernel) - the test / A-B selector of conv3_zm_kernel<1, .., false>
+  mode &= 3;
   if (mode == 0) return 1;
   if (!(c.tz == 4 && c.ty == 8 && c.tx == 16 && c.ns == 1) || p0.Cout != 16 || p0.ps > 1) return 1;
   if (!(p0.Cin == 16 || p0.Cin == 48)) return 1;
@@ -561,6 +919,22 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   p.dbg = 0;
   const int nch = p.Cin / 16;
   const bool sck = p.sc != nullptr && p.sc_C >= 16;
+  {   // the role-split form (conv3_zs_kernel) of the one-chunk layers without a wide shortcut; BPX_CONV_ZS = 0 (or mode bit 2): conv3_zm_kernel
+    static const char* e = getenv("BPX_CONV_ZS");
+    static const int zs = e ? atoi(e) : 1;
+    if (zs && !no_zs && nch == 1 && !sck) {
+      int gz = std::max(8, (zm_cu_count() * 2) & ~7);
+      if (wgs > 0) gz = std::max(8, std::min(gz, wgs & ~7));
+      gz = std::min(gz, 8 * p.tilesPerXcd);
+      if (mode == 1 && (p.totalTiles < 4 * gz || p.tilesZ < 4)) return 1;
+      const bool elu_ = p.act == BPX_ACT_ELU;
+      ++g_zm_launches;
+      dim3 gridz((unsigned)gz, 1);
+      if (p.f16) { if (elu_) conv3_zs_kernel<1, true><<<gridz, 512, 0, s>>>(p); else conv3_zs_kernel<0, true><<<gridz, 512, 0, s>>>(p); }
+      else { if (elu_) conv3_zs_kernel<1, false><<<gridz, 512, 0, s>>>(p); else conv3_zs_kernel<0, false><<<gridz, 512, 0, s>>>(p); }
+      return 0;
+    }
+  }
   if (sck && (p.sc_C > 48 || nch != 1)) return 1;                      // wider shortcuts / three chunks + shortcut: the lean kernel
   const int occ = zm_occ(nch, sck);
   int gx = std::max(8, (zm_cu_count() * occ) & ~7);

@@ -20,7 +20,7 @@ def _conv_rx(epi):
     """conv3_lp_kernel<TZ, TY, TX, NS, EPI, ACTK, F16, TF16> and conv3_kernel<T, TZ, TY, TX, NS, EPI, ACTK, TT>, demangled or - rocprofv3 leaves the
     names with _Float16 arguments mangled - as conv3_kernelIDF16_Li4ELi4ELi8ELi4ELi<EPI>E... / conv3_lp_kernelILi4E...Li<EPI>E..."""
     e = str(epi)
-    zm = r"|conv3_zm_kernel(<|I)" if epi == 0 else ""      # the z-marching forward kernel of the level-0 layers (round 5): forward only
+    zm = r"|conv3_z[ms]_kernel(<|I)" if epi == 0 else ""      # the z-marching forward kernel of the level-0 layers (round 5): forward only
     return re.compile(r"conv3_lp_kernel<\d+, \d+, \d+, \d+, " + e + r",|conv3_kernel<[^,>]+, \d+, \d+, \d+, \d+, " + e + r"," + zm +
                       r"|conv3_lp_kernelI(?:Li\d+E){4}Li" + e + r"E|conv3_kernelI(?:DF16_|t|f)(?:Li\d+E){4}Li" + e + r"E")
 

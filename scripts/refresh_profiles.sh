@@ -42,13 +42,14 @@ python tests/bench_kernels.py bwd --reps 10 2>&1 | grep -v amdgpu.ids > $O/${R}_
 # round 5: the z-marching forward kernel of the level-0 layers against the lean kernel (same call), its per-phase cycle stamps, its runtime occupancy
 ( python -c "
 from biapy_amd import _lib as L
-print('resident workgroups per CU as the runtime computes them: conv3_zm_kernel<1> (one input chunk)', L.lib.bpx_debug_conv_zm_occupancy(1), ', <3> (three chunks)', L.lib.bpx_debug_conv_zm_occupancy(3))"
+print('resident workgroups per CU as the runtime computes them: conv3_zm_kernel<1> (one input chunk)', L.lib.bpx_debug_conv_zm_occupancy(1), ', <3> (three chunks)', L.lib.bpx_debug_conv_zm_occupancy(3), ', conv3_zs_kernel (role split, 512 threads)', L.lib.bpx_debug_conv_zm_occupancy(0))"
   for rep in 1 2; do
     echo "== z-march"; BPX_CONV_ZM=1 python tests/bench_kernels.py conv_fwd --dtype f16 --only 0,1,2 --reps 20 | grep conv_fwd
     echo "== lean (BPX_CONV_ZM=0)"; BPX_CONV_ZM=0 python tests/bench_kernels.py conv_fwd --dtype f16 --only 0,1,2 --reps 20 | grep conv_fwd
+    echo "== z-march without the role split (BPX_CONV_ZS=0: conv3_zm_kernel<1> instead of conv3_zs_kernel)"; BPX_CONV_ZS=0 python tests/bench_kernels.py conv_fwd --dtype f16 --only 2 --reps 20 | grep conv_fwd
   done ) 2>&1 | grep -v amdgpu.ids > $O/${R}_zmarch_vs_lean.txt
 if [ -f biapy_amd/libbiapy_amd_zmstamps.so ]; then
-  ( for k in 2 1 0; do BPX_STAMP_SPLIT=1 BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_zmstamps.so BPX_CONV_ZM=2 python scripts/zm_stamps.py $k; done ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_zmarch.txt
+  ( for k in 2 1 0; do BPX_STAMP_SPLIT=1 BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_zmstamps.so BPX_CONV_ZM=6 python scripts/zm_stamps.py $k; done ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_zmarch.txt
 fi
 for zm in 1 0; do BPX_CONV_ZM=$zm python bench.py --mode train --steps 40 --warmup 8 --no-cpu-baseline --no-bf16-record --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_ZM=$zm train ms_per_step %.4f' % d['ms_per_step'])"; done > $O/${R}_step_zmarch_ab.txt 2>&1
 for zm in 1 0; do BPX_CONV_ZM=$zm python bench.py --mode infer --steps 40 --warmup 8 --no-cpu-baseline --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_ZM=$zm infer ms_per_step %.4f' % d['ms_per_step'])"; done >> $O/${R}_step_zmarch_ab.txt 2>&1
@@ -76,7 +77,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p --
 cd $ROOT
 python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 python scripts/pmc_traffic.py $(find $O/pmc_tf -name "p_results.db" | head -1) $(find $O/pmc_tw -name "p_results.db" | head -1) > $O/pmc_traffic_tiling.json 2>> $O/pmc_traffic.err
-for k in conv3_zm_kernel conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel pw_nbs_kernel wgrad_k1_dma_kernel; do
+for k in conv3_zm_kernel conv3_zs_kernel conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel pw_nbs_kernel wgrad_k1_dma_kernel; do
   python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
   python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
 done > $O/${R}_pmc_sq_conv_wgrad.txt 2>&1

@@ -321,12 +321,13 @@ def check_conv3d_fwd(dt, B, S, Cin, Cout, norm=True, sc_C=0, slices=False, seed=
     return res
 
 
-def check_conv3d_zmarch(f16, B, S, Cin, sc_C=0, pool=0, planar=False, norm=True, act=1, wgs=0, seed=0):
+def check_conv3d_zmarch(f16, B, S, Cin, sc_C=0, pool=0, planar=False, norm=True, act=1, wgs=0, seed=0, role_split=True):
     """The z-marching forward kernel (conv3d_zmarch.hip, round 5) against the lean kernel it replaces on the same operands: the output, the
     statistics partial sums and the fused pool's tensor + sums must be BIT-IDENTICAL (same MFMAs in the same order, same reduction order) - so
     the lean kernel's own parity rows carry over and the choice between the two may depend on the batch size.  wgs: cap on the z-march
     workgroups, so that a run covers many z-steps and crosses columns on a small volume.  planar: x (and a 16+-channel shortcut operand) as
-    chunk-planar buffers, as the decoder's concat tensors are."""
+    chunk-planar buffers, as the decoder's concat tensors are.  role_split=False: mode bit 2, i.e. conv3_zm_kernel also where the role-split
+    form (conv3_zs_kernel: 16 input channels, no wide shortcut) is the default."""
     dt = L.F16 if f16 else L.BF16
     T = tdtype(dt)
     D, H, W = S
@@ -350,7 +351,7 @@ def check_conv3d_zmarch(f16, B, S, Cin, sc_C=0, pool=0, planar=False, norm=True,
     tiles = lib.bpx_conv3d_stats_tiles(dt, B, D, H, W, 16)
     outs = []
     n_zm = []
-    for mode in (0, 2 | (wgs << 8)):
+    for mode in (0, (2 if role_split else 6) | (wgs << 8)):
         lib.bpx_debug_set_conv_zm(mode)
         n_zm.append(lib.bpx_debug_conv_zm_launches())
         try:
@@ -370,7 +371,7 @@ def check_conv3d_zmarch(f16, B, S, Cin, sc_C=0, pool=0, planar=False, norm=True,
             torch.cuda.synchronize()
         finally:
             lib.bpx_debug_set_conv_zm(-1)
-    tag = f"conv3d_zmarch[{'f16' if f16 else 'bf16'} B{B} {S} {Cin}->16 sc={sc_C} pool={pool} planar={int(planar)} norm={int(norm)} act={act} wgs={wgs}]"
+    tag = f"conv3d_zmarch[{'f16' if f16 else 'bf16'} B{B} {S} {Cin}->16 sc={sc_C} pool={pool} planar={int(planar)} norm={int(norm)} act={act} wgs={wgs} zs={int(role_split)}]"
     res = []
     for name, a, b in zip(("y", "stats", "pooled", "pool_stats"), outs[0], outs[1]):
         res.append(_res(f"{tag}.{name}_bits_equal_lean", float((a.contiguous().view(torch.uint8) != b.contiguous().view(torch.uint8)).sum()), 0))
