@@ -1004,9 +1004,21 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
   const int n = tt / tilesPerSample, tile = tt - n * tilesPerSample;
   const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
   __syncthreads();                                   // the previous tile's reads of simg / red are done
+  // 16-bit storage (round 5): the hi + lo split happens HERE, once per halo voxel (5 values per thread), and LDS holds the pair as one word
+  // (hi in the low half); the gather below then builds the two MFMA operands with two byte permutes per pair of taps.  Before, every lane split
+  // the 8 gathered taps of each of its 8 voxels itself: 24 conversions / subtractions per m-subtile, ~40 % of the kernel's VALU work.  Same
+  // conversions of the same values: same bits.
 #pragma unroll
   for (int u = 0; u < NI; ++u)
-    if (u * 256 + tid < HV) simg[u * 256 + tid] = pi[u];
+    if (u * 256 + tid < HV) {
+      if constexpr (BF) {
+        const float f = pi[u];
+        const float hf = lo16<T>(pk16<T>(f, 0.f));
+        simg[u * 256 + tid] = __uint_as_float(pk16<T>(f, f - hf));
+      } else {
+        simg[u * 256 + tid] = pi[u];
+      }
+    }
   __syncthreads();
   if (tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1017,15 +1029,15 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
     const float* base = simg + (tz * HY + ty) * HX + tx;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (BF) {
-      float v[8], lo[8];
+      uint32_t v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = base[toff[e]];
-      u32x4_t hi = pack16<T>(v);
-      float hf[8];
-      unpack16<T>(hi, hf);
+      for (int e = 0; e < 8; ++e) v[e] = __float_as_uint(base[toff[e]]);
+      u32x4_t hi, lov;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) lo[e] = v[e] - hf[e];
-      u32x4_t lov = pack16<T>(lo);
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = __builtin_amdgcn_perm(v[2 * k + 1], v[2 * k], 0x05040100u);    // the low halves (hi parts) of taps 2k, 2k + 1
+        lov[k] = __builtin_amdgcn_perm(v[2 * k + 1], v[2 * k], 0x07060302u);   // the high halves (lo parts)
+      }
       acc = mfma_step<T>(wa, hi, acc);
       acc = mfma_step<T>(wa, lov, acc);
     } else {
@@ -1227,9 +1239,13 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
       }
     }
     __syncthreads();
+    // (round 5) the hi + lo bf16 split once per halo voxel, the pair as one LDS word (hi in the low half) - see conv_c1_fwd_kernel
 #pragma unroll
     for (int u = 0; u < NI; ++u)
-      if (u * 256 + tid < HV) simg[u * 256 + tid] = sg.pi[u];
+      if (u * 256 + tid < HV) {
+        const float f = sg.pi[u];
+        simg[u * 256 + tid] = __uint_as_float(cvt_pk_bf16(f, f - bf16lo(cvt_pk_bf16(f, 0.f))));
+      }
 #pragma unroll
     for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = piece(u, tt, sg);
     __syncthreads();
@@ -1249,15 +1265,14 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        float f[8];
+        uint32_t f[8];   // {hi | lo << 16} words; the ones row: bf16(1) = 0x3F80 with lo part 0
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = toff[b] >= 0 ? simg[hb + toff[b] + k] : ((b == 1 && i == 11) ? 1.f : 0.f);
+        for (int k = 0; k < 8; ++k) f[k] = toff[b] >= 0 ? __float_as_uint(simg[hb + toff[b] + k]) : ((b == 1 && i == 11) ? 0x3F80u : 0u);
         u32x4_t ah, al;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t h = cvt_pk_bf16(f[2 * k], f[2 * k + 1]);
-          ah[k] = h;
-          al[k] = cvt_pk_bf16(f[2 * k] - bf16lo(h), f[2 * k + 1] - bf16hi(h));
+          ah[k] = __builtin_amdgcn_perm(f[2 * k + 1], f[2 * k], 0x05040100u);
+          al[k] = __builtin_amdgcn_perm(f[2 * k + 1], f[2 * k], 0x07060302u);
         }
         acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, gf), acc[b], 0, 0, 0);
         acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, gf), acc[b], 0, 0, 0);

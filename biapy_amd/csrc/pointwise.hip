@@ -155,9 +155,13 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int nbk = p.Ncols / (16 * NS);
-  const int nb = blockIdx.x % nbk;
-  const int grp = (blockIdx.x / nbk) % p.mgroups;
-  const int n = blockIdx.x / (nbk * p.mgroups);
+  // (Round 5, measured and dropped: an XCD swizzle - workgroup i as logical id (i % 8) * (grid / 8) + i / 8, so that the 4 column blocks of a voxel
+  // group, which read the same input voxels, share one L2 instead of four.  Level 0 of cfg 2: 202 -> 225 us; levels 1-3: 56 -> 52, 28 -> 27, 17 -> 16 us.
+  // The input is 1/8 of the traffic and comes from the MALL either way; the writes of an XCD concentrated on 1/8 of the output cost more.)
+  const unsigned bid = blockIdx.x;
+  const int nb = bid % nbk;
+  const int grp = (bid / nbk) % p.mgroups;
+  const int n = bid / (nbk * p.mgroups);
   const int col_base = nb * 16 * NS;
   // PERM (transposed conv into a chunk-planar buffer, 64 columns per block, Cout % 32 == 0): the block is the x pair of sub-positions
   // (2 sp, 2 sp + 1) of the 32 channels [32 pp, 32 pp + 32), and lane row g owns 8 channels of EACH of the two 16-channel planes at
