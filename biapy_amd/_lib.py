@@ -94,6 +94,7 @@ _SIGS = {
     "bpx_debug_set_wgrad_cap": ([_i], _i),
     "bpx_debug_set_wgrad_k1": ([_i], _i),
     "bpx_debug_set_pw_stream": ([_i], _i),
+    "bpx_debug_set_convt_k1": ([_i], _i),
     "bpx_debug_set_c1_persist": ([_i], _i),
     "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),

@@ -13,6 +13,17 @@
 
 #include "bpx_common.h"
 
+// transposed-conv forward, K1STEP instance: voxel blocks whose operands are in flight ahead of the one being computed (pw_kernel)
+#ifndef BPX_PW_MS_CT
+#define BPX_PW_MS_CT 2
+#endif
+#ifndef BPX_CONVT_OCC
+#define BPX_CONVT_OCC 2                    // waves per SIMD the convt_k1_kernel is compiled for
+#endif
+#ifndef BPX_CONVT_PD
+#define BPX_CONVT_PD 2
+#endif
+
 namespace {
 
 enum { PW_CONV1 = 0, PW_CONVT = 1, PW_CONVTD = 2 };
@@ -137,6 +148,7 @@ struct PwParams {
   int t_cs, y_cs;                          // elements between 16-channel chunks of t / y: 16, or the plane of a chunk-planar tensor
   const void* addend; int addend_ld;
   float* part; int mblocks;                // voxel blocks (64 * MS voxels each) per sample
+  uint32_t y_bytes;                        // convt_k1_kernel: extent of y in bytes from p.y (buffer range)
   int mgroups;                             // CONVT: persistent workgroups per (sample, column block), each walking blocks grp, grp + mgroups, ..;
                                            // stats: [N][mgroups * 4 sz][2][Csub]; the other modes: mgroups = mblocks (one block per workgroup)
 };
@@ -188,19 +200,28 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
   // its weight fragments, re-loaded per block - also waited for the write acknowledgement of block i's stores: every iteration was
   // [load latency + store latency], 2.3 TB/s written.  With one K step (Cin = 32, the level-0 / cfg-2 case) the weights now stay in registers and the
   // operand of the NEXT block is requested BEFORE this block's stores: its wait leaves the stores outstanding.
+  // Round 5: the operands of the next PD blocks, not of one.  VMEM retires in order, so the wait for block i + 1's operand also waits for every store
+  // issued before its request: with one block ahead a wave had the stores of ONE block (4 KB) in flight, a CU of two 176-VGPR workgroups 32 KB, the
+  // chip 8 MB - at ~3 us of write latency 2.7 TB/s, which is what the launch measured (537 MB in 204 us) while a plain store loop reaches 4.8-5.2 TB/s
+  // in any lane order (scripts/probes/store_pattern_probe.hip).  The operand is 8 registers per block.
   constexpr bool PRE = MODE == PW_CONVT && K1STEP;
   constexpr bool pre = PRE;                        // (the launcher picks the instance for K <= 32)
-  u32x4_t af_pre[PRE ? MS : 1], wf_keep[PRE ? NS : 1];
-  auto prefetch = [&](int mbn) {
+  constexpr int PD = PRE ? BPX_CONVT_PD : 1;
+  u32x4_t af_pre[PD][PRE ? MS : 1], wf_keep[PRE ? NS : 1];
+  auto prefetch = [&](int mbn, auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
     for (int ms = 0; ms < (PRE ? MS : 1); ++ms) {
       const uint32_t vn = ((uint32_t)mbn * 4u + (uint32_t)wave) * (uint32_t)(MS * 16) + (uint32_t)(ms * 16 + j);
-      af_pre[ms] = u32x4_t{0u, 0u, 0u, 0u};
-      if (g * KPL < p.K && vn < (uint32_t)p.vps) af_pre[ms] = *reinterpret_cast<const u32x4_t*>(xin + ((size_t)n * p.vps + vn) * (size_t)p.x_ld + g * KPL);
+      af_pre[SL][ms] = u32x4_t{0u, 0u, 0u, 0u};
+      if (g * KPL < p.K && vn < (uint32_t)p.vps) af_pre[SL][ms] = *reinterpret_cast<const u32x4_t*>(xin + ((size_t)n * p.vps + vn) * (size_t)p.x_ld + g * KPL);
     }
   };
   if (pre) {
-    prefetch(mb);
+    prefetch(mb, std::integral_constant<int, 0>{});
+    if (PD > 1 && mb + p.mgroups < p.mblocks) prefetch(mb + p.mgroups, std::integral_constant<int, (PD > 1 ? 1 : 0)>{});
+    if (PD > 2 && mb + 2 * p.mgroups < p.mblocks) prefetch(mb + 2 * p.mgroups, std::integral_constant<int, (PD > 2 ? 2 : 0)>{});
+    if (PD > 3 && mb + 3 * p.mgroups < p.mblocks) prefetch(mb + 3 * p.mgroups, std::integral_constant<int, (PD > 3 ? 3 : 0)>{});
 #pragma unroll
     for (int ns = 0; ns < (PRE ? NS : 1); ++ns) {
       const int gq = j >> 2;
@@ -209,7 +230,31 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
       wf_keep[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)g * p.Ncols + colw) * KPL);
     }
   }
-  do {   // one pass for every mode but the transposed-conv forward (a compile-time fact: as a run-time loop it cost the 48-column GEMM 40 VGPRs and a wave per SIMD)
+  // ---- column binding of the epilogue and bias -------------------------------------------------------------------------------------
+  // MFMA row i of column block ns is bound to column col_base + (i/4)*4NS + ns*4 + i%4 (see the weight load above), so
+  // lane (g, j) ends up with the 4*NS CONSECUTIVE columns col_base + g*4NS .. of voxel j: its g / t / addend operands and
+  // its results move as 16-byte (two column quads) + 8-byte accesses, and the 4 lanes of a voxel cover 16*NS contiguous
+  // channels.
+  // Transposed-conv forward (round 5): set up ONCE, in front of the block loop.  Inside the loop the bias loads were re-issued per block - the
+  // output stores may alias them as far as the compiler knows - and sat in the VMEM queue BEHIND the prefetch of the next block's operand: the
+  // epilogue's wait for its 16 bias values was a wait for that prefetch, a full memory latency per block, whatever the depth of the operand
+  // ring.  (The single-pass modes keep the setup behind their MFMA loop: in front of it the values cost the 1x1x1 GEMMs up to a wave per SIMD.)
+  const int col0 = col_base + g * 4 * NS;        // first of this lane's columns
+  int sub = 0, co0 = col0;
+  if (MODE == PW_CONVT) { sub = col0 / p.Csub; co0 = col0 % p.Csub; }
+  if (PERM) { sub = 2 * sp + (g >> 1); co0 = pp * 32 + (g & 1) * 8; }
+  auto cof = [&](int ns) { return PERM ? co0 + (ns >> 1) * 16 + (ns & 1) * 4 : co0 + ns * 4; };   // first channel of column quad ns
+  float add[NS][4];
+  auto load_bias = [&]() {
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) add[ns][r] = p.bias ? p.bias[cof(ns) + r] : 0.f;
+  };
+  if (MODE == PW_CONVT) load_bias();
+  // one voxel block; slot_c = the operand ring slot it consumes (and refills for block mb + PD mgroups)
+  auto one_block = [&](auto slot_c) {
+  constexpr int SL = decltype(slot_c)::value;
   // voxel of lane (j) for each m-subtile
   // voxels per sample < 2^31 (checked on the host): 32-bit index math - the 64-bit div/mod sequences of the transposed-conv
   // coordinates were ~300 of the kernel's ~490 VALU instructions per wave, which bound it
@@ -266,33 +311,23 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
       u32x4_t af = u32x4_t{0u, 0u, 0u, 0u};
-      if (PRE && pre) af = af_pre[PRE ? ms : 0];
+      if (PRE && pre) af = af_pre[SL][PRE ? ms : 0];
       else if (kin && valid[ms]) af = *reinterpret_cast<const u32x4_t*>(xin + abase[ms] + koff);
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af, acc[ms][ns]);
     }
   }
-  if (PRE && pre && mb + p.mgroups < p.mblocks) prefetch(mb + p.mgroups);   // before the stores below
+  if (PRE && pre && mb + PD * p.mgroups < p.mblocks) prefetch(mb + PD * p.mgroups, slot_c);   // before the stores below
 
-  // ---- epilogue ---------------------------------------------------------------------------------------------------
-  // MFMA row i of column block ns is bound to column col_base + (i/4)*4NS + ns*4 + i%4 (see the weight load above), so
-  // lane (g, j) ends up with the 4*NS CONSECUTIVE columns col_base + g*4NS .. of voxel j: its g / t / addend operands and
-  // its results move as 16-byte (two column quads) + 8-byte accesses, and the 4 lanes of a voxel cover 16*NS contiguous
-  // channels.
-  const int col0 = col_base + g * 4 * NS;        // first of this lane's columns
-  int sub = 0, co0 = col0;
-  if (MODE == PW_CONVT) { sub = col0 / p.Csub; co0 = col0 % p.Csub; }
-  if (PERM) { sub = 2 * sp + (g >> 1); co0 = pp * 32 + (g & 1) * 8; }
-  auto cof = [&](int ns) { return PERM ? co0 + (ns >> 1) * 16 + (ns & 1) * 4 : co0 + ns * 4; };   // first channel of column quad ns
-  float add[NS][4];
+  // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+  if (MODE != PW_CONVT) load_bias();
   bpx_nbwd_coef cf[NS][4];
+  if (MODE == PW_CONV1 && p.coef) {
 #pragma unroll
-  for (int ns = 0; ns < NS; ++ns)
+    for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      add[ns][r] = p.bias ? p.bias[cof(ns) + r] : 0.f;
-      if (MODE == PW_CONV1 && p.coef) cf[ns][r] = p.coef[(size_t)n * p.Ncols + co0 + ns * 4 + r];
-    }
+      for (int r = 0; r < 4; ++r) cf[ns][r] = p.coef[(size_t)n * p.Ncols + co0 + ns * 4 + r];
+  }
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
     if (!valid[ms]) continue;
@@ -353,7 +388,27 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwParams p) {
     }
   }
 
-  } while (MODE == PW_CONVT && (mb += p.mgroups) < p.mblocks);   // voxel blocks of this workgroup
+  };   // one_block
+  // one pass for every mode but the transposed-conv forward (a compile-time fact: as a run-time loop it cost the 48-column GEMM 40 VGPRs and a wave per SIMD);
+  // the ring's slots are compile-time indices: the loop is unrolled PD times
+  if constexpr (PD == 1) {
+    do { one_block(std::integral_constant<int, 0>{}); } while (MODE == PW_CONVT && (mb += p.mgroups) < p.mblocks);
+  } else {
+    for (;;) {
+      one_block(std::integral_constant<int, 0>{});
+      if ((mb += p.mgroups) >= p.mblocks) break;
+      one_block(std::integral_constant<int, 1>{});
+      if ((mb += p.mgroups) >= p.mblocks) break;
+      if constexpr (PD > 2) {
+        one_block(std::integral_constant<int, (PD > 2 ? 2 : 0)>{});
+        if ((mb += p.mgroups) >= p.mblocks) break;
+      }
+      if constexpr (PD > 3) {
+        one_block(std::integral_constant<int, (PD > 3 ? 3 : 0)>{});
+        if ((mb += p.mgroups) >= p.mblocks) break;
+      }
+    }
+  }
 
   mb = grp;                                      // row of this workgroup's partial sums
   if (MODE == PW_CONVT && p.part != nullptr) {
@@ -514,11 +569,191 @@ __global__ void __launch_bounds__(256) pw_nbs_kernel(const PwsParams p) {
   }
 }
 
+// ---- transposed-conv forward with ONE K step into a chunk-planar buffer (round 5; level 0 of cfg 2: 32 -> 32 channels, 64^3 -> 128^3) -------------
+// The same arithmetic, column binding (pw_kernel's PERM form) and statistics rows as pw_kernel<T, MS, 4, PW_CONVT, true>, as a loop WITHOUT BRANCHES.
+// In pw_kernel the operand loads and the stores sit in predicated blocks (voxels beyond the volume, K < 32 lanes) and behind a run-time K loop; at
+// every such join the compiler's wait-count pass gives up and emits `s_waitcnt vmcnt(0)` - a wave's VMEM operations retire in order, so that is a
+// wait for every store issued so far: each block was [operand latency + write latency], 2.6 TB/s written where a plain store loop reaches 4.8-6.5
+// (scripts/probes/store_pattern_probe.hip), and a deeper operand ring changed nothing.  Here operands and results move through BUFFER instructions:
+// a lane that has nothing to load / store uses an out-of-range offset (loads return zeros, stores are dropped), there is no branch between the
+// loop head and its end, the waits are counted ones, and the operands of the next PD blocks are in flight across the stores.
+template <typename T>
+__global__ void __launch_bounds__(256, BPX_CONVT_OCC) convt_k1_kernel(const PwParams p) {
+  constexpr int MS = BPX_PW_MS_CT, NS = 4, KPL = 8, PD = BPX_CONVT_PD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int nbk = p.Ncols / 64;
+  const int nb = blockIdx.x % nbk;
+  const int grp = (blockIdx.x / nbk) % p.mgroups;
+  const int n = blockIdx.x / (nbk * p.mgroups);
+  const int ppb = p.Csub / 32;
+  const int sp = nb / ppb, pp = nb - sp * ppb;
+  const int sub = 2 * sp + (g >> 1), co0 = pp * 32 + (g & 1) * 8;          // this lane's sub-position and first channel (8 of each of two planes)
+  const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+  u32x4_t wf[NS];
+  f32x2_t add[NS][2];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int gq = j >> 2;
+    const int colw = (2 * sp + (gq >> 1)) * p.Csub + pp * 32 + (ns >> 1) * 16 + (gq & 1) * 8 + (ns & 1) * 4 + (j & 3);
+    wf[ns] = *reinterpret_cast<const u32x4_t*>(wp + ((size_t)g * p.Ncols + colw) * KPL);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = co0 + (ns >> 1) * 16 + (ns & 1) * 4 + 2 * h;
+      add[ns][h] = p.bias ? f32x2_t{p.bias[c], p.bias[c + 1]} : f32x2_t{0.f, 0.f};
+    }
+  }
+  // Addresses: W % 16 == 0 (host-checked), so the 16 voxels of an m-subtile are one run of an x row, all inside or all outside the sample: the
+  // (x, y, z) of the run's first voxel is WAVE-UNIFORM - kept in scalar registers and advanced by a fixed (dx, dy, dz) per block, no division in
+  // the loop - and goes into the buffer instructions' scalar offset; the lane's share of the address is a constant.  (pw_kernel derives the
+  // coordinates per lane and block: two 32-bit divisions per m-subtile, a third of its VALU work.)
+  const uint32_t xrow = (uint32_t)p.x_ld * 2u;                              // bytes per input voxel
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(reinterpret_cast<const T*>(p.x) + (size_t)n * p.vps * p.x_ld), 0, (int)((uint32_t)p.vps * xrow), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+  const uint32_t OOB = 0xFFFFFFF0u;
+  const uint32_t xlane = (g * KPL < p.K) ? (uint32_t)j * xrow + (uint32_t)(g * 16) : OOB;   // lanes beyond K read zeros
+  const uint32_t W2 = 2u * (uint32_t)p.W, H2 = 2u * (uint32_t)p.H;
+  const uint32_t yvox = (uint32_t)p.y_ld * 2u;                              // bytes per output voxel of one plane
+  const uint32_t yplane = (uint32_t)p.y_cs * 2u;
+  const uint32_t a_ = (sub >> 2) & 1, b_ = (sub >> 1) & 1, c_ = sub & 1;
+  const uint32_t ylane = ((a_ * H2 + b_) * W2 + 2u * (uint32_t)j + c_) * yvox + ((uint32_t)(co0 >> 4) * (uint32_t)p.y_cs + (uint32_t)(co0 & 15)) * 2u;
+  const uint32_t zbase = (uint32_t)n * (uint32_t)(p.sz * p.D);
+  const uint32_t uW = (uint32_t)p.W, uH = (uint32_t)p.H;
+  const uint32_t bstep = (uint32_t)p.mgroups * 4u * (uint32_t)(MS * 16);    // voxels between consecutive blocks of this workgroup
+  uint32_t vb = ((uint32_t)grp * 4u + (uint32_t)wave) * (uint32_t)(MS * 16);   // first voxel of this wave in the current block (uniform)
+  uint32_t x0, y0, z0;
+  { const uint32_t row = vb / uW; x0 = vb - row * uW; z0 = row / uH; y0 = row - z0 * uH; }
+  uint32_t dx, dy, dz;
+  { const uint32_t row = bstep / uW; dx = bstep - row * uW; dz = row / uH; dy = row - dz * uH; }
+  x0 = __builtin_amdgcn_readfirstlane(x0); y0 = __builtin_amdgcn_readfirstlane(y0); z0 = __builtin_amdgcn_readfirstlane(z0);
+  dx = __builtin_amdgcn_readfirstlane(dx); dy = __builtin_amdgcn_readfirstlane(dy); dz = __builtin_amdgcn_readfirstlane(dz);
+  u32x4_t af[PD][MS];
+  auto request = [&](uint32_t vbn, auto slot_c) {       // operands of the block whose first voxel (of this wave) is vbn
+    constexpr int SL = decltype(slot_c)::value;
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      const uint32_t v = vbn + (uint32_t)(ms * 16);
+      const bool in = v < (uint32_t)p.vps;                                  // (uniform)
+      af[SL][ms] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(in ? xlane : OOB), (int)(in ? v * xrow : 0u), 0));
+    }
+  };
+  f32x2_t s1[NS][2], s2[NS][2];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) s1[ns][h] = s2[ns][h] = f32x2_t{0.f, 0.f};
+  auto one_block = [&](auto slot_c) {
+    constexpr int SL = decltype(slot_c)::value;
+    f32x4_t acc[MS][NS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(wf[ns], af[SL][ms], f32x4_t{0.f, 0.f, 0.f, 0.f});
+    request(vb + (uint32_t)PD * bstep, slot_c);                             // (beyond the sample: out of range, zeros nobody reads)
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      // the run's first voxel: (x0 + 16 ms, y0, z0) with one carry (16 ms <= W)
+      uint32_t x = x0 + (uint32_t)(ms * 16), y = y0, z = z0;
+      if (x >= uW) { x -= uW; if (++y >= uH) { y -= uH; ++z; } }
+      const bool valid = vb + (uint32_t)(ms * 16) < (uint32_t)p.vps;        // (uniform)
+      const uint32_t srun = (((zbase + (uint32_t)p.sz * z) * H2 + 2u * y) * W2 + 2u * x) * yvox;
+      f32x2_t val[NS][2];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) val[ns][h] = f32x2_t{acc[ms][ns][2 * h], acc[ms][ns][2 * h + 1]} + add[ns][h];
+      if (valid) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            s1[ns][h] = s1[ns][h] + val[ns][h];
+            s2[ns][h] = s2[ns][h] + val[ns][h] * val[ns][h];
+          }
+      }
+      uint32_t pk[NS][2];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2_t w2 = val[ns][h];
+          const float lo = w2[0], hi = w2[1];
+          pk[ns][h] = pk16s<T>(lo, hi);
+        }
+      const u32x4_t q0{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+      const u32x4_t q1{pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
+      // The run's offset goes into the VECTOR offset of the stores (one v_add each), not into their scalar offset: with an SGPR soffset hipcc 7.2
+      // leaves out the wait states between a 128-bit buffer store and a VALU write of its data registers (its hazard recogniser assumes the
+      // hazard away for a register soffset; on gfx950 it is there) - the next m-subtile's v_pk_add overwrote two of the four data registers and
+      // the fp16 output held fp32 halves (NaNs; the bf16 instance happened to allocate differently).  The loads have no data registers to lose.
+      __builtin_amdgcn_raw_buffer_store_b128(q0, rs_y, (int)(valid ? ylane + srun : OOB), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(q1, rs_y, (int)(valid ? ylane + srun + yplane : OOB), 0, 0);
+    }
+    // the next block of this workgroup
+    vb += bstep;
+    x0 += dx; uint32_t cy = 0u, cz = 0u;
+    if (x0 >= uW) { x0 -= uW; cy = 1u; }
+    y0 += dy + cy;
+    if (y0 >= uH) { y0 -= uH; cz = 1u; }
+    z0 += dz + cz;
+  };
+  // The prologue issues what a steady-state block issues - a request, then 2 MS stores (out of range: dropped by the hardware, but counted) - so
+  // that the wait count the compiler derives at the loop head for "slot 0 has landed" is the steady state's (2 (PD - 1) MS loads + 2 PD MS stores
+  // may stay in flight) and not the entry path's: the count at a join is the smaller one, and with a bare prologue the first block of every
+  // PD-block trip waited for all but 2 PD MS - 1 operations, i.e. for the stores of the whole previous trip.
+  auto dummy_stores = [&](int k) {   // (distinct out-of-range offsets: identical stores would be merged; y_bytes < 0xFFFFFF00, host-checked)
+#pragma unroll
+    for (int q = 0; q < 2 * MS; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, rs_y, (int)(0xFFFFFF00u + (uint32_t)(((k * 2 * MS + q) & 15) * 16)), 0, 0);
+  };
+  request(vb, std::integral_constant<int, 0>{});
+  dummy_stores(0);
+  if (PD > 1) { request(vb + bstep, std::integral_constant<int, (PD > 1 ? 1 : 0)>{}); dummy_stores(1); }
+  if (PD > 2) { request(vb + 2u * bstep, std::integral_constant<int, (PD > 2 ? 2 : 0)>{}); dummy_stores(2); }
+  if (PD > 3) { request(vb + 3u * bstep, std::integral_constant<int, (PD > 3 ? 3 : 0)>{}); dummy_stores(3); }
+  // full trips of PD blocks in a loop with ONE back edge, the last 0 .. PD - 1 blocks behind it.  (With an exit test after every block the exits
+  // share a latch block that also leads back to the loop head, and along that path - never taken back, but the wait counts are static - only the
+  // operations of ONE block follow slot 0's request: the head's wait became vmcnt(5) instead of vmcnt(17).)
+  const int nblk = (p.mblocks - grp + p.mgroups - 1) / p.mgroups;
+  int t = 0;
+  for (; t + PD <= nblk; t += PD) {
+    one_block(std::integral_constant<int, 0>{});
+    if constexpr (PD > 1) one_block(std::integral_constant<int, (PD > 1 ? 1 : 0)>{});
+    if constexpr (PD > 2) one_block(std::integral_constant<int, (PD > 2 ? 2 : 0)>{});
+    if constexpr (PD > 3) one_block(std::integral_constant<int, (PD > 3 ? 3 : 0)>{});
+  }
+  if (t < nblk) { one_block(std::integral_constant<int, 0>{}); ++t; }
+  if (PD > 2 && t < nblk) { one_block(std::integral_constant<int, (PD > 1 ? 1 : 0)>{}); ++t; }
+  if (PD > 3 && t < nblk) { one_block(std::integral_constant<int, (PD > 2 ? 2 : 0)>{}); ++t; }
+  if (p.part != nullptr) {   // one partial row per workgroup, pw_kernel's layout and summation order
+    __shared__ float red[4 * NS * 16 * 2];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[ns][r >> 1][r & 1]), b = row16_sum(s2[ns][r >> 1][r & 1]);
+        if (j == 0) {
+          red[((wave * NS * 16) + g * 4 * NS + ns * 4 + r) * 2 + 0] = a;
+          red[((wave * NS * 16) + g * 4 * NS + ns * 4 + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < NS * 16 * 2) {
+      const int c = tid >> 1, k = tid & 1;
+      const float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] + red[(3 * NS * 16 + c) * 2 + k];
+      const int gg = c >> 4, ns = (c >> 2) & 3;
+      const int sub_c = 2 * sp + (gg >> 1);
+      const int co = pp * 32 + (ns >> 1) * 16 + (gg & 1) * 8 + (ns & 1) * 4 + (c & 3);
+      p.part[((((size_t)n * p.mgroups + grp) * (4 * p.sz) + sub_c) * 2 + k) * p.Csub + co] = a;
+    }
+  }
+}
+
 int g_pw_stream = 1;   // bpx_debug_set_pw_stream
+int g_convt_k1 = -1;   // bpx_debug_set_convt_k1: -1 = environment (BPX_CONVT_K1, default on), 0 = pw_kernel, 1 = convt_k1_kernel where it applies
 constexpr int PW_MS = 2;  // 4 waves x 2 x 16 = 128 voxels per workgroup
-#ifndef BPX_PW_MS_CT
-#define BPX_PW_MS_CT 2
-#endif
 constexpr int PW_MS_CT = BPX_PW_MS_CT;   // the same for the transposed-conv forward.  Measured (32 -> 32 channels, 64^3 -> 128^3, planar output):
                                          // 1 (78 VGPRs, 5 waves / SIMD) 266 us, 2 266 us, 4 (162 VGPRs) 271 us - neither tile size nor residency binds
 
@@ -540,8 +775,19 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
   if (MODE == PW_CONVT && planar && ns == 4 && p.Csub % 32 != 0) { bpx_set_error("transposed conv: the 64-column planar form needs Cout % 32 == 0"); return 1; }
   if (MODE != PW_CONVTD && planar) {
     constexpr bool PL = MODE != PW_CONVTD;    // no planar instances of the transposed-conv dgrad
-    if (ns == 4 && MODE == PW_CONVT && sizeof(T) == 2 && p.K * (int)sizeof(T) <= 64) pw_kernel<T, MSK, 4, MODE, PL, TT, MODE == PW_CONVT && sizeof(T) == 2><<<grid, 256, 0, s>>>(p);
-    else if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
+    if constexpr (MODE == PW_CONVT && sizeof(T) == 2) {
+      // one K step: the branch-free buffer-addressed kernel when x (per sample) and y lie within 32-bit byte offsets of their bases
+      const int64_t ovox = (int64_t)p.N * p.vps * 4 * p.sz;
+      const int64_t ybytes = ((int64_t)(p.Csub / 16 - 1) * p.y_cs + (ovox - 1) * p.y_ld + 16) * 2;
+      static const bool k1_env = getenv("BPX_CONVT_K1") == nullptr || atoi(getenv("BPX_CONVT_K1")) != 0;   // A/B: BPX_CONVT_K1=0 = pw_kernel
+      const bool k1 = g_convt_k1 < 0 ? k1_env : g_convt_k1 != 0;
+      if (k1 && ns == 4 && p.K * 2 <= 64 && p.W % 16 == 0 && p.vps * p.x_ld * 2 < 0xFFFFFF00ll && ybytes < 0xFFFFFF00ll) {
+        p.y_bytes = (uint32_t)ybytes;
+        convt_k1_kernel<T><<<grid, 256, 0, s>>>(p);
+        return 0;
+      }
+    }
+    if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else if (ns == 3) pw_kernel<T, MSK, 3, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else if (ns == 2) pw_kernel<T, MSK, 2, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else pw_kernel<T, MSK, 1, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
@@ -565,6 +811,7 @@ int chk(const char* fn, const char* name, const bpx_tensor& t, int es) {
 }  // namespace
 
 extern "C" int bpx_debug_set_pw_stream(int on) { g_pw_stream = on; return 0; }
+extern "C" int bpx_debug_set_convt_k1(int on) { g_convt_k1 = on; return 0; }
 extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return convt_groups((int64_t)D * H * W) * 4 * (sz == 1 ? 1 : 2); }
 
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,

@@ -574,6 +574,43 @@ def check_convT(dt, B, S, Cc, seed=0, sz=2, Cout=None):
     return res
 
 
+def check_convT_planar_k1(dt, B, S, Cin, Cout, sz=2, seed=0):
+    """Round 5: the transposed-conv forward with ONE K step (Cin <= 32) into channels [0, Cout) of a chunk-planar concat buffer - the branch-free
+    buffer-addressed kernel (convt_k1_kernel: scalar run coordinates, out-of-range offsets instead of predicates) against the general kernel on
+    the same operands: output planes, the untouched skip plane and the statistics rows BIT-IDENTICAL; and against torch."""
+    D, H, W = S
+    T = tdtype(dt)
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(B, D, H, W, Cin, generator=g), dt)
+    w = torch.randn(Cin, Cout, sz, 2, 2, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    y_ref = ndhwc(F.conv_transpose3d(ncdhw(x), rnd(w, dt), b, stride=(sz, 2, 2)))
+    wp = pack(w, L.PK_CT if sz == 2 else L.PK_CT4, Cin, Cout, dt)
+    xd, bd = to_dev(x, dt), b.to(DEV)
+    S2 = (sz * D, 2 * H, 2 * W)
+    tiles = lib.bpx_convT3d_stats_tiles(D, H, W, sz)
+    outs = []
+    for k1 in (0, 1):
+        lib.bpx_debug_set_convt_k1(k1)
+        try:
+            cat = L.Planar(B, S2, Cout + 16, T, DEV)
+            cat.t.fill_(3.0)
+            part = torch.zeros(B, tiles, 2, Cout, dtype=torch.float32, device=DEV)
+            L.check(lib.bpx_convT3d_k2s2_fwd(dt, B, D, H, W, sz, L.tview(xd), wp.data_ptr(), bd.data_ptr(), L.tview(cat, 0, Cout), part.data_ptr(), L.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append((cat.dense(), part))
+        finally:
+            lib.bpx_debug_set_convt_k1(-1)
+    tag = f"convT_planar_k1[{'f16' if dt == L.F16 else 'bf16'} B{B} {S} C{Cin}->{Cout} sz{sz}]"
+    res = [_res(tag + ".y_bits_equal_general_kernel", float((outs[0][0].view(torch.uint8) != outs[1][0].view(torch.uint8)).sum()), 0),
+           _res(tag + ".stats_bits_equal_general_kernel", float((outs[0][1].view(torch.uint8) != outs[1][1].view(torch.uint8)).sum()), 0),
+           _res(tag + ".fwd_vs_torch", relerr(outs[1][0][..., :Cout], y_ref), tol_for(dt)),
+           _res(tag + ".skip_plane_untouched", 0 if (outs[1][0][..., Cout:].float() == 3).all().item() else 1, 0)]
+    s_ref = torch.stack([y_ref.sum((1, 2, 3)), (y_ref * y_ref).sum((1, 2, 3))], 1)
+    res.append(_res(tag + ".stats_vs_torch", relerr(outs[1][1].sum(1), s_ref), 5e-3))
+    return res
+
+
 def check_norm_pool_head(dt, seed=0):
     res = []
     g = torch.Generator().manual_seed(seed)

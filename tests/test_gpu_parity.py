@@ -203,6 +203,23 @@ def test_pointwise_and_transposed_conv(K, dt):
     _assert_all(rows)
 
 
+def test_transposed_conv_one_k_step_kernel_is_bit_identical_to_the_general_kernel(K):
+    """Round 5: convt_k1_kernel (level 0 of cfg 2: 32 -> 32 channels into the planar concat buffer) - full and ragged block counts, batches,
+    16- and 32-channel inputs (lanes beyond K read zeros), 64 output channels (two column blocks per sub-position), the (1, 2, 2) kernel of the
+    anisotropic levels, widths of one and several 16-voxel runs per row."""
+    from biapy_amd import _lib as L
+    rows = []
+    rows += K.check_convT_planar_k1(L.F16, 2, (8, 8, 16), 32, 32)
+    rows += K.check_convT_planar_k1(L.BF16, 1, (16, 16, 32), 32, 32)
+    rows += K.check_convT_planar_k1(L.F16, 3, (5, 7, 48), 32, 32)             # 1680 voxels per sample: a ragged last block, carries in y and z
+    rows += K.check_convT_planar_k1(L.F16, 2, (6, 10, 16), 16, 32)            # K = 16
+    rows += K.check_convT_planar_k1(L.BF16, 2, (4, 6, 32), 32, 64)            # two 32-channel column blocks per sub-position
+    rows += K.check_convT_planar_k1(L.F16, 2, (3, 12, 64), 32, 32, sz=1)      # anisotropic level
+    rows += K.check_convT_planar_k1(L.F16, 1, (32, 32, 32), 32, 32)           # more blocks than persistent workgroups
+    _assert_all(rows)
+
+
+
 @pytest.mark.parametrize("dt", [0, 1], ids=["f32", "bf16"])
 def test_norm_pool_head_first_layer(K, dt):
     _assert_all(K.check_norm_pool_head(dt))
