@@ -946,10 +946,16 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(const TX* __restrict__ x,
 // Implicit GEMM with K = 27 taps (padded to 32 / 28): the image halo tile sits in LDS as fp32, a lane gathers the taps
 // of its voxel straight from it.  bf16 storage: the fp32 image value is split into hi + lo bf16 parts (two MFMAs) so the
 // raw input keeps ~16 mantissa bits; the weights are rounded to bf16 like every other layer in that mode.
-template <typename T>
+// BUF (round 5): image and output move through BUFFER instructions - a halo voxel outside the volume / a tile beyond the launch's range / an output
+// voxel outside the volume uses an out-of-range offset (loads return the zero padding, stores are dropped) instead of a predicate.  With predicated
+// loads the compiler's wait at the loop head for the prefetched halo was `s_waitcnt vmcnt(0)` (its wait-count pass gives up at the joins of the
+// bounds tests), i.e. a wait for the previous tile's 8 stores as well - what the prefetch-before-the-stores order was meant to avoid; now the
+// wait is a counted one that leaves the stores in flight.  The launcher takes BUF when image and output lie within 32-bit byte offsets.
+template <typename T, bool BUF>
 __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w /* (Cout,1,27) */,
                                                           const float* __restrict__ bias, T* __restrict__ y, int y_ld, int Cout, int D,
-                                                          int H, int W, int tilesY, int tilesX, int tilesPerSample, float* __restrict__ part, int totalTiles) {
+                                                          int H, int W, int tilesY, int tilesX, int tilesPerSample, float* __restrict__ part, int totalTiles,
+                                                          uint32_t img_bytes, uint32_t y_bytes) {
   constexpr bool BF = sizeof(T) == 2;   // 16-bit storage (bf16 bits or fp16): hi + lo split of the fp32 image, two MFMAs
   constexpr int TZ = 4, TY = 8, TX = 16, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX, MS = 8;
   __shared__ float simg[HV];
@@ -962,18 +968,47 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
   // those loads then leaves the stores outstanding; weights / tap offsets / bias are set up once.
   constexpr int NI = (HV + 255) / 256;
   float pi[NI];
-  auto issue = [&](int tt) {
-    const int n_ = tt / tilesPerSample, tile_ = tt - n_ * tilesPerSample;
-    const int x0_ = (tile_ % tilesX) * TX, y0_ = ((tile_ / tilesX) % tilesY) * TY, z0_ = (tile_ / (tilesX * tilesY)) * TZ;
+  const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)y_bytes, 0x00020000);
+  // BUF: the halo voxel (hz, hy, hx) a thread stages is the same for every tile - its coordinates (one packed word per piece) and its offset
+  // relative to the tile's first voxel are set up once; a tile costs three unsigned range tests and one add per piece.  (As written for the
+  // pointer-addressed instance - the divisions by HX / HY inside the tile loop - the five requests were 200 of the loop's 1060 instructions, and
+  // the kernel is bound by instruction issue: ~1000 instructions per tile and wave = the 105 us it takes.)
+  uint32_t hpk[BUF ? NI : 1];
+  int hrel[BUF ? NI : 1];
+  if constexpr (BUF) {
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
       const int i = u * 256 + tid;
       const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
-      const int z = z0_ + hz - 1, yy = y0_ + hy - 1, x = x0_ + hx - 1;
-      pi[u] = (i < HV && z >= 0 && z < D && yy >= 0 && yy < H && x >= 0 && x < W) ? img[(((size_t)n_ * D + z) * H + yy) * W + x] : 0.f;
+      hpk[u] = i < HV ? (uint32_t)(hz | (hy << 8) | (hx << 16)) : 0xFFFFFFFFu;
+      hrel[u] = ((hz - 1) * H + (hy - 1)) * W + (hx - 1);
+    }
+  }
+  auto issue = [&](int tt) {
+    const int n_ = tt / tilesPerSample, tile_ = tt - n_ * tilesPerSample;
+    const int x0_ = (tile_ % tilesX) * TX, y0_ = ((tile_ / tilesX) % tilesY) * TY, z0_ = (tile_ / (tilesX * tilesY)) * TZ;
+    if constexpr (BUF) {
+      const int base = ((n_ * D + z0_) * H + y0_) * W + x0_;
+      const bool live = tt < totalTiles;
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        // z0 + hz - 1 in [0, D) <=> (unsigned)(z0 - 1 + hz) < D; a piece beyond the halo has hz = 255: out of every volume the launcher admits
+        const uint32_t z = (uint32_t)(z0_ - 1) + (hpk[u] & 255u), yy = (uint32_t)(y0_ - 1) + ((hpk[u] >> 8) & 255u), x = (uint32_t)(x0_ - 1) + (hpk[u] >> 16);
+        const bool in = live && hpk[u] != 0xFFFFFFFFu && z < (uint32_t)D && yy < (uint32_t)H && x < (uint32_t)W;
+        pi[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, (int)(in ? (uint32_t)(base + hrel[u]) * 4u : 0xFFFFFFF0u), 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int i = u * 256 + tid;
+        const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
+        const int z = z0_ + hz - 1, yy = y0_ + hy - 1, x = x0_ + hx - 1;
+        pi[u] = (i < HV && z >= 0 && z < D && yy >= 0 && yy < H && x >= 0 && x < W) ? img[(((size_t)n_ * D + z) * H + yy) * W + x] : 0.f;
+      }
     }
   };
-  if ((int)blockIdx.x < totalTiles) issue(blockIdx.x);
+  if (BUF || (int)blockIdx.x < totalTiles) issue(blockIdx.x);
   // weight operand of this lane: output channel cb + j, taps 8g..8g+7 (bf16) or 4s+g (f32)
   u32x4_t wa = u32x4_t{0u, 0u, 0u, 0u};
   float wf32[7];
@@ -1020,8 +1055,12 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
       }
     }
   __syncthreads();
-  if (tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);
+  if (BUF || tt + (int)gridDim.x < totalTiles) issue(tt + gridDim.x);   // (BUF: a tile beyond the range requests nothing - every lane out of range)
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t ybase = ((uint32_t)(((n * D + z0 + wave) * H + y0) * W + x0 + j) * (uint32_t)y_ld + (uint32_t)(cb + 4 * g)) * (uint32_t)sizeof(T);
+  const uint32_t yrowb = (uint32_t)(W * y_ld) * (uint32_t)sizeof(T);
+  const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;       // (uniform)
+  f32x2_t p1[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}}, p2[2] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};   // BUF: s1 / s2 as pairs
 #pragma unroll
   for (int ms = 0; ms < MS; ++ms) {
     int t = (wave * MS + ms) * 16 + j;
@@ -1045,7 +1084,20 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
       for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf32[s], base[toff[s]], acc, 0, 0, 0);
     }
     int z = z0 + tz, yy = y0 + ty, x = x0 + tx;
-    if (z < D && yy < H && x < W) {
+    const bool inside = z < D && yy < H && x < W;
+    if constexpr (BUF) {
+      // (packed fp32 pairs: the same additions / multiplications, half the instructions; the outside-the-volume select only on a partial tile)
+      const f32x2_t va = f32x2_t{acc[0], acc[1]} + f32x2_t{bsv[0], bsv[1]}, vb = f32x2_t{acc[2], acc[3]} + f32x2_t{bsv[2], bsv[3]};
+      const float v4[4] = {va[0], va[1], vb[0], vb[1]};
+      f32x2_t sa = va, sb = vb;
+      if (!full && !inside) sa = sb = f32x2_t{0.f, 0.f};
+      p1[0] = p1[0] + sa; p1[1] = p1[1] + sb;
+      p2[0] = p2[0] + sa * sa; p2[1] = p2[1] + sb * sb;
+      // (t = (wave MS + ms) 16 + j: tz = wave, ty = ms, tx = j - the voxel's offset is the m-subtile-0 offset of this lane + ms rows)
+      const uint32_t off = inside ? ybase + (uint32_t)ms * yrowb : 0xFFFFFFF0u;
+      if constexpr (BF) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pk16s<T>(v4[0], v4[1]), pk16s<T>(v4[2], v4[3])}, rs_y, (int)off, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v4[0]), __float_as_uint(v4[1]), __float_as_uint(v4[2]), __float_as_uint(v4[3])}, rs_y, (int)off, 0, 0);
+    } else if (inside) {
       float v4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v4[r] = acc[r] + bsv[r]; s1[r] += v4[r]; s2[r] += v4[r] * v4[r]; }
@@ -1055,11 +1107,16 @@ __global__ void __launch_bounds__(256) conv_c1_fwd_kernel(const float* __restric
     }
   }
   if (part) {
+    if constexpr (BUF) {
+      const f32x2_t q0 = p1[0], q1 = p1[1], q2 = p2[0], q3 = p2[1];   // (copies first: elements of an array of vectors, see bpx_common.h)
+      s1[0] = q0[0]; s1[1] = q0[1]; s1[2] = q1[0]; s1[3] = q1[1];
+      s2[0] = q2[0]; s2[1] = q2[1]; s2[2] = q3[0]; s2[3] = q3[1];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float a = s1[r], b = s2[r];
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+      // (row16_sum pairs lanes as the xor butterfly it replaces did - 1, 2, then the other quad of the half, then the other half - the same
+      //  additions of the same values: same bits; four DPP adds instead of four cross-lane shuffles each)
+      const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
       if (j == 0) { red[wave][4 * g + r] = a; red[wave][16 + 4 * g + r] = b; }
     }
     __syncthreads();
@@ -2422,7 +2479,8 @@ extern "C" int bpx_head_bwd(int dtype, int64_t vps, int N, bpx_tensor x, const f
 }
 
 static int g_c1_persist = 2048;   // persistent workgroups of the first-layer forward (bpx_debug_set_c1_persist; 0 = one workgroup per tile, as until round 3)
-extern "C" int bpx_debug_set_c1_persist(int wgs) { g_c1_persist = wgs; return 0; }
+static int g_c1_nobuf = 0;        // bit 30 of the hook's argument: the pointer-addressed instance (tests / A-B of the buffer-addressed one)
+extern "C" int bpx_debug_set_c1_persist(int wgs) { g_c1_nobuf = (wgs >> 30) & 1; g_c1_persist = wgs & 0x3FFFFFFF; return 0; }
 extern "C" int bpx_conv3d_c1_stats_tiles(int D, int H, int W) { return cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16); }
 
 extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const float* img_d, const float* w_d, const float* bias_d,
@@ -2436,10 +2494,16 @@ extern "C" int bpx_conv3d_c1_fwd(int dtype, int N, int D, int H, int W, const fl
   const int total = tiles * N;
   dim3 grid((unsigned)std::min(total, g_c1_persist > 0 ? g_c1_persist : total), (unsigned)(y.C / 16));   // persistent: 8 workgroups per CU
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == BPX_BF16) conv_c1_fwd_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (uint16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total);
-  else if (dtype == BPX_F16) conv_c1_fwd_kernel<f16_t><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (f16_t*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total);
-  else if (dtype == BPX_F32) conv_c1_fwd_kernel<float><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (float*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total);
-  else BPX_FAIL("%s: dtype must be BF16 or F32", fn);
+  BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F16 || dtype == BPX_F32, "%s: dtype must be BF16, F16 or F32", fn);
+  // the buffer-addressed instance when image and output lie within 32-bit byte offsets of their bases (A/B and tests: bpx_debug_set_c1_persist bit 30 clears it)
+  const int64_t vox = (int64_t)N * D * H * W;
+  const int64_t ib = vox * 4, yb = vox * y.ld * (int64_t)dtype_size(dtype);
+  const bool buf = !g_c1_nobuf && ib < 0xFFFFFF00ll && yb < 0xFFFFFF00ll;
+#define C1F(T_, B_) conv_c1_fwd_kernel<T_, B_><<<grid, 256, 0, s>>>(img_d, w_d, bias_d, (T_*)y.ptr, y.ld, y.C, D, H, W, tY, tX, tiles, stats_part_d, total, (uint32_t)ib, (uint32_t)yb)
+  if (dtype == BPX_BF16) { if (buf) C1F(uint16_t, true); else C1F(uint16_t, false); }
+  else if (dtype == BPX_F16) { if (buf) C1F(f16_t, true); else C1F(f16_t, false); }
+  else { if (buf) C1F(float, true); else C1F(float, false); }
+#undef C1F
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -55,7 +55,7 @@ int bpx_debug_set_conv_occ(int wg_per_cu); /* test / A-B hook: persistent workgr
 int bpx_debug_set_conv_zm(int mode);       /* test / A-B hook of the z-marching forward kernel of the 16-output-channel layers (conv3d_zmarch.hip; same bits as the lean kernel): -1 = environment BPX_CONV_ZM (default 1), 0 = off, 1 = where a run has several z-steps, 2 = wherever the shape admits it; + 4 = without the role-split form (conv3_zs_kernel) of the one-chunk layers; bits 8.. (tests) = cap on the number of workgroups */
 int bpx_debug_conv_zm_launches(void);      /* tests: how many launches took the z-marching kernel so far */
 int bpx_debug_conv_zm_occupancy(int nch);  /* tests: resident workgroups per CU of the z-marching kernel (1 or 3 input chunks; 0 = its role-split form of 512 threads) as the runtime computes it; -1 = query failed */
-int bpx_debug_set_c1_persist(int wgs); /* test / A-B hook: persistent workgroups of bpx_conv3d_c1_fwd (default 2048; 0 = one workgroup per tile) */
+int bpx_debug_set_c1_persist(int wgs); /* test / A-B hook: persistent workgroups of bpx_conv3d_c1_fwd (default 2048; 0 = one workgroup per tile); + 2^30 = the pointer-addressed instance instead of the buffer-addressed one (same bits) */
 int bpx_debug_set_convt_k1(int on);  /* test / A-B hook of the transposed-conv forward with one K step into a chunk-planar buffer: -1 = environment BPX_CONVT_K1 (default 1), 1 = the branch-free buffer-addressed kernel where it applies (W % 16 == 0, operands within 32-bit offsets), 0 = the general kernel; same bits */
 int bpx_debug_set_pw_stream(int on); /* test / A-B hook: 1 (default) = the streaming kernel for bpx_conv1x1_fwd_split with the IN-backward affine at the large levels, 0 = the tile kernel */
 int bpx_debug_set_wgrad_k1(int on); /* test / A-B hook of the streaming weight-gradient kernels at the large levels: 1 (default) = both on, 0 = the tile kernels, 3 = streaming k = 1 (raw-input shortcut) only, 5 = streaming transposed-conv only, 7 = both and the 32 -> 32 transposed-conv instance too (measured slower than its tile kernel) */

@@ -574,6 +574,39 @@ def check_convT(dt, B, S, Cc, seed=0, sz=2, Cout=None):
     return res
 
 
+def check_c1_fwd_buffer_vs_pointer(dt, B, S, Cout=16, ld_extra=0, persist=2048, seed=0):
+    """Round 5: the first layer's buffer-addressed instance (out-of-range offsets for the zero padding, for tiles beyond the launch and for output
+    voxels outside the volume) against the pointer-addressed one (hook bit 30): output (with its neighbours in a wider buffer), statistics rows -
+    BIT-IDENTICAL; and against torch.  persist: workgroup cap, so that a run covers several tiles per workgroup on a small volume."""
+    D, H, W = S
+    T = tdtype(dt)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, D, H, W, generator=g)
+    w1 = torch.randn(Cout, 1, 3, 3, 3, generator=g) * 0.2
+    b1 = torch.randn(Cout, generator=g) * 0.1
+    y_ref = ndhwc(F.conv3d(img[:, None], rnd(w1, dt), b1, padding=1))
+    imgd, w1_d, b1_d = img.to(DEV).contiguous(), w1.to(DEV), b1.to(DEV)
+    tiles = lib.bpx_conv3d_c1_stats_tiles(D, H, W)
+    outs = []
+    for flag in (1 << 30, 0):
+        lib.bpx_debug_set_c1_persist(persist | flag)
+        try:
+            yb = torch.full((B, D, H, W, Cout + ld_extra), 3.0, dtype=T, device=DEV)
+            part = torch.zeros(B, tiles, 2, Cout, dtype=torch.float32, device=DEV)
+            L.check(lib.bpx_conv3d_c1_fwd(dt, B, D, H, W, imgd.data_ptr(), w1_d.data_ptr(), b1_d.data_ptr(), L.tview(yb, 0, Cout), part.data_ptr(), L.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append((yb, part))
+        finally:
+            lib.bpx_debug_set_c1_persist(2048)
+    tag = f"c1_fwd_buffer[{ {L.F16: 'f16', L.BF16: 'bf16'}.get(dt, 'f32') } B{B} {S} C{Cout}+{ld_extra} wgs{persist}]"
+    res = [_res(tag + ".y_bits_equal_pointer_instance", float((outs[0][0].view(torch.uint8) != outs[1][0].view(torch.uint8)).sum()), 0),
+           _res(tag + ".stats_bits_equal_pointer_instance", float((outs[0][1].view(torch.uint8) != outs[1][1].view(torch.uint8)).sum()), 0),
+           _res(tag + ".fwd_vs_torch", relerr(outs[1][0][..., :Cout], y_ref), 4e-3 if dt != L.F32 else 1e-5)]
+    if ld_extra:
+        res.append(_res(tag + ".neighbours_untouched", 0 if (outs[1][0][..., Cout:].float() == 3).all().item() else 1, 0))
+    return res
+
+
 def check_convT_planar_k1(dt, B, S, Cin, Cout, sz=2, seed=0):
     """Round 5: the transposed-conv forward with ONE K step (Cin <= 32) into channels [0, Cout) of a chunk-planar concat buffer - the branch-free
     buffer-addressed kernel (convt_k1_kernel: scalar run coordinates, out-of-range offsets instead of predicates) against the general kernel on

@@ -203,6 +203,20 @@ def test_pointwise_and_transposed_conv(K, dt):
     _assert_all(rows)
 
 
+def test_first_layer_buffer_addressed_instance_is_bit_identical_to_the_pointer_addressed_one(K):
+    """Round 5: conv_c1_fwd_kernel<T, BUF = true> - ragged volumes (zero padding and partial tiles through out-of-range offsets), several tiles per
+    workgroup incl. a workgroup whose last prefetch lies beyond the launch, batches, 32 output channels (two column blocks), a channel slice of a
+    wider buffer, the three storage types."""
+    from biapy_amd import _lib as L
+    rows = []
+    rows += K.check_c1_fwd_buffer_vs_pointer(L.F16, 2, (8, 16, 32))
+    rows += K.check_c1_fwd_buffer_vs_pointer(L.F16, 3, (9, 13, 21), persist=8)               # ragged on every axis, 8 workgroups for 36 tiles
+    rows += K.check_c1_fwd_buffer_vs_pointer(L.BF16, 2, (12, 20, 36), Cout=32, persist=16)
+    rows += K.check_c1_fwd_buffer_vs_pointer(L.F32, 1, (7, 9, 19), ld_extra=16, persist=4)
+    rows += K.check_c1_fwd_buffer_vs_pointer(L.F16, 1, (32, 32, 32), ld_extra=32)
+    _assert_all(rows)
+
+
 def test_transposed_conv_one_k_step_kernel_is_bit_identical_to_the_general_kernel(K):
     """Round 5: convt_k1_kernel (level 0 of cfg 2: 32 -> 32 channels into the planar concat buffer) - full and ragged block counts, batches,
     16- and 32-channel inputs (lanes beyond K read zeros), 64 output channels (two column blocks per sub-position), the (1, 2, 2) kernel of the
