@@ -9,6 +9,17 @@ O=gpurun_out/profiles_new
 mkdir -p $O
 export TMPDIR=/tmp
 ROOT=$(pwd)
+# HBM traffic first: bench.py reads profiles/pmc_traffic*.json (stamped with the sha256 of csrc/) for `roofline.traffic`, so the counters of THIS tree
+# must be in place before the bench line is produced
+cd /tmp
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_f -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_w -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_w.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_tf -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tf.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tw.log 2>&1
+cd $ROOT
+python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
+python scripts/pmc_traffic.py $(find $O/pmc_tf -name "p_results.db" | head -1) $(find $O/pmc_tw -name "p_results.db" | head -1) > $O/pmc_traffic_tiling.json 2>> $O/pmc_traffic.err
+cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic_tiling.json profiles/pmc_traffic_tiling.json
 ( time python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/${R}_gpu_tests.txt 2>&1
 python bench.py > $O/${R}_bench.json 2> $O/bench.err
 python bench.py --force-ddp --self-check --mode train --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
@@ -54,6 +65,13 @@ fi
 for zm in 1 0; do BPX_CONV_ZM=$zm python bench.py --mode train --steps 40 --warmup 8 --no-cpu-baseline --no-bf16-record --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_ZM=$zm train ms_per_step %.4f' % d['ms_per_step'])"; done > $O/${R}_step_zmarch_ab.txt 2>&1
 for zm in 1 0; do BPX_CONV_ZM=$zm python bench.py --mode infer --steps 40 --warmup 8 --no-cpu-baseline --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_ZM=$zm infer ms_per_step %.4f' % d['ms_per_step'])"; done >> $O/${R}_step_zmarch_ab.txt 2>&1
 ( python tests/bench_kernels.py k1 --reps 20; python tests/bench_kernels.py pws --reps 20 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stream_vs_tile.txt
+# round 5: transposed-conv forward of level 0 (convt_k1_kernel against pw_kernel) and the first layer (buffer- against pointer-addressed), event timing
+# in the network; the store-pattern probe
+( for rep in 1 2; do
+    for k1 in 1 0; do echo "== BPX_CONVT_K1=$k1"; BPX_CONVT_K1=$k1 python bench.py --breakdown --graph off --mode infer 2>/dev/null | grep "convT3d_k2s2_fwd (2, 4, 64\|c1_fwd"; done
+    echo "== first layer, pointer-addressed instance (BPX_C1_PERSIST bit 30)"; BPX_C1_PERSIST=$((2048 + (1 << 30))) python bench.py --breakdown --graph off --mode infer 2>/dev/null | grep "c1_fwd"
+  done
+  echo "== store patterns (scripts/probes/store_pattern_probe.hip)"; [ -x scripts/probes/store_pattern_probe.bin ] && scripts/probes/store_pattern_probe.bin ) 2>&1 | grep -v amdgpu.ids > $O/${R}_convt_c1_ab.txt
 python tests/gpu_diag.py --net --out $O/${R}_gpu_diag.txt > /dev/null 2>&1
 [ -f gpurun_out/diag_values.txt ] && cp gpurun_out/diag_values.txt $O/${R}_gpu_test_values.txt     # measured values the parity tests recorded (loss-curve gap, Dice rows)
 python tests/bench_kernels.py rcan 2>&1 | grep -v "Warning\|run_backward" > $O/${R}_rcan_trunk_64.txt
@@ -66,17 +84,11 @@ cp $(find $O/kt -name "train_kernel_stats.csv" | head -1) $O/${R}_bench_train_ke
 cp $(find $O/kt -name "infer_kernel_stats.csv" | head -1) $O/${R}_bench_infer_kernel_stats.csv
 cp $(find $O/kt -name "resunetpp_kernel_stats.csv" | head -1) $O/${R}_bench_resunetpp_kernel_stats.csv
 cd /tmp
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_f -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_f.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_w -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_w.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES --kernel-trace \
    -d $ROOT/$O/pmc_a -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_a.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace \
    -d $ROOT/$O/pmc_b -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_b.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $ROOT/$O/pmc_tf -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tf.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $ROOT/$O/pmc_tw -o p -- python $ROOT/tests/bench_kernels.py merge_rows --reps 4 > $ROOT/$O/pmc_tw.log 2>&1
 cd $ROOT
-python scripts/pmc_traffic.py $(find $O/pmc_f -name "p_results.db" | head -1) $(find $O/pmc_w -name "p_results.db" | head -1) > $O/pmc_traffic.json 2> $O/pmc_traffic.err
-python scripts/pmc_traffic.py $(find $O/pmc_tf -name "p_results.db" | head -1) $(find $O/pmc_tw -name "p_results.db" | head -1) > $O/pmc_traffic_tiling.json 2>> $O/pmc_traffic.err
 for k in conv3_zm_kernel conv3_zs_kernel conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel pw_nbs_kernel wgrad_k1_dma_kernel; do
   python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
   python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
