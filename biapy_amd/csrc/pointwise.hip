@@ -686,8 +686,10 @@ __global__ void __launch_bounds__(256, BPX_CONVT_OCC) convt_k1_kernel(const PwPa
       const u32x4_t q1{pk[2][0], pk[2][1], pk[3][0], pk[3][1]};
       // The run's offset goes into the VECTOR offset of the stores (one v_add each), not into their scalar offset: with an SGPR soffset hipcc 7.2
       // leaves out the wait states between a 128-bit buffer store and a VALU write of its data registers (its hazard recogniser assumes the
-      // hazard away for a register soffset; on gfx950 it is there) - the next m-subtile's v_pk_add overwrote two of the four data registers and
-      // the fp16 output held fp32 halves (NaNs; the bf16 instance happened to allocate differently).  The loads have no data registers to lose.
+      // hazard away for a register soffset).  On gfx950 that holds for ONE store but not for the second of two back-to-back stores
+      // (scripts/probes/soffset_store_hazard.hip: 16 of 256 words lost with no wait state, none with one) - which is this epilogue: the next
+      // m-subtile's v_pk_add overwrote two of the second store's four data registers and the fp16 output held fp32 halves (NaNs; the bf16
+      // instance happened to allocate differently).  The loads have no data registers to lose.
       __builtin_amdgcn_raw_buffer_store_b128(q0, rs_y, (int)(valid ? ylane + srun : OOB), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(q1, rs_y, (int)(valid ? ylane + srun + yplane : OOB), 0, 0);
     }
