@@ -1215,11 +1215,17 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_kernel(const float* __restr
 //   dy = a[n,c] * g + b[n,c] * t + c0[n,c]   (bpx_norm_bwd_finalize's coefficients; t = the conv's raw output, TT = fp16 in the mixed mode)
 // in the arithmetic of norm_bwd_apply_kernel and rounded to bf16 as that kernel's store would: the pass that wrote dy (3 tensor units of
 // traffic at 128^3, 139 us per cfg-2 step) is gone and this kernel reads two units instead of one.
-template <typename TT, bool NB>
+// BUF (round 5): image, dy and t arrive through buffer loads with out-of-range offsets for voxels outside the volume and for tiles beyond the
+// launch, requested unconditionally.  With predicated loads every wait for a staged tile was `s_waitcnt vmcnt(0)` (the wait-count pass gives up at
+// the joins of the bounds tests): the wait for tile i also waited for tile i + 1's requests, issued later - the two-tiles-ahead staging ran one
+// tile ahead.  The sample's coefficients are re-read behind a SCALAR branch (they were re-loaded for every tile: 8 more 16-byte loads per thread,
+// as many VMEM instructions as the tile's own operands).
+template <typename TT, bool NB, bool BUF>
 __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __restrict__ img, const uint16_t* __restrict__ dy, int dy_ld,
                                                                  int D, int H, int W, int N, int totalTiles, float* __restrict__ dw,
                                                                  float* __restrict__ db, const TT* __restrict__ tsrc, int t_ld,
-                                                                 const bpx_nbwd_coef* __restrict__ coef) {
+                                                                 const bpx_nbwd_coef* __restrict__ coef, uint32_t img_bytes, uint32_t dy_bytes,
+                                                                 uint32_t t_bytes) {
   constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX, HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
   constexpr int VBG = 32;
   __shared__ float simg[HV + 8];
@@ -1245,26 +1251,61 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
   Stage st0, st1;
   f32x4_t ck[NB ? 8 : 1];   // {a, b, c0, -} of this thread's 8 channels in the current sample
   int cur_n = -1;
-  auto issue = [&](int tt, Stage& sg) {
-    const int n = tt / tps, tile = tt % tps;
-    const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
+  const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dy), 0, (int)dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<TT*>(tsrc), 0, (int)t_bytes, 0x00020000);
+  // BUF: this thread's halo voxels (packed coordinates, offset relative to the tile's first voxel) and tile voxels are the same for every tile
+  uint32_t hpk[BUF ? NI : 1];
+  int hrel[BUF ? NI : 1];
+  if constexpr (BUF) {
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
       const int q = u * 256 + tid;
       const int hx = q % HX, hy = (q / HX) % HY, hz = q / (HX * HY);
-      const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
-      sg.pi[u] = (q < HV && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
+      hpk[u] = q < HV ? (uint32_t)(hz | (hy << 8) | (hx << 16)) : 0xFFFFFFFFu;
+      hrel[u] = ((hz - 1) * H + (hy - 1)) * W + (hx - 1);
     }
+  }
+  auto issue = [&](int tt, Stage& sg) {
+    const int n = tt / tps, tile = tt % tps;
+    const int x0 = (tile % tilesX) * TX, y0 = ((tile / tilesX) % tilesY) * TY, z0 = (tile / (tilesX * tilesY)) * TZ;
+    if constexpr (BUF) {
+      const bool live = tt < totalTiles;
+      const int base = ((n * D + z0) * H + y0) * W + x0;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = u * 256 + tid, t = q >> 1;
-      const int x = x0 + (t & 15), y = y0 + ((t >> 4) & 3), z = z0 + (t >> 6);
-      sg.pg[u] = u32x4_t{0u, 0u, 0u, 0u};
-      if (NB) sg.pt[NB ? u : 0] = u32x4_t{0u, 0u, 0u, 0u};
-      if (z < D && y < H && x < W) {
-        const size_t v = (((size_t)n * D + z) * H + y) * W + x;
-        sg.pg[u] = *reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + cb + (q & 1) * 8);
-        if (NB) sg.pt[NB ? u : 0] = *reinterpret_cast<const u32x4_t*>(tsrc + v * t_ld + cb + (q & 1) * 8);
+      for (int u = 0; u < NI; ++u) {
+        const uint32_t z = (uint32_t)(z0 - 1) + (hpk[u] & 255u), y = (uint32_t)(y0 - 1) + ((hpk[u] >> 8) & 255u), x = (uint32_t)(x0 - 1) + (hpk[u] >> 16);
+        const bool in = live && hpk[u] != 0xFFFFFFFFu && z < (uint32_t)D && y < (uint32_t)H && x < (uint32_t)W;
+        sg.pi[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, (int)(in ? (uint32_t)(base + hrel[u]) * 4u : 0xFFFFFFF0u), 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = u * 256 + tid, t = q >> 1;
+        const int x = x0 + (t & 15), y = y0 + ((t >> 4) & 3), z = z0 + (t >> 6);
+        const bool in = live && z < D && y < H && x < W;
+        const uint32_t v = (uint32_t)(((n * D + z) * H + y) * W + x);
+        sg.pg[u] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)(in ? (v * (uint32_t)dy_ld + (uint32_t)(cb + (q & 1) * 8)) * 2u : 0xFFFFFFF0u), 0, 0));
+        if (NB) sg.pt[NB ? u : 0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_t, (int)(in ? (v * (uint32_t)t_ld + (uint32_t)(cb + (q & 1) * 8)) * 2u : 0xFFFFFFF0u), 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int q = u * 256 + tid;
+        const int hx = q % HX, hy = (q / HX) % HY, hz = q / (HX * HY);
+        const int z = z0 + hz - 1, y = y0 + hy - 1, x = x0 + hx - 1;
+        sg.pi[u] = (q < HV && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)n * D + z) * H + y) * W + x] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = u * 256 + tid, t = q >> 1;
+        const int x = x0 + (t & 15), y = y0 + ((t >> 4) & 3), z = z0 + (t >> 6);
+        sg.pg[u] = u32x4_t{0u, 0u, 0u, 0u};
+        if (NB) sg.pt[NB ? u : 0] = u32x4_t{0u, 0u, 0u, 0u};
+        if (z < D && y < H && x < W) {
+          const size_t v = (((size_t)n * D + z) * H + y) * W + x;
+          sg.pg[u] = *reinterpret_cast<const u32x4_t*>(dy + v * dy_ld + cb + (q & 1) * 8);
+          if (NB) sg.pt[NB ? u : 0] = *reinterpret_cast<const u32x4_t*>(tsrc + v * t_ld + cb + (q & 1) * 8);
+        }
       }
     }
   };
@@ -1274,25 +1315,39 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
     const int q = u * 256 + tid, t = q >> 1;
     const int tile = tt % tps;
     const int x = (tile % tilesX) * TX + (t & 15), y = ((tile / tilesX) % tilesY) * TY + ((t >> 4) & 3), z = (tile / (tilesX * tilesY)) * TZ + (t >> 6);
-    if (!(z < D && y < H && x < W)) return u32x4_t{0u, 0u, 0u, 0u};
+    const bool inside = z < D && y < H && x < W;
+    if (!BUF && !inside) return u32x4_t{0u, 0u, 0u, 0u};
     float gf[8], tf[8], of[8];
     unpack16<uint16_t>(sg.pg[u], gf);
     unpack16<TT>(sg.pt[NB ? u : 0], tf);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const f32x4_t k = ck[NB ? e : 0]; of[e] = k[0] * gf[e] + k[1] * tf[e] + k[2]; }
-    return pack16<uint16_t>(of);
+    const u32x4_t r = pack16<uint16_t>(of);
+    if (BUF) return inside ? r : u32x4_t{0u, 0u, 0u, 0u};          // (a select: no branch between the staged loads and their consumers)
+    return r;
   };
   const int step = gridDim.x;
-  if ((int)blockIdx.x < totalTiles) issue(blockIdx.x, st0);
-  if ((int)blockIdx.x + step < totalTiles) issue(blockIdx.x + step, st1);
+  if (BUF || (int)blockIdx.x < totalTiles) issue(blockIdx.x, st0);
+  if (BUF || (int)blockIdx.x + step < totalTiles) issue(blockIdx.x + step, st1);
   auto body = [&](int tt, Stage& sg) {
     if (NB) {
-      const int n = tt / tps;
-      if (n != cur_n) {                                     // (a handful of times per workgroup)
+      const int n = BUF ? __builtin_amdgcn_readfirstlane(tt / tps) : tt / tps;
+      if (n != (BUF ? __builtin_amdgcn_readfirstlane(cur_n) : cur_n)) {   // (a handful of times per workgroup; BUF: a scalar branch)
         cur_n = n;
-        const f32x4_t* kp = reinterpret_cast<const f32x4_t*>(coef + (size_t)n * (16 * gridDim.y) + cb + (tid & 1) * 8);
+        if constexpr (BUF) {
+          // through the SCALAR cache (uniform addresses, lgkmcnt): as vector loads they would be the youngest VMEM operations at the staged tile's first
+          // use, and the wait for them - on every path, the counts are static - a wait for the prefetched tiles behind them
+          const f32x4_t* kp = reinterpret_cast<const f32x4_t*>(coef + (size_t)n * (16 * gridDim.y) + cb);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ck[NB ? e : 0] = kp[e];
+          for (int e = 0; e < 8; ++e) {
+            const f32x4_t lo = kp[e], hi = kp[8 + e];
+            ck[NB ? e : 0] = (tid & 1) ? hi : lo;
+          }
+        } else {
+          const f32x4_t* kp = reinterpret_cast<const f32x4_t*>(coef + (size_t)n * (16 * gridDim.y) + cb + (tid & 1) * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ck[NB ? e : 0] = kp[e];
+        }
       }
     }
     __syncthreads();
@@ -1306,7 +1361,7 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
 #pragma unroll
     for (int u = 0; u < 2; ++u) *reinterpret_cast<u32x4_t*>(sG + (size_t)(u * 256 + tid) * 16) = piece(u, tt, sg);
     __syncthreads();
-    if (tt + 2 * step < totalTiles) issue(tt + 2 * step, sg);
+    if (BUF || tt + 2 * step < totalTiles) issue(tt + 2 * step, sg);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int kc = wave * 2 + kk;
@@ -1336,9 +1391,21 @@ __global__ void __launch_bounds__(256) conv_c1_wgrad_mfma_kernel(const float* __
       }
     }
   };
-  for (int tt = blockIdx.x; tt < totalTiles; tt += 2 * step) {
-    body(tt, st0);
-    if (tt + step < totalTiles) body(tt + step, st1);
+  if constexpr (BUF) {
+    // pairs of tiles in a loop whose every trip runs both bodies, the odd last tile behind it: with the second body under a test inside the loop
+    // there is a static path on which stage 1 was not refilled, and the first body's waits are counted for THAT path (vmcnt(6 .. 0): a wait for
+    // stage 1's requests as well)
+    int tt = blockIdx.x;
+    for (; tt + step < totalTiles; tt += 2 * step) {
+      body(tt, st0);
+      body(tt + step, st1);
+    }
+    if (tt < totalTiles) body(tt, st0);
+  } else {
+    for (int tt = blockIdx.x; tt < totalTiles; tt += 2 * step) {
+      body(tt, st0);
+      if (tt + step < totalTiles) body(tt + step, st1);
+    }
   }
   // lane holds D[row = 4g + r][co = i] of each block: sum the four waves, then one partial per (tap, co) and workgroup
 #pragma unroll
@@ -2528,12 +2595,18 @@ static int c1_wgrad_impl(const char* fn, int dtype, int N, int D, int H, int W, 
   if (mfma_ok) {
     const int tiles = N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
     // 768 workgroups (3 per CU), each looping over its share of the tiles
-    dim3 gm((unsigned)std::min(tiles, 768), (unsigned)(dy.C / 16));
+    dim3 gm((unsigned)std::min(std::min(tiles, 768), g_c1_persist > 0 ? g_c1_persist : tiles), (unsigned)(dy.C / 16));   // (tests cap the workgroups through bpx_debug_set_c1_persist)
     groups = (int)gm.x;
     float* pb = db_d ? pw + (size_t)groups * 27 * dy.C : nullptr;
-    if (nb && mix) conv_c1_wgrad_mfma_kernel<f16_t, true><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, (const f16_t*)t.ptr, t.ld, coef_d);
-    else if (nb) conv_c1_wgrad_mfma_kernel<uint16_t, true><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, (const uint16_t*)t.ptr, t.ld, coef_d);
-    else conv_c1_wgrad_mfma_kernel<uint16_t, false><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, nullptr, 0, nullptr);
+    // the buffer-addressed instances when the three operands lie within 32-bit byte offsets (bpx_debug_set_c1_persist bit 30 clears it: tests / A-B)
+    const int64_t vox = (int64_t)N * D * H * W;
+    const int64_t ib = vox * 4, gb = vox * dy.ld * 2, tb = nb ? vox * t.ld * 2 : 16;
+    const bool buf = !g_c1_nobuf && ib < 0xFFFFFF00ll && gb < 0xFFFFFF00ll && tb < 0xFFFFFF00ll;
+#define C1W(TT_, NB_, B_, tp_, tld_, cf_) conv_c1_wgrad_mfma_kernel<TT_, NB_, B_><<<gm, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, tiles, pw, pb, tp_, tld_, cf_, (uint32_t)ib, (uint32_t)gb, (uint32_t)tb)
+    if (nb && mix) { if (buf) C1W(f16_t, true, true, (const f16_t*)t.ptr, t.ld, coef_d); else C1W(f16_t, true, false, (const f16_t*)t.ptr, t.ld, coef_d); }
+    else if (nb) { if (buf) C1W(uint16_t, true, true, (const uint16_t*)t.ptr, t.ld, coef_d); else C1W(uint16_t, true, false, (const uint16_t*)t.ptr, t.ld, coef_d); }
+    else { if (buf) C1W(uint16_t, false, true, (const uint16_t*)nullptr, 0, (const bpx_nbwd_coef*)nullptr); else C1W(uint16_t, false, false, (const uint16_t*)nullptr, 0, (const bpx_nbwd_coef*)nullptr); }
+#undef C1W
   } else {
     float* pb = db_d ? pw + (size_t)groups * 27 * dy.C : nullptr;
     if (dtype == BPX_BF16) conv_c1_wgrad_kernel<uint16_t><<<grid, 256, 0, s>>>(img_d, (const uint16_t*)dy.ptr, dy.ld, D, H, W, N, totalTiles, pw, pb);

@@ -2086,6 +2086,24 @@ def check_c1_wgrad_nb(mix=True, B=2, S=(12, 20, 36), seed=0):
     dwf, dbf = fused()
     dwf2, dbf2 = fused()
     res.append(_res(tag + ".run_to_run_bits", 0 if torch.equal(dwf, dwf2) and torch.equal(dbf, dbf2) else 1, 0))
+    # round 5: the pointer-addressed instance (hook bit 30) against the buffer-addressed default, with a workgroup cap so that a workgroup walks
+    # several tile pairs and an odd last tile
+    lib.bpx_debug_set_c1_persist(2048 | (1 << 30))
+    try:
+        dwp, dbp = fused()
+    finally:
+        lib.bpx_debug_set_c1_persist(2048)
+    res.append(_res(tag + ".buffer_instance_bits_equal_pointer_instance", 0 if torch.equal(dwf, dwp) and torch.equal(dbf, dbp) else 1, 0,
+                    extra=f"max diff {(dwf - dwp).abs().max().item():.2e}"))
+    few = []
+    for flag in (0, 1 << 30):
+        lib.bpx_debug_set_c1_persist(7 | flag)          # 7 workgroups: tile pairs in a loop and an odd last tile per workgroup
+        try:
+            few.append(fused())
+        finally:
+            lib.bpx_debug_set_c1_persist(2048)
+    res.append(_res(tag + ".seven_workgroups.buffer_bits_equal_pointer", 0 if torch.equal(few[0][0], few[1][0]) and torch.equal(few[0][1], few[1][1]) else 1, 0))
+    res.append(_res(tag + ".seven_workgroups.close_to_default_grid", relerr(few[0][0], dwf), 1e-5))
     dyd = torch.empty_like(gd)
     L.check(lib.bpx_norm_bwd_apply(dt, B, D * H * W, L.tview(gd), L.tview(td), cd.data_ptr(), L.NULL_T, L.tview(dyd), L.stream_ptr()))
     dws = torch.zeros(16, 1, 3, 3, 3, dtype=torch.float32, device=DEV); dbs = torch.zeros(16, dtype=torch.float32, device=DEV)
