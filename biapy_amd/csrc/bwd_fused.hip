@@ -32,6 +32,16 @@ using namespace bpxconv;
 #ifndef BPX_BWD_LDSW
 #define BPX_BWD_LDSW 1
 #endif
+// role-split kernel (conv3_bwd_rs_kernel): staging of the next tile through registers (1) or by LDS-DMA (0); DMA pieces spread over the wgrad K-chunks
+#ifndef BPX_BWD_RS_STAGE
+#define BPX_BWD_RS_STAGE 0
+#endif
+#ifndef BPX_BWD_RS_WPRIO
+#define BPX_BWD_RS_WPRIO 1
+#endif
+#ifndef BPX_BWD_RS_SPREAD
+#define BPX_BWD_RS_SPREAD 0
+#endif
 
 namespace {
 
@@ -49,6 +59,7 @@ struct BwdParams {
   float* part; float* dbpart; int want_db;         // [grid][27][Ct][16] weight-gradient partials, [grid][16] bias-gradient partials
   int tilesZ, tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd, stripY;
   long long* stamps;                               // profiling: per-workgroup cycle stamps [block][16] of the 5th tile (scripts/bwd_stamps.py), else null
+  int stagger;                                     // role-split kernel: start-up skew between the workgroups of an XCD, in units of 256 cycles per slot step
 };
 
 // CG = 16-channel chunks of dy (1: the 16-channel layers of level 0; 2: the 32-channel layers of level 1), CT = chunks of t / g this workgroup
@@ -570,6 +581,503 @@ __global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) 
 #endif
 }
 
+
+// ---- ROLE-SPLIT form (round 6) ----------------------------------------------------------------------------------------------------------------
+// The kernel above runs a tile's phases one after the other in every wave - staging, transform, dgrad MFMA steps, dgrad epilogue, wgrad MFMA steps -
+// at two workgroups (8 waves) per CU; its per-phase stamps (profiles/r05_stamps_bwd_fused.txt) show the two MFMA phases at a third of a tile and
+// the VALU phases (transform, epilogue) and the exposed DMA latency at the rest.  Here ONE workgroup of 8 waves owns the CU and splits the work by
+// ROLE, two tiles in flight in a double-buffered LDS (2 x (dy halo + raw t + act(t)) = 140 KB for 48 channels):
+//   waves 0-3 (D): barrier X_i - dgrad MFMA steps on G[b] - dgrad epilogue with the raw T[b] (ELU', per-lane statistics, g stores)
+//   waves 4-7 (W): wait for their own DMA pieces of tile i - transform T[b] -> A[b] - barrier X_i - request tile i + 1 into G[b^1], T[b^1] by
+//                  `buffer_load ... lds` - wgrad MFMA steps on A[b], G[b]
+// One barrier per tile.  At X_i the D waves have finished tile i - 1 and the W waves its wgrad phase, so buffer b ^ 1 is free for the requests of
+// tile i + 1, which then have a whole wgrad phase to land.  Each SIMD holds one wave of either role: the VALU sections of one overlap the MFMA
+// steps of the other, and neither role carries the other's accumulators (the D waves have room for per-lane statistics over all tiles of a
+// sample: no per-tile statistics row, no cross-wave exchange - every D wave writes its own row).  The norm records of the sample are wave-private
+// LDS copies (the W waves run one tile ahead of the D waves and may be in the next sample).
+// One LDS-DMA piece (64 lanes x 16 bytes -> LDS at `lds` + 16 lane) as INLINE ASSEMBLY: hipcc's wait-count pass treats an LDS-DMA intrinsic as a
+// store to "some LDS" and puts `s_waitcnt vmcnt(0)` in front of the next ds_read of ANY LDS address - the role-split kernel's W waves then waited
+// for the requests of the NEXT tile (other buffer) at the top of their wgrad phase.  The assembly form is invisible to that pass; every consumer
+// of the pieces sits behind an explicit `s_waitcnt vmcnt(0)` and a barrier (conv3_bwd_rs_kernel).
+__device__ __forceinline__ void dma16_asm(const u32x4_t& rsrc, uint32_t lds, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4_t raw_rsrc(const void* ptr, uint32_t num_records) {
+  const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+  return u32x4_t{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xFFFFu, num_records, 0x00020000u};
+}
+
+template <int CT, int ACTK, bool TF16>
+__global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(const BwdParams p) {
+  using T = uint16_t;
+  using TT = typename std::conditional<TF16, f16_t, uint16_t>::type;
+  constexpr int TZ = 4, TY = 4, TX = 16, TV = TZ * TY * TX;
+  constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
+  constexpr int KPL = 8, VB = 32, NS = CT, MS = 4, STEPS = 14;
+  constexpr int NPGT = HV * 2, NPG = (NPGT + 255) / 256;
+  constexpr int SG_BYTES = HV * VB + 64;
+  constexpr int ST_BYTES = CT * TV * VB;
+  constexpr int HSTR = HX * VB;
+  constexpr int NKC = TV / 32;
+  constexpr int SN_BYTES = CT * 16 * 16;                                  // one wave's copy of the sample's norm records
+  constexpr int QPADB = 56;
+  // dgrad weights (the same 14 x NS KB for every tile): steps [0, WL) live in LDS, steps [WL, WL + WR) in registers of every D wave, the last WV
+  // steps are requested at the top of the tile and used ~2 K cycles later.  (One step ahead from L2, as the serial kernel does it, costs the
+  // role-split form its point: 42 requests per wave and tile keep the CU's texture path busy - the W waves' DMA requests took 300 cycles each -
+  // and every step waits for its operands: dgrad steps 6.6 K cycles for 2.7 K of MFMA, profiles/r06_stamps_bwd_rs.txt.)
+  constexpr int WL = 13, WR = 1, WV = STEPS - WL - WR;
+  constexpr int SW_BYTES = WL * NS * 1024;
+  // The activated tile A is NOT double-buffered (that is what makes room for the weights): only the W waves touch it, and they order themselves with
+  // a counter in LDS - a W wave writes its pieces of tile i + 1 only after all four have finished the wgrad steps of tile i (wsync below).
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SG_BYTES + 3 * ST_BYTES + 8 * SN_BYTES + SW_BYTES + 16];
+  unsigned char* const sG0 = smem;                                        // dy halo [2][HV][32 B]
+  unsigned char* const sT0 = smem + 2 * SG_BYTES;                         // raw t tile [2][CT][TV][32 B]
+  unsigned char* const sA0 = sT0 + 2 * ST_BYTES;                          // act(norm(t)) as bf16 [CT][TV][32 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  float* const sN = reinterpret_cast<float*>(sA0 + ST_BYTES + wave * SN_BYTES);   // [CT * 16]{mean, rstd, scale, shift}, this wave's copy
+  unsigned char* const sW = sA0 + ST_BYTES + 8 * SN_BYTES;                 // [WL][NS][64 lanes][16 B]
+  unsigned* const wsync = reinterpret_cast<unsigned*>(sW + SW_BYTES);      // W waves that have finished their wgrad steps, summed over tiles
+  if (tid == 0) *wsync = 0u;
+  // Start-up skew: the workgroups run identical tiles at identical speed, i.e. in LOCKSTEP - every CU requests its 48 KB of the next tile in the
+  // same ~4 K cycles (the chip then runs at the HBM limit, ~11 bytes per cycle and CU) and nothing for the rest of the tile.  A one-off delay of
+  // (slot mod 8) x stagger x 256 cycles spreads the CUs' phases over a tile time; it costs one tile time of ~130.
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(4);
+  __syncthreads();
+  const int j = lane & 15, g = lane >> 4;
+  const int D = p.D, H = p.H, W = p.W, Ct = p.Ct;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  constexpr uint32_t OOR = 0x80000000u;   // out of range of the buffers: a load returns zeros, a store is dropped
+#ifdef BPX_BWD_STAMPS
+  long long* stamps = (p.stamps && (tid & 255) == 0) ? p.stamps + (size_t)blockIdx.x * 16 + (wave >> 2) * 8 : nullptr;
+  int stamp_i = 0;
+#define BPX_STAMP() do { if (stamps && it == 4 && stamp_i < 8) stamps[stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BPX_STAMP() do { } while (0)
+#endif
+
+#ifdef BPX_RS_NO_D
+  if (false) {
+#elif defined(BPX_RS_NO_W)
+  if (true) {
+#else
+  if (wave < 4) {
+#endif
+    // =========================================================== D role ===========================================================================
+    const int cg_off = (g & 1) * 16;
+    const bool hi_tap = (g >> 1) != 0;
+    const int hb0 = ((wave * HY) * HX + j) * VB + cg_off;
+    const int lbase[4] = {hb0 + (hi_tap ? VB : 0), hb0 + (hi_tap ? HX * VB : 0), hb0 + (hi_tap ? HY * HX * VB : 0), hb0};
+    const int evox_rel = (wave * H) * W + j;
+    const uint32_t wlane = (uint32_t)((g * Ct + j) * KPL) * 2u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wT), 0, QPADB * Ct * 16, 0x00020000);
+    const uint32_t wstep = (uint32_t)(4 * Ct * 16);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.g, 0, (int)0x80000000u, 0x00020000);
+    for (int q = wave; q < WL * NS; q += 4)   // LDS-resident steps: piece (s, ns) at sW + (s NS + ns) KB; visible after the first tile barrier
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sW + q * 1024), 16, wlane + (uint32_t)(q % NS) * 256u, (q / NS) * wstep, 0, 0);
+    u32x4_t wres[WR > 0 ? WR : 1][NS];
+#pragma unroll
+    for (int k = 0; k < WR; ++k)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        wres[k][ns] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)((WL + k) * wstep), 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uint32_t v = wres[k][ns][e]; asm volatile("" : "+v"(v)); wres[k][ns][e] = v; }   // opaque: kept, not re-requested per tile
+      }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's weight pieces are in LDS before it reaches the first barrier
+    const int rows = (int)gridDim.x * 4, row = (int)blockIdx.x * 4 + wave;
+    float ps1[NS][4], ps2[NS][4];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ps1[ns][r] = 0.f; ps2[ns][r] = 0.f; }
+    auto flush_stats = [&](int nn) {   // this wave's row of sample nn: sums over its voxels of every tile of the sample so far
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(ps1[ns][r]), b = row16_sum(ps2[ns][r]);
+          if (j == 0) {
+            float* q = p.red + ((size_t)nn * rows + row) * 2 * Ct + ns * 16 + g * 4 + r;
+            q[0] = a; q[Ct] = b;
+          }
+          ps1[ns][r] = 0.f; ps2[ns][r] = 0.f;
+        }
+    };
+    int n_cur = -1, n_first = -1, it = 0;
+    const uint32_t yrow = (uint32_t)(W * p.g_ld) * 2u;
+    for (int local = slot; local < p.tilesPerXcd; local += spx, ++it) {
+      const int tileId = xcd * p.tilesPerXcd + local;
+      if (tileId >= p.totalTiles) break;
+      int n, tzi, tyi, txi;
+      decode_tile(tileId, p.tilesZ, p.tilesY, p.tilesX, p.tilesPerSample, p.stripY, n, tzi, tyi, txi);
+      const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+      const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+      const unsigned char* sG = sG0 + (it & 1) * SG_BYTES;
+      const unsigned char* sT = sT0 + (it & 1) * ST_BYTES;
+      if (n != n_cur) {   // wave-uniform
+        if (n_cur >= 0) flush_stats(n_cur);
+        if (n_cur < 0) n_first = n;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));   // (the lane's 64-bit record address stays inside this rare branch: hoisted, it is a spilled register pair)
+        if (lo < CT * 16) reinterpret_cast<f32x4_t*>(sN)[lo] = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n * Ct + lo]);
+        n_cur = n;
+      }
+      BPX_STAMP();   // D0: tile start
+      __syncthreads();   // X_i: tile i's dy halo and raw t have landed (W waves); the D waves are done with tile i - 1
+      BPX_STAMP();   // D1: barrier passed
+      const int vox0 = ((n * D + z0) * H + y0) * W + x0 + evox_rel;
+      const bool okzx = full || (z0 + wave < D && x0 + j < W);
+      const int yrem = full ? (1 << 20) : H - y0;
+      const uint32_t yb0 = (uint32_t)(vox0 * p.g_ld + g * 4) * 2u;
+      const unsigned char* tl = sT + ((wave * MS) * 16 + j) * VB + g * 8;
+      // out-of-volume voxels of edge tiles carry no gradient: an AND with an opaque all-ones / zero mask per row.  (As `in ? x : 0` the compiler
+      // moved each pair's exp2 under a branch on `in`: 24 basic blocks per tile, each ending in its own wait.)
+      uint32_t mk[MS], yoff[MS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) {
+        const bool in = okzx && ms < yrem;
+        mk[ms] = in ? 0xFFFFFFFFu : 0u;
+        yoff[ms] = in ? yb0 + ms * yrow : OOR;
+        asm volatile("" : "+v"(mk[ms]), "+v"(yoff[ms]));
+      }
+      f32x4_t acc[MS][NS];
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      u32x4_t wv[WV > 0 ? WV : 1][NS];   // the last WV steps' weights: requested now, used at the end of the step loop
+#pragma unroll
+      for (int k = 0; k < WV; ++k)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          wv[k][ns] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)((WL + WR + k) * wstep), 0));
+      __builtin_amdgcn_sched_barrier(0);   // (the requests stay here: the scheduler sinks them to their use and exposes the L2 latency)
+      // fragments one step ahead of the MFMAs (the compiler's own order reads a step's fragments and waits for them at once: every step paid the
+      // LDS latency, 33 cycles per MFMA instead of 16)
+      u32x4_t af[2][MS], wf[2][NS];
+      auto load_frag = [&](int s_, u32x4_t* a_, u32x4_t* w_) {
+        const int cls = s_ < 9 ? 0 : s_ < 12 ? 1 : s_ == 12 ? 2 : 3;
+        const int imm = tap_off<HY, HX, VB>(bpx_tap_order_bf16(2 * s_));
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) a_[ms] = *reinterpret_cast<const u32x4_t*>(sG + lbase[cls] + ms * HSTR + imm);
+        if (s_ < WL) {
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) w_[ns] = *reinterpret_cast<const u32x4_t*>(sW + (s_ * NS + ns) * 1024 + lane * 16);
+        }
+      };
+      load_frag(0, af[0], wf[0]);
+#pragma unroll
+      for (int s_ = 0; s_ < STEPS; ++s_) {
+        if (s_ + 1 < STEPS) load_frag(s_ + 1, af[(s_ + 1) & 1], wf[(s_ + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns) {
+            const u32x4_t w = s_ < WL ? wf[s_ & 1][ns] : s_ < WL + WR ? wres[(s_ - WL >= 0 && s_ - WL < WR) ? s_ - WL : 0][ns] : wv[(s_ - WL - WR >= 0 && WV > 0) ? s_ - WL - WR : 0][ns];
+            acc[ms][ns] = mfma_step<T>(w, af[s_ & 1][ms], acc[ms][ns]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      BPX_STAMP();   // D2: dgrad steps done
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        u32x2_t tv[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) tv[ms] = *reinterpret_cast<const u32x2_t*>(tl + ns * TV * VB + ms * 16 * VB);
+        if (ACTK == 1) {
+#pragma unroll
+          for (int rp = 0; rp < 4; rp += 2) {
+            const f32x4_t* rsrc = reinterpret_cast<const f32x4_t*>(sN) + (ns * 16 + g * 4 + rp);
+            const f32x4_t ra = rsrc[0], rb = rsrc[1];
+            const f32x2_t sc2{ra[2], rb[2]}, sh2{ra[3], rb[3]}, rs2{ra[1], rb[1]}, nm2{-ra[0] * ra[1], -rb[0] * rb[1]};
+            f32x2_t s1p{0.f, 0.f}, s2p{0.f, 0.f};
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+              const uint32_t w = tv[ms][rp >> 1];
+              const f32x2_t tt{lo16<TT>(w), hi16<TT>(w)};
+              const f32x2_t u = __builtin_elementwise_fma(sc2, tt, sh2);
+              const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
+              const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
+              f32x2_t a_{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
+              const f32x2_t gu = f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a_;
+              const f32x2_t gv{__uint_as_float(__float_as_uint(gu[0]) & mk[ms]), __uint_as_float(__float_as_uint(gu[1]) & mk[ms])};
+              acc[ms][ns][rp] = gv[0]; acc[ms][ns][rp + 1] = gv[1];
+              s1p = s1p + gv;
+              s2p = __builtin_elementwise_fma(gv, xh, s2p);
+            }
+            ps1[ns][rp] += s1p[0]; ps1[ns][rp + 1] += s1p[1]; ps2[ns][rp] += s2p[0]; ps2[ns][rp + 1] += s2p[1];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4_t rec = reinterpret_cast<const f32x4_t*>(sN)[ns * 16 + g * 4 + r];
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) {
+              const uint32_t w = tv[ms][r >> 1];
+              const float tf = (r & 1) ? hi16<TT>(w) : lo16<TT>(w);
+              const float u = fmaf(rec[2], tf, rec[3]);
+              const float gv = __uint_as_float(__float_as_uint(acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.act)) & mk[ms]);
+              acc[ms][ns][r] = gv;
+              ps1[ns][r] += gv;
+              ps2[ns][r] += gv * ((tf - rec[0]) * rec[1]);
+            }
+          }
+        }
+        // buffer stores, out-of-volume rows to an out-of-range offset: no predicate, hence no branch - the predicated form cut the epilogue into
+        // 36 basic blocks of ~15 instructions, each ending in its own wait (5.4 K cycles for ~600 instructions)
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{cvt_pk_bf16(acc[ms][ns][0], acc[ms][ns][1]), cvt_pk_bf16(acc[ms][ns][2], acc[ms][ns][3])}, rs_y,
+                                                (int)(yoff[ms] + ns * 32u), 0, 0);
+      }
+      BPX_STAMP();   // D3: epilogue stores issued
+    }
+    if (n_cur >= 0) flush_stats(n_cur);
+    for (int nn = 0; nn < p.N; ++nn)
+      if (n_cur < 0 || nn < n_first || nn > n_cur)
+        for (int c = lane; c < 2 * Ct; c += 64) p.red[((size_t)nn * rows + row) * 2 * Ct + c] = 0.f;
+  } else {
+    // =========================================================== W role ===========================================================================
+    const int wt = tid & 255, ww = __builtin_amdgcn_readfirstlane(wave) - 4;   // (an SGPR: the pieces' LDS targets are scalar arithmetic)
+#if BPX_BWD_RS_WPRIO
+    __builtin_amdgcn_s_setprio(BPX_BWD_RS_WPRIO);   // the W waves are the younger half of the workgroup (arbitration losers) and the longer role
+#endif
+    const int sub = wt & 1;
+    const uint32_t dy_ld2 = (uint32_t)p.dy_ld * 2u;
+    uint32_t rel_t[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int tv = (u * 256 + wt) >> 1;
+      rel_t[u] = (uint32_t)((((tv >> 6) * H + ((tv >> 4) & 3)) * W + (tv & 15)) * p.t_ld + sub * KPL) * 2u;
+      asm volatile("" : "+v"(rel_t[u]));
+    }
+    const bool last_ok = (NPG - 1) * 256 + wt < NPGT;
+    const uint32_t t_csb = (uint32_t)p.t_cs * 2u;
+    const u32x4_t rs_g = raw_rsrc(p.dy, 0x80000000u), rs_t = raw_rsrc(p.t, 0x80000000u);
+#if BPX_BWD_RS_STAGE
+    // staging through REGISTERS: plain 16-byte buffer loads at the top of the wgrad phase, ds_write_b128 behind it.  (An LDS-DMA piece costs the
+    // CU's texture path ~64 cycles - four dword passes - against 16 for the plain load: 48 pieces per tile were ~3 K cycles of the W waves' tile.)
+    const __amdgpu_buffer_rsrc_t rb_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t), 0, (int)0x80000000u, 0x00020000);
+#endif
+    auto lds_off = [](const unsigned char* q) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t)const_cast<unsigned char*>(q)); };
+    // The WHOLE tile loop is instantiated per W wave (its seven taps are template constants of the MFMA phase): with the four-way switch inside the
+    // loop the accumulators met in a phi behind it, the register allocator did not coalesce them - 2 x 84 accumulator registers, 84 moves per tile,
+    // and spills whose reloads (scratch loads) waited for the DMA pieces in flight.
+    auto w_role = [&](auto wwc) {
+    constexpr int WW = decltype(wwc)::value;
+    f32x4_t accw[1][7][CT];
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) accw[0][a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool want_b = p.want_db != 0;
+    bool okt[2] = {false, false};
+    int n_tile = 0;
+    // requests of one tile into buffer b, the raw t tile and the dy halo by LDS-DMA (out-of-volume pieces: out-of-range offset = zeros), as NP
+    // pieces that are issued one by one: `setup` fixes the tile, `piece(q)` requests piece q (t pieces first, then the dy pieces IN ORDER - their halo
+    // coordinates are a running counter).  In the steady state the pieces are spread over the K-chunks of the wgrad phase: requested in one burst
+    // the wave sat in the issue for 4.4 K cycles per tile (the CU's request queue was full: it waited for HBM instead of computing).
+    constexpr int NP = CT * 2 + NPG;
+    uint32_t q_base_g = 0, q_base_t = 0, q_sG = 0, q_sT = 0, q_pk = 0;   // q_pk: halo coordinates of the next dy piece, hz | hy << 8 | hx << 16 (edge tiles only)
+    int q_z0 = 0, q_y0 = 0, q_x0 = 0;
+    bool q_interior = false, q_live = false;
+    // this thread's dy pieces relative to the halo origin (piece u = halo voxel (wt >> 1) + 128 u, half wt & 1): interior tiles - two thirds of a
+    // 128^3 volume - add the tile's base and are done; edge tiles also walk the halo coordinates for the bounds test
+    uint32_t rel_g[NPG];
+    const int hv0 = wt >> 1;
+    const uint32_t hpk0 = (uint32_t)(hv0 / (HX * HY)) | ((uint32_t)((hv0 / HX) % HY) << 8) | ((uint32_t)(hv0 % HX) << 16);
+#pragma unroll
+    for (int u = 0; u < NPG; ++u) {
+      const int hv = hv0 + u * 128, hz = hv / (HX * HY), hy = (hv / HX) % HY, hx = hv % HX;
+      rel_g[u] = (uint32_t)((hz * H + hy) * W + hx) * dy_ld2 + (uint32_t)sub * 16u;
+    }
+    // the next tile, in two parts: `decode` (scalar divisions, ~1 K cycles of dependent latency) runs at the TOP of the iteration, beside the
+    // transform's VALU work; `bases` - a few multiplies - behind the tile barrier, when the buffer is free
+    int d_n = 0, d_z0 = 0, d_y0 = 0, d_x0 = 0;
+    auto decode = [&](int tileId) {
+      int n, tzi, tyi, txi;
+      decode_tile(tileId, p.tilesZ, p.tilesY, p.tilesX, p.tilesPerSample, p.stripY, n, tzi, tyi, txi);
+      d_n = n; d_z0 = tzi * TZ; d_y0 = tyi * TY; d_x0 = txi * TX;
+    };
+    auto bases = [&](int b) {
+      const int n = d_n, z0 = d_z0, y0 = d_y0, x0 = d_x0;
+      n_tile = n;
+      const bool full = z0 + TZ <= D && y0 + TY <= H && x0 + TX <= W;
+      q_interior = full && z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+      q_base_g = (uint32_t)(((n * D + z0 - 1) * H + (y0 - 1)) * W + (x0 - 1)) * (uint32_t)p.dy_ld * 2u;
+      q_base_t = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.t_ld * 2u;
+      q_sG = lds_off(sG0 + b * SG_BYTES + ww * 1024);
+      q_sT = lds_off(sT0 + b * ST_BYTES + ww * 1024);
+      q_z0 = z0; q_y0 = y0; q_x0 = x0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int tv = (u * 256 + wt) >> 1;
+        okt[u] = full || (z0 + (tv >> 6) < D && y0 + ((tv >> 4) & 3) < H && x0 + (tv & 15) < W);
+      }
+      q_pk = hpk0;
+    };
+    static_assert(HX * HY + HX + 2 == 128 && NPG * 128 >= HV, "piece u + 1 = piece u + 128 voxels = one plane + one row + 2");
+    u32x4_t stg[BPX_BWD_RS_STAGE ? NP : 1];
+    auto piece = [&](int q) {
+      if (q < CT * 2) {
+        const int c = q >> 1, u = q & 1;
+        const uint32_t off = (okt[u] && q_live) ? q_base_t + rel_t[u] + (uint32_t)c * t_csb : OOR;
+#if BPX_BWD_RS_STAGE
+        stg[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb_t, (int)off, 0, 0));
+#else
+        dma16_asm(rs_t, q_sT + (uint32_t)(c * TV * VB + u * 4096), off);
+#endif
+      } else {
+        const int u = q - CT * 2;
+        const uint32_t inoff = q_base_g + rel_g[u];
+        int ok = (int)q_live;
+        if (!q_interior) {   // workgroup-uniform
+          int hz = (int)(q_pk & 255u), hy = (int)((q_pk >> 8) & 255u), hx = (int)(q_pk >> 16);
+          ok &= (int)((unsigned)(q_z0 - 1 + hz) < (unsigned)D) & (int)((unsigned)(q_y0 - 1 + hy) < (unsigned)H) & (int)((unsigned)(q_x0 - 1 + hx) < (unsigned)W);
+          hx += 2; hy += 1; hz += 1;
+          const int cx = hx >= HX; hx -= cx * HX; hy += cx;
+          const int cy = hy >= HY; hy -= cy * HY; hz += cy;
+          q_pk = (uint32_t)hz | ((uint32_t)hy << 8) | ((uint32_t)hx << 16);
+        }
+#if BPX_BWD_RS_STAGE
+        stg[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb_g, (int)(ok ? inoff : OOR), 0, 0));
+#else
+        if (u < NPG - 1) dma16_asm(rs_g, q_sG + (uint32_t)(u * 4096), ok ? inoff : OOR);
+        else if (last_ok) dma16_asm(rs_g, q_sG + (uint32_t)(u * 4096), ok ? inoff : OOR);   // (the tail piece: lanes beyond the halo stay masked - they would write past the buffer)
+#endif
+      }
+    };
+    auto land = [&](int b) {   // register staging: the pieces' ds_write_b128 into buffer b (each thread its own pieces: the transform needs no barrier)
+#if BPX_BWD_RS_STAGE
+      unsigned char* dT = sT0 + b * ST_BYTES + wt * 16;
+      unsigned char* dG = sG0 + b * SG_BYTES + wt * 16;
+#pragma unroll
+      for (int q = 0; q < CT * 2; ++q) *reinterpret_cast<u32x4_t*>(dT + (q >> 1) * TV * VB + (q & 1) * 4096) = stg[q];
+#pragma unroll
+      for (int u = 0; u < NPG; ++u)
+        if (u < NPG - 1 || last_ok) *reinterpret_cast<u32x4_t*>(dG + u * 4096) = stg[CT * 2 + u];
+#else
+      (void)b;
+#endif
+    };
+    int it = 0, n_cur = -1;
+    int local = slot;
+    bool have = local < p.tilesPerXcd && xcd * p.tilesPerXcd + local < p.totalTiles;
+    if (have) {
+      decode(xcd * p.tilesPerXcd + local);
+      bases(0);
+      q_live = true;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) piece(q);
+      land(0);
+    }
+    for (; have; ++it) {
+      const int b = it & 1;
+      unsigned char* sG = sG0 + b * SG_BYTES;
+      unsigned char* sT = sT0 + b * ST_BYTES;
+      unsigned char* sA = sA0;
+      BPX_STAMP();   // W0: tile start
+      local += spx;
+      const bool have_next = local < p.tilesPerXcd && xcd * p.tilesPerXcd + local < p.totalTiles;
+      if (have_next) decode(xcd * p.tilesPerXcd + local);
+      if (n_tile != n_cur) {   // wave-uniform: this wave's copy of the sample's norm records
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        if (lo < CT * 16) reinterpret_cast<f32x4_t*>(sN)[lo] = *reinterpret_cast<const f32x4_t*>(&p.t_norm[(size_t)n_tile * Ct + lo]);
+        n_cur = n_tile;
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA pieces of tile i have landed
+      while (__hip_atomic_load(wsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)it) __builtin_amdgcn_s_sleep(1);   // A is free
+      BPX_STAMP();   // W1: DMA landed, A free
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float psc[KPL], psh[KPL];
+        {
+          const f32x4_t* q = reinterpret_cast<const f32x4_t*>(sN) + (c * 16 + sub * KPL);
+#pragma unroll
+          for (int e = 0; e < KPL; ++e) {
+            const f32x4_t v = q[e];
+            psc[e] = v[2]; psh[e] = v[3];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          u32x4_t v = *reinterpret_cast<const u32x4_t*>(sT + c * TV * VB + (u * 256 + wt) * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {   // (a select, not a branch: out-of-volume voxels of ragged tiles stay zero - the conv pads the ACTIVATED tensor)
+            float a = fmaf(psc[2 * q], lo16<TT>(v[q]), psh[2 * q]), bb = fmaf(psc[2 * q + 1], hi16<TT>(v[q]), psh[2 * q + 1]);
+            act_pair<ACTK>(a, bb, p.act);
+            v[q] = okt[u] ? cvt_pk_bf16(a, bb) : 0u;
+          }
+          *reinterpret_cast<u32x4_t*>(sA + c * TV * VB + (u * 256 + wt) * 16) = v;
+        }
+      }
+      BPX_STAMP();   // W2: transformed
+      __syncthreads();   // X_i
+      BPX_STAMP();   // W3: barrier passed
+      have = have_next;
+      int lo = lane;
+      asm volatile("" : "+v"(lo));
+      const int jo = lo & 15, go = lo >> 4, trl = (jo >> 2), trc = (jo & 3) * 8;
+      const int a_base = go * 8 * VB + trl * VB + trc;
+      const int g_lane = (((go >> 1) * HX + (go & 1) * 8) + trl) * VB + trc;
+      if (have) bases(b ^ 1);
+      else {           // behind the last tile the pieces are still issued, with out-of-range offsets - zeros into the FREE buffer: no branch in the wgrad phase
+        q_sG = lds_off(sG0 + (b ^ 1) * SG_BYTES + ww * 1024);
+        q_sT = lds_off(sT0 + (b ^ 1) * ST_BYTES + ww * 1024);
+      }
+      q_live = have;
+      BPX_STAMP();   // W4: next tile set up
+#if BPX_BWD_RS_SPREAD
+      auto between = [&](int kc) {   // K-chunk kc of the wgrad phase requests the pieces [kc NP / NKC, (kc + 1) NP / NKC) of the next tile
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+          if (q >= kc * NP / NKC && q < (kc + 1) * NP / NKC) piece(q);
+      };
+#else
+      // (measured, profiles/r06_bwd_rs_log.txt: spread over the K-chunks of the wgrad phase the pieces cost the same ~370 cycles each - the phase grew
+      //  by what the burst had taken - and the chunk boundaries cost the scheduler its freedom: 905 vs 808 us)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) piece(q);
+      __builtin_amdgcn_sched_barrier(0);
+      BPX_STAMP();   // W5: pieces requested
+      auto between = [&](int) {};
+#endif
+      bpxwg::sd_mfma_phase<WW, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw[0], want_b, between);
+      __builtin_amdgcn_sched_barrier(0);
+      BPX_STAMP();   // W6: wgrad steps done
+      if (have) land(b ^ 1);
+      if (lane == 0) __hip_atomic_fetch_add(wsync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order: behind its last read of A)
+      BPX_STAMP();   // W7: pieces landed in LDS (register staging)
+    }
+    float* pp = p.part + (size_t)blockIdx.x * 27 * Ct * 16;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+      const int tap = 7 * WW + a;
+      if (tap >= 27) continue;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[((size_t)tap * Ct + c * 16 + 4 * g + r) * 16 + j] = accw[0][a][c][r];
+    }
+    if (want_b && WW == 3 && g == 0) p.dbpart[(size_t)blockIdx.x * 16 + j] = accw[0][6][0][0];
+    };
+    switch (ww) {   // wave-uniform
+      case 0: w_role(std::integral_constant<int, 0>{}); break;
+      case 1: w_role(std::integral_constant<int, 1>{}); break;
+      case 2: w_role(std::integral_constant<int, 2>{}); break;
+      default: w_role(std::integral_constant<int, 3>{}); break;
+    }
+  }
+#undef BPX_STAMP
+}
+
 int cu_count_() {
   static int n = 0;
   if (n == 0) {
@@ -581,8 +1089,16 @@ int cu_count_() {
 }
 
 int g_bwd_fused = 1;   // test / A-B hook (bpx_debug_set_bwd_fused)
+int g_bwd_stagger = 0; // (bpx_debug_set_bwd_stagger)
+int g_bwd_grid = 0;    // (bpx_debug_set_bwd_stagger, bits 16..)
 
-struct BwdPlan { int cg, ct, gy, grid, tilesZ, tilesY, tilesX; bool per_wg_rows; };
+// bit 0: the (dy 16, t 48) shape takes the role-split kernel, bit 1: (dy 16, t 16) does (test / A-B hook: bpx_debug_set_bwd_rs)
+#ifndef BPX_BWD_RS_DEFAULT
+#define BPX_BWD_RS_DEFAULT 3
+#endif
+int g_bwd_rs = BPX_BWD_RS_DEFAULT;
+
+struct BwdPlan { int cg, ct, gy, grid, tilesZ, tilesY, tilesX; bool per_wg_rows; bool rs; };
 // instance for (dy.C, t.C): 16 -> {16, 48}: (CG 1, CT 1 | 3); 32 -> {16, 32, ... 128}: (CG 2, CT 1) with t.C / 16 workgroup columns.  (A (CG 2, CT 2)
 // instance - two t chunks per workgroup, half the dy staging - needs 2 x 56 weight-gradient accumulators beside the rest and spilled 312 bytes per
 // lane at the 256 VGPRs of two workgroups per CU, in the staging section too, where a reload serialises the DMA pieces: not built.)
@@ -593,7 +1109,8 @@ bool bwd_instance(int Ct, int Cdy, BwdPlan& q) {
   else if (Cdy == 32 && (Ct == 16 || Ct == 32)) { q.cg = 2; q.ct = 1; q.gy = Ct / 16; }   // (t.C = 96 measured: 457 vs 449 us for the two kernels - six
   //                                                                                          columns re-stage the dy halo six times: not taken)
   else return false;
-  q.per_wg_rows = !(q.cg == 1 && q.ct == 3);
+  q.rs = q.cg == 1 && ((q.ct == 3 && (g_bwd_rs & 1)) || (q.ct == 1 && (g_bwd_rs & 2)));
+  q.per_wg_rows = q.rs || !(q.cg == 1 && q.ct == 3);
   return true;
 }
 BwdPlan bwd_plan(int N, int D, int H, int W, int Ct, int Cdy) {
@@ -601,9 +1118,10 @@ BwdPlan bwd_plan(int N, int D, int H, int W, int Ct, int Cdy) {
   bwd_instance(Ct, Cdy, q);
   q.tilesZ = cdiv(D, 4); q.tilesY = cdiv(H, 4); q.tilesX = cdiv(W, 16);
   const int total = N * q.tilesZ * q.tilesY * q.tilesX;
-  const int occ = (q.cg == 1 && q.ct == 1) ? BPX_BWD_OCC1 : 2;
+  const int occ = q.rs ? (q.ct == 1 ? 2 : 1) : (q.cg == 1 && q.ct == 1) ? BPX_BWD_OCC1 : 2;   // role-split: one 8-wave workgroup per CU (two with 16 channels)
   int gx = std::max(8, (cu_count_() * occ / std::max(1, q.gy)) & ~7);    // a multiple of 8: workgroup (x, y) then runs on XCD x % 8 for every y
   gx = std::min(gx, 8 * cdiv(total, 8));
+  if (g_bwd_grid > 0) gx = std::min(gx, std::max(8, g_bwd_grid & ~7));   // measurement only: fewer workgroups than CUs (is a phase bound per CU or chip-wide?)
   q.grid = gx;
   return q;
 }
@@ -623,6 +1141,8 @@ bool bwd_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) {
 
 // bit 0: the fused backward at all; bit 1 set = without the dy.C == 32 instances (A/B of the level-1 layers)
 extern "C" int bpx_debug_set_bwd_fused(int on) { g_bwd_fused = on & 1; g_bwd_level1 = (on & 2) ? 0 : 1; return 0; }
+extern "C" int bpx_debug_set_bwd_rs(int mask) { g_bwd_rs = mask & 3; return 0; }
+extern "C" int bpx_debug_set_bwd_stagger(int n) { g_bwd_stagger = n < 0 ? 0 : (n & 0xFFFF); g_bwd_grid = n < 0 ? 0 : (n >> 16); return 0; }
 
 extern "C" int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) { return bwd_supported(dtype, N, D, H, W, Ct, Cdy) ? 1 : 0; }
 
@@ -630,7 +1150,7 @@ extern "C" int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, in
 // (dy 16, t 48) instance, which writes one row per 4x4x16 tile
 extern "C" int bpx_conv3d_bwd_fused_stats_tiles(int N, int D, int H, int W, int Ct, int Cdy) {
   const BwdPlan q = bwd_plan(N, D, H, W, Ct, Cdy);
-  return q.per_wg_rows ? q.grid : cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);
+  return q.rs ? 4 * q.grid : q.per_wg_rows ? q.grid : cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16);   // role-split: one row per D wave
 }
 
 extern "C" int64_t bpx_conv3d_bwd_fused_workspace(int N, int D, int H, int W, int Ct, int Cdy) {
@@ -675,6 +1195,7 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   p.tilesPerXcd = cdiv(p.totalTiles, 8);
   p.stripY = strip_rows(q.tilesX);
   p.stamps = g_conv_stamps;
+  p.stagger = g_bwd_stagger;
   const bool mix = dtype == BPX_MIX16, elu = act == BPX_ACT_ELU;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)q.grid, (unsigned)q.gy);
@@ -683,7 +1204,17 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
     if (mix) { if (elu) conv3_bwd_kernel<CG_, CT_, 1, true><<<grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CG_, CT_, 0, true><<<grid, 256, 0, s>>>(p); }   \
     else { if (elu) conv3_bwd_kernel<CG_, CT_, 1, false><<<grid, 256, 0, s>>>(p); else conv3_bwd_kernel<CG_, CT_, 0, false><<<grid, 256, 0, s>>>(p); }     \
   }
-  LB(1, 1) LB(1, 3) LB(2, 1)
+  if (q.rs) {
+#define LR(CT_)                                                                                      \
+    if (q.ct == CT_) {                                                                                \
+      if (mix) { if (elu) conv3_bwd_rs_kernel<CT_, 1, true><<<grid, 512, 0, s>>>(p); else conv3_bwd_rs_kernel<CT_, 0, true><<<grid, 512, 0, s>>>(p); }   \
+      else { if (elu) conv3_bwd_rs_kernel<CT_, 1, false><<<grid, 512, 0, s>>>(p); else conv3_bwd_rs_kernel<CT_, 0, false><<<grid, 512, 0, s>>>(p); }     \
+    }
+    LR(1) LR(3)
+#undef LR
+  } else {
+    LB(1, 1) LB(1, 3) LB(2, 1)
+  }
 #undef LB
   BPX_LAUNCH_CHECK(fn);
   // dW in the PyTorch layout (Cout = dy.C, Cin = Ct, 3, 3, 3): index = ci * 27 + co * Ct * 27 + tap

@@ -7,6 +7,7 @@ failure - useful on the GPU box where a call costs minutes).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -913,7 +914,7 @@ def check_mix16_kernels(S=(8, 16, 32), B=2, Cin=32, Cout=16, seed=0):
     return res
 
 
-def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, act=1, Cdy=16):
+def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, act=1, Cdy=16, rs=None):
     """bpx_conv3d_bwd_fused (dgrad + wgrad of one conv in one pass) against the two separate entry points on the same device operands
     (g bit for bit, statistics / dW / db to fp32 summation order) and against the fp32 PyTorch operators on the same rounded inputs."""
     D, H, W = S
@@ -921,8 +922,22 @@ def check_bwd_fused(mix=True, B=2, S=(32, 32, 32), Ct=16, planar=False, seed=0, 
     A, G_ = (L.F16 if mix else L.BF16), L.BF16
     dtc = L.MIX16 if mix else L.BF16
     st = L.stream_ptr()
-    tag = f"bwd_fused[{'mix16' if mix else 'bf16'} B{B} {S} dy{Cdy}->g{Ct}{' planar' if planar else ''} act{act}]"
+    tag = f"bwd_fused[{'mix16' if mix else 'bf16'} B{B} {S} dy{Cdy}->g{Ct}{' planar' if planar else ''} act{act}{'' if rs is None else f' rs{rs}'}]"
     res = []
+    if rs is not None:      # role-split kernel mask (bpx_debug_set_bwd_rs): bit 0 = the 48-channel shape, bit 1 = the 16-channel shape
+        lib.bpx_debug_set_bwd_rs(rs)
+    try:
+        return _check_bwd_fused(tag, res, mix, B, S, Ct, planar, seed, act, Cdy, dtc, A, G_, gen, st)
+    finally:
+        if rs is not None:
+            lib.bpx_debug_set_bwd_rs(RS_DEFAULT)
+
+
+RS_DEFAULT = int(os.environ.get("BPX_BWD_RS", "3"))
+
+
+def _check_bwd_fused(tag, res, mix, B, S, Ct, planar, seed, act, Cdy, dtc, A, G_, gen, st):
+    D, H, W = S
     if not lib.bpx_conv3d_bwd_fused_supported(dtc, B, D, H, W, Ct, Cdy):
         return [_res(tag + ".supported", 1, 0)]
     rec, _, _ = make_recs(B, Ct, seed + 1)
