@@ -91,7 +91,6 @@ _SIGS = {
     "bpx_conv3d_bwd_fused": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_debug_set_bwd_fused": ([_i], _i),
     "bpx_debug_set_bwd_rs": ([_i], _i),
-    "bpx_debug_set_bwd_stagger": ([_i], _i),
     "bpx_debug_set_tile_order": ([_i], _i),
     "bpx_debug_set_wgrad_cap": ([_i], _i),
     "bpx_debug_set_wgrad_k1": ([_i], _i),
@@ -170,7 +169,7 @@ def _load() -> C.CDLL:
     # A/B hooks through the environment: wgrad partial-slab cap in percent
     for env, hook in (("BPX_WGRAD_CAP", "bpx_debug_set_wgrad_cap"), ("BPX_WGRAD_K1", "bpx_debug_set_wgrad_k1"),
                       ("BPX_PW_STREAM", "bpx_debug_set_pw_stream"), ("BPX_C1_PERSIST", "bpx_debug_set_c1_persist"),
-                      ("BPX_BWD_RS", "bpx_debug_set_bwd_rs"), ("BPX_BWD_STAGGER", "bpx_debug_set_bwd_stagger")):
+                      ("BPX_BWD_RS", "bpx_debug_set_bwd_rs")):
         if os.environ.get(env) is not None:
             getattr(lib, hook)(int(os.environ[env]))
     return lib

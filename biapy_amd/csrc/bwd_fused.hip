@@ -32,15 +32,8 @@ using namespace bpxconv;
 #ifndef BPX_BWD_LDSW
 #define BPX_BWD_LDSW 1
 #endif
-// role-split kernel (conv3_bwd_rs_kernel): staging of the next tile through registers (1) or by LDS-DMA (0); DMA pieces spread over the wgrad K-chunks
-#ifndef BPX_BWD_RS_STAGE
-#define BPX_BWD_RS_STAGE 0
-#endif
 #ifndef BPX_BWD_RS_WPRIO
 #define BPX_BWD_RS_WPRIO 1
-#endif
-#ifndef BPX_BWD_RS_SPREAD
-#define BPX_BWD_RS_SPREAD 0
 #endif
 
 namespace {
@@ -59,7 +52,6 @@ struct BwdParams {
   float* part; float* dbpart; int want_db;         // [grid][27][Ct][16] weight-gradient partials, [grid][16] bias-gradient partials
   int tilesZ, tilesY, tilesX, tilesPerSample, totalTiles, tilesPerXcd, stripY;
   long long* stamps;                               // profiling: per-workgroup cycle stamps [block][16] of the 5th tile (scripts/bwd_stamps.py), else null
-  int stagger;                                     // role-split kernel: start-up skew between the workgroups of an XCD, in units of 256 cycles per slot step
 };
 
 // CG = 16-channel chunks of dy (1: the 16-channel layers of level 0; 2: the 32-channel layers of level 1), CT = chunks of t / g this workgroup
@@ -639,10 +631,6 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
   unsigned char* const sW = sA0 + ST_BYTES + 8 * SN_BYTES;                 // [WL][NS][64 lanes][16 B]
   unsigned* const wsync = reinterpret_cast<unsigned*>(sW + SW_BYTES);      // W waves that have finished their wgrad steps, summed over tiles
   if (tid == 0) *wsync = 0u;
-  // Start-up skew: the workgroups run identical tiles at identical speed, i.e. in LOCKSTEP - every CU requests its 48 KB of the next tile in the
-  // same ~4 K cycles (the chip then runs at the HBM limit, ~11 bytes per cycle and CU) and nothing for the rest of the tile.  A one-off delay of
-  // (slot mod 8) x stagger x 256 cycles spreads the CUs' phases over a tile time; it costs one tile time of ~130.
-  for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(4);
   __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const int D = p.D, H = p.H, W = p.W, Ct = p.Ct;
@@ -858,12 +846,6 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
     const bool last_ok = (NPG - 1) * 256 + wt < NPGT;
     const uint32_t t_csb = (uint32_t)p.t_cs * 2u;
     const u32x4_t rs_g = raw_rsrc(p.dy, 0x80000000u), rs_t = raw_rsrc(p.t, 0x80000000u);
-#if BPX_BWD_RS_STAGE
-    // staging through REGISTERS: plain 16-byte buffer loads at the top of the wgrad phase, ds_write_b128 behind it.  (An LDS-DMA piece costs the
-    // CU's texture path ~64 cycles - four dword passes - against 16 for the plain load: 48 pieces per tile were ~3 K cycles of the W waves' tile.)
-    const __amdgpu_buffer_rsrc_t rb_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t), 0, (int)0x80000000u, 0x00020000);
-#endif
     auto lds_off = [](const unsigned char* q) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t)const_cast<unsigned char*>(q)); };
     // The WHOLE tile loop is instantiated per W wave (its seven taps are template constants of the MFMA phase): with the four-way switch inside the
     // loop the accumulators met in a phi behind it, the register allocator did not coalesce them - 2 x 84 accumulator registers, 84 moves per tile,
@@ -922,16 +904,11 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
       q_pk = hpk0;
     };
     static_assert(HX * HY + HX + 2 == 128 && NPG * 128 >= HV, "piece u + 1 = piece u + 128 voxels = one plane + one row + 2");
-    u32x4_t stg[BPX_BWD_RS_STAGE ? NP : 1];
     auto piece = [&](int q) {
       if (q < CT * 2) {
         const int c = q >> 1, u = q & 1;
         const uint32_t off = (okt[u] && q_live) ? q_base_t + rel_t[u] + (uint32_t)c * t_csb : OOR;
-#if BPX_BWD_RS_STAGE
-        stg[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb_t, (int)off, 0, 0));
-#else
         dma16_asm(rs_t, q_sT + (uint32_t)(c * TV * VB + u * 4096), off);
-#endif
       } else {
         const int u = q - CT * 2;
         const uint32_t inoff = q_base_g + rel_g[u];
@@ -944,26 +921,9 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
           const int cy = hy >= HY; hy -= cy * HY; hz += cy;
           q_pk = (uint32_t)hz | ((uint32_t)hy << 8) | ((uint32_t)hx << 16);
         }
-#if BPX_BWD_RS_STAGE
-        stg[q] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb_g, (int)(ok ? inoff : OOR), 0, 0));
-#else
         if (u < NPG - 1) dma16_asm(rs_g, q_sG + (uint32_t)(u * 4096), ok ? inoff : OOR);
         else if (last_ok) dma16_asm(rs_g, q_sG + (uint32_t)(u * 4096), ok ? inoff : OOR);   // (the tail piece: lanes beyond the halo stay masked - they would write past the buffer)
-#endif
       }
-    };
-    auto land = [&](int b) {   // register staging: the pieces' ds_write_b128 into buffer b (each thread its own pieces: the transform needs no barrier)
-#if BPX_BWD_RS_STAGE
-      unsigned char* dT = sT0 + b * ST_BYTES + wt * 16;
-      unsigned char* dG = sG0 + b * SG_BYTES + wt * 16;
-#pragma unroll
-      for (int q = 0; q < CT * 2; ++q) *reinterpret_cast<u32x4_t*>(dT + (q >> 1) * TV * VB + (q & 1) * 4096) = stg[q];
-#pragma unroll
-      for (int u = 0; u < NPG; ++u)
-        if (u < NPG - 1 || last_ok) *reinterpret_cast<u32x4_t*>(dG + u * 4096) = stg[CT * 2 + u];
-#else
-      (void)b;
-#endif
     };
     int it = 0, n_cur = -1;
     int local = slot;
@@ -974,7 +934,6 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
       q_live = true;
 #pragma unroll
       for (int q = 0; q < NP; ++q) piece(q);
-      land(0);
     }
     for (; have; ++it) {
       const int b = it & 1;
@@ -1033,28 +992,15 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
       }
       q_live = have;
       BPX_STAMP();   // W4: next tile set up
-#if BPX_BWD_RS_SPREAD
-      auto between = [&](int kc) {   // K-chunk kc of the wgrad phase requests the pieces [kc NP / NKC, (kc + 1) NP / NKC) of the next tile
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-          if (q >= kc * NP / NKC && q < (kc + 1) * NP / NKC) piece(q);
-      };
-#else
       // (measured, profiles/r06_bwd_rs_log.txt: spread over the K-chunks of the wgrad phase the pieces cost the same ~370 cycles each - the phase grew
       //  by what the burst had taken - and the chunk boundaries cost the scheduler its freedom: 905 vs 808 us)
 #pragma unroll
       for (int q = 0; q < NP; ++q) piece(q);
       __builtin_amdgcn_sched_barrier(0);
       BPX_STAMP();   // W5: pieces requested
-      auto between = [&](int) {};
-#endif
-      bpxwg::sd_mfma_phase<WW, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw[0], want_b, between);
-      __builtin_amdgcn_sched_barrier(0);
+      bpxwg::sd_mfma_phase<WW, CT, HY, HX, VB, VB, TV, NKC>(sA, sG, a_base, g_lane, accw[0], want_b);
       BPX_STAMP();   // W6: wgrad steps done
-      if (have) land(b ^ 1);
       if (lane == 0) __hip_atomic_fetch_add(wsync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order: behind its last read of A)
-      BPX_STAMP();   // W7: pieces landed in LDS (register staging)
     }
     float* pp = p.part + (size_t)blockIdx.x * 27 * Ct * 16;
 #pragma unroll
@@ -1089,8 +1035,6 @@ int cu_count_() {
 }
 
 int g_bwd_fused = 1;   // test / A-B hook (bpx_debug_set_bwd_fused)
-int g_bwd_stagger = 0; // (bpx_debug_set_bwd_stagger)
-int g_bwd_grid = 0;    // (bpx_debug_set_bwd_stagger, bits 16..)
 
 // bit 0: the (dy 16, t 48) shape takes the role-split kernel, bit 1: (dy 16, t 16) does (test / A-B hook: bpx_debug_set_bwd_rs)
 #ifndef BPX_BWD_RS_DEFAULT
@@ -1121,7 +1065,6 @@ BwdPlan bwd_plan(int N, int D, int H, int W, int Ct, int Cdy) {
   const int occ = q.rs ? (q.ct == 1 ? 2 : 1) : (q.cg == 1 && q.ct == 1) ? BPX_BWD_OCC1 : 2;   // role-split: one 8-wave workgroup per CU (two with 16 channels)
   int gx = std::max(8, (cu_count_() * occ / std::max(1, q.gy)) & ~7);    // a multiple of 8: workgroup (x, y) then runs on XCD x % 8 for every y
   gx = std::min(gx, 8 * cdiv(total, 8));
-  if (g_bwd_grid > 0) gx = std::min(gx, std::max(8, g_bwd_grid & ~7));   // measurement only: fewer workgroups than CUs (is a phase bound per CU or chip-wide?)
   q.grid = gx;
   return q;
 }
@@ -1142,7 +1085,6 @@ bool bwd_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) {
 // bit 0: the fused backward at all; bit 1 set = without the dy.C == 32 instances (A/B of the level-1 layers)
 extern "C" int bpx_debug_set_bwd_fused(int on) { g_bwd_fused = on & 1; g_bwd_level1 = (on & 2) ? 0 : 1; return 0; }
 extern "C" int bpx_debug_set_bwd_rs(int mask) { g_bwd_rs = mask & 3; return 0; }
-extern "C" int bpx_debug_set_bwd_stagger(int n) { g_bwd_stagger = n < 0 ? 0 : (n & 0xFFFF); g_bwd_grid = n < 0 ? 0 : (n >> 16); return 0; }
 
 extern "C" int bpx_conv3d_bwd_fused_supported(int dtype, int N, int D, int H, int W, int Ct, int Cdy) { return bwd_supported(dtype, N, D, H, W, Ct, Cdy) ? 1 : 0; }
 
@@ -1195,7 +1137,6 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   p.tilesPerXcd = cdiv(p.totalTiles, 8);
   p.stripY = strip_rows(q.tilesX);
   p.stamps = g_conv_stamps;
-  p.stagger = g_bwd_stagger;
   const bool mix = dtype == BPX_MIX16, elu = act == BPX_ACT_ELU;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)q.grid, (unsigned)q.gy);

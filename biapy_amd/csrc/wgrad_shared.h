@@ -16,16 +16,12 @@ namespace bpxwg {
 // in every row of acc[6][0] (bf16 1.0 x dy is exact, the sums are fp32 like the weight gradients) - no extra registers, and it replaces
 // a 16-iteration scalar-load loop over the dy tile that every wave of the workgroup ran per tile (~150 of the kernel's ~540 VALU
 // instructions per tile and wave; the kernel is VALU-bound).
-struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
-// `between(kc)` runs at the top of K-chunk kc (bwd_fused.hip's role-split kernel requests the next tile's DMA pieces there, a few per chunk)
-template <int W, int MC, int HY, int HX, int VBA, int VBG, int TV, int NKC, typename Between = NoBetween>
-__device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC], bool want_b,
-                                              Between&& between = Between()) {
+template <int W, int MC, int HY, int HX, int VBA, int VBG, int TV, int NKC>
+__device__ __forceinline__ void sd_mfma_phase(const unsigned char* sA, const unsigned char* sG, int a_base, int g_lane, f32x4_t (&acc)[7][MC], bool want_b) {
   constexpr int T0 = 7 * W, T1 = (T0 + 7 < 27) ? T0 + 7 : 27;
   typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc) {
-    between(kc);
     const int ka = kc * 32 * VBA;
     const int kg = (((kc >> 1) * HY + (kc & 1) * 2) * HX) * VBG;
     u32x4_t af[MC];

@@ -360,8 +360,27 @@ def test_fp16_raw_outputs_saturate_instead_of_overflowing(K):
                          ids=["mix-16", "mix-48-planar", "bf16-16-ragged", "mix-48-planar-ragged", "bf16-48-relu", "mix-16-64^3"])
 def test_fused_conv_backward_equals_dgrad_plus_wgrad(K, mix, B, S, Ct, planar, act):
     """bpx_conv3d_bwd_fused: one pass over (dy, t) gives the dgrad kernel's g bit for bit, and its statistics / dW / db to fp32 summation order;
-    also against the fp32 PyTorch operators, and bit-reproducible."""
-    _assert_all(K.check_bwd_fused(mix, B, S, Ct, planar, act=act))
+    also against the fp32 PyTorch operators, and bit-reproducible.  With the library's default these shapes run the ROLE-SPLIT kernel
+    (conv3_bwd_rs_kernel, round 6: four dgrad + four wgrad waves per CU, two tiles in flight)."""
+    _assert_all(K.check_bwd_fused(mix, B, S, Ct, planar, act=act, rs=3))
+
+
+@pytest.mark.parametrize("mix,B,S,Ct,planar,act", [(True, 2, (32, 32, 32), 16, False, 1), (True, 2, (34, 38, 44), 48, True, 1), (False, 1, (32, 32, 48), 48, False, 2),
+                                                   (True, 3, (32, 32, 32), 16, False, 3), (True, 4, (64, 64, 64), 48, True, 1)],
+                         ids=["mix-16", "mix-48-planar-ragged", "bf16-48-relu", "mix-16-silu-3-samples", "mix-48-64^3-4-samples"])
+def test_fused_conv_backward_serial_kernel_still_matches(K, mix, B, S, Ct, planar, act):
+    """The one-workgroup-per-tile-phase form of the fused backward (conv3_bwd_kernel) stays the fallback of the role-split kernel (g beyond 2 GB) and
+    the A/B partner of its measurements: same checks with the role-split mask cleared."""
+    _assert_all(K.check_bwd_fused(mix, B, S, Ct, planar, act=act, rs=0))
+
+
+def test_role_split_backward_walks_many_tiles_and_samples(K):
+    """Several tiles per workgroup and sample boundaries inside a workgroup's run (4 x 64^3 and 3 x 40 x 72 x 80 are 2-4 tiles per workgroup: the LDS
+    double buffer alternates, the W waves' counter on the single activated tile advances, per-wave statistics rows are flushed at sample changes)."""
+    _assert_all(K.check_bwd_fused(True, 4, (64, 64, 64), 48, True, act=1, rs=3))
+    _assert_all(K.check_bwd_fused(True, 4, (64, 64, 64), 16, False, act=1, rs=3))
+    _assert_all(K.check_bwd_fused(True, 3, (40, 72, 80), 48, True, act=1, rs=3))
+    _assert_all(K.check_bwd_fused(False, 5, (36, 70, 50), 16, False, act=2, rs=3))
 
 
 @pytest.mark.parametrize("mix,B,S,Ct,planar,act", [(True, 2, (32, 32, 32), 32, False, 1), (True, 1, (32, 32, 32), 32, True, 1), (False, 1, (36, 34, 40), 16, False, 1),
