@@ -12,8 +12,8 @@ exactly K steps between barriers + synchronize, max over ranks).  The same proce
 and reported as a sub-record with its own roofline entry:
   ``infer``   - forward + fused sigmoid of the same batch (weak scaling: every rank its own batch);
   ``sliding`` - cfg 3, crop -> forward -> blend of a 1024^3 synthetic volume, 4096 patches sharded over the ranks by Z-slab, each
-                rank holding only its input slab; strong scaling (N = 1 measures one GPU's share of the 8-GPU job, a 512^3 volume,
-                unless --vol is given).
+                rank holding only its input slab; strong scaling (N = 1 runs the whole 1024^3 volume on one GPU; --vol 512 is one GPU's
+                share of the 8-GPU job).
 Workload = BASELINE.json configs[1]: 3D ResUNet (feature maps 16-32-64-128-256, InstanceNorm, ELU), 128^3 1-channel patches,
 batch 4 per GPU, bf16 storage / fp32 accumulate, synthetic data, random-init weights.  One step = one pass over one batch.
 """
@@ -384,8 +384,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["all", "train", "infer", "sliding"], default="all",
                     help="all = train (the headline value) + the infer and sliding sub-records; one name = that section only")
-    ap.add_argument("--vol", type=int, default=None, help="edge of the synthetic sliding-window volume (cfg 3 = 1024; default: 1024 for N > 1, "
-                                                          "512 = one GPU's share for N = 1)")
+    ap.add_argument("--vol", type=int, default=None, help="edge of the synthetic sliding-window volume (default: cfg 3's 1024 at every N; 512 = one GPU's share of the "
+                                                          "8-GPU job, the round 1-5 default at N = 1)")
+    ap.add_argument("--feed", choices=["host", "device"], default="host",
+                    help="host (default): every timed train step takes its batch from pinned host memory (async H2D on a copy stream + a device-to-device "
+                         "copy into the step's inputs), as the reference's loop does; device: one device-resident batch, no copies (rounds 1-5)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--dtype", choices=["mix16", "bf16", "f32"], default="mix16",
@@ -460,7 +463,7 @@ def main():
     model = ResUNet(image_shape=(a.patch,) * 3 + (1,), activation="elu", feature_maps=FM, drop_values=[0.0] * 5, normalization="in",
                     yx_down=[2] * 4, z_down=[2] * 4, isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=dtype).to(dev)
     init_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}     # the sliding-window sections run with THESE weights at every N
-    V = a.vol if a.vol is not None else (1024 if world > 1 else 512)
+    V = a.vol if a.vol is not None else 1024     # cfg 3's own size at every N (one GPU holds it: 4.3 GB in, 4.3 GB out; a timed pass is ~2.6 s)
     inf_name = {"mix16": "f16"}.get(a.dtype, a.dtype) if (a.infer_dtype == "same" or a.dtype == "f32") else a.infer_dtype
     inf_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[inf_name]
     if a.mode == "sliding":
@@ -525,6 +528,39 @@ def main():
 
                     estep = DataParallelTrainStep(net, loss_fn, opt, x, tgt, graph=False, broadcast_parameters=False)
                     step = lambda: estep()  # noqa: E731
+        feed_note = "device-resident batch, H2D excluded"
+        if a.feed == "host" and not a.breakdown:
+            # The reference copies every batch to the device (train_engine.py:116, 125: two H2D copies per step).  Here: the batch lies in PINNED host
+            # memory, a copy stream brings the NEXT step's batch into a staging pair while this step computes, and the step begins with a
+            # device-to-device copy of the staged pair into its (graph-static) input tensors - all inside the timed region.
+            xs_h, ts_h = x.cpu().pin_memory(), tgt.cpu().pin_memory()       # (channels_last_3d strides kept: a plain byte copy)
+            xs_d, ts_d = torch.empty_like(x), torch.empty_like(tgt)
+            copy_stream = torch.cuda.Stream(device=dev)
+            ev_staged, ev_taken = torch.cuda.Event(), torch.cuda.Event()
+
+            def stage():
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(ev_taken)
+                    xs_d.copy_(xs_h, non_blocking=True)
+                    ts_d.copy_(ts_h, non_blocking=True)
+                    ev_staged.record(copy_stream)
+
+            ev_taken.record(torch.cuda.current_stream())
+            stage()
+            inner_step = step
+
+            def fed_step():
+                main = torch.cuda.current_stream()
+                main.wait_event(ev_staged)
+                x.copy_(xs_d)
+                tgt.copy_(ts_d)
+                ev_taken.record(main)
+                stage()
+                return inner_step()
+
+            step = fed_step
+            feed_note = ("pinned host batch (%.1f MB): async H2D on a copy stream beside the previous step, then a device-to-device copy into the step's static "
+                         "inputs; both inside the timed region" % ((xs_h.numel() * xs_h.element_size() + ts_h.numel() * ts_h.element_size()) / 1e6))
         for _ in range(a.warmup):
             out = step()
         torch.cuda.synchronize()
@@ -574,7 +610,7 @@ def main():
             line = dict(
                 metric="voxels/sec 3D ResUNet 128^3 patch (train: fwd+bwd+AdamW; sub-records: infer, sliding)",
                 value=value, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic",
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic", feed=feed_note,
                 config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, train" % (a.patch, a.batch),
                             global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode="train"),
                 launch=(("hip-graph replays (forward+loss+backward up to the first encoder block | its backward | optimizer), the flat-gradient RCCL all-reduce "

@@ -202,8 +202,14 @@ class ChunkedPredictor:
                         q = grid.region(v)
                         regs[r * slots + k, 3:] = q[3:]
             regions = torch.from_numpy(regs).to(vol.device, non_blocking=True)
+            del cores   #  the rank's own cores are inside `got` now: the result volume takes their place instead of sitting beside them
             out = torch.zeros((Z, Y, X, Co), dtype=torch.float32, device=vol.device)
-            L.check(lib.bpx_scatter3d_regions(got.data_ptr(), world * slots, cz, cy, cx, Co, regions.data_ptr(), out.data_ptr(), Z, Y, X, st))
+            # bpx_scatter3d_regions puts the patch index on grid.y (<= 65535): bounded groups of slots, in rank-major order like the one call was
+            total, step_n = world * slots, 32768
+            core_bytes = cz * cy * cx * Co * 4
+            for s0 in range(0, total, step_n):
+                n = min(step_n, total - s0)
+                L.check(lib.bpx_scatter3d_regions(got.data_ptr() + s0 * core_bytes, n, cz, cy, cx, Co, regions.data_ptr() + s0 * 9 * 4, out.data_ptr(), Z, Y, X, st))
         return out
 
 

@@ -902,6 +902,7 @@ int launch_conv3_zm(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   if (mode == 0) return 1;
   if (!(c.tz == 4 && c.ty == 8 && c.tx == 16 && c.ns == 1) || p0.Cout != 16 || p0.ps > 1) return 1;
   if (!(p0.Cin == 16 || p0.Cin == 48)) return 1;
+  if (p0.pool != nullptr && p0.Cin != 16) return 1;   // the fused MaxPool epilogue exists in the one-chunk kernels only: 48 -> 16 + pool takes the lean kernel
   {   // A/B aid: BPX_CONV_ZM_MASK bit 0 = one chunk without a wide shortcut, bit 1 = one chunk + shortcut of 16 .. 48 channels, bit 2 = three chunks
     static const char* e = getenv("BPX_CONV_ZM_MASK");
     static const int mask = e ? atoi(e) : 7;

@@ -789,7 +789,10 @@ int launch_pw(PwParams& p, int ns, hipStream_t s) {
         return 0;
       }
     }
-    if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
+    // one K step without the buffer-addressed kernel (W % 16 != 0, operands beyond 32-bit offsets, BPX_CONVT_K1 = 0): the round-4 instance that
+    // keeps its weights in registers and requests the next blocks' operands ahead of the stores (it had lost its launch)
+    if (ns == 4 && MODE == PW_CONVT && sizeof(T) == 2 && p.K * (int)sizeof(T) <= 64) pw_kernel<T, MSK, 4, MODE, PL, TT, MODE == PW_CONVT && sizeof(T) == 2><<<grid, 256, 0, s>>>(p);
+    else if (ns == 4) pw_kernel<T, MSK, 4, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else if (ns == 3) pw_kernel<T, MSK, 3, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else if (ns == 2) pw_kernel<T, MSK, 2, MODE, PL, TT><<<grid, 256, 0, s>>>(p);
     else pw_kernel<T, MSK, 1, MODE, PL, TT><<<grid, 256, 0, s>>>(p);

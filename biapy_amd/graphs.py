@@ -291,9 +291,11 @@ class DataParallelTrainStep:
             return False
         # the overlapped form calls engine.forward / engine.backward itself: module forward hooks would be skipped, so a hooked model keeps the
         # serial form (which goes through model.forward) under overlap="auto"
-        for m_ in {id(model): model, id(inner): inner}.values():
-            if getattr(m_, "_forward_hooks", None) or getattr(m_, "_forward_pre_hooks", None) or getattr(m_, "_backward_hooks", None):
-                return False
+        hooked = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
+        for top in {id(model): model, id(inner): inner}.values():
+            for m_ in top.modules():      # submodules too: a hook on a block would be skipped just the same
+                if any(getattr(m_, h, None) for h in hooked):
+                    return False
         names, params = inner._named()
         if [id(p) for p in params] != [id(p) for p in self.params]:
             return False
