@@ -1,4 +1,5 @@
 """GPU parity tests: every C-ABI kernel and the whole network against the oracle (run with -m gpu)."""
+import numpy as np
 import pytest
 import torch
 
@@ -1611,6 +1612,133 @@ def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve(dtype):
     print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
     _record_diag(f"loss_curve[resunet++ {dtype} vs fp32 oracle, fm 16-32-64 at 32^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar 0.05)")
     assert rel < 0.05, (rel, curve_c, curve_d)
+
+
+PP_CFG4_CURVE_TOL = 1e-2      # VERDICT r5 next #5b: the loss-curve bar on cfg 4's own architecture (measured values: profiles/r06_gpu_test_values.txt)
+
+
+def test_resunetpp_cfg4_architecture_mixed_training_follows_the_fp32_oracle_loss_curve():
+    """VERDICT r5 weak #3 / next #5b: the ResUNet++ loss-curve test on cfg 4's OWN architecture - five levels, fm 16-32-64-128-256, B / C / D loss -
+    in the mode cfg 4 is benched in (fp16 forward, bf16 gradients), at cfg 4's own 80^3 patch size, 12 AdamW steps beside the fp32 oracle from the
+    same weights on the same batches (the fp32 CPU oracle graph of the five-level net at 80^3 is what bounds the step count: ~8 s per step).
+    Bar 1e-2 on the worst relative gap of the curves; measured 4.2e-3 over 20 steps (profiles/r06_gpu_test_values.txt).  The three-level test
+    above keeps its 0.05.  (At 48^3 the same net reads 2.5e-2: its deepest level is 3^3 voxels per InstanceNorm - a property of the size, not of
+    the arithmetic.)"""
+    import torch.nn.functional as F_
+
+    from biapy_amd.losses import InstanceChannelsLoss
+    from biapy_amd.resunetpp import ResUNetPlusPlus
+    from oracle import loss_oracle, resunetpp_oracle
+
+    fm, steps, S = [16, 32, 64, 128, 256], 12, 80
+    torch.manual_seed(3)
+    dev_m = ResUNetPlusPlus(image_shape=(S, S, S, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", k_size=3,
+                            upsample_layer="convtranspose", yx_down=[2] * 4, z_down=[2] * 4, output_channels=[3], output_channel_info=["BCD"],
+                            head_activations=["ce_sigmoid", "ce_sigmoid", "tanh"], isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5,
+                            compute_dtype=torch.float16).cuda().train()
+    cpu_p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dev_m.named_parameters()}
+    g = torch.Generator().manual_seed(8)
+    batches = []
+    for _ in range(4):
+        t_bc = (F_.avg_pool3d(torch.randn(1, 2, S, S, S, generator=g), 5, stride=1, padding=2) > 0.02).float()
+        t_d = torch.tanh(F_.avg_pool3d(torch.randn(1, 1, S, S, S, generator=g), 5, stride=1, padding=2) * 4)
+        x = t_bc[:, :1] * 1.5 + 0.5 * t_d + 0.6 * torch.randn(1, 1, S, S, S, generator=g)
+        batches.append((x, torch.cat([t_bc, t_d], 1)))
+    loss_fn = InstanceChannelsLoss(channel_weights=(1, 1, 1), out_channels=["B", "C", "D"], losses_to_use=["bce", "bce", "mse"]).cuda()
+    opt_d = torch.optim.AdamW(dev_m.parameters(), lr=1e-3)
+    opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=1e-3)
+    curve_d, curve_c = [], []
+    for it in range(steps):
+        x, t = batches[it % len(batches)]
+        opt_d.zero_grad(set_to_none=True)
+        ld = loss_fn(dev_m(x.cuda()), t.cuda())
+        ld.backward()
+        opt_d.step()
+        opt_c.zero_grad(set_to_none=True)
+        lo = resunetpp_oracle.resunetpp_forward(cpu_p, x, fm)
+        lc = loss_oracle.instance_channels(loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True), t, ["bce", "bce", "mse"], [1, 1, 1])
+        lc.backward()
+        opt_c.step()
+        curve_d.append(ld.item())
+        curve_c.append(lc.item())
+    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+    assert cc[-4:].mean() < 0.9 * cc[:4].mean() and cd[-4:].mean() < 0.9 * cd[:4].mean(), (curve_c, curve_d)
+    rel = ((cd - cc).abs() / cc).max().item()
+    print(f"cfg-4 architecture: worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
+    _record_diag(f"loss_curve[resunet++ cfg-4 arch (fm 16-32-64-128-256) mixed vs fp32 oracle, {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {PP_CFG4_CURVE_TOL:g})")
+    assert rel < PP_CFG4_CURVE_TOL, (rel, curve_c, curve_d)
+
+
+PLATEAU_DICE_TOL = 1e-3       # VERDICT r5 next #5a: measured |Dice delta| of the two trained weight sets 1.8e-4 after 240 steps, 4.5e-4 at step 160 (profiles/r06_gpu_test_values.txt)
+
+
+def test_resunet_mixed_training_reaches_the_fp32_oracles_plateau(K):
+    """VERDICT r5 weak #2 / next #5a: training parity beyond 30 steps.  The cfg-2 architecture, 200 AdamW steps on the device in the benched mixed
+    mode (fp16 forward, bf16 gradients) and the same 200 steps as the fp32 CPU oracle graph, from one initialisation on the same batches (8
+    training volumes of 32^3 visited in order - the size is what 200 fp32 CPU steps of the five-level net allow: ~1 s each on the GPU box's host; the level-0 layers still take the
+    fused backward and lean forward kernels from 32^3 on).  Two runs in different arithmetic do not stay step-for-step together that long -
+    rounding noise is amplified by training - so the claim tested is the one that matters: BOTH weight sets are evaluated by the SAME fp32 oracle
+    forward on 6 held-out volumes, after 140 and after 200 steps; the held-out Dice has stopped moving between the two (the plateau), and at the
+    end the two runs' Dice and loss agree.  A biased gradient would land the device run on a different plateau.  Bar 1e-3 against measured gaps of 1.8e-4 ... 4.5e-4 (240-step run)."""
+    import torch.nn.functional as F_
+
+    from biapy_amd.resunet import ResUNet
+    from oracle import net_oracle
+
+    fm, steps, S, probe = [16, 32, 64, 128, 256], 200, 32, 140
+    torch.manual_seed(5)
+    dev_m = ResUNet(image_shape=(S, S, S, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4, z_down=[2] * 4,
+                    isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=torch.float16).cuda().train()
+    cpu_p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dev_m.named_parameters()}
+    g = torch.Generator().manual_seed(21)
+
+    def volume():
+        tgt = (F_.avg_pool3d(torch.randn(1, 1, S, S, S, generator=g), 7, stride=1, padding=3) > 0.0).float()
+        return tgt * 1.2 + 0.8 * torch.randn(1, 1, S, S, S, generator=g), tgt
+
+    train, held = [volume() for _ in range(8)], [volume() for _ in range(6)]
+
+    def held_out():
+        sd_d = {k: v.detach().cpu() for k, v in dev_m.state_dict().items()}
+        sd_c = {k: v.detach() for k, v in cpu_p.items()}
+        dd, dc, ld_, lc_ = [], [], [], []
+        with torch.no_grad():
+            for x, t in held:      # the SAME fp32 evaluator for both weight sets
+                lo_d, lo_c = net_oracle.resunet_forward(sd_d, x, fm), net_oracle.resunet_forward(sd_c, x, fm)
+                dd.append(net_oracle.dice(torch.sigmoid(lo_d), t)); dc.append(net_oracle.dice(torch.sigmoid(lo_c), t))
+                ld_.append(net_oracle.bce_with_logits(lo_d, t).item()); lc_.append(net_oracle.bce_with_logits(lo_c, t).item())
+        return float(np.mean(dd)), float(np.mean(dc)), float(np.mean(ld_)), float(np.mean(lc_))
+
+    opt_d = torch.optim.AdamW(dev_m.parameters(), lr=1e-3)
+    opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=1e-3)
+    curve_d, curve_c, mid = [], [], None
+    for it in range(steps):
+        if it == probe:
+            mid = held_out()
+        x, t = train[it % len(train)]
+        opt_d.zero_grad(set_to_none=True)
+        ld = F_.binary_cross_entropy_with_logits(dev_m(x.cuda()), t.cuda())
+        ld.backward()
+        opt_d.step()
+        opt_c.zero_grad(set_to_none=True)
+        lc = net_oracle.bce_with_logits(net_oracle.resunet_forward(cpu_p, x, fm), t)
+        lc.backward()
+        opt_c.step()
+        curve_d.append(ld.item())
+        curve_c.append(lc.item())
+    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+    md, mc, hl_d, hl_c = held_out()
+    gap, lgap = abs(md - mc), abs(hl_d - hl_c) / hl_c
+    print(f"after {probe} steps: held-out Dice device-trained {mid[0]:.6f} / oracle-trained {mid[1]:.6f}; after {steps}: {md:.6f} / {mc:.6f} (|delta| {gap:.3e}); "
+          f"held-out loss {hl_d:.5f} / {hl_c:.5f} (rel gap {lgap:.3e}); train loss first 8 {cc[:8].mean().item():.4f}, last 40 {cd[-40:].mean().item():.4f} / {cc[-40:].mean().item():.4f}")
+    _record_diag(f"plateau[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].heldout_dice device-trained = {md:.6f}, oracle-trained = {mc:.6f}, abs_delta = {gap:.3e} "
+                 f"(bar {PLATEAU_DICE_TOL:g}); at step {probe}: {mid[0]:.6f} / {mid[1]:.6f}; heldout_loss_rel_gap = {lgap:.3e}; train_loss_last40 = "
+                 f"{cd[-40:].mean().item():.4f} / {cc[-40:].mean().item():.4f}")
+    for name, c in (("device", cd), ("oracle", cc)):
+        assert c[-40:].mean() < 0.5 * c[:8].mean(), (name, c[:8].mean().item(), c[-40:].mean().item())
+    assert abs(md - mid[0]) < 0.02 and abs(mc - mid[1]) < 0.02, (mid, md, mc)      # the held-out Dice has plateaued
+    assert gap < PLATEAU_DICE_TOL, (md, mc)
+    assert lgap < 0.1, (hl_d, hl_c)
 
 
 def test_resunet_mixed_training_follows_the_fp32_oracle_loss_curve(K):
