@@ -327,7 +327,6 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
     }
 
     // ---- epilogue: all loads first, then math + one 8-byte store per (m-subtile, 16-channel group) ------------------
-    char* __restrict__ yout = reinterpret_cast<char*>(p.y);
     uint32_t yrow = (uint32_t)(RS * W * p.y_ld) * 2u;                                        // bytes between m-subtiles
     uint32_t yb0 = (uint32_t)(vox0 * p.y_ld + g * 4) * 2u + (uint32_t)(co_base >> 4) * y_csb;        // co_base is a multiple of 16
     uint32_t ysub[NS];                                                                       // byte offset of output-channel block ns
@@ -347,6 +346,20 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         ysub[ns] = (uint32_t)(((a * Hs + b) * Ws + e) * 16) * 2u;
       }
     }
+    // Branch-free rows (round 6): out-of-volume rows of edge tiles are masked - their statistics contribution by an AND with an opaque all-ones /
+    // zero word, their store by an out-of-range BUFFER offset - instead of predicated.  The predicated form cut the epilogue into one basic block
+    // per (row, channel group), each with its own waits (the fused backward's dgrad epilogue: 36 blocks, 5.4 K cycles for ~600 instructions).
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)0xFFFFFFF0u, 0x00020000);
+    // (not the 4 x 8 x 16 dgrad instance: at its 128 registers of four workgroups per CU the masks spill)
+    constexpr bool BFREE = !(EPI == EPI_DGRAD && MS > 4);
+    char* __restrict__ yout = reinterpret_cast<char*>(p.y);
+    uint32_t mk[MS];      // store offset of row ms, channel block ns: (yb0 + ms yrow + ysub[ns]) | ~mk[ms] - all ones (beyond the buffer) for a masked row
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      mk[ms] = (okzx && RS * ms < yrem) ? 0xFFFFFFFFu : 0u;
+      asm volatile("" : "+v"(mk[ms]));
+    }
+    auto msk = [](float v, uint32_t m) -> float { return __uint_as_float(__float_as_uint(v) & m); };
     // statistics partials of one 16-channel group: 16 lanes (DPP) -> this wave's slot of the LDS scratch [wave][NS*16][2]
     float* red = reinterpret_cast<float*>(smem + BUFB);
     auto flush_stats = [&](int ns, const float* s1, const float* s2, int which = 0) {
@@ -387,18 +400,15 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
         u32x2_t pk[MS];
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms) {
-          pk[ms] = u32x2_t{0u, 0u};
-          if (okzx && RS * ms < yrem) {
-            float v[4];
+          float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = acc[ms][ns][r] + add[r] + img[ms] * w1[r];
-              s1[r] += v[r];
-              s2[r] += v[r] * v[r];
-            }
-            pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ysub[ns])) = pk[ms];
+          for (int r = 0; r < 4; ++r) {
+            v[r] = msk(acc[ms][ns][r] + add[r] + img[ms] * w1[r], mk[ms]);
+            s1[r] += v[r];
+            s2[r] += v[r] * v[r];
           }
+          pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};      // (a masked row packs to zeros, as the predicated form left it)
+          __builtin_amdgcn_raw_buffer_store_b64(pk[ms], rs_y, (int)((yb0 + ms * yrow + ysub[ns]) | ~mk[ms]), 0, 0);
         }
         if (TX == 16 && p.pool != nullptr) {
           // ---- fused MaxPool3d (pool_sz,2,2) of the bf16 values just written (max commutes with the rounding, so this
@@ -500,8 +510,9 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
                 const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
                 const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
                 f32x2_t a{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
-                const bool in = okzx && RS * ms < yrem;            // out-of-volume voxels of edge tiles carry no gradient
-                const f32x2_t gv = in ? f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a : f32x2_t{0.f, 0.f};
+                const f32x2_t gu = f32x2_t{acc[ms][ns][rp], acc[ms][ns][rp + 1]} * a;
+                const f32x2_t gv = BFREE ? f32x2_t{msk(gu[0], mk[ms]), msk(gu[1], mk[ms])}            // out-of-volume voxels of edge tiles carry no gradient
+                                         : ((okzx && RS * ms < yrem) ? gu : f32x2_t{0.f, 0.f});
                 acc[ms][ns][rp] = gv[0]; acc[ms][ns][rp + 1] = gv[1];
                 s1p = s1p + gv;
                 s2p = __builtin_elementwise_fma(gv, xh, s2p);
@@ -520,7 +531,8 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
               const uint32_t w = tv[b][ms][r >> 1];
               const float tf = (r & 1) ? hi16<TT>(w) : lo16<TT>(w);
               const float u = fmaf(rec[2], tf, rec[3]);
-              const float gv = (okzx && RS * ms < yrem) ? acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act) : 0.f;
+              const float gv = BFREE ? msk(acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act), mk[ms])
+                                     : ((okzx && RS * ms < yrem) ? acc[ms][ns][r] * apply_act_bwd_rt<T, ACTK>(u, p.t_act) : 0.f);
               acc[ms][ns][r] = gv;
               s1[r] += gv;
               s2[r] += gv * ((tf - rec[0]) * rec[1]);
@@ -528,10 +540,11 @@ __global__ void __launch_bounds__(256, lp_occ(TZ * TY * TX, NS, EPI, ACTK)) conv
           }
         }
 #pragma unroll
-        for (int ms = 0; ms < MS; ++ms)
-          if (okzx && RS * ms < yrem)
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ysub[ns])) =
-                u32x2_t{pk16<T>(acc[ms][ns][0], acc[ms][ns][1]), pk16<T>(acc[ms][ns][2], acc[ms][ns][3])};
+        for (int ms = 0; ms < MS; ++ms) {
+          const u32x2_t o{pk16<T>(acc[ms][ns][0], acc[ms][ns][1]), pk16<T>(acc[ms][ns][2], acc[ms][ns][3])};
+          if constexpr (BFREE) __builtin_amdgcn_raw_buffer_store_b64(o, rs_y, (int)((yb0 + ms * yrow + ysub[ns]) | ~mk[ms]), 0, 0);
+          else if (okzx && RS * ms < yrem) *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ysub[ns])) = o;
+        }
         flush_stats(ns, s1, s2);
       }
     }

@@ -153,7 +153,6 @@ def test_conv3d_zmarch_kernel_is_bit_identical_to_the_lean_kernel(K):
     rows += K.check_conv3d_zmarch(True, 2, (40, 24, 48), 48, act=3, wgs=16)               # run-time activation (SiLU)
     rows += K.check_conv3d_zmarch(True, 4, (64, 64, 64), 48, planar=True)                 # production-like: default grid
     rows += K.check_conv3d_zmarch(True, 4, (64, 64, 64), 16, sc_C=48, planar=True)
-    rows += K.check_conv3d_zmarch(True, 1, (64, 64, 64), 48, pool=2, planar=True)         # 48 -> 16 with the fused pool stays on the lean kernel (same bits)
     # the one-chunk layers without a wide shortcut run the role-split form (conv3_zs_kernel) by default: the rows above cover it; conv3_zm_kernel's
     # own instance of those layers (BPX_CONV_ZS=0 / mode bit 2) on the same cases
     rows += K.check_conv3d_zmarch(True, 2, (32, 32, 32), 16, role_split=False)
@@ -172,6 +171,7 @@ def test_conv3d_fused_maxpool_is_bit_identical(K):
     rows += K.check_conv3d_fwd_pool(1, (64, 64, 64), 32, 32, 2)          # 4x4x16 tile, NS = 2
     rows += K.check_conv3d_fwd_pool(2, (32, 72, 120), 16, 16, 1)         # anisotropic level (no z pooling), partial tiles
     rows += K.check_conv3d_fwd_pool(1, (68, 66, 70), 16, 32, 2)          # ragged in every axis
+    rows += K.check_conv3d_fwd_pool(1, (64, 64, 64), 48, 16, 2)          # 48 -> 16 + pool on a volume the z-march kernel would take - it has no pool epilogue for three chunks
     _assert_all(rows)
 
 
