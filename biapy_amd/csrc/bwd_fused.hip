@@ -283,6 +283,14 @@ __global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) 
     // weights of step s and group ns: LDS (CT == 1), or a BUFFER load - resource + one lane-offset VGPR + the step's byte offset in an SGPR +
     // the group as immediate.  (As pointer arithmetic the compiler hoists the 14 x NS 64-bit lane addresses out of the tile loop: 84 VGPRs, spilled.)
     const uint32_t wstep = LDSW ? 1024u : (uint32_t)(4 * Ct * 16);
+    // group-by-group form: branch-free rows as in the role-split kernel (masks + buffer stores with out-of-range offsets for out-of-volume rows)
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.g, 0, (int)0xFFFFFFF0u, 0x00020000);
+    uint32_t mk[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+      mk[ms] = (okzx && ms < yrem) ? 0xFFFFFFFFu : 0u;
+      asm volatile("" : "+v"(mk[ms]));
+    }
     if constexpr (ALLNS) {
       // NS accumulator sets at once, weights through a one-step register ring (conv3_lp_kernel's form), statistics row per TILE.  Measured
       // alternatives for the 48-channel instance: the per-group form below + per-lane statistics over all tiles (what the 16-channel instance
@@ -490,8 +498,8 @@ __global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) 
             const f32x2_t xh = __builtin_elementwise_fma(rs2, tt, nm2);
             const f32x2_t e = u * f32x2_t{1.44269504088896341f, 1.44269504088896341f};
             f32x2_t a{__builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[0]), 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[1]), 0.f, 1.f)};
-            const bool in = okzx && ms < yrem;            // out-of-volume voxels of edge tiles carry no gradient
-            const f32x2_t gv = in ? f32x2_t{acc[ms][rp], acc[ms][rp + 1]} * a : f32x2_t{0.f, 0.f};
+            const f32x2_t gu = f32x2_t{acc[ms][rp], acc[ms][rp + 1]} * a;            // out-of-volume voxels of edge tiles carry no gradient:
+            const f32x2_t gv{__uint_as_float(__float_as_uint(gu[0]) & mk[ms]), __uint_as_float(__float_as_uint(gu[1]) & mk[ms])};   // a mask, not a branch
             acc[ms][rp] = gv[0]; acc[ms][rp + 1] = gv[1];
             s1p = s1p + gv;
             s2p = __builtin_elementwise_fma(gv, xh, s2p);
@@ -507,7 +515,7 @@ __global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) 
             const uint32_t w = tv[ms][r >> 1];
             const float tf = (r & 1) ? hi16<TT>(w) : lo16<TT>(w);
             const float u = fmaf(rec[2], tf, rec[3]);
-            const float gv = (okzx && ms < yrem) ? acc[ms][r] * apply_act_bwd_rt<T, ACTK>(u, p.act) : 0.f;
+            const float gv = __uint_as_float(__float_as_uint(acc[ms][r] * apply_act_bwd_rt<T, ACTK>(u, p.act)) & mk[ms]);
             acc[ms][r] = gv;
             ps1[ns][r] += gv;
             ps2[ns][r] += gv * ((tf - rec[0]) * rec[1]);
@@ -515,9 +523,9 @@ __global__ void __launch_bounds__(256, (CG == 1 && CT == 1) ? BPX_BWD_OCC1 : 2) 
         }
       }
 #pragma unroll
-      for (int ms = 0; ms < MS; ++ms)
-        if (okzx && ms < yrem)
-          *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow + ns * 32u)) = u32x2_t{cvt_pk_bf16(acc[ms][0], acc[ms][1]), cvt_pk_bf16(acc[ms][2], acc[ms][3])};
+      for (int ms = 0; ms < MS; ++ms)      // (out-of-volume rows: an offset beyond the buffer)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{cvt_pk_bf16(acc[ms][0], acc[ms][1]), cvt_pk_bf16(acc[ms][2], acc[ms][3])}, rs_y,
+                                              (int)((yb0 + ms * yrow + ns * 32u) | ~mk[ms]), 0, 0);
     }
     }
     if (CT == 1) BPX_STAMP();   // 7: epilogue stores issued
