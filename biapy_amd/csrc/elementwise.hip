@@ -784,49 +784,64 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, int x_cs, 
   }
 }
 
-// TX: element type of the pooled layer's INPUT x (BPX_MIX16: fp16 beside bf16 gradients), else T
-template <typename T, typename TX = T>
+// TX: element type of the pooled layer's INPUT x (BPX_MIX16: fp16 beside bf16 gradients), else T.  SZ (z extent of the window) and the presence of the
+// addend are template constants (round 6): with the run-time `if (k >= 4 sz) break` inside the unrolled window loops every load sat in its own basic
+// block behind an `s_waitcnt vmcnt(0)` (12 such sites) - a wait for all stores issued so far (level 0: 3.8 TB/s).  Now a window's 4 SZ x loads, its dy
+// load and its 4 SZ addend loads are requested together, then the arg-max, then the 4 SZ stores.
+template <typename T, typename TX, int SZ, bool ADD>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const TX* __restrict__ x, int x_ld, int x_cs, const T* __restrict__ dy, int dy_ld,
                                                           const T* __restrict__ addend, int a_ld, T* __restrict__ dx, int dx_ld, int C,
-                                                          int D, int H, int W, int sz, int N) {
-  constexpr int KPL = ElemTraits<T>::KPL;
+                                                          int D, int H, int W, int N) {
+  constexpr int KPL = ElemTraits<T>::KPL, NW = 4 * SZ;
   const int G = C / KPL;
-  const int Do = D / sz, Ho = H / 2, Wo = W / 2;
+  const int Do = D / SZ, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int cg = (int)(i % G);
-    int64_t ov = i / G;
-    int xo = (int)(ov % Wo), yo = (int)((ov / Wo) % Ho), zo = (int)((ov / ((int64_t)Wo * Ho)) % Do), n = (int)(ov / ((int64_t)Wo * Ho * Do));
-    float f[8][KPL];
+    const int cg = (int)(i % G);
+    const int64_t ov = i / G;
+    const int xo = (int)(ov % Wo), yo = (int)((ov / Wo) % Ho), zo = (int)((ov / ((int64_t)Wo * Ho)) % Do), n = (int)(ov / ((int64_t)Wo * Ho * Do));
+    const size_t v0 = (((size_t)n * D + SZ * zo) * H + 2 * yo) * W + 2 * xo;
+    const size_t xoff = (size_t)((cg * KPL) >> 4) * x_cs + ((cg * KPL) & 15);
+    u32x4_t vx[NW], va[ADD ? NW : 1];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const size_t vox = v0 + ((size_t)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+      vx[k] = *reinterpret_cast<const u32x4_t*>(x + vox * x_ld + xoff);
+    }
+    const u32x4_t vd = *reinterpret_cast<const u32x4_t*>(dy + (size_t)ov * dy_ld + cg * KPL);
+    if (ADD) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const size_t vox = v0 + ((size_t)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
+        va[k] = *reinterpret_cast<const u32x4_t*>(addend + vox * a_ld + cg * KPL);
+      }
+    }
     float m[KPL];
     int am[KPL];
 #pragma unroll
     for (int e = 0; e < KPL; ++e) { m[e] = -INFINITY; am[e] = 0; }
-    size_t voxk[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k >= 4 * sz) break;
-      voxk[k] = (((size_t)n * D + sz * zo + (k >> 2)) * H + 2 * yo + ((k >> 1) & 1)) * W + 2 * xo + (k & 1);
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + voxk[k] * x_ld + (size_t)((cg * KPL) >> 4) * x_cs + ((cg * KPL) & 15));
-      unpack16<TX>(v, f[k]);
+    for (int k = 0; k < NW; ++k) {
+      float f[KPL];
+      unpack16<TX>(vx[k], f);
 #pragma unroll
       for (int e = 0; e < KPL; ++e)
-        if (f[k][e] > m[e]) { m[e] = f[k][e]; am[e] = k; }  // strict >: first maximum wins, as in PyTorch
+        if (f[e] > m[e]) { m[e] = f[e]; am[e] = k; }  // strict >: first maximum wins, as in PyTorch
     }
     float d[KPL];
-    unpack16<T>(*reinterpret_cast<const u32x4_t*>(dy + (size_t)ov * dy_ld + cg * KPL), d);
+    unpack16<T>(vd, d);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k >= 4 * sz) break;
+    for (int k = 0; k < NW; ++k) {
+      const size_t vox = v0 + ((size_t)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1);
       float o[KPL];
-      if (addend) unpack16<T>(*reinterpret_cast<const u32x4_t*>(addend + voxk[k] * a_ld + cg * KPL), o);
+      if (ADD) unpack16<T>(va[k], o);
       else {
 #pragma unroll
         for (int e = 0; e < KPL; ++e) o[e] = 0.f;
       }
 #pragma unroll
       for (int e = 0; e < KPL; ++e) o[e] += (am[e] == k) ? d[e] : 0.f;
-      *reinterpret_cast<u32x4_t*>(dx + voxk[k] * dx_ld + cg * KPL) = pack16<T>(o);
+      *reinterpret_cast<u32x4_t*>(dx + vox * dx_ld + cg * KPL) = pack16<T>(o);
     }
   }
 }
@@ -2481,16 +2496,20 @@ extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, 
   int64_t total = (int64_t)N * (D / sz) * (H / 2) * (W / 2) * (x.C / kpl);
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == BPX_BF16)
-    maxpool_bwd_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>((const uint16_t*)x.ptr, x.ld, xcs, (const uint16_t*)dy.ptr, dy.ld,
-                                                                 (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
-  else if (dtype == BPX_MIX16)   // x = the forward pass's fp16 tensor; dy, addend, dx bf16
-    maxpool_bwd_kernel<uint16_t, f16_t><<<grid_for(total), 256, 0, s>>>((const f16_t*)x.ptr, x.ld, xcs, (const uint16_t*)dy.ptr, dy.ld,
-                                                                        (const uint16_t*)addend.ptr, addend.ld, (uint16_t*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
-  else if (dtype == BPX_F32)
-    maxpool_bwd_kernel<float><<<grid_for(total), 256, 0, s>>>((const float*)x.ptr, x.ld, xcs, (const float*)dy.ptr, dy.ld, (const float*)addend.ptr,
-                                                              addend.ld, (float*)dx.ptr, dx.ld, x.C, D, H, W, sz, N);
+  const bool add = addend.ptr != nullptr;
+#define MPB(T_, TX_)                                                                                                                                        \
+  do {                                                                                                                                                      \
+    const TX_* xp = (const TX_*)x.ptr; const T_* dyp = (const T_*)dy.ptr; const T_* ap = (const T_*)addend.ptr; T_* dxp = (T_*)dx.ptr;                     \
+    if (sz == 2 && add) maxpool_bwd_kernel<T_, TX_, 2, true><<<grid_for(total), 256, 0, s>>>(xp, x.ld, xcs, dyp, dy.ld, ap, addend.ld, dxp, dx.ld, x.C, D, H, W, N);   \
+    else if (sz == 2) maxpool_bwd_kernel<T_, TX_, 2, false><<<grid_for(total), 256, 0, s>>>(xp, x.ld, xcs, dyp, dy.ld, ap, addend.ld, dxp, dx.ld, x.C, D, H, W, N);    \
+    else if (add) maxpool_bwd_kernel<T_, TX_, 1, true><<<grid_for(total), 256, 0, s>>>(xp, x.ld, xcs, dyp, dy.ld, ap, addend.ld, dxp, dx.ld, x.C, D, H, W, N);         \
+    else maxpool_bwd_kernel<T_, TX_, 1, false><<<grid_for(total), 256, 0, s>>>(xp, x.ld, xcs, dyp, dy.ld, ap, addend.ld, dxp, dx.ld, x.C, D, H, W, N);                 \
+  } while (0)
+  if (dtype == BPX_BF16) MPB(uint16_t, uint16_t);
+  else if (dtype == BPX_MIX16) MPB(uint16_t, f16_t);   // x = the forward pass's fp16 tensor; dy, addend, dx bf16
+  else if (dtype == BPX_F32) MPB(float, float);
   else BPX_FAIL("%s: dtype must be BF16, F32 or MIX16", fn);
+#undef MPB
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }
