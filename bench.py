@@ -592,6 +592,9 @@ def main():
             L.lib.prof = prof
         elapsed = _timed(step, a.steps, world, dev)
         L.lib.prof = None
+        device_resident_ms = None
+        if a.feed == "host" and not a.breakdown:      # the same step without the feed (rounds 1-5 timed this), as a sub-field beside the headline
+            device_resident_ms = 1e3 * _timed(inner_step, a.steps, world, dev) / a.steps
         prof_steps = a.steps
         fb_graphs = getattr(model, "_graphs", None) is not None
         if fb_graphs:
@@ -610,7 +613,7 @@ def main():
             line = dict(
                 metric="voxels/sec 3D ResUNet 128^3 patch (train: fwd+bwd+AdamW; sub-records: infer, sliding)",
                 value=value, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic", feed=feed_note,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic", feed=feed_note, device_resident_ms_per_step=device_resident_ms,
                 config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, train" % (a.patch, a.batch),
                             global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode="train"),
                 launch=(("hip-graph replays (forward+loss+backward up to the first encoder block | its backward | optimizer), the flat-gradient RCCL all-reduce "
