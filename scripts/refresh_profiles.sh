@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates every file of profiles/ in ONE run on one GPU box (run through gpurun from the repo root):
 #   bash scripts/ab_build_flags.sh zmstamps -DBPX_ZM_STAMPS -DBPX_ZM_SPLIT=8 ; bash scripts/ab_build_flags.sh stamps -DBPX_BWD_STAMPS      (profiling builds, before the call)
-#   gpurun --timeout 2400 -- 'bash scripts/refresh_profiles.sh r05'
+#   gpurun --timeout 3600 -- 'bash scripts/refresh_profiles.sh r06'
 # Outputs land in gpurun_out/profiles_new/ (merged back by gpurun); copy them into profiles/ afterwards.
 # PMC counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa trace domains).
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/profiles_new
 mkdir -p $O
 export TMPDIR=/tmp
@@ -24,12 +24,13 @@ cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic_tiling.json 
 python bench.py > $O/${R}_bench.json 2> $O/bench.err
 python bench.py --force-ddp --self-check --mode train --no-cpu-baseline > $O/${R}_bench_train_dp_1rank.json 2> $O/bench_dp.err
 python bench.py --mode sliding --vol 1024 --steps 1 --warmup 1 --no-cpu-baseline > $O/${R}_bench_sliding_1024.json 2> $O/bench_sliding.err
+python bench.py --mode sliding --vol 512 --steps 2 --warmup 1 --no-cpu-baseline > $O/${R}_bench_sliding_512.json 2>> $O/bench_sliding.err
 # the single-GPU checksums of the blended cfg-3 volumes (initial weights of seed 0): what `bench.py --gpus N` compares its gathered volume with
 python - "$O" "$R" <<'PY' > $O/sliding_checksums.json
 import json, sys
 O, R = sys.argv[1:3]
 out = {}
-for vol, path, pick in ((512, f"{O}/{R}_bench.json", lambda d: d.get("sliding")), (1024, f"{O}/{R}_bench_sliding_1024.json", lambda d: d.get("sliding") or d)):
+for vol, path, pick in ((512, f"{O}/{R}_bench_sliding_512.json", lambda d: d.get("sliding") or d), (1024, f"{O}/{R}_bench_sliding_1024.json", lambda d: d.get("sliding") or d)):
     try:
         rec = pick(json.loads(open(path).read().strip().splitlines()[-1]))
         out[str(vol)] = dict(checksum=rec["checksum"], dtype=rec.get("dtype"), patches=rec.get("config", {}).get("patches"), source=path.split("/")[-1])
@@ -47,9 +48,11 @@ python tests/bench_kernels.py merge > $O/${R}_merge_crop.txt 2>&1
 ( python scripts/dgrad_stamps.py 64 96 32; python scripts/dgrad_stamps.py 64 32 32; python scripts/conv_stamps.py 0; python scripts/conv_stamps.py 11; python scripts/hbm_rw_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_fwd_dgrad.txt
 # fused backward: per-phase cycle stamps need the profiling build (bash scripts/ab_build_flags.sh stamps -DBPX_BWD_STAMPS, done before the gpurun call)
 if [ -f biapy_amd/libbiapy_amd_stamps.so ]; then
-  ( BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 16; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 48 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_bwd_fused.txt
+  ( echo "== role-split form (conv3_bwd_rs_kernel, round 6)"; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_rs_stamps.py 128 48; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_rs_stamps.py 128 16
+    echo "== serial form (conv3_bwd_kernel, BPX_BWD_RS=0)"; BPX_BWD_RS=0 BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 16; BPX_BWD_RS=0 BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_stamps.py 128 48 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stamps_bwd_fused.txt
 fi
-python tests/bench_kernels.py bwd --reps 10 2>&1 | grep -v amdgpu.ids > $O/${R}_bwd_fused_vs_separate.txt
+( for rep in 1 2; do echo "== role-split (default)"; python tests/bench_kernels.py bwd --reps 10; echo "== serial fused kernel (BPX_BWD_RS=0)"; BPX_BWD_RS=0 python tests/bench_kernels.py bwd --reps 10; done ) 2>&1 | grep -v amdgpu.ids > $O/${R}_bwd_fused_vs_separate.txt
+for rs in 3 0 3 0; do BPX_BWD_RS=$rs python bench.py --mode train --feed device --steps 40 --warmup 8 --no-cpu-baseline --no-bf16-record --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_BWD_RS=$rs train ms_per_step %.4f (device-resident batch)' % d['ms_per_step'])"; done > $O/${R}_step_bwd_rs_ab.txt 2>&1
 # round 5: the z-marching forward kernel of the level-0 layers against the lean kernel (same call), its per-phase cycle stamps, its runtime occupancy
 ( python -c "
 from biapy_amd import _lib as L
@@ -89,7 +92,7 @@ timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_V
 timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace \
    -d $ROOT/$O/pmc_b -o p -- python $ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-record --graph off > $ROOT/$O/pmc_b.log 2>&1
 cd $ROOT
-for k in conv3_zm_kernel conv3_zs_kernel conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel pw_nbs_kernel wgrad_k1_dma_kernel; do
+for k in conv3_bwd_rs_kernel conv3_zm_kernel conv3_zs_kernel conv3_lp_kernel wgrad_sdm_kernel conv3_bwd_kernel pw_nbs_kernel wgrad_k1_dma_kernel; do
   python scripts/pmc_report.py $(find $O/pmc_a -name "p_results.db" | head -1) $k
   python scripts/pmc_report.py $(find $O/pmc_b -name "p_results.db" | head -1) $k
 done > $O/${R}_pmc_sq_conv_wgrad.txt 2>&1
