@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(256, zm_occ(NCH, SCK)) conv3_zm_kernel(const C
   };
 
   char* __restrict__ yout = reinterpret_cast<char*>(p.y);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)0xFFFFFFF0u, 0x00020000);   // (epilogue rows: out-of-volume rows store beyond it)
   const uint32_t yrow = (uint32_t)(W * p.y_ld) * 2u;
 
   for (int L = L0; L < L1; ++L) {
@@ -406,17 +407,23 @@ __global__ void __launch_bounds__(256, zm_occ(NCH, SCK)) conv3_zm_kernel(const C
       u32x2_t pk[MS];
 #pragma unroll
       for (int ms = 0; ms < MS; ++ms) {
+        // branch-free rows (round 6): out-of-volume rows contribute zeros and store to an offset beyond the buffer.  (Not the one-chunk instance without a
+        // wide shortcut - the A/B partner of conv3_zs_kernel: at its 168 registers of three workgroups per CU the straight-line form spills 36 bytes.)
+        constexpr bool BFREE = NCH == 3 || SCK;
+        const bool in = okzx && ms < yrem;
         pk[ms] = u32x2_t{0u, 0u};
-        if (okzx && ms < yrem) {
+        if (BFREE || in) {
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = acc[ms][r] + addk[r] + img[ms] * w1k[r];
+            const float t = acc[ms][r] + addk[r] + img[ms] * w1k[r];
+            v[r] = (!BFREE || in) ? t : 0.f;
             s1[r] += v[r];
             s2[r] += v[r] * v[r];
           }
           pk[ms] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
-          *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
+          if constexpr (BFREE) __builtin_amdgcn_raw_buffer_store_b64(pk[ms], rs_y, (int)(in ? yb0 + ms * yrow : 0xFFFFFFFFu), 0, 0);
+          else *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[ms];
         }
       }
       // (Measured and removed: 16-byte stores - lanes (j, g) and (j, g ^ 1) exchange their 8-byte halves with v_permlane16_swap, 4 stores per lane
@@ -638,6 +645,7 @@ __global__ void __launch_bounds__(512, 4) conv3_zs_kernel(const Conv3Params p) {
   };
 
   char* __restrict__ yout = reinterpret_cast<char*>(p.y);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)0xFFFFFFF0u, 0x00020000);   // (epilogue rows: out-of-volume rows store beyond it)
   const uint32_t yrow = (uint32_t)(W * p.y_ld) * 2u;
   const bool pool2 = p.pool != nullptr && p.pool_sz == 2;
 
@@ -777,18 +785,17 @@ __global__ void __launch_bounds__(512, 4) conv3_zs_kernel(const Conv3Params p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int ms = 2 * k + h;
-          pk[h] = u32x2_t{0u, 0u};
-          if (okzx && ms < yrem) {
-            float v[4];
+          const bool in = okzx && ms < yrem;      // branch-free rows (round 6)
+          float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = acc[ms][r] + addk[r] + img[ms] * w1k[r];
-              s1[r] += v[r];
-              s2[r] += v[r] * v[r];
-            }
-            pk[h] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
-            *reinterpret_cast<u32x2_t*>(yout + (yb0 + ms * yrow)) = pk[h];
+          for (int r = 0; r < 4; ++r) {
+            const float t = acc[ms][r] + addk[r] + img[ms] * w1k[r];
+            v[r] = in ? t : 0.f;
+            s1[r] += v[r];
+            s2[r] += v[r] * v[r];
           }
+          pk[h] = u32x2_t{pk16s<T>(v[0], v[1]), pk16s<T>(v[2], v[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(pk[h], rs_y, (int)(in ? yb0 + ms * yrow : 0xFFFFFFFFu), 0, 0);
         }
         if (p.pool != nullptr) {
           const u32x2_t a = pk[0], b = pk[1];
