@@ -72,16 +72,18 @@ class BCEWithLogitsLoss(torch.nn.Module):
 
 
 class DiceLoss(torch.nn.Module):
-    """metrics.py:726-762 with ``batch_dice=True``."""
+    """metrics.py:726-762, one-channel head: ``batch_dice=True`` (sums over batch and space) and ``batch_dice=False`` (Dice per sample, then the mean)."""
 
     def __init__(self, batch_dice: bool = True, smooth: float = 1e-5):
         super().__init__()
-        if not batch_dice:
-            raise NotImplementedError("per-sample Dice (batch_dice=False) is not implemented on the MI355X path")
-        self.smooth = smooth
+        self.batch_dice, self.smooth = bool(batch_dice), smooth
 
     def forward(self, logits, target):
-        return _SegLossFn.apply(logits, target, 0.0, 1.0, self.smooth)
+        if self.batch_dice:
+            return _SegLossFn.apply(logits, target, 0.0, 1.0, self.smooth)
+        # batch_dice=False (:749-751): the sums stay per sample, the loss is 1 - mean_n dice_n = mean_n (1 - dice_n): the same fused passes once per
+        # sample (contiguous slices of the one-channel logits), averaged
+        return torch.stack([_SegLossFn.apply(logits[i:i + 1], target[i:i + 1], 0.0, 1.0, self.smooth) for i in range(logits.shape[0])]).mean()
 
 
 class DiceCELoss(torch.nn.Module):

@@ -1273,6 +1273,7 @@ def losses_fixtures():
 
     rec("bce", lambda z: met.CrossEntropyLoss_wrapper(num_classes=2, ndim=3)(z, t1), z1)
     rec("dice", lambda z: met.DiceLoss(batch_dice=True)(z, t1), z1)
+    rec("dice_per_sample", lambda z: met.DiceLoss(batch_dice=False)(z, t1), z1)     # round 6: Dice per sample, then the mean (metrics.py:749-751)
     rec("dice_ce_1_1", lambda z: met.DiceCELoss(num_classes=2, ndim=3)(z, t1), z1)
     rec("dice_ce_03_17", lambda z: met.DiceCELoss(num_classes=2, ndim=3, w_ce=0.3, w_dice=1.7)(z, t1), z1)
     acts = ["ce_sigmoid", "ce_sigmoid", "tanh"]

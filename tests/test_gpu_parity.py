@@ -705,7 +705,7 @@ def test_segmentation_losses_match_the_reference_classes():
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_golden.npz"))
     z1, t1, _, _ = loss_inputs()
     for name, mod in (("bce", losses.BCEWithLogitsLoss()), ("dice", losses.DiceLoss()), ("dice_ce_1_1", losses.DiceCELoss()),
-                      ("dice_ce_03_17", losses.DiceCELoss(0.3, 1.7))):
+                      ("dice_ce_03_17", losses.DiceCELoss(0.3, 1.7)), ("dice_per_sample", losses.DiceLoss(batch_dice=False))):   # (per sample: round 6)
         z = z1.cuda().requires_grad_(True)
         out = mod(z, t1.cuda())
         out.backward()

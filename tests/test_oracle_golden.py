@@ -645,6 +645,7 @@ def test_loss_oracle_matches_the_reference_loss_classes():
 
     check("bce", lambda z: LO.bce(z, t1), z1)
     check("dice", lambda z: LO.dice(z, t1), z1)
+    check("dice_per_sample", lambda z: LO.dice(z, t1, batch_dice=False), z1)
     check("dice_ce_1_1", lambda z: LO.dice_ce(z, t1), z1)
     check("dice_ce_03_17", lambda z: LO.dice_ce(z, t1, 0.3, 1.7), z1)
     acts = ["ce_sigmoid", "ce_sigmoid", "tanh"]
