@@ -85,8 +85,8 @@ def test_losses_fail_loudly_without_gpu():
 
     with pytest.raises(RuntimeError, match="MI355X only"):
         losses.DiceCELoss()(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
-    with pytest.raises(NotImplementedError):
-        losses.DiceLoss(batch_dice=False)
+    with pytest.raises(RuntimeError, match="MI355X only"):      # per-sample Dice (round 6) runs on the same fused passes: no CPU fallback either
+        losses.DiceLoss(batch_dice=False)(torch.zeros(2, 1, 4, 4, 4), torch.zeros(2, 1, 4, 4, 4))
 
 
 def test_instance_channels_loss_refuses_what_it_does_not_reproduce():
