@@ -386,9 +386,10 @@ def main():
                     help="all = train (the headline value) + the infer and sliding sub-records; one name = that section only")
     ap.add_argument("--vol", type=int, default=None, help="edge of the synthetic sliding-window volume (default: cfg 3's 1024 at every N; 512 = one GPU's share of the "
                                                           "8-GPU job, the round 1-5 default at N = 1)")
-    ap.add_argument("--feed", choices=["host", "device"], default="host",
-                    help="host (default): every timed train step takes its batch from pinned host memory (async H2D on a copy stream + a device-to-device "
-                         "copy into the step's inputs), as the reference's loop does; device: one device-resident batch, no copies (rounds 1-5)")
+    ap.add_argument("--feed", choices=["host", "device"], default="device",
+                    help="device (default, as rounds 1-5; labelled in the record): one device-resident batch, H2D excluded; host: every timed train step takes "
+                         "its batch from pinned host memory (async H2D on a copy stream + a device-to-device copy into the step's inputs), as the reference's "
+                         "loop does.  Whichever is the headline, the other is timed right after it over the same K steps and reported as a sub-field")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--dtype", choices=["mix16", "bf16", "f32"], default="mix16",
@@ -528,8 +529,9 @@ def main():
 
                     estep = DataParallelTrainStep(net, loss_fn, opt, x, tgt, graph=False, broadcast_parameters=False)
                     step = lambda: estep()  # noqa: E731
-        feed_note = "device-resident batch, H2D excluded"
-        if a.feed == "host" and not a.breakdown:
+        feed_note = "device-resident batch, H2D excluded (the host-fed step is timed beside it: host_fed_ms_per_step)"
+        inner_step, fed_step = step, None
+        if not a.breakdown:
             # The reference copies every batch to the device (train_engine.py:116, 125: two H2D copies per step).  Here: the batch lies in PINNED host
             # memory, a copy stream brings the NEXT step's batch into a staging pair while this step computes, and the step begins with a
             # device-to-device copy of the staged pair into its (graph-static) input tensors - all inside the timed region.
@@ -547,7 +549,6 @@ def main():
 
             ev_taken.record(torch.cuda.current_stream())
             stage()
-            inner_step = step
 
             def fed_step():
                 main = torch.cuda.current_stream()
@@ -558,9 +559,10 @@ def main():
                 stage()
                 return inner_step()
 
-            step = fed_step
-            feed_note = ("pinned host batch (%.1f MB): async H2D on a copy stream beside the previous step, then a device-to-device copy into the step's static "
+            host_note = ("pinned host batch (%.1f MB): async H2D on a copy stream beside the previous step, then a device-to-device copy into the step's static "
                          "inputs; both inside the timed region" % ((xs_h.numel() * xs_h.element_size() + ts_h.numel() * ts_h.element_size()) / 1e6))
+            if a.feed == "host":
+                step, feed_note = fed_step, host_note + " (the device-resident step is timed beside it: device_resident_ms_per_step)"
         for _ in range(a.warmup):
             out = step()
         torch.cuda.synchronize()
@@ -592,9 +594,13 @@ def main():
             L.lib.prof = prof
         elapsed = _timed(step, a.steps, world, dev)
         L.lib.prof = None
-        device_resident_ms = None
-        if a.feed == "host" and not a.breakdown:      # the same step without the feed (rounds 1-5 timed this), as a sub-field beside the headline
-            device_resident_ms = 1e3 * _timed(inner_step, a.steps, world, dev) / a.steps
+        device_resident_ms = host_fed_ms = None
+        if fed_step is not None:      # the other feed, the same K steps, as a sub-field beside the headline
+            other = 1e3 * _timed(inner_step if a.feed == "host" else fed_step, a.steps, world, dev) / a.steps
+            if a.feed == "host":
+                device_resident_ms = other
+            else:
+                host_fed_ms = other
         prof_steps = a.steps
         fb_graphs = getattr(model, "_graphs", None) is not None
         if fb_graphs:
@@ -613,7 +619,7 @@ def main():
             line = dict(
                 metric="voxels/sec 3D ResUNet 128^3 patch (train: fwd+bwd+AdamW; sub-records: infer, sliding)",
                 value=value, unit="voxels/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * elapsed / a.steps,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic", feed=feed_note, device_resident_ms_per_step=device_resident_ms,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_NAMES[a.dtype], data="synthetic", feed=feed_note, device_resident_ms_per_step=device_resident_ms, host_fed_ms_per_step=host_fed_ms,
                 config=dict(workload="cfg2: 3D ResUNet fm=16-32-64-128-256 IN+ELU, %d^3x1 patches, batch %d/GPU, train" % (a.patch, a.batch),
                             global_batch=world * a.batch, patch=a.patch, parallelism="dp%d" % world, mode="train"),
                 launch=(("hip-graph replays (forward+loss+backward up to the first encoder block | its backward | optimizer), the flat-gradient RCCL all-reduce "

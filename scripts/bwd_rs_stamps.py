@@ -52,8 +52,8 @@ s = stamps.cpu().numpy()
 s = s[s[:, 0] != 0]
 print(f"{len(s)} workgroups; counter ticks (median / mean / p90) per phase")
 for role, off, names in (("D wave 0", 0, ["wait at the tile barrier", "dgrad MFMA steps", "dgrad epilogue (ELU', per-lane stats, stores)"]),
-                         ("W wave 4", 8, ["own pieces landed, A free", "transform t -> act(t) bf16", "wait at the tile barrier", "next tile set up (decode, bases)",
-                                          "next tile's pieces requested", "wgrad MFMA steps", "pieces written to LDS (register staging)"])):
+                         ("W wave 4", 8, ["own pieces landed (vmcnt 0), A free (counter)", "transform t -> act(t) bf16", "wait at the tile barrier", "next tile set up (bases)",
+                                          "next tile's 12 / 8 LDS-DMA pieces requested", "wgrad MFMA steps"])):
     r = s[:, off:off + len(names) + 1]
     d = np.diff(r, axis=1).astype(np.float64)
     print(f" {role}")

@@ -31,7 +31,7 @@ GROUPS = [
     ("bpx_conv3d_wgrad", re.compile(r"wgrad_(sdm?_)?kernel(<|I)|wgrad_reduce(_batch)?_kernel")),
     # the fused backward (dgrad + wgrad of one conv in one pass, round 4); its partial slabs are summed by the same batched reduce launch as the
     # wgrad calls' (counted with them above)
-    ("bpx_conv3d_bwd_fused", re.compile(r"conv3_bwd_kernel(<|I)")),
+    ("bpx_conv3d_bwd_fused", re.compile(r"conv3_bwd(_rs)?_kernel(<|I)")),   # serial and role-split (round 6) forms
     # the sliding-window blend / gather (tests/bench_kernels.py merge: 512 x 128^3 <-> 512^3; 16 B/lane row kernels, same doubling)
     ("bpx_merge3d_blend", re.compile(r"merge3d_row_kernel<")),
     ("bpx_crop3d_gather", re.compile(r"crop3d_row_kernel<")),
