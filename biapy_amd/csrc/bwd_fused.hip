@@ -621,11 +621,11 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
   constexpr int NKC = TV / 32;
   constexpr int SN_BYTES = CT * 16 * 16;                                  // one wave's copy of the sample's norm records
   constexpr int QPADB = 56;
-  // dgrad weights (the same 14 x NS KB for every tile): steps [0, WL) live in LDS, steps [WL, WL + WR) in registers of every D wave, the last WV
-  // steps are requested at the top of the tile and used ~2 K cycles later.  (One step ahead from L2, as the serial kernel does it, costs the
-  // role-split form its point: 42 requests per wave and tile keep the CU's texture path busy - the W waves' DMA requests took 300 cycles each -
-  // and every step waits for its operands: dgrad steps 6.6 K cycles for 2.7 K of MFMA, profiles/r06_stamps_bwd_rs.txt.)
-  constexpr int WL = 13, WR = 1, WV = STEPS - WL - WR;
+  // dgrad weights (the same 14 x NS KB for every tile): steps [0, WL) live in LDS, the last one in registers of every D wave.  (One step ahead from
+  // L2, as the serial kernel does it, costs the role-split form its point: 42 requests per wave and tile keep the CU's texture path busy - the W
+  // waves' DMA requests took 300 cycles each - and every step waits for its operands: dgrad steps 6.6 K cycles for 2.7 K of MFMA,
+  // profiles/r06_bwd_rs_log.txt #1.)
+  constexpr int WL = 13, WR = STEPS - WL;
   constexpr int SW_BYTES = WL * NS * 1024;
   // The activated tile A is NOT double-buffered (that is what makes room for the weights): only the W waves touch it, and they order themselves with
   // a counter in LDS - a W wave writes its pieces of tile i + 1 only after all four have finished the wgrad steps of tile i (wsync below).
@@ -653,13 +653,7 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
 #define BPX_STAMP() do { } while (0)
 #endif
 
-#ifdef BPX_RS_NO_D
-  if (false) {
-#elif defined(BPX_RS_NO_W)
-  if (true) {
-#else
   if (wave < 4) {
-#endif
     // =========================================================== D role ===========================================================================
     const int cg_off = (g & 1) * 16;
     const bool hi_tap = (g >> 1) != 0;
@@ -672,7 +666,7 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.g, 0, (int)0x80000000u, 0x00020000);
     for (int q = wave; q < WL * NS; q += 4)   // LDS-resident steps: piece (s, ns) at sW + (s NS + ns) KB; visible after the first tile barrier
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sW + q * 1024), 16, wlane + (uint32_t)(q % NS) * 256u, (q / NS) * wstep, 0, 0);
-    u32x4_t wres[WR > 0 ? WR : 1][NS];
+    u32x4_t wres[WR][NS];
 #pragma unroll
     for (int k = 0; k < WR; ++k)
 #pragma unroll
@@ -743,13 +737,6 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
       for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      u32x4_t wv[WV > 0 ? WV : 1][NS];   // the last WV steps' weights: requested now, used at the end of the step loop
-#pragma unroll
-      for (int k = 0; k < WV; ++k)
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
-          wv[k][ns] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wlane + ns * 256u), (int)((WL + WR + k) * wstep), 0));
-      __builtin_amdgcn_sched_barrier(0);   // (the requests stay here: the scheduler sinks them to their use and exposes the L2 latency)
       // fragments one step ahead of the MFMAs (the compiler's own order reads a step's fragments and waits for them at once: every step paid the
       // LDS latency, 33 cycles per MFMA instead of 16)
       u32x4_t af[2][MS], wf[2][NS];
@@ -772,7 +759,7 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns) {
-            const u32x4_t w = s_ < WL ? wf[s_ & 1][ns] : s_ < WL + WR ? wres[(s_ - WL >= 0 && s_ - WL < WR) ? s_ - WL : 0][ns] : wv[(s_ - WL - WR >= 0 && WV > 0) ? s_ - WL - WR : 0][ns];
+            const u32x4_t w = s_ < WL ? wf[s_ & 1][ns] : wres[s_ - WL >= 0 ? s_ - WL : 0][ns];
             acc[ms][ns] = mfma_step<T>(w, af[s_ & 1][ms], acc[ms][ns]);
           }
         __builtin_amdgcn_sched_barrier(0);
@@ -869,9 +856,9 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
     bool okt[2] = {false, false};
     int n_tile = 0;
     // requests of one tile into buffer b, the raw t tile and the dy halo by LDS-DMA (out-of-volume pieces: out-of-range offset = zeros), as NP
-    // pieces that are issued one by one: `setup` fixes the tile, `piece(q)` requests piece q (t pieces first, then the dy pieces IN ORDER - their halo
-    // coordinates are a running counter).  In the steady state the pieces are spread over the K-chunks of the wgrad phase: requested in one burst
-    // the wave sat in the issue for 4.4 K cycles per tile (the CU's request queue was full: it waited for HBM instead of computing).
+    // pieces: `bases` fixes the tile, `piece(q)` requests piece q (t pieces first, then the dy pieces IN ORDER - on edge tiles their halo coordinates
+    // are a running counter).  One burst behind the tile barrier: a piece costs its issuer 100-370 cycles wherever it is placed (spread over the
+    // K-chunks of the wgrad phase, staged through registers instead, issued by the D waves: all measured, profiles/r06_bwd_rs_log.txt #5, #7, #12).
     constexpr int NP = CT * 2 + NPG;
     uint32_t q_base_g = 0, q_base_t = 0, q_sG = 0, q_sT = 0, q_pk = 0;   // q_pk: halo coordinates of the next dy piece, hz | hy << 8 | hx << 16 (edge tiles only)
     int q_z0 = 0, q_y0 = 0, q_x0 = 0;
@@ -1000,8 +987,6 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
       }
       q_live = have;
       BPX_STAMP();   // W4: next tile set up
-      // (measured, profiles/r06_bwd_rs_log.txt: spread over the K-chunks of the wgrad phase the pieces cost the same ~370 cycles each - the phase grew
-      //  by what the burst had taken - and the chunk boundaries cost the scheduler its freedom: 905 vs 808 us)
 #pragma unroll
       for (int q = 0; q < NP; ++q) piece(q);
       __builtin_amdgcn_sched_barrier(0);

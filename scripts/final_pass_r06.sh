@@ -1,6 +1,6 @@
 #!/bin/bash
 # the bench line on the final tree (default arguments and the driver's), the role-split stamps with the final script, the tests touched after the refresh
-O=gpurun_out/r06_final; mkdir -p $O
+O=gpurun_out/r06_final   # (copied into profiles/ afterwards); mkdir -p $O
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/r06_bench_driver_args.json 2> $O/bench_driver.err
 python bench.py > $O/r06_bench.json 2> $O/bench.err
 ( echo "== role-split form (conv3_bwd_rs_kernel, round 6)"; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_rs_stamps.py 128 48; BPX_LIB_PATH=$PWD/biapy_amd/libbiapy_amd_stamps.so python scripts/bwd_rs_stamps.py 128 16
