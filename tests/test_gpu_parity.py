@@ -17,6 +17,22 @@ def _assert_all(rows):
 LOSS_CURVE_TOL = 1e-3
 
 
+class _oracle_threads:
+    """The fp32 CPU oracle graphs of the long training tests are many small operators: on the GPU box's 128-thread host the default intra-op pool costs
+    more in fork / join than it gains (cpu_baseline's legs: 16 threads beat 128 at 128^3 already).  Results do not depend on the thread count to the
+    tolerances used (fp32 reductions reassociate at the 1e-7 level)."""
+
+    def __init__(self, n=16):
+        self.n = n
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(self.n, self.old)))
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.old)
+
+
 def _record_diag(line):
     """Measured values of the parity tests, appended to gpurun_out/diag_values.txt on the GPU box (merged back by gpurun) so that the numbers a bar
     is derived from are recorded numbers, not a pass / fail."""
@@ -1593,25 +1609,26 @@ def test_resunetpp_bf16_training_follows_the_fp32_oracle_loss_curve(dtype):
     opt_d = torch.optim.AdamW(dev_m.parameters(), lr=2e-3)
     opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=2e-3)
     curve_d, curve_c = [], []
-    for it in range(steps):
-        x, t = batches[it % len(batches)]
-        opt_d.zero_grad(set_to_none=True)
-        ld = loss_fn(dev_m(x.cuda()), t.cuda())
-        ld.backward()
-        opt_d.step()
-        opt_c.zero_grad(set_to_none=True)
-        lo = resunetpp_oracle.resunetpp_forward(cpu_p, x, fm)
-        lc = loss_oracle.instance_channels(loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True), t, ["bce", "bce", "mse"], [1, 1, 1])
-        lc.backward()
-        opt_c.step()
-        curve_d.append(ld.item())
-        curve_c.append(lc.item())
-    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
-    assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
-    rel = ((cd - cc).abs() / cc).max().item()
-    print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
-    _record_diag(f"loss_curve[resunet++ {dtype} vs fp32 oracle, fm 16-32-64 at 32^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar 0.05)")
-    assert rel < 0.05, (rel, curve_c, curve_d)
+    with _oracle_threads():
+        for it in range(steps):
+            x, t = batches[it % len(batches)]
+            opt_d.zero_grad(set_to_none=True)
+            ld = loss_fn(dev_m(x.cuda()), t.cuda())
+            ld.backward()
+            opt_d.step()
+            opt_c.zero_grad(set_to_none=True)
+            lo = resunetpp_oracle.resunetpp_forward(cpu_p, x, fm)
+            lc = loss_oracle.instance_channels(loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True), t, ["bce", "bce", "mse"], [1, 1, 1])
+            lc.backward()
+            opt_c.step()
+            curve_d.append(ld.item())
+            curve_c.append(lc.item())
+        cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+        assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
+        rel = ((cd - cc).abs() / cc).max().item()
+        print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
+        _record_diag(f"loss_curve[resunet++ {dtype} vs fp32 oracle, fm 16-32-64 at 32^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar 0.05)")
+        assert rel < 0.05, (rel, curve_c, curve_d)
 
 
 PP_CFG4_CURVE_TOL = 1e-2      # VERDICT r5 next #5b: the loss-curve bar on cfg 4's own architecture (measured values: profiles/r06_gpu_test_values.txt)
@@ -1619,18 +1636,17 @@ PP_CFG4_CURVE_TOL = 1e-2      # VERDICT r5 next #5b: the loss-curve bar on cfg 4
 
 def test_resunetpp_cfg4_architecture_mixed_training_follows_the_fp32_oracle_loss_curve():
     """VERDICT r5 weak #3 / next #5b: the ResUNet++ loss-curve test on cfg 4's OWN architecture - five levels, fm 16-32-64-128-256, B / C / D loss -
-    in the mode cfg 4 is benched in (fp16 forward, bf16 gradients), at cfg 4's own 80^3 patch size, 12 AdamW steps beside the fp32 oracle from the
-    same weights on the same batches (the fp32 CPU oracle graph of the five-level net at 80^3 is what bounds the step count: ~8 s per step).
-    Bar 1e-2 on the worst relative gap of the curves; measured 4.2e-3 over 20 steps (profiles/r06_gpu_test_values.txt).  The three-level test
-    above keeps its 0.05.  (At 48^3 the same net reads 2.5e-2: its deepest level is 3^3 voxels per InstanceNorm - a property of the size, not of
-    the arithmetic.)"""
+    in the mode cfg 4 is benched in (fp16 forward, bf16 gradients), at cfg 4's own 80^3 patch size, 20 AdamW steps beside the fp32 oracle from the
+    same weights on the same batches (the oracle on 16 host threads: ~1.5 s per step).  Bar 1e-2 on the worst relative gap of the curves; measured
+    5.4e-3 (4.2e-3 with the oracle on the default thread pool: profiles/r06_gpu_test_values.txt).  The three-level test above keeps its 0.05.  (At
+    48^3 the same net reads 2.5e-2: its deepest level is 3^3 voxels per InstanceNorm - a property of the size, not of the arithmetic.)"""
     import torch.nn.functional as F_
 
     from biapy_amd.losses import InstanceChannelsLoss
     from biapy_amd.resunetpp import ResUNetPlusPlus
     from oracle import loss_oracle, resunetpp_oracle
 
-    fm, steps, S = [16, 32, 64, 128, 256], 12, 80
+    fm, steps, S = [16, 32, 64, 128, 256], 20, 80
     torch.manual_seed(3)
     dev_m = ResUNetPlusPlus(image_shape=(S, S, S, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", k_size=3,
                             upsample_layer="convtranspose", yx_down=[2] * 4, z_down=[2] * 4, output_channels=[3], output_channel_info=["BCD"],
@@ -1648,44 +1664,46 @@ def test_resunetpp_cfg4_architecture_mixed_training_follows_the_fp32_oracle_loss
     opt_d = torch.optim.AdamW(dev_m.parameters(), lr=1e-3)
     opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=1e-3)
     curve_d, curve_c = [], []
-    for it in range(steps):
-        x, t = batches[it % len(batches)]
-        opt_d.zero_grad(set_to_none=True)
-        ld = loss_fn(dev_m(x.cuda()), t.cuda())
-        ld.backward()
-        opt_d.step()
-        opt_c.zero_grad(set_to_none=True)
-        lo = resunetpp_oracle.resunetpp_forward(cpu_p, x, fm)
-        lc = loss_oracle.instance_channels(loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True), t, ["bce", "bce", "mse"], [1, 1, 1])
-        lc.backward()
-        opt_c.step()
-        curve_d.append(ld.item())
-        curve_c.append(lc.item())
-    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
-    assert cc[-4:].mean() < 0.9 * cc[:4].mean() and cd[-4:].mean() < 0.9 * cd[:4].mean(), (curve_c, curve_d)
-    rel = ((cd - cc).abs() / cc).max().item()
-    print(f"cfg-4 architecture: worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
-    _record_diag(f"loss_curve[resunet++ cfg-4 arch (fm 16-32-64-128-256) mixed vs fp32 oracle, {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {PP_CFG4_CURVE_TOL:g})")
-    assert rel < PP_CFG4_CURVE_TOL, (rel, curve_c, curve_d)
+    with _oracle_threads():
+        for it in range(steps):
+            x, t = batches[it % len(batches)]
+            opt_d.zero_grad(set_to_none=True)
+            ld = loss_fn(dev_m(x.cuda()), t.cuda())
+            ld.backward()
+            opt_d.step()
+            opt_c.zero_grad(set_to_none=True)
+            lo = resunetpp_oracle.resunetpp_forward(cpu_p, x, fm)
+            lc = loss_oracle.instance_channels(loss_oracle.apply_head_activations(lo, ["ce_sigmoid", "ce_sigmoid", "tanh"], training=True), t, ["bce", "bce", "mse"], [1, 1, 1])
+            lc.backward()
+            opt_c.step()
+            curve_d.append(ld.item())
+            curve_c.append(lc.item())
+        cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+        assert cc[-4:].mean() < 0.9 * cc[:4].mean() and cd[-4:].mean() < 0.9 * cd[:4].mean(), (curve_c, curve_d)
+        rel = ((cd - cc).abs() / cc).max().item()
+        print(f"cfg-4 architecture: worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
+        _record_diag(f"loss_curve[resunet++ cfg-4 arch (fm 16-32-64-128-256) mixed vs fp32 oracle, {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {PP_CFG4_CURVE_TOL:g})")
+        assert rel < PP_CFG4_CURVE_TOL, (rel, curve_c, curve_d)
 
 
-PLATEAU_DICE_TOL = 1e-3       # VERDICT r5 next #5a: measured |Dice delta| of the two trained weight sets 1.8e-4 after 240 steps, 4.5e-4 at step 160 (profiles/r06_gpu_test_values.txt)
+PLATEAU_DICE_TOL = 3e-4       # VERDICT r5 next #5a: ~4 x the measured |Dice delta| of the two trained weight sets (6.8e-5 after 480 steps, 7.3e-5 at step 400: profiles/r06_gpu_test_values.txt)
 
 
 def test_resunet_mixed_training_reaches_the_fp32_oracles_plateau(K):
-    """VERDICT r5 weak #2 / next #5a: training parity beyond 30 steps.  The cfg-2 architecture, 200 AdamW steps on the device in the benched mixed
-    mode (fp16 forward, bf16 gradients) and the same 200 steps as the fp32 CPU oracle graph, from one initialisation on the same batches (8
-    training volumes of 32^3 visited in order - the size is what 200 fp32 CPU steps of the five-level net allow: ~1 s each on the GPU box's host; the level-0 layers still take the
-    fused backward and lean forward kernels from 32^3 on).  Two runs in different arithmetic do not stay step-for-step together that long -
-    rounding noise is amplified by training - so the claim tested is the one that matters: BOTH weight sets are evaluated by the SAME fp32 oracle
-    forward on 6 held-out volumes, after 140 and after 200 steps; the held-out Dice has stopped moving between the two (the plateau), and at the
-    end the two runs' Dice and loss agree.  A biased gradient would land the device run on a different plateau.  Bar 1e-3 against measured gaps of 1.8e-4 ... 4.5e-4 (240-step run)."""
+    """VERDICT r5 weak #2 / next #5a: training parity beyond 30 steps.  The cfg-2 architecture at 64^3, 480 AdamW steps on the device in the benched
+    mixed mode (fp16 forward, bf16 gradients) and the same 480 steps as the fp32 CPU oracle graph, from one initialisation on the same batches (8
+    training volumes visited in order; the oracle runs on 16 host threads: ~0.15 s per step).  Two runs in different arithmetic do not stay
+    step-for-step together that long - rounding noise is amplified by training: after 240 steps, with the loss still falling, the two held-out Dice
+    values are 1.8e-3 apart - so the claim tested is the one that matters: both runs are trained to their plateau (train loss 0.38 -> 4e-4), and BOTH
+    weight sets are evaluated by the SAME fp32 oracle forward on 6 held-out volumes, after 400 and after 480 steps; the held-out Dice has stopped
+    moving between the two, and at the end the two runs' Dice and loss agree.  A biased gradient would land the device run on a different plateau.
+    Measured |Dice delta| 6.8e-5 (7.3e-5 at step 400), bar 3e-4; held-out loss gap 1.7e-2, bar 0.1.  (The 32^3 variant of this test: 1.4e-4 ... 3.0e-4.)"""
     import torch.nn.functional as F_
 
     from biapy_amd.resunet import ResUNet
     from oracle import net_oracle
 
-    fm, steps, S, probe = [16, 32, 64, 128, 256], 200, 32, 140
+    fm, steps, S, probe = [16, 32, 64, 128, 256], 480, 64, 400
     torch.manual_seed(5)
     dev_m = ResUNet(image_shape=(S, S, S, 1), activation="elu", feature_maps=fm, drop_values=[0.0] * 5, normalization="in", yx_down=[2] * 4, z_down=[2] * 4,
                     isotropy=[True] * 5, larger_io=False, conv_layers=[2] * 5, compute_dtype=torch.float16).cuda().train()
@@ -1712,33 +1730,34 @@ def test_resunet_mixed_training_reaches_the_fp32_oracles_plateau(K):
     opt_d = torch.optim.AdamW(dev_m.parameters(), lr=1e-3)
     opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=1e-3)
     curve_d, curve_c, mid = [], [], None
-    for it in range(steps):
-        if it == probe:
-            mid = held_out()
-        x, t = train[it % len(train)]
-        opt_d.zero_grad(set_to_none=True)
-        ld = F_.binary_cross_entropy_with_logits(dev_m(x.cuda()), t.cuda())
-        ld.backward()
-        opt_d.step()
-        opt_c.zero_grad(set_to_none=True)
-        lc = net_oracle.bce_with_logits(net_oracle.resunet_forward(cpu_p, x, fm), t)
-        lc.backward()
-        opt_c.step()
-        curve_d.append(ld.item())
-        curve_c.append(lc.item())
-    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
-    md, mc, hl_d, hl_c = held_out()
-    gap, lgap = abs(md - mc), abs(hl_d - hl_c) / hl_c
-    print(f"after {probe} steps: held-out Dice device-trained {mid[0]:.6f} / oracle-trained {mid[1]:.6f}; after {steps}: {md:.6f} / {mc:.6f} (|delta| {gap:.3e}); "
-          f"held-out loss {hl_d:.5f} / {hl_c:.5f} (rel gap {lgap:.3e}); train loss first 8 {cc[:8].mean().item():.4f}, last 40 {cd[-40:].mean().item():.4f} / {cc[-40:].mean().item():.4f}")
-    _record_diag(f"plateau[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].heldout_dice device-trained = {md:.6f}, oracle-trained = {mc:.6f}, abs_delta = {gap:.3e} "
-                 f"(bar {PLATEAU_DICE_TOL:g}); at step {probe}: {mid[0]:.6f} / {mid[1]:.6f}; heldout_loss_rel_gap = {lgap:.3e}; train_loss_last40 = "
-                 f"{cd[-40:].mean().item():.4f} / {cc[-40:].mean().item():.4f}")
-    for name, c in (("device", cd), ("oracle", cc)):
-        assert c[-40:].mean() < 0.5 * c[:8].mean(), (name, c[:8].mean().item(), c[-40:].mean().item())
-    assert abs(md - mid[0]) < 0.02 and abs(mc - mid[1]) < 0.02, (mid, md, mc)      # the held-out Dice has plateaued
-    assert gap < PLATEAU_DICE_TOL, (md, mc)
-    assert lgap < 0.1, (hl_d, hl_c)
+    with _oracle_threads():
+        for it in range(steps):
+            if it == probe:
+                mid = held_out()
+            x, t = train[it % len(train)]
+            opt_d.zero_grad(set_to_none=True)
+            ld = F_.binary_cross_entropy_with_logits(dev_m(x.cuda()), t.cuda())
+            ld.backward()
+            opt_d.step()
+            opt_c.zero_grad(set_to_none=True)
+            lc = net_oracle.bce_with_logits(net_oracle.resunet_forward(cpu_p, x, fm), t)
+            lc.backward()
+            opt_c.step()
+            curve_d.append(ld.item())
+            curve_c.append(lc.item())
+        cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+        md, mc, hl_d, hl_c = held_out()
+        gap, lgap = abs(md - mc), abs(hl_d - hl_c) / hl_c
+        print(f"after {probe} steps: held-out Dice device-trained {mid[0]:.6f} / oracle-trained {mid[1]:.6f}; after {steps}: {md:.6f} / {mc:.6f} (|delta| {gap:.3e}); "
+              f"held-out loss {hl_d:.5f} / {hl_c:.5f} (rel gap {lgap:.3e}); train loss first 8 {cc[:8].mean().item():.4f}, last 40 {cd[-40:].mean().item():.4f} / {cc[-40:].mean().item():.4f}")
+        _record_diag(f"plateau[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].heldout_dice device-trained = {md:.6f}, oracle-trained = {mc:.6f}, abs_delta = {gap:.3e} "
+                     f"(bar {PLATEAU_DICE_TOL:g}); at step {probe}: {mid[0]:.6f} / {mid[1]:.6f}; heldout_loss_rel_gap = {lgap:.3e}; train_loss_last40 = "
+                     f"{cd[-40:].mean().item():.4f} / {cc[-40:].mean().item():.4f}")
+        for name, c in (("device", cd), ("oracle", cc)):
+            assert c[-40:].mean() < 0.5 * c[:8].mean(), (name, c[:8].mean().item(), c[-40:].mean().item())
+        assert abs(md - mid[0]) < 0.02 and abs(mc - mid[1]) < 0.02, (mid, md, mc)      # the held-out Dice has plateaued
+        assert gap < PLATEAU_DICE_TOL, (md, mc)
+        assert lgap < 0.1, (hl_d, hl_c)
 
 
 def test_resunet_mixed_training_follows_the_fp32_oracle_loss_curve(K):
@@ -1767,32 +1786,33 @@ def test_resunet_mixed_training_follows_the_fp32_oracle_loss_curve(K):
     opt_d = torch.optim.AdamW(dev_m.parameters(), lr=1e-3)
     opt_c = torch.optim.AdamW(list(cpu_p.values()), lr=1e-3)
     curve_d, curve_c = [], []
-    for it in range(steps):
-        x, t = batches[it % len(batches)]
-        opt_d.zero_grad(set_to_none=True)
-        ld = F_.binary_cross_entropy_with_logits(dev_m(x.cuda()), t.cuda())
-        ld.backward()
-        opt_d.step()
-        opt_c.zero_grad(set_to_none=True)
-        lc = net_oracle.bce_with_logits(net_oracle.resunet_forward(cpu_p, x, fm), t)
-        lc.backward()
-        opt_c.step()
-        curve_d.append(ld.item())
-        curve_c.append(lc.item())
-    cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
-    print("mixed-mode loss curve (device):", [round(v, 4) for v in curve_d])
-    print("fp32 oracle loss curve   (cpu):", [round(v, 4) for v in curve_c])
-    assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
-    rel = ((cd - cc).abs() / cc).max().item()
-    print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
-    _record_diag(f"loss_curve[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {LOSS_CURVE_TOL:g})")
-    assert rel < LOSS_CURVE_TOL, (rel, curve_c, curve_d)
-    # the north-star Dice bar on THIS architecture in the benched forward mode, on the weights just trained, held-out batches
-    # at 64^3 and at the benched 128^3 x 1 shape
-    rows = K.check_dice_benched_arch(model=dev_m, S=S, big=128)
-    for r in rows:
-        _record_diag(f"{r['name']} = {r['err']:.3e} (tol {r['tol']:g}) {r.get('extra', '')}")
-    _assert_all(rows)
+    with _oracle_threads():
+        for it in range(steps):
+            x, t = batches[it % len(batches)]
+            opt_d.zero_grad(set_to_none=True)
+            ld = F_.binary_cross_entropy_with_logits(dev_m(x.cuda()), t.cuda())
+            ld.backward()
+            opt_d.step()
+            opt_c.zero_grad(set_to_none=True)
+            lc = net_oracle.bce_with_logits(net_oracle.resunet_forward(cpu_p, x, fm), t)
+            lc.backward()
+            opt_c.step()
+            curve_d.append(ld.item())
+            curve_c.append(lc.item())
+        cd, cc = torch.tensor(curve_d), torch.tensor(curve_c)
+        print("mixed-mode loss curve (device):", [round(v, 4) for v in curve_d])
+        print("fp32 oracle loss curve   (cpu):", [round(v, 4) for v in curve_c])
+        assert cc[-4:].mean() < 0.8 * cc[:4].mean() and cd[-4:].mean() < 0.8 * cd[:4].mean(), (curve_c, curve_d)
+        rel = ((cd - cc).abs() / cc).max().item()
+        print(f"worst relative gap of the two loss curves over {steps} steps: {rel:.3e}")
+        _record_diag(f"loss_curve[mixed vs fp32 oracle, cfg-2 arch {S}^3, {steps} steps].worst_rel_gap = {rel:.3e} (bar {LOSS_CURVE_TOL:g})")
+        assert rel < LOSS_CURVE_TOL, (rel, curve_c, curve_d)
+        # the north-star Dice bar on THIS architecture in the benched forward mode, on the weights just trained, held-out batches
+        # at 64^3 and at the benched 128^3 x 1 shape
+        rows = K.check_dice_benched_arch(model=dev_m, S=S, big=128)
+        for r in rows:
+            _record_diag(f"{r['name']} = {r['err']:.3e} (tol {r['tol']:g}) {r.get('extra', '')}")
+        _assert_all(rows)
 
 
 def _sw2_worker(rank, world, port, q):
