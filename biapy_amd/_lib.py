@@ -91,6 +91,7 @@ _SIGS = {
     "bpx_conv3d_bwd_fused": ([_i, _i, _i, _i, _i, Tensor, _vp, Tensor, _vp, _i, Tensor, _vp, _vp, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_debug_set_bwd_fused": ([_i], _i),
     "bpx_debug_set_bwd_rs": ([_i], _i),
+    "bpx_debug_set_conv_kg": ([_i], _i),
     "bpx_debug_set_tile_order": ([_i], _i),
     "bpx_debug_set_wgrad_cap": ([_i], _i),
     "bpx_debug_set_wgrad_k1": ([_i], _i),

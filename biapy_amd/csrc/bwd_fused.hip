@@ -1006,6 +1006,7 @@ __global__ void __launch_bounds__(512, CT == 1 ? 4 : 2) conv3_bwd_rs_kernel(cons
         for (int r = 0; r < 4; ++r) pp[((size_t)tap * Ct + c * 16 + 4 * g + r) * 16 + j] = accw[0][a][c][r];
     }
     if (want_b && WW == 3 && g == 0) p.dbpart[(size_t)blockIdx.x * 16 + j] = accw[0][6][0][0];
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no LDS-DMA piece of this wave (the zero pieces behind the last tile) is in flight when the workgroup's LDS is released
     };
     switch (ww) {   // wave-uniform
       case 0: w_role(std::integral_constant<int, 0>{}); break;
@@ -1111,6 +1112,8 @@ extern "C" int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_t
   const int64_t tbytes = 2 * (t.cs ? (int64_t)t.cs * (t.C / 16 - 1) + (vox - 1) * t.ld + 16 : vox * (int64_t)t.ld);
   BPX_CHECK(tbytes < (1ll << 31) && vox * dy.ld * 2 < (1ll << 31) && vox * g.ld * 2 < (1ll << 32), "%s: tensors beyond the 32-bit / buffer addressing range", fn);
   const BwdPlan q = bwd_plan(N, D, H, W, t.C, dy.C);
+  BPX_CHECK(!q.rs || vox * g.ld * 2 < (1ll << 31), "%s: the role-split kernel stores g through a 2 GB buffer window (pitch %d over %lld voxels is beyond it); "
+            "clear the shape's bit with bpx_debug_set_bwd_rs before sizing the workspace", fn, g.ld, (long long)vox);
   const int64_t need = (int64_t)q.grid * ((int64_t)27 * t.C + 1) * dy.C * 4;
   BPX_CHECK(ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
   BwdParams p{};

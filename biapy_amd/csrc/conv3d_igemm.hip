@@ -24,6 +24,8 @@ namespace bpxconv { long long* g_conv_stamps = nullptr; }  // profiling hook: de
 #define g_stamps bpxconv::g_conv_stamps
 extern "C" int bpx_debug_set_conv_stamps(void* p) { g_stamps = (long long*)p; return 0; }
 static int g_use_ws = 0;  // bf16 kernel selection, see bpx_debug_set_conv_ws below
+static int g_conv_kg = -1; // two K groups in the small-tile kernel: -1 = environment (BPX_CONV_KG, default on), 0 / 1 (bpx_debug_set_conv_kg)
+extern "C" int bpx_debug_set_conv_kg(int on) { g_conv_kg = on; return 0; }
 static int64_t g_lean_min_vps = 32768;   // voxels per sample from which the lean kernel is used (test hook: bpx_debug_set_conv_ws 10 = 64^3 as in round 2, 11 = 32^3)
 
 namespace {
@@ -97,8 +99,13 @@ __host__ __device__ constexpr int wreg_next(int s, int np, int per) {
 }
 
 // TT: element type of the dgrad epilogue's activation operand t (BPX_MIX16: fp16 beside bf16 gradients), else T
-template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK, typename TT = T>
-__global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
+// KG = 2 (round 6, the <= 16^3 layers of the bottom of the U): TWO K groups of four waves in one 512-thread workgroup.  Those launches have 64-128
+// workgroups for 256 CUs and a serial chain of Cin / 16 chunk rounds (stage - barrier - 14 MFMA steps) per workgroup: they are latency-bound, and
+// splitting K across WORKGROUPS costs a device-scope fence per workgroup (round 4: 2.5-5x slower).  Inside a workgroup it costs one LDS exchange:
+// group kg takes the chunks kg, kg + 2, ... through its own pair of halo buffers (the chunk barriers are shared), group 1 hands its accumulators
+// to group 0 through LDS at the end, group 0 runs the shortcut steps and the epilogue.  The chain is half as long and every SIMD holds two waves.
+template <typename T, int TZ, int TY, int TX, int NS, int EPI, int ACTK, typename TT = T, int KG = 1>
+__global__ void __launch_bounds__(256 * KG, 2) conv3_kernel(const Conv3Params p) {
   using Tr = ElemTraits<T>;
   constexpr int KPL = Tr::KPL, GPT = 16 / KPL, VB = 16 * (int)sizeof(T);
   constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HV = HZ * HY * HX;
@@ -111,9 +118,14 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   constexpr int BUFB = HV * VB;                 // one halo buffer; two of them (double buffering) + reduction scratch
   static_assert(NS * 16 * 2 * 4 * 4 <= RED_BYTES, "reduction scratch");
   constexpr int NBUF = 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUFB + RED_BYTES];
+  static_assert(KG == 1 || (TX == 8 && sizeof(T) == 2), "two K groups: the small-tile 16-bit instances only");
+  constexpr int XCH_BYTES = KG == 2 ? MS * NS * 256 * 16 : 0;     // the accumulator hand-over [ms][ns][thread] f32x4 re-uses the halo buffers
+  static_assert(XCH_BYTES <= KG * NBUF * BUFB, "accumulator exchange fits the halo buffers");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[KG * NBUF * BUFB + RED_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = KG == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // K group of this wave
+  unsigned char* const smem = smem_all + kg * NBUF * BUFB;                                     // this group's pair of halo buffers
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x % p.tilesPerSample, n = blockIdx.x / p.tilesPerSample;
   const int txi = tile % p.tilesX, tyi = (tile / p.tilesX) % p.tilesY, tzi = tile / (p.tilesX * p.tilesY);
@@ -122,9 +134,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   const int Cout = p.Cout;
 
   int stamp_i = 0;
-#define BPX_STAMP() do { if (p.stamps && tid == 0 && blockIdx.y == 0 && stamp_i < 15) p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define BPX_STAMP() do { if (p.stamps && tid == 0 && kg == 0 && blockIdx.y == 0 && stamp_i < 15) p.stamps[(size_t)blockIdx.x * 16 + stamp_i++] = (long long)__builtin_readcyclecounter(); } while (0)
   BPX_STAMP();  // 0: start
-  if (p.stamps && tid == 0 && blockIdx.y == 0)  // slot 15: where the workgroup ran (HW_ID | XCC_ID << 32)
+  if (p.stamps && tid == 0 && kg == 0 && blockIdx.y == 0)  // slot 15: where the workgroup ran (HW_ID | XCC_ID << 32)
     p.stamps[(size_t)blockIdx.x * 16 + 15] =
         (long long)(((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));
   f32x4_t acc[MS][NS];
@@ -182,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   const T* __restrict__ xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.D * p.H * p.W * p.x_ld + sub * KPL;
   const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
   const bpx_norm_rec* __restrict__ nrec = p.in_norm ? p.in_norm + (size_t)n * p.Cin + sub * KPL : nullptr;
-  const int nchunks = p.Cin / 16;
+  const int nchunks = p.Cin / 16;   // KG == 2: a multiple of 2 (launcher); group kg walks kg, kg + KG, ...
 
   u32x4_t pbuf[NP];
   float psc[KPL], psh[KPL];
@@ -223,12 +235,12 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
 #pragma unroll
   for (int u = 0; u < NP; ++u) {
     pbuf[u] = u32x4_t{0u, 0u, 0u, 0u};
-    if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u]);
+    if (goff[u] != 0xFFFFFFFFu) pbuf[u] = *reinterpret_cast<const u32x4_t*>(xin + goff[u] + (size_t)kg * p.x_cs);
   }
-  BPX_LOAD_NORM(0);
+  BPX_LOAD_NORM(kg);
 #pragma unroll
-  for (int u = 0; u < NP; ++u) BPX_STAGE_PIECE(u, 0, 1);
-  BPX_LOAD_NORM(1);
+  for (int u = 0; u < NP; ++u) BPX_STAGE_PIECE(u, 0, kg + KG);
+  BPX_LOAD_NORM(kg + KG);
   BPX_STAMP();  // 2: chunk 0 transformed + written (includes the HBM latency of its loads)
   __syncthreads();
   BPX_STAMP();  // 3: first barrier
@@ -246,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   constexpr int PER = WREG ? (STEPS + WSTEPS - 1) / WSTEPS : 1;       // fragments re-loaded per such step
   u32x4_t wreg[NWR][NS];
   if (WREG) {
-    const T* wl0 = wp + ((size_t)g * Cout + co_base + j) * KPL;
+    const T* wl0 = wp + ((size_t)kg * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
 #pragma unroll
     for (int s = 0; s < NWR; ++s)
 #pragma unroll
@@ -265,18 +277,18 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   constexpr int NAF = SMALL ? 2 : 1;
   u32x4_t wq[WREG ? 1 : WD + 1][NS];
   if (!WREG) {
-    const T* wl0 = wp + ((size_t)g * Cout + co_base + j) * KPL;
+    const T* wl0 = wp + ((size_t)kg * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
 #pragma unroll
     for (int d = 0; d < WD; ++d)
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) wq[d][ns] = *reinterpret_cast<const u32x4_t*>(wl0 + ((size_t)d * 4 * Cout + ns * 16) * KPL);
   }
   int cur = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = kg; chunk < nchunks; chunk += KG) {
     const int nxt = BUFB - cur;
-    const bool stage_next = chunk + 1 < nchunks;
+    const bool stage_next = chunk + KG < nchunks;
     const T* wl = wp + ((size_t)chunk * QPAD * Cout + (size_t)g * Cout + co_base + j) * KPL;
-    const T* wl1 = wl + (size_t)QPAD * Cout * KPL;   // next chunk
+    const T* wl1 = wl + (size_t)KG * QPAD * Cout * KPL;   // this group's next chunk
     u32x4_t af[NAF][MS];
     auto read_frags = [&](int s_, u32x4_t* f) {
       const int tapA = (GPT == 2) ? bpx_tap_order_bf16(2 * s_) : s_;
@@ -302,7 +314,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = mfma_step<T>(WREG ? wreg[WREG ? s : 0][ns] : wq[WREG ? 0 : s % (WD + 1)][ns], af[s % NAF][ms], acc[ms][ns]);
       }
-      if (s < NP && stage_next) BPX_STAGE_PIECE(s < NP ? s : 0, nxt, chunk + 2);
+      if (s < NP && stage_next) BPX_STAGE_PIECE(s < NP ? s : 0, nxt, chunk + 2 * KG);
       if (WREG && s >= NP && stage_next) {
         // re-load fragments [k0, k1) of the NEXT chunk; never a fragment this chunk has not consumed yet (k <= s)
         const int k0 = wreg_next(s, NP, PER), k1 = wreg_next(s + 1, NP, PER);
@@ -321,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
         for (int ns = 0; ns < NS; ++ns) wq[WREG ? 0 : d][ns] = *reinterpret_cast<const u32x4_t*>(wl1 + ((size_t)d * 4 * Cout + ns * 16) * KPL);
     }
     BPX_STAMP();  // 4,6,8..: step loop of the chunk done
-    BPX_LOAD_NORM(chunk + 2);
+    BPX_LOAD_NORM(chunk + 2 * KG);
     // flip the read buffer: every ds_read base register moves by +-BUFB (cheaper than an add per read)
     const int flip = cur ? -BUFB : BUFB;
 #pragma unroll
@@ -333,6 +345,22 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
   }
 #undef BPX_STAGE_PIECE
 #undef BPX_LOAD_NORM
+  if constexpr (KG == 2) {   // group 1's accumulators -> group 0 (the loop's last barrier has released every halo buffer)
+    f32x4_t* xch = reinterpret_cast<f32x4_t*>(smem_all);
+    if (kg == 1) {
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) xch[(ms * NS + ns) * 256 + tid] = acc[ms][ns];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) acc[ms][ns] += xch[(ms * NS + ns) * 256 + tid];
+    }
+  }
 
   // ---- fused 1x1x1 shortcut on a second raw tensor (EPI_FWD only) ------------------------------
   if (EPI == EPI_FWD && p.sc != nullptr && p.sc_C >= 16) {
@@ -341,8 +369,9 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     const int nch = p.sc_C / 16;
     for (int chunk = 0; chunk < nch; ++chunk) {
       __syncthreads();
-      stage_block<T, TZ, TY, TX>(smem, scin, p.sc_ld, p.sc_cs, chunk, n, p.D, p.H, p.W, z0, y0, x0, nullptr, 0, 0, tid);
+      if (kg == 0) stage_block<T, TZ, TY, TX>(smem, scin, p.sc_ld, p.sc_cs, chunk, n, p.D, p.H, p.W, z0, y0, x0, nullptr, 0, 0, tid);
       __syncthreads();
+      if (kg != 0) continue;
       const T* wl = wsc + ((size_t)chunk * 4 * Cout + (size_t)g * Cout + co_base + j) * KPL;
       u32x4_t wf[NS];
 #pragma unroll
@@ -363,6 +392,7 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[ns][r] = s2[ns][r] = 0.f;
 
+  if (kg == 0) {
   T* __restrict__ yout = reinterpret_cast<T*>(p.y);
   // Every operand of the epilogue is requested first, unconditionally (out-of-volume lanes read the tile's first voxel) and awaited ONCE:
   // with the loads inside the predicated per-voxel blocks the compiler put an `s_waitcnt vmcnt(0)` into each block, and that counter also holds
@@ -452,9 +482,10 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
     }
   }
 
+  }   // kg == 0
   BPX_STAMP();  // epilogue stores issued
   if (p.part != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + NBUF * BUFB);  // [wave][NS*16][2]
+    float* red = reinterpret_cast<float*>(smem_all + KG * NBUF * BUFB);  // [wave][NS*16][2]
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -462,13 +493,13 @@ __global__ void __launch_bounds__(256, 2) conv3_kernel(const Conv3Params p) {
         float a = s1[ns][r], b = s2[ns][r];
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-        if (j == 0) {
+        if (j == 0 && kg == 0) {
           red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 0] = a;
           red[((wave * NS * 16) + ns * 16 + g * 4 + r) * 2 + 1] = b;
         }
       }
     __syncthreads();
-    if (tid < NS * 16 * 2) {
+    if (tid < NS * 16 * 2 && kg == 0) {
       int c = tid >> 1, k = tid & 1;
       float a = red[(0 * NS * 16 + c) * 2 + k] + red[(1 * NS * 16 + c) * 2 + k] + red[(2 * NS * 16 + c) * 2 + k] +
                 red[(3 * NS * 16 + c) * 2 + k];
@@ -489,6 +520,22 @@ int launch_conv3(const Conv3Params& p0, const TileCfg& c, hipStream_t s) {
   dim3 grid((unsigned)(p.N * p.tilesPerSample), (unsigned)(p.Cout / (16 * c.ns)));
   const bool elu = (EPI == EPI_FWD ? p.act : p.t_act) == BPX_ACT_ELU;
   const bool ext = (EPI == EPI_FWD ? p.act : p.t_act) > BPX_ACT_SILU;   // leaky_relu ... softplus: the ACTK = 2 instances
+  // two K groups per workgroup (KG = 2) for the small-tile 16-bit launches with an even number of >= 4 input chunks: the <= 16^3 layers
+  if constexpr (sizeof(T) == 2) {
+    static const bool kg_env = getenv("BPX_CONV_KG") == nullptr || atoi(getenv("BPX_CONV_KG")) != 0;   // A/B: BPX_CONV_KG=0
+    const int nchunks = p.Cin / 16;
+    if ((g_conv_kg < 0 ? kg_env : g_conv_kg != 0) && c.tz == 4 && c.ty == 4 && c.tx == 8 && (c.ns == 2 || c.ns == 4) && nchunks >= 4 && nchunks % 2 == 0) {
+#define LK(NS)                                                                                   \
+      if (c.ns == NS) {                                                                          \
+        if (elu) conv3_kernel<T, 4, 4, 8, NS, EPI, 1, TT, 2><<<grid, 512, 0, s>>>(p);            \
+        else if (ext) conv3_kernel<T, 4, 4, 8, NS, EPI, 2, TT, 2><<<grid, 512, 0, s>>>(p);       \
+        else conv3_kernel<T, 4, 4, 8, NS, EPI, 0, TT, 2><<<grid, 512, 0, s>>>(p);                \
+        return 0;                                                                                \
+      }
+      LK(2) LK(4)
+#undef LK
+    }
+  }
 #define L(TZ, TY, TX, NS)                                                        \
   if (c.tz == TZ && c.ty == TY && c.tx == TX && c.ns == NS) {                    \
     if (elu) conv3_kernel<T, TZ, TY, TX, NS, EPI, 1, TT><<<grid, 256, 0, s>>>(p);    \

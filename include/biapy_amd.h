@@ -242,6 +242,7 @@ int bpx_conv3d_bwd_fused(int dtype, int N, int D, int H, int W, bpx_tensor dy, c
                          void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 int bpx_debug_set_bwd_fused(int bits); /* test / A-B hook: bit 0 clear = bpx_conv3d_bwd_fused_supported answers 0 everywhere (the engine then takes the two separate kernels); bit 1 set = only the dy.C == 16 instances */
 int bpx_debug_set_bwd_rs(int mask);     /* test / A-B hook: bit 0 = the (dy 16, t 48) shape of bpx_conv3d_bwd_fused runs the role-split kernel (8 waves per CU: 4 dgrad + 4 wgrad, two tiles in flight), bit 1 = the (dy 16, t 16) shape does; call before _stats_tiles / _workspace */
+int bpx_debug_set_conv_kg(int on);      /* test / A-B hook: the two-K-group form of the small-tile conv kernel (<= 16^3 layers with >= 4 input chunks): 1 on, 0 off, -1 = environment BPX_CONV_KG (default on) */
 
 /* Deferred reduction of the weight-gradient partials.  Between bpx_wgrad_defer_begin() and bpx_wgrad_defer_flush() (same
  * host thread) bpx_conv3d_wgrad and the bf16 bpx_convT3d_k2s2_wgrad write only their partial slabs and queue the reduction;

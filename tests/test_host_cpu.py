@@ -740,3 +740,29 @@ def test_explicit_activation_tail_follows_prepare_activation_layers(tag):
         assert out[k].shape == ref.shape and (out[k] - ref).abs().max().item() < 1e-6, (tag, k)
     if tag == "multiclass":          # the joint softmax: channels sum to one (a per-channel softmax would be all ones)
         assert (out["pred"].sum(1) - 1).abs().max().item() < 1e-5 and out["pred"].max().item() < 1.0
+
+
+def test_fused_backward_plan_of_the_role_split_and_serial_forms():
+    """Host side of bpx_conv3d_bwd_fused (no GPU: the planner assumes 256 CUs when there is no device): which shapes it takes, how many statistics
+    rows per sample it writes and how much workspace it wants, for the role-split kernel (round 6: one 8-wave workgroup per CU for 48 channels, two
+    for 16; one statistics row per D wave) and for the serial kernel behind the A/B mask."""
+    from biapy_amd import _lib as L
+
+    lib = L.lib
+    N, S = 4, 128
+    try:
+        for mask, rows48, rows16, grid48, grid16 in ((3, 4 * 256, 4 * 512, 256, 512), (0, (S // 4) * (S // 4) * (S // 16), 768, 512, 768)):
+            lib.bpx_debug_set_bwd_rs(mask)
+            assert lib.bpx_conv3d_bwd_fused_supported(L.MIX16, N, S, S, S, 48, 16) == 1 and lib.bpx_conv3d_bwd_fused_supported(L.BF16, N, S, S, S, 16, 16) == 1
+            assert lib.bpx_conv3d_bwd_fused_stats_tiles(N, S, S, S, 48, 16) == rows48          # serial 48-channel form: one row per 4 x 4 x 16 tile
+            assert lib.bpx_conv3d_bwd_fused_stats_tiles(N, S, S, S, 16, 16) == rows16
+            assert lib.bpx_conv3d_bwd_fused_workspace(N, S, S, S, 48, 16) == grid48 * (27 * 48 + 1) * 16 * 4
+            assert lib.bpx_conv3d_bwd_fused_workspace(N, S, S, S, 16, 16) == grid16 * (27 * 16 + 1) * 16 * 4
+        lib.bpx_debug_set_bwd_rs(3)
+        # the dy.C == 32 shapes of level 1 stay on the serial kernel whatever the mask; unsupported: f32 storage, small volumes, other widths
+        assert lib.bpx_conv3d_bwd_fused_supported(L.MIX16, N, 64, 64, 64, 32, 32) == 1 and lib.bpx_conv3d_bwd_fused_supported(L.MIX16, N, 64, 64, 64, 96, 32) == 0
+        assert lib.bpx_conv3d_bwd_fused_supported(L.F32, N, S, S, S, 16, 16) == 0 and lib.bpx_conv3d_bwd_fused_supported(L.MIX16, 1, 16, 16, 16, 16, 16) == 0
+        small = lib.bpx_conv3d_bwd_fused_stats_tiles(1, 32, 32, 32, 48, 16)      # 128 tiles: the grid is capped at the tile count (a multiple of 8)
+        assert small == 4 * 128
+    finally:
+        lib.bpx_debug_set_bwd_rs(3)
