@@ -74,6 +74,11 @@ _SIGS = {
     "bpx_seg_loss_bwd": ([_vp, _vp, _i64, _vp, _vp, _vp], _i),
     "bpx_seg_loss_finish": ([_vp, _i, _i64, _f, _f, _f, _vp, _vp, _vp], _i),
     "bpx_seg_loss_bwd_fused": ([_vp, _vp, _i64, _vp, _vp, _f, _f, _f, _vp, _vp], _i),
+    "bpx_softmax_ce_blocks": ([_i64], _i),
+    "bpx_softmax_ce_row": ([], _i),
+    "bpx_softmax_ce_sums": ([_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp], _i),
+    "bpx_softmax_ce_finish": ([_vp, _i, _i64, _vp, _vp, _vp], _i),
+    "bpx_softmax_ce_bwd": ([_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "bpx_chan_loss_finish": ([_vp, _i, _i, _i64, _vp, _vp, _vp], _i),
     "bpx_chan_loss_bwd_fused": ([_vp, _vp, _i, _i, _i64, C.c_uint, _vp, _vp, _vp, _vp], _i),
     "bpx_conv3d_fwd": ([_i, _i, _i, _i, _i, Tensor, _vp, _i, _vp, _vp, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),

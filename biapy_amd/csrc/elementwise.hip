@@ -1494,11 +1494,23 @@ __global__ void __launch_bounds__(256) rank1_wgrad_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 enum { PK_K3 = 0, PK_K3_T = 1, PK_K1 = 2, PK_DENSE = 3, PK_DENSE_T = 4, PK_CT = 5, PK_CT_T = 6, PK_CT4 = 7, PK_CT4_T = 8 };
 
+// element (chunk, k-group q, column, e) of a packed 3x3x3 operand
+template <int KPL>
+__device__ __forceinline__ float pack_k3_value(const float* __restrict__ w, int mode, int Cin, int chunk, int q, int col, int e) {
+  constexpr int GPT = 16 / KPL, QTOT = 27 * GPT;
+  int tap = (q < QTOT) ? q / GPT : -1;
+  const int cgp = q % GPT;
+  if (GPT == 2 && q < 56) tap = bpx_tap_order_bf16(q / GPT);  // paired tap order of the bf16 kernels
+  if (tap < 0) return 0.f;
+  const int kc = chunk * 16 + cgp * KPL + e;  // reduction channel
+  return mode == PK_K3 ? w[((size_t)col * Cin + kc) * 27 + tap]                 // W[co][ci][tap]
+                       : w[((size_t)kc * Cin + col) * 27 + (26 - tap)];         // W[co=kc][ci=col][mirrored tap]
+}
+
 template <typename T>
-__device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int64_t total,
-                                           int64_t first, int64_t stride) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int64_t i) {
   constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL;
-  for (int64_t i = first; i < total; i += stride) {
+  {
     int e = (int)(i % KPL);
     int64_t r = i / KPL;
     float v = 0.f;
@@ -1508,13 +1520,7 @@ __device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __res
       int col = (int)(r % ncol); r /= ncol;
       int q = (int)(r % QPAD);
       int chunk = (int)(r / QPAD);
-      int tap = (q < QTOT) ? q / GPT : -1, cgp = q % GPT;
-      if (GPT == 2 && q < 56) tap = bpx_tap_order_bf16(q / GPT);  // paired tap order of the bf16 kernels
-      if (tap >= 0) {
-        int kc = chunk * 16 + cgp * KPL + e;  // reduction channel
-        if (mode == PK_K3) v = w[((size_t)col * Cin + kc) * 27 + tap];                 // W[co][ci][tap]
-        else v = w[((size_t)kc * Cin + col) * 27 + (26 - tap)];                         // W[co=kc][ci=col][mirrored tap]
-      }
+      v = pack_k3_value<KPL>(w, mode, Cin, chunk, q, col, e);
     } else if (mode == PK_K1) {
       int col = (int)(r % Cout); r /= Cout;
       int q = (int)(r % 4);
@@ -1546,26 +1552,99 @@ __device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __res
 }
 
 template <typename T>
+__device__ __forceinline__ void pack_elems(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int64_t total,
+                                           int64_t first, int64_t stride) {
+  for (int64_t i = first; i < total; i += stride) pack_one<T>(w, out, mode, Cin, Cout, i);
+}
+
+// The 3x3x3 operands in COLUMN BLOCKS (round 6).  In the linear order a workgroup covers 32 columns of ONE k-group q, and the 27 taps of a source
+// row (w[co][ci][27]: neighbouring reduction channels lie 108 bytes apart) are fetched by 27 different workgroups: every 128-byte line of the fp32
+// weights crosses the L2 -> L1 path ~27 times (0.7 GB per training step, 50 us).  Here a workgroup owns 8 columns of one 16-channel chunk and walks
+// ALL of its k-groups: the lines it touches are used completely while they sit in its L1, and every k-group's 8 columns x KPL elements are one
+// 128-byte store.  The elements are the linear order's own (pack_one): same bits.
+constexpr int PACK_COLS = 8;
+__host__ __device__ inline bool pack_by_columns(int mode, int Cin, int Cout) {
+  return (mode == PK_K3 && Cout % PACK_COLS == 0) || (mode == PK_K3_T && Cin % PACK_COLS == 0);
+}
+__host__ __device__ inline int pack_qpad(int kpl) { return ((27 * (16 / kpl) + 3) / 4) * 4; }
+__host__ __device__ inline int pack_column_blocks(int mode, int Cin, int Cout) {   // chunks x column groups
+  return mode == PK_K3 ? (Cin / 16) * (Cout / PACK_COLS) : (Cout / 16) * (Cin / PACK_COLS);
+}
+// `stage`: PACK_COLS * 16 * 27 floats of LDS.  The block's source is 8 runs of 432 contiguous floats (PK_K3: one run per column = output channel) or
+// 16 runs of 216 (PK_K3_T: one per reduction channel): it is brought in with consecutive lanes on consecutive floats - gathering straight from
+// global memory put each lane of a load on its own cache line, 64 lines per wave instruction, and that (not the arithmetic) was the kernel's 50 us -
+// and gathered from LDS (stride 27 words: conflict-free).
+constexpr int PACK_STAGE = PACK_COLS * 16 * 27;
+template <typename T>
+__device__ __forceinline__ void pack_column_block(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int blk, float* stage) {
+  constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL, QTOT = 27 * GPT, QPAD = ((QTOT + 3) / 4) * 4;
+  const int ncol = mode == PK_K3 ? Cout : Cin, cgs = ncol / PACK_COLS;
+  const int chunk = blk / cgs, c0 = (blk - chunk * cgs) * PACK_COLS;
+  const bool fwd = mode == PK_K3;
+  const int run = fwd ? 16 * 27 : PACK_COLS * 27;                                  // contiguous floats per source run
+  const size_t base = fwd ? ((size_t)c0 * Cin + chunk * 16) * 27 : ((size_t)chunk * 16 * Cin + c0) * 27, rstride = (size_t)Cin * 27;
+  for (int l = threadIdx.x; l < PACK_STAGE; l += blockDim.x) {
+    const int r = l / run, off = l - r * run;
+    stage[l] = w[base + (size_t)r * rstride + off];
+  }
+  __syncthreads();
+  T* const o = out + ((size_t)chunk * QPAD * ncol + c0) * KPL;
+  for (int l = threadIdx.x; l < QPAD * PACK_COLS * KPL; l += blockDim.x) {
+    const int q = l / (PACK_COLS * KPL), ce = l % (PACK_COLS * KPL);          // ce = column-in-block * KPL + e: contiguous in the packed operand
+    const int col_l = ce / KPL, e = ce % KPL;
+    // the element function of pack_k3_value on the staged copy: w[co][ci][tap] sits at stage[(col_l * 16 + kc_l) * 27 + tap] (PK_K3),
+    // w[co = kc][ci = col][tap] at stage[(kc_l * PACK_COLS + col_l) * 27 + tap] (PK_K3_T, read at the mirrored tap)
+    int tap = (q < QTOT) ? q / GPT : -1;
+    if (GPT == 2 && q < 56) tap = bpx_tap_order_bf16(q / GPT);
+    const int kc_l = (q % GPT) * KPL + e;
+    float v = 0.f;
+    if (tap >= 0) v = fwd ? stage[(col_l * 16 + kc_l) * 27 + tap] : stage[(kc_l * PACK_COLS + col_l) * 27 + (26 - tap)];
+    ElemTraits<T>::st(o + (size_t)q * ncol * KPL + ce, v);
+  }
+}
+
+template <typename T>
 __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout,
                                                    int64_t total) {
   pack_elems<T>(w, out, mode, Cin, Cout, total, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
-struct PackBatch { bpx_pack_job job[64]; int64_t total[64]; };
+// One launch for up to 64 operands.  Job k owns the blocks [first_block[k], first_block[k + 1]), their number proportional to its size (round 6: with
+// 256 blocks for EVERY job the 1.8 M-element operands of the bottom of the U took 27 elements per thread while most of the grid idled; four elements
+// per thread now, and the 3x3x3 operands in column blocks - pack_column_block above).  Same per-element function: the packed bits do not change.
+struct PackBatch { bpx_pack_job job[64]; int64_t total[64]; int first_block[65]; int count; };
+constexpr int PACK_EPT = 4;
+__device__ __forceinline__ int pack_job_of_block(const PackBatch& b, int blk) {   // block-uniform search
+  int lo = 0, hi = b.count;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk >= b.first_block[mid]) lo = mid; else hi = mid;
+  }
+  return lo;
+}
 template <typename T>
-__global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch b) {   // blockIdx.y = job
-  const bpx_pack_job j = b.job[blockIdx.y];
-  pack_elems<T>(j.w_d, reinterpret_cast<T*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[blockIdx.y],
-                (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+__global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch b) {
+  const int k = pack_job_of_block(b, (int)blockIdx.x);
+  const bpx_pack_job j = b.job[k];
+  const int nb = b.first_block[k + 1] - b.first_block[k], blk = (int)blockIdx.x - b.first_block[k];
+  __shared__ float stage[PACK_STAGE];
+  if (pack_by_columns(j.mode, j.Cin, j.Cout)) pack_column_block<T>(j.w_d, reinterpret_cast<T*>(j.packed_d), j.mode, j.Cin, j.Cout, blk, stage);
+  else pack_elems<T>(j.w_d, reinterpret_cast<T*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[k], (int64_t)blk * blockDim.x + threadIdx.x, (int64_t)nb * blockDim.x);
 }
 
 // BPX_MIX16 (fp16 forward / bf16 backward training): the forward operators' weights are fp16, the transposed (backward) operators' bf16
 __host__ __device__ inline bool mix_mode_is_bf16(int mode) { return mode == PK_K3_T || mode == PK_DENSE_T || mode == PK_CT_T || mode == PK_CT4_T; }
-__global__ void __launch_bounds__(256) pack_batch_mix_kernel(const PackBatch b) {   // blockIdx.y = job
-  const bpx_pack_job j = b.job[blockIdx.y];
-  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
-  if (mix_mode_is_bf16(j.mode)) pack_elems<uint16_t>(j.w_d, reinterpret_cast<uint16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[blockIdx.y], first, step);
-  else pack_elems<f16_t>(j.w_d, reinterpret_cast<f16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[blockIdx.y], first, step);
+__global__ void __launch_bounds__(256) pack_batch_mix_kernel(const PackBatch b) {
+  const int k = pack_job_of_block(b, (int)blockIdx.x);
+  const bpx_pack_job j = b.job[k];
+  const int nb = b.first_block[k + 1] - b.first_block[k], blk = (int)blockIdx.x - b.first_block[k];
+  const int64_t first = (int64_t)blk * blockDim.x + threadIdx.x, step = (int64_t)nb * blockDim.x;
+  __shared__ float stage[PACK_STAGE];
+  if (pack_by_columns(j.mode, j.Cin, j.Cout)) {
+    if (mix_mode_is_bf16(j.mode)) pack_column_block<uint16_t>(j.w_d, reinterpret_cast<uint16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, blk, stage);
+    else pack_column_block<f16_t>(j.w_d, reinterpret_cast<f16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, blk, stage);
+  } else if (mix_mode_is_bf16(j.mode)) pack_elems<uint16_t>(j.w_d, reinterpret_cast<uint16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[k], first, step);
+  else pack_elems<f16_t>(j.w_d, reinterpret_cast<f16_t*>(j.packed_d), j.mode, j.Cin, j.Cout, b.total[k], first, step);
 }
 
 inline int64_t packed_elems(int mode, int Cin, int Cout, int dtype) {
@@ -2001,6 +2080,115 @@ __global__ void __launch_bounds__(256) chan_loss_bwd_kernel(const float* __restr
     float dz;
     chan_loss_term(z[off + i], t[off + i], code, dz);
     dzo[off + i] = k * dz;
+  }
+}
+
+// ---- multi-class cross entropy (metrics.py:493-586 CrossEntropyLoss_wrapper with num_classes > 2 -> torch.nn.CrossEntropyLoss(ignore_index, weight),
+// mean reduction: sum_v w[y_v] * (logsumexp_c z[v][c] - z[v][y_v]) / sum_v w[y_v] over the voxels whose label is not ignore_index) and the per-class
+// counts of the multi-class IoU (:138-232: argmax prediction against the label map).  logits are planar (N, C, voxels) fp32 - what bpx_head_fwd
+// writes -, the label map (N, 1, voxels) holds class ids as floats.  Row of partials per (sample, block): {sum w * nll, sum w, tp[8], pred[8], tgt[8]}.
+constexpr int SCE_MAXC = 8, SCE_ROW = 2 + 3 * SCE_MAXC;
+__device__ __forceinline__ int sce_label(float t, int C, int ignore_index) {   // class id, or -1 = not counted (ignore_index / outside [0, C))
+  const int y = (int)t;
+  return (y == ignore_index || y < 0 || y >= C) ? -1 : y;
+}
+__global__ void __launch_bounds__(256) softmax_ce_sums_kernel(const float* __restrict__ z, const float* __restrict__ t, int C, int64_t vox, int ignore_index,
+                                                              const float* __restrict__ cw, float* __restrict__ part) {
+  const int n = blockIdx.y;
+  const float* zp = z + (size_t)n * C * vox;
+  const float* tp = t + (size_t)n * vox;
+  float s_nll = 0.f, s_w = 0.f, cnt[3][SCE_MAXC];
+#pragma unroll
+  for (int c = 0; c < SCE_MAXC; ++c) cnt[0][c] = cnt[1][c] = cnt[2][c] = 0.f;
+  float w[SCE_MAXC];
+#pragma unroll
+  for (int c = 0; c < SCE_MAXC; ++c) w[c] = (cw && c < C) ? cw[c] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vox; i += (int64_t)gridDim.x * 256) {
+    float zc[SCE_MAXC], m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < SCE_MAXC; ++c) {
+      zc[c] = c < C ? zp[(size_t)c * vox + i] : -INFINITY;
+      if (zc[c] > m) { m = zc[c]; am = c; }      // first maximum, as torch.argmax
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < SCE_MAXC; ++c) se += c < C ? expf(zc[c] - m) : 0.f;
+    const float lse = m + logf(se);
+    const int y = sce_label(tp[i], C, ignore_index);
+    if (y >= 0) {
+#pragma unroll
+      for (int c = 0; c < SCE_MAXC; ++c) {
+        const bool is_y = c == y, is_p = c == am;
+        if (is_y) { s_nll += w[c] * (lse - zc[c]); s_w += w[c]; }
+        cnt[0][c] += (is_y && is_p) ? 1.f : 0.f; cnt[1][c] += is_p ? 1.f : 0.f; cnt[2][c] += is_y ? 1.f : 0.f;
+      }
+    }
+  }
+  __shared__ float red[4][SCE_ROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  };
+  float a = wsum(s_nll), b = wsum(s_w);
+  if (lane == 0) { red[wave][0] = a; red[wave][1] = b; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int c = 0; c < SCE_MAXC; ++c) {
+      const float v = wsum(cnt[k][c]);
+      if (lane == 0) red[wave][2 + k * SCE_MAXC + c] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < SCE_ROW)
+    part[((size_t)n * gridDim.x + blockIdx.x) * SCE_ROW + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one workgroup: the rows summed in a fixed order in double; loss = sums[0] / sums[1] (NaN when every label is ignored, as torch's mean reduction)
+__global__ void __launch_bounds__(256) softmax_ce_finish_kernel(const float* __restrict__ part, int rows, double* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double red[8][SCE_ROW];
+  const int k = threadIdx.x % 32, lane_r = threadIdx.x / 32;        // 8 row lanes x 32 columns (26 used)
+  double a = 0.;
+  if (k < SCE_ROW)
+    for (int r = lane_r; r < rows; r += 8) a += (double)part[(size_t)r * SCE_ROW + k];
+  if (k < SCE_ROW) red[lane_r][k] = a;
+  __syncthreads();
+  if (threadIdx.x < SCE_ROW) {
+    double v = 0.;
+    for (int q = 0; q < 8; ++q) v += red[q][threadIdx.x];
+    sums[threadIdx.x] = v;
+    red[0][threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (float)(red[0][0] / red[0][1]);
+}
+
+// dlogits[n][c][v] = gup * w[y] / sum_w * (softmax_c - [c == y]); 0 where the label is not counted
+__global__ void __launch_bounds__(256) softmax_ce_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t, int C, int64_t vox, int ignore_index,
+                                                             const float* __restrict__ cw, const double* __restrict__ sums, const float* __restrict__ gup,
+                                                             float* __restrict__ dz) {
+  const int n = blockIdx.y;
+  const float* zp = z + (size_t)n * C * vox;
+  const float* tp = t + (size_t)n * vox;
+  float* dp = dz + (size_t)n * C * vox;
+  const float k0 = (float)((double)gup[0] / sums[1]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vox; i += (int64_t)gridDim.x * 256) {
+    float zc[SCE_MAXC], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SCE_MAXC; ++c) {
+      zc[c] = c < C ? zp[(size_t)c * vox + i] : -INFINITY;
+      m = fmaxf(m, zc[c]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < SCE_MAXC; ++c) { zc[c] = c < C ? expf(zc[c] - m) : 0.f; se += zc[c]; }
+    const int y = sce_label(tp[i], C, ignore_index);
+    const float k = y >= 0 ? k0 * (cw ? cw[y] : 1.f) : 0.f, inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < SCE_MAXC; ++c)
+      if (c < C) dp[(size_t)c * vox + i] = k * (zc[c] * inv - (c == y ? 1.f : 0.f));
   }
 }
 
@@ -2698,6 +2886,8 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
   for (int base = 0; base < count; base += 64) {
     PackBatch b{};
     const int n = std::min(64, count - base);
+    int blocks = 0;
+    b.count = n;
     for (int k = 0; k < n; ++k) {
       const bpx_pack_job& j = jobs[base + k];
       BPX_CHECK(j.w_d && j.packed_d, "%s: job %d has a null pointer", fn, base + k);
@@ -2707,8 +2897,11 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
       if (j.mode == PK_K3_T) BPX_CHECK(j.Cout % 16 == 0, "%s: job %d: Cout must be a multiple of 16", fn, base + k);
       b.job[k] = j;
       b.total[k] = packed_elems(j.mode, j.Cin, j.Cout, dtype);
+      b.first_block[k] = blocks;
+      blocks += pack_by_columns(j.mode, j.Cin, j.Cout) ? pack_column_blocks(j.mode, j.Cin, j.Cout) : (int)std::max<int64_t>(1, cdiv64(b.total[k], 256 * PACK_EPT));
     }
-    dim3 grid(256, (unsigned)n);   // the largest operands (256x256x27) are ~1.8 M elements: 27 per thread
+    b.first_block[n] = blocks;
+    const unsigned grid = (unsigned)blocks;
     if (dtype == BPX_BF16) pack_batch_kernel<uint16_t><<<grid, 256, 0, s>>>(b);
     else if (dtype == BPX_MIX16) pack_batch_mix_kernel<<<grid, 256, 0, s>>>(b);
     else if (dtype == BPX_F16) pack_batch_kernel<f16_t><<<grid, 256, 0, s>>>(b);
@@ -2816,6 +3009,39 @@ extern "C" int bpx_chan_loss_bwd(const float* logits_d, const float* target_d, i
   BPX_CHECK(N > 0 && C >= 1 && C <= 8 && voxels > 0, "%s: 1 <= C <= 8 channels", fn);
   dim3 grid((unsigned)std::min<int64_t>(cdiv64(voxels, 256), 1024), (unsigned)(N * C));
   chan_loss_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits_d, target_d, voxels, C, codes, coef_d, dlogits_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_softmax_ce_blocks(int64_t voxels) { return (int)std::min<int64_t>(std::max<int64_t>(1, cdiv64(voxels, 1024)), 512); }
+extern "C" int bpx_softmax_ce_row(void) { return SCE_ROW; }
+
+extern "C" int bpx_softmax_ce_sums(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, int ignore_index, const float* class_w_d,
+                                   float* partials_d, bpx_stream_t stream) {
+  const char* fn = "bpx_softmax_ce_sums";
+  BPX_CHECK(logits_d && target_d && partials_d, "%s: null pointer", fn);
+  BPX_CHECK(N > 0 && N <= 65535 && C >= 2 && C <= SCE_MAXC && voxels > 0, "%s: 2 <= C <= %d classes, 1 <= N <= 65535", fn, SCE_MAXC);
+  dim3 grid((unsigned)bpx_softmax_ce_blocks(voxels), (unsigned)N);
+  softmax_ce_sums_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits_d, target_d, C, voxels, ignore_index, class_w_d, partials_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_softmax_ce_finish(const float* partials_d, int N, int64_t voxels, double* sums_d, float* loss_d, bpx_stream_t stream) {
+  const char* fn = "bpx_softmax_ce_finish";
+  BPX_CHECK(partials_d && sums_d && loss_d && N > 0 && voxels > 0, "%s: bad arguments", fn);
+  softmax_ce_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials_d, N * bpx_softmax_ce_blocks(voxels), sums_d, loss_d);
+  BPX_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+extern "C" int bpx_softmax_ce_bwd(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, int ignore_index, const float* class_w_d,
+                                  const double* sums_d, const float* gup_d, float* dlogits_d, bpx_stream_t stream) {
+  const char* fn = "bpx_softmax_ce_bwd";
+  BPX_CHECK(logits_d && target_d && sums_d && gup_d && dlogits_d, "%s: null pointer", fn);
+  BPX_CHECK(N > 0 && N <= 65535 && C >= 2 && C <= SCE_MAXC && voxels > 0, "%s: 2 <= C <= %d classes, 1 <= N <= 65535", fn, SCE_MAXC);
+  dim3 grid((unsigned)std::min<int64_t>(cdiv64(voxels, 256), 1024), (unsigned)N);
+  softmax_ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits_d, target_d, C, voxels, ignore_index, class_w_d, sums_d, gup_d, dlogits_d);
   BPX_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -3,8 +3,9 @@
 Mirrors ``biapy/engine/metrics.py``: ``CrossEntropyLoss_wrapper`` (:493-586; the default ``LOSS.TYPE = "CE"`` on one output
 channel is ``BCEWithLogitsLoss``), ``DiceLoss`` (:726-762, ``batch_dice=True``, smooth 1e-5), ``DiceCELoss`` (:764-973,
 binary case: ``w_ce * BCE + w_dice * (1 - Dice)``) and ``jaccard_index`` (:138-232, threshold 0.5).  One streaming HIP kernel
-produces every sum the four need (``bpx_seg_loss_sums``); the backward is one more pass (``bpx_seg_loss_bwd``).  Multi-class
-heads / class re-balancing / ignore_index stay on the reference implementation (NotImplementedError here).
+produces every sum the four need (``bpx_seg_loss_sums``); the backward is one more pass (``bpx_seg_loss_bwd``).  Round 6: the multi-class
+case of ``CrossEntropyLoss_wrapper`` (``num_classes > 2``: softmax cross entropy over 3..8 class channels with ``ignore_index`` and the "manual"
+class weights) and the confusion counts of the multi-class IoU run on the device too (``bpx_softmax_ce_*``); ``DiceCELoss`` stays binary.
 """
 from __future__ import annotations
 
@@ -111,6 +112,120 @@ def hard_dice(logits: torch.Tensor, target: torch.Tensor, smooth: float = 1e-5) 
     z, t = _prep(logits, target)
     s = _sums(z, t)
     return ((2.0 * s[4] + smooth) / (s[4] + s[5] + smooth)).to(torch.float32)   # |P| + |T| = |P&T| + |P|T|
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# multi-class semantic segmentation (MODEL.N_CLASSES > 2): softmax cross entropy + per-class confusion counts
+# ---------------------------------------------------------------------------------------------------------------------------
+def _prep_classes(logits: torch.Tensor, target: torch.Tensor):
+    if not logits.is_cuda:
+        raise RuntimeError("biapy_amd.losses run on the MI355X only (logits are on %s); there is no CPU path" % logits.device)
+    if logits.dim() < 3 or not 2 <= logits.shape[1] <= 8:
+        raise NotImplementedError("biapy_amd.losses: the multi-class cross entropy takes 2..8 class channels; use the reference loss beyond that")
+    if target.dim() == logits.dim() - 1:
+        target = target.unsqueeze(1)
+    if target.shape[0] != logits.shape[0] or target.shape[1] != 1 or target.shape[2:] != logits.shape[2:]:
+        raise ValueError(f"target shape {tuple(target.shape)} does not match logits {tuple(logits.shape)} (one label channel expected)")
+    return logits.contiguous().to(torch.float32), target.contiguous().to(torch.float32)      # class ids as floats (exact below 2^24)
+
+
+def _softmax_ce_sums(z: torch.Tensor, t: torch.Tensor, ignore_index: int, weight):
+    N, C = z.shape[0], z.shape[1]
+    vox = z.numel() // (N * C)
+    nb, row = lib.bpx_softmax_ce_blocks(vox), lib.bpx_softmax_ce_row()
+    part = torch.empty((N * nb, row), dtype=torch.float32, device=z.device)
+    L.check(lib.bpx_softmax_ce_sums(z.data_ptr(), t.data_ptr(), N, C, vox, ignore_index, L.ptr(weight), part.data_ptr(), L.stream_ptr()))
+    sums = torch.empty(row, dtype=torch.float64, device=z.device)
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    L.check(lib.bpx_softmax_ce_finish(part.data_ptr(), N, vox, sums.data_ptr(), loss.data_ptr(), L.stream_ptr()))
+    return sums, loss
+
+
+class _SoftmaxCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight, ignore_index):
+        z, t = _prep_classes(logits, target)
+        s, loss = _softmax_ce_sums(z, t, ignore_index, weight)
+        ctx.save_for_backward(z, t, s, weight if weight is not None else z.new_empty(0))
+        ctx.cfg = (ignore_index, weight is not None, logits.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        z, t, s, w = ctx.saved_tensors
+        ignore_index, has_w, dtype = ctx.cfg
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            g = g.to(torch.float32).contiguous()
+        N, C = z.shape[0], z.shape[1]
+        dz = torch.empty_like(z)
+        L.check(lib.bpx_softmax_ce_bwd(z.data_ptr(), t.data_ptr(), N, C, z.numel() // (N * C), ignore_index, w.data_ptr() if has_w else None,
+                                       s.data_ptr(), g.data_ptr(), dz.data_ptr(), L.stream_ptr()))
+        return dz.to(dtype), None, None, None
+
+
+class CrossEntropyLoss_wrapper(torch.nn.Module):
+    """``biapy.engine.metrics.CrossEntropyLoss_wrapper`` (metrics.py:493-586), same constructor: ``num_classes <= 2`` is ``BCEWithLogitsLoss`` on the
+    one-channel head, ``num_classes > 2`` is ``torch.nn.CrossEntropyLoss(ignore_index, weight)`` on the class channels against the label map
+    ``y_true[:, 0]`` - both as fused device passes.  ``class_rebalance="manual"`` passes ``class_weights``; ``ignore_index=-1`` means torch's
+    default -100 (:535).  A dict prediction is read at ``"pred"``; a LIST of predictions (deep supervision, :566-583) is weighted by 0.5^i / sum
+    with the target rescaled by nearest-neighbour interpolation, as the reference does."""
+
+    def __init__(self, num_classes: int, ndim: int = 2, class_rebalance: str = "none", class_weights=(), ignore_index: int = -1, device=None):
+        super().__init__()
+        self.ndim, self.num_classes, self.class_rebalance = ndim, int(num_classes), class_rebalance
+        self.ignore_index = ignore_index if ignore_index != -1 else -100
+        self.gamma = 0.5
+        self.class_weights = None
+        if class_rebalance == "manual":
+            self.class_weights = torch.tensor(list(class_weights), dtype=torch.float32, device=device)
+        if self.num_classes <= 2 and self.class_weights is not None:
+            raise NotImplementedError("biapy_amd.losses: class weights of the binary (BCEWithLogits) case are not built; use the reference loss")
+
+    def _one(self, pd, y_true):
+        if self.num_classes <= 2:
+            return _SegLossFn.apply(pd, y_true, 1.0, 0.0, 1e-5)
+        w = self.class_weights
+        if w is not None:
+            if w.numel() != pd.shape[1]:
+                raise ValueError(f"{w.numel()} class weights for {pd.shape[1]} class channels")
+            if w.device != pd.device:
+                w = self.class_weights = w.to(pd.device)
+        return _SoftmaxCEFn.apply(pd, y_true[:, 0:1], w, self.ignore_index)
+
+    def forward(self, y_pred, y_true):
+        pds = y_pred["pred"] if isinstance(y_pred, dict) and "pred" in y_pred else y_pred
+        if not isinstance(pds, list):
+            pds, ws = [pds], [1.0]
+        else:
+            ws = [self.gamma ** i for i in range(len(pds))]
+            ws = [x / sum(ws) for x in ws]
+        loss = 0
+        for pd, wj in zip(pds, ws):
+            yt = y_true
+            if pd.shape[-self.ndim:] != y_true.shape[-self.ndim:]:
+                yt = torch.nn.functional.interpolate(y_true.clone().float(), size=pd.shape[-self.ndim:], mode="nearest")     # scale_target, metrics.py:437-455
+            loss = loss + self._one(pd, yt) * wj
+        return loss
+
+
+@torch.no_grad()
+def class_confusion_counts(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """(3, C) float64 device tensor {|P_c & T_c|, |P_c|, |T_c|} of the argmax prediction against the label map, labels equal to ``ignore_index``
+    left out - the confusion counts behind the multi-class ``jaccard_index`` (metrics.py:170-176)."""
+    z, t = _prep_classes(logits, target)
+    s, _ = _softmax_ce_sums(z, t, ignore_index, None)
+    return s[2:].view(3, 8)[:, : z.shape[1]]
+
+
+@torch.no_grad()
+def jaccard_index_multiclass(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Macro-averaged IoU over the classes that occur in the prediction or the labels: mean_c tp_c / (|P_c| + |T_c| - tp_c).  The reference hands this
+    to ``torchmetrics.JaccardIndex(task="multiclass")`` (metrics.py:170-173), which is not installed in this image: the definition is torchmetrics'
+    documented macro average and is PARITY-UNPINNED (the counts themselves are checked against a confusion matrix in the tests)."""
+    c = class_confusion_counts(logits, target, ignore_index)
+    union = c[1] + c[2] - c[0]
+    seen = union > 0
+    return ((c[0] / torch.clamp(union, min=1.0)) * seen).sum().div(torch.clamp(seen.sum(), min=1)).to(torch.float32)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -468,6 +468,20 @@ int bpx_chan_loss_sums(const float* logits_d, const float* target_d, int N, int 
                        bpx_stream_t stream);
 int bpx_chan_loss_bwd(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, unsigned codes, const float* coef_d,
                       float* dlogits_d, bpx_stream_t stream);
+/* Multi-class cross entropy of the semantic-segmentation head and the counts of the multi-class IoU (replaces biapy/engine/metrics.py:493-586
+ * CrossEntropyLoss_wrapper with num_classes > 2 = torch.nn.CrossEntropyLoss(ignore_index, weight), mean reduction, and the confusion counts behind
+ * :138-232 jaccard_index).  logits (N, C, voxels) fp32 planar, 2 <= C <= 8; target (N, 1, voxels) class ids as floats; class_w_d: C floats or NULL;
+ * labels equal to ignore_index (or outside [0, C)) are not counted.
+ *   bpx_softmax_ce_sums  : partials_d[N * bpx_softmax_ce_blocks(voxels)][bpx_softmax_ce_row()] = {sum w nll, sum w, tp[8], pred[8], tgt[8]} per block
+ *   bpx_softmax_ce_finish: sums_d[bpx_softmax_ce_row()] (double, fixed summation order), loss_d = sums[0] / sums[1]
+ *   bpx_softmax_ce_bwd   : dlogits = gup_d[0] * w[y] / sums[1] * (softmax - onehot(y)), 0 for uncounted labels. */
+int bpx_softmax_ce_blocks(int64_t voxels);
+int bpx_softmax_ce_row(void);
+int bpx_softmax_ce_sums(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, int ignore_index, const float* class_w_d,
+                        float* partials_d, bpx_stream_t stream);
+int bpx_softmax_ce_finish(const float* partials_d, int N, int64_t voxels, double* sums_d, float* loss_d, bpx_stream_t stream);
+int bpx_softmax_ce_bwd(const float* logits_d, const float* target_d, int N, int C, int64_t voxels, int ignore_index, const float* class_w_d,
+                       const double* sums_d, const float* gup_d, float* dlogits_d, bpx_stream_t stream);
 /*   bpx_chan_loss_finish  : loss_d = sum_c weights_d[c] * (fixed-order double sum of channel c's partials) / (N * voxels)
  *   bpx_chan_loss_bwd_fused: bpx_chan_loss_bwd with coef[c] = gup_d[0] * weights_d[c] / (N * voxels) formed in the kernel. */
 int bpx_chan_loss_finish(const float* partials_d, int N, int C, int64_t voxels, const float* weights_d, float* loss_d, bpx_stream_t stream);

@@ -6,6 +6,9 @@ and gradients on seeded inputs (``tests/golden/losses_golden.npz``); ``tests/tes
 
 Restates (paths relative to /root/reference):
   * bce .................. biapy/engine/metrics.py:493-586  CrossEntropyLoss_wrapper, num_classes <= 2 -> BCEWithLogitsLoss (mean)
+  * softmax_ce ........... :493-586  CrossEntropyLoss_wrapper, num_classes > 2 -> torch.nn.CrossEntropyLoss(ignore_index, weight) on the label map
+                           y_true[:, 0]: sum_v w[y_v] (logsumexp(z_v) - z_v[y_v]) / sum_v w[y_v] over the voxels with y_v != ignore_index; a LIST of
+                           predictions (:566-583) is weighted 0.5^i / sum with the target rescaled by nearest-neighbour interpolation (:437-455)
   * dice ................. :726-762  DiceLoss: sigmoid, batch_dice sums over batch + space, 1 - mean_c (2I + s) / (U + s)
   * dice_ce .............. :764-973  DiceCELoss binary case: w_ce * BCEWithLogits + w_dice * dice
   * instance_channels .... :1418-1810 instance_segmentation_loss for plain channels without masks / class re-balancing / border
@@ -23,6 +26,39 @@ import torch.nn.functional as F
 
 def bce(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return F.binary_cross_entropy_with_logits(logits, target.float())
+
+
+def softmax_ce(logits: torch.Tensor, target: torch.Tensor, weight=None, ignore_index: int = -100) -> torch.Tensor:
+    """logits (N, C, *space), target (N, 1, *space) class ids; written out (not F.cross_entropy) so that the fixture checks the formula."""
+    C = logits.shape[1]
+    y = target[:, 0].long()
+    keep = y != ignore_index
+    lse = torch.logsumexp(logits, dim=1)
+    zy = torch.gather(logits, 1, torch.where(keep, y, torch.zeros_like(y)).unsqueeze(1))[:, 0]
+    w = torch.ones(C, dtype=logits.dtype) if weight is None else torch.as_tensor(weight, dtype=logits.dtype)
+    wy = torch.where(keep, w[torch.where(keep, y, torch.zeros_like(y))], torch.zeros((), dtype=logits.dtype))
+    return torch.sum(wy * (lse - zy)) / torch.sum(wy)
+
+
+def softmax_ce_deep(preds: Sequence[torch.Tensor], target: torch.Tensor, weight=None, ignore_index: int = -100, gamma: float = 0.5) -> torch.Tensor:
+    ws = [gamma ** i for i in range(len(preds))]
+    loss = 0
+    for pd, wj in zip(preds, ws):
+        yt = target if pd.shape[2:] == target.shape[2:] else F.interpolate(target.clone().float(), size=pd.shape[2:], mode="nearest")
+        loss = loss + softmax_ce(pd, yt, weight, ignore_index) * (wj / sum(ws))
+    return loss
+
+
+def confusion_counts(logits: torch.Tensor, target: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """(3, C): |P_c & T_c|, |P_c|, |T_c| of the argmax prediction against the label map without the ignored voxels (the counts behind the multi-class
+    jaccard_index, metrics.py:170-176; torchmetrics itself is not installed here, so the IoU built on them is parity-unpinned)."""
+    C = logits.shape[1]
+    y = target[:, 0].long().reshape(-1)
+    p = logits.argmax(1).reshape(-1)
+    keep = y != ignore_index
+    y, p = y[keep], p[keep]
+    cm = torch.bincount(y * C + p, minlength=C * C).view(C, C).double()      # rows = label, columns = prediction
+    return torch.stack([cm.diag(), cm.sum(0), cm.sum(1)])
 
 
 def dice(logits: torch.Tensor, target: torch.Tensor, smooth: float = 1e-5, batch_dice: bool = True) -> torch.Tensor:

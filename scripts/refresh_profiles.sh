@@ -67,6 +67,12 @@ if [ -f biapy_amd/libbiapy_amd_zmstamps.so ]; then
 fi
 for zm in 1 0; do BPX_CONV_ZM=$zm python bench.py --mode train --steps 40 --warmup 8 --no-cpu-baseline --no-bf16-record --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_ZM=$zm train ms_per_step %.4f' % d['ms_per_step'])"; done > $O/${R}_step_zmarch_ab.txt 2>&1
 for zm in 1 0; do BPX_CONV_ZM=$zm python bench.py --mode infer --steps 40 --warmup 8 --no-cpu-baseline --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_ZM=$zm infer ms_per_step %.4f' % d['ms_per_step'])"; done >> $O/${R}_step_zmarch_ab.txt 2>&1
+# round 6: two K groups in the small-tile kernel of the <= 16^3 layers (conv3_kernel<..., KG = 2>): kernel times and the whole step, alternating
+( echo "# two K groups in the small-tile conv kernel (conv3_kernel<..., KG = 2>), kernel times by HIP events (tests/bench_kernels.py conv_fwd), same box, alternating"
+  for kg in 1 0 1 0; do echo "== BPX_CONV_KG=$kg"; BPX_CONV_KG=$kg python tests/bench_kernels.py conv_fwd 2>&1 | grep -E "^conv_fwd +(16|8)\^3"; done
+  echo "# whole step, 40 graph-replayed steps, same box, alternating (bench.py --mode train / infer)"
+  for kg in 1 0 1 0; do BPX_CONV_KG=$kg python bench.py --mode train --feed device --steps 40 --warmup 8 --no-cpu-baseline --no-bf16-record --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_KG=$kg train ms_per_step %.4f (device-resident batch)' % d['ms_per_step'])"; done
+  for kg in 1 0 1 0; do BPX_CONV_KG=$kg python bench.py --mode infer --steps 40 --warmup 8 --no-cpu-baseline --no-launch-events 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('BPX_CONV_KG=$kg infer ms_per_step %.4f' % d['ms_per_step'])"; done ) 2>&1 | grep -v amdgpu.ids > $O/${R}_step_conv_kg_ab.txt
 ( python tests/bench_kernels.py k1 --reps 20; python tests/bench_kernels.py pws --reps 20 ) 2>&1 | grep -v amdgpu.ids > $O/${R}_stream_vs_tile.txt
 # round 5: transposed-conv forward of level 0 (convt_k1_kernel against pw_kernel) and the first layer (buffer- against pointer-addressed), event timing
 # in the network; the store-pattern probe

