@@ -118,10 +118,10 @@ def hard_dice(logits: torch.Tensor, target: torch.Tensor, smooth: float = 1e-5) 
 # multi-class semantic segmentation (MODEL.N_CLASSES > 2): softmax cross entropy + per-class confusion counts
 # ---------------------------------------------------------------------------------------------------------------------------
 def _prep_classes(logits: torch.Tensor, target: torch.Tensor):
-    if not logits.is_cuda:
-        raise RuntimeError("biapy_amd.losses run on the MI355X only (logits are on %s); there is no CPU path" % logits.device)
     if logits.dim() < 3 or not 2 <= logits.shape[1] <= 8:
         raise NotImplementedError("biapy_amd.losses: the multi-class cross entropy takes 2..8 class channels; use the reference loss beyond that")
+    if not logits.is_cuda:
+        raise RuntimeError("biapy_amd.losses run on the MI355X only (logits are on %s); there is no CPU path" % logits.device)
     if target.dim() == logits.dim() - 1:
         target = target.unsqueeze(1)
     if target.shape[0] != logits.shape[0] or target.shape[1] != 1 or target.shape[2:] != logits.shape[2:]:

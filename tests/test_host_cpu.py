@@ -87,6 +87,10 @@ def test_losses_fail_loudly_without_gpu():
         losses.DiceCELoss()(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
     with pytest.raises(RuntimeError, match="MI355X only"):      # per-sample Dice (round 6) runs on the same fused passes: no CPU fallback either
         losses.DiceLoss(batch_dice=False)(torch.zeros(2, 1, 4, 4, 4), torch.zeros(2, 1, 4, 4, 4))
+    with pytest.raises(RuntimeError, match="MI355X only"):      # multi-class cross entropy (round 6): the reference's constructor, device passes only
+        losses.CrossEntropyLoss_wrapper(num_classes=3, ndim=3, class_rebalance="manual", class_weights=[0.2, 0.5, 0.3])(torch.zeros(1, 3, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
+    with pytest.raises(NotImplementedError):                      # beyond eight class channels: refused, not computed wrongly
+        losses.CrossEntropyLoss_wrapper(num_classes=9, ndim=3)(torch.zeros(1, 9, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
 
 
 def test_instance_channels_loss_refuses_what_it_does_not_reproduce():
