@@ -1511,8 +1511,11 @@ template <typename T>
 __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restrict__ out, int mode, int Cin, int Cout, int64_t i) {
   constexpr int KPL = ElemTraits<T>::KPL, GPT = 16 / KPL;
   {
-    int e = (int)(i % KPL);
-    int64_t r = i / KPL;
+    // 32-bit index arithmetic (the launchers bound an operand below 2^31 elements): the divisions by run-time channel counts below are ~25
+    // instructions each on 32 bits and ~120 on 64 - with 64-bit indices the transposed-conv and 1x1x1 operands alone cost the batched launch 20 us
+    const unsigned iu = (unsigned)i;
+    int e = (int)(iu % KPL);
+    unsigned r = iu / KPL;
     float v = 0.f;
     if (mode == PK_K3 || mode == PK_K3_T) {
       constexpr int QTOT = 27 * GPT, QPAD = ((QTOT + 3) / 4) * 4;
@@ -2878,6 +2881,7 @@ extern "C" int bpx_pack_weight(int mode, const float* w_d, int Cin, int Cout, in
   if (mode <= PK_K1) BPX_CHECK(Cin % 16 == 0 && Cout % 16 == 0, "%s: Cin/Cout must be multiples of 16", fn);
   if (mode == PK_K3_T) BPX_CHECK(Cout % 16 == 0, "%s: Cout must be a multiple of 16", fn);
   int64_t total = packed_elems(mode, Cin, Cout, dtype);
+  BPX_CHECK(total < (1ll << 31), "%s: an operand of %lld elements is beyond the 32-bit index range of the pack kernels", fn, (long long)total);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == BPX_BF16) pack_kernel<uint16_t><<<grid_for(total), 256, 0, s>>>(w_d, (uint16_t*)packed_d, mode, Cin, Cout, total);
   else if (dtype == BPX_F16) pack_kernel<f16_t><<<grid_for(total), 256, 0, s>>>(w_d, (f16_t*)packed_d, mode, Cin, Cout, total);
@@ -2905,6 +2909,7 @@ extern "C" int bpx_pack_weights_batched(int dtype, int count, const bpx_pack_job
       if (j.mode == PK_K3_T) BPX_CHECK(j.Cout % 16 == 0, "%s: job %d: Cout must be a multiple of 16", fn, base + k);
       b.job[k] = j;
       b.total[k] = packed_elems(j.mode, j.Cin, j.Cout, dtype);
+      BPX_CHECK(b.total[k] < (1ll << 31), "%s: job %d: an operand of %lld elements is beyond the 32-bit index range of the pack kernels", fn, base + k, (long long)b.total[k]);
       b.first_block[k] = blocks;
       blocks += pack_by_columns(j.mode, j.Cin, j.Cout) ? pack_column_blocks(j.mode, j.Cin, j.Cout) : (int)std::max<int64_t>(1, cdiv64(b.total[k], 256 * PACK_EPT));
     }
