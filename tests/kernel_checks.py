@@ -1781,6 +1781,22 @@ def check_multiclass_ce():
     union = co[1] + co[2] - co[0]
     iou_ref = (co[0][union > 0] / union[union > 0]).mean().item()
     res.append(_res("multiclass_ce[8 classes].macro_iou", abs(jaccard_index_multiclass(zd.detach(), yb.to(DEV)).item() - iou_ref), 1e-6))
+    # the metric OBJECT of the reference's call sites: jaccard_index(num_classes=...)(y_pred, y_true), dict / list predictions
+    from biapy_amd.losses import jaccard_index
+    met = jaccard_index(num_classes=8, device=DEV, ndim=3)
+    res.append(_res("jaccard_index[object, 8 classes, dict]", abs(met({"pred": zd.detach()}, yb.to(DEV)).item() - iou_ref), 1e-6))
+    zb1 = torch.randn(2, 1, 9, 20, 24, generator=g)
+    tb1 = (torch.rand(2, 1, 9, 20, 24, generator=g) > 0.5).float()
+    P, T = torch.sigmoid(zb1) > 0.5, tb1 > 0.5
+    ref1 = ((P & T).sum().double() / (P | T).sum().double()).item()
+    met2 = jaccard_index(num_classes=2, device=DEV, ndim=3)
+    res.append(_res("jaccard_index[object, binary]", abs(met2(zb1.to(DEV), tb1.to(DEV)).item() - ref1), 1e-6))
+    res.append(_res("jaccard_index[functional form kept]", abs(jaccard_index(zb1.to(DEV), tb1.to(DEV)).item() - ref1), 1e-6))
+    half = torch.nn.functional.interpolate(tb1, size=(5, 10, 12), mode="nearest")
+    zh = torch.randn(2, 1, 5, 10, 12, generator=g)
+    Ph, Th = torch.sigmoid(zh) > 0.5, half > 0.5
+    ref2 = 0.5 * (ref1 + ((Ph & Th).sum().double() / (Ph | Th).sum().double()).item())
+    res.append(_res("jaccard_index[object, list of two predictions]", abs(met2([zb1.to(DEV), zh.to(DEV)], tb1.to(DEV)).item() - ref2), 1e-6))
     return res
 
 

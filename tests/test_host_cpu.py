@@ -89,6 +89,13 @@ def test_losses_fail_loudly_without_gpu():
         losses.DiceLoss(batch_dice=False)(torch.zeros(2, 1, 4, 4, 4), torch.zeros(2, 1, 4, 4, 4))
     with pytest.raises(RuntimeError, match="MI355X only"):      # multi-class cross entropy (round 6): the reference's constructor, device passes only
         losses.CrossEntropyLoss_wrapper(num_classes=3, ndim=3, class_rebalance="manual", class_weights=[0.2, 0.5, 0.3])(torch.zeros(1, 3, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
+    # the IoU metric object of the reference (metrics.py:138-232): same constructor; what the kernels do not reproduce is refused at construction
+    m = losses.jaccard_index(num_classes=2, device="cpu", ndim=3)
+    assert m.num_classes == 2 and m.ignore_index is None and losses.jaccard_index(num_classes=4, device="cpu", ndim=3, ignore_index=255).ignore_index == 255
+    with pytest.raises(NotImplementedError):
+        losses.jaccard_index(num_classes=2, device="cpu", t=0.3)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 1, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
     with pytest.raises(NotImplementedError):                      # beyond eight class channels: refused, not computed wrongly
         losses.CrossEntropyLoss_wrapper(num_classes=9, ndim=3)(torch.zeros(1, 9, 4, 4, 4), torch.zeros(1, 1, 4, 4, 4))
 
