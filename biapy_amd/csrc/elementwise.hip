@@ -35,10 +35,17 @@ __global__ void __launch_bounds__(1024) stats_compact_kernel(float* __restrict__
   red[0][tl][c] = s1;
   red[1][tl][c] = s2;
   __syncthreads();   // every read of the segment is done
+  // two levels, as lane_reduce below: eight lanes sum eight rows each, then 32 threads sum the eight (a chain of 16 dependent LDS reads instead of 64)
+  double a = 0.0, b = 0.0;
+  if (tl < 8)
+    for (int t = tl; t < 64; t += 8) { a += red[0][t][c]; b += red[1][t][c]; }
+  __syncthreads();
+  if (tl < 8) { red[0][tl][c] = a; red[1][tl][c] = b; }
+  __syncthreads();
   if (threadIdx.x < 32) {
     const int k = threadIdx.x >> 4, cc = threadIdx.x & 15;
     double s = 0.0;
-    for (int t = 0; t < 64; ++t) s += red[k][t][cc];
+    for (int t = 0; t < 8; ++t) s += red[k][t][cc];
     if (c0 + cc < C && t0 < tiles) part[((size_t)n * tiles + t0) * 2 * C + (size_t)k * C + c0 + cc] = (float)s;
   }
 }
@@ -58,6 +65,23 @@ __device__ __forceinline__ void tile_sums(const float* __restrict__ pp, int C, i
   // `lanes` tile lanes x 4 independent loads in flight per thread: the partial arrays have up to 16K tiles
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
   int t = tl;
+  // (round 6) eight rows per lane requested at once where there are that many - the 64^3 levels have 1024 rows, 16 per lane: four dependent L2 round
+  // trips with four rows in flight, two with eight.  The additions are those of two rounds of the four-row loop below, in the same order: same bits.
+  for (; t + 7 * lanes < nt; t += 8 * lanes) {
+    float c0, c1, c2, c3, d0, d1, d2, d3;
+    a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
+    a1 = pp[(size_t)(t + lanes) * ts]; b1 = pp[(size_t)(t + lanes) * ts + C];
+    a2 = pp[(size_t)(t + 2 * lanes) * ts]; b2 = pp[(size_t)(t + 2 * lanes) * ts + C];
+    a3 = pp[(size_t)(t + 3 * lanes) * ts]; b3 = pp[(size_t)(t + 3 * lanes) * ts + C];
+    c0 = pp[(size_t)(t + 4 * lanes) * ts]; d0 = pp[(size_t)(t + 4 * lanes) * ts + C];
+    c1 = pp[(size_t)(t + 5 * lanes) * ts]; d1 = pp[(size_t)(t + 5 * lanes) * ts + C];
+    c2 = pp[(size_t)(t + 6 * lanes) * ts]; d2 = pp[(size_t)(t + 6 * lanes) * ts + C];
+    c3 = pp[(size_t)(t + 7 * lanes) * ts]; d3 = pp[(size_t)(t + 7 * lanes) * ts + C];
+    s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    s1 += ((double)c0 + (double)c1) + ((double)c2 + (double)c3);
+    s2 += ((double)d0 + (double)d1) + ((double)d2 + (double)d3);
+  }
   for (; t + 3 * lanes < nt; t += 4 * lanes) {
     a0 = pp[(size_t)t * ts]; b0 = pp[(size_t)t * ts + C];
     a1 = pp[(size_t)(t + lanes) * ts]; b1 = pp[(size_t)(t + lanes) * ts + C];
@@ -73,15 +97,30 @@ __device__ __forceinline__ void tile_sums(const float* __restrict__ pp, int C, i
 }
 
 // block-wide reduction over the tile lanes: red[k][0 .. cb) holds the channel totals afterwards (all barriers are uniform)
+// Two levels (round 6): eight groups of tile lanes first (lane tl sums tl, tl + 8, ...), then the eight group sums.  One level - 2 cb threads walking
+// all 64 lanes - was a chain of 64 dependent LDS reads, ~2.7 of the ~5 us these kernels take, and a training step launches 38 of them (a forward 21).
+// Fixed order, fp64: the totals differ from the one-level sum in the last bit of a double at most.
 __device__ __forceinline__ void lane_reduce(double (*red)[1024], int cb, int lanes, double s1, double s2) {
   red[0][threadIdx.x] = s1;
   red[1][threadIdx.x] = s2;
   __syncthreads();
+  int rows = lanes;
+  if (lanes >= 16) {                                      // (lanes = 1024 / cb: a power of two)
+    constexpr int G = 8;
+    const int tl = threadIdx.x / cb, c = threadIdx.x % cb;
+    double a = 0.0, b = 0.0;
+    if (tl < G)
+      for (int t = tl; t < lanes; t += G) { a += red[0][t * cb + c]; b += red[1][t * cb + c]; }
+    __syncthreads();                                      // every lane is read before rows 0 .. G - 1 are overwritten
+    if (tl < G) { red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; }
+    __syncthreads();
+    rows = G;
+  }
   const bool mine = (int)threadIdx.x < 2 * cb;
   const int k = mine ? threadIdx.x / cb : 0, cc = mine ? threadIdx.x % cb : 0;
   double s = 0.0;
   if (mine)
-    for (int t = 0; t < lanes; ++t) s += red[k][t * cb + cc];
+    for (int t = 0; t < rows; ++t) s += red[k][t * cb + cc];
   __syncthreads();                                        // every total is read before any is overwritten
   if (mine) red[k][cc] = s;
   __syncthreads();
@@ -1586,23 +1625,42 @@ __device__ __forceinline__ void pack_column_block(const float* __restrict__ w, T
   const bool fwd = mode == PK_K3;
   const int run = fwd ? 16 * 27 : PACK_COLS * 27;                                  // contiguous floats per source run
   const size_t base = fwd ? ((size_t)c0 * Cin + chunk * 16) * 27 : ((size_t)chunk * 16 * Cin + c0) * 27, rstride = (size_t)Cin * 27;
-  for (int l = threadIdx.x; l < PACK_STAGE; l += blockDim.x) {
-    const int r = l / run, off = l - r * run;
-    stage[l] = w[base + (size_t)r * rstride + off];
+  // (every run starts at a multiple of 216 floats and Cin is a multiple of 4 wherever this path is taken: 16-byte loads when the tensor itself is aligned)
+  const bool al = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && (Cin & 3) == 0;
+  if (al) {
+    for (int l = threadIdx.x * 4; l < PACK_STAGE; l += blockDim.x * 4) {
+      const int r = l / run, off = l - r * run;
+      *reinterpret_cast<f32x4_t*>(stage + l) = *reinterpret_cast<const f32x4_t*>(w + base + (size_t)r * rstride + off);
+    }
+  } else {
+    for (int l = threadIdx.x; l < PACK_STAGE; l += blockDim.x) {
+      const int r = l / run, off = l - r * run;
+      stage[l] = w[base + (size_t)r * rstride + off];
+    }
   }
   __syncthreads();
   T* const o = out + ((size_t)chunk * QPAD * ncol + c0) * KPL;
-  for (int l = threadIdx.x; l < QPAD * PACK_COLS * KPL; l += blockDim.x) {
-    const int q = l / (PACK_COLS * KPL), ce = l % (PACK_COLS * KPL);          // ce = column-in-block * KPL + e: contiguous in the packed operand
-    const int col_l = ce / KPL, e = ce % KPL;
-    // the element function of pack_k3_value on the staged copy: w[co][ci][tap] sits at stage[(col_l * 16 + kc_l) * 27 + tap] (PK_K3),
-    // w[co = kc][ci = col][tap] at stage[(kc_l * PACK_COLS + col_l) * 27 + tap] (PK_K3_T, read at the mirrored tap)
+  // the element function of pack_k3_value on the staged copy: w[co][ci][tap] sits at stage[(col_l * 16 + kc_l) * 27 + tap] (PK_K3),
+  // w[co = kc][ci = col][tap] at stage[(kc_l * PACK_COLS + col_l) * 27 + tap] (PK_K3_T, read at the mirrored tap)
+  auto value = [&](int q, int col_l, int e) -> float {
     int tap = (q < QTOT) ? q / GPT : -1;
     if (GPT == 2 && q < 56) tap = bpx_tap_order_bf16(q / GPT);
     const int kc_l = (q % GPT) * KPL + e;
-    float v = 0.f;
-    if (tap >= 0) v = fwd ? stage[(col_l * 16 + kc_l) * 27 + tap] : stage[(kc_l * PACK_COLS + col_l) * 27 + (26 - tap)];
-    ElemTraits<T>::st(o + (size_t)q * ncol * KPL + ce, v);
+    return tap < 0 ? 0.f : fwd ? stage[(col_l * 16 + kc_l) * 27 + tap] : stage[(kc_l * PACK_COLS + col_l) * 27 + (26 - tap)];
+  };
+  if (al) {   // one 16-byte piece (k-group q, column) per thread and round: KPL element conversions of ElemTraits<T>::st, one store
+    for (int pz = threadIdx.x; pz < QPAD * PACK_COLS; pz += blockDim.x) {
+      const int q = pz / PACK_COLS, col_l = pz % PACK_COLS;
+      alignas(16) T tmp[KPL];
+#pragma unroll
+      for (int e = 0; e < KPL; ++e) ElemTraits<T>::st(&tmp[e], value(q, col_l, e));
+      *reinterpret_cast<u32x4_t*>(o + ((size_t)q * ncol + col_l) * KPL) = *reinterpret_cast<const u32x4_t*>(tmp);
+    }
+  } else {
+    for (int l = threadIdx.x; l < QPAD * PACK_COLS * KPL; l += blockDim.x) {
+      const int q = l / (PACK_COLS * KPL), ce = l % (PACK_COLS * KPL);          // ce = column-in-block * KPL + e: contiguous in the packed operand
+      ElemTraits<T>::st(o + (size_t)q * ncol * KPL + ce, value(q, ce / KPL, ce % KPL));
+    }
   }
 }
 
@@ -1974,9 +2032,18 @@ __global__ void __launch_bounds__(256) seg_loss_finish_kernel(const float* __res
 #pragma unroll
   for (int k = 0; k < 6; ++k) red[threadIdx.x][k] = s[k];
   __syncthreads();
+  // two levels (16 groups of 16 rows, then the 16 group sums): 32 dependent LDS reads instead of 256
+  __shared__ double red2[16][6];
+  if (threadIdx.x < 96) {
+    const int gq = threadIdx.x / 6, k = threadIdx.x % 6;
+    double a = 0.;
+    for (int q = gq; q < 256; q += 16) a += red[q][k];
+    red2[gq][k] = a;
+  }
+  __syncthreads();
   if (threadIdx.x < 6) {
     double a = 0.;
-    for (int q = 0; q < 256; ++q) a += red[q][threadIdx.x];
+    for (int q = 0; q < 16; ++q) a += red2[q][threadIdx.x];
     red[0][threadIdx.x] = a;
     sums[threadIdx.x] = a;
   }
