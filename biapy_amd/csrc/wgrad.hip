@@ -807,7 +807,9 @@ __global__ void __launch_bounds__(256, MC == 1 ? 4 : MC == 2 ? 3 : 2) wgrad_sdm_
 // re-reads x eight times with a stride-2 gather of dy; here a workgroup stages a 2x4x16 tile of x and the matching
 // CONTIGUOUS 4x8x32 block of dy (de-interleaved into 8 per-sub planes while writing LDS), wave w owns subs 2w and 2w+1,
 // and the x fragment of a K-chunk is shared by all subs.  Partials [group][sub][Cin][Cout] -> wgrad_reduce_kernel.
-template <int NS, int SZ>   // SZ = z extent of the kernel = z stride (1 or 2): 4*SZ sub-positions, sub = (a*2 + b)*2 + c
+// MC (round 6): x chunks per workgroup.  With one chunk a 32 -> 32 layer stages the 64 KB dy block of a tile TWICE (once per x chunk) for 16 MFMAs per
+// wave each time - the staging, not HBM, is what the level-0 launch of cfg 2 takes (150 us for 600 MB); MC = 2 stages it once for 32.
+template <int NS, int SZ, int MC = 1>   // SZ = z extent of the kernel = z stride (1 or 2): 4*SZ sub-positions, sub = (a*2 + b)*2 + c
 __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const WgradParams p) {
   using T = uint16_t;
   constexpr int TZ = 2, TY = 4, TX = 16, TV = TZ * TY * TX;       // x tile
@@ -817,14 +819,14 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   constexpr int NKC = TV / 32;
   constexpr int NPG = GV * PPVG / 256, BATCH = NPG < 8 ? NPG : 8;
   static_assert(NPG % BATCH == 0 && 256 % PPVG == 0, "staging plan");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[TV * VBA + GV * VBG];
-  unsigned char* sA = smem;
-  unsigned char* sG = smem + TV * VBA;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MC * TV * VBA + GV * VBG];
+  unsigned char* sA = smem;                                       // MC tiles of x, one after the other
+  unsigned char* sG = smem + MC * TV * VBA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int D = p.D, H = p.H, W = p.W;
-  const int nchunks_ = p.Cin / 16, groups8 = (p.groups + 7) & ~7;
+  const int nchunks_ = p.Cin / (16 * MC), groups8 = (p.groups + 7) & ~7;   // (chunk GROUPS of MC chunks)
   const int per_cb = groups8 * nchunks_;
   const int cbi = (int)blockIdx.x / per_cb, rem = (int)blockIdx.x % per_cb;
   const int chunk = (rem % (8 * nchunks_)) / 8;
@@ -832,11 +834,13 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   const int co_base = cbi * CB;
   if (grp >= p.groups) return;
 
-  f32x4_t acc[SPW][NS];
+  f32x4_t acc[MC][SPW][NS];
 #pragma unroll
-  for (int a = 0; a < SPW; ++a)
+  for (int c = 0; c < MC; ++c)
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) acc[a][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < SPW; ++a)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[c][a][ns] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float bsum[KPL];
 #pragma unroll
   for (int e = 0; e < KPL; ++e) bsum[e] = 0.f;
@@ -846,7 +850,7 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
   const char* __restrict__ gin = reinterpret_cast<const char*>(p.dy);
   // this thread's x piece: voxel t = tid>>1 of the tile, 8 channels
   const int ta = tid >> 1, taz = ta >> 6, tay = (ta >> 4) & 3, tax = ta & 15;
-  const uint32_t rel_a = (uint32_t)(((taz * H + tay) * W + tax) * p.x_ld + chunk * p.x_cs + (tid & 1) * KPL) * 2u;
+  const uint32_t rel_a = (uint32_t)(((taz * H + tay) * W + tax) * p.x_ld + chunk * MC * p.x_cs + (tid & 1) * KPL) * 2u;   // chunk c of the group: + c * x_cs elements
   const int subG = tid % PPVG, qlane = tid / PPVG;                 // dy piece u: block voxel q = u*(256/PPVG) + qlane
   const int trl = (i >> 2), trc = (i & 3) * 8;
   const int a_base = (g * 8 + trl) * VBA + trc;
@@ -859,14 +863,19 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
     const uint32_t base_a = (uint32_t)(((n * D + z0) * H + y0) * W + x0) * (uint32_t)p.x_ld * 2u;
     const uint32_t base_g = (uint32_t)(((n * SZ * D + SZ * z0) * 2 * H + 2 * y0) * 2 * W + 2 * x0) * (uint32_t)p.dy_ld * 2u;
 
-    u32x4_t pa = u32x4_t{0u, 0u, 0u, 0u};
-    if (full || (z0 + taz < D && y0 + tay < H && x0 + tax < W)) pa = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a));
-    if (p.x_f16) {   // BPX_MIX16 (uniform): x is the forward pass's fp16 tensor, the MFMA operands are bf16
+    u32x4_t pa[MC];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pa[q] = cvt_pk_bf16(lo16<f16_t>(pa[q]), hi16<f16_t>(pa[q]));
+    for (int c = 0; c < MC; ++c) {
+      pa[c] = u32x4_t{0u, 0u, 0u, 0u};
+      if (full || (z0 + taz < D && y0 + tay < H && x0 + tax < W)) pa[c] = *reinterpret_cast<const u32x4_t*>(xin + (base_a + rel_a + (uint32_t)(c * p.x_cs) * 2u));
+      if (p.x_f16) {   // BPX_MIX16 (uniform): x is the forward pass's fp16 tensor, the MFMA operands are bf16
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pa[c][q] = cvt_pk_bf16(lo16<f16_t>(pa[c][q]), hi16<f16_t>(pa[c][q]));
+      }
     }
     __syncthreads();  // previous tile's MFMA phase is done with LDS
-    *reinterpret_cast<u32x4_t*>(sA + (size_t)tid * 16) = pa;
+#pragma unroll
+    for (int c = 0; c < MC; ++c) *reinterpret_cast<u32x4_t*>(sA + (size_t)c * TV * VBA + (size_t)tid * 16) = pa[c];
 #pragma unroll
     for (int b0 = 0; b0 < NPG; b0 += BATCH) {
       u32x4_t pg[BATCH];
@@ -894,13 +903,14 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
 
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-      u32x4_t af, gf[SPW][NS];
-      {
-        const unsigned char* q = sA + a_base + kc * 32 * VBA;
+      u32x4_t af[MC], gf[SPW][NS];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const unsigned char* q = sA + c * TV * VBA + a_base + kc * 32 * VBA;
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(q + 4 * VBA));
         u32x2_t l2 = __builtin_bit_cast(u32x2_t, lo), h2 = __builtin_bit_cast(u32x2_t, hi);
-        af = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+        af[c] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
       }
 #pragma unroll
       for (int a = 0; a < SPW; ++a)
@@ -914,23 +924,27 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a = 0; a < SPW; ++a)
+      for (int c = 0; c < MC; ++c)
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns)
-          acc[a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[a][ns], 0, 0, 0);
+        for (int a = 0; a < SPW; ++a)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+            acc[c][a][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[c]), __builtin_bit_cast(bf16x8_t, gf[a][ns]), acc[c][a][ns], 0, 0, 0);
     }
   }
 
   float* pp = p.part + (size_t)grp * NSUB * p.Cin * p.Cout;
 #pragma unroll
-  for (int a = 0; a < SPW; ++a)
+  for (int c = 0; c < MC; ++c)
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns)
+    for (int a = 0; a < SPW; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = chunk * 16 + 4 * g + r, co = co_base + ns * 16 + i;
-        pp[((size_t)(SPW * wave + a) * p.Cin + ci) * p.Cout + co] = acc[a][ns][r];
-      }
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = (chunk * MC + c) * 16 + 4 * g + r, co = co_base + ns * 16 + i;
+          pp[((size_t)(SPW * wave + a) * p.Cin + ci) * p.Cout + co] = acc[c][a][ns][r];
+        }
   if (want_bias) {  // every thread summed the 8 channels of its pieces: combine the 256/PPVG threads of a channel group
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [256][8]
@@ -948,13 +962,19 @@ __global__ void __launch_bounds__(256, NS == 1 ? 4 : 2) wgrad_ct_kernel(const Wg
 
 int g_ct_resident = 1;   // test hook bit 6 clears it: the former 2048-workgroup target
 struct CtCfg { int ns, groups, totalTiles, tilesY, tilesX, tilesPerSample; };
+// x chunks per workgroup of the tile kernel: two for the big even-chunk layers (cfg 2: 32 -> 32 @64^3 -> 128^3), where the dy staging binds; the small
+// levels keep one (they need every workgroup they can get).  BPX_CT_MC=1: the one-chunk kernel everywhere (A/B).
+inline int ct_mc(int N, int D, int H, int W, int sz, int Cin, int Cout) {
+  static const int env = getenv("BPX_CT_MC") ? atoi(getenv("BPX_CT_MC")) : 2;
+  return (env >= 2 && sz == 2 && (Cin / 16) % 2 == 0 && Cout % 32 == 0 && (int64_t)N * D * H * W >= 262144) ? 2 : 1;
+}
 inline CtCfg pick_ct(int N, int D, int H, int W, int sz, int Cin, int Cout) {
   CtCfg c;
   c.ns = (Cout % 32 == 0) ? 2 : 1;
   c.tilesY = cdiv(H, 4); c.tilesX = cdiv(W, 16);
   c.tilesPerSample = cdiv(D, 2) * c.tilesY * c.tilesX;
   c.totalTiles = N * c.tilesPerSample;
-  const int nchunks = Cin / 16, nb = Cout / (16 * c.ns);
+  const int nchunks = Cin / (16 * ct_mc(N, D, H, W, sz, Cin, Cout)), nb = Cout / (16 * c.ns);   // workgroups per group
   const int64_t cap = std::max<int64_t>(1, (int64_t)6400000 / ((int64_t)4 * sz * Cin * Cout));
   // one resident wave of workgroups (256 CUs x occupancy of wgrad_ct_kernel), each looping over its share of the tiles:
   // measured best for the shift-dy kernels, same structure here
@@ -1641,10 +1661,12 @@ extern "C" int bpx_convT3d_k2s2_wgrad(int dtype, int N, int D, int H, int W, int
     p.part = reinterpret_cast<float*>(ws_d); p.db = db_d;
     p.dbpart = p.part + (size_t)c.groups * nsub * x.C * dy.C;
     p.tilesY = c.tilesY; p.tilesX = c.tilesX; p.tilesPerSample = c.tilesPerSample; p.totalTiles = c.totalTiles; p.groups = c.groups;
-    const int nchunks = x.C / 16, nb = dy.C / (16 * c.ns);
+    const int mc = ct_mc(N, D, H, W, sz, x.C, dy.C);
+    const int nchunks = x.C / (16 * mc), nb = dy.C / (16 * c.ns);
     dim3 grid((unsigned)(((c.groups + 7) & ~7) * nchunks * nb));
     hipStream_t s = (hipStream_t)stream;
-    if (sz == 2) { if (c.ns == 2) wgrad_ct_kernel<2, 2><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 2><<<grid, 256, 0, s>>>(p); }
+    if (mc == 2) wgrad_ct_kernel<2, 2, 2><<<grid, 256, 0, s>>>(p);      // (ct_mc: sz == 2 and 32-channel output blocks only)
+    else if (sz == 2) { if (c.ns == 2) wgrad_ct_kernel<2, 2><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 2><<<grid, 256, 0, s>>>(p); }
     else { if (c.ns == 2) wgrad_ct_kernel<2, 1><<<grid, 256, 0, s>>>(p); else wgrad_ct_kernel<1, 1><<<grid, 256, 0, s>>>(p); }
     BPX_LAUNCH_CHECK(fn);
     // (Cin, Cout, sz, 2, 2): index = ci*Cout*nsub + co*nsub + sub

@@ -386,10 +386,13 @@ def test_graphed_train_step_draws_a_new_dropout_mask_at_every_replay(K):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("mix,B,S,Cc", [(True, 2, (32, 32, 32), 32), (False, 1, (40, 36, 64), 32), (True, 3, (24, 28, 32), 64), (False, 1, (64, 32, 32), 64)],
-                         ids=["mix-32", "bf16-32-ragged", "mix-64-3samples", "bf16-64"])
+@pytest.mark.parametrize("mix,B,S,Cc", [(True, 2, (32, 32, 32), 32), (False, 1, (40, 36, 64), 32), (True, 3, (24, 28, 32), 64), (False, 1, (64, 32, 32), 64),
+                                        (True, 1, (64, 64, 64), 32), (False, 2, (46, 52, 64), 32)],
+                         ids=["mix-32", "bf16-32-ragged", "mix-64-3samples", "bf16-64", "mix-32-two-x-chunks", "bf16-32-two-x-chunks-ragged"])
 def test_streaming_transposed_conv_weight_gradient(K, mix, B, S, Cc):
-    """wgrad_ct_dma_kernel: the k = s = 2 transposed conv's weight / bias gradient at the large levels through the LDS-DMA ring (x and dy read once)."""
+    """wgrad_ct_dma_kernel: the k = s = 2 transposed conv's weight / bias gradient at the large levels through the LDS-DMA ring (x and dy read once).
+    The last two cases (>= 262144 input voxels, 32 channels) are the shape class where the TILE kernel - the partner in this comparison and the production
+    kernel of cfg 2's level-0 up-sampling - takes two x chunks per workgroup (round 6, `wgrad_ct_kernel<2, 2, 2>`): against fp64 and the streaming kernel."""
     _assert_all(K.check_convT_wgrad_stream(mix, B, S, Cc))
 
 
