@@ -105,6 +105,8 @@ _SIGS = {
     "bpx_debug_set_c1_persist": ([_i], _i),
     "bpx_convT3d_k2s2_wgrad_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
     "bpx_conv1x1_fwd": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp], _i),
+    "bpx_conv1x1_fwd_split_wgrad_workspace": ([_i, _i, _i64, _i], _i64),
+    "bpx_conv1x1_fwd_split_wgrad": ([_i, _i, _i64, Tensor, _vp, Tensor, Tensor, _vp, Tensor, Tensor, _vp, _vp, _i64, _vp], _i),
     "bpx_conv1x1_fwd_split": ([_i, _i, _i64, Tensor, _vp, _vp, Tensor, Tensor, _vp, Tensor, Tensor, Tensor, _vp], _i),
     "bpx_convT3d_k2s2_fwd": ([_i, _i, _i, _i, _i, _i, Tensor, _vp, _vp, Tensor, _vp, _vp], _i),
     "bpx_convT3d_stats_tiles": ([_i, _i, _i, _i], _i),

@@ -453,10 +453,16 @@ struct PwsParams {
   const void* wp; const bpx_nbwd_coef* coef;
   void* y; int y_ld; void* y2; int y2_ld; int ysplit;            // columns [0, ysplit) -> y, the rest -> y2
   int64_t vps; int N; int nblocks; int groups; int bps;          // bps = blocks per sample
+  float* part;                                                   // WG instances: this launch's partial slabs [groups][3 K][K] of dWsc
 };
 __host__ __device__ constexpr int pws_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
-template <int KC, int TV, typename TT>
+// WG (round 6): the block's SHORTCUT WEIGHT GRADIENT dWsc[ci][co] = sum_v t[v][ci] dOut[v][co] rides along.  Both operands of that k = 1 weight gradient
+// are in this kernel's LDS stages already (t = the raw block input, dOut); as a kernel of its own (wgrad_k1_dma_kernel) it read them from HBM a second
+// time - 4 tensor units, 209 us at level 0 of cfg 2, 60 us at level 1.  Here wave w multiplies the 32-voxel K chunks it owns (KC = 1: chunk w of the four;
+// KC = 2: chunk w & 1 of the two, t chunks 3 (w >> 1) ..) with transposing LDS reads exactly as that kernel does (t converted fp16 -> bf16 behind the
+// read in the mixed mode), the waves' sums meet once after the last block, one slab per workgroup, reduced with the step's other weight gradients.
+template <int KC, int TV, typename TT, bool WG = false>
 __global__ void __launch_bounds__(256) pw_nbs_kernel(const PwsParams p) {
   constexpr int VB = 32, SUBS = TV / 32, NCH = 7 * KC, NS = 3 * KC, NCOL = 48 * KC, K = 16 * KC;
   constexpr int STAGE = NCH * TV * VB, RING = 4 * STAGE <= 131072 ? 4 : 3;
@@ -509,6 +515,18 @@ __global__ void __launch_bounds__(256) pw_nbs_kernel(const PwsParams p) {
   f32x4_t cf[NS][4];                                             // {a, b, c0, -} of this lane's columns in the current sample
   int cur_n = -1;
 
+  // WG: this wave's K chunk and t chunks; accumulators [t chunk][dOut chunk]
+  constexpr int WCH = 3, WKC = SUBS == 4 ? 1 : 2;                 // t chunks per wave; waves per ... (SUBS == 4: every wave owns one K chunk and all three t chunks)
+  static_assert(!WG || (KC == 1 && SUBS == 4) || (KC == 2 && SUBS == 2), "weight-gradient split of the two instances");
+  const int w_kc = SUBS == 4 ? wave : (wave & 1), w_c0 = SUBS == 4 ? 0 : (wave >> 1) * WCH;
+  const int a_base = (g * 8 + (j >> 2)) * VB + (j & 3) * 8;       // lane (j, g): voxels 8g .. 8g + 7 of a K chunk through ds_read_b64_tr_b16
+  f32x4_t wacc[WG ? WCH : 1][WG ? KC : 1];
+#pragma unroll
+  for (int c = 0; c < (WG ? WCH : 1); ++c)
+#pragma unroll
+    for (int d = 0; d < (WG ? KC : 1); ++d) wacc[c][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  (void)WKC;
+
   const int nst = grp < nblocks ? (nblocks - grp + groups - 1) / groups : 0;
 #pragma unroll
   for (int s = 0; s < RING - 1; ++s)
@@ -538,6 +556,31 @@ __global__ void __launch_bounds__(256) pw_nbs_kernel(const PwsParams p) {
     __syncthreads();
     if (s + RING - 1 < nst) issue(grp + (s + RING - 1) * groups, (s + RING - 1) % RING);
     const unsigned char* st = smem + (s % RING) * STAGE;
+    if constexpr (WG) {
+      typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+      u32x4_t gfw[KC];
+#pragma unroll
+      for (int d = 0; d < KC; ++d) {
+        const unsigned char* q = st + d * TV * VB + a_base + w_kc * 32 * VB;
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+        const u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VB)));
+        gfw[d] = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+      }
+#pragma unroll
+      for (int c = 0; c < WCH; ++c) {
+        const unsigned char* q = st + (KC + NS + w_c0 + c) * TV * VB + a_base + w_kc * 32 * VB;
+        const u32x2_t l2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q)));
+        const u32x2_t h2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(q + 4 * VB)));
+        u32x4_t afw = u32x4_t{l2[0], l2[1], h2[0], h2[1]};
+        if constexpr (sizeof(TT) == 2 && !std::is_same<TT, uint16_t>::value) {   // fp16 activations: bf16 MFMA operands, as wgrad_k1_dma_kernel
+#pragma unroll
+          for (int e = 0; e < 4; ++e) afw[e] = cvt_pk_bf16(lo16<f16_t>(afw[e]), hi16<f16_t>(afw[e]));
+        }
+#pragma unroll
+        for (int d = 0; d < KC; ++d)
+          wacc[c][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afw), __builtin_bit_cast(bf16x8_t, gfw[d]), wacc[c][d], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int ms = 0; ms < MS; ++ms) {
       const int vl = (wave * MS + ms) * 16 + j;                   // voxel inside the block
@@ -565,6 +608,34 @@ __global__ void __launch_bounds__(256) pw_nbs_kernel(const PwsParams p) {
           *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pk16<uint16_t>(val[0], val[1]), pk16<uint16_t>(val[2], val[3])};
         }
       }
+    }
+  }
+  if constexpr (WG) {
+    // the waves' sums (fixed order) -> this workgroup's slab [3 K][K]: dWsc[ci][co], ci = t channel, co = dOut channel
+    __builtin_amdgcn_s_waitcnt(pws_vmcnt(0));                       // (no DMA of this wave is still writing LDS)
+    __syncthreads();
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);                // [wave][WCH][KC][64 lanes]
+    static_assert(4 * WCH * KC * 64 * 16 <= RING * STAGE, "reduction scratch");
+#pragma unroll
+    for (int c = 0; c < WCH; ++c)
+#pragma unroll
+      for (int d = 0; d < KC; ++d) red[((wave * WCH + c) * KC + d) * 64 + lane] = wacc[c][d];
+    __syncthreads();
+    constexpr int CIN = 48 * KC, COUT = 16 * KC;
+    float* pp = p.part + (size_t)grp * CIN * COUT;
+    for (int q = tid; q < 3 * KC * KC * 64; q += 256) {             // (t chunk tc, dOut chunk d, lane)
+      const int ln = q & 63, cn = q >> 6, tc = cn / KC, d = cn % KC;
+      f32x4_t a;
+      if (SUBS == 4) {                                              // four K chunks: waves 0 .. 3 hold (tc, d)
+        a = (red[((0 * WCH + tc) * KC + d) * 64 + ln] + red[((1 * WCH + tc) * KC + d) * 64 + ln]) +
+            (red[((2 * WCH + tc) * KC + d) * 64 + ln] + red[((3 * WCH + tc) * KC + d) * 64 + ln]);
+      } else {                                                      // two K chunks: waves 2 (tc / 3) and 2 (tc / 3) + 1 hold t chunk tc as their c = tc % 3
+        const int w0 = 2 * (tc / WCH), c = tc % WCH;
+        a = red[((w0 * WCH + c) * KC + d) * 64 + ln] + red[(((w0 + 1) * WCH + c) * KC + d) * 64 + ln];
+      }
+      const int gi = ln >> 4, ii = ln & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[(size_t)(tc * 16 + 4 * gi + r) * COUT + d * 16 + ii] = a[r];
     }
   }
 }
@@ -821,7 +892,8 @@ extern "C" int bpx_convT3d_stats_tiles(int D, int H, int W, int sz) { return con
 
 static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                         bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y, bpx_tensor y2,
-                        bpx_stream_t stream) {
+                        bpx_stream_t stream, float* wg_part = nullptr, int* wg_groups = nullptr) {
+  // wg_part (bpx_conv1x1_fwd_split_wgrad): the streaming kernel also forms the shortcut weight gradient's partial slabs there and reports how many
   BPX_CHECK(dtype == BPX_BF16 || dtype == BPX_F32 || dtype == BPX_MIX16 || dtype == BPX_F16,
             "%s: dtype must be BF16, F32, MIX16 (t fp16, everything else bf16) or F16 (plain forward GEMM, no IN-backward operands)", fn);
   const bool mix = dtype == BPX_MIX16 && coef_d != nullptr;
@@ -864,18 +936,48 @@ static int conv1x1_impl(const char* fn, int dtype, int N, int64_t vps, bpx_tenso
       q.wp = w_packed_d; q.coef = coef_d; q.y = y.ptr; q.y_ld = y.ld; q.y2 = y2.ptr; q.y2_ld = y2.ld; q.ysplit = y.C;
       q.vps = vps; q.N = N; q.bps = (int)(vps / TV); q.nblocks = (int)(vox / TV);
       q.groups = (int)std::min<int64_t>(256, q.nblocks);        // one persistent workgroup per CU (the ring holds ~115 KB)
+      q.part = wg_part;
       hipStream_t s = (hipStream_t)stream;
-      if (KC == 1) { if (mix) pw_nbs_kernel<1, 128, f16_t><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<1, 128, uint16_t><<<q.groups, 256, 0, s>>>(q); }
+      if (wg_part != nullptr) {
+        if (KC == 1) { if (mix) pw_nbs_kernel<1, 128, f16_t, true><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<1, 128, uint16_t, true><<<q.groups, 256, 0, s>>>(q); }
+        else { if (mix) pw_nbs_kernel<2, 64, f16_t, true><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<2, 64, uint16_t, true><<<q.groups, 256, 0, s>>>(q); }
+        *wg_groups = q.groups;
+      } else if (KC == 1) { if (mix) pw_nbs_kernel<1, 128, f16_t><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<1, 128, uint16_t><<<q.groups, 256, 0, s>>>(q); }
       else { if (mix) pw_nbs_kernel<2, 64, f16_t><<<q.groups, 256, 0, s>>>(q); else pw_nbs_kernel<2, 64, uint16_t><<<q.groups, 256, 0, s>>>(q); }
       BPX_LAUNCH_CHECK(fn);
       return 0;
     }
   }
+  BPX_CHECK(wg_part == nullptr, "%s: these operands do not take the streaming kernel (bpx_conv1x1_fwd_split_wgrad_workspace answers 0 for the shape classes it "
+            "refuses; alignment, pitches and 32-bit spans must hold too): use bpx_conv1x1_fwd_split and bpx_conv3d_wgrad", fn);
   if ((mix ? launch_pw<uint16_t, PW_CONV1, f16_t>(p, ns, (hipStream_t)stream)
        : f16 ? launch_pw<f16_t, PW_CONV1>(p, ns, (hipStream_t)stream)
        : dtype == BPX_BF16 ? launch_pw<uint16_t, PW_CONV1>(p, ns, (hipStream_t)stream) : launch_pw<float, PW_CONV1>(p, ns, (hipStream_t)stream)) != 0) return 1;
   BPX_LAUNCH_CHECK(fn);
   return 0;
+}
+
+// bpx_conv1x1_fwd_split with the block's shortcut weight gradient riding along (pw_nbs_kernel<.., WG = true>)
+extern "C" int64_t bpx_conv1x1_fwd_split_wgrad_workspace(int dtype, int N, int64_t vps, int K) {
+  static const bool on = getenv("BPX_PWS_WG") == nullptr || atoi(getenv("BPX_PWS_WG")) != 0;   // A/B: BPX_PWS_WG=0 = the two separate kernels
+  if (!on || !g_pw_stream || (dtype != BPX_BF16 && dtype != BPX_MIX16) || (K != 16 && K != 32)) return 0;
+  const int TV = K == 16 ? 128 : 64;
+  if (vps % TV != 0 || (int64_t)N * vps < 262144) return 0;
+  return (int64_t)256 * (3 * K) * K * 4;
+}
+extern "C" int bpx_conv1x1_fwd_split_wgrad(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, bpx_tensor g, bpx_tensor t,
+                                           const bpx_nbwd_coef* coef_d, bpx_tensor y_lo, bpx_tensor y_hi, float* dw_d, void* ws_d, int64_t ws_bytes,
+                                           bpx_stream_t stream) {
+  const char* fn = "bpx_conv1x1_fwd_split_wgrad";
+  BPX_CHECK(x.cs == 0 && g.cs == 0 && y_lo.cs == 0 && y_hi.cs == 0, "%s: only t may be chunk-planar", fn);
+  BPX_CHECK(y_hi.ptr != nullptr && dw_d != nullptr && ws_d != nullptr && coef_d != nullptr, "%s: null pointer", fn);
+  const int64_t need = bpx_conv1x1_fwd_split_wgrad_workspace(dtype, N, vps, x.C);
+  BPX_CHECK(need > 0, "%s: unsupported here (dtype %d, %d channels, %lld voxels per sample): use bpx_conv1x1_fwd_split and bpx_conv3d_wgrad", fn, dtype, x.C, (long long)vps);
+  BPX_CHECK(ws_bytes >= need && (((uintptr_t)ws_d) & 15) == 0, "%s: workspace too small or misaligned (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
+  int groups = 0;
+  if (conv1x1_impl(fn, dtype, N, vps, x, w_packed_d, nullptr, g, t, coef_d, bpx_tensor{nullptr, 0, 0}, y_lo, y_hi, stream, reinterpret_cast<float*>(ws_d), &groups) != 0) return 1;
+  // dWsc (Cout = x.C, Cin = t.C, 1, 1, 1): index co * Cin + ci; slabs [groups][Cin][Cout]
+  return bpxred::reduce_partials(fn, reinterpret_cast<const float*>(ws_d), dw_d, groups, 1, t.C, x.C, 1, t.C, 1, nullptr, nullptr, 0, true, (hipStream_t)stream);
 }
 
 extern "C" int bpx_conv1x1_fwd(int dtype, int N, int64_t vps, bpx_tensor x, const void* w_packed_d, const float* bias_d,

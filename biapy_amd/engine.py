@@ -787,11 +787,17 @@ class ResUNetEngine:
             self._wgrad(B, blk.S, L.tview(blk.a), None, 0, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
         elif not fused2:
             self._wgrad(B, blk.S, L.tview(blk.h), blk.rec_h, self.act, dOut, 3, G[k["w2"]], G[k["b2"]], st, dev, db2=G[k["bsc"]])
+        # decoder blocks at the large levels (round 6): the shortcut's weight gradient rides along in the pass that forms the block's input gradient
+        # (bpx_conv1x1_fwd_split_wgrad below streams both of its operands anyway); everywhere else it is a launch of its own
+        sc_ws = 0
+        if (isinstance(dx_out, tuple) and blk.rec_x is not None and self._deferred and not self.use_side_stream and self.cfg.gn_groups == 0
+                and dOut.C * 3 == blk.cin and self.dtype != torch.float32):
+            sc_ws = int(lib.bpx_conv1x1_fwd_split_wgrad_workspace(self.bdt, B, vox, dOut.C))
         if blk.first and self.cfg.in_ch == 1:
             ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
             self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.gdt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
                                                                             ws1.data_ptr(), ws1.numel(), s_)))
-        else:
+        elif not sc_ws:
             self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
         g1 = torch.empty((B, D, H, W, C1), dtype=T, device=dev)
@@ -868,8 +874,13 @@ class ResUNetEngine:
                                                            G[k["g0"]].data_ptr(), G[k["be0"]].data_ptr(), gng or Cx, coef0.data_ptr(), st))
             if isinstance(dx_out, tuple):   # decoder block: the gradient of the concatenated input leaves as its (up, skip) parts
                 assert dx_extra is None
-                L.check(lib.bpx_conv1x1_fwd_split(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
-                                                  L.NULL_T, dx_out[0], dx_out[1], st))
+                if sc_ws:
+                    wsw = self._workspace(sc_ws, dev)
+                    L.check(lib.bpx_conv1x1_fwd_split_wgrad(self.bdt, B, vox, dOut, wsct.data_ptr(), L.tview(g0), xv, coef0.data_ptr(), dx_out[0], dx_out[1],
+                                                            G[k["wsc"]].data_ptr(), wsw.data_ptr(), wsw.numel(), st))
+                else:
+                    L.check(lib.bpx_conv1x1_fwd_split(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
+                                                      L.NULL_T, dx_out[0], dx_out[1], st))
             else:
                 L.check(lib.bpx_conv1x1_fwd(self.bdt, B, vox, dOut, wsct.data_ptr(), None, L.tview(g0), xv, coef0.data_ptr(),
                                             dx_extra if dx_extra is not None else L.NULL_T, dx_out, st))

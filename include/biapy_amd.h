@@ -267,6 +267,14 @@ int bpx_conv1x1_fwd(int dtype, int N, int64_t voxels, bpx_tensor x, const void* 
 int bpx_conv1x1_fwd_split(int dtype, int N, int64_t voxels, bpx_tensor x, const void* w_packed_d, const float* bias_d,
                           bpx_tensor g, bpx_tensor t, const bpx_nbwd_coef* coef_d, bpx_tensor addend, bpx_tensor y_lo,
                           bpx_tensor y_hi, bpx_stream_t stream);
+/* The same with the residual block's SHORTCUT WEIGHT GRADIENT riding along (round 6): dw_d[co][ci] (Cout = x.C, Cin = t.C, 1, 1, 1) = sum_v t[v][ci] * x[v][co]
+ * - the k = 1 bpx_conv3d_wgrad of the raw block input t against dOut = x (biapy/models/blocks.py ResConvBlock `shortcut(x)`), whose two operands this
+ * kernel streams anyway.  Only where the streaming kernel applies: _workspace answers the bytes of ws_d, or 0 = call bpx_conv1x1_fwd_split and
+ * bpx_conv3d_wgrad instead (BPX_PWS_WG=0 forces that).  Between bpx_wgrad_defer_begin and _flush dw_d is complete at the flush and ws_d must stay untouched until then. */
+int64_t bpx_conv1x1_fwd_split_wgrad_workspace(int dtype, int N, int64_t voxels, int K);
+int bpx_conv1x1_fwd_split_wgrad(int dtype, int N, int64_t voxels, bpx_tensor x, const void* w_packed_d, bpx_tensor g, bpx_tensor t,
+                                const bpx_nbwd_coef* coef_d, bpx_tensor y_lo, bpx_tensor y_hi, float* dw_d, void* ws_d, int64_t ws_bytes,
+                                bpx_stream_t stream);
 
 /* ConvTranspose3d k = s = (sz,2,2), sz = z_down of the level = 1 or 2 (blocks.py:1607):
  * y[n,sz*z+a,2y+b,2x+c,:] = x[n,z,y,x,:]*W[:,:,a,b,c] + b.

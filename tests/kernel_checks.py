@@ -2453,7 +2453,32 @@ def check_pw_stream(mix=True, B=2, vps=131072, K=16, planar=True, seed=0):
         c = run()
     finally:
         lib.bpx_debug_set_pw_stream(1)
-    return [_res(tag + ".vs_fp32", relerr(a, y_ref), 1.5e-2), _res(tag + ".same_bits_as_tile_kernel", 0 if torch.equal(a.view(torch.int16), c.view(torch.int16)) else 1, 0,
+    extra = []
+    need = int(lib.bpx_conv1x1_fwd_split_wgrad_workspace(dt, B, vps, K))
+    if need > 0:
+        # round 6: the same pass with the block's shortcut weight gradient riding along: the outputs keep their bits, dWsc[co][ci] = sum_v t[v][ci] dOut[v][co]
+        # against the fp64 sum, against the k = 1 weight-gradient kernel it replaces, and run to run
+        def run_wg():
+            y_lo = torch.full((B, vps, lo), 7.0, dtype=torch.bfloat16, device=DEV)
+            y_hi = torch.full((B, vps, C3 - lo), 7.0, dtype=torch.bfloat16, device=DEV)
+            dw = torch.full((K, C3), 7.0, dtype=torch.float32, device=DEV)
+            wsw = torch.empty(need, dtype=torch.uint8, device=DEV)
+            L.check(lib.bpx_conv1x1_fwd_split_wgrad(dt, B, vps, L.tview(xd), wp.data_ptr(), L.tview(gd), tv, cd.data_ptr(), L.tview(y_lo), L.tview(y_hi), dw.data_ptr(),
+                                                    wsw.data_ptr(), wsw.numel(), L.stream_ptr()))
+            torch.cuda.synchronize()
+            return torch.cat([y_lo, y_hi], -1), dw
+
+        (ya, dwa), (_, dwb) = run_wg(), run_wg()
+        dw_ref = torch.einsum("bvk,bvc->kc", x.double(), tt.double())
+        dwk = torch.full((K, C3), 7.0, dtype=torch.float32, device=DEV)
+        wsk = torch.empty(lib.bpx_conv3d_wgrad_workspace(B, S[0], S[1], S[2], C3, K, 1), dtype=torch.uint8, device=DEV)
+        L.check(lib.bpx_conv3d_wgrad(dt, B, S[0], S[1], S[2], tv, None, 0, L.tview(xd), 1, dwk.data_ptr(), None, wsk.data_ptr(), wsk.numel(), L.stream_ptr()))
+        torch.cuda.synchronize()
+        extra = [_res(tag + ".with_wgrad.same_output_bits", 0 if torch.equal(ya.view(torch.int16), a.view(torch.int16)) else 1, 0),
+                 _res(tag + ".with_wgrad.dw_vs_fp64", relerr(dwa, dw_ref), 4e-3 if mix else 1e-4),
+                 _res(tag + ".with_wgrad.dw_vs_k1_kernel", relerr(dwa, dwk), 1e-4),
+                 _res(tag + ".with_wgrad.run_to_run_bits", 0 if torch.equal(dwa, dwb) else 1, 0)]
+    return extra + [_res(tag + ".vs_fp32", relerr(a, y_ref), 1.5e-2), _res(tag + ".same_bits_as_tile_kernel", 0 if torch.equal(a.view(torch.int16), c.view(torch.int16)) else 1, 0,
                                                                    extra=f"max diff {(a.float() - c.float()).abs().max().item():.2e}"),
             _res(tag + ".run_to_run_bits", 0 if torch.equal(a.view(torch.int16), b.view(torch.int16)) else 1, 0)]
 
