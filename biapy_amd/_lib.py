@@ -138,6 +138,8 @@ _SIGS = {
     "bpx_norm_act_bwd": ([_i, _i, _i64, Tensor, Tensor, _vp, _i, Tensor, Tensor, _vp, _vp], _i),
     "bpx_maxpool3d_fwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, _vp, _vp], _i),
     "bpx_maxpool3d_stats_tiles": ([_i, _i, _i, _i, _i, _i], _i),
+    "bpx_maxpool3d_bwd_r1_workspace": ([_i, _i, _i, _i, _i, _i, _i], _i64),
+    "bpx_maxpool3d_bwd_r1": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp, _vp, _vp, _i64, _vp], _i),
     "bpx_maxpool3d_bwd": ([_i, _i, _i, _i, _i, _i, Tensor, Tensor, Tensor, Tensor, _vp], _i),
     "bpx_head_fwd": ([_i, _i64, _i, Tensor, _vp, _vp, _i, _i, _vp, _i64, _i64, _vp], _i),
     "bpx_head_bwd": ([_i, _i64, _i, Tensor, _vp, _i, _vp, _i64, _i64, Tensor, _vp, _vp, _vp, _i64, _vp], _i),

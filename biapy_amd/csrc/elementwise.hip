@@ -827,11 +827,17 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, int x_ld, int x_cs, 
 // addend are template constants (round 6): with the run-time `if (k >= 4 sz) break` inside the unrolled window loops every load sat in its own basic
 // block behind an `s_waitcnt vmcnt(0)` (12 such sites) - a wait for all stores issued so far (level 0: 3.8 TB/s).  Now a window's 4 SZ x loads, its dy
 // load and its 4 SZ addend loads are requested together, then the arg-max, then the 4 SZ stores.
-template <typename T, typename TX, int SZ, bool ADD>
+// R1 (round 6, level 0 of a one-channel-image network): the first block's rank-1 shortcut weight gradient dWsc[co] = sum_v img[v] * dx[v][co] rides along - dx
+// is that block's output gradient and this kernel is what writes it; as a kernel of its own (rank1_wgrad_kernel) it read the 268 MB back (60 us).  C = 16:
+// a thread keeps the 8 channels of its channel group (its parity) over its whole grid-stride walk; one row of 16 partial sums per workgroup.
+template <typename T, typename TX, int SZ, bool ADD, bool R1 = false>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const TX* __restrict__ x, int x_ld, int x_cs, const T* __restrict__ dy, int dy_ld,
                                                           const T* __restrict__ addend, int a_ld, T* __restrict__ dx, int dx_ld, int C,
-                                                          int D, int H, int W, int N) {
+                                                          int D, int H, int W, int N, const float* __restrict__ img = nullptr, float* __restrict__ r1part = nullptr) {
   constexpr int KPL = ElemTraits<T>::KPL, NW = 4 * SZ;
+  float r1acc[R1 ? KPL : 1];
+#pragma unroll
+  for (int e = 0; e < (R1 ? KPL : 1); ++e) r1acc[e] = 0.f;
   const int G = C / KPL;
   const int Do = D / SZ, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
@@ -880,7 +886,31 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const TX* __restrict__
       }
 #pragma unroll
       for (int e = 0; e < KPL; ++e) o[e] += (am[e] == k) ? d[e] : 0.f;
-      *reinterpret_cast<u32x4_t*>(dx + vox * dx_ld + cg * KPL) = pack16<T>(o);
+      const u32x4_t po = pack16<T>(o);
+      *reinterpret_cast<u32x4_t*>(dx + vox * dx_ld + cg * KPL) = po;
+      if constexpr (R1) {                                       // the STORED (rounded) values, as the separate kernel read them
+        const float iv = img[vox];
+        float orr[KPL];
+        unpack16<T>(po, orr);
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) r1acc[e] = fmaf(iv, orr[e], r1acc[e]);
+      }
+    }
+  }
+  if constexpr (R1) {
+    // C = 16 = two channel groups: thread parity = channel group (the grid stride is even).  Lanes of one parity, then the four waves, in a fixed order.
+    __shared__ float r1red[4][2][KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      float a = r1acc[e];
+#pragma unroll
+      for (int m = 2; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+      if ((threadIdx.x & 63) < 2) r1red[threadIdx.x >> 6][threadIdx.x & 1][e] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const int par = threadIdx.x >> 3, e = threadIdx.x & 7;
+      r1part[(size_t)blockIdx.x * 16 + threadIdx.x] = (r1red[0][par][e] + r1red[1][par][e]) + (r1red[2][par][e] + r1red[3][par][e]);
     }
   }
 }
@@ -2778,6 +2808,41 @@ extern "C" int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, 
 #undef MPB
   BPX_LAUNCH_CHECK(fn);
   return 0;
+}
+
+// bpx_maxpool3d_bwd (with addend) + the rank-1 shortcut weight gradient of the block whose output gradient it writes (maxpool_bwd_kernel<.., R1 = true>)
+extern "C" int64_t bpx_maxpool3d_bwd_r1_workspace(int dtype, int N, int D, int H, int W, int sz, int C) {
+  static const bool on = getenv("BPX_POOL_R1") == nullptr || atoi(getenv("BPX_POOL_R1")) != 0;   // A/B: BPX_POOL_R1=0 = the two separate kernels
+  if (!on || (dtype != BPX_BF16 && dtype != BPX_MIX16) || C != 16 || (sz != 1 && sz != 2) || D % sz || H % 2 || W % 2) return 0;
+  const int64_t total = (int64_t)N * (D / sz) * (H / 2) * (W / 2) * 2;
+  if (total < 65536) return 0;
+  return (int64_t)grid_for(total) * 16 * 4;
+}
+extern "C" int bpx_maxpool3d_bwd_r1(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, bpx_tensor addend, bpx_tensor dx,
+                                    const float* img_d, float* dw_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream) {
+  const char* fn = "bpx_maxpool3d_bwd_r1";
+  BPX_CHECK(dy.cs == 0 && addend.cs == 0 && dx.cs == 0, "%s: only x may be chunk-planar", fn);
+  BPX_CHECK(x.cs == 0 || (x.cs % 8 == 0 && x.cs >= ((int64_t)N * D * H * W - 1) * x.ld + 16), "%s: x has chunk stride %lld", fn, (long long)x.cs);
+  const int xcs = x.cs ? (int)x.cs : 16;
+  BPX_CHECK(x.ptr && dy.ptr && dx.ptr && addend.ptr && img_d && dw_d && ws_d, "%s: null pointer", fn);
+  BPX_CHECK(x.C == dy.C && x.C == dx.C && x.C == addend.C, "%s: channel mismatch", fn);
+  const int64_t need = bpx_maxpool3d_bwd_r1_workspace(dtype, N, D, H, W, sz, x.C);
+  BPX_CHECK(need > 0, "%s: unsupported here (16 channels, 16-bit storage): use bpx_maxpool3d_bwd and bpx_conv1x1_c1_wgrad", fn);
+  BPX_CHECK(ws_bytes >= need, "%s: workspace too small (%lld < %lld bytes)", fn, (long long)ws_bytes, (long long)need);
+  const int64_t total = (int64_t)N * (D / sz) * (H / 2) * (W / 2) * 2;
+  const int blocks = grid_for(total);
+  hipStream_t s = (hipStream_t)stream;
+  float* pw = reinterpret_cast<float*>(ws_d);
+  const uint16_t* dyp = (const uint16_t*)dy.ptr; const uint16_t* ap = (const uint16_t*)addend.ptr; uint16_t* dxp = (uint16_t*)dx.ptr;
+#define MPR(TX_)                                                                                                                                                          \
+  do {                                                                                                                                                                    \
+    if (sz == 2) maxpool_bwd_kernel<uint16_t, TX_, 2, true, true><<<blocks, 256, 0, s>>>((const TX_*)x.ptr, x.ld, xcs, dyp, dy.ld, ap, addend.ld, dxp, dx.ld, x.C, D, H, W, N, img_d, pw); \
+    else maxpool_bwd_kernel<uint16_t, TX_, 1, true, true><<<blocks, 256, 0, s>>>((const TX_*)x.ptr, x.ld, xcs, dyp, dy.ld, ap, addend.ld, dxp, dx.ld, x.C, D, H, W, N, img_d, pw);         \
+  } while (0)
+  if (dtype == BPX_MIX16) MPR(f16_t); else MPR(uint16_t);
+#undef MPR
+  BPX_LAUNCH_CHECK(fn);
+  return bpxred::reduce_partials(fn, pw, dw_d, blocks, 1, 1, 16, 0, 1, 0, nullptr, nullptr, 0, true, s);
 }
 
 extern "C" int bpx_head_fwd(int dtype, int64_t vps, int N, bpx_tensor x, const float* w_d, const float* b_d, int Cout, int head_act,

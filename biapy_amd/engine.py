@@ -794,9 +794,12 @@ class ResUNetEngine:
                 and dOut.C * 3 == blk.cin and self.dtype != torch.float32):
             sc_ws = int(lib.bpx_conv1x1_fwd_split_wgrad_workspace(self.bdt, B, vox, dOut.C))
         if blk.first and self.cfg.in_ch == 1:
-            ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
-            self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.gdt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
-                                                                            ws1.data_ptr(), ws1.numel(), s_)))
+            if getattr(self, "_r1_done", False):       # formed by bpx_maxpool3d_bwd_r1, the pass that wrote dOut (see _backward)
+                self._r1_done = False
+            else:
+                ws1 = self._workspace(lib.bpx_conv1x1_c1_wgrad_workspace(C1), dev)
+                self._run_side(dev, lambda s_: L.check(lib.bpx_conv1x1_c1_wgrad(self.gdt, B * vox, img.data_ptr(), dOut, G[k["wsc"]].data_ptr(),
+                                                                                ws1.data_ptr(), ws1.numel(), s_)))
         elif not sc_ws:
             self._wgrad(B, blk.S, L.tview(blk.x, blk.x_c0, blk.cin), None, 0, dOut, 1, G[k["wsc"]], None, st, dev)
         # conv2 dgrad fused with ELU' and the InstanceNorm reductions
@@ -1023,7 +1026,17 @@ class ResUNetEngine:
             Cup = fm[i + 1]
             # dOut_i = dSkip + unpool(dP); written in place over dSkip
             skipv = L.tview(dskip[i])
-            L.check(lib.bpx_maxpool3d_bwd(self.bdt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
+            r1_ws = 0
+            if i == 0 and cfg.in_ch == 1 and self._deferred and not self.use_side_stream and self.dtype != torch.float32:
+                # level 0 of a one-channel-image network (round 6): the first block's rank-1 shortcut weight gradient is a sum over the tensor this pass writes
+                r1_ws = int(lib.bpx_maxpool3d_bwd_r1_workspace(self.bdt, B, D, H, W, cfg.z_down[i], fm[i]))
+            if r1_ws:
+                wsr = self._workspace(r1_ws, dev)
+                L.check(lib.bpx_maxpool3d_bwd_r1(self.bdt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, img.data_ptr(),
+                                                 G[blocks[0].keys["wsc"]].data_ptr(), wsr.data_ptr(), wsr.numel(), st))
+                self._r1_done = True
+            else:
+                L.check(lib.bpx_maxpool3d_bwd(self.bdt, B, D, H, W, cfg.z_down[i], L.tview(cat[i], Cup, fm[i]), L.tview(dP), skipv, skipv, st))
             if i == 0 and getattr(self, "_on_last_block", None) is not None:
                 if self._deferred:      # the reductions queued so far write their gradients now; the last block's are queued afresh
                     L.check(lib.bpx_wgrad_defer_flush(L.stream_ptr()))

@@ -391,6 +391,13 @@ int bpx_maxpool3d_stats_tiles(int dtype, int D, int H, int W, int sz, int C);
 /* dx = addend + scatter(dy to the first maximal element of each window) */
 int bpx_maxpool3d_bwd(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, bpx_tensor addend,
                       bpx_tensor dx, bpx_stream_t stream);
+/* The same (addend required) with the rank-1 shortcut weight gradient of the first residual block riding along (round 6): dw_d[co] (16, 1, 1, 1, 1) =
+ * sum_v img_d[v] * dx[v][co] over the values this call STORES - what bpx_conv1x1_c1_wgrad computes from dx afterwards (blocks.py ResConvBlock `shortcut(x)`
+ * on a one-channel image).  16 channels, 16-bit storage; _workspace answers the bytes of ws_d or 0 = call the two entry points (BPX_POOL_R1=0 forces that).
+ * Between bpx_wgrad_defer_begin and _flush dw_d is complete at the flush and ws_d must stay untouched until then. */
+int64_t bpx_maxpool3d_bwd_r1_workspace(int dtype, int N, int D, int H, int W, int sz, int C);
+int bpx_maxpool3d_bwd_r1(int dtype, int N, int D, int H, int W, int sz, bpx_tensor x, bpx_tensor dy, bpx_tensor addend, bpx_tensor dx,
+                         const float* img_d, float* dw_d, void* ws_d, int64_t ws_bytes, bpx_stream_t stream);
 
 /* Output head: Conv3d k=1 to `Cout` (<= 4) fp32 channels (resunet.py:346-348) with the head
  * activation (base_workflow.py:1403-1457) fused: head_act holds one 4-bit code per output channel (channel 0 in the low

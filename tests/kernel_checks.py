@@ -922,6 +922,32 @@ def check_mix16_kernels(S=(8, 16, 32), B=2, Cin=32, Cout=16, seed=0):
         L.check(lib.bpx_maxpool3d_bwd(L.MIX16, B, D, H, W, sz, L.tview(td), L.tview(dypd), L.tview(addd), L.tview(dx), st))
         torch.cuda.synchronize()
         res.append(_res(tag + f".maxpool_bwd[sz{sz}]", relerr(dx, rnd(ndhwc(xr.grad) + add, G_)), 1e-6))
+        need = int(lib.bpx_maxpool3d_bwd_r1_workspace(L.MIX16, B, D, H, W, sz, Cin))
+        if need > 0:
+            # round 6: the same pass with the rank-1 shortcut weight gradient riding along: dx keeps its bits; dWsc[co] = sum_v img[v] dx[v][co] over the STORED
+            # values against the fp64 sum, against the kernel it replaces (bpx_conv1x1_c1_wgrad on dx), and run to run
+            img = torch.randn(B, D, H, W, generator=g)
+            imgd = img.to(DEV)
+
+            def run_r1():
+                dx2 = torch.empty(B, D, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+                dw = torch.full((Cin,), 7.0, dtype=torch.float32, device=DEV)
+                wsr = torch.empty(need, dtype=torch.uint8, device=DEV)
+                L.check(lib.bpx_maxpool3d_bwd_r1(L.MIX16, B, D, H, W, sz, L.tview(td), L.tview(dypd), L.tview(addd), L.tview(dx2), imgd.data_ptr(), dw.data_ptr(),
+                                                 wsr.data_ptr(), wsr.numel(), st))
+                torch.cuda.synchronize()
+                return dx2, dw
+
+            (dx2, dwa), (_, dwb) = run_r1(), run_r1()
+            dwk = torch.full((Cin,), 7.0, dtype=torch.float32, device=DEV)
+            wsk = torch.empty(lib.bpx_conv1x1_c1_wgrad_workspace(Cin), dtype=torch.uint8, device=DEV)
+            L.check(lib.bpx_conv1x1_c1_wgrad(L.BF16, B * D * H * W, imgd.data_ptr(), L.tview(dx), dwk.data_ptr(), wsk.data_ptr(), wsk.numel(), st))
+            torch.cuda.synchronize()
+            ref = torch.einsum("bdhw,bdhwc->c", img.double(), dx.float().cpu().double())
+            res.append(_res(tag + f".maxpool_bwd_r1[sz{sz}].same_dx_bits", 0 if torch.equal(dx2.view(torch.int16), dx.view(torch.int16)) else 1, 0))
+            res.append(_res(tag + f".maxpool_bwd_r1[sz{sz}].dw_vs_fp64", relerr(dwa, ref), 1e-4))
+            res.append(_res(tag + f".maxpool_bwd_r1[sz{sz}].dw_vs_rank1_kernel", relerr(dwa, dwk), 1e-4))
+            res.append(_res(tag + f".maxpool_bwd_r1[sz{sz}].run_to_run_bits", 0 if torch.equal(dwa, dwb) else 1, 0))
     # ---- transposed-conv wgrad: x fp16 (raw), dy bf16 ---------------------------------------------------------------------------
     for sz in (2, 1):
         wt = torch.zeros(Cin, Cin, sz, 2, 2, requires_grad=True)
